@@ -1,0 +1,223 @@
+/*
+ * libtbx_hip.so — C ABI of the MI355X-native hot path of TrafficBots V1.5 (HPTR / KNARPE transformer +
+ * closed-loop rollout). gfx950 only. Plain pointers and sizes, no torch types.
+ *
+ * Contract:
+ *   - every pointer is a DEVICE pointer to a caller-owned, contiguous buffer unless marked "host";
+ *   - nothing is allocated or retained, no global state, no host<->device synchronisation: every entry point only
+ *     enqueues kernels on `stream` (a hipStream_t passed as void*), so a whole simulation step is hipGraph-capturable;
+ *   - return value: 0 (TBX_OK) or a negative tbx error code; never throws, never exits.
+ *
+ * The reference (zhejz/TrafficBotsV1.5) has no native layer: each entry point replaces a chain of aten ops of the
+ * Python reference, cited per function as `file:line` relative to the reference's src/.
+ */
+#ifndef TBX_HIP_H
+#define TBX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBX_ABI_VERSION 1
+
+enum {
+  TBX_OK = 0,
+  TBX_ERR_ARG = -1,          /* null pointer / non-positive size */
+  TBX_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels are built for */
+  TBX_ERR_ALIGN = -3,        /* pointer / leading dimension alignment */
+  TBX_ERR_LAUNCH = -4        /* hipGetLastError() != hipSuccess after the launch */
+};
+
+int tbx_version(void);
+const char* tbx_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K1+K2+K4: relative pose, K-nearest selection, pose embedding.
+ * Replaces utils/rpe.py:8-37 (get_rel_pose), utils/rpe.py:61-90 (get_tgt_knn_idx: topk(largest=False) + mask +
+ * gather) and utils/pose_emb.py:50-55 + utils/positional_emb.py:25,40-41,53 (PoseEmb pe_xy_yaw on the gathered
+ * relative poses), as called from agent_encoder.py:321-387, traffic_light.py:118-152, map_encoder.py:82-97.
+ *
+ *   src_pose [n_batch, n_src, 3] (x,y,yaw)   src_invalid [n_batch, n_src] u8
+ *   tgt_pose [n_batch/tgt_batch_div, n_tgt, 3], tgt_invalid likewise (rollouts of one scene may share targets)
+ *   idx      [n_batch, n_src, k] i32   k smallest distances (set semantics, order unspecified; ties -> lower index)
+ *   invalid  [n_batch, n_src, k] u8    tgt_invalid[idx] | dist > dist_limit   (+inf distances are always invalid)
+ *   rel_pose [n_batch, n_src, k, 3]    optional (may be NULL): rotated offset and un-wrapped yaw difference
+ *   emb      [n_batch, n_src, k, pe_dim] optional (may be NULL): [cos(x f) sin(x f) cos(y f) sin(y f) cos(k yaw) sin(k yaw)]
+ *   freqs_xy [pe_dim/4], freqs_yaw [pe_dim/2]: the reference's repeat-interleaved `freqs` buffers.
+ * Limits: 0 < k < n_tgt, k <= 64, n_tgt <= 2048, pe_dim in {64, 128}.
+ */
+int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, const float* tgt_pose, const uint8_t* tgt_invalid,
+                  int n_batch, int n_src, int n_tgt, int tgt_batch_div, int k, float dist_limit, int32_t* idx,
+                  uint8_t* invalid, float* rel_pose, float* emb, const float* freqs_xy, const float* freqs_yaw,
+                  int pe_dim, void* stream);
+
+/* Pose embedding of explicit (x,y,yaw) triples (utils/pose_emb.py:50-55); out[i, col_off : col_off+pe_dim]. */
+int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim, float* out,
+                   int ld_out, int col_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K6: fused KNARPE attention (gather + relative-pose bias + ragged masked softmax + weighted sum).
+ * Replaces modules/attention_rpe.py:137-190 (rpe branch, apply_q_rpe = False) in the exact factorised form
+ *   score[h,t] = q_h . k_h[idx_t] + qt_h . e_t + qb_h          (qt_h = W_rpe_k,h^T q_h ; qb_h = q_h . b_rpe_k,h)
+ *   out       = [ sum_t a[h,t] v_h[idx_t]  |  sum_t a[h,t] e_t  (one 128-vector per head) ]
+ * with K/V projected BEFORE the gather (per-token tables), mask -> -inf, rows without any valid target un-masked and
+ * flagged in `row_no_valid` (the caller zeroes their out-projection, attention_rpe.py:112-118,188-190), softmax of
+ * score / sqrt(d_head). d_model = 128, n_head = 4, d_rpe = 128.
+ *
+ *   qbuf [n_batch*n_src, ldq]: q at q_off (128), qt at qt_off (4*128); rpe_k_bias [128] = linear_rpe.bias[0:128]
+ *   (qb_h is formed in-kernel from q and rpe_k_bias)
+ *   seg[i]: kv [n_batch/batch_div, n_tgt, ld_kv] with K at k_off and V at v_off; idx / invalid / emb [n_batch, n_src, k(,128)]
+ *   out  [n_batch*n_src, ldo >= 640]; row_no_valid [n_batch*n_src] u8
+ * Limits: 1 <= n_seg <= 2, sum of k <= 128, 16-byte aligned rows.
+ */
+typedef struct tbx_attn_seg {
+  const float* kv;
+  const int32_t* idx;
+  const uint8_t* invalid;
+  const float* emb;
+  int32_t ld_kv, k_off, v_off, n_tgt, batch_div, k;
+} tbx_attn_seg_t;
+
+int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                        int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo,
+                        uint8_t* row_no_valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
+ * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per
+ * row + one 260-float auxiliary buffer) and the weights streamed once from L2/HBM into exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32). Replaces the F.linear / layer_norm / relu / masked_fill / amax / cat chains of
+ * modules/mlp.py:69-72, modules/input_encoder.py:51-59, modules/polyline_encoder.py:49-61 + utils/pooling.py:18-19,38,
+ * modules/transformer_rpe.py:207-245 (LN, projections, out-proj + residual, FFN, row masking),
+ * modules/add_navi_latent.py:43-65, modules/action_head.py:74-100, traffic_light.py:279-286, navigation.py:65-79.
+ *
+ * Row addressing: flat (group_rows == 0): tile t owns global rows [t*tile_rows, (t+1)*tile_rows);
+ * grouped (group_rows = W > 0): tile t owns the W rows of group t (polyline / track), padded to tile_rows.
+ */
+enum {
+  TBX_OP_LOAD = 1,      /* dst[:, dst_col:+n] (=|+=) p0[row_of(g) * ld + c]; cols [n, k) zero-filled (k = padded width) */
+  TBX_OP_LINEAR = 2,    /* dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b); W=p0 [n,k] ld (or [k,n] if TBX_F_WT), b=p1 */
+  TBX_OP_LAYERNORM = 3, /* dst[:, dst_col:+n] = LN(src[:, src_col:+n]) * p0 + p1, eps = f0 */
+  TBX_OP_ADD = 4,       /* dst[:, dst_col:+n] += src[:, src_col:+n] */
+  TBX_OP_COPY = 5,      /* dst[:, dst_col:+n]  = src[:, src_col:+n] */
+  TBX_OP_ROWMASK = 6,   /* rows with p0[row_of(g)] != 0 (and padding rows): dst[:, dst_col:+n] = f0 */
+  TBX_OP_GROUPMAX = 7,  /* dst[r, dst_col + c] = max_r' src[r', src_col + c]  (all rows of the tile) */
+  TBX_OP_POOLMAX = 8,   /* p0[group * ld + dst_col + c] = max over un-masked rows (mask p1) of src[:, src_col + c]; none -> 0 */
+  TBX_OP_STORE = 9,     /* p0[g * ld + dst_col + c] = src[:, src_col + c] for valid rows */
+  TBX_OP_CLAMP = 10     /* dst[:, dst_col:+n] = clamp(dst, f0, f1) */
+};
+enum { TBX_ACT_NONE = 0, TBX_ACT_RELU = 1 };
+enum {
+  TBX_F_ACCUM = 1,    /* LOAD / LINEAR: accumulate into dst */
+  TBX_F_WT = 2,       /* LINEAR: weight stored [k, n] (x @ W instead of x @ W^T) */
+  TBX_F_ROW_DIV = 4,  /* row_of(g) = g / div   (per-group / per-agent broadcast) */
+  TBX_F_ROW_MOD = 8,  /* row_of(g) = g % div */
+  TBX_F_ROW_IDX = 16, /* row_of(g) = ((const int32_t*)p1)[g]  (LOAD gather) */
+  TBX_F_ROW_BATCH_MOD = 32 /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
+};
+enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2 };
+#define TBX_MAX_STAGES 48
+#define TBX_AUX_LD 260
+
+typedef struct tbx_stage {
+  int32_t op, src, dst, src_col, dst_col, k, n, act, flags, ld, div, reserved;
+  float f0, f1;
+  const void* p0;
+  const void* p1;
+} tbx_stage_t;
+
+/* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
+int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
+                 int ldw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-step feature preparation (token frames, attribute rows, input pose embeddings).
+ */
+
+/* agent_encoder.py:130-159 (+ navigation.py:69-78 for the destination's relative pose, action_head.py:76 masks):
+ * hist_* hold the W-step sliding window, oldest first, missing steps invalid.
+ *   tok_pose [n,A,3] last-valid pose (0 if never valid), tok_invalid [n,A] u8,
+ *   attr [n*A*W, 32]: size3 type3 | spd acc yaw_rate | one-hot_W(position) | 0-pad   (W <= 23)
+ *   pe   [n*A*W, pe_dim]: pe_xy_yaw of the step's pose in the token frame, row_invalid [n*A*W] u8
+ *   type_mask [3, n*A] u8: ~(type_i & valid_now)
+ *   navi_pose3 [n*A, 3]: dest token pose relative to the agent's current pose; navi_row [n*A] i32 = b*M + dest
+ */
+int tbx_agent_prep(const uint8_t* hist_valid, const float* hist_pose, const float* hist_motion, const float* ag_attr6,
+                   const uint8_t* ag_type_idx, int n_batch, int n_ag, int window, const float* freqs_xy,
+                   const float* freqs_yaw, int pe_dim, float* tok_pose, uint8_t* tok_invalid, float* attr, float* pe,
+                   uint8_t* row_invalid, uint8_t* type_mask, const int64_t* dest, const float* mp_tok_pose, int n_mp,
+                   int mp_batch_div, float* navi_pose3, int32_t* navi_row, void* stream);
+
+/* traffic_light.py:219-226: attr [n*L*W, ld_attr] = one-hot5(state) | one-hot_W(position) | 0-pad; rows of missing
+ * steps (hist_tl == 0xFF) and of invalid lights are flagged in row_invalid. hist_tl holds the 5-bit state mask per step. */
+int tbx_tl_prep(const uint8_t* hist_tl, const uint8_t* tl_invalid, int n_batch, int n_tl, int window, int ld_attr,
+                float* attr, uint8_t* row_invalid, void* stream);
+
+/* map_encoder.py:64-77: per polyline node, attr [n*M*N, 32] = type11 | one-hot_N(node) | 0-pad, pe [n*M*N, 8] = the
+ * 7-d MultiPath++ polyline feature of the node in the token (first node) frame (pose_emb.py:58-89) | 0. */
+int tbx_map_prep(const uint8_t* mp_valid, const float* mp_type11, const float* mp_pose, int n_batch, int n_mp, int n_node,
+                 float* attr, float* pe, uint8_t* row_invalid, float* tok_pose, uint8_t* tok_invalid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K10: one closed-loop simulation step, all agents / lights of all scenes, no host round trip.
+ * Replaces dynamics.py:66-163 (update_ag / MultiPathPP / override_ag / override_tl), dynamics.py:165-204
+ * (disable_ag / disable_navi), teacher_forcing.py:108-167 (get), traffic_rule_checker.py:109-120,300-330
+ * (outside-map and destination-reached checks: the two that feed back into the rollout) and
+ * traffic_bots.py:123-143 (_append_hist), buffer.py:39-78 (add).
+ * The step index is read from and incremented in `st->step` (device), so one captured graph replays every step.
+ */
+typedef struct tbx_sim_state {
+  /* sizes */
+  int32_t n_batch, n_ag, n_tl, window, n_step_gt, n_step_tl_gt, n_step_out, n_node;
+  /* device step counter (1-based step being simulated) */
+  int32_t* step;
+  /* agent state, updated in place */
+  uint8_t* ag_valid;    /* [n,A] */
+  uint8_t* ag_disabled; /* [n,A] */
+  float* ag_pose;       /* [n,A,3] */
+  float* ag_motion;     /* [n,A,3] */
+  uint8_t* navi_valid;  /* [n,A] */
+  uint8_t* outside_map; /* [n,A] accumulated */
+  uint8_t* dest_reached;/* [n,A] accumulated */
+  uint8_t* tl_state;    /* [n,L] 5-bit one-hot mask */
+  /* sliding windows (oldest first) */
+  uint8_t* hist_valid;  /* [n,A,W] */
+  float* hist_pose;     /* [n,A,W,3] */
+  float* hist_motion;   /* [n,A,W,3] */
+  uint8_t* hist_tl;     /* [n,L,W] state mask, 0xFF = missing */
+  /* static per rollout */
+  const uint8_t* ag_type_idx; /* [n,A] 0 veh 1 ped 2 cyc */
+  const uint8_t* tf_mask;     /* [n,A,n_step_gt] teacher-forcing / spawn mask */
+  const uint8_t* gt_valid;    /* [n,A,n_step_gt] */
+  const float* gt_pose;       /* [n,A,n_step_gt,3] */
+  const float* gt_motion;     /* [n,A,n_step_gt,3] */
+  const uint8_t* tl_gt;       /* [n,L,n_step_tl_gt] state masks */
+  const float* boundary;      /* [n,4] xmin xmax ymin ymax */
+  const float* dest_pos;      /* [n,A,n_node,2] */
+  const float* dest_dir;      /* [n,A,n_node,2] unit */
+  const uint8_t* dest_invalid;/* [n,A,n_node] */
+  const uint8_t* dest_kind;   /* [n,A] bit0 lane (type<=3) bit1 road-edge boundary (type 4) */
+  const float* dest_thresh;   /* [n,A] */
+  /* model outputs of this step */
+  const float* action_mean;   /* [n,A,2] unbounded */
+  const float* tl_logits;     /* [n,L,5] */
+  /* rollout log, written at [.., step-1, ..] */
+  uint8_t* out_valid;         /* [n,A,T] validity BEFORE this step's override */
+  float* out_pose;            /* [n,A,T,3] */
+  float* out_motion;          /* [n,A,T,3] */
+  float* out_action;          /* [n,A,T,2] */
+  uint8_t* out_tl_state;      /* [n,L,T] */
+  uint8_t* out_outside_map;   /* [n,A,T] */
+  uint8_t* out_dest_reached;  /* [n,A,T] */
+  float max_acc[3], max_yaw_rate[3]; /* per type idx (veh, ped, cyc) */
+  float dt;
+} tbx_sim_state_t;
+
+int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBX_HIP_H */

@@ -1,0 +1,165 @@
+// tbx_knn_embed / tbx_pose_embed: relative pose + K-nearest selection + pose embedding (see include/tbx_hip.h).
+//
+// One wavefront per source token. Each lane keeps n_tgt/64 candidate distances in registers; the K winners are
+// extracted by K rounds of (lane-local argmin, wave-wide argmin by xor-shuffles), ties resolved to the lower index.
+// Distances follow the reference's operation order without FMA contraction (SURVEY.md Appx A.2):
+//   rx = dx*c + dy*s ; ry = dy*c - dx*s ; dist = sqrt(rx*rx + ry*ry), +inf if either side is invalid.
+// The embedding of the K selected relative poses is written by the same wave (lanes = channels), so the
+// [S, T, 3] relative-pose tensor of the reference is never materialised.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace {
+
+struct KnnArgs {
+  const float* src_pose;
+  const uint8_t* src_invalid;
+  const float* tgt_pose;
+  const uint8_t* tgt_invalid;
+  int32_t* idx;
+  uint8_t* invalid;
+  float* rel_pose;
+  float* emb;
+  const float* fxy;
+  const float* fyaw;
+  int n_rows, n_src, n_tgt, tgt_batch_div, k, pe_dim;
+  float dist_limit;
+};
+
+__device__ __forceinline__ void rel_xy(float x1, float y1, float c, float s, float x2, float y2, float& rx, float& ry) {
+  const float dx = __fsub_rn(x2, x1), dy = __fsub_rn(y2, y1);
+  rx = __fadd_rn(__fmul_rn(dx, c), __fmul_rn(dy, s));
+  ry = __fadd_rn(__fmul_rn(dx, -s), __fmul_rn(dy, c));
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
+  __shared__ float rel_s[4][64][3];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.n_rows) return;
+  const int b = row / a.n_src;
+  const int bt = b / a.tgt_batch_div;
+  const float x1 = a.src_pose[row * 3 + 0], y1 = a.src_pose[row * 3 + 1], yaw1 = a.src_pose[row * 3 + 2];
+  const bool inv1 = a.src_invalid[row] != 0;
+  const float c = cosf(yaw1), s = sinf(yaw1);
+  const float* tp = a.tgt_pose + (int64_t)bt * a.n_tgt * 3;
+  const uint8_t* ti = a.tgt_invalid + (int64_t)bt * a.n_tgt;
+
+  float d[MAXC];
+  uint32_t taken = 0;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int j = lane + 64 * q;
+    if (j < a.n_tgt) {
+      float rx, ry;
+      rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
+      const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)));
+      d[q] = (inv1 || ti[j] != 0) ? INFINITY : dist;
+    } else {
+      d[q] = INFINITY;
+      taken |= 1u << q;
+    }
+  }
+
+  int my_idx = 0;
+  float my_dist = INFINITY;
+  for (int it = 0; it < a.k; ++it) {
+    float v = INFINITY;
+    int j = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+      const bool free_q = ((taken >> q) & 1u) == 0;
+      // strict < keeps the lowest q (= lowest index within the lane) on ties; a free +inf slot still beats "none"
+      if (free_q && (d[q] < v || j == INT_MAX)) {
+        v = d[q];
+        j = lane + 64 * q;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(v, off, 64);
+      const int oj = __shfl_xor(j, off, 64);
+      if (ov < v || (ov == v && oj < j)) {
+        v = ov;
+        j = oj;
+      }
+    }
+    if ((j & 63) == lane) taken |= 1u << (j >> 6);
+    if (lane == it) {
+      my_idx = j;
+      my_dist = v;
+    }
+  }
+
+  if (lane < a.k) {
+    const int64_t o = (int64_t)row * a.k + lane;
+    a.idx[o] = my_idx;
+    a.invalid[o] = (ti[my_idx] != 0 || my_dist > a.dist_limit) ? 1 : 0;
+    float rx, ry;
+    rel_xy(x1, y1, c, s, tp[my_idx * 3 + 0], tp[my_idx * 3 + 1], rx, ry);
+    const float ryaw = __fsub_rn(tp[my_idx * 3 + 2], yaw1);
+    rel_s[wave][lane][0] = rx;
+    rel_s[wave][lane][1] = ry;
+    rel_s[wave][lane][2] = ryaw;
+    if (a.rel_pose != nullptr) {
+      a.rel_pose[o * 3 + 0] = rx;
+      a.rel_pose[o * 3 + 1] = ry;
+      a.rel_pose[o * 3 + 2] = ryaw;
+    }
+  }
+  if (a.emb == nullptr) return;
+  __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this only pins the compiler's ordering
+  for (int t = 0; t < a.k; ++t) {
+    const float x = rel_s[wave][t][0], y = rel_s[wave][t][1], yaw = rel_s[wave][t][2];
+    float* e = a.emb + ((int64_t)row * a.k + t) * a.pe_dim;
+    for (int ch = lane; ch < a.pe_dim; ch += 64) e[ch] = tbx::pose_emb_channel(ch, a.pe_dim, x, y, yaw, a.fxy, a.fyaw);
+  }
+}
+
+__global__ void pose_embed_kernel(const float* __restrict__ pose3, int64_t n, const float* __restrict__ fxy,
+                                  const float* __restrict__ fyaw, int pe_dim, float* __restrict__ out, int ld, int col_off) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * pe_dim) return;
+  const int64_t i = e / pe_dim;
+  const int c = (int)(e - i * pe_dim);
+  out[i * ld + col_off + c] = tbx::pose_emb_channel(c, pe_dim, pose3[i * 3], pose3[i * 3 + 1], pose3[i * 3 + 2], fxy, fyaw);
+}
+
+}  // namespace
+
+extern "C" int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, const float* tgt_pose,
+                             const uint8_t* tgt_invalid, int n_batch, int n_src, int n_tgt, int tgt_batch_div, int k,
+                             float dist_limit, int32_t* idx, uint8_t* invalid, float* rel_pose, float* emb,
+                             const float* freqs_xy, const float* freqs_yaw, int pe_dim, void* stream) {
+  if (!src_pose || !src_invalid || !tgt_pose || !tgt_invalid || !idx || !invalid) return TBX_ERR_ARG;
+  if (n_batch <= 0 || n_src <= 0 || n_tgt <= 0 || tgt_batch_div <= 0 || n_batch % tgt_batch_div != 0) return TBX_ERR_ARG;
+  if (k <= 0 || k >= n_tgt || k > 64 || n_tgt > 2048) return TBX_ERR_UNSUPPORTED;
+  if (emb != nullptr && (!freqs_xy || !freqs_yaw || (pe_dim != 64 && pe_dim != 128))) return TBX_ERR_UNSUPPORTED;
+  KnnArgs a{src_pose, src_invalid, tgt_pose, tgt_invalid, idx, invalid, rel_pose, emb, freqs_xy, freqs_yaw,
+            n_batch * n_src, n_src, n_tgt, tgt_batch_div, k, pe_dim, dist_limit};
+  const dim3 grid((a.n_rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (n_tgt <= 128)
+    hipLaunchKernelGGL(knn_embed_kernel<2>, grid, block, 0, s, a);
+  else if (n_tgt <= 1024)
+    hipLaunchKernelGGL(knn_embed_kernel<16>, grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL(knn_embed_kernel<32>, grid, block, 0, s, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
+                              float* out, int ld_out, int col_off, void* stream) {
+  if (!pose3 || !freqs_xy || !freqs_yaw || !out || n <= 0) return TBX_ERR_ARG;
+  if ((pe_dim != 64 && pe_dim != 128) || ld_out < col_off + pe_dim) return TBX_ERR_UNSUPPORTED;
+  const int64_t total = n * pe_dim;
+  hipLaunchKernelGGL(pose_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pose3, n,
+                     freqs_xy, freqs_yaw, pe_dim, out, ld_out, col_off);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

@@ -1,0 +1,363 @@
+// Row-tile chain interpreter (tbx_rowchain): see include/tbx_hip.h for the stage semantics.
+//
+// One 256-thread workgroup (4 wavefronts of 64) owns TILE_ROWS = 16*MT rows. Activations stay in LDS between stages
+// (two ping-pong buffers of `ldw` floats per row + a 260-float auxiliary buffer for residuals); weights are streamed
+// straight from L2/HBM into VGPRs once per tile (GEMV-like regime: no reuse across waves, so no LDS staging) and fed
+// to v_mfma_f32_16x16x4_f32, which is an exact fp32 fma chain. Wave w owns output column tiles w, w+4, ...
+//
+// MFMA operand mapping (guide: cdna_hip_programming.md §3): A lane l supplies A[i=l&15][k=l>>4], B lane l supplies
+// B[k=l>>4][j=l&15], C/D: col = l&15, row = (l>>4)*4 + reg. K is walked in blocks of 16 with the 4 MFMAs of a block
+// taking k = kb*16 + (l>>4)*4 + t, so every lane reads ONE float4 of activations (ds_read_b128) and ONE float4 of
+// weights (global_load_dwordx4) per 4 MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace {
+
+struct RowchainArgs {
+  tbx_stage_t st[TBX_MAX_STAGES];
+  int32_t n_stages;
+  int32_t group_rows;
+  int32_t ldw;
+  int32_t pad;
+  int64_t n_rows;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT>
+struct Tile {
+  static constexpr int ROWS = 16 * MT;
+  float* base;    // LDS base; buffers 0/1 are ROWS*ldw floats each, the auxiliary buffer follows
+  int ldw;
+  // computed, not indexed: a runtime-indexed member array would live in scratch memory
+  __device__ __forceinline__ float* b(int i) const { return base + (i == TBX_BUF_AUX ? 2 : i) * ROWS * ldw; }
+  __device__ __forceinline__ int l(int i) const { return i == TBX_BUF_AUX ? TBX_AUX_LD : ldw; }
+  int64_t g0;      // first global row of the tile
+  int n_valid;     // rows r < n_valid map to a global row
+  int64_t group;   // group index (grouped mode) or tile index
+};
+
+__device__ __forceinline__ int64_t row_of(const tbx_stage_t& s, int64_t g) {
+  if (s.flags & TBX_F_ROW_DIV) return g / s.div;
+  if (s.flags & TBX_F_ROW_MOD) return g % s.div;
+  if (s.flags & TBX_F_ROW_BATCH_MOD) return (g / s.k) * s.div + g % s.div;
+  if (s.flags & TBX_F_ROW_IDX) return (int64_t)((const int32_t*)s.p1)[g];
+  return g;
+}
+
+template <int MT>
+__device__ void op_load(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int ld = t.l(s.dst);
+  const float* src = (const float*)s.p0;
+  const int width = (s.flags & TBX_F_ROW_BATCH_MOD) ? s.n : (s.k > s.n ? s.k : s.n);
+  for (int e = threadIdx.x; e < ROWS * width; e += blockDim.x) {
+    const int r = e / width, c = e - r * width;
+    float v = 0.f;
+    if (r < t.n_valid && c < s.n && src != nullptr) v = src[row_of(s, t.g0 + r) * (int64_t)s.ld + c];
+    if ((s.flags & TBX_F_ACCUM) && c < s.n)
+      dst[r * ld + c] += v;
+    else if (!(s.flags & TBX_F_ACCUM))
+      dst[r * ld + c] = v;
+  }
+}
+
+template <int MT>
+__device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwave = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const float* src = t.b(s.src) + s.src_col;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
+  const float* W = (const float*)s.p0;
+  const float* bias = (const float*)s.p1;
+  const int K = s.k, N = s.n, ldw = s.ld;
+  const bool wt = (s.flags & TBX_F_WT) != 0;
+  const bool accum = (s.flags & TBX_F_ACCUM) != 0;
+  const bool fast = !wt && (K % 16 == 0) && (ldw % 4 == 0) && ((((uintptr_t)W) & 15) == 0);
+  const int n_tiles = (N + 15) / 16;
+  const int kblocks = (K + 15) / 16;
+  for (int nt = wave; nt < n_tiles; nt += nwave) {
+    const int n0 = nt * 16;
+    const int col = n0 + j;
+    const bool col_ok = col < N;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float b = (bias != nullptr && col_ok) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float c0 = b;
+        if (accum && col_ok) c0 += dst[(m * 16 + g * 4 + r) * lds_d + col];
+        acc[m][r] = c0;
+      }
+    }
+    for (int kb = 0; kb < kblocks; ++kb) {
+      const int k0 = kb * 16 + g * 4;
+      float4 bv;
+      if (fast) {
+        bv = col_ok ? *(const float4*)(W + (int64_t)col * ldw + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float tmp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = k0 + q;
+          float w = 0.f;
+          if (col_ok && kk < K) w = wt ? W[(int64_t)kk * ldw + col] : W[(int64_t)col * ldw + kk];
+          tmp[q] = w;
+        }
+        bv = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[m][r];
+        if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
+        // columns of the last partial tile beyond n are zero-filled (unless accumulating) so that the next stage may
+        // read a K padded to 16
+        if (col_ok)
+          dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+        else if (!accum && col < lds_d - s.dst_col)
+          dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
+      }
+    }
+  }
+}
+
+template <int MT>
+__device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const float* src = t.b(s.src) + s.src_col;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
+  const float* gamma = (const float*)s.p0;
+  const float* beta = (const float*)s.p1;
+  const int n = s.n;
+  for (int r = wave; r < ROWS; r += nwave) {
+    float v[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + 64 * q;
+      v[q] = (c < n) ? src[r * lds_s + c] : 0.f;
+      sum += v[q];
+    }
+    sum = tbx::wave_sum(sum);
+    const float mean = sum / (float)n;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + 64 * q;
+      const float d = (c < n) ? v[q] - mean : 0.f;
+      var += d * d;
+    }
+    var = tbx::wave_sum(var) / (float)n;
+    const float rstd = 1.0f / sqrtf(var + s.f0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + 64 * q;
+      if (c < n) dst[r * lds_d + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
+    }
+  }
+}
+
+template <int MT>
+__device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  const float* src = t.b(s.src) + s.src_col;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
+  const int n = s.n;
+  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
+    const int r = e / n, c = e - r * n;
+    if (s.op == TBX_OP_ADD)
+      dst[r * lds_d + c] += src[r * lds_s + c];
+    else if (s.op == TBX_OP_COPY)
+      dst[r * lds_d + c] = src[r * lds_s + c];
+    else  // CLAMP
+      dst[r * lds_d + c] = fminf(fmaxf(dst[r * lds_d + c], s.f0), s.f1);
+  }
+}
+
+template <int MT>
+__device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_d = t.l(s.dst);
+  const uint8_t* mask = (const uint8_t*)s.p0;
+  const int n = s.n;
+  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
+    const int r = e / n, c = e - r * n;
+    bool m = r >= t.n_valid;
+    if (!m && mask != nullptr) m = mask[row_of(s, t.g0 + r)] != 0;
+    if (m) dst[r * lds_d + c] = s.f0;
+  }
+}
+
+template <int MT>
+__device__ void op_groupmax(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  const float* src = t.b(s.src) + s.src_col;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
+  for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
+    float m = -INFINITY;
+    for (int r = 0; r < ROWS; ++r) m = fmaxf(m, src[r * lds_s + c]);
+    for (int r = 0; r < ROWS; ++r) dst[r * lds_d + c] = m;
+  }
+}
+
+template <int MT>
+__device__ void op_poolmax(const tbx_stage_t& s, const Tile<MT>& t) {
+  const float* src = t.b(s.src) + s.src_col;
+  const int lds_s = t.l(s.src);
+  const uint8_t* mask = (const uint8_t*)s.p1;
+  float* out = (float*)s.p0;
+  for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
+    float m = -INFINITY;
+    bool any = false;
+    for (int r = 0; r < t.n_valid; ++r) {
+      if (mask != nullptr && mask[t.g0 + r] != 0) continue;
+      any = true;
+      m = fmaxf(m, src[r * lds_s + c]);
+    }
+    out[t.group * (int64_t)s.ld + s.dst_col + c] = any ? m : 0.f;
+  }
+}
+
+template <int MT>
+__device__ void op_store(const tbx_stage_t& s, const Tile<MT>& t) {
+  constexpr int ROWS = 16 * MT;
+  const float* src = t.b(s.src) + s.src_col;
+  const int lds_s = t.l(s.src);
+  float* out = (float*)s.p0;
+  const int n = s.n;
+  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
+    const int r = e / n, c = e - r * n;
+    if (r < t.n_valid) out[(t.g0 + r) * (int64_t)s.ld + s.dst_col + c] = src[r * lds_s + c];
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void rowchain_kernel(const RowchainArgs a) {
+  constexpr int ROWS = 16 * MT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  Tile<MT> t;
+  t.base = lds;
+  t.ldw = a.ldw;
+  t.group = blockIdx.x;
+  if (a.group_rows > 0) {
+    t.g0 = (int64_t)blockIdx.x * a.group_rows;
+    t.n_valid = a.group_rows;
+  } else {
+    t.g0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t left = a.n_rows - t.g0;
+    t.n_valid = left < ROWS ? (int)left : ROWS;
+  }
+  for (int i = 0; i < a.n_stages; ++i) {
+    const tbx_stage_t& s = a.st[i];
+    switch (s.op) {
+      case TBX_OP_LOAD: op_load<MT>(s, t); break;
+      case TBX_OP_LINEAR: op_linear<MT>(s, t); break;
+      case TBX_OP_LAYERNORM: op_layernorm<MT>(s, t); break;
+      case TBX_OP_ADD:
+      case TBX_OP_COPY:
+      case TBX_OP_CLAMP: op_elementwise<MT>(s, t); break;
+      case TBX_OP_ROWMASK: op_rowmask<MT>(s, t); break;
+      case TBX_OP_GROUPMAX: op_groupmax<MT>(s, t); break;
+      case TBX_OP_POOLMAX: op_poolmax<MT>(s, t); break;
+      case TBX_OP_STORE: op_store<MT>(s, t); break;
+      default: break;
+    }
+    __syncthreads();
+  }
+}
+
+int check_stage(const tbx_stage_t& s, int ldw, int tile_rows) {
+  auto buf_ld = [&](int b) { return b == TBX_BUF_AUX ? TBX_AUX_LD : ldw; };
+  if (s.op < TBX_OP_LOAD || s.op > TBX_OP_CLAMP) return TBX_ERR_ARG;
+  if (s.src < 0 || s.src > 2 || s.dst < 0 || s.dst > 2) return TBX_ERR_ARG;
+  if (s.n <= 0) return TBX_ERR_ARG;
+  const bool reads_src = s.op == TBX_OP_LINEAR || s.op == TBX_OP_LAYERNORM || s.op == TBX_OP_ADD || s.op == TBX_OP_COPY ||
+                         s.op == TBX_OP_GROUPMAX || s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE;
+  const bool writes_dst = s.op != TBX_OP_POOLMAX && s.op != TBX_OP_STORE;
+  if (writes_dst) {
+    int w = s.n;
+    if (s.op == TBX_OP_LOAD && !(s.flags & TBX_F_ROW_BATCH_MOD) && s.k > w) w = s.k;
+    if (s.dst_col < 0 || s.dst_col + w > buf_ld(s.dst)) return TBX_ERR_UNSUPPORTED;
+  }
+  if (reads_src) {
+    const int w = s.op == TBX_OP_LINEAR ? ((s.k + 15) / 16) * 16 : s.n;
+    if (s.src_col < 0 || s.src_col + w > buf_ld(s.src)) return TBX_ERR_UNSUPPORTED;
+  }
+  if (s.op == TBX_OP_LINEAR) {
+    if (s.k <= 0 || s.p0 == nullptr || s.ld <= 0) return TBX_ERR_ARG;
+    if (s.src_col % 4 != 0) return TBX_ERR_ALIGN;
+    if (s.src == s.dst) {  // in-place only on disjoint column ranges
+      const int kw = ((s.k + 15) / 16) * 16;
+      const int nw = ((s.n + 15) / 16) * 16;
+      if (!(s.dst_col >= s.src_col + kw || s.src_col >= s.dst_col + nw)) return TBX_ERR_UNSUPPORTED;
+    }
+  }
+  if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
+  if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
+  if ((s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;
+  if ((s.flags & TBX_F_ROW_BATCH_MOD) && s.k <= 0) return TBX_ERR_ARG;
+  (void)tile_rows;
+  return TBX_OK;
+}
+
+}  // namespace
+
+extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
+                            int ldw, void* stream) {
+  if (stages == nullptr || n_stages <= 0 || n_rows <= 0) return TBX_ERR_ARG;
+  if (n_stages > TBX_MAX_STAGES) return TBX_ERR_UNSUPPORTED;
+  if (tile_rows != 16 && tile_rows != 32) return TBX_ERR_UNSUPPORTED;
+  if (ldw <= 0 || ldw % 4 != 0) return TBX_ERR_ALIGN;
+  if (group_rows < 0 || group_rows > tile_rows) return TBX_ERR_UNSUPPORTED;
+  if (group_rows > 0 && n_rows % group_rows != 0) return TBX_ERR_ARG;
+  const size_t lds_bytes = (size_t)(2 * ldw + TBX_AUX_LD) * tile_rows * sizeof(float);
+  if (lds_bytes > 160 * 1024) return TBX_ERR_UNSUPPORTED;
+  RowchainArgs a;
+  for (int i = 0; i < n_stages; ++i) {
+    const int rc = check_stage(stages[i], ldw, tile_rows);
+    if (rc != TBX_OK) return rc;
+    a.st[i] = stages[i];
+  }
+  a.n_stages = n_stages;
+  a.group_rows = group_rows;
+  a.ldw = ldw;
+  a.pad = 0;
+  a.n_rows = n_rows;
+  const int64_t n_tiles = group_rows > 0 ? n_rows / group_rows : (n_rows + tile_rows - 1) / tile_rows;
+  hipStream_t s = (hipStream_t)stream;
+  if (tile_rows == 16) {
+    if (lds_bytes > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)rowchain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(rowchain_kernel<1>, dim3((unsigned)n_tiles), dim3(256), lds_bytes, s, a);
+  } else {
+    if (lds_bytes > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)rowchain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(rowchain_kernel<2>, dim3((unsigned)n_tiles), dim3(256), lds_bytes, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

@@ -1,0 +1,166 @@
+// tbx_sim_step: one closed-loop simulation step for every agent and traffic light of every scene
+// (see include/tbx_hip.h; restates dynamics.py / teacher_forcing.py / the feeding-back subset of
+// traffic_rule_checker.py as the oracle's Sim.rollout does). Elementwise, one thread per agent / light; the 1-based
+// step index lives in device memory and is bumped by a second single-thread kernel so that one captured graph replays
+// every step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace {
+
+__global__ void sim_step_kernel(const tbx_sim_state_t s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = *s.step;  // step being simulated: model saw the state of step t-1
+  const int n_ag_tot = s.n_batch * s.n_ag;
+  const int n_tl_tot = s.n_batch * s.n_tl;
+  const int T = s.n_step_out;
+  const int W = s.window;
+  if (i < n_ag_tot) {
+    const int b = i / s.n_ag;
+    const bool valid0 = s.ag_valid[i] != 0;
+    const int ty = s.ag_type_idx[i];
+    float px = s.ag_pose[i * 3], py = s.ag_pose[i * 3 + 1], pyaw = s.ag_pose[i * 3 + 2];
+    float spd = s.ag_motion[i * 3];
+    // Dynamics.update_ag + MultiPathPP (dynamics.py:84-120,237-274)
+    float acc = 0.f, yr = 0.f;
+    if (valid0) {
+      acc = tanhf(s.action_mean[i * 2]) * s.max_acc[ty];
+      yr = tanhf(s.action_mean[i * 2 + 1]) * s.max_yaw_rate[ty];
+    }
+    const float half_dt = 0.5f * s.dt;
+    const float v_t = spd + half_dt * acc;
+    const float th_t = pyaw + half_dt * yr;
+    float nx = px + s.dt * (v_t * cosf(th_t));
+    float ny = py + s.dt * (v_t * sinf(th_t));
+    float nyaw = pyaw + s.dt * yr;
+    float nspd = spd + s.dt * acc, nacc = acc, nyr = yr;
+    if (!valid0) nx = ny = nyaw = nspd = nacc = nyr = 0.f;
+    if (t - 1 < T) {
+      const int64_t o = (int64_t)i * T + (t - 1);
+      s.out_valid[o] = valid0 ? 1 : 0;
+      s.out_pose[o * 3] = nx;
+      s.out_pose[o * 3 + 1] = ny;
+      s.out_pose[o * 3 + 2] = nyaw;
+      s.out_motion[o * 3] = nspd;
+      s.out_motion[o * 3 + 1] = nacc;
+      s.out_motion[o * 3 + 2] = nyr;
+      s.out_action[o * 2] = acc;
+      s.out_action[o * 2 + 1] = yr;
+    }
+    // outside-map / destination-reached on the predicted (pre-override) state (traffic_rule_checker.py:109-120,300-330)
+    const float* bd = s.boundary + b * 4;
+    const bool out_now = valid0 && (nx > bd[1] || nx < bd[0] || ny > bd[3] || ny < bd[2]);
+    const bool outside = (s.outside_map[i] != 0) || out_now;
+    bool pos_ok = false, rot_ok = false;
+    const float hx = cosf(nyaw), hy = sinf(nyaw);
+    for (int k = 0; k < s.n_node; ++k) {
+      const int64_t d = (int64_t)i * s.n_node + k;
+      if (s.dest_invalid[d]) continue;
+      const float ex = nx - s.dest_pos[d * 2], ey = ny - s.dest_pos[d * 2 + 1];
+      if (sqrtf(ex * ex + ey * ey) < s.dest_thresh[i]) pos_ok = true;
+      if (hx * s.dest_dir[d * 2] + hy * s.dest_dir[d * 2 + 1] > 0.8660254037844387f) rot_ok = true;
+    }
+    const uint8_t kind = s.dest_kind[i];
+    const bool reached0 = s.dest_reached[i] != 0;
+    const bool reach_now = !reached0 && valid0 && (((kind & 1) && pos_ok && rot_ok) || ((kind & 2) && pos_ok));
+    const bool reached = reached0 || reach_now;
+    if (t - 1 < T) {
+      s.out_outside_map[(int64_t)i * T + (t - 1)] = outside ? 1 : 0;
+      s.out_dest_reached[(int64_t)i * T + (t - 1)] = reached ? 1 : 0;
+    }
+    // TeacherForcing.get + Dynamics.override_ag (teacher_forcing.py:128-147, dynamics.py:122-141)
+    bool valid = valid0;
+    bool disabled = s.ag_disabled[i] != 0;
+    bool has_gt = t < s.n_step_gt;
+    bool gt_v = false;
+    if (has_gt) {
+      const int64_t g = (int64_t)i * s.n_step_gt + t;
+      gt_v = s.gt_valid[g] != 0;
+      if (s.tf_mask[g] != 0 && !disabled) {
+        valid = true;
+        nx = s.gt_pose[g * 3];
+        ny = s.gt_pose[g * 3 + 1];
+        nyaw = s.gt_pose[g * 3 + 2];
+        nspd = s.gt_motion[g * 3];
+        nacc = s.gt_motion[g * 3 + 1];
+        nyr = s.gt_motion[g * 3 + 2];
+      }
+    }
+    // Dynamics.disable_ag / disable_navi (dynamics.py:165-204)
+    const bool dis = out_now && !(has_gt && gt_v);
+    disabled = disabled || dis;
+    valid = valid && !dis;
+    s.ag_valid[i] = valid ? 1 : 0;
+    s.ag_disabled[i] = disabled ? 1 : 0;
+    s.ag_pose[i * 3] = nx;
+    s.ag_pose[i * 3 + 1] = ny;
+    s.ag_pose[i * 3 + 2] = nyaw;
+    s.ag_motion[i * 3] = nspd;
+    s.ag_motion[i * 3 + 1] = nacc;
+    s.ag_motion[i * 3 + 2] = nyr;
+    s.outside_map[i] = outside ? 1 : 0;
+    s.dest_reached[i] = reached ? 1 : 0;
+    if (reach_now) s.navi_valid[i] = 0;
+    // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see
+    uint8_t* hv = s.hist_valid + (int64_t)i * W;
+    float* hp = s.hist_pose + (int64_t)i * W * 3;
+    float* hm = s.hist_motion + (int64_t)i * W * 3;
+    for (int w = 0; w < W - 1; ++w) {
+      hv[w] = hv[w + 1];
+      for (int c = 0; c < 3; ++c) {
+        hp[w * 3 + c] = hp[(w + 1) * 3 + c];
+        hm[w * 3 + c] = hm[(w + 1) * 3 + c];
+      }
+    }
+    hv[W - 1] = valid ? 1 : 0;
+    hp[(W - 1) * 3] = nx;
+    hp[(W - 1) * 3 + 1] = ny;
+    hp[(W - 1) * 3 + 2] = nyaw;
+    hm[(W - 1) * 3] = nspd;
+    hm[(W - 1) * 3 + 1] = nacc;
+    hm[(W - 1) * 3 + 2] = nyr;
+  }
+  if (i < n_tl_tot) {
+    // Dynamics.override_tl (dynamics.py:143-163): argmax -> one-hot, ground truth while it lasts
+    const float* lg = s.tl_logits + (int64_t)i * 5;
+    int am = 0;
+    float best = lg[0];
+    for (int c = 1; c < 5; ++c)
+      if (lg[c] > best) {
+        best = lg[c];
+        am = c;
+      }
+    uint8_t st = (uint8_t)(1u << am);
+    if (t < s.n_step_tl_gt) st = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+    s.tl_state[i] = st;
+    if (t - 1 < T) s.out_tl_state[(int64_t)i * T + (t - 1)] = st;
+    uint8_t* ht = s.hist_tl + (int64_t)i * W;
+    for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
+    ht[W - 1] = st;
+  }
+}
+
+__global__ void sim_bump_kernel(int32_t* step) { *step += 1; }
+
+}  // namespace
+
+extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
+  if (!st) return TBX_ERR_ARG;
+  const tbx_sim_state_t& s = *st;
+  if (s.n_batch <= 0 || s.n_ag <= 0 || s.n_tl <= 0 || s.window <= 0 || s.n_step_out <= 0 || s.n_node <= 0) return TBX_ERR_ARG;
+  const void* need[] = {s.step, s.ag_valid, s.ag_disabled, s.ag_pose, s.ag_motion, s.navi_valid, s.outside_map,
+                        s.dest_reached, s.tl_state, s.hist_valid, s.hist_pose, s.hist_motion, s.hist_tl, s.ag_type_idx,
+                        s.tf_mask, s.gt_valid, s.gt_pose, s.gt_motion, s.tl_gt, s.boundary, s.dest_pos, s.dest_dir,
+                        s.dest_invalid, s.dest_kind, s.dest_thresh, s.action_mean, s.tl_logits, s.out_valid, s.out_pose,
+                        s.out_motion, s.out_action, s.out_tl_state, s.out_outside_map, s.out_dest_reached};
+  for (const void* p : need)
+    if (p == nullptr) return TBX_ERR_ARG;
+  const int n = s.n_batch * (s.n_ag > s.n_tl ? s.n_ag : s.n_tl);
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(sim_step_kernel, dim3((n + 127) / 128), dim3(128), 0, hs, s);
+  hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

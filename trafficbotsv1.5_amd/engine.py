@@ -1,0 +1,186 @@
+"""Host-side scheduling of the HIP kernels for the HPTR transformer stack.
+
+Everything here only *enqueues* kernels through the C ABI (hip.py) on the current HIP stream; there is no host
+synchronisation and no data-dependent branching, so a whole simulation step can be captured in a hipGraph.
+
+Formulation (exact restatements of modules/attention_rpe.py, SURVEY.md §0 finding 5):
+  * K/V are projected once per *token* (tables) and gathered by KNN index inside the attention kernel, instead of
+    per (src, tgt) pair after the gather;
+  * `linear_rpe` is folded into the query side (qt_h = W_rpe_k,h^T q_h) and into the weighted sum
+    (sum_t a_t (W_rpe_v e_t + b) = W_rpe_v (sum_t a_t e_t) + b  with sum_t a_t = 1 in eval mode).
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import hip
+from .hip import AUX, BUF0, BUF1, Chain, Seg
+
+D, NH, DH = 128, 4, 32
+QKV_LD, Q_LD, O_LD = 896, 640, 640  # [q|k|v|qt] , [q|qt] , [sum a v | sum a e per head]
+
+
+def _u8(mask: torch.Tensor) -> torch.Tensor:
+    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+
+
+def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col: int, with_kv: bool) -> int:
+    """[q | k | v | qt] (896 cols) or [q | qt] (640 cols) of the tile at dst_col. attention_rpe.py:92-98,147."""
+    w_in, b_in = attn.in_proj_weight, attn.in_proj_bias
+    nq = 3 * D if with_kv else D
+    ch.linear(src_buf, src_col, dst_buf, dst_col, w_in[:nq], b_in[:nq])
+    w_rpe = attn.linear_rpe.weight
+    for h in range(NH):  # qt_h = q_h @ W_rpe_k[h*32:(h+1)*32, :]
+        ch.linear(dst_buf, dst_col + h * DH, dst_buf, dst_col + nq + h * D, w_rpe[h * DH:(h + 1) * DH], wt=True)
+    return nq + NH * D
+
+
+def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1):
+    """x += out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), zero for rows without a valid target.
+    attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233."""
+    ch.load(obuf, BUF0, 0, n=O_LD)
+    w_rpe, b_rpe = attn.linear_rpe.weight, attn.linear_rpe.bias
+    for h in range(NH):
+        ch.linear(BUF0, D + h * D, BUF0, h * DH, w_rpe[D + h * DH:D + (h + 1) * DH], b_rpe[D + h * DH:D + (h + 1) * DH],
+                  accum=True)
+    ch.linear(BUF0, 0, AUX, 0, attn.out_proj_weight, attn.out_proj_bias)
+    ch.rowmask(AUX, 0, D, mask=row_no_valid)
+    ch.add(AUX, 0, x_buf, 0, D)
+
+
+def emit_ffn(ch: Chain, layer, x_buf: int = BUF1):
+    """x += linear2(relu(linear1(norm2(x)))). transformer_rpe.py:234-237."""
+    ch.layernorm(x_buf, 0, BUF0, 0, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+    ch.linear(BUF0, 0, BUF0, D, layer.linear1.weight, layer.linear1.bias, relu=True)
+    ch.linear(BUF0, D, AUX, 0, layer.linear2.weight, layer.linear2.bias)
+    ch.add(AUX, 0, x_buf, 0, D)
+
+
+def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_col: int = 0, end_buf: Optional[int] = None):
+    """A `MLP` container (modules/mlp.py) as Linear[+LN]+ReLU stages, ping-ponging between two buffers.
+    Returns the buffer that holds the output at out_col."""
+    lins = mlp.linear_layers()
+    cur, col = src_buf, src_col
+    for j, (lin, ln, act) in enumerate(lins):
+        last = j == len(lins) - 1
+        dst = bufs[0] if cur != bufs[0] else bufs[1]
+        if last and end_buf is not None:
+            dst = end_buf
+        if ln is None:
+            ch.linear(cur, col, dst, out_col, lin.weight, lin.bias, relu=act)
+        else:
+            ch.linear(cur, col, dst, out_col, lin.weight, lin.bias)
+            other = bufs[0] if dst != bufs[0] else bufs[1]
+            ch.layernorm(dst, out_col, dst, out_col, ln.weight, ln.bias, ln.eps)
+            if act:
+                ch.clamp(dst, out_col, lin.weight.shape[0], 0.0, float("inf"))
+            del other
+        cur, col = dst, out_col
+    return cur
+
+
+def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.Tensor, x_buf: int = BUF1):
+    """PointNet over the rows of one group (tile): polyline_encoder.py:49-61 + pooling.py:18-19,38.
+    Input x at x_buf[:, 0:128]; pooled row -> out[group]."""
+    cur = x_buf
+    for mlp in pl_encoder.mlp_layers:
+        lin = mlp.linear_layers()[0][0]
+        nxt = BUF0 if cur != BUF0 else BUF1
+        half = lin.weight.shape[0]
+        ch.linear(cur, 0, nxt, 0, lin.weight, lin.bias, relu=True)
+        ch.rowmask(nxt, 0, half, mask=row_invalid, fill=float("-inf"))
+        ch.groupmax(nxt, 0, nxt, half, half)
+        ch.rowmask(nxt, 0, 2 * half, mask=row_invalid, fill=0.0)
+        cur = nxt
+    ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid)
+
+
+class SelfKnn:
+    """KNN set among the source tokens themselves (idx i32 / invalid u8 / emb f32, all [n,S,K(,128)])."""
+
+    def __init__(self, idx, invalid, emb):
+        self.idx, self.invalid, self.emb = idx.contiguous(), _u8(invalid).contiguous(), emb.contiguous()
+
+
+def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
+              cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
+              tile_rows: int = 16) -> None:
+    """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
+    token matrix x [n*S, 128] IN PLACE. `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
+    appends row-local stages to the last layer's chain (x is in BUF1[:, 0:128] at that point)."""
+    assert x.shape == (n * S, D) and x.is_contiguous()
+    rows = n * S
+    dev = x.device
+    src_invalid = _u8(src_invalid).reshape(-1).contiguous()
+    qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
+    obuf = torch.empty(rows, O_LD, dtype=torch.float32, device=dev)
+    flag = torch.empty(rows, dtype=torch.uint8, device=dev)
+    layers = list(block.layers)
+    dec = block.mode == "dec_cross_attn"
+    if not dec and block.mode != "enc_self_attn":
+        raise NotImplementedError(f"TransformerBlockRPE mode {block.mode} is not on the default hot path")
+    q2 = torch.empty(rows, Q_LD, dtype=torch.float32, device=dev) if dec else None
+
+    def first_attn(l):
+        return layers[l].attn_src if dec else layers[l].attn
+
+    def first_norm(l):
+        return layers[l].norm_src if dec else layers[l].norm1
+
+    def emit_first_proj(ch, l):
+        nm = first_norm(l)
+        ch.layernorm(BUF1, 0, BUF0, 0, nm.weight, nm.bias, nm.eps)
+        w = emit_qkv(ch, first_attn(l), BUF0, 0, BUF0, D, with_kv=True)
+        ch.store(BUF0, D, w, qkv)
+
+    ch = Chain(tile_rows, 1028)
+    ch.load(x, BUF1, 0, n=D)
+    emit_first_proj(ch, 0)
+    ch.run(rows)
+    for l, layer in enumerate(layers):
+        a1 = first_attn(l)
+        self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb)
+        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag)
+        ch = Chain(tile_rows, 1028)
+        ch.load(x, BUF1, 0, n=D)
+        emit_attn_out(ch, a1, obuf, flag)
+        if dec:
+            ch.store(BUF1, 0, D, x)
+            ch.layernorm(BUF1, 0, BUF0, 0, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            w = emit_qkv(ch, layer.attn, BUF0, 0, BUF0, D, with_kv=False)
+            ch.store(BUF0, D, w, q2)
+            ch.run(rows)
+            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag)
+            ch = Chain(tile_rows, 1028)
+            ch.load(x, BUF1, 0, n=D)
+            emit_attn_out(ch, layer.attn, obuf, flag)
+        emit_ffn(ch, layer)
+        ch.rowmask(BUF1, 0, D, mask=src_invalid)
+        ch.store(BUF1, 0, D, x)
+        if l + 1 < len(layers):
+            emit_first_proj(ch, l + 1)
+        elif tail is not None:
+            tail(ch)
+        ch.run(rows)
+
+
+def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = None, tile_rows: int = 16) -> torch.Tensor:
+    """Per-token K/V tables of a target set for several attention layers at once:
+    out[:, l*256:(l+1)*256] = LN_l(x) @ W_kv,l^T + b_kv,l   (transformer_rpe.py:220-223 + attention_rpe.py:92-98,
+    projected before the gather)."""
+    rows = x.shape[0]
+    L = len(norms_and_attns)
+    if out is None:
+        out = torch.empty(rows, 2 * D * L, dtype=torch.float32, device=x.device)
+    ch = Chain(tile_rows, 516)
+    ch.load(x, BUF1, 0, n=D)
+    emit_kv_tables(ch, norms_and_attns, out)
+    ch.run(rows)
+    return out
+
+
+def emit_kv_tables(ch: Chain, norms_and_attns, out: torch.Tensor, x_buf: int = BUF1):
+    for l, (nm, attn) in enumerate(norms_and_attns):
+        ch.layernorm(x_buf, 0, BUF0, 0, nm.weight, nm.bias, nm.eps)
+        ch.linear(BUF0, 0, BUF0, D, attn.in_proj_weight[D:], attn.in_proj_bias[D:])
+        ch.store(BUF0, D, 2 * D, out, out_col=l * 2 * D)

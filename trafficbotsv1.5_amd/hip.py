@@ -1,0 +1,283 @@
+"""ctypes binding of libtbx_hip.so (include/tbx_hip.h) + the `Chain` builder for tbx_rowchain programs.
+
+The HIP library IS the product path: there is no CPU or PyTorch fallback. `load()` raises if the shared object is
+missing, and every wrapper raises on a non-zero tbx return code or on tensors that are not on a HIP device.
+"""
+import ctypes as C
+import re
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "csrc" / "libtbx_hip.so"
+HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
+
+# ---- constants mirrored from include/tbx_hip.h
+OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
+ACT_NONE, ACT_RELU = 0, 1
+F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD = 1, 2, 4, 8, 16, 32
+BUF0, BUF1, AUX = 0, 1, 2
+MAX_STAGES, AUX_LD = 48, 260
+
+
+class Stage(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("op", "src", "dst", "src_col", "dst_col", "k", "n", "act", "flags", "ld", "div",
+                                         "reserved")] + [("f0", C.c_float), ("f1", C.c_float), ("p0", C.c_void_p),
+                                                         ("p1", C.c_void_p)]
+
+
+class AttnSeg(C.Structure):
+    _fields_ = [("kv", C.c_void_p), ("idx", C.c_void_p), ("invalid", C.c_void_p), ("emb", C.c_void_p)] + [
+        (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k")]
+
+
+class SimState(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
+        + [(n, C.c_void_p) for n in (
+            "step", "ag_valid", "ag_disabled", "ag_pose", "ag_motion", "navi_valid", "outside_map", "dest_reached",
+            "tl_state", "hist_valid", "hist_pose", "hist_motion", "hist_tl", "ag_type_idx", "tf_mask", "gt_valid", "gt_pose",
+            "gt_motion", "tl_gt", "boundary", "dest_pos", "dest_dir", "dest_invalid", "dest_kind", "dest_thresh",
+            "action_mean", "tl_logits", "out_valid", "out_pose", "out_motion", "out_action", "out_tl_state",
+            "out_outside_map", "out_dest_reached")]
+        + [("max_acc", C.c_float * 3), ("max_yaw_rate", C.c_float * 3), ("dt", C.c_float)]
+    )
+
+
+_lib = None
+
+
+def declared_symbols() -> List[str]:
+    """Entry points declared in include/tbx_hip.h (the C-ABI contract)."""
+    txt = HEADER_PATH.read_text()
+    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(tbx_\w+)\s*\(", txt, flags=re.M)))
+
+
+def load():
+    """dlopen the in-tree library and check it exports every declared symbol. No GPU needed."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for s in declared_symbols():
+        if not hasattr(lib, s):
+            raise ImportError(f"libtbx_hip.so does not export {s}")
+    lib.tbx_error_string.restype = C.c_char_p
+    lib.tbx_version.restype = C.c_int
+    i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+    lib.tbx_knn_embed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.tbx_pose_embed.argtypes = [vp, i64, vp, vp, i32, vp, i32, i32, vp]
+    lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp]
+    lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
+    lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
+                                   i32, vp, vp, vp]
+    lib.tbx_tl_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
+    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep",
+                 "tbx_map_prep", "tbx_sim_step"):
+        getattr(lib, name).restype = C.c_int
+    if lib.tbx_version() != 1:
+        raise ImportError("libtbx_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what}: tbx error {rc}: {load().tbx_error_string(rc).decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tbx kernels need device tensors (HIP); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _cptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is not None and not t.is_contiguous():
+        raise RuntimeError("tbx kernels need contiguous tensors")
+    return _ptr(t, dtype)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------ wrappers
+def knn_embed(src_pose, src_invalid, tgt_pose, tgt_invalid, k: int, dist_limit: float, freqs_xy=None, freqs_yaw=None,
+              pe_dim: int = 128, tgt_batch_div: int = 1, want_rel_pose: bool = False, want_emb: bool = True):
+    """-> idx i32 [n,S,k], invalid u8 [n,S,k], rel_pose f32 [n,S,k,3] | None, emb f32 [n,S,k,pe_dim] | None."""
+    n, S, _ = src_pose.shape
+    T = tgt_pose.shape[1]
+    dev = src_pose.device
+    idx = torch.empty(n, S, k, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, S, k, dtype=torch.uint8, device=dev)
+    rel = torch.empty(n, S, k, 3, dtype=torch.float32, device=dev) if want_rel_pose else None
+    emb = torch.empty(n, S, k, pe_dim, dtype=torch.float32, device=dev) if want_emb else None
+    rc = load().tbx_knn_embed(_cptr(src_pose, torch.float32), _cptr(src_invalid, torch.uint8), _cptr(tgt_pose, torch.float32),
+                              _cptr(tgt_invalid, torch.uint8), n, S, T, tgt_batch_div, k, float(dist_limit), _ptr(idx),
+                              _ptr(inv), _ptr(rel), _ptr(emb), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr())
+    _check(rc, "tbx_knn_embed")
+    return idx, inv, rel, emb
+
+
+def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int = 0):
+    n = pose3.numel() // 3
+    if out is None:
+        out = torch.empty(n, pe_dim, dtype=torch.float32, device=pose3.device)
+    rc = load().tbx_pose_embed(_cptr(pose3, torch.float32), n, _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, _ptr(out),
+                               out.stride(0), col_off, stream_ptr())
+    _check(rc, "tbx_pose_embed")
+    return out
+
+
+class Seg:
+    """One target segment of a KNARPE attention call: a K/V table + the KNN set that indexes it."""
+
+    def __init__(self, kv, k_off, v_off, n_tgt, idx, invalid, emb, batch_div=1):
+        assert kv.dim() == 2 and kv.stride(1) == 1
+        self.kv, self.k_off, self.v_off, self.n_tgt, self.batch_div = kv, k_off, v_off, n_tgt, batch_div
+        self.idx, self.invalid, self.emb = idx, invalid, emb
+        self.k = idx.shape[-1]
+
+    def c(self) -> AttnSeg:
+        return AttnSeg(_ptr(self.kv, torch.float32), _cptr(self.idx, torch.int32), _cptr(self.invalid, torch.uint8),
+                       _cptr(self.emb, torch.float32), self.kv.stride(0), self.k_off, self.v_off, self.n_tgt,
+                       self.batch_div, self.k)
+
+
+def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid):
+    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
+    rc = load().tbx_knarpe_attn_fwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+                                    n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
+                                    _ptr(row_no_valid, torch.uint8), stream_ptr())
+    _check(rc, "tbx_knarpe_attn_fwd")
+
+
+def agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,
+               mp_tok_pose=None, n_mp=0, mp_batch_div=1):
+    n, A, W = hist_valid.shape
+    rc = load().tbx_agent_prep(
+        _cptr(hist_valid, torch.uint8), _cptr(hist_pose, torch.float32), _cptr(hist_motion, torch.float32),
+        _cptr(ag_attr6, torch.float32), _cptr(ag_type_idx, torch.uint8), n, A, W, _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim,
+        _ptr(out["tok_pose"]), _ptr(out["tok_invalid"]), _ptr(out["attr"]), _ptr(out["pe"]), _ptr(out["row_invalid"]),
+        _ptr(out.get("type_mask")), _cptr(dest, torch.int64), _cptr(mp_tok_pose, torch.float32), n_mp, mp_batch_div,
+        _ptr(out.get("navi_pose3")), _ptr(out.get("navi_row")), stream_ptr())
+    _check(rc, "tbx_agent_prep")
+
+
+def tl_prep(hist_tl, tl_invalid, attr, row_invalid):
+    n, L, W = hist_tl.shape
+    rc = load().tbx_tl_prep(_cptr(hist_tl, torch.uint8), _cptr(tl_invalid, torch.uint8), n, L, W, attr.stride(0),
+                            _ptr(attr, torch.float32), _ptr(row_invalid, torch.uint8), stream_ptr())
+    _check(rc, "tbx_tl_prep")
+
+
+def map_prep(mp_valid_u8, mp_type11, mp_pose, attr, pe, row_invalid, tok_pose, tok_invalid):
+    n, M, N = mp_valid_u8.shape
+    rc = load().tbx_map_prep(_cptr(mp_valid_u8, torch.uint8), _cptr(mp_type11, torch.float32), _cptr(mp_pose, torch.float32),
+                             n, M, N, _ptr(attr), _ptr(pe), _ptr(row_invalid), _ptr(tok_pose), _ptr(tok_invalid), stream_ptr())
+    _check(rc, "tbx_map_prep")
+
+
+def sim_step(state: SimState):
+    _check(load().tbx_sim_step(C.byref(state), stream_ptr()), "tbx_sim_step")
+
+
+# ------------------------------------------------------------------------------------------------ rowchain builder
+class Chain:
+    """Builds one tbx_rowchain program. Tensors handed to stages are kept alive by the chain; the encoded program
+    holds raw device pointers, so a chain is valid as long as those tensors are not re-allocated."""
+
+    def __init__(self, tile_rows: int = 16, ldw: int = 132):
+        self.tile_rows, self.ldw = tile_rows, ldw
+        self.stages: List[Stage] = []
+        self._keep = []
+        self._arr = None
+
+    def _add(self, **kw):
+        p0, p1 = kw.pop("p0", None), kw.pop("p1", None)
+        for t in (p0, p1):
+            if t is not None:
+                self._keep.append(t)
+        st = Stage(**kw)
+        st.p0, st.p1 = _ptr(p0), _ptr(p1)
+        self.stages.append(st)
+        self._arr = None
+        return self
+
+    @staticmethod
+    def _rows2d(t):
+        assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
+        return t
+
+    def load(self, src, dst, dst_col=0, n=None, pad_to=0, accum=False, row_div=0, row_mod=0, row_idx=None, batch_mod=None):
+        """dst[:, dst_col:+n] (=|+=) src[row_of(g), :n]. batch_mod=(rows_per_batch_here, rows_per_batch_src)."""
+        n = src.shape[1] if n is None else n
+        flags, div, k, p1 = (F_ACCUM if accum else 0), 0, pad_to, None
+        if row_div:
+            flags, div = flags | F_ROW_DIV, row_div
+        elif row_mod:
+            flags, div = flags | F_ROW_MOD, row_mod
+        elif row_idx is not None:
+            flags, p1 = flags | F_ROW_IDX, row_idx
+        elif batch_mod is not None:
+            flags, k, div = flags | F_ROW_BATCH_MOD, batch_mod[0], batch_mod[1]
+        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=k, flags=flags, div=div, ld=self._rows2d(src).stride(0),
+                         p0=src, p1=p1)
+
+    def zero(self, dst, dst_col, n):
+        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
+
+    def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False):
+        """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt)."""
+        w = self._rows2d(weight)
+        n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
+        flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
+        return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
+                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias)
+
+    def layernorm(self, src, src_col, dst, dst_col, weight, bias, eps=1e-5):
+        return self._add(op=OP_LAYERNORM, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=weight.shape[0], f0=eps,
+                         p0=weight, p1=bias)
+
+    def add(self, src, src_col, dst, dst_col, n):
+        return self._add(op=OP_ADD, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
+
+    def copy(self, src, src_col, dst, dst_col, n):
+        return self._add(op=OP_COPY, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
+
+    def clamp(self, dst, dst_col, n, lo, hi):
+        return self._add(op=OP_CLAMP, dst=dst, dst_col=dst_col, n=n, f0=lo, f1=hi)
+
+    def rowmask(self, dst, dst_col, n, mask=None, fill=0.0, row_div=0):
+        flags, div = (F_ROW_DIV, row_div) if row_div else (0, 0)
+        return self._add(op=OP_ROWMASK, dst=dst, dst_col=dst_col, n=n, f0=fill, flags=flags, div=div, p0=mask)
+
+    def groupmax(self, src, src_col, dst, dst_col, n):
+        return self._add(op=OP_GROUPMAX, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
+
+    def poolmax(self, src, src_col, n, out, out_col=0, mask=None):
+        return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
+                         p1=mask)
+
+    def store(self, src, src_col, n, out, out_col=0):
+        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out)
+
+    def run(self, n_rows: int, group_rows: int = 0):
+        if self._arr is None:
+            assert len(self.stages) <= MAX_STAGES, f"{len(self.stages)} stages > {MAX_STAGES}"
+            self._arr = (Stage * len(self.stages))(*self.stages)
+        rc = load().tbx_rowchain(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, stream_ptr())
+        _check(rc, "tbx_rowchain")

@@ -1,0 +1,122 @@
+"""`AgentEncoder` (models/agent_encoder.py:15-466), HPTR variant (`_forward_hptr`): per step, the agents' W-step
+windows -> local-frame PointNet tokens -> 4 dec_cross_attn layers over [K nearest agents | K nearest map tokens ++
+K nearest traffic lights]."""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import hip
+from ..engine import D, SelfKnn, emit_pointnet, kv_tables, run_block
+from ..hip import Chain, Seg
+from ..utils.pose_emb import PoseEmb
+from .modules.input_encoder import InputEncoder
+from .modules.polyline_encoder import PolylineEncoder
+from .modules.transformer_rpe import TransformerBlockRPE
+
+
+class AgentEncoder(nn.Module):
+    def __init__(self, hidden_dim: int, ag_attr_dim: int, ag_motion_dim: int, pairwise_relative: bool, pose_emb,
+                 input_encoder, temp_encoder, pose_rpe: PoseEmb, tf_cfg, n_tgt_knn: int, k_tgt_knn_ag2ag: float,
+                 k_tgt_knn_ag2mp: float, k_tgt_knn_ag2tl: float, dist_limit: float, k_dist_limit: float, n_layer_tf: int,
+                 temp_window_size: int, rnn_latent_temp_pool_mode: str) -> None:
+        super().__init__()
+        if not pairwise_relative or temp_window_size <= 0 or input_encoder["mode"] != "cat":
+            raise NotImplementedError("the MI355X path implements the default pairwise-relative HPTR agent encoder")
+        self.hidden_dim, self.temp_window_size = hidden_dim, temp_window_size
+        self.n_tgt_knn_ag2ag = int(n_tgt_knn * k_tgt_knn_ag2ag)
+        self.n_tgt_knn_ag2mp = int(n_tgt_knn * k_tgt_knn_ag2mp)
+        self.n_tgt_knn_ag2tl = int(n_tgt_knn * k_tgt_knn_ag2tl)
+        self.dist_limit = dist_limit * k_dist_limit
+        self.pose_emb = PoseEmb(pe_dim=hidden_dim // 2, **pose_emb)
+        self.pose_rpe = pose_rpe
+        attr_dim = ag_attr_dim + ag_motion_dim + temp_window_size
+        assert ag_attr_dim == 6 and ag_motion_dim == 3 and attr_dim <= 32
+        self.register_buffer("hist_ohe", torch.eye(temp_window_size))
+        self.temp_encoder = PolylineEncoder(hidden_dim=hidden_dim, tf_cfg=tf_cfg, **temp_encoder)
+        self.tf_ag2agmptl = TransformerBlockRPE(n_layer=n_layer_tf, mode="dec_cross_attn", d_rpe=pose_rpe.out_dim, **tf_cfg)
+        self.input_encoder = InputEncoder(hidden_dim=hidden_dim, attr_dim=attr_dim, pe_dim=self.pose_emb.out_dim, **input_encoder)
+
+    # ---- static per scene
+    def kv_mp(self, mp: Dict[str, Tensor]) -> Tensor:
+        """K/V tables of the map tokens for this encoder's ag2mp layers; cached in the map-token dict."""
+        cache = mp.setdefault("_kv_ag", {})
+        if id(self) not in cache:
+            feat = mp["mp_token_feature"].reshape(-1, self.hidden_dim).contiguous()
+            cache[id(self)] = kv_tables(feat, [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers])
+        return cache[id(self)]
+
+    def tl_kv_layers(self):
+        return [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers]
+
+    def alloc_prep(self, n: int, A: int, dev, with_heads: bool) -> Dict[str, Tensor]:
+        W, pe = self.temp_window_size, self.pose_emb.out_dim
+        f32, u8 = torch.float32, torch.uint8
+        out = dict(tok_pose=torch.empty(n, A, 3, dtype=f32, device=dev), tok_invalid=torch.empty(n, A, dtype=u8, device=dev),
+                   attr=torch.empty(n * A * W, 32, dtype=f32, device=dev), pe=torch.empty(n * A * W, pe, dtype=f32, device=dev),
+                   row_invalid=torch.empty(n * A * W, dtype=u8, device=dev))
+        if with_heads:
+            out.update(type_mask=torch.empty(3, n * A, dtype=u8, device=dev), navi_pose3=torch.empty(n * A, 3, dtype=f32, device=dev),
+                       navi_row=torch.empty(n * A, dtype=torch.int32, device=dev))
+        return out
+
+    def encode(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, mp: Dict[str, Tensor],
+               tl_invalid_u8: Tensor, tl_pose: Tensor, tl_kv: Tensor, prep: Optional[Dict[str, Tensor]] = None,
+               ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1,
+               tail: Optional[Callable[[Chain], None]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+        """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256].
+        -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows)."""
+        n, A, W = hist_valid.shape
+        assert W == self.temp_window_size
+        dev, d, rp = hist_pose.device, self.hidden_dim, self.pose_rpe
+        M, L = mp["mp_token_pose"].shape[1], tl_pose.shape[1]
+        if prep is None:
+            prep = self.alloc_prep(n, A, dev, with_heads=dest is not None)
+        hip.agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, self.pose_emb.pe_xy.freqs,
+                       self.pose_emb.pe_yaw.freqs, self.pose_emb.out_dim, prep, dest=dest,
+                       mp_tok_pose=mp["mp_token_pose"] if dest is not None else None, n_mp=M, mp_batch_div=mp_batch_div)
+        tok_pose, tok_inv = prep["tok_pose"], prep["tok_invalid"]
+        mp_inv = mp.get("mp_token_invalid_u8")
+        if mp_inv is None:
+            mp_inv = mp["mp_token_invalid_u8"] = mp["mp_token_invalid"].to(torch.uint8).contiguous()
+        fx, fy, pd = rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim
+        i_aa, m_aa, _, e_aa = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit, fx, fy, pd)
+        i_am, m_am, _, e_am = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
+                                            self.dist_limit, fx, fy, pd, tgt_batch_div=mp_batch_div)
+        i_at, m_at, _, e_at = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl, self.dist_limit,
+                                            fx, fy, pd)
+        prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
+                    knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at)
+        x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+        ch = Chain(16 if W <= 16 else 32, d + 4)
+        cur = self.input_encoder.emit(ch, prep["attr"], prep["pe"])
+        emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
+        ch.run(n * A * W, group_rows=W)
+        kv_mp = self.kv_mp(mp)
+        run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, e_aa),
+                  cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, e_am, mp_batch_div),
+                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, e_at)], tail=tail)
+        return x, prep
+
+    @staticmethod
+    def pad_hist(ag_valid: Tensor, ag_pose: Tensor, ag_motion: Tensor, window: int):
+        """Left-pad a [n,A,n_step,..] history (n_step <= window) with invalid steps: same tokens, fixed shape."""
+        n, A, n_step = ag_valid.shape
+        assert n_step <= window
+        p = window - n_step
+        hv = torch.cat([torch.zeros(n, A, p, dtype=torch.uint8, device=ag_valid.device), ag_valid.to(torch.uint8)], 2)
+        hp = torch.cat([torch.zeros(n, A, p, 3, dtype=torch.float32, device=ag_valid.device), ag_pose.float()], 2)
+        hm = torch.cat([torch.zeros(n, A, p, 3, dtype=torch.float32, device=ag_valid.device), ag_motion.float()], 2)
+        return hv.contiguous(), hp.contiguous(), hm.contiguous()
+
+    def forward(self, called_by_latent_encoder=False, **kw) -> Tuple[Tensor, Optional[Tensor]]:
+        """Reference signature (`_forward_hptr` kwargs): ag_valid [n,A,n_step], ag_attr [n,A,6], ag_motion, ag_pose,
+        mp_token_*, tl_token_invalid / tl_token_feature / tl_token_pose."""
+        n, A, _ = kw["ag_valid"].shape
+        hv, hp, hm = self.pad_hist(kw["ag_valid"], kw["ag_pose"], kw["ag_motion"], self.temp_window_size)
+        mp = {k: v for k, v in kw.items() if k.startswith("mp_token") or k.startswith("_kv")}
+        tl_feat = kw["tl_token_feature"].reshape(-1, self.hidden_dim).contiguous().float()
+        tl_kv = kv_tables(tl_feat, self.tl_kv_layers())
+        x, _ = self.encode(hv, hp, hm, kw["ag_attr"].float().contiguous(), mp, kw["tl_token_invalid"].to(torch.uint8).contiguous(),
+                           kw["tl_token_pose"].float().contiguous(), tl_kv)
+        return x.view(n, A, self.hidden_dim), None

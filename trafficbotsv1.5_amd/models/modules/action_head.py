@@ -1,0 +1,49 @@
+"""`ActionHead` (modules/action_head.py:9-100), branch_type=True with per-type log_std parameters."""
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+from torch.distributions import Independent, Normal
+
+from ...hip import AUX, BUF0, BUF1, Chain
+from .mlp import MLP
+
+
+class ActionHead(nn.Module):
+    def __init__(self, hidden_dim: int, action_dim: int, n_layer: int, mlp_use_layernorm: bool,
+                 log_std: Optional[float] = None, branch_type: bool = False, n_ag_type: int = 3) -> None:
+        super().__init__()
+        if not branch_type or log_std is None or mlp_use_layernorm:
+            raise NotImplementedError("the MI355X path implements the default branch_type head with fixed log_std")
+        self.branch_type, self.out_dim, self.hidden_dim = branch_type, action_dim, hidden_dim
+        self.mlp_mean = nn.ModuleList([MLP([hidden_dim] * n_layer + [action_dim], end_layer_activation=False)
+                                       for _ in range(n_ag_type)])
+        self.log_std = nn.ParameterList([nn.Parameter(log_std * torch.ones(action_dim)) for _ in range(n_ag_type)])
+
+    def emit(self, ch: Chain, type_mask: Tensor, out_mean: Tensor):
+        """x in BUF1[:, 0:d]; type_mask u8 [3, rows] = ~(type_i & valid); writes the masked-sum mean to out_mean."""
+        d = self.hidden_dim
+        for i, mlp in enumerate(self.mlp_mean):
+            lins = [t[0] for t in mlp.linear_layers()]
+            assert len(lins) == 3
+            ch.linear(BUF1, 0, BUF0, 0, lins[0].weight, lins[0].bias, relu=True)
+            ch.linear(BUF0, 0, BUF0, d, lins[1].weight, lins[1].bias, relu=True)
+            ch.linear(BUF0, d, BUF0, 2 * d, lins[2].weight, lins[2].bias)
+            ch.rowmask(BUF0, 2 * d, self.out_dim, mask=type_mask[i])
+            (ch.copy if i == 0 else ch.add)(BUF0, 2 * d, AUX, 0, self.out_dim)
+        ch.store(AUX, 0, self.out_dim, out_mean)
+
+    def masked_log_std(self, valid: Tensor, ag_type: Tensor) -> Tensor:
+        m = (ag_type & valid.unsqueeze(-1)).unsqueeze(-1).to(self.log_std[0].dtype)  # [n,A,3,1]
+        return (m * torch.stack(list(self.log_std), 0)).sum(2)
+
+    def forward(self, x: Tensor, valid: Tensor, ag_type: Tensor) -> Independent:
+        n_sc, n_ag, _ = ag_type.shape
+        x2 = x.reshape(-1, self.hidden_dim).contiguous().float()
+        tm = (~(ag_type & valid.unsqueeze(-1))).permute(2, 0, 1).reshape(3, -1).to(torch.uint8).contiguous()
+        mean = torch.empty(x2.shape[0], self.out_dim, dtype=torch.float32, device=x.device)
+        ch = Chain(16, 3 * self.hidden_dim + 4)
+        ch.load(x2, BUF1, 0, n=self.hidden_dim)
+        self.emit(ch, tm, mean)
+        ch.run(x2.shape[0])
+        return Independent(Normal(mean.view(n_sc, n_ag, self.out_dim), self.masked_log_std(valid, ag_type).exp()), 1)

@@ -1,0 +1,60 @@
+"""`AddNaviLatent` (modules/add_navi_latent.py:8-65), mode=cat, res_add=True: x + MLP([x, MLP_in(z)])."""
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from ...hip import BUF0, BUF1, Chain
+from .mlp import MLP
+
+
+class AddNaviLatent(nn.Module):
+    def __init__(self, hidden_dim: int, in_dim: int, dummy: bool, mode: str, n_layer: int, mlp_use_layernorm: bool,
+                 mlp_dropout_p: float, res_add: bool = False) -> None:
+        super().__init__()
+        self.dummy, self.hidden_dim, self.in_dim = dummy, hidden_dim, in_dim
+        if not dummy:
+            if mode != "cat" or not res_add or mlp_use_layernorm:
+                raise NotImplementedError("the MI355X path implements the default cat / res_add AddNaviLatent")
+            self.mode, self.res_add, self.mlp_dropout_p = mode, res_add, mlp_dropout_p
+            self.mlp_in = MLP([in_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
+            self.mlp = MLP([2 * hidden_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
+
+    def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None):
+        """x in BUF1[:, 0:d] (updated in place). z either already in BUF0[:, d:2d] (z=None) or loaded from `z`
+        [rows, in_dim]. Uses BUF0 columns [0, 4d)."""
+        d = self.hidden_dim
+        l_in, l_mlp = [t[0] for t in self.mlp_in.linear_layers()], [t[0] for t in self.mlp.linear_layers()]
+        assert len(l_in) == 3 and len(l_mlp) == 3, "default n_layer = 3"
+        if z is not None:
+            pad = ((self.in_dim + 15) // 16) * 16
+            ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)
+            ch.linear(BUF0, 0, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
+        else:
+            ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
+        ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
+        ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        ch.rowmask(BUF0, 2 * d, d, mask=z_invalid)
+        ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
+        ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
+        ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
+        ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
+        ch.rowmask(BUF0, 3 * d, d, mask=z_invalid)
+        ch.add(BUF0, 3 * d, BUF1, 0, d)
+
+    def forward(self, x: Tensor, z: Optional[Tensor], z_valid: Optional[Tensor] = None) -> Tensor:
+        if self.dummy:
+            return x
+        if self.training and self.mlp_dropout_p > 0:
+            raise NotImplementedError("dropout inside the HIP chain is not implemented yet (train with p = 0)")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.hidden_dim).contiguous().float()
+        z2 = z.reshape(-1, self.in_dim).contiguous().float()
+        zi = torch.zeros(x2.shape[0], dtype=torch.uint8, device=x.device) if z_valid is None else (~z_valid).reshape(-1).to(torch.uint8)
+        out = torch.empty_like(x2)
+        ch = Chain(16, 4 * self.hidden_dim + 4)
+        ch.load(x2, BUF1, 0, n=self.hidden_dim)
+        self.emit(ch, zi.contiguous(), z2)
+        ch.store(BUF1, 0, self.hidden_dim, out)
+        ch.run(x2.shape[0])
+        return out.view(*lead, self.hidden_dim)

@@ -1,0 +1,135 @@
+"""`TrafficBots` (models/traffic_bots.py:17-221): model assembly with the reference's constructor, sub-module names
+and state-dict keys. `forward` is the per-step policy: sliding windows -> tl encoder -> agent encoder -> navi/latent
+fusion -> action head + tl-state head, every stage a HIP kernel launch on the current stream."""
+from copy import deepcopy
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.distributions import Categorical, Independent, Normal
+
+from .. import hip
+from ..engine import emit_kv_tables
+from ..hip import BUF0, BUF1, Chain
+from ..utils.pose_emb import PoseEmb
+from .agent_encoder import AgentEncoder
+from .latent_encoder import LatentEncoder
+from .map_encoder import MapEncoder
+from .modules.action_head import ActionHead
+from .modules.add_navi_latent import AddNaviLatent
+from .navigation import NaviEncoder, NaviPredictor
+from .traffic_light import TrafficLightEncoder, TrafficLightStatePredictor
+
+
+class TrafficBots(nn.Module):
+    def __init__(self, hidden_dim: int, mp_attr_dim: int, tl_state_dim: int, ag_attr_dim: int, ag_motion_dim: int,
+                 navi_mode: str, navi_dim: int, mp_encoder, tl_encoder, tl_state_predictor, ag_encoder, navi_encoder,
+                 navi_predictor, latent_encoder, tf_cfg, time_step_gt: int, n_mp_pl_node: int, add_navi_latent, pose_rpe,
+                 pairwise_relative: bool, temp_window_size: int, n_tgt_knn: int, dist_limit: float, tl_mode: str,
+                 action_dim: int, action_head) -> None:
+        super().__init__()
+        if hidden_dim != 128 or tf_cfg["n_head"] != 4:
+            raise NotImplementedError("the gfx950 kernels are built for hidden_dim=128, n_head=4")
+        tl_encoder, ag_encoder = deepcopy(tl_encoder), deepcopy(ag_encoder)
+        self.temp_window_size, self.hidden_dim, self.tl_state_dim = temp_window_size, hidden_dim, tl_state_dim
+        self.pose_rpe = PoseEmb(pe_dim=hidden_dim, **pose_rpe) if pairwise_relative else None
+        self.mp_encoder = MapEncoder(hidden_dim=hidden_dim, attr_dim=mp_attr_dim, n_mp_pl_node=n_mp_pl_node,
+                                     pairwise_relative=pairwise_relative, n_tgt_knn=n_tgt_knn, dist_limit=dist_limit,
+                                     tf_cfg=tf_cfg, pose_rpe=self.pose_rpe, **mp_encoder)
+        tl_encoder.update(hidden_dim=hidden_dim, tl_state_dim=tl_state_dim, tl_mode=tl_mode, pairwise_relative=pairwise_relative,
+                          n_tgt_knn=n_tgt_knn, dist_limit=dist_limit, tf_cfg=tf_cfg, temp_window_size=temp_window_size,
+                          temp_encoder=mp_encoder["pl_encoder"])
+        self.tl_encoder = TrafficLightEncoder(pose_rpe=self.pose_rpe, **tl_encoder)
+        self.tl_state_predictor = TrafficLightStatePredictor(hidden_dim=hidden_dim, tl_state_dim=tl_state_dim,
+                                                             temp_window_size=temp_window_size, **tl_state_predictor)
+        ag_encoder.update(hidden_dim=hidden_dim, ag_attr_dim=ag_attr_dim, ag_motion_dim=ag_motion_dim,
+                          pairwise_relative=pairwise_relative, n_tgt_knn=n_tgt_knn, dist_limit=dist_limit, tf_cfg=tf_cfg,
+                          temp_window_size=temp_window_size, temp_encoder=mp_encoder["pl_encoder"])
+        self.ag_encoder = AgentEncoder(pose_rpe=self.pose_rpe, **ag_encoder)
+        self.latent_encoder = LatentEncoder(tl_encoder=tl_encoder, ag_encoder=ag_encoder, pose_rpe=self.pose_rpe,
+                                            time_step_gt=time_step_gt, **latent_encoder)
+        self.navi_encoder = NaviEncoder(hidden_dim=hidden_dim, navi_mode=navi_mode, navi_dim=navi_dim,
+                                        pairwise_relative=pairwise_relative, mp_pose_emb=self.mp_encoder.pose_emb,
+                                        pose_rpe=self.pose_rpe, **navi_encoder)
+        self.navi_predictor = NaviPredictor(navi_mode=navi_mode, navi_dim=navi_dim, ag_encoder=ag_encoder,
+                                            pose_rpe=self.pose_rpe, **navi_predictor)
+        self.add_navi = AddNaviLatent(hidden_dim=hidden_dim, in_dim=hidden_dim, dummy=self.navi_encoder.dummy, **add_navi_latent)
+        self.add_latent = AddNaviLatent(hidden_dim=hidden_dim, in_dim=self.latent_encoder.out_dim,
+                                        dummy=self.latent_encoder.dummy, **add_navi_latent)
+        self.action_head = ActionHead(hidden_dim=hidden_dim, action_dim=action_dim, **action_head)
+
+    # ------------------------------------------------------------------ fused per-step policy on raw windows
+    def policy_step(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, hist_tl: Tensor, ag_attr6: Tensor,
+                    ag_type_idx: Tensor, ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
+                    tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], out: Dict[str, Tensor]) -> None:
+        """One policy evaluation for all agents / lights. Inputs are the device-resident sliding windows (oldest first);
+        writes out['action_mean'] [n*A,2], out['tl_logits'] [n*L,5] (+ out['ag_feat'], out['tl_feat']).
+        No host synchronisation: capturable in a hipGraph. traffic_bots.py:188-221."""
+        n, A, W = hist_valid.shape
+        L, d = hist_tl.shape[1], self.hidden_dim
+        dev = hist_pose.device
+        div = tl_tokens.get("mp_batch_div", 1)
+        tl_inv = tl_tokens["tl_token_invalid_u8"]
+        tl_kv = out.get("tl_kv")
+        if tl_kv is None:
+            tl_kv = out["tl_kv"] = torch.empty(n * L, 2 * d * len(self.ag_encoder.tf_ag2agmptl.layers), dtype=torch.float32, device=dev)
+
+        def tl_tail(ch: Chain):
+            emit_kv_tables(ch, self.ag_encoder.tl_kv_layers(), tl_kv)
+            self.tl_state_predictor.emit(ch, tl_inv, out["tl_logits"])
+
+        out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail)
+        feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
+                                            tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
+                                            dest=dest, mp_batch_div=div)
+        out["prep"], out["ag_feat"] = prep, feat
+        rp = self.pose_rpe
+        navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)
+        navi_inv = out.get("navi_invalid")
+        if navi_inv is None:
+            navi_inv = out["navi_invalid"] = torch.empty(n * A, dtype=torch.uint8, device=dev)
+        torch.sub(1, navi_valid_u8.reshape(-1), out=navi_inv)
+        ch = Chain(16, 4 * d + 4)
+        ch.load(feat, BUF1, 0, n=d)
+        self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe)
+        self.add_navi.emit(ch, navi_inv)
+        self.add_latent.emit(ch, latent_invalid, ag_latent)
+        self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
+        ch.run(n * A)
+
+    # ------------------------------------------------------------------ reference per-step API
+    def init(self) -> None:
+        self.hist_ag_valid = self.hist_ag_pose = self.hist_ag_motion = self.hist_tl_state = None
+        self.navi_feature = None
+        self.tl_state_predictor.init()
+
+    def _append_hist(self, ag_valid, ag_pose, ag_motion, tl_state) -> None:
+        new = [ag_valid.unsqueeze(2), ag_pose.unsqueeze(2), ag_motion.unsqueeze(2), tl_state.unsqueeze(2)]
+        if self.hist_ag_valid is None:
+            self.hist_ag_valid, self.hist_ag_pose, self.hist_ag_motion, self.hist_tl_state = new
+        else:
+            W = self.temp_window_size
+            self.hist_ag_valid = torch.cat([self.hist_ag_valid, new[0]], 2)[:, :, -W:]
+            self.hist_ag_pose = torch.cat([self.hist_ag_pose, new[1]], 2)[:, :, -W:]
+            self.hist_ag_motion = torch.cat([self.hist_ag_motion, new[2]], 2)[:, :, -W:]
+            self.hist_tl_state = torch.cat([self.hist_tl_state, new[3]], 2)[:, :, -W:]
+
+    def forward(self, ag_valid: Tensor, ag_pose: Tensor, ag_motion: Tensor, ag_attr: Tensor, ag_type: Tensor,
+                ag_latent: Optional[Tensor], ag_latent_valid: Optional[Tensor], ag_navi: Optional[Tensor],
+                ag_navi_valid: Tensor, ag_navi_updated: bool, tl_state: Tensor, tl_tokens: Dict[str, Tensor],
+                mp_tokens: Dict[str, Tensor]) -> Tuple[Independent, Categorical]:
+        """Reference signature (traffic_bots.py:151-166)."""
+        self._append_hist(ag_valid, ag_pose, ag_motion, tl_state)
+        n, A = ag_valid.shape
+        L, W, dev = tl_state.shape[1], self.temp_window_size, ag_pose.device
+        hv, hp, hm = self.ag_encoder.pad_hist(self.hist_ag_valid, self.hist_ag_pose, self.hist_ag_motion, W)
+        ht = self.tl_encoder.states_to_hist(self.hist_tl_state, W)
+        out = dict(action_mean=torch.empty(n * A, 2, dtype=torch.float32, device=dev),
+                   tl_logits=torch.empty(n * L, self.tl_state_dim, dtype=torch.float32, device=dev))
+        lat_inv = (~ag_latent_valid).reshape(-1).to(torch.uint8).contiguous()
+        type_idx = ag_type.to(torch.uint8).argmax(-1).to(torch.uint8).contiguous()
+        self.policy_step(hv, hp, hm, ht, ag_attr.float().contiguous(), type_idx, ag_latent.reshape(n * A, -1).float().contiguous(),
+                         lat_inv, ag_navi.contiguous(), ag_navi_valid.to(torch.uint8).contiguous(), tl_tokens, mp_tokens, out)
+        mean = out["action_mean"].view(n, A, 2)
+        log_std = self.action_head.masked_log_std(ag_valid, ag_type)
+        return Independent(Normal(mean, log_std.exp()), 1), Categorical(logits=out["tl_logits"].view(n, L, -1))
