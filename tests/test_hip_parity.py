@@ -1,0 +1,206 @@
+"""GPU parity tests proper: the HIP path (called through the C ABI via hip.py / the reference-named modules) against
+the oracle on identical seeded inputs. Bit-exact for K-nearest index sets and masks; fp32 tolerance stated per check.
+Run on the MI355X box with `pytest -m gpu`."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hptr_ops as H
+from oracle import trafficbots_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-4, atol=2e-5)  # fp32 kernels vs fp32 CPU oracle (different summation order, ocml vs sleef sin/cos)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip(tb):
+    h = import_module("trafficbots_amd.hip")
+    h.load()
+    return h
+
+
+def _poses(g, n, S, span=200.0):
+    return torch.cat([(torch.rand(n, S, 2, generator=g) - 0.5) * span, (torch.rand(n, S, 1, generator=g) - 0.5) * 6.28], -1)
+
+
+@pytest.mark.parametrize("S,T,K,limit", [(12, 40, 6, 80.0), (64, 1024, 64, 500.0), (128, 128, 24, 250.0), (5, 2000, 33, 1e9)])
+def test_knn_embed(hip, dev, S, T, K, limit):
+    g = torch.Generator().manual_seed(S * 1000 + T)
+    n = 2
+    pose, pose2 = _poses(g, n, S), _poses(g, n, T)
+    inv, inv2 = torch.rand(n, S, generator=g) < 0.2, torch.rand(n, T, generator=g) < 0.3
+    inv2[1, K // 2:] = True  # fewer valid targets than K in scene 1
+    rp, rd = H.rel_pose(pose, inv, pose2, inv2)
+    idx_o, inv_o, rpe_o = H.knn_select(inv2, rp, rd, K, limit)
+    fxy, fyw = H.make_freqs_xy(32, 1e3), H.make_freqs_rad(64)
+    idx, kinv, rel, emb = hip.knn_embed(pose.to(dev), inv.to(torch.uint8).to(dev), pose2.to(dev), inv2.to(torch.uint8).to(dev), K,
+                                        limit, fxy.to(dev), fyw.to(dev), 128, want_rel_pose=True)
+    assert torch.equal(H.sorted_valid_sets(idx.cpu(), kinv.cpu()), H.sorted_valid_sets(idx_o, inv_o))  # bit-exact sets
+    assert int(idx.min()) >= 0 and int(idx.max()) < T
+    # relative poses / embeddings of the valid neighbours, matched by index
+    rel_full = torch.gather(rp, 2, idx.cpu().long()[..., None].expand(-1, -1, -1, 3))
+    ok = ~kinv.cpu().bool()
+    torch.testing.assert_close(rel.cpu()[ok], rel_full[ok], rtol=1e-5, atol=1e-4)
+    e_ref = H.pe_xy_yaw(rel.cpu()[..., :2], rel.cpu()[..., 2], fxy, fyw)
+    torch.testing.assert_close(emb.cpu()[ok], e_ref[ok], rtol=1e-4, atol=2e-5)
+
+
+def test_knn_lattice_exact(hip, dev):
+    """Integer-lattice poses: every distance is exact in fp32, so the sets must agree even at near-ties."""
+    g = torch.Generator().manual_seed(5)
+    lat = torch.cat([torch.randint(-40, 40, (1, 200, 2), generator=g).float() * 0.25,
+                     torch.randint(0, 4, (1, 200, 1), generator=g).float() * (np.pi / 2)], -1)
+    inv = torch.zeros(1, 200, dtype=torch.bool)
+    rp, rd = H.rel_pose(lat, inv)
+    K = 9
+    idx, kinv, _, _ = hip.knn_embed(lat.to(dev), inv.to(torch.uint8).to(dev), lat.to(dev), inv.to(torch.uint8).to(dev), K, 1e9,
+                                    want_emb=False)
+    # compare the multiset of selected DISTANCES (ties at the K-th place may pick different equal-distance indices)
+    d_hip = torch.gather(rd, 2, idx.cpu().long()).sort(-1)[0]
+    d_ref = torch.topk(rd, K, dim=-1, largest=False)[0].sort(-1)[0]
+    torch.testing.assert_close(d_hip, d_ref, rtol=0, atol=2e-5)
+
+
+def _filled(tb, cls, seed, dev, **kw):
+    m = cls(**kw)
+    tb.utils.det_fill(m, seed)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to(dev).eval(), P
+
+
+def test_mlp_input_pointnet(tb, hip, dev):
+    M = import_module("trafficbots_amd.models.modules")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 7, 20, generator=g)
+    inv = torch.rand(2, 5, 7, generator=g) < 0.4
+    inv[0, 0] = True
+    m, P = _filled(tb, M.mlp.MLP, 11, dev, fc_dims=[20, 64, 64, 64], end_layer_activation=False)
+    P = {"m." + k: v for k, v in P.items()}
+    torch.testing.assert_close(m(x.to(dev)).cpu(), H.mlp(P, "m", x, end_act=False), **TOL)
+    torch.testing.assert_close(m(x.to(dev), inv.to(dev), float("-inf")).cpu(),
+                               H.mlp(P, "m", x, end_act=False, mask_invalid=inv, fill=float("-inf")), **TOL)
+    m, P = _filled(tb, M.mlp.MLP, 12, dev, fc_dims=[48, 32, 32, 1], end_layer_activation=False, use_layernorm=True)
+    P = {"m." + k: v for k, v in P.items()}
+    x2 = torch.randn(37, 48, generator=g)
+    torch.testing.assert_close(m(x2.to(dev)).cpu(), H.mlp(P, "m", x2, end_act=False), **TOL)
+    m, P = _filled(tb, M.mlp.MLP, 13, dev, fc_dims=[31, 121, 121, 121], end_layer_activation=False)  # unaligned K / N
+    P = {"m." + k: v for k, v in P.items()}
+    x3 = torch.randn(50, 31, generator=g)
+    torch.testing.assert_close(m(x3.to(dev)).cpu(), H.mlp(P, "m", x3, end_act=False), **TOL)
+    for mode, pe_dim in (("cat", 64), ("add", 128)):
+        m, P = _filled(tb, M.input_encoder.InputEncoder, 13, dev, hidden_dim=128, attr_dim=20, pe_dim=pe_dim, n_layer=3,
+                       mlp_dropout_p=0, mlp_use_layernorm=False, mode=mode)
+        P = {"ie." + k: v for k, v in P.items()}
+        pe = torch.randn(2, 5, 7, pe_dim, generator=g)
+        torch.testing.assert_close(m(x.to(dev), pe.to(dev)).cpu(), H.input_encoder(P, "ie", mode, x, pe), **TOL)
+    for n_node in (7, 11, 20):
+        m, P = _filled(tb, M.polyline_encoder.PolylineEncoder, 14, dev, hidden_dim=128, tf_cfg={}, n_layer=3,
+                       mlp_use_layernorm=False, mlp_dropout_p=0.1, use_pointnet=True, pooling_mode="max_valid")
+        P = {"pn." + k: v for k, v in P.items()}
+        xp = torch.randn(2, 5, n_node, 128, generator=g)
+        ip = torch.rand(2, 5, n_node, generator=g) < 0.4
+        ip[0, 0] = True
+        torch.testing.assert_close(m(xp.to(dev), ip.to(dev)).cpu(), H.pointnet(P, "pn", xp, ip, 3), **TOL)
+
+
+def _attn_inputs(g, n=2, S=9, K=11, d=128, Ks=5):
+    src = torch.randn(n, S, d, generator=g)
+    tgt = torch.randn(n, S, K, d, generator=g)
+    rpe_e = torch.randn(n, S, K, d, generator=g)
+    m = torch.rand(n, S, K, generator=g) < 0.3
+    m[0, 2] = True
+    m[1, 0] = True
+    src_inv = torch.rand(n, S, generator=g) < 0.2
+    idx_self = torch.randint(0, S, (n, S, Ks), generator=g)
+    m_self = torch.rand(n, S, Ks, generator=g) < 0.3
+    m_self[0, 1] = True
+    rpe_self = torch.randn(n, S, Ks, d, generator=g)
+    return src, tgt, rpe_e, m, src_inv, idx_self, m_self, rpe_self
+
+
+@pytest.mark.parametrize("S,K", [(9, 11), (70, 89), (33, 128)])
+def test_attention_rpe(tb, hip, dev, S, K):
+    M = import_module("trafficbots_amd.models.modules")
+    g = torch.Generator().manual_seed(S)
+    src, tgt, rpe_e, m, *_ = _attn_inputs(g, S=S, K=K)
+    att, P = _filled(tb, M.attention_rpe.AttentionRPE, 15, dev, d_model=128, n_head=4, dropout_p=0.1, d_rpe=128)
+    P = {"a." + k: v for k, v in P.items()}
+    out, _ = att(src.to(dev), tgt.to(dev), tgt_padding_mask=m.to(dev), rpe=rpe_e.to(dev))
+    ref = H.attention_rpe(P, "a", 4, src, tgt, m, rpe_e)
+    torch.testing.assert_close(out.cpu(), ref, **TOL)
+    assert float(out[0, 2].abs().max()) == 0.0 and float(out[1, 0].abs().max()) == 0.0  # all-invalid rows -> exact 0
+
+
+@pytest.mark.parametrize("mode", ["enc_self_attn", "dec_cross_attn"])
+def test_transformer_block(tb, hip, dev, mode):
+    M = import_module("trafficbots_amd.models.modules")
+    g = torch.Generator().manual_seed(21)
+    src, tgt, rpe_e, m, src_inv, idx_self, m_self, rpe_self = _attn_inputs(g, S=37, K=13, Ks=7)
+    tf_cfg = dict(d_model=128, n_head=4, k_feedforward=4, dropout_p=0.1, bias=True, activation="relu", out_layernorm=False,
+                  apply_q_rpe=False)
+    blk, P = _filled(tb, M.transformer_rpe.TransformerBlockRPE, 16, dev, n_layer=3, mode=mode, d_rpe=128, **tf_cfg)
+    P = {"t." + k: v for k, v in P.items()}
+    to = lambda t: t.to(dev)
+    if mode == "enc_self_attn":
+        y, _ = blk(src=to(src), src_padding_mask=to(src_inv), tgt=to(idx_self), tgt_padding_mask=to(m_self), rpe=to(rpe_self))
+        ref = H.transformer_block(P, "t", mode, 3, 4, src, src_inv, idx_self, m_self, rpe_self)
+    else:
+        y, _ = blk(src=to(src), src_padding_mask=to(src_inv), tgt=to(tgt), tgt_padding_mask=to(m), rpe=to(rpe_e),
+                   decoder_tgt=to(idx_self), decoder_tgt_padding_mask=to(m_self), decoder_rpe=to(rpe_self))
+        ref = H.transformer_block(P, "t", mode, 3, 4, src, src_inv, tgt, m, rpe_e, idx_self, m_self, rpe_self)
+    torch.testing.assert_close(y.cpu(), ref, rtol=5e-4, atol=5e-5)
+
+
+def _model(tb, dev, n_tgt_knn):
+    cfg = tb.config.default_model_cfg(n_tgt_knn=n_tgt_knn)
+    M = import_module("trafficbots_amd.models.traffic_bots")
+    model = M.TrafficBots(**cfg)
+    tb.utils.det_fill(model, 0)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return cfg, model.to(dev).eval(), P
+
+
+@pytest.mark.parametrize("sizes,knn,n_steps", [((8, 64, 8), 4, 14), ((64, 1024, 128), 32, 3)])
+def test_model_tokens_and_policy_steps(tb, hip, dev, sizes, knn, n_steps):
+    """Rows 8-14: map tokens, tl pre-compute KNN sets, and the per-step policy (reference `TrafficBots.forward` API)
+    driven by ground-truth states, vs the oracle."""
+    cfg, model, P = _model(tb, dev, knn)
+    batch = tb.synthetic.make_scene(1, *sizes, seed=0)
+    b = O.scene_centric({**batch, **tb.synthetic.to_history_batch(batch)}, training=False)
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    with torch.no_grad():
+        mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
+        tl_o = om.tl_pre_compute(b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
+    bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    mp = model.mp_encoder(bd["sc/mp_valid"], bd["sc/mp_attr"], bd["sc/mp_pose"], bd["ref/mp_type"])
+    assert torch.equal(mp["mp_token_invalid"].cpu(), mp_o["mp_token_invalid"])
+    torch.testing.assert_close(mp["mp_token_feature"].cpu(), mp_o["mp_token_feature"], rtol=1e-3, atol=1e-4)
+    tl = model.tl_encoder.pre_compute(tl_valid=bd["gt/tl_valid"], tl_attr=bd["sc/tl_attr"], tl_pose=bd["sc/tl_pose"], **mp)
+    assert torch.equal(H.sorted_valid_sets(tl["knn_idx_tl2tl"].cpu(), tl["knn_invalid_tl2tl"].cpu()),
+                       H.sorted_valid_sets(tl_o["knn_idx_tl2tl"], tl_o["knn_invalid_tl2tl"]))
+    assert torch.equal(H.sorted_valid_sets(tl["knn_idx_tl2mp"].cpu(), tl["knn_invalid_tl2mp"].cpu()),
+                       H.sorted_valid_sets(tl_o["knn_idx_tl2mp"], tl_o["knn_invalid_tl2mp"]))
+    # per-step policy on ground-truth states (open loop), same injected latent
+    g = torch.Generator().manual_seed(1)
+    n, A = b["gt/ag_valid"].shape[:2]
+    z = torch.randn(n, A, 16, generator=g)
+    z_valid = b["gt/ag_valid"].any(-1)
+    model.init()
+    om.init()
+    for t in range(n_steps):
+        args = dict(ag_valid=b["gt/ag_valid"][:, :, t], ag_pose=b["gt/ag_pose"][:, :, t], ag_motion=b["gt/ag_motion"][:, :, t],
+                    ag_attr=b["sc/ag_attr"], ag_type=b["ref/ag_type"], ag_latent=z, ag_latent_valid=z_valid,
+                    ag_navi=b["gt/ag_navi"], ag_navi_valid=z_valid, tl_state=b["gt/tl_state"][:, :, t])
+        with torch.no_grad():
+            mean_o, _, logit_o = om.forward(tl_tokens=tl_o, mp_tokens=mp_o, **args)
+        a_dist, tl_dist = model(ag_navi_updated=True, tl_tokens=tl, mp_tokens=mp, **{k: v.to(dev) for k, v in args.items()})
+        torch.testing.assert_close(a_dist.mean.cpu(), mean_o, rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(tl_dist.logits.cpu(), torch.log_softmax(logit_o, -1), rtol=2e-3, atol=2e-4)
