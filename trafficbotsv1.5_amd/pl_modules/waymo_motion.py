@@ -1,0 +1,182 @@
+"""`WaymoMotion` (pl_modules/waymo_motion.py:29-524): the closed-loop driver with the reference's entry points
+`forward / rollout / reactive_replay / joint_future_pred / training_step / configure_optimizers`.
+
+The rollout is a device-resident state machine (utils/rollout_engine.py) replaying one hipGraph per step; scenes and
+rollouts are independent, so multi-GPU inference shards them over ranks with no collective.
+WOMD / WOSAC metrics, submission writers and video logging of the reference are out of scope.
+"""
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor, nn
+
+from ..config import AttrDict, to_attr
+from ..data_modules.scene_centric import SceneCentricPreProcessing
+from ..models.modules.distributions import MyDist
+from ..models.traffic_bots import TrafficBots
+from ..utils.buffer import RolloutBuffer
+from ..utils.dynamics import Dynamics
+from ..utils.rollout_engine import RolloutEngine
+from ..utils.teacher_forcing import TeacherForcing
+from ..utils.traffic_rule_checker import TrafficRuleChecker
+
+try:  # Lightning is not in the container image; the hot path only needs hparams / log / current_epoch
+    from pytorch_lightning import LightningModule  # type: ignore
+except Exception:  # pragma: no cover
+    class LightningModule(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.current_epoch, self.global_rank, self.logged = 0, 0, {}
+
+        def log(self, k, v, **kw):
+            self.logged[k] = v
+
+
+def _strip_target(cfg):
+    return AttrDict({k: v for k, v in dict(cfg).items() if k != "_target_"})
+
+
+class WaymoMotion(LightningModule):
+    def __init__(self, time_step_current: int, time_step_gt: int, time_step_end: int, time_step_sim_start: int,
+                 hidden_dim: int, data_size, pre_processing, model, p_training_rollout_prior: float,
+                 training_detach_model_input: bool, training_deterministic_action: bool, pred_navi_after_reached: bool,
+                 differentiable_reward, dynamics, teacher_forcing_training, teacher_forcing_reactive_replay,
+                 teacher_forcing_joint_future_pred, training_metrics, optimizer, lr_scheduler, lr_navi: float,
+                 n_joint_future_wosac: int = 32, joint_future_pred_deterministic_k0: bool = False, **unused) -> None:
+        super().__init__()
+        if pred_navi_after_reached:
+            raise NotImplementedError("pred_navi_after_reached=False is the default (no per-step host branch)")
+        self.hparams_ = to_attr(dict(
+            time_step_current=time_step_current, time_step_gt=time_step_gt, time_step_end=time_step_end,
+            p_training_rollout_prior=p_training_rollout_prior, training_detach_model_input=training_detach_model_input,
+            training_deterministic_action=training_deterministic_action, n_joint_future_wosac=n_joint_future_wosac,
+            joint_future_pred_deterministic_k0=joint_future_pred_deterministic_k0, optimizer=optimizer,
+            lr_scheduler=lr_scheduler, lr_navi=lr_navi, differentiable_reward=differentiable_reward,
+            training_metrics=training_metrics))
+        pp = [(k, SceneCentricPreProcessing(time_step_current=time_step_current, data_size=data_size, **_strip_target(v)))
+              for k, v in pre_processing.items()]
+        kwargs = {"time_step_gt": time_step_gt}
+        for _, m in pp:
+            kwargs.update(m.model_kwargs)
+        self.pre_processing = nn.Sequential(OrderedDict(pp))
+        self.dynamics = Dynamics(navi_mode=kwargs["navi_mode"], **dynamics)
+        mcfg = to_attr({**_strip_target(model), **kwargs, "action_dim": self.dynamics.action_dim})
+        self.model = TrafficBots(**mcfg)
+        self.teacher_forcing_training = TeacherForcing(**teacher_forcing_training)
+        self.teacher_forcing_reactive_replay = TeacherForcing(**teacher_forcing_reactive_replay)
+        self.teacher_forcing_joint_future_pred = TeacherForcing(**teacher_forcing_joint_future_pred)
+        self._engine: Optional[RolloutEngine] = None
+
+    @property
+    def hp(self):
+        return self.hparams_
+
+    # ------------------------------------------------------------------ once per scene
+    def encode_scene(self, batch: Dict[str, Tensor], tl_valid_key: str = "sc/tl_valid", n_rollout: int = 1):
+        """Map tokens + static traffic-light tokens (waymo_motion.py:316-323, 528-535). With n_rollout > 1 the
+        traffic-light tokens are expanded per rollout while the map tokens stay shared (mp_batch_div)."""
+        mp = self.model.mp_encoder(batch["sc/mp_valid"], batch["sc/mp_attr"], batch["sc/mp_pose"], batch["ref/mp_type"])
+        r = lambda t: t.repeat_interleave(n_rollout, 0) if n_rollout > 1 else t
+        tl = self.model.tl_encoder.pre_compute(tl_valid=r(batch[tl_valid_key]), tl_attr=r(batch["sc/tl_attr"]),
+                                               tl_pose=r(batch["sc/tl_pose"]), mp_batch_div=n_rollout, **mp)
+        return mp, tl
+
+    # ------------------------------------------------------------------ rollout
+    @torch.no_grad()
+    def rollout(self, ag_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor],
+                tl_state_gt: Tensor, teacher_forcing: TeacherForcing, rule_checker: TrafficRuleChecker, step_end: int,
+                deterministic_action: bool, player_policy=None, use_graph: bool = True) -> RolloutBuffer:
+        """Reference signature (waymo_motion.py:206-217). Inference only: deterministic actions, no autograd."""
+        if not deterministic_action:
+            raise NotImplementedError("stochastic actions are not used by any default entry point")
+        teacher_forcing.init(ag_valid=ag_tokens["gt_valid"], ag_pose=ag_tokens["gt_pose"], ag_motion=ag_tokens["gt_motion"],
+                             tl_state=tl_state_gt, current_epoch=self.current_epoch)
+        dev = ag_tokens["gt_pose"].device
+        eng = RolloutEngine(self.model, self.dynamics, dev)
+        eng.reset(gt_valid=ag_tokens["gt_valid"], gt_pose=ag_tokens["gt_pose"], gt_motion=ag_tokens["gt_motion"],
+                  tl_state_gt=tl_state_gt, tf_mask=teacher_forcing.ag_teacher_forcing, ag_type=ag_tokens["ag_type"],
+                  ag_attr=ag_tokens["ag_attr"], ag_latent=ag_tokens["ag_latent"], ag_latent_valid=ag_tokens["ag_latent_valid"],
+                  ag_navi=ag_tokens["ag_navi"], ag_navi_valid=ag_tokens["ag_navi_valid"], mp_tokens=mp_tokens,
+                  tl_tokens=tl_tokens, map_valid=rule_checker.mp_valid, map_type=rule_checker.mp_type,
+                  map_pos=rule_checker.mp_pos, map_dir=rule_checker.mp_dir, map_boundary=rule_checker.mp_boundary,
+                  n_step=step_end)
+        eng.run(step_end, use_graph=use_graph)
+        self._engine = eng
+        return eng.buffer(self.hp.time_step_current)
+
+    def _rule_checker(self, batch, ag_dest, tl_tokens):
+        return TrafficRuleChecker(mp_boundary=batch["map/boundary"], mp_valid=batch["map/valid"], mp_type=batch["map/type"],
+                                  mp_pos=batch["map/pos"], mp_dir=batch["map/dir"], ag_type=batch["ref/ag_type"],
+                                  ag_size=batch["ref/ag_size"], ag_goal=None, ag_dest=ag_dest,
+                                  tl_valid=tl_tokens["tl_token_valid"], tl_pose=tl_tokens["tl_token_pose"],
+                                  disable_check=self.training)
+
+    @torch.no_grad()
+    def reactive_replay(self, batch, mp_tokens, tl_tokens, ag_latent, ag_latent_valid, ag_navi, ag_navi_valid,
+                        teacher_forcing: TeacherForcing, deterministic_action: bool, step_end: Optional[int] = None,
+                        use_graph: bool = True) -> RolloutBuffer:
+        """waymo_motion.py:387-437: scene reconstruction given a complete episode."""
+        ag_tokens = {"ag_type": batch["ref/ag_type"], "ag_size": batch["ref/ag_size"], "ag_attr": batch["sc/ag_attr"],
+                     "gt_valid": batch["gt/ag_valid"], "gt_pose": batch["gt/ag_pose"], "gt_motion": batch["gt/ag_motion"],
+                     "ag_latent": ag_latent, "ag_latent_valid": ag_latent_valid, "ag_navi": ag_navi, "ag_navi_valid": ag_navi_valid}
+        buf = self.rollout(ag_tokens, mp_tokens, tl_tokens, batch["gt/tl_state"], teacher_forcing,
+                           self._rule_checker(batch, ag_navi, tl_tokens), step_end or self.hp.time_step_end,
+                           deterministic_action, use_graph=use_graph)
+        buf.flatten_joint_future(1)
+        return buf
+
+    @torch.no_grad()
+    def joint_future_pred(self, batch, mp_tokens, tl_tokens, ag_latent_dist: Optional[MyDist], ag_navi_dist: Optional[MyDist],
+                          teacher_forcing: TeacherForcing, n_joint_future: int, step_end: Optional[int] = None,
+                          use_graph: bool = True) -> RolloutBuffer:
+        """waymo_motion.py:439-524: K parallel rollouts per scene from the history only. The K rollouts of a scene
+        share one copy of the map tokens / K-V tables (tl_tokens must come from encode_scene(n_rollout=K))."""
+        K = n_joint_future
+        assert tl_tokens.get("mp_batch_div", 1) == K, "build tl_tokens with encode_scene(..., n_rollout=n_joint_future)"
+        r = lambda t: t.repeat_interleave(K, 0)
+        ag_tokens = {"ag_type": r(batch["ref/ag_type"]), "ag_size": r(batch["ref/ag_size"]), "ag_attr": r(batch["sc/ag_attr"]),
+                     "gt_valid": r(batch["sc/ag_valid"]), "gt_pose": r(batch["sc/ag_pose"]), "gt_motion": r(batch["sc/ag_motion"])}
+        if self.hp.joint_future_pred_deterministic_k0:
+            det = torch.zeros_like(ag_tokens["gt_valid"][:, :, 0])
+            det[::K] = True
+        else:
+            det = False
+        ag_latent_dist.repeat_interleave_(K, 0)
+        ag_tokens["ag_latent"] = ag_latent_dist.sample(deterministic=det)
+        ag_tokens["ag_latent_valid"] = ag_latent_dist.valid
+        ag_navi_dist.repeat_interleave_(K, 0)
+        ag_tokens["ag_navi"] = ag_navi_dist.sample(det)
+        ag_tokens["ag_navi_valid"] = ag_navi_dist.valid
+        checker = self._rule_checker(batch, ag_tokens["ag_navi"], tl_tokens)
+        buf = self.rollout(ag_tokens, mp_tokens, tl_tokens, r(batch["sc/tl_state"]), teacher_forcing, checker,
+                           step_end or self.hp.time_step_end, True, use_graph=use_graph)
+        buf.flatten_joint_future(K)
+        return buf
+
+    def forward(self, *args, **kwargs):
+        """One closed-loop step of the current rollout engine (waymo_motion.py:118-204 semantics: policy, dynamics
+        update, overrides). Use `rollout` for whole episodes; this exists for step-wise drivers."""
+        if self._engine is None:
+            raise RuntimeError("call rollout()/reactive_replay()/joint_future_pred() first to set up the simulation state")
+        self._engine.step()
+        S = self._engine.S
+        return {"pred_valid": S["ag_valid"].bool(), "pred_pose": S["ag_pose"], "pred_motion": S["ag_motion"]}, {}
+
+    # ------------------------------------------------------------------ training
+    def training_step(self, batch: Dict[str, Tensor], batch_idx: int):
+        raise NotImplementedError(
+            "training_step (waymo_motion.py:313-385) needs the backward kernels of tbx_rowchain / tbx_knarpe_attn, which are "
+            "the next row of the build plan (DESIGN.md §6); there is deliberately no autograd fallback through PyTorch ops.")
+
+    def configure_optimizers(self):
+        """waymo_motion.py:820-838: AdamW, separate lr group for navi_predictor, StepLR."""
+        navi, rest = [], []
+        for k, v in self.named_parameters():
+            (navi if "navi_predictor" in k else rest).append(v)
+        o = _strip_target(self.hp.optimizer)
+        opt = torch.optim.AdamW(rest, **o)
+        if navi:
+            opt.add_param_group({"params": navi, "lr": self.hp.lr_navi})
+        sch = torch.optim.lr_scheduler.StepLR(opt, **_strip_target(self.hp.lr_scheduler))
+        return [opt], [{"scheduler": sch, "monitor": "val/loss", "interval": "epoch"}]

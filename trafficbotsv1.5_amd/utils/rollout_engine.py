@@ -1,0 +1,151 @@
+"""Closed-loop rollout engine: the device-resident simulation state + one hipGraph that replays
+[policy (tl encoder -> agent encoder -> heads) -> tbx_sim_step] once per 0.1 s step.
+
+Replaces the Python loop of `WaymoMotion.rollout` (pl_modules/waymo_motion.py:206-311) and everything it drives per
+step (Dynamics, TeacherForcing.get, the feeding-back rule checks, RolloutBuffer.add, TrafficBots._append_hist); the
+reference's >= 19 host synchronisations per step (SURVEY.md Appx D.1) are gone: the step index lives on the device.
+"""
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from .. import hip
+from .buffer import RolloutBuffer
+
+
+def _u8(t: Tensor) -> Tensor:
+    return t.to(torch.uint8).contiguous()
+
+
+def _state_bits(one_hot: Tensor) -> Tensor:
+    """[..., 5] one-hot bool -> u8 bit mask."""
+    w = (1 << torch.arange(one_hot.shape[-1], device=one_hot.device, dtype=torch.int32))
+    return (one_hot.to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+
+
+class RolloutEngine:
+    def __init__(self, model, dynamics, device) -> None:
+        self.model, self.dyn, self.dev = model, dynamics, device
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    # ------------------------------------------------------------------ setup
+    @torch.no_grad()
+    def reset(self, *, gt_valid: Tensor, gt_pose: Tensor, gt_motion: Tensor, tl_state_gt: Tensor, tf_mask: Tensor,
+              ag_type: Tensor, ag_attr: Tensor, ag_latent: Tensor, ag_latent_valid: Tensor, ag_navi: Tensor,
+              ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
+              map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int) -> None:
+        """All tensors on the device. gt_* [n,A,Tg(,3)], tl_state_gt [n,L,Tt,5] bool, tf_mask [n,A,Tg] bool
+        (TeacherForcing.ag_teacher_forcing), ag_navi [n,A] int64 dest; map_* are the raw polylines of the scene(s)
+        ([n/div, M, N, ..]) for the destination check."""
+        dev = self.dev
+        n, A, Tg = gt_valid.shape
+        L, Tt = tl_state_gt.shape[1], tl_state_gt.shape[2]
+        W = self.model.temp_window_size
+        N = map_valid.shape[2]
+        div = tl_tokens.get("mp_batch_div", 1)
+        f32, u8 = torch.float32, torch.uint8
+        self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)
+        S = {}
+        # ---- static
+        S["ag_type_idx"] = _u8(ag_type.to(u8).argmax(-1))
+        S["tf_mask"], S["gt_valid"] = _u8(tf_mask), _u8(gt_valid)
+        S["gt_pose"], S["gt_motion"] = gt_pose.float().contiguous(), gt_motion.float().contiguous()
+        S["tl_gt"] = _state_bits(tl_state_gt)
+        S["boundary"] = map_boundary.float().repeat_interleave(n // map_boundary.shape[0], 0).contiguous()
+        bsel = (torch.arange(n, device=dev) // div).unsqueeze(1)
+        d_type = map_type[bsel, ag_navi]                      # [n,A,11]
+        d_dir = map_dir[bsel, ag_navi][..., :2].float()       # traffic_rule_checker.py:87-107
+        d_dir = d_dir / torch.norm(d_dir, dim=-1, keepdim=True)
+        S["dest_pos"] = map_pos[bsel, ag_navi][..., :2].float().contiguous()
+        S["dest_dir"] = d_dir.contiguous()
+        S["dest_invalid"] = _u8(~map_valid[bsel, ag_navi])
+        S["dest_kind"] = (d_type[:, :, :4].any(-1).to(u8) + 2 * d_type[:, :, 4].to(u8)).contiguous()
+        S["dest_thresh"] = (50.0 * (1 - d_type[:, :, 4].float() * 0.8)).contiguous()
+        self.ag_attr6 = ag_attr.float().contiguous()
+        self.ag_latent = ag_latent.reshape(n * A, -1).float().contiguous()
+        self.latent_invalid = _u8(~ag_latent_valid.reshape(-1))
+        self.dest = ag_navi.contiguous()
+        # ---- initial dynamic state (Dynamics.init, dynamics.py:29-64) and its pristine copy
+        init = dict(
+            step=torch.ones(1, dtype=torch.int32, device=dev),
+            ag_valid=_u8(gt_valid[:, :, 0]), ag_disabled=z(n, A, dt=u8), ag_pose=gt_pose[:, :, 0].float().contiguous(),
+            ag_motion=gt_motion[:, :, 0].float().contiguous(), navi_valid=_u8(ag_navi_valid), outside_map=z(n, A, dt=u8),
+            dest_reached=z(n, A, dt=u8), tl_state=S["tl_gt"][:, :, 0].contiguous(),
+            hist_valid=z(n, A, W, dt=u8), hist_pose=z(n, A, W, 3), hist_motion=z(n, A, W, 3),
+            hist_tl=torch.full((n, L, W), 0xFF, dtype=u8, device=dev))
+        init["hist_valid"][:, :, -1] = init["ag_valid"]
+        init["hist_pose"][:, :, -1] = init["ag_pose"]
+        init["hist_motion"][:, :, -1] = init["ag_motion"]
+        init["hist_tl"][:, :, -1] = init["tl_state"]
+        self.init_state = init
+        for k, v in init.items():
+            S[k] = v.clone()
+        # ---- per-step model outputs and the rollout log
+        S["action_mean"], S["tl_logits"] = z(n * A, 2), z(n * L, 5)
+        S.update(out_valid=z(n, A, n_step, dt=u8), out_pose=z(n, A, n_step, 3), out_motion=z(n, A, n_step, 3),
+                 out_action=z(n, A, n_step, 2), out_tl_state=z(n, L, n_step, dt=u8), out_outside_map=z(n, A, n_step, dt=u8),
+                 out_dest_reached=z(n, A, n_step, dt=u8))
+        self.S = S
+        self.mp_tokens, self.tl_tokens = mp_tokens, tl_tokens
+        st = hip.SimState()
+        st.n_batch, st.n_ag, st.n_tl, st.window = n, A, L, W
+        st.n_step_gt, st.n_step_tl_gt, st.n_step_out, st.n_node = Tg, Tt, n_step, N
+        for name, _ in hip.SimState._fields_:
+            if name in S:
+                setattr(st, name, S[name].data_ptr())
+        st.max_acc = (C.c_float * 3)(*self.dyn.max_acc)
+        st.max_yaw_rate = (C.c_float * 3)(*self.dyn.max_yaw_rate)
+        st.dt = self.dyn.dt
+        self.sim_state = st
+        self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
+        self.graph = None
+
+    @torch.no_grad()
+    def restore(self) -> None:
+        """Back to step 1 without re-allocating (pointers captured in the graph stay valid)."""
+        for k, v in self.init_state.items():
+            self.S[k].copy_(v)
+
+    # ------------------------------------------------------------------ stepping
+    @torch.no_grad()
+    def step(self) -> None:
+        S = self.S
+        self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6, S["ag_type_idx"],
+                               self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens,
+                               self.policy_out)
+        hip.sim_step(self.sim_state)
+
+    @torch.no_grad()
+    def capture(self) -> None:
+        """Warm up one eager step, restore, then capture one step into a hipGraph on a side stream."""
+        self.step()
+        torch.cuda.synchronize()
+        self.restore()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step()
+        self.graph = g
+
+    @torch.no_grad()
+    def run(self, n_steps: Optional[int] = None, use_graph: bool = True) -> None:
+        n_steps = self.T if n_steps is None else n_steps
+        if use_graph and self.graph is None:
+            self.capture()
+        for _ in range(n_steps):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.step()
+
+    # ------------------------------------------------------------------ results
+    def buffer(self, step_current: int = 10) -> RolloutBuffer:
+        S, buf = self.S, RolloutBuffer(self.T, step_current)
+        buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
+        buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
+        bits = (S["out_tl_state"].to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=self.dev, dtype=torch.int32)) & 1
+        buf.vis_dict = {"action": S["out_action"], "tl_state": bits.bool()}
+        return buf
