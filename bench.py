@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Headline benchmark: closed-loop sim-agent-steps/s of the HIP hot path (BASELINE.json metric, config[1]:
+synthetic 64-agent / 1024-polyline / 128-light scene, 10 teacher-forced prime steps (untimed warm-up) + 80 closed-loop
+steps (timed), one hipGraph replay per step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes S] [--rollouts R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; scenes / rollouts are independent, so ranks never communicate on the data path (weak scaling:
+every rank simulates its own scenes); the only collectives are the timing barrier and a MAX over ranks of the wall time.
+Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events around every tbx_knarpe_attn launch of a few
+extra (untimed-region) eager steps on the launch stream; `cpu_baseline` times the oracle (CPU port of the reference
+formulation) on a bounded sample of the same workload on rank 0's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from importlib import import_module
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
+    ap.add_argument("--rollouts", type=int, default=1, help="parallel rollouts per scene (share the map tokens)")
+    ap.add_argument("--agents", type=int, default=64)
+    ap.add_argument("--polylines", type=int, default=1024)
+    ap.add_argument("--lights", type=int, default=128)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events for the roofline")
+    return ap.parse_args()
+
+
+def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int) -> float:
+    """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b with fp32 (b = 4), d = d_rpe = 128."""
+    d, b = 128, 4
+    return n_src_rows * 2 * d * b + n_pairs * (2 * d * b + 17) + (d * 2 * d + 2 * d) * b
+
+
+class KernelEvents:
+    """Brackets every tbx_knarpe_attn / tbx_rowchain launch with HIP events on the launch stream."""
+
+    def __init__(self, hip):
+        self.hip, self.attn, self.chain = hip, [], []
+
+    def __enter__(self):
+        hip = self.hip
+        self._attn, self._run = hip.knarpe_attn, hip.Chain.run
+
+        def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag)
+            e1.record()
+            self.attn.append((e0, e1, attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs))))
+
+        def run(ch, n_rows, group_rows=0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fl = sum(2.0 * n_rows * s.k * s.n for s in ch.stages if s.op == hip.OP_LINEAR)
+            e0.record()
+            self._run(ch, n_rows, group_rows)
+            e1.record()
+            self.chain.append((e0, e1, fl))
+
+        hip.knarpe_attn, hip.Chain.run = attn, run
+        return self
+
+    def __exit__(self, *a):
+        self.hip.knarpe_attn, self.hip.Chain.run = self._attn, self._run
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ta = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in self.attn]
+        tc = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in self.chain]
+        return (sum(ta), sum(b for *_, b in self.attn), len(ta)), (sum(tc), sum(f for *_, f in self.chain), len(tc))
+
+
+def build(tb, args, dev, rank):
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    torch.manual_seed(0)
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    wm = wm.to(dev).eval()  # random init of the reference architecture (no checkpoint on the box)
+    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=1000 * rank)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    return wm, full
+
+
+def gpu_rollout_setup(tb, wm, full, args, dev):
+    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+    R = args.rollouts
+    t0 = time.perf_counter()
+    mp, tl = wm.encode_scene(bd, n_rollout=R)
+    torch.cuda.synchronize()
+    t_scene = time.perf_counter() - t0
+    r = (lambda t: t.repeat_interleave(R, 0)) if R > 1 else (lambda t: t)
+    n, A = args.scenes * R, args.agents
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(n, A, 16, generator=g).to(dev)  # prior sample (std-normal), injected
+    valid = r(bd["sc/ag_valid"].any(-1))
+    tf = wm.teacher_forcing_joint_future_pred
+    tf.init(ag_valid=r(bd["sc/ag_valid"]), ag_pose=r(bd["sc/ag_pose"]), ag_motion=r(bd["sc/ag_motion"]),
+            tl_state=r(bd["sc/tl_state"]), current_epoch=0)
+    Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    eng = Eng(wm.model, wm.dynamics, dev)
+    eng.reset(gt_valid=r(bd["sc/ag_valid"]), gt_pose=r(bd["sc/ag_pose"]), gt_motion=r(bd["sc/ag_motion"]),
+              tl_state_gt=r(bd["sc/tl_state"]), tf_mask=tf.ag_teacher_forcing, ag_type=r(bd["ref/ag_type"]),
+              ag_attr=r(bd["sc/ag_attr"]), ag_latent=z, ag_latent_valid=valid, ag_navi=r(bd["gt/ag_navi"]), ag_navi_valid=valid,
+              mp_tokens=mp, tl_tokens=tl, map_valid=bd["map/valid"], map_type=bd["map/type"], map_pos=bd["map/pos"],
+              map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=args.warmup + args.steps + args.profile_steps)
+    return eng, t_scene
+
+
+def cpu_baseline(tb, wm, full, args):
+    """Oracle (CPU port, reference formulation) on a bounded sample: first scene, `cpu_steps` closed-loop steps."""
+    from oracle import trafficbots_oracle as O
+
+    P = {k: v.detach().cpu().clone() for k, v in wm.model.state_dict().items()}
+    one = {k: v[:1] for k, v in full.items()}
+    b = O.scene_centric(one, training=False)
+    cfg, scfg = tb.config.default_model_cfg(), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, args.agents, 16, generator=g)
+    valid = b["sc/ag_valid"].any(-1)
+    bh = dict(b)
+    bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
+    with torch.no_grad():
+        mp = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
+        tl = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp)
+        sim = O.Sim(om, scfg, False)
+        run = lambda n: sim.rollout(bh, mp, tl, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred, n,
+                                    gt_prefix="hist", tl_gt_key="sc/tl_state")
+        run(2)  # warm up thread pools / allocator
+        # pick the thread count that is fastest for this small-op workload (all cores is rarely it), then time
+        best, n_all = None, torch.get_num_threads()
+        for nt in sorted({8, 16, 32, 64, n_all} & set(range(1, n_all + 1))):
+            torch.set_num_threads(nt)
+            run(2)
+            t0 = time.perf_counter()
+            run(4)
+            d = time.perf_counter() - t0
+            if best is None or d < best[0]:
+                best = (d, nt)
+        torch.set_num_threads(best[1])
+        t0 = time.perf_counter()
+        run(args.cpu_steps)
+        dt = time.perf_counter() - t0
+        torch.set_num_threads(n_all)
+    return {"value": args.agents * args.cpu_steps / dt, "unit": "sim-agent-steps/s", "cores": best[1],
+            "kind": "port", "sample": f"1 scene x {args.agents} agents x {args.cpu_steps} closed-loop steps in {dt:.1f}s "
+                                      f"(oracle, torch {torch.__version__} CPU fp32, best of 8/16/32/64/all = {best[1]} threads of {n_all}, "
+                                      f"map encoding excluded)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    tb = load_package()
+    hip = import_module("trafficbots_amd.hip")
+    hip.load()
+    wm, full = build(tb, args, dev, rank)
+    eng, t_scene = gpu_rollout_setup(tb, wm, full, args, dev)
+    use_graph = not args.no_graph
+    if use_graph:
+        eng.capture()
+    eng.run(args.warmup, use_graph=use_graph)  # teacher-forced prime steps (untimed)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps, use_graph=use_graph)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_roll_rank = args.scenes * args.rollouts
+    units = world * n_roll_rank * args.agents * args.steps
+    # ---- live per-kernel timing (eager steps right after the timed region, same state, same stream)
+    with KernelEvents(hip) as ke:
+        eng.run(args.profile_steps, use_graph=False)
+    (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
+    finite = bool(torch.isfinite(eng.S["out_pose"]).all())
+    if rank == 0:
+        ach = b_attn / t_attn / 1e9
+        line = {
+            "metric": "sim-agent-steps/sec (closed-loop rollout)", "value": units / dt, "unit": "sim-agent-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.agents}-agent/{args.polylines}-polyline/{args.lights}-light synthetic scene, "
+                                   f"{args.warmup}-step teacher-forced prime + {args.steps}-step closed-loop rollout",
+                       "scenes_per_gpu": args.scenes, "rollouts_per_scene": args.rollouts, "graph": use_graph,
+                       "weights": "random init of the 10,657,094-parameter default architecture"},
+            "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": n_attn / args.profile_steps,
+                         "avg_launch_us": t_attn / n_attn * 1e6, "algorithmic_bytes_per_launch": b_attn / n_attn},
+            "roofline_gemm": {"kernel": "rowchain_kernel", "bound": "mfma", "achieved": f_chain / t_chain / 1e12,
+                              "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f_chain / t_chain / 1e12 / FP32_MFMA_PEAK_TF,
+                              "launches_per_step": n_chain / args.profile_steps, "avg_launch_us": t_chain / n_chain * 1e6},
+            "scene_encode_ms": t_scene * 1e3, "finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(tb, wm, full, args)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,8 @@ def _poses(g, n, S, span=200.0):
     return torch.cat([(torch.rand(n, S, 2, generator=g) - 0.5) * span, (torch.rand(n, S, 1, generator=g) - 0.5) * 6.28], -1)
 
 
-@pytest.mark.parametrize("S,T,K,limit", [(12, 40, 6, 80.0), (64, 1024, 64, 500.0), (128, 128, 24, 250.0), (5, 2000, 33, 1e9)])
+@pytest.mark.parametrize("S,T,K,limit", [(12, 40, 6, 80.0), (64, 1024, 64, 500.0), (128, 128, 24, 250.0), (5, 2000, 33, 1e9),
+                                         (2100, 40, 6, 80.0)])  # last: >= 4096 rows -> the one-wave-per-row kernel variant
 def test_knn_embed(hip, dev, S, T, K, limit):
     g = torch.Generator().manual_seed(S * 1000 + T)
     n = 2
@@ -126,7 +127,7 @@ def _attn_inputs(g, n=2, S=9, K=11, d=128, Ks=5):
     return src, tgt, rpe_e, m, src_inv, idx_self, m_self, rpe_self
 
 
-@pytest.mark.parametrize("S,K", [(9, 11), (70, 89), (33, 128)])
+@pytest.mark.parametrize("S,K", [(9, 11), (70, 89), (33, 128), (2100, 8)])  # last: one-wave-per-row variant
 def test_attention_rpe(tb, hip, dev, S, K):
     M = import_module("trafficbots_amd.models.modules")
     g = torch.Generator().manual_seed(S)
@@ -137,6 +138,15 @@ def test_attention_rpe(tb, hip, dev, S, K):
     ref = H.attention_rpe(P, "a", 4, src, tgt, m, rpe_e)
     torch.testing.assert_close(out.cpu(), ref, **TOL)
     assert float(out[0, 2].abs().max()) == 0.0 and float(out[1, 0].abs().max()) == 0.0  # all-invalid rows -> exact 0
+
+
+def test_pose_embed(tb, hip, dev):
+    g = torch.Generator().manual_seed(2)
+    pose = torch.cat([(torch.rand(300, 2, generator=g) - 0.5) * 900, (torch.rand(300, 1, generator=g) - 0.5) * 12], -1)
+    for dim in (128, 64):
+        fxy, fyw = H.make_freqs_xy(dim // 4, 1e3), H.make_freqs_rad(dim // 2)
+        e = hip.pose_embed(pose.to(dev), fxy.to(dev), fyw.to(dev), dim)
+        torch.testing.assert_close(e.cpu(), H.pe_xy_yaw(pose[:, :2], pose[:, 2], fxy, fyw), rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("mode", ["enc_self_attn", "dec_cross_attn"])

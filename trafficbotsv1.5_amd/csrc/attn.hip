@@ -1,6 +1,6 @@
 // tbx_knarpe_attn_fwd: fused KNARPE attention (see include/tbx_hip.h for the math and the layouts).
 //
-// One wavefront per source token, 4 tokens per 256-thread workgroup.
+// One wavefront per source token, 4 tokens per 256-thread workgroup (large grids), or 4 wavefronts per token (small grids).
 //   phase 1 (scores): 8 lanes per target, 8 targets per pass. The 8 lanes of a group read one full 128-B line of the
 //     target's K row and of its embedding row per step (coalesced gathers), keep the query side (q, qt = W_rpe_k^T q)
 //     in registers, and reduce with three xor-shuffles. Raw scores go to LDS.
@@ -31,17 +31,33 @@ struct AttnArgs {
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// WPR = wavefronts cooperating on one source row: 1 for large grids (a wave per row, 4 rows per workgroup), 4 for small
+// grids (the closed loop at a few scenes is latency-bound: 4 waves split a row's targets and combine through LDS).
+template <int WPR>
 __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
-  __shared__ float p_s[4][NH][KMAX];
-  __shared__ uint8_t inv_s[4][KMAX];
+  constexpr int RPB = 4 / WPR;  // rows per workgroup
+  __shared__ float p_s[RPB][NH][KMAX];
+  __shared__ uint8_t inv_s[RPB][KMAX];
+  __shared__ int act_s[RPB][KMAX];
+  __shared__ int misc_s[RPB][2];  // [0] any_valid, [1] n_active
+  __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (D + NH * DR) : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.n_rows) return;
+  const int rib = wave / WPR;  // row in block
+  const int wir = wave % WPR;  // wave in row
+  const int row = blockIdx.x * RPB + rib;
+  if (row >= a.n_rows) return;  // uniform per row group (and per workgroup when WPR == 4)
   const int b = row / a.n_src;
   const int k0 = a.seg[0].k;
   const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
   const int s8 = lane & 7, tg = lane >> 3;
+  auto row_sync = [&]() {
+    if constexpr (WPR > 1)
+      __syncthreads();
+    else
+      __builtin_amdgcn_wave_barrier();
+  };
+  if (WPR > 1 && threadIdx.x == 0) misc_s[0][0] = 0;
 
   // ---- query side in registers
   const float* qrow = a.qbuf + (int64_t)row * a.ldq;
@@ -55,10 +71,11 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) qtv[h][st] = *(const float4*)(qrow + a.qt_off + h * DR + st * 32 + s8 * 4);
   }
+  row_sync();
 
-  // ---- phase 1: raw scores
+  // ---- phase 1: raw scores, 8 lanes per target, 8 targets per wave per pass
   bool any_valid = false;
-  for (int base = 0; base < ktot; base += 8) {
+  for (int base = wir * 8; base < ktot; base += 8 * WPR) {
     const int t = base + tg;
     const bool active = t < ktot;
     const int sg = (active && t >= k0) ? 1 : 0;
@@ -72,85 +89,145 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       inv = S.invalid[pi] != 0;
       const float* krow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.k_off;
       const float* erow = S.emb + pi * DR;
+      float4 kq[4], e[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        const float4 kq = *(const float4*)(krow + st * 32 + s8 * 4);
-        const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
-        acc[st] += dot4(kq, qv[st]);
+        kq[st] = *(const float4*)(krow + st * 32 + s8 * 4);
+        e[st] = *(const float4*)(erow + st * 32 + s8 * 4);
+      }
 #pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h] += dot4(e, qtv[h][st]);
+      for (int st = 0; st < 4; ++st) {
+        acc[st] += dot4(kq[st], qv[st]);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h] += dot4(e[st], qtv[h][st]);
       }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]) + qb[h];
     if (active && s8 == 0) {
 #pragma unroll
-      for (int h = 0; h < NH; ++h) p_s[wave][h][t] = acc[h];
-      inv_s[wave][t] = inv ? 1 : 0;
+      for (int h = 0; h < NH; ++h) p_s[rib][h][t] = acc[h];
+      inv_s[rib][t] = inv ? 1 : 0;
     }
     any_valid = any_valid || (__ballot(active && !inv) != 0ull);
   }
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (WPR > 1) {
+    if (any_valid && lane == 0) misc_s[0][0] = 1;  // benign same-value race
+    __syncthreads();
+    any_valid = misc_s[0][0] != 0;
+  } else {
+    __builtin_amdgcn_wave_barrier();
+  }
 
-  // ---- softmax over targets (lanes = targets), scale applied after masking as the reference does
+  // ---- softmax over targets (lanes = targets), scale applied after masking as the reference does.
+  // With WPR > 1 every wave of the row computes the same values; wave 0 publishes them.
+  float prob[NH][2];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
-    float sv[2];
     float m = -INFINITY;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = lane + 64 * q;
-      float s = -INFINITY;
-      if (t < ktot && !(any_valid && inv_s[wave][t] != 0)) s = p_s[wave][h][t] * a.scale;
-      sv[q] = s;
-      m = fmaxf(m, s);
+      float sc = -INFINITY;
+      if (t < ktot && !(any_valid && inv_s[rib][t] != 0)) sc = p_s[rib][h][t] * a.scale;
+      prob[h][q] = sc;
+      m = fmaxf(m, sc);
     }
     m = tbx::wave_max(m);
     float sum = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      sv[q] = (sv[q] == -INFINITY) ? 0.f : expf(sv[q] - m);
-      sum += sv[q];
+      prob[h][q] = (prob[h][q] == -INFINITY) ? 0.f : expf(prob[h][q] - m);
+      sum += prob[h][q];
     }
     sum = tbx::wave_sum(sum);
 #pragma unroll
+    for (int q = 0; q < 2; ++q) prob[h][q] = prob[h][q] / sum;
+  }
+  row_sync();  // every wave has consumed the raw scores
+  if (wir == 0) {
+    // publish probabilities + the compacted list of targets that carry any weight
+    int n_act = 0;
+#pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = lane + 64 * q;
-      if (t < ktot) p_s[wave][h][t] = sv[q] / sum;
+      bool on = false;
+      if (t < ktot) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          p_s[rib][h][t] = prob[h][q];
+          on = on || prob[h][q] != 0.f;
+        }
+      }
+      const unsigned long long mk = __ballot(on);
+      if (on) act_s[rib][n_act + __popcll(mk & ((1ull << lane) - 1ull))] = t;
+      n_act += __popcll(mk);
     }
+    if (lane == 0) misc_s[rib][1] = n_act;
   }
-  __builtin_amdgcn_wave_barrier();
+  row_sync();
+  const int n_act = misc_s[rib][1];
 
-  // ---- phase 2: out = [sum a v | sum a e per head], lanes = channel pairs
+  // ---- phase 2: out = [sum a v | sum a e per head], lanes = channel pairs, 4 targets of loads in flight
   const int c2 = lane * 2;
   const int myh = lane >> 4;
   float2 o = make_float2(0.f, 0.f);
   float2 eb[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) eb[h] = make_float2(0.f, 0.f);
-  for (int t = 0; t < ktot; ++t) {
-    const float a0 = p_s[wave][0][t], a1 = p_s[wave][1][t], a2 = p_s[wave][2][t], a3 = p_s[wave][3][t];
-    if (a0 == 0.f && a1 == 0.f && a2 == 0.f && a3 == 0.f) continue;
-    const int sg = t >= k0 ? 1 : 0;
-    const tbx_attn_seg_t& S = a.seg[sg];
-    const int64_t pi = (int64_t)row * S.k + (sg ? t - k0 : t);
-    const int j = __builtin_amdgcn_readfirstlane(S.idx[pi]);
-    const float* vrow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.v_off;
-    const float2 v = *(const float2*)(vrow + c2);
-    const float2 e = *(const float2*)(S.emb + pi * DR + c2);
-    const float am = myh == 0 ? a0 : (myh == 1 ? a1 : (myh == 2 ? a2 : a3));
-    o.x += am * v.x;
-    o.y += am * v.y;
-    eb[0].x += a0 * e.x; eb[0].y += a0 * e.y;
-    eb[1].x += a1 * e.x; eb[1].y += a1 * e.y;
-    eb[2].x += a2 * e.x; eb[2].y += a2 * e.y;
-    eb[3].x += a3 * e.x; eb[3].y += a3 * e.y;
+  constexpr int UB = 4;
+  for (int i0 = wir * UB; i0 < n_act; i0 += UB * WPR) {
+    float2 v[UB], e[UB];
+    int tt[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + u;
+      tt[u] = -1;
+      v[u] = e[u] = make_float2(0.f, 0.f);
+      if (i < n_act) {
+        const int t = act_s[rib][i];
+        tt[u] = t;
+        const int sg = t >= k0 ? 1 : 0;
+        const tbx_attn_seg_t& S = a.seg[sg];
+        const int64_t pi = (int64_t)row * S.k + (sg ? t - k0 : t);
+        const int j = __builtin_amdgcn_readfirstlane(S.idx[pi]);
+        v[u] = *(const float2*)(S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.v_off + c2);
+        e[u] = *(const float2*)(S.emb + pi * DR + c2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (tt[u] >= 0) {
+        const float a0 = p_s[rib][0][tt[u]], a1 = p_s[rib][1][tt[u]], a2 = p_s[rib][2][tt[u]], a3 = p_s[rib][3][tt[u]];
+        const float am = myh == 0 ? a0 : (myh == 1 ? a1 : (myh == 2 ? a2 : a3));
+        o.x += am * v[u].x;
+        o.y += am * v[u].y;
+        eb[0].x += a0 * e[u].x; eb[0].y += a0 * e[u].y;
+        eb[1].x += a1 * e[u].x; eb[1].y += a1 * e[u].y;
+        eb[2].x += a2 * e[u].x; eb[2].y += a2 * e[u].y;
+        eb[3].x += a3 * e[u].x; eb[3].y += a3 * e[u].y;
+      }
+    }
   }
   float* orow = a.out + (int64_t)row * a.ldo;
-  *(float2*)(orow + c2) = o;
+  if constexpr (WPR > 1) {
+    *(float2*)(&red_s[wir][c2]) = o;
 #pragma unroll
-  for (int h = 0; h < NH; ++h) *(float2*)(orow + D + h * DR + c2) = eb[h];
-  if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+    for (int h = 0; h < NH; ++h) *(float2*)(&red_s[wir][D + h * DR + c2]) = eb[h];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D + NH * DR; c += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) acc += red_s[w][c];
+      orow[c] = acc;
+    }
+    if (threadIdx.x == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+  } else {
+    *(float2*)(orow + c2) = o;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) *(float2*)(orow + D + h * DR + c2) = eb[h];
+    if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+  }
 }
 
 }  // namespace
@@ -187,6 +264,9 @@ extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt
   a.n_src = n_src;
   a.n_seg = n_seg;
   a.scale = 1.0f / sqrtf((float)DH);
-  hipLaunchKernelGGL(knarpe_attn_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.n_rows >= 4096)
+    hipLaunchKernelGGL(knarpe_attn_kernel<1>, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(knarpe_attn_kernel<4>, dim3(a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

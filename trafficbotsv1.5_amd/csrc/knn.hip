@@ -36,13 +36,18 @@ __device__ __forceinline__ void rel_xy(float x1, float y1, float c, float s, flo
   ry = __fadd_rn(__fmul_rn(dx, -s), __fmul_rn(dy, c));
 }
 
-template <int MAXC>
+// WPR = wavefronts per source row: the selection is done by the row's first wave, the K embeddings are split over all
+// WPR waves (4 on the small grids of a few scenes, where the kernel is latency-bound; 1 on large grids).
+template <int MAXC, int WPR>
 __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
-  __shared__ float rel_s[4][64][3];
+  constexpr int RPB = 4 / WPR;
+  __shared__ float rel_s[RPB][64][3];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.n_rows) return;
+  const int wv = threadIdx.x >> 6;
+  const int wave = wv / WPR;  // row slot in the workgroup
+  const int wir = wv % WPR;   // wave within the row
+  const int row = blockIdx.x * RPB + wave;
+  if (row >= a.n_rows) return;  // uniform per row (per workgroup when WPR == 4)
   const int b = row / a.n_src;
   const int bt = b / a.tgt_batch_div;
   const float x1 = a.src_pose[row * 3 + 0], y1 = a.src_pose[row * 3 + 1], yaw1 = a.src_pose[row * 3 + 2];
@@ -51,6 +56,7 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
   const float* tp = a.tgt_pose + (int64_t)bt * a.n_tgt * 3;
   const uint8_t* ti = a.tgt_invalid + (int64_t)bt * a.n_tgt;
 
+  if (wir == 0) {
   float d[MAXC];
   uint32_t taken = 0;
 #pragma unroll
@@ -113,22 +119,26 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
       a.rel_pose[o * 3 + 2] = ryaw;
     }
   }
+  }  // wir == 0
   if (a.emb == nullptr) return;
-  __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this only pins the compiler's ordering
-  for (int t = 0; t < a.k; ++t) {
+  if constexpr (WPR > 1)
+    __syncthreads();
+  else
+    __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this only pins the compiler's ordering
+  for (int t = wir; t < a.k; t += WPR) {
     const float x = rel_s[wave][t][0], y = rel_s[wave][t][1], yaw = rel_s[wave][t][2];
-    float* e = a.emb + ((int64_t)row * a.k + t) * a.pe_dim;
-    for (int ch = lane; ch < a.pe_dim; ch += 64) e[ch] = tbx::pose_emb_channel(ch, a.pe_dim, x, y, yaw, a.fxy, a.fyaw);
+    tbx::pose_emb_write(a.emb + ((int64_t)row * a.k + t) * a.pe_dim, a.pe_dim, x, y, yaw, a.fxy, a.fyaw, lane, 64);
   }
 }
 
 __global__ void pose_embed_kernel(const float* __restrict__ pose3, int64_t n, const float* __restrict__ fxy,
                                   const float* __restrict__ fyaw, int pe_dim, float* __restrict__ out, int ld, int col_off) {
+  const int half = pe_dim >> 1;  // one thread per (pose, argument): writes a cos and a sin channel
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * pe_dim) return;
-  const int64_t i = e / pe_dim;
-  const int c = (int)(e - i * pe_dim);
-  out[i * ld + col_off + c] = tbx::pose_emb_channel(c, pe_dim, pose3[i * 3], pose3[i * 3 + 1], pose3[i * 3 + 2], fxy, fyaw);
+  if (e >= n * half) return;
+  const int64_t i = e / half;
+  const int c = (int)(e - i * half);
+  tbx::pose_emb_write(out + i * ld + col_off, pe_dim, pose3[i * 3], pose3[i * 3 + 1], pose3[i * 3 + 2], fxy, fyaw, c, half);
 }
 
 }  // namespace
@@ -143,14 +153,24 @@ extern "C" int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, 
   if (emb != nullptr && (!freqs_xy || !freqs_yaw || (pe_dim != 64 && pe_dim != 128))) return TBX_ERR_UNSUPPORTED;
   KnnArgs a{src_pose, src_invalid, tgt_pose, tgt_invalid, idx, invalid, rel_pose, emb, freqs_xy, freqs_yaw,
             n_batch * n_src, n_src, n_tgt, tgt_batch_div, k, pe_dim, dist_limit};
-  const dim3 grid((a.n_rows + 3) / 4), block(256);
+  const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool small = a.n_rows < 4096;
+  const dim3 grid(small ? a.n_rows : (a.n_rows + 3) / 4);
+#define TBX_KNN_LAUNCH(MAXC)                                                   \
+  do {                                                                         \
+    if (small)                                                                 \
+      hipLaunchKernelGGL((knn_embed_kernel<MAXC, 4>), grid, block, 0, s, a);   \
+    else                                                                       \
+      hipLaunchKernelGGL((knn_embed_kernel<MAXC, 1>), grid, block, 0, s, a);   \
+  } while (0)
   if (n_tgt <= 128)
-    hipLaunchKernelGGL(knn_embed_kernel<2>, grid, block, 0, s, a);
+    TBX_KNN_LAUNCH(2);
   else if (n_tgt <= 1024)
-    hipLaunchKernelGGL(knn_embed_kernel<16>, grid, block, 0, s, a);
+    TBX_KNN_LAUNCH(16);
   else
-    hipLaunchKernelGGL(knn_embed_kernel<32>, grid, block, 0, s, a);
+    TBX_KNN_LAUNCH(32);
+#undef TBX_KNN_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -158,7 +178,7 @@ extern "C" int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_
                               float* out, int ld_out, int col_off, void* stream) {
   if (!pose3 || !freqs_xy || !freqs_yaw || !out || n <= 0) return TBX_ERR_ARG;
   if ((pe_dim != 64 && pe_dim != 128) || ld_out < col_off + pe_dim) return TBX_ERR_UNSUPPORTED;
-  const int64_t total = n * pe_dim;
+  const int64_t total = n * (pe_dim / 2);
   hipLaunchKernelGGL(pose_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pose3, n,
                      freqs_xy, freqs_yaw, pe_dim, out, ld_out, col_off);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

@@ -66,8 +66,7 @@ __global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) 
     float rx, ry;
     to_local(x0, y0, c, s, hp[w * 3], hp[w * 3 + 1], rx, ry);
     const float ryaw = __fsub_rn(hp[w * 3 + 2], yaw0);
-    for (int ch = lane; ch < a.pe_dim; ch += 64)
-      a.pe[r * a.pe_dim + ch] = tbx::pose_emb_channel(ch, a.pe_dim, rx, ry, ryaw, a.fxy, a.fyaw);
+    tbx::pose_emb_write(a.pe + r * a.pe_dim, a.pe_dim, rx, ry, ryaw, a.fxy, a.fyaw, lane, 64);
     if (lane < 32) {
       float v = 0.f;
       if (lane < 6)

@@ -1,9 +1,9 @@
 // Row-tile chain interpreter (tbx_rowchain): see include/tbx_hip.h for the stage semantics.
 //
-// One 256-thread workgroup (4 wavefronts of 64) owns TILE_ROWS = 16*MT rows. Activations stay in LDS between stages
+// One 512-thread workgroup (8 wavefronts of 64) owns TILE_ROWS = 16*MT rows. Activations stay in LDS between stages
 // (two ping-pong buffers of `ldw` floats per row + a 260-float auxiliary buffer for residuals); weights are streamed
 // straight from L2/HBM into VGPRs once per tile (GEMV-like regime: no reuse across waves, so no LDS staging) and fed
-// to v_mfma_f32_16x16x4_f32, which is an exact fp32 fma chain. Wave w owns output column tiles w, w+4, ...
+// to v_mfma_f32_16x16x4_f32, which is an exact fp32 fma chain. Wave w owns output column tiles w, w+8, ...
 //
 // MFMA operand mapping (guide: cdna_hip_programming.md §3): A lane l supplies A[i=l&15][k=l>>4], B lane l supplies
 // B[k=l>>4][j=l&15], C/D: col = l&15, row = (l>>4)*4 + reg. K is walked in blocks of 16 with the 4 MFMAs of a block
@@ -56,16 +56,31 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT>& t) {
   const int ld = t.l(s.dst);
   const float* src = (const float*)s.p0;
   const int width = (s.flags & TBX_F_ROW_BATCH_MOD) ? s.n : (s.k > s.n ? s.k : s.n);
+  const bool accum = (s.flags & TBX_F_ACCUM) != 0;
+  // fast path: whole float4s, 16-byte aligned on both sides (the common case: 128 / 640 wide activations)
+  if (src != nullptr && !accum && width == s.n && (s.n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 &&
+      ((((uintptr_t)src) & 15) == 0)) {
+    const int w4 = s.n >> 2;
+    for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
+      const int r = e / w4, c4 = e - r * w4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < t.n_valid) v = *(const float4*)(src + row_of(s, t.g0 + r) * (int64_t)s.ld + c4 * 4);
+      *(float4*)(dst + r * ld + c4 * 4) = v;
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < ROWS * width; e += blockDim.x) {
     const int r = e / width, c = e - r * width;
     float v = 0.f;
     if (r < t.n_valid && c < s.n && src != nullptr) v = src[row_of(s, t.g0 + r) * (int64_t)s.ld + c];
-    if ((s.flags & TBX_F_ACCUM) && c < s.n)
+    if (accum && c < s.n)
       dst[r * ld + c] += v;
-    else if (!(s.flags & TBX_F_ACCUM))
+    else if (!accum)
       dst[r * ld + c] = v;
   }
 }
+
+constexpr int CH = 8;  // k-blocks (of 16) whose weight fragments are in flight per wave
 
 template <int MT>
 __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
@@ -76,8 +91,8 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
-  const float* W = (const float*)s.p0;
-  const float* bias = (const float*)s.p1;
+  const float* __restrict__ W = (const float*)s.p0;
+  const float* __restrict__ bias = (const float*)s.p1;
   const int K = s.k, N = s.n, ldw = s.ld;
   const bool wt = (s.flags & TBX_F_WT) != 0;
   const bool accum = (s.flags & TBX_F_ACCUM) != 0;
@@ -99,12 +114,38 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
         acc[m][r] = c0;
       }
     }
-    for (int kb = 0; kb < kblocks; ++kb) {
-      const int k0 = kb * 16 + g * 4;
-      float4 bv;
-      if (fast) {
-        bv = col_ok ? *(const float4*)(W + (int64_t)col * ldw + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
+    if (fast) {
+      // weights streamed straight to VGPRs, CH k-blocks ahead: the L2/HBM latency is paid once per chunk, not per k-block
+      const float* wrow = W + (int64_t)(col_ok ? col : 0) * ldw + g * 4;
+      float4 cur[CH], nxt[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c0 = 0; c0 < kblocks; c0 += CH) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+          nxt[q] = (c0 + CH + q < kblocks) ? *(const float4*)(wrow + (c0 + CH + q) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          if (c0 + q < kblocks) {
+            const int k0 = (c0 + q) * 16 + g * 4;
+            float4 bv = cur[q];
+            if (!col_ok) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+      }
+    } else {
+      for (int kb = 0; kb < kblocks; ++kb) {
+        const int k0 = kb * 16 + g * 4;
         float tmp[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -113,15 +154,14 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
           if (col_ok && kk < K) w = wt ? W[(int64_t)kk * ldw + col] : W[(int64_t)col * ldw + kk];
           tmp[q] = w;
         }
-        bv = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-      }
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) {
+          const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, tmp[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, tmp[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, tmp[2], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, tmp[3], acc[m], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -250,6 +290,14 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT>& t) {
   const int lds_s = t.l(s.src);
   float* out = (float*)s.p0;
   const int n = s.n;
+  if ((n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 && (s.src_col & 3) == 0 && ((((uintptr_t)out) & 15) == 0)) {
+    const int w4 = n >> 2;
+    for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
+      const int r = e / w4, c4 = e - r * w4;
+      if (r < t.n_valid) *(float4*)(out + (t.g0 + r) * (int64_t)s.ld + s.dst_col + c4 * 4) = *(const float4*)(src + r * lds_s + c4 * 4);
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
     const int r = e / n, c = e - r * n;
     if (r < t.n_valid) out[(t.g0 + r) * (int64_t)s.ld + s.dst_col + c] = src[r * lds_s + c];
@@ -257,7 +305,7 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT>& t) {
 }
 
 template <int MT>
-__global__ __launch_bounds__(256) void rowchain_kernel(const RowchainArgs a) {
+__global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   constexpr int ROWS = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   Tile<MT> t;
@@ -353,11 +401,11 @@ extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_r
   if (tile_rows == 16) {
     if (lds_bytes > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)rowchain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(rowchain_kernel<1>, dim3((unsigned)n_tiles), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(rowchain_kernel<1>, dim3((unsigned)n_tiles), dim3(512), lds_bytes, s, a);
   } else {
     if (lds_bytes > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)rowchain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(rowchain_kernel<2>, dim3((unsigned)n_tiles), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(rowchain_kernel<2>, dim3((unsigned)n_tiles), dim3(512), lds_bytes, s, a);
   }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
