@@ -47,6 +47,12 @@ def parse():
     return ap.parse_args()
 
 
+def shard_scenes(n_total: int, rank: int, world: int):
+    """Scene ids simulated by `rank`: contiguous, disjoint, covering (no data-path collective is ever needed)."""
+    per = (n_total + world - 1) // world
+    return list(range(rank * per, min(n_total, (rank + 1) * per)))
+
+
 def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int) -> float:
     """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b with fp32 (b = 4), d = d_rpe = 128."""
     d, b = 128, 4
@@ -96,7 +102,9 @@ def build(tb, args, dev, rank):
     torch.manual_seed(0)
     wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
     wm = wm.to(dev).eval()  # random init of the reference architecture (no checkpoint on the box)
-    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=1000 * rank)
+    # weak scaling: rank r simulates scenes [r*S, (r+1)*S) of the global list (seed = scene id)
+    seeds = shard_scenes(args.scenes * int(os.environ.get("WORLD_SIZE", 1)), rank, int(os.environ.get("WORLD_SIZE", 1)))
+    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=seeds[0])
     full = {**batch, **tb.synthetic.to_history_batch(batch)}
     return wm, full
 

@@ -98,7 +98,9 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
  */
 enum {
   TBX_OP_LOAD = 1,      /* dst[:, dst_col:+n] (=|+=) p0[row_of(g) * ld + c]; cols [n, k) zero-filled (k = padded width) */
-  TBX_OP_LINEAR = 2,    /* dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b); W=p0 [n,k] ld (or [k,n] if TBX_F_WT), b=p1 */
+  TBX_OP_LINEAR = 2,    /* dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b); W=p0 [n,k] ld (or [k,n] if TBX_F_WT), b=p1.
+                         * Grouped (block-diagonal) form: reserved = G > 1, div = (src_col_stride << 16) | dst_col_stride;
+                         * group g uses the next n (or k if WT) weight rows and the next n bias entries. */
   TBX_OP_LAYERNORM = 3, /* dst[:, dst_col:+n] = LN(src[:, src_col:+n]) * p0 + p1, eps = f0 */
   TBX_OP_ADD = 4,       /* dst[:, dst_col:+n] += src[:, src_col:+n] */
   TBX_OP_COPY = 5,      /* dst[:, dst_col:+n]  = src[:, src_col:+n] */

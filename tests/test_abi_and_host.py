@@ -1,0 +1,94 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/tbx_hip.h
+declares, argument validation returns error codes (no compute without a GPU), state-dict layout equals the reference's,
+host-side schedules (teacher forcing masks, scene-centric re-keying) equal the oracle's."""
+import ctypes as C
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trafficbots_oracle as O
+
+
+@pytest.fixture(scope="module")
+def hip(tb):
+    h = import_module("trafficbots_amd.hip")
+    h.load()
+    return h
+
+
+def test_library_exports_every_declared_symbol(hip):
+    lib = hip.load()
+    syms = hip.declared_symbols()
+    assert set(syms) >= {"tbx_version", "tbx_error_string", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd",
+                         "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep", "tbx_map_prep", "tbx_sim_step"}
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.tbx_version() == 1
+    assert lib.tbx_error_string(-2).decode().startswith("shape")
+
+
+def test_argument_validation_returns_codes_without_a_gpu(hip):
+    lib = hip.load()
+    # null pointers / bad sizes are rejected before any launch
+    assert lib.tbx_knn_embed(None, None, None, None, 1, 1, 1, 1, 1, 1.0, None, None, None, None, None, None, 128, None) == -1
+    assert lib.tbx_rowchain(None, 0, 0, 0, 16, 132, None) == -1
+    st = (hip.Stage * 1)(hip.Stage(op=hip.OP_LINEAR, src=0, dst=1, k=128, n=128, ld=128))
+    assert lib.tbx_rowchain(st, 1, 16, 0, 24, 132, None) == -2      # tile_rows must be 16 or 32
+    assert lib.tbx_rowchain(st, 1, 16, 0, 16, 130, None) == -3      # ldw % 4
+    assert lib.tbx_rowchain(st, 1, 16, 0, 16, 132, None) == -1      # LINEAR without a weight pointer
+    assert lib.tbx_sim_step(None, None) == -1
+    with pytest.raises(RuntimeError):
+        hip.pose_embed(torch.zeros(4, 3), torch.zeros(32), torch.zeros(64), 128)  # CPU tensor: no fallback path
+
+
+def test_state_dict_layout_equals_reference(tb, golden_dir):
+    M = import_module("trafficbots_amd.models.traffic_bots")
+    model = M.TrafficBots(**tb.config.default_model_cfg())
+    want = dict(l.split(" ", 1) for l in (golden_dir / "state_dict_keys.txt").read_text().strip().split("\n"))
+    got = {k: str(tuple(v.shape)) for k, v in model.state_dict().items()}
+    assert got == want
+    assert sum(p.numel() for p in model.parameters()) == 10657094
+    # a reference-shaped (Lightning-prefixed) checkpoint loads strictly
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    ckpt = {"model." + k: v for k, v in model.state_dict().items()}
+    missing, unexpected = wm.load_state_dict(ckpt, strict=True)
+    assert not missing and not unexpected
+    opt, sch = wm.configure_optimizers()
+    assert len(opt[0].param_groups) == 2 and opt[0].param_groups[0]["lr"] == 2e-4
+
+
+def test_host_schedules_equal_oracle(tb):
+    batch = tb.synthetic.make_scene(2, 8, 64, 8, seed=3)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    SC = import_module("trafficbots_amd.data_modules.scene_centric").SceneCentricPreProcessing
+    for training in (True, False):
+        pp = SC(time_step_current=10, tl_mode="lane", navi_mode="dest", dropout_p_history=-1, data_size=tb.synthetic.DATA_SIZE)
+        pp.train(training)
+        b = pp({k: v.clone() for k, v in full.items()})
+        bo = O.scene_centric(full, training=training)
+        for k in bo:
+            if k.startswith(("sc/", "gt/", "ref/")):
+                assert torch.equal(b[k], bo[k]), k
+    TF = import_module("trafficbots_amd.utils.teacher_forcing").TeacherForcing
+    for cfg in (dict(step_spawn_agent=10, step_warm_start=10), dict(step_spawn_agent=90, step_warm_start=10),
+                dict(step_spawn_agent=0, step_warm_start=-1)):
+        tf = TF(**cfg)
+        tf.init(bo["gt/ag_valid"], bo["gt/ag_pose"], bo["gt/ag_motion"], bo["gt/tl_state"], 0)
+        assert torch.equal(tf.ag_teacher_forcing, O.Sim.teacher_forcing_mask(bo["gt/ag_valid"], **cfg))
+        ag, tl = tf.get(5, None, None, None)
+        assert torch.equal(ag["valid"], tf.ag_teacher_forcing[:, :, 5]) and bool(tl["valid"].all())
+        ag, tl = tf.get(200, None, None, None)
+        assert not bool(ag["valid"].any()) and not bool(tl["valid"].any())
+
+
+def test_chain_program_encoding(hip):
+    """The Chain builder encodes strides / groups / flags the way include/tbx_hip.h documents (host logic only)."""
+    ch = hip.Chain(16, 132)
+    w = torch.zeros(256, 128)
+    ch._add(op=hip.OP_COPY, src=0, dst=1, n=4)
+    st = ch.stages[0]
+    assert (st.op, st.src, st.dst, st.n) == (hip.OP_COPY, 0, 1, 4)
+    assert C.sizeof(hip.Stage) == 72 and C.sizeof(hip.AttnSeg) == 56

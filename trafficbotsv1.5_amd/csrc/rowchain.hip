@@ -1,9 +1,9 @@
 // Row-tile chain interpreter (tbx_rowchain): see include/tbx_hip.h for the stage semantics.
 //
-// One 512-thread workgroup (8 wavefronts of 64) owns TILE_ROWS = 16*MT rows. Activations stay in LDS between stages
+// One workgroup of 16 wavefronts (16-row tiles) or 8 wavefronts (32-row tiles) owns TILE_ROWS = 16*MT rows. Activations stay in LDS between stages
 // (two ping-pong buffers of `ldw` floats per row + a 260-float auxiliary buffer for residuals); weights are streamed
 // straight from L2/HBM into VGPRs once per tile (GEMV-like regime: no reuse across waves, so no LDS staging) and fed
-// to v_mfma_f32_16x16x4_f32, which is an exact fp32 fma chain. Wave w owns output column tiles w, w+8, ...
+// to v_mfma_f32_16x16x4_f32, which is an exact fp32 fma chain. Wave w owns output column tiles w, w+16, ...
 //
 // MFMA operand mapping (guide: cdna_hip_programming.md §3): A lane l supplies A[i=l&15][k=l>>4], B lane l supplies
 // B[k=l>>4][j=l&15], C/D: col = l&15, row = (l>>4)*4 + reg. K is walked in blocks of 16 with the 4 MFMAs of a block
@@ -82,27 +82,57 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT>& t) {
 
 constexpr int CH = 8;  // k-blocks (of 16) whose weight fragments are in flight per wave
 
+// LINEAR (optionally grouped: `reserved` = G groups, group g reads src columns src_col + g*src_stride, writes
+// dst_col + g*dst_stride, with src_stride / dst_stride packed in `div` as (src << 16 | dst); its weight block is the next
+// n rows (or k rows if TBX_F_WT) after the previous group's, its bias the next n entries).
 template <int MT>
 __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwave = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const float* src = t.b(s.src) + s.src_col;
-  float* dst = t.b(s.dst) + s.dst_col;
+  const float* src0 = t.b(s.src) + s.src_col;
+  float* dst0 = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
-  const float* __restrict__ W = (const float*)s.p0;
-  const float* __restrict__ bias = (const float*)s.p1;
+  const float* __restrict__ W0 = (const float*)s.p0;
+  const float* __restrict__ bias0 = (const float*)s.p1;
   const int K = s.k, N = s.n, ldw = s.ld;
+  const int G = s.reserved > 0 ? s.reserved : 1;
+  const int gs_src = (s.div >> 16) & 0xffff, gs_dst = s.div & 0xffff;
   const bool wt = (s.flags & TBX_F_WT) != 0;
   const bool accum = (s.flags & TBX_F_ACCUM) != 0;
-  const bool fast = !wt && (K % 16 == 0) && (ldw % 4 == 0) && ((((uintptr_t)W) & 15) == 0);
+  const bool fast = (K % 16 == 0) && (wt || ((ldw % 4 == 0) && ((((uintptr_t)W0) & 15) == 0)));
   const int n_tiles = (N + 15) / 16;
   const int kblocks = (K + 15) / 16;
-  for (int nt = wave; nt < n_tiles; nt += nwave) {
-    const int n0 = nt * 16;
+  const int tiles_total = G * n_tiles;
+
+  const bool fast_wt = fast && wt && kblocks <= 4;
+  const bool fast_n = fast && !wt;
+  // row pointer (already offset to this lane's 4-float slice) of tile ti in the normal [n,k] layout; tiles past the end
+  // and columns past n are clamped to a valid row (their products are zeroed at use / never stored)
+  auto wrow_of = [&](int ti) -> const float* {
+    ti = ti < tiles_total ? ti : tiles_total - 1;
+    const int grp = ti / n_tiles;
+    int col = (ti - grp * n_tiles) * 16 + j;
+    col = col < N ? col : N - 1;
+    return W0 + ((int64_t)grp * N + col) * ldw + g * 4;
+  };
+
+  float4 cur[CH], nxt[CH];
+  const float* wrow = nullptr;
+  if (fast_n) {
+    wrow = wrow_of(wave);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int ti = wave; ti < tiles_total; ti += nwave) {
+    const int grp = ti / n_tiles;
+    const int n0 = (ti - grp * n_tiles) * 16;
     const int col = n0 + j;
     const bool col_ok = col < N;
+    const float* src = src0 + grp * gs_src;
+    float* dst = dst0 + grp * gs_dst;
+    const float* bias = bias0 != nullptr ? bias0 + grp * N : nullptr;
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -114,16 +144,16 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
         acc[m][r] = c0;
       }
     }
-    if (fast) {
-      // weights streamed straight to VGPRs, CH k-blocks ahead: the L2/HBM latency is paid once per chunk, not per k-block
-      const float* wrow = W + (int64_t)(col_ok ? col : 0) * ldw + g * 4;
-      float4 cur[CH], nxt[CH];
-#pragma unroll
-      for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fast_n) {
+      // weights go straight to VGPRs, CH k-blocks ahead and across tile boundaries: the L2/HBM latency is paid once
+      // per chunk and overlaps the previous chunk's MFMAs
+      const float* wnext = wrow_of(ti + nwave);
       for (int c0 = 0; c0 < kblocks; c0 += CH) {
+        const bool last = c0 + CH >= kblocks;
+        const float* pn = last ? wnext : wrow + (c0 + CH) * 16;
+        const int kb_left = last ? kblocks : kblocks - (c0 + CH);
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-          nxt[q] = (c0 + CH + q < kblocks) ? *(const float4*)(wrow + (c0 + CH + q) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < CH; ++q) nxt[q] = (q < kb_left) ? *(const float4*)(pn + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
           if (c0 + q < kblocks) {
@@ -143,7 +173,33 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
 #pragma unroll
         for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
       }
+      wrow = wnext;
+    } else if (fast_wt) {
+      // [k, n] layout with a short K (the per-head rpe fold, K = 32): every k-block's 4 rows are fetched up front
+      const float* w = W0 + ((int64_t)grp * K + g * 4) * ldw + (col_ok ? col : 0);
+      float4 bw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bw[q] = (q < kblocks) ? make_float4(w[(q * 16) * ldw], w[(q * 16 + 1) * ldw], w[(q * 16 + 2) * ldw], w[(q * 16 + 3) * ldw])
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < kblocks) {
+          const int k0 = q * 16 + g * 4;
+          float4 bv = bw[q];
+          if (!col_ok) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+          }
+        }
+      }
     } else {
+      const float* W = W0 + (int64_t)grp * (wt ? K : N) * ldw;
       for (int kb = 0; kb < kblocks; ++kb) {
         const int k0 = kb * 16 + g * 4;
         float tmp[4];
@@ -170,11 +226,11 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT>& t) {
       for (int r = 0; r < 4; ++r) {
         float v = acc[m][r];
         if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
-        // columns of the last partial tile beyond n are zero-filled (unless accumulating) so that the next stage may
-        // read a K padded to 16
+        // columns of the last partial tile beyond n are zero-filled (unless accumulating or grouped) so that the next
+        // stage may read a K padded to 16
         if (col_ok)
           dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
-        else if (!accum && col < lds_d - s.dst_col)
+        else if (!accum && G == 1 && col < lds_d - s.dst_col)
           dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
       }
     }
@@ -305,7 +361,7 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT>& t) {
 }
 
 template <int MT>
-__global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
+__global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const RowchainArgs a) {
   constexpr int ROWS = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   Tile<MT> t;
@@ -358,16 +414,19 @@ int check_stage(const tbx_stage_t& s, int ldw, int tile_rows) {
   }
   if (s.op == TBX_OP_LINEAR) {
     if (s.k <= 0 || s.p0 == nullptr || s.ld <= 0) return TBX_ERR_ARG;
-    if (s.src_col % 4 != 0) return TBX_ERR_ALIGN;
-    if (s.src == s.dst) {  // in-place only on disjoint column ranges
-      const int kw = ((s.k + 15) / 16) * 16;
-      const int nw = ((s.n + 15) / 16) * 16;
-      if (!(s.dst_col >= s.src_col + kw || s.src_col >= s.dst_col + nw)) return TBX_ERR_UNSUPPORTED;
-    }
+    const int G = s.reserved > 0 ? s.reserved : 1;
+    const int gs_src = (s.div >> 16) & 0xffff, gs_dst = s.div & 0xffff;
+    if (s.src_col % 4 != 0 || (G > 1 && gs_src % 4 != 0)) return TBX_ERR_ALIGN;
+    const int kw = ((s.k + 15) / 16) * 16;
+    const int nw = ((s.n + 15) / 16) * 16;
+    const int src_hi = s.src_col + (G - 1) * gs_src + kw, dst_hi = s.dst_col + (G - 1) * gs_dst + (G > 1 ? s.n : nw);
+    if (G > 1 && (s.n % 16 != 0)) return TBX_ERR_UNSUPPORTED;
+    if (src_hi > buf_ld(s.src) || s.dst_col + (G - 1) * gs_dst + s.n > buf_ld(s.dst)) return TBX_ERR_UNSUPPORTED;
+    if (s.src == s.dst && !(s.dst_col >= src_hi || s.src_col >= dst_hi)) return TBX_ERR_UNSUPPORTED;  // in place: disjoint only
   }
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
-  if ((s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;
+  if (s.op != TBX_OP_LINEAR && (s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;
   if ((s.flags & TBX_F_ROW_BATCH_MOD) && s.k <= 0) return TBX_ERR_ARG;
   (void)tile_rows;
   return TBX_OK;
@@ -401,7 +460,7 @@ extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_r
   if (tile_rows == 16) {
     if (lds_bytes > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)rowchain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(rowchain_kernel<1>, dim3((unsigned)n_tiles), dim3(512), lds_bytes, s, a);
+    hipLaunchKernelGGL(rowchain_kernel<1>, dim3((unsigned)n_tiles), dim3(1024), lds_bytes, s, a);
   } else {
     if (lds_bytes > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)rowchain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -29,9 +29,8 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     w_in, b_in = attn.in_proj_weight, attn.in_proj_bias
     nq = 3 * D if with_kv else D
     ch.linear(src_buf, src_col, dst_buf, dst_col, w_in[:nq], b_in[:nq])
-    w_rpe = attn.linear_rpe.weight
-    for h in range(NH):  # qt_h = q_h @ W_rpe_k[h*32:(h+1)*32, :]
-        ch.linear(dst_buf, dst_col + h * DH, dst_buf, dst_col + nq + h * D, w_rpe[h * DH:(h + 1) * DH], wt=True)
+    # qt_h = q_h @ W_rpe_k[h*32:(h+1)*32, :]  for the 4 heads as one block-diagonal stage
+    ch.linear(dst_buf, dst_col, dst_buf, dst_col + nq, attn.linear_rpe.weight[:D], wt=True, groups=NH, src_stride=DH, dst_stride=D)
     return nq + NH * D
 
 
@@ -39,10 +38,9 @@ def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tenso
     """x += out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), zero for rows without a valid target.
     attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233."""
     ch.load(obuf, BUF0, 0, n=O_LD)
-    w_rpe, b_rpe = attn.linear_rpe.weight, attn.linear_rpe.bias
-    for h in range(NH):
-        ch.linear(BUF0, D + h * D, BUF0, h * DH, w_rpe[D + h * DH:D + (h + 1) * DH], b_rpe[D + h * DH:D + (h + 1) * DH],
-                  accum=True)
+    # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
+    ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
+              dst_stride=DH)
     ch.linear(BUF0, 0, AUX, 0, attn.out_proj_weight, attn.out_proj_bias)
     ch.rowmask(AUX, 0, D, mask=row_no_valid)
     ch.add(AUX, 0, x_buf, 0, D)

@@ -240,13 +240,17 @@ class Chain:
     def zero(self, dst, dst_col, n):
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
 
-    def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False):
-        """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt)."""
+    def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False, groups=1,
+               src_stride=0, dst_stride=0):
+        """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt).
+        groups > 1: block-diagonal; weight holds the groups' blocks stacked along dim 0, group g reads
+        src_col + g*src_stride and writes dst_col + g*dst_stride."""
         w = self._rows2d(weight)
-        n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
+        n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias)
+                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias,
+                         reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
 
     def layernorm(self, src, src_col, dst, dst_col, weight, bias, eps=1e-5):
         return self._add(op=OP_LAYERNORM, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=weight.shape[0], f0=eps,
