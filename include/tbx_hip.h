@@ -84,6 +84,16 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
                         int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo,
                         uint8_t* row_no_valid, void* stream);
 
+/* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
+ *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
+ *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)
+ *   dkv[i] : gradient of seg[i].kv, same shape / leading dimension; dK, dV are ACCUMULATED with atomicAdd (zero it first)
+ *   dbias_k [128]: accumulated gradient of rpe_k_bias.
+ * Probabilities are recomputed from the forward inputs; the pose embeddings carry no gradient (utils/rpe.py:7). */
+int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
+                        const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo, float* dqbuf,
+                        float* const* dkv /* host array of n_seg device pointers */, float* dbias_k, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
  * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per

@@ -355,6 +355,29 @@ def gen_model(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_roll_steps, train_fixture):
             out["gradnorm_" + k] = np.float64(v) ** 0.5
         no_grad = sorted(k for k, p in wm_t.model.named_parameters() if p.grad is None)
         (OUT / "params_without_grad.txt").write_text("\n".join(no_grad) + "\n")
+        # same step with the action head's output layer scaled by 0.02 ("damped"): the closed loop is then not chaotic,
+        # so implementations with a different fp32 summation order can be compared tightly on loss AND gradients
+        wm_t.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for k, p in wm_t.model.named_parameters():
+                if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                    p.mul_(0.02)
+        torch.manual_seed(7)
+        loss = wm_t.training_step({k: v.clone() for k, v in batch.items()}, 0)
+        loss.backward()
+        out["dtrain_loss"] = loss.detach()
+        for k, v in wm_t.logged.items():
+            out["dtrain_" + k.split("/")[1]] = v.detach()
+        gn = {}
+        for k, p in wm_t.model.named_parameters():
+            top = k.split(".")[0]
+            if p.grad is not None:
+                gn[top] = gn.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+        for k, v in gn.items():
+            out["dgradnorm_" + k] = np.float64(v) ** 0.5
+        for k in ("ag_encoder.tf_ag2agmptl.layers.3.attn.linear_rpe.weight", "mp_encoder.tf_mp2mp.layers.0.attn.in_proj_weight",
+                  "tl_encoder.tf_tl2tlmp.layers.1.attn_src.out_proj_weight", "latent_encoder.ag_encoder_post.input_encoder.mlp.fc_layers.0.weight"):
+            out["dgrad_" + k] = dict(wm_t.model.named_parameters())[k].grad[:8, :16]
     npz(f"model_{tag}.npz", **out)
 
 

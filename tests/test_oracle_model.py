@@ -87,10 +87,18 @@ def test_model_c2_eval(tb, golden_dir):
     check_eval(tb, g, cfg, P, (64, 1024, 128), 14, dict(rtol=2e-4, atol=2e-5))
 
 
-def test_model_c1_training_step(tb, golden_dir):
-    """Row 19/20: loss dict and per-module gradient norms of one training_step with every RNG site neutralised."""
+@pytest.mark.parametrize("damped", [False, True])
+def test_model_c1_training_step(tb, golden_dir, damped):
+    """Row 19/20: loss dict and per-module gradient norms of one training_step with every RNG site neutralised
+    (also with the action head damped by 0.02: the non-chaotic variant the GPU path is compared on)."""
     g = np.load(golden_dir / "model_c1.npz")
+    pre = "dtrain_" if damped else "train_"
+    gpre = "dgradnorm_" if damped else "gradnorm_"
     cfg, P = build(tb, 4, no_dropout=True)
+    if damped:
+        for k in P:
+            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                P[k] = P[k] * 0.02
     trainable = P.pop("__trainable__")
     P = {k: (v.requires_grad_(True) if k in trainable else v) for k, v in P.items()}
     scfg = tb.config.default_sim_cfg(p_training_rollout_prior=0.0)
@@ -102,15 +110,18 @@ def test_model_c1_training_step(tb, golden_dir):
     torch.manual_seed(7)
     out = sim.training_step(batch)
     for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss"):
-        torch.testing.assert_close(out[k].detach(), _t(g["train_" + k]), rtol=2e-4, atol=1e-5)
+        torch.testing.assert_close(out[k].detach(), _t(g[pre + k]), rtol=2e-4, atol=1e-5)
     out["loss"].backward()
     gn = {}
     for k, p in P.items():
         if p.requires_grad and p.grad is not None:
             gn[k.split(".")[0]] = gn.get(k.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
     for top, v in gn.items():
-        ref = float(g["gradnorm_" + top])
+        ref = float(g[gpre + top])
         assert abs(v**0.5 - ref) <= 2e-3 * max(ref, 1e-6), (top, v**0.5, ref)
+    if damped:
+        for k in [x for x in g.files if x.startswith("dgrad_")]:
+            torch.testing.assert_close(P[k[6:]].grad[:8, :16], _t(g[k]), rtol=1e-3, atol=1e-6)
     dead = set((golden_dir / "params_without_grad.txt").read_text().split())
     for k, p in P.items():
         if p.requires_grad and k in dead:

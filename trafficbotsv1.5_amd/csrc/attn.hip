@@ -270,3 +270,292 @@ extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt
     hipLaunchKernelGGL(knarpe_attn_kernel<4>, dim3(a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
+
+// =====================================================================================================================
+// Backward of the fused KNARPE attention (training). Same factorised math as the forward:
+//   s[h,t] = q_h.(k_h[idx_t] + bk_h) + qt_h.e_t ;  a = softmax(s * scale) (masked) ;  out = [sum_t a v_h | sum_t a e_t]
+// Given dout = [dO (128) | dE (4 x 128)] per row it produces
+//   dq, dqt (written to dqbuf at q_off / qt_off), dK / dV scattered with atomicAdd into the K/V-table-shaped gradient
+//   of each segment, and d(rpe_k_bias) (atomicAdd, 128 floats).
+// The pose embeddings carry no gradient (relative poses are computed under no_grad in the reference, utils/rpe.py:7).
+// One wavefront per source row; probabilities are recomputed (nothing but the inputs is saved by the forward).
+namespace {
+
+struct AttnBwdArgs {
+  AttnArgs f;            // forward arguments (qbuf, segs, ...); f.out is unused
+  const float* dout;     // [rows, ldo] = dO | dE
+  float* dqbuf;          // [rows, ldq]: dq at q_off, dqt at qt_off (overwritten)
+  float* dkv[2];         // per segment, same [.., ld_kv] layout as seg.kv (accumulated)
+  float* dbias_k;        // [128] (accumulated)
+};
+
+__global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs b) {
+  const AttnArgs& a = b.f;
+  __shared__ float p_s[4][NH][KMAX];   // probabilities a[h,t]
+  __shared__ float d_s[4][NH][KMAX];   // da[h,t], then dS[h,t]
+  __shared__ uint8_t inv_s[4][KMAX];
+  const int lane = threadIdx.x & 63;
+  const int rib = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + rib;
+  if (row >= a.n_rows) return;
+  const int bidx = row / a.n_src;
+  const int k0 = a.seg[0].k;
+  const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
+  const int s8 = lane & 7, tg = lane >> 3;
+  const float* qrow = a.qbuf + (int64_t)row * a.ldq;
+  float4 qv[NH], bkv[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
+    bkv[h] = *(const float4*)(a.rpe_k_bias + h * DH + s8 * 4);
+  }
+  // ---- recompute raw scores
+  bool any_valid = false;
+  {
+    float4 qtv[NH][4];
+    float qb[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      qb[h] = tbx::group8_sum(dot4(qv[h], bkv[h]));
+#pragma unroll
+      for (int st = 0; st < 4; ++st) qtv[h][st] = *(const float4*)(qrow + a.qt_off + h * DR + st * 32 + s8 * 4);
+    }
+    for (int base = 0; base < ktot; base += 8) {
+      const int t = base + tg;
+      const bool active = t < ktot;
+      const int sg = (active && t >= k0) ? 1 : 0;
+      const tbx_attn_seg_t& S = a.seg[sg];
+      const int kk = sg ? t - k0 : t;
+      float acc[NH] = {0.f, 0.f, 0.f, 0.f};
+      bool inv = true;
+      if (active) {
+        const int64_t pi = (int64_t)row * S.k + kk;
+        const int j = S.idx[pi];
+        inv = S.invalid[pi] != 0;
+        const float* krow = S.kv + ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.k_off;
+        const float* erow = S.emb + pi * DR;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const float4 kq = *(const float4*)(krow + st * 32 + s8 * 4);
+          const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
+          acc[st] += dot4(kq, qv[st]);
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[h] += dot4(e, qtv[h][st]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]) + qb[h];
+      if (active && s8 == 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) p_s[rib][h][t] = acc[h];
+        inv_s[rib][t] = inv ? 1 : 0;
+      }
+      any_valid = any_valid || (__ballot(active && !inv) != 0ull);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- softmax (probabilities back into p_s)
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    float sv[2];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = lane + 64 * q;
+      float sc = -INFINITY;
+      if (t < ktot && !(any_valid && inv_s[rib][t] != 0)) sc = p_s[rib][h][t] * a.scale;
+      sv[q] = sc;
+      m = fmaxf(m, sc);
+    }
+    m = tbx::wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sv[q] = (sv[q] == -INFINITY) ? 0.f : expf(sv[q] - m);
+      sum += sv[q];
+    }
+    sum = tbx::wave_sum(sum);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = lane + 64 * q;
+      if (t < ktot) p_s[rib][h][t] = sv[q] / sum;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- pass B: da[h,t] = dO_h . v_h[idx_t] + dE_h . e_t
+  const float* drow = b.dout + (int64_t)row * a.ldo;
+  float4 dov[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) dov[h] = *(const float4*)(drow + h * DH + s8 * 4);
+  {
+    float4 dev[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) dev[h][st] = *(const float4*)(drow + D + h * DR + st * 32 + s8 * 4);
+    for (int base = 0; base < ktot; base += 8) {
+      const int t = base + tg;
+      const bool active = t < ktot;
+      const int sg = (active && t >= k0) ? 1 : 0;
+      const tbx_attn_seg_t& S = a.seg[sg];
+      const int kk = sg ? t - k0 : t;
+      float acc[NH] = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const int64_t pi = (int64_t)row * S.k + kk;
+        const int j = S.idx[pi];
+        const float* vrow = S.kv + ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.v_off;
+        const float* erow = S.emb + pi * DR;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const float4 v = *(const float4*)(vrow + st * 32 + s8 * 4);
+          const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
+          acc[st] += dot4(v, dov[st]);
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[h] += dot4(e, dev[h][st]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]);
+      if (active && s8 == 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) d_s[rib][h][t] = acc[h];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- softmax backward: dS = a (da - sum_t a da) * scale
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = lane + 64 * q;
+      if (t < ktot) part += p_s[rib][h][t] * d_s[rib][h][t];
+    }
+    const float dotv = tbx::wave_sum(part);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = lane + 64 * q;
+      if (t < ktot) d_s[rib][h][t] = p_s[rib][h][t] * (d_s[rib][h][t] - dotv) * a.scale;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- pass C: dq, dqt, d bias_k (registers, reduced over the 8 target slots at the end); dK, dV scattered
+  float4 dq[NH], dbk[NH], dqt[NH][4];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    dq[h] = dbk[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) dqt[h][st] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int base = 0; base < ktot; base += 8) {
+    const int t = base + tg;
+    if (t >= ktot) continue;
+    const int sg = t >= k0 ? 1 : 0;
+    const tbx_attn_seg_t& S = a.seg[sg];
+    const int64_t pi = (int64_t)row * S.k + (sg ? t - k0 : t);
+    const int j = S.idx[pi];
+    const int64_t trow = ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv;
+    const float* krow = S.kv + trow + S.k_off;
+    const float* erow = S.emb + pi * DR;
+    float* dk = b.dkv[sg] + trow + S.k_off;
+    float* dv = b.dkv[sg] + trow + S.v_off;
+    float ds[NH], pa[NH];
+    bool any = false;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      ds[h] = d_s[rib][h][t];
+      pa[h] = p_s[rib][h][t];
+      any = any || ds[h] != 0.f || pa[h] != 0.f;
+    }
+    if (!any) continue;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {  // st doubles as the head of the K/V channel block
+      const float4 kq = *(const float4*)(krow + st * 32 + s8 * 4);
+      const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
+      const float g = ds[st];
+      dq[st].x += g * (kq.x + bkv[st].x); dq[st].y += g * (kq.y + bkv[st].y);
+      dq[st].z += g * (kq.z + bkv[st].z); dq[st].w += g * (kq.w + bkv[st].w);
+      dbk[st].x += g * qv[st].x; dbk[st].y += g * qv[st].y; dbk[st].z += g * qv[st].z; dbk[st].w += g * qv[st].w;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        dqt[h][st].x += ds[h] * e.x; dqt[h][st].y += ds[h] * e.y; dqt[h][st].z += ds[h] * e.z; dqt[h][st].w += ds[h] * e.w;
+      }
+      const int c0 = st * 32 + s8 * 4;
+      atomicAdd(dk + c0 + 0, g * qv[st].x); atomicAdd(dk + c0 + 1, g * qv[st].y);
+      atomicAdd(dk + c0 + 2, g * qv[st].z); atomicAdd(dk + c0 + 3, g * qv[st].w);
+      const float pv = pa[st];
+      atomicAdd(dv + c0 + 0, pv * dov[st].x); atomicAdd(dv + c0 + 1, pv * dov[st].y);
+      atomicAdd(dv + c0 + 2, pv * dov[st].z); atomicAdd(dv + c0 + 3, pv * dov[st].w);
+    }
+  }
+  // reduce over the 8 target slots (lanes with equal s8)
+  auto red4 = [](float4 v) {
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
+      v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+    }
+    return v;
+  };
+  float* dqrow = b.dqbuf + (int64_t)row * a.ldq;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const float4 r = red4(dq[h]);
+    const float4 rb = red4(dbk[h]);
+    if (tg == 0) {
+      *(float4*)(dqrow + a.q_off + h * DH + s8 * 4) = r;
+      float* db = b.dbias_k + h * DH + s8 * 4;
+      atomicAdd(db + 0, rb.x); atomicAdd(db + 1, rb.y); atomicAdd(db + 2, rb.z); atomicAdd(db + 3, rb.w);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const float4 rt = red4(dqt[h][st]);
+      if (tg == 0) *(float4*)(dqrow + a.qt_off + h * DR + st * 32 + s8 * 4) = rt;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
+                                   float* const* dkv, float* dbias_k, void* stream) {
+  if (!qbuf || !rpe_k_bias || !segs || !dout || !dqbuf || !dkv || !dbias_k || n_batch <= 0 || n_src <= 0) return TBX_ERR_ARG;
+  if (n_seg < 1 || n_seg > 2 || ldo < D + NH * DR) return TBX_ERR_UNSUPPORTED;
+  if ((ldq % 4) || (q_off % 4) || (qt_off % 4) || (ldo % 4) || (((uintptr_t)qbuf) & 15) || (((uintptr_t)dout) & 15) ||
+      (((uintptr_t)dqbuf) & 15) || (((uintptr_t)rpe_k_bias) & 15))
+    return TBX_ERR_ALIGN;
+  AttnBwdArgs b;
+  int ktot = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const tbx_attn_seg_t& s = segs[i];
+    if (!s.kv || !s.idx || !s.invalid || !s.emb || !dkv[i] || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
+    if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (((uintptr_t)s.emb) & 15)) return TBX_ERR_ALIGN;
+    ktot += s.k;
+    b.f.seg[i] = s;
+    b.dkv[i] = dkv[i];
+  }
+  if (n_seg == 1) {
+    b.f.seg[1] = b.f.seg[0];
+    b.dkv[1] = b.dkv[0];
+  }
+  if (ktot > KMAX) return TBX_ERR_UNSUPPORTED;
+  b.f.qbuf = qbuf;
+  b.f.rpe_k_bias = rpe_k_bias;
+  b.f.out = nullptr;
+  b.f.row_no_valid = nullptr;
+  b.f.ldq = ldq;
+  b.f.q_off = q_off;
+  b.f.qt_off = qt_off;
+  b.f.ldo = ldo;
+  b.f.n_rows = n_batch * n_src;
+  b.f.n_src = n_src;
+  b.f.n_seg = n_seg;
+  b.f.scale = 1.0f / sqrtf((float)DH);
+  b.dout = dout;
+  b.dqbuf = dqbuf;
+  b.dbias_k = dbias_k;
+  hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

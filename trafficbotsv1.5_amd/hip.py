@@ -74,13 +74,15 @@ def load():
     lib.tbx_knn_embed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.tbx_pose_embed.argtypes = [vp, i64, vp, vp, i32, vp, i32, i32, vp]
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp]
+    lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
+                                        C.POINTER(C.c_void_p), vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                    i32, vp, vp, vp]
     lib.tbx_tl_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
-    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -163,6 +165,16 @@ def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: 
                                     n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
                                     _ptr(row_no_valid, torch.uint8), stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd")
+
+
+def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
+                    dkv: Sequence[torch.Tensor], dbias_k):
+    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
+    dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
+    rc = load().tbx_knarpe_attn_bwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+                                    n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
+                                    _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), stream_ptr())
+    _check(rc, "tbx_knarpe_attn_bwd")
 
 
 def agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,

@@ -165,9 +165,15 @@ class WaymoMotion(LightningModule):
 
     # ------------------------------------------------------------------ training
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int):
-        raise NotImplementedError(
-            "training_step (waymo_motion.py:313-385) needs the backward kernels of tbx_rowchain / tbx_knarpe_attn, which are "
-            "the next row of the build plan (DESIGN.md §6); there is deliberately no autograd fallback through PyTorch ops.")
+        """waymo_motion.py:313-385. KNARPE attention forward/backward, KNN and embeddings are HIP kernels; projections
+        are library GEMMs; see train_graph.py for what is (not yet) fused."""
+        from .. import train_graph
+
+        out = train_graph.training_step(self, batch)
+        for k, v in out.items():
+            self.log(f"training/{k}", v, on_step=True)
+        self.last_metrics = out
+        return out["loss"]
 
     def configure_optimizers(self):
         """waymo_motion.py:820-838: AdamW, separate lr group for navi_predictor, StepLR."""

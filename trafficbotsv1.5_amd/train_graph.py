@@ -1,0 +1,451 @@
+"""Differentiable (training) schedule of the hot path on the GPU.
+
+Forward AND backward of the KNARPE attention are hand-written HIP kernels (tbx_knarpe_attn_fwd / _bwd) behind
+`KnarpeAttnFn`; K-nearest selection, pose embeddings and feature preparation are the same HIP kernels as in inference
+(no gradient flows through them: the reference computes them under no_grad, utils/rpe.py:7,40,61). The dense
+projections are plain library GEMMs (`F.linear` -> hipBLASLt) and the LayerNorm / ReLU / masking / max-pool glue is
+elementwise torch on the device, so autograd provides their backward. Fusing those into chain-backward kernels is the
+next step; the formulation (K/V projected before the gather, linear_rpe folded) is identical to the
+inference engine, so both are checked against the same oracle.
+
+Everything takes the reference-named nn.Modules as parameter containers (same state dict as inference).
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.distributions import Categorical, Independent, Normal, kl_divergence
+
+from . import hip
+from .hip import Seg
+from .models.modules.distributions import DestCategorical, DiagGaussian
+
+D, NH, DH = 128, 4, 32
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class KnarpeAttnFn(torch.autograd.Function):
+    """out [rows, 640] = [sum_t a v | sum_t a e (4 heads)], flag [rows] (no valid target) for 1-2 target segments."""
+
+    @staticmethod
+    def forward(ctx, q, qt, bias_k, n, S, meta, *kvs):
+        # meta: list of (idx, invalid, emb, n_tgt, batch_div) per segment; kvs: K|V tables [tokens, 256]
+        qbuf = torch.cat([q, qt], 1).contiguous()
+        kvs = [kv.contiguous() for kv in kvs]
+        segs = [Seg(kv, 0, D, m[3], m[0], m[1], m[2], m[4]) for kv, m in zip(kvs, meta)]
+        out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=q.device)
+        flag = torch.empty(n * S, dtype=torch.uint8, device=q.device)
+        bias_k = bias_k.contiguous()
+        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, segs, out, flag)
+        ctx.save_for_backward(qbuf, bias_k, *kvs)
+        ctx.meta, ctx.n, ctx.S = meta, n, S
+        ctx.mark_non_differentiable(flag)
+        return out, flag
+
+    @staticmethod
+    def backward(ctx, dout, _dflag):
+        qbuf, bias_k, *kvs = ctx.saved_tensors
+        meta, n, S = ctx.meta, ctx.n, ctx.S
+        segs = [Seg(kv, 0, D, m[3], m[0], m[1], m[2], m[4]) for kv, m in zip(kvs, meta)]
+        dq = torch.empty_like(qbuf)
+        dkv = [torch.zeros_like(kv) for kv in kvs]
+        db = torch.zeros_like(bias_k)
+        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, segs, dout.contiguous(), dq, dkv, db)
+        return (dq[:, :D], dq[:, D:], db, None, None, None, *dkv)
+
+
+class Targets:
+    """One target segment in table form: tokens [n_tables*T, 128] (already normalised), KNN set, sharing factor."""
+
+    def __init__(self, tokens: Tensor, idx: Tensor, invalid: Tensor, emb: Tensor, n_tgt: int, batch_div: int = 1,
+                 cache: Optional[dict] = None, key: Optional[str] = None):
+        self.tokens, self.idx, self.invalid, self.emb, self.n_tgt, self.batch_div = tokens, idx, invalid, emb, n_tgt, batch_div
+        self.cache, self.key = cache, key  # static targets (map tokens): K/V tables computed once per training step
+
+
+def kv_table(attn, norm, t: Targets) -> Tensor:
+    """K|V table [tokens, 256] of a target set for one attention layer (LayerNorm + projection, before the gather)."""
+    make = lambda: F.linear(F.layer_norm(t.tokens, (D,), norm.weight, norm.bias, norm.eps) if norm is not None else t.tokens,
+                            attn.in_proj_weight[D:], attn.in_proj_bias[D:])
+    if t.cache is None or t.key is None:
+        return make()
+    k = (t.key, id(attn))
+    if k not in t.cache:
+        t.cache[k] = make()
+    return t.cache[k]
+
+
+def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor], n: int, S: int) -> Tensor:
+    """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source."""
+    W, b = attn.in_proj_weight, attn.in_proj_bias
+    wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
+    rows = xq.shape[0]
+    q = F.linear(xq, W[:D], b[:D])
+    qt = torch.einsum("rhj,hjc->rhc", q.view(rows, NH, DH), wr[:D].view(NH, DH, D)).reshape(rows, NH * D)
+    meta = [(t.idx, t.invalid, t.emb, t.n_tgt, t.batch_div) for t in targets]
+    out, flag = KnarpeAttnFn.apply(q, qt, br[:D], n, S, meta, *kvs)
+    o = out[:, :D] + (torch.einsum("rhc,hjc->rhj", out[:, D:].reshape(rows, NH, D), wr[D:].view(NH, DH, D))
+                      + br[D:].view(NH, DH)).reshape(rows, D)
+    y = F.linear(o, attn.out_proj_weight, attn.out_proj_bias)
+    return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
+
+
+def _drop(x: Tensor, p: float, training: bool) -> Tensor:
+    return F.dropout(x, p, training) if (training and p > 0) else x
+
+
+def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, self_knn, cross=None, p: float = 0.0,
+                      training: bool = False) -> Tensor:
+    """transformer_rpe.py:48-135,207-245. x [n*S,128]; self_knn = (idx, invalid, emb) among the sources;
+    cross(layer) -> list[Targets] with UN-normalised tokens (norm_tgt is applied here)."""
+    ln = lambda m, t: F.layer_norm(t, (D,), m.weight, m.bias, m.eps)
+    inv = src_invalid.reshape(-1).bool().unsqueeze(-1)
+    for layer in block.layers:
+        if block.mode == "dec_cross_attn":
+            s = ln(layer.norm_src, x)
+            ts = Targets(s, *self_knn, n_tgt=S)
+            x = x + _drop(attention(layer.attn_src, s, [ts], [kv_table(layer.attn_src, None, ts)], n, S), p, training)
+            s2 = ln(layer.norm1, x)
+            tg = list(cross(layer))
+            x = x + _drop(attention(layer.attn, s2, tg, [kv_table(layer.attn, layer.norm_tgt, t) for t in tg], n, S), p, training)
+        else:  # enc_self_attn: gathered targets share norm1 with the source
+            s2 = ln(layer.norm1, x)
+            ts = Targets(s2, *self_knn, n_tgt=S)
+            x = x + _drop(attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S), p, training)
+        h = F.relu(F.linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias))
+        x = x + _drop(F.linear(_drop(h, p, training), layer.linear2.weight, layer.linear2.bias), p, training)
+        x = x.masked_fill(inv, 0.0)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ small modules
+def mlp(m, x: Tensor, training: bool = False) -> Tensor:
+    """modules/mlp.py:69-72 (Linear [+LN] [+ReLU] [+Dropout] per layer)."""
+    p = m.dropout_p
+    for lin, lnm, act in m.linear_layers():
+        x = F.linear(x, lin.weight, lin.bias)
+        if lnm is not None:
+            x = F.layer_norm(x, lnm.weight.shape, lnm.weight, lnm.bias, lnm.eps)
+        if act:
+            x = F.relu(x)
+        x = _drop(x, p, training)
+    return x
+
+
+def pointnet(enc, x: Tensor, invalid: Tensor, training: bool = False) -> Tensor:
+    """polyline_encoder.py:49-61 + pooling.py:18-19,38. x [G, W, 128], invalid [G, W] bool -> [G, 128]."""
+    im = invalid.unsqueeze(-1)
+    for m in enc.mlp_layers:
+        h = mlp(m, x, training).masked_fill(im, float("-inf"))
+        x = torch.cat([h, h.amax(dim=1, keepdim=True).expand(-1, h.shape[1], -1)], -1).masked_fill(im, 0.0)
+    y = x.masked_fill(im, float("-inf")).amax(1)
+    return y.masked_fill(invalid.all(-1, keepdim=True), 0.0)
+
+
+def _knn(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, rp, div=1):
+    idx, inv, _, emb = hip.knn_embed(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim,
+                                     tgt_batch_div=div)
+    return idx, inv, emb
+
+
+# ------------------------------------------------------------------------------------------------ encoders
+def map_encoder(me, mp_valid, mp_attr, mp_pose, mp_type, training: bool) -> Dict[str, Tensor]:
+    n, M, N = mp_valid.shape
+    dev, d = mp_pose.device, me.hidden_dim
+    rows = n * M * N
+    attr = torch.empty(rows, 32, dtype=torch.float32, device=dev)
+    pe = torch.empty(rows, 8, dtype=torch.float32, device=dev)
+    row_inv = torch.empty(rows, dtype=torch.uint8, device=dev)
+    tok_pose = torch.empty(n, M, 3, dtype=torch.float32, device=dev)
+    tok_inv = torch.empty(n, M, dtype=torch.uint8, device=dev)
+    hip.map_prep(mp_valid.to(torch.uint8).contiguous(), mp_attr.float().contiguous(), mp_pose.float().contiguous(), attr, pe, row_inv,
+                 tok_pose, tok_inv)
+    x = torch.cat([mlp(me.input_encoder.mlp, attr[:, :me.input_encoder.mlp.input_dim], training), pe[:, :7]], -1)
+    feat = pointnet(me.pl_encoder, x.view(n * M, N, d), row_inv.view(n * M, N).bool(), training)
+    knn = _knn(tok_pose, tok_inv, tok_pose, tok_inv, me.n_tgt_knn, me.dist_limit, me.pose_rpe)
+    feat = transformer_block(me.tf_mp2mp, feat, tok_inv, n, M, knn, p=me.tf_mp2mp.dropout_p, training=training)
+    return {"mp_token_invalid": tok_inv.bool(), "mp_token_invalid_u8": tok_inv, "mp_token_feature": feat.view(n, M, d),
+            "mp_token_pose": tok_pose, "mp_token_type": mp_type}
+
+
+def tl_pre_compute(te, tl_valid, tl_attr, tl_pose, mp: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    n, L = tl_valid.shape
+    dev = tl_pose.device
+    tl_inv = (~tl_valid).to(torch.uint8).contiguous()
+    pose = tl_pose.float().contiguous()
+    mpf = mp["mp_token_feature"].detach() if te.tl_lane_detach_mp_feature else mp["mp_token_feature"]
+    t = {"tl_token_valid": tl_valid, "tl_token_invalid": ~tl_valid, "tl_token_invalid_u8": tl_inv, "tl_token_pose": pose,
+         "tl_token_attr": mpf[torch.arange(n, device=dev).unsqueeze(1), tl_attr], "mp_feat_for_tl": mpf}
+    t["tt"] = _knn(pose, tl_inv, pose, tl_inv, te.n_tgt_knn_tl2tl, te.dist_limit, te.pose_rpe)
+    t["tm"] = _knn(pose, tl_inv, mp["mp_token_pose"], mp["mp_token_invalid_u8"], te.n_tgt_knn_tl2mp, te.dist_limit, te.pose_rpe)
+    return t
+
+
+def tl_encoder(te, hist_tl: Tensor, t: Dict[str, Tensor], training: bool) -> Tensor:
+    """hist_tl [n,L,W] u8 masks (0xFF missing) -> [n*L, 128]. traffic_light.py:184-246."""
+    n, L, W = hist_tl.shape
+    dev, d = hist_tl.device, te.hidden_dim
+    ld = 16 if 5 + W <= 16 else 32
+    attr = torch.empty(n * L * W, ld, dtype=torch.float32, device=dev)
+    row_inv = torch.empty(n * L * W, dtype=torch.uint8, device=dev)
+    hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
+    x = mlp(te.input_encoder.mlp, attr[:, :5 + W], training).view(n * L, W, d) + t["tl_token_attr"].reshape(n * L, 1, d)
+    x = pointnet(te.temp_encoder, x, row_inv.view(n * L, W).bool(), training)
+    M = t["mp_feat_for_tl"].shape[1]
+    mp_tokens = t["mp_feat_for_tl"].reshape(-1, d)
+    return transformer_block(te.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, t["tt"],
+                             cross=lambda layer: [Targets(mp_tokens, *t["tm"], n_tgt=M, cache=t.get("_kv_cache"), key="tl2mp")],
+                             p=te.tf_tl2tlmp.dropout_p, training=training)
+
+
+def agent_encoder(ae, hist_valid, hist_pose, hist_motion, ag_attr6, mp, tl_inv_u8, tl_pose, tl_feat, training: bool):
+    """agent_encoder.py:114-178,321-387. hist_* [n,A,W(,3)] oldest first -> (feat [n*A,128], prep dict)."""
+    n, A, W = hist_valid.shape
+    dev, d = hist_pose.device, ae.hidden_dim
+    prep = ae.alloc_prep(n, A, dev, with_heads=False)
+    hip.agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, None, ae.pose_emb.pe_xy.freqs, ae.pose_emb.pe_yaw.freqs,
+                   ae.pose_emb.out_dim, prep)
+    tok_pose, tok_inv = prep["tok_pose"], prep["tok_invalid"]
+    aa = _knn(tok_pose, tok_inv, tok_pose, tok_inv, ae.n_tgt_knn_ag2ag, ae.dist_limit, ae.pose_rpe)
+    am = _knn(tok_pose, tok_inv, mp["mp_token_pose"], mp["mp_token_invalid_u8"], ae.n_tgt_knn_ag2mp, ae.dist_limit, ae.pose_rpe)
+    at = _knn(tok_pose, tok_inv, tl_pose, tl_inv_u8, ae.n_tgt_knn_ag2tl, ae.dist_limit, ae.pose_rpe)
+    x = torch.cat([mlp(ae.input_encoder.mlp, prep["attr"][:, :ae.input_encoder.mlp.input_dim], training), prep["pe"]], -1)
+    x = pointnet(ae.temp_encoder, x.view(n * A, W, d), prep["row_invalid"].view(n * A, W).bool(), training)
+    M, L = mp["mp_token_pose"].shape[1], tl_pose.shape[1]
+    mp_tokens = mp["mp_token_feature"].reshape(-1, d)
+    x = transformer_block(ae.tf_ag2agmptl, x, tok_inv, n, A, aa,
+                          cross=lambda layer: [Targets(mp_tokens, *am, n_tgt=M, cache=mp.get("_kv_cache"), key="ag2mp"),
+                                               Targets(tl_feat, *at, n_tgt=L)],
+                          p=ae.tf_ag2agmptl.dropout_p, training=training)
+    return x, prep
+
+
+def add_navi_latent(m, x: Tensor, z: Tensor, z_invalid: Tensor, training: bool) -> Tensor:
+    zi = z_invalid.unsqueeze(-1)
+    zz = mlp(m.mlp_in, z, training).masked_fill(zi, 0.0)
+    h = mlp(m.mlp, torch.cat([x, zz], -1), training).masked_fill(zi, 0.0)
+    return h + x
+
+
+def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, dest, navi_valid, tl_tokens, mp, training: bool):
+    """traffic_bots.py:188-221 -> (action mean [n,A,2], tl logits [n,L,5])."""
+    hv, hp, hm, ht = hist
+    n, A, W = hv.shape
+    d = model.hidden_dim
+    L = ht.shape[1]
+    tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
+    feat, _ = agent_encoder(model.ag_encoder, hv, hp, hm, ag_attr6, mp, tl_tokens["tl_token_invalid_u8"], tl_tokens["tl_token_pose"],
+                            tl_feat, training)
+    # NaviEncoder (navigation.py:65-79): detached map feature of the destination + pose embedding of its relative pose
+    ne = model.navi_encoder
+    bi = torch.arange(n, device=feat.device).unsqueeze(1)
+    mpf = mp["mp_token_feature"].detach() if ne.dest_detach_mp_feature else mp["mp_token_feature"]
+    gp = mp["mp_token_pose"][bi, dest]
+    c, s = torch.cos(ag_pose[..., 2]), torch.sin(ag_pose[..., 2])
+    dx, dy = gp[..., 0] - ag_pose[..., 0], gp[..., 1] - ag_pose[..., 1]
+    rel = torch.stack([dx * c + dy * s, dx * (-s) + dy * c, gp[..., 2] - ag_pose[..., 2]], -1).reshape(-1, 3).contiguous()
+    pe = hip.pose_embed(rel, ne.pose_emb.pe_xy.freqs, ne.pose_emb.pe_yaw.freqs, ne.pose_emb.out_dim)
+    navi = mlp(ne.mlp_mp, mpf[bi, dest].reshape(n * A, d)) + mlp(ne.mlp_pe, pe)
+    feat = add_navi_latent(model.add_navi, feat, navi, ~navi_valid.reshape(-1), training)
+    feat = add_navi_latent(model.add_latent, feat, z.reshape(n * A, -1), ~z_valid.reshape(-1), training)
+    mask_type = ~(ag_type & ag_valid.unsqueeze(-1)).reshape(n * A, 3)
+    mean = 0
+    for i, m in enumerate(model.action_head.mlp_mean):
+        mean = mean + mlp(m, feat).masked_fill(mask_type[:, [i]], 0.0)
+    sp = model.tl_state_predictor
+    xt = tl_feat.detach() if sp.detach_tl_feature else tl_feat
+    logits = torch.clamp(mlp(sp.mlp, xt).masked_fill(tl_tokens["tl_token_invalid"].reshape(-1, 1), 0.0), -3, 3)
+    return mean.view(n, A, 2), logits.view(n, L, -1)
+
+
+def latent_posterior(le, b, mp, tl_tokens, training: bool) -> DiagGaussian:
+    r = le.temporal_down_sample_rate
+    v, m, p, s = b["gt/ag_valid"][:, :, ::r], b["gt/ag_motion"][:, :, ::r], b["gt/ag_pose"][:, :, ::r], b["gt/tl_state"][:, :, ::r]
+    te, ae = le.tl_encoder_post, le.ag_encoder_post
+    n, A, _ = v.shape
+    tl_feat = tl_encoder(te, te.states_to_hist(s, te.temp_window_size), tl_tokens, training)
+    hv, hp, hm = ae.pad_hist(v, p, m, ae.temp_window_size)
+    feat, _ = agent_encoder(ae, hv, hp, hm, b["sc/ag_attr"].float().contiguous(), mp, tl_tokens["tl_token_invalid_u8"],
+                            tl_tokens["tl_token_pose"], tl_feat, training)
+    valid = b["gt/ag_valid"].any(-1)
+    mean = mlp(le.latent_dist_post.mlp_mean, feat).view(n, A, -1).masked_fill(~valid.unsqueeze(-1), 0.0)
+    return DiagGaussian(mean, le.latent_dist_post.log_std, valid=valid)
+
+
+def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
+    """navigation.py:175-278 (dest)."""
+    ag_valid, ag_pose, ag_motion = b["sc/ag_valid"], b["sc/ag_pose"].detach(), b["sc/ag_motion"].detach()
+    n, A, W = ag_valid.shape
+    assert W <= npd.temp_window_size
+    dev, d = ag_pose.device, npd.hidden_dim
+    from .models.agent_encoder import AgentEncoder
+
+    hv, hp, hm = AgentEncoder.pad_hist(ag_valid, ag_pose, ag_motion, npd.temp_window_size)
+    Wn = npd.temp_window_size
+    f32, u8 = torch.float32, torch.uint8
+    prep = dict(tok_pose=torch.empty(n, A, 3, dtype=f32, device=dev), tok_invalid=torch.empty(n, A, dtype=u8, device=dev),
+                attr=torch.empty(n * A * Wn, 32, dtype=f32, device=dev), pe=torch.empty(n * A * Wn, npd.pose_emb.out_dim, dtype=f32, device=dev),
+                row_invalid=torch.empty(n * A * Wn, dtype=u8, device=dev))
+    hip.agent_prep(hv, hp, hm, b["sc/ag_attr"].float().contiguous(), None, npd.pose_emb.pe_xy.freqs, npd.pose_emb.pe_yaw.freqs,
+                   npd.pose_emb.out_dim, prep)
+    x = torch.cat([mlp(npd.input_encoder.mlp, prep["attr"][:, :npd.input_encoder.mlp.input_dim], training), prep["pe"]], -1)
+    feat = pointnet(npd.temp_encoder, x.view(n * A, Wn, d), prep["row_invalid"].view(n * A, Wn).bool(), training)
+    mpf = mp["mp_token_feature"].detach() if npd.detach_input else mp["mp_token_feature"]
+    M = mpf.shape[1]
+    tp, mpp = prep["tok_pose"], mp["mp_token_pose"]
+    c, s = torch.cos(tp[..., 2])[:, :, None], torch.sin(tp[..., 2])[:, :, None]
+    dx, dy = mpp[:, None, :, 0] - tp[:, :, None, 0], mpp[:, None, :, 1] - tp[:, :, None, 1]
+    rel = torch.stack([dx * c + dy * s, dx * (-s) + dy * c, mpp[:, None, :, 2] - tp[:, :, None, 2]], -1).reshape(-1, 3).contiguous()
+    emb = hip.pose_embed(rel, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs, npd.pose_rpe.out_dim).view(n, A, M, -1)
+    zc = torch.cat([feat.view(n, A, 1, d).expand(-1, -1, M, -1), mpf[:, None].expand(-1, A, -1, -1), emb], -1)
+    logits = mlp(npd.mlp, zc, training).squeeze(-1)
+    ty, ag_type = mp["mp_token_type"], b["ref/ag_type"]
+    tok_valid = ag_valid.any(-1)
+    mp_mask = mp["mp_token_invalid"] | ~(ty[:, :, :5].any(-1))
+    bad = (mp_mask[:, None] | (ag_type[:, :, [0]] & ty[:, :, 3][:, None]) | (ag_type[:, :, [1]] & ty[:, :, :4].any(-1)[:, None])
+           | (ag_type[:, :, [2]] & ty[:, :, :3].any(-1)[:, None]))
+    logits = logits.masked_fill(bad, float("-inf")).masked_fill((~tok_valid).unsqueeze(-1) | bad.all(-1, keepdim=True), 0)
+    return DestCategorical(logits=logits, valid=tok_valid)
+
+
+# ------------------------------------------------------------------------------------------------ rollout + loss
+def _bits(one_hot: Tensor) -> Tensor:
+    w = (1 << torch.arange(one_hot.shape[-1], device=one_hot.device, dtype=torch.int32))
+    return (one_hot.to(torch.int32) * w).sum(-1).to(torch.uint8)
+
+
+def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
+    """Closed-loop training rollout (waymo_motion.py:206-311 with training=True: model inputs detached, the only
+    cross-step gradient path is the dynamics chain). The per-step state machine is elementwise torch on [n,A] tensors
+    (it needs autograd); rule feedback = outside-map + dest-reached as in tbx_sim_step."""
+    model, dyn, rc = wm.model, wm.dynamics, wm.hp.differentiable_reward
+    gt_valid, gt_pose, gt_motion, tl_gt = b["gt/ag_valid"], b["gt/ag_pose"], b["gt/ag_motion"], b["gt/tl_state"]
+    ag_type, ag_attr6, dest = b["ref/ag_type"], b["sc/ag_attr"].float().contiguous(), b["gt/ag_navi"]
+    n, A, Tg = gt_valid.shape
+    L, Tt = tl_gt.shape[1], tl_gt.shape[2]
+    W, dev = model.temp_window_size, gt_pose.device
+    dt = dyn.dt
+    max_act = torch.tensor([[a, y] for a, y in zip(dyn.max_acc, dyn.max_yaw_rate)], device=dev)
+    lim = (ag_type.unsqueeze(-1) * max_act).sum(2)
+    bi = torch.arange(n, device=dev).unsqueeze(1)
+    d_type = b["map/type"][bi, dest]
+    d_dir = b["map/dir"][bi, dest][..., :2]
+    d_dir = d_dir / torch.norm(d_dir, dim=-1, keepdim=True)
+    d_pos, d_inv = b["map/pos"][bi, dest][..., :2], ~b["map/valid"][bi, dest]
+    d_thresh = 50.0 * (1 - d_type[:, :, 4].float() * 0.8)
+    bnd = b["map/boundary"]
+    valid, disabled = gt_valid[:, :, 0], torch.zeros_like(gt_valid[:, :, 0])
+    pose, motion = gt_pose[:, :, 0], gt_motion[:, :, 0]
+    tl_bits = _bits(tl_gt)
+    navi_valid = gt_valid.any(-1)
+    outside, reached = torch.zeros_like(valid), torch.zeros_like(valid)
+    hv = torch.zeros(n, A, W, dtype=torch.uint8, device=dev)
+    hp, hm = torch.zeros(n, A, W, 3, device=dev), torch.zeros(n, A, W, 3, device=dev)
+    ht = torch.full((n, L, W), 0xFF, dtype=torch.uint8, device=dev)
+    tl_cur = tl_bits[:, :, 0]
+    out = {k: [] for k in ("pred_valid", "pred_pose", "pred_motion", "tl_nll", "tl_nll_invalid", "reward", "reward_valid", "tf")}
+    for step in range(1, step_end + 1):
+        hv = torch.cat([hv[:, :, 1:], valid.to(torch.uint8).unsqueeze(2)], 2)
+        hp = torch.cat([hp[:, :, 1:], pose.detach().unsqueeze(2)], 2)
+        hm = torch.cat([hm[:, :, 1:], motion.detach().unsqueeze(2)], 2)
+        ht = torch.cat([ht[:, :, 1:], tl_cur.unsqueeze(2)], 2)
+        mean, logits = policy_step(model, (hv.contiguous(), hp.contiguous(), hm.contiguous(), ht.contiguous()), ag_attr6, ag_type,
+                                   valid, pose.detach(), z, z_valid, dest, navi_valid, tl_tokens, mp, model.training)
+        inv1 = ~valid.unsqueeze(-1)
+        action = (torch.tanh(mean) * lim).masked_fill(inv1, 0)
+        acc, yr = action[..., 0], action[..., 1]
+        v_t, th_t = motion[..., 0] + 0.5 * dt * acc, pose[..., 2] + 0.5 * dt * yr
+        pose = (pose + dt * torch.stack([v_t * torch.cos(th_t), v_t * torch.sin(th_t), yr], -1)).masked_fill(inv1, 0)
+        motion = torch.stack([motion[..., 0] + dt * acc, acc, yr], -1).masked_fill(inv1, 0)
+        pred_valid, pred_pose, pred_motion = valid, pose, motion
+        if step < Tg:
+            ov = tf_mask[:, :, step] & ~disabled
+            valid = valid | ov
+            pose = pose.masked_fill(ov.unsqueeze(-1), 0) + gt_pose[:, :, step].masked_fill(~ov.unsqueeze(-1), 0)
+            motion = motion.masked_fill(ov.unsqueeze(-1), 0) + gt_motion[:, :, step].masked_fill(~ov.unsqueeze(-1), 0)
+            ov_log = tf_mask[:, :, step]
+        else:
+            ov_log = torch.zeros_like(valid)
+        with torch.no_grad():
+            tl_cur = tl_bits[:, :, step] if step < Tt else (1 << logits.argmax(-1)).to(torch.uint8)
+            x, y = pred_pose[..., 0], pred_pose[..., 1]
+            out_now = ((x > bnd[:, [1]]) | (x < bnd[:, [0]]) | (y > bnd[:, [3]]) | (y < bnd[:, [2]])) & pred_valid
+            outside = outside | out_now
+            dd = torch.norm(pred_pose[:, :, None, :2] - d_pos, dim=-1).masked_fill(d_inv, float("inf"))
+            pos_ok = (dd < d_thresh.unsqueeze(-1)).any(-1)
+            hf = torch.stack([torch.cos(pred_pose[..., 2]), torch.sin(pred_pose[..., 2])], -1)
+            rot_ok = ((hf.unsqueeze(2) * d_dir).sum(-1).masked_fill(d_inv, 0) > 0.8660254037844387).any(-1)
+            reach_now = (~reached) & pred_valid & ((d_type[:, :, :4].any(-1) & pos_ok & rot_ok) | (d_type[:, :, 4] & pos_ok))
+            reached = reached | reach_now
+        if step < Tg:  # rewards.py:58-74
+            g_valid, g_pose, g_motion = gt_valid[:, :, step], gt_pose[:, :, step], gt_motion[:, :, step]
+            r_valid = pred_valid & g_valid
+            e_pos = F.smooth_l1_loss(g_pose[..., :2], pred_pose[..., :2], reduction="none").sum(-1)
+            e_rot = 0.5 * (1 - torch.cos(g_pose[..., 2] - pred_pose[..., 2]))
+            e_spd = F.smooth_l1_loss(g_motion[..., 0], pred_motion[..., 0], reduction="none")
+            rew = ((-rc.l_pos.weight * e_pos).masked_fill(~r_valid, 0) + (-rc.l_rot.weight * e_rot).masked_fill(~r_valid, 0)
+                   + (-rc.l_spd.weight * e_spd).masked_fill(~r_valid, 0))
+            dis = out_now & ~g_valid
+        else:
+            r_valid, rew, dis = pred_valid, torch.zeros_like(pred_pose[..., 0]), out_now
+        if step < Tt:
+            nll = -Categorical(logits=logits).log_prob(tl_gt[:, :, step].max(-1)[1])
+            nll_inv = tl_tokens["tl_token_invalid"]
+        else:
+            nll, nll_inv = torch.zeros_like(logits[..., 0]), torch.ones_like(tl_tokens["tl_token_invalid"])
+        for k, v in (("pred_valid", pred_valid), ("pred_pose", pred_pose), ("pred_motion", pred_motion), ("tl_nll", nll),
+                     ("tl_nll_invalid", nll_inv), ("reward", rew), ("reward_valid", r_valid), ("tf", ov_log)):
+            out[k].append(v)
+        disabled = disabled | dis
+        valid = valid & ~dis
+        navi_valid = navi_valid & ~reach_now
+    return {k: torch.stack(v, 2) for k, v in out.items()}
+
+
+def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussian, prior: DiagGaussian) -> Dict[str, Tensor]:
+    """metrics/training.py:74-189 + metrics/loss.py:39-77 (default weights / switches)."""
+    lv = ro["pred_valid"].clone()
+    lv[:, :, : cfg.step_training_start] &= False
+    if not cfg.loss_for_teacher_forcing:
+        lv &= ~ro["tf"]
+    any_valid = lv.any(-1)
+    P, Q = post.distribution, prior.distribution
+    dP = Independent(Normal(P.base_dist.loc.detach(), P.base_dist.scale.detach()), 1)
+    dQ = Independent(Normal(Q.base_dist.loc.detach(), Q.base_dist.scale.detach()), 1)
+    e0 = torch.clamp(kl_divergence(dP, Q), min=cfg.kl_free_nats)
+    e1 = torch.clamp(kl_divergence(P, dQ), min=cfg.kl_free_nats)
+    kv = (post.valid if cfg.kl_for_unseen_agent else prior.valid) & any_valid
+    vae_kl = cfg.w_vae_kl * (e0 + cfg.kl_balance_scale * e1).masked_fill(~kv, 0).sum() / kv.sum()
+    rv = lv & ro["reward_valid"]
+    reward = cfg.w_diffbar_reward * ro["reward"].masked_fill(~rv, 0).sum() / rv.sum()
+    nv = navi_pred.valid & any_valid
+    navi = cfg.w_navi * (-navi_pred.log_prob(navi_gt)).masked_fill(~nv, 0).sum() / nv.sum()
+    tv = ~ro["tl_nll_invalid"]
+    tl = cfg.w_tl_state * ro["tl_nll"].masked_fill(~tv, 0).sum() / tv.sum()
+    return {"loss": vae_kl - reward + navi + tl, "vae_kl": vae_kl, "diffbar_reward": reward, "navi_loss": navi, "tl_state_loss": tl}
+
+
+def training_step(wm, raw_batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """waymo_motion.py:313-385."""
+    model, hp = wm.model, wm.hp
+    tr = model.training
+    with torch.no_grad():
+        b = wm.pre_processing(raw_batch)
+    mp = map_encoder(model.mp_encoder, b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"], tr)
+    tl_tokens = tl_pre_compute(model.tl_encoder, b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], mp)
+    mp["_kv_cache"], tl_tokens["_kv_cache"] = {}, {}  # map K/V tables: once per training step, shared by all 90 steps
+    post = latent_posterior(model.latent_encoder, b, mp, tl_tokens, tr)
+    pr = model.latent_encoder.latent_dist_prior
+    valid_hist = b["sc/ag_valid"].any(-1)
+    prior = DiagGaussian(pr.mean.expand(*valid_hist.shape, -1), pr.log_std, valid=valid_hist)
+    lat = prior if torch.rand(1) < hp.p_training_rollout_prior else post
+    # rsample with the noise drawn from the CPU generator, as the reference's CPU path does (same stream under the same
+    # seed); one [n, A, 16] host-to-device copy per training step
+    z = lat.mean + lat.stddev * torch.randn(lat.mean.shape).to(lat.mean.device)
+    navi_pred = navi_predictor(model.navi_predictor, b, mp, tr)
+    tf = wm.teacher_forcing_training
+    tf.init(ag_valid=b["gt/ag_valid"], ag_pose=b["gt/ag_pose"], ag_motion=b["gt/ag_motion"], tl_state=b["gt/tl_state"],
+            current_epoch=wm.current_epoch)
+    ro = training_rollout(wm, b, mp, tl_tokens, z, lat.valid, tf.ag_teacher_forcing, hp.time_step_end)
+    return training_loss(hp.training_metrics, ro, navi_pred, b["gt/ag_navi"], post, prior)
