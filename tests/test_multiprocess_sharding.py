@@ -62,3 +62,41 @@ def test_two_rank_sharding_equals_single_process(tmp_path, tb):
     ref = {s: _rollout_checksum(tb, s) for s in (0, 3)}
     for s, v in ref.items():
         assert abs(got[s] - v) < 1e-9 * max(1.0, abs(v))
+
+
+# ---------------------------------------------------------------------------------------------------- DDP wiring
+def _ddp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from importlib import import_module
+
+    from __graft_entry__ import load_package
+
+    load_package()
+    dp = import_module("trafficbots_amd.pl_modules.data_parallel")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    dead = torch.nn.Linear(3, 3)  # never used: must be skipped, as the 2.75 M gradient-less parameters are
+    x = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    xs = x[rank * 2:(rank + 1) * 2]  # each rank: its shard of the global batch
+    net(xs).pow(2).mean().backward()
+    live = dp.live_parameters(torch.nn.ModuleList([net, dead]))
+    assert len(live) == 4
+    nbytes = dp.allreduce_gradients(live)
+    assert nbytes == sum(p.numel() for p in live) * 4
+    torch.save([p.grad.clone() for p in live], os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_full_batch(tmp_path):
+    world, port = 2, 29541
+    mp.spawn(_ddp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    x = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    net(x).pow(2).mean().backward()
+    for a, b, p in zip(g0, g1, net.parameters()):
+        assert torch.equal(a, b)  # every rank ends with the same averaged gradient
+        torch.testing.assert_close(a, p.grad, rtol=1e-6, atol=1e-7)  # = gradient of the full batch
