@@ -60,6 +60,19 @@ def shard_scenes(n_total: int, rank: int, world: int):
     return list(range(rank * per, min(n_total, (rank + 1) * per)))
 
 
+def pmc_traffic(args, kernel: str):
+    """HBM traffic per launch from the committed PMC passes (profiles/*pmc*.json), if one matches this workload."""
+    import glob
+
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*pmc*.json")), reverse=True):
+        d = json.load(open(f))
+        w = d.get("workload", {})
+        if (w.get("agents"), w.get("polylines"), w.get("lights"), w.get("scenes"), w.get("rollouts")) == (
+                args.agents, args.polylines, args.lights, args.scenes, args.rollouts) and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["traffic_bytes_per_launch"], Path(f).name
+    return None, None
+
+
 def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int) -> float:
     """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b with fp32 (b = 4), d = d_rpe = 128."""
     d, b = 128, 4
@@ -280,6 +293,7 @@ def main():
     finite = bool(torch.isfinite(eng.S["out_pose"]).all())
     if rank == 0:
         ach = b_attn / t_attn / 1e9
+        traffic, traffic_src = pmc_traffic(args, "knarpe_attn_kernel")
         line = {
             "metric": "sim-agent-steps/sec (closed-loop rollout)", "value": units / dt, "unit": "sim-agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -289,7 +303,7 @@ def main():
                        "scenes_per_gpu": args.scenes, "rollouts_per_scene": args.rollouts, "graph": use_graph,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": n_attn / args.profile_steps,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n_attn / args.profile_steps,
                          "avg_launch_us": t_attn / n_attn * 1e6, "algorithmic_bytes_per_launch": b_attn / n_attn},
             "roofline_gemm": {"kernel": "rowchain_kernel", "bound": "mfma", "achieved": f_chain / t_chain / 1e12,
                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f_chain / t_chain / 1e12 / FP32_MFMA_PEAK_TF,
