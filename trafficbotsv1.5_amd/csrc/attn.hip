@@ -1,14 +1,10 @@
 // tbx_knarpe_attn_fwd: fused KNARPE attention (see include/tbx_hip.h for the math and the layouts).
 //
 // One wavefront per source token, 4 tokens per 256-thread workgroup (large grids), or 4 wavefronts per token (small grids).
-//   phase 1 (scores): 8 lanes per target, 8 targets per pass. The 8 lanes of a group read one full 128-B line of the
-//     target's K row and of its embedding row per step (coalesced gathers), keep the query side (q, qt = W_rpe_k^T q)
-//     in registers, and reduce with three xor-shuffles. Raw scores go to LDS.
-//   softmax: lanes = targets (<= 128), masked -inf unless the whole row is masked (then un-masked and flagged).
-//   phase 2 (weighted sums): lanes = channel pairs; V rows and embedding rows are streamed fully coalesced, the
-//     probabilities are LDS broadcasts; fully-masked targets are skipped (wave-uniform branch).
-// HBM-bound by construction: per pair it reads the K row, the V row, the embedding row (second pass from L2),
-// 4 B of index and 1 B of mask. d_model 128, 4 heads of 32, d_rpe 128.
+// Forward: single pass with an online softmax (see knarpe_attn_kernel below): per pair it reads the K row, the V row and
+// the embedding row exactly once (full 128-B lines per 8-lane group), 4 B of index and 1 B of mask; masked targets
+// contribute nothing, rows without any valid target are written as zeros and flagged.
+// d_model 128, 4 heads of 32, d_rpe 128.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,31 +29,29 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a
 
 // WPR = wavefronts cooperating on one source row: 1 for large grids (a wave per row, 4 rows per workgroup), 4 for small
 // grids (the closed loop at a few scenes is latency-bound: 4 waves split a row's targets and combine through LDS).
+//
+// Single pass, online softmax: 8 lanes per target, 8 targets per wave per pass. The 8 lanes of a group read one full
+// 128-B line of the target's K row, V row and embedding row per step (coalesced gathers) - every row exactly once - and
+// keep, for THEIR target slot, a running (max, sum) per head and the un-normalised partial sums
+//   O_slot[c] += p[h(c)] v[c] ,  E_slot[h][c] += p[h] e[c]      (their 16-channel slice c)
+// rescaled when the slot's running max grows. The 8 slots (and the WPR waves) are merged once per row:
+//   out = sum_slots exp(m_slot - M) acc_slot / sum_slots exp(m_slot - M) l_slot.
+// No LDS traffic and no barrier inside the target loop.
 template <int WPR>
 __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
-  constexpr int RPB = 4 / WPR;  // rows per workgroup
-  __shared__ float p_s[RPB][NH][KMAX];
-  __shared__ uint8_t inv_s[RPB][KMAX];
-  __shared__ int act_s[RPB][KMAX];
-  __shared__ int misc_s[RPB][2];  // [0] any_valid, [1] n_active
-  __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (D + NH * DR) : 1];
+  constexpr int OUTW = D + NH * DR;  // 640
+  __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
+  constexpr int RPB = 4 / WPR;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int rib = wave / WPR;  // row in block
-  const int wir = wave % WPR;  // wave in row
+  const int rib = wave / WPR;
+  const int wir = wave % WPR;
   const int row = blockIdx.x * RPB + rib;
   if (row >= a.n_rows) return;  // uniform per row group (and per workgroup when WPR == 4)
   const int b = row / a.n_src;
   const int k0 = a.seg[0].k;
   const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
   const int s8 = lane & 7, tg = lane >> 3;
-  auto row_sync = [&]() {
-    if constexpr (WPR > 1)
-      __syncthreads();
-    else
-      __builtin_amdgcn_wave_barrier();
-  };
-  if (WPR > 1 && threadIdx.x == 0) misc_s[0][0] = 0;
 
   // ---- query side in registers
   const float* qrow = a.qbuf + (int64_t)row * a.ldq;
@@ -71,10 +65,21 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) qtv[h][st] = *(const float4*)(qrow + a.qt_off + h * DR + st * 32 + s8 * 4);
   }
-  row_sync();
 
-  // ---- phase 1: raw scores, 8 lanes per target, 8 targets per wave per pass
-  bool any_valid = false;
+  // ---- per-slot online softmax state and partial sums (this lane's 16-channel slice: channels st*32 + s8*4 .. +3)
+  float m_run[NH], l_run[NH];
+  float4 oacc[4], eacc[NH][4];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    m_run[h] = -INFINITY;
+    l_run[h] = 0.f;
+    oacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) eacc[h][st] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto scale4 = [](float4& v, float f) { v.x *= f; v.y *= f; v.z *= f; v.w *= f; };
+  auto fma4 = [](float4& acc, float p, const float4 v) { acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w; };
+
   for (int base = wir * 8; base < ktot; base += 8 * WPR) {
     const int t = base + tg;
     const bool active = t < ktot;
@@ -83,17 +88,21 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     const int kk = sg ? t - k0 : t;
     float acc[NH] = {0.f, 0.f, 0.f, 0.f};
     bool inv = true;
+    float4 v[4], e[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) v[st] = e[st] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
       const int64_t pi = (int64_t)row * S.k + kk;
       const int j = S.idx[pi];
       inv = S.invalid[pi] != 0;
-      const float* krow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.k_off;
+      const float* trow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv;
       const float* erow = S.emb + pi * DR;
-      float4 kq[4], e[4];
+      float4 kq[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        kq[st] = *(const float4*)(krow + st * 32 + s8 * 4);
+        kq[st] = *(const float4*)(trow + S.k_off + st * 32 + s8 * 4);
         e[st] = *(const float4*)(erow + st * 32 + s8 * 4);
+        v[st] = *(const float4*)(trow + S.v_off + st * 32 + s8 * 4);
       }
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
@@ -103,130 +112,116 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       }
     }
 #pragma unroll
-    for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]) + qb[h];
-    if (active && s8 == 0) {
+    for (int h = 0; h < NH; ++h) {
+      const float sc = (tbx::group8_sum(acc[h]) + qb[h]) * a.scale;  // scale applied after masking as the reference does
+      if (active && !inv) {  // uniform within the 8-lane group
+        const float m_new = fmaxf(m_run[h], sc);
+        const float alpha = expf(m_run[h] - m_new);  // exp(-inf) = 0 on the slot's first valid target
+        const float pr = expf(sc - m_new);
+        l_run[h] = l_run[h] * alpha + pr;
+        m_run[h] = m_new;
+        scale4(oacc[h], alpha);      // K/V channel block st == h belongs to head h
+        fma4(oacc[h], pr, v[h]);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) p_s[rib][h][t] = acc[h];
-      inv_s[rib][t] = inv ? 1 : 0;
-    }
-    any_valid = any_valid || (__ballot(active && !inv) != 0ull);
-  }
-  if constexpr (WPR > 1) {
-    if (any_valid && lane == 0) misc_s[0][0] = 1;  // benign same-value race
-    __syncthreads();
-    any_valid = misc_s[0][0] != 0;
-  } else {
-    __builtin_amdgcn_wave_barrier();
-  }
-
-  // ---- softmax over targets (lanes = targets), scale applied after masking as the reference does.
-  // With WPR > 1 every wave of the row computes the same values; wave 0 publishes them.
-  float prob[NH][2];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int t = lane + 64 * q;
-      float sc = -INFINITY;
-      if (t < ktot && !(any_valid && inv_s[rib][t] != 0)) sc = p_s[rib][h][t] * a.scale;
-      prob[h][q] = sc;
-      m = fmaxf(m, sc);
-    }
-    m = tbx::wave_max(m);
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      prob[h][q] = (prob[h][q] == -INFINITY) ? 0.f : expf(prob[h][q] - m);
-      sum += prob[h][q];
-    }
-    sum = tbx::wave_sum(sum);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) prob[h][q] = prob[h][q] / sum;
-  }
-  row_sync();  // every wave has consumed the raw scores
-  if (wir == 0) {
-    // publish probabilities + the compacted list of targets that carry any weight
-    int n_act = 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int t = lane + 64 * q;
-      bool on = false;
-      if (t < ktot) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          p_s[rib][h][t] = prob[h][q];
-          on = on || prob[h][q] != 0.f;
+        for (int st = 0; st < 4; ++st) {
+          scale4(eacc[h][st], alpha);
+          fma4(eacc[h][st], pr, e[st]);
         }
       }
-      const unsigned long long mk = __ballot(on);
-      if (on) act_s[rib][n_act + __popcll(mk & ((1ull << lane) - 1ull))] = t;
-      n_act += __popcll(mk);
     }
-    if (lane == 0) misc_s[rib][1] = n_act;
   }
-  row_sync();
-  const int n_act = misc_s[rib][1];
 
-  // ---- phase 2: out = [sum a v | sum a e per head], lanes = channel pairs, 4 targets of loads in flight
-  const int c2 = lane * 2;
-  const int myh = lane >> 4;
-  float2 o = make_float2(0.f, 0.f);
-  float2 eb[NH];
+  // ---- merge the 8 target slots of this wave (lanes with equal s8: xor 8, 16, 32)
+  float M[NH], L[NH];
 #pragma unroll
-  for (int h = 0; h < NH; ++h) eb[h] = make_float2(0.f, 0.f);
-  constexpr int UB = 4;
-  for (int i0 = wir * UB; i0 < n_act; i0 += UB * WPR) {
-    float2 v[UB], e[UB];
-    int tt[UB];
+  for (int h = 0; h < NH; ++h) {
+    float mm = m_run[h];
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int i = i0 + u;
-      tt[u] = -1;
-      v[u] = e[u] = make_float2(0.f, 0.f);
-      if (i < n_act) {
-        const int t = act_s[rib][i];
-        tt[u] = t;
-        const int sg = t >= k0 ? 1 : 0;
-        const tbx_attn_seg_t& S = a.seg[sg];
-        const int64_t pi = (int64_t)row * S.k + (sg ? t - k0 : t);
-        const int j = __builtin_amdgcn_readfirstlane(S.idx[pi]);
-        v[u] = *(const float2*)(S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.v_off + c2);
-        e[u] = *(const float2*)(S.emb + pi * DR + c2);
-      }
+    for (int off = 8; off < 64; off <<= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
+    M[h] = mm;
+    const float f = (m_run[h] == -INFINITY) ? 0.f : expf(m_run[h] - mm);
+    float ll = l_run[h] * f;
+    scale4(oacc[h], f);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) scale4(eacc[h][st], f);
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) ll += __shfl_xor(ll, off, 64);
+    L[h] = ll;
+  }
+  auto red4 = [](float4 v) {
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
+      v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
     }
+    return v;
+  };
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      if (tt[u] >= 0) {
-        const float a0 = p_s[rib][0][tt[u]], a1 = p_s[rib][1][tt[u]], a2 = p_s[rib][2][tt[u]], a3 = p_s[rib][3][tt[u]];
-        const float am = myh == 0 ? a0 : (myh == 1 ? a1 : (myh == 2 ? a2 : a3));
-        o.x += am * v[u].x;
-        o.y += am * v[u].y;
-        eb[0].x += a0 * e[u].x; eb[0].y += a0 * e[u].y;
-        eb[1].x += a1 * e[u].x; eb[1].y += a1 * e[u].y;
-        eb[2].x += a2 * e[u].x; eb[2].y += a2 * e[u].y;
-        eb[3].x += a3 * e[u].x; eb[3].y += a3 * e[u].y;
-      }
-    }
+  for (int h = 0; h < NH; ++h) {
+    oacc[h] = red4(oacc[h]);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) eacc[h][st] = red4(eacc[h][st]);
   }
   float* orow = a.out + (int64_t)row * a.ldo;
-  if constexpr (WPR > 1) {
-    *(float2*)(&red_s[wir][c2]) = o;
+  if constexpr (WPR == 1) {
+    const bool any_valid = M[0] > -INFINITY;  // masks are per target, so every head sees the same validity
+    if (tg == 0) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h) *(float2*)(&red_s[wir][D + h * DR + c2]) = eb[h];
+      for (int h = 0; h < NH; ++h) {
+        const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
+        float4 o = oacc[h];
+        scale4(o, inv_l);
+        *(float4*)(orow + h * DH + s8 * 4) = o;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          float4 ev = eacc[h][st];
+          scale4(ev, inv_l);
+          *(float4*)(orow + D + h * DR + st * 32 + s8 * 4) = ev;
+        }
+      }
+    }
+    if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+  } else {
+    // per-wave (M, L, un-normalised sums) -> LDS, then all threads combine the WPR waves
+    if (tg == 0) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        *(float4*)(&red_s[wir][h * DH + s8 * 4]) = oacc[h];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) *(float4*)(&red_s[wir][D + h * DR + st * 32 + s8 * 4]) = eacc[h][st];
+      }
+    }
+    if (lane < NH) {
+      red_s[wir][OUTW + lane] = M[lane];
+      red_s[wir][OUTW + NH + lane] = L[lane];
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < D + NH * DR; c += 256) {
+    float Mx[NH], inv_l[NH], fw[WPR][NH];
+    bool any_valid = false;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) mm = fmaxf(mm, red_s[w][OUTW + h]);
+      Mx[h] = mm;
+      float ll = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) {
+        const float mw = red_s[w][OUTW + h];
+        fw[w][h] = (mw == -INFINITY) ? 0.f : expf(mw - mm);
+        ll += fw[w][h] * red_s[w][OUTW + NH + h];
+      }
+      any_valid = any_valid || mm > -INFINITY;
+      inv_l[h] = (mm > -INFINITY) ? 1.0f / ll : 0.f;
+    }
+    for (int c = threadIdx.x; c < OUTW; c += 256) {
+      const int h = c < D ? c / DH : (c - D) / DR;
       float acc = 0.f;
 #pragma unroll
-      for (int w = 0; w < WPR; ++w) acc += red_s[w][c];
-      orow[c] = acc;
+      for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
+      orow[c] = acc * inv_l[h];
     }
     if (threadIdx.x == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
-  } else {
-    *(float2*)(orow + c2) = o;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) *(float2*)(orow + D + h * DR + c2) = eb[h];
-    if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
   }
 }
 
