@@ -68,7 +68,10 @@ int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const f
  *
  *   qbuf [n_batch*n_src, ldq]: q at q_off (128), qt at qt_off (4*128); rpe_k_bias [128] = linear_rpe.bias[0:128]
  *   (qb_h is formed in-kernel from q and rpe_k_bias)
- *   seg[i]: kv [n_batch/batch_div, n_tgt, ld_kv] with K at k_off and V at v_off; idx / invalid / emb [n_batch, n_src, k(,128)]
+ *   seg[i]: kv [n_batch/batch_div, n_tgt, ld_kv] with K at k_off and V at v_off; idx / invalid [n_batch, n_src, k];
+ *           the pair's pose embedding either materialised (emb [n_batch, n_src, k, 128]) or as its relative pose
+ *           (rel_pose [n_batch, n_src, k, 3] + freqs_xy / freqs_yaw = the `pose_rpe` buffers): then the kernel moves exactly
+ *           the algorithmic K row + V row + 12 B + 4 B + 1 B per pair
  *   out  [n_batch*n_src, ldo >= 640]; row_no_valid [n_batch*n_src] u8
  * Limits: 1 <= n_seg <= 2, sum of k <= 128, 16-byte aligned rows.
  */
@@ -76,13 +79,15 @@ typedef struct tbx_attn_seg {
   const float* kv;
   const int32_t* idx;
   const uint8_t* invalid;
-  const float* emb;
+  const float* emb;      /* [n_batch, n_src, k, 128] materialised pose embedding, or NULL */
+  const float* rel_pose; /* [n_batch, n_src, k, 3] relative pose (used when emb == NULL: the embedding is rebuilt in registers) */
   int32_t ld_kv, k_off, v_off, n_tgt, batch_div, k;
 } tbx_attn_seg_t;
 
 int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
                         int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo,
-                        uint8_t* row_no_valid, void* stream);
+                        uint8_t* row_no_valid, const float* freqs_xy /* [32] or NULL */, const float* freqs_yaw /* [64] or NULL */,
+                        void* stream);
 
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
@@ -92,7 +97,8 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
  * Probabilities are recomputed from the forward inputs; the pose embeddings carry no gradient (utils/rpe.py:7). */
 int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
                         const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo, float* dqbuf,
-                        float* const* dkv /* host array of n_seg device pointers */, float* dbias_k, void* stream);
+                        float* const* dkv /* host array of n_seg device pointers */, float* dbias_k,
+                        const float* freqs_xy, const float* freqs_yaw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs

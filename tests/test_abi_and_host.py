@@ -91,4 +91,4 @@ def test_chain_program_encoding(hip):
     ch._add(op=hip.OP_COPY, src=0, dst=1, n=4)
     st = ch.stages[0]
     assert (st.op, st.src, st.dst, st.n) == (hip.OP_COPY, 0, 1, 4)
-    assert C.sizeof(hip.Stage) == 72 and C.sizeof(hip.AttnSeg) == 56
+    assert C.sizeof(hip.Stage) == 72 and C.sizeof(hip.AttnSeg) == 64

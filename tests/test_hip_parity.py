@@ -214,3 +214,30 @@ def test_model_tokens_and_policy_steps(tb, hip, dev, sizes, knn, n_steps):
         a_dist, tl_dist = model(ag_navi_updated=True, tl_tokens=tl, mp_tokens=mp, **{k: v.to(dev) for k, v in args.items()})
         torch.testing.assert_close(a_dist.mean.cpu(), mean_o, rtol=2e-3, atol=2e-4)
         torch.testing.assert_close(tl_dist.logits.cpu(), torch.log_softmax(logit_o, -1), rtol=2e-3, atol=2e-4)
+
+
+def test_attention_relative_pose_mode_matches_materialised(tb, hip, dev):
+    """The attention kernel fed with 12-B relative poses (embedding rebuilt in registers through the hardware
+    sin/cos with an exact two-constant range reduction) must match the same call fed with the materialised embedding
+    (libm sincosf), also for the ~600 rad arguments of far-away targets."""
+    M = import_module("trafficbots_amd.models.modules")
+    g = torch.Generator().manual_seed(9)
+    n, S, T, K, d = 2, 40, 300, 33, 128
+    att, P = _filled(tb, M.attention_rpe.AttentionRPE, 15, dev, d_model=d, n_head=4, dropout_p=0.1, d_rpe=d)
+    src_pose, tgt_pose = _poses(g, n, S, 900.0), _poses(g, n, T, 900.0)
+    inv_s, inv_t = torch.zeros(n, S, dtype=torch.uint8), (torch.rand(n, T, generator=g) < 0.2).to(torch.uint8)
+    fxy, fyw = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
+    idx, kinv, rel, emb = hip.knn_embed(src_pose.to(dev), inv_s.to(dev), tgt_pose.to(dev), inv_t.to(dev), K, 1e9, fxy, fyw, 128,
+                                        want_rel_pose=True, want_emb=True)
+    qbuf = torch.randn(n * S, 640, generator=g).to(dev)
+    kv = torch.randn(n * T, 256, generator=g).to(dev)
+    outs = []
+    for mode in ("emb", "rel"):
+        out = torch.empty(n * S, 640, device=dev)
+        flag = torch.empty(n * S, dtype=torch.uint8, device=dev)
+        seg = hip.Seg(kv, 0, 128, T, idx, kinv, emb if mode == "emb" else None, rel=rel if mode == "rel" else None)
+        hip.knarpe_attn(qbuf, 0, 128, att.linear_rpe.bias, n, S, [seg], out, flag, fxy, fyw)
+        outs.append(out)
+    torch.testing.assert_close(outs[1], outs[0], rtol=2e-4, atol=2e-5)
+    # the E-sums are convex combinations of embedding channels: their agreement bounds the per-channel sin/cos error
+    assert float((outs[1][:, 128:] - outs[0][:, 128:]).abs().max()) < 1e-5

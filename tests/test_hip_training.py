@@ -36,7 +36,7 @@ def test_attention_backward_vs_oracle_autograd(tb):
     att = att.to(dev)
     src_h, tok_h = src.to(dev).requires_grad_(True), tokens.to(dev).requires_grad_(True)
     t = TG.Targets(tok_h.reshape(n * T, d), idx.to(torch.int32).to(dev).contiguous(), m.to(torch.uint8).to(dev).contiguous(),
-                   emb.to(dev).contiguous(), n_tgt=T)
+                   emb.to(dev).contiguous(), n_tgt=T)  # materialised-embedding form of the kernel pair
     y_h = TG.attention(att, src_h.reshape(n * S, d), [t], [TG.kv_table(att, None, t)], n, S).view(n, S, d)
     (y_h * w_out.to(dev)).sum().backward()
     tol = dict(rtol=2e-3, atol=2e-4)

@@ -1,10 +1,18 @@
-// tbx_knarpe_attn_fwd: fused KNARPE attention (see include/tbx_hip.h for the math and the layouts).
+// tbx_knarpe_attn_fwd / tbx_knarpe_attn_bwd: fused KNARPE attention (see include/tbx_hip.h for the math and layouts).
 //
 // One wavefront per source token, 4 tokens per 256-thread workgroup (large grids), or 4 wavefronts per token (small grids).
-// Forward: single pass with an online softmax (see knarpe_attn_kernel below): per pair it reads the K row, the V row and
-// the embedding row exactly once (full 128-B lines per 8-lane group), 4 B of index and 1 B of mask; masked targets
-// contribute nothing, rows without any valid target are written as zeros and flagged.
-// d_model 128, 4 heads of 32, d_rpe 128.
+// Forward: single pass with an online softmax: per (src, tgt) pair it reads the K row and the V row exactly once (full
+// 128-B lines per 8-lane group), 4 B of index, 1 B of mask and EITHER the 512-B materialised pose embedding OR the 12-B
+// relative pose, from which the 128-d embedding is rebuilt in registers (one sincosf per (cos, sin) channel pair: the
+// kernel then moves exactly the algorithmic 1041 B per pair). Masked targets contribute nothing; rows without any valid
+// target are written as zeros and flagged. d_model 128, 4 heads of 32, d_rpe 128.
+//
+// Channel ownership inside an 8-lane target group (lane slot s8 = lane & 7):
+//   K / V / q / out[0:128]   : 4 float4 at channels st*32 + s8*4 (st = 0..3 is also the head of that channel block)
+//   embedding e / qt / E-sums : the (cos, sin) pairs of 8 arguments -> 16 channels:
+//       x f_i, i in {2s8, 2s8+1}   -> cos at 2s8+.., sin at 16+2s8+..      y f_i likewise at 32+.. / 48+..
+//       k yaw, k-1 in {4s8..4s8+3} -> cos at 64+4s8+.., sin at 96+4s8+..
+//   (pose_emb.py:50-55, positional_emb.py:25,53: [cos(x f)16 sin(x f)16 cos(y f)16 sin(y f)16 cos(k yaw)32 sin(k yaw)32]).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -18,6 +26,8 @@ constexpr int D = 128, NH = 4, DH = 32, DR = 128, KMAX = 128;
 struct AttnArgs {
   const float* qbuf;
   const float* rpe_k_bias;
+  const float* fxy;   // pose_rpe.pe_xy.freqs  [32]  (only for segments given as relative poses)
+  const float* fyaw;  // pose_rpe.pe_yaw.freqs [64]
   float* out;
   uint8_t* row_no_valid;
   tbx_attn_seg_t seg[2];
@@ -26,14 +36,115 @@ struct AttnArgs {
 };
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void scale4(float4& v, float f) { v.x *= f; v.y *= f; v.z *= f; v.w *= f; }
+__device__ __forceinline__ void fma4(float4& acc, float p, const float4 v) { acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w; }
+__device__ __forceinline__ void scale2(float2& v, float f) { v.x *= f; v.y *= f; }
+__device__ __forceinline__ void fma2(float2& acc, float p, const float2 v) { acc.x += p * v.x; acc.y += p * v.y; }
+
+// A lane's 16-channel slice of a 128-d embedding-space vector (see the header comment for the channel set).
+struct ESlice {
+  float2 xc, xs, yc, ys;
+  float4 wc, ws;
+  __device__ __forceinline__ void zero() {
+    xc = xs = yc = ys = make_float2(0.f, 0.f);
+    wc = ws = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int s8) {
+    xc = *(const float2*)(p + 2 * s8);
+    xs = *(const float2*)(p + 16 + 2 * s8);
+    yc = *(const float2*)(p + 32 + 2 * s8);
+    ys = *(const float2*)(p + 48 + 2 * s8);
+    wc = *(const float4*)(p + 64 + 4 * s8);
+    ws = *(const float4*)(p + 96 + 4 * s8);
+  }
+  __device__ __forceinline__ void store(float* __restrict__ p, int s8) const {
+    *(float2*)(p + 2 * s8) = xc;
+    *(float2*)(p + 16 + 2 * s8) = xs;
+    *(float2*)(p + 32 + 2 * s8) = yc;
+    *(float2*)(p + 48 + 2 * s8) = ys;
+    *(float4*)(p + 64 + 4 * s8) = wc;
+    *(float4*)(p + 96 + 4 * s8) = ws;
+  }
+  __device__ __forceinline__ float dot(const ESlice& o) const {
+    return xc.x * o.xc.x + xc.y * o.xc.y + xs.x * o.xs.x + xs.y * o.xs.y + yc.x * o.yc.x + yc.y * o.yc.y + ys.x * o.ys.x +
+           ys.y * o.ys.y + dot4(wc, o.wc) + dot4(ws, o.ws);
+  }
+  __device__ __forceinline__ void scale(float f) {
+    scale2(xc, f); scale2(xs, f); scale2(yc, f); scale2(ys, f);
+    scale4(wc, f); scale4(ws, f);
+  }
+  __device__ __forceinline__ void fma(float p, const ESlice& o) {
+    fma2(xc, p, o.xc); fma2(xs, p, o.xs); fma2(yc, p, o.yc); fma2(ys, p, o.ys);
+    fma4(wc, p, o.wc); fma4(ws, p, o.ws);
+  }
+  __device__ __forceinline__ void reduce_slots() {  // sum over the 8 target slots (lanes with equal s8)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      xc.x += __shfl_xor(xc.x, off, 64); xc.y += __shfl_xor(xc.y, off, 64);
+      xs.x += __shfl_xor(xs.x, off, 64); xs.y += __shfl_xor(xs.y, off, 64);
+      yc.x += __shfl_xor(yc.x, off, 64); yc.y += __shfl_xor(yc.y, off, 64);
+      ys.x += __shfl_xor(ys.x, off, 64); ys.y += __shfl_xor(ys.y, off, 64);
+      wc.x += __shfl_xor(wc.x, off, 64); wc.y += __shfl_xor(wc.y, off, 64);
+      wc.z += __shfl_xor(wc.z, off, 64); wc.w += __shfl_xor(wc.w, off, 64);
+      ws.x += __shfl_xor(ws.x, off, 64); ws.y += __shfl_xor(ws.y, off, 64);
+      ws.z += __shfl_xor(ws.z, off, 64); ws.w += __shfl_xor(ws.w, off, 64);
+    }
+  }
+};
+
+// sin / cos of an fp32 angle through the hardware v_sin_f32 / v_cos_f32 (argument in revolutions, |rev| <= 256), with a
+// two-constant 1/(2 pi) and an fma-exact reduction to [-0.5, 0.5]: the reduction error is ~1e-9 rev even for the
+// ~500 rad arguments of x * f_0, so the result is within the hardware's ~1e-6 absolute error of sin/cos of the SAME fp32
+// product the reference feeds to torch.sin / torch.cos. ~10 instructions instead of ~100 for the libm sincosf.
+__device__ __forceinline__ void sincos_rev(float arg, float* sn, float* cs) {
+  constexpr float INV2PI_HI = 0.15915494f;          // float(1 / 2pi)
+  constexpr float INV2PI_LO = 6.4206395e-09f;       // 1 / 2pi - INV2PI_HI
+  const float n = rintf(arg * INV2PI_HI);
+  float f = fmaf(arg, INV2PI_HI, -n);
+  f = fmaf(arg, INV2PI_LO, f);
+  *sn = __builtin_amdgcn_sinf(f);
+  *cs = __builtin_amdgcn_cosf(f);
+}
+
+// The lane's frequencies for rebuilding its embedding slice from a relative pose.
+struct EFreq {
+  float fx[2], fw[4];
+  __device__ __forceinline__ void init(const float* __restrict__ fxy, const float* __restrict__ fyaw, int s8) {
+    fx[0] = fx[1] = 0.f;
+    fw[0] = fw[1] = fw[2] = fw[3] = 0.f;
+    if (fxy == nullptr) return;
+    // the reference's buffers are repeat-interleaved [f0,f0,f1,f1,..]; the even entry serves the (cos, sin) pair
+    fx[0] = fxy[2 * (2 * s8)];
+    fx[1] = fxy[2 * (2 * s8 + 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[i] = fyaw[2 * (4 * s8 + i)];
+  }
+  __device__ __forceinline__ void embed(const float* __restrict__ rel3, ESlice& e) const {
+    const float x = rel3[0], y = rel3[1], w = rel3[2];
+    sincos_rev(x * fx[0], &e.xs.x, &e.xc.x);
+    sincos_rev(x * fx[1], &e.xs.y, &e.xc.y);
+    sincos_rev(y * fx[0], &e.ys.x, &e.yc.x);
+    sincos_rev(y * fx[1], &e.ys.y, &e.yc.y);
+    sincos_rev(w * fw[0], &e.ws.x, &e.wc.x);
+    sincos_rev(w * fw[1], &e.ws.y, &e.wc.y);
+    sincos_rev(w * fw[2], &e.ws.z, &e.wc.z);
+    sincos_rev(w * fw[3], &e.ws.w, &e.wc.w);
+  }
+};
+
+__device__ __forceinline__ void load_e(const tbx_attn_seg_t& S, int64_t pi, int s8, const EFreq& fq, ESlice& e) {
+  if (S.emb != nullptr)
+    e.load(S.emb + pi * DR, s8);
+  else
+    fq.embed(S.rel_pose + pi * 3, e);
+}
 
 // WPR = wavefronts cooperating on one source row: 1 for large grids (a wave per row, 4 rows per workgroup), 4 for small
 // grids (the closed loop at a few scenes is latency-bound: 4 waves split a row's targets and combine through LDS).
 //
-// Single pass, online softmax: 8 lanes per target, 8 targets per wave per pass. The 8 lanes of a group read one full
-// 128-B line of the target's K row, V row and embedding row per step (coalesced gathers) - every row exactly once - and
-// keep, for THEIR target slot, a running (max, sum) per head and the un-normalised partial sums
-//   O_slot[c] += p[h(c)] v[c] ,  E_slot[h][c] += p[h] e[c]      (their 16-channel slice c)
+// Single pass, online softmax: 8 lanes per target, 8 targets per wave per pass. Each 8-lane group keeps, for ITS target
+// slot, a running (max, sum) per head and the un-normalised partial sums
+//   O_slot[c] += p[h(c)] v[c] ,  E_slot[h][c] += p[h] e[c]      (the lane's channel slices)
 // rescaled when the slot's running max grows. The 8 slots (and the WPR waves) are merged once per row:
 //   out = sum_slots exp(m_slot - M) acc_slot / sum_slots exp(m_slot - M) l_slot.
 // No LDS traffic and no barrier inside the target loop.
@@ -55,30 +166,30 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
 
   // ---- query side in registers
   const float* qrow = a.qbuf + (int64_t)row * a.ldq;
-  float4 qv[NH], qtv[NH][4];
+  float4 qv[NH];
+  ESlice qt[NH];
   float qb[NH];
+  EFreq fq;
+  fq.init(a.fxy, a.fyaw, s8);
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
     const float4 bk = *(const float4*)(a.rpe_k_bias + h * DH + s8 * 4);
     qb[h] = tbx::group8_sum(dot4(qv[h], bk));
-#pragma unroll
-    for (int st = 0; st < 4; ++st) qtv[h][st] = *(const float4*)(qrow + a.qt_off + h * DR + st * 32 + s8 * 4);
+    qt[h].load(qrow + a.qt_off + h * DR, s8);
   }
 
-  // ---- per-slot online softmax state and partial sums (this lane's 16-channel slice: channels st*32 + s8*4 .. +3)
+  // ---- per-slot online softmax state and partial sums
   float m_run[NH], l_run[NH];
-  float4 oacc[4], eacc[NH][4];
+  float4 oacc[NH];
+  ESlice eacc[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     m_run[h] = -INFINITY;
     l_run[h] = 0.f;
     oacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) eacc[h][st] = make_float4(0.f, 0.f, 0.f, 0.f);
+    eacc[h].zero();
   }
-  auto scale4 = [](float4& v, float f) { v.x *= f; v.y *= f; v.z *= f; v.w *= f; };
-  auto fma4 = [](float4& acc, float p, const float4 v) { acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w; };
 
   for (int base = wir * 8; base < ktot; base += 8 * WPR) {
     const int t = base + tg;
@@ -88,28 +199,25 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     const int kk = sg ? t - k0 : t;
     float acc[NH] = {0.f, 0.f, 0.f, 0.f};
     bool inv = true;
-    float4 v[4], e[4];
+    float4 v[4];
+    ESlice e;
+    e.zero();
 #pragma unroll
-    for (int st = 0; st < 4; ++st) v[st] = e[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int st = 0; st < 4; ++st) v[st] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
       const int64_t pi = (int64_t)row * S.k + kk;
       const int j = S.idx[pi];
       inv = S.invalid[pi] != 0;
       const float* trow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv;
-      const float* erow = S.emb + pi * DR;
       float4 kq[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         kq[st] = *(const float4*)(trow + S.k_off + st * 32 + s8 * 4);
-        e[st] = *(const float4*)(erow + st * 32 + s8 * 4);
         v[st] = *(const float4*)(trow + S.v_off + st * 32 + s8 * 4);
       }
+      load_e(S, pi, s8, fq, e);
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        acc[st] += dot4(kq[st], qv[st]);
-#pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h] += dot4(e[st], qtv[h][st]);
-      }
+      for (int h = 0; h < NH; ++h) acc[h] = dot4(kq[h], qv[h]) + e.dot(qt[h]);
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -120,13 +228,10 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         const float pr = expf(sc - m_new);
         l_run[h] = l_run[h] * alpha + pr;
         m_run[h] = m_new;
-        scale4(oacc[h], alpha);      // K/V channel block st == h belongs to head h
+        scale4(oacc[h], alpha);  // K/V channel block st == h belongs to head h
         fma4(oacc[h], pr, v[h]);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          scale4(eacc[h][st], alpha);
-          fma4(eacc[h][st], pr, e[st]);
-        }
+        eacc[h].scale(alpha);
+        eacc[h].fma(pr, e);
       }
     }
   }
@@ -142,25 +247,16 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     const float f = (m_run[h] == -INFINITY) ? 0.f : expf(m_run[h] - mm);
     float ll = l_run[h] * f;
     scale4(oacc[h], f);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) scale4(eacc[h][st], f);
+    eacc[h].scale(f);
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) ll += __shfl_xor(ll, off, 64);
     L[h] = ll;
-  }
-  auto red4 = [](float4 v) {
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
-      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
-      v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+      oacc[h].x += __shfl_xor(oacc[h].x, off, 64); oacc[h].y += __shfl_xor(oacc[h].y, off, 64);
+      oacc[h].z += __shfl_xor(oacc[h].z, off, 64); oacc[h].w += __shfl_xor(oacc[h].w, off, 64);
     }
-    return v;
-  };
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    oacc[h] = red4(oacc[h]);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) eacc[h][st] = red4(eacc[h][st]);
+    eacc[h].reduce_slots();
   }
   float* orow = a.out + (int64_t)row * a.ldo;
   if constexpr (WPR == 1) {
@@ -172,12 +268,9 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         float4 o = oacc[h];
         scale4(o, inv_l);
         *(float4*)(orow + h * DH + s8 * 4) = o;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          float4 ev = eacc[h][st];
-          scale4(ev, inv_l);
-          *(float4*)(orow + D + h * DR + st * 32 + s8 * 4) = ev;
-        }
+        ESlice ev = eacc[h];
+        ev.scale(inv_l);
+        ev.store(orow + D + h * DR, s8);
       }
     }
     if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
@@ -187,8 +280,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         *(float4*)(&red_s[wir][h * DH + s8 * 4]) = oacc[h];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) *(float4*)(&red_s[wir][D + h * DR + st * 32 + s8 * 4]) = eacc[h][st];
+        eacc[h].store(&red_s[wir][D + h * DR], s8);
       }
     }
     if (lane < NH) {
@@ -196,14 +288,13 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       red_s[wir][OUTW + NH + lane] = L[lane];
     }
     __syncthreads();
-    float Mx[NH], inv_l[NH], fw[WPR][NH];
+    float inv_l[NH], fw[WPR][NH];
     bool any_valid = false;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       float mm = -INFINITY;
 #pragma unroll
       for (int w = 0; w < WPR; ++w) mm = fmaxf(mm, red_s[w][OUTW + h]);
-      Mx[h] = mm;
       float ll = 0.f;
 #pragma unroll
       for (int w = 0; w < WPR; ++w) {
@@ -225,69 +316,25 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   }
 }
 
-}  // namespace
-
-extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
-                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
-                                   uint8_t* row_no_valid, void* stream) {
-  if (!qbuf || !rpe_k_bias || !segs || !out || !row_no_valid || n_batch <= 0 || n_src <= 0) return TBX_ERR_ARG;
-  if (n_seg < 1 || n_seg > 2 || ldo < D + NH * DR) return TBX_ERR_UNSUPPORTED;
-  if ((ldq % 4) || (q_off % 4) || (qt_off % 4) || (ldo % 4) || (((uintptr_t)qbuf) & 15) || (((uintptr_t)out) & 15) ||
-      (((uintptr_t)rpe_k_bias) & 15))
-    return TBX_ERR_ALIGN;
-  AttnArgs a;
-  int ktot = 0;
-  for (int i = 0; i < n_seg; ++i) {
-    const tbx_attn_seg_t& s = segs[i];
-    if (!s.kv || !s.idx || !s.invalid || !s.emb || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
-    if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (((uintptr_t)s.emb) & 15))
-      return TBX_ERR_ALIGN;
-    ktot += s.k;
-    a.seg[i] = s;
-  }
-  if (n_seg == 1) a.seg[1] = a.seg[0];
-  if (ktot > KMAX) return TBX_ERR_UNSUPPORTED;
-  a.qbuf = qbuf;
-  a.rpe_k_bias = rpe_k_bias;
-  a.out = out;
-  a.row_no_valid = row_no_valid;
-  a.ldq = ldq;
-  a.q_off = q_off;
-  a.qt_off = qt_off;
-  a.ldo = ldo;
-  a.n_rows = n_batch * n_src;
-  a.n_src = n_src;
-  a.n_seg = n_seg;
-  a.scale = 1.0f / sqrtf((float)DH);
-  if (a.n_rows >= 4096)
-    hipLaunchKernelGGL(knarpe_attn_kernel<1>, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(knarpe_attn_kernel<4>, dim3(a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
-}
-
 // =====================================================================================================================
-// Backward of the fused KNARPE attention (training). Same factorised math as the forward:
+// Backward (training). Same factorised math as the forward:
 //   s[h,t] = q_h.(k_h[idx_t] + bk_h) + qt_h.e_t ;  a = softmax(s * scale) (masked) ;  out = [sum_t a v_h | sum_t a e_t]
-// Given dout = [dO (128) | dE (4 x 128)] per row it produces
-//   dq, dqt (written to dqbuf at q_off / qt_off), dK / dV scattered with atomicAdd into the K/V-table-shaped gradient
-//   of each segment, and d(rpe_k_bias) (atomicAdd, 128 floats).
+// Given dout = [dO (128) | dE (4 x 128)] per row it produces dq, dqt (written to dqbuf at q_off / qt_off), dK / dV
+// scattered with atomicAdd into the K/V-table-shaped gradient of each segment, and d(rpe_k_bias) (atomicAdd, 128 floats).
 // The pose embeddings carry no gradient (relative poses are computed under no_grad in the reference, utils/rpe.py:7).
 // One wavefront per source row; probabilities are recomputed (nothing but the inputs is saved by the forward).
-namespace {
-
 struct AttnBwdArgs {
-  AttnArgs f;            // forward arguments (qbuf, segs, ...); f.out is unused
-  const float* dout;     // [rows, ldo] = dO | dE
-  float* dqbuf;          // [rows, ldq]: dq at q_off, dqt at qt_off (overwritten)
-  float* dkv[2];         // per segment, same [.., ld_kv] layout as seg.kv (accumulated)
-  float* dbias_k;        // [128] (accumulated)
+  AttnArgs f;         // forward arguments (qbuf, segs, ...); f.out is unused
+  const float* dout;  // [rows, ldo] = dO | dE
+  float* dqbuf;       // [rows, ldq]: dq at q_off, dqt at qt_off (overwritten)
+  float* dkv[2];      // per segment, same [.., ld_kv] layout as seg.kv (accumulated)
+  float* dbias_k;     // [128] (accumulated)
 };
 
 __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs b) {
   const AttnArgs& a = b.f;
-  __shared__ float p_s[4][NH][KMAX];   // probabilities a[h,t]
-  __shared__ float d_s[4][NH][KMAX];   // da[h,t], then dS[h,t]
+  __shared__ float p_s[4][NH][KMAX];  // probabilities a[h,t]
+  __shared__ float d_s[4][NH][KMAX];  // da[h,t], then dS[h,t]
   __shared__ uint8_t inv_s[4][KMAX];
   const int lane = threadIdx.x & 63;
   const int rib = threadIdx.x >> 6;
@@ -299,6 +346,8 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   const int s8 = lane & 7, tg = lane >> 3;
   const float* qrow = a.qbuf + (int64_t)row * a.ldq;
   float4 qv[NH], bkv[NH];
+  EFreq fq;
+  fq.init(a.fxy, a.fyaw, s8);
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
@@ -307,13 +356,12 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   // ---- recompute raw scores
   bool any_valid = false;
   {
-    float4 qtv[NH][4];
+    ESlice qt[NH];
     float qb[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       qb[h] = tbx::group8_sum(dot4(qv[h], bkv[h]));
-#pragma unroll
-      for (int st = 0; st < 4; ++st) qtv[h][st] = *(const float4*)(qrow + a.qt_off + h * DR + st * 32 + s8 * 4);
+      qt[h].load(qrow + a.qt_off + h * DR, s8);
     }
     for (int base = 0; base < ktot; base += 8) {
       const int t = base + tg;
@@ -328,15 +376,10 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
         const int j = S.idx[pi];
         inv = S.invalid[pi] != 0;
         const float* krow = S.kv + ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.k_off;
-        const float* erow = S.emb + pi * DR;
+        ESlice e;
+        load_e(S, pi, s8, fq, e);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const float4 kq = *(const float4*)(krow + st * 32 + s8 * 4);
-          const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
-          acc[st] += dot4(kq, qv[st]);
-#pragma unroll
-          for (int h = 0; h < NH; ++h) acc[h] += dot4(e, qtv[h][st]);
-        }
+        for (int h = 0; h < NH; ++h) acc[h] = dot4(*(const float4*)(krow + h * 32 + s8 * 4), qv[h]) + e.dot(qt[h]);
       }
 #pragma unroll
       for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]) + qb[h];
@@ -349,7 +392,8 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // ---- softmax (probabilities back into p_s)
+  // ---- softmax (probabilities back into p_s); rows without a valid target get zero probabilities (their forward output
+  //      is zero and the caller masks them, so every gradient of such a row is zero)
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     float sv[2];
@@ -358,7 +402,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
     for (int q = 0; q < 2; ++q) {
       const int t = lane + 64 * q;
       float sc = -INFINITY;
-      if (t < ktot && !(any_valid && inv_s[rib][t] != 0)) sc = p_s[rib][h][t] * a.scale;
+      if (t < ktot && any_valid && inv_s[rib][t] == 0) sc = p_s[rib][h][t] * a.scale;
       sv[q] = sc;
       m = fmaxf(m, sc);
     }
@@ -370,10 +414,11 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
       sum += sv[q];
     }
     sum = tbx::wave_sum(sum);
+    const float inv_sum = any_valid ? 1.0f / sum : 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = lane + 64 * q;
-      if (t < ktot) p_s[rib][h][t] = sv[q] / sum;
+      if (t < ktot) p_s[rib][h][t] = sv[q] * inv_sum;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -383,11 +428,9 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
 #pragma unroll
   for (int h = 0; h < NH; ++h) dov[h] = *(const float4*)(drow + h * DH + s8 * 4);
   {
-    float4 dev[NH][4];
+    ESlice dev[NH];
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int st = 0; st < 4; ++st) dev[h][st] = *(const float4*)(drow + D + h * DR + st * 32 + s8 * 4);
+    for (int h = 0; h < NH; ++h) dev[h].load(drow + D + h * DR, s8);
     for (int base = 0; base < ktot; base += 8) {
       const int t = base + tg;
       const bool active = t < ktot;
@@ -399,15 +442,10 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
         const int64_t pi = (int64_t)row * S.k + kk;
         const int j = S.idx[pi];
         const float* vrow = S.kv + ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv + S.v_off;
-        const float* erow = S.emb + pi * DR;
+        ESlice e;
+        load_e(S, pi, s8, fq, e);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const float4 v = *(const float4*)(vrow + st * 32 + s8 * 4);
-          const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
-          acc[st] += dot4(v, dov[st]);
-#pragma unroll
-          for (int h = 0; h < NH; ++h) acc[h] += dot4(e, dev[h][st]);
-        }
+        for (int h = 0; h < NH; ++h) acc[h] = dot4(*(const float4*)(vrow + h * 32 + s8 * 4), dov[h]) + e.dot(dev[h]);
       }
 #pragma unroll
       for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]);
@@ -436,12 +474,12 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   }
   __builtin_amdgcn_wave_barrier();
   // ---- pass C: dq, dqt, d bias_k (registers, reduced over the 8 target slots at the end); dK, dV scattered
-  float4 dq[NH], dbk[NH], dqt[NH][4];
+  float4 dq[NH], dbk[NH];
+  ESlice dqt[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     dq[h] = dbk[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) dqt[h][st] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dqt[h].zero();
   }
   for (int base = 0; base < ktot; base += 8) {
     const int t = base + tg;
@@ -452,7 +490,6 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
     const int j = S.idx[pi];
     const int64_t trow = ((int64_t)(bidx / S.batch_div) * S.n_tgt + j) * S.ld_kv;
     const float* krow = S.kv + trow + S.k_off;
-    const float* erow = S.emb + pi * DR;
     float* dk = b.dkv[sg] + trow + S.k_off;
     float* dv = b.dkv[sg] + trow + S.v_off;
     float ds[NH], pa[NH];
@@ -464,27 +501,24 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
       any = any || ds[h] != 0.f || pa[h] != 0.f;
     }
     if (!any) continue;
+    ESlice e;
+    load_e(S, pi, s8, fq, e);
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {  // st doubles as the head of the K/V channel block
-      const float4 kq = *(const float4*)(krow + st * 32 + s8 * 4);
-      const float4 e = *(const float4*)(erow + st * 32 + s8 * 4);
-      const float g = ds[st];
-      dq[st].x += g * (kq.x + bkv[st].x); dq[st].y += g * (kq.y + bkv[st].y);
-      dq[st].z += g * (kq.z + bkv[st].z); dq[st].w += g * (kq.w + bkv[st].w);
-      dbk[st].x += g * qv[st].x; dbk[st].y += g * qv[st].y; dbk[st].z += g * qv[st].z; dbk[st].w += g * qv[st].w;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        dqt[h][st].x += ds[h] * e.x; dqt[h][st].y += ds[h] * e.y; dqt[h][st].z += ds[h] * e.z; dqt[h][st].w += ds[h] * e.w;
-      }
-      const int c0 = st * 32 + s8 * 4;
-      atomicAdd(dk + c0 + 0, g * qv[st].x); atomicAdd(dk + c0 + 1, g * qv[st].y);
-      atomicAdd(dk + c0 + 2, g * qv[st].z); atomicAdd(dk + c0 + 3, g * qv[st].w);
-      const float pv = pa[st];
-      atomicAdd(dv + c0 + 0, pv * dov[st].x); atomicAdd(dv + c0 + 1, pv * dov[st].y);
-      atomicAdd(dv + c0 + 2, pv * dov[st].z); atomicAdd(dv + c0 + 3, pv * dov[st].w);
+    for (int h = 0; h < NH; ++h) {  // h doubles as the K/V channel block
+      const float4 kq = *(const float4*)(krow + h * 32 + s8 * 4);
+      const float g = ds[h];
+      dq[h].x += g * (kq.x + bkv[h].x); dq[h].y += g * (kq.y + bkv[h].y);
+      dq[h].z += g * (kq.z + bkv[h].z); dq[h].w += g * (kq.w + bkv[h].w);
+      fma4(dbk[h], g, qv[h]);
+      dqt[h].fma(g, e);
+      const int c0 = h * 32 + s8 * 4;
+      atomicAdd(dk + c0 + 0, g * qv[h].x); atomicAdd(dk + c0 + 1, g * qv[h].y);
+      atomicAdd(dk + c0 + 2, g * qv[h].z); atomicAdd(dk + c0 + 3, g * qv[h].w);
+      const float pv = pa[h];
+      atomicAdd(dv + c0 + 0, pv * dov[h].x); atomicAdd(dv + c0 + 1, pv * dov[h].y);
+      atomicAdd(dv + c0 + 2, pv * dov[h].z); atomicAdd(dv + c0 + 3, pv * dov[h].w);
     }
   }
-  // reduce over the 8 target slots (lanes with equal s8)
   auto red4 = [](float4 v) {
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
@@ -498,56 +532,84 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   for (int h = 0; h < NH; ++h) {
     const float4 r = red4(dq[h]);
     const float4 rb = red4(dbk[h]);
+    dqt[h].reduce_slots();
     if (tg == 0) {
       *(float4*)(dqrow + a.q_off + h * DH + s8 * 4) = r;
       float* db = b.dbias_k + h * DH + s8 * 4;
       atomicAdd(db + 0, rb.x); atomicAdd(db + 1, rb.y); atomicAdd(db + 2, rb.z); atomicAdd(db + 3, rb.w);
-    }
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const float4 rt = red4(dqt[h][st]);
-      if (tg == 0) *(float4*)(dqrow + a.qt_off + h * DR + st * 32 + s8 * 4) = rt;
+      dqt[h].store(dqrow + a.qt_off + h * DR, s8);
     }
   }
 }
 
-}  // namespace
-
-extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
-                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
-                                   float* const* dkv, float* dbias_k, void* stream) {
-  if (!qbuf || !rpe_k_bias || !segs || !dout || !dqbuf || !dkv || !dbias_k || n_batch <= 0 || n_src <= 0) return TBX_ERR_ARG;
+int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
+              const tbx_attn_seg_t* segs, int n_seg, int ldo, const float* fxy, const float* fyaw) {
+  if (!qbuf || !rpe_k_bias || !segs || n_batch <= 0 || n_src <= 0) return TBX_ERR_ARG;
   if (n_seg < 1 || n_seg > 2 || ldo < D + NH * DR) return TBX_ERR_UNSUPPORTED;
-  if ((ldq % 4) || (q_off % 4) || (qt_off % 4) || (ldo % 4) || (((uintptr_t)qbuf) & 15) || (((uintptr_t)dout) & 15) ||
-      (((uintptr_t)dqbuf) & 15) || (((uintptr_t)rpe_k_bias) & 15))
+  if ((ldq % 4) || (q_off % 4) || (qt_off % 4) || (ldo % 4) || (((uintptr_t)qbuf) & 15) || (((uintptr_t)rpe_k_bias) & 15))
     return TBX_ERR_ALIGN;
-  AttnBwdArgs b;
   int ktot = 0;
   for (int i = 0; i < n_seg; ++i) {
     const tbx_attn_seg_t& s = segs[i];
-    if (!s.kv || !s.idx || !s.invalid || !s.emb || !dkv[i] || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
-    if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (((uintptr_t)s.emb) & 15)) return TBX_ERR_ALIGN;
+    if (!s.kv || !s.idx || !s.invalid || (!s.emb && !s.rel_pose) || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
+    if (!s.emb && (!fxy || !fyaw)) return TBX_ERR_ARG;
+    if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (s.emb && (((uintptr_t)s.emb) & 15)))
+      return TBX_ERR_ALIGN;
     ktot += s.k;
-    b.f.seg[i] = s;
+    a.seg[i] = s;
+  }
+  if (n_seg == 1) a.seg[1] = a.seg[0];
+  if (ktot > KMAX) return TBX_ERR_UNSUPPORTED;
+  a.qbuf = qbuf;
+  a.rpe_k_bias = rpe_k_bias;
+  a.fxy = fxy;
+  a.fyaw = fyaw;
+  a.out = nullptr;
+  a.row_no_valid = nullptr;
+  a.ldq = ldq;
+  a.q_off = q_off;
+  a.qt_off = qt_off;
+  a.ldo = ldo;
+  a.n_rows = n_batch * n_src;
+  a.n_src = n_src;
+  a.n_seg = n_seg;
+  a.scale = 1.0f / sqrtf((float)DH);
+  return TBX_OK;
+}
+
+}  // namespace
+
+extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
+                                   uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, void* stream) {
+  if (!out || !row_no_valid) return TBX_ERR_ARG;
+  if (((uintptr_t)out) & 15) return TBX_ERR_ALIGN;
+  AttnArgs a;
+  const int rc = fill_args(a, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  a.out = out;
+  a.row_no_valid = row_no_valid;
+  if (a.n_rows >= 4096)
+    hipLaunchKernelGGL(knarpe_attn_kernel<1>, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(knarpe_attn_kernel<4>, dim3(a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
+                                   float* const* dkv, float* dbias_k, const float* freqs_xy, const float* freqs_yaw,
+                                   void* stream) {
+  if (!dout || !dqbuf || !dkv || !dbias_k) return TBX_ERR_ARG;
+  if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
+  AttnBwdArgs b;
+  const int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  for (int i = 0; i < n_seg; ++i) {
+    if (!dkv[i]) return TBX_ERR_ARG;
     b.dkv[i] = dkv[i];
   }
-  if (n_seg == 1) {
-    b.f.seg[1] = b.f.seg[0];
-    b.dkv[1] = b.dkv[0];
-  }
-  if (ktot > KMAX) return TBX_ERR_UNSUPPORTED;
-  b.f.qbuf = qbuf;
-  b.f.rpe_k_bias = rpe_k_bias;
-  b.f.out = nullptr;
-  b.f.row_no_valid = nullptr;
-  b.f.ldq = ldq;
-  b.f.q_off = q_off;
-  b.f.qt_off = qt_off;
-  b.f.ldo = ldo;
-  b.f.n_rows = n_batch * n_src;
-  b.f.n_src = n_src;
-  b.f.n_seg = n_seg;
-  b.f.scale = 1.0f / sqrtf((float)DH);
+  if (n_seg == 1) b.dkv[1] = b.dkv[0];
   b.dout = dout;
   b.dqbuf = dqbuf;
   b.dbias_k = dbias_k;

@@ -94,19 +94,24 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
 
 
 class SelfKnn:
-    """KNN set among the source tokens themselves (idx i32 / invalid u8 / emb f32, all [n,S,K(,128)])."""
+    """KNN set among the source tokens themselves: idx i32 / invalid u8 [n,S,K] and either the materialised pose embedding
+    emb f32 [n,S,K,128] or the relative pose rel f32 [n,S,K,3] (embedding rebuilt inside the attention kernel)."""
 
-    def __init__(self, idx, invalid, emb):
-        self.idx, self.invalid, self.emb = idx.contiguous(), _u8(invalid).contiguous(), emb.contiguous()
+    def __init__(self, idx, invalid, emb=None, rel=None):
+        self.idx, self.invalid = idx.contiguous(), _u8(invalid).contiguous()
+        self.emb = None if emb is None else emb.contiguous()
+        self.rel = None if rel is None else rel.contiguous()
 
 
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
-              tile_rows: int = 16) -> None:
+              tile_rows: int = 16, pose_rpe=None) -> None:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE. `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
     appends row-local stages to the last layer's chain (x is in BUF1[:, 0:128] at that point)."""
     assert x.shape == (n * S, D) and x.is_contiguous()
+    fxy = None if pose_rpe is None else pose_rpe.pe_xy.freqs
+    fyw = None if pose_rpe is None else pose_rpe.pe_yaw.freqs
     rows = n * S
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
@@ -137,8 +142,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     ch.run(rows)
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
-        self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb)
-        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag)
+        self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel)
+        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw)
         ch = Chain(tile_rows, 1028)
         ch.load(x, BUF1, 0, n=D)
         emit_attn_out(ch, a1, obuf, flag)
@@ -148,7 +153,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             w = emit_qkv(ch, layer.attn, BUF0, 0, BUF0, D, with_kv=False)
             ch.store(BUF0, D, w, q2)
             ch.run(rows)
-            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag)
+            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw)
             ch = Chain(tile_rows, 1028)
             ch.load(x, BUF1, 0, n=D)
             emit_attn_out(ch, layer.attn, obuf, flag)

@@ -29,7 +29,7 @@ class Stage(C.Structure):
 
 
 class AttnSeg(C.Structure):
-    _fields_ = [("kv", C.c_void_p), ("idx", C.c_void_p), ("invalid", C.c_void_p), ("emb", C.c_void_p)] + [
+    _fields_ = [("kv", C.c_void_p), ("idx", C.c_void_p), ("invalid", C.c_void_p), ("emb", C.c_void_p), ("rel_pose", C.c_void_p)] + [
         (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k")]
 
 
@@ -73,9 +73,9 @@ def load():
     i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
     lib.tbx_knn_embed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.tbx_pose_embed.argtypes = [vp, i64, vp, vp, i32, vp, i32, i32, vp]
-    lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp]
+    lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
-                                        C.POINTER(C.c_void_p), vp, vp]
+                                        C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                    i32, vp, vp, vp]
@@ -147,33 +147,37 @@ def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int =
 class Seg:
     """One target segment of a KNARPE attention call: a K/V table + the KNN set that indexes it."""
 
-    def __init__(self, kv, k_off, v_off, n_tgt, idx, invalid, emb, batch_div=1):
+    def __init__(self, kv, k_off, v_off, n_tgt, idx, invalid, emb=None, batch_div=1, rel=None):
+        """emb [n,S,k,128] (materialised embedding) or rel [n,S,k,3] (relative pose; embedding rebuilt in-kernel)."""
         assert kv.dim() == 2 and kv.stride(1) == 1
+        assert (emb is None) != (rel is None), "exactly one of emb / rel"
         self.kv, self.k_off, self.v_off, self.n_tgt, self.batch_div = kv, k_off, v_off, n_tgt, batch_div
-        self.idx, self.invalid, self.emb = idx, invalid, emb
+        self.idx, self.invalid, self.emb, self.rel = idx, invalid, emb, rel
         self.k = idx.shape[-1]
 
     def c(self) -> AttnSeg:
         return AttnSeg(_ptr(self.kv, torch.float32), _cptr(self.idx, torch.int32), _cptr(self.invalid, torch.uint8),
-                       _cptr(self.emb, torch.float32), self.kv.stride(0), self.k_off, self.v_off, self.n_tgt,
-                       self.batch_div, self.k)
+                       _cptr(self.emb, torch.float32), _cptr(self.rel, torch.float32), self.kv.stride(0), self.k_off, self.v_off,
+                       self.n_tgt, self.batch_div, self.k)
 
 
-def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid):
+def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid,
+                freqs_xy=None, freqs_yaw=None):
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
     rc = load().tbx_knarpe_attn_fwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
                                     n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
-                                    _ptr(row_no_valid, torch.uint8), stream_ptr())
+                                    _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy), _cptr(freqs_yaw), stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd")
 
 
 def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
-                    dkv: Sequence[torch.Tensor], dbias_k):
+                    dkv: Sequence[torch.Tensor], dbias_k, freqs_xy=None, freqs_yaw=None):
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
     dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
     rc = load().tbx_knarpe_attn_bwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
                                     n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
-                                    _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), stream_ptr())
+                                    _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy), _cptr(freqs_yaw),
+                                    stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd")
 
 

@@ -79,12 +79,13 @@ class AgentEncoder(nn.Module):
         mp_inv = mp.get("mp_token_invalid_u8")
         if mp_inv is None:
             mp_inv = mp["mp_token_invalid_u8"] = mp["mp_token_invalid"].to(torch.uint8).contiguous()
-        fx, fy, pd = rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim
-        i_aa, m_aa, _, e_aa = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit, fx, fy, pd)
-        i_am, m_am, _, e_am = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
-                                            self.dist_limit, fx, fy, pd, tgt_batch_div=mp_batch_div)
-        i_at, m_at, _, e_at = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl, self.dist_limit,
-                                            fx, fy, pd)
+        # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
+        # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
+        kw = dict(want_rel_pose=True, want_emb=False)
+        i_aa, m_aa, r_aa, _ = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit, **kw)
+        i_am, m_am, r_am, _ = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
+                                            self.dist_limit, tgt_batch_div=mp_batch_div, **kw)
+        i_at, m_at, r_at, _ = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl, self.dist_limit, **kw)
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at)
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
@@ -93,9 +94,9 @@ class AgentEncoder(nn.Module):
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
         ch.run(n * A * W, group_rows=W)
         kv_mp = self.kv_mp(mp)
-        run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, e_aa),
-                  cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, e_am, mp_batch_div),
-                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, e_at)], tail=tail)
+        run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa),
+                  cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
+                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, rel=r_at)], tail=tail, pose_rpe=rp)
         return x, prep
 
     @staticmethod

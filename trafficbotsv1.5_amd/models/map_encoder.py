@@ -46,8 +46,8 @@ class MapEncoder(nn.Module):
         cur = self.input_encoder.emit(ch, attr, pe)
         emit_pointnet(ch, self.pl_encoder, row_inv, feat, x_buf=cur)
         ch.run(rows, group_rows=N)
-        idx, inv, _, emb = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn, self.dist_limit,
-                                         self.pose_rpe.pe_xy.freqs, self.pose_rpe.pe_yaw.freqs, self.pose_rpe.out_dim)
-        run_block(self.tf_mp2mp, feat, tok_inv, n, M, SelfKnn(idx, inv, emb))
+        idx, inv, rel, _ = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn, self.dist_limit,
+                                         want_rel_pose=True, want_emb=False)
+        run_block(self.tf_mp2mp, feat, tok_inv, n, M, SelfKnn(idx, inv, rel=rel), pose_rpe=self.pose_rpe)
         return {"mp_token_invalid": tok_inv.bool(), "mp_token_feature": feat.view(n, M, d), "mp_token_pose": tok_pose,
                 "mp_token_type": mp_type, "knn_idx_mp2mp": idx, "knn_invalid_mp2mp": inv}

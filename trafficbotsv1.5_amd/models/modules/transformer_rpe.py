@@ -58,10 +58,10 @@ class TransformerBlockRPE(nn.Module):
         x = src.reshape(n * S, d).contiguous().float().clone()
         inv = src_padding_mask if src_padding_mask is not None else torch.zeros(n, S, dtype=torch.bool, device=src.device)
         if self.mode == "enc_self_attn":
-            knn = SelfKnn(tgt.to(torch.int32), tgt_padding_mask, rpe.float())
+            knn = SelfKnn(tgt.to(torch.int32), tgt_padding_mask, emb=rpe.float())
             run_block(self, x, inv, n, S, knn)
         elif self.mode == "dec_cross_attn":
-            knn = SelfKnn(decoder_tgt.to(torch.int32), decoder_tgt_padding_mask, decoder_rpe.float())
+            knn = SelfKnn(decoder_tgt.to(torch.int32), decoder_tgt_padding_mask, emb=decoder_rpe.float())
             K = tgt.shape[2]
             kv = kv_tables(tgt.reshape(n * S * K, d).contiguous().float(), [(l.norm_tgt, l.attn) for l in self.layers])
             idx = torch.arange(S * K, dtype=torch.int32, device=src.device).view(1, S, K).expand(n, -1, -1).contiguous()

@@ -52,12 +52,17 @@ class TrafficLightEncoder(nn.Module):
              "tl_token_attr": mp_token_feature[bsel, tl_attr].contiguous()}
         pose = t["tl_token_pose"]
         mp_pose = mp_token_pose.float().contiguous()
-        i_tt, m_tt, _, e_tt = hip.knn_embed(pose, tl_inv, pose, tl_inv, self.n_tgt_knn_tl2tl, self.dist_limit, rp.pe_xy.freqs,
-                                            rp.pe_yaw.freqs, rp.out_dim)
-        i_tm, m_tm, _, e_tm = hip.knn_embed(pose, tl_inv, mp_pose, mp_inv, self.n_tgt_knn_tl2mp, self.dist_limit,
-                                            rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim, tgt_batch_div=mp_batch_div)
-        t.update(knn_idx_tl2tl=i_tt, knn_invalid_tl2tl=m_tt, rpe_tl2tl=e_tt, knn_idx_tl2mp=i_tm, knn_invalid_tl2mp=m_tm,
-                 rpe_tl2mp=e_tm, mp_batch_div=mp_batch_div, n_mp=M, mp_feat_flat=mp_feat)
+        # Static per scene. Few rollouts: materialise the 128-d pose embeddings once (every step then just reads them);
+        # many rollouts: keep only the 12-B relative poses and let the attention kernel rebuild the embedding (the step is
+        # HBM-bound there and the materialised form is 512 B per pair per layer).
+        mat = n * L < 2048
+        i_tt, m_tt, r_tt, e_tt = hip.knn_embed(pose, tl_inv, pose, tl_inv, self.n_tgt_knn_tl2tl, self.dist_limit, rp.pe_xy.freqs,
+                                               rp.pe_yaw.freqs, rp.out_dim, want_rel_pose=not mat, want_emb=mat)
+        i_tm, m_tm, r_tm, e_tm = hip.knn_embed(pose, tl_inv, mp_pose, mp_inv, self.n_tgt_knn_tl2mp, self.dist_limit, rp.pe_xy.freqs,
+                                               rp.pe_yaw.freqs, rp.out_dim, tgt_batch_div=mp_batch_div, want_rel_pose=not mat,
+                                               want_emb=mat)
+        t.update(knn_idx_tl2tl=i_tt, knn_invalid_tl2tl=m_tt, rpe_tl2tl=e_tt, rel_tl2tl=r_tt, knn_idx_tl2mp=i_tm,
+                 knn_invalid_tl2mp=m_tm, rpe_tl2mp=e_tm, rel_tl2mp=r_tm, mp_batch_div=mp_batch_div, n_mp=M, mp_feat_flat=mp_feat)
         return t
 
     def _kv_mp(self, t: Dict[str, Tensor]) -> Tensor:
@@ -84,10 +89,10 @@ class TrafficLightEncoder(nn.Module):
         ch.run(rows, group_rows=W)
         kv = self._kv_mp(t)
         M, div = t["n_mp"], t["mp_batch_div"]
-        knn = SelfKnn(t["knn_idx_tl2tl"], t["knn_invalid_tl2tl"], t["rpe_tl2tl"])
+        knn = SelfKnn(t["knn_idx_tl2tl"], t["knn_invalid_tl2tl"], t["rpe_tl2tl"], rel=t["rel_tl2tl"])
         run_block(self.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, knn,
                   cross=lambda l: [Seg(kv, l * 2 * D, l * 2 * D + D, M, t["knn_idx_tl2mp"], t["knn_invalid_tl2mp"],
-                                       t["rpe_tl2mp"], div)], tail=tail)
+                                       t["rpe_tl2mp"], div, rel=t["rel_tl2mp"])], tail=tail, pose_rpe=self.pose_rpe)
         return x
 
     @staticmethod

@@ -29,17 +29,21 @@ class KnarpeAttnFn(torch.autograd.Function):
     """out [rows, 640] = [sum_t a v | sum_t a e (4 heads)], flag [rows] (no valid target) for 1-2 target segments."""
 
     @staticmethod
-    def forward(ctx, q, qt, bias_k, n, S, meta, *kvs):
-        # meta: list of (idx, invalid, emb, n_tgt, batch_div) per segment; kvs: K|V tables [tokens, 256]
+    def _segs(kvs, meta):
+        # meta per segment: (idx, invalid, emb | None, rel | None, n_tgt, batch_div)
+        return [Seg(kv, 0, D, m[4], m[0], m[1], m[2], m[5], rel=m[3]) for kv, m in zip(kvs, meta)]
+
+    @staticmethod
+    def forward(ctx, q, qt, bias_k, n, S, meta, freqs, *kvs):
+        # kvs: K|V tables [tokens, 256]; freqs = (pose_rpe.pe_xy.freqs, pose_rpe.pe_yaw.freqs) or (None, None)
         qbuf = torch.cat([q, qt], 1).contiguous()
         kvs = [kv.contiguous() for kv in kvs]
-        segs = [Seg(kv, 0, D, m[3], m[0], m[1], m[2], m[4]) for kv, m in zip(kvs, meta)]
         out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=q.device)
         flag = torch.empty(n * S, dtype=torch.uint8, device=q.device)
         bias_k = bias_k.contiguous()
-        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, segs, out, flag)
+        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), out, flag, *freqs)
         ctx.save_for_backward(qbuf, bias_k, *kvs)
-        ctx.meta, ctx.n, ctx.S = meta, n, S
+        ctx.meta, ctx.n, ctx.S, ctx.freqs = meta, n, S, freqs
         ctx.mark_non_differentiable(flag)
         return out, flag
 
@@ -47,20 +51,21 @@ class KnarpeAttnFn(torch.autograd.Function):
     def backward(ctx, dout, _dflag):
         qbuf, bias_k, *kvs = ctx.saved_tensors
         meta, n, S = ctx.meta, ctx.n, ctx.S
-        segs = [Seg(kv, 0, D, m[3], m[0], m[1], m[2], m[4]) for kv, m in zip(kvs, meta)]
         dq = torch.empty_like(qbuf)
         dkv = [torch.zeros_like(kv) for kv in kvs]
         db = torch.zeros_like(bias_k)
-        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, segs, dout.contiguous(), dq, dkv, db)
-        return (dq[:, :D], dq[:, D:], db, None, None, None, *dkv)
+        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs)
+        return (dq[:, :D], dq[:, D:], db, None, None, None, None, *dkv)
 
 
 class Targets:
     """One target segment in table form: tokens [n_tables*T, 128] (already normalised), KNN set, sharing factor."""
 
-    def __init__(self, tokens: Tensor, idx: Tensor, invalid: Tensor, emb: Tensor, n_tgt: int, batch_div: int = 1,
-                 cache: Optional[dict] = None, key: Optional[str] = None):
+    def __init__(self, tokens: Tensor, idx: Tensor, invalid: Tensor, emb: Optional[Tensor], n_tgt: int, batch_div: int = 1,
+                 cache: Optional[dict] = None, key: Optional[str] = None, rel: Optional[Tensor] = None, freqs=(None, None)):
+        """Pose information per pair: `emb` [n,S,K,128] materialised, or `rel` [n,S,K,3] + freqs (rebuilt in-kernel)."""
         self.tokens, self.idx, self.invalid, self.emb, self.n_tgt, self.batch_div = tokens, idx, invalid, emb, n_tgt, batch_div
+        self.rel, self.freqs = rel, freqs
         self.cache, self.key = cache, key  # static targets (map tokens): K/V tables computed once per training step
 
 
@@ -83,8 +88,9 @@ def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor
     rows = xq.shape[0]
     q = F.linear(xq, W[:D], b[:D])
     qt = torch.einsum("rhj,hjc->rhc", q.view(rows, NH, DH), wr[:D].view(NH, DH, D)).reshape(rows, NH * D)
-    meta = [(t.idx, t.invalid, t.emb, t.n_tgt, t.batch_div) for t in targets]
-    out, flag = KnarpeAttnFn.apply(q, qt, br[:D], n, S, meta, *kvs)
+    meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div) for t in targets]
+    freqs = next((t.freqs for t in targets if t.rel is not None), (None, None))
+    out, flag = KnarpeAttnFn.apply(q, qt, br[:D], n, S, meta, freqs, *kvs)
     o = out[:, :D] + (torch.einsum("rhc,hjc->rhj", out[:, D:].reshape(rows, NH, D), wr[D:].view(NH, DH, D))
                       + br[D:].view(NH, DH)).reshape(rows, D)
     y = F.linear(o, attn.out_proj_weight, attn.out_proj_bias)
@@ -97,21 +103,21 @@ def _drop(x: Tensor, p: float, training: bool) -> Tensor:
 
 def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, self_knn, cross=None, p: float = 0.0,
                       training: bool = False) -> Tensor:
-    """transformer_rpe.py:48-135,207-245. x [n*S,128]; self_knn = (idx, invalid, emb) among the sources;
+    """transformer_rpe.py:48-135,207-245. x [n*S,128]; self_knn = Targets kwargs (idx, invalid, emb | rel, freqs) among the sources;
     cross(layer) -> list[Targets] with UN-normalised tokens (norm_tgt is applied here)."""
     ln = lambda m, t: F.layer_norm(t, (D,), m.weight, m.bias, m.eps)
     inv = src_invalid.reshape(-1).bool().unsqueeze(-1)
     for layer in block.layers:
         if block.mode == "dec_cross_attn":
             s = ln(layer.norm_src, x)
-            ts = Targets(s, *self_knn, n_tgt=S)
+            ts = Targets(s, n_tgt=S, **self_knn)
             x = x + _drop(attention(layer.attn_src, s, [ts], [kv_table(layer.attn_src, None, ts)], n, S), p, training)
             s2 = ln(layer.norm1, x)
             tg = list(cross(layer))
             x = x + _drop(attention(layer.attn, s2, tg, [kv_table(layer.attn, layer.norm_tgt, t) for t in tg], n, S), p, training)
         else:  # enc_self_attn: gathered targets share norm1 with the source
             s2 = ln(layer.norm1, x)
-            ts = Targets(s2, *self_knn, n_tgt=S)
+            ts = Targets(s2, n_tgt=S, **self_knn)
             x = x + _drop(attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S), p, training)
         h = F.relu(F.linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias))
         x = x + _drop(F.linear(_drop(h, p, training), layer.linear2.weight, layer.linear2.bias), p, training)
@@ -144,9 +150,10 @@ def pointnet(enc, x: Tensor, invalid: Tensor, training: bool = False) -> Tensor:
 
 
 def _knn(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, rp, div=1):
-    idx, inv, _, emb = hip.knn_embed(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim,
-                                     tgt_batch_div=div)
-    return idx, inv, emb
+    """-> kwargs of Targets: KNN indices / mask + the relative poses (the embedding is rebuilt inside the attention kernels)."""
+    idx, inv, rel, _ = hip.knn_embed(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, tgt_batch_div=div, want_rel_pose=True,
+                                     want_emb=False)
+    return dict(idx=idx, invalid=inv, emb=None, rel=rel, freqs=(rp.pe_xy.freqs, rp.pe_yaw.freqs))
 
 
 # ------------------------------------------------------------------------------------------------ encoders
@@ -195,7 +202,7 @@ def tl_encoder(te, hist_tl: Tensor, t: Dict[str, Tensor], training: bool) -> Ten
     M = t["mp_feat_for_tl"].shape[1]
     mp_tokens = t["mp_feat_for_tl"].reshape(-1, d)
     return transformer_block(te.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, t["tt"],
-                             cross=lambda layer: [Targets(mp_tokens, *t["tm"], n_tgt=M, cache=t.get("_kv_cache"), key="tl2mp")],
+                             cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=t.get("_kv_cache"), key="tl2mp", **t["tm"])],
                              p=te.tf_tl2tlmp.dropout_p, training=training)
 
 
@@ -215,8 +222,8 @@ def agent_encoder(ae, hist_valid, hist_pose, hist_motion, ag_attr6, mp, tl_inv_u
     M, L = mp["mp_token_pose"].shape[1], tl_pose.shape[1]
     mp_tokens = mp["mp_token_feature"].reshape(-1, d)
     x = transformer_block(ae.tf_ag2agmptl, x, tok_inv, n, A, aa,
-                          cross=lambda layer: [Targets(mp_tokens, *am, n_tgt=M, cache=mp.get("_kv_cache"), key="ag2mp"),
-                                               Targets(tl_feat, *at, n_tgt=L)],
+                          cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=mp.get("_kv_cache"), key="ag2mp", **am),
+                                               Targets(tl_feat, n_tgt=L, **at)],
                           p=ae.tf_ag2agmptl.dropout_p, training=training)
     return x, prep
 
