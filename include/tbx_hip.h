@@ -135,20 +135,28 @@ enum {
   TBX_F_ROW_IDX = 16, /* row_of(g) = ((const int32_t*)p1)[g]  (LOAD gather) */
   TBX_F_ROW_BATCH_MOD = 32 /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
 };
-enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2 };
-#define TBX_MAX_STAGES 48
+enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
+       TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };
+#define TBX_MAX_STAGES 44
 #define TBX_AUX_LD 260
 
 typedef struct tbx_stage {
-  int32_t op, src, dst, src_col, dst_col, k, n, act, flags, ld, div, reserved;
+  int32_t op, src, dst, src_col, dst_col, k, n, act, flags, ld, div, reserved, ld2, pad;
   float f0, f1;
   const void* p0;
   const void* p1;
+  const void* p2;
 } tbx_stage_t;
 
 /* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                  int ldw, void* stream);
+
+/* Same, with one LDS row width per buffer (BUF0 / BUF1 / AUX): programs whose wide intermediates live in BUF0 only (and
+ * whose wide outputs go straight to global memory, TBX_BUF_GLOBAL) fit 32-row tiles or two workgroups per CU.
+ * LDS = (ldw0 + ldw1 + ld_aux) * tile_rows * 4 bytes <= 160 KiB. */
+int tbx_rowchain_ex(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
+                    int ldw0, int ldw1, int ld_aux, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Per-step feature preparation (token frames, attribute rows, input pose embeddings).

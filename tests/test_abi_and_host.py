@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(hip):
     lib = hip.load()
     syms = hip.declared_symbols()
     assert set(syms) >= {"tbx_version", "tbx_error_string", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd",
-                         "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep", "tbx_map_prep", "tbx_sim_step"}
+                         "tbx_rowchain", "tbx_rowchain_ex", "tbx_knarpe_attn_bwd", "tbx_agent_prep", "tbx_tl_prep", "tbx_map_prep", "tbx_sim_step"}
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.tbx_version() == 1
@@ -91,4 +91,4 @@ def test_chain_program_encoding(hip):
     ch._add(op=hip.OP_COPY, src=0, dst=1, n=4)
     st = ch.stages[0]
     assert (st.op, st.src, st.dst, st.n) == (hip.OP_COPY, 0, 1, 4)
-    assert C.sizeof(hip.Stage) == 72 and C.sizeof(hip.AttnSeg) == 64
+    assert C.sizeof(hip.Stage) == 88 and C.sizeof(hip.AttnSeg) == 64

@@ -14,7 +14,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import hip
-from .hip import AUX, BUF0, BUF1, Chain, Seg
+from .hip import AUX, BUF0, BUF1, GLOBAL, Chain, Seg
 
 D, NH, DH = 128, 4, 32
 QKV_LD, Q_LD, O_LD = 896, 640, 640  # [q|k|v|qt] , [q|qt] , [sum a v | sum a e per head]
@@ -93,6 +93,45 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
     ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid)
 
 
+# LDS row widths of the transformer-layer chains: BUF0 holds the wide intermediates (attention output 640, FFN hidden
+# 128+512), BUF1 the token row x, AUX one 128-wide temporary; wide OUTPUTS (k|v, qt) go straight to global memory.
+# 16-row tiles: 58 KB -> two workgroups per CU; 32-row tiles (large grids): 116 KB, half the weight traffic per row.
+LAYER_LDW0, LAYER_LDW1, LAYER_AUX = 644, 132, 132
+
+
+BIG_ROWS = 16384  # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
+
+
+def layer_chain(rows: int) -> Chain:
+    """Small grids: 16-row tiles, everything staged in LDS (2 x 1028-float buffers, 1 workgroup per CU, fewest stages).
+    Large grids: 32-row tiles with asymmetric buffers (116 KB) and wide outputs written straight to global memory."""
+    return Chain(32, LAYER_LDW0, LAYER_LDW1, LAYER_AUX) if rows >= BIG_ROWS else Chain(16, 1028)
+
+
+def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool):
+    """LN(x in BUF1) -> [q | k | v | qt] / [q | qt] stored to `out`."""
+    if rows >= BIG_ROWS:
+        emit_proj_to(ch, norm, attn, out, with_kv)
+    else:
+        ch.layernorm(BUF1, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
+        w = emit_qkv(ch, attn, BUF0, 0, BUF0, D, with_kv=with_kv)
+        ch.store(BUF0, D, w, out)
+
+
+def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf: int = BUF1):
+    """LN(x) -> q [| k | v] | qt written to `out` ([rows, 896] or [rows, 640]); only q is staged in LDS (BUF0[:, 128:256],
+    it feeds the per-head rpe fold), k|v and qt go straight to global memory. attention_rpe.py:92-98,147."""
+    w_in, b_in = attn.in_proj_weight, attn.in_proj_bias
+    ch.layernorm(x_buf, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
+    ch.linear(BUF0, 0, BUF0, D, w_in[:D], b_in[:D])
+    ch.store(BUF0, D, D, out, 0)
+    nq = D
+    if with_kv:
+        ch.linear(BUF0, 0, GLOBAL, D, w_in[D:], b_in[D:], out=out)
+        nq = 3 * D
+    ch.linear(BUF0, D, GLOBAL, nq, attn.linear_rpe.weight[:D], wt=True, groups=NH, src_stride=DH, dst_stride=D, out=out)
+
+
 class SelfKnn:
     """KNN set among the source tokens themselves: idx i32 / invalid u8 [n,S,K] and either the materialised pose embedding
     emb f32 [n,S,K,128] or the relative pose rel f32 [n,S,K,3] (embedding rebuilt inside the attention kernel)."""
@@ -130,38 +169,30 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     def first_norm(l):
         return layers[l].norm_src if dec else layers[l].norm1
 
-    def emit_first_proj(ch, l):
-        nm = first_norm(l)
-        ch.layernorm(BUF1, 0, BUF0, 0, nm.weight, nm.bias, nm.eps)
-        w = emit_qkv(ch, first_attn(l), BUF0, 0, BUF0, D, with_kv=True)
-        ch.store(BUF0, D, w, qkv)
-
-    ch = Chain(tile_rows, 1028)
+    ch = layer_chain(rows)
     ch.load(x, BUF1, 0, n=D)
-    emit_first_proj(ch, 0)
+    emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True)
     ch.run(rows)
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel)
         hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw)
-        ch = Chain(tile_rows, 1028)
+        ch = layer_chain(rows)
         ch.load(x, BUF1, 0, n=D)
         emit_attn_out(ch, a1, obuf, flag)
         if dec:
             ch.store(BUF1, 0, D, x)
-            ch.layernorm(BUF1, 0, BUF0, 0, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-            w = emit_qkv(ch, layer.attn, BUF0, 0, BUF0, D, with_kv=False)
-            ch.store(BUF0, D, w, q2)
+            emit_proj(ch, rows, layer.norm1, layer.attn, q2, with_kv=False)
             ch.run(rows)
             hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw)
-            ch = Chain(tile_rows, 1028)
+            ch = layer_chain(rows)
             ch.load(x, BUF1, 0, n=D)
             emit_attn_out(ch, layer.attn, obuf, flag)
         emit_ffn(ch, layer)
         ch.rowmask(BUF1, 0, D, mask=src_invalid)
         ch.store(BUF1, 0, D, x)
         if l + 1 < len(layers):
-            emit_first_proj(ch, l + 1)
+            emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True)
         elif tail is not None:
             tail(ch)
         ch.run(rows)
@@ -175,7 +206,7 @@ def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = No
     L = len(norms_and_attns)
     if out is None:
         out = torch.empty(rows, 2 * D * L, dtype=torch.float32, device=x.device)
-    ch = Chain(tile_rows, 516)
+    ch = Chain(32, 132, 132, 132) if rows >= BIG_ROWS else Chain(tile_rows, 132, 132, 132)
     ch.load(x, BUF1, 0, n=D)
     emit_kv_tables(ch, norms_and_attns, out)
     ch.run(rows)
@@ -185,5 +216,4 @@ def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = No
 def emit_kv_tables(ch: Chain, norms_and_attns, out: torch.Tensor, x_buf: int = BUF1):
     for l, (nm, attn) in enumerate(norms_and_attns):
         ch.layernorm(x_buf, 0, BUF0, 0, nm.weight, nm.bias, nm.eps)
-        ch.linear(BUF0, 0, BUF0, D, attn.in_proj_weight[D:], attn.in_proj_bias[D:])
-        ch.store(BUF0, D, 2 * D, out, out_col=l * 2 * D)
+        ch.linear(BUF0, 0, GLOBAL, l * 2 * D, attn.in_proj_weight[D:], attn.in_proj_bias[D:], out=out)

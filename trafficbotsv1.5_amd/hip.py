@@ -18,14 +18,14 @@ HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
 ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD = 1, 2, 4, 8, 16, 32
-BUF0, BUF1, AUX = 0, 1, 2
-MAX_STAGES, AUX_LD = 48, 260
+BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
+MAX_STAGES, AUX_LD = 44, 260
 
 
 class Stage(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("op", "src", "dst", "src_col", "dst_col", "k", "n", "act", "flags", "ld", "div",
-                                         "reserved")] + [("f0", C.c_float), ("f1", C.c_float), ("p0", C.c_void_p),
-                                                         ("p1", C.c_void_p)]
+                                         "reserved", "ld2", "pad")] + [("f0", C.c_float), ("f1", C.c_float), ("p0", C.c_void_p),
+                                                                       ("p1", C.c_void_p), ("p2", C.c_void_p)]
 
 
 class AttnSeg(C.Structure):
@@ -77,12 +77,13 @@ def load():
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
+    lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                    i32, vp, vp, vp]
     lib.tbx_tl_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
-    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -216,19 +217,22 @@ class Chain:
     """Builds one tbx_rowchain program. Tensors handed to stages are kept alive by the chain; the encoded program
     holds raw device pointers, so a chain is valid as long as those tensors are not re-allocated."""
 
-    def __init__(self, tile_rows: int = 16, ldw: int = 132):
+    def __init__(self, tile_rows: int = 16, ldw: int = 132, ldw1: Optional[int] = None, ld_aux: Optional[int] = None):
+        """ldw = LDS row width of BUF0 (floats); ldw1 / ld_aux default to ldw / 260 (tbx_rowchain), else tbx_rowchain_ex."""
         self.tile_rows, self.ldw = tile_rows, ldw
+        self.ldw1 = ldw if ldw1 is None else ldw1
+        self.ld_aux = AUX_LD if ld_aux is None else ld_aux
         self.stages: List[Stage] = []
         self._keep = []
         self._arr = None
 
     def _add(self, **kw):
-        p0, p1 = kw.pop("p0", None), kw.pop("p1", None)
-        for t in (p0, p1):
+        p0, p1, p2 = kw.pop("p0", None), kw.pop("p1", None), kw.pop("p2", None)
+        for t in (p0, p1, p2):
             if t is not None:
                 self._keep.append(t)
         st = Stage(**kw)
-        st.p0, st.p1 = _ptr(p0), _ptr(p1)
+        st.p0, st.p1, st.p2 = _ptr(p0), _ptr(p1), _ptr(p2)
         self.stages.append(st)
         self._arr = None
         return self
@@ -257,15 +261,18 @@ class Chain:
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
 
     def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False, groups=1,
-               src_stride=0, dst_stride=0):
+               src_stride=0, dst_stride=0, out=None):
         """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt).
         groups > 1: block-diagonal; weight holds the groups' blocks stacked along dim 0, group g reads
-        src_col + g*src_stride and writes dst_col + g*dst_stride."""
+        src_col + g*src_stride and writes dst_col + g*dst_stride.
+        dst = GLOBAL with out = [rows, ld] tensor: the result goes straight to out[g, dst_col:+n] (no LDS staging)."""
         w = self._rows2d(weight)
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
+        assert (dst == GLOBAL) == (out is not None)
         return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias,
+                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias, p2=out,
+                         ld2=0 if out is None else self._rows2d(out).stride(0),
                          reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
 
     def layernorm(self, src, src_col, dst, dst_col, weight, bias, eps=1e-5):
@@ -299,5 +306,6 @@ class Chain:
         if self._arr is None:
             assert len(self.stages) <= MAX_STAGES, f"{len(self.stages)} stages > {MAX_STAGES}"
             self._arr = (Stage * len(self.stages))(*self.stages)
-        rc = load().tbx_rowchain(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, stream_ptr())
+        rc = load().tbx_rowchain_ex(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, self.ldw1,
+                                    self.ld_aux, stream_ptr())
         _check(rc, "tbx_rowchain")

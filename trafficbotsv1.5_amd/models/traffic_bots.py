@@ -89,7 +89,7 @@ class TrafficBots(nn.Module):
         if navi_inv is None:
             navi_inv = out["navi_invalid"] = torch.empty(n * A, dtype=torch.uint8, device=dev)
         torch.sub(1, navi_valid_u8.reshape(-1), out=navi_inv)
-        ch = Chain(16, 4 * d + 4)
+        ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
         ch.load(feat, BUF1, 0, n=d)
         self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe)
         self.add_navi.emit(ch, navi_inv)
