@@ -133,7 +133,8 @@ enum {
   TBX_F_ROW_DIV = 4,  /* row_of(g) = g / div   (per-group / per-agent broadcast) */
   TBX_F_ROW_MOD = 8,  /* row_of(g) = g % div */
   TBX_F_ROW_IDX = 16, /* row_of(g) = ((const int32_t*)p1)[g]  (LOAD gather) */
-  TBX_F_ROW_BATCH_MOD = 32 /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
+  TBX_F_ROW_BATCH_MOD = 32, /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
+  TBX_F_WPACK = 64    /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };
@@ -147,6 +148,14 @@ typedef struct tbx_stage {
   const void* p1;
   const void* p2;
 } tbx_stage_t;
+
+/* Fragment-order image of a LINEAR weight (nn.Linear [n,k] row-major with row stride ld, or [k,n] if wt != 0; `groups`
+ * blocks stacked along dim 0 as LINEAR's grouped mode expects): 16x16 output-column tile by 16-wide k-block, each block
+ * stored as the 64 lanes x float4 an MFMA 16x16x4 B operand sequence consumes, zero-padded to whole blocks, so a
+ * wavefront's weight load is one contiguous 1 KiB. out holds tbx_pack_weight_size(n, k, groups) floats. Pack once per
+ * weight update; the packed image replaces p0 in stages flagged TBX_F_WPACK. */
+int64_t tbx_pack_weight_size(int n, int k, int groups);
+int tbx_pack_weight(const float* w, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 
 /* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,

@@ -117,12 +117,18 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int kblocks = (K + 15) / 16;
   const int tiles_total = G * n_tiles;
 
-  const bool fast_wt = fast && wt && kblocks <= 4;
-  const bool fast_n = fast && !wt;
-  // row pointer (already offset to this lane's 4-float slice) of tile ti in the normal [n,k] layout; tiles past the end
-  // and columns past n are clamped to a valid row (their products are zeroed at use / never stored)
+  // TBX_F_WPACK: p0 holds the MFMA B fragments in load order (tbx_pack_weight): every wave-wide float4 load is one
+  // contiguous 1 KiB. A row-major [n,k] weight makes the 16 lanes of a fragment row read 16 different 512-byte rows,
+  // i.e. 64 separate 16-byte requests per load - measured 2.6 us of a 5.4 us 128x128 stage, L2-resident or not.
+  const bool packed = (s.flags & TBX_F_WPACK) != 0;
+  const bool fast_wt = !packed && fast && wt && kblocks <= 4;
+  const bool fast_n = packed || (fast && !wt);
+  const int kstride = packed ? 256 : 16;
+  // pointer (already offset to this lane's float4) to the first k-block of tile ti; tiles past the end and, in the
+  // row-major layout, columns past n are clamped to valid memory (their products are zeroed at use / never stored)
   auto wrow_of = [&](int ti) -> const float* {
     ti = ti < tiles_total ? ti : tiles_total - 1;
+    if (packed) return W0 + ((int64_t)ti * kblocks) * 256 + lane * 4;
     const int grp = ti / n_tiles;
     int col = (ti - grp * n_tiles) * 16 + j;
     col = col < N ? col : N - 1;
@@ -134,7 +140,7 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   if (fast_n) {
     wrow = wrow_of(wave);
 #pragma unroll
-    for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
@@ -162,10 +168,10 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
       const float* wnext = wrow_of(ti + nwave);
       for (int c0 = 0; c0 < kblocks; c0 += CH) {
         const bool last = c0 + CH >= kblocks;
-        const float* pn = last ? wnext : wrow + (c0 + CH) * 16;
+        const float* pn = last ? wnext : wrow + (c0 + CH) * kstride;
         const int kb_left = last ? kblocks : kblocks - (c0 + CH);
 #pragma unroll
-        for (int q = 0; q < CH; ++q) nxt[q] = (q < kb_left) ? *(const float4*)(pn + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < CH; ++q) nxt[q] = (q < kb_left) ? *(const float4*)(pn + q * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
           if (c0 + q < kblocks) {
@@ -374,10 +380,34 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   }
 }
 
+#ifdef TBX_STAGE_CLOCK
+// Profiling build only (libtbx_hip_clk.so, tools/stage_clock.py): workgroup 0 of every launch stamps the 100 MHz wall clock
+// at each stage boundary. Never compiled into libtbx_hip.so.
+constexpr int CLK_LAUNCHES = 2048, CLK_SLOTS = TBX_MAX_STAGES + 4;
+__device__ unsigned long long g_clk[CLK_LAUNCHES * CLK_SLOTS];
+__device__ unsigned int g_clk_launch;
+#define TBX_CLK(i)                                                                          \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clk_slot < (unsigned)CLK_LAUNCHES)           \
+      g_clk[clk_slot * CLK_SLOTS + (i)] = wall_clock64();                                   \
+  } while (0)
+#else
+#define TBX_CLK(i)
+#endif
+
 template <int MT, bool EXT>
 __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const RowchainArgs a) {
   constexpr int ROWS = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef TBX_STAGE_CLOCK
+  unsigned clk_slot = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk_slot = atomicAdd(&g_clk_launch, 1u);
+    if (clk_slot < (unsigned)CLK_LAUNCHES) g_clk[clk_slot * CLK_SLOTS + CLK_SLOTS - 1] = ((unsigned long long)gridDim.x << 32) | a.n_stages;
+  }
+  TBX_CLK(0);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && clk_slot < (unsigned)CLK_LAUNCHES) g_clk[clk_slot * CLK_SLOTS + CLK_SLOTS - 3] = clock64();
+#endif
   Tile<MT, EXT> t;
   t.base = lds;
   t.ldw0 = a.ldw0;
@@ -392,8 +422,26 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
     const int64_t left = a.n_rows - t.g0;
     t.n_valid = left < ROWS ? (int)left : ROWS;
   }
+  // The program is copied kernarg -> LDS once (one parallel read) and each stage descriptor is decoded from LDS into
+  // SGPRs (readfirstlane): a scalar load per stage from the kernarg segment costs ~0.6 us of exposed latency per stage.
+  constexpr int SW = (int)(sizeof(tbx_stage_t) / 4);
+  uint32_t* prog = (uint32_t*)(lds + (size_t)ROWS * (a.ldw0 + a.ldw1 + a.ld_aux));
+  {
+    const uint32_t* ka = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int e = threadIdx.x; e < a.n_stages * SW; e += blockDim.x) prog[e] = ka[e];
+  }
+  __syncthreads();
   for (int i = 0; i < a.n_stages; ++i) {
-    const tbx_stage_t& s = a.st[i];
+    const uint32_t* ps = prog + i * SW;
+    auto rd = [&](int w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ps[w]); };
+    auto rdp = [&](int w) -> const void* { return (const void*)(((uint64_t)rd(w + 1) << 32) | rd(w)); };
+    tbx_stage_t s;
+    s.op = (int32_t)rd(0), s.src = (int32_t)rd(1), s.dst = (int32_t)rd(2), s.src_col = (int32_t)rd(3);
+    s.dst_col = (int32_t)rd(4), s.k = (int32_t)rd(5), s.n = (int32_t)rd(6), s.act = (int32_t)rd(7);
+    s.flags = (int32_t)rd(8), s.ld = (int32_t)rd(9), s.div = (int32_t)rd(10), s.reserved = (int32_t)rd(11);
+    s.ld2 = (int32_t)rd(12), s.pad = 0;
+    s.f0 = __uint_as_float(rd(14)), s.f1 = __uint_as_float(rd(15));
+    s.p0 = rdp(16), s.p1 = rdp(18), s.p2 = rdp(20);
     switch (s.op) {
       case TBX_OP_LOAD: op_load<MT, EXT>(s, t); break;
       case TBX_OP_LINEAR: op_linear<MT, EXT>(s, t); break;
@@ -408,6 +456,27 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
       default: break;
     }
     __syncthreads();
+    TBX_CLK(i + 1);
+  }
+#ifdef TBX_STAGE_CLOCK
+  if (blockIdx.x == 0 && threadIdx.x == 0 && clk_slot < (unsigned)CLK_LAUNCHES) g_clk[clk_slot * CLK_SLOTS + CLK_SLOTS - 2] = clock64();
+#endif
+}
+
+// out[(((grp*n_tiles + tile)*kblocks + kb)*64 + lane)*4 + t] = W_grp[col = tile*16 + (lane & 15)][kk = kb*16 + (lane >> 4)*4 + t]
+__global__ void pack_weight_kernel(const float* __restrict__ w, int n, int k, int ld, int groups, int wt, float* __restrict__ out,
+                                   int64_t total) {
+  const int n_tiles = (n + 15) / 16, kblocks = (k + 15) / 16;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    int64_t r = e >> 8;
+    const int kb = (int)(r % kblocks);
+    r /= kblocks;
+    const int tile = (int)(r % n_tiles), grp = (int)(r / n_tiles);
+    const int col = tile * 16 + (lane & 15), kk = kb * 16 + (lane >> 4) * 4 + t;
+    float v = 0.f;
+    if (col < n && kk < k) v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+    out[e] = v;
   }
 }
 
@@ -455,6 +524,38 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
 extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                                int ldw0, int ldw1, int ld_aux, void* stream);
 
+#ifdef TBX_STAGE_CLOCK
+extern "C" int tbx_debug_clock_reset() {
+  unsigned int z = 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_clk_launch), &z, sizeof(z)) == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+// host_out: [max_launches][TBX_MAX_STAGES + 4] u64; returns the number of launches recorded (or a negative error)
+extern "C" int tbx_debug_clock_dump(unsigned long long* host_out, int max_launches) {
+  unsigned int n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return TBX_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_clk_launch), sizeof(n)) != hipSuccess) return TBX_ERR_LAUNCH;
+  int m = (int)n < max_launches ? (int)n : max_launches;
+  m = m < CLK_LAUNCHES ? m : CLK_LAUNCHES;
+  if (m > 0 && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clk), (size_t)m * CLK_SLOTS * sizeof(unsigned long long)) != hipSuccess)
+    return TBX_ERR_LAUNCH;
+  return m;
+}
+#endif
+
+extern "C" int64_t tbx_pack_weight_size(int n, int k, int groups) {
+  if (n <= 0 || k <= 0 || groups <= 0) return TBX_ERR_ARG;
+  return (int64_t)groups * ((n + 15) / 16) * ((k + 15) / 16) * 256;
+}
+
+extern "C" int tbx_pack_weight(const float* w, int n, int k, int ld, int groups, int wt, float* out, void* stream) {
+  if (w == nullptr || out == nullptr || n <= 0 || k <= 0 || ld <= 0 || groups <= 0) return TBX_ERR_ARG;
+  if (groups > 1 && n % 16 != 0) return TBX_ERR_UNSUPPORTED;
+  const int64_t total = tbx_pack_weight_size(n, k, groups);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, k, ld, groups, wt, out, total);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
 extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                             int ldw, void* stream) {
   return tbx_rowchain_ex(stages, n_stages, n_rows, group_rows, tile_rows, ldw, ldw, TBX_AUX_LD, stream);
@@ -468,7 +569,8 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   if (ldw0 <= 0 || ldw1 <= 0 || ld_aux <= 0 || ldw0 % 4 != 0 || ldw1 % 4 != 0 || ld_aux % 4 != 0) return TBX_ERR_ALIGN;
   if (group_rows < 0 || group_rows > tile_rows) return TBX_ERR_UNSUPPORTED;
   if (group_rows > 0 && n_rows % group_rows != 0) return TBX_ERR_ARG;
-  const size_t lds_bytes = (size_t)(ldw0 + ldw1 + ld_aux) * tile_rows * sizeof(float);
+  // activation buffers + the program itself (decoded from LDS by the kernel)
+  const size_t lds_bytes = (size_t)(ldw0 + ldw1 + ld_aux) * tile_rows * sizeof(float) + (size_t)n_stages * sizeof(tbx_stage_t);
   if (lds_bytes > 160 * 1024) return TBX_ERR_UNSUPPORTED;
   RowchainArgs a;
   for (int i = 0; i < n_stages; ++i) {

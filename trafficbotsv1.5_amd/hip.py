@@ -4,6 +4,7 @@ The HIP library IS the product path: there is no CPU or PyTorch fallback. `load(
 missing, and every wrapper raises on a non-zero tbx return code or on tensors that are not on a HIP device.
 """
 import ctypes as C
+import os
 import re
 from pathlib import Path
 from typing import List, Optional, Sequence
@@ -17,7 +18,7 @@ HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 # ---- constants mirrored from include/tbx_hip.h
 OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
 ACT_NONE, ACT_RELU = 0, 1
-F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD = 1, 2, 4, 8, 16, 32
+F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK = 1, 2, 4, 8, 16, 32, 64
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -52,7 +53,7 @@ _lib = None
 def declared_symbols() -> List[str]:
     """Entry points declared in include/tbx_hip.h (the C-ABI contract)."""
     txt = HEADER_PATH.read_text()
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(tbx_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|const char\*)\s+(tbx_\w+)\s*\(", txt, flags=re.M)))
 
 
 def load():
@@ -60,11 +61,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    lib_path = Path(os.environ.get("TBX_HIP_LIB", LIB_PATH))  # profiling builds only (tools/stage_clock.py)
+    if not lib_path.exists():
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback path.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(lib_path))
     for s in declared_symbols():
         if not hasattr(lib, s):
             raise ImportError(f"libtbx_hip.so does not export {s}")
@@ -76,6 +78,9 @@ def load():
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
+    lib.tbx_pack_weight_size.argtypes = [i32, i32, i32]
+    lib.tbx_pack_weight_size.restype = C.c_int64
+    lib.tbx_pack_weight.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
@@ -83,7 +88,7 @@ def load():
     lib.tbx_tl_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
-    for name in ("tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -213,6 +218,28 @@ def sim_step(state: SimState):
 
 
 # ------------------------------------------------------------------------------------------------ rowchain builder
+def packed_weight(w: torch.Tensor, wt: bool = False, groups: int = 1) -> torch.Tensor:
+    """tbx_pack_weight image of a LINEAR weight. Cached on the weight's base tensor object (the nn.Parameter) per view
+    and version: re-packed after an in-place update (optimizer step, load_state_dict), reused otherwise - chains are
+    rebuilt every eager step - and dropped with the parameter."""
+    assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
+    base = w._base if w._base is not None else w
+    cache = base.__dict__.setdefault("_tbx_packed", {})
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
+        return hit[1]
+    n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
+    lib = load()
+    size = lib.tbx_pack_weight_size(n, k, groups)
+    if size <= 0:
+        _check(int(size), "tbx_pack_weight_size")
+    out = torch.empty(size, dtype=torch.float32, device=w.device)
+    _check(lib.tbx_pack_weight(_ptr(w), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
+    cache[key] = (w._version, out, w.data_ptr())
+    return out
+
+
 class Chain:
     """Builds one tbx_rowchain program. Tensors handed to stages are kept alive by the chain; the encoded program
     holds raw device pointers, so a chain is valid as long as those tensors are not re-allocated."""
@@ -225,6 +252,9 @@ class Chain:
         self.stages: List[Stage] = []
         self._keep = []
         self._arr = None
+        self.pack_weights = Chain.pack_default
+
+    pack_default = True  # LINEAR weights are handed to the kernel as tbx_pack_weight images (row-major kept for tests)
 
     def _add(self, **kw):
         p0, p1, p2 = kw.pop("p0", None), kw.pop("p1", None), kw.pop("p2", None)
@@ -270,6 +300,12 @@ class Chain:
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         assert (dst == GLOBAL) == (out is not None)
+        if self.pack_weights:
+            w, flags = packed_weight(w, wt, groups), (flags & ~F_WT) | F_WPACK
+            return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
+                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=bias, p2=out,
+                             ld2=0 if out is None else self._rows2d(out).stride(0),
+                             reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
         return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
                          act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias, p2=out,
                          ld2=0 if out is None else self._rows2d(out).stride(0),
