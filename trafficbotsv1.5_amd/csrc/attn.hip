@@ -78,17 +78,11 @@ struct ESlice {
     fma4(wc, p, o.wc); fma4(ws, p, o.ws);
   }
   __device__ __forceinline__ void reduce_slots() {  // sum over the 8 target slots (lanes with equal s8)
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-      xc.x += __shfl_xor(xc.x, off, 64); xc.y += __shfl_xor(xc.y, off, 64);
-      xs.x += __shfl_xor(xs.x, off, 64); xs.y += __shfl_xor(xs.y, off, 64);
-      yc.x += __shfl_xor(yc.x, off, 64); yc.y += __shfl_xor(yc.y, off, 64);
-      ys.x += __shfl_xor(ys.x, off, 64); ys.y += __shfl_xor(ys.y, off, 64);
-      wc.x += __shfl_xor(wc.x, off, 64); wc.y += __shfl_xor(wc.y, off, 64);
-      wc.z += __shfl_xor(wc.z, off, 64); wc.w += __shfl_xor(wc.w, off, 64);
-      ws.x += __shfl_xor(ws.x, off, 64); ws.y += __shfl_xor(ws.y, off, 64);
-      ws.z += __shfl_xor(ws.z, off, 64); ws.w += __shfl_xor(ws.w, off, 64);
-    }
+    using tbx::slot_sum;
+    xc.x = slot_sum(xc.x); xc.y = slot_sum(xc.y); xs.x = slot_sum(xs.x); xs.y = slot_sum(xs.y);
+    yc.x = slot_sum(yc.x); yc.y = slot_sum(yc.y); ys.x = slot_sum(ys.x); ys.y = slot_sum(ys.y);
+    wc.x = slot_sum(wc.x); wc.y = slot_sum(wc.y); wc.z = slot_sum(wc.z); wc.w = slot_sum(wc.w);
+    ws.x = slot_sum(ws.x); ws.y = slot_sum(ws.y); ws.z = slot_sum(ws.z); ws.w = slot_sum(ws.w);
   }
 };
 
@@ -240,22 +234,16 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   float M[NH], L[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
-    float mm = m_run[h];
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
+    const float mm = tbx::slot_max(m_run[h]);
     M[h] = mm;
     const float f = (m_run[h] == -INFINITY) ? 0.f : expf(m_run[h] - mm);
     float ll = l_run[h] * f;
     scale4(oacc[h], f);
     eacc[h].scale(f);
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) ll += __shfl_xor(ll, off, 64);
+    ll = tbx::slot_sum(ll);
     L[h] = ll;
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-      oacc[h].x += __shfl_xor(oacc[h].x, off, 64); oacc[h].y += __shfl_xor(oacc[h].y, off, 64);
-      oacc[h].z += __shfl_xor(oacc[h].z, off, 64); oacc[h].w += __shfl_xor(oacc[h].w, off, 64);
-    }
+    oacc[h].x = tbx::slot_sum(oacc[h].x); oacc[h].y = tbx::slot_sum(oacc[h].y);
+    oacc[h].z = tbx::slot_sum(oacc[h].z); oacc[h].w = tbx::slot_sum(oacc[h].w);
     eacc[h].reduce_slots();
   }
   float* orow = a.out + (int64_t)row * a.ldo;
@@ -520,11 +508,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
     }
   }
   auto red4 = [](float4 v) {
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
-      v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
-    }
+    v.x = tbx::slot_sum(v.x); v.y = tbx::slot_sum(v.y); v.z = tbx::slot_sum(v.z); v.w = tbx::slot_sum(v.w);
     return v;
   };
   float* dqrow = b.dqbuf + (int64_t)row * a.ldq;

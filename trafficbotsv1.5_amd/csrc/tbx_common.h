@@ -6,24 +6,83 @@
 
 namespace tbx {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// Cross-lane exchange without the LDS crossbar: DPP modifiers inside a 16-lane row (they fuse into the consuming
+// v_add / v_max) and the gfx950 v_permlane{16,32}_swap for the two cross-row steps. Each helper returns exactly what the
+// __shfl_xor butterfly it replaces returns (same operands per add, commuted at most), so results are bit-identical.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <- lane 7-i of its 8-lane half row (== xor 4 once quads are uniform)
+constexpr int DPP_MIRROR = 0x140;      // lane i <- lane 15-i of its row (== xor 8 once 8-lane groups are uniform)
+constexpr int DPP_XOR8 = 0x128;        // row_ror:8
+
+// (v[l], v[l ^ 16]) and (v[l], v[l ^ 32]) pairs, one of them being the lane's own value. v_permlane16_swap exchanges the
+// odd rows of its first register with the even rows of its second in place, v_permlane32_swap the upper half of the
+// first with the lower half of the second; fed two copies of v they leave (rows 0,0,2,2 | 1,1,3,3) and (lo,lo | hi,hi).
+// Inline asm with two read-write operands: the clang 22 builtin folds both results into one register. The s_nops cover
+// the VALU-write -> permlane-swap and permlane-swap -> VALU-read wait states the assembler does not insert in asm.
+__device__ __forceinline__ void swap16(float v, float* a, float* b) {
+  float x = v, y = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  *a = x;
+  *b = y;
+}
+__device__ __forceinline__ void swap32(float v, float* a, float* b) {
+  float x = v, y = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  *a = x;
+  *b = y;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+// sum / max over lanes l ^ {8, 16, 32} (the 8 lanes that share l & 7)
+__device__ __forceinline__ float slot_sum(float v) {
+  float a, b;
+  v += dpp<DPP_XOR8>(v);
+  swap16(v, &a, &b);
+  v = a + b;
+  swap32(v, &a, &b);
+  return a + b;
+}
+__device__ __forceinline__ float slot_max(float v) {
+  float a, b;
+  v = fmaxf(v, dpp<DPP_XOR8>(v));
+  swap16(v, &a, &b);
+  v = fmaxf(a, b);
+  swap32(v, &a, &b);
+  return fmaxf(a, b);
 }
 
 // sum over aligned groups of 8 lanes
 __device__ __forceinline__ float group8_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+  v += dpp<DPP_XOR1>(v);
+  v += dpp<DPP_XOR2>(v);
+  v += dpp<DPP_HALF_MIRROR>(v);
   return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group8_sum(v);
+  v += dpp<DPP_MIRROR>(v);
+  float a, b;
+  swap16(v, &a, &b);
+  v = a + b;
+  swap32(v, &a, &b);
+  return a + b;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp<DPP_XOR1>(v));
+  v = fmaxf(v, dpp<DPP_XOR2>(v));
+  v = fmaxf(v, dpp<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp<DPP_MIRROR>(v));
+  float a, b;
+  swap16(v, &a, &b);
+  v = fmaxf(a, b);
+  swap32(v, &a, &b);
+  return fmaxf(a, b);
 }
 
 // 128-d (or 64-d) pe_xy_yaw channel c of pose (x, y, yaw): utils/pose_emb.py:50-55, utils/positional_emb.py:25,53.
