@@ -142,20 +142,22 @@ enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
 #define TBX_AUX_LD 260
 
 typedef struct tbx_stage {
-  int32_t op, src, dst, src_col, dst_col, k, n, act, flags, ld, div, reserved, ld2, pad;
+  int32_t op, src, dst, src_col, dst_col, k, n, act, flags, ld, div, reserved, ld2, pad; /* pad: set by the library */
   float f0, f1;
   const void* p0;
   const void* p1;
   const void* p2;
 } tbx_stage_t;
 
-/* Fragment-order image of a LINEAR weight (nn.Linear [n,k] row-major with row stride ld, or [k,n] if wt != 0; `groups`
- * blocks stacked along dim 0 as LINEAR's grouped mode expects): 16x16 output-column tile by 16-wide k-block, each block
- * stored as the 64 lanes x float4 an MFMA 16x16x4 B operand sequence consumes, zero-padded to whole blocks, so a
- * wavefront's weight load is one contiguous 1 KiB. out holds tbx_pack_weight_size(n, k, groups) floats. Pack once per
- * weight update; the packed image replaces p0 in stages flagged TBX_F_WPACK. */
+/* Fragment-order image of a LINEAR weight + bias (nn.Linear [n,k] row-major with row stride ld, or [k,n] if wt != 0;
+ * `groups` blocks stacked along dim 0 as LINEAR's grouped mode expects; bias [groups*n] or NULL = zeros): per 16-column
+ * output tile, ceil(k/16) k-blocks stored as the 64 lanes x float4 an MFMA 16x16x4 B operand sequence consumes (zero-
+ * padded to whole blocks) followed by the tile's bias replicated per lane, so every wavefront-wide weight load is one
+ * contiguous 1 KiB and a stage's first fragments can be requested while the previous stage still computes. out holds
+ * tbx_pack_weight_size(n, k, groups) floats. Pack once per weight update; the image replaces p0 in stages flagged
+ * TBX_F_WPACK (their p1 / ld / TBX_F_WT are ignored). */
 int64_t tbx_pack_weight_size(int n, int k, int groups);
-int tbx_pack_weight(const float* w, int n, int k, int ld, int groups, int wt, float* out, void* stream);
+int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 
 /* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,

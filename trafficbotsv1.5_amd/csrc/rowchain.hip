@@ -22,10 +22,37 @@ struct RowchainArgs {
   int32_t n_stages;
   int32_t group_rows;
   int32_t ldw0, ldw1, ld_aux;
+  int32_t first_packed;  // first TBX_F_WPACK LINEAR stage (-1: none): its weights are requested before stage 0 runs
   int64_t n_rows;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Pointers decoded from the LDS-resident program are generic to the compiler; loads through them would be FLAT
+// instructions, which also count against lgkmcnt and so serialise with every LDS wait. These casts state what the ABI
+// guarantees: stage pointers are device global memory.
+#define TBX_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float4 gld4(const float* p) {
+  const f32x4 v = *(const TBX_GLOBAL f32x4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+// uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr addressing form, no 64-bit VGPR address per load
+__device__ __forceinline__ float4 gld4(const float* sbase, uint32_t lane_bytes) {
+  const f32x4 v = *(const TBX_GLOBAL f32x4*)((const TBX_GLOBAL char*)sbase + lane_bytes);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float gld1(const float* sbase, uint32_t lane_bytes) {
+  return *(const TBX_GLOBAL float*)((const TBX_GLOBAL char*)sbase + lane_bytes);
+}
+__device__ __forceinline__ float gld1(const float* p) { return *(const TBX_GLOBAL float*)p; }
+__device__ __forceinline__ uint8_t gld1(const uint8_t* p) { return *(const TBX_GLOBAL uint8_t*)p; }
+__device__ __forceinline__ int32_t gld1(const int32_t* p) { return *(const TBX_GLOBAL int32_t*)p; }
+__device__ __forceinline__ void gst4(float* p, float4 v) {
+  f32x4 x;
+  x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+  *(TBX_GLOBAL f32x4*)p = x;
+}
+__device__ __forceinline__ void gst1(float* p, float v) { *(TBX_GLOBAL float*)p = v; }
 
 template <int MT, bool EXT>
 struct Tile {
@@ -52,13 +79,22 @@ __device__ __forceinline__ int64_t row_of(const tbx_stage_t& s, int64_t g) {
   if (s.flags & TBX_F_ROW_DIV) return g / s.div;
   if (s.flags & TBX_F_ROW_MOD) return g % s.div;
   if (s.flags & TBX_F_ROW_BATCH_MOD) return (g / s.k) * s.div + g % s.div;
-  if (s.flags & TBX_F_ROW_IDX) return (int64_t)((const int32_t*)s.p1)[g];
+  if (s.flags & TBX_F_ROW_IDX) return (int64_t)gld1((const int32_t*)s.p1 + g);
   return g;
 }
+
+// The row-wise ops below give every wavefront whole rows (row = wave, wave + nwave, ...; lanes walk the columns): with 16
+// wavefronts sharing one CU a VALU instruction costs 16 issue cycles per workgroup, and a per-element e / n, e % n index
+// was most of a trivial stage's time.
+#define TBX_WAVE_ROWS                                                            \
+  const int lane = threadIdx.x & 63;                                             \
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      \
+  const int nwave = (int)(blockDim.x >> 6)
 
 template <int MT, bool EXT>
 __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
+  TBX_WAVE_ROWS;
   float* dst = t.b(s.dst) + s.dst_col;
   const int ld = t.l(s.dst);
   const float* src = (const float*)s.p0;
@@ -68,32 +104,186 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   if (src != nullptr && !accum && width == s.n && (s.n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 &&
       ((((uintptr_t)src) & 15) == 0)) {
     const int w4 = s.n >> 2;
-    for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
-      const int r = e / w4, c4 = e - r * w4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < t.n_valid) v = *(const float4*)(src + row_of(s, t.g0 + r) * (int64_t)s.ld + c4 * 4);
-      *(float4*)(dst + r * ld + c4 * 4) = v;
+    for (int r = wave; r < ROWS; r += nwave) {
+      const bool live = r < t.n_valid;
+      const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
+      for (int c4 = lane; c4 < w4; c4 += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = gld4(srow + c4 * 4);
+        *(float4*)(dst + r * ld + c4 * 4) = v;
+      }
     }
     return;
   }
-  for (int e = threadIdx.x; e < ROWS * width; e += blockDim.x) {
-    const int r = e / width, c = e - r * width;
-    float v = 0.f;
-    if (r < t.n_valid && c < s.n && src != nullptr) v = src[row_of(s, t.g0 + r) * (int64_t)s.ld + c];
-    if (accum && c < s.n)
-      dst[r * ld + c] += v;
-    else if (!accum)
-      dst[r * ld + c] = v;
+  for (int r = wave; r < ROWS; r += nwave) {
+    const bool live = r < t.n_valid && src != nullptr;
+    const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
+    for (int c = lane; c < width; c += 64) {
+      float v = 0.f;
+      if (live && c < s.n) v = gld1(srow + c);
+      if (accum && c < s.n)
+        dst[r * ld + c] += v;
+      else if (!accum)
+        dst[r * ld + c] = v;
+    }
   }
 }
 
 constexpr int CH = 8;  // k-blocks (of 16) whose weight fragments are in flight per wave
+constexpr int SW = (int)(sizeof(tbx_stage_t) / 4);  // stage descriptor, dwords (the program lives in LDS)
+
+// Packed weight image (tbx_pack_weight): per 16-column tile, kblocks x (64 lanes x float4) B fragments followed by 64
+// floats of bias (lane l holds bias[col(l & 15)]). One wave-wide load = one contiguous 1 KiB / 256 B.
+__device__ __forceinline__ int wp_tile_stride(int kblocks) { return kblocks * 256 + 64; }
+
+// Weight fragments a wave holds ahead of their use: the first CH k-blocks (+ bias) of its first tile of packed LINEAR
+// stage `stage`. Filled at kernel start and by the previous packed LINEAR while it works on its last tile, so the
+// L2/HBM latency of a stage's first weights overlaps the stages before it. The stage barrier therefore only orders LDS.
+struct WeightAhead {
+  float4 w[CH];
+  float bias;
+  int stage;  // -1: nothing held
+};
+
+__device__ __forceinline__ uint32_t prog_word(const uint32_t* prog, int stage, int w) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[stage * SW + w]);
+}
+
+// shape of packed LINEAR stage j, read from the LDS program
+struct PackedShape {
+  const float* W;
+  int kblocks, tiles_total;
+};
+__device__ __forceinline__ PackedShape packed_shape(const uint32_t* prog, int j) {
+  PackedShape ps;
+  const int k = (int)prog_word(prog, j, 5), n = (int)prog_word(prog, j, 6), G = (int)prog_word(prog, j, 11);
+  ps.W = (const float*)(((uint64_t)prog_word(prog, j, 17) << 32) | prog_word(prog, j, 16));
+  ps.kblocks = (k + 15) / 16;
+  ps.tiles_total = (G > 0 ? G : 1) * ((n + 15) / 16);
+  return ps;
+}
+
+__device__ __forceinline__ void weights_ahead(const uint32_t* prog, int j, int lane, int wave, WeightAhead& wa) {
+  const PackedShape ps = packed_shape(prog, j);
+  const int ti = wave < ps.tiles_total ? wave : ps.tiles_total - 1;
+  const float* base = ps.W + (int64_t)ti * wp_tile_stride(ps.kblocks);
+#pragma unroll
+  for (int q = 0; q < CH; ++q)
+    wa.w[q] = gld4(base + (q < ps.kblocks ? q : 0) * 256, (uint32_t)lane * 16u);
+  wa.bias = gld1(base + ps.kblocks * 256, (uint32_t)lane * 4u);
+  wa.stage = j;
+}
+
+// Packed-weight tiles of one LINEAR stage for one wave. `cur` (= the wave's WeightAhead registers) holds the CH k-blocks
+// being multiplied, `nxt` the CH after them in the wave's stream: this tile's next chunk, then the wave's next tile, then
+// its first tile of the next packed LINEAR stage (whose fragments are thus in flight across the stage barrier). Loads
+// are unconditional with scalar-selected addresses (a load under a branch is waited for on the spot and degrades the
+// vmcnt bookkeeping to vmcnt(0)); with nothing left to fetch they re-read the tile's first block, an L2 hit.
+template <int MT, bool EXT>
+__device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, WeightAhead& wa,
+                                              int lane, int wave, int nwave, bool to_global) {
+  const int j = lane & 15, g = lane >> 4;
+  const float* src0 = t.b(s.src) + s.src_col;
+  float* dst0 = t.b(to_global ? 0 : s.dst) + s.dst_col;
+  float* __restrict__ gout0 = to_global ? (float*)s.p2 + t.g0 * (int64_t)s.ld2 + s.dst_col : nullptr;
+  const int lds_s = t.l(s.src), lds_d = t.l(to_global ? 0 : s.dst);
+  const float* __restrict__ W0 = (const float*)s.p0;
+  const int N = s.n;
+  const int G = s.reserved > 0 ? s.reserved : 1;
+  const int gs_src = (s.div >> 16) & 0xffff, gs_dst = s.div & 0xffff;
+  const bool accum = (s.flags & TBX_F_ACCUM) != 0;
+  const int n_tiles = (N + 15) / 16;
+  const int kblocks = (s.k + 15) / 16;
+  const int tiles_total = G * n_tiles;
+  const int tstride = wp_tile_stride(kblocks);
+  const int nj = s.pad;
+  PackedShape nx;
+  nx.W = W0, nx.kblocks = 0, nx.tiles_total = 1;
+  if (nj > 0) nx = packed_shape(prog, nj);
+  float4(&cur)[CH] = wa.w;
+  float4 nxt[CH];
+  float cb = wa.bias;
+  for (int ti = wave; ti < tiles_total; ti += nwave) {
+    const int grp = ti / n_tiles;
+    const int n0 = (ti - grp * n_tiles) * 16;
+    const int col = n0 + j;
+    const bool col_ok = col < N;
+    const float* src = src0 + grp * gs_src;
+    float* dst = dst0 + grp * gs_dst;
+    float* gout = gout0 + grp * gs_dst;
+    const float* tbase = W0 + (int64_t)ti * tstride;
+    // the tile after this one in the wave's stream
+    const float* nbase = tbase;
+    int kb_next = 0;
+    if (ti + nwave < tiles_total) {
+      nbase = tbase + (int64_t)nwave * tstride;
+      kb_next = kblocks;
+    } else if (nj > 0) {
+      const int tn = wave < nx.tiles_total ? wave : nx.tiles_total - 1;
+      nbase = nx.W + (int64_t)tn * wp_tile_stride(nx.kblocks);
+      kb_next = nx.kblocks;
+    }
+    const float nb = gld1(nbase + (kb_next > 0 ? kb_next : kblocks) * 256, (uint32_t)lane * 4u);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float c0 = cb;
+        if (accum && col_ok) c0 += dst[(m * 16 + g * 4 + r) * lds_d + col];
+        acc[m][r] = c0;
+      }
+    }
+    for (int c0 = 0; c0 < kblocks; c0 += CH) {
+      const bool last = c0 + CH >= kblocks;
+      const float* pn = last ? nbase : tbase + (c0 + CH) * 256;
+      const int kb_left = last ? kb_next : kblocks - (c0 + CH);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) nxt[q] = gld4(pn + (q < kb_left ? q : 0) * 256, (uint32_t)lane * 16u);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        if (c0 + q < kblocks) {
+          const int k0 = (c0 + q) * 16 + g * 4;
+          const float4 bv = cur[q];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+    }
+    cb = nb;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[m][r];
+        if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
+        // columns of the last partial tile beyond n are zero-filled (unless accumulating or grouped) so that the next
+        // stage may read a K padded to 16
+        if (to_global) {
+          if (col_ok && m * 16 + g * 4 + r < t.n_valid) gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
+        } else if (col_ok)
+          dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+        else if (!accum && G == 1 && col < lds_d - s.dst_col)
+          dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
+      }
+    }
+  }
+  wa.bias = cb;
+}
 
 // LINEAR (optionally grouped: `reserved` = G groups, group g reads src columns src_col + g*src_stride, writes
 // dst_col + g*dst_stride, with src_stride / dst_stride packed in `div` as (src << 16 | dst); its weight block is the next
 // n rows (or k rows if TBX_F_WT) after the previous group's, its bias the next n entries).
 template <int MT, bool EXT>
-__device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
+__device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, int stage, WeightAhead& wa) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwave = blockDim.x >> 6;
@@ -112,36 +302,27 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int gs_src = (s.div >> 16) & 0xffff, gs_dst = s.div & 0xffff;
   const bool wt = (s.flags & TBX_F_WT) != 0;
   const bool accum = (s.flags & TBX_F_ACCUM) != 0;
-  const bool fast = (K % 16 == 0) && (wt || ((ldw % 4 == 0) && ((((uintptr_t)W0) & 15) == 0)));
   const int n_tiles = (N + 15) / 16;
   const int kblocks = (K + 15) / 16;
   const int tiles_total = G * n_tiles;
-
   // TBX_F_WPACK: p0 holds the MFMA B fragments in load order (tbx_pack_weight): every wave-wide float4 load is one
   // contiguous 1 KiB. A row-major [n,k] weight makes the 16 lanes of a fragment row read 16 different 512-byte rows,
   // i.e. 64 separate 16-byte requests per load - measured 2.6 us of a 5.4 us 128x128 stage, L2-resident or not.
   const bool packed = (s.flags & TBX_F_WPACK) != 0;
-  const bool fast_wt = !packed && fast && wt && kblocks <= 4;
-  const bool fast_n = packed || (fast && !wt);
-  const int kstride = packed ? 256 : 16;
-  // pointer (already offset to this lane's float4) to the first k-block of tile ti; tiles past the end and, in the
-  // row-major layout, columns past n are clamped to valid memory (their products are zeroed at use / never stored)
-  auto wrow_of = [&](int ti) -> const float* {
-    ti = ti < tiles_total ? ti : tiles_total - 1;
-    if (packed) return W0 + ((int64_t)ti * kblocks) * 256 + lane * 4;
-    const int grp = ti / n_tiles;
-    int col = (ti - grp * n_tiles) * 16 + j;
-    col = col < N ? col : N - 1;
-    return W0 + ((int64_t)grp * N + col) * ldw + g * 4;
-  };
 
-  float4 cur[CH], nxt[CH];
-  const float* wrow = nullptr;
-  if (fast_n) {
-    wrow = wrow_of(wave);
-#pragma unroll
-    for (int q = 0; q < CH; ++q) cur[q] = (q < kblocks) ? *(const float4*)(wrow + q * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (packed) {
+    // wa holds this stage's first fragments by construction: requested at kernel start for the first packed LINEAR
+    // (RowchainArgs::first_packed) and by every packed LINEAR for the next one (stage.pad, set by tbx_rowchain_ex)
+    const int nj = s.pad;
+    if (wave < tiles_total)
+      linear_packed<MT, EXT>(s, t, prog, wa, lane, wave, nwave, to_global);
+    else if (nj > 0)  // no tile here: only keep the pipeline of the next stage fed
+      weights_ahead(prog, nj, lane, wave, wa);
+    wa.stage = nj > 0 ? nj : -1;
+    return;
   }
+
+  // row-major weights ([n,k], or [k,n] with TBX_F_WT): reference path of the ABI, one k-block at a time
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
     const int n0 = (ti - grp * n_tiles) * 16;
@@ -154,7 +335,7 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float b = (bias != nullptr && col_ok) ? bias[col] : 0.f;
+      const float b = (bias != nullptr && col_ok) ? gld1(bias + col) : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float c0 = b;
@@ -162,80 +343,24 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
         acc[m][r] = c0;
       }
     }
-    if (fast_n) {
-      // weights go straight to VGPRs, CH k-blocks ahead and across tile boundaries: the L2/HBM latency is paid once
-      // per chunk and overlaps the previous chunk's MFMAs
-      const float* wnext = wrow_of(ti + nwave);
-      for (int c0 = 0; c0 < kblocks; c0 += CH) {
-        const bool last = c0 + CH >= kblocks;
-        const float* pn = last ? wnext : wrow + (c0 + CH) * kstride;
-        const int kb_left = last ? kblocks : kblocks - (c0 + CH);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) nxt[q] = (q < kb_left) ? *(const float4*)(pn + q * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-          if (c0 + q < kblocks) {
-            const int k0 = (c0 + q) * 16 + g * 4;
-            float4 bv = cur[q];
-            if (!col_ok) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
-      }
-      wrow = wnext;
-    } else if (fast_wt) {
-      // [k, n] layout with a short K (the per-head rpe fold, K = 32): every k-block's 4 rows are fetched up front
-      const float* w = W0 + ((int64_t)grp * K + g * 4) * ldw + (col_ok ? col : 0);
-      float4 bw[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bw[q] = (q < kblocks) ? make_float4(w[(q * 16) * ldw], w[(q * 16 + 1) * ldw], w[(q * 16 + 2) * ldw], w[(q * 16 + 3) * ldw])
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* W = W0 + (int64_t)grp * (wt ? K : N) * ldw;
+    for (int kb = 0; kb < kblocks; ++kb) {
+      const int k0 = kb * 16 + g * 4;
+      float tmp[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q < kblocks) {
-          const int k0 = q * 16 + g * 4;
-          float4 bv = bw[q];
-          if (!col_ok) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
-          }
-        }
+        const int kk = k0 + q;
+        float w = 0.f;
+        if (col_ok && kk < K) w = gld1(wt ? W + (int64_t)kk * ldw + col : W + (int64_t)col * ldw + kk);
+        tmp[q] = w;
       }
-    } else {
-      const float* W = W0 + (int64_t)grp * (wt ? K : N) * ldw;
-      for (int kb = 0; kb < kblocks; ++kb) {
-        const int k0 = kb * 16 + g * 4;
-        float tmp[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kk = k0 + q;
-          float w = 0.f;
-          if (col_ok && kk < K) w = wt ? W[(int64_t)kk * ldw + col] : W[(int64_t)col * ldw + kk];
-          tmp[q] = w;
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, tmp[0], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, tmp[1], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, tmp[2], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, tmp[3], acc[m], 0, 0, 0);
-        }
+      for (int m = 0; m < MT; ++m) {
+        const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, tmp[0], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, tmp[1], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, tmp[2], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, tmp[3], acc[m], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -244,10 +369,8 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
       for (int r = 0; r < 4; ++r) {
         float v = acc[m][r];
         if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
-        // columns of the last partial tile beyond n are zero-filled (unless accumulating or grouped) so that the next
-        // stage may read a K padded to 16
         if (to_global) {
-          if (col_ok && m * 16 + g * 4 + r < t.n_valid) gout[(int64_t)(m * 16 + g * 4 + r) * s.ld2 + col] = v;
+          if (col_ok && m * 16 + g * 4 + r < t.n_valid) gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
         } else if (col_ok)
           dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
         else if (!accum && G == 1 && col < lds_d - s.dst_col)
@@ -257,10 +380,41 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   }
 }
 
+template <int NQ>
+__device__ __forceinline__ void ln_row(const float* __restrict__ src, float* __restrict__ dst, int n, int lane, float eps,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
+  float v[NQ], gm[NQ], bt[NQ];
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q;
+    const bool ok = c < n;
+    v[q] = ok ? src[c] : 0.f;
+    gm[q] = ok ? gld1(gamma + c) : 0.f;  // issued before the reductions: their latency overlaps them
+    bt[q] = ok ? gld1(beta + c) : 0.f;
+    sum += v[q];
+  }
+  sum = tbx::wave_sum(sum);
+  const float mean = sum / (float)n;
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float d = (lane + 64 * q < n) ? v[q] - mean : 0.f;
+    var += d * d;
+  }
+  var = tbx::wave_sum(var) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q;
+    if (c < n) dst[c] = (v[q] - mean) * rstd * gm[q] + bt[q];
+  }
+}
+
 template <int MT, bool EXT>
 __device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
@@ -268,63 +422,61 @@ __device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const float* beta = (const float*)s.p1;
   const int n = s.n;
   for (int r = wave; r < ROWS; r += nwave) {
-    float v[8];
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = lane + 64 * q;
-      v[q] = (c < n) ? src[r * lds_s + c] : 0.f;
-      sum += v[q];
-    }
-    sum = tbx::wave_sum(sum);
-    const float mean = sum / (float)n;
-    float var = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = lane + 64 * q;
-      const float d = (c < n) ? v[q] - mean : 0.f;
-      var += d * d;
-    }
-    var = tbx::wave_sum(var) / (float)n;
-    const float rstd = 1.0f / sqrtf(var + s.f0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = lane + 64 * q;
-      if (c < n) dst[r * lds_d + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
-    }
+    if (n <= 128)
+      ln_row<2>(src + r * lds_s, dst + r * lds_d, n, lane, s.f0, gamma, beta);
+    else if (n <= 256)
+      ln_row<4>(src + r * lds_s, dst + r * lds_d, n, lane, s.f0, gamma, beta);
+    else
+      ln_row<8>(src + r * lds_s, dst + r * lds_d, n, lane, s.f0, gamma, beta);
   }
 }
 
 template <int MT, bool EXT>
 __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
+  TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
   const int n = s.n;
-  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
-    const int r = e / n, c = e - r * n;
-    if (s.op == TBX_OP_ADD)
-      dst[r * lds_d + c] += src[r * lds_s + c];
-    else if (s.op == TBX_OP_COPY)
-      dst[r * lds_d + c] = src[r * lds_s + c];
-    else  // CLAMP
-      dst[r * lds_d + c] = fminf(fmaxf(dst[r * lds_d + c], s.f0), s.f1);
+  if (s.op != TBX_OP_CLAMP && (n & 3) == 0 && ((s.src_col | s.dst_col) & 3) == 0) {
+    const int w4 = n >> 2;
+    for (int r = wave; r < ROWS; r += nwave)
+      for (int c4 = lane; c4 < w4; c4 += 64) {
+        float4 v = *(const float4*)(src + r * lds_s + c4 * 4);
+        float4* d = (float4*)(dst + r * lds_d + c4 * 4);
+        if (s.op == TBX_OP_ADD) {
+          const float4 o = *d;
+          v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+        }
+        *d = v;
+      }
+    return;
   }
+  for (int r = wave; r < ROWS; r += nwave)
+    for (int c = lane; c < n; c += 64) {
+      if (s.op == TBX_OP_ADD)
+        dst[r * lds_d + c] += src[r * lds_s + c];
+      else if (s.op == TBX_OP_COPY)
+        dst[r * lds_d + c] = src[r * lds_s + c];
+      else  // CLAMP
+        dst[r * lds_d + c] = fminf(fmaxf(dst[r * lds_d + c], s.f0), s.f1);
+    }
 }
 
 template <int MT, bool EXT>
 __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
+  TBX_WAVE_ROWS;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_d = t.l(s.dst);
   const uint8_t* mask = (const uint8_t*)s.p0;
   const int n = s.n;
-  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
-    const int r = e / n, c = e - r * n;
+  for (int r = wave; r < ROWS; r += nwave) {
     bool m = r >= t.n_valid;
-    if (!m && mask != nullptr) m = mask[row_of(s, t.g0 + r)] != 0;
-    if (m) dst[r * lds_d + c] = s.f0;
+    if (!m && mask != nullptr) m = gld1(mask + row_of(s, t.g0 + r)) != 0;
+    if (m)
+      for (int c = lane; c < n; c += 64) dst[r * lds_d + c] = s.f0;
   }
 }
 
@@ -351,32 +503,33 @@ __device__ void op_poolmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     float m = -INFINITY;
     bool any = false;
     for (int r = 0; r < t.n_valid; ++r) {
-      if (mask != nullptr && mask[t.g0 + r] != 0) continue;
+      if (mask != nullptr && gld1(mask + t.g0 + r) != 0) continue;
       any = true;
       m = fmaxf(m, src[r * lds_s + c]);
     }
-    out[t.group * (int64_t)s.ld + s.dst_col + c] = any ? m : 0.f;
+    gst1(out + t.group * (int64_t)s.ld + s.dst_col + c, any ? m : 0.f);
   }
 }
 
 template <int MT, bool EXT>
 __device__ void op_store(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
+  TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   const int lds_s = t.l(s.src);
   float* out = (float*)s.p0;
   const int n = s.n;
   if ((n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 && (s.src_col & 3) == 0 && ((((uintptr_t)out) & 15) == 0)) {
     const int w4 = n >> 2;
-    for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
-      const int r = e / w4, c4 = e - r * w4;
-      if (r < t.n_valid) *(float4*)(out + (t.g0 + r) * (int64_t)s.ld + s.dst_col + c4 * 4) = *(const float4*)(src + r * lds_s + c4 * 4);
+    for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
+      float* orow = out + (t.g0 + r) * (int64_t)s.ld + s.dst_col;
+      for (int c4 = lane; c4 < w4; c4 += 64) gst4(orow + c4 * 4, *(const float4*)(src + r * lds_s + c4 * 4));
     }
     return;
   }
-  for (int e = threadIdx.x; e < ROWS * n; e += blockDim.x) {
-    const int r = e / n, c = e - r * n;
-    if (r < t.n_valid) out[(t.g0 + r) * (int64_t)s.ld + s.dst_col + c] = src[r * lds_s + c];
+  for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
+    float* orow = out + (t.g0 + r) * (int64_t)s.ld + s.dst_col;
+    for (int c = lane; c < n; c += 64) gst1(orow + c, src[r * lds_s + c]);
   }
 }
 
@@ -396,7 +549,7 @@ __device__ unsigned int g_clk_launch;
 #endif
 
 template <int MT, bool EXT>
-__global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const RowchainArgs a) {
+__global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   constexpr int ROWS = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef TBX_STAGE_CLOCK
@@ -424,13 +577,19 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
   }
   // The program is copied kernarg -> LDS once (one parallel read) and each stage descriptor is decoded from LDS into
   // SGPRs (readfirstlane): a scalar load per stage from the kernarg segment costs ~0.6 us of exposed latency per stage.
-  constexpr int SW = (int)(sizeof(tbx_stage_t) / 4);
   uint32_t* prog = (uint32_t*)(lds + (size_t)ROWS * (a.ldw0 + a.ldw1 + a.ld_aux));
   {
     const uint32_t* ka = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     for (int e = threadIdx.x; e < a.n_stages * SW; e += blockDim.x) prog[e] = ka[e];
   }
   __syncthreads();
+  WeightAhead wa;
+#pragma unroll
+  for (int q = 0; q < CH; ++q) wa.w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  wa.bias = 0.f;
+  wa.stage = -1;
+  if (a.first_packed >= 0)
+    weights_ahead(prog, a.first_packed, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wa);
   for (int i = 0; i < a.n_stages; ++i) {
     const uint32_t* ps = prog + i * SW;
     auto rd = [&](int w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ps[w]); };
@@ -439,12 +598,12 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
     s.op = (int32_t)rd(0), s.src = (int32_t)rd(1), s.dst = (int32_t)rd(2), s.src_col = (int32_t)rd(3);
     s.dst_col = (int32_t)rd(4), s.k = (int32_t)rd(5), s.n = (int32_t)rd(6), s.act = (int32_t)rd(7);
     s.flags = (int32_t)rd(8), s.ld = (int32_t)rd(9), s.div = (int32_t)rd(10), s.reserved = (int32_t)rd(11);
-    s.ld2 = (int32_t)rd(12), s.pad = 0;
+    s.ld2 = (int32_t)rd(12), s.pad = (int32_t)rd(13);
     s.f0 = __uint_as_float(rd(14)), s.f1 = __uint_as_float(rd(15));
     s.p0 = rdp(16), s.p1 = rdp(18), s.p2 = rdp(20);
     switch (s.op) {
       case TBX_OP_LOAD: op_load<MT, EXT>(s, t); break;
-      case TBX_OP_LINEAR: op_linear<MT, EXT>(s, t); break;
+      case TBX_OP_LINEAR: op_linear<MT, EXT>(s, t, prog, i, wa); break;
       case TBX_OP_LAYERNORM: op_layernorm<MT, EXT>(s, t); break;
       case TBX_OP_ADD:
       case TBX_OP_COPY:
@@ -455,7 +614,9 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
       case TBX_OP_STORE: op_store<MT, EXT>(s, t); break;
       default: break;
     }
-    __syncthreads();
+    // Stage barrier: orders LDS only. Weight loads issued ahead stay in flight across it, and global memory written by
+    // a stage (STORE / POOLMAX / LINEAR-to-global) is an output of the launch, never read back by a later stage.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TBX_CLK(i + 1);
   }
 #ifdef TBX_STAGE_CLOCK
@@ -463,19 +624,25 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : 512) void rowchain_kernel(const Ro
 #endif
 }
 
-// out[(((grp*n_tiles + tile)*kblocks + kb)*64 + lane)*4 + t] = W_grp[col = tile*16 + (lane & 15)][kk = kb*16 + (lane >> 4)*4 + t]
-__global__ void pack_weight_kernel(const float* __restrict__ w, int n, int k, int ld, int groups, int wt, float* __restrict__ out,
-                                   int64_t total) {
+// Image layout per 16-column tile (tile index = grp*n_tiles + tile): kblocks x [64 lanes][4] weights, where lane l / slot t
+// holds W_grp[col = tile*16 + (l & 15)][kk = kb*16 + (l >> 4)*4 + t], then [64] bias values bias[grp*n + col(l)].
+__global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld,
+                                   int groups, int wt, float* __restrict__ out, int64_t total) {
   const int n_tiles = (n + 15) / 16, kblocks = (k + 15) / 16;
+  const int tstride = kblocks * 256 + 64;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(e & 3), lane = (int)((e >> 2) & 63);
-    int64_t r = e >> 8;
-    const int kb = (int)(r % kblocks);
-    r /= kblocks;
-    const int tile = (int)(r % n_tiles), grp = (int)(r / n_tiles);
-    const int col = tile * 16 + (lane & 15), kk = kb * 16 + (lane >> 4) * 4 + t;
+    const int64_t tix = e / tstride;
+    const int o = (int)(e - tix * tstride);
+    const int tile = (int)(tix % n_tiles), grp = (int)(tix / n_tiles);
     float v = 0.f;
-    if (col < n && kk < k) v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+    if (o < kblocks * 256) {
+      const int t = o & 3, lane = (o >> 2) & 63, kb = o >> 8;
+      const int col = tile * 16 + (lane & 15), kk = kb * 16 + (lane >> 4) * 4 + t;
+      if (col < n && kk < k) v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+    } else {
+      const int col = tile * 16 + ((o - kblocks * 256) & 15);
+      if (bias != nullptr && col < n) v = bias[(int64_t)grp * n + col];
+    }
     out[e] = v;
   }
 }
@@ -544,15 +711,17 @@ extern "C" int tbx_debug_clock_dump(unsigned long long* host_out, int max_launch
 
 extern "C" int64_t tbx_pack_weight_size(int n, int k, int groups) {
   if (n <= 0 || k <= 0 || groups <= 0) return TBX_ERR_ARG;
-  return (int64_t)groups * ((n + 15) / 16) * ((k + 15) / 16) * 256;
+  return (int64_t)groups * ((n + 15) / 16) * (((k + 15) / 16) * 256 + 64);
 }
 
-extern "C" int tbx_pack_weight(const float* w, int n, int k, int ld, int groups, int wt, float* out, void* stream) {
+extern "C" int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
+                               void* stream) {
   if (w == nullptr || out == nullptr || n <= 0 || k <= 0 || ld <= 0 || groups <= 0) return TBX_ERR_ARG;
   if (groups > 1 && n % 16 != 0) return TBX_ERR_UNSUPPORTED;
   const int64_t total = tbx_pack_weight_size(n, k, groups);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, k, ld, groups, wt, out, total);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out,
+                     total);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -578,6 +747,16 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
     if (rc != TBX_OK) return rc;
     a.st[i] = stages[i];
   }
+  // pad = index of the next packed LINEAR stage after this one (0: none): the kernel fetches that stage's first weights
+  // while this one is still computing
+  int next_packed = 0;
+  for (int i = n_stages - 1; i >= 0; --i) {
+    a.st[i].pad = next_packed;
+    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & TBX_F_WPACK)) next_packed = i;
+  }
+  a.first_packed = -1;
+  for (int i = n_stages - 1; i >= 0; --i)
+    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & TBX_F_WPACK)) a.first_packed = i;
   a.n_stages = n_stages;
   a.group_rows = group_rows;
   a.ldw0 = ldw0;
@@ -597,9 +776,9 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   } while (0)
   if (tile_rows == 16) {
     if (ext)
-      TBX_RC_LAUNCH(1, true, 1024);
+      TBX_RC_LAUNCH(1, true, 512);
     else
-      TBX_RC_LAUNCH(1, false, 1024);
+      TBX_RC_LAUNCH(1, false, 512);
   } else {
     if (ext)
       TBX_RC_LAUNCH(2, true, 512);

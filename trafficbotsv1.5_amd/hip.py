@@ -80,7 +80,7 @@ def load():
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_pack_weight_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_size.restype = C.c_int64
-    lib.tbx_pack_weight.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_pack_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
@@ -218,25 +218,30 @@ def sim_step(state: SimState):
 
 
 # ------------------------------------------------------------------------------------------------ rowchain builder
-def packed_weight(w: torch.Tensor, wt: bool = False, groups: int = 1) -> torch.Tensor:
-    """tbx_pack_weight image of a LINEAR weight. Cached on the weight's base tensor object (the nn.Parameter) per view
-    and version: re-packed after an in-place update (optimizer step, load_state_dict), reused otherwise - chains are
-    rebuilt every eager step - and dropped with the parameter."""
+def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1) -> torch.Tensor:
+    """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
+    per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused
+    otherwise - chains are rebuilt every eager step - and dropped with the parameter."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
     base = w._base if w._base is not None else w
     cache = base.__dict__.setdefault("_tbx_packed", {})
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups)
+    bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey)
+    stamp = (w._version, w.data_ptr(), None if bias is None else bias._version)
     hit = cache.get(key)
-    if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
+    if hit is not None and hit[0] == stamp:
         return hit[1]
     n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
+    if bias is not None:
+        assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n
     lib = load()
     size = lib.tbx_pack_weight_size(n, k, groups)
     if size <= 0:
         _check(int(size), "tbx_pack_weight_size")
     out = torch.empty(size, dtype=torch.float32, device=w.device)
-    _check(lib.tbx_pack_weight(_ptr(w), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
-    cache[key] = (w._version, out, w.data_ptr())
+    _check(lib.tbx_pack_weight(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()),
+           "tbx_pack_weight")
+    cache[key] = (stamp, out)
     return out
 
 
@@ -301,9 +306,9 @@ class Chain:
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         assert (dst == GLOBAL) == (out is not None)
         if self.pack_weights:
-            w, flags = packed_weight(w, wt, groups), (flags & ~F_WT) | F_WPACK
+            w, flags = packed_weight(w, bias, wt, groups), (flags & ~F_WT) | F_WPACK
             return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=bias, p2=out,
+                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=None, p2=out,
                              ld2=0 if out is None else self._rows2d(out).stride(0),
                              reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
         return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
