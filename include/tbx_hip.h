@@ -254,6 +254,13 @@ typedef struct tbx_sim_state {
 
 int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
 
+/* The same step in separately launchable parts. The traffic lights' recurrence (tl_state -> tl encoder -> tl_logits ->
+ * tl_state, traffic_bots.py:188-199 + dynamics.py:143-163) never reads an agent, so a rollout may advance the lights on
+ * one stream while the agents of the same step run on another; both parts read *step, TBX_SIM_ADVANCE bumps it and
+ * must be ordered after both. tbx_sim_step == all three on one stream. */
+enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4 };
+int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,14 +11,14 @@
 
 namespace {
 
-__global__ void sim_step_kernel(const tbx_sim_state_t s) {
+__global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = *s.step;  // step being simulated: model saw the state of step t-1
   const int n_ag_tot = s.n_batch * s.n_ag;
   const int n_tl_tot = s.n_batch * s.n_tl;
   const int T = s.n_step_out;
   const int W = s.window;
-  if (i < n_ag_tot) {
+  if ((parts & TBX_SIM_AGENTS) && i < n_ag_tot) {
     const int b = i / s.n_ag;
     const bool valid0 = s.ag_valid[i] != 0;
     const int ty = s.ag_type_idx[i];
@@ -123,7 +123,7 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s) {
     hm[(W - 1) * 3 + 1] = nacc;
     hm[(W - 1) * 3 + 2] = nyr;
   }
-  if (i < n_tl_tot) {
+  if ((parts & TBX_SIM_LIGHTS) && i < n_tl_tot) {
     // Dynamics.override_tl (dynamics.py:143-163): argmax -> one-hot, ground truth while it lasts
     const float* lg = s.tl_logits + (int64_t)i * 5;
     int am = 0;
@@ -148,7 +148,11 @@ __global__ void sim_bump_kernel(int32_t* step) { *step += 1; }
 }  // namespace
 
 extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
-  if (!st) return TBX_ERR_ARG;
+  return tbx_sim_step_parts(st, TBX_SIM_AGENTS | TBX_SIM_LIGHTS | TBX_SIM_ADVANCE, stream);
+}
+
+extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* stream) {
+  if (!st || (parts & ~(TBX_SIM_AGENTS | TBX_SIM_LIGHTS | TBX_SIM_ADVANCE)) || parts == 0) return TBX_ERR_ARG;
   const tbx_sim_state_t& s = *st;
   if (s.n_batch <= 0 || s.n_ag <= 0 || s.n_tl <= 0 || s.window <= 0 || s.n_step_out <= 0 || s.n_node <= 0) return TBX_ERR_ARG;
   const void* need[] = {s.step, s.ag_valid, s.ag_disabled, s.ag_pose, s.ag_motion, s.navi_valid, s.outside_map,
@@ -158,9 +162,12 @@ extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
                         s.out_motion, s.out_action, s.out_tl_state, s.out_outside_map, s.out_dest_reached};
   for (const void* p : need)
     if (p == nullptr) return TBX_ERR_ARG;
-  const int n = s.n_batch * (s.n_ag > s.n_tl ? s.n_ag : s.n_tl);
+  const int per = ((parts & TBX_SIM_AGENTS) && (parts & TBX_SIM_LIGHTS)) ? (s.n_ag > s.n_tl ? s.n_ag : s.n_tl)
+                                                                          : ((parts & TBX_SIM_AGENTS) ? s.n_ag : s.n_tl);
+  const int n = s.n_batch * per;
   hipStream_t hs = (hipStream_t)stream;
-  hipLaunchKernelGGL(sim_step_kernel, dim3((n + 127) / 128), dim3(128), 0, hs, s);
-  hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
+  if (parts & (TBX_SIM_AGENTS | TBX_SIM_LIGHTS))
+    hipLaunchKernelGGL(sim_step_kernel, dim3((n + 127) / 128), dim3(128), 0, hs, s, parts);
+  if (parts & TBX_SIM_ADVANCE) hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

@@ -88,8 +88,9 @@ def load():
     lib.tbx_tl_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
+    lib.tbx_sim_step_parts.argtypes = [C.POINTER(SimState), i32, vp]
     for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step"):
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -213,8 +214,11 @@ def map_prep(mp_valid_u8, mp_type11, mp_pose, attr, pe, row_invalid, tok_pose, t
     _check(rc, "tbx_map_prep")
 
 
-def sim_step(state: SimState):
-    _check(load().tbx_sim_step(C.byref(state), stream_ptr()), "tbx_sim_step")
+SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE = 1, 2, 4
+
+
+def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE):
+    _check(load().tbx_sim_step_parts(C.byref(state), parts, stream_ptr()), "tbx_sim_step_parts")
 
 
 # ------------------------------------------------------------------------------------------------ rowchain builder

@@ -65,20 +65,39 @@ class TrafficBots(nn.Module):
         """One policy evaluation for all agents / lights. Inputs are the device-resident sliding windows (oldest first);
         writes out['action_mean'] [n*A,2], out['tl_logits'] [n*L,5] (+ out['ag_feat'], out['tl_feat']).
         No host synchronisation: capturable in a hipGraph. traffic_bots.py:188-221."""
-        n, A, W = hist_valid.shape
-        L, d = hist_tl.shape[1], self.hidden_dim
-        dev = hist_pose.device
-        div = tl_tokens.get("mp_batch_div", 1)
+        tl_kv = self.tl_policy(hist_tl, tl_tokens, out)
+        self.agent_policy(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, ag_latent, latent_invalid, dest,
+                          navi_valid_u8, tl_tokens, mp_tokens, tl_kv, out)
+
+    def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor]) -> Tensor:
+        """The traffic-light half (traffic_bots.py:188-199): tl tokens of the window -> next-state logits in
+        out['tl_logits'] and the per-layer K/V tables the agents' tl cross-attention reads (returned, out['tl_kv']).
+        Reads no agent state, so the rollout engine runs it one step ahead on its own stream."""
+        n, L, _ = hist_tl.shape
+        d = self.hidden_dim
         tl_inv = tl_tokens["tl_token_invalid_u8"]
         tl_kv = out.get("tl_kv")
         if tl_kv is None:
-            tl_kv = out["tl_kv"] = torch.empty(n * L, 2 * d * len(self.ag_encoder.tf_ag2agmptl.layers), dtype=torch.float32, device=dev)
+            tl_kv = out["tl_kv"] = torch.empty(n * L, 2 * d * len(self.ag_encoder.tf_ag2agmptl.layers), dtype=torch.float32,
+                                               device=hist_tl.device)
 
         def tl_tail(ch: Chain):
             emit_kv_tables(ch, self.ag_encoder.tl_kv_layers(), tl_kv)
             self.tl_state_predictor.emit(ch, tl_inv, out["tl_logits"])
 
         out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail)
+        return tl_kv
+
+    def agent_policy(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, ag_type_idx: Tensor,
+                     ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
+                     tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor]) -> None:
+        """The agent half (traffic_bots.py:200-221): agent tokens attending to agents / map / tl K/V tables `tl_kv`, then
+        navi + latent + action head -> out['action_mean']."""
+        n, A, W = hist_valid.shape
+        d = self.hidden_dim
+        dev = hist_pose.device
+        div = tl_tokens.get("mp_batch_div", 1)
+        tl_inv = tl_tokens["tl_token_invalid_u8"]
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div)

@@ -1,6 +1,12 @@
 """Closed-loop rollout engine: the device-resident simulation state + one hipGraph that replays
 [policy (tl encoder -> agent encoder -> heads) -> tbx_sim_step] once per 0.1 s step.
 
+The traffic lights' recurrence (window -> tl encoder -> logits -> next state) never reads an agent, so it runs one step
+ahead on a second HIP stream: a replay of step t forks into { lights(t), tl encoder of the new window } and
+{ agent policy on the tl K/V tables of step t-1's window, agents(t) }, joins and bumps the step counter. Results are
+those of the sequential order (same inputs to every kernel); with one 64-agent scene the two halves occupy 8 and 4
+workgroups of a 256-CU device, so they overlap completely.
+
 Replaces the Python loop of `WaymoMotion.rollout` (pl_modules/waymo_motion.py:206-311) and everything it drives per
 step (Dynamics, TeacherForcing.get, the feeding-back rule checks, RolloutBuffer.add, TrafficBots._append_hist); the
 reference's >= 19 host synchronisations per step (SURVEY.md Appx D.1) are gone: the step index lives on the device.
@@ -103,21 +109,38 @@ class RolloutEngine:
         self.sim_state = st
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
         self.graph = None
+        self.tl_kv_cur = None
+        self.side = torch.cuda.Stream(device=dev)
+        self._tl_ahead()
 
     @torch.no_grad()
     def restore(self) -> None:
         """Back to step 1 without re-allocating (pointers captured in the graph stay valid)."""
         for k, v in self.init_state.items():
             self.S[k].copy_(v)
+        self._tl_ahead()
+
+    def _tl_ahead(self) -> None:
+        """tl encoder on the current light window: logits for the next lights update, K/V tables for the next agent step."""
+        kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
+        if self.tl_kv_cur is None:
+            self.tl_kv_cur = torch.empty_like(kv)
 
     # ------------------------------------------------------------------ stepping
     @torch.no_grad()
     def step(self) -> None:
-        S = self.S
-        self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6, S["ag_type_idx"],
-                               self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens,
-                               self.policy_out)
-        hip.sim_step(self.sim_state)
+        S, main = self.S, torch.cuda.current_stream()
+        self.tl_kv_cur.copy_(self.policy_out["tl_kv"])  # tables of the window the agents see this step
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            hip.sim_step(self.sim_state, hip.SIM_LIGHTS)  # logits of the previous tl encoder pass -> lights of this step
+            self._tl_ahead()
+        self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
+                                self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
+                                self.mp_tokens, self.tl_kv_cur, self.policy_out)
+        hip.sim_step(self.sim_state, hip.SIM_AGENTS)
+        main.wait_stream(self.side)
+        hip.sim_step(self.sim_state, hip.SIM_ADVANCE)
 
     @torch.no_grad()
     def capture(self) -> None:
