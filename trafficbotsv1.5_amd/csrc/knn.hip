@@ -1,7 +1,7 @@
 // tbx_knn_embed / tbx_pose_embed: relative pose + K-nearest selection + pose embedding (see include/tbx_hip.h).
 //
-// One wavefront per source token. Each lane keeps n_tgt/64 candidate distances in registers; the K winners are
-// extracted by K rounds of (lane-local argmin, wave-wide argmin by xor-shuffles), ties resolved to the lower index.
+// One wavefront per source token. Each lane keeps n_tgt/64 candidate distances in registers; the K-th smallest distance is
+// found by bisection over the key bits (wave ballots), the K winners are everything below it plus the lowest-index ties.
 // Distances follow the reference's operation order without FMA contraction (SURVEY.md Appx A.2):
 //   rx = dx*c + dy*s ; ry = dy*c - dx*s ; dist = sqrt(rx*rx + ry*ry), +inf if either side is invalid.
 // The embedding of the K selected relative poses is written by the same wave (lanes = channels), so the
@@ -57,68 +57,68 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
   const uint8_t* ti = a.tgt_invalid + (int64_t)bt * a.n_tgt;
 
   if (wir == 0) {
-  float d[MAXC];
-  uint32_t taken = 0;
-#pragma unroll
-  for (int q = 0; q < MAXC; ++q) {
-    const int j = lane + 64 * q;
-    if (j < a.n_tgt) {
-      float rx, ry;
-      rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
-      const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)));
-      d[q] = (inv1 || ti[j] != 0) ? INFINITY : dist;
-    } else {
-      d[q] = INFINITY;
-      taken |= 1u << q;
-    }
-  }
-
-  int my_idx = 0;
-  float my_dist = INFINITY;
-  for (int it = 0; it < a.k; ++it) {
-    float v = INFINITY;
-    int j = INT_MAX;
+    // Candidate keys: the fp32 bits of the distance (non-negative, so unsigned order == float order; +inf for masked
+    // pairs), 0xffffffff for slots past n_tgt. Lane l owns targets l, l+64, ...
+    uint32_t key[MAXC];
 #pragma unroll
     for (int q = 0; q < MAXC; ++q) {
-      const bool free_q = ((taken >> q) & 1u) == 0;
-      // strict < keeps the lowest q (= lowest index within the lane) on ties; a free +inf slot still beats "none"
-      if (free_q && (d[q] < v || j == INT_MAX)) {
-        v = d[q];
-        j = lane + 64 * q;
+      const int j = lane + 64 * q;
+      key[q] = 0xffffffffu;
+      if (j < a.n_tgt) {
+        float rx, ry;
+        rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
+        const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)));
+        key[q] = __float_as_uint((inv1 || ti[j] != 0) ? INFINITY : dist);
       }
     }
+    // K-th smallest key by bisection over its 31 value bits: count(key < cand) is a sum of wave ballots' popcounts, so
+    // it lands in a scalar register and the pivot update is scalar too. ~50 instructions per bit instead of the ~150
+    // per extracted neighbour of a K-round argmin (K = 64 for agent -> map).
+    uint32_t kth = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+      const uint32_t cand = kth | (1u << bit);
+      int cnt = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(v, off, 64);
-      const int oj = __shfl_xor(j, off, 64);
-      if (ov < v || (ov == v && oj < j)) {
-        v = ov;
-        j = oj;
+      for (int q = 0; q < MAXC; ++q) cnt += __popcll(__ballot(key[q] < cand));
+      if (cnt < a.k) kth = cand;
+    }
+    // Everything below the K-th key is in; keys equal to it fill the remaining slots in ascending target index (the
+    // reference's topk leaves the order among equal distances open; masked +inf pairs are don't-cares). Output slots
+    // are assigned in ascending target index: position = number of chosen targets with a smaller index.
+    int n_less = 0;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) n_less += __popcll(__ballot(key[q] < kth));
+    const int n_ties = a.k - n_less;  // >= 1
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    int ties_before = 0, chosen_before = 0;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+      const bool tie = key[q] == kth;
+      const uint64_t tie_m = __ballot(tie);
+      const bool take = key[q] < kth || (tie && ties_before + __popcll(tie_m & lt_mask) < n_ties);
+      const uint64_t take_m = __ballot(take);
+      if (take) {
+        const int pos = chosen_before + __popcll(take_m & lt_mask);
+        const int j = lane + 64 * q;
+        const int64_t o = (int64_t)row * a.k + pos;
+        const float dist = __uint_as_float(key[q]);
+        a.idx[o] = j;
+        a.invalid[o] = (ti[j] != 0 || dist > a.dist_limit) ? 1 : 0;
+        float rx, ry;
+        rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
+        const float ryaw = __fsub_rn(tp[j * 3 + 2], yaw1);
+        rel_s[wave][pos][0] = rx;
+        rel_s[wave][pos][1] = ry;
+        rel_s[wave][pos][2] = ryaw;
+        if (a.rel_pose != nullptr) {
+          a.rel_pose[o * 3 + 0] = rx;
+          a.rel_pose[o * 3 + 1] = ry;
+          a.rel_pose[o * 3 + 2] = ryaw;
+        }
       }
+      ties_before += __popcll(tie_m);
+      chosen_before += __popcll(take_m);
     }
-    if ((j & 63) == lane) taken |= 1u << (j >> 6);
-    if (lane == it) {
-      my_idx = j;
-      my_dist = v;
-    }
-  }
-
-  if (lane < a.k) {
-    const int64_t o = (int64_t)row * a.k + lane;
-    a.idx[o] = my_idx;
-    a.invalid[o] = (ti[my_idx] != 0 || my_dist > a.dist_limit) ? 1 : 0;
-    float rx, ry;
-    rel_xy(x1, y1, c, s, tp[my_idx * 3 + 0], tp[my_idx * 3 + 1], rx, ry);
-    const float ryaw = __fsub_rn(tp[my_idx * 3 + 2], yaw1);
-    rel_s[wave][lane][0] = rx;
-    rel_s[wave][lane][1] = ry;
-    rel_s[wave][lane][2] = ryaw;
-    if (a.rel_pose != nullptr) {
-      a.rel_pose[o * 3 + 0] = rx;
-      a.rel_pose[o * 3 + 1] = ry;
-      a.rel_pose[o * 3 + 2] = ryaw;
-    }
-  }
   }  // wir == 0
   if (a.emb == nullptr) return;
   if constexpr (WPR > 1)
