@@ -241,3 +241,32 @@ def test_attention_relative_pose_mode_matches_materialised(tb, hip, dev):
     torch.testing.assert_close(outs[1], outs[0], rtol=2e-4, atol=2e-5)
     # the E-sums are convex combinations of embedding channels: their agreement bounds the per-channel sin/cos error
     assert float((outs[1][:, 128:] - outs[0][:, 128:]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,k,n,groups,wt", [(64, 128, 128, 1, False), (40, 20, 5, 1, False), (16, 512, 128, 1, False),
+                                                (70, 32, 128, 4, True), (33, 128, 32, 4, False), (5000, 128, 384, 1, False)])
+def test_packed_weight_image_equals_row_major_linear(hip, dev, rows, k, n, groups, wt):
+    """tbx_pack_weight + TBX_F_WPACK feed the MFMAs the same operands in the same order as the row-major reference path
+    of LINEAR: bit-identical outputs (odd k / n, grouped, [k,n] layout, >= 4096 rows), and both match torch."""
+    g = torch.Generator().manual_seed(rows + k + n)
+    x = torch.randn(rows, groups * k if groups > 1 and not wt else max(k, groups * k), generator=g)
+    w = torch.randn(groups * (k if wt else n), n if wt else k, generator=g) * 0.1
+    bias = torch.randn(groups * n, generator=g)
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    outs = []
+    for pack in (True, False):
+        out = torch.zeros(rows, groups * n, device=dev)
+        ch = hip.Chain(16, 1028)
+        ch.pack_weights = pack
+        kw = max(k, 16)
+        ch.load(xd, hip.BUF0, 0, n=xd.shape[1], pad_to=((xd.shape[1] + 15) // 16) * 16)
+        ch.linear(hip.BUF0, 0, hip.BUF1, 0, wd, bd, wt=wt, groups=groups, src_stride=k if groups > 1 else 0,
+                  dst_stride=n if groups > 1 else 0)
+        ch.store(hip.BUF1, 0, groups * n, out)
+        ch.run(rows)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    xs = x[:, :groups * k].reshape(rows, groups, k)
+    ws = w.reshape(groups, k, n) if wt else w.reshape(groups, n, k).transpose(1, 2)
+    ref = torch.einsum("rgk,gkn->rgn", xs.double(), ws.double()).reshape(rows, groups * n) + bias.double()
+    torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4)

@@ -162,3 +162,31 @@ def test_joint_future_pred_shares_map_and_matches_single(tb):
     for k in range(K):
         torch.testing.assert_close(bK.pred_pose[:, k], b1.pred_pose[:, 0], rtol=1e-5, atol=1e-4)
         assert torch.equal(bK.pred_valid[:, k], b1.pred_valid[:, 0])
+
+
+def test_lights_one_step_ahead_equals_sequential_order(tb):
+    """The engine advances the traffic lights one step ahead on a second stream (tbx_sim_step_parts): every kernel sees
+    the inputs of the sequential order, so the rollout must be bit-identical to it, eager and as a graph."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
+    E = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 8, 16, generator=g).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    outs = {}
+    try:
+        for ahead in (True, False):
+            for use_graph in (False, True):
+                E.lights_ahead = ahead
+                outs[ahead, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid,
+                                                            wm.teacher_forcing_joint_future_pred, True, step_end=40,
+                                                            use_graph=use_graph)
+    finally:
+        E.lights_ahead = True
+    ref = outs[False, False]
+    for k, o in outs.items():
+        assert torch.equal(o.pred_pose, ref.pred_pose), k
+        assert torch.equal(o.pred_valid, ref.pred_valid), k
+        assert torch.equal(o.vis_dict["tl_state"], ref.vis_dict["tl_state"]), k
+        assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), k

@@ -33,6 +33,8 @@ def _state_bits(one_hot: Tensor) -> Tensor:
 
 
 class RolloutEngine:
+    lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
+
     def __init__(self, model, dynamics, device) -> None:
         self.model, self.dyn, self.dev = model, dynamics, device
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -130,6 +132,12 @@ class RolloutEngine:
     @torch.no_grad()
     def step(self) -> None:
         S, main = self.S, torch.cuda.current_stream()
+        if not self.lights_ahead:
+            self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6,
+                                   S["ag_type_idx"], self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"],
+                                   self.tl_tokens, self.mp_tokens, self.policy_out)
+            hip.sim_step(self.sim_state)
+            return
         self.tl_kv_cur.copy_(self.policy_out["tl_kv"])  # tables of the window the agents see this step
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
