@@ -46,10 +46,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events for the roofline")
+    ap.add_argument("--no-wosac-shape", action="store_true",
+                    help="skip the second measurement (32 rollouts x 128 agents per GPU) the default rollout run appends")
     a = ap.parse_args()
     tr = a.mode == "train"
     a.steps = a.steps if a.steps is not None else (3 if tr else 80)
     a.warmup = a.warmup if a.warmup is not None else (1 if tr else 10)
+    # the WOSAC-shape measurement rides along only with the default (configs[1]) workload
+    a.wosac_shape = (not tr and not a.no_wosac_shape and a.scenes is None and a.rollouts == 1 and a.agents == 64
+                     and a.profile_steps > 0)
     a.scenes = a.scenes if a.scenes is not None else (16 if tr else 1)
     return a
 
@@ -186,12 +191,16 @@ def cpu_baseline(tb, wm, full, args):
             if best is None or d < best[0]:
                 best = (d, nt)
         torch.set_num_threads(best[1])
-        t0 = time.perf_counter()
-        run(args.cpu_steps)
+        # bounded sample: whole `cpu_steps`-step rollouts until ~10 s of CPU work (the host cores of a box are shared and
+        # their speed varies an order of magnitude between boxes; a sub-second sample is noise)
+        n_done, t0 = 0, time.perf_counter()
+        while n_done == 0 or (time.perf_counter() - t0 < 10.0 and n_done < 40 * args.cpu_steps):
+            run(args.cpu_steps)
+            n_done += args.cpu_steps
         dt = time.perf_counter() - t0
         torch.set_num_threads(n_all)
-    return {"value": args.agents * args.cpu_steps / dt, "unit": "sim-agent-steps/s", "cores": best[1],
-            "kind": "port", "sample": f"1 scene x {args.agents} agents x {args.cpu_steps} closed-loop steps in {dt:.1f}s "
+    return {"value": args.agents * n_done / dt, "unit": "sim-agent-steps/s", "cores": best[1],
+            "kind": "port", "sample": f"1 scene x {args.agents} agents x {n_done} closed-loop steps ({n_done // args.cpu_steps} rollouts of {args.cpu_steps}) in {dt:.1f}s "
                                       f"(oracle, torch {torch.__version__} CPU fp32, best of 8/16/32/64/all = {best[1]} threads of {n_all}, "
                                       f"map encoding excluded)"}
 
@@ -262,54 +271,69 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    wm, full = build(tb, args, dev, rank)
-    eng, t_scene = gpu_rollout_setup(tb, wm, full, args, dev)
-    use_graph = not args.no_graph
-    if use_graph:
-        eng.capture()
-    eng.run(args.warmup, use_graph=use_graph)  # teacher-forced prime steps (untimed)
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    eng.run(args.steps, use_graph=use_graph)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    n_roll_rank = args.scenes * args.rollouts
-    units = world * n_roll_rank * args.agents * args.steps
-    # ---- live per-kernel timing (eager steps right after the timed region, same state, same stream)
-    with KernelEvents(hip) as ke:
-        eng.run(args.profile_steps, use_graph=False)
-    (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
-    finite = bool(torch.isfinite(eng.S["out_pose"]).all())
-    if rank == 0:
+    def measure(a):
+        """One timed closed-loop rollout of workload `a` on this rank; returns the JSON fields of that measurement."""
+        wm, full = build(tb, a, dev, rank)
+        eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
+        use_graph = not a.no_graph
+        if use_graph:
+            eng.capture()
+        eng.run(a.warmup, use_graph=use_graph)  # teacher-forced prime steps (untimed)
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(a.steps, use_graph=use_graph)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        units = world * a.scenes * a.rollouts * a.agents * a.steps
+        # ---- live per-kernel timing (eager steps right after the timed region, same state; events on the launch stream)
+        with KernelEvents(hip) as ke:
+            eng.run(a.profile_steps, use_graph=False)
+        (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
         ach = b_attn / t_attn / 1e9
-        traffic, traffic_src = pmc_traffic(args, "knarpe_attn_kernel")
-        line = {
-            "metric": "sim-agent-steps/sec (closed-loop rollout)", "value": units / dt, "unit": "sim-agent-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.agents}-agent/{args.polylines}-polyline/{args.lights}-light synthetic scene, "
-                                   f"{args.warmup}-step teacher-forced prime + {args.steps}-step closed-loop rollout",
-                       "scenes_per_gpu": args.scenes, "rollouts_per_scene": args.rollouts, "graph": use_graph,
+        traffic, traffic_src = pmc_traffic(a, "knarpe_attn_kernel")
+        res = {
+            "value": units / dt, "ms_per_step": dt / a.steps * 1e3,
+            "config": {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
+                                   f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
+                       "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n_attn / args.profile_steps,
-                         "avg_launch_us": t_attn / n_attn * 1e6, "algorithmic_bytes_per_launch": b_attn / n_attn},
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches_per_step": n_attn / a.profile_steps, "avg_launch_us": t_attn / n_attn * 1e6,
+                         "algorithmic_bytes_per_launch": b_attn / n_attn},
             "roofline_gemm": {"kernel": "rowchain_kernel", "bound": "mfma", "achieved": f_chain / t_chain / 1e12,
                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f_chain / t_chain / 1e12 / FP32_MFMA_PEAK_TF,
-                              "launches_per_step": n_chain / args.profile_steps, "avg_launch_us": t_chain / n_chain * 1e6},
-            "scene_encode_ms": t_scene * 1e3, "finite": finite,
+                              "launches_per_step": n_chain / a.profile_steps, "avg_launch_us": t_chain / n_chain * 1e6},
+            "scene_encode_ms": t_scene * 1e3, "finite": bool(torch.isfinite(eng.S["out_pose"]).all()),
         }
+        return res, wm, full
+
+    res, wm, full = measure(args)
+    line = {"metric": "sim-agent-steps/sec (closed-loop rollout)", "value": res.pop("value"), "unit": "sim-agent-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **res}
+    if args.wosac_shape:
+        # BASELINE.json configs[4] on the same device(s): 32 parallel rollouts x 128 agents per scenario, one scenario per
+        # GPU - the size at which the relative-pose attention kernel fills the chip (its roofline fraction is the one
+        # north_star's >= 50 % target refers to; the single 64-agent scene above launches 64-128 workgroups).
+        import copy
+
+        big = copy.copy(args)
+        big.scenes, big.rollouts, big.agents, big.steps = 1, 32, 128, min(args.steps, 40)
+        r5, _, _ = measure(big)
+        line["wosac_shape"] = {"metric": line["metric"], "unit": line["unit"], "n_gpus": world, "steps": big.steps,
+                               "warmup": big.warmup, **r5}
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(tb, wm, full, args)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

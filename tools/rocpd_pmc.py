@@ -1,11 +1,14 @@
 #!/usr/bin/env python
-"""Per-kernel average of one PMC counter from a rocprofv3 rocpd database (separate --pmc pass per counter).
-    python tools/rocpd_pmc.py fetch.db write.db > profiles/rNN_pmc.json
-FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 counter definition). gfx950 correction (MI355X_MICROARCH.md §HBM):
-FETCH_SIZE counts 128-B requests of wide coalesced reads at 64 B, i.e. reports half of the bytes of a 16 B/lane stream."""
+"""HBM traffic per launch of every tbx kernel from two rocprofv3 rocpd databases (one --pmc pass per counter).
+    python tools/rocpd_pmc.py --agents 64 --polylines 1024 --lights 128 --scenes 1 --rollouts 1 fetch.db write.db \
+        > profiles/rNN_pmc_<tag>.json
+FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 counter definition). gfx950 correction (MI355X_MICROARCH.md, HBM section):
+FETCH_SIZE tallies the 128-byte read requests of wide coalesced loads at 64 B, so read bytes = 2 * FETCH_SIZE.
+bench.py's roofline.traffic reads the file whose `workload` matches the run."""
+import argparse
 import json
+import re
 import sqlite3
-import sys
 
 
 def per_kernel(path):
@@ -13,23 +16,61 @@ def per_kernel(path):
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     t = lambda stem: next(x for x in tabs if x.startswith(stem))
     pe, pi, kd, ks = t("rocpd_pmc_event"), t("rocpd_info_pmc"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
-    q = (f"select s.kernel_name, p.name, count(*), avg(e.value), sum(e.value) from {pe} e join {pi} p on e.pmc_id = p.id "
+    q = (f"select s.kernel_name, p.name, count(*), avg(e.value) from {pe} e join {pi} p on e.pmc_id = p.id "
          f"join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id group by s.kernel_name, p.name")
     out = {}
-    for name, ctr, n, avg, tot in db.execute(q):
-        short = name.split("(")[0]
-        out.setdefault(short, {})[ctr] = {"launches": n, "avg": avg, "sum": tot}
+    for name, ctr, n, avg in db.execute(q):
+        out.setdefault(name, {})[ctr] = (n, avg)
     return out
 
 
-def main(paths):
-    res = {}
-    for p in paths:
+def short(mangled: str) -> str:
+    """_ZN12_GLOBAL__N_118knarpe_attn_kernelILi4EEEv... -> knarpe_attn_kernel<4>"""
+    m = re.search(r"GLOBAL__N_1\d+([a-z_0-9]+?_kernel)(I(?:L[ib]\d+E)+E)?", mangled)
+    if not m:
+        return mangled
+    targs = re.findall(r"L[ib](\d+)E", m.group(2) or "")
+    return m.group(1) + ("<" + ",".join(targs) + ">" if targs else "")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for k in ("agents", "polylines", "lights", "scenes", "rollouts"):
+        ap.add_argument("--" + k, type=int, required=True)
+    ap.add_argument("--cmd", default="")
+    ap.add_argument("dbs", nargs="+")
+    a = ap.parse_args()
+    raw = {}
+    for p in a.dbs:
         for k, v in per_kernel(p).items():
-            res.setdefault(k, {}).update(v)
-    keep = {k: v for k, v in res.items() if "GLOBAL__N" in k}
-    print(json.dumps(keep, indent=1))
+            raw.setdefault(k, {}).update(v)
+    kernels = {}
+    for name, c in raw.items():
+        if "GLOBAL__N" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        (n, f), (_, w) = c["FETCH_SIZE"], c["WRITE_SIZE"]
+        e = kernels.setdefault(short(name), {"launches": 0, "FETCH_SIZE_KiB_avg": 0.0, "WRITE_SIZE_KiB_avg": 0.0})
+        tot = e["launches"] + n  # template variants of one kernel are merged launch-weighted
+        e["FETCH_SIZE_KiB_avg"] = (e["FETCH_SIZE_KiB_avg"] * e["launches"] + f * n) / tot
+        e["WRITE_SIZE_KiB_avg"] = (e["WRITE_SIZE_KiB_avg"] * e["launches"] + w * n) / tot
+        e["launches"] = tot
+    merged = {}
+    for k, e in kernels.items():  # also a template-free entry (what bench.py looks up)
+        b = merged.setdefault(k.split("<")[0], {"launches": 0, "FETCH_SIZE_KiB_avg": 0.0, "WRITE_SIZE_KiB_avg": 0.0})
+        tot = b["launches"] + e["launches"]
+        for f in ("FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg"):
+            b[f] = (b[f] * b["launches"] + e[f] * e["launches"]) / tot
+        b["launches"] = tot
+    kernels.update({k: v for k, v in merged.items() if k not in kernels})
+    for e in kernels.values():
+        e["traffic_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KiB_avg"] + e["WRITE_SIZE_KiB_avg"]) * 1024)
+    print(json.dumps({
+        "collected_with": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (separate passes) -- " + a.cmd,
+        "workload": {k: getattr(a, k) for k in ("agents", "polylines", "lights", "scenes", "rollouts")},
+        "units": "KiB per launch (rocprofv3 counter definition); traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
+                 "doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE as is",
+        "kernels": kernels}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    main()
