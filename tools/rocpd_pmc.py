@@ -46,8 +46,8 @@ def main():
             raw.setdefault(k, {}).update(v)
     kernels = {}
     for name, c in raw.items():
-        if "GLOBAL__N" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-            continue
+        if "GLOBAL__N" not in name or "at6native" in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue  # tbx kernels only
         (n, f), (_, w) = c["FETCH_SIZE"], c["WRITE_SIZE"]
         e = kernels.setdefault(short(name), {"launches": 0, "FETCH_SIZE_KiB_avg": 0.0, "WRITE_SIZE_KiB_avg": 0.0})
         tot = e["launches"] + n  # template variants of one kernel are merged launch-weighted
