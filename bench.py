@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events for the roofline")
+    ap.add_argument("--no-lights-ahead", action="store_true",
+                    help="one-stream engine (tl encoder -> agents -> sim step in order): the kernel-trace profiles use it so "
+                         "that rocprofv3's per-kernel averages are of kernels running alone, like the live roofline events")
     ap.add_argument("--no-wosac-shape", action="store_true",
                     help="skip the second measurement (32 rollouts x 128 agents per GPU) the default rollout run appends")
     a = ap.parse_args()
@@ -280,6 +283,7 @@ def main():
     def measure(a):
         """One timed closed-loop rollout of workload `a` on this rank; returns the JSON fields of that measurement."""
         wm, full = build(tb, a, dev, rank)
+        import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.lights_ahead = not a.no_lights_ahead
         eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
         use_graph = not a.no_graph
         if use_graph:
@@ -295,9 +299,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         units = world * a.scenes * a.rollouts * a.agents * a.steps
-        # ---- live per-kernel timing (eager steps right after the timed region, same state; events on the launch stream)
-        with KernelEvents(hip) as ke:
-            eng.run(a.profile_steps, use_graph=False)
+        # ---- live per-kernel timing: eager steps right after the timed region, same state, events on the launch stream, in
+        # the engine's one-stream order so that a kernel's duration is its own (in the timed region the light and agent
+        # halves share the device, which stretches the kernels of both)
+        Eng = type(eng)
+        Eng.lights_ahead = False
+        try:
+            with KernelEvents(hip) as ke:
+                eng.run(a.profile_steps, use_graph=False)
+        finally:
+            Eng.lights_ahead = not a.no_lights_ahead
         (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
         ach = b_attn / t_attn / 1e9
         traffic, traffic_src = pmc_traffic(a, "knarpe_attn_kernel")
@@ -306,6 +317,7 @@ def main():
             "config": {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
                                    f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
                        "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
+                       "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

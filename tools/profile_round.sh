@@ -10,8 +10,8 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
 wl="--agents $ag --polylines $pl --lights $tl --scenes $sc --rollouts $ro"
-kt="bench.py --no-cpu-baseline --no-wosac-shape $wl $*"
-pmc="bench.py --no-cpu-baseline --no-wosac-shape --no-graph --profile-steps 0 --steps 8 --warmup 2 $wl $*"
+kt="bench.py --no-cpu-baseline --no-wosac-shape --no-lights-ahead $wl $*"
+pmc="bench.py --no-cpu-baseline --no-wosac-shape --no-lights-ahead --no-graph --profile-steps 0 --steps 8 --warmup 2 $wl $*"
 
 rocprofv3 --kernel-trace --stats -d "$out/kt_$tag" -o kt -- python3 $kt > "$out/${tag}_bench.log" 2>&1
 db=$(find "$out/kt_$tag" -name '*.db' | head -1)
