@@ -134,7 +134,8 @@ enum {
   TBX_F_ROW_MOD = 8,  /* row_of(g) = g % div */
   TBX_F_ROW_IDX = 16, /* row_of(g) = ((const int32_t*)p1)[g]  (LOAD gather) */
   TBX_F_ROW_BATCH_MOD = 32, /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
-  TBX_F_WPACK = 64    /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
+  TBX_F_WPACK = 64,   /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
+  TBX_F_MASK_INV = 128 /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };
@@ -208,7 +209,8 @@ int tbx_map_prep(const uint8_t* mp_valid, const float* mp_type11, const float* m
 typedef struct tbx_sim_state {
   /* sizes */
   int32_t n_batch, n_ag, n_tl, window, n_step_gt, n_step_tl_gt, n_step_out, n_node;
-  /* device step counter (1-based step being simulated) */
+  /* device step counter: step[0] = 1-based step being simulated, step[1] = workgroup arrival counter used when the
+   * advance is fused into a part's kernel (zero-initialised by the caller, left at zero) */
   int32_t* step;
   /* agent state, updated in place */
   uint8_t* ag_valid;    /* [n,A] */
@@ -257,7 +259,8 @@ int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
 /* The same step in separately launchable parts. The traffic lights' recurrence (tl_state -> tl encoder -> tl_logits ->
  * tl_state, traffic_bots.py:188-199 + dynamics.py:143-163) never reads an agent, so a rollout may advance the lights on
  * one stream while the agents of the same step run on another; both parts read *step, TBX_SIM_ADVANCE bumps it and
- * must be ordered after both. tbx_sim_step == all three on one stream. */
+ * must be ordered after both. With TBX_SIM_ADVANCE next to a part, the last workgroup of that part's kernel to arrive
+ * bumps the counter (every workgroup has read it by then): no extra launch. tbx_sim_step == all three, one kernel. */
 enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4 };
 int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* stream);
 

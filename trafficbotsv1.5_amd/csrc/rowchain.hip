@@ -474,7 +474,7 @@ __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int n = s.n;
   for (int r = wave; r < ROWS; r += nwave) {
     bool m = r >= t.n_valid;
-    if (!m && mask != nullptr) m = gld1(mask + row_of(s, t.g0 + r)) != 0;
+    if (!m && mask != nullptr) m = (gld1(mask + row_of(s, t.g0 + r)) != 0) != ((s.flags & TBX_F_MASK_INV) != 0);
     if (m)
       for (int c = lane; c < n; c += 64) dst[r * lds_d + c] = s.f0;
   }

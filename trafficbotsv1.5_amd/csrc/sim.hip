@@ -141,6 +141,19 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
     ht[W - 1] = st;
   }
+  if (parts & TBX_SIM_ADVANCE) {
+    // every thread of this workgroup has read *step above; the last workgroup to arrive advances it
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned prev = atomicAdd((unsigned*)(s.step + 1), 1u);
+      if (prev == gridDim.x - 1) {
+        s.step[1] = 0;
+        __threadfence();
+        s.step[0] = t + 1;
+      }
+    }
+  }
 }
 
 __global__ void sim_bump_kernel(int32_t* step) { *step += 1; }
@@ -168,6 +181,7 @@ extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* st
   hipStream_t hs = (hipStream_t)stream;
   if (parts & (TBX_SIM_AGENTS | TBX_SIM_LIGHTS))
     hipLaunchKernelGGL(sim_step_kernel, dim3((n + 127) / 128), dim3(128), 0, hs, s, parts);
-  if (parts & TBX_SIM_ADVANCE) hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
+  else
+    hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

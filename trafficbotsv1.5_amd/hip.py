@@ -18,7 +18,7 @@ HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 # ---- constants mirrored from include/tbx_hip.h
 OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
 ACT_NONE, ACT_RELU = 0, 1
-F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK = 1, 2, 4, 8, 16, 32, 64
+F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -125,14 +125,19 @@ def stream_ptr() -> int:
 
 # ------------------------------------------------------------------------------------------------ wrappers
 def knn_embed(src_pose, src_invalid, tgt_pose, tgt_invalid, k: int, dist_limit: float, freqs_xy=None, freqs_yaw=None,
-              pe_dim: int = 128, tgt_batch_div: int = 1, want_rel_pose: bool = False, want_emb: bool = True):
-    """-> idx i32 [n,S,k], invalid u8 [n,S,k], rel_pose f32 [n,S,k,3] | None, emb f32 [n,S,k,pe_dim] | None."""
+              pe_dim: int = 128, tgt_batch_div: int = 1, want_rel_pose: bool = False, want_emb: bool = True, out=None):
+    """-> idx i32 [n,S,k], invalid u8 [n,S,k], rel_pose f32 [n,S,k,3] | None, emb f32 [n,S,k,pe_dim] | None.
+    out = (idx, invalid, rel_pose) of a previous call: written in place (buffers shared across streams / steps)."""
     n, S, _ = src_pose.shape
     T = tgt_pose.shape[1]
     dev = src_pose.device
-    idx = torch.empty(n, S, k, dtype=torch.int32, device=dev)
-    inv = torch.empty(n, S, k, dtype=torch.uint8, device=dev)
-    rel = torch.empty(n, S, k, 3, dtype=torch.float32, device=dev) if want_rel_pose else None
+    if out is not None:
+        idx, inv, rel = out
+        assert idx.shape == (n, S, k) and inv.shape == (n, S, k) and (rel is not None) == want_rel_pose
+    else:
+        idx = torch.empty(n, S, k, dtype=torch.int32, device=dev)
+        inv = torch.empty(n, S, k, dtype=torch.uint8, device=dev)
+        rel = torch.empty(n, S, k, 3, dtype=torch.float32, device=dev) if want_rel_pose else None
     emb = torch.empty(n, S, k, pe_dim, dtype=torch.float32, device=dev) if want_emb else None
     rc = load().tbx_knn_embed(_cptr(src_pose, torch.float32), _cptr(src_invalid, torch.uint8), _cptr(tgt_pose, torch.float32),
                               _cptr(tgt_invalid, torch.uint8), n, S, T, tgt_batch_div, k, float(dist_limit), _ptr(idx),
@@ -333,8 +338,10 @@ class Chain:
     def clamp(self, dst, dst_col, n, lo, hi):
         return self._add(op=OP_CLAMP, dst=dst, dst_col=dst_col, n=n, f0=lo, f1=hi)
 
-    def rowmask(self, dst, dst_col, n, mask=None, fill=0.0, row_div=0):
+    def rowmask(self, dst, dst_col, n, mask=None, fill=0.0, row_div=0, valid_mask=False):
+        """Fill rows whose mask byte is set (valid_mask: whose byte is clear, i.e. `mask` is a validity array)."""
         flags, div = (F_ROW_DIV, row_div) if row_div else (0, 0)
+        flags |= F_MASK_INV if valid_mask else 0
         return self._add(op=OP_ROWMASK, dst=dst, dst_col=dst_col, n=n, f0=fill, flags=flags, div=div, p0=mask)
 
     def groupmax(self, src, src_col, dst, dst_col, n):

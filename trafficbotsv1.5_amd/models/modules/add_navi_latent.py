@@ -20,7 +20,7 @@ class AddNaviLatent(nn.Module):
             self.mlp_in = MLP([in_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
             self.mlp = MLP([2 * hidden_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
 
-    def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None):
+    def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None, mask_is_valid: bool = False):
         """x in BUF1[:, 0:d] (updated in place). z either already in BUF0[:, d:2d] (z=None) or loaded from `z`
         [rows, in_dim]. Uses BUF0 columns [0, 4d)."""
         d = self.hidden_dim
@@ -34,12 +34,12 @@ class AddNaviLatent(nn.Module):
             ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
-        ch.rowmask(BUF0, 2 * d, d, mask=z_invalid)
+        ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
         ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
         ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
         ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
         ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
-        ch.rowmask(BUF0, 3 * d, d, mask=z_invalid)
+        ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
         ch.add(BUF0, 3 * d, BUF1, 0, d)
 
     def forward(self, x: Tensor, z: Optional[Tensor], z_valid: Optional[Tensor] = None) -> Tensor:

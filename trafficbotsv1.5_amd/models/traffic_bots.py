@@ -90,7 +90,8 @@ class TrafficBots(nn.Module):
 
     def agent_policy(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, ag_type_idx: Tensor,
                      ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
-                     tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor]) -> None:
+                     tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor],
+                     aux_stream=None) -> None:
         """The agent half (traffic_bots.py:200-221): agent tokens attending to agents / map / tl K/V tables `tl_kv`, then
         navi + latent + action head -> out['action_mean']."""
         n, A, W = hist_valid.shape
@@ -100,18 +101,14 @@ class TrafficBots(nn.Module):
         tl_inv = tl_tokens["tl_token_invalid_u8"]
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
-                                            dest=dest, mp_batch_div=div)
+                                            dest=dest, mp_batch_div=div, aux_stream=aux_stream)
         out["prep"], out["ag_feat"] = prep, feat
         rp = self.pose_rpe
         navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)
-        navi_inv = out.get("navi_invalid")
-        if navi_inv is None:
-            navi_inv = out["navi_invalid"] = torch.empty(n * A, dtype=torch.uint8, device=dev)
-        torch.sub(1, navi_valid_u8.reshape(-1), out=navi_inv)
         ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
         ch.load(feat, BUF1, 0, n=d)
         self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe)
-        self.add_navi.emit(ch, navi_inv)
+        self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
         self.add_latent.emit(ch, latent_invalid, ag_latent)
         self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
         ch.run(n * A)

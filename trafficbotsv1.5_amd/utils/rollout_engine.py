@@ -79,7 +79,7 @@ class RolloutEngine:
         self.dest = ag_navi.contiguous()
         # ---- initial dynamic state (Dynamics.init, dynamics.py:29-64) and its pristine copy
         init = dict(
-            step=torch.ones(1, dtype=torch.int32, device=dev),
+            step=torch.tensor([1, 0], dtype=torch.int32, device=dev),  # [step index, arrival counter of the fused advance]
             ag_valid=_u8(gt_valid[:, :, 0]), ag_disabled=z(n, A, dt=u8), ag_pose=gt_pose[:, :, 0].float().contiguous(),
             ag_motion=gt_motion[:, :, 0].float().contiguous(), navi_valid=_u8(ag_navi_valid), outside_map=z(n, A, dt=u8),
             dest_reached=z(n, A, dt=u8), tl_state=S["tl_gt"][:, :, 0].contiguous(),
@@ -111,22 +111,29 @@ class RolloutEngine:
         self.sim_state = st
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
         self.graph = None
-        self.tl_kv_cur = None
-        self.side = torch.cuda.Stream(device=dev)
-        self._tl_ahead()
+        self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
+        self.parity = 0
+        self.side, self.aux = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self._tl_ahead(0)
 
     @torch.no_grad()
     def restore(self) -> None:
         """Back to step 1 without re-allocating (pointers captured in the graph stay valid)."""
         for k, v in self.init_state.items():
             self.S[k].copy_(v)
-        self._tl_ahead()
+        self.parity = 0
+        self._tl_ahead(0)
 
-    def _tl_ahead(self) -> None:
-        """tl encoder on the current light window: logits for the next lights update, K/V tables for the next agent step."""
-        kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
-        if self.tl_kv_cur is None:
-            self.tl_kv_cur = torch.empty_like(kv)
+    def _tl_ahead(self, slot: int) -> None:
+        """tl encoder on the current light window: logits for the next lights update, K/V tables (into buffer `slot`)
+        for the next agent step."""
+        if self.tl_kv is None:
+            self.policy_out.pop("tl_kv", None)
+            kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
+            self.tl_kv = [kv, torch.empty_like(kv)] if slot == 0 else [torch.empty_like(kv), kv]
+            return
+        self.policy_out["tl_kv"] = self.tl_kv[slot]
+        self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
 
     # ------------------------------------------------------------------ stepping
     @torch.no_grad()
@@ -138,28 +145,34 @@ class RolloutEngine:
                                    self.tl_tokens, self.mp_tokens, self.policy_out)
             hip.sim_step(self.sim_state)
             return
-        self.tl_kv_cur.copy_(self.policy_out["tl_kv"])  # tables of the window the agents see this step
+        p = self.parity
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             hip.sim_step(self.sim_state, hip.SIM_LIGHTS)  # logits of the previous tl encoder pass -> lights of this step
-            self._tl_ahead()
+            self._tl_ahead(1 - p)
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
-                                self.mp_tokens, self.tl_kv_cur, self.policy_out)
-        hip.sim_step(self.sim_state, hip.SIM_AGENTS)
+                                self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux)
         main.wait_stream(self.side)
-        hip.sim_step(self.sim_state, hip.SIM_ADVANCE)
+        hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
+        self.parity = 1 - p
 
     @torch.no_grad()
     def capture(self) -> None:
-        """Warm up one eager step, restore, then capture one step into a hipGraph on a side stream."""
+        """Warm up one eager step, restore, then capture the step into hipGraphs (one per parity of the light-table
+        double buffer; capturing executes nothing, so the state stays at the restored start)."""
         self.step()
         torch.cuda.synchronize()
         self.restore()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.step()
-        self.graph = g
+        graphs = []
+        for p in ((0, 1) if self.lights_ahead else (0,)):
+            self.parity = p
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            graphs.append(g)
+        self.parity = 0
+        self.graph = graphs
 
     @torch.no_grad()
     def run(self, n_steps: Optional[int] = None, use_graph: bool = True) -> None:
@@ -168,7 +181,8 @@ class RolloutEngine:
             self.capture()
         for _ in range(n_steps):
             if use_graph:
-                self.graph.replay()
+                self.graph[self.parity % len(self.graph)].replay()
+                self.parity = 1 - self.parity
             else:
                 self.step()
 
