@@ -51,6 +51,9 @@ def parse():
                          "that rocprofv3's per-kernel averages are of kernels running alone, like the live roofline events")
     ap.add_argument("--no-wosac-shape", action="store_true",
                     help="skip the second measurement (32 rollouts x 128 agents per GPU) the default rollout run appends")
+    ap.add_argument("--no-train-shape", action="store_true",
+                    help="skip the training_step measurement (16 scenes per GPU, fwd+bwd+all-reduce+AdamW) the default run appends")
+    ap.add_argument("--train-steps", type=int, default=2, help="timed training steps of that appended measurement")
     a = ap.parse_args()
     tr = a.mode == "train"
     a.steps = a.steps if a.steps is not None else (3 if tr else 80)
@@ -58,6 +61,7 @@ def parse():
     # the WOSAC-shape measurement rides along only with the default (configs[1]) workload
     a.wosac_shape = (not tr and not a.no_wosac_shape and a.scenes is None and a.rollouts == 1 and a.agents == 64
                      and a.profile_steps > 0)
+    a.train_shape = a.wosac_shape and not a.no_train_shape
     a.scenes = a.scenes if a.scenes is not None else (16 if tr else 1)
     return a
 
@@ -240,9 +244,8 @@ def train_main(args, tb, dev, rank, world, dist):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        n_live = sum(p.numel() for p in (live or []))
-        print(json.dumps({
+    n_live = sum(p.numel() for p in (live or []))
+    return {
             "metric": "training scenes/sec", "value": world * args.scenes * args.steps / dt, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -251,7 +254,7 @@ def train_main(args, tb, dev, rank, world, dist):
                        "global_batch": world * args.scenes, "parallelism": f"dp{world}",
                        "allreduce_bytes": n_live * 4, "note": "dropout on residual/FFN/MLP paths as configured (p=0.1); "
                                                              "attention-probability dropout not applied inside the HIP kernel yet"},
-            "loss": float(m["loss"]), "finite": bool(torch.isfinite(m["loss"]))}), flush=True)
+            "loss": float(m["loss"]), "finite": bool(torch.isfinite(m["loss"]))}
 
 
 def main():
@@ -270,7 +273,9 @@ def main():
     hip = import_module("trafficbots_amd.hip")
     hip.load()
     if args.mode == "train":
-        train_main(args, tb, dev, rank, world, dist if world > 1 else None)
+        line = train_main(args, tb, dev, rank, world, dist if world > 1 else None)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -345,6 +350,17 @@ def main():
         r5, _, _ = measure(big)
         line["wosac_shape"] = {"metric": line["metric"], "unit": line["unit"], "n_gpus": world, "steps": big.steps,
                                "warmup": big.warmup, **r5}
+    if args.train_shape:
+        # BASELINE.json configs[2] / [3] (the metric's second half): training_step on 16 scenes per GPU, gradients
+        # all-reduced over RCCL when world > 1. Every rank must take part (collective), a failure is reported, not fatal.
+        import copy
+
+        tr = copy.copy(args)
+        tr.scenes, tr.steps, tr.warmup, tr.agents = 16, args.train_steps, 1, 64
+        try:
+            line["training"] = train_main(tr, tb, dev, rank, world, dist if world > 1 else None)
+        except Exception as e:  # noqa: BLE001
+            line["training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(tb, wm, full, args)

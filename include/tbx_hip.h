@@ -264,6 +264,55 @@ int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
 enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4 };
 int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Metric-only traffic-rule checks of a rollout, batched over the (rollout, step) frames of the
+ * rollout log. Replaces TrafficRuleChecker.check as called once per Python step (pl_modules/waymo_motion.py:250;
+ * utils/traffic_rule_checker.py:342-451) for the five violations that do not feed back into the simulation:
+ *   collided (:122-156), collided_wosac (utils/wosac_collision.py:211-257), run_road_edge (:158-181, 453-484),
+ *   run_red_light (:183-233), passive (:235-298, 486-501).
+ * Boolean results, bit-exact against the reference formulation (same fp32 operation order).
+ */
+enum { TBX_RULE_COLLIDED = 1, TBX_RULE_COLLIDED_WOSAC = 2, TBX_RULE_RUN_ROAD_EDGE = 4, TBX_RULE_RUN_RED_LIGHT = 8,
+       TBX_RULE_PASSIVE = 16 };
+
+/* Static tables of a scene (TrafficRuleChecker._get_road_edge / _get_lane_center): node segments (x0,y0,x1,y1 = pos,
+ * pos + dir) of polylines of type 4 / 5 / 7 and node positions of polylines of type 0 / 1 / 2, valid nodes only,
+ * compacted in unspecified order (every consumer is an any()).
+ *   mp_valid [n_scene, n_mp, n_node] u8, mp_type_idx [n_scene, n_mp] u8 (argmax of the one-hot type),
+ *   mp_pos / mp_dir [n_scene, n_mp, n_node, ld_xy] (ld_xy = 2 or 3: x, y first)
+ *   seg [n_scene, n_mp*n_node, 4] (16-byte aligned), lane [n_scene, n_mp*n_node, 2], n_seg / n_lane [n_scene] i32 */
+int tbx_rule_tables(const uint8_t* mp_valid, const uint8_t* mp_type_idx, const float* mp_pos, const float* mp_dir, int ld_xy,
+                    int n_scene, int n_mp, int n_node, float* seg, int32_t* n_seg, float* lane, int32_t* n_lane, void* stream);
+
+typedef struct tbx_rule_ctx {
+  int32_t n_batch, n_ag, n_tl;
+  int32_t map_batch_div;      /* rollouts [b*div, (b+1)*div) share scene b's tables */
+  int32_t cap;                /* n_mp*n_node: rows per scene of seg / lane */
+  const float* seg;
+  const int32_t* n_seg;
+  const float* lane;
+  const int32_t* n_lane;
+  const float* ag_size;       /* [n, A, 3] length width height, as handed to the reference constructor (un-scaled) */
+  const uint8_t* ag_type_idx; /* [n, A] 0 veh 1 ped 2 cyc */
+  const uint8_t* tl_valid;    /* [n, L] */
+  const float* tl_pose;       /* [n, L, 3] */
+  float collision_size_scale; /* 1.1 */
+} tbx_rule_ctx_t;
+
+/* Raw per-frame flags for steps [t0, t0 + n_t) of a log with ld_t steps per agent (ld_t = 1, t0 = 0 for a single step):
+ *   valid [n, A, ld_t] u8, pose / motion [n, A, ld_t, 3], tl_state [n, L, ld_t] u8 5-bit state masks
+ *   flags [n, A, ld_t] u8: TBX_RULE_* bits of this step; TBX_RULE_PASSIVE here is the un-counted condition
+ *   (traffic_rule_checker.py:291), the counter lives in tbx_rule_accumulate. n_ag <= 256. */
+int tbx_rule_check(const tbx_rule_ctx_t* ctx /* host */, const uint8_t* valid, const float* pose, const float* motion,
+                   const uint8_t* tl_state, int ld_t, int t0, int n_t, uint8_t* flags, void* stream);
+
+/* traffic_rule_checker.py:293-296 + the running ORs of check(): acc_state [n_rows] u8 and passive_counter [n_rows] f32 are
+ * read and updated (zero them before the first step); out_now / out_acc [n_rows, ld_t] u8 receive the `*_this_step` and the
+ * accumulated flags of every step in the range. raw may alias out_now. */
+int tbx_rule_accumulate(const uint8_t* raw, int n_rows, int ld_t, int t0, int n_t, uint8_t* acc_state, float* passive_counter,
+                        uint8_t* out_now, uint8_t* out_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -381,10 +381,42 @@ def gen_model(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_roll_steps, train_fixture):
     npz(f"model_{tag}.npz", **out)
 
 
+@torch.no_grad()
+def gen_rules():
+    """the reference's TrafficRuleChecker stepped over seeded crowded episodes. Inputs come from
+    `synthetic.make_rule_episode(seed)` (ours, shipped); the fixture holds the reference's outputs only."""
+    from utils.traffic_rule_checker import TrafficRuleChecker
+    from utils.wosac_collision import check_collided_wosac
+
+    out = {}
+    for tag, kw in (("a", dict(n_sc=2, n_ag=16, n_mp=64, n_tl=8, n_step=40, seed=0)),
+                    ("b", dict(n_sc=1, n_ag=40, n_mp=96, n_tl=12, n_step=30, seed=7, extent=40.0))):
+        e = tb.synthetic.make_rule_episode(**kw)
+        rc = TrafficRuleChecker(
+            mp_boundary=e["map/boundary"], mp_valid=e["map/valid"], mp_type=e["map/type"], mp_pos=e["map/pos"], mp_dir=e["map/dir"],
+            ag_type=e["agent/type"], ag_size=e["agent/size"], ag_goal=None, ag_dest=None, tl_valid=e["tl/valid"],
+            tl_pose=e["tl/pose"], disable_check=False)
+        T = e["agent/valid"].shape[2]
+        log = {}
+        for t in range(T):
+            v = rc.check(e["agent/valid"][:, :, t], e["agent/pose"][:, :, t], e["agent/motion"][:, :, t], e["tl/state"][:, :, t])
+            for k, x in v.items():
+                log.setdefault(k, []).append(x.clone())
+        for k in ("collided", "collided_wosac", "run_road_edge", "run_red_light", "passive"):
+            out[f"{tag}_{k}"] = np.packbits(torch.stack(log[k], 2).numpy(), axis=-1)
+            out[f"{tag}_{k}_this_step"] = np.packbits(torch.stack(log[k + "_this_step"], 2).numpy(), axis=-1)
+            print(tag, k, int(torch.stack(log[k + "_this_step"], 2).sum()), "this-step positives")
+        out[f"{tag}_passive_counter"] = rc.passive_counter
+        out[f"{tag}_n_step"] = np.int64(T)
+    npz("rules.npz", **out)
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "c1", "c2"]
+    which = sys.argv[1:] or ["ops", "c1", "c2", "rules"]
+    if "rules" in which:
+        gen_rules()
     if "ops" in which:
         gen_ops()
     if "c1" in which:

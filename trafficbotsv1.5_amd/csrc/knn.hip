@@ -3,7 +3,8 @@
 // One wavefront per source token. Each lane keeps n_tgt/64 candidate distances in registers; the K-th smallest distance is
 // found by bisection over the key bits (wave ballots), the K winners are everything below it plus the lowest-index ties.
 // Distances follow the reference's operation order without FMA contraction (SURVEY.md Appx A.2):
-//   rx = dx*c + dy*s ; ry = dy*c - dx*s ; dist = sqrt(rx*rx + ry*ry), +inf if either side is invalid.
+//   rx = dx*c + dy*s ; ry = dy*c - dx*s ; dist = sqrt(fma(ry, ry, rx*rx)) - torch's CPU 2-norm accumulates its squares
+//   with a fused multiply-add (measured: 100 % bit-equal to this form, 91 % to the unfused one); +inf if either side is invalid.
 // The embedding of the K selected relative poses is written by the same wave (lanes = channels), so the
 // [S, T, 3] relative-pose tensor of the reference is never materialised.
 #include <hip/hip_runtime.h>
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
       if (j < a.n_tgt) {
         float rx, ry;
         rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
-        const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)));
+        const float dist = __fsqrt_rn(__fmaf_rn(ry, ry, __fmul_rn(rx, rx)));
         key[q] = __float_as_uint((inv1 || ti[j] != 0) ? INFINITY : dist);
       }
     }

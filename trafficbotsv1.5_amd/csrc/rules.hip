@@ -1,0 +1,367 @@
+// tbx_rule_*: the metric-only traffic-rule checks of a closed-loop rollout, batched over every
+// (rollout, step) frame of the rollout log instead of once per Python step: collided (separating edge test), collided_wosac
+// (signed distance of the Minkowski difference of two rounded boxes), run_road_edge (box edge x road-edge segment crossing),
+// run_red_light (stop point leaves the footprint within 0.1 s) and passive (slow vehicle on a lane with nothing ahead).
+// Restates utils/traffic_rule_checker.py:122-298,453-505 and utils/wosac_collision.py:20-257 of the reference; the outputs
+// are booleans, so every expression keeps the reference's operation order (no FMA contraction; torch's 2-norm is
+// sqrt(fma(y, y, x*x)) on the CPU, measured) and the CPU oracle (oracle/rule_checks.py) is matched bit for bit.
+//
+// One wavefront per (frame, agent): the frame's agents (pose, boxes) are staged once per workgroup in LDS, lanes stride over
+// the other agents / the lights / the scene's compacted road-edge and lane-centre tables (static per scene, L2-resident,
+// 16-byte coalesced loads), wave ballots give the any() reductions. HBM-light, latency / VALU bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int MAX_AG = 256;
+constexpr float BIG = 1e10f;
+
+__device__ __forceinline__ float norm2(float x, float y) { return __fsqrt_rn(__fmaf_rn(y, y, __fmul_rn(x, x))); }
+
+// ---------------------------------------------------------------------------------------------- static tables
+// traffic_rule_checker.py:453-501: road-edge node segments (types 4, 5, 7) and lane-centre nodes (types 0, 1, 2) of one
+// scene, compacted (their order is irrelevant: every consumer is an any()). One workgroup per scene.
+__global__ void rule_tables_kernel(const uint8_t* __restrict__ mp_valid, const uint8_t* __restrict__ mp_type_idx,
+                                   const float* __restrict__ mp_pos, const float* __restrict__ mp_dir, int ld_xy, int n_mp,
+                                   int n_node, float* __restrict__ seg, int32_t* __restrict__ n_seg, float* __restrict__ lane,
+                                   int32_t* __restrict__ n_lane) {
+  __shared__ int cnt[2];
+  const int b = blockIdx.x;
+  const int cap = n_mp * n_node;
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) {
+    const int64_t g = (int64_t)b * cap + i;
+    if (!mp_valid[g]) continue;
+    const int ty = mp_type_idx[(int64_t)b * n_mp + i / n_node];
+    const float px = mp_pos[g * ld_xy], py = mp_pos[g * ld_xy + 1];
+    if (ty == 4 || ty == 5 || ty == 7) {
+      const int s = atomicAdd(&cnt[0], 1);
+      float4 v = make_float4(px, py, px + mp_dir[g * ld_xy], py + mp_dir[g * ld_xy + 1]);
+      reinterpret_cast<float4*>(seg)[(int64_t)b * cap + s] = v;
+    } else if (ty <= 2) {
+      const int s = atomicAdd(&cnt[1], 1);
+      reinterpret_cast<float2*>(lane)[(int64_t)b * cap + s] = make_float2(px, py);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n_seg[b] = cnt[0];
+    n_lane[b] = cnt[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- per-frame checks
+struct Frame {
+  float x[MAX_AG], y[MAX_AG], c[MAX_AG], s[MAX_AG];
+  float bb[MAX_AG][8];  // collision box (size x scale), corners 0..3 (x, y)
+  float wb[MAX_AG][8];  // wosac core box (scaled size shrunk by the rounding radius)
+  float shrink[MAX_AG];
+  uint8_t valid[MAX_AG], type[MAX_AG];
+};
+
+// wosac_collision.py:20-47
+__device__ __forceinline__ void box_corners(float x, float y, float c, float s, float l, float w, float* o) {
+  const float hl = 0.5f * l, hw = 0.5f * w;
+  const float ofx = hl * c, ofy = hl * s;
+  const float orx = hw * s, ory = hw * (-c);
+  o[0] = x + (ofx - orx);
+  o[1] = y + (ofy - ory);
+  o[2] = x + (-ofx - orx);
+  o[3] = y + (-ofy - ory);
+  o[4] = x + (-ofx + orx);
+  o[5] = y + (-ofy + ory);
+  o[6] = x + (ofx + orx);
+  o[7] = y + (ofy + ory);
+}
+
+// traffic_rule_checker.py:127-148: some edge line of box p has all four corners of box q strictly on its outer side
+__device__ __forceinline__ bool separated_by_edge_of(const float* p, const float* q) {
+  bool any_e = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float cx = p[2 * e], cy = p[2 * e + 1];
+    const float nx = p[2 * ((e + 1) & 3)], ny = p[2 * ((e + 1) & 3) + 1];
+    const float la = ny - cy, lb = cx - nx, lc = nx * cy - ny * cx;
+    bool all_out = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) all_out = all_out && (((la * q[2 * k] + lb * q[2 * k + 1]) + lc) > 0.f);
+    any_e = any_e || all_out;
+  }
+  return any_e;
+}
+
+// wosac_collision.py:144-179: index of the lowest corner (first on ties) and the unit direction of the edge leaving it
+__device__ __forceinline__ int downmost(const float* b, float sgn, float* dx, float* dy) {
+  int i0 = 0;
+  float best = sgn * b[1];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float v = sgn * b[2 * k + 1];
+    if (v < best) {
+      best = v;
+      i0 = k;
+    }
+  }
+  const int i1 = (i0 + 1) & 3;
+  const float ex = sgn * b[2 * i1] - sgn * b[2 * i0], ey = sgn * b[2 * i1 + 1] - sgn * b[2 * i0 + 1];
+  const float ln = norm2(ex, ey);
+  *dx = ex / ln;
+  *dy = ey / ln;
+  return i0;
+}
+
+// wosac_collision.py:50-116,182-250: signed distance from the origin to the Minkowski sum of box1 and (-box2)
+__device__ __forceinline__ float wosac_pair_distance(const float* b1, const float* b2) {
+  float d1x, d1y, d2x, d2y;
+  const int s1 = downmost(b1, 1.f, &d1x, &d1y);
+  const int s2 = downmost(b2, -1.f, &d2x, &d2y);
+  const bool cond = (d1x * d2y - d1y * d2x) >= 0.f;
+  float px[8], py[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int oa = k >> 1, ob = ((k + 1) >> 1) & 3;  // [0,0,1,1,2,2,3,3] and [0,1,1,2,2,3,3,0]
+    const int i1 = ((cond ? ob : oa) + s1) & 3;
+    const int i2 = ((cond ? oa : ob) + s2) & 3;
+    px[k] = b1[2 * i1] + (-b2[2 * i2]);
+    py[k] = b1[2 * i1 + 1] + (-b2[2 * i2 + 1]);
+  }
+  bool inside = true;
+  float m = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int k1 = (k + 1) & 7;
+    const float ex = px[k1] - px[k], ey = py[k1] - py[k];
+    const float ln = norm2(ex, ey);
+    const float tx = ex / ln, ty = ey / ln;
+    const float nx = -ty, ny = tx;
+    const float qx = 0.f - px[k], qy = 0.f - py[k];
+    const float dv = norm2(qx, qy);
+    const float perp = (-nx) * qx + (-ny) * qy;
+    inside = inside && (perp <= 0.f);
+    const float prop = (tx * qx + ty * qy) / ln;
+    const float de = (prop >= 0.f && prop <= 1.f) ? fabsf(perp) : (0.f + BIG);
+    m = fminf(m, fminf(de, dv));
+  }
+  return inside ? -m : m;
+}
+
+// traffic_rule_checker.py:504-505
+__device__ __forceinline__ bool ccw(float ax, float ay, float bx, float by, float cx, float cy) {
+  return (cy - ay) * (bx - ax) > (by - ay) * (cx - ax);
+}
+
+struct RuleArgs {
+  tbx_rule_ctx_t c;
+  const uint8_t* valid;
+  const float* pose;
+  const float* motion;
+  const uint8_t* tl_state;
+  uint8_t* flags;
+  int ld_t, t0, n_t, tiles;
+};
+
+__global__ __launch_bounds__(256) void rule_check_kernel(const RuleArgs a) {
+  __shared__ Frame F;
+  const tbx_rule_ctx_t& c = a.c;
+  const int A = c.n_ag, L = c.n_tl;
+  const int tile = blockIdx.x % a.tiles;
+  const int frame = blockIdx.x / a.tiles;
+  const int b = frame / a.n_t, t = a.t0 + frame % a.n_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- stage the frame's agents
+  for (int j = threadIdx.x; j < A; j += blockDim.x) {
+    const int64_t r = ((int64_t)b * A + j) * a.ld_t + t;
+    const float x = a.pose[r * 3], y = a.pose[r * 3 + 1], yaw = a.pose[r * 3 + 2];
+    const float cs = cosf(yaw), sn = sinf(yaw);
+    const float* sz = c.ag_size + ((int64_t)b * A + j) * 3;
+    const float l = sz[0] * c.collision_size_scale, w = sz[1] * c.collision_size_scale;
+    F.x[j] = x;
+    F.y[j] = y;
+    F.c[j] = cs;
+    F.s[j] = sn;
+    box_corners(x, y, cs, sn, l, w, F.bb[j]);
+    const float sh = fminf(l, w) * 0.7f / 2.0f;
+    F.shrink[j] = sh;
+    box_corners(x, y, cs, sn, l - 2.0f * sh, w - 2.0f * sh, F.wb[j]);
+    F.valid[j] = a.valid[r];
+    F.type[j] = c.ag_type_idx[(int64_t)b * A + j];
+  }
+  __syncthreads();
+  const int i = tile * 4 + wave;
+  if (i >= A) return;
+  const int64_t ri = ((int64_t)b * A + i) * a.ld_t + t;
+  const bool valid_i = F.valid[i] != 0;
+  const int type_i = F.type[i];
+  const bool veh = type_i == 0;
+  const float xi = F.x[i], yi = F.y[i], ci = F.c[i], si = F.s[i];
+  const float spd = a.motion[ri * 3];
+  float bi[8], wi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    bi[k] = F.bb[i][k];
+    wi[k] = F.wb[i][k];
+  }
+  const float shrink_i = F.shrink[i];
+  // ---- agent pairs: collided / collided_wosac / an agent ahead (passive)
+  bool collided = false, wosac = false, ag_ahead = false;
+  for (int j = lane; j < A; j += 64) {
+    const bool pair_ok = valid_i && F.valid[j] != 0 && j != i;
+    if (!pair_ok) continue;
+    float bj[8], wj[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bj[k] = F.bb[j][k];
+      wj[k] = F.wb[j][k];
+    }
+    if (!(type_i == 1 && F.type[j] == 1))  // no pedestrian-pedestrian collisions (traffic_rule_checker.py:47-49)
+      collided = collided || !(separated_by_edge_of(bi, bj) || separated_by_edge_of(bj, bi));
+    const float sd = (wosac_pair_distance(wi, wj) - F.shrink[j]) - shrink_i;
+    wosac = wosac || (sd < 0.f);
+    const float wx = F.x[j] - xi, wy = F.y[j] - yi;
+    const float wn = norm2(wx, wy);
+    ag_ahead = ag_ahead || ((wn < 10.f) && (((ci * wx + si * wy) / wn) > 0.95f));
+  }
+  // ---- lights: run_red_light / a non-green light ahead (passive)
+  bool red = false, red_ahead = false;
+  {
+    const float* sz = c.ag_size + ((int64_t)b * A + i) * 3;
+    const float half_len = sz[0] * 0.5f * 0.6f, half_wid = sz[1] * 0.5f * 1.8f;
+    const float rx = si, ry = -ci;
+    const float adv = 0.1f * spd;
+    const float x1 = xi + adv * ci, y1 = yi + adv * si;
+    for (int k = lane; k < L; k += 64) {
+      const int64_t lk = (int64_t)b * L + k;
+      if (!c.tl_valid[lk]) continue;
+      const uint8_t st = a.tl_state[lk * a.ld_t + t];
+      const float tx = c.tl_pose[lk * 3], ty = c.tl_pose[lk * 3 + 1];
+      if ((st & 2) && valid_i && veh) {
+        const float d0x = tx - xi, d0y = ty - yi, d1x = tx - x1, d1y = ty - y1;
+        const bool in0 = (fabsf(d0x * ci + d0y * si) < half_len) && (fabsf(d0x * rx + d0y * ry) < half_wid);
+        const bool in1 = (fabsf(d1x * ci + d1y * si) < half_len) && (fabsf(d1x * rx + d1y * ry) < half_wid);
+        red = red || (in0 && !in1);
+      }
+      if (st & 0x17) {  // UNKNOWN | STOP | CAUTION | FLASHING
+        const float vx = tx - xi, vy = ty - yi;
+        const float vn = norm2(vx, vy);
+        red_ahead = red_ahead || ((vn < 10.f) && (((ci * vx + si * vy) / vn) > 0.95f));
+      }
+    }
+  }
+  collided = __any(collided);
+  wosac = __any(wosac);
+  ag_ahead = __any(ag_ahead);
+  red = __any(red);
+  red_ahead = __any(red_ahead);
+  // ---- the scene's static tables (vehicles only)
+  bool edge = false, passive = false;
+  if (valid_i && veh) {
+    const int sc = b / c.map_batch_div;
+    const float4* seg = reinterpret_cast<const float4*>(c.seg) + (int64_t)sc * c.cap;
+    const int ns = c.n_seg[sc];
+    for (int k0 = 0; k0 < ns; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < ns) {
+        const float4 s = seg[k];  // C = (x, y), D = (z, w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ax = bi[2 * e], ay = bi[2 * e + 1];
+          const float bx = bi[2 * ((e + 1) & 3)], by = bi[2 * ((e + 1) & 3) + 1];
+          hit = hit || ((ccw(ax, ay, s.x, s.y, s.z, s.w) != ccw(bx, by, s.x, s.y, s.z, s.w)) &&
+                        (ccw(ax, ay, bx, by, s.x, s.y) != ccw(ax, ay, bx, by, s.z, s.w)));
+        }
+      }
+      if (__any(hit)) {
+        edge = true;
+        break;
+      }
+    }
+    if ((spd < 5.f) && !red_ahead && !ag_ahead) {
+      const float2* lc = reinterpret_cast<const float2*>(c.lane) + (int64_t)sc * c.cap;
+      const int nl = c.n_lane[sc];
+      for (int k0 = 0; k0 < nl; k0 += 64) {
+        const int k = k0 + lane;
+        bool near_lane = false;
+        if (k < nl) {
+          const float2 p = lc[k];
+          near_lane = norm2(xi - p.x, yi - p.y) < 2.f;
+        }
+        if (__any(near_lane)) {
+          passive = true;
+          break;
+        }
+      }
+    }
+  }
+  if (lane == 0)
+    a.flags[ri] = (uint8_t)((collided ? TBX_RULE_COLLIDED : 0) | (wosac ? TBX_RULE_COLLIDED_WOSAC : 0) |
+                            (edge ? TBX_RULE_RUN_ROAD_EDGE : 0) | (red ? TBX_RULE_RUN_RED_LIGHT : 0) |
+                            (passive ? TBX_RULE_PASSIVE : 0));
+}
+
+// traffic_rule_checker.py:293-296,352-404: the counter turns raw passivity into the passive flag, every flag is OR-ed
+// over time. One thread per (rollout, agent), sequential over the steps of the range.
+__global__ void rule_accumulate_kernel(const uint8_t* raw, int n_rows, int ld_t, int t0, int n_t, uint8_t* __restrict__ acc_state,
+                                       float* __restrict__ counter, uint8_t* out_now, uint8_t* __restrict__ out_acc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  uint8_t acc = acc_state[r];
+  float cnt = counter[r];
+  for (int t = t0; t < t0 + n_t; ++t) {
+    const uint8_t f = raw[(int64_t)r * ld_t + t];
+    const float p = (f & TBX_RULE_PASSIVE) ? 1.f : 0.f;
+    cnt = (cnt + p) * p;
+    const uint8_t now = (uint8_t)((f & ~TBX_RULE_PASSIVE) | (cnt > 20.f ? TBX_RULE_PASSIVE : 0));
+    acc |= now;
+    out_now[(int64_t)r * ld_t + t] = now;
+    out_acc[(int64_t)r * ld_t + t] = acc;
+  }
+  acc_state[r] = acc;
+  counter[r] = cnt;
+}
+
+}  // namespace
+
+extern "C" int tbx_rule_tables(const uint8_t* mp_valid, const uint8_t* mp_type_idx, const float* mp_pos, const float* mp_dir,
+                               int ld_xy, int n_scene, int n_mp, int n_node, float* seg, int32_t* n_seg, float* lane,
+                               int32_t* n_lane, void* stream) {
+  if (!mp_valid || !mp_type_idx || !mp_pos || !mp_dir || !seg || !n_seg || !lane || !n_lane) return TBX_ERR_ARG;
+  if (n_scene <= 0 || n_mp <= 0 || n_node <= 0 || ld_xy < 2) return TBX_ERR_ARG;
+  if (((uintptr_t)seg & 15) || ((uintptr_t)lane & 7)) return TBX_ERR_ALIGN;
+  hipLaunchKernelGGL(rule_tables_kernel, dim3(n_scene), dim3(1024), 0, (hipStream_t)stream, mp_valid, mp_type_idx, mp_pos,
+                     mp_dir, ld_xy, n_mp, n_node, seg, n_seg, lane, n_lane);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_rule_check(const tbx_rule_ctx_t* ctx, const uint8_t* valid, const float* pose, const float* motion,
+                              const uint8_t* tl_state, int ld_t, int t0, int n_t, uint8_t* flags, void* stream) {
+  if (!ctx || !valid || !pose || !motion || !tl_state || !flags) return TBX_ERR_ARG;
+  const tbx_rule_ctx_t& c = *ctx;
+  if (!c.seg || !c.n_seg || !c.lane || !c.n_lane || !c.ag_size || !c.ag_type_idx || !c.tl_valid || !c.tl_pose) return TBX_ERR_ARG;
+  if (c.n_batch <= 0 || c.n_ag <= 0 || c.n_tl <= 0 || c.map_batch_div <= 0 || c.cap <= 0 || ld_t <= 0 || t0 < 0 || n_t <= 0 ||
+      t0 + n_t > ld_t || c.n_batch % c.map_batch_div)
+    return TBX_ERR_ARG;
+  if (c.n_ag > MAX_AG) return TBX_ERR_UNSUPPORTED;
+  if (((uintptr_t)c.seg & 15) || ((uintptr_t)c.lane & 7)) return TBX_ERR_ALIGN;
+  RuleArgs a{c, valid, pose, motion, tl_state, flags, ld_t, t0, n_t, (c.n_ag + 3) / 4};
+  const int64_t blocks = (int64_t)c.n_batch * n_t * a.tiles;
+  if (blocks > 0x7fffffff) return TBX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rule_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_rule_accumulate(const uint8_t* raw, int n_rows, int ld_t, int t0, int n_t, uint8_t* acc_state,
+                                   float* passive_counter, uint8_t* out_now, uint8_t* out_acc, void* stream) {
+  if (!raw || !acc_state || !passive_counter || !out_now || !out_acc) return TBX_ERR_ARG;
+  if (n_rows <= 0 || ld_t <= 0 || t0 < 0 || n_t <= 0 || t0 + n_t > ld_t) return TBX_ERR_ARG;
+  hipLaunchKernelGGL(rule_accumulate_kernel, dim3((n_rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, raw, n_rows, ld_t,
+                     t0, n_t, acc_state, passive_counter, out_now, out_acc);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

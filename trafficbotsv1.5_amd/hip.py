@@ -47,6 +47,14 @@ class SimState(C.Structure):
     )
 
 
+class RuleCtx(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "map_batch_div", "cap")]
+                + [(n, C.c_void_p) for n in ("seg", "n_seg", "lane", "n_lane", "ag_size", "ag_type_idx", "tl_valid", "tl_pose")]
+                + [("collision_size_scale", C.c_float)])
+
+
+RULE_COLLIDED, RULE_COLLIDED_WOSAC, RULE_RUN_ROAD_EDGE, RULE_RUN_RED_LIGHT, RULE_PASSIVE = 1, 2, 4, 8, 16
+
 _lib = None
 
 
@@ -89,8 +97,11 @@ def load():
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
     lib.tbx_sim_step_parts.argtypes = [C.POINTER(SimState), i32, vp]
+    lib.tbx_rule_tables.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts"):
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -227,6 +238,34 @@ def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE
 
 
 # ------------------------------------------------------------------------------------------------ rowchain builder
+def rule_tables(mp_valid_u8, mp_type_idx_u8, mp_pos, mp_dir):
+    """-> (seg [n,M*N,4], n_seg [n] i32, lane [n,M*N,2], n_lane [n] i32): compacted road-edge segments / lane-centre nodes."""
+    n, M, N = mp_valid_u8.shape
+    dev = mp_pos.device
+    seg = torch.empty(n, M * N, 4, dtype=torch.float32, device=dev)
+    lane = torch.empty(n, M * N, 2, dtype=torch.float32, device=dev)
+    n_seg = torch.empty(n, dtype=torch.int32, device=dev)
+    n_lane = torch.empty(n, dtype=torch.int32, device=dev)
+    rc = load().tbx_rule_tables(_cptr(mp_valid_u8, torch.uint8), _cptr(mp_type_idx_u8, torch.uint8), _cptr(mp_pos, torch.float32),
+                                _cptr(mp_dir, torch.float32), mp_pos.shape[-1], n, M, N, _ptr(seg), _ptr(n_seg), _ptr(lane),
+                                _ptr(n_lane), stream_ptr())
+    _check(rc, "tbx_rule_tables")
+    return seg, n_seg, lane, n_lane
+
+
+def rule_check(ctx: RuleCtx, valid_u8, pose, motion, tl_state_u8, ld_t: int, t0: int, n_t: int, flags):
+    rc = load().tbx_rule_check(C.byref(ctx), _cptr(valid_u8, torch.uint8), _cptr(pose, torch.float32), _cptr(motion, torch.float32),
+                               _cptr(tl_state_u8, torch.uint8), ld_t, t0, n_t, _cptr(flags, torch.uint8), stream_ptr())
+    _check(rc, "tbx_rule_check")
+
+
+def rule_accumulate(raw, n_rows: int, ld_t: int, t0: int, n_t: int, acc_state, passive_counter, out_now, out_acc):
+    rc = load().tbx_rule_accumulate(_cptr(raw, torch.uint8), n_rows, ld_t, t0, n_t, _cptr(acc_state, torch.uint8),
+                                    _cptr(passive_counter, torch.float32), _cptr(out_now, torch.uint8), _cptr(out_acc, torch.uint8),
+                                    stream_ptr())
+    _check(rc, "tbx_rule_accumulate")
+
+
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
     per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused

@@ -14,7 +14,7 @@ class MyDist:
 class DiagGaussian(MyDist):
     def __init__(self, mean: Tensor, log_std: Tensor, valid: Optional[Tensor] = None) -> None:
         self.mean, self.valid = mean, valid
-        self.distribution = Independent(Normal(mean, log_std.exp()), 1)
+        self.distribution = Independent(Normal(mean, log_std.exp(), validate_args=False), 1, validate_args=False)
         self.stddev = self.distribution.stddev
 
     def log_prob(self, sample: Tensor) -> Tensor:
@@ -29,14 +29,15 @@ class DiagGaussian(MyDist):
     def repeat_interleave_(self, repeats: int, dim: int) -> None:
         self.mean = self.mean.repeat_interleave(repeats, dim)
         self.stddev = self.stddev.repeat_interleave(repeats, dim)
-        self.distribution = Independent(Normal(self.mean, self.stddev), 1)
+        self.distribution = Independent(Normal(self.mean, self.stddev, validate_args=False), 1, validate_args=False)
         if self.valid is not None:
             self.valid = self.valid.repeat_interleave(repeats, dim)
 
 
 class DestCategorical(MyDist):
     def __init__(self, probs: Optional[Tensor] = None, logits: Optional[Tensor] = None, valid: Optional[Tensor] = None):
-        self.distribution = Categorical(logits=logits) if probs is None else Categorical(probs=probs)
+        self.distribution = (Categorical(logits=logits, validate_args=False) if probs is None
+                             else Categorical(probs=probs, validate_args=False))
         self.probs, self.valid = self.distribution.probs, valid
 
     def log_prob(self, sample: Tensor) -> Tensor:
@@ -49,6 +50,6 @@ class DestCategorical(MyDist):
 
     def repeat_interleave_(self, repeats: int, dim: int) -> None:
         self.probs = self.probs.repeat_interleave(repeats, dim)
-        self.distribution = Categorical(probs=self.probs)
+        self.distribution = Categorical(probs=self.probs, validate_args=False)
         if self.valid is not None:
             self.valid = self.valid.repeat_interleave(repeats, dim)

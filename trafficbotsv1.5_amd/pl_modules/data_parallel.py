@@ -51,3 +51,78 @@ def train_step(wm, optimizer: torch.optim.Optimizer, batch: Dict[str, Tensor], c
         torch.nn.utils.clip_grad_norm_(params, clip_grad_norm)
     optimizer.step()
     return wm.last_metrics
+
+
+class GraphedTrainStep:
+    """The same training step with forward + backward replayed as ONE hipGraph.
+
+    The eager step issues ~10^5 small launches (90 closed-loop steps x the per-step schedule, forward and backward) and is
+    bound by the host's launch rate; shapes are static on synthetic / fixed-size batches, the custom kernels only
+    enqueue on the current stream, and the step's two host-drawn random inputs (latent noise, prior/posterior choice)
+    are fed as device tensors, so the whole of fwd + bwd captures. Per call: copy the batch into the static input
+    buffers, refill the random inputs, replay, then (eagerly, outside the graph) the flat gradient all-reduce over
+    RCCL, the clip and the optimizer step - the exchange keeps its own place between backward and update, as in
+    `train_step`. Device-side generators (dropout, teacher-forcing Bernoulli draws) advance per replay through
+    torch's graph-safe Philox offsets.
+
+    Re-capture when the epoch changes (TeacherForcing's schedules read `current_epoch` on the host).
+    """
+
+    def __init__(self, wm, optimizer: torch.optim.Optimizer, example_batch: Dict[str, Tensor], clip_grad_norm: float = 5.0,
+                 warmup: int = 2, verbose: bool = False) -> None:
+        self.wm, self.opt, self.clip = wm, optimizer, clip_grad_norm
+        dev = next(wm.model.parameters()).device
+        self.static = self._pre(example_batch)  # static input buffers: the re-keyed (sc/*, gt/*, ref/*) batch
+        n, A = example_batch["agent/valid"].shape[:2]
+        self.noise = torch.zeros(n, A, wm.model.latent_encoder.out_dim, device=dev)
+        self.use_prior = torch.zeros((), dtype=torch.bool, device=dev)
+        self.epoch = wm.current_epoch
+        self.live: Optional[List[torch.nn.Parameter]] = None
+        # warm-up on the stream the capture will use (allocator / library workspaces / lazy inits must not happen inside the
+        # capture, and autograd's AccumulateGrad nodes must not outlive an iteration on another stream)
+        say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(warmup):
+                self._refill()
+                optimizer.zero_grad(set_to_none=True)
+                self._fwd_bwd()
+                self.live = self.live or live_parameters(wm.model)
+                say("warm-up", i, "done")
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)
+        wm.last_metrics = None
+        getattr(wm, "logged", {}).clear()
+        self.graph = torch.cuda.CUDAGraph()
+        say("capture begins")
+        with torch.cuda.graph(self.graph, stream=s):
+            self._fwd_bwd()  # gradients are allocated from the graph's pool: static addresses, rewritten by every replay
+        say("capture done")
+        self.metrics = dict(wm.last_metrics)
+
+    @torch.no_grad()
+    def _pre(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        return {k: v for k, v in self.wm.pre_processing({k: v.clone() for k, v in batch.items()}).items() if torch.is_tensor(v)}
+
+    def _fwd_bwd(self) -> None:
+        loss = self.wm.training_step(dict(self.static), 0, noise=self.noise, use_prior=self.use_prior)
+        loss.backward()
+
+    def _refill(self) -> None:
+        self.noise.copy_(torch.randn(self.noise.shape), non_blocking=False)  # CPU generator, as the reference's CPU path
+        self.use_prior.fill_(bool(torch.rand(1) < self.wm.hp.p_training_rollout_prior))
+
+    def __call__(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        assert self.wm.current_epoch == self.epoch, "re-capture the step after an epoch change"
+        b = self._pre(batch)  # eager (tiny); its advanced-indexing index tensors are host data, not capturable
+        for k, v in self.static.items():
+            v.copy_(b[k])
+        self._refill()
+        self.graph.replay()
+        allreduce_gradients(self.live)
+        if self.clip and self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.live, self.clip)
+        self.opt.step()
+        return self.metrics

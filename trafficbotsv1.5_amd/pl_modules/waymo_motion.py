@@ -103,7 +103,7 @@ class WaymoMotion(LightningModule):
                   n_step=step_end)
         eng.run(step_end, use_graph=use_graph)
         self._engine = eng
-        return eng.buffer(self.hp.time_step_current)
+        return eng.buffer(self.hp.time_step_current, rule_checker=rule_checker)
 
     def _rule_checker(self, batch, ag_dest, tl_tokens):
         return TrafficRuleChecker(mp_boundary=batch["map/boundary"], mp_valid=batch["map/valid"], mp_type=batch["map/type"],
@@ -164,12 +164,13 @@ class WaymoMotion(LightningModule):
         return {"pred_valid": S["ag_valid"].bool(), "pred_pose": S["ag_pose"], "pred_motion": S["ag_motion"]}, {}
 
     # ------------------------------------------------------------------ training
-    def training_step(self, batch: Dict[str, Tensor], batch_idx: int):
+    def training_step(self, batch: Dict[str, Tensor], batch_idx: int, noise: Optional[Tensor] = None,
+                      use_prior: Optional[Tensor] = None):
         """waymo_motion.py:313-385. KNARPE attention forward/backward, KNN and embeddings are HIP kernels; projections
         are library GEMMs; see train_graph.py for what is (not yet) fused."""
         from .. import train_graph
 
-        out = train_graph.training_step(self, batch)
+        out = train_graph.training_step(self, batch, noise=noise, use_prior=use_prior)
         for k, v in out.items():
             self.log(f"training/{k}", v, on_step=True)
         self.last_metrics = out

@@ -130,3 +130,64 @@ DATA_SIZE = {
     "tl_stop/state": (50, 91, 5), "agent/spd": (64, 91, 1), "agent/acc": (64, 91, 1), "agent/yaw_rate": (64, 91, 1),
     "agent/size": (64, 3), "agent/type": (64, 3),
 }
+
+
+def make_rule_episode(n_sc: int = 2, n_ag: int = 16, n_mp: int = 64, n_tl: int = 8, n_step: int = 40, seed: int = 0,
+                      n_pl_node: int = 20, extent: float = 60.0) -> Dict[str, torch.Tensor]:
+    """A crowded little world for the traffic-rule checks: agents start on map polylines, drive along
+    them in platoons (so boxes overlap, road edges get crossed, stop points get run over, slow vehicles idle on lanes),
+    with ragged validity and all three agent types. Returns the TrafficRuleChecker constructor tensors plus a
+    [n_sc, n_ag, n_step] episode (valid, pose, motion) and per-step light states."""
+    scenes = []
+    for i in range(n_sc):
+        g = torch.Generator().manual_seed(10_000 + seed + i)
+        U = lambda *s: torch.rand(*s, generator=g)
+        N = lambda *s: torch.randn(*s, generator=g)
+        start = (U(n_mp, 2) - 0.5) * 2 * extent
+        head = ((U(n_mp) - 0.5) * 2 * math.pi)[:, None] + torch.cat([torch.zeros(n_mp, 1), N(n_mp, n_pl_node - 1) * 0.03], 1).cumsum(1)
+        seg = torch.stack([head.cos(), head.sin()], -1)
+        pos = start[:, None] + torch.cat([torch.zeros(n_mp, 1, 2), seg[:, :-1].cumsum(1)], 1)
+        mp_valid = torch.arange(n_pl_node)[None] < torch.randint(1, n_pl_node + 1, (n_mp, 1), generator=g)
+        ty = torch.randint(0, 11, (n_mp,), generator=g)
+        ty[:8] = torch.tensor([0, 1, 2, 4, 5, 7, 0, 4])
+        mp_valid[:8] = True
+        tl_idx = torch.cat([torch.tensor([0, 1, 6]), 8 + torch.randperm(n_mp - 8, generator=g)[: n_tl - 3]])[:n_tl]
+        tl_state = torch.nn.functional.one_hot(
+            torch.randint(0, 5, (n_tl, (n_step + 4) // 5), generator=g).repeat_interleave(5, 1)[:, :n_step], 5).bool()
+        tl_state[0, :, :] = torch.tensor([False, True, False, False, False])  # light 0 stays on STOP
+        # agents: platoons of 2 on a polyline, the follower faster than the leader
+        lane = torch.randint(0, n_mp, (n_ag,), generator=g)
+        lane[: min(6, n_ag)] = torch.tensor([0, 0, 1, 1, 6, 6])[: min(6, n_ag)]
+        lane[1::2] = lane[0::2][: len(lane[1::2])]
+        node = torch.randint(0, n_pl_node // 2, (n_ag,), generator=g)
+        node[1::2] = node[0::2][: len(node[1::2])] + 4
+        node[: min(6, n_ag)] = torch.tensor([0, 4, 0, 5, 0, 3])[: min(6, n_ag)]  # start at / just past the lights' stop points
+        xy0 = pos[lane, node] + N(n_ag, 2) * 0.6
+        back = torch.zeros(n_ag)
+        back[: min(6, n_ag) : 2] = 6.0  # the lights' followers start 6 m before the stop point
+        xy0 = xy0 - back[:, None] * seg[lane, node]
+        yaw0 = head[lane, node] + N(n_ag) * 0.15
+        spd = U(n_ag) * 6.0
+        spd[0::2] += 6.0
+        yaw_rate = N(n_ag) * 0.05
+        t = torch.arange(n_step, dtype=torch.float32) * 0.1
+        yaw = yaw0[:, None] + yaw_rate[:, None] * t[None]
+        vel = spd[:, None, None] * torch.stack([yaw.cos(), yaw.sin()], -1)
+        xy = xy0[:, None] + torch.cat([torch.zeros(n_ag, 1, 2), (vel[:, :-1] * 0.1).cumsum(1)], 1)
+        valid = U(n_ag, n_step) > 0.05
+        valid[n_ag - 1] = False
+        valid[n_ag - 2, n_step // 2:] = False
+        at = torch.randint(0, 3, (n_ag,), generator=g)
+        at[: min(8, n_ag)] = 0
+        base = torch.tensor([[4.5, 2.0, 1.6], [0.8, 0.8, 1.7], [1.8, 0.6, 1.6]])[at]
+        scenes.append({
+            "map/valid": mp_valid, "map/type": torch.nn.functional.one_hot(ty, 11).bool(),
+            "map/pos": torch.cat([pos, torch.zeros(n_mp, n_pl_node, 1)], -1), "map/dir": torch.cat([seg, torch.zeros(n_mp, n_pl_node, 1)], -1),
+            "map/boundary": torch.tensor([-200.0, 200.0, -200.0, 200.0]),
+            "tl/valid": U(n_tl) < 0.8, "tl/pose": torch.cat([pos[tl_idx, 0], head[tl_idx, :1]], -1), "tl/state": tl_state,
+            "agent/type": torch.nn.functional.one_hot(at, 3).bool(), "agent/size": base * (0.8 + 0.4 * U(n_ag, 1)),
+            "agent/valid": valid, "agent/pose": torch.cat([xy, yaw[..., None]], -1),
+            "agent/motion": torch.stack([spd[:, None].expand(-1, n_step), torch.zeros(n_ag, n_step), yaw_rate[:, None].expand(-1, n_step)], -1),
+        })
+        scenes[-1]["tl/valid"][0] = True
+    return {k: torch.stack([s[k] for s in scenes], 0) for k in scenes[0]}

@@ -259,7 +259,7 @@ def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, d
     mask_type = ~(ag_type & ag_valid.unsqueeze(-1)).reshape(n * A, 3)
     mean = 0
     for i, m in enumerate(model.action_head.mlp_mean):
-        mean = mean + mlp(m, feat).masked_fill(mask_type[:, [i]], 0.0)
+        mean = mean + mlp(m, feat).masked_fill(mask_type[:, i:i + 1], 0.0)
     sp = model.tl_state_predictor
     xt = tl_feat.detach() if sp.detach_tl_feature else tl_feat
     logits = torch.clamp(mlp(sp.mlp, xt).masked_fill(tl_tokens["tl_token_invalid"].reshape(-1, 1), 0.0), -3, 3)
@@ -310,8 +310,8 @@ def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
     ty, ag_type = mp["mp_token_type"], b["ref/ag_type"]
     tok_valid = ag_valid.any(-1)
     mp_mask = mp["mp_token_invalid"] | ~(ty[:, :, :5].any(-1))
-    bad = (mp_mask[:, None] | (ag_type[:, :, [0]] & ty[:, :, 3][:, None]) | (ag_type[:, :, [1]] & ty[:, :, :4].any(-1)[:, None])
-           | (ag_type[:, :, [2]] & ty[:, :, :3].any(-1)[:, None]))
+    bad = (mp_mask[:, None] | (ag_type[:, :, 0:1] & ty[:, :, 3][:, None]) | (ag_type[:, :, 1:2] & ty[:, :, :4].any(-1)[:, None])
+           | (ag_type[:, :, 2:3] & ty[:, :, :3].any(-1)[:, None]))
     logits = logits.masked_fill(bad, float("-inf")).masked_fill((~tok_valid).unsqueeze(-1) | bad.all(-1, keepdim=True), 0)
     return DestCategorical(logits=logits, valid=tok_valid)
 
@@ -333,7 +333,9 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
     L, Tt = tl_gt.shape[1], tl_gt.shape[2]
     W, dev = model.temp_window_size, gt_pose.device
     dt = dyn.dt
-    max_act = torch.tensor([[a, y] for a, y in zip(dyn.max_acc, dyn.max_yaw_rate)], device=dev)
+    if getattr(dyn, "_max_act", None) is None or dyn._max_act.device != dev:  # host -> device once (not inside a captured step)
+        dyn._max_act = torch.tensor([[a, y] for a, y in zip(dyn.max_acc, dyn.max_yaw_rate)], device=dev)
+    max_act = dyn._max_act
     lim = (ag_type.unsqueeze(-1) * max_act).sum(2)
     bi = torch.arange(n, device=dev).unsqueeze(1)
     d_type = b["map/type"][bi, dest]
@@ -377,7 +379,7 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
         with torch.no_grad():
             tl_cur = tl_bits[:, :, step] if step < Tt else (1 << logits.argmax(-1)).to(torch.uint8)
             x, y = pred_pose[..., 0], pred_pose[..., 1]
-            out_now = ((x > bnd[:, [1]]) | (x < bnd[:, [0]]) | (y > bnd[:, [3]]) | (y < bnd[:, [2]])) & pred_valid
+            out_now = ((x > bnd[:, 1:2]) | (x < bnd[:, 0:1]) | (y > bnd[:, 3:4]) | (y < bnd[:, 2:3])) & pred_valid
             outside = outside | out_now
             dd = torch.norm(pred_pose[:, :, None, :2] - d_pos, dim=-1).masked_fill(d_inv, float("inf"))
             pos_ok = (dd < d_thresh.unsqueeze(-1)).any(-1)
@@ -397,7 +399,7 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
         else:
             r_valid, rew, dis = pred_valid, torch.zeros_like(pred_pose[..., 0]), out_now
         if step < Tt:
-            nll = -Categorical(logits=logits).log_prob(tl_gt[:, :, step].max(-1)[1])
+            nll = -Categorical(logits=logits, validate_args=False).log_prob(tl_gt[:, :, step].max(-1)[1])
             nll_inv = tl_tokens["tl_token_invalid"]
         else:
             nll, nll_inv = torch.zeros_like(logits[..., 0]), torch.ones_like(tl_tokens["tl_token_invalid"])
@@ -418,8 +420,8 @@ def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussi
         lv &= ~ro["tf"]
     any_valid = lv.any(-1)
     P, Q = post.distribution, prior.distribution
-    dP = Independent(Normal(P.base_dist.loc.detach(), P.base_dist.scale.detach()), 1)
-    dQ = Independent(Normal(Q.base_dist.loc.detach(), Q.base_dist.scale.detach()), 1)
+    dP = Independent(Normal(P.base_dist.loc.detach(), P.base_dist.scale.detach(), validate_args=False), 1, validate_args=False)
+    dQ = Independent(Normal(Q.base_dist.loc.detach(), Q.base_dist.scale.detach(), validate_args=False), 1, validate_args=False)
     e0 = torch.clamp(kl_divergence(dP, Q), min=cfg.kl_free_nats)
     e1 = torch.clamp(kl_divergence(P, dQ), min=cfg.kl_free_nats)
     kv = (post.valid if cfg.kl_for_unseen_agent else prior.valid) & any_valid
@@ -433,12 +435,17 @@ def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussi
     return {"loss": vae_kl - reward + navi + tl, "vae_kl": vae_kl, "diffbar_reward": reward, "navi_loss": navi, "tl_state_loss": tl}
 
 
-def training_step(wm, raw_batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
-    """waymo_motion.py:313-385."""
+def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = None, use_prior: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """waymo_motion.py:313-385. `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
+    inputs of a step as device tensors: a captured step (pl_modules/data_parallel.GraphedTrainStep) refills them before
+    every replay; left None they are drawn here from the CPU generator like the reference's CPU path does."""
     model, hp = wm.model, wm.hp
     tr = model.training
-    with torch.no_grad():
-        b = wm.pre_processing(raw_batch)
+    if "sc/mp_valid" in raw_batch:  # already re-keyed (a captured step pre-processes eagerly: its index tensors come from the host)
+        b = raw_batch
+    else:
+        with torch.no_grad():
+            b = wm.pre_processing(raw_batch)
     mp = map_encoder(model.mp_encoder, b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"], tr)
     tl_tokens = tl_pre_compute(model.tl_encoder, b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], mp)
     mp["_kv_cache"], tl_tokens["_kv_cache"] = {}, {}  # map K/V tables: once per training step, shared by all 90 steps
@@ -446,13 +453,21 @@ def training_step(wm, raw_batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
     pr = model.latent_encoder.latent_dist_prior
     valid_hist = b["sc/ag_valid"].any(-1)
     prior = DiagGaussian(pr.mean.expand(*valid_hist.shape, -1), pr.log_std, valid=valid_hist)
-    lat = prior if torch.rand(1) < hp.p_training_rollout_prior else post
     # rsample with the noise drawn from the CPU generator, as the reference's CPU path does (same stream under the same
     # seed); one [n, A, 16] host-to-device copy per training step
-    z = lat.mean + lat.stddev * torch.randn(lat.mean.shape).to(lat.mean.device)
+    if use_prior is None:
+        lat = prior if torch.rand(1) < hp.p_training_rollout_prior else post
+        l_mean, l_std, l_valid = lat.mean, lat.stddev, lat.valid
+    else:  # the same choice as a device-side select (no host branch inside a captured step)
+        l_mean = torch.where(use_prior, prior.mean, post.mean)
+        l_std = torch.where(use_prior, prior.stddev.expand_as(post.mean), post.stddev.expand_as(post.mean))
+        l_valid = torch.where(use_prior, prior.valid, post.valid)
+    if noise is None:
+        noise = torch.randn(l_mean.shape).to(l_mean.device)
+    z = l_mean + l_std * noise
     navi_pred = navi_predictor(model.navi_predictor, b, mp, tr)
     tf = wm.teacher_forcing_training
     tf.init(ag_valid=b["gt/ag_valid"], ag_pose=b["gt/ag_pose"], ag_motion=b["gt/ag_motion"], tl_state=b["gt/tl_state"],
             current_epoch=wm.current_epoch)
-    ro = training_rollout(wm, b, mp, tl_tokens, z, lat.valid, tf.ag_teacher_forcing, hp.time_step_end)
+    ro = training_rollout(wm, b, mp, tl_tokens, z, l_valid, tf.ag_teacher_forcing, hp.time_step_end)
     return training_loss(hp.training_metrics, ro, navi_pred, b["gt/ag_navi"], post, prior)

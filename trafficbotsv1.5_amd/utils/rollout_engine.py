@@ -187,10 +187,15 @@ class RolloutEngine:
                 self.step()
 
     # ------------------------------------------------------------------ results
-    def buffer(self, step_current: int = 10) -> RolloutBuffer:
+    def buffer(self, step_current: int = 10, rule_checker=None) -> RolloutBuffer:
+        """The rollout log as the reference's RolloutBuffer. With a TrafficRuleChecker, the five metric-only rule checks
+        (collided, collided_wosac, run_road_edge, run_red_light, passive: waymo_motion.py:250 in the reference's loop) are
+        evaluated here for all steps at once from the device-resident log (tbx_rule_check over n x T frames)."""
         S, buf = self.S, RolloutBuffer(self.T, step_current)
         buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
         buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
+        if rule_checker is not None:
+            buf.violation.update(rule_checker.check_log(S["out_valid"], S["out_pose"], S["out_motion"], S["out_tl_state"]))
         bits = (S["out_tl_state"].to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=self.dev, dtype=torch.int32)) & 1
         buf.vis_dict = {"action": S["out_action"], "tl_state": bits.bool()}
         return buf

@@ -1,10 +1,25 @@
-"""`TrafficRuleChecker` (utils/traffic_rule_checker.py:10-85) as the holder of the static tensors the rule checks
-need. The two checks that feed back into the closed loop (outside-map -> disable agent, destination reached ->
-disable navi) run inside `tbx_sim_step`; the metric-only checks (collision, road edge, red light, passive) are the
-next row of the scope table and are not computed yet."""
-from typing import Optional
+"""`TrafficRuleChecker` (utils/traffic_rule_checker.py:10-451) on the HIP rule kernels.
 
+The reference calls `check` once per Python step of the rollout (pl_modules/waymo_motion.py:250). Two of its checks feed
+back into the simulation (outside-map -> disable agent, destination reached -> disable navi) and run inside
+`tbx_sim_step`; the other five (collided, collided_wosac, run_road_edge, run_red_light, passive) only produce metrics and
+the WOSAC rollout filter, so here they are evaluated for ALL steps of a finished rollout at once from the device-resident
+rollout log (`check_log`, one `tbx_rule_check` launch over n_rollout x n_step frames + one `tbx_rule_accumulate`), which
+fills a 256-CU device where 80 per-step calls on 64-128 agents would not. `check` keeps the reference's per-step
+signature (a one-frame log). Constructor arguments are the reference's; map tensors may be given per scene while the
+agent tensors are per rollout (n_rollout = K * n_scene): the K rollouts of a scene share one copy of the tables.
+
+There is no CPU path: every method needs device tensors and the HIP library.
+"""
+from typing import Dict, Optional
+
+import torch
 from torch import Tensor
+
+from .. import hip
+
+_KEYS = (("collided", hip.RULE_COLLIDED), ("collided_wosac", hip.RULE_COLLIDED_WOSAC), ("run_road_edge", hip.RULE_RUN_ROAD_EDGE),
+         ("run_red_light", hip.RULE_RUN_RED_LIGHT), ("passive", hip.RULE_PASSIVE))
 
 
 class TrafficRuleChecker:
@@ -15,3 +30,71 @@ class TrafficRuleChecker:
         self.mp_pos, self.mp_dir = mp_pos, mp_dir
         self.ag_type, self.ag_size, self.ag_goal, self.ag_dest = ag_type, ag_size, ag_goal, ag_dest
         self.tl_valid, self.tl_pose, self.disable_check = tl_valid, tl_pose, disable_check
+        self.collision_size_scale = collision_size_scale
+        self._ctx: Optional[hip.RuleCtx] = None
+        self._keep = None
+        self._acc: Optional[Tensor] = None          # running OR of the five flags [n, A] u8 bits
+        self.passive_counter: Optional[Tensor] = None  # [n, A] f32 (traffic_rule_checker.py:42)
+
+    # ------------------------------------------------------------------ static tables (once per scene batch)
+    @torch.no_grad()
+    def _setup(self) -> hip.RuleCtx:
+        if self._ctx is not None:
+            return self._ctx
+        n, A = self.ag_type.shape[:2]
+        n_scene = self.mp_valid.shape[0]
+        assert n % n_scene == 0, "agent tensors must hold a whole number of rollouts per scene"
+        u8 = torch.uint8
+        seg, n_seg, lane, n_lane = hip.rule_tables(self.mp_valid.to(u8).contiguous(), self.mp_type.to(u8).argmax(-1).to(u8).contiguous(),
+                                                   self.mp_pos.float().contiguous(), self.mp_dir.float().contiguous())
+        size = self.ag_size.float().contiguous()
+        if size.shape[-1] != 3:
+            size = torch.cat([size, size.new_zeros(*size.shape[:-1], 3 - size.shape[-1])], -1).contiguous()
+        keep = dict(seg=seg, n_seg=n_seg, lane=lane, n_lane=n_lane, ag_size=size,
+                    ag_type_idx=self.ag_type.to(u8).argmax(-1).to(u8).contiguous(), tl_valid=self.tl_valid.to(u8).contiguous(),
+                    tl_pose=self.tl_pose.float().contiguous())
+        ctx = hip.RuleCtx()
+        ctx.n_batch, ctx.n_ag, ctx.n_tl = n, A, self.tl_valid.shape[1]
+        ctx.map_batch_div, ctx.cap = n // n_scene, seg.shape[1]
+        for k, v in keep.items():
+            setattr(ctx, k, v.data_ptr())
+        ctx.collision_size_scale = self.collision_size_scale
+        self._keep, self._ctx = keep, ctx
+        self._acc = torch.zeros(n, A, dtype=u8, device=size.device)
+        self.passive_counter = torch.zeros(n, A, dtype=torch.float32, device=size.device)
+        return ctx
+
+    # ------------------------------------------------------------------ whole rollout log
+    @torch.no_grad()
+    def check_log(self, valid: Tensor, pose: Tensor, motion: Tensor, tl_state_bits: Tensor, t0: int = 0,
+                  n_t: Optional[int] = None) -> Dict[str, Tensor]:
+        """valid [n,A,T] u8/bool, pose / motion [n,A,T,3], tl_state_bits [n,L,T] u8 (5-bit state masks): steps [t0, t0+n_t)
+        continue from the accumulated state of earlier calls. -> the reference's violation dict restricted to the five
+        metric-only checks, every entry [n, A, T] bool (`k` accumulated, `k_this_step` per step)."""
+        ctx = self._setup()
+        n, A, T = valid.shape
+        n_t = T - t0 if n_t is None else n_t
+        if self.disable_check:  # training: the reference returns its (all-false) accumulators (:357-404)
+            z = torch.zeros(n, A, T, dtype=torch.bool, device=pose.device)
+            return {k + s: z for k, _ in _KEYS for s in ("", "_this_step")}
+        v8 = valid.to(torch.uint8).contiguous()
+        now = torch.zeros(n, A, T, dtype=torch.uint8, device=pose.device)
+        acc = torch.zeros(n, A, T, dtype=torch.uint8, device=pose.device)
+        hip.rule_check(ctx, v8, pose.float().contiguous(), motion.float().contiguous(), tl_state_bits.contiguous(), T, t0, n_t, now)
+        hip.rule_accumulate(now, n * A, T, t0, n_t, self._acc, self.passive_counter, now, acc)
+        out = {}
+        for k, bit in _KEYS:
+            out[k] = (acc & bit).bool()
+            out[k + "_this_step"] = (now & bit).bool()
+        return out
+
+    # ------------------------------------------------------------------ the reference's per-step entry point
+    @torch.no_grad()
+    def check(self, valid: Tensor, pose: Tensor, motion: Tensor, tl_state: Tensor) -> Dict[str, Tensor]:
+        """traffic_rule_checker.py:342-451 for one step: valid [n,A] bool, pose / motion [n,A,3], tl_state [n,L,5] one-hot
+        bool -> {collided, collided_this_step, ...} [n,A] bool, accumulating across calls like the reference's object.
+        (outside_map / dest_reached are produced by the simulation step itself: RolloutBuffer.violation.)"""
+        w = 1 << torch.arange(tl_state.shape[-1], device=tl_state.device, dtype=torch.int32)
+        bits = (tl_state.to(torch.int32) * w).sum(-1).to(torch.uint8)
+        out = self.check_log(valid.unsqueeze(-1), pose.unsqueeze(2), motion.unsqueeze(2), bits.unsqueeze(-1))
+        return {k: v[..., 0] for k, v in out.items()}
