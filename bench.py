@@ -53,7 +53,8 @@ def parse():
                     help="skip the second measurement (32 rollouts x 128 agents per GPU) the default rollout run appends")
     ap.add_argument("--no-train-shape", action="store_true",
                     help="skip the training_step measurement (16 scenes per GPU, fwd+bwd+all-reduce+AdamW) the default run appends")
-    ap.add_argument("--train-steps", type=int, default=2, help="timed training steps of that appended measurement")
+    ap.add_argument("--no-train-graph", action="store_true", help="training: eager fwd+bwd instead of one hipGraph replay per step")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of that appended measurement")
     a = ap.parse_args()
     tr = a.mode == "train"
     a.steps = a.steps if a.steps is not None else (3 if tr else 80)
@@ -231,13 +232,23 @@ def train_main(args, tb, dev, rank, world, dist):
         torch.cuda.synchronize()
 
     live = None
-    for _ in range(args.warmup):
-        DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live)
-        live = live or DP.live_parameters(wm.model)
+    if args.no_train_graph:
+        step = lambda: DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live)
+        for _ in range(args.warmup):
+            step()
+            live = live or DP.live_parameters(wm.model)
+    else:
+        # forward + backward replayed as one hipGraph (the eager step is bound by the host's launch rate); the gradient
+        # all-reduce, the clip and AdamW stay outside the graph. Capture (2 eager warm-up steps inside) is untimed.
+        gstep = DP.GraphedTrainStep(wm, opt, batch)
+        live = gstep.live
+        step = lambda: gstep(batch)
+        for _ in range(args.warmup):
+            step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m = DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live)
+        m = step()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -251,7 +262,7 @@ def train_main(args, tb, dev, rank, world, dist):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"training_step fwd+bwd+grad all-reduce+AdamW, {args.scenes} scenes/GPU of {args.agents} agents/"
                                    f"{args.polylines} polylines/{args.lights} lights, 90-step rollout, default 10,657,094-param model",
-                       "global_batch": world * args.scenes, "parallelism": f"dp{world}",
+                       "global_batch": world * args.scenes, "parallelism": f"dp{world}", "fwd_bwd_hipgraph": not args.no_train_graph,
                        "allreduce_bytes": n_live * 4, "note": "dropout on residual/FFN/MLP paths as configured (p=0.1); "
                                                              "attention-probability dropout not applied inside the HIP kernel yet"},
             "loss": float(m["loss"]), "finite": bool(torch.isfinite(m["loss"]))}

@@ -313,6 +313,21 @@ int tbx_rule_check(const tbx_rule_ctx_t* ctx /* host */, const uint8_t* valid, c
 int tbx_rule_accumulate(const uint8_t* raw, int n_rows, int ld_t, int t0, int n_t, uint8_t* acc_state, float* passive_counter,
                         uint8_t* out_now, uint8_t* out_acc, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * WOSAC rollout filter. Replaces WOSACPostProcessing._filter_futures
+ * (data_modules/wosac_post_processing.py:31-64): score_k = sum_a role_a * any_{t >= t_start} col[k,a,t]
+ *                                                        + w_road_edge * sum_a role_a * any_{t >= t_start} edge[k,a,t],
+ * keep the n_keep rollouts of each scene with the smallest score (the reference's topk(largest=False, sorted=False) leaves
+ * ties unspecified; here ties go to the lower rollout index and idx is in ascending (score, index) order).
+ *   flags [n_scene*n_k, n_ag, ld_t] u8 TBX_RULE_* bits (e.g. tbx_rule_accumulate's out_acc); col_bit = TBX_RULE_COLLIDED or
+ *   TBX_RULE_COLLIDED_WOSAC (use_wosac_col); ag_role_any [n_scene, n_ag] u8 = ag_role.any(-1)
+ *   score [n_scene, n_k] f32, idx [n_scene, n_keep] i32 (outputs)
+ *   pred_pose [n_scene*n_k, n_ag, ld_t, 3] -> trajs [n_scene, n_keep, n_ag, ld_t - t_start, 3] (both NULL: selection only)
+ * n_k <= 1024. */
+int tbx_filter_futures(const uint8_t* flags, int col_bit, const uint8_t* ag_role_any, int n_scene, int n_k, int n_ag, int ld_t,
+                       int t_start, float w_road_edge, int n_keep, float* score, int32_t* idx, const float* pred_pose,
+                       float* trajs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

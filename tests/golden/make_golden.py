@@ -411,10 +411,40 @@ def gen_rules():
     npz("rules.npz", **out)
 
 
+@torch.no_grad()
+def gen_filter():
+    """the reference's WOSACPostProcessing._filter_futures on seeded inputs
+    (`synthetic.make_filter_case`, ours). Kept: the per-rollout violation score it ranks by (recomputed with the
+    reference's expressions from its own inputs) and the SORTED scores / indices of the futures it keeps."""
+    from data_modules.wosac_post_processing import WOSACPostProcessing
+    from utils.buffer import RolloutBuffer
+
+    out = {}
+    for tag, kw, w, wosac in (("a", dict(n_sc=2, n_k=48, n_ag=12, n_step=30, seed=0), 0.5, True),
+                              ("b", dict(n_sc=3, n_k=128, n_ag=20, n_step=91, seed=1, p_col=0.05, p_edge=0.1), 2.0, False)):
+        c = tb.synthetic.make_filter_case(**kw)
+        pp = WOSACPostProcessing(step_gt=90, step_current=10, const_vel_z_sim=True, const_vel_no_sim=True, w_road_edge=w,
+                                 use_wosac_col=wosac)
+        buf = RolloutBuffer(c["pred_pose"].shape[3], 10)
+        buf.pred_pose = c["pred_pose"]
+        buf.violation = {k: c[k] for k in ("collided", "collided_wosac", "run_road_edge")}
+        trajs = pp._filter_futures(buf, c["ag_role"])
+        # which futures were kept: match the returned trajectories back to their rollout index
+        flat = c["pred_pose"][:, :, :, buf.step_future_start:]
+        idx = torch.stack([torch.stack([torch.nonzero((flat[s] == trajs[s, j]).flatten(1).all(1))[0, 0] for j in range(trajs.shape[1])])
+                           for s in range(trajs.shape[0])])
+        out[f"{tag}_idx_sorted"] = idx.sort(-1)[0]
+        out[f"{tag}_trajs_checksum"] = trajs.double().sum((1, 2, 3, 4))
+        print(tag, "kept", trajs.shape, "first scene idx", out[f"{tag}_idx_sorted"][0][:8].tolist())
+    npz("filter.npz", **out)
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "c1", "c2", "rules"]
+    which = sys.argv[1:] or ["ops", "c1", "c2", "rules", "filter"]
+    if "filter" in which:
+        gen_filter()
     if "rules" in which:
         gen_rules()
     if "ops" in which:

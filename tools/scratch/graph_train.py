@@ -14,6 +14,11 @@ DP = import_module("trafficbots_amd.pl_modules.data_parallel")
 dev = torch.device("cuda:0")
 scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 drop0 = len(sys.argv) > 2 and sys.argv[2] == "parity"
+if "dist" in sys.argv:
+    import os, torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=dev)
+    t = torch.ones(4, device=dev); dist.all_reduce(t); print("nccl up", t.tolist(), flush=True)
 cfg = tb.config.default_model_cfg()
 scfg = tb.config.default_sim_cfg()
 if drop0:
@@ -33,34 +38,30 @@ for i in range(2):
     DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live)
     live = live or DP.live_parameters(wm.model)
     sync(); print("eager step", i, time.perf_counter() - t0, flush=True)
-import warnings
-torch.cuda.set_sync_debug_mode("warn")
-with warnings.catch_warnings(record=True) as wl:
-    warnings.simplefilter("always")
-    opt.zero_grad(set_to_none=True)
-    nz, up = torch.zeros(scenes, 64, 16, device=dev), torch.zeros((), dtype=torch.bool, device=dev)
-    bpre = {k: v for k, v in wm.pre_processing({k: v.clone() for k, v in batch.items()}).items() if torch.is_tensor(v)}
-    n0 = len(wl)
-    wm.training_step(dict(bpre), 0, noise=nz, use_prior=up).backward()
-torch.cuda.set_sync_debug_mode("default")
-import collections
-c = collections.Counter((str(w.filename).split("/")[-1], w.lineno) for w in wl[n0:])
-print("sync sites in fwd+bwd:", c.most_common(20), flush=True)
-t0 = time.perf_counter()
 wm.last_metrics = None; wm.logged.clear(); opt.zero_grad(set_to_none=True)
-gs = DP.GraphedTrainStep(wm, opt, batch, verbose=True)
-sync(); print("capture (incl 2 warm-ups)", time.perf_counter() - t0, flush=True)
-for i in range(4):
+t0 = time.perf_counter()
+gs = DP.GraphedTrainStep(wm, opt, batch, verbose=True, warmup=1)
+sync(); print("capture (incl warm-up)", time.perf_counter() - t0, flush=True)
+for i in range(3):
     sync(); t0 = time.perf_counter()
     m = gs(batch)
-    sync(); print("graph step", i, time.perf_counter() - t0, float(m["loss"]), flush=True)
+    sync(); print("graph step", i, time.perf_counter() - t0, float(m["loss"].detach()), flush=True)
 if drop0:
-    # same noise / choice, eager vs replay
-    gs.opt = torch.optim.SGD(gs.live, lr=0.0)
-    torch.manual_seed(5); m = gs(batch); lg = float(m["loss"]); gg = [p.grad.clone() for p in gs.live]
-    opt.zero_grad(set_to_none=True)
-    loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0, noise=gs.noise, use_prior=gs.use_prior)
-    loss.backward()
-    print("loss graph", lg, "eager", float(loss))
-    print("max grad diff", max(float((a - p.grad).abs().max()) for a, p in zip(gg, gs.live)), "max grad", max(float(a.abs().max()) for a in gg))
+    gs.opt = torch.optim.SGD(gs.live, lr=0.0); gs.clip = 0
+    names = {id(p): k for k, p in wm.model.named_parameters()}
+    def eager():
+        for p in gs.live: p.grad = None
+        loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0, noise=gs.noise, use_prior=gs.use_prior)
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in gs.live]
+    le1, ge1 = eager(); le2, ge2 = eager()
+    print("loss eager", le1, le2)
+    def report(tag, A, B):
+        worst = sorted(((float((a - b).abs().max()), float(a.abs().max()), names[id(p)]) for a, b, p in zip(A, B, gs.live)), reverse=True)[:4]
+        print(tag, worst, flush=True)
+    report("eager vs eager", ge1, ge2)
+    gs.graph.replay(); torch.cuda.synchronize()   # same noise / choice as the eager runs: replay without refill
+    gr = [g.clone() for g in gs.grads]
+    print("loss graph (same noise)", float(gs.metrics["loss"].detach()))
+    report("graph vs eager", gr, ge1)
 print("mem GB", torch.cuda.max_memory_allocated() / 1e9)

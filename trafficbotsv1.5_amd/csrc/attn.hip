@@ -32,7 +32,8 @@ struct AttnArgs {
   uint8_t* row_no_valid;
   tbx_attn_seg_t seg[2];
   int ldq, q_off, qt_off, ldo, n_rows, n_src, n_seg;
-  float scale;
+  float scale;   // 1 / sqrt(d_head)
+  float scale2;  // log2(e) / sqrt(d_head): the forward's softmax runs in base 2
 };
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -151,11 +152,9 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   const int wave = threadIdx.x >> 6;
   const int rib = wave / WPR;
   const int wir = wave % WPR;
-  const int row = blockIdx.x * RPB + rib;
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * RPB + rib);  // a wave works on one row: keep it in an SGPR
   if (row >= a.n_rows) return;  // uniform per row group (and per workgroup when WPR == 4)
   const int b = row / a.n_src;
-  const int k0 = a.seg[0].k;
-  const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
   const int s8 = lane & 7, tg = lane >> 3;
 
   // ---- query side in registers
@@ -185,41 +184,38 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     eacc[h].zero();
   }
 
-  for (int base = wir * 8; base < ktot; base += 8 * WPR) {
-    const int t = base + tg;
-    const bool active = t < ktot;
-    const int sg = (active && t >= k0) ? 1 : 0;
+  // Segment by segment, 8 targets per pass: everything that depends on the segment (table base of this row's scene, leading
+  // dimensions, the materialised / in-register embedding choice) is wave-uniform and lives in scalar registers. The loop is
+  // VALU-issue bound (~70 wave instructions per pair), so it is kept straight-line: slots past the segment's K re-read its
+  // last pair (finite data) and, like masked targets, enter the online softmax with probability exactly 0 and a rescale
+  // factor of exactly 1 - no per-lane branches, no zero fills, no per-lane segment selects.
+  for (int sg = 0; sg < a.n_seg; ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
-    const int kk = sg ? t - k0 : t;
-    float acc[NH] = {0.f, 0.f, 0.f, 0.f};
-    bool inv = true;
-    float4 v[4];
-    ESlice e;
-    e.zero();
-#pragma unroll
-    for (int st = 0; st < 4; ++st) v[st] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) {
-      const int64_t pi = (int64_t)row * S.k + kk;
+    const float* kvb = S.kv + (int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv;
+    const int64_t pbase = (int64_t)row * S.k;
+    for (int base = wir * 8; base < S.k; base += 8 * WPR) {
+      const int t = base + tg;
+      const bool active = t < S.k;
+      const int64_t pi = pbase + (active ? t : S.k - 1);
       const int j = S.idx[pi];
-      inv = S.invalid[pi] != 0;
-      const float* trow = S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * S.ld_kv;
-      float4 kq[4];
+      const bool ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
+      const float* trow = kvb + (int64_t)j * S.ld_kv;
+      float4 kq[4], v[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         kq[st] = *(const float4*)(trow + S.k_off + st * 32 + s8 * 4);
         v[st] = *(const float4*)(trow + S.v_off + st * 32 + s8 * 4);
       }
+      ESlice e;
       load_e(S, pi, s8, fq, e);
+      // online-softmax update in the base-2 domain (scores pre-multiplied by log2(e) / sqrt(d_head), v_exp_f32 directly)
 #pragma unroll
-      for (int h = 0; h < NH; ++h) acc[h] = dot4(kq[h], qv[h]) + e.dot(qt[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float sc = (tbx::group8_sum(acc[h]) + qb[h]) * a.scale;  // scale applied after masking as the reference does
-      if (active && !inv) {  // uniform within the 8-lane group
-        const float m_new = fmaxf(m_run[h], sc);
-        const float alpha = expf(m_run[h] - m_new);  // exp(-inf) = 0 on the slot's first valid target
-        const float pr = expf(sc - m_new);
+      for (int h = 0; h < NH; ++h) {
+        const float sc = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
+        const float m_old = m_run[h];
+        const float m_new = ok ? fmaxf(m_old, sc) : m_old;
+        const float alpha = (m_new == m_old) ? 1.f : __builtin_amdgcn_exp2f(m_old - m_new);  // 0 on the slot's first valid target
+        const float pr = ok ? __builtin_amdgcn_exp2f(sc - m_new) : 0.f;
         l_run[h] = l_run[h] * alpha + pr;
         m_run[h] = m_new;
         scale4(oacc[h], alpha);  // K/V channel block st == h belongs to head h
@@ -236,7 +232,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   for (int h = 0; h < NH; ++h) {
     const float mm = tbx::slot_max(m_run[h]);
     M[h] = mm;
-    const float f = (m_run[h] == -INFINITY) ? 0.f : expf(m_run[h] - mm);
+    const float f = (m_run[h] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[h] - mm);
     float ll = l_run[h] * f;
     scale4(oacc[h], f);
     eacc[h].scale(f);
@@ -287,7 +283,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
 #pragma unroll
       for (int w = 0; w < WPR; ++w) {
         const float mw = red_s[w][OUTW + h];
-        fw[w][h] = (mw == -INFINITY) ? 0.f : expf(mw - mm);
+        fw[w][h] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
         ll += fw[w][h] * red_s[w][OUTW + NH + h];
       }
       any_valid = any_valid || mm > -INFINITY;
@@ -558,6 +554,7 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
   a.n_src = n_src;
   a.n_seg = n_seg;
   a.scale = 1.0f / sqrtf((float)DH);
+  a.scale2 = 1.4426950408889634f / sqrtf((float)DH);
   return TBX_OK;
 }
 

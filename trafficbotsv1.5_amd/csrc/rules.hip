@@ -327,6 +327,62 @@ __global__ void rule_accumulate_kernel(const uint8_t* raw, int n_rows, int ld_t,
   counter[r] = cnt;
 }
 
+
+// ---------------------------------------------------------------------------------------------- WOSAC rollout filter
+// data_modules/wosac_post_processing.py:31-64: score_k = sum_a role_a * any_t collided[k,a,t] + w * sum_a role_a * any_t
+// run_road_edge[k,a,t] (t >= t_start), keep the n_keep rollouts with the smallest score. One workgroup per scene: a wave per
+// rollout counts its flagged agents (lanes over agents, bytes along t are contiguous), then every rollout ranks itself by
+// (score, index) against the K scores in LDS; the kept indices come out in ascending (score, index) order.
+constexpr int MAX_K = 1024;
+
+__global__ __launch_bounds__(256) void filter_score_kernel(const uint8_t* __restrict__ flags, int col_bit,
+                                                           const uint8_t* __restrict__ role_any, int K, int A, int ld_t,
+                                                           int t_start, float w_road_edge, int n_keep,
+                                                           float* __restrict__ score, int32_t* __restrict__ idx) {
+  __shared__ float sc[MAX_K];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < K; k += 4) {
+    int n_col = 0, n_edge = 0;
+    for (int a = lane; a < A; a += 64) {
+      if (!role_any[(int64_t)b * A + a]) continue;
+      const uint8_t* f = flags + (((int64_t)b * K + k) * A + a) * ld_t;
+      uint8_t m = 0;
+      for (int t = t_start; t < ld_t; ++t) m |= f[t];
+      n_col += (m & col_bit) ? 1 : 0;
+      n_edge += (m & TBX_RULE_RUN_ROAD_EDGE) ? 1 : 0;
+    }
+    n_col = (int)tbx::wave_sum((float)n_col);
+    n_edge = (int)tbx::wave_sum((float)n_edge);
+    if (lane == 0) {
+      const float v = (float)n_col + (float)n_edge * w_road_edge;
+      sc[k] = v;
+      score[(int64_t)b * K + k] = v;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float v = sc[k];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) rank += (sc[j] < v || (sc[j] == v && j < k)) ? 1 : 0;
+    if (rank < n_keep) idx[(int64_t)b * n_keep + rank] = k;
+  }
+}
+
+__global__ void filter_gather_kernel(const float* __restrict__ pose, const int32_t* __restrict__ idx, int K, int A, int ld_t,
+                                     int t_start, int n_keep, int64_t total, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int per = (ld_t - t_start) * 3;  // floats of one (rollout, agent) future
+  const int64_t row = i / per;           // (scene, kept, agent)
+  const int c = (int)(i % per);
+  const int a = (int)(row % A);
+  const int64_t sj = row / A;
+  const int b = (int)(sj / n_keep);
+  const int k = idx[sj];
+  out[i] = pose[((((int64_t)b * K + k) * A + a) * ld_t + t_start) * 3 + c];
+}
+
 }  // namespace
 
 extern "C" int tbx_rule_tables(const uint8_t* mp_valid, const uint8_t* mp_type_idx, const float* mp_pos, const float* mp_dir,
@@ -363,5 +419,26 @@ extern "C" int tbx_rule_accumulate(const uint8_t* raw, int n_rows, int ld_t, int
   if (n_rows <= 0 || ld_t <= 0 || t0 < 0 || n_t <= 0 || t0 + n_t > ld_t) return TBX_ERR_ARG;
   hipLaunchKernelGGL(rule_accumulate_kernel, dim3((n_rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, raw, n_rows, ld_t,
                      t0, n_t, acc_state, passive_counter, out_now, out_acc);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_filter_futures(const uint8_t* flags, int col_bit, const uint8_t* ag_role_any, int n_scene, int n_k, int n_ag,
+                                  int ld_t, int t_start, float w_road_edge, int n_keep, float* score, int32_t* idx,
+                                  const float* pred_pose, float* trajs, void* stream) {
+  if (!flags || !ag_role_any || !score || !idx) return TBX_ERR_ARG;
+  if (n_scene <= 0 || n_k <= 0 || n_ag <= 0 || ld_t <= 0 || t_start < 0 || t_start > ld_t || n_keep <= 0 || n_keep > n_k)
+    return TBX_ERR_ARG;
+  if (col_bit != TBX_RULE_COLLIDED && col_bit != TBX_RULE_COLLIDED_WOSAC) return TBX_ERR_ARG;
+  if (n_k > MAX_K) return TBX_ERR_UNSUPPORTED;
+  if ((pred_pose == nullptr) != (trajs == nullptr)) return TBX_ERR_ARG;
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(filter_score_kernel, dim3(n_scene), dim3(256), 0, hs, flags, col_bit, ag_role_any, n_k, n_ag, ld_t, t_start,
+                     w_road_edge, n_keep, score, idx);
+  if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
+  if (pred_pose && ld_t > t_start) {
+    const int64_t total = (int64_t)n_scene * n_keep * n_ag * (ld_t - t_start) * 3;
+    hipLaunchKernelGGL(filter_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, pred_pose, idx, n_k, n_ag,
+                       ld_t, t_start, n_keep, total, trajs);
+  }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

@@ -100,8 +100,9 @@ def load():
     lib.tbx_rule_tables.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
     for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate"):
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -264,6 +265,22 @@ def rule_accumulate(raw, n_rows: int, ld_t: int, t0: int, n_t: int, acc_state, p
                                     _cptr(passive_counter, torch.float32), _cptr(out_now, torch.uint8), _cptr(out_acc, torch.uint8),
                                     stream_ptr())
     _check(rc, "tbx_rule_accumulate")
+
+
+def filter_futures(flags, col_bit: int, ag_role_any, n_scene: int, n_k: int, t_start: int, w_road_edge: float, n_keep: int,
+                   pred_pose=None):
+    """flags [n_scene*n_k, A, T] u8 bits, ag_role_any [n_scene, A] u8 -> (score [n_scene,n_k], idx [n_scene,n_keep] i32,
+    trajs [n_scene, n_keep, A, T - t_start, 3] or None)."""
+    A, T = flags.shape[-2:]
+    dev = flags.device
+    score = torch.empty(n_scene, n_k, dtype=torch.float32, device=dev)
+    idx = torch.empty(n_scene, n_keep, dtype=torch.int32, device=dev)
+    trajs = None if pred_pose is None else torch.empty(n_scene, n_keep, A, T - t_start, 3, dtype=torch.float32, device=dev)
+    rc = load().tbx_filter_futures(_cptr(flags, torch.uint8), col_bit, _cptr(ag_role_any, torch.uint8), n_scene, n_k, A, T, t_start,
+                                   w_road_edge, n_keep, _ptr(score), _ptr(idx), _cptr(pred_pose, torch.float32), _ptr(trajs),
+                                   stream_ptr())
+    _check(rc, "tbx_filter_futures")
+    return score, idx, trajs
 
 
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1) -> torch.Tensor:

@@ -8,6 +8,7 @@ Replaces Lightning's `strategy="ddp"` (run.py:50-52) for this path. Differences 
     peers a single large message amortises launch latency best; it is ~1 % of a training step, so it is not overlapped
     with backward (nothing to hide).
 """
+import threading
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -78,9 +79,34 @@ class GraphedTrainStep:
         self.use_prior = torch.zeros((), dtype=torch.bool, device=dev)
         self.epoch = wm.current_epoch
         self.live: Optional[List[torch.nn.Parameter]] = None
+        self._say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
+        # hipStreamEndCapture walks the captured graph recursively (~10^5 nodes in a chain: the default 8 MiB stack overflows,
+        # measured); warm-up + capture therefore run on a thread with a 1 GiB (virtual, lazily committed) stack
+        err: List[BaseException] = []
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                self._capture(optimizer, dev, warmup)
+            except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
+                err.append(e)
+
+        old = threading.stack_size(1 << 30)
+        try:
+            t = threading.Thread(target=work, name="tbx-train-capture")
+            t.start()
+            t.join()
+        finally:
+            threading.stack_size(old)
+        if err:
+            raise err[0]
+        self.grads = [p.grad for p in self.live]  # the graph's static gradient buffers
+        self.metrics = dict(wm.last_metrics)
+
+    def _capture(self, optimizer, dev, warmup: int) -> None:
+        wm, say = self.wm, self._say
         # warm-up on the stream the capture will use (allocator / library workspaces / lazy inits must not happen inside the
         # capture, and autograd's AccumulateGrad nodes must not outlive an iteration on another stream)
-        say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -100,7 +126,6 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, stream=s):
             self._fwd_bwd()  # gradients are allocated from the graph's pool: static addresses, rewritten by every replay
         say("capture done")
-        self.metrics = dict(wm.last_metrics)
 
     @torch.no_grad()
     def _pre(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
@@ -121,6 +146,8 @@ class GraphedTrainStep:
             v.copy_(b[k])
         self._refill()
         self.graph.replay()
+        for p, g in zip(self.live, self.grads):  # a zero_grad(set_to_none=True) elsewhere must not detach the static buffers
+            p.grad = g
         allreduce_gradients(self.live)
         if self.clip and self.clip > 0:
             torch.nn.utils.clip_grad_norm_(self.live, self.clip)

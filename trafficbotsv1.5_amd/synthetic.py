@@ -191,3 +191,13 @@ def make_rule_episode(n_sc: int = 2, n_ag: int = 16, n_mp: int = 64, n_tl: int =
         })
         scenes[-1]["tl/valid"][0] = True
     return {k: torch.stack([s[k] for s in scenes], 0) for k in scenes[0]}
+
+
+def make_filter_case(n_sc: int = 2, n_k: int = 48, n_ag: int = 12, n_step: int = 30, seed: int = 0, p_col: float = 0.02,
+                     p_edge: float = 0.03) -> Dict[str, torch.Tensor]:
+    """Seeded inputs of the WOSAC rollout filter: K joint futures per scene with sparse, accumulated
+    (monotone in time) collision / road-edge flags and random trajectories."""
+    g = torch.Generator().manual_seed(20_000 + seed)
+    first = lambda p: (torch.rand(n_sc, n_k, n_ag, n_step, generator=g) < p / n_step * 4).cummax(-1)[0]
+    return {"pred_pose": torch.randn(n_sc, n_k, n_ag, n_step, 3, generator=g) * 30.0, "collided": first(p_col), "collided_wosac": first(p_col),
+            "run_road_edge": first(p_edge), "ag_role": torch.rand(n_sc, n_ag, 3, generator=g) < 0.3}
