@@ -20,7 +20,12 @@ import time
 from importlib import import_module
 from pathlib import Path
 
-import torch
+# ROCm 7.0 replays hipGraph memset nodes (torch's reduction semaphores) out of order on its AQL-packet fast path: a replay
+# then reads sums of the previous replay (measured, tools/scratch/graph_sum2.py). The captured training step needs the
+# ordered path; the rollout graphs (kernel nodes only) run at the same speed either way. Must be set before HIP initialises.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -1,5 +1,8 @@
+import os
 import sys
 from pathlib import Path
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # ordered hipGraph memset nodes (see pl_modules/data_parallel.py)
 
 import pytest
 

@@ -90,3 +90,44 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir):
     for k, p in wm.model.named_parameters():
         if k in dead:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+
+
+def test_graphed_train_step_equals_eager_across_optimizer_steps(tb):
+    """GraphedTrainStep (fwd + bwd replayed as one hipGraph) vs the eager step: after real AdamW updates between replays the
+    replayed loss / gradients must be those of the CURRENT weights and inputs (a stale replay - see the ROCm caveat in
+    data_parallel.py - passes a same-weights comparison), and two replays of the same inputs must agree."""
+    dev = torch.device("cuda:0")
+    DP = import_module("trafficbots_amd.pl_modules.data_parallel")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    cfg = tb.config.default_model_cfg(n_tgt_knn=4)
+    cfg["tf_cfg"]["dropout_p"] = 0.0
+    cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
+    cfg["add_navi_latent"]["mlp_dropout_p"] = 0.0
+    scfg = tb.config.default_sim_cfg()
+    scfg["teacher_forcing_training"]["prob_forcing_agent"] = 0.0
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    scfg["time_step_end"] = 30
+    torch.manual_seed(0)
+    wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg).to(dev).train()
+    (opt,), _ = wm.configure_optimizers()
+    batches = [{k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=s).items()} for s in (0, 2)]
+    gs = DP.GraphedTrainStep(wm, opt, batches[0], warmup=1)
+    for i in range(3):  # replay + clip + AdamW: the weights move
+        gs(batches[i % 2])
+    gs.opt, gs.clip = torch.optim.SGD(gs.live, lr=0.0), 0
+    m = gs(batches[1])
+    loss_g = float(m["loss"].detach())
+    g1 = [g.clone() for g in gs.grads]
+    gs.graph.replay()
+    torch.cuda.synchronize()
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+    for a, b in zip(g1, gs.grads):
+        assert close(a, b, 1e-4)  # atomics in the attention backward: not bitwise
+    for p in gs.live:
+        p.grad = None
+    loss = wm.training_step({k: v.clone() for k, v in batches[1].items()}, 0, noise=gs.noise, use_prior=gs.use_prior)
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_g) <= 1e-5 * abs(loss_g)
+    names = {id(p): k for k, p in wm.model.named_parameters()}
+    for a, p in zip(g1, gs.live):
+        assert close(a, p.grad, 1e-3), names[id(p)]

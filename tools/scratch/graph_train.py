@@ -64,4 +64,15 @@ if drop0:
     gr = [g.clone() for g in gs.grads]
     print("loss graph (same noise)", float(gs.metrics["loss"].detach()))
     report("graph vs eager", gr, ge1)
+    gs.graph.replay(); torch.cuda.synchronize()
+    gr2 = [g.clone() for g in gs.grads]
+    report("graph vs graph", gr, gr2)
+    bad = []
+    for a, b, p in zip(gr, ge1, gs.live):
+        d = (a - b).abs()
+        if float(d.max()) > 1e-3 * max(1.0, float(b.abs().max())):
+            i = int(d.flatten().argmax())
+            bad.append((names[id(p)], tuple(p.shape), int((d > 1e-3).sum()), float(a.flatten()[i]), float(b.flatten()[i]), float(gr2[len(bad)].flatten()[0]) if False else 0))
+    print("n bad params", len(bad), "of", len(gs.live))
+    for x in bad[:40]: print("   ", x)
 print("mem GB", torch.cuda.max_memory_allocated() / 1e9)

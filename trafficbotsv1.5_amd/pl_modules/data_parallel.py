@@ -8,6 +8,7 @@ Replaces Lightning's `strategy="ddp"` (run.py:50-52) for this path. Differences 
     peers a single large message amortises launch latency best; it is ~1 % of a training step, so it is not overlapped
     with backward (nothing to hide).
 """
+import os
 import threading
 from typing import Dict, Iterable, List, Optional
 
@@ -67,10 +68,18 @@ class GraphedTrainStep:
     torch's graph-safe Philox offsets.
 
     Re-capture when the epoch changes (TeacherForcing's schedules read `current_epoch` on the host).
+
+    ROCm caveat (7.0.x, measured with tools/scratch/graph_sum2.py): on the runtime's AQL-packet fast path hipGraph memset nodes
+    are not ordered with the kernels around them, and torch's multi-block reductions zero their semaphores with one - a
+    replay then returns bias gradients of the PREVIOUS replay. `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` (read when HIP initialises)
+    selects the ordered path at no measurable cost; the constructor refuses to capture without it.
     """
 
     def __init__(self, wm, optimizer: torch.optim.Optimizer, example_batch: Dict[str, Tensor], clip_grad_norm: float = 5.0,
                  warmup: int = 2, verbose: bool = False) -> None:
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            raise RuntimeError("GraphedTrainStep needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before HIP "
+                               "initialises (hipGraph memset nodes replay out of order otherwise: stale gradients)")
         self.wm, self.opt, self.clip = wm, optimizer, clip_grad_norm
         dev = next(wm.model.parameters()).device
         self.static = self._pre(example_batch)  # static input buffers: the re-keyed (sc/*, gt/*, ref/*) batch

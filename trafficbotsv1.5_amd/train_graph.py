@@ -34,12 +34,13 @@ class KnarpeAttnFn(torch.autograd.Function):
         return [Seg(kv, 0, D, m[4], m[0], m[1], m[2], m[5], rel=m[3]) for kv, m in zip(kvs, meta)]
 
     @staticmethod
-    def forward(ctx, q, qt, bias_k, n, S, meta, freqs, *kvs):
-        # kvs: K|V tables [tokens, 256]; freqs = (pose_rpe.pe_xy.freqs, pose_rpe.pe_yaw.freqs) or (None, None)
-        qbuf = torch.cat([q, qt], 1).contiguous()
+    def forward(ctx, qbuf, bias_k, n, S, meta, freqs, *kvs):
+        # qbuf [rows, 640] = q | qt (4 heads x 128); kvs: K|V tables [tokens, 256];
+        # freqs = (pose_rpe.pe_xy.freqs, pose_rpe.pe_yaw.freqs) or (None, None)
+        qbuf = qbuf.contiguous()
         kvs = [kv.contiguous() for kv in kvs]
-        out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=q.device)
-        flag = torch.empty(n * S, dtype=torch.uint8, device=q.device)
+        out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=qbuf.device)
+        flag = torch.empty(n * S, dtype=torch.uint8, device=qbuf.device)
         bias_k = bias_k.contiguous()
         hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), out, flag, *freqs)
         ctx.save_for_backward(qbuf, bias_k, *kvs)
@@ -55,7 +56,7 @@ class KnarpeAttnFn(torch.autograd.Function):
         dkv = [torch.zeros_like(kv) for kv in kvs]
         db = torch.zeros_like(bias_k)
         hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs)
-        return (dq[:, :D], dq[:, D:], db, None, None, None, None, *dkv)
+        return (dq, db, None, None, None, None, *dkv)
 
 
 class Targets:
@@ -69,10 +70,38 @@ class Targets:
         self.cache, self.key = cache, key  # static targets (map tokens): K/V tables computed once per training step
 
 
+# Folded projection weights of the attention modules, valid while the parameters do not change: `training_step` opens a
+# cache for its 90 closed-loop steps (the same weights serve every step), so the folding - and its backward - run once per
+# training step and each attention call is [one GEMM -> tbx_knarpe_attn -> one GEMM]. None = no caching (fold per call).
+_FOLD_CACHE: Optional[dict] = None
+
+
+def fold_attention_weights(attn):
+    """The exact algebra of DESIGN.md §3 as GEMM weights:
+      [q | qt] = x W_in^T + b_in        with  W_in  = [I | B_k]^T W_q           (640 x 128),  b_in  = [I | B_k]^T b_q
+      y        = [sum a v | sum a e] W_out^T + b_out  with  W_out = W_o [I ; B_v]^T (128 x 640), b_out = W_o b_rpe_v + b_o
+    B_k (128 x 512) / B_v (512 x 128): per-head blocks of linear_rpe's key / value halves. Also the K|V slice of in_proj."""
+    if _FOLD_CACHE is not None and id(attn) in _FOLD_CACHE:
+        return _FOLD_CACHE[id(attn)]
+    W, b = attn.in_proj_weight, attn.in_proj_bias
+    wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
+    eye = torch.eye(D, dtype=W.dtype, device=W.device)
+    bk = torch.block_diag(*[wr[h * DH:(h + 1) * DH] for h in range(NH)])              # [128, 512]
+    bv_t = torch.block_diag(*[wr[D + h * DH:D + (h + 1) * DH] for h in range(NH)])    # [128, 512] = B_v^T
+    sel_in = torch.cat([eye, bk], 1)                                                   # [128, 640]
+    sel_out = torch.cat([eye, bv_t], 1)                                                # [128, 640]
+    f = dict(w_in=sel_in.t() @ W[:D], b_in=sel_in.t() @ b[:D], w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
+             w_out=attn.out_proj_weight @ sel_out, b_out=attn.out_proj_weight @ br[D:] + attn.out_proj_bias)
+    if _FOLD_CACHE is not None:
+        _FOLD_CACHE[id(attn)] = f
+    return f
+
+
 def kv_table(attn, norm, t: Targets) -> Tensor:
     """K|V table [tokens, 256] of a target set for one attention layer (LayerNorm + projection, before the gather)."""
+    f = fold_attention_weights(attn)
     make = lambda: F.linear(F.layer_norm(t.tokens, (D,), norm.weight, norm.bias, norm.eps) if norm is not None else t.tokens,
-                            attn.in_proj_weight[D:], attn.in_proj_bias[D:])
+                            f["w_kv"], f["b_kv"])
     if t.cache is None or t.key is None:
         return make()
     k = (t.key, id(attn))
@@ -83,17 +112,12 @@ def kv_table(attn, norm, t: Targets) -> Tensor:
 
 def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor], n: int, S: int) -> Tensor:
     """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source."""
-    W, b = attn.in_proj_weight, attn.in_proj_bias
-    wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
-    rows = xq.shape[0]
-    q = F.linear(xq, W[:D], b[:D])
-    qt = torch.einsum("rhj,hjc->rhc", q.view(rows, NH, DH), wr[:D].view(NH, DH, D)).reshape(rows, NH * D)
+    f = fold_attention_weights(attn)
+    qbuf = F.linear(xq, f["w_in"], f["b_in"])
     meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div) for t in targets]
     freqs = next((t.freqs for t in targets if t.rel is not None), (None, None))
-    out, flag = KnarpeAttnFn.apply(q, qt, br[:D], n, S, meta, freqs, *kvs)
-    o = out[:, :D] + (torch.einsum("rhc,hjc->rhj", out[:, D:].reshape(rows, NH, D), wr[D:].view(NH, DH, D))
-                      + br[D:].view(NH, DH)).reshape(rows, D)
-    y = F.linear(o, attn.out_proj_weight, attn.out_proj_bias)
+    out, flag = KnarpeAttnFn.apply(qbuf, f["bias_k"], n, S, meta, freqs, *kvs)
+    y = F.linear(out, f["w_out"], f["b_out"])
     return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
 
 
@@ -439,6 +463,15 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
     """waymo_motion.py:313-385. `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
     inputs of a step as device tensors: a captured step (pl_modules/data_parallel.GraphedTrainStep) refills them before
     every replay; left None they are drawn here from the CPU generator like the reference's CPU path does."""
+    global _FOLD_CACHE
+    _FOLD_CACHE = {}
+    try:
+        return _training_step(wm, raw_batch, noise, use_prior)
+    finally:
+        _FOLD_CACHE = None
+
+
+def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
     model, hp = wm.model, wm.hp
     tr = model.training
     if "sc/mp_valid" in raw_batch:  # already re-keyed (a captured step pre-processes eagerly: its index tensors come from the host)
