@@ -109,7 +109,13 @@ def test_mlp_input_pointnet(tb, hip, dev):
         xp = torch.randn(2, 5, n_node, 128, generator=g)
         ip = torch.rand(2, 5, n_node, generator=g) < 0.4
         ip[0, 0] = True
-        torch.testing.assert_close(m(xp.to(dev), ip.to(dev)).cpu(), H.pointnet(P, "pn", xp, ip, 3), **TOL)
+        y16 = m(xp.to(dev), ip.to(dev))
+        torch.testing.assert_close(y16.cpu(), H.pointnet(P, "pn", xp, ip, 3), **TOL)
+        # 32-row tiles hold floor(32 / n_node) whole polylines (10 polylines: the last tile is partial); same rows, same
+        # arithmetic per row -> bit-identical
+        m.tile_rows = 32
+        assert torch.equal(m(xp.to(dev), ip.to(dev)), y16), n_node
+        m.tile_rows = None
 
 
 def _attn_inputs(g, n=2, S=9, K=11, d=128, Ks=5):

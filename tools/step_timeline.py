@@ -9,7 +9,7 @@ t = lambda stem: next(x for x in tabs if x.startswith(stem))
 kd, ks = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
 rows = db.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.workgroup_size_x from {kd} d join {ks} s "
                   f"on d.kernel_id=s.id order by d.start").fetchall()
-idx = [i for i, r in enumerate(rows) if "sim_bump" in r[0]]
+idx = [i for i, r in enumerate(rows) if "sim_step_kernel" in r[0]]  # one per step in the one-stream order (--no-lights-ahead)
 a, b = idx[-3], idx[-2]
 step = rows[a + 1:b + 1]
 t0, tot, agg = step[0][1], 0, {}

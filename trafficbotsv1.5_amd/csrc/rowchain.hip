@@ -72,7 +72,9 @@ struct Tile {
   }
   int64_t g0;      // first global row of the tile
   int n_valid;     // rows r < n_valid map to a global row
-  int64_t group;   // group index (grouped mode) or tile index
+  int64_t group;   // index of the tile's first group (grouped mode) or tile index
+  int gw, ng;      // grouped mode: rows per group and groups in this tile (rows [j*gw, (j+1)*gw) = group `group + j`);
+                   // flat mode: gw = ROWS, ng = 1
 };
 
 __device__ __forceinline__ int64_t row_of(const tbx_stage_t& s, int64_t g) {
@@ -486,10 +488,21 @@ __device__ void op_groupmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
-  for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
+  if (t.ng == 1) {
+    for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
+      float m = -INFINITY;
+      for (int r = 0; r < ROWS; ++r) m = fmaxf(m, src[r * lds_s + c]);
+      for (int r = 0; r < ROWS; ++r) dst[r * lds_d + c] = m;
+    }
+    return;
+  }
+  // several groups in the tile: one (group, column) per thread; padding rows past the last group are left alone (their
+  // content is never read across rows and the program masks them)
+  for (int e = threadIdx.x; e < s.n * t.ng; e += blockDim.x) {
+    const int j = e / s.n, c = e - j * s.n;
     float m = -INFINITY;
-    for (int r = 0; r < ROWS; ++r) m = fmaxf(m, src[r * lds_s + c]);
-    for (int r = 0; r < ROWS; ++r) dst[r * lds_d + c] = m;
+    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r) m = fmaxf(m, src[r * lds_s + c]);
+    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r) dst[r * lds_d + c] = m;
   }
 }
 
@@ -499,15 +512,17 @@ __device__ void op_poolmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int lds_s = t.l(s.src);
   const uint8_t* mask = (const uint8_t*)s.p1;
   float* out = (float*)s.p0;
-  for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
+  for (int e = threadIdx.x; e < s.n * t.ng; e += blockDim.x) {
+    const int j = e / s.n, c = e - j * s.n;
+    const int r0 = t.ng == 1 ? 0 : j * t.gw, r1 = t.ng == 1 ? t.n_valid : (j + 1) * t.gw;
     float m = -INFINITY;
     bool any = false;
-    for (int r = 0; r < t.n_valid; ++r) {
+    for (int r = r0; r < r1; ++r) {
       if (mask != nullptr && gld1(mask + t.g0 + r) != 0) continue;
       any = true;
       m = fmaxf(m, src[r * lds_s + c]);
     }
-    gst1(out + t.group * (int64_t)s.ld + s.dst_col + c, any ? m : 0.f);
+    gst1(out + (t.group + j) * (int64_t)s.ld + s.dst_col + c, any ? m : 0.f);
   }
 }
 
@@ -567,9 +582,19 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   t.ldw1 = a.ldw1;
   t.ld_aux = a.ld_aux;
   t.group = blockIdx.x;
+  t.gw = ROWS;
+  t.ng = 1;
   if (a.group_rows > 0) {
-    t.g0 = (int64_t)blockIdx.x * a.group_rows;
-    t.n_valid = a.group_rows;
+    // as many whole groups as fit the tile (consecutive groups are consecutive rows): the per-stage fixed costs (weight
+    // stream, barriers, decode) are shared by all of them
+    const int per = ROWS / a.group_rows;
+    const int64_t n_groups = a.n_rows / a.group_rows;
+    t.group = (int64_t)blockIdx.x * per;
+    const int64_t left = n_groups - t.group;
+    t.gw = a.group_rows;
+    t.ng = left < per ? (int)left : per;
+    t.g0 = t.group * a.group_rows;
+    t.n_valid = t.ng * a.group_rows;
   } else {
     t.g0 = (int64_t)blockIdx.x * ROWS;
     const int64_t left = a.n_rows - t.g0;
@@ -763,7 +788,8 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   a.ldw1 = ldw1;
   a.ld_aux = ld_aux;
   a.n_rows = n_rows;
-  const int64_t n_tiles = group_rows > 0 ? n_rows / group_rows : (n_rows + tile_rows - 1) / tile_rows;
+  const int per_tile = group_rows > 0 ? tile_rows / group_rows : 1;  // whole groups per tile
+  const int64_t n_tiles = group_rows > 0 ? (n_rows / group_rows + per_tile - 1) / per_tile : (n_rows + tile_rows - 1) / tile_rows;
   hipStream_t s = (hipStream_t)stream;
   bool ext = !(ldw0 == ldw1 && ld_aux == TBX_AUX_LD);
   for (int i = 0; i < n_stages; ++i) ext = ext || (stages[i].op == TBX_OP_LINEAR && stages[i].dst == TBX_BUF_GLOBAL);

@@ -98,7 +98,7 @@ class AgentEncoder(nn.Module):
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
                     _knn_at=(i_at, m_at, r_at))
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
-        ch = Chain(16 if W <= 16 else 32, d + 4)
+        ch = Chain(hip.group_tile_rows(W, n * A), d + 4)
         cur = self.input_encoder.emit(ch, prep["attr"], prep["pe"])
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
         ch.run(n * A * W, group_rows=W)

@@ -15,6 +15,7 @@ class PolylineEncoder(nn.Module):
             raise NotImplementedError("the MI355X path implements the default PointNet / max_valid polyline encoder")
         self.use_pointnet, self.pooling_mode, self.hidden_dim = use_pointnet, pooling_mode, hidden_dim
         self.mlp_dropout_p = mlp_dropout_p
+        self.tile_rows = None  # None: one group per tile (16 / 32 rows by n_node); 32: floor(32 / n_node) groups per tile
         self.mlp_layers = nn.ModuleList([MLP([hidden_dim, hidden_dim // 2], dropout_p=mlp_dropout_p) for _ in range(n_layer)])
 
     def forward(self, x: Tensor, invalid: Tensor) -> Tensor:
@@ -25,7 +26,7 @@ class PolylineEncoder(nn.Module):
         x2 = x.reshape(-1, d).contiguous().float()
         inv = invalid.reshape(-1).to(torch.uint8).contiguous()
         out = torch.empty(n_sc * n_mp, d, dtype=torch.float32, device=x.device)
-        ch = Chain(16 if n_node <= 16 else 32, d + 4)
+        ch = Chain(self.tile_rows or (16 if n_node <= 16 else 32), d + 4)
         ch.load(x2, BUF1, 0, n=d)
         emit_pointnet(ch, self, inv, out)
         ch.run(x2.shape[0], group_rows=n_node)

@@ -102,7 +102,7 @@ class NaviPredictor(nn.Module):
         hip.agent_prep(hv, hp, hm, ag_attr.float().contiguous(), None, self.pose_emb.pe_xy.freqs, self.pose_emb.pe_yaw.freqs,
                        self.pose_emb.out_dim, prep)
         feat = torch.empty(n * A, d, dtype=f32, device=dev)
-        ch = Chain(16 if W <= 16 else 32, d + 4)
+        ch = Chain(hip.group_tile_rows(W, n * A), d + 4)
         cur = self.input_encoder.emit(ch, prep["attr"], prep["pe"])
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], feat, x_buf=cur)
         ch.run(n * A * W, group_rows=W)

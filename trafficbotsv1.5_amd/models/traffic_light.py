@@ -83,7 +83,7 @@ class TrafficLightEncoder(nn.Module):
         row_inv = torch.empty(rows, dtype=torch.uint8, device=dev)
         hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
         x = torch.empty(n * L, d, dtype=torch.float32, device=dev)
-        ch = Chain(16 if W <= 16 else 32, d + 4)
+        ch = Chain(hip.group_tile_rows(W, n * L), d + 4)
         cur = self.input_encoder.emit(ch, attr, t["tl_token_attr"].reshape(n * L, d), pe_row_div=W)
         emit_pointnet(ch, self.temp_encoder, row_inv, x, x_buf=cur)
         ch.run(rows, group_rows=W)

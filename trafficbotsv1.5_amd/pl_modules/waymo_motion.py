@@ -105,10 +105,12 @@ class WaymoMotion(LightningModule):
         self._engine = eng
         return eng.buffer(self.hp.time_step_current, rule_checker=rule_checker)
 
-    def _rule_checker(self, batch, ag_dest, tl_tokens):
+    def _rule_checker(self, batch, ag_dest, tl_tokens, n_rollout: int = 1):
+        """waymo_motion.py:399-412,497-510. Agent tensors per rollout, map tensors per scene (shared by its rollouts)."""
+        r = (lambda t: t.repeat_interleave(n_rollout, 0)) if n_rollout > 1 else (lambda t: t)
         return TrafficRuleChecker(mp_boundary=batch["map/boundary"], mp_valid=batch["map/valid"], mp_type=batch["map/type"],
-                                  mp_pos=batch["map/pos"], mp_dir=batch["map/dir"], ag_type=batch["ref/ag_type"],
-                                  ag_size=batch["ref/ag_size"], ag_goal=None, ag_dest=ag_dest,
+                                  mp_pos=batch["map/pos"], mp_dir=batch["map/dir"], ag_type=r(batch["ref/ag_type"]),
+                                  ag_size=r(batch["ref/ag_size"]), ag_goal=None, ag_dest=ag_dest,
                                   tl_valid=tl_tokens["tl_token_valid"], tl_pose=tl_tokens["tl_token_pose"],
                                   disable_check=self.training)
 
@@ -148,7 +150,7 @@ class WaymoMotion(LightningModule):
         ag_navi_dist.repeat_interleave_(K, 0)
         ag_tokens["ag_navi"] = ag_navi_dist.sample(det)
         ag_tokens["ag_navi_valid"] = ag_navi_dist.valid
-        checker = self._rule_checker(batch, ag_tokens["ag_navi"], tl_tokens)
+        checker = self._rule_checker(batch, ag_tokens["ag_navi"], tl_tokens, n_rollout=K)
         buf = self.rollout(ag_tokens, mp_tokens, tl_tokens, r(batch["sc/tl_state"]), teacher_forcing, checker,
                            step_end or self.hp.time_step_end, True, use_graph=use_graph)
         buf.flatten_joint_future(K)
