@@ -100,6 +100,21 @@ int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const
                         float* const* dkv /* host array of n_seg device pointers */, float* dbias_k,
                         const float* freqs_xy, const float* freqs_yaw, void* stream);
 
+/* The same pair with attention-probability dropout (training; modules/attention_rpe.py:171-172: dropout on the softmax
+ * output, scaled by 1 / (1 - p)). The mask bit of (row, target slot, head) is a counter-based hash of the 64-bit seed at
+ * *drop_seed (DEVICE memory, read by the kernels) and of drop_call (distinguishes the calls of one training step), so
+ * the backward regenerates the forward's mask from the same (seed, call) and a captured graph draws fresh masks when the
+ * host rewrites the seed between replays. p_drop = 0 is exactly tbx_knarpe_attn_fwd / _bwd (drop_seed may be NULL). */
+int tbx_knarpe_attn_fwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo,
+                                uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                const uint64_t* drop_seed /* device */, uint32_t drop_call, void* stream);
+int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo,
+                                float* dqbuf, float* const* dkv /* host array of n_seg device pointers */, float* dbias_k,
+                                const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                const uint64_t* drop_seed /* device */, uint32_t drop_call, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
  * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per

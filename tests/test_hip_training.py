@@ -131,3 +131,63 @@ def test_graphed_train_step_equals_eager_across_optimizer_steps(tb):
     names = {id(p): k for k, p in wm.model.named_parameters()}
     for a, p in zip(g1, gs.live):
         assert close(a, p.grad, 1e-3), names[id(p)]
+
+
+def test_attention_probability_dropout_vs_explicit_mask(tb):
+    """tbx_knarpe_attn_fwd_dropout / _bwd_dropout (attention_rpe.py:171-172 inside the kernels) against explicit torch math with
+    the mask the (seed, call) pair produces (hip.dropout_keep_mask restates the kernels' counter hash): forward outputs and
+    every gradient; two target segments so that the second segment's slots continue the first's."""
+    dev = torch.device("cuda:0")
+    hip = import_module("trafficbots_amd.hip")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(9)
+    n, S, T1, T2, K1, K2, p, call = 2, 19, 23, 11, 7, 5, 0.25, 3
+    rows = n * S
+    qbuf = torch.randn(rows, 640, generator=g)
+    bias_k = torch.randn(128, generator=g)
+    kvs = [torch.randn(n * T1, 256, generator=g), torch.randn(n * T2, 256, generator=g)]
+    idx = [torch.randint(0, T1, (n, S, K1), generator=g), torch.randint(0, T2, (n, S, K2), generator=g)]
+    inv = [torch.rand(n, S, K1, generator=g) < 0.3, torch.rand(n, S, K2, generator=g) < 0.3]
+    inv[0][0, 2] = True
+    inv[1][0, 2] = True  # a row without any valid target
+    emb = [torch.randn(n, S, K1, 128, generator=g), torch.randn(n, S, K2, 128, generator=g)]
+    w_out = torch.randn(rows, 640, generator=g)
+    seed = torch.tensor([0x1234_5678_9ABC_DEF1], dtype=torch.int64)
+    keep = hip.dropout_keep_mask(int(seed[0]), call, rows, K1 + K2, p).float()  # [rows, 4, K]
+    assert 0.6 < float(keep.mean()) < 0.9
+
+    def reference(qbuf, bias_k, kv1, kv2):
+        q, qt = qbuf[:, :128].view(rows, 4, 32), qbuf[:, 128:].view(rows, 4, 128)
+        ks, vs, es, ms = [], [], [], []
+        for kv, ix, iv, e, T in ((kv1, idx[0], inv[0], emb[0], T1), (kv2, idx[1], inv[1], emb[1], T2)):
+            flat = (torch.arange(n)[:, None, None] * T + ix).reshape(rows, -1)
+            ks.append(kv[flat][..., :128].view(rows, -1, 4, 32))
+            vs.append(kv[flat][..., 128:].view(rows, -1, 4, 32))
+            es.append(e.reshape(rows, -1, 128))
+            ms.append(iv.reshape(rows, -1))
+        k, v, e, m = torch.cat(ks, 1), torch.cat(vs, 1), torch.cat(es, 1), torch.cat(ms, 1)
+        sc = (torch.einsum("rhc,rthc->rht", q, k) + torch.einsum("rhc,rtc->rht", qt, e)
+              + torch.einsum("rhc,hc->rh", q, bias_k.view(4, 32)).unsqueeze(-1)) / 32 ** 0.5
+        dead = m.all(-1)
+        sc = sc.masked_fill((m & ~dead[:, None]).unsqueeze(1), float("-inf"))
+        a = torch.softmax(sc, -1) * keep / (1 - p)
+        out = torch.cat([torch.einsum("rht,rthc->rhc", a, v).reshape(rows, 128), torch.einsum("rht,rtc->rhc", a, e).reshape(rows, 512)], 1)
+        return out.masked_fill(dead[:, None], 0.0), dead
+
+    leaves_c = [t.clone().requires_grad_(True) for t in (qbuf, bias_k, *kvs)]
+    out_c, dead = reference(*leaves_c)
+    (out_c * w_out).sum().backward()
+    leaves_h = [t.clone().to(dev).requires_grad_(True) for t in (qbuf, bias_k, *kvs)]
+    meta = [(idx[i].to(torch.int32).to(dev).contiguous(), inv[i].to(torch.uint8).to(dev).contiguous(), emb[i].to(dev).contiguous(), None,
+             (T1, T2)[i], 1) for i in range(2)]
+    out_h, flag = TG.KnarpeAttnFn.apply(leaves_h[0], leaves_h[1], n, S, meta, (None, None), (p, seed.to(dev), call), *leaves_h[2:])
+    assert torch.equal(flag.bool().cpu(), dead)
+    out_h = out_h.masked_fill(flag.bool().unsqueeze(-1), 0.0)
+    (out_h * w_out.to(dev)).sum().backward()
+    torch.testing.assert_close(out_h.detach().cpu(), out_c.detach(), rtol=2e-4, atol=2e-5)
+    for a, b in zip(leaves_h, leaves_c):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4)
+    # p = 0 through the same entry points is the plain kernel pair
+    o0, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), None, *[t.detach() for t in leaves_h[2:]])
+    o1, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), (0.0, None, 0), *[t.detach() for t in leaves_h[2:]])
+    assert torch.equal(o0, o1)

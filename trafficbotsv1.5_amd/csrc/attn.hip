@@ -34,6 +34,12 @@ struct AttnArgs {
   int ldq, q_off, qt_off, ldo, n_rows, n_src, n_seg;
   float scale;   // 1 / sqrt(d_head)
   float scale2;  // log2(e) / sqrt(d_head): the forward's softmax runs in base 2
+  // attention-probability dropout (training, attention_rpe.py:171-172): keep(row, t, head) is a counter-based hash of the
+  // 64-bit seed read from device memory, so the backward regenerates the forward's mask and a captured graph draws a new
+  // mask per replay (the host refills *drop_seed between replays)
+  const uint64_t* drop_seed;
+  uint32_t drop_call, drop_thresh;  // call id mixed into the seed; drop when hash < thresh = p * 2^32
+  float drop_scale;                 // 1 / (1 - p)
 };
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -101,6 +107,27 @@ __device__ __forceinline__ void sincos_rev(float arg, float* sn, float* cs) {
   *cs = __builtin_amdgcn_cosf(f);
 }
 
+// Dropout mask bit of (row, global target slot t < 128, head): lowbias32 finaliser over a counter keyed by the seed.
+struct DropKey {
+  uint32_t lo, hi;
+  __device__ __forceinline__ void init(const AttnArgs& a) {
+    const uint64_t sd = *a.drop_seed;
+    lo = (uint32_t)sd ^ (a.drop_call * 0x85EBCA6Bu);
+    hi = (uint32_t)(sd >> 32) + a.drop_call * 0xC2B2AE35u;
+  }
+  __device__ __forceinline__ bool keep(uint32_t row, uint32_t t, uint32_t h, uint32_t thresh) const {
+    uint32_t x = ((row * 128u + t) * 4u + h) ^ lo;
+    x *= 0x9E3779B1u;
+    x ^= hi;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >= thresh;
+  }
+};
+
 // The lane's frequencies for rebuilding its embedding slice from a relative pose.
 struct EFreq {
   float fx[2], fw[4];
@@ -143,7 +170,7 @@ __device__ __forceinline__ void load_e(const tbx_attn_seg_t& S, int64_t pi, int 
 // rescaled when the slot's running max grows. The 8 slots (and the WPR waves) are merged once per row:
 //   out = sum_slots exp(m_slot - M) acc_slot / sum_slots exp(m_slot - M) l_slot.
 // No LDS traffic and no barrier inside the target loop.
-template <int WPR>
+template <int WPR, bool DROP>
 __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
@@ -189,7 +216,10 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   // VALU-issue bound (~70 wave instructions per pair), so it is kept straight-line: slots past the segment's K re-read its
   // last pair (finite data) and, like masked targets, enter the online softmax with probability exactly 0 and a rescale
   // factor of exactly 1 - no per-lane branches, no zero fills, no per-lane segment selects.
-  for (int sg = 0; sg < a.n_seg; ++sg) {
+  DropKey dk;
+  if constexpr (DROP) dk.init(a);
+  int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
+  for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
     const float* kvb = S.kv + (int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv;
     const int64_t pbase = (int64_t)row * S.k;
@@ -216,12 +246,14 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         const float m_new = ok ? fmaxf(m_old, sc) : m_old;
         const float alpha = (m_new == m_old) ? 1.f : __builtin_amdgcn_exp2f(m_old - m_new);  // 0 on the slot's first valid target
         const float pr = ok ? __builtin_amdgcn_exp2f(sc - m_new) : 0.f;
-        l_run[h] = l_run[h] * alpha + pr;
+        l_run[h] = l_run[h] * alpha + pr;  // the normaliser is that of the un-dropped softmax
         m_run[h] = m_new;
+        float pd = pr;
+        if constexpr (DROP) pd = dk.keep((uint32_t)row, (uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
         scale4(oacc[h], alpha);  // K/V channel block st == h belongs to head h
-        fma4(oacc[h], pr, v[h]);
+        fma4(oacc[h], pd, v[h]);
         eacc[h].scale(alpha);
-        eacc[h].fma(pr, e);
+        eacc[h].fma(pd, e);
       }
     }
   }
@@ -319,12 +351,17 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   const AttnArgs& a = b.f;
   __shared__ float p_s[4][NH][KMAX];  // probabilities a[h,t]
   __shared__ float d_s[4][NH][KMAX];  // da[h,t], then dS[h,t]
+  __shared__ float k_s[4][NH][KMAX];  // dropout factor m / (1 - p) of (h, t); 1 without dropout
   __shared__ uint8_t inv_s[4][KMAX];
   const int lane = threadIdx.x & 63;
   const int rib = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + rib;
   if (row >= a.n_rows) return;
   const int bidx = row / a.n_src;
+  const bool drop = a.drop_thresh != 0u;
+  DropKey dkey;
+  dkey.lo = dkey.hi = 0u;
+  if (drop) dkey.init(a);
   const int k0 = a.seg[0].k;
   const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
   const int s8 = lane & 7, tg = lane >> 3;
@@ -435,7 +472,13 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
       for (int h = 0; h < NH; ++h) acc[h] = tbx::group8_sum(acc[h]);
       if (active && s8 == 0) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) d_s[rib][h][t] = acc[h];
+        for (int h = 0; h < NH; ++h) {
+          // out = sum_t a_t m_t / (1 - p) (v_t | e_t): the mask factor multiplies d(a_t); kept in k_s for the dV weights
+          float kf = 1.f;
+          if (drop) kf = dkey.keep((uint32_t)row, (uint32_t)t, (uint32_t)h, a.drop_thresh) ? a.drop_scale : 0.f;
+          k_s[rib][h][t] = kf;
+          d_s[rib][h][t] = acc[h] * kf;
+        }
       }
     }
   }
@@ -481,7 +524,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       ds[h] = d_s[rib][h][t];
-      pa[h] = p_s[rib][h][t];
+      pa[h] = p_s[rib][h][t] * k_s[rib][h][t];  // weight of v_t in the output (dropped probability)
       any = any || ds[h] != 0.f || pa[h] != 0.f;
     }
     if (!any) continue;
@@ -560,31 +603,71 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
 
 }  // namespace
 
-extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
-                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
-                                   uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, void* stream) {
+namespace {
+int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t drop_call) {
+  a.drop_seed = drop_seed;
+  a.drop_call = drop_call;
+  a.drop_thresh = 0u;
+  a.drop_scale = 1.f;
+  if (p_drop < 0.f || p_drop >= 1.f) return TBX_ERR_ARG;
+  if (p_drop > 0.f) {
+    if (!drop_seed) return TBX_ERR_ARG;
+    const double th = (double)p_drop * 4294967296.0;
+    a.drop_thresh = th < 1.0 ? 1u : (uint32_t)th;
+    a.drop_scale = 1.0f / (1.0f - p_drop);
+  }
+  return TBX_OK;
+}
+}  // namespace
+
+extern "C" int tbx_knarpe_attn_fwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
+                                           uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                           const uint64_t* drop_seed, uint32_t drop_call, void* stream) {
   if (!out || !row_no_valid) return TBX_ERR_ARG;
   if (((uintptr_t)out) & 15) return TBX_ERR_ALIGN;
   AttnArgs a;
-  const int rc = fill_args(a, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  int rc = fill_args(a, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  rc = set_dropout(a, p_drop, drop_seed, drop_call);
   if (rc != TBX_OK) return rc;
   a.out = out;
   a.row_no_valid = row_no_valid;
-  if (a.n_rows >= 4096)
-    hipLaunchKernelGGL(knarpe_attn_kernel<1>, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(knarpe_attn_kernel<4>, dim3(a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
+  const bool big = a.n_rows >= 4096;
+  const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
+  hipStream_t hs = (hipStream_t)stream;
+  if (a.drop_thresh != 0u) {
+    if (big)
+      hipLaunchKernelGGL((knarpe_attn_kernel<1, true>), grid, block, 0, hs, a);
+    else
+      hipLaunchKernelGGL((knarpe_attn_kernel<4, true>), grid, block, 0, hs, a);
+  } else {
+    if (big)
+      hipLaunchKernelGGL((knarpe_attn_kernel<1, false>), grid, block, 0, hs, a);
+    else
+      hipLaunchKernelGGL((knarpe_attn_kernel<4, false>), grid, block, 0, hs, a);
+  }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
-extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
-                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
-                                   float* const* dkv, float* dbias_k, const float* freqs_xy, const float* freqs_yaw,
-                                   void* stream) {
+extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
+                                   uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, void* stream) {
+  return tbx_knarpe_attn_fwd_dropout(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid,
+                                     freqs_xy, freqs_yaw, 0.f, nullptr, 0u, stream);
+}
+
+extern "C" int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                           int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                           const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                           void* stream) {
   if (!dout || !dqbuf || !dkv || !dbias_k) return TBX_ERR_ARG;
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
   AttnBwdArgs b;
-  const int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  rc = set_dropout(b.f, p_drop, drop_seed, drop_call);
   if (rc != TBX_OK) return rc;
   for (int i = 0; i < n_seg; ++i) {
     if (!dkv[i]) return TBX_ERR_ARG;
@@ -596,4 +679,12 @@ extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt
   b.dbias_k = dbias_k;
   hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
+                                   float* const* dkv, float* dbias_k, const float* freqs_xy, const float* freqs_yaw,
+                                   void* stream) {
+  return tbx_knarpe_attn_bwd_dropout(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, dout, ldo, dqbuf, dkv,
+                                     dbias_k, freqs_xy, freqs_yaw, 0.f, nullptr, 0u, stream);
 }

@@ -86,6 +86,10 @@ def load():
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
+    lib.tbx_knarpe_attn_fwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp,
+                                                f32, vp, C.c_uint32, vp]
+    lib.tbx_knarpe_attn_bwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
+                                                C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, vp]
     lib.tbx_pack_weight_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_size.restype = C.c_int64
     lib.tbx_pack_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -101,7 +105,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -186,23 +190,53 @@ class Seg:
 
 
 def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid,
-                freqs_xy=None, freqs_yaw=None):
+                freqs_xy=None, freqs_yaw=None, drop=None):
+    """drop = None, or (p, seed int64[1] device tensor, call id): attention-probability dropout (training)."""
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
-    rc = load().tbx_knarpe_attn_fwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
-                                    n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
-                                    _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy), _cptr(freqs_yaw), stream_ptr())
+    p, seed, call = drop if drop is not None else (0.0, None, 0)
+    rc = load().tbx_knarpe_attn_fwd_dropout(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+                                            n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
+                                            _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy), _cptr(freqs_yaw), float(p),
+                                            _ptr(seed, torch.int64), int(call), stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd")
 
 
 def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
-                    dkv: Sequence[torch.Tensor], dbias_k, freqs_xy=None, freqs_yaw=None):
+                    dkv: Sequence[torch.Tensor], dbias_k, freqs_xy=None, freqs_yaw=None, drop=None):
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
     dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
-    rc = load().tbx_knarpe_attn_bwd(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
-                                    n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
-                                    _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy), _cptr(freqs_yaw),
-                                    stream_ptr())
+    p, seed, call = drop if drop is not None else (0.0, None, 0)
+    rc = load().tbx_knarpe_attn_bwd_dropout(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+                                            n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
+                                            _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy),
+                                            _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd")
+
+
+def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n_head: int = 4) -> torch.Tensor:
+    """Host restatement of the kernels' counter-based mask (csrc/attn.hip DropKey): bool [n_rows, n_head, k_tot] - for tests
+    and for anyone who needs the mask a (seed, call) pair produces."""
+    import numpy as np
+
+    sd = np.uint64(seed % (1 << 64))
+    m32 = np.uint64(0xFFFFFFFF)
+    lo = np.uint32(sd & m32) ^ np.uint32((call * 0x85EBCA6B) & 0xFFFFFFFF)
+    hi = np.uint32((int((sd >> np.uint64(32)) & m32) + call * 0xC2B2AE35) & 0xFFFFFFFF)
+    row = np.arange(n_rows, dtype=np.uint32)[:, None, None]
+    h = np.arange(n_head, dtype=np.uint32)[None, :, None]
+    t = np.arange(k_tot, dtype=np.uint32)[None, None, :]
+    with np.errstate(over="ignore"):
+        x = ((row * np.uint32(128) + t) * np.uint32(4) + h) ^ lo
+        x = x * np.uint32(0x9E3779B1)
+        x = x ^ hi
+        x = x ^ (x >> np.uint32(16))
+        x = x * np.uint32(0x7FEB352D)
+        x = x ^ (x >> np.uint32(15))
+        x = x * np.uint32(0x846CA68B)
+        x = x ^ (x >> np.uint32(16))
+    th = p * 4294967296.0
+    th = np.uint32(1 if 0 < th < 1 else int(th))
+    return torch.from_numpy(x >= th)
 
 
 def agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,

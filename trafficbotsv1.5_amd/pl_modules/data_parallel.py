@@ -86,6 +86,7 @@ class GraphedTrainStep:
         n, A = example_batch["agent/valid"].shape[:2]
         self.noise = torch.zeros(n, A, wm.model.latent_encoder.out_dim, device=dev)
         self.use_prior = torch.zeros((), dtype=torch.bool, device=dev)
+        wm.attn_dropout_seed = self.drop_seed = torch.zeros(1, dtype=torch.int64, device=dev)  # static: the graph reads it
         self.epoch = wm.current_epoch
         self.live: Optional[List[torch.nn.Parameter]] = None
         self._say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
@@ -147,6 +148,7 @@ class GraphedTrainStep:
     def _refill(self) -> None:
         self.noise.copy_(torch.randn(self.noise.shape), non_blocking=False)  # CPU generator, as the reference's CPU path
         self.use_prior.fill_(bool(torch.rand(1) < self.wm.hp.p_training_rollout_prior))
+        self.drop_seed.random_()  # new attention-dropout masks for this replay
 
     def __call__(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         assert self.wm.current_epoch == self.epoch, "re-capture the step after an epoch change"

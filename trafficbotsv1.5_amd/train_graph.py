@@ -34,17 +34,18 @@ class KnarpeAttnFn(torch.autograd.Function):
         return [Seg(kv, 0, D, m[4], m[0], m[1], m[2], m[5], rel=m[3]) for kv, m in zip(kvs, meta)]
 
     @staticmethod
-    def forward(ctx, qbuf, bias_k, n, S, meta, freqs, *kvs):
+    def forward(ctx, qbuf, bias_k, n, S, meta, freqs, drop, *kvs):
         # qbuf [rows, 640] = q | qt (4 heads x 128); kvs: K|V tables [tokens, 256];
-        # freqs = (pose_rpe.pe_xy.freqs, pose_rpe.pe_yaw.freqs) or (None, None)
+        # freqs = (pose_rpe.pe_xy.freqs, pose_rpe.pe_yaw.freqs) or (None, None);
+        # drop = None or (p, seed tensor, call id): dropout on the attention probabilities (attention_rpe.py:171-172)
         qbuf = qbuf.contiguous()
         kvs = [kv.contiguous() for kv in kvs]
         out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=qbuf.device)
         flag = torch.empty(n * S, dtype=torch.uint8, device=qbuf.device)
         bias_k = bias_k.contiguous()
-        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), out, flag, *freqs)
+        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), out, flag, *freqs, drop=drop)
         ctx.save_for_backward(qbuf, bias_k, *kvs)
-        ctx.meta, ctx.n, ctx.S, ctx.freqs = meta, n, S, freqs
+        ctx.meta, ctx.n, ctx.S, ctx.freqs, ctx.drop = meta, n, S, freqs, drop
         ctx.mark_non_differentiable(flag)
         return out, flag
 
@@ -55,8 +56,9 @@ class KnarpeAttnFn(torch.autograd.Function):
         dq = torch.empty_like(qbuf)
         dkv = [torch.zeros_like(kv) for kv in kvs]
         db = torch.zeros_like(bias_k)
-        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs)
-        return (dq, db, None, None, None, None, *dkv)
+        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs,
+                            drop=ctx.drop)
+        return (dq, db, None, None, None, None, None, *dkv)
 
 
 class Targets:
@@ -74,6 +76,9 @@ class Targets:
 # cache for its 90 closed-loop steps (the same weights serve every step), so the folding - and its backward - run once per
 # training step and each attention call is [one GEMM -> tbx_knarpe_attn -> one GEMM]. None = no caching (fold per call).
 _FOLD_CACHE: Optional[dict] = None
+# Attention-probability dropout of a training step: {"seed": int64[1] device tensor, "call": running call id}. The seed lives
+# on the device (a captured step draws new masks when the host rewrites it between replays); None = no dropout.
+_DROP: Optional[dict] = None
 
 
 def fold_attention_weights(attn):
@@ -116,7 +121,11 @@ def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor
     qbuf = F.linear(xq, f["w_in"], f["b_in"])
     meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div) for t in targets]
     freqs = next((t.freqs for t in targets if t.rel is not None), (None, None))
-    out, flag = KnarpeAttnFn.apply(qbuf, f["bias_k"], n, S, meta, freqs, *kvs)
+    drop = None
+    if _DROP is not None and attn.training and attn.dropout_p > 0:
+        _DROP["call"] += 1
+        drop = (float(attn.dropout_p), _DROP["seed"], _DROP["call"])
+    out, flag = KnarpeAttnFn.apply(qbuf, f["bias_k"], n, S, meta, freqs, drop, *kvs)
     y = F.linear(out, f["w_out"], f["b_out"])
     return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
 
@@ -460,15 +469,21 @@ def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussi
 
 
 def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = None, use_prior: Optional[Tensor] = None) -> Dict[str, Tensor]:
-    """waymo_motion.py:313-385. `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
+    """waymo_motion.py:313-385. Dropout: residual / FFN / MLP dropouts through torch, the attention-probability dropout inside
+    the HIP attention kernels (seed on the device, one call id per attention call of the step). `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
     inputs of a step as device tensors: a captured step (pl_modules/data_parallel.GraphedTrainStep) refills them before
     every replay; left None they are drawn here from the CPU generator like the reference's CPU path does."""
-    global _FOLD_CACHE
+    global _FOLD_CACHE, _DROP
     _FOLD_CACHE = {}
+    if wm.model.training:
+        seed = getattr(wm, "attn_dropout_seed", None)  # a captured step owns a static seed tensor and refills it per replay
+        if seed is None:
+            seed = torch.empty(1, dtype=torch.int64, device=next(wm.model.parameters()).device).random_()
+        _DROP = {"seed": seed, "call": 0}
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
-        _FOLD_CACHE = None
+        _FOLD_CACHE, _DROP = None, None
 
 
 def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
