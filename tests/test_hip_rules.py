@@ -198,3 +198,27 @@ def test_joint_futures_rule_checks_and_filter_end_to_end(tb):
     for s in range(n):
         assert torch.equal(score[s, idx[s]].sort()[0], score[s].sort()[0][:32])
     assert torch.equal(trajs.cpu(), buf.pred_pose.cpu()[torch.arange(n).unsqueeze(1), idx][:, :, :, 10:])
+
+
+@pytest.mark.parametrize("case", ["no_edges_no_lanes", "all_invalid", "single_agent", "no_lights_on"])
+def test_rule_kernels_edge_cases(tb, case):
+    """Empty tables (a map without road-edge / lane polylines), frames without a valid agent, a single agent (no pairs), no
+    valid light: the kernels must agree with the oracle (and not read past empty tables)."""
+    e = tb.synthetic.make_rule_episode(n_sc=2, n_ag=1 if case == "single_agent" else 10, n_mp=24, n_tl=4, n_step=25, seed=21)
+    if case == "no_edges_no_lanes":
+        e["map/type"] = torch.nn.functional.one_hot(torch.full(e["map/type"].shape[:2], 10), 11).bool()  # crosswalks only
+    if case == "all_invalid":
+        e["agent/valid"] = torch.zeros_like(e["agent/valid"])
+    if case == "single_agent":
+        e["agent/valid"] = torch.ones_like(e["agent/valid"])
+        e["agent/type"] = torch.nn.functional.one_hot(torch.zeros(2, 1, dtype=torch.int64), 3).bool()
+    if case == "no_lights_on":
+        e["tl/valid"] = torch.zeros_like(e["tl/valid"])
+    got = _checker(tb, e).check_log(*_log_inputs(e))
+    ora, counter = run_oracle(e)
+    for k in got:
+        assert torch.equal(got[k].cpu(), ora[k]), (case, k)
+    if case in ("no_edges_no_lanes", "all_invalid"):
+        assert not got["run_road_edge"].any() and not got["passive"].any()
+    if case in ("all_invalid", "single_agent"):
+        assert not got["collided"].any() and not got["collided_wosac"].any()

@@ -11,14 +11,21 @@
 
 namespace {
 
+// Agents: 32 lanes (half a wavefront) per agent - every lane repeats the agent's scalar dynamics (broadcast loads), the
+// lanes split the destination polyline's nodes and the window shift, so the kernel is 2-3 dependent loads deep instead
+// of ~30 (it closes the critical path of every step: 23 -> ~7 us). Lights: one thread per light.
+constexpr int LPA = 32;
+
 __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i_ag = gid / LPA, sub = gid % LPA;
   const int t = *s.step;  // step being simulated: model saw the state of step t-1
   const int n_ag_tot = s.n_batch * s.n_ag;
   const int n_tl_tot = s.n_batch * s.n_tl;
   const int T = s.n_step_out;
   const int W = s.window;
-  if ((parts & TBX_SIM_AGENTS) && i < n_ag_tot) {
+  if ((parts & TBX_SIM_AGENTS) && i_ag < n_ag_tot) {
+    const int i = i_ag;
     const int b = i / s.n_ag;
     const bool valid0 = s.ag_valid[i] != 0;
     const int ty = s.ag_type_idx[i];
@@ -38,7 +45,7 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     float nyaw = pyaw + s.dt * yr;
     float nspd = spd + s.dt * acc, nacc = acc, nyr = yr;
     if (!valid0) nx = ny = nyaw = nspd = nacc = nyr = 0.f;
-    if (t - 1 < T) {
+    if (t - 1 < T && sub == 0) {
       const int64_t o = (int64_t)i * T + (t - 1);
       s.out_valid[o] = valid0 ? 1 : 0;
       s.out_pose[o * 3] = nx;
@@ -56,18 +63,23 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     const bool outside = (s.outside_map[i] != 0) || out_now;
     bool pos_ok = false, rot_ok = false;
     const float hx = cosf(nyaw), hy = sinf(nyaw);
-    for (int k = 0; k < s.n_node; ++k) {
+    for (int k = sub; k < s.n_node; k += LPA) {
       const int64_t d = (int64_t)i * s.n_node + k;
-      if (s.dest_invalid[d]) continue;
+      const bool ok = s.dest_invalid[d] == 0;
       const float ex = nx - s.dest_pos[d * 2], ey = ny - s.dest_pos[d * 2 + 1];
-      if (sqrtf(ex * ex + ey * ey) < s.dest_thresh[i]) pos_ok = true;
-      if (hx * s.dest_dir[d * 2] + hy * s.dest_dir[d * 2 + 1] > 0.8660254037844387f) rot_ok = true;
+      pos_ok = pos_ok || (ok && sqrtf(ex * ex + ey * ey) < s.dest_thresh[i]);
+      rot_ok = rot_ok || (ok && hx * s.dest_dir[d * 2] + hy * s.dest_dir[d * 2 + 1] > 0.8660254037844387f);
+    }
+    {  // any() over the agent's 32 lanes (its half of the wavefront's ballot)
+      const int sh = (threadIdx.x & 32);
+      pos_ok = ((__ballot(pos_ok) >> sh) & 0xffffffffull) != 0ull;
+      rot_ok = ((__ballot(rot_ok) >> sh) & 0xffffffffull) != 0ull;
     }
     const uint8_t kind = s.dest_kind[i];
     const bool reached0 = s.dest_reached[i] != 0;
     const bool reach_now = !reached0 && valid0 && (((kind & 1) && pos_ok && rot_ok) || ((kind & 2) && pos_ok));
     const bool reached = reached0 || reach_now;
-    if (t - 1 < T) {
+    if (t - 1 < T && sub == 0) {
       s.out_outside_map[(int64_t)i * T + (t - 1)] = outside ? 1 : 0;
       s.out_dest_reached[(int64_t)i * T + (t - 1)] = reached ? 1 : 0;
     }
@@ -93,37 +105,53 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     const bool dis = out_now && !(has_gt && gt_v);
     disabled = disabled || dis;
     valid = valid && !dis;
-    s.ag_valid[i] = valid ? 1 : 0;
-    s.ag_disabled[i] = disabled ? 1 : 0;
-    s.ag_pose[i * 3] = nx;
-    s.ag_pose[i * 3 + 1] = ny;
-    s.ag_pose[i * 3 + 2] = nyaw;
-    s.ag_motion[i * 3] = nspd;
-    s.ag_motion[i * 3 + 1] = nacc;
-    s.ag_motion[i * 3 + 2] = nyr;
-    s.outside_map[i] = outside ? 1 : 0;
-    s.dest_reached[i] = reached ? 1 : 0;
-    if (reach_now) s.navi_valid[i] = 0;
-    // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see
+    // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see. Lane w
+    // moves entry w + 1 to w: the wavefront runs in lockstep, so every lane has loaded before any lane stores (chunks of 32
+    // go upwards, each reads only entries no earlier chunk wrote).
     uint8_t* hv = s.hist_valid + (int64_t)i * W;
     float* hp = s.hist_pose + (int64_t)i * W * 3;
     float* hm = s.hist_motion + (int64_t)i * W * 3;
-    for (int w = 0; w < W - 1; ++w) {
-      hv[w] = hv[w + 1];
-      for (int c = 0; c < 3; ++c) {
-        hp[w * 3 + c] = hp[(w + 1) * 3 + c];
-        hm[w * 3 + c] = hm[(w + 1) * 3 + c];
+    for (int w0 = 0; w0 < W - 1; w0 += LPA) {
+      const int w = w0 + sub;
+      const bool mv = w < W - 1;
+      uint8_t v1 = 0;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f;
+      if (mv) {
+        v1 = hv[w + 1];
+        p0 = hp[(w + 1) * 3], p1 = hp[(w + 1) * 3 + 1], p2 = hp[(w + 1) * 3 + 2];
+        m0 = hm[(w + 1) * 3], m1 = hm[(w + 1) * 3 + 1], m2 = hm[(w + 1) * 3 + 2];
       }
+      __builtin_amdgcn_wave_barrier();
+      if (mv) {
+        hv[w] = v1;
+        hp[w * 3] = p0, hp[w * 3 + 1] = p1, hp[w * 3 + 2] = p2;
+        hm[w * 3] = m0, hm[w * 3 + 1] = m1, hm[w * 3 + 2] = m2;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    hv[W - 1] = valid ? 1 : 0;
-    hp[(W - 1) * 3] = nx;
-    hp[(W - 1) * 3 + 1] = ny;
-    hp[(W - 1) * 3 + 2] = nyaw;
-    hm[(W - 1) * 3] = nspd;
-    hm[(W - 1) * 3 + 1] = nacc;
-    hm[(W - 1) * 3 + 2] = nyr;
+    if (sub == 0) {
+      s.ag_valid[i] = valid ? 1 : 0;
+      s.ag_disabled[i] = disabled ? 1 : 0;
+      s.ag_pose[i * 3] = nx;
+      s.ag_pose[i * 3 + 1] = ny;
+      s.ag_pose[i * 3 + 2] = nyaw;
+      s.ag_motion[i * 3] = nspd;
+      s.ag_motion[i * 3 + 1] = nacc;
+      s.ag_motion[i * 3 + 2] = nyr;
+      s.outside_map[i] = outside ? 1 : 0;
+      s.dest_reached[i] = reached ? 1 : 0;
+      if (reach_now) s.navi_valid[i] = 0;
+      hv[W - 1] = valid ? 1 : 0;
+      hp[(W - 1) * 3] = nx;
+      hp[(W - 1) * 3 + 1] = ny;
+      hp[(W - 1) * 3 + 2] = nyaw;
+      hm[(W - 1) * 3] = nspd;
+      hm[(W - 1) * 3 + 1] = nacc;
+      hm[(W - 1) * 3 + 2] = nyr;
+    }
   }
-  if ((parts & TBX_SIM_LIGHTS) && i < n_tl_tot) {
+  if ((parts & TBX_SIM_LIGHTS) && gid < n_tl_tot) {
+    const int i = gid;
     // Dynamics.override_tl (dynamics.py:143-163): argmax -> one-hot, ground truth while it lasts
     const float* lg = s.tl_logits + (int64_t)i * 5;
     int am = 0;
@@ -175,12 +203,12 @@ extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* st
                         s.out_motion, s.out_action, s.out_tl_state, s.out_outside_map, s.out_dest_reached};
   for (const void* p : need)
     if (p == nullptr) return TBX_ERR_ARG;
-  const int per = ((parts & TBX_SIM_AGENTS) && (parts & TBX_SIM_LIGHTS)) ? (s.n_ag > s.n_tl ? s.n_ag : s.n_tl)
-                                                                          : ((parts & TBX_SIM_AGENTS) ? s.n_ag : s.n_tl);
-  const int n = s.n_batch * per;
+  const int64_t th_ag = (parts & TBX_SIM_AGENTS) ? (int64_t)s.n_batch * s.n_ag * LPA : 0;
+  const int64_t th_tl = (parts & TBX_SIM_LIGHTS) ? (int64_t)s.n_batch * s.n_tl : 0;
+  const int64_t n = th_ag > th_tl ? th_ag : th_tl;
   hipStream_t hs = (hipStream_t)stream;
   if (parts & (TBX_SIM_AGENTS | TBX_SIM_LIGHTS))
-    hipLaunchKernelGGL(sim_step_kernel, dim3((n + 127) / 128), dim3(128), 0, hs, s, parts);
+    hipLaunchKernelGGL(sim_step_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, hs, s, parts);
   else
     hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
