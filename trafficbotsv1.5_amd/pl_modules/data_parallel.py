@@ -133,7 +133,10 @@ class GraphedTrainStep:
         getattr(wm, "logged", {}).clear()
         self.graph = torch.cuda.CUDAGraph()
         say("capture begins")
-        with torch.cuda.graph(self.graph, stream=s):
+        # thread_local: only this thread's calls are policed during the capture (the RCCL watchdog / heartbeat threads of an
+        # initialised process group may query events at any time); the autograd engine's launches still land on the capturing
+        # stream and are captured
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
             self._fwd_bwd()  # gradients are allocated from the graph's pool: static addresses, rewritten by every replay
         say("capture done")
 
