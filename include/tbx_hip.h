@@ -93,7 +93,8 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)
  *   dkv[i] : gradient of seg[i].kv, same shape / leading dimension; dK, dV are ACCUMULATED with atomicAdd (zero it first)
- *   dbias_k [128]: accumulated gradient of rpe_k_bias.
+ *   dbias_k [n_batch*n_src, 128]: per-row gradient of rpe_k_bias, overwritten (the parameter's gradient is the sum over
+ *   rows: one shared 128-float accumulator serialises ~10^3-deep at the L2 atomic units).
  * Probabilities are recomputed from the forward inputs; the pose embeddings carry no gradient (utils/rpe.py:7). */
 int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
                         const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo, float* dqbuf,

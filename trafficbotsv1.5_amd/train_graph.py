@@ -55,10 +55,10 @@ class KnarpeAttnFn(torch.autograd.Function):
         meta, n, S = ctx.meta, ctx.n, ctx.S
         dq = torch.empty_like(qbuf)
         dkv = [torch.zeros_like(kv) for kv in kvs]
-        db = torch.zeros_like(bias_k)
+        db = torch.empty(qbuf.shape[0], D, dtype=bias_k.dtype, device=bias_k.device)  # per-row d(bias_k); summed below
         hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs,
                             drop=ctx.drop)
-        return (dq, db, None, None, None, None, None, *dkv)
+        return (dq, db.sum(0), None, None, None, None, None, *dkv)
 
 
 class Targets:
