@@ -116,6 +116,22 @@ int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_of
                                 const float* freqs_xy, const float* freqs_yaw, float p_drop,
                                 const uint64_t* drop_seed /* device */, uint32_t drop_call, void* stream);
 
+/* The backward without dK / dV atomics. tbx_knn_inverse turns a K-nearest set into per-table inverse lists (for every
+ * target token the un-masked (source row, slot) pairs that selected it; pair id = row * k + slot; order unspecified):
+ *   inv_ptr [n_batch / tgt_batch_div, n_tgt + 1] i32 (offsets into the table's list), inv_list [n_tables, n_src * div * k] i32.
+ * tbx_knarpe_attn_bwd_gather = tbx_knarpe_attn_bwd_dropout, but the row kernel only stores 8 coefficients per pair into
+ * `coef` [n_batch*n_src, sum k, 8] (scratch) and a second kernel sums every target token's dK / dV row through the lists
+ * (ADDED to dkv, no atomics: 23 M float atomics per launch at 1024 rows x 89 pairs were 2/3 of the launch).
+ * n_tgt <= 2048. */
+int tbx_knn_inverse(const int32_t* idx, const uint8_t* invalid, int n_batch, int n_src, int k, int n_tgt, int tgt_batch_div,
+                    int32_t* inv_ptr, int32_t* inv_list, void* stream);
+int tbx_knarpe_attn_bwd_gather(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                               int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo,
+                               float* dqbuf, float* const* dkv /* host array */, float* dbias_k, const float* freqs_xy,
+                               const float* freqs_yaw, float p_drop, const uint64_t* drop_seed /* device */, uint32_t drop_call,
+                               const int32_t* const* inv_ptr /* host array of n_seg device pointers */,
+                               const int32_t* const* inv_list /* host array */, float* coef, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
  * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per

@@ -187,6 +187,22 @@ def test_attention_probability_dropout_vs_explicit_mask(tb):
     torch.testing.assert_close(out_h.detach().cpu(), out_c.detach(), rtol=2e-4, atol=2e-5)
     for a, b in zip(leaves_h, leaves_c):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4)
+    # the same backward through inverse K-nearest lists (tbx_knn_inverse + tbx_knarpe_attn_bwd_gather): no dK / dV atomics
+    lists = [hip.knn_inverse(meta[i][0], meta[i][1], (T1, T2)[i]) for i in range(2)]
+    for i, (T, K) in enumerate(((T1, K1), (T2, K2))):  # the lists are the un-masked pairs grouped by target token
+        ptr, lst = lists[i][0].cpu(), lists[i][1].cpu()
+        ix, iv = idx[i].reshape(n, -1), inv[i].reshape(n, -1)
+        for b_ in range(n):
+            for j in (0, 3, T - 1):
+                want = sorted((b_ * S * K + torch.nonzero((ix[b_] == j) & ~iv[b_]).flatten()).tolist())
+                assert sorted(lst[b_, ptr[b_, j]:ptr[b_, j + 1]].tolist()) == want
+            assert int(ptr[b_, T]) == int((~iv[b_]).sum())
+    leaves_g = [t.clone().to(dev).requires_grad_(True) for t in (qbuf, bias_k, *kvs)]
+    meta_g = [m + (lists[i],) for i, m in enumerate(meta)]
+    out_g, _ = TG.KnarpeAttnFn.apply(leaves_g[0], leaves_g[1], n, S, meta_g, (None, None), (p, seed.to(dev), call), *leaves_g[2:])
+    (out_g.masked_fill(flag.bool().unsqueeze(-1), 0.0) * w_out.to(dev)).sum().backward()
+    for a, b in zip(leaves_g, leaves_h):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-5)
     # p = 0 through the same entry points is the plain kernel pair
     o0, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), None, *[t.detach() for t in leaves_h[2:]])
     o1, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), (0.0, None, 0), *[t.detach() for t in leaves_h[2:]])

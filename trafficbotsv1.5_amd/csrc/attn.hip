@@ -345,6 +345,10 @@ struct AttnBwdArgs {
   float* dqbuf;       // [rows, ldq]: dq at q_off, dqt at qt_off (overwritten)
   float* dkv[2];      // per segment, same [.., ld_kv] layout as seg.kv (accumulated)
   float* dbias_k;     // [rows, 128]: per-row gradient of rpe_k_bias (overwritten; the parameter's gradient is the column sum)
+  // gather mode (coef != nullptr): instead of scattering dK / dV with atomics the row kernel stores, per pair, the four
+  // dS[h] and the four (dropped) probabilities; knarpe_attn_dkv_kernel then sums each target token's contributions through
+  // the inverse K-nearest lists - no atomics, ~4x less time at 1024 rows x 89 pairs
+  float* coef;        // [rows, ktot, 8]
 };
 
 __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs b) {
@@ -501,6 +505,14 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
           pa[h] = p_s[rib][h][t] * k_s[rib][h][t];  // weight of v_t in the output (dropped probability)
           any = any || ds[h] != 0.f || pa[h] != 0.f;
         }
+        if (b.coef != nullptr) {  // gather mode: the 8 lanes of the target's group store its 8 coefficients (32 contiguous bytes)
+          float cv = ds[0];
+#pragma unroll
+          for (int h = 1; h < NH; ++h) cv = (s8 == h) ? ds[h] : cv;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) cv = (s8 == NH + h) ? pa[h] : cv;
+          b.coef[((int64_t)row * ktot + t) * 8 + s8] = cv;
+        }
         if (!any) continue;  // masked target (or an all-masked row): nothing flows
         const int64_t pi = pbase + tl;
         const int64_t trow = tb + (int64_t)S.idx[pi] * S.ld_kv;
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
           dq[h].z += g * (kq.z + bkv[h].z); dq[h].w += g * (kq.w + bkv[h].w);
           fma4(dbk[h], g, qv[h]);
           dqt[h].fma(g, e);
+          if (b.coef != nullptr) continue;
           const int c0 = h * 32 + s8 * 4;
           atomicAdd(dk + c0 + 0, g * qv[h].x); atomicAdd(dk + c0 + 1, g * qv[h].y);
           atomicAdd(dk + c0 + 2, g * qv[h].z); atomicAdd(dk + c0 + 3, g * qv[h].w);
@@ -545,6 +558,59 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
       dqt[h].store(dqrow + a.qt_off + h * DR, s8);
     }
   }
+}
+
+// dK / dV of one target token = sum over the pairs that selected it (inverse K-nearest list) of dS[h] q_h / p[h] dO_h.
+// A wavefront per token: lanes 0-31 own the 128 dK channels (float4 each), lanes 32-63 the 128 dV channels; a pair costs
+// one 512-B row of q or dO per half-wave and one coefficient per lane. Tokens nobody selected keep their zero gradient.
+struct DkvArgs {
+  const float* qbuf;   // q at q_off
+  const float* dout;   // dO at column 0
+  const float* coef;   // [rows, ktot, 8]
+  const int32_t* inv_ptr[2];
+  const int32_t* inv_list[2];
+  float* dkv[2];
+  int32_t k[2], t_off[2], n_tgt[2], ld_kv[2], k_off[2], v_off[2], list_cap[2], tok0[2];  // tok0: first wave of the segment
+  int ldq, q_off, ldo, ktot, n_tok;
+};
+
+__global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (w >= a.n_tok) return;
+  const int sg = (w >= a.tok0[1]) ? 1 : 0;
+  const int tok = w - a.tok0[sg];            // table * n_tgt + j
+  const int table = tok / a.n_tgt[sg], j = tok - table * a.n_tgt[sg];
+  const int32_t* ptr = a.inv_ptr[sg] + (int64_t)table * (a.n_tgt[sg] + 1);
+  const int p0 = ptr[j], p1 = ptr[j + 1];
+  if (p0 == p1) return;
+  const int32_t* list = a.inv_list[sg] + (int64_t)table * a.list_cap[sg];
+  const int half = lane >> 5, c4 = lane & 31, h = c4 >> 3;
+  const int k = a.k[sg];
+  const float* src = half ? a.dout : a.qbuf + a.q_off;
+  const int lds = half ? a.ldo : a.ldq;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = p0;
+  for (; p + 1 < p1; p += 2) {  // two pairs in flight
+    const int g0 = list[p], g1 = list[p + 1];
+    const int r0 = g0 / k, r1 = g1 / k;
+    const float c0 = a.coef[((int64_t)r0 * a.ktot + a.t_off[sg] + (g0 - r0 * k)) * 8 + half * 4 + h];
+    const float c1 = a.coef[((int64_t)r1 * a.ktot + a.t_off[sg] + (g1 - r1 * k)) * 8 + half * 4 + h];
+    const float4 v0 = *(const float4*)(src + (int64_t)r0 * lds + c4 * 4);
+    const float4 v1 = *(const float4*)(src + (int64_t)r1 * lds + c4 * 4);
+    fma4(acc, c0, v0);
+    fma4(acc, c1, v1);
+  }
+  if (p < p1) {
+    const int g0 = list[p];
+    const int r0 = g0 / k;
+    const float c0 = a.coef[((int64_t)r0 * a.ktot + a.t_off[sg] + (g0 - r0 * k)) * 8 + half * 4 + h];
+    fma4(acc, c0, *(const float4*)(src + (int64_t)r0 * lds + c4 * 4));
+  }
+  float* out = a.dkv[sg] + ((int64_t)table * a.n_tgt[sg] + j) * a.ld_kv[sg] + (half ? a.v_off[sg] : a.k_off[sg]) + c4 * 4;
+  float4 o = *(float4*)out;  // accumulate (the row is this wave's alone)
+  o.x += acc.x, o.y += acc.y, o.z += acc.z, o.w += acc.w;
+  *(float4*)out = o;
 }
 
 int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
@@ -659,7 +725,53 @@ extern "C" int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off
   b.dout = dout;
   b.dqbuf = dqbuf;
   b.dbias_k = dbias_k;
+  b.coef = nullptr;
   hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_attn_bwd_gather(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                          int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                          int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                          const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                          const int32_t* const* inv_ptr, const int32_t* const* inv_list, float* coef,
+                                          void* stream) {
+  if (!dout || !dqbuf || !dkv || !dbias_k || !inv_ptr || !inv_list || !coef) return TBX_ERR_ARG;
+  if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
+  AttnBwdArgs b;
+  int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  rc = set_dropout(b.f, p_drop, drop_seed, drop_call);
+  if (rc != TBX_OK) return rc;
+  DkvArgs d;
+  d.qbuf = qbuf, d.dout = dout, d.coef = coef;
+  d.ldq = ldq, d.q_off = q_off, d.ldo = ldo;
+  int t_off = 0, tok = 0;
+  for (int i = 0; i < 2; ++i) {
+    const int s = i < n_seg ? i : 0;
+    if (i < n_seg && (!dkv[i] || !inv_ptr[i] || !inv_list[i] || (((uintptr_t)dkv[i]) & 15) || n_batch % segs[i].batch_div))
+      return TBX_ERR_ARG;
+    b.dkv[i] = dkv[s];
+    d.dkv[i] = dkv[s], d.inv_ptr[i] = inv_ptr[s], d.inv_list[i] = inv_list[s];
+    d.k[i] = segs[s].k, d.n_tgt[i] = segs[s].n_tgt, d.ld_kv[i] = segs[s].ld_kv, d.k_off[i] = segs[s].k_off, d.v_off[i] = segs[s].v_off;
+    d.list_cap[i] = n_src * segs[s].batch_div * segs[s].k;
+    d.t_off[i] = i < n_seg ? t_off : 0;
+    d.tok0[i] = i < n_seg ? tok : 0x7fffffff;
+    if (i < n_seg) {
+      t_off += segs[i].k;
+      tok += (n_batch / segs[i].batch_div) * segs[i].n_tgt;
+    }
+  }
+  d.ktot = t_off;
+  d.n_tok = tok;
+  b.dout = dout;
+  b.dqbuf = dqbuf;
+  b.dbias_k = dbias_k;
+  b.coef = coef;
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, hs, b);
+  if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
+  hipLaunchKernelGGL(knarpe_attn_dkv_kernel, dim3((d.n_tok + 3) / 4), dim3(256), 0, hs, d);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

@@ -175,6 +175,72 @@ extern "C" int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, 
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
+namespace {
+// Inverse of a K-nearest set, per target table: for every target token the (source row, slot) pairs that selected it
+// (masked pairs left out). One workgroup per table: counts in LDS, an exclusive scan, then a fill through LDS cursors (the
+// order inside a target's list is unspecified). pair id = global row * k + slot.
+constexpr int INV_MAX_TGT = 2048;
+__global__ __launch_bounds__(1024) void knn_inverse_kernel(const int32_t* __restrict__ idx, const uint8_t* __restrict__ invalid,
+                                                           int n_src, int k, int n_tgt, int batch_div,
+                                                           int32_t* __restrict__ inv_ptr, int32_t* __restrict__ inv_list) {
+  __shared__ int cnt[INV_MAX_TGT + 1];
+  __shared__ int part[1024];
+  const int table = blockIdx.x;
+  const int rows = n_src * batch_div;  // consecutive batches share the table
+  const int64_t row0 = (int64_t)table * rows;
+  const int n_pairs = rows * k;
+  for (int j = threadIdx.x; j <= n_tgt; j += blockDim.x) cnt[j] = 0;
+  __syncthreads();
+  for (int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
+    const int64_t g = row0 * k + p;
+    if (invalid[g] == 0) atomicAdd(&cnt[idx[g]], 1);
+  }
+  __syncthreads();
+  // exclusive scan of cnt[0..n_tgt): each thread owns a contiguous chunk
+  const int chunk = (n_tgt + blockDim.x - 1) / blockDim.x;
+  const int j0 = threadIdx.x * chunk, j1 = min(j0 + chunk, n_tgt);
+  int sum = 0;
+  for (int j = j0; j < j1; ++j) sum += cnt[j];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < (int)blockDim.x; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  int32_t* ptr = inv_ptr + (int64_t)table * (n_tgt + 1);
+  for (int j = j0; j < j1; ++j) {
+    const int v = cnt[j];
+    ptr[j] = run;
+    cnt[j] = run;  // becomes the fill cursor
+    run += v;
+  }
+  if (j1 == n_tgt && j0 < n_tgt) ptr[n_tgt] = run;
+  if (n_tgt == 0 && threadIdx.x == 0) ptr[0] = 0;
+  __syncthreads();
+  int32_t* list = inv_list + (int64_t)table * n_pairs;
+  for (int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
+    const int64_t g = row0 * k + p;
+    if (invalid[g] == 0) list[atomicAdd(&cnt[idx[g]], 1)] = (int32_t)g;
+  }
+}
+}  // namespace
+
+extern "C" int tbx_knn_inverse(const int32_t* idx, const uint8_t* invalid, int n_batch, int n_src, int k, int n_tgt,
+                               int tgt_batch_div, int32_t* inv_ptr, int32_t* inv_list, void* stream) {
+  if (!idx || !invalid || !inv_ptr || !inv_list) return TBX_ERR_ARG;
+  if (n_batch <= 0 || n_src <= 0 || k <= 0 || n_tgt <= 0 || tgt_batch_div <= 0 || n_batch % tgt_batch_div) return TBX_ERR_ARG;
+  if (n_tgt > INV_MAX_TGT || (int64_t)n_batch * n_src * k > 0x7fffffff) return TBX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(knn_inverse_kernel, dim3(n_batch / tgt_batch_div), dim3(1024), 0, (hipStream_t)stream, idx, invalid, n_src, k,
+                     n_tgt, tgt_batch_div, inv_ptr, inv_list);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
 extern "C" int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
                               float* out, int ld_out, int col_off, void* stream) {
   if (!pose3 || !freqs_xy || !freqs_yaw || !out || n <= 0) return TBX_ERR_ARG;

@@ -90,6 +90,10 @@ def load():
                                                 f32, vp, C.c_uint32, vp]
     lib.tbx_knarpe_attn_bwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                                 C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, vp]
+    lib.tbx_knn_inverse.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.tbx_knarpe_attn_bwd_gather.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
+                                               C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), vp, vp]
     lib.tbx_pack_weight_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_size.restype = C.c_int64
     lib.tbx_pack_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -105,7 +109,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -211,6 +215,35 @@ def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_s
                                             _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy),
                                             _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd")
+
+
+def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):
+    """Inverse lists of a K-nearest set idx / invalid [n_batch, n_src, k] -> (inv_ptr [n_tables, n_tgt+1], inv_list [n_tables, cap])."""
+    n, S, k = idx.shape
+    nt = n // tgt_batch_div
+    ptr = torch.empty(nt, n_tgt + 1, dtype=torch.int32, device=idx.device)
+    lst = torch.empty(nt, S * tgt_batch_div * k, dtype=torch.int32, device=idx.device)
+    rc = load().tbx_knn_inverse(_cptr(idx, torch.int32), _cptr(invalid, torch.uint8), n, S, k, n_tgt, tgt_batch_div, _ptr(ptr), _ptr(lst),
+                                stream_ptr())
+    _check(rc, "tbx_knn_inverse")
+    return ptr, lst
+
+
+def knarpe_attn_bwd_gather(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
+                           dkv: Sequence[torch.Tensor], dbias_rows, inv: Sequence, freqs_xy=None, freqs_yaw=None, drop=None):
+    """Backward through inverse K-nearest lists (inv[i] = knn_inverse(...) of segment i): no dK / dV atomics."""
+    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
+    dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
+    ip = (C.c_void_p * len(segs))(*[_cptr(p, torch.int32) for p, _ in inv])
+    il = (C.c_void_p * len(segs))(*[_cptr(l, torch.int32) for _, l in inv])
+    coef = torch.empty(n_batch * n_src, sum(s.k for s in segs), 8, dtype=torch.float32, device=qbuf.device)
+    p, seed, call = drop if drop is not None else (0.0, None, 0)
+    rc = load().tbx_knarpe_attn_bwd_gather(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+                                           n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
+                                           _ptr(dqbuf, torch.float32), dk, _ptr(dbias_rows, torch.float32), _cptr(freqs_xy),
+                                           _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), ip, il, _ptr(coef),
+                                           stream_ptr())
+    _check(rc, "tbx_knarpe_attn_bwd_gather")
 
 
 def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n_head: int = 4) -> torch.Tensor:

@@ -30,7 +30,7 @@ class KnarpeAttnFn(torch.autograd.Function):
 
     @staticmethod
     def _segs(kvs, meta):
-        # meta per segment: (idx, invalid, emb | None, rel | None, n_tgt, batch_div)
+        # meta per segment: (idx, invalid, emb | None, rel | None, n_tgt, batch_div[, (inv_ptr, inv_list) | None])
         return [Seg(kv, 0, D, m[4], m[0], m[1], m[2], m[5], rel=m[3]) for kv, m in zip(kvs, meta)]
 
     @staticmethod
@@ -56,8 +56,13 @@ class KnarpeAttnFn(torch.autograd.Function):
         dq = torch.empty_like(qbuf)
         dkv = [torch.zeros_like(kv) for kv in kvs]
         db = torch.empty(qbuf.shape[0], D, dtype=bias_k.dtype, device=bias_k.device)  # per-row d(bias_k); summed below
-        hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs,
-                            drop=ctx.drop)
+        inv = [m[6] if len(m) > 6 else None for m in meta]
+        if all(i is not None for i in inv):  # inverse K-nearest lists: dK / dV gathered per target token, no atomics
+            hip.knarpe_attn_bwd_gather(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, inv,
+                                       *ctx.freqs, drop=ctx.drop)
+        else:
+            hip.knarpe_attn_bwd(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, *ctx.freqs,
+                                drop=ctx.drop)
         return (dq, db.sum(0), None, None, None, None, None, *dkv)
 
 
@@ -65,10 +70,11 @@ class Targets:
     """One target segment in table form: tokens [n_tables*T, 128] (already normalised), KNN set, sharing factor."""
 
     def __init__(self, tokens: Tensor, idx: Tensor, invalid: Tensor, emb: Optional[Tensor], n_tgt: int, batch_div: int = 1,
-                 cache: Optional[dict] = None, key: Optional[str] = None, rel: Optional[Tensor] = None, freqs=(None, None)):
+                 cache: Optional[dict] = None, key: Optional[str] = None, rel: Optional[Tensor] = None, freqs=(None, None),
+                 inv=None):
         """Pose information per pair: `emb` [n,S,K,128] materialised, or `rel` [n,S,K,3] + freqs (rebuilt in-kernel)."""
         self.tokens, self.idx, self.invalid, self.emb, self.n_tgt, self.batch_div = tokens, idx, invalid, emb, n_tgt, batch_div
-        self.rel, self.freqs = rel, freqs
+        self.rel, self.freqs, self.inv = rel, freqs, inv
         self.cache, self.key = cache, key  # static targets (map tokens): K/V tables computed once per training step
 
 
@@ -119,7 +125,7 @@ def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor
     """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source."""
     f = fold_attention_weights(attn)
     qbuf = F.linear(xq, f["w_in"], f["b_in"])
-    meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div) for t in targets]
+    meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div, t.inv) for t in targets]
     freqs = next((t.freqs for t in targets if t.rel is not None), (None, None))
     drop = None
     if _DROP is not None and attn.training and attn.dropout_p > 0:
@@ -186,7 +192,9 @@ def _knn(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, rp, div=1):
     """-> kwargs of Targets: KNN indices / mask + the relative poses (the embedding is rebuilt inside the attention kernels)."""
     idx, inv, rel, _ = hip.knn_embed(src_pose, src_inv, tgt_pose, tgt_inv, k, limit, tgt_batch_div=div, want_rel_pose=True,
                                      want_emb=False)
-    return dict(idx=idx, invalid=inv, emb=None, rel=rel, freqs=(rp.pe_xy.freqs, rp.pe_yaw.freqs))
+    # with gradients on: the inverse lists the attention backward gathers dK / dV through
+    lists = hip.knn_inverse(idx, inv, tgt_pose.shape[1], div) if torch.is_grad_enabled() else None
+    return dict(idx=idx, invalid=inv, emb=None, rel=rel, freqs=(rp.pe_xy.freqs, rp.pe_yaw.freqs), inv=lists)
 
 
 # ------------------------------------------------------------------------------------------------ encoders
