@@ -121,7 +121,8 @@ int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_of
  *   inv_ptr [n_batch / tgt_batch_div, n_tgt + 1] i32 (offsets into the table's list), inv_list [n_tables, n_src * div * k] i32.
  * tbx_knarpe_attn_bwd_gather = tbx_knarpe_attn_bwd_dropout, but the row kernel only stores 8 coefficients per pair into
  * `coef` [n_batch*n_src, sum k, 8] (scratch) and a second kernel sums every target token's dK / dV row through the lists
- * (ADDED to dkv, no atomics: 23 M float atomics per launch at 1024 rows x 89 pairs were 2/3 of the launch).
+ * (the K and V columns of every token row of dkv are OVERWRITTEN - no pre-zeroing, no atomics: 23 M float atomics per launch
+ * at 1024 rows x 89 pairs were 2/3 of the launch).
  * n_tgt <= 2048. */
 int tbx_knn_inverse(const int32_t* idx, const uint8_t* invalid, int n_batch, int n_src, int k, int n_tgt, int tgt_batch_div,
                     int32_t* inv_ptr, int32_t* inv_list, void* stream);

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
 
 // dK / dV of one target token = sum over the pairs that selected it (inverse K-nearest list) of dS[h] q_h / p[h] dO_h.
 // A wavefront per token: lanes 0-31 own the 128 dK channels (float4 each), lanes 32-63 the 128 dV channels; a pair costs
-// one 512-B row of q or dO per half-wave and one coefficient per lane. Tokens nobody selected keep their zero gradient.
+// one 512-B row of q or dO per half-wave and one coefficient per lane. The K and V columns of every token are overwritten.
 struct DkvArgs {
   const float* qbuf;   // q at q_off
   const float* dout;   // dO at column 0
@@ -583,7 +583,6 @@ __global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
   const int table = tok / a.n_tgt[sg], j = tok - table * a.n_tgt[sg];
   const int32_t* ptr = a.inv_ptr[sg] + (int64_t)table * (a.n_tgt[sg] + 1);
   const int p0 = ptr[j], p1 = ptr[j + 1];
-  if (p0 == p1) return;
   const int32_t* list = a.inv_list[sg] + (int64_t)table * a.list_cap[sg];
   const int half = lane >> 5, c4 = lane & 31, h = c4 >> 3;
   const int k = a.k[sg];
@@ -608,9 +607,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
     fma4(acc, c0, *(const float4*)(src + (int64_t)r0 * lds + c4 * 4));
   }
   float* out = a.dkv[sg] + ((int64_t)table * a.n_tgt[sg] + j) * a.ld_kv[sg] + (half ? a.v_off[sg] : a.k_off[sg]) + c4 * 4;
-  float4 o = *(float4*)out;  // accumulate (the row is this wave's alone)
-  o.x += acc.x, o.y += acc.y, o.z += acc.z, o.w += acc.w;
-  *(float4*)out = o;
+  *(float4*)out = acc;  // every token's K and V gradient columns are written (zero when nobody selected it): no pre-zeroing
 }
 
 int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,

@@ -54,10 +54,12 @@ class KnarpeAttnFn(torch.autograd.Function):
         qbuf, bias_k, *kvs = ctx.saved_tensors
         meta, n, S = ctx.meta, ctx.n, ctx.S
         dq = torch.empty_like(qbuf)
-        dkv = [torch.zeros_like(kv) for kv in kvs]
         db = torch.empty(qbuf.shape[0], D, dtype=bias_k.dtype, device=bias_k.device)  # per-row d(bias_k); summed below
         inv = [m[6] if len(m) > 6 else None for m in meta]
-        if all(i is not None for i in inv):  # inverse K-nearest lists: dK / dV gathered per target token, no atomics
+        gather = all(i is not None for i in inv)
+        # gather mode overwrites every K|V row (the tables here are exactly [tokens, 256] = K|V); the atomics path accumulates
+        dkv = [torch.empty_like(kv) if gather and kv.shape[1] == 2 * D else torch.zeros_like(kv) for kv in kvs]
+        if gather:  # inverse K-nearest lists: dK / dV gathered per target token, no atomics
             hip.knarpe_attn_bwd_gather(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), dout.contiguous(), dq, dkv, db, inv,
                                        *ctx.freqs, drop=ctx.drop)
         else:
