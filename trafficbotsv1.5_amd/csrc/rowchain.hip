@@ -106,6 +106,34 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   if (src != nullptr && !accum && width == s.n && (s.n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 &&
       ((((uintptr_t)src) & 15) == 0)) {
     const int w4 = s.n >> 2;
+    // all of a wave's requests first, then the LDS writes: the rows were written by the previous launch and come from L2 /
+    // HBM at ~1 us per dependent round trip; a 640-wide load was 6 of them in a row (2.7 us -> one round trip)
+    constexpr int RPW = ROWS / 8;  // rows per wave at the 8-wave workgroups every launch uses
+    if (nwave == 8 && w4 <= 256) {
+      float4 v[RPW][4];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave + rr * 8;
+        const bool live = r < t.n_valid;
+        const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c4 = lane + 64 * it;
+          v[rr][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (live && c4 < w4) v[rr][it] = gld4(srow + c4 * 4);
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave + rr * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c4 = lane + 64 * it;
+          if (c4 < w4) *(float4*)(dst + r * ld + c4 * 4) = v[rr][it];
+        }
+      }
+      return;
+    }
     for (int r = wave; r < ROWS; r += nwave) {
       const bool live = r < t.n_valid;
       const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
