@@ -21,7 +21,7 @@ from importlib import import_module
 from pathlib import Path
 
 # ROCm 7.0 replays hipGraph memset nodes (torch's reduction semaphores) out of order on its AQL-packet fast path: a replay
-# then reads sums of the previous replay (measured, tools/scratch/graph_sum2.py). The captured training step needs the
+# then reads sums of the previous replay (measured, tools/hipgraph_memset_repro.py). The captured training step needs the
 # ordered path; the rollout graphs (kernel nodes only) run at the same speed either way. Must be set before HIP initialises.
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 

@@ -1,4 +1,11 @@
-"""Micro-repro 2: long captured chain; which node types break replay-to-replay correctness when inputs change?"""
+"""Repro of the ROCm 7.0 hipGraph hazard the captured training step has to avoid (pl_modules/data_parallel.GraphedTrainStep):
+a captured chain whose inputs change between replays; with `sum` (torch's multi-block reduction zeroes its semaphores with a
+memset node) replays after the first return stale results unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the environment.
+
+    python tools/hipgraph_memset_repro.py 3000 sum            # BAD on the default AQL-packet path
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python tools/hipgraph_memset_repro.py 3000 sum clone slice churn   # ok
+    flags: sum | clone (memcpy node) | slice (zeros + slice copy) | kcopy (strided copy kernel) | churn (small-block reuse)
+"""
 import sys, threading, torch
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

@@ -69,7 +69,7 @@ class GraphedTrainStep:
 
     Re-capture when the epoch changes (TeacherForcing's schedules read `current_epoch` on the host).
 
-    ROCm caveat (7.0.x, measured with tools/scratch/graph_sum2.py): on the runtime's AQL-packet fast path hipGraph memset nodes
+    ROCm caveat (7.0.x, measured with tools/hipgraph_memset_repro.py): on the runtime's AQL-packet fast path hipGraph memset nodes
     are not ordered with the kernels around them, and torch's multi-block reductions zero their semaphores with one - a
     replay then returns bias gradients of the PREVIOUS replay. `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` (read when HIP initialises)
     selects the ordered path at no measurable cost; the constructor refuses to capture without it.
