@@ -190,3 +190,25 @@ def test_lights_one_step_ahead_equals_sequential_order(tb):
         assert torch.equal(o.pred_valid, ref.pred_valid), k
         assert torch.equal(o.vis_dict["tl_state"], ref.vis_dict["tl_state"]), k
         assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), k
+
+
+def test_hoisted_rollout_constants_are_bit_identical(tb):
+    """The engine embeds the latent and the destination feature once per rollout instead of in every step's heads chain
+    (TrafficBots.rollout_constants): same kernels on the same inputs, so the rollout must not change by a bit."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
+    E = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 8, 16, generator=g).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    outs = {}
+    try:
+        for hoist in (True, False):
+            E.hoist_constants = hoist
+            outs[hoist] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
+                                             step_end=30)
+    finally:
+        E.hoist_constants = True
+    assert torch.equal(outs[True].pred_pose, outs[False].pred_pose)
+    assert torch.equal(outs[True].vis_dict["action"], outs[False].vis_dict["action"])

@@ -20,12 +20,36 @@ class AddNaviLatent(nn.Module):
             self.mlp_in = MLP([in_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
             self.mlp = MLP([2 * hidden_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
 
-    def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None, mask_is_valid: bool = False):
+    def emit_embed(self, ch: Chain, z: Tensor, out: Tensor):
+        """mlp_in(z) alone -> out [rows, d] (before the validity mask): for inputs that stay the same over a whole rollout (the
+        latent) the engine evaluates this once and hands the result to `emit(..., z_embedded=...)` every step."""
+        d = self.hidden_dim
+        l_in = [t[0] for t in self.mlp_in.linear_layers()]
+        pad = ((self.in_dim + 15) // 16) * 16
+        ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)
+        ch.linear(BUF0, 0, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
+        ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
+        ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        ch.store(BUF0, 2 * d, d, out)
+
+    def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None, mask_is_valid: bool = False,
+             z_embedded: Optional[Tensor] = None):
         """x in BUF1[:, 0:d] (updated in place). z either already in BUF0[:, d:2d] (z=None) or loaded from `z`
-        [rows, in_dim]. Uses BUF0 columns [0, 4d)."""
+        [rows, in_dim], or given as `z_embedded` = mlp_in(z) [rows, d] (emit_embed; same values, three stages fewer).
+        Uses BUF0 columns [0, 4d)."""
         d = self.hidden_dim
         l_in, l_mlp = [t[0] for t in self.mlp_in.linear_layers()], [t[0] for t in self.mlp.linear_layers()]
         assert len(l_in) == 3 and len(l_mlp) == 3, "default n_layer = 3"
+        if z_embedded is not None:
+            ch.load(z_embedded, BUF0, 2 * d, n=d)
+            ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
+            ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
+            ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
+            ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
+            ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
+            ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
+            ch.add(BUF0, 3 * d, BUF1, 0, d)
+            return
         if z is not None:
             pad = ((self.in_dim + 15) // 16) * 16
             ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)

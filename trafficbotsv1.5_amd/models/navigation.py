@@ -28,12 +28,24 @@ class NaviEncoder(nn.Module):
         self.pose_emb = pose_rpe
         self.mlp_pe = MLP([pose_rpe.out_dim, hidden_dim], end_layer_activation=False)
 
-    def emit(self, ch: Chain, mp_feat_flat: Tensor, navi_row: Tensor, navi_pe: Tensor):
+    def emit_dest_feature(self, ch: Chain, mp_feat_flat: Tensor, navi_row: Tensor, out: Tensor):
+        """mlp_mp(mp_feature[dest]) -> out [rows, d]: fixed while the destinations are (a whole rollout with
+        pred_navi_after_reached off), so the engine evaluates it once and passes it to `emit(..., dest_feature=...)`."""
+        d = self.hidden_dim
+        l_mp = self.mlp_mp.linear_layers()[0][0]
+        ch.load(mp_feat_flat, BUF0, 0, n=d, row_idx=navi_row)
+        ch.linear(BUF0, 0, BUF0, d, l_mp.weight, l_mp.bias)
+        ch.store(BUF0, d, d, out)
+
+    def emit(self, ch: Chain, mp_feat_flat: Tensor, navi_row: Tensor, navi_pe: Tensor, dest_feature: Optional[Tensor] = None):
         """navi feature -> BUF0[:, d:2d]: mlp_mp(mp_feature[dest]) + mlp_pe(pe(rel pose of dest)). navigation.py:65-79."""
         d = self.hidden_dim
         l_mp, l_pe = self.mlp_mp.linear_layers()[0][0], self.mlp_pe.linear_layers()[0][0]
-        ch.load(mp_feat_flat, BUF0, 0, n=d, row_idx=navi_row)
-        ch.linear(BUF0, 0, BUF0, d, l_mp.weight, l_mp.bias)
+        if dest_feature is not None:
+            ch.load(dest_feature, BUF0, d, n=d)
+        else:
+            ch.load(mp_feat_flat, BUF0, 0, n=d, row_idx=navi_row)
+            ch.linear(BUF0, 0, BUF0, d, l_mp.weight, l_mp.bias)
         ch.load(navi_pe, BUF0, 0, n=d)
         ch.linear(BUF0, 0, BUF0, d, l_pe.weight, l_pe.bias, accum=True)
 

@@ -91,7 +91,7 @@ class TrafficBots(nn.Module):
     def agent_policy(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, ag_type_idx: Tensor,
                      ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
                      tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor],
-                     aux_stream=None) -> None:
+                     aux_stream=None, rollout_consts: Optional[Dict[str, Tensor]] = None) -> None:
         """The agent half (traffic_bots.py:200-221): agent tokens attending to agents / map / tl K/V tables `tl_kv`, then
         navi + latent + action head -> out['action_mean']."""
         n, A, W = hist_valid.shape
@@ -107,11 +107,31 @@ class TrafficBots(nn.Module):
         navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)
         ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
         ch.load(feat, BUF1, 0, n=d)
-        self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe)
+        rc = rollout_consts or {}
+        self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe,
+                               dest_feature=rc.get("dest_feature"))
         self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
-        self.add_latent.emit(ch, latent_invalid, ag_latent)
+        self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"))
         self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
         ch.run(n * A)
+
+    @torch.no_grad()
+    def rollout_constants(self, ag_latent: Tensor, dest: Tensor, mp_tokens: Dict[str, Tensor], mp_batch_div: int = 1) -> Dict[str, Tensor]:
+        """What the heads chain would recompute identically at every step of a rollout: mlp_in(latent) of `add_latent` and
+        mlp_mp(map feature of the destination) of the navi encoder (latent and destination are fixed per rollout:
+        waymo_motion.py:232-311 with pred_navi_after_reached off). Same kernels, same values - evaluated once."""
+        n, A = dest.shape
+        d, dev, M = self.hidden_dim, ag_latent.device, mp_tokens["mp_token_pose"].shape[1]
+        lat = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+        ch = Chain(16, 4 * d + 4)
+        self.add_latent.emit_embed(ch, ag_latent.reshape(n * A, -1).float().contiguous(), lat)
+        ch.run(n * A)
+        rows = ((torch.arange(n, device=dev) // mp_batch_div).unsqueeze(1) * M + dest).reshape(-1).to(torch.int32).contiguous()
+        dst = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+        ch = Chain(16, 4 * d + 4)
+        self.navi_encoder.emit_dest_feature(ch, mp_tokens["mp_token_feature"].reshape(-1, d), rows, dst)
+        ch.run(n * A)
+        return {"latent_embedded": lat, "dest_feature": dst}
 
     # ------------------------------------------------------------------ reference per-step API
     def init(self) -> None:

@@ -13,6 +13,7 @@ reference's >= 19 host synchronisations per step (SURVEY.md Appx D.1) are gone: 
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -34,6 +35,19 @@ def _state_bits(one_hot: Tensor) -> Tensor:
 
 class RolloutEngine:
     lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
+    hoist_constants = os.environ.get("TBX_NO_HOIST") is None  # False: the heads chain re-embeds the latent / destination feature every step (same values)
+
+    _streams: Dict[int, tuple] = {}
+
+    @classmethod
+    def _side_streams(cls, dev):
+        """One (lights, K-nearest) stream pair per device for every engine of the process: engines of one process run one
+        after the other, and torch hands out its 32 pool streams round-robin, so a fresh pair per rollout would soon share
+        streams with unrelated work."""
+        key = torch.device(dev).index or 0
+        if key not in cls._streams:
+            cls._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return cls._streams[key]
 
     def __init__(self, model, dynamics, device) -> None:
         self.model, self.dyn, self.dev = model, dynamics, device
@@ -113,7 +127,9 @@ class RolloutEngine:
         self.graph = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
-        self.side, self.aux = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.side, self.aux = self._side_streams(dev)
+        # per-rollout constants of the heads chain (embedded latent, destination feature): once, not every step
+        self.consts = self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div) if self.hoist_constants else None
         self._tl_ahead(0)
 
     @torch.no_grad()
@@ -152,7 +168,7 @@ class RolloutEngine:
             self._tl_ahead(1 - p)
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
-                                self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux)
+                                self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux, rollout_consts=self.consts)
         main.wait_stream(self.side)
         hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
         self.parity = 1 - p
