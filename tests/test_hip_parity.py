@@ -276,3 +276,55 @@ def test_packed_weight_image_equals_row_major_linear(hip, dev, rows, k, n, group
     ws = w.reshape(groups, k, n) if wt else w.reshape(groups, n, k).transpose(1, 2)
     ref = torch.einsum("rgk,gkn->rgn", xs.double(), ws.double()).reshape(rows, groups * n) + bias.double()
     torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["rel", "emb", "rel_dropout"])
+def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mode):
+    """Grids of >= 4096 rows run one wavefront per row, smaller ones four wavefronts per row merged through LDS (checked
+    against the oracle above): the same 4096 rows as one launch and as four 1024-row launches must agree - two segments with
+    shared tables (batch_div), masked pairs, a row without a valid target, in-register and materialised embeddings, and the
+    dropout mask (keyed by the launch-local row index, hence compared on the first quarter only)."""
+    g = torch.Generator().manual_seed(12)
+    n, S, T1, T2, K1, K2, div = 32, 128, 128, 96, 25, 9, 8
+    rows = n * S
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    qbuf = torch.randn(rows, 640, generator=g).to(dev)
+    bias = torch.randn(128, generator=g).to(dev)
+    kv1 = torch.randn(n * T1, 256, generator=g).to(dev)
+    kv2 = torch.randn((n // div) * T2, 512, generator=g).to(dev)  # shared by `div` batches, K | V inside a wider table
+    idx1 = torch.randint(0, T1, (n, S, K1), generator=g).to(torch.int32).to(dev)
+    idx2 = torch.randint(0, T2, (n, S, K2), generator=g).to(torch.int32).to(dev)
+    inv1 = (torch.rand(n, S, K1, generator=g) < 0.3).to(torch.uint8)
+    inv2 = (torch.rand(n, S, K2, generator=g) < 0.3).to(torch.uint8)
+    inv1[3, 5], inv2[3, 5] = 1, 1  # a row without any valid target
+    inv1, inv2 = inv1.to(dev), inv2.to(dev)
+    rel1 = torch.cat([(torch.rand(n, S, K1, 2, generator=g) - 0.5) * 300, (torch.rand(n, S, K1, 1, generator=g) - 0.5) * 6.28], -1).to(dev)
+    rel2 = torch.cat([(torch.rand(n, S, K2, 2, generator=g) - 0.5) * 300, (torch.rand(n, S, K2, 1, generator=g) - 0.5) * 6.28], -1).to(dev)
+    fx, fy = pe.pe_xy.freqs, pe.pe_yaw.freqs
+    emb = mode == "emb"
+    if emb:
+        e1 = pe(rel1[..., :2], rel1[..., 2:3]).contiguous()
+        e2 = pe(rel2[..., :2], rel2[..., 2:3]).contiguous()
+    drop = (0.2, torch.tensor([987654321012345], dtype=torch.int64, device=dev), 5) if mode == "rel_dropout" else None
+
+    def run(b0, nb):
+        sl = slice(b0, b0 + nb)
+        seg1 = hip.Seg(kv1[b0 * T1:(b0 + nb) * T1], 0, 128, T1, idx1[sl].contiguous(), inv1[sl].contiguous(),
+                       emb=e1[sl].contiguous() if emb else None, rel=None if emb else rel1[sl].contiguous())
+        seg2 = hip.Seg(kv2[(b0 // div) * T2:((b0 + nb) // div) * T2], 128, 384, T2, idx2[sl].contiguous(), inv2[sl].contiguous(),
+                       emb=e2[sl].contiguous() if emb else None, rel=None if emb else rel2[sl].contiguous(), batch_div=div)
+        out = torch.empty(nb * S, 640, device=dev)
+        flag = torch.empty(nb * S, dtype=torch.uint8, device=dev)
+        hip.knarpe_attn(qbuf[b0 * S:(b0 + nb) * S], 0, 128, bias, nb, S, [seg1, seg2], out, flag, None if emb else fx, None if emb else fy,
+                        drop=drop)
+        return out, flag
+
+    big, flag_big = run(0, n)                      # 4096 rows: a wave per row
+    parts = [run(b0, 8) for b0 in range(0, n, 8)]  # 1024 rows each: four waves per row
+    n_cmp = 1 if drop is not None else len(parts)  # the dropout counter uses the launch's own row numbering
+    small = torch.cat([p[0] for p in parts[:n_cmp]])
+    flag_small = torch.cat([p[1] for p in parts[:n_cmp]])
+    assert torch.equal(flag_big[:small.shape[0] // 1], flag_small) if n_cmp == len(parts) else torch.equal(flag_big[:1024], flag_small)
+    assert int(flag_big.sum()) == 1
+    torch.testing.assert_close(big[:small.shape[0]], small, rtol=2e-4, atol=2e-5)
