@@ -168,7 +168,8 @@ enum {
   TBX_F_ROW_IDX = 16, /* row_of(g) = ((const int32_t*)p1)[g]  (LOAD gather) */
   TBX_F_ROW_BATCH_MOD = 32, /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
   TBX_F_WPACK = 64,   /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
-  TBX_F_MASK_INV = 128 /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
+  TBX_F_MASK_INV = 128, /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
+  TBX_F_WSPLIT = 512    /* LINEAR + TBX_F_WPACK: p0 is a tbx_pack_weight_split() image: split-bf16, three products on the bf16 MFMA */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };
@@ -192,6 +193,11 @@ typedef struct tbx_stage {
  * TBX_F_WPACK (their p1 / ld / TBX_F_WT are ignored). */
 int64_t tbx_pack_weight_size(int n, int k, int groups);
 int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
+/* Same image size and layout, but the 16 bytes of a (lane, k-block) hold the four weights as bf16 hi (8 B) + bf16 lo = bf16(w -
+ * hi) (8 B). Stages flagged TBX_F_WPACK | TBX_F_WSPLIT split the activations the same way in registers and form
+ * a_hi w_hi + a_hi w_lo + a_lo w_hi on v_mfma_f32_16x16x16_bf16 (fp32 accumulation): ~1e-5 relative error instead of the
+ * exact-fp32 MFMA's ~1e-7, at 1/16 of the matrix-core time (the fp32 MFMA is the floor of a 16-row stage: 0.85 of 2.9 us). */
+int tbx_pack_weight_split(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 
 /* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,

@@ -278,6 +278,33 @@ def test_packed_weight_image_equals_row_major_linear(hip, dev, rows, k, n, group
     torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,k,n,groups,wt,tile", [(64, 128, 128, 1, False, 16), (40, 20, 5, 1, False, 16), (16, 512, 128, 1, False, 16),
+                                                     (70, 32, 128, 4, True, 16), (33, 128, 32, 4, False, 32), (5000, 128, 384, 1, False, 32)])
+def test_split_bf16_linear_close_to_exact_fp32_linear(hip, dev, rows, k, n, groups, wt, tile):
+    """TBX_F_WSPLIT (tbx_pack_weight_split image, three bf16 MFMA products with fp32 accumulation): within 3e-5 of the
+    magnitude sum_k |x_k w_k| + |b| of the exact result (bf16 hi + lo keeps 16 mantissa bits of each operand; the dropped
+    lo*lo term is 2^-18 of a product), opt-in through Chain.split_bf16 / TBX_SPLIT_BF16=1."""
+    g = torch.Generator().manual_seed(rows + k + n)
+    x = torch.randn(rows, groups * k if groups > 1 and not wt else max(k, groups * k), generator=g)
+    w = torch.randn(groups * (k if wt else n), n if wt else k, generator=g) * 0.1
+    bias = torch.randn(groups * n, generator=g)
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    out = torch.zeros(rows, groups * n, device=dev)
+    ch = hip.Chain(tile, 1028 if tile == 16 else 388)  # LDS bound: (2 ldw + 260) * tile_rows * 4 <= 160 KiB
+    ch.split_bf16 = True
+    ch.load(xd, hip.BUF0, 0, n=xd.shape[1], pad_to=((xd.shape[1] + 15) // 16) * 16)
+    ch.linear(hip.BUF0, 0, hip.BUF1, 0, wd, bd, wt=wt, groups=groups, src_stride=k if groups > 1 else 0,
+              dst_stride=n if groups > 1 else 0)
+    ch.store(hip.BUF1, 0, groups * n, out)
+    ch.run(rows)
+    xs = x[:, :groups * k].reshape(rows, groups, k).double()
+    ws = (w.reshape(groups, k, n) if wt else w.reshape(groups, n, k).transpose(1, 2)).double()
+    ref = torch.einsum("rgk,gkn->rgn", xs, ws).reshape(rows, groups * n) + bias.double()
+    mag = torch.einsum("rgk,gkn->rgn", xs.abs(), ws.abs()).reshape(rows, groups * n) + bias.double().abs()
+    err = (out.cpu().double() - ref).abs()
+    assert float((err / mag).max()) < 3e-5, float((err / mag).max())
+
+
 @pytest.mark.parametrize("mode", ["rel", "emb", "rel_dropout"])
 def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mode):
     """Grids of >= 4096 rows run one wavefront per row, smaller ones four wavefronts per row merged through LDS (checked

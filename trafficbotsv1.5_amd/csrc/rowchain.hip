@@ -27,6 +27,9 @@ struct RowchainArgs {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 // Pointers decoded from the LDS-resident program are generic to the compiler; loads through them would be FLAT
 // instructions, which also count against lgkmcnt and so serialise with every LDS wait. These casts state what the ABI
@@ -233,6 +236,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
   float4(&cur)[CH] = wa.w;
   float4 nxt[CH];
   float cb = wa.bias;
+  const bool split = (s.flags & TBX_F_WSPLIT) != 0;
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
     const int n0 = (ti - grp * n_tiles) * 16;
@@ -254,7 +258,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
       kb_next = nx.kblocks;
     }
     const float nb = gld1(nbase + (kb_next > 0 ? kb_next : kblocks) * 256, (uint32_t)lane * 4u);
-    f32x4 acc[MT];
+    f32x4 acc[MT], acc_x[MT], acc_y[MT];  // acc_x / acc_y: the two cross products of the split path
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -262,6 +266,8 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
         float c0 = cb;
         if (accum && col_ok) c0 += dst[(m * 16 + g * 4 + r) * lds_d + col];
         acc[m][r] = c0;
+        acc_x[m][r] = 0.f;
+        acc_y[m][r] = 0.f;
       }
     }
     for (int c0 = 0; c0 < kblocks; c0 += CH) {
@@ -270,18 +276,48 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
       const int kb_left = last ? kb_next : kblocks - (c0 + CH);
 #pragma unroll
       for (int q = 0; q < CH; ++q) nxt[q] = gld4(pn + (q < kb_left ? q : 0) * 256, (uint32_t)lane * 16u);
+      if (split) {
+        // three-product split-bf16 (TBX_F_WSPLIT): a = a_hi + a_lo, w = w_hi + w_lo in bf16 (RNE, ~2^-17 relative), the
+        // products hi*hi + hi*lo + lo*hi on the 16x-faster v_mfma_f32_16x16x16_bf16 with fp32 accumulation (lo*lo, ~2^-18
+        // of a product on average, is dropped). The A fragment of a k-block - the lane's four k values - is exactly the
+        // bf16 MFMA's A operand, the packed image's 16 bytes exactly its B operands.
 #pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        if (c0 + q < kblocks) {
-          const int k0 = (c0 + q) * 16 + g * 4;
-          const float4 bv = cur[q];
+        for (int q = 0; q < CH; ++q) {
+          if (c0 + q < kblocks) {
+            const int k0 = (c0 + q) * 16 + g * 4;
+            const float4 bw = cur[q];
+            const s16x4_t bh = __builtin_bit_cast(s16x4_t, make_float2(bw.x, bw.y));
+            const s16x4_t bl = __builtin_bit_cast(s16x4_t, make_float2(bw.z, bw.w));
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+              const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+              const f32x2_t a01 = {av.x, av.y}, a23 = {av.z, av.w};
+              const bf16x2_t h01 = __builtin_convertvector(a01, bf16x2_t), h23 = __builtin_convertvector(a23, bf16x2_t);
+              const f32x2_t r01 = a01 - __builtin_convertvector(h01, f32x2_t), r23 = a23 - __builtin_convertvector(h23, f32x2_t);
+              const bf16x2_t l01 = __builtin_convertvector(r01, bf16x2_t), l23 = __builtin_convertvector(r23, bf16x2_t);
+              struct P2 { bf16x2_t a, b; };
+              const s16x4_t ah = __builtin_bit_cast(s16x4_t, (P2{h01, h23}));
+              const s16x4_t al = __builtin_bit_cast(s16x4_t, (P2{l01, l23}));
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[m], 0, 0, 0);
+              acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc_x[m], 0, 0, 0);
+              acc_y[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc_y[m], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          if (c0 + q < kblocks) {
+            const int k0 = (c0 + q) * 16 + g * 4;
+            const float4 bv = cur[q];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float4 av = *(const float4*)(src + (m * 16 + j) * lds_s + k0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[m], 0, 0, 0);
+            }
           }
         }
       }
@@ -293,7 +329,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[m][r];
+        float v = acc[m][r] + (acc_x[m][r] + acc_y[m][r]);
         if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
         // columns of the last partial tile beyond n are zero-filled (unless accumulating or grouped) so that the next
         // stage may read a K padded to 16
@@ -679,8 +715,10 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
 
 // Image layout per 16-column tile (tile index = grp*n_tiles + tile): kblocks x [64 lanes][4] weights, where lane l / slot t
 // holds W_grp[col = tile*16 + (l & 15)][kk = kb*16 + (l >> 4)*4 + t], then [64] bias values bias[grp*n + col(l)].
+// split == 0: the fp32 image. split != 0: the same 16 bytes per (lane, k-block) hold the four weights as bf16 hi (8 bytes)
+// followed by bf16 lo = bf16(w - hi) (8 bytes): operands of the three-product bf16 MFMA path (TBX_F_WSPLIT).
 __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld,
-                                   int groups, int wt, float* __restrict__ out, int64_t total) {
+                                   int groups, int wt, int split, float* __restrict__ out, int64_t total) {
   const int n_tiles = (n + 15) / 16, kblocks = (k + 15) / 16;
   const int tstride = kblocks * 256 + 64;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -690,8 +728,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
     float v = 0.f;
     if (o < kblocks * 256) {
       const int t = o & 3, lane = (o >> 2) & 63, kb = o >> 8;
-      const int col = tile * 16 + (lane & 15), kk = kb * 16 + (lane >> 4) * 4 + t;
-      if (col < n && kk < k) v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+      const int col = tile * 16 + (lane & 15);
+      auto wv = [&](int tt) {
+        const int kk = kb * 16 + (lane >> 4) * 4 + tt;
+        return (col < n && kk < k) ? (wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk]) : 0.f;
+      };
+      if (!split) {
+        v = wv(t);
+      } else {  // dword t of the lane's 16 bytes: t = 0,1 -> hi pairs (0,1),(2,3); t = 2,3 -> lo pairs
+        const int p = (t & 1) * 2;
+        const float a = wv(p), b = wv(p + 1);
+        const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+        __bf16 x = ha, y = hb;
+        if (t >= 2) {
+          x = (__bf16)(a - (float)ha);
+          y = (__bf16)(b - (float)hb);
+        }
+        const uint32_t bits = (uint32_t)__builtin_bit_cast(unsigned short, x) | ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
+        v = __uint_as_float(bits);
+      }
     } else {
       const int col = tile * 16 + ((o - kblocks * 256) & 15);
       if (bias != nullptr && col < n) v = bias[(int64_t)grp * n + col];
@@ -767,15 +822,27 @@ extern "C" int64_t tbx_pack_weight_size(int n, int k, int groups) {
   return (int64_t)groups * ((n + 15) / 16) * (((k + 15) / 16) * 256 + 64);
 }
 
-extern "C" int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
-                               void* stream) {
+namespace {
+int pack_weight_impl(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, int split, float* out,
+                     void* stream) {
   if (w == nullptr || out == nullptr || n <= 0 || k <= 0 || ld <= 0 || groups <= 0) return TBX_ERR_ARG;
   if (groups > 1 && n % 16 != 0) return TBX_ERR_UNSUPPORTED;
   const int64_t total = tbx_pack_weight_size(n, k, groups);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out,
-                     total);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, split,
+                     out, total);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
+                               void* stream) {
+  return pack_weight_impl(w, bias, n, k, ld, groups, wt, 0, out, stream);
+}
+
+extern "C" int tbx_pack_weight_split(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
+                                     void* stream) {
+  return pack_weight_impl(w, bias, n, k, ld, groups, wt, 1, out, stream);
 }
 
 extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,

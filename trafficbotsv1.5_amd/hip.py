@@ -19,6 +19,7 @@ HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
 ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
+F_WSPLIT = 512
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -97,6 +98,7 @@ def load():
     lib.tbx_pack_weight_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_size.restype = C.c_int64
     lib.tbx_pack_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_pack_weight_split.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
@@ -109,7 +111,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -350,15 +352,17 @@ def filter_futures(flags, col_bit: int, ag_role_any, n_scene: int, n_k: int, t_s
     return score, idx, trajs
 
 
-def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1) -> torch.Tensor:
+def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
+                  split: bool = False) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
     per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused
-    otherwise - chains are rebuilt every eager step - and dropped with the parameter."""
+    otherwise - chains are rebuilt every eager step - and dropped with the parameter.
+    split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
     base = w._base if w._base is not None else w
     cache = base.__dict__.setdefault("_tbx_packed", {})
     bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey)
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split)
     stamp = (w._version, w.data_ptr(), None if bias is None else bias._version)
     hit = cache.get(key)
     if hit is not None and hit[0] == stamp:
@@ -371,8 +375,8 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     if size <= 0:
         _check(int(size), "tbx_pack_weight_size")
     out = torch.empty(size, dtype=torch.float32, device=w.device)
-    _check(lib.tbx_pack_weight(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()),
-           "tbx_pack_weight")
+    fn = lib.tbx_pack_weight_split if split else lib.tbx_pack_weight
+    _check(fn(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
     cache[key] = (stamp, out)
     return out
 
@@ -399,8 +403,12 @@ class Chain:
         self._keep = []
         self._arr = None
         self.pack_weights = Chain.pack_default
+        self.split_bf16 = Chain.split_default
 
     pack_default = True  # LINEAR weights are handed to the kernel as tbx_pack_weight images (row-major kept for tests)
+    # packed LINEAR stages on the three-product split-bf16 MFMA path (~1e-5 relative instead of exact fp32; include/tbx_hip.h
+    # TBX_F_WSPLIT). Off by default: the exact-fp32 MFMA is the parity path; TBX_SPLIT_BF16=1 turns it on for a process.
+    split_default = os.environ.get("TBX_SPLIT_BF16", "0") == "1"
 
     def _add(self, **kw):
         p0, p1, p2 = kw.pop("p0", None), kw.pop("p1", None), kw.pop("p2", None)
@@ -447,7 +455,9 @@ class Chain:
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         assert (dst == GLOBAL) == (out is not None)
         if self.pack_weights:
-            w, flags = packed_weight(w, bias, wt, groups), (flags & ~F_WT) | F_WPACK
+            w, flags = packed_weight(w, bias, wt, groups, self.split_bf16), (flags & ~F_WT) | F_WPACK
+            if self.split_bf16:
+                flags |= F_WSPLIT
             return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
                              act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=None, p2=out,
                              ld2=0 if out is None else self._rows2d(out).stride(0),
