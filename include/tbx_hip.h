@@ -133,6 +133,46 @@ int tbx_knarpe_attn_bwd_gather(const float* qbuf, int ldq, int q_off, int qt_off
                                const int32_t* const* inv_ptr /* host array of n_seg device pointers */,
                                const int32_t* const* inv_list /* host array */, float* coef, void* stream);
 
+/* Time-batched forms (training, train_graph.training_rollout_batched): the reference's training rollout detaches the policy
+ * inputs of every closed-loop step (waymo_motion.py:206-311 with training=True: the only cross-step gradient path is the
+ * dynamics chain), so once the states of the T steps are known the T policy evaluations of a scene are independent and are
+ * evaluated - and differentiated - as T consecutive batch entries: batch entry b is step time0 + b % time_batch of scene
+ * b / time_batch. The dropout mask is then keyed by (seed, call, scene row, step, slot, head): the batched call draws exactly
+ * the masks of time_batch per-step calls made with (time_batch = 1, time0 = step). (1, 0) = the entry points above. */
+int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo,
+                                   uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                   const uint64_t* drop_seed /* device */, uint32_t drop_call, int time_batch, int time0,
+                                   void* stream);
+int tbx_knarpe_attn_bwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                   int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo,
+                                   float* dqbuf, float* const* dkv /* host array */, float* dbias_k, const float* freqs_xy,
+                                   const float* freqs_yaw, float p_drop, const uint64_t* drop_seed /* device */,
+                                   uint32_t drop_call, int time_batch, int time0, void* stream);
+int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                  int n_src, const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo,
+                                  float* dqbuf, float* const* dkv /* host array */, float* dbias_k, const float* freqs_xy,
+                                  const float* freqs_yaw, float p_drop, const uint64_t* drop_seed /* device */,
+                                  uint32_t drop_call, int time_batch, int time0, const int32_t* const* inv_ptr /* host array */,
+                                  const int32_t* const* inv_list /* host array */, float* coef, void* stream);
+
+/* Elementwise dropout with the same kind of key (replaces F.dropout at modules/mlp.py:60-61, transformer_rpe.py:56-60,
+ * 93-131 in training): y[row, c] = x[row, c] * keep / (1 - p), keep = hash(seed, site, step, scene row, c) >= p * 2^32.
+ * x, y [rows, cols] contiguous (y may alias x); rows_per_scene rows per batch entry; batch entry b = row / rows_per_scene is
+ * step time0 + b % time_batch of scene b / time_batch (see above), scene row = (b / time_batch) * rows_per_scene + row %
+ * rows_per_scene. Its own backward (the gradient takes the same mask). `site` distinguishes the dropout sites of a step. */
+int tbx_keyed_dropout(const float* x, float* y, int64_t rows, int cols, int rows_per_scene, float p_drop,
+                      const uint64_t* drop_seed /* device */, uint32_t site, int time_batch, int time0, void* stream);
+
+/* Weight gradient of a LINEAR over very many rows (training; autograd of F.linear at modules/mlp.py:69-72,
+ * attention_rpe.py:95-120,190, transformer_rpe.py:119-131 in the time-batched pass): dw[n,k] = dy[rows,n]^T x[rows,k],
+ * db[n] = sum_rows dy (db may be NULL). dy / x row-major with leading dimensions ld_dy / ld_x; n, k and both ld multiples of 4,
+ * 16-byte aligned. Exact-fp32 MFMA; `scratch` holds splits x (n*k + n) floats (splits from tbx_linear_wgrad_splits, any value
+ * >= 1 is legal), summed by a second kernel in a fixed order (deterministic). */
+int tbx_linear_wgrad_splits(int64_t rows, int n, int k);
+int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                     float* scratch, int splits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
  * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per

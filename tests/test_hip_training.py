@@ -207,3 +207,146 @@ def test_attention_probability_dropout_vs_explicit_mask(tb):
     o0, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), None, *[t.detach() for t in leaves_h[2:]])
     o1, _ = TG.KnarpeAttnFn.apply(leaves_h[0].detach(), leaves_h[1].detach(), n, S, meta, (None, None), (0.0, None, 0), *[t.detach() for t in leaves_h[2:]])
     assert torch.equal(o0, o1)
+
+
+def test_keyed_dropout_time_batched_masks_equal_per_step_masks(tb):
+    """tbx_keyed_dropout: the call over T time-batched entries per scene ([scene][step] order) draws exactly the masks of T
+    per-step calls keyed with (time_batch = 1, time0 = step); rate ~ p, scale 1 / (1 - p), the backward re-applies the mask,
+    other sites / seeds give other masks."""
+    dev = torch.device("cuda:0")
+    hip = import_module("trafficbots_amd.hip")
+    TG = import_module("trafficbots_amd.train_graph")
+    n, T, R, cols, p = 3, 5, 14, 36, 0.2
+    seed = torch.tensor([0x0123_4567_89AB_CDEF], dtype=torch.int64, device=dev)
+    x = torch.randn(n, T, R, cols, device=dev)
+    yb = hip.keyed_dropout(x.reshape(n * T * R, cols), p, seed, 7, R, T, 1).view(n, T, R, cols)
+    for t in range(T):
+        yt = hip.keyed_dropout(x[:, t].reshape(n * R, cols).contiguous(), p, seed, 7, R, 1, 1 + t).view(n, R, cols)
+        assert torch.equal(yt, yb[:, t])
+    kept = yb != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    torch.testing.assert_close(yb[kept], x[kept] / (1 - p))
+    assert not torch.equal(kept[:, 0], kept[:, 1])  # steps differ
+    assert not torch.equal(kept, hip.keyed_dropout(x.reshape(-1, cols), p, seed, 8, R, T, 1).view(n, T, R, cols) != 0)
+    assert not torch.equal(kept, hip.keyed_dropout(x.reshape(-1, cols), p, seed + 1, 7, R, T, 1).view(n, T, R, cols) != 0)
+    odd = torch.randn(6, 7, device=dev)  # scalar path (cols % 4 != 0)
+    assert abs(float((hip.keyed_dropout(odd, 0.5, seed, 1, 2) != 0).float().mean()) - 0.5) < 0.3
+    xg = x.reshape(-1, cols).clone().requires_grad_(True)
+    y = TG.KeyedDropoutFn.apply(xg, p, seed, 7, R, T, 1)
+    y.sum().backward()
+    torch.testing.assert_close(xg.grad, kept.reshape(-1, cols).float() / (1 - p))
+
+
+def test_attention_dropout_time_batched_call_equals_per_step_calls(tb):
+    """tbx_knarpe_attn_fwd_dropout_tb: one call over n x T entries (a scene's T steps consecutive, the scene's table shared
+    through batch_div = T) == T calls of n entries keyed (1, step), forward and backward."""
+    dev = torch.device("cuda:0")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(3)
+    n, T, S, Tt, K, p, call = 2, 3, 9, 13, 5, 0.3, 11
+    qbuf = torch.randn(n, T, S, 640, generator=g).to(dev)
+    bias_k = torch.randn(128, generator=g).to(dev)
+    kv = torch.randn(n * Tt, 256, generator=g).to(dev)  # one table per scene
+    idx = torch.randint(0, Tt, (n, T, S, K), generator=g).to(torch.int32).to(dev)
+    inv = (torch.rand(n, T, S, K, generator=g) < 0.2).to(torch.uint8).to(dev)
+    emb = torch.randn(n, T, S, K, 128, generator=g).to(dev)
+    seed = torch.tensor([77], dtype=torch.int64, device=dev)
+    w = torch.randn(n, T, S, 640, generator=g).to(dev)
+    qb, kvb = qbuf.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    meta = [(idx.reshape(n * T, S, K).contiguous(), inv.reshape(n * T, S, K).contiguous(), emb.reshape(n * T, S, K, 128).contiguous(), None, Tt, T)]
+    out_b, _ = TG.KnarpeAttnFn.apply(qb.reshape(n * T * S, 640), bias_k, n * T, S, meta, (None, None), (p, seed, call, T, 1), kvb)
+    (out_b * w.reshape(-1, 640)).sum().backward()
+    gq, gkv = torch.zeros_like(qbuf), torch.zeros_like(kv)
+    for t in range(T):
+        qs, kvs = qbuf[:, t].clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        m = [(idx[:, t].contiguous(), inv[:, t].contiguous(), emb[:, t].contiguous(), None, Tt, 1)]
+        out_s, _ = TG.KnarpeAttnFn.apply(qs.reshape(n * S, 640), bias_k, n, S, m, (None, None), (p, seed, call, 1, 1 + t), kvs)
+        assert torch.equal(out_s.view(n, S, 640), out_b.view(n, T, S, 640)[:, t])
+        (out_s * w[:, t].reshape(-1, 640)).sum().backward()
+        gq[:, t], gkv = qs.grad, gkv + kvs.grad
+    torch.testing.assert_close(qb.grad, gq, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(kvb.grad, gkv, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout):
+    """training_rollout_batched (no-grad stepping pass + ONE differentiated policy batch over all steps + the dynamics chain) vs
+    training_rollout (autograd through 30 sequential policy steps): same loss terms and parameter gradients - also in train mode
+    with every dropout live, since the keyed masks of the batched pass are those of the per-step pass."""
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    cfg = tb.config.default_model_cfg(n_tgt_knn=4)
+    if not dropout:
+        cfg["tf_cfg"]["dropout_p"] = 0.0
+        cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
+        cfg["add_navi_latent"]["mlp_dropout_p"] = 0.0
+    scfg = tb.config.default_sim_cfg(p_training_rollout_prior=0.0)
+    scfg["teacher_forcing_training"]["prob_forcing_agent"] = 0.0
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    scfg["time_step_end"] = 30
+    wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg)
+    tb.utils.det_fill(wm.model, 0)
+    with torch.no_grad():  # damped action head: the free-running closed loop is chaotic otherwise (DESIGN.md §2)
+        for k, p in wm.model.named_parameters():
+            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                p.mul_(0.02)
+    wm = wm.to(dev).train()
+    wm.attn_dropout_seed = torch.tensor([4242], dtype=torch.int64, device=dev)
+    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=1).items()}
+    noise = torch.randn(2, 8, wm.model.latent_encoder.out_dim, generator=torch.Generator().manual_seed(5)).to(dev)
+    use_prior = torch.zeros((), dtype=torch.bool, device=dev)
+    res = {}
+    for mode in (True, False):
+        wm.time_batched_training = mode
+        wm.zero_grad(set_to_none=True)
+        loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0, noise=noise, use_prior=use_prior)
+        loss.backward()
+        res[mode] = ({k: float(v) for k, v in wm.last_metrics.items()}, {k: p.grad.clone() for k, p in wm.model.named_parameters() if p.grad is not None})
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, res[True][0][k], v)
+    assert res[True][1].keys() == res[False][1].keys()
+    for k, gs in res[False][1].items():
+        gb = res[True][1][k]
+        assert float((gb - gs).abs().max()) <= 1e-3 * max(float(gs.abs().max()), 1e-7), k
+
+
+@pytest.mark.parametrize("rows,n,k,ld_pad", [(20000, 128, 128, 0), (70001, 640, 128, 0), (33333, 128, 640, 0), (16390, 64, 20, 12), (50000, 4, 256, 0),
+                                            (17, 128, 64, 0), (300000, 256, 128, 0)])
+def test_linear_wgrad_vs_float64(tb, rows, n, k, ld_pad):
+    """tbx_linear_wgrad (dW = dY^T X, db = sum dY over 10^4..10^5 rows; exact-fp32 MFMA, fixed summation order) vs float64:
+    relative to sum |dy||x| the error stays at fp32 accumulation level; deterministic across calls; strided x (a column slice)."""
+    dev = torch.device("cuda:0")
+    hip = import_module("trafficbots_amd.hip")
+    g = torch.Generator().manual_seed(rows + n + k)
+    dy = torch.randn(rows, n, generator=g).to(dev)
+    xs = torch.randn(rows, k + ld_pad, generator=g).to(dev)
+    x = xs[:, :k]
+    assert hip.linear_wgrad_ok(dy, x)
+    dw, db = hip.linear_wgrad(dy, x, True)
+    dw2, db2 = hip.linear_wgrad(dy, x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    ref = dy.double().t() @ x.double()
+    mag = dy.double().abs().t() @ x.double().abs()
+    assert float(((dw.double() - ref).abs() / mag).max()) < 2e-6
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-5, atol=1e-5 * rows ** 0.5)
+    dw3, none = hip.linear_wgrad(dy, x, False)
+    assert none is None and torch.equal(dw3, dw)
+
+
+def test_tall_linear_fn_gradients(tb):
+    """TallLinearFn (library GEMMs for y and dx, tbx_linear_wgrad for dW / db) vs autograd of F.linear."""
+    dev = torch.device("cuda:0")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(40, 500, 128, generator=g).to(dev)
+    w, b = (torch.randn(256, 128, generator=g) * 0.1).to(dev), torch.randn(256, generator=g).to(dev)
+    go = torch.randn(40, 500, 256, generator=g).to(dev)
+    outs = []
+    for fn in (TG.linear, torch.nn.functional.linear):
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(xx, ww, bb)
+        (y * go).sum().backward()
+        outs.append((y.detach(), xx.grad, ww.grad, bb.grad))
+    assert isinstance(TG.linear(x.requires_grad_(True), w, b).grad_fn, TG.TallLinearFn._backward_cls)
+    for a, r in zip(*outs):
+        torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))

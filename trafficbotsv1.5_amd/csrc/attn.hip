@@ -40,6 +40,10 @@ struct AttnArgs {
   const uint64_t* drop_seed;
   uint32_t drop_call, drop_thresh;  // call id mixed into the seed; drop when hash < thresh = p * 2^32
   float drop_scale;                 // 1 / (1 - p)
+  // time-batched calls (training: the T closed-loop steps of a scene evaluated as T consecutive batch entries): batch entry
+  // b is step drop_time0 + b % T of scene b / T, and the mask is keyed by (scene row, step) - the masks of the batched call
+  // are exactly those of T per-step calls with (T = 1, time0 = step). T = 1, time0 = 0: the plain (row) key.
+  int drop_time_batch, drop_time0;
 };
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -109,14 +113,18 @@ __device__ __forceinline__ void sincos_rev(float arg, float* sn, float* cs) {
 
 // Dropout mask bit of (row, global target slot t < 128, head): lowbias32 finaliser over a counter keyed by the seed.
 struct DropKey {
-  uint32_t lo, hi;
-  __device__ __forceinline__ void init(const AttnArgs& a) {
+  uint32_t lo, hi, krow;
+  // row: the wave's source row (uniform); b = row / n_src
+  __device__ __forceinline__ void init(const AttnArgs& a, int row, int b) {
     const uint64_t sd = *a.drop_seed;
-    lo = (uint32_t)sd ^ (a.drop_call * 0x85EBCA6Bu);
-    hi = (uint32_t)(sd >> 32) + a.drop_call * 0xC2B2AE35u;
+    const int sc = b / a.drop_time_batch;
+    const uint32_t ts = (uint32_t)(a.drop_time0 + (b - sc * a.drop_time_batch));
+    krow = (uint32_t)(sc * a.n_src + (row - b * a.n_src));
+    lo = (uint32_t)sd ^ (a.drop_call * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
+    hi = (uint32_t)(sd >> 32) + a.drop_call * 0xC2B2AE35u + ts * 0x165667B1u;
   }
-  __device__ __forceinline__ bool keep(uint32_t row, uint32_t t, uint32_t h, uint32_t thresh) const {
-    uint32_t x = ((row * 128u + t) * 4u + h) ^ lo;
+  __device__ __forceinline__ bool keep(uint32_t t, uint32_t h, uint32_t thresh) const {
+    uint32_t x = ((krow * 128u + t) * 4u + h) ^ lo;
     x *= 0x9E3779B1u;
     x ^= hi;
     x ^= x >> 16;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   // last pair (finite data) and, like masked targets, enter the online softmax with probability exactly 0 and a rescale
   // factor of exactly 1 - no per-lane branches, no zero fills, no per-lane segment selects.
   DropKey dk;
-  if constexpr (DROP) dk.init(a);
+  if constexpr (DROP) dk.init(a, row, b);
   int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
   for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
         l_run[h] += pr;  // the normaliser is that of the un-dropped softmax
         float pd = pr;
-        if constexpr (DROP) pd = dk.keep((uint32_t)row, (uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
+        if constexpr (DROP) pd = dk.keep((uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
         fma4(oacc[h], pd, v[h]);  // K/V channel block st == h belongs to head h
         eacc[h].fma(pd, e);
       }
@@ -380,8 +388,8 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   const int bidx = row / a.n_src;
   const bool drop = a.drop_thresh != 0u;
   DropKey dkey;
-  dkey.lo = dkey.hi = 0u;
-  if (drop) dkey.init(a);
+  dkey.lo = dkey.hi = dkey.krow = 0u;
+  if (drop) dkey.init(a, row, bidx);
   const int k0 = a.seg[0].k;
   const int ktot = k0 + (a.n_seg > 1 ? a.seg[1].k : 0);
   const int s8 = lane & 7, tg = lane >> 3;
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
           for (int h = 0; h < NH; ++h) {
             // out = sum_t a_t m_t / (1 - p) (v_t | e_t): the mask factor multiplies d(a_t); kept in k_s for the dV weights
             float kf = 1.f;
-            if (drop) kf = dkey.keep((uint32_t)row, (uint32_t)t, (uint32_t)h, a.drop_thresh) ? a.drop_scale : 0.f;
+            if (drop) kf = dkey.keep((uint32_t)t, (uint32_t)h, a.drop_thresh) ? a.drop_scale : 0.f;
             p_s[rib][h][t] = sc[h];
             k_s[rib][h][t] = kf;
             d_s[rib][h][t] = da[h] * kf;
@@ -665,12 +673,14 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
 }  // namespace
 
 namespace {
-int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t drop_call) {
+int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t drop_call, int time_batch, int time0) {
   a.drop_seed = drop_seed;
   a.drop_call = drop_call;
   a.drop_thresh = 0u;
   a.drop_scale = 1.f;
-  if (p_drop < 0.f || p_drop >= 1.f) return TBX_ERR_ARG;
+  a.drop_time_batch = time_batch;
+  a.drop_time0 = time0;
+  if (p_drop < 0.f || p_drop >= 1.f || time_batch < 1 || time0 < 0) return TBX_ERR_ARG;
   if (p_drop > 0.f) {
     if (!drop_seed) return TBX_ERR_ARG;
     const double th = (double)p_drop * 4294967296.0;
@@ -681,16 +691,17 @@ int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t d
 }
 }  // namespace
 
-extern "C" int tbx_knarpe_attn_fwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
-                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
-                                           uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
-                                           const uint64_t* drop_seed, uint32_t drop_call, void* stream) {
+extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                              int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
+                                              uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                              const uint64_t* drop_seed, uint32_t drop_call, int time_batch, int time0,
+                                              void* stream) {
   if (!out || !row_no_valid) return TBX_ERR_ARG;
   if (((uintptr_t)out) & 15) return TBX_ERR_ALIGN;
   AttnArgs a;
   int rc = fill_args(a, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
   if (rc != TBX_OK) return rc;
-  rc = set_dropout(a, p_drop, drop_seed, drop_call);
+  rc = set_dropout(a, p_drop, drop_seed, drop_call, time_batch, time0);
   if (rc != TBX_OK) return rc;
   a.out = out;
   a.row_no_valid = row_no_valid;
@@ -714,21 +725,21 @@ extern "C" int tbx_knarpe_attn_fwd_dropout(const float* qbuf, int ldq, int q_off
 extern "C" int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
                                    int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
                                    uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, void* stream) {
-  return tbx_knarpe_attn_fwd_dropout(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid,
-                                     freqs_xy, freqs_yaw, 0.f, nullptr, 0u, stream);
+  return tbx_knarpe_attn_fwd_dropout_tb(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid,
+                                        freqs_xy, freqs_yaw, 0.f, nullptr, 0u, 1, 0, stream);
 }
 
-extern "C" int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
-                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
-                                           int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
-                                           const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
-                                           void* stream) {
+extern "C" int tbx_knarpe_attn_bwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                              int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                              int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                              const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                              int time_batch, int time0, void* stream) {
   if (!dout || !dqbuf || !dkv || !dbias_k) return TBX_ERR_ARG;
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
   if (rc != TBX_OK) return rc;
-  rc = set_dropout(b.f, p_drop, drop_seed, drop_call);
+  rc = set_dropout(b.f, p_drop, drop_seed, drop_call, time_batch, time0);
   if (rc != TBX_OK) return rc;
   for (int i = 0; i < n_seg; ++i) {
     if (!dkv[i]) return TBX_ERR_ARG;
@@ -743,18 +754,18 @@ extern "C" int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
-extern "C" int tbx_knarpe_attn_bwd_gather(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
-                                          int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
-                                          int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
-                                          const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
-                                          const int32_t* const* inv_ptr, const int32_t* const* inv_list, float* coef,
-                                          void* stream) {
+extern "C" int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                             int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                             int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                             const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                             int time_batch, int time0, const int32_t* const* inv_ptr,
+                                             const int32_t* const* inv_list, float* coef, void* stream) {
   if (!dout || !dqbuf || !dkv || !dbias_k || !inv_ptr || !inv_list || !coef) return TBX_ERR_ARG;
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
   if (rc != TBX_OK) return rc;
-  rc = set_dropout(b.f, p_drop, drop_seed, drop_call);
+  rc = set_dropout(b.f, p_drop, drop_seed, drop_call, time_batch, time0);
   if (rc != TBX_OK) return rc;
   DkvArgs d;
   d.qbuf = qbuf, d.dout = dout, d.coef = coef;
@@ -792,6 +803,35 @@ extern "C" int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt
                                    int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout, int ldo, float* dqbuf,
                                    float* const* dkv, float* dbias_k, const float* freqs_xy, const float* freqs_yaw,
                                    void* stream) {
-  return tbx_knarpe_attn_bwd_dropout(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, dout, ldo, dqbuf, dkv,
-                                     dbias_k, freqs_xy, freqs_yaw, 0.f, nullptr, 0u, stream);
+  return tbx_knarpe_attn_bwd_dropout_tb(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, dout, ldo, dqbuf, dkv,
+                                        dbias_k, freqs_xy, freqs_yaw, 0.f, nullptr, 0u, 1, 0, stream);
+}
+
+// The per-call forms (time_batch = 1, time0 = 0): the mask is keyed by (call, row, target slot, head) alone.
+extern "C" int tbx_knarpe_attn_fwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
+                                           uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                                           const uint64_t* drop_seed, uint32_t drop_call, void* stream) {
+  return tbx_knarpe_attn_fwd_dropout_tb(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid,
+                                        freqs_xy, freqs_yaw, p_drop, drop_seed, drop_call, 1, 0, stream);
+}
+
+extern "C" int tbx_knarpe_attn_bwd_dropout(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                           int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                           int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                           const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                           void* stream) {
+  return tbx_knarpe_attn_bwd_dropout_tb(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, dout, ldo, dqbuf, dkv,
+                                        dbias_k, freqs_xy, freqs_yaw, p_drop, drop_seed, drop_call, 1, 0, stream);
+}
+
+extern "C" int tbx_knarpe_attn_bwd_gather(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
+                                          int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, const float* dout,
+                                          int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
+                                          const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
+                                          const int32_t* const* inv_ptr, const int32_t* const* inv_list, float* coef,
+                                          void* stream) {
+  return tbx_knarpe_attn_bwd_gather_tb(qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, dout, ldo, dqbuf, dkv,
+                                       dbias_k, freqs_xy, freqs_yaw, p_drop, drop_seed, drop_call, 1, 0, inv_ptr, inv_list, coef,
+                                       stream);
 }

@@ -1,0 +1,164 @@
+// Weight gradient of a tall-skinny LINEAR (tbx_linear_wgrad, include/tbx_hip.h): dW[N,K] = dY[R,N]^T X[R,K], db[N] = sum_r dY,
+// with R = 10^5..10^6 rows (the time-batched training pass: every closed-loop step of every scene is a row block) and
+// N, K <= a few hundred. The library GEMM for this shape (one or two output tiles, reduction depth R) ran at 2.5-6.7 ms per call;
+// the shape is HBM-bound (both operands are read once: 2 GB at R = 2 M, N = K = 128) with the exact-fp32 MFMA as second bound.
+//
+// A wavefront owns a 64 x 64 block of dW over a range of rows. Per 4 rows every lane loads ONE float4 of dY and ONE of X
+// (lane l: row l >> 4, columns 4 (l & 15) .. +3 of the block: 256 B contiguous per row) and issues 16 v_mfma_f32_16x16x4_f32:
+// MFMA (t, u) takes component t of the dY float4 as A[i = l & 15][kk = l >> 4] and component u of the X float4 as B, i.e. it
+// accumulates the strided 16 x 16 tile dW[n0 + 4 i + t][k0 + 4 j + u] - 16 independent accumulators (64 VGPRs), 2 loads per
+// 16 MFMAs, no LDS. Row ranges (splits) go to blockIdx.y; partial blocks land in a scratch buffer and a second kernel sums
+// them (deterministic: no float atomics). The 4 waves of a workgroup take a 2 x 2 group of blocks and share the rows (L1 / L2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define TBX_GLOBAL __attribute__((address_space(1)))
+
+struct WgradArgs {
+  const float* dy;
+  const float* x;
+  float* part;  // [splits][n*k + n]
+  int64_t rows, rows_per_split;
+  int ld_dy, ld_x, n, k, groups_k, with_db;
+};
+
+constexpr int P = 4;  // 4-row groups loaded ahead per pipeline stage (16 rows)
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
+
+__global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int gk = blockIdx.x % a.groups_k, gn = blockIdx.x / a.groups_k;
+  const int n0 = (gn * 2 + (wave & 1)) * 64, k0 = (gk * 2 + (wave >> 1)) * 64;
+  if (n0 >= a.n || k0 >= a.k) return;  // no barriers below: a wave may leave
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_split;
+  const int64_t r1 = r0 + a.rows_per_split < a.rows ? r0 + a.rows_per_split : a.rows;
+  const int rr = lane >> 4, c = (lane & 15) * 4;
+  const bool n_ok = n0 + c < a.n, k_ok = k0 + c < a.k;  // n, k are multiples of 4: a float4 is wholly inside or outside
+  const float* py = a.dy + n0 + c;
+  const float* px = a.x + k0 + c;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = zero;
+  f32x4 bsum = zero;
+  const bool want_db = a.with_db && k0 == 0;
+  f32x4 ya[P], xa[P], yb[P], xb[P];
+  auto load = [&](f32x4(&y)[P], f32x4(&x)[P], int64_t r) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int64_t row = r + q * 4 + rr;
+      const bool live = row < r1;
+      y[q] = (live && n_ok) ? ldg4(py + row * a.ld_dy) : zero;
+      x[q] = (live && k_ok) ? ldg4(px + row * a.ld_x) : zero;
+    }
+  };
+  load(ya, xa, r0);
+  for (int64_t r = r0; r < r1; r += 4 * P) {
+    load(yb, xb, r + 4 * P);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      if (want_db) bsum += ya[q];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[q][t], xa[q][u], acc[t][u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) ya[q] = yb[q], xa[q] = xb[q];
+  }
+  // acc[t][u][reg] at lane l = dW[n0 + 4 ((l >> 4) * 4 + reg) + t][k0 + 4 (l & 15) + u]
+  float* part = a.part + (int64_t)blockIdx.y * ((int64_t)a.n * a.k + a.n);
+  if (k_ok) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + 4 * (rr * 4 + reg) + t;
+        if (n < a.n) {
+          f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+          *(TBX_GLOBAL f32x4*)(part + (int64_t)n * a.k + k0 + c) = v;
+        }
+      }
+  }
+  if (want_db) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = bsum[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      bsum[e] = v;
+    }
+    if (rr == 0 && n_ok) *(TBX_GLOBAL f32x4*)(part + (int64_t)a.n * a.k + n0 + c) = bsum;
+  }
+}
+
+// out[e] = sum_g part[g][e], e < total (dW then db): a workgroup per 64 outputs, its 4 waves take a quarter of the splits each
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t total, int nk,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float s[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float v = 0.f;
+  if (e < total) {
+    float v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    int g = wave;
+    for (; g + 12 < splits; g += 16) {
+      v += part[(int64_t)g * total + e];
+      v2 += part[(int64_t)(g + 4) * total + e];
+      v3 += part[(int64_t)(g + 8) * total + e];
+      v4 += part[(int64_t)(g + 12) * total + e];
+    }
+    for (; g < splits; g += 4) v += part[(int64_t)g * total + e];
+    v = (v + v2) + (v3 + v4);
+  }
+  s[wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && e < total) {
+    const float r = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+    if (e < nk)
+      dw[e] = r;
+    else if (db != nullptr)
+      db[e - nk] = r;
+  }
+}
+
+}  // namespace
+
+extern "C" int tbx_linear_wgrad_splits(int64_t rows, int n, int k) {
+  if (rows <= 0 || n <= 0 || k <= 0) return TBX_ERR_ARG;
+  const int groups = ((n + 127) / 128) * ((k + 127) / 128);
+  int64_t s = 1024 / groups;  // ~1024 workgroups: 2-4 wavefronts per SIMD on the 256 CUs
+  if (s < 1) s = 1;
+  const int64_t cap = (rows + 63) / 64;  // at least 64 rows per split
+  if (s > cap) s = cap;
+  return (int)s;
+}
+
+extern "C" int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                                float* scratch, int splits, void* stream) {
+  if (!dy || !x || !dw || !scratch || rows <= 0 || n <= 0 || k <= 0 || splits <= 0) return TBX_ERR_ARG;
+  if ((n & 3) || (k & 3) || (ld_dy & 3) || (ld_x & 3) || ld_dy < n || ld_x < k) return TBX_ERR_UNSUPPORTED;
+  if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)scratch)) & 15) return TBX_ERR_ALIGN;
+  WgradArgs a;
+  a.dy = dy, a.x = x, a.part = scratch, a.rows = rows, a.ld_dy = ld_dy, a.ld_x = ld_x, a.n = n, a.k = k;
+  a.rows_per_split = (((rows + splits - 1) / splits + 4 * P - 1) / (4 * P)) * (4 * P);
+  a.groups_k = (k + 127) / 128;
+  a.with_db = db != nullptr;
+  const int groups = ((n + 127) / 128) * a.groups_k;
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
+  if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
+  const int64_t total = (int64_t)n * k + n;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, hs, scratch, splits, total, n * k, dw, db);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

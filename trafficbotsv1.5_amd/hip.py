@@ -91,6 +91,16 @@ def load():
                                                 f32, vp, C.c_uint32, vp]
     lib.tbx_knarpe_attn_bwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                                 C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, vp]
+    lib.tbx_knarpe_attn_fwd_dropout_tb.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp,
+                                                   f32, vp, C.c_uint32, i32, i32, vp]
+    lib.tbx_knarpe_attn_bwd_dropout_tb.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
+                                                   C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, i32, i32, vp]
+    lib.tbx_knarpe_attn_bwd_gather_tb.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
+                                                  C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, i32, i32,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), vp, vp]
+    lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
+    lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
+    lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
     lib.tbx_knn_inverse.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd_gather.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                                C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, C.POINTER(C.c_void_p),
@@ -111,7 +121,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -195,15 +205,60 @@ class Seg:
                        self.n_tgt, self.batch_div, self.k)
 
 
+def _drop_args(drop):
+    if drop is None:
+        return 0.0, None, 0, 1, 0
+    p, seed, call = drop[:3]
+    tb, t0 = (drop[3], drop[4]) if len(drop) > 3 else (1, 0)
+    return p, seed, call, int(tb), int(t0)
+
+
+def keyed_dropout(x: torch.Tensor, p: float, seed: torch.Tensor, site: int, rows_per_scene: int, time_batch: int = 1,
+                  time0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tbx_keyed_dropout on x viewed as [rows, cols = x.shape[-1]] (contiguous); rows_per_scene = rows per batch entry."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols if cols else 0
+    y = torch.empty_like(x) if out is None else out
+    rc = load().tbx_keyed_dropout(_ptr(x), _ptr(y), rows, cols, rows_per_scene, float(p), _ptr(seed, torch.int64), int(site),
+                                  int(time_batch), int(time0), stream_ptr())
+    _check(rc, "tbx_keyed_dropout")
+    return y
+
+
+def linear_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:
+    """Shapes tbx_linear_wgrad takes: 2-D row-major fp32 views, n, k and both leading dimensions multiples of 4, 16-B aligned."""
+    return (dy.dim() == 2 and x.dim() == 2 and dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0
+            and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
+    """(dw [n,k], db [n] | None) = (dy^T x, sum_rows dy) for dy [rows,n], x [rows,k] (tbx_linear_wgrad)."""
+    rows, n = dy.shape
+    k = x.shape[1]
+    lib = load()
+    splits = lib.tbx_linear_wgrad_splits(rows, n, k)
+    if splits <= 0:
+        _check(int(splits), "tbx_linear_wgrad_splits")
+    scratch = torch.empty(splits, n * k + n, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if want_db else None
+    _check(lib.tbx_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits,
+                                stream_ptr()), "tbx_linear_wgrad")
+    return dw, db
+
+
 def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid,
                 freqs_xy=None, freqs_yaw=None, drop=None):
-    """drop = None, or (p, seed int64[1] device tensor, call id): attention-probability dropout (training)."""
+    """drop = None, or (p, seed int64[1] device tensor, call id[, time_batch, time0]): attention-probability dropout
+    (training; the last two for time-batched calls, include/tbx_hip.h)."""
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
-    p, seed, call = drop if drop is not None else (0.0, None, 0)
-    rc = load().tbx_knarpe_attn_fwd_dropout(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+    p, seed, call, tb, t0 = _drop_args(drop)
+    rc = load().tbx_knarpe_attn_fwd_dropout_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
                                             n_batch, n_src, arr, len(segs), _ptr(out, torch.float32), out.stride(0),
                                             _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy), _cptr(freqs_yaw), float(p),
-                                            _ptr(seed, torch.int64), int(call), stream_ptr())
+                                            _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd")
 
 
@@ -211,11 +266,11 @@ def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_s
                     dkv: Sequence[torch.Tensor], dbias_k, freqs_xy=None, freqs_yaw=None, drop=None):
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
     dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
-    p, seed, call = drop if drop is not None else (0.0, None, 0)
-    rc = load().tbx_knarpe_attn_bwd_dropout(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+    p, seed, call, tb, t0 = _drop_args(drop)
+    rc = load().tbx_knarpe_attn_bwd_dropout_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
                                             n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
                                             _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy),
-                                            _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), stream_ptr())
+                                            _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd")
 
 
@@ -239,24 +294,24 @@ def knarpe_attn_bwd_gather(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: i
     ip = (C.c_void_p * len(segs))(*[_cptr(p, torch.int32) for p, _ in inv])
     il = (C.c_void_p * len(segs))(*[_cptr(l, torch.int32) for _, l in inv])
     coef = torch.empty(n_batch * n_src, sum(s.k for s in segs), 8, dtype=torch.float32, device=qbuf.device)
-    p, seed, call = drop if drop is not None else (0.0, None, 0)
-    rc = load().tbx_knarpe_attn_bwd_gather(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
+    p, seed, call, tb, t0 = _drop_args(drop)
+    rc = load().tbx_knarpe_attn_bwd_gather_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
                                            n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
                                            _ptr(dqbuf, torch.float32), dk, _ptr(dbias_rows, torch.float32), _cptr(freqs_xy),
-                                           _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), ip, il, _ptr(coef),
+                                           _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, ip, il, _ptr(coef),
                                            stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd_gather")
 
 
-def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n_head: int = 4) -> torch.Tensor:
+def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n_head: int = 4, step: int = 0) -> torch.Tensor:
     """Host restatement of the kernels' counter-based mask (csrc/attn.hip DropKey): bool [n_rows, n_head, k_tot] - for tests
     and for anyone who needs the mask a (seed, call) pair produces."""
     import numpy as np
 
     sd = np.uint64(seed % (1 << 64))
     m32 = np.uint64(0xFFFFFFFF)
-    lo = np.uint32(sd & m32) ^ np.uint32((call * 0x85EBCA6B) & 0xFFFFFFFF)
-    hi = np.uint32((int((sd >> np.uint64(32)) & m32) + call * 0xC2B2AE35) & 0xFFFFFFFF)
+    lo = np.uint32(sd & m32) ^ np.uint32((call * 0x85EBCA6B) & 0xFFFFFFFF) ^ np.uint32((step * 0x27D4EB2F) & 0xFFFFFFFF)
+    hi = np.uint32((int((sd >> np.uint64(32)) & m32) + call * 0xC2B2AE35 + step * 0x165667B1) & 0xFFFFFFFF)
     row = np.arange(n_rows, dtype=np.uint32)[:, None, None]
     h = np.arange(n_head, dtype=np.uint32)[None, :, None]
     t = np.arange(k_tot, dtype=np.uint32)[None, None, :]

@@ -9,6 +9,15 @@ next step; the formulation (K/V projected before the gather, lin
 inference engine, so both are checked against the same oracle.
 
 Everything takes the reference-named nn.Modules as parameter containers (same state dict as inference).
+
+Time-batched rollout (`training_rollout_batched`, the default): the reference detaches the policy inputs of every
+closed-loop step (waymo_motion.py:206-311 with training=True), so the only gradient path across steps is the dynamics
+chain. The rollout therefore runs twice: (1) step by step WITHOUT autograd, recording each step's (detached) policy inputs;
+(2) the 90 policy evaluations of a scene as ONE batch of 90 x n_scene entries WITH autograd (map K/V tables shared through
+`batch_div`, dropout masks keyed by (site, step, row, column) so that the batched pass draws the masks of the sequential
+one), followed by the tiny per-step dynamics / reward chain on the batched means. Same loss and gradients as stepping with
+autograd (`training_rollout`, kept as the checked reference of the restructure), but ~25 large launches per layer
+instead of 90 x as many small ones.
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -22,6 +31,45 @@ from .hip import Seg
 from .models.modules.distributions import DestCategorical, DiagGaussian
 
 D, NH, DH = 128, 4, 32
+
+
+# ------------------------------------------------------------------------------------------------ dense contractions
+WGRAD_MIN_ROWS = 16384  # from here on dW = dY^T X is a reduction over so many rows that the library GEMM has 1-2 output tiles
+
+
+class TallLinearFn(torch.autograd.Function):
+    """F.linear over very many rows (the time-batched pass: [n_scene * T * tokens (* window), k]). Forward and input gradient
+    are library GEMMs in the form the library is fast at (row-major activations x K-contiguous weights: 60-100 TF/s fp32
+    measured; the input gradient therefore multiplies by an explicit W^T copy instead of the library's NN kernel), the weight /
+    bias gradient - a reduction over 10^5..10^6 rows into a [n, k] block - is tbx_linear_wgrad (csrc/wgrad.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = F.linear(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            if not dy2.is_contiguous():
+                dy2 = dy2.contiguous()
+            if hip.linear_wgrad_ok(dy2, x2):
+                dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b)
+            else:
+                dw, db = dy2.t() @ x2, (dy2.sum(0) if ctx.has_b else None)
+        return dx, dw, db
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """F.linear; over >= WGRAD_MIN_ROWS rows with gradients on: TallLinearFn."""
+    if torch.is_grad_enabled() and x.is_cuda and x.numel() // max(x.shape[-1], 1) >= WGRAD_MIN_ROWS and (w.requires_grad or x.requires_grad):
+        return TallLinearFn.apply(x, w, b)
+    return F.linear(x, w, b)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -84,9 +132,46 @@ class Targets:
 # cache for its 90 closed-loop steps (the same weights serve every step), so the folding - and its backward - run once per
 # training step and each attention call is [one GEMM -> tbx_knarpe_attn -> one GEMM]. None = no caching (fold per call).
 _FOLD_CACHE: Optional[dict] = None
-# Attention-probability dropout of a training step: {"seed": int64[1] device tensor, "call": running call id}. The seed lives
-# on the device (a captured step draws new masks when the host rewrites it between replays); None = no dropout.
+# Dropout of a training step: {"seed": int64[1] device tensor, "call": running attention call id, "site": running id of the
+# elementwise dropout sites, "n_batch" / "tb" / "t0": batch entries of the current scope and its time batching (include/
+# tbx_hip.h: entry b = step t0 + b % tb of scene b / tb)}. The seed lives on the device (a captured step draws new masks when
+# the host rewrites it between replays); None = no dropout. Every mask is a hash of (seed, site | call, step, scene row, ...),
+# so the time-batched pass of the rollout re-draws the masks of the step-by-step pass.
 _DROP: Optional[dict] = None
+_POLICY_SITE0 = 1 << 20  # site / call ids of a policy step restart here every step (the step number is part of the key)
+
+
+class _DropScope:
+    def __init__(self, n_batch: int, tb: int = 1, t0: int = 0, restart: Optional[int] = None):
+        self.kw = dict(n_batch=n_batch, tb=tb, t0=t0)
+        self.restart = restart
+
+    def __enter__(self):
+        if _DROP is not None:
+            self.saved = dict(_DROP)
+            _DROP.update(self.kw)
+            if self.restart is not None:
+                _DROP["site"] = _DROP["call"] = self.restart
+
+    def __exit__(self, *exc):
+        if _DROP is not None:
+            site, call = _DROP["site"], _DROP["call"]
+            _DROP.update(self.saved)
+            if self.restart is None:  # ids keep running across the step's non-policy scopes
+                _DROP["site"], _DROP["call"] = site, call
+        return False
+
+
+class KeyedDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, site, rows_per_scene, tb, t0):
+        ctx.args = (p, seed, site, rows_per_scene, tb, t0)
+        return hip.keyed_dropout(x.contiguous(), p, seed, site, rows_per_scene, tb, t0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, site, rows_per_scene, tb, t0 = ctx.args
+        return hip.keyed_dropout(dy.contiguous(), p, seed, site, rows_per_scene, tb, t0), None, None, None, None, None, None
 
 
 def fold_attention_weights(attn):
@@ -94,8 +179,9 @@ def fold_attention_weights(attn):
       [q | qt] = x W_in^T + b_in        with  W_in  = [I | B_k]^T W_q           (640 x 128),  b_in  = [I | B_k]^T b_q
       y        = [sum a v | sum a e] W_out^T + b_out  with  W_out = W_o [I ; B_v]^T (128 x 640), b_out = W_o b_rpe_v + b_o
     B_k (128 x 512) / B_v (512 x 128): per-head blocks of linear_rpe's key / value halves. Also the K|V slice of in_proj."""
-    if _FOLD_CACHE is not None and id(attn) in _FOLD_CACHE:
-        return _FOLD_CACHE[id(attn)]
+    ck = (id(attn), torch.is_grad_enabled())  # a no-grad pass must not hand its graph-less tensors to a differentiated one
+    if _FOLD_CACHE is not None and ck in _FOLD_CACHE:
+        return _FOLD_CACHE[ck]
     W, b = attn.in_proj_weight, attn.in_proj_bias
     wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
     eye = torch.eye(D, dtype=W.dtype, device=W.device)
@@ -106,14 +192,14 @@ def fold_attention_weights(attn):
     f = dict(w_in=sel_in.t() @ W[:D], b_in=sel_in.t() @ b[:D], w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
              w_out=attn.out_proj_weight @ sel_out, b_out=attn.out_proj_weight @ br[D:] + attn.out_proj_bias)
     if _FOLD_CACHE is not None:
-        _FOLD_CACHE[id(attn)] = f
+        _FOLD_CACHE[ck] = f
     return f
 
 
 def kv_table(attn, norm, t: Targets) -> Tensor:
     """K|V table [tokens, 256] of a target set for one attention layer (LayerNorm + projection, before the gather)."""
     f = fold_attention_weights(attn)
-    make = lambda: F.linear(F.layer_norm(t.tokens, (D,), norm.weight, norm.bias, norm.eps) if norm is not None else t.tokens,
+    make = lambda: linear(F.layer_norm(t.tokens, (D,), norm.weight, norm.bias, norm.eps) if norm is not None else t.tokens,
                             f["w_kv"], f["b_kv"])
     if t.cache is None or t.key is None:
         return make()
@@ -126,20 +212,29 @@ def kv_table(attn, norm, t: Targets) -> Tensor:
 def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor], n: int, S: int) -> Tensor:
     """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source."""
     f = fold_attention_weights(attn)
-    qbuf = F.linear(xq, f["w_in"], f["b_in"])
+    qbuf = linear(xq, f["w_in"], f["b_in"])
     meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div, t.inv) for t in targets]
     freqs = next((t.freqs for t in targets if t.rel is not None), (None, None))
     drop = None
     if _DROP is not None and attn.training and attn.dropout_p > 0:
         _DROP["call"] += 1
-        drop = (float(attn.dropout_p), _DROP["seed"], _DROP["call"])
+        assert n == _DROP["n_batch"], "attention call outside its dropout scope"
+        drop = (float(attn.dropout_p), _DROP["seed"], _DROP["call"], _DROP["tb"], _DROP["t0"])
     out, flag = KnarpeAttnFn.apply(qbuf, f["bias_k"], n, S, meta, freqs, drop, *kvs)
-    y = F.linear(out, f["w_out"], f["b_out"])
+    y = linear(out, f["w_out"], f["b_out"])
     return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
 
 
 def _drop(x: Tensor, p: float, training: bool) -> Tensor:
-    return F.dropout(x, p, training) if (training and p > 0) else x
+    """F.dropout of the reference as tbx_keyed_dropout (x [..., cols], batch entries = the scope's n_batch)."""
+    if not (training and p > 0):
+        return x
+    if _DROP is None:  # outside a training step (unit tests of single modules): torch's generator
+        return F.dropout(x, p, True)
+    _DROP["site"] += 1
+    rows = x.numel() // x.shape[-1]
+    assert rows % _DROP["n_batch"] == 0
+    return KeyedDropoutFn.apply(x, float(p), _DROP["seed"], _DROP["site"], rows // _DROP["n_batch"], _DROP["tb"], _DROP["t0"])
 
 
 def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, self_knn, cross=None, p: float = 0.0,
@@ -160,8 +255,8 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
             s2 = ln(layer.norm1, x)
             ts = Targets(s2, n_tgt=S, **self_knn)
             x = x + _drop(attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S), p, training)
-        h = F.relu(F.linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias))
-        x = x + _drop(F.linear(_drop(h, p, training), layer.linear2.weight, layer.linear2.bias), p, training)
+        h = F.relu(linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias))
+        x = x + _drop(linear(_drop(h, p, training), layer.linear2.weight, layer.linear2.bias), p, training)
         x = x.masked_fill(inv, 0.0)
     return x
 
@@ -171,7 +266,7 @@ def mlp(m, x: Tensor, training: bool = False) -> Tensor:
     """modules/mlp.py:69-72 (Linear [+LN] [+ReLU] [+Dropout] per layer)."""
     p = m.dropout_p
     for lin, lnm, act in m.linear_layers():
-        x = F.linear(x, lin.weight, lin.bias)
+        x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
             x = F.layer_norm(x, lnm.weight.shape, lnm.weight, lnm.bias, lnm.eps)
         if act:
@@ -232,8 +327,24 @@ def tl_pre_compute(te, tl_valid, tl_attr, tl_pose, mp: Dict[str, Tensor]) -> Dic
     return t
 
 
+def expand_tl_tokens(te, t: Dict[str, Tensor], mp: Dict[str, Tensor], T: int) -> Dict[str, Tensor]:
+    """tl_pre_compute's per-scene dict for a time-batched call: batch entry b = scene b // T. Per-light tensors are repeated,
+    the K-nearest sets are searched again on the repeated poses (identical sets; the map tables stay per scene: div = T)."""
+    rep = lambda x: x.repeat_interleave(T, 0)
+    e = {k: rep(t[k]) for k in ("tl_token_valid", "tl_token_invalid", "tl_token_invalid_u8", "tl_token_pose", "tl_token_attr")}
+    e["tl_token_invalid_u8"], e["tl_token_pose"] = e["tl_token_invalid_u8"].contiguous(), e["tl_token_pose"].contiguous()
+    e["mp_feat_for_tl"], e["time_batch"] = t["mp_feat_for_tl"], T
+    e["tt"] = _knn(e["tl_token_pose"], e["tl_token_invalid_u8"], e["tl_token_pose"], e["tl_token_invalid_u8"], te.n_tgt_knn_tl2tl,
+                   te.dist_limit, te.pose_rpe)
+    e["tm"] = _knn(e["tl_token_pose"], e["tl_token_invalid_u8"], mp["mp_token_pose"], mp["mp_token_invalid_u8"], te.n_tgt_knn_tl2mp,
+                   te.dist_limit, te.pose_rpe, div=T)
+    e["_kv_cache"] = {}
+    return e
+
+
 def tl_encoder(te, hist_tl: Tensor, t: Dict[str, Tensor], training: bool) -> Tensor:
-    """hist_tl [n,L,W] u8 masks (0xFF missing) -> [n*L, 128]. traffic_light.py:184-246."""
+    """hist_tl [n,L,W] u8 masks (0xFF missing) -> [n*L, 128]. traffic_light.py:184-246. `t` = tl_pre_compute's dict, or
+    expand_tl_tokens' (n = scenes x time batch, the map tokens shared by the T entries of a scene)."""
     n, L, W = hist_tl.shape
     dev, d = hist_tl.device, te.hidden_dim
     ld = 16 if 5 + W <= 16 else 32
@@ -245,12 +356,14 @@ def tl_encoder(te, hist_tl: Tensor, t: Dict[str, Tensor], training: bool) -> Ten
     M = t["mp_feat_for_tl"].shape[1]
     mp_tokens = t["mp_feat_for_tl"].reshape(-1, d)
     return transformer_block(te.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, t["tt"],
-                             cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=t.get("_kv_cache"), key="tl2mp", **t["tm"])],
+                             cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=t.get("_kv_cache"), key="tl2mp",
+                                                          batch_div=t.get("time_batch", 1), **t["tm"])],
                              p=te.tf_tl2tlmp.dropout_p, training=training)
 
 
-def agent_encoder(ae, hist_valid, hist_pose, hist_motion, ag_attr6, mp, tl_inv_u8, tl_pose, tl_feat, training: bool):
-    """agent_encoder.py:114-178,321-387. hist_* [n,A,W(,3)] oldest first -> (feat [n*A,128], prep dict)."""
+def agent_encoder(ae, hist_valid, hist_pose, hist_motion, ag_attr6, mp, tl_inv_u8, tl_pose, tl_feat, training: bool, T: int = 1):
+    """agent_encoder.py:114-178,321-387. hist_* [n,A,W(,3)] oldest first -> (feat [n*A,128], prep dict). T > 1: time-batched
+    call, n = scenes x T, `mp` per scene (shared by a scene's T entries), the light tensors per entry."""
     n, A, W = hist_valid.shape
     dev, d = hist_pose.device, ae.hidden_dim
     prep = ae.alloc_prep(n, A, dev, with_heads=False)
@@ -258,14 +371,14 @@ def agent_encoder(ae, hist_valid, hist_pose, hist_motion, ag_attr6, mp, tl_inv_u
                    ae.pose_emb.out_dim, prep)
     tok_pose, tok_inv = prep["tok_pose"], prep["tok_invalid"]
     aa = _knn(tok_pose, tok_inv, tok_pose, tok_inv, ae.n_tgt_knn_ag2ag, ae.dist_limit, ae.pose_rpe)
-    am = _knn(tok_pose, tok_inv, mp["mp_token_pose"], mp["mp_token_invalid_u8"], ae.n_tgt_knn_ag2mp, ae.dist_limit, ae.pose_rpe)
+    am = _knn(tok_pose, tok_inv, mp["mp_token_pose"], mp["mp_token_invalid_u8"], ae.n_tgt_knn_ag2mp, ae.dist_limit, ae.pose_rpe, div=T)
     at = _knn(tok_pose, tok_inv, tl_pose, tl_inv_u8, ae.n_tgt_knn_ag2tl, ae.dist_limit, ae.pose_rpe)
     x = torch.cat([mlp(ae.input_encoder.mlp, prep["attr"][:, :ae.input_encoder.mlp.input_dim], training), prep["pe"]], -1)
     x = pointnet(ae.temp_encoder, x.view(n * A, W, d), prep["row_invalid"].view(n * A, W).bool(), training)
     M, L = mp["mp_token_pose"].shape[1], tl_pose.shape[1]
     mp_tokens = mp["mp_token_feature"].reshape(-1, d)
     x = transformer_block(ae.tf_ag2agmptl, x, tok_inv, n, A, aa,
-                          cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=mp.get("_kv_cache"), key="ag2mp", **am),
+                          cross=lambda layer: [Targets(mp_tokens, n_tgt=M, cache=mp.get("_kv_cache"), key="ag2mp", batch_div=T, **am),
                                                Targets(tl_feat, n_tgt=L, **at)],
                           p=ae.tf_ag2agmptl.dropout_p, training=training)
     return x, prep
@@ -278,18 +391,21 @@ def add_navi_latent(m, x: Tensor, z: Tensor, z_invalid: Tensor, training: bool) 
     return h + x
 
 
-def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, dest, navi_valid, tl_tokens, mp, training: bool):
-    """traffic_bots.py:188-221 -> (action mean [n,A,2], tl logits [n,L,5])."""
+def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, dest, navi_valid, tl_tokens, mp, training: bool,
+                T: int = 1):
+    """traffic_bots.py:188-221 -> (action mean [n,A,2], tl logits [n,L,5]). T > 1: time-batched call - every per-entry
+    argument has n = scenes x T entries ([scene][step] order), `mp` stays per scene and `tl_tokens` is expand_tl_tokens'."""
     hv, hp, hm, ht = hist
     n, A, W = hv.shape
     d = model.hidden_dim
     L = ht.shape[1]
+    assert tl_tokens.get("time_batch", 1) == T
     tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
     feat, _ = agent_encoder(model.ag_encoder, hv, hp, hm, ag_attr6, mp, tl_tokens["tl_token_invalid_u8"], tl_tokens["tl_token_pose"],
-                            tl_feat, training)
+                            tl_feat, training, T)
     # NaviEncoder (navigation.py:65-79): detached map feature of the destination + pose embedding of its relative pose
     ne = model.navi_encoder
-    bi = torch.arange(n, device=feat.device).unsqueeze(1)
+    bi = (torch.arange(n, device=feat.device) // T).unsqueeze(1)
     mpf = mp["mp_token_feature"].detach() if ne.dest_detach_mp_feature else mp["mp_token_feature"]
     gp = mp["mp_token_pose"][bi, dest]
     c, s = torch.cos(ag_pose[..., 2]), torch.sin(ag_pose[..., 2])
@@ -365,10 +481,14 @@ def _bits(one_hot: Tensor) -> Tensor:
     return (one_hot.to(torch.int32) * w).sum(-1).to(torch.uint8)
 
 
-def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
+def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int, policy=None, record: Optional[dict] = None,
+                     need_hist: bool = True) -> Dict[str, Tensor]:
     """Closed-loop training rollout (waymo_motion.py:206-311 with training=True: model inputs detached, the only
     cross-step gradient path is the dynamics chain). The per-step state machine is elementwise torch on [n,A] tensors
-    (it needs autograd); rule feedback = outside-map + dest-reached as in tbx_sim_step."""
+    (it needs autograd); rule feedback = outside-map + dest-reached as in tbx_sim_step.
+    policy(step, hist, valid, pose, navi_valid) -> (mean [n,A,2], logits [n,L,5]); None = policy_step with autograd, one step
+    at a time (the reference's order of evaluation). record: dict of lists that receives every step's policy inputs.
+    need_hist=False: the policy does not read the windows (they are not built)."""
     model, dyn, rc = wm.model, wm.dynamics, wm.hp.differentiable_reward
     gt_valid, gt_pose, gt_motion, tl_gt = b["gt/ag_valid"], b["gt/ag_pose"], b["gt/ag_motion"], b["gt/tl_state"]
     ag_type, ag_attr6, dest = b["ref/ag_type"], b["sc/ag_attr"].float().contiguous(), b["gt/ag_navi"]
@@ -397,13 +517,24 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
     ht = torch.full((n, L, W), 0xFF, dtype=torch.uint8, device=dev)
     tl_cur = tl_bits[:, :, 0]
     out = {k: [] for k in ("pred_valid", "pred_pose", "pred_motion", "tl_nll", "tl_nll_invalid", "reward", "reward_valid", "tf")}
+    if policy is None:
+        def policy(step, hist, valid_, pose_, navi_valid_):
+            with _DropScope(n, 1, step, restart=_POLICY_SITE0):
+                return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z, z_valid, dest, navi_valid_, tl_tokens, mp,
+                                   model.training)
     for step in range(1, step_end + 1):
-        hv = torch.cat([hv[:, :, 1:], valid.to(torch.uint8).unsqueeze(2)], 2)
-        hp = torch.cat([hp[:, :, 1:], pose.detach().unsqueeze(2)], 2)
-        hm = torch.cat([hm[:, :, 1:], motion.detach().unsqueeze(2)], 2)
-        ht = torch.cat([ht[:, :, 1:], tl_cur.unsqueeze(2)], 2)
-        mean, logits = policy_step(model, (hv.contiguous(), hp.contiguous(), hm.contiguous(), ht.contiguous()), ag_attr6, ag_type,
-                                   valid, pose.detach(), z, z_valid, dest, navi_valid, tl_tokens, mp, model.training)
+        hist = None
+        if need_hist:
+            hv = torch.cat([hv[:, :, 1:], valid.to(torch.uint8).unsqueeze(2)], 2)
+            hp = torch.cat([hp[:, :, 1:], pose.detach().unsqueeze(2)], 2)
+            hm = torch.cat([hm[:, :, 1:], motion.detach().unsqueeze(2)], 2)
+            ht = torch.cat([ht[:, :, 1:], tl_cur.unsqueeze(2)], 2)
+            hist = (hv.contiguous(), hp.contiguous(), hm.contiguous(), ht.contiguous())
+        if record is not None:
+            for k, v in (("hv", hist[0]), ("hp", hist[1]), ("hm", hist[2]), ("ht", hist[3]), ("valid", valid), ("pose", pose.detach()),
+                         ("navi_valid", navi_valid)):
+                record.setdefault(k, []).append(v)
+        mean, logits = policy(step, hist, valid, pose.detach(), navi_valid)
         inv1 = ~valid.unsqueeze(-1)
         action = (torch.tanh(mean) * lim).masked_fill(inv1, 0)
         acc, yr = action[..., 0], action[..., 1]
@@ -420,7 +551,8 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
         else:
             ov_log = torch.zeros_like(valid)
         with torch.no_grad():
-            tl_cur = tl_bits[:, :, step] if step < Tt else (1 << logits.argmax(-1)).to(torch.uint8)
+            if need_hist:
+                tl_cur = tl_bits[:, :, step] if step < Tt else (1 << logits.argmax(-1)).to(torch.uint8)
             x, y = pred_pose[..., 0], pred_pose[..., 1]
             out_now = ((x > bnd[:, 1:2]) | (x < bnd[:, 0:1]) | (y > bnd[:, 3:4]) | (y < bnd[:, 2:3])) & pred_valid
             outside = outside | out_now
@@ -453,6 +585,29 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
         valid = valid & ~dis
         navi_valid = navi_valid & ~reach_now
     return {k: torch.stack(v, 2) for k, v in out.items()}
+
+
+def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
+    """The same rollout, time-batched (module docstring): a step-by-step pass without autograd that records every step's
+    policy inputs, then the T policy evaluations of every scene as one differentiated batch of n x T entries in [scene][step]
+    order, then the per-step dynamics / reward chain on the batched means (the only cross-step gradient path)."""
+    model = wm.model
+    T = step_end
+    n = b["gt/ag_valid"].shape[0]
+    rec: Dict[str, List[Tensor]] = {}
+    with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
+        training_rollout(wm, b, dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={}), z.detach(), z_valid, tf_mask, step_end, record=rec)
+    st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
+    flat = lambda x: x.reshape(n * T, *x.shape[2:]).contiguous()
+    rep = lambda x: x.repeat_interleave(T, 0)
+    tl_T = expand_tl_tokens(model.tl_encoder, tl_tokens, mp, T)
+    with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
+        mean, logits = policy_step(model, (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["ht"])),
+                                   rep(b["sc/ag_attr"].float()).contiguous(), rep(b["ref/ag_type"]), flat(st["valid"]), flat(st["pose"]),
+                                   rep(z), rep(z_valid), rep(b["gt/ag_navi"]), flat(st["navi_valid"]), tl_T, mp, model.training, T=T)
+    mean, logits = mean.view(n, T, *mean.shape[1:]), logits.view(n, T, *logits.shape[1:])
+    return training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask, step_end, need_hist=False,
+                            policy=lambda step, hist, v, p, nv: (mean[:, step - 1], logits[:, step - 1]))
 
 
 def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussian, prior: DiagGaussian) -> Dict[str, Tensor]:
@@ -489,7 +644,7 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
         seed = getattr(wm, "attn_dropout_seed", None)  # a captured step owns a static seed tensor and refills it per replay
         if seed is None:
             seed = torch.empty(1, dtype=torch.int64, device=next(wm.model.parameters()).device).random_()
-        _DROP = {"seed": seed, "call": 0}
+        _DROP = {"seed": seed, "call": 0, "site": 0, "n_batch": 0, "tb": 1, "t0": 0}
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
@@ -504,6 +659,8 @@ def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
     else:
         with torch.no_grad():
             b = wm.pre_processing(raw_batch)
+    if _DROP is not None:
+        _DROP["n_batch"] = b["sc/mp_valid"].shape[0]
     mp = map_encoder(model.mp_encoder, b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"], tr)
     tl_tokens = tl_pre_compute(model.tl_encoder, b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], mp)
     mp["_kv_cache"], tl_tokens["_kv_cache"] = {}, {}  # map K/V tables: once per training step, shared by all 90 steps
@@ -527,5 +684,6 @@ def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
     tf = wm.teacher_forcing_training
     tf.init(ag_valid=b["gt/ag_valid"], ag_pose=b["gt/ag_pose"], ag_motion=b["gt/ag_motion"], tl_state=b["gt/tl_state"],
             current_epoch=wm.current_epoch)
-    ro = training_rollout(wm, b, mp, tl_tokens, z, l_valid, tf.ag_teacher_forcing, hp.time_step_end)
+    rollout = training_rollout_batched if getattr(wm, "time_batched_training", True) else training_rollout
+    ro = rollout(wm, b, mp, tl_tokens, z, l_valid, tf.ag_teacher_forcing, hp.time_step_end)
     return training_loss(hp.training_metrics, ro, navi_pred, b["gt/ag_navi"], post, prior)
