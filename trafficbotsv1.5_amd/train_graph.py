@@ -392,15 +392,21 @@ def add_navi_latent(m, x: Tensor, z: Tensor, z_invalid: Tensor, training: bool) 
 
 
 def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, dest, navi_valid, tl_tokens, mp, training: bool,
-                T: int = 1):
+                T: int = 1, tl_pre=None):
     """traffic_bots.py:188-221 -> (action mean [n,A,2], tl logits [n,L,5]). T > 1: time-batched call - every per-entry
-    argument has n = scenes x T entries ([scene][step] order), `mp` stays per scene and `tl_tokens` is expand_tl_tokens'."""
+    argument has n = scenes x T entries ([scene][step] order), `mp` stays per scene and `tl_tokens` is expand_tl_tokens'.
+    tl_pre = (tl_feat [n*L,128], (site, call) dropout ids after the light encoder): the light tokens were encoded ahead."""
     hv, hp, hm, ht = hist
     n, A, W = hv.shape
     d = model.hidden_dim
     L = ht.shape[1]
     assert tl_tokens.get("time_batch", 1) == T
-    tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
+    if tl_pre is None:
+        tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
+    else:
+        tl_feat = tl_pre[0]
+        if _DROP is not None:  # the agents' dropout sites keep the ids they have when the light encoder runs in place
+            _DROP["site"], _DROP["call"] = tl_pre[1]
     feat, _ = agent_encoder(model.ag_encoder, hv, hp, hm, ag_attr6, mp, tl_tokens["tl_token_invalid_u8"], tl_tokens["tl_token_pose"],
                             tl_feat, training, T)
     # NaviEncoder (navigation.py:65-79): detached map feature of the destination + pose embedding of its relative pose
@@ -594,17 +600,41 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
     model = wm.model
     T = step_end
     n = b["gt/ag_valid"].shape[0]
-    rec: Dict[str, List[Tensor]] = {}
-    with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
-        training_rollout(wm, b, dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={}), z.detach(), z_valid, tf_mask, step_end, record=rec)
-    st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
     flat = lambda x: x.reshape(n * T, *x.shape[2:]).contiguous()
     rep = lambda x: x.repeat_interleave(T, 0)
+    ag_attr6, ag_type, dest = b["sc/ag_attr"].float().contiguous(), b["ref/ag_type"], b["gt/ag_navi"]
     tl_T = expand_tl_tokens(model.tl_encoder, tl_tokens, mp, T)
+    # The lights are teacher-forced while ground truth lasts (tl_cur = gt state for step < Tt), so with step_end <= Tt every
+    # light window is known before the rollout: the light encoder of all T steps runs ONCE, differentiated, ahead of pass 1,
+    # which then only steps the agents' half of the policy on its (detached) tokens.
+    tl_gt = b["gt/tl_state"]
+    L, Tt, W = tl_gt.shape[1], tl_gt.shape[2], model.temp_window_size
+    tl_pre, tl_steps = None, None
+    if step_end <= Tt and getattr(wm, "tl_encoder_ahead", True):
+        pad = torch.full((n, L, W), 0xFF, dtype=torch.uint8, device=tl_gt.device)
+        ht_all = torch.cat([pad, _bits(tl_gt)[:, :, :T]], 2).unfold(2, W, 1)[:, :, 1:T + 1]  # [n, L, T, W]: window of step s = states s-W .. s-1
+        ht_all = ht_all.permute(0, 2, 1, 3).reshape(n * T, L, W).contiguous()
+        with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
+            tl_feat_all = tl_encoder(model.tl_encoder, ht_all, tl_T, model.training)
+            ids = (_DROP["site"], _DROP["call"]) if _DROP is not None else None
+        tl_pre = (tl_feat_all, ids)
+        tl_steps = tl_feat_all.detach().view(n, T, L, -1)
+    rec: Dict[str, List[Tensor]] = {}
+    with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
+        mp1, tl1 = dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={})
+
+        def policy1(step, hist, valid_, pose_, navi_valid_):
+            pre = None if tl_steps is None else (tl_steps[:, step - 1].reshape(n * L, -1), tl_pre[1])
+            with _DropScope(n, 1, step, restart=_POLICY_SITE0):
+                return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z.detach(), z_valid, dest, navi_valid_, tl1, mp1,
+                                   model.training, tl_pre=pre)
+
+        training_rollout(wm, b, mp1, tl1, z.detach(), z_valid, tf_mask, step_end, policy=policy1, record=rec)
+    st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
     with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
-        mean, logits = policy_step(model, (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["ht"])),
-                                   rep(b["sc/ag_attr"].float()).contiguous(), rep(b["ref/ag_type"]), flat(st["valid"]), flat(st["pose"]),
-                                   rep(z), rep(z_valid), rep(b["gt/ag_navi"]), flat(st["navi_valid"]), tl_T, mp, model.training, T=T)
+        mean, logits = policy_step(model, (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["ht"])), rep(ag_attr6).contiguous(),
+                                   rep(ag_type), flat(st["valid"]), flat(st["pose"]), rep(z), rep(z_valid), rep(dest),
+                                   flat(st["navi_valid"]), tl_T, mp, model.training, T=T, tl_pre=tl_pre)
     mean, logits = mean.view(n, T, *mean.shape[1:]), logits.view(n, T, *logits.shape[1:])
     return training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask, step_end, need_hist=False,
                             policy=lambda step, hist, v, p, nv: (mean[:, step - 1], logits[:, step - 1]))
