@@ -279,7 +279,7 @@ def test_packed_weight_image_equals_row_major_linear(hip, dev, rows, k, n, group
 
 
 @pytest.mark.parametrize("rows,k,n,groups,wt,tile", [(64, 128, 128, 1, False, 16), (40, 20, 5, 1, False, 16), (16, 512, 128, 1, False, 16),
-                                                     (70, 32, 128, 4, True, 16), (33, 128, 32, 4, False, 32), (5000, 128, 384, 1, False, 32)])
+                                                     (70, 32, 128, 4, True, 16), (33, 128, 32, 4, False, 16), (5000, 128, 384, 1, False, 32), (100, 64, 128, 2, False, 32)])
 def test_split_bf16_linear_close_to_exact_fp32_linear(hip, dev, rows, k, n, groups, wt, tile):
     """TBX_F_WSPLIT (tbx_pack_weight_split image, three bf16 MFMA products with fp32 accumulation): within 3e-5 of the
     magnitude sum_k |x_k w_k| + |b| of the exact result (bf16 hi + lo keeps 16 mantissa bits of each operand; the dropped

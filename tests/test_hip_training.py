@@ -303,7 +303,7 @@ def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout,
         wm.zero_grad(set_to_none=True)
         loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0, noise=noise, use_prior=use_prior)
         loss.backward()
-        res[mode] = ({k: float(v) for k, v in wm.last_metrics.items()}, {k: p.grad.clone() for k, p in wm.model.named_parameters() if p.grad is not None})
+        res[mode] = ({k: float(v.detach()) for k, v in wm.last_metrics.items()}, {k: p.grad.clone() for k, p in wm.model.named_parameters() if p.grad is not None})
     for k, v in res[False][0].items():
         assert abs(res[True][0][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, res[True][0][k], v)
     assert res[True][1].keys() == res[False][1].keys()
@@ -344,11 +344,14 @@ def test_tall_linear_fn_gradients(tb):
     w, b = (torch.randn(256, 128, generator=g) * 0.1).to(dev), torch.randn(256, generator=g).to(dev)
     go = torch.randn(40, 500, 256, generator=g).to(dev)
     outs = []
-    for fn in (TG.linear, torch.nn.functional.linear):
-        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = fn(xx, ww, bb)
-        (y * go).sum().backward()
-        outs.append((y.detach(), xx.grad, ww.grad, bb.grad))
+    for kk, nn in ((128, 256), (121, 5), (31, 121), (128, 1)):  # the odd widths go through zero-padded copies
+        xk, wk, bk, gk = x[..., :kk].contiguous(), w[:nn, :kk].contiguous(), b[:nn].contiguous(), go[..., :nn].contiguous()
+        outs = []
+        for fn in (TG.linear, torch.nn.functional.linear):
+            xx, ww, bb = xk.clone().requires_grad_(True), wk.clone().requires_grad_(True), bk.clone().requires_grad_(True)
+            y = fn(xx, ww, bb)
+            (y * gk).sum().backward()
+            outs.append((y.detach(), xx.grad, ww.grad, bb.grad))
+        for a, r in zip(*outs):
+            torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))
     assert isinstance(TG.linear(x.requires_grad_(True), w, b).grad_fn, TG.TallLinearFn._backward_cls)
-    for a, r in zip(*outs):
-        torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))

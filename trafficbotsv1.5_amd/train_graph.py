@@ -58,10 +58,14 @@ class TallLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             if not dy2.is_contiguous():
                 dy2 = dy2.contiguous()
-            if hip.linear_wgrad_ok(dy2, x2):
-                dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b)
-            else:
-                dw, db = dy2.t() @ x2, (dy2.sum(0) if ctx.has_b else None)
+            n, k = dy2.shape[1], x2.shape[1]
+            if not hip.linear_wgrad_ok(dy2, x2):
+                # odd widths (heads with 1 / 2 / 5 outputs, the 31- / 121-wide map MLP): zero-padded copies with 4-float rows
+                # (the library's GEMM for [n, rows] x [rows, k] with n = 1 took 56 ms at 10^6 rows)
+                dy2 = F.pad(dy2, (0, -n % 4))
+                x2 = F.pad(x2, (0, -k % 4)) if (k % 4 or not x2.is_contiguous()) else x2
+            dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b)
+            dw, db = dw[:n, :k], (db[:n] if db is not None else None)
         return dx, dw, db
 
 
