@@ -173,6 +173,48 @@ int tbx_linear_wgrad_splits(int64_t rows, int n, int k);
 int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
                      float* scratch, int splits, void* stream);
 
+/* The per-step state machine of the TRAINING rollout (waymo_motion.py:206-311 with training=True; utils/dynamics.py:66-204,
+ * 237-274, utils/teacher_forcing.py:108-167, utils/traffic_rule_checker.py:109-120,300-330, utils/rewards.py:35-85,
+ * utils/buffer.py:39-78) for steps t in [t0, t1) (step number s = t + 1 = ground-truth index): action = tanh(mean) * lim,
+ * kinematic step, teacher-forcing override (tf_mask & ~disabled), outside-map / destination-reached flags on the prediction,
+ * the differentiable reward -(w_pos SmoothL1(xy) + w_rot (1 - cos dyaw) / 2 + w_spd SmoothL1(speed)) on pred & gt valid, and
+ * the disabling of agents that left the map. A thread per agent; the state persists in the struct's buffers between calls
+ * (the stepping pass calls one step at a time, the differentiated pass all steps at once). All arrays are caller-owned
+ * device memory; `mean` element (b, t, a, c) is mean[b * stride_n + (t - t0) * stride_t + a * 2 + c].
+ *   rec_*: the state BEFORE every step, time-major with window - 1 leading slots the caller zero-fills: slot window - 1 + t
+ *   holds the state before step t + 1 (slot window - 1 is written by the caller from the initial state), so the W-step history
+ *   window of step t + 1 is slots [t, t + window). [n, T + window, A(,3)].
+ * tbx_train_chain_bwd: d_mean [n,T,A,2] from d_reward [n,T,A] after a forward over [0, T) (reads rec_*, ov, reward_valid,
+ * pred_*): the reverse walk with a 4-float adjoint (x, y, yaw, speed) per agent. */
+typedef struct tbx_train_chain {
+  int32_t n_batch, n_ag, n_step, n_step_gt, n_node, window;
+  float dt, w_pos, w_rot, w_spd;
+  const uint8_t* gt_valid;   /* [n,A,Tg] */
+  const float* gt_pose;      /* [n,A,Tg,3] */
+  const float* gt_motion;    /* [n,A,Tg,3] */
+  const uint8_t* tf_mask;    /* [n,A,Tg] TeacherForcing.ag_teacher_forcing */
+  const float* lim;          /* [n,A,2] max acceleration / yaw rate of the agent's type */
+  const float* dest_pos;     /* [n,A,N,2] */
+  const float* dest_dir;     /* [n,A,N,2] unit */
+  const uint8_t* dest_invalid; /* [n,A,N] */
+  const float* dest_thresh;  /* [n,A] */
+  const uint8_t* dest_kind;  /* [n,A] bit 0: lane-like destination (position and heading), bit 1: type 4 (position only) */
+  const float* boundary;     /* [n,4] x0 x1 y0 y1 */
+  uint8_t *valid, *disabled, *navi_valid, *outside, *reached; /* state [n,A] */
+  float *pose, *motion;      /* state [n,A,3] */
+  uint8_t* rec_valid;        /* [n,T+W,A] */
+  float* rec_pose;           /* [n,T+W,A,3] */
+  float* rec_motion;         /* [n,T+W,A,3] */
+  uint8_t* rec_navi_valid;   /* [n,T+W,A] */
+  uint8_t *pred_valid, *tf, *ov, *reward_valid; /* [n,T,A]: tf = logged forcing mask, ov = override applied */
+  float *pred_pose, *pred_motion; /* [n,T,A,3] */
+  float* reward;             /* [n,T,A] */
+} tbx_train_chain_t;
+int tbx_train_chain_fwd(const tbx_train_chain_t* c /* host */, const float* mean, int64_t mean_stride_n, int64_t mean_stride_t, int t0,
+                        int t1, void* stream);
+int tbx_train_chain_bwd(const tbx_train_chain_t* c /* host */, const float* mean, int64_t mean_stride_n, int64_t mean_stride_t,
+                        const float* d_reward, float* d_mean, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs
  * a short program of stages over it with the activations resident in LDS (two ping-pong buffers of `ldw` floats per

@@ -268,12 +268,13 @@ def test_attention_dropout_time_batched_call_equals_per_step_calls(tb):
     torch.testing.assert_close(kvb.grad, gkv, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("dropout,tl_ahead", [(False, True), (True, True), (True, False)])
-def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout, tl_ahead):
+@pytest.mark.parametrize("dropout,tl_ahead,fused", [(False, True, True), (True, True, True), (True, False, True), (True, True, False)])
+def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout, tl_ahead, fused):
     """training_rollout_batched (no-grad stepping pass + ONE differentiated policy batch over all steps + the dynamics chain) vs
     training_rollout (autograd through 30 sequential policy steps): same loss terms and parameter gradients - also in train mode
     with every dropout live, since the keyed masks of the batched pass are those of the per-step pass. tl_ahead: the light encoder
-    of all steps evaluated once ahead of the stepping pass (lights are teacher-forced while ground truth lasts) or inside it."""
+    of all steps evaluated once ahead of the stepping pass (lights are teacher-forced while ground truth lasts) or inside it;
+    fused: the per-step state machine (dynamics, forcing, rule flags, reward) as tbx_train_chain_fwd / _bwd or as torch ops."""
     dev = torch.device("cuda:0")
     W = import_module("trafficbots_amd.pl_modules.waymo_motion")
     cfg = tb.config.default_model_cfg(n_tgt_knn=4)
@@ -293,7 +294,7 @@ def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout,
                 p.mul_(0.02)
     wm = wm.to(dev).train()
     wm.attn_dropout_seed = torch.tensor([4242], dtype=torch.int64, device=dev)
-    wm.tl_encoder_ahead = tl_ahead
+    wm.tl_encoder_ahead, wm.fused_train_chain = tl_ahead, fused
     batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=1).items()}
     noise = torch.randn(2, 8, wm.model.latent_encoder.out_dim, generator=torch.Generator().manual_seed(5)).to(dev)
     use_prior = torch.zeros((), dtype=torch.bool, device=dev)

@@ -48,6 +48,17 @@ class SimState(C.Structure):
     )
 
 
+class TrainChainArgs(C.Structure):
+    """tbx_train_chain_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ("n_batch", "n_ag", "n_step", "n_step_gt", "n_node", "window")]
+                + [(n, C.c_float) for n in ("dt", "w_pos", "w_rot", "w_spd")]
+                + [(n, C.c_void_p) for n in (
+                    "gt_valid", "gt_pose", "gt_motion", "tf_mask", "lim", "dest_pos", "dest_dir", "dest_invalid", "dest_thresh",
+                    "dest_kind", "boundary", "valid", "disabled", "navi_valid", "outside", "reached", "pose", "motion",
+                    "rec_valid", "rec_pose", "rec_motion", "rec_navi_valid", "pred_valid", "tf", "ov", "reward_valid",
+                    "pred_pose", "pred_motion", "reward")])
+
+
 class RuleCtx(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "map_batch_div", "cap")]
                 + [(n, C.c_void_p) for n in ("seg", "n_seg", "lane", "n_lane", "ag_size", "ag_type_idx", "tl_valid", "tl_pose")]
@@ -101,6 +112,8 @@ def load():
     lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
     lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
     lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
+    lib.tbx_train_chain_fwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp]
+    lib.tbx_train_chain_bwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, vp, vp, vp]
     lib.tbx_knn_inverse.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd_gather.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                                C.POINTER(C.c_void_p), vp, vp, vp, f32, vp, C.c_uint32, C.POINTER(C.c_void_p),
@@ -121,7 +134,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 1:
@@ -356,6 +369,15 @@ def map_prep(mp_valid_u8, mp_type11, mp_pose, attr, pe, row_invalid, tok_pose, t
 
 
 SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE = 1, 2, 4
+
+
+def train_chain_fwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, t0: int, t1: int):
+    _check(load().tbx_train_chain_fwd(C.byref(args), _ptr(mean, torch.float32), stride_n, stride_t, t0, t1, stream_ptr()), "tbx_train_chain_fwd")
+
+
+def train_chain_bwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, d_reward: torch.Tensor, d_mean: torch.Tensor):
+    _check(load().tbx_train_chain_bwd(C.byref(args), _ptr(mean, torch.float32), stride_n, stride_t, _ptr(d_reward, torch.float32),
+                                      _ptr(d_mean, torch.float32), stream_ptr()), "tbx_train_chain_bwd")
 
 
 def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE):

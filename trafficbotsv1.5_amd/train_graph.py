@@ -597,6 +597,126 @@ def training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end
     return {k: torch.stack(v, 2) for k, v in out.items()}
 
 
+class TrainChain:
+    """Device-resident state + buffers of tbx_train_chain (csrc/train_chain.hip): the per-step state machine of the training
+    rollout - what `training_rollout` spells out in ~75 elementwise torch ops per step - for one batch. `step(s, mean)` advances
+    one step (stepping pass), `run_all(mean)` all T steps from the initial state (differentiated pass, through TrainChainFn)."""
+
+    def __init__(self, wm, b, tf_mask: Tensor, T: int) -> None:
+        model, dyn, rc = wm.model, wm.dynamics, wm.hp.differentiable_reward
+        gt_valid, gt_pose, gt_motion = b["gt/ag_valid"], b["gt/ag_pose"], b["gt/ag_motion"]
+        ag_type, dest = b["ref/ag_type"], b["gt/ag_navi"]
+        n, A, Tg = gt_valid.shape
+        dev, W = gt_pose.device, model.temp_window_size
+        self.n, self.A, self.T, self.W, self.dev = n, A, T, W, dev
+        if getattr(dyn, "_max_act", None) is None or dyn._max_act.device != dev:
+            dyn._max_act = torch.tensor([[a, y] for a, y in zip(dyn.max_acc, dyn.max_yaw_rate)], device=dev)
+        u8, f32 = torch.uint8, torch.float32
+        bi = torch.arange(n, device=dev).unsqueeze(1)
+        d_type = b["map/type"][bi, dest]
+        d_dir = b["map/dir"][bi, dest][..., :2].float()
+        N = d_dir.shape[2]
+        k = dict(gt_valid=gt_valid.to(u8), gt_pose=gt_pose.float(), gt_motion=gt_motion.float(), tf_mask=tf_mask.to(u8),
+                 lim=(ag_type.unsqueeze(-1) * dyn._max_act).sum(2).float(), dest_pos=b["map/pos"][bi, dest][..., :2].float(),
+                 dest_dir=d_dir / torch.norm(d_dir, dim=-1, keepdim=True), dest_invalid=(~b["map/valid"][bi, dest]).to(u8),
+                 dest_thresh=50.0 * (1 - d_type[:, :, 4].float() * 0.8),
+                 dest_kind=d_type[:, :, :4].any(-1).to(u8) + 2 * d_type[:, :, 4].to(u8), boundary=b["map/boundary"].float())
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)
+        k.update(valid=z(n, A, dt=u8), disabled=z(n, A, dt=u8), navi_valid=z(n, A, dt=u8), outside=z(n, A, dt=u8), reached=z(n, A, dt=u8),
+                 pose=z(n, A, 3), motion=z(n, A, 3), rec_valid=z(n, T + W, A, dt=u8), rec_pose=z(n, T + W, A, 3), rec_motion=z(n, T + W, A, 3),
+                 rec_navi_valid=z(n, T + W, A, dt=u8), pred_valid=z(n, T, A, dt=u8), tf=z(n, T, A, dt=u8), ov=z(n, T, A, dt=u8),
+                 reward_valid=z(n, T, A, dt=u8), pred_pose=z(n, T, A, 3), pred_motion=z(n, T, A, 3), reward=z(n, T, A))
+        self.t = {name: v.contiguous() for name, v in k.items()}
+        a = hip.TrainChainArgs()
+        a.n_batch, a.n_ag, a.n_step, a.n_step_gt, a.n_node, a.window = n, A, T, Tg, N, W
+        a.dt, a.w_pos, a.w_rot, a.w_spd = float(dyn.dt), float(rc.l_pos.weight), float(rc.l_rot.weight), float(rc.l_spd.weight)
+        for name, v in self.t.items():
+            setattr(a, name, v.data_ptr())
+        self.args = a
+        self.init = (gt_valid[:, :, 0].to(u8), gt_pose[:, :, 0].float(), gt_motion[:, :, 0].float(), gt_valid.any(-1).to(u8))
+        self.reset()
+
+    def reset(self) -> None:
+        """Initial state (Dynamics.init, dynamics.py:29-64) into the state buffers and into record slot W - 1."""
+        t, W = self.t, self.W
+        v, p, m, nv = self.init
+        t["valid"].copy_(v), t["pose"].copy_(p), t["motion"].copy_(m), t["navi_valid"].copy_(nv)
+        for name in ("disabled", "outside", "reached"):
+            t[name].zero_()
+        t["rec_valid"][:, W - 1].copy_(v), t["rec_pose"][:, W - 1].copy_(p), t["rec_motion"][:, W - 1].copy_(m)
+        t["rec_navi_valid"][:, W - 1].copy_(nv)
+
+    def before(self, s: int):
+        """Policy inputs of step s (1-based): windows (valid u8 [n,A,W], pose, motion [n,A,W,3]; oldest first) and the current
+        (valid bool [n,A], pose [n,A,3], navi_valid bool [n,A])."""
+        t, W = self.t, self.W
+        sl = slice(s - 1, s - 1 + W)
+        hv = t["rec_valid"][:, sl].permute(0, 2, 1).contiguous()
+        hp = t["rec_pose"][:, sl].permute(0, 2, 1, 3).contiguous()
+        hm = t["rec_motion"][:, sl].permute(0, 2, 1, 3).contiguous()
+        cur = s - 1 + W - 1
+        return hv, hp, hm, t["rec_valid"][:, cur].bool(), t["rec_pose"][:, cur], t["rec_navi_valid"][:, cur].bool()
+
+    def step(self, s: int, mean: Tensor) -> None:
+        mean = mean.detach().reshape(self.n, self.A, 2).contiguous()
+        hip.train_chain_fwd(self.args, mean, self.A * 2, 0, s - 1, s)
+
+    def windows(self):
+        """All steps' policy inputs in [scene][step] order: (hv [n*T,A,W] u8, hp, hm [n*T,A,W,3], valid [n*T,A] bool, pose
+        [n*T,A,3], navi_valid [n*T,A] bool) from the records of a finished stepping pass."""
+        t, W, T, n, A = self.t, self.W, self.T, self.n, self.A
+        win = lambda x: x[:, :T + W - 1].unfold(1, W, 1)  # [n, T, A(,3), W]
+        hv = win(t["rec_valid"]).reshape(n * T, A, W).contiguous()
+        hp = win(t["rec_pose"]).permute(0, 1, 2, 4, 3).reshape(n * T, A, W, 3).contiguous()
+        hm = win(t["rec_motion"]).permute(0, 1, 2, 4, 3).reshape(n * T, A, W, 3).contiguous()
+        cur = slice(W - 1, W - 1 + T)
+        return (hv, hp, hm, t["rec_valid"][:, cur].reshape(n * T, A).bool(), t["rec_pose"][:, cur].reshape(n * T, A, 3).contiguous(),
+                t["rec_navi_valid"][:, cur].reshape(n * T, A).bool())
+
+    def outputs(self, reward: Tensor) -> Dict[str, Tensor]:
+        """The rollout log in training_rollout's layout ([n, A, T(,3)])."""
+        t = self.t
+        p = lambda x: x.permute(0, 2, 1) if x.dim() == 3 else x.permute(0, 2, 1, 3)
+        return {"pred_valid": p(t["pred_valid"]).bool(), "pred_pose": p(t["pred_pose"]), "pred_motion": p(t["pred_motion"]),
+                "reward": p(reward), "reward_valid": p(t["reward_valid"]).bool(), "tf": p(t["tf"]).bool()}
+
+
+class TrainChainFn(torch.autograd.Function):
+    """reward [n,T,A] of the whole rollout from the batched action means [n,T,A,2] (tbx_train_chain_fwd over all steps from the
+    initial state); backward = tbx_train_chain_bwd (reverse walk over the steps)."""
+
+    @staticmethod
+    def forward(ctx, mean, chain):
+        mean = mean.contiguous()
+        chain.reset()
+        hip.train_chain_fwd(chain.args, mean, chain.T * chain.A * 2, chain.A * 2, 0, chain.T)
+        ctx.chain = chain
+        ctx.save_for_backward(mean)
+        return chain.t["reward"].clone()
+
+    @staticmethod
+    def backward(ctx, d_reward):
+        (mean,) = ctx.saved_tensors
+        chain = ctx.chain
+        d_mean = torch.empty_like(mean)
+        hip.train_chain_bwd(chain.args, mean, chain.T * chain.A * 2, chain.A * 2, d_reward.contiguous(), d_mean)
+        return d_mean, None
+
+
+def tl_nll_all_steps(logits: Tensor, tl_gt: Tensor, tl_invalid: Tensor):
+    """The light-state NLL of every step at once (waymo_motion.py:277-283): logits [n,T,L,5] of steps 1..T, tl_gt [n,L,Tt,5] one-hot,
+    -> (nll [n,L,T], invalid [n,L,T]); steps without ground truth count as invalid."""
+    n, T, L, _ = logits.shape
+    S = min(T, tl_gt.shape[2] - 1)
+    nll = torch.zeros(n, T, L, device=logits.device)
+    inv = torch.ones(n, T, L, dtype=torch.bool, device=logits.device)
+    if S > 0:
+        idx = tl_gt[:, :, 1:S + 1].max(-1)[1].permute(0, 2, 1)  # [n,S,L]
+        nll[:, :S] = -torch.log_softmax(logits[:, :S], -1).gather(-1, idx.unsqueeze(-1)).squeeze(-1)
+        inv[:, :S] = tl_invalid.unsqueeze(1)
+    return nll.permute(0, 2, 1), inv.permute(0, 2, 1)
+
+
 def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
     """The same rollout, time-batched (module docstring): a step-by-step pass without autograd that records every step's
     policy inputs, then the T policy evaluations of every scene as one differentiated batch of n x T entries in [scene][step]
@@ -613,16 +733,19 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
     # which then only steps the agents' half of the policy on its (detached) tokens.
     tl_gt = b["gt/tl_state"]
     L, Tt, W = tl_gt.shape[1], tl_gt.shape[2], model.temp_window_size
-    tl_pre, tl_steps = None, None
-    if step_end <= Tt and getattr(wm, "tl_encoder_ahead", True):
+    tl_pre, tl_steps, ht_all = None, None, None
+    if step_end <= Tt:
         pad = torch.full((n, L, W), 0xFF, dtype=torch.uint8, device=tl_gt.device)
         ht_all = torch.cat([pad, _bits(tl_gt)[:, :, :T]], 2).unfold(2, W, 1)[:, :, 1:T + 1]  # [n, L, T, W]: window of step s = states s-W .. s-1
         ht_all = ht_all.permute(0, 2, 1, 3).reshape(n * T, L, W).contiguous()
+    if ht_all is not None and getattr(wm, "tl_encoder_ahead", True):
         with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
             tl_feat_all = tl_encoder(model.tl_encoder, ht_all, tl_T, model.training)
             ids = (_DROP["site"], _DROP["call"]) if _DROP is not None else None
         tl_pre = (tl_feat_all, ids)
         tl_steps = tl_feat_all.detach().view(n, T, L, -1)
+    fused = getattr(wm, "fused_train_chain", True) and ht_all is not None  # (lights from their own logits: the torch state machine)
+    chain = TrainChain(wm, b, tf_mask, T) if fused else None
     rec: Dict[str, List[Tensor]] = {}
     with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
         mp1, tl1 = dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={})
@@ -633,13 +756,27 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
                 return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z.detach(), z_valid, dest, navi_valid_, tl1, mp1,
                                    model.training, tl_pre=pre)
 
-        training_rollout(wm, b, mp1, tl1, z.detach(), z_valid, tf_mask, step_end, policy=policy1, record=rec)
-    st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
+        if fused:  # the state machine is tbx_train_chain: per step the policy, then ONE launch
+            ht_steps = ht_all.view(n, T, L, W)
+            for step in range(1, T + 1):
+                hv, hp, hm, valid_, pose_, navi_valid_ = chain.before(step)
+                mean1, _ = policy1(step, (hv, hp, hm, ht_steps[:, step - 1].contiguous()), valid_, pose_, navi_valid_)
+                chain.step(step, mean1)
+            inputs = chain.windows()
+        else:
+            training_rollout(wm, b, mp1, tl1, z.detach(), z_valid, tf_mask, step_end, policy=policy1, record=rec)
+            st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
+            inputs = (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["valid"]), flat(st["pose"]), flat(st["navi_valid"]))
+    hv, hp, hm, valid_all, pose_all, navi_all = inputs
+    ht_in = ht_all if ht_all is not None else flat(st["ht"])
     with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
-        mean, logits = policy_step(model, (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["ht"])), rep(ag_attr6).contiguous(),
-                                   rep(ag_type), flat(st["valid"]), flat(st["pose"]), rep(z), rep(z_valid), rep(dest),
-                                   flat(st["navi_valid"]), tl_T, mp, model.training, T=T, tl_pre=tl_pre)
+        mean, logits = policy_step(model, (hv, hp, hm, ht_in), rep(ag_attr6).contiguous(), rep(ag_type), valid_all, pose_all, rep(z),
+                                   rep(z_valid), rep(dest), navi_all, tl_T, mp, model.training, T=T, tl_pre=tl_pre)
     mean, logits = mean.view(n, T, *mean.shape[1:]), logits.view(n, T, *logits.shape[1:])
+    if fused:
+        ro = chain.outputs(TrainChainFn.apply(mean, chain))
+        ro["tl_nll"], ro["tl_nll_invalid"] = tl_nll_all_steps(logits, tl_gt, tl_tokens["tl_token_invalid"])
+        return ro
     return training_rollout(wm, b, mp, tl_tokens, z, z_valid, tf_mask, step_end, need_hist=False,
                             policy=lambda step, hist, v, p, nv: (mean[:, step - 1], logits[:, step - 1]))
 
