@@ -356,3 +356,60 @@ def test_tall_linear_fn_gradients(tb):
         for a, r in zip(*outs):
             torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))
     assert isinstance(TG.linear(x.requires_grad_(True), w, b).grad_fn, TG.TallLinearFn._backward_cls)
+
+
+def test_train_chain_kernels_vs_torch_state_machine(tb):
+    """tbx_train_chain_fwd / _bwd vs `training_rollout`'s elementwise torch state machine + autograd on random action means that
+    make agents leave the map, reach destinations, get disabled and re-spawned by forcing: every logged tensor and d(mean)."""
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    TG = import_module("trafficbots_amd.train_graph")
+    scfg = tb.config.default_sim_cfg()
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **scfg).to(dev)
+    n, A, T = 3, 40, 90
+    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(n, A, 64, 8, seed=3).items()}
+    with torch.no_grad():
+        b = wm.pre_processing(batch)
+    b["map/boundary"] = torch.tensor([[-60.0, 60.0, -60.0, 60.0]], device=dev).repeat(n, 1)  # tight: many agents leave
+    torch.manual_seed(11)
+    b["gt/ag_valid"] = b["gt/ag_valid"] & (torch.rand(b["gt/ag_valid"].shape, device=dev) > 0.1)  # holes in the ground truth
+    tf = wm.teacher_forcing_training
+    tf.init(ag_valid=b["gt/ag_valid"], ag_pose=b["gt/ag_pose"], ag_motion=b["gt/ag_motion"], tl_state=b["gt/tl_state"], current_epoch=0)
+    tf_mask = tf.ag_teacher_forcing | (torch.rand(b["gt/ag_valid"].shape, device=dev) < 0.05) & b["gt/ag_valid"]
+    g = torch.Generator().manual_seed(2)
+    mean0 = (torch.randn(n, T, A, 2, generator=g) * 1.5).to(dev)
+    w_r = torch.randn(n, A, T, generator=g).to(dev)
+    L = b["gt/tl_state"].shape[1]
+    logits = torch.zeros(n, L, 5, device=dev)
+    m1 = mean0.clone().requires_grad_(True)
+    ro = TG.training_rollout(wm, b, None, {"tl_token_invalid": torch.zeros(n, L, dtype=torch.bool, device=dev)}, None, None, tf_mask, T,
+                             need_hist=False, policy=lambda s, h, v, p, nv: (m1[:, s - 1], logits))
+    (ro["reward"] * w_r).sum().backward()
+    m2 = mean0.clone().requires_grad_(True)
+    chain = TG.TrainChain(wm, b, tf_mask, T)
+    out = chain.outputs(TG.TrainChainFn.apply(m2, chain))
+    (out["reward"] * w_r).sum().backward()
+    for k in ("pred_valid", "reward_valid", "tf"):
+        assert torch.equal(out[k], ro[k]), k
+    assert 0.05 < float(ro["pred_valid"].float().mean()) < 0.98
+    assert bool((~ro["pred_valid"][:, :, -1] & ro["pred_valid"][:, :, 0]).any())  # some agents were disabled on the way
+    for k in ("pred_pose", "pred_motion", "reward"):
+        torch.testing.assert_close(out[k], ro[k], rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(m2.grad, m1.grad, rtol=1e-3, atol=1e-5 * float(m1.grad.abs().max()))
+    assert float(m1.grad.abs().max()) > 0
+    # one step at a time == all steps at once
+    chain.reset()
+    for s in range(1, T + 1):
+        chain.step(s, mean0[:, s - 1])
+    for k in ("pred_pose", "reward"):
+        assert torch.equal(chain.outputs(chain.t["reward"])[k], out[k].detach()), k
+    # the recorded pre-step states are the windows the torch loop builds
+    rec = {}
+    TG.training_rollout(wm, b, None, {"tl_token_invalid": torch.zeros(n, L, dtype=torch.bool, device=dev)}, None, None, tf_mask, T,
+                        record=rec, policy=lambda s, h, v, p, nv: (mean0[:, s - 1], logits))
+    hv, hp, hm, valid, pose, navi = chain.windows()
+    assert torch.equal(hv.view(n, T, A, -1), torch.stack(rec["hv"], 1))
+    torch.testing.assert_close(hp.view(n, T, A, -1, 3), torch.stack(rec["hp"], 1), rtol=1e-4, atol=2e-4)
+    assert torch.equal(navi.view(n, T, A), torch.stack(rec["navi_valid"], 1))
+    assert bool((~navi.view(n, T, A)[:, -1] & navi.view(n, T, A)[:, 0]).any())  # some destinations were reached
