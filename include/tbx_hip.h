@@ -239,7 +239,10 @@ enum {
   TBX_OP_GROUPMAX = 7,  /* dst[r, dst_col + c] = max_r' src[r', src_col + c]  (r' over the rows of r's group; flat mode: the tile) */
   TBX_OP_POOLMAX = 8,   /* p0[group * ld + dst_col + c] = max over un-masked rows (mask p1) of src[:, src_col + c]; none -> 0 */
   TBX_OP_STORE = 9,     /* p0[g * ld + dst_col + c] = src[:, src_col + c] for valid rows */
-  TBX_OP_CLAMP = 10     /* dst[:, dst_col:+n] = clamp(dst, f0, f1) */
+  TBX_OP_CLAMP = 10,    /* dst[:, dst_col:+n] = clamp(dst, f0, f1) */
+  TBX_OP_DROPOUT = 11   /* dst[g, dst_col + c] *= keep ? f0 : 0 with tbx_keyed_dropout's mask for (seed = *(u64*)p0, site = div, step = k,
+                           scene row = global row g, column c of n): keep = hash >= threshold = (uint32_t)reserved (p * 2^32),
+                           f0 = 1 / (1 - p). The stepping (no-grad) pass of training runs its layers as chains with these stages. */
 };
 enum { TBX_ACT_NONE = 0, TBX_ACT_RELU = 1 };
 enum {

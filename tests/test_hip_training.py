@@ -413,3 +413,50 @@ def test_train_chain_kernels_vs_torch_state_machine(tb):
     torch.testing.assert_close(hp.view(n, T, A, -1, 3), torch.stack(rec["hp"], 1), rtol=1e-4, atol=2e-4)
     assert torch.equal(navi.view(n, T, A), torch.stack(rec["navi_valid"], 1))
     assert bool((~navi.view(n, T, A)[:, -1] & navi.view(n, T, A)[:, 0]).any())  # some destinations were reached
+
+
+@pytest.mark.parametrize("sizes,knn", [((2, 8, 64, 8), 4), ((1, 64, 1024, 128), None)])
+def test_nograd_policy_step_on_chain_kernels_equals_torch_ops_with_dropout(tb, sizes, knn):
+    """The stepping pass of the time-batched rollout: with autograd off, train_graph runs whole layers as the inference engine's
+    chain kernels (keyed dropouts as DROPOUT stages / inside the attention kernels). Same action means and light logits as the
+    torch-op path with every dropout live (p = 0.1; the masks agree or the results would differ at the 10 % level)."""
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    TG = import_module("trafficbots_amd.train_graph")
+    scfg = tb.config.default_sim_cfg()
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    cfg = tb.config.default_model_cfg(n_tgt_knn=knn) if knn else tb.config.default_model_cfg()
+    wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg)
+    tb.utils.det_fill(wm.model, 0)
+    wm = wm.to(dev).train()
+    model = wm.model
+    n, A, M, L = sizes
+    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(n, A, M, L, seed=4).items()}
+    outs = {}
+    with torch.no_grad():
+        b = wm.pre_processing(batch)
+        for chains in (False, True):
+            TG.NOGRAD_CHAINS = chains
+            TG._DROP = {"seed": torch.tensor([99], dtype=torch.int64, device=dev), "call": 0, "site": 0, "n_batch": n, "tb": 1, "t0": 0}
+            TG._FOLD_CACHE = {}
+            try:
+                mp = TG.map_encoder(model.mp_encoder, b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"], True)
+                tl = TG.tl_pre_compute(model.tl_encoder, b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], mp)
+                mp["_kv_cache"], tl["_kv_cache"] = {}, {}
+                Wn = model.temp_window_size
+                hv, hp, hm = model.ag_encoder.pad_hist(b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"], Wn)
+                ht = model.tl_encoder.states_to_hist(b["gt/tl_state"][:, :, :Wn], Wn)
+                z = torch.randn(n, A, model.latent_encoder.out_dim, generator=torch.Generator().manual_seed(1)).to(dev)
+                valid = b["sc/ag_valid"][:, :, -1]
+                res = []
+                for step in (1, 2):  # two steps: the masks move with the step, the static map tables are cached
+                    with TG._DropScope(n, 1, step, restart=TG._POLICY_SITE0):
+                        res.append(TG.policy_step(model, (hv, hp, hm, ht), b["sc/ag_attr"].float().contiguous(), b["ref/ag_type"], valid,
+                                                  b["sc/ag_pose"][:, :, -1], z, valid, b["gt/ag_navi"], valid, tl, mp, True))
+                outs[chains] = res
+            finally:
+                TG._DROP, TG._FOLD_CACHE, TG.NOGRAD_CHAINS = None, None, True
+    for (m0, l0), (m1, l1) in zip(outs[False], outs[True]):
+        torch.testing.assert_close(m1, m0, rtol=2e-4, atol=2e-5 + 2e-4 * float(m0.abs().max()))
+        torch.testing.assert_close(l1, l0, rtol=2e-4, atol=2e-5 + 2e-4 * float(l0.abs().max()))
+    assert not torch.equal(outs[False][0][0], outs[False][1][0])

@@ -530,6 +530,36 @@ __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     }
 }
 
+// tbx_keyed_dropout's mask (csrc/dropout.hip) applied in place to an LDS-resident block: time_batch = 1, so the key row is the
+// chain's global row.
+template <int MT, bool EXT>
+__device__ void op_dropout(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
+  constexpr int ROWS = 16 * MT;
+  TBX_WAVE_ROWS;
+  float* dst = t.b(s.dst) + s.dst_col;
+  const int lds_d = t.l(s.dst);
+  const int n = s.n;
+  const uint64_t sd = *(const TBX_GLOBAL uint64_t*)s.p0;
+  const uint32_t site = (uint32_t)s.div, ts = (uint32_t)s.k, thresh = (uint32_t)s.reserved;
+  const uint32_t lo = (uint32_t)sd ^ (site * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
+  const uint32_t hi = (uint32_t)(sd >> 32) + site * 0xC2B2AE35u + ts * 0x165667B1u;
+  for (int r = wave; r < ROWS; r += nwave) {
+    const uint32_t base = (uint32_t)(t.g0 + r) * (uint32_t)n;
+    for (int c = lane; c < n; c += 64) {
+      uint32_t x = (base + (uint32_t)c) ^ lo;
+      x *= 0x9E3779B1u;
+      x ^= hi;
+      x ^= x >> 16;
+      x *= 0x7feb352du;
+      x ^= x >> 15;
+      x *= 0x846ca68bu;
+      x ^= x >> 16;
+      const float v = dst[r * lds_d + c];
+      dst[r * lds_d + c] = x >= thresh ? v * s.f0 : 0.f;
+    }
+  }
+}
+
 template <int MT, bool EXT>
 __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = 16 * MT;
@@ -698,6 +728,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       case TBX_OP_COPY:
       case TBX_OP_CLAMP: op_elementwise<MT, EXT>(s, t); break;
       case TBX_OP_ROWMASK: op_rowmask<MT, EXT>(s, t); break;
+      case TBX_OP_DROPOUT: op_dropout<MT, EXT>(s, t); break;
       case TBX_OP_GROUPMAX: op_groupmax<MT, EXT>(s, t); break;
       case TBX_OP_POOLMAX: op_poolmax<MT, EXT>(s, t); break;
       case TBX_OP_STORE: op_store<MT, EXT>(s, t); break;
@@ -757,7 +788,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
 
 int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_rows) {
   auto buf_ld = [&](int b) { return b == 0 ? ldw0 : (b == 1 ? ldw1 : (b == 2 ? ld_aux : (1 << 30))); };
-  if (s.op < TBX_OP_LOAD || s.op > TBX_OP_CLAMP) return TBX_ERR_ARG;
+  if (s.op < TBX_OP_LOAD || s.op > TBX_OP_DROPOUT) return TBX_ERR_ARG;
+  if (s.op == TBX_OP_DROPOUT && (s.p0 == nullptr || s.k < 0)) return TBX_ERR_ARG;
   const bool gdst = s.op == TBX_OP_LINEAR && s.dst == TBX_BUF_GLOBAL;
   if (s.src < 0 || s.src > 2 || s.dst < 0 || (s.dst > 2 && !gdst)) return TBX_ERR_ARG;
   if (gdst && (s.p2 == nullptr || s.ld2 <= 0 || (s.flags & TBX_F_ACCUM))) return TBX_ERR_ARG;

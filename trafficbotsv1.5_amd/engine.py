@@ -34,23 +34,30 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     return nq + NH * D
 
 
-def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1):
+def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1, drop=None):
     """x += out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), zero for rows without a valid target.
-    attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233."""
+    attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233. drop = (p, seed, site, step): the residual dropout of training
+    (transformer_rpe.py:56-60) as a keyed DROPOUT stage."""
     ch.load(obuf, BUF0, 0, n=O_LD)
     # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
     ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
               dst_stride=DH)
     ch.linear(BUF0, 0, AUX, 0, attn.out_proj_weight, attn.out_proj_bias)
     ch.rowmask(AUX, 0, D, mask=row_no_valid)
+    if drop is not None:
+        ch.dropout(AUX, 0, D, *drop)
     ch.add(AUX, 0, x_buf, 0, D)
 
 
-def emit_ffn(ch: Chain, layer, x_buf: int = BUF1):
-    """x += linear2(relu(linear1(norm2(x)))). transformer_rpe.py:234-237."""
+def emit_ffn(ch: Chain, layer, x_buf: int = BUF1, drop_hidden=None, drop_out=None):
+    """x += linear2(relu(linear1(norm2(x)))). transformer_rpe.py:234-237; drop_* = (p, seed, site, step) in training."""
     ch.layernorm(x_buf, 0, BUF0, 0, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     ch.linear(BUF0, 0, BUF0, D, layer.linear1.weight, layer.linear1.bias, relu=True)
+    if drop_hidden is not None:
+        ch.dropout(BUF0, D, layer.linear1.weight.shape[0], *drop_hidden)
     ch.linear(BUF0, D, AUX, 0, layer.linear2.weight, layer.linear2.bias)
+    if drop_out is not None:
+        ch.dropout(AUX, 0, D, *drop_out)
     ch.add(AUX, 0, x_buf, 0, D)
 
 
@@ -144,13 +151,36 @@ class SelfKnn:
 
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
-              tile_rows: int = 16, pose_rpe=None) -> None:
+              tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None) -> None:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE. `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
-    appends row-local stages to the last layer's chain (x is in BUF1[:, 0:128] at that point)."""
+    appends row-local stages to the last layer's chain (x is in BUF1[:, 0:128] at that point).
+    drop (the stepping pass of training, train_graph.py): dict(p=residual / FFN dropout, seed=int64[1] device tensor, site=last
+    elementwise site id used, call=last attention call id used, step=closed-loop step): the keyed dropouts of training - in
+    the attention kernels and as DROPOUT stages - with the ids train_graph.transformer_block gives them (per layer: call + 1 [,
+    call + 2], sites + 1 .. + 3 [+ 4] in execution order)."""
     assert x.shape == (n * S, D) and x.is_contiguous()
     fxy = None if pose_rpe is None else pose_rpe.pe_xy.freqs
     fyw = None if pose_rpe is None else pose_rpe.pe_yaw.freqs
+    if freqs is not None:  # (pe_xy.freqs, pe_yaw.freqs) given directly
+        fxy, fyw = freqs
+    site = call = 0
+    if drop is not None:
+        site, call = drop["site"], drop["call"]
+
+    def next_site():
+        nonlocal site
+        if drop is None or not drop["p"] > 0:
+            return None
+        site += 1
+        return (drop["p"], drop["seed"], site, drop["step"])
+
+    def next_call(attn):
+        nonlocal call
+        if drop is None or not attn.dropout_p > 0:
+            return None
+        call += 1
+        return (float(attn.dropout_p), drop["seed"], call, 1, drop["step"])
     rows = n * S
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
@@ -176,19 +206,19 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel)
-        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw)
+        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1))
         ch = layer_chain(rows)
         ch.load(x, BUF1, 0, n=D)
-        emit_attn_out(ch, a1, obuf, flag)
+        emit_attn_out(ch, a1, obuf, flag, drop=next_site())
         if dec:
             ch.store(BUF1, 0, D, x)
             emit_proj(ch, rows, layer.norm1, layer.attn, q2, with_kv=False)
             ch.run(rows)
-            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw)
+            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
             ch = layer_chain(rows)
             ch.load(x, BUF1, 0, n=D)
-            emit_attn_out(ch, layer.attn, obuf, flag)
-        emit_ffn(ch, layer)
+            emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site())
+        emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site())
         ch.rowmask(BUF1, 0, D, mask=src_invalid)
         ch.store(BUF1, 0, D, x)
         if l + 1 < len(layers):
@@ -196,6 +226,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         elif tail is not None:
             tail(ch)
         ch.run(rows)
+    if drop is not None:
+        drop["site"], drop["call"] = site, call
 
 
 def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = None, tile_rows: int = 16) -> torch.Tensor:

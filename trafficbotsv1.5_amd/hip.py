@@ -16,7 +16,7 @@ LIB_PATH = _PKG / "csrc" / "libtbx_hip.so"
 HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 
 # ---- constants mirrored from include/tbx_hip.h
-OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP = range(1, 11)
+OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP, OP_DROPOUT = range(1, 12)
 ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
 F_WSPLIT = 512
@@ -556,6 +556,13 @@ class Chain:
 
     def clamp(self, dst, dst_col, n, lo, hi):
         return self._add(op=OP_CLAMP, dst=dst, dst_col=dst_col, n=n, f0=lo, f1=hi)
+
+    def dropout(self, dst, dst_col, n, p: float, seed, site: int, step: int):
+        """dst[:, dst_col:+n] in place with tbx_keyed_dropout's mask of (seed, site, step, global row, column of n)."""
+        th = p * 4294967296.0
+        th = 1 if 0 < th < 1 else int(th)
+        return self._add(op=OP_DROPOUT, dst=dst, dst_col=dst_col, n=n, k=int(step), div=int(site), f0=1.0 / (1.0 - p),
+                         reserved=th - (1 << 32) if th >= (1 << 31) else th, p0=seed)
 
     def rowmask(self, dst, dst_col, n, mask=None, fill=0.0, row_div=0, valid_mask=False):
         """Fill rows whose mask byte is set (valid_mask: whose byte is clear, i.e. `mask` is a validity array)."""

@@ -229,6 +229,44 @@ def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor
     return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
 
 
+# The stepping pass of the time-batched rollout needs no autograd: with gradients off, whole layers run as the inference
+# engine's chain kernels (engine.run_block: ~6 launches per transformer layer instead of ~40 torch ops), with the keyed dropouts
+# of training as DROPOUT stages / inside the attention kernels - same site / call ids, hence same masks, as the torch ops here.
+NOGRAD_CHAINS = True
+
+
+def _chains_ok(x: Tensor) -> bool:
+    return NOGRAD_CHAINS and not torch.is_grad_enabled() and x.is_cuda and (_DROP is None or _DROP["tb"] == 1)
+
+
+def _transformer_block_chains(block, x, src_invalid, n, S, self_knn, cross, p, training) -> Tensor:
+    from .engine import SelfKnn, kv_tables, run_block
+
+    layers = list(block.layers)
+    xx = x.contiguous().clone()
+    knn = SelfKnn(self_knn["idx"], self_knn["invalid"], emb=self_knn.get("emb"), rel=self_knn.get("rel"))
+    cross_fn = None
+    if block.mode == "dec_cross_attn":
+        tg = list(cross(layers[0]))  # the same token sets for every layer
+        tabs = []
+        for t in tg:  # K|V tables of all layers in one chain launch ([tokens, n_layer * 256]); static sets: once per training step
+            ck = None if (t.cache is None or t.key is None) else (t.key, id(block), "all-layers")
+            if ck is None or ck not in t.cache:
+                tab = kv_tables(t.tokens.contiguous(), [(l.norm_tgt, l.attn) for l in layers])
+                if ck is not None:
+                    t.cache[ck] = tab
+            tabs.append(tab if ck is None else t.cache[ck])
+        cross_fn = lambda l: [Seg(tab, l * 2 * D, l * 2 * D + D, t.n_tgt, t.idx, t.invalid, t.emb, t.batch_div, rel=t.rel)
+                              for tab, t in zip(tabs, tg)]
+    drop = None
+    if training and _DROP is not None:
+        drop = dict(p=float(p), seed=_DROP["seed"], site=_DROP["site"], call=_DROP["call"], step=_DROP["t0"])
+    run_block(block, xx, src_invalid, n, S, knn, cross=cross_fn, freqs=self_knn.get("freqs"), drop=drop)
+    if drop is not None:
+        _DROP["site"], _DROP["call"] = drop["site"], drop["call"]
+    return xx
+
+
 def _drop(x: Tensor, p: float, training: bool) -> Tensor:
     """F.dropout of the reference as tbx_keyed_dropout (x [..., cols], batch entries = the scope's n_batch)."""
     if not (training and p > 0):
@@ -245,6 +283,8 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
                       training: bool = False) -> Tensor:
     """transformer_rpe.py:48-135,207-245. x [n*S,128]; self_knn = Targets kwargs (idx, invalid, emb | rel, freqs) among the sources;
     cross(layer) -> list[Targets] with UN-normalised tokens (norm_tgt is applied here)."""
+    if _chains_ok(x):
+        return _transformer_block_chains(block, x, src_invalid, n, S, self_knn, cross, p, training)
     ln = lambda m, t: F.layer_norm(t, (D,), m.weight, m.bias, m.eps)
     inv = src_invalid.reshape(-1).bool().unsqueeze(-1)
     for layer in block.layers:
