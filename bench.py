@@ -271,7 +271,7 @@ def train_main(args, tb, dev, rank, world, dist):
             "config": {"workload": f"training_step fwd+bwd+grad all-reduce+AdamW, {args.scenes} scenes/GPU of {args.agents} agents/"
                                    f"{args.polylines} polylines/{args.lights} lights, 90-step rollout, default 10,657,094-param model",
                        "global_batch": world * args.scenes, "parallelism": f"dp{world}", "fwd_bwd_hipgraph": not args.no_train_graph,
-                       "allreduce_bytes": n_live * 4, "note": "dropout as configured (p=0.1): residual / FFN / MLP through torch, "
+                       "allreduce_bytes": n_live * 4, "note": "time-batched rollout (stepping pass + one differentiated policy batch over the 90 steps); dropout as configured (p=0.1) with keyed masks: residual / FFN / MLP through tbx_keyed_dropout, "
                                                              "attention probabilities inside the HIP attention kernels"},
             "loss": float(m["loss"]), "finite": bool(torch.isfinite(m["loss"]))}
 
