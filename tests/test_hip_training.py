@@ -454,9 +454,24 @@ def test_nograd_policy_step_on_chain_kernels_equals_torch_ops_with_dropout(tb, s
                         res.append(TG.policy_step(model, (hv, hp, hm, ht), b["sc/ag_attr"].float().contiguous(), b["ref/ag_type"], valid,
                                                   b["sc/ag_pose"][:, :, -1], z, valid, b["gt/ag_navi"], valid, tl, mp, True))
                 outs[chains] = res
+                # light tokens encoded ahead (tl_pre): the agents' half alone - on the engine's schedule when chains are on
+                eng = []
+                for step in (1, 2):
+                    with TG._DropScope(n, 1, step, restart=TG._POLICY_SITE0):
+                        tl_feat = TG.tl_encoder(model.tl_encoder, ht, tl, True)
+                        ids = (TG._DROP["site"], TG._DROP["call"])
+                    with TG._DropScope(n, 1, step, restart=TG._POLICY_SITE0):
+                        eng.append(TG.policy_step(model, (hv, hp, hm, ht), b["sc/ag_attr"].float().contiguous(), b["ref/ag_type"], valid,
+                                                  b["sc/ag_pose"][:, :, -1], z, valid, b["gt/ag_navi"], valid, tl, mp, True,
+                                                  tl_pre=(tl_feat, ids), want_logits=False)[0])
+                outs[("engine", chains)] = eng
             finally:
                 TG._DROP, TG._FOLD_CACHE, TG.NOGRAD_CHAINS = None, None, True
     for (m0, l0), (m1, l1) in zip(outs[False], outs[True]):
         torch.testing.assert_close(m1, m0, rtol=2e-4, atol=2e-5 + 2e-4 * float(m0.abs().max()))
         torch.testing.assert_close(l1, l0, rtol=2e-4, atol=2e-5 + 2e-4 * float(l0.abs().max()))
     assert not torch.equal(outs[False][0][0], outs[False][1][0])
+    for step in range(2):  # agents' half: torch ops == engine chains == the full torch step
+        ref = outs[False][step][0]
+        for k in (("engine", False), ("engine", True)):
+            torch.testing.assert_close(outs[k][step], ref, rtol=2e-4, atol=2e-5 + 2e-4 * float(ref.abs().max()))

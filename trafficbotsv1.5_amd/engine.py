@@ -24,6 +24,28 @@ def _u8(mask: torch.Tensor) -> torch.Tensor:
     return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
 
 
+# Keyed dropouts of training for whoever emits chains while it is set (train_graph's stepping pass; None in inference):
+# dict(seed=int64[1] device tensor, site=last elementwise site id used, call=last attention call id used, step=closed-loop step).
+# The emitters below take their ids from it in execution order - the order train_graph's torch ops take theirs.
+DROP_CTX: Optional[dict] = None
+
+
+def drop_site(p: float):
+    """(p, seed, site, step) for a Chain.dropout stage, or None (inference / p = 0)."""
+    if DROP_CTX is None or not (p is not None and p > 0):
+        return None
+    DROP_CTX["site"] += 1
+    return (float(p), DROP_CTX["seed"], DROP_CTX["site"], DROP_CTX["step"])
+
+
+def drop_call(attn):
+    """hip.knarpe_attn's `drop` argument for an attention module, or None."""
+    if DROP_CTX is None or not attn.dropout_p > 0:
+        return None
+    DROP_CTX["call"] += 1
+    return (float(attn.dropout_p), DROP_CTX["seed"], DROP_CTX["call"], 1, DROP_CTX["step"])
+
+
 def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col: int, with_kv: bool) -> int:
     """[q | k | v | qt] (896 cols) or [q | qt] (640 cols) of the tile at dst_col. attention_rpe.py:92-98,147."""
     w_in, b_in = attn.in_proj_weight, attn.in_proj_bias
@@ -80,6 +102,9 @@ def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_
             if act:
                 ch.clamp(dst, out_col, lin.weight.shape[0], 0.0, float("inf"))
             del other
+        d = drop_site(mlp.dropout_p)
+        if d is not None:
+            ch.dropout(dst, out_col, lin.weight.shape[0], *d)
         cur, col = dst, out_col
     return cur
 
@@ -93,6 +118,9 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
         nxt = BUF0 if cur != BUF0 else BUF1
         half = lin.weight.shape[0]
         ch.linear(cur, 0, nxt, 0, lin.weight, lin.bias, relu=True)
+        d = drop_site(mlp.dropout_p)
+        if d is not None:
+            ch.dropout(nxt, 0, half, *d)
         ch.rowmask(nxt, 0, half, mask=row_invalid, fill=float("-inf"))
         ch.groupmax(nxt, 0, nxt, half, half)
         ch.rowmask(nxt, 0, 2 * half, mask=row_invalid, fill=0.0)
@@ -164,23 +192,13 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     fyw = None if pose_rpe is None else pose_rpe.pe_yaw.freqs
     if freqs is not None:  # (pe_xy.freqs, pe_yaw.freqs) given directly
         fxy, fyw = freqs
-    site = call = 0
-    if drop is not None:
-        site, call = drop["site"], drop["call"]
-
-    def next_site():
-        nonlocal site
-        if drop is None or not drop["p"] > 0:
-            return None
-        site += 1
-        return (drop["p"], drop["seed"], site, drop["step"])
-
-    def next_call(attn):
-        nonlocal call
-        if drop is None or not attn.dropout_p > 0:
-            return None
-        call += 1
-        return (float(attn.dropout_p), drop["seed"], call, 1, drop["step"])
+    global DROP_CTX
+    outer = DROP_CTX
+    if drop is not None:  # explicit ids (train_graph.transformer_block)
+        DROP_CTX = dict(seed=drop["seed"], site=drop["site"], call=drop["call"], step=drop["step"])
+    p_res = drop["p"] if drop is not None else block.dropout_p
+    next_site = lambda: drop_site(p_res)
+    next_call = drop_call
     rows = n * S
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
@@ -227,7 +245,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             tail(ch)
         ch.run(rows)
     if drop is not None:
-        drop["site"], drop["call"] = site, call
+        drop["site"], drop["call"] = DROP_CTX["site"], DROP_CTX["call"]
+        DROP_CTX = outer
 
 
 def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = None, tile_rows: int = 16) -> torch.Tensor:

@@ -50,19 +50,32 @@ class AddNaviLatent(nn.Module):
             ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
             ch.add(BUF0, 3 * d, BUF1, 0, d)
             return
+        from ...engine import drop_site
+
+        def drop(buf_col, mlp):  # the MLP's dropout after a layer (training's stepping pass; nothing in inference)
+            dd = drop_site(mlp.dropout_p)
+            if dd is not None:
+                ch.dropout(BUF0, buf_col, d, *dd)
+
         if z is not None:
             pad = ((self.in_dim + 15) // 16) * 16
             ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)
             ch.linear(BUF0, 0, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         else:
             ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
+        drop(2 * d, self.mlp_in)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
+        drop(d, self.mlp_in)
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        drop(2 * d, self.mlp_in)
         ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
         ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
         ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
+        drop(3 * d, self.mlp)
         ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
+        drop(0, self.mlp)
         ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
+        drop(3 * d, self.mlp)
         ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
         ch.add(BUF0, 3 * d, BUF1, 0, d)
 

@@ -10,6 +10,7 @@ from torch.distributions import Categorical, Independent, Normal
 
 from .. import hip
 from ..engine import emit_kv_tables
+from .. import engine
 from ..hip import BUF0, BUF1, Chain
 from ..utils.pose_emb import PoseEmb
 from .agent_encoder import AgentEncoder
@@ -111,6 +112,12 @@ class TrafficBots(nn.Module):
         self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe,
                                dest_feature=rc.get("dest_feature"))
         self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
+        if engine.DROP_CTX is not None:  # training's stepping pass: 12 DROPOUT stages more than a program holds - two launches
+            mid = torch.empty_like(feat)
+            ch.store(BUF1, 0, d, mid)
+            ch.run(n * A)
+            ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
+            ch.load(mid, BUF1, 0, n=d)
         self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"))
         self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
         ch.run(n * A)

@@ -435,16 +435,46 @@ def add_navi_latent(m, x: Tensor, z: Tensor, z_invalid: Tensor, training: bool) 
     return h + x
 
 
+def _agent_policy_engine(model, hv, hp, hm, ag_attr6, ag_type, z, z_valid, dest, navi_valid, tl_tokens, mp, tl_pre, training) -> Tensor:
+    """The agents' half of a policy step on the inference engine's schedule (TrafficBots.agent_policy: window PointNet chain,
+    3 K-nearest searches, 4 layer chains + 8 attention launches, 2 heads chains) - for the stepping pass of training: no
+    autograd, light tokens given (tl_pre), keyed dropouts emitted as stages / in-kernel in the torch path's site order."""
+    from . import engine
+
+    n, A, _ = hv.shape
+    tl_feat, ids = tl_pre
+    u8 = torch.uint8
+    out = dict(action_mean=torch.empty(n * A, 2, dtype=torch.float32, device=hp.device))
+    tl_kv = engine.kv_tables(tl_feat.contiguous(), model.ag_encoder.tl_kv_layers())
+    ctx = None
+    if training and _DROP is not None:
+        ctx = dict(seed=_DROP["seed"], site=ids[0], call=ids[1], step=_DROP["t0"])
+    engine.DROP_CTX = ctx
+    try:
+        model.agent_policy(hv, hp, hm, ag_attr6, ag_type.to(u8).argmax(-1).to(u8).contiguous(), z.reshape(n * A, -1).float().contiguous(),
+                           (~z_valid).reshape(-1).to(u8).contiguous(), dest.contiguous(), navi_valid.to(u8).contiguous(), tl_tokens, mp,
+                           tl_kv, out)
+    finally:
+        engine.DROP_CTX = None
+    if ctx is not None:
+        _DROP["site"], _DROP["call"] = ctx["site"], ctx["call"]
+    return out["action_mean"].view(n, A, 2)
+
+
 def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, dest, navi_valid, tl_tokens, mp, training: bool,
-                T: int = 1, tl_pre=None):
+                T: int = 1, tl_pre=None, want_logits: bool = True):
     """traffic_bots.py:188-221 -> (action mean [n,A,2], tl logits [n,L,5]). T > 1: time-batched call - every per-entry
     argument has n = scenes x T entries ([scene][step] order), `mp` stays per scene and `tl_tokens` is expand_tl_tokens'.
-    tl_pre = (tl_feat [n*L,128], (site, call) dropout ids after the light encoder): the light tokens were encoded ahead."""
+    tl_pre = (tl_feat [n*L,128], (site, call) dropout ids after the light encoder): the light tokens were encoded ahead.
+    want_logits=False (with tl_pre, autograd off): only the action means are needed - the agents' half runs on the engine's
+    chains (`_agent_policy_engine`) and None is returned for the logits."""
     hv, hp, hm, ht = hist
     n, A, W = hv.shape
     d = model.hidden_dim
     L = ht.shape[1]
     assert tl_tokens.get("time_batch", 1) == T
+    if tl_pre is not None and T == 1 and not want_logits and _chains_ok(hp):
+        return _agent_policy_engine(model, hv, hp, hm, ag_attr6, ag_type, z, z_valid, dest, navi_valid, tl_tokens, mp, tl_pre, training), None
     if tl_pre is None:
         tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
     else:
@@ -794,7 +824,7 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
             pre = None if tl_steps is None else (tl_steps[:, step - 1].reshape(n * L, -1), tl_pre[1])
             with _DropScope(n, 1, step, restart=_POLICY_SITE0):
                 return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z.detach(), z_valid, dest, navi_valid_, tl1, mp1,
-                                   model.training, tl_pre=pre)
+                                   model.training, tl_pre=pre, want_logits=not fused)
 
         if fused:  # the state machine is tbx_train_chain: per step the policy, then ONE launch
             ht_steps = ht_all.view(n, T, L, W)
