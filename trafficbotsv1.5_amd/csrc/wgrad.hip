@@ -11,6 +11,7 @@
 // them (deterministic: no float atomics). The 4 waves of a workgroup take a 2 x 2 group of blocks and share the rows (L1 / L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tbx_hip.h"
 #include "tbx_common.h"
@@ -137,7 +138,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 extern "C" int tbx_linear_wgrad_splits(int64_t rows, int n, int k) {
   if (rows <= 0 || n <= 0 || k <= 0) return TBX_ERR_ARG;
   const int groups = ((n + 127) / 128) * ((k + 127) / 128);
-  int64_t s = 1024 / groups;  // ~1024 workgroups: 2-4 wavefronts per SIMD on the 256 CUs
+  static const int target = [] {
+    const char* e = getenv("TBX_WGRAD_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 768;
+  }();
+  int64_t s = target / groups;  // 768 workgroups = 3 per CU = the 3 wavefronts per SIMD the kernel's 154 VGPRs allow: one full wave of workgroups, no tail
   if (s < 1) s = 1;
   const int64_t cap = (rows + 63) / 64;  // at least 64 rows per split
   if (s > cap) s = cap;
