@@ -107,10 +107,10 @@ class KernelEvents:
         hip = self.hip
         self._attn, self._run = hip.knarpe_attn, hip.Chain.run
 
-        def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs):
+        def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs)
+            self._attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw)
             e1.record()
             self.attn.append((e0, e1, attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs))))
 

@@ -429,6 +429,13 @@ def filter_futures(flags, col_bit: int, ag_role_any, n_scene: int, n_k: int, t_s
     return score, idx, trajs
 
 
+# Set to a dict for the duration of a training step (train_graph.training_step): chain kernels of the step's no-grad stepping
+# pass then pack each weight ONCE PER STEP into this scope instead of the per-parameter cache. A captured training step
+# (GraphedTrainStep) replays after the optimizer has moved the weights: a cached image from before the capture would be read by
+# the replay without ever being re-packed (its tbx_pack_weight launch is not in the graph) - with the scope the packing is.
+PACK_SCOPE: Optional[dict] = None
+
+
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
                   split: bool = False) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
@@ -437,9 +444,13 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
     base = w._base if w._base is not None else w
-    cache = base.__dict__.setdefault("_tbx_packed", {})
     bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
     key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split)
+    if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
+        cache, key = PACK_SCOPE, (id(base),) + key
+        PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
+    else:
+        cache = base.__dict__.setdefault("_tbx_packed", {})
     stamp = (w._version, w.data_ptr(), None if bias is None else bias._version)
     hit = cache.get(key)
     if hit is not None and hit[0] == stamp:

@@ -886,10 +886,11 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
         if seed is None:
             seed = torch.empty(1, dtype=torch.int64, device=next(wm.model.parameters()).device).random_()
         _DROP = {"seed": seed, "call": 0, "site": 0, "n_batch": 0, "tb": 1, "t0": 0}
+    hip.PACK_SCOPE = {}  # chain kernels of the stepping pass: weight images packed once per step (inside a captured step too)
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
-        _FOLD_CACHE, _DROP = None, None
+        _FOLD_CACHE, _DROP, hip.PACK_SCOPE = None, None, None
 
 
 def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
