@@ -1,0 +1,108 @@
+"""the data-loading boundary (`data_modules/data_h5_womd.py`) on the fixed-shape scene pack. CPU tests:
+the module's tensor-size tables equal the reference's (golden fixture generated from the reference's class), a pack round-trips
+to exactly what the reference's `__getitem__` hands out (float32 -> float16, everything else untouched: data_h5_womd.py:36-43),
+a batch of consecutive episodes equals the default collation of the per-episode dicts, and the pre-processing accepts it."""
+import json
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def D(tb):
+    return import_module("trafficbots_amd.data_modules.data_h5_womd")
+
+
+def test_tensor_sizes_equal_the_references(D, golden_dir):
+    g = json.loads((golden_dir / "womd_tensor_sizes.json").read_text())
+    for n_ag in (64, 128):
+        dm = D.DataH5womd(data_dir="/nonexistent", n_ag_sim=n_ag)
+        for name in ("tensor_size_train", "tensor_size_test", "tensor_size_val"):
+            ours = {k: list(v) for k, v in getattr(dm, name).items()}
+            assert ours == g[str(n_ag)][name], name
+            assert list(ours) == list(g[str(n_ag)][name]) or sorted(ours) == sorted(g[str(n_ag)][name])
+
+
+def _episodes(tb, n, n_ag=16, n_mp=64, n_tl=8):
+    eps = []
+    for s in range(n):
+        b = tb.synthetic.make_scene(1, n_ag, n_mp, n_tl, seed=100 + s)
+        eps.append({k: v[0].numpy() for k, v in b.items()})
+    return eps
+
+
+def test_pack_round_trip_equals_reference_loader_semantics(tb, D, tmp_path):
+    eps = _episodes(tb, 5)
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items()}
+    path = tmp_path / "training.tbxpack"
+    assert D.write_scene_pack(str(path), eps, sizes) == 5
+    ds = D.DatasetTrain(str(tmp_path / "training.h5"), sizes)  # the reference's path argument: served from the pack next to it
+    assert len(ds) == 5
+    saw_half = False
+    for i in (0, 3, 4):
+        item = ds[i]
+        assert item["episode_idx"] == i
+        for k, x in eps[i].items():
+            want = np.ascontiguousarray(x, dtype=np.float16 if x.dtype == np.dtype("<f4") else None)  # data_h5_womd.py:41-42
+            assert item[k].dtype == want.dtype and item[k].shape == want.shape, k
+            assert np.array_equal(item[k], want), k
+            assert item[k].flags["C_CONTIGUOUS"]
+            saw_half = saw_half or want.dtype == np.float16
+    assert saw_half
+    pack = D.ScenePack(str(path))
+    for kd in pack.keys.values():
+        assert kd["offset"] % D.ALIGN == 0
+    # a batch of consecutive episodes: one contiguous slice per key == default collation of the items
+    from torch.utils.data import default_collate
+
+    want = default_collate([ds[i] for i in (1, 2, 3)])
+    got = pack.batch(1, 3)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # DataLoader path (workers re-open the map), shuffled and not
+    dl = D.DataH5womd._get_dataloader(ds, 2, 0, shuffle=False)
+    first = next(iter(dl))
+    assert torch.equal(first["agent/pos"], want["agent/pos"][:0].new_tensor(np.stack([ds[0]["agent/pos"], ds[1]["agent/pos"]])))
+
+
+def test_val_items_attrs_and_dummy_agents(tb, D, tmp_path):
+    eps = _episodes(tb, 3)
+    for i, e in enumerate(eps):
+        e.update(scenario_id=f"scn{i:03d}", scenario_center=np.array([1.0 * i, 2.0, 0.0]), scenario_yaw=0.1 * i, with_map=bool(i % 2))
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items() if "/" in k}
+    D.write_scene_pack(str(tmp_path / "validation.tbxpack"), eps, sizes, attr_keys=("scenario_id", "scenario_center", "scenario_yaw", "with_map"))
+    big = dict(sizes)
+    big["agent/valid"] = (32,) + sizes["agent/valid"][1:]  # more agents than packed: dummy ones, as the reference does
+    ds = D.DatasetVal(str(tmp_path / "validation.h5"), big)
+    it = ds[2]
+    assert it["scenario_id"] == "scn002" and it["with_map"] is False and np.allclose(it["scenario_center"], [2.0, 2.0, 0.0])
+    assert it["agent/valid"].shape == (32,) + sizes["agent/valid"][1:] and it["agent/valid"].all()
+    assert np.array_equal(it["map/pos"], np.asarray(eps[2]["map/pos"], dtype=np.float16))
+    with pytest.raises(FileNotFoundError):
+        D.DatasetTrain(str(tmp_path / "missing.h5"), sizes)
+    (tmp_path / "bad.tbxpack").write_bytes(b"not a pack at all")
+    with pytest.raises(ValueError):
+        D.ScenePack(str(tmp_path / "bad.tbxpack"))
+
+
+def test_preprocessing_accepts_a_pack_batch(tb, D, tmp_path):
+    """The batch a pack delivers (float16 / bool / int64) goes through SceneCentricPreProcessing like the reference's batches."""
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    eps = _episodes(tb, 2, n_ag=8, n_mp=64, n_tl=8)
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items()}
+    D.write_scene_pack(str(tmp_path / "training.tbxpack"), eps, sizes)
+    batch = D.ScenePack(str(tmp_path / "training.tbxpack")).batch(0, 2)
+    ref = {k: torch.from_numpy(np.stack([e[k] for e in eps])) for k in sizes}
+    scfg = tb.config.default_sim_cfg()
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **scfg)
+    with torch.no_grad():
+        a = wm.pre_processing({k: v.clone() for k, v in batch.items()})
+        b = wm.pre_processing({k: v.clone() for k, v in ref.items()})
+    for k in ("sc/ag_pose", "sc/mp_pose", "gt/ag_pose"):
+        assert a[k].shape == b[k].shape
+        torch.testing.assert_close(a[k].float(), b[k].float(), rtol=2e-3, atol=0.15)  # float16 storage of coordinates up to +-150 m
+    assert torch.equal(a["sc/ag_valid"], b["sc/ag_valid"])
