@@ -62,9 +62,10 @@ class AgentEncoder(nn.Module):
 
     def encode(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, mp: Dict[str, Tensor],
                tl_invalid_u8: Tensor, tl_pose: Tensor, tl_kv: Tensor, prep: Optional[Dict[str, Tensor]] = None,
-               ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1,
+               ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1, tl_batch_div: int = 1,
                tail: Optional[Callable[[Chain], None]] = None, aux_stream=None) -> Tuple[Tensor, Dict[str, Tensor]]:
-        """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256].
+        """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256]
+        ([n/tl_batch_div * L, ..] with tl_pose / tl_invalid_u8 [n/tl_batch_div, L, ..] when the rollouts of a scene share its lights).
         -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows).
         aux_stream: the three K-nearest searches (they need the token poses only) run there while this stream runs the
         temporal PointNet of the agents' windows; their outputs live in `prep` across steps."""
@@ -93,7 +94,7 @@ class AgentEncoder(nn.Module):
             i_am, m_am, r_am, _ = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
                                                 self.dist_limit, tgt_batch_div=mp_batch_div, out=prep.get("_knn_am"), **kw)
             i_at, m_at, r_at, _ = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl,
-                                                self.dist_limit, out=prep.get("_knn_at"), **kw)
+                                                self.dist_limit, tgt_batch_div=tl_batch_div, out=prep.get("_knn_at"), **kw)
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
                     _knn_at=(i_at, m_at, r_at))
@@ -107,7 +108,7 @@ class AgentEncoder(nn.Module):
         kv_mp = self.kv_mp(mp)
         run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
-                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, rel=r_at)], tail=tail, pose_rpe=rp)
+                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp)
         return x, prep
 
     @staticmethod

@@ -98,11 +98,14 @@ class TrafficBots(nn.Module):
         n, A, W = hist_valid.shape
         d = self.hidden_dim
         dev = hist_pose.device
-        div = tl_tokens.get("mp_batch_div", 1)
+        # rollouts of one scene share its map tokens (mp_batch_div) and, in the rollout engine, its lights (tl_batch_div: the
+        # light tokens are then per scene and "ag_mp_batch_div" carries the agents' map sharing)
+        div = tl_tokens.get("ag_mp_batch_div", tl_tokens.get("mp_batch_div", 1))
         tl_inv = tl_tokens["tl_token_invalid_u8"]
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
-                                            dest=dest, mp_batch_div=div, aux_stream=aux_stream)
+                                            dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
+                                            aux_stream=aux_stream)
         out["prep"], out["ag_feat"] = prep, feat
         rp = self.pose_rpe
         navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)

@@ -33,8 +33,28 @@ def _state_bits(one_hot: Tensor) -> Tensor:
     return (one_hot.to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
 
 
+def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
+    """Per-scene view of traffic-light tokens that were expanded per rollout (`encode_scene(n_rollout=k)`: every per-light
+    tensor repeated k times along the batch, map targets indexed per scene through mp_batch_div = k): entry 0 of every group
+    of k, map targets indexed directly."""
+    n = tl_tokens["tl_token_pose"].shape[0]
+    out = {}
+    for key, v in tl_tokens.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n and key != "mp_feat_flat":
+            out[key] = v[::k].contiguous()
+        elif not key.startswith("_"):  # caches (K/V tables keyed by module) are rebuilt for the view
+            out[key] = v
+    out.update(mp_batch_div=1, tl_batch_div=k, ag_mp_batch_div=k)
+    return out
+
+
 class RolloutEngine:
     lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
+    # The light recurrence (window -> light encoder -> argmax of the next-state logits, dynamics.py:143-163) reads no agent and
+    # no latent, so the K rollouts of a scene (joint_future_pred, waymo_motion.py:458-462) carry K identical copies of it: with
+    # share_lights the engine steps the lights once per scene and the agents of the K rollouts attend to that one copy
+    # (batch_div = K on the light K/V tables, like the map's). Same kernels on the same rows' inputs: bit-identical rollouts.
+    share_lights = True
     hoist_constants = os.environ.get("TBX_NO_HOIST") is None  # False: the heads chain re-embeds the latent / destination feature every step (same values)
 
     _streams: Dict[int, tuple] = {}
@@ -70,6 +90,19 @@ class RolloutEngine:
         div = tl_tokens.get("mp_batch_div", 1)
         f32, u8 = torch.float32, torch.uint8
         self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
+        # lights once per scene when the K = div rollouts of every scene were given identical lights (one host check per reset)
+        kl = 1
+        if self.share_lights and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
+            g = tl_state_gt.reshape(n // div, div, *tl_state_gt.shape[1:])
+            tv = tl_tokens["tl_token_valid"].reshape(n // div, div, L)
+            tp = tl_tokens["tl_token_pose"].reshape(n // div, div, L, 3)
+            if bool((g == g[:, :1]).all()) and bool((tv == tv[:, :1]).all()) and bool((tp == tp[:, :1]).all()):
+                kl = div
+        self.tl_div = kl
+        nl = n // kl  # light batch entries
+        if kl > 1:
+            tl_tokens = lights_per_scene(tl_tokens, kl)
+            tl_state_gt = tl_state_gt[::kl]
         z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)
         S = {}
         # ---- static
@@ -98,7 +131,7 @@ class RolloutEngine:
             ag_motion=gt_motion[:, :, 0].float().contiguous(), navi_valid=_u8(ag_navi_valid), outside_map=z(n, A, dt=u8),
             dest_reached=z(n, A, dt=u8), tl_state=S["tl_gt"][:, :, 0].contiguous(),
             hist_valid=z(n, A, W, dt=u8), hist_pose=z(n, A, W, 3), hist_motion=z(n, A, W, 3),
-            hist_tl=torch.full((n, L, W), 0xFF, dtype=u8, device=dev))
+            hist_tl=torch.full((nl, L, W), 0xFF, dtype=u8, device=dev))
         init["hist_valid"][:, :, -1] = init["ag_valid"]
         init["hist_pose"][:, :, -1] = init["ag_pose"]
         init["hist_motion"][:, :, -1] = init["ag_motion"]
@@ -107,9 +140,9 @@ class RolloutEngine:
         for k, v in init.items():
             S[k] = v.clone()
         # ---- per-step model outputs and the rollout log
-        S["action_mean"], S["tl_logits"] = z(n * A, 2), z(n * L, 5)
+        S["action_mean"], S["tl_logits"] = z(n * A, 2), z(nl * L, 5)
         S.update(out_valid=z(n, A, n_step, dt=u8), out_pose=z(n, A, n_step, 3), out_motion=z(n, A, n_step, 3),
-                 out_action=z(n, A, n_step, 2), out_tl_state=z(n, L, n_step, dt=u8), out_outside_map=z(n, A, n_step, dt=u8),
+                 out_action=z(n, A, n_step, 2), out_tl_state=z(nl, L, n_step, dt=u8), out_outside_map=z(n, A, n_step, dt=u8),
                  out_dest_reached=z(n, A, n_step, dt=u8))
         self.S = S
         self.mp_tokens, self.tl_tokens = mp_tokens, tl_tokens
@@ -123,6 +156,13 @@ class RolloutEngine:
         st.max_yaw_rate = (C.c_float * 3)(*self.dyn.max_yaw_rate)
         st.dt = self.dyn.dt
         self.sim_state = st
+        # the lights' part of tbx_sim_step only touches the light arrays: its own descriptor with their batch size
+        self.sim_state_tl = st
+        if kl > 1:
+            stl = hip.SimState()
+            C.memmove(C.byref(stl), C.byref(st), C.sizeof(hip.SimState))
+            stl.n_batch = nl
+            self.sim_state_tl = stl
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
         self.graph = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
@@ -159,12 +199,16 @@ class RolloutEngine:
             self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6,
                                    S["ag_type_idx"], self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"],
                                    self.tl_tokens, self.mp_tokens, self.policy_out)
-            hip.sim_step(self.sim_state)
+            if self.tl_div > 1:
+                hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)
+                hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
+            else:
+                hip.sim_step(self.sim_state)
             return
         p = self.parity
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            hip.sim_step(self.sim_state, hip.SIM_LIGHTS)  # logits of the previous tl encoder pass -> lights of this step
+            hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)  # logits of the previous tl encoder pass -> lights of this step
             self._tl_ahead(1 - p)
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
@@ -210,8 +254,9 @@ class RolloutEngine:
         S, buf = self.S, RolloutBuffer(self.T, step_current)
         buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
         buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
+        out_tl = S["out_tl_state"] if self.tl_div == 1 else S["out_tl_state"].repeat_interleave(self.tl_div, 0)  # per rollout again
         if rule_checker is not None:
-            buf.violation.update(rule_checker.check_log(S["out_valid"], S["out_pose"], S["out_motion"], S["out_tl_state"]))
-        bits = (S["out_tl_state"].to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=self.dev, dtype=torch.int32)) & 1
+            buf.violation.update(rule_checker.check_log(S["out_valid"], S["out_pose"], S["out_motion"], out_tl))
+        bits = (out_tl.to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=self.dev, dtype=torch.int32)) & 1
         buf.vis_dict = {"action": S["out_action"], "tl_state": bits.bool()}
         return buf
