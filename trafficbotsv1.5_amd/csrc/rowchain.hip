@@ -212,7 +212,7 @@ __device__ __forceinline__ void weights_ahead(const uint32_t* prog, int j, int l
 // its first tile of the next packed LINEAR stage (whose fragments are thus in flight across the stage barrier). Loads
 // are unconditional with scalar-selected addresses (a load under a branch is waited for on the spot and degrades the
 // vmcnt bookkeeping to vmcnt(0)); with nothing left to fetch they re-read the tile's first block, an L2 hit.
-template <int MT, bool EXT>
+template <int MT, bool EXT, bool FULL>
 __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, WeightAhead& wa,
                                               int lane, int wave, int nwave, bool to_global) {
   const int j = lane & 15, g = lane >> 4;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
   float4(&cur)[CH] = wa.w;
   float4 nxt[CH];
   float cb = wa.bias;
-  const bool split = (s.flags & TBX_F_WSPLIT) != 0;
+  const bool split = FULL && (s.flags & TBX_F_WSPLIT) != 0;  // the lean kernel carries no split-bf16 code
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
     const int n0 = (ti - grp * n_tiles) * 16;
@@ -276,7 +276,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
       const int kb_left = last ? kb_next : kblocks - (c0 + CH);
 #pragma unroll
       for (int q = 0; q < CH; ++q) nxt[q] = gld4(pn + (q < kb_left ? q : 0) * 256, (uint32_t)lane * 16u);
-      if (split) {
+      if (FULL && split) {
         // three-product split-bf16 (TBX_F_WSPLIT): a = a_hi + a_lo, w = w_hi + w_lo in bf16 (RNE, ~2^-17 relative), the
         // products hi*hi + hi*lo + lo*hi on the 16x-faster v_mfma_f32_16x16x16_bf16 with fp32 accumulation (lo*lo, ~2^-18
         // of a product on average, is dropped). The A fragment of a k-block - the lane's four k values - is exactly the
@@ -348,7 +348,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
 // LINEAR (optionally grouped: `reserved` = G groups, group g reads src columns src_col + g*src_stride, writes
 // dst_col + g*dst_stride, with src_stride / dst_stride packed in `div` as (src << 16 | dst); its weight block is the next
 // n rows (or k rows if TBX_F_WT) after the previous group's, its bias the next n entries).
-template <int MT, bool EXT>
+template <int MT, bool EXT, bool FULL>
 __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, int stage, WeightAhead& wa) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,14 +381,15 @@ __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t, const ui
     // (RowchainArgs::first_packed) and by every packed LINEAR for the next one (stage.pad, set by tbx_rowchain_ex)
     const int nj = s.pad;
     if (wave < tiles_total)
-      linear_packed<MT, EXT>(s, t, prog, wa, lane, wave, nwave, to_global);
+      linear_packed<MT, EXT, FULL>(s, t, prog, wa, lane, wave, nwave, to_global);
     else if (nj > 0)  // no tile here: only keep the pipeline of the next stage fed
       weights_ahead(prog, nj, lane, wave, wa);
     wa.stage = nj > 0 ? nj : -1;
     return;
   }
 
-  // row-major weights ([n,k], or [k,n] with TBX_F_WT): reference path of the ABI, one k-block at a time
+  // row-major weights ([n,k], or [k,n] with TBX_F_WT): reference path of the ABI, one k-block at a time (not in the lean kernel)
+  if constexpr (FULL)
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
     const int n0 = (ti - grp * n_tiles) * 16;
@@ -657,7 +658,10 @@ __device__ unsigned int g_clk_launch;
 #define TBX_CLK(i)
 #endif
 
-template <int MT, bool EXT>
+// FULL = false: the lean instantiation every program of the hot path runs on - packed exact-fp32 LINEAR stages only, no DROPOUT.
+// Row-major weights (the ABI's reference path), split-bf16 stages and the training dropouts select FULL = true. The interpreter
+// is sensitive to its own size (its text is ~2/3 of the instruction cache): what a program does not use is not compiled in.
+template <int MT, bool EXT, bool FULL>
 __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   constexpr int ROWS = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -722,13 +726,15 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     s.p0 = rdp(16), s.p1 = rdp(18), s.p2 = rdp(20);
     switch (s.op) {
       case TBX_OP_LOAD: op_load<MT, EXT>(s, t); break;
-      case TBX_OP_LINEAR: op_linear<MT, EXT>(s, t, prog, i, wa); break;
+      case TBX_OP_LINEAR: op_linear<MT, EXT, FULL>(s, t, prog, i, wa); break;
       case TBX_OP_LAYERNORM: op_layernorm<MT, EXT>(s, t); break;
       case TBX_OP_ADD:
       case TBX_OP_COPY:
       case TBX_OP_CLAMP: op_elementwise<MT, EXT>(s, t); break;
       case TBX_OP_ROWMASK: op_rowmask<MT, EXT>(s, t); break;
-      case TBX_OP_DROPOUT: op_dropout<MT, EXT>(s, t); break;
+      case TBX_OP_DROPOUT:
+        if constexpr (FULL) op_dropout<MT, EXT>(s, t);
+        break;
       case TBX_OP_GROUPMAX: op_groupmax<MT, EXT>(s, t); break;
       case TBX_OP_POOLMAX: op_poolmax<MT, EXT>(s, t); break;
       case TBX_OP_STORE: op_store<MT, EXT>(s, t); break;
@@ -920,24 +926,33 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   hipStream_t s = (hipStream_t)stream;
   bool ext = !(ldw0 == ldw1 && ld_aux == TBX_AUX_LD);
   for (int i = 0; i < n_stages; ++i) ext = ext || (stages[i].op == TBX_OP_LINEAR && stages[i].dst == TBX_BUF_GLOBAL);
-#define TBX_RC_LAUNCH(MT, EXTF, NT)                                                                                        \
+  bool full = false;
+  for (int i = 0; i < n_stages; ++i)
+    full = full || stages[i].op == TBX_OP_DROPOUT ||
+           (stages[i].op == TBX_OP_LINEAR && (!(stages[i].flags & TBX_F_WPACK) || (stages[i].flags & TBX_F_WSPLIT)));
+#define TBX_RC_LAUNCH(MT, EXTF, FULLF, NT)                                                                                 \
   do {                                                                                                                     \
     if (lds_bytes > 64 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute((const void*)rowchain_kernel<MT, EXTF>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+      (void)hipFuncSetAttribute((const void*)rowchain_kernel<MT, EXTF, FULLF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds_bytes);                                                                           \
-    hipLaunchKernelGGL((rowchain_kernel<MT, EXTF>), dim3((unsigned)n_tiles), dim3(NT), lds_bytes, s, a);                   \
+    hipLaunchKernelGGL((rowchain_kernel<MT, EXTF, FULLF>), dim3((unsigned)n_tiles), dim3(NT), lds_bytes, s, a);            \
   } while (0)
-  if (tile_rows == 16) {
-    if (ext)
-      TBX_RC_LAUNCH(1, true, 512);
-    else
-      TBX_RC_LAUNCH(1, false, 512);
-  } else {
-    if (ext)
-      TBX_RC_LAUNCH(2, true, 512);
-    else
-      TBX_RC_LAUNCH(2, false, 512);
-  }
+#define TBX_RC_PICK(MT)                      \
+  do {                                       \
+    if (ext && full)                         \
+      TBX_RC_LAUNCH(MT, true, true, 512);    \
+    else if (ext)                            \
+      TBX_RC_LAUNCH(MT, true, false, 512);   \
+    else if (full)                           \
+      TBX_RC_LAUNCH(MT, false, true, 512);   \
+    else                                     \
+      TBX_RC_LAUNCH(MT, false, false, 512);  \
+  } while (0)
+  if (tile_rows == 16)
+    TBX_RC_PICK(1);
+  else
+    TBX_RC_PICK(2);
+#undef TBX_RC_PICK
 #undef TBX_RC_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
