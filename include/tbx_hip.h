@@ -284,7 +284,7 @@ int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int
  * exact-fp32 MFMA's ~1e-7, at 1/16 of the matrix-core time (the fp32 MFMA is the floor of a 16-row stage: 0.85 of 2.9 us). */
 int tbx_pack_weight_split(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 
-/* tile_rows in {16, 32}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
+/* tile_rows in {16, 32, 48}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                  int ldw, void* stream);
 

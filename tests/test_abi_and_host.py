@@ -35,7 +35,7 @@ def test_argument_validation_returns_codes_without_a_gpu(hip):
     assert lib.tbx_knn_embed(None, None, None, None, 1, 1, 1, 1, 1, 1.0, None, None, None, None, None, None, 128, None) == -1
     assert lib.tbx_rowchain(None, 0, 0, 0, 16, 132, None) == -1
     st = (hip.Stage * 1)(hip.Stage(op=hip.OP_LINEAR, src=0, dst=1, k=128, n=128, ld=128))
-    assert lib.tbx_rowchain(st, 1, 16, 0, 24, 132, None) == -2      # tile_rows must be 16 or 32
+    assert lib.tbx_rowchain(st, 1, 16, 0, 24, 132, None) == -2      # tile_rows must be 16, 32 or 48
     assert lib.tbx_rowchain(st, 1, 16, 0, 16, 130, None) == -3      # ldw % 4
     assert lib.tbx_rowchain(st, 1, 16, 0, 16, 132, None) == -1      # LINEAR without a weight pointer
     assert lib.tbx_sim_step(None, None) == -1

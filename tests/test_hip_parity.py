@@ -111,10 +111,11 @@ def test_mlp_input_pointnet(tb, hip, dev):
         ip[0, 0] = True
         y16 = m(xp.to(dev), ip.to(dev))
         torch.testing.assert_close(y16.cpu(), H.pointnet(P, "pn", xp, ip, 3), **TOL)
-        # 32-row tiles hold floor(32 / n_node) whole polylines (10 polylines: the last tile is partial); same rows, same
+        # 32- / 48-row tiles hold floor(tile / n_node) whole polylines (10 polylines: the last tile is partial); same rows, same
         # arithmetic per row -> bit-identical
-        m.tile_rows = 32
-        assert torch.equal(m(xp.to(dev), ip.to(dev)), y16), n_node
+        for tile in (32, 48):  # 48 rows: 6 / 4 / 2 whole polylines per tile
+            m.tile_rows = tile
+            assert torch.equal(m(xp.to(dev), ip.to(dev)), y16), (n_node, tile)
         m.tile_rows = None
 
 

@@ -112,7 +112,7 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     // all of a wave's requests first, then the LDS writes: the rows were written by the previous launch and come from L2 /
     // HBM at ~1 us per dependent round trip; a 640-wide load was 6 of them in a row (2.7 us -> one round trip)
     constexpr int RPW = ROWS / 8;  // rows per wave at the 8-wave workgroups every launch uses
-    if (nwave == 8 && w4 <= 256) {
+    if (RPW <= 4 && nwave == 8 && w4 <= 256) {  // (48-row tiles would hold 96 registers here: they take the loop below)
       float4 v[RPW][4];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
@@ -892,7 +892,7 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
                                int ldw0, int ldw1, int ld_aux, void* stream) {
   if (stages == nullptr || n_stages <= 0 || n_rows <= 0) return TBX_ERR_ARG;
   if (n_stages > TBX_MAX_STAGES) return TBX_ERR_UNSUPPORTED;
-  if (tile_rows != 16 && tile_rows != 32) return TBX_ERR_UNSUPPORTED;
+  if (tile_rows != 16 && tile_rows != 32 && tile_rows != 48) return TBX_ERR_UNSUPPORTED;
   if (ldw0 <= 0 || ldw1 <= 0 || ld_aux <= 0 || ldw0 % 4 != 0 || ldw1 % 4 != 0 || ld_aux % 4 != 0) return TBX_ERR_ALIGN;
   if (group_rows < 0 || group_rows > tile_rows) return TBX_ERR_UNSUPPORTED;
   if (group_rows > 0 && n_rows % group_rows != 0) return TBX_ERR_ARG;
@@ -950,8 +950,10 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   } while (0)
   if (tile_rows == 16)
     TBX_RC_PICK(1);
-  else
+  else if (tile_rows == 32)
     TBX_RC_PICK(2);
+  else
+    TBX_RC_PICK(3);
 #undef TBX_RC_PICK
 #undef TBX_RC_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

@@ -470,12 +470,16 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
 
 
 def group_tile_rows(group_rows: int, n_groups: int) -> int:
-    """Tile height of a grouped chain: 32-row tiles hold floor(32 / W) whole groups, so the per-stage fixed costs of a
-    workgroup are shared by them - worth it once the groups outnumber the CUs several times (measured at 4096 windows of 11
-    rows: 415 -> ~230 us); small grids keep one group per 16-row tile (more workgroups, shortest critical path)."""
-    if group_rows > 16:
-        return 32
-    return 32 if (32 // group_rows >= 2 and n_groups >= 1024) else 16
+    """Tile height of a grouped chain. Small grids keep one group per 16-row tile (more workgroups, shortest critical path). Once
+    the groups outnumber the CUs several times the per-stage fixed costs of a workgroup are worth sharing: the tile (32 or 48 rows)
+    that wastes the fewest rows holds floor(tile / W) whole groups - 11-step windows: 4 in 48 rows (92 % of the MFMA rows used; 2 in
+    32 rows: 69 %). Measured at 4096 windows of 11 rows: 415 us (16) -> ~230 us (32) -> see DESIGN.md (48). TBX_TILE48=0: never 48."""
+    if n_groups < 1024 or group_rows > 24:
+        return 32 if group_rows > 16 else 16
+    use = lambda t: (t // group_rows) * group_rows / t
+    cands = [t for t in ((32, 48) if os.environ.get("TBX_TILE48", "1") != "0" else (32,)) if t // group_rows >= 1]
+    best = max(cands, key=lambda t: (use(t), -t))
+    return best if best // group_rows >= 2 or group_rows > 16 else 16
 
 
 class Chain:
