@@ -92,3 +92,62 @@ def test_chain_program_encoding(hip):
     st = ch.stages[0]
     assert (st.op, st.src, st.dst, st.n) == (hip.OP_COPY, 0, 1, 4)
     assert C.sizeof(hip.Stage) == 88 and C.sizeof(hip.AttnSeg) == 64
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu(hip):
+    lib = hip.load()
+    assert lib.tbx_keyed_dropout(None, None, 4, 4, 2, 0.1, None, 0, 1, 0, None) == -1
+    assert lib.tbx_linear_wgrad_splits(0, 128, 128) == -1
+    assert 1 <= lib.tbx_linear_wgrad_splits(2_000_000, 128, 128) <= 1024
+    assert lib.tbx_linear_wgrad_splits(100, 128, 128) == 2  # at least 64 rows per split
+    assert lib.tbx_linear_wgrad(None, 128, None, 128, 1000, 128, 128, None, None, None, 4, None) == -1
+    assert lib.tbx_train_chain_fwd(None, None, 0, 0, 0, 1, None) == -1
+    args = hip.TrainChainArgs()
+    args.n_batch, args.n_ag, args.n_step, args.n_step_gt, args.n_node, args.window = 1, 4, 10, 11, 20, 11
+    assert lib.tbx_train_chain_fwd(C.byref(args), None, 8, 0, 0, 1, None) == -1  # null state pointers
+    assert lib.tbx_train_chain_bwd(C.byref(args), None, 8, 8, None, None, None) == -1
+
+
+def test_group_tile_rows_picks_the_least_wasteful_tile(hip):
+    assert hip.group_tile_rows(11, 64) == 16          # small grid: one window per 16-row tile (shortest critical path)
+    assert hip.group_tile_rows(11, 4096) == 48        # 4 windows in 48 rows (92 %) beat 2 in 32 (69 %)
+    assert hip.group_tile_rows(20, 4096) == 48        # 2 polylines in 48 rows beat 1 in 32
+    assert hip.group_tile_rows(20, 100) == 32
+    assert hip.group_tile_rows(16, 4096) == 32        # 2 x 16 fills 32 rows exactly
+    assert hip.group_tile_rows(5, 4096) == 32         # 6 in 32 (94 %) vs 9 in 48 (94 %): the smaller tile
+
+
+def test_lights_per_scene_view_of_expanded_light_tokens(tb):
+    """RolloutEngine steps the lights once per scene: the per-scene view of tokens that encode_scene expanded per rollout."""
+    E = import_module("trafficbots_amd.utils.rollout_engine")
+    n_scene, K, L, M = 3, 4, 5, 7
+    g = torch.Generator().manual_seed(0)
+    per_scene = {"tl_token_pose": torch.randn(n_scene, L, 3, generator=g), "tl_token_valid": torch.rand(n_scene, L, generator=g) > 0.3,
+                 "knn_idx_tl2mp": torch.randint(0, M, (n_scene, L, 2), generator=g), "tl_token_attr": torch.randn(n_scene, L, 8, generator=g)}
+    expanded = {k: v.repeat_interleave(K, 0) for k, v in per_scene.items()}
+    expanded.update(mp_batch_div=K, n_mp=M, mp_feat_flat=torch.randn(n_scene * M, 8, generator=g), _kv_mp={"cached": 1})
+    view = E.lights_per_scene(expanded, K)
+    for k, v in per_scene.items():
+        assert torch.equal(view[k], v), k
+    assert view["mp_batch_div"] == 1 and view["tl_batch_div"] == K and view["ag_mp_batch_div"] == K and view["n_mp"] == M
+    assert view["mp_feat_flat"] is expanded["mp_feat_flat"] and "_kv_mp" not in view
+
+
+def test_tl_nll_all_steps_equals_the_per_step_loop(tb):
+    """train_graph.tl_nll_all_steps (waymo_motion.py:270-283 for every step at once) vs the step loop with Categorical."""
+    TG = import_module("trafficbots_amd.train_graph")
+    from torch.distributions import Categorical
+
+    g = torch.Generator().manual_seed(1)
+    n, T, L, Tt = 2, 12, 5, 9  # ground truth ends before the rollout does
+    logits = torch.randn(n, T, L, 5, generator=g)
+    tl_gt = torch.nn.functional.one_hot(torch.randint(0, 5, (n, L, Tt), generator=g), 5).bool()
+    inv = torch.rand(n, L, generator=g) < 0.3
+    nll, nll_inv = TG.tl_nll_all_steps(logits, tl_gt, inv)
+    for step in range(1, T + 1):
+        if step < Tt:
+            want = -Categorical(logits=logits[:, step - 1]).log_prob(tl_gt[:, :, step].max(-1)[1])
+            torch.testing.assert_close(nll[:, :, step - 1], want)
+            assert torch.equal(nll_inv[:, :, step - 1], inv)
+        else:
+            assert float(nll[:, :, step - 1].abs().max()) == 0.0 and bool(nll_inv[:, :, step - 1].all())
