@@ -254,7 +254,10 @@ enum {
   TBX_F_ROW_BATCH_MOD = 32, /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
   TBX_F_WPACK = 64,   /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
   TBX_F_MASK_INV = 128, /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
-  TBX_F_WSPLIT = 512    /* LINEAR + TBX_F_WPACK: p0 is a tbx_pack_weight_split() image: split-bf16, three products on the bf16 MFMA */
+  TBX_F_WSPLIT = 512,   /* LINEAR + TBX_F_WPACK: p0 is a tbx_pack_weight_split() image: split-bf16, three products on the bf16 MFMA */
+  TBX_F_ROWSKIP = 1024  /* LINEAR + TBX_F_WPACK (LDS destination): p1 holds a byte per global row; rows whose byte is set (clear with
+                           TBX_F_MASK_INV) and padding rows are NOT written - with TBX_F_ACCUM into the residual buffer this is
+                           x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };

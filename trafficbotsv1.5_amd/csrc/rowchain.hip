@@ -237,6 +237,7 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
   float4 nxt[CH];
   float cb = wa.bias;
   const bool split = FULL && (s.flags & TBX_F_WSPLIT) != 0;  // the lean kernel carries no split-bf16 code
+  const bool rowskip = (s.flags & TBX_F_ROWSKIP) != 0 && !to_global;
   for (int ti = wave; ti < tiles_total; ti += nwave) {
     const int grp = ti / n_tiles;
     const int n0 = (ti - grp * n_tiles) * 16;
@@ -258,6 +259,21 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
       kb_next = nx.kblocks;
     }
     const float nb = gld1(nbase + (kb_next > 0 ? kb_next : kblocks) * 256, (uint32_t)lane * 4u);
+    // TBX_F_ROWSKIP: bit (m * 4 + r) set = the lane's row m*16 + g*4 + r keeps its old content (requested now, used after the MFMAs)
+    uint32_t skip = 0u;
+    if (rowskip) {
+      const uint8_t* mask = (const uint8_t*)s.p1;
+      const bool inv = (s.flags & TBX_F_MASK_INV) != 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m * 16 + g * 4 + r;
+          bool sk = row >= t.n_valid;
+          if (!sk) sk = (gld1(mask + t.g0 + row) != 0) != inv;
+          skip |= sk ? (1u << (m * 4 + r)) : 0u;
+        }
+    }
     f32x4 acc[MT], acc_x[MT], acc_y[MT];  // acc_x / acc_y: the two cross products of the split path
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -335,8 +351,9 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
         // stage may read a K padded to 16
         if (to_global) {
           if (col_ok && m * 16 + g * 4 + r < t.n_valid) gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
-        } else if (col_ok)
-          dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+        } else if (col_ok) {
+          if (!(skip & (1u << (m * 4 + r)))) dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+        }
         else if (!accum && G == 1 && col < lds_d - s.dst_col)
           dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
       }
@@ -824,6 +841,7 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
     if (src_hi > buf_ld(s.src) || s.dst_col + (G - 1) * gs_dst + s.n > buf_ld(s.dst)) return TBX_ERR_UNSUPPORTED;
     if (s.src == s.dst && !(s.dst_col >= src_hi || s.src_col >= dst_hi)) return TBX_ERR_UNSUPPORTED;  // in place: disjoint only
   }
+  if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP) && (!(s.flags & TBX_F_WPACK) || gdst || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
   if (s.op != TBX_OP_LINEAR && (s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;

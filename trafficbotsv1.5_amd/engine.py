@@ -9,6 +9,7 @@ Formulation (exact restatements of modules/attention_rpe.py, SURVEY.md §0 findi
   * `linear_rpe` is folded into the query side (qt_h = W_rpe_k,h^T q_h) and into the weighted sum
     (sum_t a_t (W_rpe_v e_t + b) = W_rpe_v (sum_t a_t e_t) + b  with sum_t a_t = 1 in eval mode).
 """
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -28,6 +29,9 @@ def _u8(mask: torch.Tensor) -> torch.Tensor:
 # dict(seed=int64[1] device tensor, site=last elementwise site id used, call=last attention call id used, step=closed-loop step).
 # The emitters below take their ids from it in execution order - the order train_graph's torch ops take theirs.
 DROP_CTX: Optional[dict] = None
+# Residual updates folded into the producing LINEAR stage (accumulate into the token row, masked rows skipped): 5 stages fewer per
+# decoder layer. False: separate ROWMASK / ADD stages (the previous schedule; results differ by fp32 rounding order only).
+FUSED_RESIDUAL = os.environ.get("TBX_FUSED_RESIDUAL", "1") != "0"
 
 
 def drop_site(p: float):
@@ -64,6 +68,10 @@ def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tenso
     # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
     ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
               dst_stride=DH)
+    if drop is None and ch.pack_weights and FUSED_RESIDUAL:
+        # one stage: x += rows without a valid target ? 0 : out_proj(...)  (TBX_F_ROWSKIP + accumulate into the token row)
+        ch.linear(BUF0, 0, x_buf, 0, attn.out_proj_weight, attn.out_proj_bias, accum=True, skip_rows=row_no_valid)
+        return
     ch.linear(BUF0, 0, AUX, 0, attn.out_proj_weight, attn.out_proj_bias)
     ch.rowmask(AUX, 0, D, mask=row_no_valid)
     if drop is not None:
@@ -77,6 +85,9 @@ def emit_ffn(ch: Chain, layer, x_buf: int = BUF1, drop_hidden=None, drop_out=Non
     ch.linear(BUF0, 0, BUF0, D, layer.linear1.weight, layer.linear1.bias, relu=True)
     if drop_hidden is not None:
         ch.dropout(BUF0, D, layer.linear1.weight.shape[0], *drop_hidden)
+    if drop_out is None and ch.pack_weights and FUSED_RESIDUAL:
+        ch.linear(BUF0, D, x_buf, 0, layer.linear2.weight, layer.linear2.bias, accum=True)  # x += linear2(...) in one stage
+        return
     ch.linear(BUF0, D, AUX, 0, layer.linear2.weight, layer.linear2.bias)
     if drop_out is not None:
         ch.dropout(AUX, 0, D, *drop_out)

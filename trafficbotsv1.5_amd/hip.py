@@ -20,6 +20,7 @@ OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_P
 ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
 F_WSPLIT = 512
+F_ROWSKIP = 1024
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -537,11 +538,13 @@ class Chain:
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
 
     def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False, groups=1,
-               src_stride=0, dst_stride=0, out=None):
+               src_stride=0, dst_stride=0, out=None, skip_rows=None, skip_is_valid=False):
         """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt).
         groups > 1: block-diagonal; weight holds the groups' blocks stacked along dim 0, group g reads
         src_col + g*src_stride and writes dst_col + g*dst_stride.
-        dst = GLOBAL with out = [rows, ld] tensor: the result goes straight to out[g, dst_col:+n] (no LDS staging)."""
+        dst = GLOBAL with out = [rows, ld] tensor: the result goes straight to out[g, dst_col:+n] (no LDS staging).
+        skip_rows (packed weights only): u8 per global row; flagged rows (un-flagged with skip_is_valid) keep dst's old content -
+        with accum into the residual buffer: x += flagged ? 0 : linear(...) in one stage."""
         w = self._rows2d(weight)
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
@@ -550,10 +553,13 @@ class Chain:
             w, flags = packed_weight(w, bias, wt, groups, self.split_bf16), (flags & ~F_WT) | F_WPACK
             if self.split_bf16:
                 flags |= F_WSPLIT
+            if skip_rows is not None:
+                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0)
             return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=None, p2=out,
+                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=skip_rows, p2=out,
                              ld2=0 if out is None else self._rows2d(out).stride(0),
                              reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
+        assert skip_rows is None, "skip_rows needs packed weights"
         return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
                          act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias, p2=out,
                          ld2=0 if out is None else self._rows2d(out).stride(0),
