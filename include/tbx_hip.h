@@ -255,6 +255,9 @@ enum {
   TBX_F_WPACK = 64,   /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
   TBX_F_MASK_INV = 128, /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
   TBX_F_WSPLIT = 512,   /* LINEAR + TBX_F_WPACK: p0 is a tbx_pack_weight_split() image: split-bf16, three products on the bf16 MFMA */
+  TBX_F_LOAD2 = 2048,   /* LOAD: a second source in the same stage (one memory round trip for both): buffer `src`, column `src_col`
+                           (=) p2[row_of(g) * ld2 + c], c < reserved; whole float4s on both sides (n, ld, reserved, ld2 % 4 == 0,
+                           16-byte aligned), reserved <= 256, no TBX_F_ACCUM */
   TBX_F_ROWSKIP = 1024  /* LINEAR + TBX_F_WPACK (LDS destination): p1 holds a byte per global row; rows whose byte is set (clear with
                            TBX_F_MASK_INV) and padding rows are NOT written - with TBX_F_ACCUM into the residual buffer this is
                            x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */

@@ -109,22 +109,30 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   if (src != nullptr && !accum && width == s.n && (s.n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 &&
       ((((uintptr_t)src) & 15) == 0)) {
     const int w4 = s.n >> 2;
+    // TBX_F_LOAD2: a second source rides in the same round trip (the token row x beside the attention output)
+    const bool two = (s.flags & TBX_F_LOAD2) != 0;
+    const float* src2 = (const float*)s.p2;
+    float* dst2 = t.b(s.src) + s.src_col;
+    const int ldb = t.l(s.src), w4b = two ? (s.reserved >> 2) : 0;
     // all of a wave's requests first, then the LDS writes: the rows were written by the previous launch and come from L2 /
     // HBM at ~1 us per dependent round trip; a 640-wide load was 6 of them in a row (2.7 us -> one round trip)
     constexpr int RPW = ROWS / 8;  // rows per wave at the 8-wave workgroups every launch uses
     if (RPW <= 4 && nwave == 8 && w4 <= 256) {  // (48-row tiles would hold 96 registers here: they take the loop below)
-      float4 v[RPW][4];
+      float4 v[RPW][4], v2[RPW];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave + rr * 8;
         const bool live = r < t.n_valid;
-        const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
+        const int64_t grow = live ? row_of(s, t.g0 + r) : 0;
+        const float* srow = src + grow * (int64_t)s.ld;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int c4 = lane + 64 * it;
           v[rr][it] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (live && c4 < w4) v[rr][it] = gld4(srow + c4 * 4);
         }
+        v2[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (two && live && lane < w4b) v2[rr] = gld4(src2 + grow * (int64_t)s.ld2 + lane * 4);
       }
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
@@ -134,16 +142,23 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
           const int c4 = lane + 64 * it;
           if (c4 < w4) *(float4*)(dst + r * ld + c4 * 4) = v[rr][it];
         }
+        if (two && lane < w4b) *(float4*)(dst2 + r * ldb + lane * 4) = v2[rr];
       }
       return;
     }
     for (int r = wave; r < ROWS; r += nwave) {
       const bool live = r < t.n_valid;
-      const float* srow = src + (live ? row_of(s, t.g0 + r) : 0) * (int64_t)s.ld;
+      const int64_t grow = live ? row_of(s, t.g0 + r) : 0;
+      const float* srow = src + grow * (int64_t)s.ld;
       for (int c4 = lane; c4 < w4; c4 += 64) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) v = gld4(srow + c4 * 4);
         *(float4*)(dst + r * ld + c4 * 4) = v;
+      }
+      if (two && lane < w4b) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = gld4(src2 + grow * (int64_t)s.ld2 + lane * 4);
+        *(float4*)(dst2 + r * ldb + lane * 4) = v;
       }
     }
     return;
@@ -840,6 +855,15 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
     if (G > 1 && (s.n % 16 != 0)) return TBX_ERR_UNSUPPORTED;
     if (src_hi > buf_ld(s.src) || s.dst_col + (G - 1) * gs_dst + s.n > buf_ld(s.dst)) return TBX_ERR_UNSUPPORTED;
     if (s.src == s.dst && !(s.dst_col >= src_hi || s.src_col >= dst_hi)) return TBX_ERR_UNSUPPORTED;  // in place: disjoint only
+  }
+  if (s.op == TBX_OP_LOAD && (s.flags & TBX_F_LOAD2)) {  // only the whole-float4 path carries the second source
+    if (s.p0 == nullptr || s.p2 == nullptr || (s.flags & TBX_F_ACCUM) || s.k > s.n) return TBX_ERR_ARG;
+    if ((s.n & 3) || (s.ld & 3) || (s.dst_col & 3) || (s.reserved & 3) || (s.ld2 & 3) || (s.src_col & 3) || s.reserved <= 0 || s.reserved > 256 ||
+        s.ld2 < s.reserved)
+      return TBX_ERR_UNSUPPORTED;
+    if ((((uintptr_t)s.p0) | ((uintptr_t)s.p2)) & 15) return TBX_ERR_ALIGN;
+    if (s.src < 0 || s.src > 2 || s.src_col < 0 || s.src_col + s.reserved > buf_ld(s.src)) return TBX_ERR_UNSUPPORTED;
+    if (s.src == s.dst && !(s.src_col >= s.dst_col + s.n || s.dst_col >= s.src_col + s.reserved)) return TBX_ERR_UNSUPPORTED;
   }
   if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP) && (!(s.flags & TBX_F_WPACK) || gdst || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;

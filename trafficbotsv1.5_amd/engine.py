@@ -32,6 +32,7 @@ DROP_CTX: Optional[dict] = None
 # Residual updates folded into the producing LINEAR stage (accumulate into the token row, masked rows skipped): 5 stages fewer per
 # decoder layer. False: separate ROWMASK / ADD stages (the previous schedule; results differ by fp32 rounding order only).
 FUSED_RESIDUAL = os.environ.get("TBX_FUSED_RESIDUAL", "1") != "0"
+LOAD2 = os.environ.get("TBX_LOAD2", "1") != "0"  # token rows + attention output loaded by one stage
 
 
 def drop_site(p: float):
@@ -60,11 +61,17 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     return nq + NH * D
 
 
-def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1, drop=None):
+def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1, drop=None, x: Optional[torch.Tensor] = None):
     """x += out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), zero for rows without a valid target.
     attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233. drop = (p, seed, site, step): the residual dropout of training
-    (transformer_rpe.py:56-60) as a keyed DROPOUT stage."""
-    ch.load(obuf, BUF0, 0, n=O_LD)
+    (transformer_rpe.py:56-60) as a keyed DROPOUT stage. x: the token rows [rows, 128] are not in x_buf yet - they are loaded in the
+    same stage as the attention output (TBX_F_LOAD2: one memory round trip for both)."""
+    if x is not None and LOAD2:
+        ch.load2(obuf, BUF0, 0, x, x_buf, 0)
+    else:
+        if x is not None:
+            ch.load(x, x_buf, 0, n=D)
+        ch.load(obuf, BUF0, 0, n=O_LD)
     # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
     ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
               dst_stride=DH)
@@ -237,16 +244,14 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel)
         hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1))
         ch = layer_chain(rows)
-        ch.load(x, BUF1, 0, n=D)
-        emit_attn_out(ch, a1, obuf, flag, drop=next_site())
+        emit_attn_out(ch, a1, obuf, flag, drop=next_site(), x=x)
         if dec:
             ch.store(BUF1, 0, D, x)
             emit_proj(ch, rows, layer.norm1, layer.attn, q2, with_kv=False)
             ch.run(rows)
             hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
             ch = layer_chain(rows)
-            ch.load(x, BUF1, 0, n=D)
-            emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site())
+            emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site(), x=x)
         emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site())
         ch.rowmask(BUF1, 0, D, mask=src_invalid)
         ch.store(BUF1, 0, D, x)

@@ -21,6 +21,7 @@ ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
 F_WSPLIT = 512
 F_ROWSKIP = 1024
+F_LOAD2 = 2048
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -533,6 +534,13 @@ class Chain:
             flags, k, div = flags | F_ROW_BATCH_MOD, batch_mod[0], batch_mod[1]
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=k, flags=flags, div=div, ld=self._rows2d(src).stride(0),
                          p0=src, p1=p1)
+
+    def load2(self, src, dst, dst_col, src_b, dst_b, dst_b_col):
+        """Two row loads in ONE stage (one memory round trip): dst[:, dst_col:+src.shape[1]] = src and dst_b[:, dst_b_col:+..] =
+        src_b (whole float4 rows on both sides, src_b at most 256 floats wide)."""
+        a, b = self._rows2d(src), self._rows2d(src_b)
+        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=a.shape[1], k=0, flags=F_LOAD2, ld=a.stride(0), p0=a,
+                         src=dst_b, src_col=dst_b_col, reserved=b.shape[1], ld2=b.stride(0), p2=b)
 
     def zero(self, dst, dst_col, n):
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
