@@ -337,6 +337,10 @@ def main():
         Eng = type(eng)
         Eng.lights_ahead = False
         try:
+            # the host must be AHEAD of the device while the events are recorded: an event pair around a launch otherwise also
+            # times the wait for the host to enqueue that launch (seen on a loaded box: 27 us "launches" of a 10 us kernel).
+            # A device-side delay in front lets the host queue all launches of the profiled steps first.
+            torch.cuda._sleep(int(2.4e9 * (0.01 + 0.006 * a.profile_steps)))
             with KernelEvents(hip) as ke:
                 eng.run(a.profile_steps, use_graph=False)
         finally:
