@@ -356,3 +356,28 @@ def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mod
     assert torch.equal(flag_big[:small.shape[0] // 1], flag_small) if n_cmp == len(parts) else torch.equal(flag_big[:1024], flag_small)
     assert int(flag_big.sum()) == 1
     torch.testing.assert_close(big[:small.shape[0]], small, rtol=2e-4, atol=2e-5)
+
+
+def test_action_head_fused_branches_bit_identical(tb, hip, dev):
+    """ActionHead.emit with the three per-type branches as stacked / block-diagonal stages (hip.stacked_linear: layer 1 one
+    128 -> 384 stage, layers 2 / 3 groups = 3, the 2-wide outputs padded to 16) == nine per-branch stages, bit for bit; the
+    stacked copies follow in-place weight updates."""
+    M = import_module("trafficbots_amd.models.modules")
+    m, _ = _filled(tb, M.action_head.ActionHead, 21, dev, hidden_dim=128, action_dim=2, n_layer=3, mlp_use_layernorm=False,
+                   log_std=-2.0, branch_type=True)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 37, 128, generator=g).to(dev)
+    ty = torch.nn.functional.one_hot(torch.randint(0, 3, (3, 37), generator=g), 3).bool().to(dev)
+    valid = (torch.rand(3, 37, generator=g) > 0.2).to(dev)
+    outs = []
+    for fused in (True, False, True):
+        m.fused_branches = fused
+        outs.append(m(x, valid, ty).mean.clone())
+        if len(outs) == 2:
+            with torch.no_grad():  # an optimizer-like in-place update: the stacked weights must be rebuilt
+                for p in m.parameters():
+                    p.mul_(1.01)
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[2], outs[0])
+    m.fused_branches = False
+    assert torch.equal(m(x, valid, ty).mean, outs[2])

@@ -471,6 +471,32 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     return out
 
 
+def stacked_linear(linears, pad_out_to: int = 0):
+    """(W [G * n, k], b [G * n]) = the weights / biases of G equally shaped nn.Linear layers stacked along the output dimension
+    (each block zero-padded to pad_out_to output rows if given): branches that read the same input become ONE LINEAR stage
+    (G * n outputs), parallel branches one block-diagonal stage (groups = G). Cached like packed_weight: per parameter version,
+    or per training step inside PACK_SCOPE."""
+    ws, bs = [l.weight for l in linears], [l.bias for l in linears]
+    key = ("stacked", tuple(id(w) for w in ws), pad_out_to)
+    stamp = tuple((w._version, w.data_ptr(), b._version) for w, b in zip(ws, bs))
+    cache = PACK_SCOPE if PACK_SCOPE is not None else ws[0].__dict__.setdefault("_tbx_stacked", {})
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    n, k = ws[0].shape
+    npad = max(n, pad_out_to)
+    with torch.no_grad():
+        W = torch.zeros(len(ws) * npad, k, dtype=torch.float32, device=ws[0].device)
+        B = torch.zeros(len(ws) * npad, dtype=torch.float32, device=ws[0].device)
+        for g, (w, b) in enumerate(zip(ws, bs)):
+            W[g * npad:g * npad + n].copy_(w)
+            B[g * npad:g * npad + n].copy_(b)
+    cache[key] = (stamp, W, B)
+    if PACK_SCOPE is not None:
+        PACK_SCOPE.setdefault("_keep", {})[id(ws[0])] = ws[0]
+    return W, B
+
+
 def group_tile_rows(group_rows: int, n_groups: int) -> int:
     """Tile height of a grouped chain. Small grids keep one group per 16-row tile (more workgroups, shortest critical path). Once
     the groups outnumber the CUs several times the per-stage fixed costs of a workgroup are worth sharing: the tile (32 or 48 rows)

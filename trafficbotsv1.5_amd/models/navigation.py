@@ -42,11 +42,11 @@ class NaviEncoder(nn.Module):
         d = self.hidden_dim
         l_mp, l_pe = self.mlp_mp.linear_layers()[0][0], self.mlp_pe.linear_layers()[0][0]
         if dest_feature is not None:
-            ch.load(dest_feature, BUF0, d, n=d)
+            ch.load2(navi_pe, BUF0, 0, dest_feature, BUF0, d)  # both inputs in one load stage (one memory round trip)
         else:
             ch.load(mp_feat_flat, BUF0, 0, n=d, row_idx=navi_row)
             ch.linear(BUF0, 0, BUF0, d, l_mp.weight, l_mp.bias)
-        ch.load(navi_pe, BUF0, 0, n=d)
+            ch.load(navi_pe, BUF0, 0, n=d)
         ch.linear(BUF0, 0, BUF0, d, l_pe.weight, l_pe.bias, accum=True)
 
     def forward(self, ag_navi: Tensor, ag_pose: Tensor, mp_token_feature: Tensor, mp_token_pose: Tensor) -> Tensor:
