@@ -106,3 +106,44 @@ def test_preprocessing_accepts_a_pack_batch(tb, D, tmp_path):
         assert a[k].shape == b[k].shape
         torch.testing.assert_close(a[k].float(), b[k].float(), rtol=2e-3, atol=0.15)  # float16 storage of coordinates up to +-150 m
     assert torch.equal(a["sc/ag_valid"], b["sc/ag_valid"])
+
+
+def test_convert_h5_through_a_stand_in_h5py(tb, D, tmp_path, monkeypatch):
+    """convert_h5 reads the reference's file layout (attrs['data_len'], one group per episode index, per-group attrs) through
+    the h5py API. h5py is absent here: a minimal in-memory stand-in of the few calls used drives the same code."""
+    import sys
+    import types
+
+    eps = _episodes(tb, 3)
+    for i, e in enumerate(eps):
+        e["_attrs"] = dict(scenario_id=f"s{i}", scenario_center=np.array([float(i), 0.0, 0.0]), scenario_yaw=0.5 * i, with_map=True)
+
+    class Group(dict):
+        def __init__(self, arrays, attrs):
+            super().__init__(arrays)
+            self.attrs = attrs
+
+    class File:
+        def __init__(self, path, mode="r", **kw):
+            self.attrs = {"data_len": len(eps)}
+            self._g = {str(i): Group({k: v for k, v in e.items() if k != "_attrs"}, e["_attrs"]) for i, e in enumerate(eps)}
+
+        def __getitem__(self, k):
+            return self._g[k]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items() if k != "_attrs"}
+    out = tmp_path / "validation.tbxpack"
+    assert D.convert_h5("validation.h5", str(out), sizes, with_attrs=True) == 3
+    ds = D.DatasetVal(str(out), sizes)
+    it = ds[1]
+    assert it["scenario_id"] == "s1" and it["with_map"] is True and float(it["scenario_yaw"]) == 0.5
+    assert np.array_equal(it["agent/pos"], np.asarray(eps[1]["agent/pos"], dtype=np.float16))
