@@ -7,8 +7,8 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import D, SelfKnn, emit_pointnet, kv_tables, run_block
-from ..hip import Chain, Seg
+from ..engine import emit_mlp, D, SelfKnn, emit_pointnet, kv_tables, run_block
+from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
 from .modules.polyline_encoder import PolylineEncoder
@@ -100,7 +100,17 @@ class AgentEncoder(nn.Module):
                     _knn_at=(i_at, m_at, r_at))
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         ch = Chain(hip.group_tile_rows(W, n * A), d + 4)
-        cur = self.input_encoder.emit(ch, prep["attr"], prep["pe"])
+        ie = self.input_encoder
+        if (ie.mode == "cat" and len(ie.mlp.linear_layers()) == 3 and ie.mlp.output_dim % 16 == 0 and prep["attr"].shape[1] % 4 == 0
+                and ie.mlp.output_dim + ie.pe_dim <= d):
+            # attribute rows (agent_prep zero-fills them to 32 columns) and pose embeddings in ONE load stage; the embedding
+            # goes straight to where the concatenation wants it (BUF1[:, out:out+pe] - the three MLP stages ping-pong
+            # BUF0 -> BUF1 -> BUF0 -> BUF1 and write whole 16-column tiles of [0, out) only)
+            ch.load2(prep["attr"], BUF0, 0, prep["pe"], BUF1, ie.mlp.output_dim)
+            cur = emit_mlp(ch, ie.mlp, BUF0, 0)
+            assert cur == BUF1
+        else:
+            cur = ie.emit(ch, prep["attr"], prep["pe"])
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
         ch.run(n * A * W, group_rows=W)
         if aux_stream is not None:
