@@ -348,7 +348,7 @@ def main():
         (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
         rows_dom, t_dom, b_dom, n_dom = ke.dominant
         ach = b_dom / t_dom / 1e9
-        variant = "knarpe_attn_kernel<1,0>" if rows_dom >= 4096 else "knarpe_attn_kernel<4,0>"  # csrc/attn.hip: wave per row from 4096 rows
+        variant = "knarpe_attn_kernel<1,0>" if rows_dom >= 1024 else "knarpe_attn_kernel<4,0>"  # csrc/attn.hip: wave per row from 1024 rows
         traffic, traffic_src = pmc_traffic(a, variant)
         if traffic is None:
             traffic, traffic_src = pmc_traffic(a, "knarpe_attn_kernel")

@@ -15,6 +15,7 @@
 //   (pose_emb.py:50-55, positional_emb.py:25,53: [cos(x f)16 sin(x f)16 cos(y f)16 sin(y f)16 cos(k yaw)32 sin(k yaw)32]).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tbx_hip.h"
 #include "tbx_common.h"
@@ -705,7 +706,12 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   if (rc != TBX_OK) return rc;
   a.out = out;
   a.row_no_valid = row_no_valid;
-  const bool big = a.n_rows >= 4096;
+  static const int big_rows = [] {
+    const char* e = getenv("TBX_ATTN_BIG_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1024;  // measured at 1024 rows x 89 pairs (training's stepping pass): 28 us with 4 waves per row, ~24 us with one
+  }();
+  const bool big = a.n_rows >= big_rows;  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
   if (a.drop_thresh != 0u) {
