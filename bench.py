@@ -232,7 +232,7 @@ def train_main(args, tb, dev, rank, world, dist):
     DP = import_module("trafficbots_amd.pl_modules.data_parallel")
     # library GEMMs of the training step through rocBLAS: hipBLASLt's pick for the [n*A*W, 64] x [64, 128] input-gradient GEMMs
     # of the window PointNets runs at ~3 TF/s (105 us each, 9 per rollout step); rocBLAS: 1.03 -> 0.98 s per step (measured)
-    torch.backends.cuda.preferred_blas_library("cublas")
+    torch.backends.cuda.preferred_blas_library(os.environ.get("TBX_BLAS", "cublas"))
     torch.manual_seed(0)  # identical initial weights on every rank
     wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
     wm = wm.to(dev).train()
