@@ -152,7 +152,7 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
 LAYER_LDW0, LAYER_LDW1, LAYER_AUX = 644, 132, 132
 
 
-BIG_ROWS = 16384  # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
+BIG_ROWS = int(os.environ.get("TBX_BIG_ROWS", "16384"))  # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
 
 
 def layer_chain(rows: int) -> Chain:
