@@ -233,13 +233,14 @@ def train_main(args, tb, dev, rank, world, dist):
     # library GEMMs of the training step through rocBLAS: hipBLASLt's pick for the [n*A*W, 64] x [64, 128] input-gradient GEMMs
     # of the window PointNets runs at ~3 TF/s (105 us each, 9 per rollout step); rocBLAS: 1.03 -> 0.98 s per step (measured)
     torch.backends.cuda.preferred_blas_library(os.environ.get("TBX_BLAS", "cublas"))
-    torch.manual_seed(0)  # identical initial weights on every rank
+    torch.manual_seed(0)  # the same initial weights on every rank ...
     wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
     wm = wm.to(dev).train()
+    DP.broadcast_parameters(wm.model)  # ... and rank 0's by construction (one flat broadcast, as DDP's constructor does)
     (opt,), _ = wm.configure_optimizers()
     seeds = shard_scenes(args.scenes * world, rank, world)
     batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=seeds[0]).items()}
-    torch.manual_seed(1234 + rank)  # per-rank noise streams (dropout, latent, forcing)
+    torch.manual_seed(DP.rank_seed(1234, rank))  # per-rank noise streams (dropout, latent, forcing)
 
     def sync():
         torch.cuda.synchronize()

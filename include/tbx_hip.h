@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define TBX_ABI_VERSION 1
+#define TBX_ABI_VERSION 2
 
 enum {
   TBX_OK = 0,
@@ -382,6 +382,24 @@ typedef struct tbx_sim_state {
   uint8_t* out_dest_reached;  /* [n,A,T] */
   float max_acc[3], max_yaw_rate[3]; /* per type idx (veh, ped, cyc) */
   float dt;
+  /* ---- optional (NULL = off): the rest of RolloutBuffer.add (buffer.py:39-78, filled at waymo_motion.py:250-300) */
+  float* out_reward;          /* [n,A,T,4] DifferentiableReward.get (rewards.py:35-85, loss.py:9-36 "cosine"):
+                                 r_imitation_pos, r_imitation_rot, r_imitation_spd, diffbar_reward = (pos + rot) + spd */
+  uint8_t* out_reward_valid;  /* [n,A,T] diffbar_reward_valid: pred_valid & gt_valid while ground truth lasts, else pred_valid */
+  uint8_t* out_tf;            /* [n,A,T] mask_teacher_forcing = ag_override["valid"] of the step */
+  float* out_tl_nll;          /* [n,L,T] -Categorical(logits).log_prob(argmax gt state), 0 once the light ground truth ended
+                                 (waymo_motion.py:276-283) */
+  float w_pos, w_rot, w_spd;  /* reward weights (l_pos / l_rot / l_spd .weight) */
+  /* ---- optional: step-wise drivers (WaymoMotion.forward, waymo_motion.py:118-204) */
+  const uint8_t* player_valid;  /* [n,A]   player_override["valid"]: the action below replaces the policy's (dynamics.py:104-107) */
+  const float* player_action;   /* [n,A,2] physical (acc, yaw rate) */
+  const uint8_t* ov_valid;      /* [n,A]   ag_override of THIS step given explicitly instead of tf_mask / gt_* at the step index */
+  const float* ov_pose;         /* [n,A,3] */
+  const float* ov_motion;       /* [n,A,3] */
+  const uint8_t* ov_tl_valid;   /* [n,L]   tl_override["valid"] (with ov_valid) */
+  const uint8_t* ov_tl_state;   /* [n,L]   5-bit state mask */
+  uint8_t* now_outside;         /* [n,A]   outside_map_this_step  (for Dynamics.disable_ag by the caller, TBX_SIM_NO_DISABLE) */
+  uint8_t* now_reached;         /* [n,A]   dest_reached_this_step */
 } tbx_sim_state_t;
 
 int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
@@ -391,7 +409,14 @@ int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
  * one stream while the agents of the same step run on another; both parts read *step, TBX_SIM_ADVANCE bumps it and
  * must be ordered after both. With TBX_SIM_ADVANCE next to a part, the last workgroup of that part's kernel to arrive
  * bumps the counter (every workgroup has read it by then): no extra launch. tbx_sim_step == all three, one kernel. */
-enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4 };
+enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4,
+       /* Step-wise drivers split a step where the reference's Python does (waymo_motion.py:118-204 is `forward`, :250-275 the
+        * caller's rule check + disable_ag / disable_navi, traffic_bots.py:123-143 appends the windows at the NEXT forward):
+        * modifiers of TBX_SIM_AGENTS / TBX_SIM_LIGHTS ... */
+       TBX_SIM_NO_DISABLE = 8,  /* flags are computed, logged and left in now_outside / now_reached; nothing is disabled */
+       TBX_SIM_NO_APPEND = 16,  /* the sliding windows are left alone */
+       /* ... and a part of its own: append the current agent / light state to the windows (no step is simulated) */
+       TBX_SIM_APPEND = 32 };
 int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* stream);
 
 

@@ -381,6 +381,45 @@ def gen_model(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_roll_steps, train_fixture):
     npz(f"model_{tag}.npz", **out)
 
 
+def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn):
+    """§8a rows 19-20 at the size of BASELINE config 3's scenes (one scene of 64 agents / 1024 polylines / 128 lights): the
+    reference's training_step with every RNG site neutralised and the damped action head (see gen_model): loss dict, per-module
+    gradient norms, spot gradients. ~3 min of reference CPU time."""
+    torch.manual_seed(0)
+    mcfg0 = ref_model_cfg(n_tgt_knn=n_tgt_knn)
+    mcfg0["tf_cfg"]["dropout_p"] = 0.0
+    mcfg0["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
+    mcfg0["add_navi_latent"]["mlp_dropout_p"] = 0.0
+    wm_t = build_wm(mcfg0, p_training_rollout_prior=0.0)
+    wm_t.teacher_forcing_training.prob_forcing_agent = 0.0
+    wm_t.pre_processing[0].dropout_p_history = -1.0
+    tb.utils.det_fill(wm_t.model, 0)
+    wm_t.train()
+    with torch.no_grad():
+        for k, p in wm_t.model.named_parameters():
+            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                p.mul_(0.02)
+    batch = tb.synthetic.make_scene(1, n_ag, n_mp, n_tl, seed=0)
+    torch.manual_seed(7)
+    loss = wm_t.training_step({k: v.clone() for k, v in batch.items()}, 0)
+    loss.backward()
+    out = {"dtrain_loss": loss.detach()}
+    for k, v in wm_t.logged.items():
+        out["dtrain_" + k.split("/")[1]] = v.detach()
+    gn = {}
+    for k, p in wm_t.model.named_parameters():
+        top = k.split(".")[0]
+        if p.grad is not None:
+            gn[top] = gn.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in gn.items():
+        out["dgradnorm_" + k] = np.float64(v) ** 0.5
+    for k in ("ag_encoder.tf_ag2agmptl.layers.3.attn.linear_rpe.weight", "mp_encoder.tf_mp2mp.layers.0.attn.in_proj_weight",
+              "tl_encoder.tf_tl2tlmp.layers.1.attn_src.out_proj_weight", "latent_encoder.ag_encoder_post.input_encoder.mlp.fc_layers.0.weight",
+              "navi_predictor.mlp.fc_layers.0.weight", "action_head.mlp_mean.0.fc_layers.0.weight"):
+        out["dgrad_" + k] = dict(wm_t.model.named_parameters())[k].grad[:8, :16]
+    npz(f"train_{tag}.npz", **out)
+
+
 @torch.no_grad()
 def gen_rules():
     """the reference's TrafficRuleChecker stepped over seeded crowded episodes. Inputs come from
@@ -442,7 +481,7 @@ def gen_filter():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "c1", "c2", "rules", "filter"]
+    which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "rules", "filter"]
     if "filter" in which:
         gen_filter()
     if "rules" in which:
@@ -453,3 +492,5 @@ if __name__ == "__main__":
         gen_model("c1", 8, 64, 8, 4, n_roll_steps=90, train_fixture=True)
     if "c2" in which:
         gen_model("c2", 64, 1024, 128, 32, n_roll_steps=14, train_fixture=False)
+    if "train_c2" in which:
+        gen_train("c2", 64, 1024, 128, 32)

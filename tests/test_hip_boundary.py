@@ -1,0 +1,295 @@
+"""GPU parity of the boundary rows the round-1 review found open (VERDICT r01 "Next round" 1-2):
+  * `WaymoMotion.forward` with the reference's arguments, `rollout(..., player_policy)`, `hparams` (waymo_motion.py:118-311);
+  * the inference `RolloutBuffer` fields `tl_state_nll`, `diffbar_reward`, `action_log_prob`, `mask_teacher_forcing`
+    (buffer.py:39-146) vs the oracle AND the reference's golden values;
+  * `NaviPredictor.forward` on the HIP chain kernel vs the reference's golden log-probabilities (navigation.py:175-278);
+  * the WOSAC shape (32 rollouts x 128 agents, shared map + shared lights) vs the oracle, rollout by rollout;
+  * 80 free-running closed-loop steps at the 64-agent / 1024-polyline / 128-light scene (damped action head) vs the oracle.
+"""
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rule_checks as R
+from oracle import trafficbots_oracle as O
+from test_hip_rollout import _compare, _oracle_tokens, _setup
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _damp(wm, P, f=0.02):
+    with torch.no_grad():
+        for k, p in wm.model.state_dict().items():
+            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                p.mul_(f)
+                P[k] = P[k] * f
+
+
+def _replay_args(tb, wm, b, bd, om, mp_o, tl_o):
+    with torch.no_grad():
+        post_o = om.latent_encoder(b["gt/ag_valid"], b["sc/ag_attr"], b["gt/ag_motion"], b["gt/ag_pose"], b["ref/ag_type"],
+                                   b["gt/tl_state"], mp_o, tl_o, posterior=True)
+    return post_o.mean, post_o.valid, b["gt/ag_valid"].any(-1)
+
+
+def test_hparams_are_the_constructor_arguments(tb):
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    scfg = tb.config.default_sim_cfg()
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **scfg)
+    for k in ("time_step_current", "time_step_end", "p_training_rollout_prior", "training_detach_model_input", "lr_navi"):
+        assert wm.hparams[k] == scfg[k] and getattr(wm.hparams, k) == scfg[k]
+    assert wm.hparams.differentiable_reward.l_rot.weight == scfg["differentiable_reward"]["l_rot"]["weight"]
+
+
+def test_rollout_buffer_fields_vs_oracle_and_reference(tb, golden_dir):
+    """tl_state_nll / diffbar_reward / mask_teacher_forcing / action_log_prob of a reactive replay (the reference fills them at
+    waymo_motion.py:250-300; tbx_sim_step logs them per step) vs the oracle's Sim.rollout and the reference's golden buffer."""
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=4), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    mp_o, tl_o = _oracle_tokens(om, b)
+    z, zv, navi_v = _replay_args(tb, wm, b, bd, om, mp_o, tl_o)
+    n_roll, n_cmp = 90, 16
+    with torch.no_grad():
+        ro = O.Sim(om, scfg, False).rollout(b, mp_o, tl_o, z, zv, b["gt/ag_navi"], navi_v, scfg.teacher_forcing_joint_future_pred, n_roll)
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    buf = wm.reactive_replay(bd, mp, tl, z.to(dev), zv.to(dev), bd["gt/ag_navi"], navi_v.to(dev), wm.teacher_forcing_joint_future_pred,
+                             True, step_end=n_roll)
+    sl = slice(0, n_cmp)
+    # the light recurrence reads no agent: teacher-forced for the whole ground truth, so its NLL compares over all 90 steps
+    assert torch.equal(buf.tl_state_nll_invalid[:, 0].cpu(), ro["tl_state_nll_invalid"])
+    torch.testing.assert_close(buf.tl_state_nll[:, 0].cpu(), ro["tl_state_nll"], rtol=1e-4, atol=2e-5)
+    assert torch.equal(buf.mask_teacher_forcing[:, 0].cpu(), ro["mask_teacher_forcing"])
+    assert torch.equal(buf.diffbar_reward["diffbar_reward_valid"][:, 0, :, sl].cpu(), ro["diffbar_reward_valid"][:, :, sl])
+    # the reward is -(0.1 SmoothL1 + 10 * cosine + ..) of a pose that agrees to ~1e-4 over these steps
+    torch.testing.assert_close(buf.diffbar_reward["diffbar_reward"][:, 0, :, sl].cpu(), ro["diffbar_reward"][:, :, sl], rtol=1e-3, atol=2e-4)
+    r = buf.diffbar_reward
+    torch.testing.assert_close(r["diffbar_reward"], (r["r_imitation_pos"] + r["r_imitation_rot"]) + r["r_imitation_spd"], rtol=0, atol=0)
+    # action_log_prob: log N(mean | mean, exp(log_std)) of the 2-d action, 0 for invalid agents (dynamics.py:87-91)
+    log_std = torch.stack([P[f"action_head.log_std.{i}"] for i in range(3)], 0)  # [3, 2]
+    lp_type = -(log_std.sum(-1) + 2 * 0.5 * np.log(2 * np.pi))
+    lp = (b["ref/ag_type"].float() * lp_type).sum(-1).unsqueeze(-1) * ro["pred_valid"].float()
+    torch.testing.assert_close(buf.action_log_prob[:, 0, :, sl].cpu(), lp[:, :, sl], rtol=1e-6, atol=1e-6)
+    assert buf.navi_log_prob.shape == (1, 1, 8, 1) and torch.equal(buf.navi_log_prob_valid[:, 0, :, 0].cpu(), navi_v)
+    buf.compute_log_prob(None)
+    assert buf.log_prob.shape == (1, 1, 8)
+    # ... and the REFERENCE's own buffer
+    g = np.load(golden_dir / "model_c1.npz")
+    np.testing.assert_allclose(buf.tl_state_nll[:, 0].cpu().numpy(), g["rr_tl_state_nll"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(buf.diffbar_reward["diffbar_reward"][:, 0, :, sl].cpu().numpy(), g["rr_diffbar_reward"][:, :, sl],
+                               rtol=1e-3, atol=5e-4)
+
+
+def test_forward_with_reference_arguments_equals_reactive_replay(tb):
+    """A step-wise driver written against the reference - teacher_forcing.get -> WaymoMotion.forward(mp_tokens, tl_tokens,
+    ag_override, tl_override, player_override, deterministic_action) -> rule check -> buffer.add -> dynamics.disable_ag /
+    disable_navi (waymo_motion.py:232-275) - must produce the engine's rollout bit for bit: same kernels, same inputs."""
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 8, 16, generator=g).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    T = 40
+    fast = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True, step_end=T)
+    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["gt/ag_valid"],
+                 "gt_pose": bd["gt/ag_pose"], "gt_motion": bd["gt/ag_motion"], "ag_latent": z, "ag_latent_valid": valid,
+                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid}
+    # (1) the packaged loop
+    slow = wm.rollout(ag_tokens, mp, tl, bd["gt/tl_state"], wm.teacher_forcing_joint_future_pred, wm._rule_checker(bd, bd["gt/ag_navi"], tl),
+                      T, True, stepwise=True)
+    slow.flatten_joint_future(1)
+    # (2) the same loop written out here, the way a user of the reference would (20 steps are enough to cover overrides + free steps)
+    tf = wm.teacher_forcing_joint_future_pred
+    eng = wm.begin_rollout(ag_tokens, mp, tl, bd["gt/tl_state"], tf, wm._rule_checker(bd, bd["gt/ag_navi"], tl), T, stepwise=True)
+    dyn, poses, valids = wm.dynamics, [], []
+    for step in range(1, 21):
+        ag_override, tl_override = tf.get(step, dyn.ag_valid, dyn.ag_pose, dyn.ag_motion)
+        pred, vis = wm.forward(mp_tokens=mp, tl_tokens=tl, ag_override=ag_override, tl_override=tl_override, player_override=None,
+                               deterministic_action=True)
+        assert set(pred) == {"action_log_prob", "pred_valid", "pred_pose", "pred_motion", "pred_tl_state_dist"}
+        assert set(vis) == {"pred_valid", "pred_pose", "pred_motion", "action", "ag_navi", "ag_navi_valid", "navi_reached", "tl_state"}
+        poses.append(pred["pred_pose"]), valids.append(pred["pred_valid"])
+        viol = {"outside_map_this_step": eng.S["now_outside"].bool(), "dest_reached_this_step": eng.S["now_reached"].bool()}
+        dyn.disable_ag(viol, bd["gt/ag_valid"][:, :, step])
+        dyn.disable_navi(viol)
+    assert torch.equal(torch.stack(poses, 2), fast.pred_pose[:, 0, :, :20])
+    assert torch.equal(torch.stack(valids, 2), fast.pred_valid[:, 0, :, :20])
+    for name in ("pred_valid", "pred_pose", "pred_motion", "tl_state_nll", "tl_state_nll_invalid", "action_log_prob",
+                 "mask_teacher_forcing", "navi_log_prob", "navi_log_prob_valid"):
+        assert torch.equal(getattr(slow, name), getattr(fast, name)), name
+    for k in fast.violation:
+        assert torch.equal(slow.violation[k], fast.violation[k]), k
+    for k in fast.diffbar_reward:
+        assert torch.equal(slow.diffbar_reward[k], fast.diffbar_reward[k]), k
+    assert torch.equal(slow.vis_dict["action"], fast.vis_dict["action"])
+    assert torch.equal(slow.vis_dict["tl_state"], fast.vis_dict["tl_state"])
+
+
+def test_player_policy_overrides_actions(tb):
+    """rollout(..., player_policy): the player's physical action replaces the policy's for the agents it claims (dynamics.py:
+    104-107). A player that hands back the policy's own logged actions reproduces the rollout bit for bit; a constant-action
+    player drives its agent along the closed-form MultiPath++ trajectory while the others' first free step is unchanged."""
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4, ragged=False)
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    valid = bd["gt/ag_valid"].any(-1)
+    z = torch.zeros(1, 8, 16, device=dev)
+    T = 25
+    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["gt/ag_valid"],
+                 "gt_pose": bd["gt/ag_pose"], "gt_motion": bd["gt/ag_motion"], "ag_latent": z, "ag_latent_valid": valid,
+                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid}
+    run = lambda pol: wm.rollout(ag_tokens, mp, tl, bd["gt/tl_state"], wm.teacher_forcing_joint_future_pred,
+                                 wm._rule_checker(bd, bd["gt/ag_navi"], tl), T, True, player_policy=pol)
+    base = run(lambda pose: None)
+    state = {"t": 0}
+
+    def echo(pose):  # the policy's own action of this step, claimed for every agent
+        t = state["t"]
+        state["t"] += 1
+        return {"valid": torch.ones(1, 8, dtype=torch.bool, device=dev), "action": base.vis_dict["action"][:, :, t]}
+
+    same = run(echo)
+    assert torch.equal(same.pred_pose, base.pred_pose) and torch.equal(same.vis_dict["action"], base.vis_dict["action"])
+
+    def constant(pose):
+        v = torch.zeros(1, 8, dtype=torch.bool, device=dev)
+        v[0, 0] = True
+        a = torch.zeros(1, 8, 2, device=dev)
+        a[0, 0, 0], a[0, 0, 1] = 1.0, 0.1
+        return {"valid": v, "action": a}
+
+    drv = run(constant)
+    act = drv.vis_dict["action"]
+    pv = drv.pred_valid[0, 0]
+    assert torch.equal(act[0, 0][pv], torch.tensor([1.0, 0.1], device=dev).expand(int(pv.sum()), 2))
+    first_free = 10  # log slot of step 11: the first step after the warm start whose state the player touched is slot 11
+    assert torch.equal(drv.pred_pose[0, 1:, first_free], base.pred_pose[0, 1:, first_free])
+    # agent 0, free-running from slot 10 on (teacher forcing ends at step 10): closed form of dynamics.py:237-274
+    p, m = drv.pred_pose[0, 0], drv.pred_motion[0, 0]
+    for t in range(first_free + 1, T):
+        if not bool(pv[t]) or not bool(pv[t - 1]):
+            continue
+        v_t, th_t = m[t - 1, 0] + 0.05 * 1.0, p[t - 1, 2] + 0.05 * 0.1
+        exp = torch.stack([p[t - 1, 0] + 0.1 * v_t * torch.cos(th_t), p[t - 1, 1] + 0.1 * v_t * torch.sin(th_t), p[t - 1, 2] + 0.1 * 0.1])
+        torch.testing.assert_close(p[t], exp, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("sizes,knn,tag", [((8, 64, 8), 4, "c1"), ((64, 1024, 128), 32, "c2")])
+def test_navi_predictor_forward_vs_reference_golden(tb, golden_dir, sizes, knn, tag):
+    """NaviPredictor.forward (navigation.py:175-278) on the chain kernel - destination logits of every (agent, polyline) pair -
+    vs the log-probabilities / argmax / validity the REFERENCE produced on the same seeded scene, and vs the oracle."""
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    om = O.TrafficBotsOracle(P, tb.config.default_model_cfg(n_tgt_knn=knn), training=False)
+    mp_o, _ = _oracle_tokens(om, b)
+    mp = wm.model.mp_encoder(bd["sc/mp_valid"], bd["sc/mp_attr"], bd["sc/mp_pose"], bd["ref/mp_type"])
+    pred = wm.model.navi_predictor(ag_valid=bd["sc/ag_valid"], ag_attr=bd["sc/ag_attr"], ag_motion=bd["sc/ag_motion"],
+                                   ag_pose=bd["sc/ag_pose"], ag_type=bd["ref/ag_type"], **mp)
+    g = np.load(golden_dir / f"model_{tag}.npz")
+    assert np.array_equal(pred.valid.cpu().numpy(), g["navi_valid"])
+    lp = pred.log_prob(bd["gt/ag_navi"]).cpu().numpy()
+    ok = g["navi_valid"] & np.isfinite(g["navi_log_prob_gt"])
+    assert np.array_equal(np.isfinite(lp)[g["navi_valid"]], np.isfinite(g["navi_log_prob_gt"])[g["navi_valid"]])
+    np.testing.assert_allclose(lp[ok], g["navi_log_prob_gt"][ok], rtol=2e-3, atol=2e-3)
+    with torch.no_grad():
+        po = om.navi_predictor(b["sc/ag_valid"], b["sc/ag_attr"], b["sc/ag_motion"], b["sc/ag_pose"], b["ref/ag_type"], mp_o)
+    probs, probs_o = pred.probs.cpu(), po.distribution.probs
+    torch.testing.assert_close(probs, probs_o, rtol=5e-3, atol=2e-5)
+    # the argmax agrees wherever the reference's top two probabilities are separated by more than the tolerance
+    top2 = probs_o.topk(2, -1)[0]
+    clear = torch.from_numpy(g["navi_valid"]) & ((top2[..., 0] - top2[..., 1]) > 1e-3 * top2[..., 0])
+    assert np.array_equal(probs.argmax(-1)[clear].numpy(), g["navi_argmax"][clear.numpy()])
+    assert int(clear.sum()) >= int(0.5 * g["navi_valid"].sum())
+
+
+def test_wosac_shape_joint_futures_vs_oracle(tb):
+    """BASELINE config 5 at its own size: 32 rollouts x 128 agents / 1024 polylines / 128 lights through
+    `joint_future_pred` - map tokens and K/V tables shared by the 32 rollouts (batch_div), lights stepped once per scene
+    (share_lights) - vs the oracle's Sim.rollout run rollout by rollout with THAT rollout's sampled latent and destination.
+    First 16 steps (10 warm start + 6 free; the loop is chaotic after that); rule flags bit-exact vs the oracle's
+    checks on the logged trajectories."""
+    dev = torch.device(DEV)
+    K, A, T, n_cmp = 32, 128, 16, 16
+    wm, P, b, bd = _setup(tb, dev, (A, 1024, 128), 32)
+    D = import_module("trafficbots_amd.models.modules.distributions")
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=32), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    with torch.no_grad():
+        mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
+        tl_o = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
+    mp, tl = wm.encode_scene(bd, n_rollout=K)
+    valid = bd["sc/ag_valid"].any(-1)
+    lat = D.DiagGaussian(torch.zeros(1, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)  # std-normal prior
+    onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], 1024).float()
+    wm.hp.joint_future_pred_deterministic_k0 = False
+    torch.manual_seed(21)
+    buf = wm.joint_future_pred(bd, mp, tl, lat, D.DestCategorical(probs=onehot, valid=valid), wm.teacher_forcing_joint_future_pred, K,
+                               step_end=T)
+    eng = wm._engine
+    assert eng.tl_div == K and eng.n == K  # the benchmarked sharing is what ran
+    z_all = eng.ag_latent.view(K, A, 16).cpu()
+    dest_all = eng.dest.cpu()
+    assert float((z_all[0] - z_all[1]).abs().max()) > 0.1
+    bh = dict(b)
+    bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
+    sim = O.Sim(om, scfg, False)
+    vc = valid.cpu()
+    for k in (0, 13, 31):
+        with torch.no_grad():
+            ro = sim.rollout(bh, mp_o, tl_o, z_all[k:k + 1], vc, dest_all[k:k + 1], vc, scfg.teacher_forcing_joint_future_pred, T,
+                             gt_prefix="hist", tl_gt_key="sc/tl_state")
+        sl = slice(0, n_cmp)
+        assert torch.equal(buf.pred_valid[:, k, :, sl].cpu(), ro["pred_valid"][:, :, sl]), k
+        assert torch.equal(buf.vis_dict["tl_state"][:, k, :, sl].cpu(), ro["tl_state"][:, :, sl]), k
+        assert torch.equal(buf.violation["outside_map"][:, k, :, sl].cpu(), ro["outside_map"][:, :, sl]), k
+        torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=3e-3)
+        torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=3e-3)
+        torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=1e-4)
+    # rule flags of three rollouts, bit-exact against the oracle's checks on the logged trajectories
+    ks = [0, 13, 31]
+    r = lambda t: t.repeat_interleave(len(ks), 0).cpu()
+    o = R.RuleCheckOracle(r(b["map/valid"]), r(b["map/type"]), r(b["map/pos"]), r(b["map/dir"]), r(b["ref/ag_type"]), r(b["ref/ag_size"]),
+                          tl["tl_token_valid"][ks].cpu(), tl["tl_token_pose"][ks].cpu())
+    pick = lambda t: t[0, ks].cpu()
+    pv, pp, pm, ts = pick(buf.pred_valid), pick(buf.pred_pose), pick(buf.pred_motion), pick(buf.vis_dict["tl_state"])
+    for t in range(T):
+        v = o.check(pv[:, :, t], pp[:, :, t], pm[:, :, t], ts[:, :, t])
+        for key, x in v.items():
+            assert torch.equal(pick(buf.violation[key])[:, :, t], x), (key, t)
+
+
+def test_c2_free_rollout_80_steps_damped_policy(tb):
+    """BASELINE config 2 over its whole horizon: 10 teacher-forced + 80 free-running closed-loop steps of the 64-agent /
+    1024-polyline / 128-light scene, hipGraph replay, with the action head's output layer scaled by 0.02 (the random-weight
+    loop is chaotic otherwise) vs the oracle, point-wise."""
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, (64, 1024, 128), 32)
+    _damp(wm, P)
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=32), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    with torch.no_grad():
+        mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
+        tl_o = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 64, 16, generator=g)
+    valid = b["sc/ag_valid"].any(-1)
+    bh = dict(b)
+    bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
+    T = 90
+    with torch.no_grad():
+        ro = O.Sim(om, scfg, False).rollout(bh, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred, T,
+                                            gt_prefix="hist", tl_gt_key="sc/tl_state")
+    mp, tl = wm.encode_scene(bd)
+    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
+                 "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
+                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid.to(dev)}
+    buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
+                     wm._rule_checker(bd, bd["gt/ag_navi"], tl), T, True)
+    buf.flatten_joint_future(1)
+    _compare(buf, ro, T, 5e-3)
+    torch.testing.assert_close(buf.tl_state_nll[:, 0].cpu(), ro["tl_state_nll"], rtol=1e-3, atol=1e-4)

@@ -47,12 +47,14 @@ def test_attention_backward_vs_oracle_autograd(tb):
         torch.testing.assert_close(p.grad.cpu(), P["a." + k].grad, **tol)
 
 
-def test_training_step_vs_oracle_and_reference(tb, golden_dir):
-    """One training_step at C1 with every RNG site neutralised (dropout 0, posterior latent, no random forcing):
-    loss terms vs the reference's golden values; per-module gradient norms vs the reference's; spot gradients vs the
-    oracle's autograd."""
+@pytest.mark.parametrize("sizes,knn,fixture", [((8, 64, 8), 4, "model_c1.npz"), ((64, 1024, 128), 32, "train_c2.npz")])
+def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture):
+    """One training_step with every RNG site neutralised (dropout 0, posterior latent, no random forcing) at C1 and at the
+    scene size of BASELINE config 3 (64 agents / 1024 polylines / 128 lights, default K-nearest sizes: the shape behind the
+    training scenes/s figure): loss terms vs the reference's golden values; per-module gradient norms vs the reference's; spot
+    gradients vs the reference's."""
     dev = torch.device("cuda:0")
-    cfg = tb.config.default_model_cfg(n_tgt_knn=4)
+    cfg = tb.config.default_model_cfg(n_tgt_knn=knn)
     cfg["tf_cfg"]["dropout_p"] = 0.0
     cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
     cfg["add_navi_latent"]["mlp_dropout_p"] = 0.0
@@ -69,11 +71,11 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir):
             if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
                 p.mul_(0.02)
     wm = wm.to(dev).train()
-    batch = tb.synthetic.make_scene(1, 8, 64, 8, seed=0)
+    batch = tb.synthetic.make_scene(1, *sizes, seed=0)
     torch.manual_seed(7)
     loss = wm.training_step({k: v.to(dev) for k, v in batch.items()}, 0)
     loss.backward()
-    g = np.load(golden_dir / "model_c1.npz")
+    g = np.load(golden_dir / fixture)
     for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss"):
         torch.testing.assert_close(wm.last_metrics[k].detach().cpu(), torch.from_numpy(g["dtrain_" + k]), rtol=1e-3, atol=1e-4)
     gn = {}
@@ -268,16 +270,23 @@ def test_attention_dropout_time_batched_call_equals_per_step_calls(tb):
     torch.testing.assert_close(kvb.grad, gkv, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("dropout,tl_ahead,fused", [(False, True, True), (True, True, True), (True, False, True), (True, True, False)])
-def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout, tl_ahead, fused):
+C1_SHAPE, C3_SHAPE = (2, (8, 64, 8), 4, 30), (16, (64, 1024, 128), 32, 14)  # (scenes, sizes, n_tgt_knn, steps)
+
+
+@pytest.mark.parametrize("dropout,tl_ahead,fused,shape", [(False, True, True, C1_SHAPE), (True, True, True, C1_SHAPE), (True, False, True, C1_SHAPE),
+                                                          (True, True, False, C1_SHAPE), (True, True, True, C3_SHAPE)])
+def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout, tl_ahead, fused, shape):
     """training_rollout_batched (no-grad stepping pass + ONE differentiated policy batch over all steps + the dynamics chain) vs
     training_rollout (autograd through 30 sequential policy steps): same loss terms and parameter gradients - also in train mode
     with every dropout live, since the keyed masks of the batched pass are those of the per-step pass. tl_ahead: the light encoder
     of all steps evaluated once ahead of the stepping pass (lights are teacher-forced while ground truth lasts) or inside it;
-    fused: the per-step state machine (dynamics, forcing, rule flags, reward) as tbx_train_chain_fwd / _bwd or as torch ops."""
+    fused: the per-step state machine (dynamics, forcing, rule flags, reward) as tbx_train_chain_fwd / _bwd or as torch ops.
+    C3_SHAPE: the batch of BASELINE config 3 (16 scenes x 64 agents / 1024 polylines / 128 lights, default K-nearest sizes), 14
+    closed-loop steps (10 warm-start steps, which carry no loss: training.py step_training_start, + 4 free-running ones)."""
     dev = torch.device("cuda:0")
     W = import_module("trafficbots_amd.pl_modules.waymo_motion")
-    cfg = tb.config.default_model_cfg(n_tgt_knn=4)
+    n_sc, sizes, knn, n_steps = shape
+    cfg = tb.config.default_model_cfg(n_tgt_knn=knn)
     if not dropout:
         cfg["tf_cfg"]["dropout_p"] = 0.0
         cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
@@ -285,7 +294,7 @@ def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout,
     scfg = tb.config.default_sim_cfg(p_training_rollout_prior=0.0)
     scfg["teacher_forcing_training"]["prob_forcing_agent"] = 0.0
     scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
-    scfg["time_step_end"] = 30
+    scfg["time_step_end"] = n_steps
     wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg)
     tb.utils.det_fill(wm.model, 0)
     with torch.no_grad():  # damped action head: the free-running closed loop is chaotic otherwise
@@ -295,8 +304,8 @@ def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout,
     wm = wm.to(dev).train()
     wm.attn_dropout_seed = torch.tensor([4242], dtype=torch.int64, device=dev)
     wm.tl_encoder_ahead, wm.fused_train_chain = tl_ahead, fused
-    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=1).items()}
-    noise = torch.randn(2, 8, wm.model.latent_encoder.out_dim, generator=torch.Generator().manual_seed(5)).to(dev)
+    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(n_sc, *sizes, seed=1).items()}
+    noise = torch.randn(n_sc, sizes[0], wm.model.latent_encoder.out_dim, generator=torch.Generator().manual_seed(5)).to(dev)
     use_prior = torch.zeros((), dtype=torch.bool, device=dev)
     res = {}
     for mode in (True, False):

@@ -147,3 +147,35 @@ def test_convert_h5_through_a_stand_in_h5py(tb, D, tmp_path, monkeypatch):
     it = ds[1]
     assert it["scenario_id"] == "s1" and it["with_map"] is True and float(it["scenario_yaw"]) == 0.5
     assert np.array_equal(it["agent/pos"], np.asarray(eps[1]["agent/pos"], dtype=np.float16))
+
+
+def test_write_scene_pack_streams_a_generator(tb, D, tmp_path):
+    """The writer consumes its episodes ONCE and holds one at a time (a WOMD split is ~487 k episodes: the ingestion path may
+    not collect them): a generator that frees every episode it handed out before producing the next one must give the same file
+    as the list, and a generator without an announced length is refused."""
+    eps = _episodes(tb, 4)
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items()}
+    live = {"n": 0, "max": 0}
+
+    class Ep(dict):
+        def __init__(self, d):
+            super().__init__(d)
+            live["n"] += 1
+            live["max"] = max(live["max"], live["n"])
+
+        def __del__(self):
+            live["n"] -= 1
+
+    def gen():
+        for e in eps:
+            yield Ep(e)
+
+    a, b = tmp_path / "a.tbxpack", tmp_path / "b.tbxpack"
+    assert D.write_scene_pack(str(a), eps, sizes) == 4
+    assert D.write_scene_pack(str(b), gen(), sizes, n=4) == 4
+    assert a.read_bytes() == b.read_bytes()
+    assert live["max"] <= 2  # the one being written + the one just fetched
+    with pytest.raises(TypeError):
+        D.write_scene_pack(str(b), gen(), sizes)
+    with pytest.raises(AssertionError):
+        D.write_scene_pack(str(b), gen(), sizes, n=5)

@@ -16,6 +16,11 @@ namespace {
 // of ~30 (it closes the critical path of every step: 23 -> ~7 us). Lights: one thread per light.
 constexpr int LPA = 32;
 
+__device__ __forceinline__ float sim_sl1(float d) {  // F.smooth_l1_loss, beta = 1
+  const float a = fabsf(d);
+  return a < 1.f ? 0.5f * d * d : a - 0.5f;
+}
+
 __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i_ag = gid / LPA, sub = gid % LPA;
@@ -36,6 +41,10 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     if (valid0) {
       acc = tanhf(s.action_mean[i * 2]) * s.max_acc[ty];
       yr = tanhf(s.action_mean[i * 2 + 1]) * s.max_yaw_rate[ty];
+      if (s.player_valid != nullptr && s.player_valid[i] != 0) {  // player-controlled agent (dynamics.py:104-107)
+        acc = s.player_action[i * 2];
+        yr = s.player_action[i * 2 + 1];
+      }
     }
     const float half_dt = 0.5f * s.dt;
     const float v_t = spd + half_dt * acc;
@@ -45,6 +54,7 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     float nyaw = pyaw + s.dt * yr;
     float nspd = spd + s.dt * acc, nacc = acc, nyr = yr;
     if (!valid0) nx = ny = nyaw = nspd = nacc = nyr = 0.f;
+    const float qx = nx, qy = ny, qyaw = nyaw, qspd = nspd;  // the prediction (before the override), for the reward
     if (t - 1 < T && sub == 0) {
       const int64_t o = (int64_t)i * T + (t - 1);
       s.out_valid[o] = valid0 ? 1 : 0;
@@ -87,11 +97,19 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
     bool valid = valid0;
     bool disabled = s.ag_disabled[i] != 0;
     bool has_gt = t < s.n_step_gt;
-    bool gt_v = false;
-    if (has_gt) {
-      const int64_t g = (int64_t)i * s.n_step_gt + t;
-      gt_v = s.gt_valid[g] != 0;
-      if (s.tf_mask[g] != 0 && !disabled) {
+    bool gt_v = false, tf_now = false;
+    const int64_t g = (int64_t)i * s.n_step_gt + t;
+    if (has_gt) gt_v = s.gt_valid[g] != 0;
+    if (s.ov_valid != nullptr) {  // the step's ag_override handed over explicitly (WaymoMotion.forward)
+      tf_now = s.ov_valid[i] != 0;
+      if (tf_now && !disabled) {
+        valid = true;
+        nx = s.ov_pose[i * 3], ny = s.ov_pose[i * 3 + 1], nyaw = s.ov_pose[i * 3 + 2];
+        nspd = s.ov_motion[i * 3], nacc = s.ov_motion[i * 3 + 1], nyr = s.ov_motion[i * 3 + 2];
+      }
+    } else if (has_gt) {
+      tf_now = s.tf_mask[g] != 0;
+      if (tf_now && !disabled) {
         valid = true;
         nx = s.gt_pose[g * 3];
         ny = s.gt_pose[g * 3 + 1];
@@ -101,17 +119,41 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
         nyr = s.gt_motion[g * 3 + 2];
       }
     }
-    // Dynamics.disable_ag / disable_navi (dynamics.py:165-204)
-    const bool dis = out_now && !(has_gt && gt_v);
+    if (t - 1 < T && sub == 0) {
+      const int64_t o = (int64_t)i * T + (t - 1);
+      if (s.out_tf != nullptr) s.out_tf[o] = tf_now ? 1 : 0;
+      // DifferentiableReward.get on the prediction (rewards.py:58-74; the same expressions as tbx_train_chain_fwd)
+      if (s.out_reward != nullptr) {
+        float r_pos = 0.f, r_rot = 0.f, r_spd = 0.f;
+        bool r_valid = valid0;
+        if (has_gt) {
+          r_valid = valid0 && gt_v;
+          if (r_valid) {
+            r_pos = -s.w_pos * (sim_sl1(s.gt_pose[g * 3] - qx) + sim_sl1(s.gt_pose[g * 3 + 1] - qy));
+            r_rot = -s.w_rot * (0.5f * (1.f - cosf(s.gt_pose[g * 3 + 2] - qyaw)));
+            r_spd = -s.w_spd * sim_sl1(s.gt_motion[g * 3] - qspd);
+          }
+        }
+        s.out_reward[o * 4] = r_pos, s.out_reward[o * 4 + 1] = r_rot, s.out_reward[o * 4 + 2] = r_spd;
+        s.out_reward[o * 4 + 3] = (r_pos + r_rot) + r_spd;
+        if (s.out_reward_valid != nullptr) s.out_reward_valid[o] = r_valid ? 1 : 0;
+      }
+    }
+    // Dynamics.disable_ag / disable_navi (dynamics.py:165-204); a step-wise caller does both itself from now_*
+    const bool no_disable = (parts & TBX_SIM_NO_DISABLE) != 0;
+    const bool dis = !no_disable && out_now && !(has_gt && gt_v);
     disabled = disabled || dis;
     valid = valid && !dis;
+    if (sub == 0 && s.now_outside != nullptr) s.now_outside[i] = out_now ? 1 : 0;
+    if (sub == 0 && s.now_reached != nullptr) s.now_reached[i] = reach_now ? 1 : 0;
     // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see. Lane w
     // moves entry w + 1 to w: the wavefront runs in lockstep, so every lane has loaded before any lane stores (chunks of 32
     // go upwards, each reads only entries no earlier chunk wrote).
     uint8_t* hv = s.hist_valid + (int64_t)i * W;
     float* hp = s.hist_pose + (int64_t)i * W * 3;
     float* hm = s.hist_motion + (int64_t)i * W * 3;
-    for (int w0 = 0; w0 < W - 1; w0 += LPA) {
+    const bool append = (parts & TBX_SIM_NO_APPEND) == 0;
+    for (int w0 = 0; append && w0 < W - 1; w0 += LPA) {
       const int w = w0 + sub;
       const bool mv = w < W - 1;
       uint8_t v1 = 0;
@@ -140,14 +182,16 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
       s.ag_motion[i * 3 + 2] = nyr;
       s.outside_map[i] = outside ? 1 : 0;
       s.dest_reached[i] = reached ? 1 : 0;
-      if (reach_now) s.navi_valid[i] = 0;
-      hv[W - 1] = valid ? 1 : 0;
-      hp[(W - 1) * 3] = nx;
-      hp[(W - 1) * 3 + 1] = ny;
-      hp[(W - 1) * 3 + 2] = nyaw;
-      hm[(W - 1) * 3] = nspd;
-      hm[(W - 1) * 3 + 1] = nacc;
-      hm[(W - 1) * 3 + 2] = nyr;
+      if (reach_now && !no_disable) s.navi_valid[i] = 0;
+      if (append) {
+        hv[W - 1] = valid ? 1 : 0;
+        hp[(W - 1) * 3] = nx;
+        hp[(W - 1) * 3 + 1] = ny;
+        hp[(W - 1) * 3 + 2] = nyaw;
+        hm[(W - 1) * 3] = nspd;
+        hm[(W - 1) * 3 + 1] = nacc;
+        hm[(W - 1) * 3 + 2] = nyr;
+      }
     }
   }
   if ((parts & TBX_SIM_LIGHTS) && gid < n_tl_tot) {
@@ -162,12 +206,30 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
         am = c;
       }
     uint8_t st = (uint8_t)(1u << am);
-    if (t < s.n_step_tl_gt) st = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+    if (s.ov_valid != nullptr) {
+      if (s.ov_tl_valid[i] != 0) st = s.ov_tl_state[i];
+    } else if (t < s.n_step_tl_gt) {
+      st = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+    }
     s.tl_state[i] = st;
     if (t - 1 < T) s.out_tl_state[(int64_t)i * T + (t - 1)] = st;
-    uint8_t* ht = s.hist_tl + (int64_t)i * W;
-    for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
-    ht[W - 1] = st;
+    if (s.out_tl_nll != nullptr && t - 1 < T) {
+      // -Categorical(logits).log_prob(gt) = logsumexp(logits) - logits[gt] (waymo_motion.py:276-283); 0 past the ground truth
+      float nll = 0.f;
+      if (t < s.n_step_tl_gt) {
+        const uint8_t gm = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+        const int gi = gm ? (__ffs((int)gm) - 1) : 0;
+        float se = 0.f;
+        for (int c = 0; c < 5; ++c) se += expf(lg[c] - best);
+        nll = (best + logf(se)) - lg[gi < 5 ? gi : 0];
+      }
+      s.out_tl_nll[(int64_t)i * T + (t - 1)] = nll;
+    }
+    if ((parts & TBX_SIM_NO_APPEND) == 0) {
+      uint8_t* ht = s.hist_tl + (int64_t)i * W;
+      for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
+      ht[W - 1] = st;
+    }
   }
   if (parts & TBX_SIM_ADVANCE) {
     // every thread of this workgroup has read *step above; the last workgroup to arrive advances it
@@ -186,6 +248,28 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
 
 __global__ void sim_bump_kernel(int32_t* step) { *step += 1; }
 
+// TBX_SIM_APPEND: TrafficBots._append_hist (traffic_bots.py:123-143) on the current state - a thread per agent / light.
+__global__ void sim_append_kernel(const tbx_sim_state_t s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = s.window;
+  if (i < s.n_batch * s.n_ag) {
+    uint8_t* hv = s.hist_valid + (int64_t)i * W;
+    float* hp = s.hist_pose + (int64_t)i * W * 3;
+    float* hm = s.hist_motion + (int64_t)i * W * 3;
+    for (int w = 0; w < W - 1; ++w) {
+      hv[w] = hv[w + 1];
+      for (int c = 0; c < 3; ++c) hp[w * 3 + c] = hp[(w + 1) * 3 + c], hm[w * 3 + c] = hm[(w + 1) * 3 + c];
+    }
+    hv[W - 1] = s.ag_valid[i];
+    for (int c = 0; c < 3; ++c) hp[(W - 1) * 3 + c] = s.ag_pose[i * 3 + c], hm[(W - 1) * 3 + c] = s.ag_motion[i * 3 + c];
+  }
+  if (i < s.n_batch * s.n_tl) {
+    uint8_t* ht = s.hist_tl + (int64_t)i * W;
+    for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
+    ht[W - 1] = s.tl_state[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
@@ -193,7 +277,10 @@ extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
 }
 
 extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* stream) {
-  if (!st || (parts & ~(TBX_SIM_AGENTS | TBX_SIM_LIGHTS | TBX_SIM_ADVANCE)) || parts == 0) return TBX_ERR_ARG;
+  const int known = TBX_SIM_AGENTS | TBX_SIM_LIGHTS | TBX_SIM_ADVANCE | TBX_SIM_NO_DISABLE | TBX_SIM_NO_APPEND | TBX_SIM_APPEND;
+  if (!st || (parts & ~known) || parts == 0) return TBX_ERR_ARG;
+  if ((parts & TBX_SIM_APPEND) && parts != TBX_SIM_APPEND) return TBX_ERR_ARG;  // a part of its own
+  if ((parts & (TBX_SIM_NO_DISABLE | TBX_SIM_NO_APPEND)) && !(parts & (TBX_SIM_AGENTS | TBX_SIM_LIGHTS))) return TBX_ERR_ARG;
   const tbx_sim_state_t& s = *st;
   if (s.n_batch <= 0 || s.n_ag <= 0 || s.n_tl <= 0 || s.window <= 0 || s.n_step_out <= 0 || s.n_node <= 0) return TBX_ERR_ARG;
   const void* need[] = {s.step, s.ag_valid, s.ag_disabled, s.ag_pose, s.ag_motion, s.navi_valid, s.outside_map,
@@ -203,6 +290,13 @@ extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* st
                         s.out_motion, s.out_action, s.out_tl_state, s.out_outside_map, s.out_dest_reached};
   for (const void* p : need)
     if (p == nullptr) return TBX_ERR_ARG;
+  if (s.player_valid != nullptr && s.player_action == nullptr) return TBX_ERR_ARG;
+  if (s.ov_valid != nullptr && (!s.ov_pose || !s.ov_motion || !s.ov_tl_valid || !s.ov_tl_state)) return TBX_ERR_ARG;
+  if (parts == TBX_SIM_APPEND) {
+    const int64_t na = (int64_t)s.n_batch * (s.n_ag > s.n_tl ? s.n_ag : s.n_tl);
+    hipLaunchKernelGGL(sim_append_kernel, dim3((unsigned)((na + 127) / 128)), dim3(128), 0, (hipStream_t)stream, s);
+    return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+  }
   const int64_t th_ag = (parts & TBX_SIM_AGENTS) ? (int64_t)s.n_batch * s.n_ag * LPA : 0;
   const int64_t th_tl = (parts & TBX_SIM_LIGHTS) ? (int64_t)s.n_batch * s.n_tl : 0;
   const int64_t n = th_ag > th_tl ? th_ag : th_tl;

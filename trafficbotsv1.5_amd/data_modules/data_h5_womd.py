@@ -41,58 +41,78 @@ def _align(x: int) -> int:
 
 
 def write_scene_pack(path: str, episodes: Iterable[Dict[str, Any]], tensor_size: Dict[str, Tuple[int, ...]],
-                     attr_keys: Sequence[str] = ()) -> int:
-    """Writes episodes (dicts of arrays with the shapes of `tensor_size`; extra `attr_keys` entries are kept per episode in
-    the header) as a scene pack. Returns the number of episodes."""
-    eps = list(episodes)
-    n = len(eps)
+                     attr_keys: Sequence[str] = (), n: Optional[int] = None) -> int:
+    """Writes episodes (dicts of arrays with the shapes of `tensor_size`; extra `attr_keys` entries are kept per episode) as a
+    scene pack, STREAMING: `episodes` is consumed once, one episode in memory at a time (a WOMD training split is ~487 k
+    episodes - data_h5_womd.py / scripts/pack_h5_womd.py:194). `n` = number of episodes (taken from len(episodes) when it has
+    one): the layout - per key one [n, *shape] array at a 4 KiB-aligned offset - is fixed before the first episode is read.
+    Per-episode attributes go to a length-prefixed JSON footer behind the arrays. Returns the number of episodes."""
+    if n is None:
+        n = len(episodes)  # a generator has none: pass n (convert_h5 reads it from the h5 attribute `data_len`)
     assert n > 0
-    keys, off = [], None
+    it = iter(episodes)
+    first = next(it)
+    keys = []
     for k, shape in tensor_size.items():
-        a0 = np.asarray(eps[0][k])
-        dt = loader_dtype(a0.dtype)
+        dt = loader_dtype(np.asarray(first[k]).dtype)
         keys.append({"name": k, "dtype": "bool" if dt == np.bool_ else dt.str, "shape": list(shape)})
-    attrs = {k: [np.asarray(e[k]).tolist() if not isinstance(e[k], (str, bytes)) else e[k] for e in eps] for k in attr_keys}
     # two passes over the header: offsets depend on its length
-    for _ in range(2):
-        hdr = json.dumps({"n": n, "keys": keys, "attrs": attrs}).encode()
-        off = _align(len(MAGIC) + 8 + len(hdr))
+    off = 0
+    for _ in range(3):
+        hdr = json.dumps({"n": n, "keys": keys, "attrs_offset": off}).encode()
+        off = _align(len(MAGIC) + 8 + len(hdr) + 32)  # 32 B of slack: the footer offset's digits may still grow
         for kd in keys:
             kd["offset"] = off
-            item = np.dtype(np.uint8 if kd["dtype"] == "bool" else kd["dtype"]).itemsize
-            off = _align(off + n * int(np.prod(kd["shape"], dtype=np.int64)) * item)
-    hdr = json.dumps({"n": n, "keys": keys, "attrs": attrs}).encode()
+            kd["_item"] = int(np.prod(kd["shape"], dtype=np.int64)) * np.dtype(np.uint8 if kd["dtype"] == "bool" else kd["dtype"]).itemsize
+            off = _align(off + n * kd["_item"])
+    items = {kd["name"]: kd.pop("_item") for kd in keys}
+    hdr = json.dumps({"n": n, "keys": keys, "attrs_offset": off}).encode()
+    assert len(MAGIC) + 8 + len(hdr) <= keys[0]["offset"]
+    attrs = {k: [] for k in attr_keys}
+    count = 0
     with open(path, "wb") as f:
         f.write(MAGIC)
         f.write(np.uint64(len(hdr)).tobytes())
         f.write(hdr)
-        for kd in keys:
-            f.seek(kd["offset"])
-            dt = np.dtype(np.uint8 if kd["dtype"] == "bool" else kd["dtype"])
-            for e in eps:
+        f.truncate(off)
+        e, first = first, None
+        while e is not None:
+            assert count < n, "more episodes than announced"
+            for kd in keys:
                 a = np.asarray(e[kd["name"]])
                 assert tuple(a.shape) == tuple(kd["shape"]), (kd["name"], a.shape, kd["shape"])
-                f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
-        f.truncate(off)
+                f.seek(kd["offset"] + count * items[kd["name"]])
+                f.write(np.ascontiguousarray(a, dtype=np.uint8 if kd["dtype"] == "bool" else np.dtype(kd["dtype"])).tobytes())
+            for k in attr_keys:
+                attrs[k].append(e[k] if isinstance(e[k], str) else (e[k].decode() if isinstance(e[k], bytes) else np.asarray(e[k]).tolist()))
+            count += 1
+            e = next(it, None)
+        assert count == n, f"{count} episodes written, {n} announced"
+        foot = json.dumps(attrs).encode()
+        f.seek(off)
+        f.write(np.uint64(len(foot)).tobytes())
+        f.write(foot)
     return n
 
 
 def convert_h5(h5_path: str, out_path: str, tensor_size: Dict[str, Tuple[int, ...]], with_attrs: bool = False) -> int:
-    """A reference h5 file (scripts/pack_h5_womd.py layout: one group per episode index) -> scene pack. Needs h5py."""
+    """A reference h5 file (scripts/pack_h5_womd.py layout: one group per episode index) -> scene pack. Needs h5py. One episode
+    is resident at a time (the generator below is consumed once by write_scene_pack)."""
     import h5py  # noqa: WPS433 - only where the h5 files live
 
     attr_keys = ("scenario_id", "scenario_center", "scenario_yaw", "with_map") if with_attrs else ()
+    with h5py.File(h5_path, "r", libver="latest", swmr=True) as hf:
+        n = int(hf.attrs["data_len"])
 
-    def episodes():
-        with h5py.File(h5_path, "r", libver="latest", swmr=True) as hf:
-            for i in range(int(hf.attrs["data_len"])):
+        def episodes():
+            for i in range(n):
                 g = hf[str(i)]
                 e = {k: np.asarray(g[k]) for k in tensor_size}
                 for a in attr_keys:
                     e[a] = g.attrs[a]
                 yield e
 
-    return write_scene_pack(out_path, episodes(), tensor_size, attr_keys)
+        return write_scene_pack(out_path, episodes(), tensor_size, attr_keys, n=n)
 
 
 class ScenePack:
@@ -106,6 +126,11 @@ class ScenePack:
             hlen = int(np.frombuffer(f.read(8), dtype=np.uint64)[0])
             hdr = json.loads(f.read(hlen).decode())
         self.n, self.attrs = int(hdr["n"]), hdr.get("attrs", {})
+        if "attrs_offset" in hdr:  # per-episode attributes: length-prefixed JSON footer behind the arrays
+            with open(self.path, "rb") as f:
+                f.seek(int(hdr["attrs_offset"]))
+                flen = int(np.frombuffer(f.read(8), dtype=np.uint64)[0])
+                self.attrs = json.loads(f.read(flen).decode())
         self.keys = {kd["name"]: kd for kd in hdr["keys"]}
         self._maps: Dict[str, np.ndarray] = {}
 
@@ -254,5 +279,16 @@ class DataH5womd(LightningDataModule):
 
     @staticmethod
     def _get_dataloader(ds: Dataset, batch_size: int, num_workers: int, shuffle: bool) -> DataLoader:
-        return DataLoader(ds, batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available(), shuffle=shuffle,
-                          drop_last=False, persistent_workers=num_workers > 0)
+        """One process per GPU: with an initialised process group every rank draws from its own 1/N share of the episodes
+        (a DistributedSampler, which Lightning's ddp strategy injected in the reference, run.py:50-52 - call
+        `loader.sampler.set_epoch(epoch)` per epoch for a fresh shuffle); single process: the reference's plain loader."""
+        import torch.distributed as dist
+
+        sampler = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.utils.data.distributed import DistributedSampler
+
+            sampler = DistributedSampler(ds, num_replicas=dist.get_world_size(), rank=dist.get_rank(), shuffle=shuffle, drop_last=False)
+        return DataLoader(ds, batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available(),
+                          shuffle=shuffle if sampler is None else False, sampler=sampler, drop_last=False,
+                          persistent_workers=num_workers > 0)

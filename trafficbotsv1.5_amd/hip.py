@@ -47,6 +47,10 @@ class SimState(C.Structure):
             "action_mean", "tl_logits", "out_valid", "out_pose", "out_motion", "out_action", "out_tl_state",
             "out_outside_map", "out_dest_reached")]
         + [("max_acc", C.c_float * 3), ("max_yaw_rate", C.c_float * 3), ("dt", C.c_float)]
+        + [(n, C.c_void_p) for n in ("out_reward", "out_reward_valid", "out_tf", "out_tl_nll")]
+        + [(n, C.c_float) for n in ("w_pos", "w_rot", "w_spd")]
+        + [(n, C.c_void_p) for n in ("player_valid", "player_action", "ov_valid", "ov_pose", "ov_motion", "ov_tl_valid",
+                                     "ov_tl_state", "now_outside", "now_reached")]
     )
 
 
@@ -139,7 +143,7 @@ def load():
     for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
-    if lib.tbx_version() != 1:
+    if lib.tbx_version() != 2:
         raise ImportError("libtbx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -370,7 +374,7 @@ def map_prep(mp_valid_u8, mp_type11, mp_pose, attr, pe, row_invalid, tok_pose, t
     _check(rc, "tbx_map_prep")
 
 
-SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE = 1, 2, 4
+SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE, SIM_NO_DISABLE, SIM_NO_APPEND, SIM_APPEND = 1, 2, 4, 8, 16, 32
 
 
 def train_chain_fwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, t0: int, t1: int):

@@ -28,8 +28,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: Option
     if not params or not dist.is_available() or not dist.is_initialized():
         return 0
     world_size = world_size or dist.get_world_size(group)
-    if world_size == 1:
-        return 0
+    # (a one-rank group still takes the exchange: the flat buffer, the RCCL call and the copy back are then exercised on one GPU)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
@@ -39,6 +38,44 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: Option
         p.grad.copy_(flat[off:off + n].view_as(p.grad))
         off += n
     return flat.numel() * flat.element_size()
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> int:
+    """Rank `src`'s parameters and buffers to every rank, as ONE flat broadcast per dtype (what DDP's constructor does with
+    its `_sync_params_and_buffers`): identical initial weights by construction, whatever each rank's RNG did before. Returns the
+    bytes sent. No-op without an initialised process group."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 0
+    sent = 0
+    with torch.no_grad():
+        tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
+        for dt in sorted({t.dtype for t in tensors}, key=str):
+            ts = [t for t in tensors if t.dtype == dt]
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            if dt == torch.bool:
+                flat = flat.to(torch.uint8)
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t).to(dt))
+                off += t.numel()
+            sent += flat.numel() * flat.element_size()
+    return sent
+
+
+def rank_seed(base: int, rank: Optional[int] = None) -> int:
+    """Seed of a rank's private random streams (dropout masks, latent noise, forcing draws): distinct per rank, so the ranks'
+    scenes see independent noise, while the weights stay identical (`broadcast_parameters`)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return int(base) + 1000003 * int(rank)
+
+
+def parameters_checksum(module: torch.nn.Module) -> Tensor:
+    """[sum, sum of squares] of all parameters in float64 on their device: equal across ranks iff the replicas agree."""
+    ps = [p.detach().double().reshape(-1) for p in module.parameters()]
+    flat = torch.cat(ps)
+    return torch.stack([flat.sum(), (flat * flat).sum()])
 
 
 def train_step(wm, optimizer: torch.optim.Optimizer, batch: Dict[str, Tensor], clip_grad_norm: float = 5.0,

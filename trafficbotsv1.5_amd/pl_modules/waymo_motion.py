@@ -29,6 +29,16 @@ except Exception:  # pragma: no cover
             super().__init__()
             self.current_epoch, self.global_rank, self.logged = 0, 0, {}
 
+        def save_hyperparameters(self):
+            """The caller's constructor arguments as `self.hparams` (attribute access), as Lightning does."""
+            import inspect
+
+            av = inspect.getargvalues(inspect.currentframe().f_back)
+            hp = {k: av.locals[k] for k in av.args if k != "self"}
+            if av.keywords:
+                hp.update(av.locals[av.keywords])
+            self.hparams = to_attr(hp)
+
         def log(self, k, v, **kw):
             self.logged[k] = v
 
@@ -47,13 +57,7 @@ class WaymoMotion(LightningModule):
         super().__init__()
         if pred_navi_after_reached:
             raise NotImplementedError("pred_navi_after_reached=False is the default (no per-step host branch)")
-        self.hparams_ = to_attr(dict(
-            time_step_current=time_step_current, time_step_gt=time_step_gt, time_step_end=time_step_end,
-            p_training_rollout_prior=p_training_rollout_prior, training_detach_model_input=training_detach_model_input,
-            training_deterministic_action=training_deterministic_action, n_joint_future_wosac=n_joint_future_wosac,
-            joint_future_pred_deterministic_k0=joint_future_pred_deterministic_k0, optimizer=optimizer,
-            lr_scheduler=lr_scheduler, lr_navi=lr_navi, differentiable_reward=differentiable_reward,
-            training_metrics=training_metrics))
+        self.save_hyperparameters()  # self.hparams.<constructor argument>, as in the reference (waymo_motion.py:66)
         pp = [(k, SceneCentricPreProcessing(time_step_current=time_step_current, data_size=data_size, **_strip_target(v)))
               for k, v in pre_processing.items()]
         kwargs = {"time_step_gt": time_step_gt}
@@ -70,7 +74,7 @@ class WaymoMotion(LightningModule):
 
     @property
     def hp(self):
-        return self.hparams_
+        return self.hparams
 
     # ------------------------------------------------------------------ once per scene
     def encode_scene(self, batch: Dict[str, Tensor], tl_valid_key: str = "sc/tl_valid", n_rollout: int = 1):
@@ -83,16 +87,15 @@ class WaymoMotion(LightningModule):
         return mp, tl
 
     # ------------------------------------------------------------------ rollout
-    @torch.no_grad()
-    def rollout(self, ag_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor],
-                tl_state_gt: Tensor, teacher_forcing: TeacherForcing, rule_checker: TrafficRuleChecker, step_end: int,
-                deterministic_action: bool, player_policy=None, use_graph: bool = True) -> RolloutBuffer:
-        """Reference signature (waymo_motion.py:206-217). Inference only: deterministic actions, no autograd."""
-        if not deterministic_action:
-            raise NotImplementedError("stochastic actions are not used by any default entry point")
+    def begin_rollout(self, ag_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor],
+                      tl_state_gt: Tensor, teacher_forcing: TeacherForcing, rule_checker: TrafficRuleChecker, step_end: int,
+                      stepwise: bool = False) -> RolloutEngine:
+        """Step 0 of `rollout` (waymo_motion.py:218-231: teacher_forcing.init, dynamics.init, model.init): the device-resident
+        simulation state. stepwise: driven through `forward` instead of the engine's own loop."""
         teacher_forcing.init(ag_valid=ag_tokens["gt_valid"], ag_pose=ag_tokens["gt_pose"], ag_motion=ag_tokens["gt_motion"],
                              tl_state=tl_state_gt, current_epoch=self.current_epoch)
         dev = ag_tokens["gt_pose"].device
+        rc = self.hparams.differentiable_reward
         eng = RolloutEngine(self.model, self.dynamics, dev)
         eng.reset(gt_valid=ag_tokens["gt_valid"], gt_pose=ag_tokens["gt_pose"], gt_motion=ag_tokens["gt_motion"],
                   tl_state_gt=tl_state_gt, tf_mask=teacher_forcing.ag_teacher_forcing, ag_type=ag_tokens["ag_type"],
@@ -100,10 +103,85 @@ class WaymoMotion(LightningModule):
                   ag_navi=ag_tokens["ag_navi"], ag_navi_valid=ag_tokens["ag_navi_valid"], mp_tokens=mp_tokens,
                   tl_tokens=tl_tokens, map_valid=rule_checker.mp_valid, map_type=rule_checker.mp_type,
                   map_pos=rule_checker.mp_pos, map_dir=rule_checker.mp_dir, map_boundary=rule_checker.mp_boundary,
-                  n_step=step_end)
-        eng.run(step_end, use_graph=use_graph)
+                  n_step=step_end, reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight) if rc.use_il_loss else (0, 0, 0),
+                  ag_navi_log_prob=ag_tokens.get("ag_navi_log_prob"), stepwise=stepwise)
         self._engine = eng
-        return eng.buffer(self.hp.time_step_current, rule_checker=rule_checker)
+        self.dynamics.bind(eng)
+        return eng
+
+    @torch.no_grad()
+    def rollout(self, ag_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor],
+                tl_state_gt: Tensor, teacher_forcing: TeacherForcing, rule_checker: TrafficRuleChecker, step_end: int,
+                deterministic_action: bool, player_policy=None, use_graph: bool = True, stepwise: bool = False) -> RolloutBuffer:
+        """Reference signature (waymo_motion.py:206-217). Inference only: deterministic actions, no autograd.
+        Default: the engine's device-side loop (one hipGraph replay per step). With a `player_policy` - a callable
+        `ag_pose [n_sc, n_ag, 3] -> None | {"valid": [n_sc, n_ag] bool, "action": [n_sc, n_ag, 2]}` asked before every step,
+        the hook the reference leaves as a todo (:240-241) - or stepwise=True, the reference's Python loop itself, one `forward`
+        per step; both produce the same buffer (tested bit for bit)."""
+        if not deterministic_action:
+            raise NotImplementedError("stochastic actions are not used by any default entry point")
+        stepwise = stepwise or player_policy is not None
+        eng = self.begin_rollout(ag_tokens, mp_tokens, tl_tokens, tl_state_gt, teacher_forcing, rule_checker, step_end, stepwise)
+        if not stepwise:
+            eng.run(step_end, use_graph=use_graph)
+            return eng.buffer(self.hp.time_step_current, rule_checker=rule_checker)
+        dyn, S = self.dynamics, eng.S
+        buf = RolloutBuffer(step_end, self.hparams.time_step_current)
+        lp0 = ag_tokens.get("ag_navi_log_prob")
+        buf.add_navi_log_prob(torch.zeros_like(ag_tokens["gt_pose"][:, :, 0, 0]) if lp0 is None else lp0, ag_tokens["ag_navi_valid"])
+        Tg, Tt = ag_tokens["gt_valid"].shape[-1], tl_state_gt.shape[2]
+        for _step in range(1, step_end + 1):
+            ag_override, tl_override = teacher_forcing.get(_step, dyn.ag_valid, dyn.ag_pose, dyn.ag_motion)
+            player_override = player_policy(dyn.ag_pose) if player_policy is not None else None
+            pred_dict, vis_dict = self.forward(mp_tokens, tl_tokens, ag_override, tl_override, player_override, deterministic_action)
+            violation = rule_checker.check(pred_dict["pred_valid"], pred_dict["pred_pose"], pred_dict["pred_motion"], dyn.tl_state)
+            violation.update(outside_map=S["outside_map"].bool(), outside_map_this_step=S["now_outside"].bool(),
+                             dest_reached=S["dest_reached"].bool(), dest_reached_this_step=S["now_reached"].bool())
+            violation = {k: v.clone() for k, v in violation.items()}
+            _gt_valid = ag_tokens["gt_valid"][:, :, _step] if _step < Tg else None
+            slot = _step - 1
+            r = S["out_reward"][:, :, slot]
+            reward = {"diffbar_reward_valid": S["out_reward_valid"][:, :, slot].bool(), "diffbar_reward": r[..., 3],
+                      "r_imitation_pos": r[..., 0], "r_imitation_rot": r[..., 1], "r_imitation_spd": r[..., 2],
+                      "r_traffic_rule_approx": torch.zeros_like(r[..., 0])}
+            nll = S["out_tl_nll"][:, :, slot]
+            nll_invalid = torch.ones_like(tl_tokens["tl_token_invalid"]) if _step >= Tt else tl_tokens["tl_token_invalid"]
+            buf.add(violation=violation, diffbar_reward=reward, tl_state_nll=nll, tl_state_nll_invalid=nll_invalid,
+                    vis_dict=vis_dict, ag_override=ag_override, **pred_dict)
+            dyn.disable_ag(violation, _gt_valid)
+            dyn.disable_navi(violation)
+        buf.finish()
+        return buf
+
+    def forward(self, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], ag_override: Dict[str, Tensor],
+                tl_override: Dict[str, Tensor], player_override: Optional[Dict[str, Tensor]] = None,
+                deterministic_action: bool = True):
+        """Reference signature and semantics (waymo_motion.py:118-204): ONE closed-loop step on the simulation state that
+        `begin_rollout(..., stepwise=True)` / `rollout(..., stepwise=True)` set up - TrafficBots policy on the sliding windows,
+        Dynamics.update_ag (player_override: {"valid", "action"} replaces the policy's physical action), then
+        Dynamics.override_ag(ag_override {"valid", "pose", "motion"}) and override_tl(tl_override {"valid", "state"}).
+        Returns (pred_dict, vis_dict) with the reference's keys. Rule checks and disable_ag / disable_navi stay with the caller
+        (`self.dynamics.disable_ag(violation, gt_valid)`), as in the reference's `rollout`."""
+        eng = self._engine
+        if eng is None or not eng.stepwise:
+            raise RuntimeError("forward() steps the state set up by begin_rollout(..., stepwise=True)")
+        if not deterministic_action:
+            raise NotImplementedError("stochastic actions are not used by any default entry point")
+        eng.mp_tokens, eng.tl_tokens = mp_tokens, tl_tokens
+        with torch.no_grad():
+            slot = eng.forward_step(ag_override, tl_override, player_override)
+        S, n, L = eng.S, eng.n, eng.L
+        pred_valid = S["out_valid"][:, :, slot].bool()
+        pred_dict = {"action_log_prob": eng.action_log_prob(S["out_valid"][:, :, slot]), "pred_valid": pred_valid,
+                     "pred_pose": S["out_pose"][:, :, slot], "pred_motion": S["out_motion"][:, :, slot],
+                     "pred_tl_state_dist": torch.distributions.Categorical(logits=S["tl_logits"].view(n, L, -1).clone())}
+        vis_dict = {}
+        if not self.training:
+            dyn = self.dynamics
+            vis_dict = {"pred_valid": dyn.ag_valid, "pred_pose": dyn.ag_pose.clone(), "pred_motion": dyn.ag_motion.clone(),
+                        "action": S["out_action"][:, :, slot], "ag_navi": dyn.ag_navi, "ag_navi_valid": dyn.ag_navi_valid,
+                        "navi_reached": dyn.mask_navi_reached, "tl_state": dyn.tl_state}
+        return pred_dict, vis_dict
 
     def _rule_checker(self, batch, ag_dest, tl_tokens, n_rollout: int = 1):
         """waymo_motion.py:399-412,497-510. Agent tensors per rollout, map tensors per scene (shared by its rollouts)."""
@@ -155,15 +233,6 @@ class WaymoMotion(LightningModule):
                            step_end or self.hp.time_step_end, True, use_graph=use_graph)
         buf.flatten_joint_future(K)
         return buf
-
-    def forward(self, *args, **kwargs):
-        """One closed-loop step of the current rollout engine (waymo_motion.py:118-204 semantics: policy, dynamics
-        update, overrides). Use `rollout` for whole episodes; this exists for step-wise drivers."""
-        if self._engine is None:
-            raise RuntimeError("call rollout()/reactive_replay()/joint_future_pred() first to set up the simulation state")
-        self._engine.step()
-        S = self._engine.S
-        return {"pred_valid": S["ag_valid"].bool(), "pred_pose": S["ag_pose"], "pred_motion": S["ag_motion"]}, {}
 
     # ------------------------------------------------------------------ training
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int, noise: Optional[Tensor] = None,

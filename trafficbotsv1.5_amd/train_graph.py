@@ -853,6 +853,9 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
 
 def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussian, prior: DiagGaussian) -> Dict[str, Tensor]:
     """metrics/training.py:74-189 + metrics/loss.py:39-77 (default weights / switches)."""
+    # A term whose counter is zero (a batch without a valid light / agent) is left out by the reference (training.py:166-186:
+    # `if counter > 0`): sum = 0 over a count clamped to 1 gives that 0 without a host branch (the step stays capturable).
+    cnt = lambda m: m.sum().clamp(min=1)
     lv = ro["pred_valid"].clone()
     lv[:, :, : cfg.step_training_start] &= False
     if not cfg.loss_for_teacher_forcing:
@@ -864,13 +867,13 @@ def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussi
     e0 = torch.clamp(kl_divergence(dP, Q), min=cfg.kl_free_nats)
     e1 = torch.clamp(kl_divergence(P, dQ), min=cfg.kl_free_nats)
     kv = (post.valid if cfg.kl_for_unseen_agent else prior.valid) & any_valid
-    vae_kl = cfg.w_vae_kl * (e0 + cfg.kl_balance_scale * e1).masked_fill(~kv, 0).sum() / kv.sum()
+    vae_kl = cfg.w_vae_kl * (e0 + cfg.kl_balance_scale * e1).masked_fill(~kv, 0).sum() / cnt(kv)
     rv = lv & ro["reward_valid"]
-    reward = cfg.w_diffbar_reward * ro["reward"].masked_fill(~rv, 0).sum() / rv.sum()
+    reward = cfg.w_diffbar_reward * ro["reward"].masked_fill(~rv, 0).sum() / cnt(rv)
     nv = navi_pred.valid & any_valid
-    navi = cfg.w_navi * (-navi_pred.log_prob(navi_gt)).masked_fill(~nv, 0).sum() / nv.sum()
+    navi = cfg.w_navi * (-navi_pred.log_prob(navi_gt)).masked_fill(~nv, 0).sum() / cnt(nv)
     tv = ~ro["tl_nll_invalid"]
-    tl = cfg.w_tl_state * ro["tl_nll"].masked_fill(~tv, 0).sum() / tv.sum()
+    tl = cfg.w_tl_state * ro["tl_nll"].masked_fill(~tv, 0).sum() / cnt(tv)
     return {"loss": vae_kl - reward + navi + tl, "vae_kl": vae_kl, "diffbar_reward": reward, "navi_loss": navi, "tl_state_loss": tl}
 
 

@@ -1,6 +1,10 @@
-"""`Dynamics` / `MultiPathPP` parameter holders (utils/dynamics.py:13-274). The state update itself
-(tanh-bounded action -> MultiPath++ midpoint integration -> overrides -> disabling) is `tbx_sim_step`."""
-from typing import Tuple
+"""`Dynamics` / `MultiPathPP` (utils/dynamics.py:13-274). The state update itself (tanh-bounded action -> MultiPath++ midpoint
+integration -> overrides -> disabling) is `tbx_sim_step`; the state lives in the rollout engine's device buffers. For step-wise
+drivers (`WaymoMotion.forward`) this object exposes that state under the reference's attribute names and the two methods the
+reference's `rollout` calls between two `forward`s (disable_ag / disable_navi)."""
+from typing import Dict, Optional, Tuple
+
+from torch import Tensor
 
 
 class MultiPathPP:
@@ -24,3 +28,39 @@ class Dynamics:
     @property
     def max_yaw_rate(self):
         return [d._max_yaw_rate for d in self.ag_dynamics]
+
+    # ------------------------------------------------------------------ state of the bound rollout engine (read-only views)
+    _eng = None
+
+    def bind(self, engine) -> None:
+        self._eng = engine
+
+    def _s(self, key: str) -> Tensor:
+        if self._eng is None:
+            raise RuntimeError("no rollout in progress: WaymoMotion.rollout / begin_rollout binds the simulation state")
+        return self._eng.S[key]
+
+    ag_valid = property(lambda self: self._s("ag_valid").bool())
+    ag_disabled = property(lambda self: self._s("ag_disabled").bool())
+    ag_pose = property(lambda self: self._s("ag_pose"))
+    ag_motion = property(lambda self: self._s("ag_motion"))
+    ag_navi_valid = property(lambda self: self._s("navi_valid").bool())
+    mask_navi_reached = property(lambda self: self._s("now_reached").bool())
+    ag_navi = property(lambda self: self._eng.dest)
+    ag_type = property(lambda self: self._eng.ag_type)
+
+    @property
+    def tl_state(self) -> Tensor:
+        """[n_sc, n_tl, 5] one-hot bool (the engine keeps a 5-bit mask per light)."""
+        import torch
+
+        m = self._s("tl_state")
+        return ((m.to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=m.device, dtype=torch.int32)) & 1).bool()
+
+    def disable_ag(self, traffic_rule_violation: Dict[str, Tensor], gt_valid: Optional[Tensor] = None) -> None:
+        """dynamics.py:165-183."""
+        self._eng.disable(outside=traffic_rule_violation["outside_map_this_step"], gt_valid=gt_valid)
+
+    def disable_navi(self, traffic_rule_violation: Dict[str, Tensor]) -> None:
+        """dynamics.py:185-204 (navi_mode dest)."""
+        self._eng.disable(reached=traffic_rule_violation["dest_reached_this_step"])

@@ -78,10 +78,13 @@ class RolloutEngine:
     def reset(self, *, gt_valid: Tensor, gt_pose: Tensor, gt_motion: Tensor, tl_state_gt: Tensor, tf_mask: Tensor,
               ag_type: Tensor, ag_attr: Tensor, ag_latent: Tensor, ag_latent_valid: Tensor, ag_navi: Tensor,
               ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
-              map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int) -> None:
+              map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int,
+              reward_weights=(0.1, 10.0, 0.1), ag_navi_log_prob: Optional[Tensor] = None, stepwise: bool = False) -> None:
         """All tensors on the device. gt_* [n,A,Tg(,3)], tl_state_gt [n,L,Tt,5] bool, tf_mask [n,A,Tg] bool
         (TeacherForcing.ag_teacher_forcing), ag_navi [n,A] int64 dest; map_* are the raw polylines of the scene(s)
-        ([n/div, M, N, ..]) for the destination check."""
+        ([n/div, M, N, ..]) for the destination check. reward_weights = (l_pos, l_rot, l_spd).weight of the
+        differentiable reward logged per step. stepwise: the engine is driven through `forward_step` (WaymoMotion.forward)
+        with explicit overrides instead of `run`."""
         dev = self.dev
         n, A, Tg = gt_valid.shape
         L, Tt = tl_state_gt.shape[1], tl_state_gt.shape[2]
@@ -92,7 +95,7 @@ class RolloutEngine:
         self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
         # lights once per scene when the K = div rollouts of every scene were given identical lights (one host check per reset)
         kl = 1
-        if self.share_lights and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
+        if self.share_lights and not stepwise and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
             g = tl_state_gt.reshape(n // div, div, *tl_state_gt.shape[1:])
             tv = tl_tokens["tl_token_valid"].reshape(n // div, div, L)
             tp = tl_tokens["tl_token_pose"].reshape(n // div, div, L, 3)
@@ -100,6 +103,7 @@ class RolloutEngine:
                 kl = div
         self.tl_div = kl
         nl = n // kl  # light batch entries
+        self.tl_invalid_full = tl_tokens["tl_token_invalid"] if "tl_token_invalid" in tl_tokens else ~tl_tokens["tl_token_valid"]
         if kl > 1:
             tl_tokens = lights_per_scene(tl_tokens, kl)
             tl_state_gt = tl_state_gt[::kl]
@@ -121,6 +125,8 @@ class RolloutEngine:
         S["dest_kind"] = (d_type[:, :, :4].any(-1).to(u8) + 2 * d_type[:, :, 4].to(u8)).contiguous()
         S["dest_thresh"] = (50.0 * (1 - d_type[:, :, 4].float() * 0.8)).contiguous()
         self.ag_attr6 = ag_attr.float().contiguous()
+        self.ag_type, self.navi_log_prob0, self.navi_valid0 = ag_type, ag_navi_log_prob, ag_navi_valid
+        self.n_step_tl_gt, self.stepwise = Tt, stepwise
         self.ag_latent = ag_latent.reshape(n * A, -1).float().contiguous()
         self.latent_invalid = _u8(~ag_latent_valid.reshape(-1))
         self.dest = ag_navi.contiguous()
@@ -143,7 +149,14 @@ class RolloutEngine:
         S["action_mean"], S["tl_logits"] = z(n * A, 2), z(nl * L, 5)
         S.update(out_valid=z(n, A, n_step, dt=u8), out_pose=z(n, A, n_step, 3), out_motion=z(n, A, n_step, 3),
                  out_action=z(n, A, n_step, 2), out_tl_state=z(nl, L, n_step, dt=u8), out_outside_map=z(n, A, n_step, dt=u8),
-                 out_dest_reached=z(n, A, n_step, dt=u8))
+                 out_dest_reached=z(n, A, n_step, dt=u8),
+                 # the rest of RolloutBuffer.add (buffer.py:39-78): reward terms, its validity, the forcing mask, light NLL
+                 out_reward=z(n, A, n_step, 4), out_reward_valid=z(n, A, n_step, dt=u8), out_tf=z(n, A, n_step, dt=u8),
+                 out_tl_nll=z(nl, L, n_step))
+        if stepwise:  # WaymoMotion.forward: this step's overrides, the player's actions, the this-step rule flags
+            S.update(ov_valid=z(n, A, dt=u8), ov_pose=z(n, A, 3), ov_motion=z(n, A, 3), ov_tl_valid=z(nl, L, dt=u8),
+                     ov_tl_state=z(nl, L, dt=u8), now_outside=z(n, A, dt=u8), now_reached=z(n, A, dt=u8),
+                     player_valid=z(n, A, dt=u8), player_action=z(n, A, 2))
         self.S = S
         self.mp_tokens, self.tl_tokens = mp_tokens, tl_tokens
         st = hip.SimState()
@@ -155,6 +168,7 @@ class RolloutEngine:
         st.max_acc = (C.c_float * 3)(*self.dyn.max_acc)
         st.max_yaw_rate = (C.c_float * 3)(*self.dyn.max_yaw_rate)
         st.dt = self.dyn.dt
+        st.w_pos, st.w_rot, st.w_spd = (float(w) for w in reward_weights)
         self.sim_state = st
         # the lights' part of tbx_sim_step only touches the light arrays: its own descriptor with their batch size
         self.sim_state_tl = st
@@ -170,7 +184,9 @@ class RolloutEngine:
         self.side, self.aux = self._side_streams(dev)
         # per-rollout constants of the heads chain (embedded latent, destination feature): once, not every step
         self.consts = self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div) if self.hoist_constants else None
-        self._tl_ahead(0)
+        self._n_forward = 0
+        if not stepwise:
+            self._tl_ahead(0)
 
     @torch.no_grad()
     def restore(self) -> None:
@@ -246,7 +262,61 @@ class RolloutEngine:
             else:
                 self.step()
 
+    # ------------------------------------------------------------------ step-wise driving (WaymoMotion.forward)
+    @torch.no_grad()
+    def forward_step(self, ag_override: Dict[str, Tensor], tl_override: Dict[str, Tensor],
+                     player_override: Optional[Dict[str, Tensor]] = None) -> int:
+        """One `WaymoMotion.forward` (waymo_motion.py:118-204): append the current state to the windows (from the second call on:
+        traffic_bots.py:123-143 does it at the head of every model call), policy, Dynamics.update_ag with the player's actions,
+        override_ag / override_tl with the overrides given. The caller owns what the reference's `rollout` does around it: rule
+        checks, disable_ag / disable_navi (`disable`). Returns the 0-based log slot the step was written to."""
+        assert self.stepwise, "reset(..., stepwise=True) first"
+        S = self.S
+        if self._n_forward > 0:
+            hip.sim_step(self.sim_state, hip.SIM_APPEND)  # (step-wise engines never share lights: tl_div == 1)
+        S["ov_valid"].copy_(ag_override["valid"])
+        S["ov_pose"].copy_(ag_override["pose"])
+        S["ov_motion"].copy_(ag_override["motion"])
+        S["ov_tl_valid"].copy_(tl_override["valid"])
+        S["ov_tl_state"].copy_(_state_bits(tl_override["state"]))
+        if player_override is not None:
+            S["player_valid"].copy_(player_override["valid"])
+            S["player_action"].copy_(player_override["action"])
+        else:
+            S["player_valid"].zero_()
+        self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6, S["ag_type_idx"],
+                               self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens,
+                               self.policy_out)
+        slot = self._n_forward
+        hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_LIGHTS | hip.SIM_ADVANCE | hip.SIM_NO_DISABLE | hip.SIM_NO_APPEND)
+        self._n_forward += 1
+        return slot
+
+    @torch.no_grad()
+    def disable(self, outside: Optional[Tensor] = None, reached: Optional[Tensor] = None, gt_valid: Optional[Tensor] = None) -> None:
+        """Dynamics.disable_ag (outside = outside_map_this_step, gt_valid) / disable_navi (reached = dest_reached_this_step)
+        (dynamics.py:165-204) on the device state, for step-wise drivers."""
+        S = self.S
+        if outside is not None:
+            dis = outside.to(torch.uint8)
+            if gt_valid is not None:
+                dis = dis & (~gt_valid.bool()).to(torch.uint8)
+            S["ag_disabled"] |= dis
+            S["ag_valid"] &= 1 - dis
+        if reached is not None:
+            S["navi_valid"] &= 1 - reached.to(torch.uint8)
+
     # ------------------------------------------------------------------ results
+    def action_log_prob(self, valid_u8: Tensor) -> Tensor:
+        """Dynamics.update_ag's action_log_prob with deterministic actions (dynamics.py:87-91): log N(mean | mean, std) of the
+        2-d action = -sum_d (log_std_d + log sqrt(2 pi)) per agent type, 0 for invalid agents. valid_u8 [n, A, ...]."""
+        ls = torch.stack(list(self.model.action_head.log_std), 0).sum(-1)  # [3]
+        per_type = -(ls + self.model.action_head.out_dim * 0.5 * math.log(2 * math.pi))
+        lp = per_type[self.S["ag_type_idx"].long()]  # [n, A]
+        while lp.dim() < valid_u8.dim():
+            lp = lp.unsqueeze(-1)
+        return lp * valid_u8.to(lp.dtype)
+
     def buffer(self, step_current: int = 10, rule_checker=None) -> RolloutBuffer:
         """The rollout log as the reference's RolloutBuffer. With a TrafficRuleChecker, the five metric-only rule checks
         (collided, collided_wosac, run_road_edge, run_red_light, passive: waymo_motion.py:250 in the reference's loop) are
@@ -254,9 +324,24 @@ class RolloutEngine:
         S, buf = self.S, RolloutBuffer(self.T, step_current)
         buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
         buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
-        out_tl = S["out_tl_state"] if self.tl_div == 1 else S["out_tl_state"].repeat_interleave(self.tl_div, 0)  # per rollout again
+        rep = (lambda t: t) if self.tl_div == 1 else (lambda t: t.repeat_interleave(self.tl_div, 0))  # per rollout again
+        out_tl = rep(S["out_tl_state"])
         if rule_checker is not None:
             buf.violation.update(rule_checker.check_log(S["out_valid"], S["out_pose"], S["out_motion"], out_tl))
         bits = (out_tl.to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=self.dev, dtype=torch.int32)) & 1
         buf.vis_dict = {"action": S["out_action"], "tl_state": bits.bool()}
+        # what the reference's loop adds per step besides the prediction (waymo_motion.py:250-300)
+        r = S["out_reward"]
+        buf.diffbar_reward = {"diffbar_reward_valid": S["out_reward_valid"].bool(), "diffbar_reward": r[..., 3],
+                              "r_imitation_pos": r[..., 0], "r_imitation_rot": r[..., 1], "r_imitation_spd": r[..., 2],
+                              "r_traffic_rule_approx": torch.zeros_like(r[..., 0])}
+        buf.tl_state_nll = rep(S["out_tl_nll"])
+        inv = self.tl_invalid_full.bool().unsqueeze(-1).expand(-1, -1, self.T).clone()
+        inv[:, :, max(self.n_step_tl_gt - 1, 0):] = True  # steps past the light ground truth carry no NLL (waymo_motion.py:277-279)
+        buf.tl_state_nll_invalid = inv
+        buf.mask_teacher_forcing = S["out_tf"].bool()
+        buf.action_log_prob = self.action_log_prob(S["out_valid"])
+        lp0 = self.navi_log_prob0 if self.navi_log_prob0 is not None else torch.zeros(self.n, self.A, device=self.dev)
+        buf.navi_log_prob, buf.navi_log_prob_valid = lp0.unsqueeze(-1), self.navi_valid0.bool().unsqueeze(-1)
+        buf._finished = True
         return buf
