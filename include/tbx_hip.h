@@ -258,9 +258,11 @@ enum {
   TBX_F_LOAD2 = 2048,   /* LOAD: a second source in the same stage (one memory round trip for both): buffer `src`, column `src_col`
                            (=) p2[row_of(g) * ld2 + c], c < reserved; whole float4s on both sides (n, ld, reserved, ld2 % 4 == 0,
                            16-byte aligned), reserved <= 256, no TBX_F_ACCUM */
-  TBX_F_ROWSKIP = 1024  /* LINEAR + TBX_F_WPACK (LDS destination): p1 holds a byte per global row; rows whose byte is set (clear with
-                           TBX_F_MASK_INV) and padding rows are NOT written - with TBX_F_ACCUM into the residual buffer this is
-                           x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */
+  TBX_F_ROWSKIP = 1024, /* LINEAR + TBX_F_WPACK / TBX_F_WGEMV (LDS destination): p1 holds a byte per global row; rows whose byte is set
+                           (clear with TBX_F_MASK_INV) and padding rows are NOT written - with TBX_F_ACCUM into the residual buffer
+                           this is x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */
+  TBX_F_WGEMV = 4096    /* LINEAR of a tbx_rowchain_live program: p0 is a tbx_pack_weight_gemv() image; a thread per output column,
+                           v_fma chains in the MFMA path's k order (bit-identical results, a fraction of the latency at 1-4 rows) */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };
@@ -290,6 +292,13 @@ int tbx_pack_weight(const float* w, const float* bias, int n, int k, int ld, int
  * exact-fp32 MFMA's ~1e-7, at 1/16 of the matrix-core time (the fp32 MFMA is the floor of a 16-row stage: 0.85 of 2.9 us). */
 int tbx_pack_weight_split(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 
+/* Column-stream image of the same weight + bias for TBX_F_WGEMV stages: per block of 128 output columns (outputs = groups*n,
+ * group-major), 1 + ceil(k/16)*4 float4 rows of [128 columns][4]: row 0 = (bias, 0, 0, 0), row 1 + q = the four weights the MFMA
+ * sequence multiplies in its k-block q / 4, step q % 4: k = (q/4)*16 + {0,4,8,12} + q%4 (zero-padded). The kernel streams it
+ * through LDS in contiguous chunks of <= 66 KiB by LDS-DMA. tbx_pack_weight_gemv_size floats. */
+int64_t tbx_pack_weight_gemv_size(int n, int k, int groups);
+int tbx_pack_weight_gemv(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
+
 /* tile_rows in {16, 32, 48}; ldw % 4 == 0; LDS = (2*ldw + 260) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                  int ldw, void* stream);
@@ -299,6 +308,15 @@ int tbx_rowchain(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_r
  * LDS = (ldw0 + ldw1 + ld_aux) * tile_rows * 4 bytes <= 160 KiB. */
 int tbx_rowchain_ex(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                     int ldw0, int ldw1, int ld_aux, void* stream);
+
+/* The same interpreter on tiles of `live_rows` (1, 2 or 4) rows - for launches of a few dozen to a few hundred rows in all (one
+ * 64-agent scene: the closed loop of BASELINE config 2), where a stage's latency, not its throughput, sets the step time: 4-16x
+ * more workgroups than 16-row tiles, and every LINEAR stage must be TBX_F_WGEMV (a thread per output element running the MFMA
+ * sequence's k-ordered fma chain on weights streamed through LDS, instead of MFMA tiles whose rows would be 3/4 .. 15/16 padding).
+ * Flat programs only (no GROUPMAX / POOLMAX / DROPOUT). LDS = 4 rows x (ldw0 + ldw1 + ld_aux) floats + 132 KiB of weight slots +
+ * the program <= 160 KiB. Results are bit-identical to the 16-row MFMA programs. */
+int tbx_rowchain_live(const tbx_stage_t* stages /* host */, int n_stages, int64_t n_rows, int live_rows, int ldw0, int ldw1,
+                      int ld_aux, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Per-step feature preparation (token frames, attribute rows, input pose embeddings).

@@ -1,0 +1,142 @@
+"""Multi-GPU readiness on ONE GPU (no 8-GPU node exists for the builder): the data-parallel training step
+through the real exchange path - a one-rank RCCL process group on the device (torch.distributed backend "nccl" IS RCCL on ROCm):
+`broadcast_parameters`, the flat gradient all-reduce of `allreduce_gradients` inside `train_step` and after `GraphedTrainStep`'s
+graph replay, per-rank seed separation, and that `bench.py --mode train --gpus 1` reports what the default line's `training`
+entry reports. No scaling curve is measured here (DESIGN.md 7 says so)."""
+import json
+import os
+import subprocess
+import sys
+from importlib import import_module
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+WORKER = r'''
+import json, os, sys, faulthandler
+faulthandler.enable()
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from importlib import import_module
+from __graft_entry__ import load_package
+tb = load_package()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+DP = import_module("trafficbots_amd.pl_modules.data_parallel")
+W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+cfg = tb.config.default_model_cfg(n_tgt_knn=4)
+scfg = tb.config.default_sim_cfg()
+scfg["time_step_end"] = 20
+out = {}
+torch.manual_seed(99)  # a rank whose RNG is NOT rank 0's: the broadcast makes the weights rank 0's anyway
+wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg).to(dev).train()
+before = DP.parameters_checksum(wm.model)
+out["broadcast_bytes"] = DP.broadcast_parameters(wm.model)
+out["checksum_kept"] = bool(torch.equal(before, DP.parameters_checksum(wm.model)))  # one rank: src == self
+chk = DP.parameters_checksum(wm.model).clone()
+dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+out["checksum_equal_across_ranks"] = bool(torch.equal(chk, DP.parameters_checksum(wm.model)))
+out["rank_seeds"] = [DP.rank_seed(1234, r) for r in range(8)]
+(opt,), _ = wm.configure_optimizers()
+batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=0).items()}
+# eager step: fwd + bwd + flat all-reduce (RCCL) + clip + AdamW
+calls = {"n": 0, "bytes": 0}
+real = DP.allreduce_gradients
+def counted(params, *a, **k):
+    b = real(params, *a, **k)
+    calls["n"] += 1
+    calls["bytes"] += b
+    return b
+DP.allreduce_gradients = counted
+m = DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()})
+live = DP.live_parameters(wm.model)
+out["eager_loss_finite"] = bool(torch.isfinite(m["loss"]))
+out["eager_allreduce_bytes"] = calls["bytes"]
+out["live_bytes"] = sum(p.numel() for p in live) * 4
+# the exchange leaves a one-rank gradient untouched (sum over one rank / 1), bit for bit
+opt.zero_grad(set_to_none=True)
+loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0)
+loss.backward()
+g0 = [p.grad.clone() for p in live]
+real(live)
+print("eager done", flush=True)
+out["allreduce_identity"] = all(bool(torch.equal(a, p.grad)) for a, p in zip(g0, live))
+# nothing of this eager iteration may stay alive into the capture: a live `loss` keeps its autograd graph and the AccumulateGrad
+# nodes of the default stream, and hipStreamEndCapture of the next backward then dies (measured: SIGSEGV in capture_end)
+del loss, g0
+opt.zero_grad(set_to_none=True)
+import gc; gc.collect()
+# graphed step: replay, then the same exchange outside the graph
+calls["n"] = calls["bytes"] = 0
+gs = DP.GraphedTrainStep(wm, opt, batch, warmup=1, verbose=True)
+for _ in range(2):
+    m = gs(batch)
+print("graph steps done", flush=True)
+out["graph_loss_finite"] = bool(torch.isfinite(m["loss"]))
+out["graph_allreduce_calls"] = calls["n"]
+out["graph_allreduce_bytes"] = calls["bytes"]
+out["graph_live_bytes"] = sum(p.numel() for p in gs.live) * 4
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out), flush=True)
+'''
+
+
+def _run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=str(ROOT), env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_one_rank_rccl_training_step_takes_the_real_exchange_path(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29617", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    out = _run([sys.executable, str(script), str(ROOT)], env)
+    res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["broadcast_bytes"] > 40e6  # 10.66 M parameters + buffers as fp32
+    assert res["checksum_kept"] and res["checksum_equal_across_ranks"]
+    assert len(set(res["rank_seeds"])) == 8 and res["rank_seeds"][0] == 1234
+    assert res["eager_loss_finite"] and res["graph_loss_finite"]
+    assert res["eager_allreduce_bytes"] == res["live_bytes"] > 30e6  # every live gradient travelled, as ONE flat buffer
+    assert res["allreduce_identity"]
+    assert res["graph_allreduce_calls"] == 2 and res["graph_allreduce_bytes"] == 2 * res["graph_live_bytes"]
+    assert res["graph_live_bytes"] == res["live_bytes"]
+
+
+def test_bench_train_mode_agrees_with_the_default_lines_training_entry():
+    """`bench.py --mode train --gpus 1` and the `training` entry the default line appends run the same step: same metric, config
+    and all-reduce size; throughput within the run-to-run spread of a 2-step measurement."""
+    a = json.loads(_run([sys.executable, "bench.py", "--mode", "train", "--gpus", "1", "--scenes", "2", "--steps", "2", "--warmup", "1",
+                         "--agents", "16", "--polylines", "128", "--lights", "16"]).strip().splitlines()[-1])
+    assert a["metric"] == "training scenes/sec" and a["n_gpus"] == 1 and a["finite"] and a["steps"] == 2
+    assert a["config"]["parallelism"] == "dp1" and a["config"]["global_batch"] == 2
+    assert a["config"]["allreduce_bytes"] > 30e6
+    assert abs(a["value"] - 2 * 2 / (a["ms_per_step"] * 2e-3)) < 1e-6 * a["value"]
+
+
+def test_loss_terms_with_empty_counters_are_left_out(tb):
+    """A per-GPU batch without a single valid traffic light (plausible on WOMD at batch 3): the reference leaves a term whose
+    counter is zero out of the loss (metrics/training.py:166-186); the step must not turn NaN."""
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    scfg = tb.config.default_sim_cfg()
+    scfg["time_step_end"] = 14
+    torch.manual_seed(0)
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **scfg).to(dev).train()
+    batch = tb.synthetic.make_scene(2, 8, 64, 8, seed=3)
+    for k in list(batch):
+        if k in ("tl_lane/valid", "tl_stop/valid", "tl_lane/state", "tl_stop/state"):
+            batch[k] = torch.zeros_like(batch[k])
+    loss = wm.training_step({k: v.to(dev) for k, v in batch.items()}, 0)
+    loss.backward()
+    m = wm.last_metrics
+    assert bool(torch.isfinite(loss)) and float(m["tl_state_loss"]) == 0.0
+    assert abs(float(m["loss"]) - float(m["vae_kl"] - m["diffbar_reward"] + m["navi_loss"])) < 1e-5 * max(1.0, abs(float(m["loss"])))

@@ -381,3 +381,54 @@ def test_action_head_fused_branches_bit_identical(tb, hip, dev):
     assert not torch.equal(outs[2], outs[0])
     m.fused_branches = False
     assert torch.equal(m(x, valid, ty).mean, outs[2])
+
+
+@pytest.mark.parametrize("live", [1, 2, 4])
+@pytest.mark.parametrize("rows", [1, 7, 64, 130])
+def test_live_row_chain_is_bit_identical_to_mfma_tiles(tb, live, rows):
+    """tbx_rowchain_live (tiles of 1 / 2 / 4 rows, LINEAR = a thread per output column running the MFMA sequence's k order as a
+    v_fma chain) vs the 16-row MFMA tiles on the same program: every stage kind the transformer-layer and head chains use -
+    LN, 128->128 / 128->384 / 128->512 / 512->128, block-diagonal per-head folds in both orientations, accumulate + row skip into
+    the residual, odd widths (20 -> 64 -> 2), straight-to-global outputs. Bit for bit."""
+    hip = import_module("trafficbots_amd.hip")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows * 10 + live)
+    R = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev)
+    d = 128
+    x, z20 = R(rows, d), R(rows, 20)
+    ln_w, ln_b = R(d) + 1.0, R(d)
+    w_in, b_in = R(3 * d, d), R(3 * d)
+    w_rpe, b_rpe = R(2 * d, d), R(2 * d)
+    w_o, b_o = R(d, d), R(d)
+    w1, b1, w2, b2 = R(4 * d, d), R(4 * d), R(d, 4 * d), R(d)
+    wa, ba, wb, bb = R(64, 20), R(64), R(2, 64), R(2)
+    skip = (torch.rand(rows, generator=g) < 0.3).to(torch.uint8).to(dev)
+    outs = {}
+    for mode in (0, live):
+        ch = hip.Chain(16, 1028, 132, 132, live_rows=mode) if mode else hip.Chain(16, 1028)
+        o_qkv, o_x, o_kv, o_small = (torch.zeros(rows, n, device=dev) for n in (7 * d, d, 2 * d, 2))
+        ch.load(x, hip.BUF1, 0, n=d)
+        ch.layernorm(hip.BUF1, 0, hip.BUF0, 0, ln_w, ln_b, 1e-5)
+        ch.linear(hip.BUF0, 0, hip.BUF0, d, w_in, b_in)                                   # q | k | v
+        ch.linear(hip.BUF0, d, hip.BUF0, 4 * d, w_rpe[:d], wt=True, groups=4, src_stride=32, dst_stride=d)  # qt = per-head W_k^T q
+        ch.store(hip.BUF0, d, 7 * d, o_qkv)
+        # per head: (k-slot)_h += W_rpe_v,h qt_h + b  (block-diagonal, accumulate), then x += skip ? 0 : out_proj(.)
+        ch.linear(hip.BUF0, 4 * d, hip.BUF0, 2 * d, w_rpe[d:], b_rpe[d:], accum=True, groups=4, src_stride=d, dst_stride=32)
+        ch.linear(hip.BUF0, 2 * d, hip.BUF1, 0, w_o, b_o, accum=True, skip_rows=skip)
+        ch.layernorm(hip.BUF1, 0, hip.BUF0, 0, ln_w, ln_b, 1e-5)
+        ch.linear(hip.BUF0, 0, hip.BUF0, d, w1, b1, relu=True)
+        ch.linear(hip.BUF0, d, hip.BUF1, 0, w2, b2, accum=True)
+        ch.rowmask(hip.BUF1, 0, d, mask=skip)
+        ch.store(hip.BUF1, 0, d, o_x)
+        ch.linear(hip.BUF1, 0, hip.GLOBAL, 0, w_in[d:], b_in[d:], out=o_kv)               # straight to global
+        ch.load(z20, hip.BUF0, 0, n=20, pad_to=32)
+        ch.linear(hip.BUF0, 0, hip.BUF0, 64, wa, ba, relu=True)
+        ch.linear(hip.BUF0, 64, hip.AUX, 0, wb, bb)
+        ch.clamp(hip.AUX, 0, 2, -0.25, 0.25)
+        ch.store(hip.AUX, 0, 2, o_small)
+        ch.run(rows)
+        outs[mode] = (o_qkv, o_x, o_kv, o_small)
+    torch.cuda.synchronize()
+    for a, b, name in zip(outs[0], outs[live], ("qkv|qt", "x", "kv (global)", "small")):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))

@@ -23,6 +23,7 @@ struct RowchainArgs {
   int32_t group_rows;
   int32_t ldw0, ldw1, ld_aux;
   int32_t first_packed;  // first TBX_F_WPACK LINEAR stage (-1: none): its weights are requested before stage 0 runs
+  int32_t live_rows;     // tbx_rowchain_live: a tile holds this many rows (1, 2 or 4) of a 16-row LDS tile; 0: whole tiles
   int64_t n_rows;
 };
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ void gst1(float* p, float v) { *(TBX_GLOBAL float*)p 
 
 template <int MT, bool EXT>
 struct Tile {
-  static constexpr int ROWS = 16 * MT;
+  static constexpr int ROWS = MT > 0 ? 16 * MT : 4;  // MT = 0: the 4-row tiles of tbx_rowchain_live
   float* base;    // LDS base; BUF0 = ROWS*ldw0 floats, then BUF1 = ROWS*ldw1, then AUX = ROWS*ld_aux
   int ldw0, ldw1, ld_aux;
   // computed, not indexed: a runtime-indexed member array would live in scratch memory
@@ -78,6 +79,7 @@ struct Tile {
   int64_t group;   // index of the tile's first group (grouped mode) or tile index
   int gw, ng;      // grouped mode: rows per group and groups in this tile (rows [j*gw, (j+1)*gw) = group `group + j`);
                    // flat mode: gw = ROWS, ng = 1
+  int rows_live;   // rows the row-wise ops walk: ROWS, or the live rows of a tbx_rowchain_live tile (the rest is padding)
 };
 
 __device__ __forceinline__ int64_t row_of(const tbx_stage_t& s, int64_t g) {
@@ -98,7 +100,7 @@ __device__ __forceinline__ int64_t row_of(const tbx_stage_t& s, int64_t g) {
 
 template <int MT, bool EXT>
 __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
+  constexpr int ROWS = Tile<MT, EXT>::ROWS;
   TBX_WAVE_ROWS;
   float* dst = t.b(s.dst) + s.dst_col;
   const int ld = t.l(s.dst);
@@ -116,8 +118,8 @@ __device__ void op_load(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     const int ldb = t.l(s.src), w4b = two ? (s.reserved >> 2) : 0;
     // all of a wave's requests first, then the LDS writes: the rows were written by the previous launch and come from L2 /
     // HBM at ~1 us per dependent round trip; a 640-wide load was 6 of them in a row (2.7 us -> one round trip)
-    constexpr int RPW = ROWS / 8;  // rows per wave at the 8-wave workgroups every launch uses
-    if (RPW <= 4 && nwave == 8 && w4 <= 256) {  // (48-row tiles would hold 96 registers here: they take the loop below)
+    constexpr int RPW = ROWS >= 8 ? ROWS / 8 : 1;  // rows per wave at the 8-wave workgroups every launch uses
+    if (ROWS >= 8 && RPW <= 4 && nwave == 8 && w4 <= 256) {  // (48-row tiles would hold 96 registers here: they take the loop below)
       float4 v[RPW][4], v2[RPW];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
@@ -377,11 +379,177 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
   wa.bias = cb;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TBX_F_WGEMV: LINEAR for the 1 / 2 / 4-row tiles of tbx_rowchain_live (the closed loop at a few scenes, where a launch has
+// 64-128 rows in all and every stage is latency-, not throughput-bound). A 16-row MFMA tile would spend 3/4 .. 15/16 of the
+// exact-fp32 matrix pipe (which runs at the VALU rate anyway) on padding rows and string 32 dependent 40-cycle MFMAs per 128 k.
+// Here a THREAD owns one output element (row r = tid / 128, column cl = tid % 128 of the current 128-column block) and runs the
+// k-ordered v_fma chain the 16x16x4 MFMA sequence is equivalent to - per k-block of 16: step t = 0..3, lane group g = 0..3,
+// k = kb*16 + g*4 + t, starting from bias (+ destination) - so results are bit-identical to the packed MFMA path
+// (cdna_hip_programming.md 3: an f32 MFMA is a k-ordered fmaf chain).
+// Weights come as the tbx_pack_weight_gemv image: per 128-column block a row of (bias, 0, 0, 0) per column, then float4 rows
+// q = kb*4 + t of [128 columns][4] = (W[c][kb*16 + t], W[c][kb*16+4 + t], W[c][kb*16+8 + t], W[c][kb*16+12 + t]). They stream
+// through two 66 KiB LDS slots in chunks of <= 8 k-blocks x 128 columns by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction, no VGPRs, no ds_write pass): chunk i+1 - or chunk 0 of the NEXT LINEAR stage - is in flight while chunk i is
+// multiplied; every thread then reads its column conflict-free (ds_read_b128, consecutive lanes = consecutive 16 B) and the row's
+// activations as broadcast reads.
+// Measured alternatives (tools/live_micro.py, 128x128 stage, 4 live rows, weights L2-hot; this form: 2.1 k cycles in the multiply
+// loop): v_mfma_f32_4x4x1_16b_f32 (4 rows x 64 columns x one k per issue, no padding): 3.2 k - ~25 cycles per dependent issue;
+// activations as SGPR operands through v_readlane instead of broadcast LDS reads: 5.2 k; the LDS reads two k-blocks deep in
+// software: 2.4 k. At 8 waves the loop is LDS-issue bound (a broadcast ds_read_b128 still costs 4 LDS cycles per wave
+// instruction), so 1- or 2-row tiles (2 / 4 multiplying waves) are the fastest per stage.
+#ifdef TBX_STAGE_CLOCK
+__device__ unsigned long long g_sub[8];  // shader-clock stamps inside the last linear_gemv call of workgroup 0 (tools/live_micro.py)
+#define TBX_SUB(i)                                                       \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_sub[i] = clock64();       \
+  } while (0)
+#else
+#define TBX_SUB(i)
+#endif
+constexpr int GCOLS = 128;                   // columns per block = threads per live row
+constexpr int GKC = 8;                       // k-blocks per chunk
+constexpr int GROW = GCOLS * 4;              // floats per float4 row of a column block (2 KiB)
+constexpr int GSLOT = (1 + GKC * 4) * GROW;  // floats per LDS weight slot: a bias row + 32 weight rows (66 KiB)
+
+struct WeightStream {
+  int stage;  // stage whose chunk 0 is (being) loaded into slot `slot`; -1: nothing in flight
+  int slot;
+};
+
+__device__ __forceinline__ int gemv_kblocks(const uint32_t* prog, int j) { return ((int)prog_word(prog, j, 5) + 15) / 16; }
+
+// LDS-DMA of chunk (cb, kc) of the image at `img` (kblocks k-blocks per column block; a column block = one row of [128][4] whose
+// .x is the bias, then kblocks*4 weight rows) into `slot`: chunk 0 of a block brings the bias row along. Pieces of 1 KiB, piece p
+// by wave p % nwave; completion = every issuing wave's vmcnt(0) + a workgroup barrier.
+// Inline asm, not __builtin_amdgcn_global_load_lds: hipcc orders every later ds_read behind a DMA it knows about (s_waitcnt
+// vmcnt(0) in front of the FMA loop's LDS reads - measured: no overlap at all, a stage = DMA latency + multiply time). The asm
+// form is invisible to its counters (which can then only over-wait: VMEM returns in order); the LDS hazard is handled by hand:
+// every consumer sits behind "s_waitcnt vmcnt(0); s_barrier" (cdna_hip_programming.md 5.7: M0 is written in the statement that
+// reads it and restored).
+__device__ __forceinline__ void gemv_dma(const float* img, int kblocks, int cb, int kc, float* slot, int lane, int wave, int nwave) {
+  const int kbc = (kblocks - kc * GKC) < GKC ? (kblocks - kc * GKC) : GKC;
+  const int rows = kbc * 4 + (kc == 0 ? 1 : 0);
+  const float* base = img + ((int64_t)cb * (1 + kblocks * 4) + (kc == 0 ? 0 : 1 + kc * GKC * 4)) * GROW;
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slot);
+  for (int p = wave; p < rows * 2; p += nwave) {
+    const float* gsrc = base + p * 256 + lane * 4;
+    const uint32_t dst = lds0 + (uint32_t)p * 1024u;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+  }
+}
+
+template <int MT, bool EXT>
+__device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, float* wslots,
+                                            const uint32_t* skipflags, WeightStream& ws, int stage) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nwave = (int)(blockDim.x >> 6);
+  const bool to_global = EXT && s.dst == TBX_BUF_GLOBAL;
+  const float* src0 = t.b(s.src) + s.src_col;
+  float* dst0 = t.b(to_global ? 0 : s.dst) + s.dst_col;
+  float* __restrict__ gout0 = to_global ? (float*)s.p2 + t.g0 * (int64_t)s.ld2 + s.dst_col : nullptr;
+  const int lds_s = t.l(s.src), lds_d = t.l(to_global ? 0 : s.dst);
+  const float* __restrict__ img = (const float*)s.p0;
+  const int N = s.n;
+  const int G = s.reserved > 0 ? s.reserved : 1;
+  const int gs_src = (s.div >> 16) & 0xffff, gs_dst = s.div & 0xffff;
+  const bool accum = (s.flags & TBX_F_ACCUM) != 0;
+  const bool rowskip = (s.flags & TBX_F_ROWSKIP) != 0 && !to_global;
+  const int kblocks = (s.k + 15) / 16;
+  const int NO = G * N;
+  const int ncb = (NO + GCOLS - 1) / GCOLS;
+  const int nkc = (kblocks + GKC - 1) / GKC;
+  const int r = (int)(threadIdx.x >> 7);  // the thread's row (wave-uniform: a wave is 64 consecutive columns of one row)
+  const int cl = (int)(threadIdx.x & (GCOLS - 1));
+  const bool row_on = r < t.rows_live;
+  // row-skip flags were gathered into LDS by the kernel prologue: an ordinary global load here would make the compiler drain
+  // the weight DMAs in flight (vmcnt is in order) - one exposed memory round trip per stage
+  const bool skip = r >= t.n_valid || (rowskip && ((skipflags[stage] >> r) & 1u) != 0u);
+  TBX_SUB(0);
+  // chunk 0 is already on its way if the previous LINEAR stage (or the kernel prologue) requested it
+  int slot = ws.stage == stage ? ws.slot : 0;
+  if (ws.stage != stage) gemv_dma(img, kblocks, 0, 0, wslots + slot * GSLOT, lane, wave, nwave);
+  const int nj = s.pad;  // next TBX_F_WGEMV stage (0: none)
+  const int n_chunks = ncb * nkc;
+  const bool n_pow2 = (N & (N - 1)) == 0;
+  const int n_shift = __builtin_ctz((unsigned)N);
+  float acc = 0.f;
+  int cb = 0, kc = 0;  // chunk i = (cb, kc), walked without divisions
+  for (int i = 0; i < n_chunks; ++i) {
+    // chunk i has landed (every wave waits for its own pieces, the barrier collects all waves'); everybody is also done with the
+    // other slot (chunk i - 1), so the next chunk may go there
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    TBX_SUB(1);
+    const float* w = wslots + slot * GSLOT;
+    if (i + 1 < n_chunks) {
+      const bool wrap = kc + 1 == nkc;
+      gemv_dma(img, kblocks, wrap ? cb + 1 : cb, wrap ? 0 : kc + 1, wslots + (1 - slot) * GSLOT, lane, wave, nwave);
+    } else if (nj > 0) {
+      const float* nimg = (const float*)(((uint64_t)prog_word(prog, nj, 17) << 32) | prog_word(prog, nj, 16));
+      gemv_dma(nimg, gemv_kblocks(prog, nj), 0, 0, wslots + (1 - slot) * GSLOT, lane, wave, nwave);
+    }
+    TBX_SUB(2);
+    const int o = cb * GCOLS + cl;
+    const bool live = o < NO;
+    const int oc = live ? o : NO - 1;
+    const int grp = G > 1 ? (n_pow2 ? oc >> n_shift : oc / N) : 0;
+    const int c = oc - grp * N;
+    if (row_on) {
+      const float* wc = w + cl * 4;
+      if (kc == 0) {
+        acc = wc[0];  // the block's bias row
+        if (accum && live) acc += dst0[r * lds_d + grp * gs_dst + c];
+        wc += GROW;
+      }
+      const float* xr = src0 + grp * gs_src + r * lds_s + kc * GKC * 16;
+      const int kbc = (kblocks - kc * GKC) < GKC ? (kblocks - kc * GKC) : GKC;
+      const float4* xr4 = (const float4*)__builtin_assume_aligned(xr, 16);  // src_col, the row widths and the chunk offset are multiples of 4 floats
+      const float4* wc4 = (const float4*)__builtin_assume_aligned(wc, 16);
+      float a = acc;
+#pragma unroll 2
+      for (int kb = 0; kb < kbc; ++kb) {
+        const float4 x0 = xr4[kb * 4], x1 = xr4[kb * 4 + 1], x2 = xr4[kb * 4 + 2], x3 = xr4[kb * 4 + 3];
+        const float4 w0 = wc4[(kb * 4) * (GROW / 4)], w1 = wc4[(kb * 4 + 1) * (GROW / 4)];
+        const float4 w2 = wc4[(kb * 4 + 2) * (GROW / 4)], w3 = wc4[(kb * 4 + 3) * (GROW / 4)];
+        a = __builtin_fmaf(x0.x, w0.x, a); a = __builtin_fmaf(x1.x, w0.y, a); a = __builtin_fmaf(x2.x, w0.z, a); a = __builtin_fmaf(x3.x, w0.w, a);
+        a = __builtin_fmaf(x0.y, w1.x, a); a = __builtin_fmaf(x1.y, w1.y, a); a = __builtin_fmaf(x2.y, w1.z, a); a = __builtin_fmaf(x3.y, w1.w, a);
+        a = __builtin_fmaf(x0.z, w2.x, a); a = __builtin_fmaf(x1.z, w2.y, a); a = __builtin_fmaf(x2.z, w2.z, a); a = __builtin_fmaf(x3.z, w2.w, a);
+        a = __builtin_fmaf(x0.w, w3.x, a); a = __builtin_fmaf(x1.w, w3.y, a); a = __builtin_fmaf(x2.w, w3.z, a); a = __builtin_fmaf(x3.w, w3.w, a);
+      }
+      acc = a;
+      TBX_SUB(3);
+      if (kc == nkc - 1) {
+        float v = acc;
+        if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
+        if (to_global) {
+          if (live && r < t.n_valid) gst1(gout0 + (int64_t)r * s.ld2 + grp * gs_dst + c, v);
+        } else if (live) {
+          if (!rowskip || !skip) dst0[r * lds_d + grp * gs_dst + c] = v;
+        } else if (!accum && G == 1 && o < (N + 15) / 16 * 16 && o < lds_d - s.dst_col) {
+          dst0[r * lds_d + o] = 0.f;  // K padding of the next stage, as the MFMA path leaves it
+        }
+      }
+    }
+    slot = 1 - slot;
+    if (++kc == nkc) kc = 0, ++cb;
+    TBX_SUB(4);
+  }
+  // `slot` now names the buffer the look-ahead request went to
+  ws.stage = nj > 0 ? nj : -1;
+  ws.slot = slot;
+}
+
 // LINEAR (optionally grouped: `reserved` = G groups, group g reads src columns src_col + g*src_stride, writes
 // dst_col + g*dst_stride, with src_stride / dst_stride packed in `div` as (src << 16 | dst); its weight block is the next
 // n rows (or k rows if TBX_F_WT) after the previous group's, its bias the next n entries).
-template <int MT, bool EXT, bool FULL>
+template <int MT, bool EXT, bool FULL, bool LIVE>
 __device__ void op_linear(const tbx_stage_t& s, const Tile<MT, EXT>& t, const uint32_t* prog, int stage, WeightAhead& wa) {
+  if constexpr (LIVE) return;  // tbx_rowchain_live programs run linear_gemv (called by the kernel: it owns the LDS weight slots)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwave = blockDim.x >> 6;
@@ -512,7 +680,6 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, float* __r
 
 template <int MT, bool EXT>
 __device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
   TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
@@ -520,7 +687,7 @@ __device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const float* gamma = (const float*)s.p0;
   const float* beta = (const float*)s.p1;
   const int n = s.n;
-  for (int r = wave; r < ROWS; r += nwave) {
+  for (int r = wave; r < t.rows_live; r += nwave) {
     if (n <= 128)
       ln_row<2>(src + r * lds_s, dst + r * lds_d, n, lane, s.f0, gamma, beta);
     else if (n <= 256)
@@ -532,7 +699,6 @@ __device__ void op_layernorm(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 
 template <int MT, bool EXT>
 __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
   TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
@@ -540,7 +706,7 @@ __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int n = s.n;
   if (s.op != TBX_OP_CLAMP && (n & 3) == 0 && ((s.src_col | s.dst_col) & 3) == 0) {
     const int w4 = n >> 2;
-    for (int r = wave; r < ROWS; r += nwave)
+    for (int r = wave; r < t.rows_live; r += nwave)
       for (int c4 = lane; c4 < w4; c4 += 64) {
         float4 v = *(const float4*)(src + r * lds_s + c4 * 4);
         float4* d = (float4*)(dst + r * lds_d + c4 * 4);
@@ -552,7 +718,7 @@ __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
       }
     return;
   }
-  for (int r = wave; r < ROWS; r += nwave)
+  for (int r = wave; r < t.rows_live; r += nwave)
     for (int c = lane; c < n; c += 64) {
       if (s.op == TBX_OP_ADD)
         dst[r * lds_d + c] += src[r * lds_s + c];
@@ -567,7 +733,7 @@ __device__ void op_elementwise(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 // chain's global row.
 template <int MT, bool EXT>
 __device__ void op_dropout(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
+  constexpr int ROWS = Tile<MT, EXT>::ROWS;
   TBX_WAVE_ROWS;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_d = t.l(s.dst);
@@ -595,13 +761,12 @@ __device__ void op_dropout(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 
 template <int MT, bool EXT>
 __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
   TBX_WAVE_ROWS;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_d = t.l(s.dst);
   const uint8_t* mask = (const uint8_t*)s.p0;
   const int n = s.n;
-  for (int r = wave; r < ROWS; r += nwave) {
+  for (int r = wave; r < t.rows_live; r += nwave) {
     bool m = r >= t.n_valid;
     if (!m && mask != nullptr) m = (gld1(mask + row_of(s, t.g0 + r)) != 0) != ((s.flags & TBX_F_MASK_INV) != 0);
     if (m)
@@ -611,7 +776,7 @@ __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 
 template <int MT, bool EXT>
 __device__ void op_groupmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
+  constexpr int ROWS = Tile<MT, EXT>::ROWS;
   const float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
@@ -655,7 +820,7 @@ __device__ void op_poolmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 
 template <int MT, bool EXT>
 __device__ void op_store(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
-  constexpr int ROWS = 16 * MT;
+  constexpr int ROWS = Tile<MT, EXT>::ROWS;
   TBX_WAVE_ROWS;
   const float* src = t.b(s.src) + s.src_col;
   const int lds_s = t.l(s.src);
@@ -693,9 +858,9 @@ __device__ unsigned int g_clk_launch;
 // FULL = false: the lean instantiation every program of the hot path runs on - packed exact-fp32 LINEAR stages only, no DROPOUT.
 // Row-major weights (the ABI's reference path), split-bf16 stages and the training dropouts select FULL = true. The interpreter
 // is sensitive to its own size (its text is ~2/3 of the instruction cache): what a program does not use is not compiled in.
-template <int MT, bool EXT, bool FULL>
+template <int MT, bool EXT, bool FULL, bool LIVE = false>
 __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
-  constexpr int ROWS = 16 * MT;
+  constexpr int ROWS = Tile<MT, EXT>::ROWS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef TBX_STAGE_CLOCK
   unsigned clk_slot = 0;
@@ -726,13 +891,18 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     t.g0 = t.group * a.group_rows;
     t.n_valid = t.ng * a.group_rows;
   } else {
-    t.g0 = (int64_t)blockIdx.x * ROWS;
+    const int per = a.live_rows > 0 ? a.live_rows : ROWS;
+    t.g0 = (int64_t)blockIdx.x * per;
     const int64_t left = a.n_rows - t.g0;
-    t.n_valid = left < ROWS ? (int)left : ROWS;
+    t.n_valid = left < per ? (int)left : per;
   }
+  t.rows_live = a.live_rows > 0 ? a.live_rows : ROWS;
   // The program is copied kernarg -> LDS once (one parallel read) and each stage descriptor is decoded from LDS into
   // SGPRs (readfirstlane): a scalar load per stage from the kernarg segment costs ~0.6 us of exposed latency per stage.
-  uint32_t* prog = (uint32_t*)(lds + (size_t)ROWS * (a.ldw0 + a.ldw1 + a.ld_aux));
+  // live kernel: [activations | two 64 KiB weight slots | program]
+  float* wslots = lds + (size_t)ROWS * (a.ldw0 + a.ldw1 + a.ld_aux);
+  uint32_t* skipflags = (uint32_t*)(wslots + (LIVE ? 2 * GSLOT : 0));  // live kernel: one word per stage, bit r = skip row r
+  uint32_t* prog = skipflags + (LIVE ? TBX_MAX_STAGES : 0);
   {
     const uint32_t* ka = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     for (int e = threadIdx.x; e < a.n_stages * SW; e += blockDim.x) prog[e] = ka[e];
@@ -743,8 +913,29 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   for (int q = 0; q < CH; ++q) wa.w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   wa.bias = 0.f;
   wa.stage = -1;
-  if (a.first_packed >= 0)
+  if (!LIVE && a.first_packed >= 0)
     weights_ahead(prog, a.first_packed, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wa);
+  WeightStream ws;
+  ws.stage = -1, ws.slot = 0;
+  if constexpr (LIVE) {  // TBX_F_ROWSKIP masks of every LINEAR stage -> LDS, before any weight DMA is in flight
+    if ((int)threadIdx.x < a.n_stages) {
+      const int j = (int)threadIdx.x;
+      uint32_t f = 0u;
+      if (prog[j * SW + 0] == (uint32_t)TBX_OP_LINEAR && (prog[j * SW + 8] & (uint32_t)TBX_F_ROWSKIP)) {
+        const uint8_t* m = (const uint8_t*)(((uint64_t)prog[j * SW + 19] << 32) | prog[j * SW + 18]);
+        const bool inv = (prog[j * SW + 8] & (uint32_t)TBX_F_MASK_INV) != 0u;
+        for (int r = 0; r < t.n_valid; ++r) f |= ((gld1(m + t.g0 + r) != 0) != inv) ? (1u << r) : 0u;
+      }
+      skipflags[j] = f;
+    }
+    __syncthreads();
+  }
+  if (LIVE && a.first_packed >= 0) {  // the first LINEAR stage's first chunk: on its way while the stages before it run
+    const int j = a.first_packed;
+    gemv_dma((const float*)(((uint64_t)prog_word(prog, j, 17) << 32) | prog_word(prog, j, 16)), gemv_kblocks(prog, j), 0, 0, wslots,
+             (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(blockDim.x >> 6));
+    ws.stage = j;
+  }
   for (int i = 0; i < a.n_stages; ++i) {
     const uint32_t* ps = prog + i * SW;
     auto rd = [&](int w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ps[w]); };
@@ -758,7 +949,12 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     s.p0 = rdp(16), s.p1 = rdp(18), s.p2 = rdp(20);
     switch (s.op) {
       case TBX_OP_LOAD: op_load<MT, EXT>(s, t); break;
-      case TBX_OP_LINEAR: op_linear<MT, EXT, FULL>(s, t, prog, i, wa); break;
+      case TBX_OP_LINEAR:
+        if constexpr (LIVE)
+          linear_gemv<MT, EXT>(s, t, prog, wslots, skipflags, ws, i);
+        else
+          op_linear<MT, EXT, FULL, LIVE>(s, t, prog, i, wa);
+        break;
       case TBX_OP_LAYERNORM: op_layernorm<MT, EXT>(s, t); break;
       case TBX_OP_ADD:
       case TBX_OP_COPY:
@@ -767,8 +963,12 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       case TBX_OP_DROPOUT:
         if constexpr (FULL) op_dropout<MT, EXT>(s, t);
         break;
-      case TBX_OP_GROUPMAX: op_groupmax<MT, EXT>(s, t); break;
-      case TBX_OP_POOLMAX: op_poolmax<MT, EXT>(s, t); break;
+      case TBX_OP_GROUPMAX:
+        if constexpr (!LIVE) op_groupmax<MT, EXT>(s, t);
+        break;
+      case TBX_OP_POOLMAX:
+        if constexpr (!LIVE) op_poolmax<MT, EXT>(s, t);
+        break;
       case TBX_OP_STORE: op_store<MT, EXT>(s, t); break;
       default: break;
     }
@@ -824,6 +1024,34 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
+// tbx_pack_weight_gemv image: [ncb column blocks][1 + kblocks*4 float4 rows][128 columns][4]. Row 0 of a block: (bias, 0, 0, 0)
+// per column; row 1 + q: W_g[c][kb*16 + {0,4,8,12} + t] of output o = (g, c), q = kb*4 + t (zero beyond k / beyond the outputs).
+__global__ void pack_weight_gemv_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld,
+                                        int groups, int wt, float* __restrict__ out, int64_t total) {
+  const int kblocks = (k + 15) / 16, NO = groups * n;
+  const int64_t per_cb = (int64_t)(1 + kblocks * 4) * GROW;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int cb = (int)(e / per_cb);
+    const int64_t f = e - cb * per_cb;
+    const int j = (int)(f & 3);
+    const int cl = (int)((f >> 2) % GCOLS);
+    const int row = (int)((f >> 2) / GCOLS);
+    const int o = cb * GCOLS + cl;
+    float v = 0.f;
+    if (row == 0) {
+      if (j == 0 && bias != nullptr && o < NO) v = bias[o];
+    } else {
+      const int q = row - 1;
+      const int kk = (q >> 2) * 16 + j * 4 + (q & 3);
+      if (o < NO && kk < k) {
+        const int grp = o / n, c = o - grp * n;
+        v = wt ? w[((int64_t)grp * k + kk) * ld + c] : w[((int64_t)grp * n + c) * ld + kk];
+      }
+    }
+    out[e] = v;
+  }
+}
+
 int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_rows) {
   auto buf_ld = [&](int b) { return b == 0 ? ldw0 : (b == 1 ? ldw1 : (b == 2 ? ld_aux : (1 << 30))); };
   if (s.op < TBX_OP_LOAD || s.op > TBX_OP_DROPOUT) return TBX_ERR_ARG;
@@ -865,7 +1093,8 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
     if (s.src < 0 || s.src > 2 || s.src_col < 0 || s.src_col + s.reserved > buf_ld(s.src)) return TBX_ERR_UNSUPPORTED;
     if (s.src == s.dst && !(s.src_col >= s.dst_col + s.n || s.dst_col >= s.src_col + s.reserved)) return TBX_ERR_UNSUPPORTED;
   }
-  if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP) && (!(s.flags & TBX_F_WPACK) || gdst || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
+  if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP) && (!(s.flags & (TBX_F_WPACK | TBX_F_WGEMV)) || gdst || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
+  if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_WGEMV) && (s.flags & (TBX_F_WPACK | TBX_F_WSPLIT | TBX_F_WT))) return TBX_ERR_ARG;
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
   if (s.op != TBX_OP_LINEAR && (s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;
@@ -880,6 +1109,10 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
                                int ldw0, int ldw1, int ld_aux, void* stream);
 
 #ifdef TBX_STAGE_CLOCK
+extern "C" int tbx_debug_sub_dump(unsigned long long* host_out) {
+  if (hipDeviceSynchronize() != hipSuccess) return TBX_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sub), 8 * sizeof(unsigned long long)) == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
 extern "C" int tbx_debug_clock_reset() {
   unsigned int z = 0;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_clk_launch), &z, sizeof(z)) == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
@@ -925,6 +1158,33 @@ extern "C" int tbx_pack_weight_split(const float* w, const float* bias, int n, i
   return pack_weight_impl(w, bias, n, k, ld, groups, wt, 1, out, stream);
 }
 
+extern "C" int64_t tbx_pack_weight_gemv_size(int n, int k, int groups) {
+  if (n <= 0 || k <= 0 || groups <= 0) return TBX_ERR_ARG;
+  const int64_t ncb = ((int64_t)groups * n + GCOLS - 1) / GCOLS;
+  return ncb * (int64_t)(1 + ((k + 15) / 16) * 4) * GROW;
+}
+
+extern "C" int tbx_pack_weight_gemv(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
+                                    void* stream) {
+  if (w == nullptr || out == nullptr || n <= 0 || k <= 0 || ld <= 0 || groups <= 0) return TBX_ERR_ARG;
+  const int64_t total = tbx_pack_weight_gemv_size(n, k, groups);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weight_gemv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out,
+                     total);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+namespace {
+int rowchain_launch(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows, int live_rows, int ldw0,
+                    int ldw1, int ld_aux, void* stream);
+}
+
+extern "C" int tbx_rowchain_live(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int live_rows, int ldw0, int ldw1,
+                                 int ld_aux, void* stream) {
+  if (live_rows != 1 && live_rows != 2 && live_rows != 4) return TBX_ERR_UNSUPPORTED;
+  return rowchain_launch(stages, n_stages, n_rows, 0, 16, live_rows, ldw0, ldw1, ld_aux, stream);
+}
+
 extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                             int ldw, void* stream) {
   return tbx_rowchain_ex(stages, n_stages, n_rows, group_rows, tile_rows, ldw, ldw, TBX_AUX_LD, stream);
@@ -932,6 +1192,12 @@ extern "C" int tbx_rowchain(const tbx_stage_t* stages, int n_stages, int64_t n_r
 
 extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows,
                                int ldw0, int ldw1, int ld_aux, void* stream) {
+  return rowchain_launch(stages, n_stages, n_rows, group_rows, tile_rows, 0, ldw0, ldw1, ld_aux, stream);
+}
+
+namespace {
+int rowchain_launch(const tbx_stage_t* stages, int n_stages, int64_t n_rows, int group_rows, int tile_rows, int live_rows, int ldw0,
+                    int ldw1, int ld_aux, void* stream) {
   if (stages == nullptr || n_stages <= 0 || n_rows <= 0) return TBX_ERR_ARG;
   if (n_stages > TBX_MAX_STAGES) return TBX_ERR_UNSUPPORTED;
   if (tile_rows != 16 && tile_rows != 32 && tile_rows != 48) return TBX_ERR_UNSUPPORTED;
@@ -939,12 +1205,19 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   if (group_rows < 0 || group_rows > tile_rows) return TBX_ERR_UNSUPPORTED;
   if (group_rows > 0 && n_rows % group_rows != 0) return TBX_ERR_ARG;
   // activation buffers + the program itself (decoded from LDS by the kernel)
-  const size_t lds_bytes = (size_t)(ldw0 + ldw1 + ld_aux) * tile_rows * sizeof(float) + (size_t)n_stages * sizeof(tbx_stage_t);
+  const size_t lds_bytes = live_rows > 0 ? (size_t)(ldw0 + ldw1 + ld_aux) * 4 * sizeof(float) + 2 * GSLOT * sizeof(float) +
+                                               TBX_MAX_STAGES * sizeof(uint32_t) + (size_t)n_stages * sizeof(tbx_stage_t)
+                                         : (size_t)(ldw0 + ldw1 + ld_aux) * tile_rows * sizeof(float) + (size_t)n_stages * sizeof(tbx_stage_t);
   if (lds_bytes > 160 * 1024) return TBX_ERR_UNSUPPORTED;
   RowchainArgs a;
   for (int i = 0; i < n_stages; ++i) {
     const int rc = check_stage(stages[i], ldw0, ldw1, ld_aux, tile_rows);
     if (rc != TBX_OK) return rc;
+    // thread-per-column LINEAR stages exist for live-row tiles only; group-wise stages need whole tiles
+    const bool gemv = stages[i].op == TBX_OP_LINEAR && (stages[i].flags & TBX_F_WGEMV);
+    if (gemv != (live_rows > 0 && stages[i].op == TBX_OP_LINEAR)) return TBX_ERR_UNSUPPORTED;
+    if (live_rows > 0 && (stages[i].op == TBX_OP_GROUPMAX || stages[i].op == TBX_OP_POOLMAX || stages[i].op == TBX_OP_DROPOUT))
+      return TBX_ERR_UNSUPPORTED;
     a.st[i] = stages[i];
   }
   // pad = index of the next packed LINEAR stage after this one (0: none): the kernel fetches that stage's first weights
@@ -952,26 +1225,29 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
   int next_packed = 0;
   for (int i = n_stages - 1; i >= 0; --i) {
     a.st[i].pad = next_packed;
-    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & TBX_F_WPACK)) next_packed = i;
+    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & (TBX_F_WPACK | TBX_F_WGEMV))) next_packed = i;
   }
   a.first_packed = -1;
   for (int i = n_stages - 1; i >= 0; --i)
-    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & TBX_F_WPACK)) a.first_packed = i;
+    if (a.st[i].op == TBX_OP_LINEAR && (a.st[i].flags & (TBX_F_WPACK | TBX_F_WGEMV))) a.first_packed = i;
   a.n_stages = n_stages;
   a.group_rows = group_rows;
   a.ldw0 = ldw0;
   a.ldw1 = ldw1;
   a.ld_aux = ld_aux;
   a.n_rows = n_rows;
+  a.live_rows = live_rows;
   const int per_tile = group_rows > 0 ? tile_rows / group_rows : 1;  // whole groups per tile
-  const int64_t n_tiles = group_rows > 0 ? (n_rows / group_rows + per_tile - 1) / per_tile : (n_rows + tile_rows - 1) / tile_rows;
+  const int rows_per_tile = live_rows > 0 ? live_rows : tile_rows;
+  const int64_t n_tiles = group_rows > 0 ? (n_rows / group_rows + per_tile - 1) / per_tile : (n_rows + rows_per_tile - 1) / rows_per_tile;
   hipStream_t s = (hipStream_t)stream;
   bool ext = !(ldw0 == ldw1 && ld_aux == TBX_AUX_LD);
   for (int i = 0; i < n_stages; ++i) ext = ext || (stages[i].op == TBX_OP_LINEAR && stages[i].dst == TBX_BUF_GLOBAL);
   bool full = false;
   for (int i = 0; i < n_stages; ++i)
     full = full || stages[i].op == TBX_OP_DROPOUT ||
-           (stages[i].op == TBX_OP_LINEAR && (!(stages[i].flags & TBX_F_WPACK) || (stages[i].flags & TBX_F_WSPLIT)));
+           (stages[i].op == TBX_OP_LINEAR && !(stages[i].flags & TBX_F_WGEMV) &&
+            (!(stages[i].flags & TBX_F_WPACK) || (stages[i].flags & TBX_F_WSPLIT)));
 #define TBX_RC_LAUNCH(MT, EXTF, FULLF, NT)                                                                                 \
   do {                                                                                                                     \
     if (lds_bytes > 64 * 1024)                                                                                             \
@@ -990,7 +1266,12 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
     else                                     \
       TBX_RC_LAUNCH(MT, false, false, 512);  \
   } while (0)
-  if (tile_rows == 16)
+  if (live_rows > 0) {
+    if (lds_bytes > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)rowchain_kernel<0, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    hipLaunchKernelGGL((rowchain_kernel<0, true, false, true>), dim3((unsigned)n_tiles), dim3(512), lds_bytes, s, a);
+  } else if (tile_rows == 16)
     TBX_RC_PICK(1);
   else if (tile_rows == 32)
     TBX_RC_PICK(2);
@@ -1000,3 +1281,4 @@ extern "C" int tbx_rowchain_ex(const tbx_stage_t* stages, int n_stages, int64_t 
 #undef TBX_RC_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
+}  // namespace

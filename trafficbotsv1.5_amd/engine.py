@@ -155,10 +155,35 @@ LAYER_LDW0, LAYER_LDW1, LAYER_AUX = 644, 132, 132
 BIG_ROWS = int(os.environ.get("TBX_BIG_ROWS", "16384"))  # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
 
 
+# Launches of a few hundred rows in all (one 64-agent scene: 64 agent rows, 128 light rows) are latency-bound: they run as
+# tbx_rowchain_live programs - tiles of LIVE_ROWS rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA
+# tiles, see csrc/rowchain.hip linear_gemv) - up to LIVE_MAX rows. TBX_LIVE_ROWS=0 turns the mode off.
+LIVE_ROWS = int(os.environ.get("TBX_LIVE_ROWS", "2"))
+LIVE_MAX = int(os.environ.get("TBX_LIVE_MAX", "512"))
+
+
+def live_rows_for(rows: int) -> int:
+    return LIVE_ROWS if (LIVE_ROWS and rows <= LIVE_MAX and DROP_CTX is None) else 0
+
+
+def row_chain(rows: int, ldw: int, ldw1: Optional[int] = None, ld_aux: Optional[int] = None, big: Optional[tuple] = None) -> Chain:
+    """A flat (un-grouped) chain for `rows` rows: live-row tiles for small launches, 16-row MFMA tiles otherwise, `big` = the
+    (tile_rows, ldw0, ldw1, ld_aux) layout of grids past BIG_ROWS if the caller has one."""
+    live = live_rows_for(rows)
+    if live:  # 4-row LDS tiles + 128 KiB of weight slots: narrow side buffers unless the caller asks for more
+        return Chain(16, ldw, ldw if ldw1 is None else ldw1, 132 if ld_aux is None else ld_aux, live_rows=live)
+    if big is not None and rows >= BIG_ROWS:
+        return Chain(*big)
+    return Chain(16, ldw, ldw1, ld_aux)
+
+
 def layer_chain(rows: int) -> Chain:
-    """Small grids: 16-row tiles, everything staged in LDS (2 x 1028-float buffers, 1 workgroup per CU, fewest stages).
-    Large grids: 32-row tiles with asymmetric buffers (116 KB) and wide outputs written straight to global memory."""
-    return Chain(32, LAYER_LDW0, LAYER_LDW1, LAYER_AUX) if rows >= BIG_ROWS else Chain(16, 1028)
+    """Small grids: 16-row tiles, everything staged in LDS (2 x 1028-float buffers, 1 workgroup per CU, fewest stages) - as
+    live-row tiles up to LIVE_MAX rows. Large grids: 32-row tiles with asymmetric buffers (116 KB) and wide outputs written
+    straight to global memory."""
+    if live_rows_for(rows):
+        return Chain(16, 1028, 132, 132, live_rows=live_rows_for(rows))  # BUF1 holds the token row only, AUX one 128-wide temporary
+    return row_chain(rows, 1028, big=(32, LAYER_LDW0, LAYER_LDW1, LAYER_AUX))
 
 
 def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool):
@@ -273,7 +298,7 @@ def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = No
     L = len(norms_and_attns)
     if out is None:
         out = torch.empty(rows, 2 * D * L, dtype=torch.float32, device=x.device)
-    ch = Chain(32, 132, 132, 132) if rows >= BIG_ROWS else Chain(tile_rows, 132, 132, 132)
+    ch = row_chain(rows, 132, 132, 132, big=(32, 132, 132, 132))
     ch.load(x, BUF1, 0, n=D)
     emit_kv_tables(ch, norms_and_attns, out)
     ch.run(rows)

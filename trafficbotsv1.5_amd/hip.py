@@ -22,6 +22,7 @@ F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK
 F_WSPLIT = 512
 F_ROWSKIP = 1024
 F_LOAD2 = 2048
+F_WGEMV = 4096
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -128,6 +129,10 @@ def load():
     lib.tbx_pack_weight_size.restype = C.c_int64
     lib.tbx_pack_weight.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_pack_weight_split.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_pack_weight_gemv_size.argtypes = [i32, i32, i32]
+    lib.tbx_pack_weight_gemv_size.restype = C.c_int64
+    lib.tbx_pack_weight_gemv.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_rowchain_live.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
     lib.tbx_agent_prep.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
@@ -140,7 +145,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 2:
@@ -443,15 +448,16 @@ PACK_SCOPE: Optional[dict] = None
 
 
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
-                  split: bool = False) -> torch.Tensor:
+                  split: bool = False, gemv: bool = False) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
     per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused
     otherwise - chains are rebuilt every eager step - and dropped with the parameter.
-    split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT."""
+    split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT.
+    gemv=True: the tbx_pack_weight_gemv image (column streams) for the F_WGEMV stages of live-row chains."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
     base = w._base if w._base is not None else w
     bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split)
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv)
     if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
         cache, key = PACK_SCOPE, (id(base),) + key
         PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
@@ -465,11 +471,11 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     if bias is not None:
         assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n
     lib = load()
-    size = lib.tbx_pack_weight_size(n, k, groups)
+    size = (lib.tbx_pack_weight_gemv_size if gemv else lib.tbx_pack_weight_size)(n, k, groups)
     if size <= 0:
         _check(int(size), "tbx_pack_weight_size")
     out = torch.empty(size, dtype=torch.float32, device=w.device)
-    fn = lib.tbx_pack_weight_split if split else lib.tbx_pack_weight
+    fn = lib.tbx_pack_weight_gemv if gemv else (lib.tbx_pack_weight_split if split else lib.tbx_pack_weight)
     _check(fn(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
     cache[key] = (stamp, out)
     return out
@@ -518,9 +524,13 @@ class Chain:
     """Builds one tbx_rowchain program. Tensors handed to stages are kept alive by the chain; the encoded program
     holds raw device pointers, so a chain is valid as long as those tensors are not re-allocated."""
 
-    def __init__(self, tile_rows: int = 16, ldw: int = 132, ldw1: Optional[int] = None, ld_aux: Optional[int] = None):
-        """ldw = LDS row width of BUF0 (floats); ldw1 / ld_aux default to ldw / 260 (tbx_rowchain), else tbx_rowchain_ex."""
-        self.tile_rows, self.ldw = tile_rows, ldw
+    def __init__(self, tile_rows: int = 16, ldw: int = 132, ldw1: Optional[int] = None, ld_aux: Optional[int] = None,
+                 live_rows: int = 0):
+        """ldw = LDS row width of BUF0 (floats); ldw1 / ld_aux default to ldw / 260 (tbx_rowchain), else tbx_rowchain_ex.
+        live_rows in (1, 2, 4): a tbx_rowchain_live program - tiles of that many rows, LINEAR stages on the thread-per-column path
+        (same results bit for bit; for launches of a few hundred rows at most)."""
+        self.tile_rows, self.ldw, self.live_rows = tile_rows, ldw, live_rows
+        assert live_rows in (0, 1, 2, 4) and (live_rows == 0 or tile_rows == 16)
         self.ldw1 = ldw if ldw1 is None else ldw1
         self.ld_aux = AUX_LD if ld_aux is None else ld_aux
         self.stages: List[Stage] = []
@@ -587,6 +597,14 @@ class Chain:
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         assert (dst == GLOBAL) == (out is not None)
+        if self.live_rows:
+            flags = (flags & ~F_WT) | F_WGEMV
+            if skip_rows is not None:
+                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0)
+            return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
+                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=packed_weight(w, bias, wt, groups, gemv=True),
+                             p1=skip_rows, p2=out, ld2=0 if out is None else self._rows2d(out).stride(0),
+                             reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
         if self.pack_weights:
             w, flags = packed_weight(w, bias, wt, groups, self.split_bf16), (flags & ~F_WT) | F_WPACK
             if self.split_bf16:
@@ -643,6 +661,11 @@ class Chain:
         if self._arr is None:
             assert len(self.stages) <= MAX_STAGES, f"{len(self.stages)} stages > {MAX_STAGES}"
             self._arr = (Stage * len(self.stages))(*self.stages)
-        rc = load().tbx_rowchain_ex(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, self.ldw1,
-                                    self.ld_aux, stream_ptr())
+        if self.live_rows:
+            assert group_rows == 0, "live-row chains are flat"
+            rc = load().tbx_rowchain_live(self._arr, len(self.stages), n_rows, self.live_rows, self.ldw, self.ldw1, self.ld_aux,
+                                          stream_ptr())
+        else:
+            rc = load().tbx_rowchain_ex(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, self.ldw1,
+                                        self.ld_aux, stream_ptr())
         _check(rc, "tbx_rowchain")

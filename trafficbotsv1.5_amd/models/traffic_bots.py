@@ -109,7 +109,7 @@ class TrafficBots(nn.Module):
         out["prep"], out["ag_feat"] = prep, feat
         rp = self.pose_rpe
         navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)
-        ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
+        ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
         rc = rollout_consts or {}
         self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe,
