@@ -179,3 +179,37 @@ def test_write_scene_pack_streams_a_generator(tb, D, tmp_path):
         D.write_scene_pack(str(b), gen(), sizes)
     with pytest.raises(AssertionError):
         D.write_scene_pack(str(b), gen(), sizes, n=5)
+
+
+@pytest.mark.gpu
+def test_scene_pack_batch_on_the_device_feeds_the_hot_path(tb, D, tmp_path):
+    """`ScenePack.batch(start, size, device)` - one contiguous slice per key through pinned staging - lands on the GPU with the
+    values, dtypes and shapes the default collation of the per-episode items would have, and the HIP hot path accepts it: the
+    pre-processing + the map encoder run on the batch and agree with the same scenes handed over as fp32 synthetic tensors (the
+    pack stores what the reference's loader delivers: float32 -> float16, data_h5_womd.py:41-42, so inputs agree to fp16)."""
+    dev = torch.device("cuda:0")
+    eps = _episodes(tb, 3, n_ag=8, n_mp=64, n_tl=8)
+    sizes = {k: tuple(v.shape) for k, v in eps[0].items()}
+    path = tmp_path / "training.tbxpack"
+    D.write_scene_pack(str(path), eps, sizes)
+    pack = D.ScenePack(str(path))
+    b = pack.batch(1, 2, device=dev)
+    assert b["episode_idx"].tolist() == [1, 2]
+    for k in sizes:
+        v = b[k]
+        assert v.is_cuda and v.shape[0] == 2
+        want = np.stack([np.ascontiguousarray(e[k], dtype=np.float16 if e[k].dtype == np.dtype("<f4") else None) for e in eps[1:3]])
+        assert v.dtype == torch.from_numpy(want).dtype and tuple(v.shape) == want.shape, k
+        assert np.array_equal(v.cpu().numpy(), want), k
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    wm = wm.to(dev).eval()
+    ref = {k: torch.from_numpy(np.stack([e[k] for e in eps[1:3]])).to(dev) for k in eps[0]}
+    outs = []
+    for batch in (b, ref):
+        bb = wm.pre_processing({k: (v.float() if v.dtype == torch.float16 else v) for k, v in batch.items() if k in sizes})
+        outs.append(wm.model.mp_encoder(bb["sc/mp_valid"], bb["sc/mp_attr"], bb["sc/mp_pose"], bb["ref/mp_type"]))
+    assert torch.equal(outs[0]["mp_token_invalid"], outs[1]["mp_token_invalid"])
+    torch.testing.assert_close(outs[0]["mp_token_pose"], outs[1]["mp_token_pose"], rtol=2e-3, atol=0.1)  # fp16 positions: 0.06 m at 150 m
+    assert torch.isfinite(outs[0]["mp_token_feature"]).all()

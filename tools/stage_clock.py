@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 
-OPS = {1: "LOAD", 2: "LINEAR", 3: "LN", 4: "ADD", 5: "COPY", 6: "ROWMASK", 7: "GROUPMAX", 8: "POOLMAX", 9: "STORE", 10: "CLAMP"}
+OPS = {1: "LOAD", 2: "LINEAR", 3: "LN", 4: "ADD", 5: "COPY", 6: "ROWMASK", 7: "GROUPMAX", 8: "POOLMAX", 9: "STORE", 10: "CLAMP", 11: "DROPOUT", 12: "ATTN", 13: "ATTNSEG"}
 
 
 def main():

@@ -18,7 +18,7 @@ lib = hip.load()
 lib.tbx_debug_clock_dump.argtypes = [C.c_void_p, C.c_int]
 from trafficbots_amd.hip import AUX, BUF0, BUF1, Chain  # noqa: E402
 
-OPS = {1: "LOAD", 2: "LINEAR", 3: "LN", 4: "ADD", 5: "COPY", 6: "ROWMASK", 7: "GROUPMAX", 8: "POOLMAX", 9: "STORE", 10: "CLAMP"}
+OPS = {1: "LOAD", 2: "LINEAR", 3: "LN", 4: "ADD", 5: "COPY", 6: "ROWMASK", 7: "GROUPMAX", 8: "POOLMAX", 9: "STORE", 10: "CLAMP", 11: "DROPOUT", 12: "ATTN", 13: "ATTNSEG"}
 dev = torch.device("cuda:0")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = torch.randn(rows, 640, device=dev)

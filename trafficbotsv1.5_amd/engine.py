@@ -158,7 +158,7 @@ BIG_ROWS = int(os.environ.get("TBX_BIG_ROWS", "16384"))  # from here on 32-row t
 # Launches of a few hundred rows in all (one 64-agent scene: 64 agent rows, 128 light rows) are latency-bound: they run as
 # tbx_rowchain_live programs - tiles of LIVE_ROWS rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA
 # tiles, see csrc/rowchain.hip linear_gemv) - up to LIVE_MAX rows. TBX_LIVE_ROWS=0 turns the mode off.
-LIVE_ROWS = int(os.environ.get("TBX_LIVE_ROWS", "2"))
+LIVE_ROWS = int(os.environ.get("TBX_LIVE_ROWS", "1"))
 LIVE_MAX = int(os.environ.get("TBX_LIVE_MAX", "512"))
 
 
