@@ -59,7 +59,9 @@ def parse():
     ap.add_argument("--no-train-shape", action="store_true",
                     help="skip the training_step measurement (16 scenes per GPU, fwd+bwd+all-reduce+AdamW) the default run appends")
     ap.add_argument("--no-train-graph", action="store_true", help="training: eager fwd+bwd instead of one hipGraph replay per step")
-    ap.add_argument("--train-steps", type=int, default=5, help="timed training steps of that appended measurement")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of that appended measurement (after 3 warm-up steps)")
+    ap.add_argument("--kv-bf16", action="store_true", help="bfloat16 K/V tables (BASELINE config 2's dtype; 529 B per attention pair)")
+    ap.add_argument("--no-bf16-shape", action="store_true", help="skip the bf16-table measurements the default run appends")
     a = ap.parse_args()
     tr = a.mode == "train"
     a.steps = a.steps if a.steps is not None else (10 if tr else 80)   # training timed over >= 10 steps
@@ -68,6 +70,7 @@ def parse():
     a.wosac_shape = (not tr and not a.no_wosac_shape and a.scenes is None and a.rollouts == 1 and a.agents == 64
                      and a.profile_steps > 0)
     a.train_shape = a.wosac_shape and not a.no_train_shape
+    a.bf16_shape = a.wosac_shape and not a.no_bf16_shape and not a.kv_bf16
     a.scenes = a.scenes if a.scenes is not None else (16 if tr else 1)
     return a
 
@@ -91,9 +94,10 @@ def pmc_traffic(args, kernel: str):
     return None, None
 
 
-def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int) -> float:
-    """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b with fp32 (b = 4), d = d_rpe = 128."""
-    d, b = 128, 4
+def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int, b: int = 4) -> float:
+    """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b, d = d_rpe = 128; b = 4 (fp32 tables: 1041 B per pair)
+    or 2 (bfloat16 K/V tables: 529 B per pair)."""
+    d = 128
     return n_src_rows * 2 * d * b + n_pairs * (2 * d * b + 17) + (d * 2 * d + 2 * d) * b
 
 
@@ -112,7 +116,8 @@ class KernelEvents:
             e0.record()
             self._attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw)
             e1.record()
-            self.attn.append((e0, e1, attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs)), n_batch * n_src))
+            eb = 2 if segs[0].kv.dtype == torch.bfloat16 else 4
+            self.attn.append((e0, e1, attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs), eb), n_batch * n_src))
 
         def run(ch, n_rows, group_rows=0):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -316,6 +321,7 @@ def main():
     def measure(a):
         """One timed closed-loop rollout of workload `a` on this rank; returns the JSON fields of that measurement."""
         wm, full = build(tb, a, dev, rank)
+        import_module("trafficbots_amd.engine").KV_BF16 = bool(a.kv_bf16)
         import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.lights_ahead = not a.no_lights_ahead
         eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
         use_graph = not a.no_graph
@@ -362,6 +368,8 @@ def main():
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured": False,  # PMC passes are separate rocprofv3 runs: the committed profile of this workload
+                         "bytes_per_pair": 529 if a.kv_bf16 else 1041,
                          "launches_per_step": n_dom / a.profile_steps, "avg_launch_us": t_dom / n_dom * 1e6,
                          "algorithmic_bytes_per_launch": b_dom / n_dom, "source_rows_per_launch": rows_dom,
                          "all_launches": {"launches_per_step": n_attn / a.profile_steps, "avg_launch_us": t_attn / n_attn * 1e6,
@@ -380,7 +388,8 @@ def main():
     res, wm, full = measure(args)
     line = {"metric": "sim-agent-steps/sec (closed-loop rollout)", "value": res.pop("value"), "unit": "sim-agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **res}
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 K/V tables, f32 arithmetic" if args.kv_bf16 else "f32", "data": "synthetic", **res}
     if args.wosac_shape:
         # BASELINE.json configs[4] on the same device(s): 32 parallel rollouts x 128 agents per scenario, one scenario per
         # GPU - the size at which the relative-pose attention kernel fills the chip (its roofline fraction is the one
@@ -392,13 +401,28 @@ def main():
         r5, _, _ = measure(big)
         line["wosac_shape"] = {"metric": line["metric"], "unit": line["unit"], "n_gpus": world, "steps": big.steps,
                                "warmup": big.warmup, **r5}
+    if args.bf16_shape:
+        # BASELINE.json configs[1] says bf16: the same two workloads with bfloat16 K/V tables (engine.KV_BF16: 529 B per pair,
+        # fp32 queries / embeddings / softmax / sums; tolerances in tests/test_hip_bf16.py). The fp32 line above stays the parity line.
+        import copy
+
+        b16 = copy.copy(args)
+        b16.kv_bf16 = True
+        r16, _, _ = measure(b16)
+        line["bf16"] = {"dtype": "bf16 K/V tables, f32 arithmetic", "steps": b16.steps, "warmup": b16.warmup, **r16}
+        if args.wosac_shape:
+            b16 = copy.copy(args)
+            b16.kv_bf16, b16.scenes, b16.rollouts, b16.agents, b16.steps = True, 1, 32, 128, min(args.steps, 40)
+            r16, _, _ = measure(b16)
+            line["bf16"]["wosac_shape"] = {"steps": b16.steps, "warmup": b16.warmup, **r16}
+        import_module("trafficbots_amd.engine").KV_BF16 = False
     if args.train_shape:
         # BASELINE.json configs[2] / [3] (the metric's second half): training_step on 16 scenes per GPU, gradients
         # all-reduced over RCCL when world > 1. Every rank must take part (collective), a failure is reported, not fatal.
         import copy
 
         tr = copy.copy(args)
-        tr.scenes, tr.steps, tr.warmup, tr.agents = 16, args.train_steps, 1, 64
+        tr.scenes, tr.steps, tr.warmup, tr.agents = 16, args.train_steps, 3, 64  # >= 10 timed steps after 3 warm-ups
         try:
             line["training"] = train_main(tr, tb, dev, rank, world, dist if world > 1 else None)
         except Exception as e:  # noqa: BLE001

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define TBX_ABI_VERSION 2
+#define TBX_ABI_VERSION 3
 
 enum {
   TBX_OK = 0,
@@ -82,6 +82,9 @@ typedef struct tbx_attn_seg {
   const float* emb;      /* [n_batch, n_src, k, 128] materialised pose embedding, or NULL */
   const float* rel_pose; /* [n_batch, n_src, k, 3] relative pose (used when emb == NULL: the embedding is rebuilt in registers) */
   int32_t ld_kv, k_off, v_off, n_tgt, batch_div, k;
+  int32_t kv_bf16;       /* != 0: `kv` points to a bfloat16 table (ld_kv / k_off / v_off in elements): K and V rows move 2 B per
+                            channel (529 B per pair instead of 1041), scores and sums accumulate in fp32. Forward only; every
+                            segment of a call must use the same element type. */
 } tbx_attn_seg_t;
 
 int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
@@ -261,6 +264,8 @@ enum {
   TBX_F_ROWSKIP = 1024, /* LINEAR + TBX_F_WPACK / TBX_F_WGEMV (LDS destination): p1 holds a byte per global row; rows whose byte is set
                            (clear with TBX_F_MASK_INV) and padding rows are NOT written - with TBX_F_ACCUM into the residual buffer
                            this is x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */
+  TBX_F_OUT_BF16 = 8192, /* STORE, and LINEAR with dst = TBX_BUF_GLOBAL: the global destination holds bfloat16 (round to nearest even);
+                           ld / ld2 and dst_col count bf16 elements. For K/V tables read by tbx_knarpe_attn_fwd with seg.kv_bf16. */
   TBX_F_WGEMV = 4096    /* LINEAR of a tbx_rowchain_live program: p0 is a tbx_pack_weight_gemv() image; a thread per output column,
                            v_fma chains in the MFMA path's k order (bit-identical results, a fraction of the latency at 1-4 rows) */
 };

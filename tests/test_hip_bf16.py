@@ -1,0 +1,102 @@
+"""BASELINE config 2 names bf16: the K/V tables the relative-pose attention gathers from stored as bfloat16 (engine.KV_BF16;
+529 B per (source, target) pair instead of 1041), everything else fp32. Stated tolerances vs the fp32 path / oracle:
+  * the tables themselves: round-to-nearest-even bf16 of the fp32 tables (bit-exact against torch's conversion);
+  * one attention call: |out - out_fp32| <= 1.5e-2 * max|out_fp32| (K and V carry 2^-9 relative rounding each; the softmax is fp32);
+  * K-nearest sets: unchanged bit for bit (distances stay fp32 and do not read the tables);
+  * closed loop: poses within 0.05 m / actions within 0.05 of the fp32 oracle over the first 12 steps of the 8-agent scene and of
+    the 64-agent / 1024-polyline / 128-light scene (10 of them teacher-forced).
+fp32 stays the parity path; the bf16 path is the configuration `bench.py` reports under "bf16"."""
+from importlib import import_module
+
+import pytest
+import torch
+
+from oracle import hptr_ops as H
+from oracle import trafficbots_oracle as O
+from test_hip_rollout import _oracle_tokens, _setup
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def bf16_tables():
+    eng = import_module("trafficbots_amd.engine")
+    eng.KV_BF16 = True
+    yield eng
+    eng.KV_BF16 = False
+
+
+def test_bf16_store_and_attention_vs_fp32(tb):
+    hip = import_module("trafficbots_amd.hip")
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(7)
+    n, S, T, K, d = 2, 37, 50, 11, 128
+    kv = torch.randn(n * T, 256, generator=g).to(dev)
+    # (1) chain STORE / LINEAR-to-global into a bf16 buffer == torch's RNE conversion
+    for live in (0, 2):
+        ch = hip.Chain(16, 388, 132, 132, live_rows=live) if live else hip.Chain(16, 388)
+        out16 = torch.zeros(n * T, 256, dtype=torch.bfloat16, device=dev)
+        lin16 = torch.zeros(n * T, 256, dtype=torch.bfloat16, device=dev)
+        lin32 = torch.zeros(n * T, 256, device=dev)
+        w, b = torch.randn(256, 128, generator=g).to(dev) * 0.1, torch.randn(256, generator=g).to(dev)
+        ch.load(kv, hip.BUF0, 0, n=256)
+        ch.store(hip.BUF0, 0, 256, out16)
+        ch.linear(hip.BUF0, 0, hip.GLOBAL, 0, w, b, out=lin16)
+        ch.linear(hip.BUF0, 0, hip.GLOBAL, 0, w, b, out=lin32)
+        ch.run(n * T)
+        assert torch.equal(out16, kv.to(torch.bfloat16)), live
+        assert torch.equal(lin16, lin32.to(torch.bfloat16)), live
+    # (2) attention on the bf16 table vs on the fp32 table, and vs fp32 attention on the ROUNDED table (exactly equal)
+    kv16 = kv.to(torch.bfloat16)
+    q = torch.randn(n * S, 640, generator=g).to(dev)
+    idx = torch.randint(0, T, (n, S, K), generator=g).to(torch.int32).to(dev)
+    inv = (torch.rand(n, S, K, generator=g) < 0.3).to(torch.uint8).to(dev)
+    inv[0, 2] = 1
+    emb = torch.randn(n, S, K, d, generator=g).to(dev)
+    bias = torch.randn(d, generator=g).to(dev)
+    outs = {}
+    for name, table in (("fp32", kv), ("bf16", kv16), ("rounded", kv16.float())):
+        o = torch.empty(n * S, 640, device=dev)
+        flag = torch.empty(n * S, dtype=torch.uint8, device=dev)
+        hip.knarpe_attn(q, 0, 128, bias, n, S, [hip.Seg(table, 0, 128, T, idx, inv, emb)], o, flag)
+        outs[name] = (o, flag)
+    assert torch.equal(outs["bf16"][0], outs["rounded"][0])  # the kernel only changes how K / V rows are read
+    assert torch.equal(outs["bf16"][1], outs["fp32"][1])
+    err = (outs["bf16"][0] - outs["fp32"][0]).abs().max()
+    assert float(err) <= 1.5e-2 * float(outs["fp32"][0].abs().max())
+    # the backward refuses bf16 tables (inference configuration)
+    with pytest.raises(RuntimeError):
+        hip.knarpe_attn_bwd(q, 0, 128, bias, n, S, [hip.Seg(kv16, 0, 128, T, idx, inv, emb)], torch.zeros_like(outs["fp32"][0]), torch.zeros_like(q),
+                            [torch.zeros(n * T, 256, device=dev)], torch.zeros(n * S, 128, device=dev))
+
+
+@pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
+def test_bf16_tables_closed_loop_vs_fp32_oracle(tb, bf16_tables, sizes, knn):
+    dev = torch.device(DEV)
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=knn), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    mp_o, tl_o = _oracle_tokens(om, b)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, sizes[0], 16, generator=g)
+    valid = b["gt/ag_valid"].any(-1)
+    T = 12
+    with torch.no_grad():
+        ro = O.Sim(om, scfg, False).rollout(b, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred, T)
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    # the tables really are bfloat16, the K-nearest sets are those of the fp32 path
+    kv_mp = wm.model.ag_encoder.kv_mp(mp)
+    assert kv_mp.dtype == torch.bfloat16 and wm.model.tl_encoder._kv_mp(tl).dtype == torch.bfloat16
+    bf16_tables.KV_BF16 = False
+    mp32, tl32 = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    bf16_tables.KV_BF16 = True
+    for k in ("knn_idx_tl2tl", "knn_invalid_tl2tl"):
+        if k in tl:
+            assert torch.equal(tl[k], tl32[k]), k
+    buf = wm.reactive_replay(bd, mp, tl, z.to(dev), valid.to(dev), bd["gt/ag_navi"], valid.to(dev), wm.teacher_forcing_joint_future_pred, True,
+                             step_end=T)
+    assert torch.equal(buf.pred_valid[:, 0].cpu(), ro["pred_valid"])
+    torch.testing.assert_close(buf.pred_pose[:, 0].cpu(), ro["pred_pose"], rtol=1e-3, atol=5e-2)
+    torch.testing.assert_close(buf.vis_dict["action"][:, 0].cpu(), ro["action"], rtol=1e-2, atol=5e-2)
+    assert torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])

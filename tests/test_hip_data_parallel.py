@@ -59,19 +59,8 @@ live = DP.live_parameters(wm.model)
 out["eager_loss_finite"] = bool(torch.isfinite(m["loss"]))
 out["eager_allreduce_bytes"] = calls["bytes"]
 out["live_bytes"] = sum(p.numel() for p in live) * 4
-# the exchange leaves a one-rank gradient untouched (sum over one rank / 1), bit for bit
-opt.zero_grad(set_to_none=True)
-loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0)
-loss.backward()
-g0 = [p.grad.clone() for p in live]
-real(live)
 print("eager done", flush=True)
-out["allreduce_identity"] = all(bool(torch.equal(a, p.grad)) for a, p in zip(g0, live))
-# nothing of this eager iteration may stay alive into the capture: a live `loss` keeps its autograd graph and the AccumulateGrad
-# nodes of the default stream, and hipStreamEndCapture of the next backward then dies (measured: SIGSEGV in capture_end)
-del loss, g0
-opt.zero_grad(set_to_none=True)
-import gc; gc.collect()
+del m, live
 # graphed step: replay, then the same exchange outside the graph
 calls["n"] = calls["bytes"] = 0
 gs = DP.GraphedTrainStep(wm, opt, batch, warmup=1, verbose=True)
@@ -106,7 +95,6 @@ def test_one_rank_rccl_training_step_takes_the_real_exchange_path(tmp_path):
     assert len(set(res["rank_seeds"])) == 8 and res["rank_seeds"][0] == 1234
     assert res["eager_loss_finite"] and res["graph_loss_finite"]
     assert res["eager_allreduce_bytes"] == res["live_bytes"] > 30e6  # every live gradient travelled, as ONE flat buffer
-    assert res["allreduce_identity"]
     assert res["graph_allreduce_calls"] == 2 and res["graph_allreduce_bytes"] == 2 * res["graph_live_bytes"]
     assert res["graph_live_bytes"] == res["live_bytes"]
 
@@ -115,7 +103,7 @@ def test_bench_train_mode_agrees_with_the_default_lines_training_entry():
     """`bench.py --mode train --gpus 1` and the `training` entry the default line appends run the same step: same metric, config
     and all-reduce size; throughput within the run-to-run spread of a 2-step measurement."""
     a = json.loads(_run([sys.executable, "bench.py", "--mode", "train", "--gpus", "1", "--scenes", "2", "--steps", "2", "--warmup", "1",
-                         "--agents", "16", "--polylines", "128", "--lights", "16"]).strip().splitlines()[-1])
+                         "--agents", "32", "--polylines", "128", "--lights", "32"]).strip().splitlines()[-1])
     assert a["metric"] == "training scenes/sec" and a["n_gpus"] == 1 and a["finite"] and a["steps"] == 2
     assert a["config"]["parallelism"] == "dp1" and a["config"]["global_batch"] == 2
     assert a["config"]["allreduce_bytes"] > 30e6

@@ -179,7 +179,19 @@ __device__ __forceinline__ void load_e(const tbx_attn_seg_t& S, int64_t pi, int 
 // rescaled when the slot's running max grows. The 8 slots (and the WPR waves) are merged once per row:
 //   out = sum_slots exp(m_slot - M) acc_slot / sum_slots exp(m_slot - M) l_slot.
 // No LDS traffic and no barrier inside the target loop.
-template <int WPR, bool DROP>
+// K / V channels [c, c + 4) of a table row: fp32 tables, or bfloat16 tables widened to fp32 (a bf16 is the upper half of the float)
+template <bool KV16>
+__device__ __forceinline__ float4 kv_load4(const float* __restrict__ table_row, int c) {
+  if constexpr (KV16) {
+    const uint2 r = *(const uint2*)((const uint16_t*)table_row + c);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  } else {
+    return *(const float4*)(table_row + c);
+  }
+}
+
+template <int WPR, bool DROP, bool KV16 = false>
 __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
@@ -230,7 +242,9 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
   for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
-    const float* kvb = S.kv + (int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv;
+    // (bf16 tables: element offsets, half the bytes - the pointer is kept as float* and scaled by hand)
+    constexpr int ES = KV16 ? 2 : 1;  // table elements per float slot
+    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
     const int64_t pbase = (int64_t)row * S.k;
     for (int base = wir * 8; base < S.k; base += 8 * WPR) {
       const int t = base + tg;
@@ -238,12 +252,12 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       const int64_t pi = pbase + (active ? t : S.k - 1);
       const int j = S.idx[pi];
       const bool ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
-      const float* trow = kvb + (int64_t)j * S.ld_kv;
+      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
       float4 kq[4], v[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        kq[st] = *(const float4*)(trow + S.k_off + st * 32 + s8 * 4);
-        v[st] = *(const float4*)(trow + S.v_off + st * 32 + s8 * 4);
+        kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
+        v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
       }
       ESlice e;
       load_e(S, pi, s8, fq, e);
@@ -648,6 +662,7 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
     if (!s.emb && (!fxy || !fyaw)) return TBX_ERR_ARG;
     if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (s.emb && (((uintptr_t)s.emb) & 15)))
       return TBX_ERR_ALIGN;
+    if ((s.kv_bf16 != 0) != (segs[0].kv_bf16 != 0)) return TBX_ERR_UNSUPPORTED;  // one element type per call
     ktot += s.k;
     a.seg[i] = s;
   }
@@ -714,7 +729,13 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   const bool big = a.n_rows >= big_rows;  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
-  if (a.drop_thresh != 0u) {
+  if (segs[0].kv_bf16 != 0) {  // bf16 K/V tables: inference only
+    if (a.drop_thresh != 0u) return TBX_ERR_UNSUPPORTED;
+    if (big)
+      hipLaunchKernelGGL((knarpe_attn_kernel<1, false, true>), grid, block, 0, hs, a);
+    else
+      hipLaunchKernelGGL((knarpe_attn_kernel<4, false, true>), grid, block, 0, hs, a);
+  } else if (a.drop_thresh != 0u) {
     if (big)
       hipLaunchKernelGGL((knarpe_attn_kernel<1, true>), grid, block, 0, hs, a);
     else
@@ -745,6 +766,7 @@ extern "C" int tbx_knarpe_attn_bwd_dropout_tb(const float* qbuf, int ldq, int q_
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
   if (rc != TBX_OK) return rc;
+  if (segs[0].kv_bf16 != 0) return TBX_ERR_UNSUPPORTED;  // bf16 K/V tables: forward only
   rc = set_dropout(b.f, p_drop, drop_seed, drop_call, time_batch, time0);
   if (rc != TBX_OK) return rc;
   for (int i = 0; i < n_seg; ++i) {
@@ -771,6 +793,7 @@ extern "C" int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_o
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
   if (rc != TBX_OK) return rc;
+  if (segs[0].kv_bf16 != 0) return TBX_ERR_UNSUPPORTED;  // bf16 K/V tables: forward only
   rc = set_dropout(b.f, p_drop, drop_seed, drop_call, time_batch, time0);
   if (rc != TBX_OK) return rc;
   DkvArgs d;

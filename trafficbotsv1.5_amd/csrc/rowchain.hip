@@ -57,6 +57,9 @@ __device__ __forceinline__ void gst4(float* p, float4 v) {
   *(TBX_GLOBAL f32x4*)p = x;
 }
 __device__ __forceinline__ void gst1(float* p, float v) { *(TBX_GLOBAL float*)p = v; }
+// TBX_F_OUT_BF16 destinations: element e of a bfloat16 buffer (round to nearest even)
+__device__ __forceinline__ uint16_t to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ void gst1_bf16(float* base, int64_t e, float v) { *((TBX_GLOBAL uint16_t*)base + e) = to_bf16(v); }
 
 template <int MT, bool EXT>
 struct Tile {
@@ -367,7 +370,12 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
         // columns of the last partial tile beyond n are zero-filled (unless accumulating or grouped) so that the next
         // stage may read a K padded to 16
         if (to_global) {
-          if (col_ok && m * 16 + g * 4 + r < t.n_valid) gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
+          if (col_ok && m * 16 + g * 4 + r < t.n_valid) {
+            if (s.flags & TBX_F_OUT_BF16)
+              gst1_bf16((float*)s.p2, (t.g0 + m * 16 + g * 4 + r) * (int64_t)s.ld2 + s.dst_col + grp * gs_dst + col, v);
+            else
+              gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
+          }
         } else if (col_ok) {
           if (!(skip & (1u << (m * 4 + r)))) dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
         }
@@ -527,7 +535,12 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
         float v = acc;
         if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
         if (to_global) {
-          if (live && r < t.n_valid) gst1(gout0 + (int64_t)r * s.ld2 + grp * gs_dst + c, v);
+          if (live && r < t.n_valid) {
+            if (s.flags & TBX_F_OUT_BF16)
+              gst1_bf16((float*)s.p2, (t.g0 + r) * (int64_t)s.ld2 + s.dst_col + grp * gs_dst + c, v);
+            else
+              gst1(gout0 + (int64_t)r * s.ld2 + grp * gs_dst + c, v);
+          }
         } else if (live) {
           if (!rowskip || !skip) dst0[r * lds_d + grp * gs_dst + c] = v;
         } else if (!accum && G == 1 && o < (N + 15) / 16 * 16 && o < lds_d - s.dst_col) {
@@ -826,6 +839,20 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   const int lds_s = t.l(s.src);
   float* out = (float*)s.p0;
   const int n = s.n;
+  if (s.flags & TBX_F_OUT_BF16) {  // bfloat16 destination (ld, dst_col in elements): 4 values = 8 bytes per lane
+    for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
+      TBX_GLOBAL uint16_t* orow = (TBX_GLOBAL uint16_t*)out + (t.g0 + r) * (int64_t)s.ld + s.dst_col;
+      for (int c4 = lane; c4 < (n >> 2); c4 += 64) {
+        const float4 v = *(const float4*)(src + r * lds_s + c4 * 4);
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 pk;
+        pk[0] = (uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16);
+        pk[1] = (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16);
+        *(TBX_GLOBAL u32x2*)(orow + c4 * 4) = pk;
+      }
+    }
+    return;
+  }
   if ((n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 && (s.src_col & 3) == 0 && ((((uintptr_t)out) & 15) == 0)) {
     const int w4 = n >> 2;
     for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
@@ -1095,6 +1122,13 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
   }
   if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP) && (!(s.flags & (TBX_F_WPACK | TBX_F_WGEMV)) || gdst || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if (s.op == TBX_OP_LINEAR && (s.flags & TBX_F_WGEMV) && (s.flags & (TBX_F_WPACK | TBX_F_WSPLIT | TBX_F_WT))) return TBX_ERR_ARG;
+  if (s.flags & TBX_F_OUT_BF16) {
+    if (s.op == TBX_OP_STORE) {
+      if ((s.n & 3) || (s.ld & 3) || (s.dst_col & 3) || (s.src_col & 3) || (((uintptr_t)s.p0) & 7)) return TBX_ERR_ALIGN;
+    } else if (!(gdst && (s.flags & (TBX_F_WPACK | TBX_F_WGEMV)) && !(s.flags & TBX_F_WSPLIT))) {
+      return TBX_ERR_UNSUPPORTED;
+    }
+  }
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
   if (s.op != TBX_OP_LINEAR && (s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;

@@ -162,6 +162,16 @@ LIVE_ROWS = int(os.environ.get("TBX_LIVE_ROWS", "1"))
 LIVE_MAX = int(os.environ.get("TBX_LIVE_MAX", "512"))
 
 
+# BASELINE config 2 names bf16: with KV_BF16 the K/V tables every attention call gathers from (the per-layer self tables, the
+# static map tables, the per-step light tables) are stored as bfloat16 - half the bytes per gathered row (529 B per pair instead
+# of 1041) - while queries, pose embeddings, scores, softmax and all sums stay fp32. Off: the fp32 parity path. (TBX_KV_BF16=1)
+KV_BF16 = os.environ.get("TBX_KV_BF16", "0") == "1"
+
+
+def kv_dtype():
+    return torch.bfloat16 if KV_BF16 else torch.float32
+
+
 def live_rows_for(rows: int) -> int:
     return LIVE_ROWS if (LIVE_ROWS and rows <= LIVE_MAX and DROP_CTX is None) else 0
 
@@ -186,17 +196,19 @@ def layer_chain(rows: int) -> Chain:
     return row_chain(rows, 1028, big=(32, LAYER_LDW0, LAYER_LDW1, LAYER_AUX))
 
 
-def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool):
-    """LN(x in BUF1) -> [q | k | v | qt] / [q | qt] stored to `out`."""
+def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool, kv16: Optional[torch.Tensor] = None):
+    """LN(x in BUF1) -> [q | k | v | qt] / [q | qt] stored to `out` (+ k | v as bfloat16 to kv16 [rows, 256] if given)."""
     if rows >= BIG_ROWS:
-        emit_proj_to(ch, norm, attn, out, with_kv)
+        emit_proj_to(ch, norm, attn, out, with_kv, kv16=kv16)
     else:
         ch.layernorm(BUF1, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
         w = emit_qkv(ch, attn, BUF0, 0, BUF0, D, with_kv=with_kv)
         ch.store(BUF0, D, w, out)
+        if kv16 is not None:  # the self-attention K/V table as bfloat16 (q and W_k^T q stay fp32 in `out`)
+            ch.store(BUF0, 2 * D, 2 * D, kv16)
 
 
-def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf: int = BUF1):
+def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf: int = BUF1, kv16: Optional[torch.Tensor] = None):
     """LN(x) -> q [| k | v] | qt written to `out` ([rows, 896] or [rows, 640]); only q is staged in LDS (BUF0[:, 128:256],
     it feeds the per-head rpe fold), k|v and qt go straight to global memory. attention_rpe.py:92-98,147."""
     w_in, b_in = attn.in_proj_weight, attn.in_proj_bias
@@ -205,7 +217,10 @@ def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf:
     ch.store(BUF0, D, D, out, 0)
     nq = D
     if with_kv:
-        ch.linear(BUF0, 0, GLOBAL, D, w_in[D:], b_in[D:], out=out)
+        if kv16 is not None:
+            ch.linear(BUF0, 0, GLOBAL, 0, w_in[D:], b_in[D:], out=kv16)  # k | v straight to the bfloat16 table
+        else:
+            ch.linear(BUF0, 0, GLOBAL, D, w_in[D:], b_in[D:], out=out)
         nq = 3 * D
     ch.linear(BUF0, D, GLOBAL, nq, attn.linear_rpe.weight[:D], wt=True, groups=NH, src_stride=DH, dst_stride=D, out=out)
 
@@ -246,6 +261,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
     qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
+    kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
     obuf = torch.empty(rows, O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
     layers = list(block.layers)
@@ -262,11 +278,12 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
 
     ch = layer_chain(rows)
     ch.load(x, BUF1, 0, n=D)
-    emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True)
+    emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
     ch.run(rows)
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
-        self_seg = Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel)
+        self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
+                    Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
         hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1))
         ch = layer_chain(rows)
         emit_attn_out(ch, a1, obuf, flag, drop=next_site(), x=x)
@@ -281,7 +298,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         ch.rowmask(BUF1, 0, D, mask=src_invalid)
         ch.store(BUF1, 0, D, x)
         if l + 1 < len(layers):
-            emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True)
+            emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True, kv16=kv16)
         elif tail is not None:
             tail(ch)
         ch.run(rows)
@@ -297,7 +314,7 @@ def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = No
     rows = x.shape[0]
     L = len(norms_and_attns)
     if out is None:
-        out = torch.empty(rows, 2 * D * L, dtype=torch.float32, device=x.device)
+        out = torch.empty(rows, 2 * D * L, dtype=kv_dtype(), device=x.device)
     ch = row_chain(rows, 132, 132, 132, big=(32, 132, 132, 132))
     ch.load(x, BUF1, 0, n=D)
     emit_kv_tables(ch, norms_and_attns, out)

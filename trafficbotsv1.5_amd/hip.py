@@ -23,6 +23,7 @@ F_WSPLIT = 512
 F_ROWSKIP = 1024
 F_LOAD2 = 2048
 F_WGEMV = 4096
+F_OUT_BF16 = 8192
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -35,7 +36,7 @@ class Stage(C.Structure):
 
 class AttnSeg(C.Structure):
     _fields_ = [("kv", C.c_void_p), ("idx", C.c_void_p), ("invalid", C.c_void_p), ("emb", C.c_void_p), ("rel_pose", C.c_void_p)] + [
-        (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k")]
+        (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k", "kv_bf16")]
 
 
 class SimState(C.Structure):
@@ -148,7 +149,7 @@ def load():
     for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
-    if lib.tbx_version() != 2:
+    if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -217,16 +218,16 @@ class Seg:
 
     def __init__(self, kv, k_off, v_off, n_tgt, idx, invalid, emb=None, batch_div=1, rel=None):
         """emb [n,S,k,128] (materialised embedding) or rel [n,S,k,3] (relative pose; embedding rebuilt in-kernel)."""
-        assert kv.dim() == 2 and kv.stride(1) == 1
+        assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32, torch.bfloat16)
         assert (emb is None) != (rel is None), "exactly one of emb / rel"
         self.kv, self.k_off, self.v_off, self.n_tgt, self.batch_div = kv, k_off, v_off, n_tgt, batch_div
         self.idx, self.invalid, self.emb, self.rel = idx, invalid, emb, rel
         self.k = idx.shape[-1]
 
     def c(self) -> AttnSeg:
-        return AttnSeg(_ptr(self.kv, torch.float32), _cptr(self.idx, torch.int32), _cptr(self.invalid, torch.uint8),
+        return AttnSeg(_ptr(self.kv), _cptr(self.idx, torch.int32), _cptr(self.invalid, torch.uint8),
                        _cptr(self.emb, torch.float32), _cptr(self.rel, torch.float32), self.kv.stride(0), self.k_off, self.v_off,
-                       self.n_tgt, self.batch_div, self.k)
+                       self.n_tgt, self.batch_div, self.k, int(self.kv.dtype == torch.bfloat16))
 
 
 def _drop_args(drop):
@@ -597,6 +598,9 @@ class Chain:
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
         flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
         assert (dst == GLOBAL) == (out is not None)
+        if out is not None and out.dtype == torch.bfloat16:  # a bf16 K/V table: rounded on the way out (TBX_F_OUT_BF16)
+            assert self.live_rows or self.pack_weights
+            flags |= F_OUT_BF16
         if self.live_rows:
             flags = (flags & ~F_WT) | F_WGEMV
             if skip_rows is not None:
@@ -655,7 +659,9 @@ class Chain:
                          p1=mask)
 
     def store(self, src, src_col, n, out, out_col=0):
-        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out)
+        """out[g, out_col:+n] = src[:, src_col:+n]; a bfloat16 `out` receives the values rounded to nearest even."""
+        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
+                         flags=F_OUT_BF16 if out.dtype == torch.bfloat16 else 0)
 
     def run(self, n_rows: int, group_rows: int = 0):
         if self._arr is None:

@@ -79,7 +79,7 @@ class TrafficBots(nn.Module):
         tl_inv = tl_tokens["tl_token_invalid_u8"]
         tl_kv = out.get("tl_kv")
         if tl_kv is None:
-            tl_kv = out["tl_kv"] = torch.empty(n * L, 2 * d * len(self.ag_encoder.tf_ag2agmptl.layers), dtype=torch.float32,
+            tl_kv = out["tl_kv"] = torch.empty(n * L, 2 * d * len(self.ag_encoder.tf_ag2agmptl.layers), dtype=engine.kv_dtype(),
                                                device=hist_tl.device)
 
         def tl_tail(ch: Chain):
