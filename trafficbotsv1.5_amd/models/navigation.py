@@ -118,17 +118,53 @@ class NaviPredictor(nn.Module):
         cur = self.input_encoder.emit(ch, prep["attr"], prep["pe"])
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], feat, x_buf=cur)
         ch.run(n * A * W, group_rows=W)
-        # pair rows (a, m): [agent feature | map feature | pose embedding of the map token in the agent frame]
+        # pair rows (a, m). The first Linear of the pair MLP acts on [agent feature | map feature | pose embedding of the map token
+        # in the agent frame] (navigation.py:245-262): its weight splits into W_a | W_m | W_e, so the per-agent term W_a f_a
+        # ([n*A, 128]) and the per-polyline term W_m f_m + b ([n*M, 128]) are computed once per token and only the per-pair
+        # embedding term remains a per-pair product - a third of the first layer's multiplies, no 384-wide pair rows.
         mp_inv_u8 = mp_token_invalid.to(u8).contiguous()
         mp_pose = mp_token_pose.float().contiguous()
+        lins = self.mlp.linear_layers()
+        (lin1, ln1, act1), rest = lins[0], lins[1:]
+        w1 = lin1.weight
+        from ..engine import row_chain
+
+        pa = torch.empty(n * A, d, dtype=f32, device=dev)
+        ch = row_chain(n * A, d + 4, d + 4, d + 4)
+        ch.load(feat, BUF0, 0, n=d)
+        ch.linear(BUF0, 0, BUF1, 0, w1[:, :d])
+        ch.store(BUF1, 0, d, pa)
+        ch.run(n * A)
+        mpf = mp_token_feature.reshape(-1, d).contiguous().float()
+        pm = torch.empty(mpf.shape[0], d, dtype=f32, device=dev)
+        ch = row_chain(mpf.shape[0], d + 4, d + 4, d + 4)
+        ch.load(mpf, BUF0, 0, n=d)
+        ch.linear(BUF0, 0, BUF1, 0, w1[:, d:2 * d], lin1.bias)
+        ch.store(BUF1, 0, d, pm)
+        ch.run(mpf.shape[0])
         logits = torch.empty(n * A * M, 1, dtype=f32, device=dev)
         rel = _all_rel_pose(prep["tok_pose"], mp_pose)  # [n*A*M, 3]
         emb = hip.pose_embed(rel, self.pose_rpe.pe_xy.freqs, self.pose_rpe.pe_yaw.freqs, self.pose_rpe.out_dim)
-        ch = Chain(16, 3 * d + 4 + 128)
-        ch.load(feat, BUF0, 0, n=d, row_div=M)
-        ch.load(mp_token_feature.reshape(-1, d).contiguous().float(), BUF0, d, n=d, batch_mod=(A * M, M))
-        ch.load(emb, BUF0, 2 * d, n=d)
-        cur = emit_mlp(ch, self.mlp, BUF0, 0, bufs=(BUF1, BUF0), out_col=0)
+        ch = Chain(16, 2 * d + 4)
+        ch.load(pa, BUF1, 0, n=d, row_div=M)
+        ch.load(pm, BUF1, 0, n=d, accum=True, batch_mod=(A * M, M))
+        ch.load(emb, BUF0, 0, n=d)
+        ch.linear(BUF0, 0, BUF1, 0, w1[:, 2 * d:], accum=True)
+        cur, other = BUF1, BUF0
+        if ln1 is not None:
+            ch.layernorm(cur, 0, cur, 0, ln1.weight, ln1.bias, ln1.eps)
+        if act1:
+            ch.clamp(cur, 0, d, 0.0, float("inf"))
+        for lin, lnm, act in rest:
+            no = lin.weight.shape[0]
+            if lnm is None:
+                ch.linear(cur, 0, other, 0, lin.weight, lin.bias, relu=act)
+            else:
+                ch.linear(cur, 0, other, 0, lin.weight, lin.bias)
+                ch.layernorm(other, 0, other, 0, lnm.weight, lnm.bias, lnm.eps)
+                if act:
+                    ch.clamp(other, 0, no, 0.0, float("inf"))
+            cur, other = other, cur
         ch.store(cur, 0, 1, logits)
         ch.run(n * A * M)
         logits = logits.view(n, A, M)

@@ -519,6 +519,37 @@ def latent_posterior(le, b, mp, tl_tokens, training: bool) -> DiagGaussian:
     return DiagGaussian(mean, le.latent_dist_post.log_std, valid=valid)
 
 
+class NaviPairFirstLayer(torch.autograd.Function):
+    """First Linear of NaviPredictor's pair MLP (navigation.py:245-262) without the [n, A, M, 384] concatenation:
+        W [128, 384] = [W_a | W_m | W_e]:  h[n, a, m] = W_a f_a[n, a] + (W_m f_m[n, m] + b) + W_e e(rel[n, a, m])
+    The per-agent and per-polyline terms are [n, A, 128] / [n, M, 128] GEMMs handed in; this function adds the per-pair term, with
+    the 128-d pose embedding e rebuilt from the 12-byte relative pose scene by scene (tbx_pose_embed) in forward AND backward -
+    neither the concatenation (1,536 B per pair) nor the embedding (512 B per pair) is kept for autograd: 12 B per pair are."""
+
+    @staticmethod
+    def forward(ctx, rel, w_e, pa, pm, fxy, fyw):
+        n, A, M, _ = rel.shape
+        d = w_e.shape[0]
+        h = torch.empty(n, A, M, d, dtype=torch.float32, device=rel.device)
+        for i in range(n):
+            emb = hip.pose_embed(rel[i].reshape(-1, 3), fxy, fyw, w_e.shape[1])
+            torch.addmm(pm[i].repeat(A, 1), emb, w_e.t(), out=h[i].view(A * M, d))
+            h[i] += pa[i].unsqueeze(1)
+        ctx.save_for_backward(rel, w_e, fxy, fyw)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        rel, w_e, fxy, fyw = ctx.saved_tensors
+        n, A, M, _ = rel.shape
+        dh = dh.contiguous()
+        dw = torch.zeros_like(w_e)
+        for i in range(n):
+            emb = hip.pose_embed(rel[i].reshape(-1, 3), fxy, fyw, w_e.shape[1])
+            dw.addmm_(dh[i].view(A * M, -1).t(), emb)
+        return None, dw, dh.sum(2), dh.sum(1), None, None
+
+
 def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
     """navigation.py:175-278 (dest)."""
     ag_valid, ag_pose, ag_motion = b["sc/ag_valid"], b["sc/ag_pose"].detach(), b["sc/ag_motion"].detach()
@@ -542,10 +573,26 @@ def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
     tp, mpp = prep["tok_pose"], mp["mp_token_pose"]
     c, s = torch.cos(tp[..., 2])[:, :, None], torch.sin(tp[..., 2])[:, :, None]
     dx, dy = mpp[:, None, :, 0] - tp[:, :, None, 0], mpp[:, None, :, 1] - tp[:, :, None, 1]
-    rel = torch.stack([dx * c + dy * s, dx * (-s) + dy * c, mpp[:, None, :, 2] - tp[:, :, None, 2]], -1).reshape(-1, 3).contiguous()
-    emb = hip.pose_embed(rel, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs, npd.pose_rpe.out_dim).view(n, A, M, -1)
-    zc = torch.cat([feat.view(n, A, 1, d).expand(-1, -1, M, -1), mpf[:, None].expand(-1, A, -1, -1), emb], -1)
-    logits = mlp(npd.mlp, zc, training).squeeze(-1)
+    rel = torch.stack([dx * c + dy * s, dx * (-s) + dy * c, mpp[:, None, :, 2] - tp[:, :, None, 2]], -1).contiguous()  # [n, A, M, 3]
+    # first Linear split into per-agent + per-polyline + per-pair terms: no [n, A, M, 384] tensor
+    (lin1, ln1, act1), rest = npd.mlp.linear_layers()[0], npd.mlp.linear_layers()[1:]
+    w1 = lin1.weight
+    pa = linear(feat.view(n, A, d), w1[:, :d], None)
+    pm = linear(mpf, w1[:, d:2 * d], lin1.bias)
+    x = NaviPairFirstLayer.apply(rel, w1[:, 2 * d:], pa, pm, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs)
+    if ln1 is not None:
+        x = F.layer_norm(x, ln1.weight.shape, ln1.weight, ln1.bias, ln1.eps)
+    if act1:
+        x = F.relu(x)
+    x = _drop(x, npd.mlp.dropout_p, training)
+    for lin, lnm, act in rest:
+        x = linear(x, lin.weight, lin.bias)
+        if lnm is not None:
+            x = F.layer_norm(x, lnm.weight.shape, lnm.weight, lnm.bias, lnm.eps)
+        if act:
+            x = F.relu(x)
+        x = _drop(x, npd.mlp.dropout_p, training)
+    logits = x.squeeze(-1)
     ty, ag_type = mp["mp_token_type"], b["ref/ag_type"]
     tok_valid = ag_valid.any(-1)
     mp_mask = mp["mp_token_invalid"] | ~(ty[:, :, :5].any(-1))
