@@ -92,6 +92,17 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
                         uint8_t* row_no_valid, const float* freqs_xy /* [32] or NULL */, const float* freqs_yaw /* [64] or NULL */,
                         void* stream);
 
+/* The forward for launches of a few hundred rows (the closed loop at one or a few scenes: 4 wavefronts share a row), with the
+ * value half of `linear_rpe` applied in the epilogue (attention_rpe.py:147,181-182: sum a (v + W_v e + b_v), softmax sums to 1):
+ *   out [n_batch*n_src, ldo >= 128] = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_rpe_v,h   (zero rows where row_no_valid)
+ * fold_image = tbx_pack_weight_gemv(linear_rpe.weight[128:256], linear_rpe.bias[128:256], n = 32, k = 128, groups = 4): 66 KiB,
+ * fetched into LDS by LDS-DMA while the targets are swept. 128 floats per row leave the kernel instead of 640, and the grouped
+ * LINEAR stage that applied the fold in the following chain disappears; the result is bit-identical to that stage's
+ * (same fma order). Inference only (no dropout). */
+int tbx_knarpe_attn_fwd_folded(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
+                               const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                               const float* freqs_xy, const float* freqs_yaw, const float* fold_image, void* stream);
+
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)

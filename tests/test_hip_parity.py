@@ -432,3 +432,41 @@ def test_live_row_chain_is_bit_identical_to_mfma_tiles(tb, live, rows):
     for a, b, name in zip(outs[0], outs[live], ("qkv|qt", "x", "kv (global)", "small")):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16):
+    """tbx_knarpe_attn_fwd_folded (the value half of linear_rpe applied in the attention kernel's epilogue, 128 floats per row
+    out) vs tbx_knarpe_attn_fwd's 640-wide row followed by the grouped LINEAR stage that applied the fold so far: bit-identical
+    (same fma order), rows without a valid target flagged the same - for a one-segment and a two-segment call."""
+    hip = import_module("trafficbots_amd.hip")
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    n, S, T, K, d = 2, 33, 60, 13, 128
+    att = M.attention_rpe.AttentionRPE(d_model=d, n_head=4, dropout_p=0.0, d_rpe=d)
+    tb.utils.det_fill(att, 15)
+    att = att.to(dev)
+    kv = torch.randn(n * T, 256, generator=g).to(dev)
+    kv2 = torch.randn(n * 40, 256, generator=g).to(dev)
+    if bf16:
+        kv, kv2 = kv.to(torch.bfloat16), kv2.to(torch.bfloat16)
+    q = torch.randn(n * S, 640, generator=g).to(dev)
+    mk = lambda T_, K_: (torch.randint(0, T_, (n, S, K_), generator=g).to(torch.int32).to(dev),
+                         (torch.rand(n, S, K_, generator=g) < 0.3).to(torch.uint8).to(dev), torch.randn(n, S, K_, d, generator=g).to(dev))
+    (i1, m1, e1), (i2, m2, e2) = mk(T, K), mk(40, 7)
+    m1[0, 2], m2[0, 2] = 1, 1  # a row without any valid target
+    for segs in ([hip.Seg(kv, 0, 128, T, i1, m1, e1)], [hip.Seg(kv, 0, 128, T, i1, m1, e1), hip.Seg(kv2, 0, 128, 40, i2, m2, e2)]):
+        o640, f640 = torch.empty(n * S, 640, device=dev), torch.empty(n * S, dtype=torch.uint8, device=dev)
+        hip.knarpe_attn(q, 0, 128, att.linear_rpe.bias, n, S, segs, o640, f640)
+        want = torch.empty(n * S, d, device=dev)
+        ch = hip.Chain(16, 644)
+        ch.load(o640, hip.BUF0, 0, n=640)
+        ch.linear(hip.BUF0, d, hip.BUF0, 0, att.linear_rpe.weight[d:], att.linear_rpe.bias[d:], accum=True, groups=4, src_stride=d, dst_stride=32)
+        ch.store(hip.BUF0, 0, d, want)
+        ch.run(n * S)
+        o128, f128 = torch.full((n * S, d), 7.0, device=dev), torch.empty(n * S, dtype=torch.uint8, device=dev)
+        hip.knarpe_attn(q, 0, 128, att.linear_rpe.bias, n, S, segs, o128, f128, fold=eng.attn_fold_image(att))
+        assert torch.equal(f128, f640) and int(f640.sum()) >= 1
+        assert torch.equal(o128, want), float((o128 - want).abs().max())

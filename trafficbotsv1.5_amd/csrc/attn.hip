@@ -45,6 +45,9 @@ struct AttnArgs {
   // b is step drop_time0 + b % T of scene b / T, and the mask is keyed by (scene row, step) - the masks of the batched call
   // are exactly those of T per-step calls with (T = 1, time0 = step). T = 1, time0 = 0: the plain (row) key.
   int drop_time_batch, drop_time0;
+  // tbx_knarpe_attn_fwd_folded: the tbx_pack_weight_gemv image of linear_rpe's value half (4 groups x 32 outputs, k = 128):
+  // the epilogue then forms (sum a v)_h + W_rpe_v,h (sum a e)_h + b_rpe_v,h itself and stores 128 floats per row instead of 640
+  const float* fold_img;
 };
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -191,10 +194,30 @@ __device__ __forceinline__ float4 kv_load4(const float* __restrict__ table_row, 
   }
 }
 
-template <int WPR, bool DROP, bool KV16 = false>
+constexpr int FOLD_ROWS = 1 + (DR / 16) * 4;  // float4 rows of the value-fold image: a bias row + 32 weight rows of [128][4]
+
+template <int WPR, bool DROP, bool KV16 = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
+  __shared__ __attribute__((aligned(16))) float fold_s[FOLD ? FOLD_ROWS * D * 4 : 4];  // 66 KiB: the fold image, by LDS-DMA
+  __shared__ float comb_s[FOLD ? OUTW : 1];
+  static_assert(!FOLD || WPR == 4, "the folded epilogue belongs to the 4-waves-per-row form");
+  if constexpr (FOLD) {
+    // the image is requested first and lands while the targets are swept: 1 KiB per wave instruction, straight into LDS (asm:
+    // the compiler would order every later LDS read behind a DMA it knows of - see csrc/rowchain.hip gemv_dma)
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)fold_s);
+    const int w4 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int p = w4; p < FOLD_ROWS * 2; p += 4) {
+      const float* gsrc = a.fold_img + p * 256 + (threadIdx.x & 63) * 4;
+      const uint32_t dst = lds0 + (uint32_t)p * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(gsrc), "s"(dst)
+                   : "memory");
+    }
+  }
   constexpr int RPB = 4 / WPR;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -342,6 +365,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       red_s[wir][OUTW + lane] = M[lane];
       red_s[wir][OUTW + NH + lane] = L[lane];
     }
+    if constexpr (FOLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the fold image have landed
     __syncthreads();
     float inv_l[NH], fw[WPR][NH];
     bool any_valid = false;
@@ -360,12 +384,45 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       any_valid = any_valid || mm > -INFINITY;
       inv_l[h] = (mm > -INFINITY) ? 1.0f / ll : 0.f;
     }
-    for (int c = threadIdx.x; c < OUTW; c += 256) {
-      const int h = c < D ? c / DH : (c - D) / DR;
-      float acc = 0.f;
+    if constexpr (FOLD) {
+      // the combined row goes to LDS instead of global memory; thread c < 128 then runs the value fold of its output column:
+      // out[c] = b[c] + (sum a v)[c] + sum_k W_rpe_v[c][k] (sum a e)_head(c)[k] as a v_fma chain in the k order of the LINEAR
+      // stage it replaces (per k-block of 16: t = 0..3, g = 0..3, k = kb*16 + g*4 + t, starting from bias + (sum a v)[c]):
+      // bit-identical to [640-wide store -> chain LOAD -> grouped LINEAR stage], without the 2.5 KB round trip per row
+      for (int c = threadIdx.x; c < OUTW; c += 256) {
+        const int h = c < D ? c / DH : (c - D) / DR;
+        float acc = 0.f;
 #pragma unroll
-      for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
-      orow[c] = acc * inv_l[h];
+        for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
+        comb_s[c] = acc * inv_l[h];
+      }
+      __syncthreads();
+      if (threadIdx.x < D) {
+        const int c = threadIdx.x, h = c / DH;
+        const float4* wq = (const float4*)fold_s + c;  // row r of the image: wq[r * 128]
+        const float* e = comb_s + D + h * DR;
+        float acc = fold_s[c * 4] + comb_s[c];
+#pragma unroll 2
+        for (int kb = 0; kb < DR / 16; ++kb) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 w4v = wq[(1 + kb * 4 + t) * D];
+            acc = __builtin_fmaf(e[kb * 16 + t], w4v.x, acc);
+            acc = __builtin_fmaf(e[kb * 16 + 4 + t], w4v.y, acc);
+            acc = __builtin_fmaf(e[kb * 16 + 8 + t], w4v.z, acc);
+            acc = __builtin_fmaf(e[kb * 16 + 12 + t], w4v.w, acc);
+          }
+        }
+        orow[c] = acc;
+      }
+    } else {
+      for (int c = threadIdx.x; c < OUTW; c += 256) {
+        const int h = c < D ? c / DH : (c - D) / DR;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
+        orow[c] = acc * inv_l[h];
+      }
     }
     if (threadIdx.x == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
   }
@@ -683,6 +740,7 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
   a.n_seg = n_seg;
   a.scale = 1.0f / sqrtf((float)DH);
   a.scale2 = 1.4426950408889634f / sqrtf((float)DH);
+  a.fold_img = nullptr;
   return TBX_OK;
 }
 
@@ -746,6 +804,28 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
     else
       hipLaunchKernelGGL((knarpe_attn_kernel<4, false>), grid, block, 0, hs, a);
   }
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_attn_fwd_folded(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch,
+                                          int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                                          const float* freqs_xy, const float* freqs_yaw, const float* fold_image, void* stream) {
+  if (!out || !row_no_valid || !fold_image) return TBX_ERR_ARG;
+  if ((((uintptr_t)out) & 15) || (((uintptr_t)fold_image) & 15) || (ldo & 3) || ldo < D) return TBX_ERR_ALIGN;
+  AttnArgs a;
+  int rc = fill_args(a, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, D + NH * DR, freqs_xy, freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  rc = set_dropout(a, 0.f, nullptr, 0u, 1, 0);
+  if (rc != TBX_OK) return rc;
+  a.ldo = ldo;
+  a.out = out;
+  a.row_no_valid = row_no_valid;
+  a.fold_img = fold_image;
+  const dim3 grid(a.n_rows), block(256);
+  if (segs[0].kv_bf16 != 0)
+    hipLaunchKernelGGL((knarpe_attn_kernel<4, false, true, true>), grid, block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((knarpe_attn_kernel<4, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

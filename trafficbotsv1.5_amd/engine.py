@@ -61,20 +61,31 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     return nq + NH * D
 
 
+# Small launches: the attention kernel applies the value half of linear_rpe in its epilogue (tbx_knarpe_attn_fwd_folded): 128
+# floats per row leave it instead of 640 and the grouped fold stage of the following chain disappears. TBX_ATTN_FOLD=0: off.
+ATTN_FOLD = os.environ.get("TBX_ATTN_FOLD", "1") != "0"
+
+
+def attn_fold_image(attn) -> torch.Tensor:
+    return hip.packed_weight(attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], groups=NH, gemv=True)
+
+
 def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tensor, x_buf: int = BUF1, drop=None, x: Optional[torch.Tensor] = None):
     """x += out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), zero for rows without a valid target.
     attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233. drop = (p, seed, site, step): the residual dropout of training
     (transformer_rpe.py:56-60) as a keyed DROPOUT stage. x: the token rows [rows, 128] are not in x_buf yet - they are loaded in the
     same stage as the attention output (TBX_F_LOAD2: one memory round trip for both)."""
+    folded = obuf.shape[1] == D  # the attention kernel already applied the fold
     if x is not None and LOAD2:
         ch.load2(obuf, BUF0, 0, x, x_buf, 0)
     else:
         if x is not None:
             ch.load(x, x_buf, 0, n=D)
-        ch.load(obuf, BUF0, 0, n=O_LD)
-    # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
-    ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
-              dst_stride=DH)
+        ch.load(obuf, BUF0, 0, n=obuf.shape[1])
+    if not folded:
+        # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
+        ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
+                  dst_stride=DH)
     if drop is None and ch.pack_weights and FUSED_RESIDUAL:
         # one stage: x += rows without a valid target ? 0 : out_proj(...)  (TBX_F_ROWSKIP + accumulate into the token row)
         ch.linear(BUF0, 0, x_buf, 0, attn.out_proj_weight, attn.out_proj_bias, accum=True, skip_rows=row_no_valid)
@@ -262,7 +273,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
     qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
     kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
-    obuf = torch.empty(rows, O_LD, dtype=torch.float32, device=dev)
+    fold = ATTN_FOLD and drop is None and DROP_CTX is None and bool(live_rows_for(rows))
+    obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
     layers = list(block.layers)
     dec = block.mode == "dec_cross_attn"
@@ -284,14 +296,16 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
-        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1))
+        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1),
+                        fold=attn_fold_image(a1) if fold else None)
         ch = layer_chain(rows)
         emit_attn_out(ch, a1, obuf, flag, drop=next_site(), x=x)
         if dec:
             ch.store(BUF1, 0, D, x)
             emit_proj(ch, rows, layer.norm1, layer.attn, q2, with_kv=False)
             ch.run(rows)
-            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
+            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn),
+                            fold=attn_fold_image(layer.attn) if fold else None)
             ch = layer_chain(rows)
             emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site(), x=x)
         emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site())
