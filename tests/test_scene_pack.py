@@ -208,7 +208,8 @@ def test_scene_pack_batch_on_the_device_feeds_the_hot_path(tb, D, tmp_path):
     ref = {k: torch.from_numpy(np.stack([e[k] for e in eps[1:3]])).to(dev) for k in eps[0]}
     outs = []
     for batch in (b, ref):
-        bb = wm.pre_processing({k: (v.float() if v.dtype == torch.float16 else v) for k, v in batch.items() if k in sizes})
+        full = {k: (v.float() if v.dtype == torch.float16 else v) for k, v in batch.items() if k in sizes}
+        bb = wm.pre_processing({**full, **tb.synthetic.to_history_batch(full)})  # eval mode reads the `history/*` view
         outs.append(wm.model.mp_encoder(bb["sc/mp_valid"], bb["sc/mp_attr"], bb["sc/mp_pose"], bb["ref/mp_type"]))
     assert torch.equal(outs[0]["mp_token_invalid"], outs[1]["mp_token_invalid"])
     torch.testing.assert_close(outs[0]["mp_token_pose"], outs[1]["mp_token_pose"], rtol=2e-3, atol=0.1)  # fp16 positions: 0.06 m at 150 m
