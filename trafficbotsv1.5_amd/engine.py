@@ -248,9 +248,10 @@ class SelfKnn:
 
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
-              tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None) -> None:
+              tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None) -> None:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
-    token matrix x [n*S, 128] IN PLACE. `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
+    token matrix x [n*S, 128] IN PLACE (join_stream: a stream the K-nearest sets are being produced on, waited for right before the
+    first attention call). `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
     appends row-local stages to the last layer's chain (x is in BUF1[:, 0:128] at that point).
     drop (the stepping pass of training, train_graph.py): dict(p=residual / FFN dropout, seed=int64[1] device tensor, site=last
     elementwise site id used, call=last attention call id used, step=closed-loop step): the keyed dropouts of training - in
@@ -292,6 +293,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     ch.load(x, BUF1, 0, n=D)
     emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
     ch.run(rows)
+    if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
+        torch.cuda.current_stream().wait_stream(join_stream)
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else

@@ -82,22 +82,13 @@ class AgentEncoder(nn.Module):
         mp_inv = mp.get("mp_token_invalid_u8")
         if mp_inv is None:
             mp_inv = mp["mp_token_invalid_u8"] = mp["mp_token_invalid"].to(torch.uint8).contiguous()
-        # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
-        # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
-        kw = dict(want_rel_pose=True, want_emb=False)
+        # Order of enqueueing = order of the captured graph's nodes = order the runtime launches them in: the window PointNet
+        # (critical path: its pooled rows feed the first projection) goes in BEFORE the three K-nearest searches of the auxiliary
+        # stream, which are only needed by the first attention call (measured on the two-stream timeline: the chain started 20 us
+        # after agent_prep ended because the three searches were launched ahead of it).
         main = torch.cuda.current_stream()
         if aux_stream is not None:
-            aux_stream.wait_stream(main)
-        with torch.cuda.stream(aux_stream if aux_stream is not None else main):
-            i_aa, m_aa, r_aa, _ = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit,
-                                                out=prep.get("_knn_aa"), **kw)
-            i_am, m_am, r_am, _ = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
-                                                self.dist_limit, tgt_batch_div=mp_batch_div, out=prep.get("_knn_am"), **kw)
-            i_at, m_at, r_at, _ = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl,
-                                                self.dist_limit, tgt_batch_div=tl_batch_div, out=prep.get("_knn_at"), **kw)
-        prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
-                    knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
-                    _knn_at=(i_at, m_at, r_at))
+            aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         ch = Chain(hip.group_tile_rows(W, n * A), d + 4)
         ie = self.input_encoder
@@ -113,12 +104,25 @@ class AgentEncoder(nn.Module):
             cur = ie.emit(ch, prep["attr"], prep["pe"])
         emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
         ch.run(n * A * W, group_rows=W)
-        if aux_stream is not None:
-            main.wait_stream(aux_stream)
+        # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
+        # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
+        kw = dict(want_rel_pose=True, want_emb=False)
+        with torch.cuda.stream(aux_stream if aux_stream is not None else main):
+            i_aa, m_aa, r_aa, _ = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit,
+                                                out=prep.get("_knn_aa"), **kw)
+            i_am, m_am, r_am, _ = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
+                                                self.dist_limit, tgt_batch_div=mp_batch_div, out=prep.get("_knn_am"), **kw)
+            i_at, m_at, r_at, _ = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl,
+                                                self.dist_limit, tgt_batch_div=tl_batch_div, out=prep.get("_knn_at"), **kw)
+        prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
+                    knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
+                    _knn_at=(i_at, m_at, r_at))
         kv_mp = self.kv_mp(mp)
+        # (the searches are joined inside run_block, right before the first attention call: the first projection chain needs x only)
         run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
-                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp)
+                                   Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
+                  join_stream=aux_stream)
         return x, prep
 
     @staticmethod
