@@ -105,11 +105,18 @@ class KernelEvents:
     """Brackets every tbx_knarpe_attn / tbx_rowchain launch with HIP events on the launch stream."""
 
     def __init__(self, hip):
-        self.hip, self.attn, self.chain = hip, [], []
+        self.hip, self.attn, self.chain, self.mid = hip, [], [], []
 
     def __enter__(self):
         hip = self.hip
-        self._attn, self._run = hip.knarpe_attn, hip.Chain.run
+        self._attn, self._run, self._mid = hip.knarpe_attn, hip.Chain.run, hip.knarpe_dec_mid
+
+        def mid(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._mid(*args, **kw)
+            e1.record()
+            self.mid.append((e0, e1))
 
         def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -127,11 +134,16 @@ class KernelEvents:
             e1.record()
             self.chain.append((e0, e1, fl))
 
-        hip.knarpe_attn, hip.Chain.run = attn, run
+        hip.knarpe_attn, hip.Chain.run, hip.knarpe_dec_mid = attn, run, mid
         return self
 
     def __exit__(self, *a):
-        self.hip.knarpe_attn, self.hip.Chain.run = self._attn, self._run
+        self.hip.knarpe_attn, self.hip.Chain.run, self.hip.knarpe_dec_mid = self._attn, self._run, self._mid
+
+    def mid_summary(self):
+        torch.cuda.synchronize()
+        tm = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in self.mid]
+        return sum(tm), len(tm)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -181,7 +193,7 @@ def gpu_rollout_setup(tb, wm, full, args, dev):
               tl_state_gt=r(bd["sc/tl_state"]), tf_mask=tf.ag_teacher_forcing, ag_type=r(bd["ref/ag_type"]),
               ag_attr=r(bd["sc/ag_attr"]), ag_latent=z, ag_latent_valid=valid, ag_navi=r(bd["gt/ag_navi"]), ag_navi_valid=valid,
               mp_tokens=mp, tl_tokens=tl, map_valid=bd["map/valid"], map_type=bd["map/type"], map_pos=bd["map/pos"],
-              map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=args.warmup + args.steps + args.profile_steps)
+              map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=args.warmup + args.steps + 2 * args.profile_steps)
     return eng, t_scene
 
 
@@ -343,7 +355,20 @@ def main():
         # halves share the device, which stretches the kernels of both)
         Eng = type(eng)
         Eng.lights_ahead = False
+        E = import_module("trafficbots_amd.engine")
+        dec_mid_on, mid_stats = E.DEC_MID, None
         try:
+            if dec_mid_on:
+                # the small-launch engine runs [self attention -> out_proj -> LN -> q -> cross attention] of a decoder layer as
+                # ONE launch (csrc/dec_mid.hip): time that launch as it runs, then profile the stand-alone attention kernel
+                # (the same sweep code, attn_core.h) on the three-launch schedule, whose results are bit-identical
+                torch.cuda._sleep(int(2.4e9 * (0.01 + 0.006 * a.profile_steps)))
+                with KernelEvents(hip) as ke0:
+                    eng.run(a.profile_steps, use_graph=False)
+                t_mid, n_mid = ke0.mid_summary()
+                if n_mid:
+                    mid_stats = {"kernel": "dec_mid_kernel", "launches_per_step": n_mid / a.profile_steps, "avg_launch_us": t_mid / n_mid * 1e6}
+                E.DEC_MID = False
             # the host must be AHEAD of the device while the events are recorded: an event pair around a launch otherwise also
             # times the wait for the host to enqueue that launch (seen on a loaded box: 27 us "launches" of a 10 us kernel).
             # A device-side delay in front lets the host queue all launches of the profiled steps first.
@@ -352,6 +377,7 @@ def main():
                 eng.run(a.profile_steps, use_graph=False)
         finally:
             Eng.lights_ahead = not a.no_lights_ahead
+            E.DEC_MID = dec_mid_on
         (t_attn, b_attn, n_attn), (t_chain, f_chain, n_chain) = ke.summary()
         rows_dom, t_dom, b_dom, n_dom = ke.dominant
         ach = b_dom / t_dom / 1e9
@@ -377,6 +403,7 @@ def main():
             "roofline_gemm": {"kernel": "rowchain_kernel", "bound": "mfma", "achieved": f_chain / t_chain / 1e12,
                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f_chain / t_chain / 1e12 / FP32_MFMA_PEAK_TF,
                               "launches_per_step": n_chain / a.profile_steps, "avg_launch_us": t_chain / n_chain * 1e6},
+            "fused_decoder_mid": mid_stats,  # None: the three-launch schedule ran in the timed region too
             "scene_encode_ms": t_scene * 1e3,
             # SURVEY §8d "end-to-end": the once-per-scene work (map encoder, traffic-light pre-compute, table packing; this
             # first call also pays one-time allocations) counted into the same units

@@ -103,6 +103,30 @@ int tbx_knarpe_attn_fwd_folded(const float* qbuf, int ldq, int q_off, int qt_off
                                const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
                                const float* freqs_xy, const float* freqs_yaw, const float* fold_image, void* stream);
 
+/* The attention half of a dec_cross_attn layer (transformer_rpe.py:207-233) as ONE launch, for launches of a few hundred rows
+ * (one workgroup per row): folded self attention -> x += no valid target ? 0 : out_proj(.) -> LayerNorm_1 -> q = W_q . + b_q ->
+ * W_rpe_k^T q per head -> folded cross attention. Replaces [tbx_knarpe_attn_fwd_folded, a row chain, tbx_knarpe_attn_fwd_folded];
+ * results are bit-identical to those three launches. All *_image arguments are tbx_pack_weight_gemv images:
+ *   fold_self_image / fold_cross_image: linear_rpe.weight[128:256], bias[128:256] of the two attention modules (n 32, k 128, groups 4)
+ *   out_proj_image: the self attention's out_proj (n 128, k 128);  q_image: the cross attention's in_proj rows [0, 128) (n 128, k 128)
+ *   qfold_image: the cross attention's linear_rpe.weight[0:128] transposed use (n 128, k 32, groups 4, wt = 1), no bias
+ * qkv [rows, ld_qkv]: q at q_off, W_k^T q at qt_off of the self attention; x [rows, 128] updated in place;
+ * out2 [rows, ld_out2 >= 128] = folded cross-attention output, flag2 [rows] = no valid cross target. Inference only. */
+typedef struct tbx_dec_mid {
+  const float* qkv;
+  float* x;
+  tbx_attn_seg_t self_seg;
+  tbx_attn_seg_t cross_seg[2];
+  const float *rpe_k_bias_self, *rpe_k_bias_cross, *freqs_xy, *freqs_yaw;
+  const float *fold_self_image, *out_proj_image, *q_image, *qfold_image, *fold_cross_image;
+  const float *ln_weight, *ln_bias;
+  float* out2;
+  uint8_t* flag2;
+  float ln_eps;
+  int32_t ld_qkv, q_off, qt_off, ld_out2, n_cross, n_batch, n_src;
+} tbx_dec_mid_t;
+int tbx_knarpe_dec_mid(const tbx_dec_mid_t* args /* host */, void* stream);
+
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)

@@ -470,3 +470,71 @@ def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16):
         hip.knarpe_attn(q, 0, 128, att.linear_rpe.bias, n, S, segs, o128, f128, fold=eng.attn_fold_image(att))
         assert torch.equal(f128, f640) and int(f640.sum()) >= 1
         assert torch.equal(o128, want), float((o128 - want).abs().max())
+
+
+@pytest.mark.parametrize("S,Ks,T,K,n_cross,bf16", [(8, 4, 64, 8, 1, False), (64, 25, 1024, 64, 1, False), (64, 36, 128, 24, 2, False),
+                                                  (33, 13, 60, 128, 1, True)])
+def test_fused_decoder_mid_launch_equals_its_three_launches(tb, hip, dev, S, Ks, T, K, n_cross, bf16):
+    """tbx_knarpe_dec_mid (self attention -> x += out_proj -> LN -> q -> W_k^T q -> cross attention, one launch per decoder
+    layer, csrc/dec_mid.hip) vs the three launches it replaces (folded attention kernel -> row chain -> folded attention
+    kernel; transformer_rpe.py:165-192 of the reference): x after the self-attention residual, the cross attention's folded
+    output and its no-valid-target flags are bit-identical - one- and two-segment cross sets, fp32 and bf16 K/V tables, rows
+    whose self or cross set has no valid target."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    Seg, BUF1, D = hip.Seg, hip.BUF1, 128
+    g = torch.Generator().manual_seed(S * 131 + K)
+    blk = M.TransformerBlockRPE(n_layer=1, mode="dec_cross_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.1,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 5)
+    layer = blk.to(dev).eval().layers[0]
+    a1, a2 = layer.attn_src, layer.attn
+    n, rows = 2, 2 * S
+    x0 = torch.randn(rows, D, generator=g).to(dev)
+    qkv = torch.randn(rows, 896, generator=g).to(dev)
+
+    def knn(T_, K_):
+        rel = torch.cat([(torch.rand(n, S, K_, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K_, 1, generator=g) - 0.5) * 6], -1)
+        return (torch.randint(0, T_, (n, S, K_), generator=g).to(torch.int32).to(dev),
+                (torch.rand(n, S, K_, generator=g) < 0.3).to(torch.uint8).to(dev), rel.to(dev).contiguous())
+
+    i0, m0, r0 = knn(S, Ks)
+    m0[0, 1] = 1  # a row without a valid self target: x keeps its value (attention_rpe.py:151-156 zero row -> out_proj skipped)
+    kv16 = None
+    if bf16:
+        kv16 = qkv[:, D:3 * D].to(torch.bfloat16).contiguous()
+    self_seg = Seg(qkv, D, 2 * D, S, i0, m0, None, rel=r0) if kv16 is None else Seg(kv16, 0, D, S, i0, m0, None, rel=r0)
+    cross = []
+    for c in range(n_cross):
+        Tc, Kc = (T, K) if c == 0 else (40, 7)
+        kv = torch.randn(n * Tc, 256, generator=g).to(dev)
+        ic, mc, rc = knn(Tc, Kc)
+        mc[1, 2] = 1  # ... and one without a valid cross target
+        cross.append(Seg(kv.to(torch.bfloat16) if bf16 else kv, 0, D, Tc, ic, mc, None, 1, rel=rc))
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    fxy, fyw = pe.pe_xy.freqs, pe.pe_yaw.freqs
+    # ---- the three launches
+    ob1, f1 = torch.empty(rows, D, device=dev), torch.empty(rows, dtype=torch.uint8, device=dev)
+    hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], ob1, f1, fxy, fyw, fold=eng.attn_fold_image(a1))
+    x_want, q2 = x0.clone(), torch.empty(rows, 640, device=dev)
+    ch = eng.layer_chain(rows)
+    eng.emit_attn_out(ch, a1, ob1, f1, x=x_want)
+    ch.store(BUF1, 0, D, x_want)
+    eng.emit_proj(ch, rows, layer.norm1, a2, q2, with_kv=False)
+    ch.run(rows)
+    o_want, f_want = torch.empty(rows, D, device=dev), torch.empty(rows, dtype=torch.uint8, device=dev)
+    hip.knarpe_attn(q2, 0, D, a2.linear_rpe.bias, n, S, cross, o_want, f_want, fxy, fyw, fold=eng.attn_fold_image(a2))
+    # ---- one launch
+    x_got, o_got, f_got = x0.clone(), torch.full((rows, D), 7.0, device=dev), torch.empty(rows, dtype=torch.uint8, device=dev)
+    hip.knarpe_dec_mid(qkv, 0, 3 * D, x_got, self_seg, cross, a1.linear_rpe.bias, a2.linear_rpe.bias,
+                       (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, eng.attn_fold_image(a1),
+                       hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, gemv=True),
+                       hip.packed_weight(a2.in_proj_weight[:D], a2.in_proj_bias[:D], gemv=True),
+                       hip.packed_weight(a2.linear_rpe.weight[:D], None, wt=True, groups=4, gemv=True), eng.attn_fold_image(a2),
+                       o_got, f_got, fxy, fyw)
+    torch.cuda.synchronize()
+    assert int(f1.sum()) >= 1 and int(f_want.sum()) >= 1
+    assert torch.equal(f_got, f_want)
+    assert torch.equal(x_got, x_want), float((x_got - x_want).abs().max())
+    assert torch.equal(o_got, o_want), float((o_got - o_want).abs().max())

@@ -253,3 +253,33 @@ def test_shared_lights_across_rollouts_are_bit_identical(tb):
         assert torch.equal(buf.vis_dict["tl_state"], ref.vis_dict["tl_state"]), key
         for k, v in ref.violation.items():
             assert torch.equal(buf.violation[k], v), (key, k)
+
+
+@pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
+def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
+    """The schedules the engine picks for launches of a few hundred rows - live-row chains (LINEAR as v_fma chains), the
+    attention kernel's folded epilogue, and the fused attention half of a decoder layer (tbx_knarpe_dec_mid) - run the same
+    arithmetic in the same order as the 16-row MFMA chains + separate attention launches: the rollouts must not differ by a bit."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    eng = import_module("trafficbots_amd.engine")
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID)
+    outs = {}
+    try:
+        for name, (live, fold, mid) in {"mfma": (0, False, False), "live1": (1, False, False), "live2": (2, False, False),
+                                        "fold": (1, True, False), "mid": (1, True, True), "mid2": (2, True, True)}.items():
+            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID = live, fold, mid
+            outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
+                                            step_end=24)
+    finally:
+        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID = saved
+    ref = outs["mfma"]
+    for name, o in outs.items():
+        assert torch.equal(o.pred_pose, ref.pred_pose), name
+        assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), name
+        assert torch.equal(o.vis_dict["tl_state"], ref.vis_dict["tl_state"]), name
+        assert torch.equal(o.tl_state_nll, ref.tl_state_nll), name

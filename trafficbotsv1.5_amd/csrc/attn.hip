@@ -18,11 +18,12 @@
 #include <stdlib.h>
 
 #include "../../include/tbx_hip.h"
+#include "attn_core.h"
 #include "tbx_common.h"
 
 namespace {
 
-constexpr int D = 128, NH = 4, DH = 32, DR = 128, KMAX = 128;
+using namespace tbx_attn;
 
 struct AttnArgs {
   const float* qbuf;
@@ -50,128 +51,6 @@ struct AttnArgs {
   const float* fold_img;
 };
 
-__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ void scale4(float4& v, float f) { v.x *= f; v.y *= f; v.z *= f; v.w *= f; }
-__device__ __forceinline__ void fma4(float4& acc, float p, const float4 v) { acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w; }
-__device__ __forceinline__ void scale2(float2& v, float f) { v.x *= f; v.y *= f; }
-__device__ __forceinline__ void fma2(float2& acc, float p, const float2 v) { acc.x += p * v.x; acc.y += p * v.y; }
-
-// A lane's 16-channel slice of a 128-d embedding-space vector (see the header comment for the channel set).
-struct ESlice {
-  float2 xc, xs, yc, ys;
-  float4 wc, ws;
-  __device__ __forceinline__ void zero() {
-    xc = xs = yc = ys = make_float2(0.f, 0.f);
-    wc = ws = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __device__ __forceinline__ void load(const float* __restrict__ p, int s8) {
-    xc = *(const float2*)(p + 2 * s8);
-    xs = *(const float2*)(p + 16 + 2 * s8);
-    yc = *(const float2*)(p + 32 + 2 * s8);
-    ys = *(const float2*)(p + 48 + 2 * s8);
-    wc = *(const float4*)(p + 64 + 4 * s8);
-    ws = *(const float4*)(p + 96 + 4 * s8);
-  }
-  __device__ __forceinline__ void store(float* __restrict__ p, int s8) const {
-    *(float2*)(p + 2 * s8) = xc;
-    *(float2*)(p + 16 + 2 * s8) = xs;
-    *(float2*)(p + 32 + 2 * s8) = yc;
-    *(float2*)(p + 48 + 2 * s8) = ys;
-    *(float4*)(p + 64 + 4 * s8) = wc;
-    *(float4*)(p + 96 + 4 * s8) = ws;
-  }
-  __device__ __forceinline__ float dot(const ESlice& o) const {
-    return xc.x * o.xc.x + xc.y * o.xc.y + xs.x * o.xs.x + xs.y * o.xs.y + yc.x * o.yc.x + yc.y * o.yc.y + ys.x * o.ys.x +
-           ys.y * o.ys.y + dot4(wc, o.wc) + dot4(ws, o.ws);
-  }
-  __device__ __forceinline__ void scale(float f) {
-    scale2(xc, f); scale2(xs, f); scale2(yc, f); scale2(ys, f);
-    scale4(wc, f); scale4(ws, f);
-  }
-  __device__ __forceinline__ void fma(float p, const ESlice& o) {
-    fma2(xc, p, o.xc); fma2(xs, p, o.xs); fma2(yc, p, o.yc); fma2(ys, p, o.ys);
-    fma4(wc, p, o.wc); fma4(ws, p, o.ws);
-  }
-  __device__ __forceinline__ void reduce_slots() {  // sum over the 8 target slots (lanes with equal s8)
-    using tbx::slot_sum;
-    xc.x = slot_sum(xc.x); xc.y = slot_sum(xc.y); xs.x = slot_sum(xs.x); xs.y = slot_sum(xs.y);
-    yc.x = slot_sum(yc.x); yc.y = slot_sum(yc.y); ys.x = slot_sum(ys.x); ys.y = slot_sum(ys.y);
-    wc.x = slot_sum(wc.x); wc.y = slot_sum(wc.y); wc.z = slot_sum(wc.z); wc.w = slot_sum(wc.w);
-    ws.x = slot_sum(ws.x); ws.y = slot_sum(ws.y); ws.z = slot_sum(ws.z); ws.w = slot_sum(ws.w);
-  }
-};
-
-// sin / cos of an fp32 angle through the hardware v_sin_f32 / v_cos_f32 (argument in revolutions, |rev| <= 256), with a
-// two-constant 1/(2 pi) and an fma-exact reduction to [-0.5, 0.5]: the reduction error is ~1e-9 rev even for the
-// ~500 rad arguments of x * f_0, so the result is within the hardware's ~1e-6 absolute error of sin/cos of the SAME fp32
-// product the reference feeds to torch.sin / torch.cos. ~10 instructions instead of ~100 for the libm sincosf.
-__device__ __forceinline__ void sincos_rev(float arg, float* sn, float* cs) {
-  constexpr float INV2PI_HI = 0.15915494f;          // float(1 / 2pi)
-  constexpr float INV2PI_LO = 6.4206395e-09f;       // 1 / 2pi - INV2PI_HI
-  const float n = rintf(arg * INV2PI_HI);
-  float f = fmaf(arg, INV2PI_HI, -n);
-  f = fmaf(arg, INV2PI_LO, f);
-  *sn = __builtin_amdgcn_sinf(f);
-  *cs = __builtin_amdgcn_cosf(f);
-}
-
-// Dropout mask bit of (row, global target slot t < 128, head): lowbias32 finaliser over a counter keyed by the seed.
-struct DropKey {
-  uint32_t lo, hi, krow;
-  // row: the wave's source row (uniform); b = row / n_src
-  __device__ __forceinline__ void init(const AttnArgs& a, int row, int b) {
-    const uint64_t sd = *a.drop_seed;
-    const int sc = b / a.drop_time_batch;
-    const uint32_t ts = (uint32_t)(a.drop_time0 + (b - sc * a.drop_time_batch));
-    krow = (uint32_t)(sc * a.n_src + (row - b * a.n_src));
-    lo = (uint32_t)sd ^ (a.drop_call * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
-    hi = (uint32_t)(sd >> 32) + a.drop_call * 0xC2B2AE35u + ts * 0x165667B1u;
-  }
-  __device__ __forceinline__ bool keep(uint32_t t, uint32_t h, uint32_t thresh) const {
-    uint32_t x = ((krow * 128u + t) * 4u + h) ^ lo;
-    x *= 0x9E3779B1u;
-    x ^= hi;
-    x ^= x >> 16;
-    x *= 0x7feb352du;
-    x ^= x >> 15;
-    x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x >= thresh;
-  }
-};
-
-// The lane's frequencies for rebuilding its embedding slice from a relative pose.
-struct EFreq {
-  float fx[2], fw[4];
-  __device__ __forceinline__ void init(const float* __restrict__ fxy, const float* __restrict__ fyaw, int s8) {
-    fx[0] = fx[1] = 0.f;
-    fw[0] = fw[1] = fw[2] = fw[3] = 0.f;
-    if (fxy == nullptr) return;
-    // the reference's buffers are repeat-interleaved [f0,f0,f1,f1,..]; the even entry serves the (cos, sin) pair
-    fx[0] = fxy[2 * (2 * s8)];
-    fx[1] = fxy[2 * (2 * s8 + 1)];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fw[i] = fyaw[2 * (4 * s8 + i)];
-  }
-  __device__ __forceinline__ void embed(const float* __restrict__ rel3, ESlice& e) const {
-    const float x = rel3[0], y = rel3[1], w = rel3[2];
-    sincos_rev(x * fx[0], &e.xs.x, &e.xc.x);
-    sincos_rev(x * fx[1], &e.xs.y, &e.xc.y);
-    sincos_rev(y * fx[0], &e.ys.x, &e.yc.x);
-    sincos_rev(y * fx[1], &e.ys.y, &e.yc.y);
-    sincos_rev(w * fw[0], &e.ws.x, &e.wc.x);
-    sincos_rev(w * fw[1], &e.ws.y, &e.wc.y);
-    sincos_rev(w * fw[2], &e.ws.z, &e.wc.z);
-    sincos_rev(w * fw[3], &e.ws.w, &e.wc.w);
-  }
-};
-
-__device__ __forceinline__ void load_e(const tbx_attn_seg_t& S, int64_t pi, int s8, const EFreq& fq, ESlice& e) {
-  if (S.emb != nullptr)
-    e.load(S.emb + pi * DR, s8);
-  else
-    fq.embed(S.rel_pose + pi * 3, e);
-}
 
 // WPR = wavefronts cooperating on one source row: 1 for large grids (a wave per row, 4 rows per workgroup), 4 for small
 // grids (the closed loop at a few scenes is latency-bound: 4 waves split a row's targets and combine through LDS).
@@ -182,18 +61,6 @@ __device__ __forceinline__ void load_e(const tbx_attn_seg_t& S, int64_t pi, int 
 // rescaled when the slot's running max grows. The 8 slots (and the WPR waves) are merged once per row:
 //   out = sum_slots exp(m_slot - M) acc_slot / sum_slots exp(m_slot - M) l_slot.
 // No LDS traffic and no barrier inside the target loop.
-// K / V channels [c, c + 4) of a table row: fp32 tables, or bfloat16 tables widened to fp32 (a bf16 is the upper half of the float)
-template <bool KV16>
-__device__ __forceinline__ float4 kv_load4(const float* __restrict__ table_row, int c) {
-  if constexpr (KV16) {
-    const uint2 r = *(const uint2*)((const uint16_t*)table_row + c);
-    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                       __uint_as_float(r.y & 0xffff0000u));
-  } else {
-    return *(const float4*)(table_row + c);
-  }
-}
-
 constexpr int FOLD_ROWS = 1 + (DR / 16) * 4;  // float4 rows of the value-fold image: a bias row + 32 weight rows of [128][4]
 
 template <int WPR, bool DROP, bool KV16 = false, bool FOLD = false>
@@ -206,17 +73,9 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   if constexpr (FOLD) {
     // the image is requested first and lands while the targets are swept: 1 KiB per wave instruction, straight into LDS (asm:
     // the compiler would order every later LDS read behind a DMA it knows of - see csrc/rowchain.hip gemv_dma)
-    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)fold_s);
+    const uint32_t lds0 = lds_addr(fold_s);
     const int w4 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int p = w4; p < FOLD_ROWS * 2; p += 4) {
-      const float* gsrc = a.fold_img + p * 256 + (threadIdx.x & 63) * 4;
-      const uint32_t dst = lds0 + (uint32_t)p * 1024u;
-      uint32_t keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(gsrc), "s"(dst)
-                   : "memory");
-    }
+    for (int p = w4; p < FOLD_ROWS * 2; p += 4) glds_1k(a.fold_img + p * 256 + (threadIdx.x & 63) * 4, lds0 + (uint32_t)p * 1024u);
   }
   constexpr int RPB = 4 / WPR;
   const int lane = threadIdx.x & 63;
@@ -243,99 +102,14 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     qt[h].load(qrow + a.qt_off + h * DR, s8);
   }
 
-  // ---- per-slot online softmax state and partial sums
-  float m_run[NH], l_run[NH];
-  float4 oacc[NH];
-  ESlice eacc[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    m_run[h] = -INFINITY;
-    l_run[h] = 0.f;
-    oacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-    eacc[h].zero();
-  }
-
-  // Segment by segment, 8 targets per pass: everything that depends on the segment (table base of this row's scene, leading
-  // dimensions, the materialised / in-register embedding choice) is wave-uniform and lives in scalar registers. The loop is
-  // VALU-issue bound (~70 wave instructions per pair), so it is kept straight-line: slots past the segment's K re-read its
-  // last pair (finite data) and, like masked targets, enter the online softmax with probability exactly 0 and a rescale
-  // factor of exactly 1 - no per-lane branches, no zero fills, no per-lane segment selects.
-  DropKey dk;
-  if constexpr (DROP) dk.init(a, row, b);
-  int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
-  for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
-    const tbx_attn_seg_t& S = a.seg[sg];
-    // (bf16 tables: element offsets, half the bytes - the pointer is kept as float* and scaled by hand)
-    constexpr int ES = KV16 ? 2 : 1;  // table elements per float slot
-    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-    const int64_t pbase = (int64_t)row * S.k;
-    for (int base = wir * 8; base < S.k; base += 8 * WPR) {
-      const int t = base + tg;
-      const bool active = t < S.k;
-      const int64_t pi = pbase + (active ? t : S.k - 1);
-      const int j = S.idx[pi];
-      const bool ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
-      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
-      float4 kq[4], v[4];
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
-        v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
-      }
-      ESlice e;
-      load_e(S, pi, s8, fq, e);
-      // Online softmax in the base-2 domain (scores pre-multiplied by log2(e) / sqrt(d_head), v_exp_f32 directly) with a
-      // LAZY reference: a slot's reference m is its first valid score and moves only when a later score exceeds it by more
-      // than 64 (2^64 headroom in fp32; a wave-uniform, practically never taken branch). The steady state has no
-      // rescaling of the 80 accumulator registers: ~18 % fewer VALU instructions in a loop that is VALU-issue bound.
-      float sc[NH];
-      bool jump = false;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        sc[h] = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
-        jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
-      }
-      if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
-            l_run[h] *= alpha;
-            scale4(oacc[h], alpha);
-            eacc[h].scale(alpha);
-            m_run[h] = sc[h];
-          }
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];  // the slot's first valid target sets the reference
-        const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
-        l_run[h] += pr;  // the normaliser is that of the un-dropped softmax
-        float pd = pr;
-        if constexpr (DROP) pd = dk.keep((uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
-        fma4(oacc[h], pd, v[h]);  // K/V channel block st == h belongs to head h
-        eacc[h].fma(pd, e);
-      }
-    }
-  }
-
-  // ---- merge the 8 target slots of this wave (lanes with equal s8: xor 8, 16, 32)
+  // ---- this wave's share of the row's targets (attn_core.h), then the merge of its 8 target slots
+  RowAcc st;
+  st.zero();
+  sweep<WPR, DROP, KV16>(a, row, b, wir, s8, tg, qv, qt, qb, fq, st);
   float M[NH], L[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const float mm = tbx::slot_max(m_run[h]);
-    M[h] = mm;
-    const float f = (m_run[h] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[h] - mm);
-    float ll = l_run[h] * f;
-    scale4(oacc[h], f);
-    eacc[h].scale(f);
-    ll = tbx::slot_sum(ll);
-    L[h] = ll;
-    oacc[h].x = tbx::slot_sum(oacc[h].x); oacc[h].y = tbx::slot_sum(oacc[h].y);
-    oacc[h].z = tbx::slot_sum(oacc[h].z); oacc[h].w = tbx::slot_sum(oacc[h].w);
-    eacc[h].reduce_slots();
-  }
+  merge_slots(st, M, L);
+  float4(&oacc)[NH] = st.oacc;
+  ESlice(&eacc)[NH] = st.eacc;
   float* orow = a.out + (int64_t)row * a.ldo;
   if constexpr (WPR == 1) {
     const bool any_valid = M[0] > -INFINITY;  // masks are per target, so every head sees the same validity
@@ -379,7 +153,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
       for (int w = 0; w < WPR; ++w) {
         const float mw = red_s[w][OUTW + h];
         fw[w][h] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
-        ll += fw[w][h] * red_s[w][OUTW + NH + h];
+        ll = __builtin_fmaf(fw[w][h], red_s[w][OUTW + NH + h], ll);
       }
       any_valid = any_valid || mm > -INFINITY;
       inv_l[h] = (mm > -INFINITY) ? 1.0f / ll : 0.f;
@@ -393,7 +167,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         const int h = c < D ? c / DH : (c - D) / DR;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
+        for (int w = 0; w < WPR; ++w) acc = __builtin_fmaf(fw[w][h], red_s[w][c], acc);
         comb_s[c] = acc * inv_l[h];
       }
       __syncthreads();
@@ -420,7 +194,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
         const int h = c < D ? c / DH : (c - D) / DR;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < WPR; ++w) acc += fw[w][h] * red_s[w][c];
+        for (int w = 0; w < WPR; ++w) acc = __builtin_fmaf(fw[w][h], red_s[w][c], acc);
         orow[c] = acc * inv_l[h];
       }
     }

@@ -1,0 +1,312 @@
+// tbx_knarpe_dec_mid: the attention half of a dec_cross_attn transformer layer (transformer_rpe.py:207-233) as ONE launch for
+// launches of a few hundred rows (the closed loop at one or a few scenes):
+//
+//   self attention over the K nearest tokens (K/V rows of the table the previous launch stored)         [tbx_knarpe_attn_fwd_folded]
+//   x += rows without a valid target ? 0 : out_proj(.)                                                 [chain: LINEAR, accumulate, row skip]
+//   h = LayerNorm_1(x);  q = W_q h + b_q;  qt_h = W_rpe_k,h^T q_h                                        [chain: LN, LINEAR, grouped LINEAR]
+//   cross attention over the K nearest map tokens ++ K nearest traffic lights, value fold applied       [tbx_knarpe_attn_fwd_folded]
+//
+// i.e. what ran as attention kernel -> row chain -> attention kernel: three dependent launches of ~12 + 15 + 15 us whose
+// work is a few hundred kFLOP per row. One workgroup (4 wavefronts) per row; the two target sweeps are attn_core.h's (4 waves
+// split a row's targets exactly like the stand-alone kernel), the four small GEMVs between them run as thread-per-output v_fma
+// chains in the MFMA sequence's k order on tbx_pack_weight_gemv images streamed into two LDS slots by LDS-DMA (see
+// csrc/rowchain.hip linear_gemv) - every number equals the three-launch path's bit for bit (tested), the row never leaves the CU
+// between the two attentions, and q / W_k^T q / the first attention's output make no round trip through global memory.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "attn_core.h"
+#include "tbx_common.h"
+
+namespace {
+
+using namespace tbx_attn;
+
+constexpr int OUTW = D + NH * DR;        // 640
+constexpr int RED = OUTW + 2 * NH;       // per-wave partial: sums + (M, L) per head
+constexpr int IMG128 = (1 + 8 * 4) * 512;      // floats of a 128-output, k = 128 image: bias row + 32 rows of [128][4] (66 KiB)
+constexpr int IMGKF = 4 * (1 + 2 * 4) * 512;   // floats of the 4 x (32 -> 128) query-side fold image: 4 column blocks of 9 rows (72 KiB)
+
+struct Sweep {
+  tbx_attn_seg_t seg[2];
+  int n_seg;
+  float scale2;
+};
+
+struct MidArgs {
+  const float* qkv;  // [rows, ld_qkv]: q at q_off, W_k^T q at qt_off (this layer's self attention)
+  float* x;          // [rows, 128] token rows, updated in place
+  Sweep self, cross;
+  const float *bias_k1, *bias_k2, *fxy, *fyaw;
+  const float *fold1, *wo, *wq, *wkf, *fold2;  // gemv images
+  const float *ln_w, *ln_b;
+  float* out2;       // [rows, ld_out2]: folded cross-attention output
+  uint8_t* flag2;
+  float ln_eps;
+  int ld_qkv, q_off, qt_off, ld_out2, n_rows, n_src;
+};
+
+// image `img` (n_pieces KiB) -> LDS `slot`, piece p by wave p % 4
+__device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane) {
+  const uint32_t lds0 = lds_addr(slot);
+  for (int p = wave; p < n_pieces; p += 4) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+}
+
+// One output of a LINEAR stage as the k-ordered fma chain of the packed MFMA path: column `c` of the 128-column block at `blk`
+// (row 0 = bias, row 1 + kb*4 + t = weights of k = kb*16 + {0,4,8,12} + t), inputs x[0 .. kblocks*16).
+__device__ __forceinline__ float gemv_chain(const float* blk, int c, const float* x, int kblocks, float acc) {
+  const float4* wq = (const float4*)blk + c;
+#pragma unroll 2
+  for (int kb = 0; kb < kblocks; ++kb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 w = wq[(1 + kb * 4 + t) * D];
+      acc = __builtin_fmaf(x[kb * 16 + t], w.x, acc);
+      acc = __builtin_fmaf(x[kb * 16 + 4 + t], w.y, acc);
+      acc = __builtin_fmaf(x[kb * 16 + 8 + t], w.z, acc);
+      acc = __builtin_fmaf(x[kb * 16 + 12 + t], w.w, acc);
+    }
+  }
+  return acc;
+}
+
+// The stand-alone kernel's epilogue for 4 waves per row with the value fold (attn.hip, FOLD): per-wave partials -> red_s, the
+// waves' combination -> comb_s, then thread c < 128 runs the fold chain of output column c. Returns the folded value (threads
+// c < 128) and whether the row had a valid target. `fold_blk` must have landed (caller waited for the DMA before the barrier).
+__device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], const float (&L)[NH], float (*red_s)[RED], float* comb_s,
+                                              const float* fold_blk, int wir, int lane, int s8, int tg, bool& any_valid) {
+  if (tg == 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      *(float4*)(&red_s[wir][h * DH + s8 * 4]) = st.oacc[h];
+      st.eacc[h].store(&red_s[wir][D + h * DR], s8);
+    }
+  }
+  if (lane < NH) {
+    red_s[wir][OUTW + lane] = M[lane];
+    red_s[wir][OUTW + NH + lane] = L[lane];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of every image in flight have landed
+  __syncthreads();
+  float inv_l[NH], fw[4][NH];
+  any_valid = false;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red_s[w][OUTW + h]);
+    float ll = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = red_s[w][OUTW + h];
+      fw[w][h] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+      ll = __builtin_fmaf(fw[w][h], red_s[w][OUTW + NH + h], ll);
+    }
+    any_valid = any_valid || mm > -INFINITY;
+    inv_l[h] = (mm > -INFINITY) ? 1.0f / ll : 0.f;
+  }
+  for (int c = threadIdx.x; c < OUTW; c += 256) {
+    const int h = c < D ? c / DH : (c - D) / DR;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc = __builtin_fmaf(fw[w][h], red_s[w][c], acc);
+    comb_s[c] = acc * inv_l[h];
+  }
+  __syncthreads();
+  float out = 0.f;
+  if (threadIdx.x < D) {
+    const int c = threadIdx.x, h = c / DH;
+    out = gemv_chain(fold_blk, c, comb_s + D + h * DR, DR / 16, fold_blk[c * 4] + comb_s[c]);
+  }
+  return out;
+}
+
+template <bool KV16>
+__global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* slot_a = lds;                       // 66 KiB: fold1 -> W_q -> fold2
+  float* slot_b = slot_a + IMG128;           // 72 KiB: W_o -> query-side fold
+  float(*red_s)[RED] = (float(*)[RED])(slot_b + IMGKF);
+  float* comb_s = (float*)(red_s + 4);
+  float* xs = comb_s + OUTW;   // the token row
+  float* o1 = xs + D;          // folded self-attention output, then LN_1(x)
+  float* q2 = o1 + D;          // q of the cross attention
+  float* qt2 = q2 + D;         // W_k^T q, 4 x 128
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wir = wave;
+  const int row = blockIdx.x;
+  const int b = row / a.n_src;
+  const int s8 = lane & 7, tg = lane >> 3;
+  dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane);
+  dma_image(a.wo, IMG128 / 256, slot_b, wave, lane);
+  if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
+  // LayerNorm parameters (wave 0 normalises the row): requested now - an ordinary load issued while an image DMA is in flight
+  // makes the compiler wait for everything outstanding (it does not see the DMAs, vmcnt is in order)
+  float ln_g[2] = {0.f, 0.f}, ln_bt[2] = {0.f, 0.f};
+  if (wave == 0) {
+    ln_g[0] = a.ln_w[lane], ln_g[1] = a.ln_w[64 + lane];
+    ln_bt[0] = a.ln_b[lane], ln_bt[1] = a.ln_b[64 + lane];
+  }
+  EFreq fq;
+  fq.init(a.fxy, a.fyaw, s8);
+  float4 qv[NH];
+  ESlice qt[NH];
+  float qb[NH];
+  // ---------------------------------------------------------------- self attention
+  {
+    const float* qrow = a.qkv + (int64_t)row * a.ld_qkv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
+      const float4 bk = *(const float4*)(a.bias_k1 + h * DH + s8 * 4);
+      qb[h] = tbx::group8_sum(dot4(qv[h], bk));
+      qt[h].load(qrow + a.qt_off + h * DR, s8);
+    }
+  }
+  bool valid1;
+  {
+    RowAcc st;
+    st.zero();
+    sweep<4, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    float M[NH], L[NH];
+    merge_slots(st, M, L);
+    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid1);
+    if (threadIdx.x < D) o1[threadIdx.x] = f;
+  }
+  __syncthreads();  // o1 complete; slot A (fold1) is free
+  // the cross attention's q . b_k term needs rpe_k_bias: requested before the next image (see ln_g above)
+  float4 bk2[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) bk2[h] = *(const float4*)(a.bias_k2 + h * DH + s8 * 4);
+  asm volatile("" : "+v"(bk2[0].x), "+v"(bk2[1].x), "+v"(bk2[2].x), "+v"(bk2[3].x));  // keep the loads here
+  dma_image(a.wq, IMG128 / 256, slot_a, wave, lane);
+  // ---------------------------------------------------------------- x += no valid target ? 0 : out_proj(o1)   (W_o landed: waited in combine_fold)
+  if (threadIdx.x < D) {
+    const int c = threadIdx.x;
+    const float v = gemv_chain(slot_b, c, o1, D / 16, slot_b[c * 4] + xs[c]);
+    if (valid1) xs[c] = v;
+  }
+  __syncthreads();  // xs updated; slot B (W_o) is free
+  dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane);
+  // ---------------------------------------------------------------- LN_1(x) -> o1 (one wavefront, the chain's ln_row<2> order)
+  if (wave == 0) {
+    float v[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      v[q] = xs[lane + 64 * q];
+      sum += v[q];
+    }
+    sum = tbx::wave_sum(sum);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float d = v[q] - mean;
+      var += d * d;
+    }
+    var = tbx::wave_sum(var) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) o1[lane + 64 * q] = (v[q] - mean) * rstd * ln_g[q] + ln_bt[q];
+  }
+  // W_q has landed once at most the 18 pieces per wave of the image requested after it are outstanding (DMA loads only: in order)
+  asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  __syncthreads();
+  // ---------------------------------------------------------------- q = W_q LN(x) + b_q
+  if (threadIdx.x < D) {
+    const int c = threadIdx.x;
+    q2[c] = gemv_chain(slot_a, c, o1, D / 16, slot_a[c * 4]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the query-side fold image has landed
+  __syncthreads();  // q2 complete; slot A (W_q) is free
+  // ---------------------------------------------------------------- qt_h = W_rpe_k,h^T q_h: 4 x (32 -> 128), two outputs per thread
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = (int)threadIdx.x + 256 * i;
+    const int g = o >> 7, c = o & (D - 1);
+    const float* blk = slot_b + g * (1 + 2 * 4) * 512;
+    qt2[o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
+  }
+  __syncthreads();
+  dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane);  // lands during the sweep
+  // ---------------------------------------------------------------- cross attention
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    qv[h] = *(const float4*)(q2 + h * DH + s8 * 4);
+    qb[h] = tbx::group8_sum(dot4(qv[h], bk2[h]));
+    qt[h].load(qt2 + h * DR, s8);
+  }
+  {
+    RowAcc st;
+    st.zero();
+    sweep<4, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    float M[NH], L[NH];
+    merge_slots(st, M, L);
+    bool valid2;
+    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid2);
+    if (threadIdx.x < D) {
+      a.out2[(int64_t)row * a.ld_out2 + threadIdx.x] = f;
+      a.x[(int64_t)row * D + threadIdx.x] = xs[threadIdx.x];  // the token row after the self-attention residual
+    }
+    if (threadIdx.x == 0) a.flag2[row] = valid2 ? 0 : 1;
+  }
+}
+
+int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
+  if (!s.kv || !s.idx || !s.invalid || (!s.emb && !s.rel_pose) || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
+  if (!s.emb && (!fxy || !fyaw)) return TBX_ERR_ARG;
+  if ((s.ld_kv % 4) || (s.k_off % 4) || (s.v_off % 4) || (((uintptr_t)s.kv) & 15) || (s.emb && (((uintptr_t)s.emb) & 15))) return TBX_ERR_ALIGN;
+  return TBX_OK;
+}
+
+}  // namespace
+
+extern "C" int tbx_knarpe_dec_mid(const tbx_dec_mid_t* p, void* stream) {
+  if (!p || !p->qkv || !p->x || !p->out2 || !p->flag2 || !p->rpe_k_bias_self || !p->rpe_k_bias_cross || !p->ln_weight || !p->ln_bias ||
+      !p->fold_self_image || !p->out_proj_image || !p->q_image || !p->qfold_image || !p->fold_cross_image)
+    return TBX_ERR_ARG;
+  if (p->n_batch <= 0 || p->n_src <= 0 || p->n_cross < 1 || p->n_cross > 2) return TBX_ERR_ARG;
+  if ((p->ld_qkv % 4) || (p->q_off % 4) || (p->qt_off % 4) || (p->ld_out2 % 4) || p->ld_out2 < D) return TBX_ERR_ALIGN;
+  const void* al[] = {p->qkv, p->x, p->out2, p->fold_self_image, p->out_proj_image, p->q_image, p->qfold_image, p->fold_cross_image,
+                      p->rpe_k_bias_self, p->rpe_k_bias_cross};
+  for (const void* q : al)
+    if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
+  MidArgs a;
+  int rc = check_seg(p->self_seg, p->freqs_xy, p->freqs_yaw);
+  if (rc != TBX_OK) return rc;
+  int ktot = 0;
+  for (int i = 0; i < p->n_cross; ++i) {
+    rc = check_seg(p->cross_seg[i], p->freqs_xy, p->freqs_yaw);
+    if (rc != TBX_OK) return rc;
+    if ((p->cross_seg[i].kv_bf16 != 0) != (p->self_seg.kv_bf16 != 0)) return TBX_ERR_UNSUPPORTED;  // one table element type per call
+    ktot += p->cross_seg[i].k;
+  }
+  if (ktot > KMAX || p->self_seg.k > KMAX) return TBX_ERR_UNSUPPORTED;
+  a.qkv = p->qkv, a.x = p->x;
+  a.self.seg[0] = a.self.seg[1] = p->self_seg;
+  a.self.n_seg = 1;
+  a.cross.seg[0] = p->cross_seg[0];
+  a.cross.seg[1] = p->cross_seg[p->n_cross > 1 ? 1 : 0];
+  a.cross.n_seg = p->n_cross;
+  a.self.scale2 = a.cross.scale2 = 1.4426950408889634f / sqrtf((float)DH);
+  a.bias_k1 = p->rpe_k_bias_self, a.bias_k2 = p->rpe_k_bias_cross, a.fxy = p->freqs_xy, a.fyaw = p->freqs_yaw;
+  a.fold1 = p->fold_self_image, a.wo = p->out_proj_image, a.wq = p->q_image, a.wkf = p->qfold_image, a.fold2 = p->fold_cross_image;
+  a.ln_w = p->ln_weight, a.ln_b = p->ln_bias, a.ln_eps = p->ln_eps;
+  a.out2 = p->out2, a.flag2 = p->flag2;
+  a.ld_qkv = p->ld_qkv, a.q_off = p->q_off, a.qt_off = p->qt_off, a.ld_out2 = p->ld_out2;
+  a.n_rows = p->n_batch * p->n_src, a.n_src = p->n_src;
+  const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float);
+  static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
+  hipStream_t hs = (hipStream_t)stream;
+  if (p->self_seg.kv_bf16 != 0) {
+    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((dec_mid_kernel<true>), dim3(a.n_rows), dim3(256), lds_bytes, hs, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((dec_mid_kernel<false>), dim3(a.n_rows), dim3(256), lds_bytes, hs, a);
+  }
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

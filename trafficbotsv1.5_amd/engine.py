@@ -66,6 +66,11 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
 ATTN_FOLD = os.environ.get("TBX_ATTN_FOLD", "1") != "0"
 
 
+# ... and a dec_cross_attn layer's [self attention -> out-proj -> LN -> q -> W_k^T q -> cross attention] runs as ONE launch
+# (tbx_knarpe_dec_mid) instead of attention kernel -> chain -> attention kernel. TBX_DEC_MID=0: the three launches.
+DEC_MID = os.environ.get("TBX_DEC_MID", "1") != "0"
+
+
 def attn_fold_image(attn) -> torch.Tensor:
     return hip.packed_weight(attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], groups=NH, gemv=True)
 
@@ -295,10 +300,31 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     ch.run(rows)
     if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
+    mid = fold and dec and DEC_MID
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
+        if mid:
+            # one launch: self attention -> x += out_proj(.) -> LN_1 -> q -> W_k^T q -> cross attention -> obuf (128 wide) + flag
+            a2 = layer.attn
+            hip.knarpe_dec_mid(qkv, 0, 3 * D, x, self_seg, list(cross(l)), a1.linear_rpe.bias, a2.linear_rpe.bias,
+                               (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, attn_fold_image(a1),
+                               hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, gemv=True),
+                               hip.packed_weight(a2.in_proj_weight[:D], a2.in_proj_bias[:D], gemv=True),
+                               hip.packed_weight(a2.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True), attn_fold_image(a2),
+                               obuf, flag, fxy, fyw)
+            ch = layer_chain(rows)
+            emit_attn_out(ch, a2, obuf, flag, drop=None, x=x)
+            emit_ffn(ch, layer)
+            ch.rowmask(BUF1, 0, D, mask=src_invalid)
+            ch.store(BUF1, 0, D, x)
+            if l + 1 < len(layers):
+                emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True, kv16=kv16)
+            elif tail is not None:
+                tail(ch)
+            ch.run(rows)
+            continue
         hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1),
                         fold=attn_fold_image(a1) if fold else None)
         ch = layer_chain(rows)

@@ -39,6 +39,16 @@ class AttnSeg(C.Structure):
         (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k", "kv_bf16")]
 
 
+class DecMid(C.Structure):
+    """tbx_dec_mid_t (include/tbx_hip.h)."""
+    _fields_ = ([("qkv", C.c_void_p), ("x", C.c_void_p), ("self_seg", AttnSeg), ("cross_seg", AttnSeg * 2)]
+                + [(n, C.c_void_p) for n in ("rpe_k_bias_self", "rpe_k_bias_cross", "freqs_xy", "freqs_yaw", "fold_self_image",
+                                             "out_proj_image", "q_image", "qfold_image", "fold_cross_image", "ln_weight", "ln_bias",
+                                             "out2", "flag2")]
+                + [("ln_eps", C.c_float)]
+                + [(n, C.c_int32) for n in ("ld_qkv", "q_off", "qt_off", "ld_out2", "n_cross", "n_batch", "n_src")])
+
+
 class SimState(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
@@ -105,6 +115,7 @@ def load():
     lib.tbx_pose_embed.argtypes = [vp, i64, vp, vp, i32, vp, i32, i32, vp]
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp,
@@ -147,7 +158,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -307,6 +318,26 @@ def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_s
                                             _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy),
                                             _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
     _check(rc, "tbx_knarpe_attn_bwd")
+
+
+def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: Sequence[Seg], bias_self, bias_cross, ln, n_batch: int,
+                   n_src: int, fold_self, out_proj, q_img, qfold, fold_cross, out2, flag2, freqs_xy=None, freqs_yaw=None):
+    """tbx_knarpe_dec_mid: folded self attention -> out-proj into x -> LN -> q -> W_k^T q -> folded cross attention, one launch.
+    ln = (weight, bias, eps); the five images are tbx_pack_weight_gemv images (include/tbx_hip.h)."""
+    a = DecMid()
+    a.qkv, a.x = _ptr(qkv, torch.float32), _cptr(x, torch.float32)
+    a.self_seg = self_seg.c()
+    cs = [sg.c() for sg in cross_segs]
+    a.cross_seg[0], a.cross_seg[1] = cs[0], cs[-1]
+    a.rpe_k_bias_self, a.rpe_k_bias_cross = _ptr(bias_self, torch.float32), _ptr(bias_cross, torch.float32)
+    a.freqs_xy, a.freqs_yaw = _cptr(freqs_xy), _cptr(freqs_yaw)
+    a.fold_self_image, a.out_proj_image, a.q_image = _ptr(fold_self), _ptr(out_proj), _ptr(q_img)
+    a.qfold_image, a.fold_cross_image = _ptr(qfold), _ptr(fold_cross)
+    a.ln_weight, a.ln_bias, a.ln_eps = _ptr(ln[0], torch.float32), _ptr(ln[1], torch.float32), float(ln[2])
+    a.out2, a.flag2 = _ptr(out2, torch.float32), _ptr(flag2, torch.uint8)
+    a.ld_qkv, a.q_off, a.qt_off, a.ld_out2 = qkv.stride(0), q_off, qt_off, out2.stride(0)
+    a.n_cross, a.n_batch, a.n_src = len(cross_segs), n_batch, n_src
+    _check(load().tbx_knarpe_dec_mid(C.byref(a), stream_ptr()), "tbx_knarpe_dec_mid")
 
 
 def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):
