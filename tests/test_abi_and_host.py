@@ -91,7 +91,23 @@ def test_chain_program_encoding(hip):
     ch._add(op=hip.OP_COPY, src=0, dst=1, n=4)
     st = ch.stages[0]
     assert (st.op, st.src, st.dst, st.n) == (hip.OP_COPY, 0, 1, 4)
-    assert C.sizeof(hip.Stage) == 88 and C.sizeof(hip.AttnSeg) == 64
+    assert C.sizeof(hip.Stage) == 88 and C.sizeof(hip.AttnSeg) == 72
+
+
+def test_ctypes_mirrors_have_the_layout_gcc_gives_the_header(hip, tmp_path):
+    """sizeof of every struct that crosses the C ABI, as gcc lays out include/tbx_hip.h, equals the ctypes mirror's."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    pairs = [("tbx_stage_t", hip.Stage), ("tbx_attn_seg_t", hip.AttnSeg), ("tbx_dec_mid_t", hip.DecMid), ("tbx_sim_state_t", hip.SimState),
+             ("tbx_train_chain_t", hip.TrainChainArgs), ("tbx_rule_ctx_t", hip.RuleCtx)]
+    src = tmp_path / "sz.c"
+    src.write_text('#include "tbx_hip.h"\n#include <stdio.h>\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", str(root / "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(t) for _, t in pairs]
 
 
 def test_new_entry_points_validate_arguments_without_a_gpu(hip):
