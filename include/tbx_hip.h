@@ -53,6 +53,25 @@ int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, const float
                   uint8_t* invalid, float* rel_pose, float* emb, const float* freqs_xy, const float* freqs_yaw,
                   int pe_dim, void* stream);
 
+/* Up to 4 searches of tbx_knn_embed in ONE launch (agent_encoder.py:321-387 runs three per step - agent->agent, agent->map,
+ * agent->light - from the same source poses; at a few hundred source rows each search is a latency-bound launch, and three
+ * dependent launches on a side stream are three chances for the queue to stall). One workgroup per (job, source row), jobs back
+ * to back over the grid in the order given; every job's outputs equal tbx_knn_embed's bit for bit (same device code). */
+typedef struct tbx_knn_job {
+  const float* src_pose;
+  const uint8_t* src_invalid;
+  const float* tgt_pose;
+  const uint8_t* tgt_invalid;
+  int32_t* idx;
+  uint8_t* invalid;
+  float* rel_pose; /* may be NULL */
+  float* emb;      /* may be NULL */
+  int32_t n_batch, n_src, n_tgt, tgt_batch_div, k;
+  float dist_limit;
+} tbx_knn_job_t;
+int tbx_knn_embed_multi(const tbx_knn_job_t* jobs /* host */, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
+                        void* stream);
+
 /* Pose embedding of explicit (x,y,yaw) triples (utils/pose_emb.py:50-55); out[i, col_off : col_off+pe_dim]. */
 int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim, float* out,
                    int ld_out, int col_off, void* stream);

@@ -538,3 +538,26 @@ def test_fused_decoder_mid_launch_equals_its_three_launches(tb, hip, dev, S, Ks,
     assert torch.equal(f_got, f_want)
     assert torch.equal(x_got, x_want), float((x_got - x_want).abs().max())
     assert torch.equal(o_got, o_want), float((o_got - o_want).abs().max())
+
+
+def test_knn_multi_launch_equals_single_searches(hip, dev):
+    """tbx_knn_embed_multi (the agents' three searches of a step in one launch) vs three tbx_knn_embed calls: identical index
+    sets, masks, relative poses and embeddings (the same device code per (job, row))."""
+    g = torch.Generator().manual_seed(77)
+    n, S = 2, 37
+    pose, inv = _poses(g, n, S).to(dev), (torch.rand(n, S, generator=g) < 0.2).to(torch.uint8).to(dev)
+    tg = [(_poses(g, 1, 1024).to(dev), (torch.rand(1, 1024, generator=g) < 0.3).to(torch.uint8).to(dev), 64, 2),
+          (pose, inv, 12, 1), (_poses(g, n, 40).to(dev), (torch.rand(n, 40, generator=g) < 0.3).to(torch.uint8).to(dev), 8, 1),
+          (_poses(g, n, 1500).to(dev), torch.zeros(n, 1500, dtype=torch.uint8, device=dev), 33, 1)]
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    for want_emb in (False, True):
+        jobs = [dict(src_pose=pose, src_invalid=inv, tgt_pose=tp, tgt_invalid=ti, k=k, dist_limit=150.0, tgt_batch_div=div,
+                     want_rel_pose=True, want_emb=want_emb) for tp, ti, k, div in tg]
+        got = hip.knn_embed_multi(jobs, pe.pe_xy.freqs, pe.pe_yaw.freqs)
+        for q, o in zip(jobs, got):
+            want = hip.knn_embed(freqs_xy=pe.pe_xy.freqs, freqs_yaw=pe.pe_yaw.freqs, **q)
+            for a, b in zip(o, want):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)

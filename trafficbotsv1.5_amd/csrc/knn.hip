@@ -40,14 +40,14 @@ __device__ __forceinline__ void rel_xy(float x1, float y1, float c, float s, flo
 // WPR = wavefronts per source row: the selection is done by the row's first wave, the K embeddings are split over all
 // WPR waves (4 on the small grids of a few scenes, where the kernel is latency-bound; 1 on large grids).
 template <int MAXC, int WPR>
-__global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
+__device__ __forceinline__ void knn_rows(const KnnArgs& a, int block) {
   constexpr int RPB = 4 / WPR;
   __shared__ float rel_s[RPB][64][3];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int wave = wv / WPR;  // row slot in the workgroup
   const int wir = wv % WPR;   // wave within the row
-  const int row = blockIdx.x * RPB + wave;
+  const int row = block * RPB + wave;
   if (row >= a.n_rows) return;  // uniform per row (per workgroup when WPR == 4)
   const int b = row / a.n_src;
   const int bt = b / a.tgt_batch_div;
@@ -60,16 +60,31 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
   if (wir == 0) {
     // Candidate keys: the fp32 bits of the distance (non-negative, so unsigned order == float order; +inf for masked
     // pairs), 0xffffffff for slots past n_tgt. Lane l owns targets l, l+64, ...
+    // The candidates' relative poses stay in registers from here to the output phase (rx, ry, yaw difference, the target's own
+    // invalid bit): the winners are written without touching the target tables again (a dependent L2 round trip per candidate
+    // slot otherwise - 16 of them in a row were most of this kernel's time on the latency-bound grids of a few scenes).
     uint32_t key[MAXC];
+    float crx[MAXC], cry[MAXC], cyaw[MAXC];
+    uint32_t tinv = 0;
+    {
+      float tx[MAXC], ty[MAXC];
+      uint8_t tb[MAXC];
 #pragma unroll
-    for (int q = 0; q < MAXC; ++q) {
-      const int j = lane + 64 * q;
-      key[q] = 0xffffffffu;
-      if (j < a.n_tgt) {
-        float rx, ry;
-        rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
-        const float dist = __fsqrt_rn(__fmaf_rn(ry, ry, __fmul_rn(rx, rx)));
-        key[q] = __float_as_uint((inv1 || ti[j] != 0) ? INFINITY : dist);
+      for (int q = 0; q < MAXC; ++q) {  // all loads first, on clamped indices (no branch between them: one latency, not MAXC)
+        const int j = min(lane + 64 * q, a.n_tgt - 1);
+        tx[q] = tp[j * 3 + 0];
+        ty[q] = tp[j * 3 + 1];
+        cyaw[q] = tp[j * 3 + 2];
+        tb[q] = ti[j];
+      }
+#pragma unroll
+      for (int q = 0; q < MAXC; ++q) {
+        const bool tin = tb[q] != 0;
+        rel_xy(x1, y1, c, s, tx[q], ty[q], crx[q], cry[q]);
+        cyaw[q] = __fsub_rn(cyaw[q], yaw1);
+        tinv |= tin ? (1u << q) : 0u;
+        const float dist = __fsqrt_rn(__fmaf_rn(cry[q], cry[q], __fmul_rn(crx[q], crx[q])));
+        key[q] = (lane + 64 * q < a.n_tgt) ? __float_as_uint((inv1 || tin) ? INFINITY : dist) : 0xffffffffu;
       }
     }
     // K-th smallest key by bisection over its 31 value bits: count(key < cand) is a sum of wave ballots' popcounts, so
@@ -104,10 +119,8 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
         const int64_t o = (int64_t)row * a.k + pos;
         const float dist = __uint_as_float(key[q]);
         a.idx[o] = j;
-        a.invalid[o] = (ti[j] != 0 || dist > a.dist_limit) ? 1 : 0;
-        float rx, ry;
-        rel_xy(x1, y1, c, s, tp[j * 3 + 0], tp[j * 3 + 1], rx, ry);
-        const float ryaw = __fsub_rn(tp[j * 3 + 2], yaw1);
+        a.invalid[o] = (((tinv >> q) & 1u) != 0 || dist > a.dist_limit) ? 1 : 0;
+        const float rx = crx[q], ry = cry[q], ryaw = cyaw[q];
         rel_s[wave][pos][0] = rx;
         rel_s[wave][pos][1] = ry;
         rel_s[wave][pos][2] = ryaw;
@@ -130,6 +143,33 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
     const float x = rel_s[wave][t][0], y = rel_s[wave][t][1], yaw = rel_s[wave][t][2];
     tbx::pose_emb_write(a.emb + ((int64_t)row * a.k + t) * a.pe_dim, a.pe_dim, x, y, yaw, a.fxy, a.fyaw, lane, 64);
   }
+}
+
+template <int MAXC, int WPR>
+__global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
+  knn_rows<MAXC, WPR>(a, blockIdx.x);
+}
+
+// Several searches in one launch (the agents' three K-nearest sets of a simulation step: one grid instead of three dependent
+// launches on the auxiliary stream). A workgroup = one source row of one job (the 4-waves-per-row form); jobs are laid out
+// back to back over blockIdx.x in the order given (the longest search first, so that its rows are dispatched first).
+constexpr int KNN_MAX_JOBS = 4;
+struct KnnMulti {
+  KnnArgs job[KNN_MAX_JOBS];
+  int first_block[KNN_MAX_JOBS + 1];
+  int n_jobs;
+};
+__global__ __launch_bounds__(256) void knn_multi_kernel(const KnnMulti m) {
+  int j = 0;
+  while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
+  const KnnArgs& a = m.job[j];
+  const int block = blockIdx.x - m.first_block[j];
+  if (a.n_tgt <= 128)
+    knn_rows<2, 4>(a, block);
+  else if (a.n_tgt <= 1024)
+    knn_rows<16, 4>(a, block);
+  else
+    knn_rows<32, 4>(a, block);
 }
 
 __global__ void pose_embed_kernel(const float* __restrict__ pose3, int64_t n, const float* __restrict__ fxy,
@@ -172,6 +212,29 @@ extern "C" int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, 
   else
     TBX_KNN_LAUNCH(32);
 #undef TBX_KNN_LAUNCH
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knn_embed_multi(const tbx_knn_job_t* jobs, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
+                                   void* stream) {
+  if (!jobs || n_jobs <= 0 || n_jobs > KNN_MAX_JOBS) return TBX_ERR_ARG;
+  KnnMulti m;
+  m.n_jobs = n_jobs;
+  int blocks = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const tbx_knn_job_t& q = jobs[j];
+    if (!q.src_pose || !q.src_invalid || !q.tgt_pose || !q.tgt_invalid || !q.idx || !q.invalid) return TBX_ERR_ARG;
+    if (q.n_batch <= 0 || q.n_src <= 0 || q.n_tgt <= 0 || q.tgt_batch_div <= 0 || q.n_batch % q.tgt_batch_div != 0) return TBX_ERR_ARG;
+    if (q.k <= 0 || q.k >= q.n_tgt || q.k > 64 || q.n_tgt > 2048) return TBX_ERR_UNSUPPORTED;
+    if (q.emb != nullptr && (!freqs_xy || !freqs_yaw || (pe_dim != 64 && pe_dim != 128))) return TBX_ERR_UNSUPPORTED;
+    m.job[j] = KnnArgs{q.src_pose, q.src_invalid, q.tgt_pose, q.tgt_invalid, q.idx, q.invalid, q.rel_pose, q.emb, freqs_xy, freqs_yaw,
+                       q.n_batch * q.n_src, q.n_src, q.n_tgt, q.tgt_batch_div, q.k, pe_dim, q.dist_limit};
+    m.first_block[j] = blocks;
+    blocks += q.n_batch * q.n_src;
+  }
+  for (int j = n_jobs; j <= KNN_MAX_JOBS; ++j) m.first_block[j] = blocks;
+  for (int j = n_jobs; j < KNN_MAX_JOBS; ++j) m.job[j] = m.job[0];
+  hipLaunchKernelGGL(knn_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

@@ -39,6 +39,12 @@ class AttnSeg(C.Structure):
         (n, C.c_int32) for n in ("ld_kv", "k_off", "v_off", "n_tgt", "batch_div", "k", "kv_bf16")]
 
 
+class KnnJob(C.Structure):
+    """tbx_knn_job_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("src_pose", "src_invalid", "tgt_pose", "tgt_invalid", "idx", "invalid", "rel_pose", "emb")]
+                + [(n, C.c_int32) for n in ("n_batch", "n_src", "n_tgt", "tgt_batch_div", "k")] + [("dist_limit", C.c_float)])
+
+
 class DecMid(C.Structure):
     """tbx_dec_mid_t (include/tbx_hip.h)."""
     _fields_ = ([("qkv", C.c_void_p), ("x", C.c_void_p), ("self_seg", AttnSeg), ("cross_seg", AttnSeg * 2)]
@@ -116,6 +122,7 @@ def load():
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
+    lib.tbx_knn_embed_multi.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp,
@@ -158,7 +165,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -213,6 +220,30 @@ def knn_embed(src_pose, src_invalid, tgt_pose, tgt_invalid, k: int, dist_limit: 
                               _ptr(inv), _ptr(rel), _ptr(emb), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr())
     _check(rc, "tbx_knn_embed")
     return idx, inv, rel, emb
+
+
+def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128):
+    """Several `knn_embed` searches in one launch. jobs: dicts with knn_embed's arguments (src_pose, src_invalid, tgt_pose,
+    tgt_invalid, k, dist_limit, tgt_batch_div, want_rel_pose, want_emb, out) -> list of (idx, invalid, rel_pose, emb)."""
+    outs, cj = [], (KnnJob * len(jobs))()
+    for j, q in enumerate(jobs):
+        n, S, _ = q["src_pose"].shape
+        T, k, dev = q["tgt_pose"].shape[1], q["k"], q["src_pose"].device
+        want_rel, want_emb = q.get("want_rel_pose", False), q.get("want_emb", True)
+        if q.get("out") is not None:
+            idx, inv, rel = q["out"]
+            assert idx.shape == (n, S, k) and inv.shape == (n, S, k) and (rel is not None) == want_rel
+        else:
+            idx = torch.empty(n, S, k, dtype=torch.int32, device=dev)
+            inv = torch.empty(n, S, k, dtype=torch.uint8, device=dev)
+            rel = torch.empty(n, S, k, 3, dtype=torch.float32, device=dev) if want_rel else None
+        emb = torch.empty(n, S, k, pe_dim, dtype=torch.float32, device=dev) if want_emb else None
+        cj[j] = KnnJob(_cptr(q["src_pose"], torch.float32), _cptr(q["src_invalid"], torch.uint8), _cptr(q["tgt_pose"], torch.float32),
+                       _cptr(q["tgt_invalid"], torch.uint8), _ptr(idx), _ptr(inv), _ptr(rel), _ptr(emb), n, S, T,
+                       q.get("tgt_batch_div", 1), k, float(q["dist_limit"]))
+        outs.append((idx, inv, rel, emb))
+    _check(load().tbx_knn_embed_multi(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr()), "tbx_knn_embed_multi")
+    return outs
 
 
 def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int = 0):

@@ -108,12 +108,16 @@ class AgentEncoder(nn.Module):
         # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
         kw = dict(want_rel_pose=True, want_emb=False)
         with torch.cuda.stream(aux_stream if aux_stream is not None else main):
-            i_aa, m_aa, r_aa, _ = hip.knn_embed(tok_pose, tok_inv, tok_pose, tok_inv, self.n_tgt_knn_ag2ag, self.dist_limit,
-                                                out=prep.get("_knn_aa"), **kw)
-            i_am, m_am, r_am, _ = hip.knn_embed(tok_pose, tok_inv, mp["mp_token_pose"], mp_inv, self.n_tgt_knn_ag2mp,
-                                                self.dist_limit, tgt_batch_div=mp_batch_div, out=prep.get("_knn_am"), **kw)
-            i_at, m_at, r_at, _ = hip.knn_embed(tok_pose, tok_inv, tl_pose, tl_invalid_u8, self.n_tgt_knn_ag2tl,
-                                                self.dist_limit, tgt_batch_div=tl_batch_div, out=prep.get("_knn_at"), **kw)
+            common = dict(src_pose=tok_pose, src_invalid=tok_inv, dist_limit=self.dist_limit, **kw)
+            jobs = [dict(common, tgt_pose=mp["mp_token_pose"], tgt_invalid=mp_inv, k=self.n_tgt_knn_ag2mp, tgt_batch_div=mp_batch_div,
+                         out=prep.get("_knn_am")),  # the longest search first
+                    dict(common, tgt_pose=tok_pose, tgt_invalid=tok_inv, k=self.n_tgt_knn_ag2ag, out=prep.get("_knn_aa")),
+                    dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
+                         out=prep.get("_knn_at"))]
+            if n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
+                (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs)
+            else:
+                (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = (hip.knn_embed(**q) for q in jobs)
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
                     _knn_at=(i_at, m_at, r_at))
