@@ -66,15 +66,21 @@ struct Tile {
   static constexpr int ROWS = MT > 0 ? 16 * MT : 4;  // MT = 0: the 4-row tiles of tbx_rowchain_live
   float* base;    // LDS base; BUF0 = ROWS*ldw0 floats, then BUF1 = ROWS*ldw1, then AUX = ROWS*ld_aux
   int ldw0, ldw1, ld_aux;
-  // computed, not indexed: a runtime-indexed member array would live in scratch memory
+  // computed, not indexed: a runtime-indexed member array would live in scratch memory - and so does the whole struct when
+  // the choice is written as nested ?: on the members (the optimiser turns it into a load through a selected ADDRESS, which
+  // pins the struct in scratch: a scratch round trip per stage in every EXT kernel). Mask arithmetic on the three values keeps
+  // them in SGPRs (ScratchSize 72 -> 0 in the ISA of all EXT variants but the two that spill VGPRs).
   // EXT = per-buffer widths + LINEAR-to-global (tbx_rowchain_ex); the plain layout (two ldw0-wide buffers + a 260-wide
   // auxiliary) keeps the address arithmetic of the common small-grid programs minimal (measured: 7 % on a C2 step)
   __device__ __forceinline__ float* b(int i) const {
-    if constexpr (EXT) return base + (i == 0 ? 0 : (i == 1 ? ROWS * ldw0 : ROWS * (ldw0 + ldw1)));
+    if constexpr (EXT) return base + ROWS * ((ldw0 & -(int)(i >= 1)) + (ldw1 & -(int)(i >= 2)));
     return base + (i == TBX_BUF_AUX ? 2 : i) * ROWS * ldw0;
   }
   __device__ __forceinline__ int l(int i) const {
-    if constexpr (EXT) return i == 0 ? ldw0 : (i == 1 ? ldw1 : ld_aux);
+    if constexpr (EXT) {
+      const int m1 = -(int)(i == 1), m2 = -(int)(i >= 2);
+      return (ldw0 & ~(m1 | m2)) | (ldw1 & m1) | (ld_aux & m2);
+    }
     return i == TBX_BUF_AUX ? TBX_AUX_LD : ldw0;
   }
   int64_t g0;      // first global row of the tile
