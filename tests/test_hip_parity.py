@@ -434,8 +434,9 @@ def test_live_row_chain_is_bit_identical_to_mfma_tiles(tb, live, rows):
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("S", [33, 1030])  # 1030: n * S >= 1024 rows -> the wave-per-row form (4 rows per workgroup, ragged tail)
 @pytest.mark.parametrize("bf16", [False, True])
-def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16):
+def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16, S):
     """tbx_knarpe_attn_fwd_folded (the value half of linear_rpe applied in the attention kernel's epilogue, 128 floats per row
     out) vs tbx_knarpe_attn_fwd's 640-wide row followed by the grouped LINEAR stage that applied the fold so far: bit-identical
     (same fma order), rows without a valid target flagged the same - for a one-segment and a two-segment call."""
@@ -444,7 +445,7 @@ def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16):
     M = import_module("trafficbots_amd.models.modules")
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
-    n, S, T, K, d = 2, 33, 60, 13, 128
+    n, T, K, d = 2, 60, 13, 128
     att = M.attention_rpe.AttentionRPE(d_model=d, n_head=4, dropout_p=0.0, d_rpe=d)
     tb.utils.det_fill(att, 15)
     att = att.to(dev)

@@ -64,12 +64,11 @@ struct AttnArgs {
 constexpr int FOLD_ROWS = 1 + (DR / 16) * 4;  // float4 rows of the value-fold image: a bias row + 32 weight rows of [128][4]
 
 template <int WPR, bool DROP, bool KV16 = false, bool FOLD = false>
-__global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
   __shared__ __attribute__((aligned(16))) float fold_s[FOLD ? FOLD_ROWS * D * 4 : 4];  // 66 KiB: the fold image, by LDS-DMA
-  __shared__ float comb_s[FOLD ? OUTW : 1];
-  static_assert(!FOLD || WPR == 4, "the folded epilogue belongs to the 4-waves-per-row form");
+  __shared__ __attribute__((aligned(16))) float comb_s[FOLD ? (WPR == 1 ? 4 : 1) * OUTW : 1];  // WPR == 1: the workgroup's 4 rows
   if constexpr (FOLD) {
     // the image is requested first and lands while the targets are swept: 1 KiB per wave instruction, straight into LDS (asm:
     // the compiler would order every later LDS read behind a DMA it knows of - see csrc/rowchain.hip gemv_dma)
@@ -82,8 +81,17 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   const int wave = threadIdx.x >> 6;
   const int rib = wave / WPR;
   const int wir = wave % WPR;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * RPB + rib);  // a wave works on one row: keep it in an SGPR
-  if (row >= a.n_rows) return;  // uniform per row group (and per workgroup when WPR == 4)
+  // The wave-per-row folded form walks row quads blockIdx.x, blockIdx.x + gridDim.x, ... (the launch has at most 2 workgroups per
+  // CU): the 66 KiB fold image is fetched once per workgroup, not once per 4 rows. Every other form: one pass, quad = blockIdx.x.
+  constexpr bool LOOP = FOLD && WPR == 1;
+  const int n_quads = LOOP ? (a.n_rows + 3) / 4 : 0;
+  for (int quad = blockIdx.x; quad == (int)blockIdx.x || (LOOP && quad < n_quads); quad += gridDim.x) {
+  int row = __builtin_amdgcn_readfirstlane(quad * RPB + rib);  // a wave works on one row: keep it in an SGPR
+  if constexpr (LOOP) {
+    row = row < a.n_rows ? row : a.n_rows - 1;  // the folded epilogue has workgroup barriers: a spare wave repeats the last row
+  } else {
+    if (row >= a.n_rows) return;  // uniform per row group (and per workgroup when WPR == 4)
+  }
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
 
@@ -111,7 +119,55 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
   float4(&oacc)[NH] = st.oacc;
   ESlice(&eacc)[NH] = st.eacc;
   float* orow = a.out + (int64_t)row * a.ldo;
-  if constexpr (WPR == 1) {
+  if constexpr (WPR == 1 && FOLD) {
+    // a wave per row, 4 rows per workgroup: the normalised row goes to LDS, then thread (c = tid & 127, r0 = tid >> 7) runs the
+    // value fold of output column c for rows r0 and r0 + 2 (one read of the weight image for both) - the same k-ordered v_fma
+    // chain as the 4-waves-per-row form below and as the LINEAR stage it replaces: 128 floats per row leave the kernel
+    const bool any_valid = M[0] > -INFINITY;
+    if (tg == 0) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
+        float4 o = oacc[h];
+        scale4(o, inv_l);
+        *(float4*)(&comb_s[rib * OUTW + h * DH + s8 * 4]) = o;
+        ESlice ev = eacc[h];
+        ev.scale(inv_l);
+        ev.store(&comb_s[rib * OUTW + D + h * DR], s8);
+      }
+    }
+    if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the fold image have landed
+    __syncthreads();
+    const int c = threadIdx.x & (D - 1), r0 = threadIdx.x >> 7, h = c / DH;
+    const float4* wq = (const float4*)fold_s + c;  // row r of the image: wq[r * 128]
+    const float* e0 = comb_s + r0 * OUTW + D + h * DR;
+    const float* e1 = e0 + 2 * OUTW;
+    float acc0 = fold_s[c * 4] + comb_s[r0 * OUTW + c], acc1 = fold_s[c * 4] + comb_s[(r0 + 2) * OUTW + c];
+    const float4* e04 = (const float4*)e0;  // comb_s rows are 16-byte aligned (OUTW, D, DR multiples of 4)
+    const float4* e14 = (const float4*)e1;
+#pragma unroll 2
+    for (int kb = 0; kb < DR / 16; ++kb) {
+      // the 16 activations of the k-block as 4 broadcast ds_read_b128 per row (element [g*4 + t] multiplies W[c][kb*16 + g*4 + t])
+      const float4 x0 = e04[kb * 4], x1 = e04[kb * 4 + 1], x2 = e04[kb * 4 + 2], x3 = e04[kb * 4 + 3];
+      const float4 y0 = e14[kb * 4], y1 = e14[kb * 4 + 1], y2 = e14[kb * 4 + 2], y3 = e14[kb * 4 + 3];
+      const float4 w0 = wq[(1 + kb * 4) * D], w1 = wq[(2 + kb * 4) * D], w2 = wq[(3 + kb * 4) * D], w3 = wq[(4 + kb * 4) * D];
+#define TBX_FOLD_STEP(W, XC)                                                                              \
+  acc0 = __builtin_fmaf(x0.XC, W.x, acc0); acc1 = __builtin_fmaf(y0.XC, W.x, acc1);                       \
+  acc0 = __builtin_fmaf(x1.XC, W.y, acc0); acc1 = __builtin_fmaf(y1.XC, W.y, acc1);                       \
+  acc0 = __builtin_fmaf(x2.XC, W.z, acc0); acc1 = __builtin_fmaf(y2.XC, W.z, acc1);                       \
+  acc0 = __builtin_fmaf(x3.XC, W.w, acc0); acc1 = __builtin_fmaf(y3.XC, W.w, acc1)
+      TBX_FOLD_STEP(w0, x);
+      TBX_FOLD_STEP(w1, y);
+      TBX_FOLD_STEP(w2, z);
+      TBX_FOLD_STEP(w3, w);
+#undef TBX_FOLD_STEP
+    }
+    const int64_t ra = (int64_t)quad * 4 + r0, rb = ra + 2;
+    if (ra < a.n_rows) a.out[ra * a.ldo + c] = acc0;
+    if (rb < a.n_rows) a.out[rb * a.ldo + c] = acc1;
+    __syncthreads();  // comb_s is rewritten by the next quad
+  } else if constexpr (WPR == 1) {
     const bool any_valid = M[0] > -INFINITY;  // masks are per target, so every head sees the same validity
     if (tg == 0) {
 #pragma unroll
@@ -200,6 +256,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_kernel(const AttnArgs a) {
     }
     if (threadIdx.x == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
   }
+  }  // quad loop
 }
 
 // =====================================================================================================================
@@ -539,6 +596,26 @@ int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t d
 }
 }  // namespace
 
+static int fold_grid_max() {  // 2 workgroups (78 KiB of LDS each) per CU
+  static const int g = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("TBX_FOLD_WG_PER_CU");
+    const int per = e && atoi(e) > 0 ? atoi(e) : 2;
+    return per * (cus > 0 ? cus : 256);
+  }();
+  return g;
+}
+
+static int attn_big_rows() {
+  static const int big_rows = [] {
+    const char* e = getenv("TBX_ATTN_BIG_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1024;  // measured at 1024 rows x 89 pairs (training's stepping pass): 28 us with 4 waves per row, ~24 us with one
+  }();
+  return big_rows;
+}
+
 extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
                                               int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo,
                                               uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
@@ -553,12 +630,7 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   if (rc != TBX_OK) return rc;
   a.out = out;
   a.row_no_valid = row_no_valid;
-  static const int big_rows = [] {
-    const char* e = getenv("TBX_ATTN_BIG_ROWS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 1024;  // measured at 1024 rows x 89 pairs (training's stepping pass): 28 us with 4 waves per row, ~24 us with one
-  }();
-  const bool big = a.n_rows >= big_rows;  // a wave per row from here on (below: 4 waves split a row's targets)
+  const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
   if (segs[0].kv_bf16 != 0) {  // bf16 K/V tables: inference only
@@ -595,11 +667,21 @@ extern "C" int tbx_knarpe_attn_fwd_folded(const float* qbuf, int ldq, int q_off,
   a.out = out;
   a.row_no_valid = row_no_valid;
   a.fold_img = fold_image;
-  const dim3 grid(a.n_rows), block(256);
-  if (segs[0].kv_bf16 != 0)
-    hipLaunchKernelGGL((knarpe_attn_kernel<4, false, true, true>), grid, block, 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((knarpe_attn_kernel<4, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+  const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on, 4 rows per workgroup
+  const int quads = (a.n_rows + 3) / 4;
+  const dim3 grid(big ? (quads < fold_grid_max() ? quads : fold_grid_max()) : a.n_rows), block(256);
+  hipStream_t hs = (hipStream_t)stream;
+  if (segs[0].kv_bf16 != 0) {
+    if (big)
+      hipLaunchKernelGGL((knarpe_attn_kernel<1, false, true, true>), grid, block, 0, hs, a);
+    else
+      hipLaunchKernelGGL((knarpe_attn_kernel<4, false, true, true>), grid, block, 0, hs, a);
+  } else {
+    if (big)
+      hipLaunchKernelGGL((knarpe_attn_kernel<1, false, false, true>), grid, block, 0, hs, a);
+    else
+      hipLaunchKernelGGL((knarpe_attn_kernel<4, false, false, true>), grid, block, 0, hs, a);
+  }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

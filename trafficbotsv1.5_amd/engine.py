@@ -61,9 +61,14 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     return nq + NH * D
 
 
-# Small launches: the attention kernel applies the value half of linear_rpe in its epilogue (tbx_knarpe_attn_fwd_folded): 128
-# floats per row leave it instead of 640 and the grouped fold stage of the following chain disappears. TBX_ATTN_FOLD=0: off.
+# Inference: the attention kernel applies the value half of linear_rpe in its epilogue (tbx_knarpe_attn_fwd_folded): 128 floats
+# per row leave it instead of 640 and the grouped fold stage of the following chain disappears. TBX_ATTN_FOLD=0: off.
 ATTN_FOLD = os.environ.get("TBX_ATTN_FOLD", "1") != "0"
+# The wave-per-row form of the kernel (>= 1024 rows) has the folded epilogue too (4 rows per workgroup share the fold image, a
+# workgroup walks several row quads). Measured at the WOSAC shape (4096 rows x 104 pairs): 52.2 us per launch instead of 46.3
+# (the 4 waves of a workgroup meet at a barrier and run two 128-long fma chains each), the following chain 39.8 us instead of
+# 42.4: 1.159 ms per step instead of 1.143. 10.5 -> 2.1 MB written per launch, but not faster: off unless TBX_ATTN_FOLD_BIG=1.
+ATTN_FOLD_BIG = os.environ.get("TBX_ATTN_FOLD_BIG", "0") == "1"
 
 
 # ... and a dec_cross_attn layer's [self attention -> out-proj -> LN -> q -> W_k^T q -> cross attention] runs as ONE launch
@@ -279,7 +284,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
     qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
     kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
-    fold = ATTN_FOLD and drop is None and DROP_CTX is None and bool(live_rows_for(rows))
+    fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
     layers = list(block.layers)
@@ -300,7 +305,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     ch.run(rows)
     if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
-    mid = fold and dec and DEC_MID
+    mid = fold and dec and DEC_MID and bool(live_rows_for(rows))  # the one-launch attention half: small launches only
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
