@@ -49,6 +49,11 @@ struct AttnArgs {
   // tbx_knarpe_attn_fwd_folded: the tbx_pack_weight_gemv image of linear_rpe's value half (4 groups x 32 outputs, k = 128):
   // the epilogue then forms (sum a v)_h + W_rpe_v,h (sum a e)_h + b_rpe_v,h itself and stores 128 floats per row instead of 640
   const float* fold_img;
+  // wave-per-row form: the 4 rows of a workgroup are the SAME source token in 4 consecutive batch entries (row = (4*(quad / n_src)
+  // + wave) * n_src + quad % n_src) instead of 4 consecutive tokens of one entry. Rollouts of a scene share the map and light
+  // K/V tables and an agent's K-nearest sets barely differ between rollouts, so the workgroup's waves gather the same table rows
+  // at about the same time (one L2 fetch, three L1 hits). Set when n_batch % 4 == 0 and a segment is shared (batch_div > 1).
+  int batch_major;
 };
 
 
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int n_quads = LOOP ? (a.n_rows + 3) / 4 : 0;
   for (int quad = blockIdx.x; quad == (int)blockIdx.x || (LOOP && quad < n_quads); quad += gridDim.x) {
   int row = __builtin_amdgcn_readfirstlane(quad * RPB + rib);  // a wave works on one row: keep it in an SGPR
+  if (WPR == 1 && a.batch_major) row = __builtin_amdgcn_readfirstlane((4 * (quad / a.n_src) + rib) * a.n_src + quad % a.n_src);
   if constexpr (LOOP) {
     row = row < a.n_rows ? row : a.n_rows - 1;  // the folded epilogue has workgroup barriers: a spare wave repeats the last row
   } else {
@@ -163,7 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       TBX_FOLD_STEP(w3, w);
 #undef TBX_FOLD_STEP
     }
-    const int64_t ra = (int64_t)quad * 4 + r0, rb = ra + 2;
+    int64_t ra = (int64_t)quad * 4 + r0, rb = ra + 2;
+    if (a.batch_major) {
+      ra = (int64_t)(4 * (quad / a.n_src) + r0) * a.n_src + quad % a.n_src;
+      rb = ra + 2 * (int64_t)a.n_src;
+    }
     if (ra < a.n_rows) a.out[ra * a.ldo + c] = acc0;
     if (rb < a.n_rows) a.out[rb * a.ldo + c] = acc1;
     __syncthreads();  // comb_s is rewritten by the next quad
@@ -572,6 +582,10 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
   a.scale = 1.0f / sqrtf((float)DH);
   a.scale2 = 1.4426950408889634f / sqrtf((float)DH);
   a.fold_img = nullptr;
+  static const bool bm_env = [] { const char* e = getenv("TBX_ATTN_BATCH_MAJOR"); return !(e && e[0] == '0'); }();
+  bool shared = false;
+  for (int i = 0; i < n_seg; ++i) shared = shared || segs[i].batch_div > 1;
+  a.batch_major = (bm_env && shared && n_batch % 4 == 0) ? 1 : 0;
   return TBX_OK;
 }
 

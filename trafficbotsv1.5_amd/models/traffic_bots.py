@@ -105,10 +105,9 @@ class TrafficBots(nn.Module):
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
-                                            aux_stream=aux_stream)
+                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe)
         out["prep"], out["ag_feat"] = prep, feat
-        rp = self.pose_rpe
-        navi_pe = hip.pose_embed(prep["navi_pose3"], rp.pe_xy.freqs, rp.pe_yaw.freqs, rp.out_dim)
+        navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
         rc = rollout_consts or {}

@@ -50,6 +50,7 @@ def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
 
 class RolloutEngine:
     lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
+    GRAPH_STEPS = max(1, int(os.environ.get("TBX_GRAPH_STEPS", "4")) // 2 * 2)  # steps per multi-step graph (even; 1: off)
     # The light recurrence (window -> light encoder -> argmax of the next-state logits, dynamics.py:143-163) reads no agent and
     # no latent, so the K rollouts of a scene (joint_future_pred, waymo_motion.py:458-462) carry K identical copies of it: with
     # share_lights the engine steps the lights once per scene and the agents of the K rollouts attend to that one copy
@@ -72,6 +73,7 @@ class RolloutEngine:
     def __init__(self, model, dynamics, device) -> None:
         self.model, self.dyn, self.dev = model, dynamics, device
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_multi: Optional[torch.cuda.CUDAGraph] = None
 
     # ------------------------------------------------------------------ setup
     @torch.no_grad()
@@ -178,7 +180,7 @@ class RolloutEngine:
             stl.n_batch = nl
             self.sim_state_tl = stl
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
-        self.graph = None
+        self.graph = self.graph_multi = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
         self.side, self.aux = self._side_streams(dev)
@@ -247,6 +249,16 @@ class RolloutEngine:
             with torch.cuda.graph(g):
                 self.step()
             graphs.append(g)
+        # ... and GRAPH_STEPS consecutive steps as one graph (starting at parity 0): a replay boundary costs ~9 us of idle device
+        # (the next graph's first kernel starts that long after the last one's last), a kernel boundary inside a graph ~1 us
+        self.graph_multi = None
+        if self.GRAPH_STEPS > 1:
+            self.parity = 0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(self.GRAPH_STEPS):
+                    self.step()
+            self.graph_multi = g
         self.parity = 0
         self.graph = graphs
 
@@ -255,12 +267,18 @@ class RolloutEngine:
         n_steps = self.T if n_steps is None else n_steps
         if use_graph and self.graph is None:
             self.capture()
-        for _ in range(n_steps):
-            if use_graph:
+        done = 0
+        while done < n_steps:
+            if not use_graph:
+                self.step()
+                done += 1
+            elif self.graph_multi is not None and n_steps - done >= self.GRAPH_STEPS and self.parity % len(self.graph) == 0:
+                self.graph_multi.replay()  # an even number of steps: the parity is back where it was
+                done += self.GRAPH_STEPS
+            else:
                 self.graph[self.parity % len(self.graph)].replay()
                 self.parity = 1 - self.parity
-            else:
-                self.step()
+                done += 1
 
     # ------------------------------------------------------------------ step-wise driving (WaymoMotion.forward)
     @torch.no_grad()
