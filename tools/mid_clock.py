@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Phase timing inside tbx_knarpe_dec_mid (profiling build libtbx_hip_clk.so: `make -C trafficbotsv1.5_amd/csrc clk`): workgroup 0
+stamps the shader clock at the phase boundaries of every launch of one eager simulation step.
+    python tools/mid_clock.py [bench.py rollout args]"""
+import ctypes as C
+import os
+import sys
+from importlib import import_module
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ["TBX_HIP_LIB"] = str(ROOT / "trafficbotsv1.5_amd" / "csrc" / "libtbx_hip_clk.so")
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+PH = ["prologue (DMA requests, x, LN params, q loads)", "self sweep + slot merge", "combine + value fold",
+      "out_proj GEMV (+ W_q request)", "LayerNorm (+ W_kf request)", "wait for W_q", "q GEMV", "W_k^T q GEMV",
+      "cross sweep + slot merge", "combine + value fold + stores"]
+
+
+def main():
+    sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-graph"] + sys.argv[1:]
+    args = bench.parse()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    tb = load_package()
+    hip = import_module("trafficbots_amd.hip")
+    lib = hip.load()
+    lib.tbx_debug_mid_dump.argtypes = [C.c_void_p, C.c_int]
+    wm, full = bench.build(tb, args, dev, 0)
+    eng, _ = bench.gpu_rollout_setup(tb, wm, full, args, dev)
+    type(eng).lights_ahead = False
+    eng.run(args.warmup + 3, use_graph=False)
+    torch.cuda.synchronize()
+    buf = (C.c_uint64 * (256 * 16))()
+    lib.tbx_debug_mid_dump(buf, 256)  # reset
+    eng.run(1, use_graph=False)
+    torch.cuda.synchronize()
+    n = lib.tbx_debug_mid_dump(buf, 256)
+    for i in range(n):
+        c = buf[i * 16:(i + 1) * 16]
+        d = [(c[j + 1] - c[j]) / 100.0 for j in range(10)]  # clock64 = s_memtime: 100 MHz on gfx950
+        print(f"launch {i}: {sum(d):6.2f} us in workgroup 0")
+        for name, v in zip(PH, d):
+            print(f"    {name:70s} {v:6.2f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -239,20 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       __syncthreads();
       if (threadIdx.x < D) {
         const int c = threadIdx.x, h = c / DH;
-        const float4* wq = (const float4*)fold_s + c;  // row r of the image: wq[r * 128]
-        const float* e = comb_s + D + h * DR;
-        float acc = fold_s[c * 4] + comb_s[c];
-#pragma unroll 2
-        for (int kb = 0; kb < DR / 16; ++kb) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float4 w4v = wq[(1 + kb * 4 + t) * D];
-            acc = __builtin_fmaf(e[kb * 16 + t], w4v.x, acc);
-            acc = __builtin_fmaf(e[kb * 16 + 4 + t], w4v.y, acc);
-            acc = __builtin_fmaf(e[kb * 16 + 8 + t], w4v.z, acc);
-            acc = __builtin_fmaf(e[kb * 16 + 12 + t], w4v.w, acc);
-          }
-        }
+        const float acc = gemv_chain(fold_s, c, comb_s + D + h * DR, DR / 16, fold_s[c * 4] + comb_s[c]);
         orow[c] = acc;
       }
     } else {

@@ -13,6 +13,7 @@
 // csrc/rowchain.hip linear_gemv) - every number equals the three-launch path's bit for bit (tested), the row never leaves the CU
 // between the two attentions, and q / W_k^T q / the first attention's output make no round trip through global memory.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/tbx_hip.h"
@@ -47,28 +48,21 @@ struct MidArgs {
   int ld_qkv, q_off, qt_off, ld_out2, n_rows, n_src;
 };
 
+#ifdef TBX_STAGE_CLOCK
+__device__ unsigned long long g_mid_clk[256 * 16];
+__device__ unsigned int g_mid_launch;
+#define MID_CLK(i)                                                                                     \
+  do {                                                                                                 \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mid_slot < 256u) g_mid_clk[mid_slot * 16 + (i)] = clock64(); \
+  } while (0)
+#else
+#define MID_CLK(i)
+#endif
+
 // image `img` (n_pieces KiB) -> LDS `slot`, piece p by wave p % 4
 __device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane) {
   const uint32_t lds0 = lds_addr(slot);
   for (int p = wave; p < n_pieces; p += 4) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
-}
-
-// One output of a LINEAR stage as the k-ordered fma chain of the packed MFMA path: column `c` of the 128-column block at `blk`
-// (row 0 = bias, row 1 + kb*4 + t = weights of k = kb*16 + {0,4,8,12} + t), inputs x[0 .. kblocks*16).
-__device__ __forceinline__ float gemv_chain(const float* blk, int c, const float* x, int kblocks, float acc) {
-  const float4* wq = (const float4*)blk + c;
-#pragma unroll 2
-  for (int kb = 0; kb < kblocks; ++kb) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float4 w = wq[(1 + kb * 4 + t) * D];
-      acc = __builtin_fmaf(x[kb * 16 + t], w.x, acc);
-      acc = __builtin_fmaf(x[kb * 16 + 4 + t], w.y, acc);
-      acc = __builtin_fmaf(x[kb * 16 + 8 + t], w.z, acc);
-      acc = __builtin_fmaf(x[kb * 16 + 12 + t], w.w, acc);
-    }
-  }
-  return acc;
 }
 
 // The stand-alone kernel's epilogue for 4 waves per row with the value fold (attn.hip, FOLD): per-wave partials -> red_s, the
@@ -137,6 +131,11 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wir = wave;
   const int row = blockIdx.x;
+#ifdef TBX_STAGE_CLOCK
+  unsigned mid_slot = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) mid_slot = atomicAdd(&g_mid_launch, 1u);
+#endif
+  MID_CLK(0);
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
   dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane);
@@ -149,6 +148,10 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     ln_g[0] = a.ln_w[lane], ln_g[1] = a.ln_w[64 + lane];
     ln_bt[0] = a.ln_b[lane], ln_bt[1] = a.ln_b[64 + lane];
   }
+  // ... and so is the cross attention's rpe_k_bias slice (its q . b_k term)
+  float4 bk2[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) bk2[h] = *(const float4*)(a.bias_k2 + h * DH + s8 * 4);
   EFreq fq;
   fq.init(a.fxy, a.fyaw, s8);
   float4 qv[NH];
@@ -166,21 +169,19 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     }
   }
   bool valid1;
+  MID_CLK(1);
   {
     RowAcc st;
     st.zero();
     sweep<4, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
     float M[NH], L[NH];
     merge_slots(st, M, L);
+    MID_CLK(2);
     const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid1);
     if (threadIdx.x < D) o1[threadIdx.x] = f;
   }
   __syncthreads();  // o1 complete; slot A (fold1) is free
-  // the cross attention's q . b_k term needs rpe_k_bias: requested before the next image (see ln_g above)
-  float4 bk2[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) bk2[h] = *(const float4*)(a.bias_k2 + h * DH + s8 * 4);
-  asm volatile("" : "+v"(bk2[0].x), "+v"(bk2[1].x), "+v"(bk2[2].x), "+v"(bk2[3].x));  // keep the loads here
+  MID_CLK(3);
   dma_image(a.wq, IMG128 / 256, slot_a, wave, lane);
   // ---------------------------------------------------------------- x += no valid target ? 0 : out_proj(o1)   (W_o landed: waited in combine_fold)
   if (threadIdx.x < D) {
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     if (valid1) xs[c] = v;
   }
   __syncthreads();  // xs updated; slot B (W_o) is free
+  MID_CLK(4);
   dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane);
   // ---------------------------------------------------------------- LN_1(x) -> o1 (one wavefront, the chain's ln_row<2> order)
   if (wave == 0) {
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     for (int q = 0; q < 2; ++q) o1[lane + 64 * q] = (v[q] - mean) * rstd * ln_g[q] + ln_bt[q];
   }
   // W_q has landed once at most the 18 pieces per wave of the image requested after it are outstanding (DMA loads only: in order)
+  MID_CLK(5);
   asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   __syncthreads();
+  MID_CLK(6);
   // ---------------------------------------------------------------- q = W_q LN(x) + b_q
   if (threadIdx.x < D) {
     const int c = threadIdx.x;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the query-side fold image has landed
   __syncthreads();  // q2 complete; slot A (W_q) is free
+  MID_CLK(7);
   // ---------------------------------------------------------------- qt_h = W_rpe_k,h^T q_h: 4 x (32 -> 128), two outputs per thread
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     qt2[o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
   }
   __syncthreads();
+  MID_CLK(8);
   dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane);  // lands during the sweep
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     sweep<4, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
     float M[NH], L[NH];
     merge_slots(st, M, L);
+    MID_CLK(9);
     bool valid2;
     const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid2);
     if (threadIdx.x < D) {
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
       a.x[(int64_t)row * D + threadIdx.x] = xs[threadIdx.x];  // the token row after the self-attention residual
     }
     if (threadIdx.x == 0) a.flag2[row] = valid2 ? 0 : 1;
+    MID_CLK(10);
   }
 }
 
@@ -310,3 +318,15 @@ extern "C" int tbx_knarpe_dec_mid(const tbx_dec_mid_t* p, void* stream) {
   }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
+
+#ifdef TBX_STAGE_CLOCK
+extern "C" int tbx_debug_mid_dump(unsigned long long* host_out, int max_launches) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mid_launch), sizeof(n)) != hipSuccess) return -1;
+  const int m = (int)n < max_launches ? (int)n : max_launches;
+  if (m > 0 && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mid_clk), (size_t)m * 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_launch), &z, sizeof(z));
+  return m;
+}
+#endif
