@@ -94,6 +94,24 @@ def pmc_traffic(args, kernel: str):
     return None, None
 
 
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate
+
+
+def attn_counters(args):
+    """VALU-busy / L2 figures of the attention kernel from the committed counter passes (profiles/*attn_counters*.json, collected by
+    tools/pmc_attn.sh at the WOSAC shape) - attached only to that workload's roofline object."""
+    import glob
+
+    if (args.agents, args.rollouts, args.scenes) != (128, 32, 1):
+        return None
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*attn_counters*.json")), reverse=True):
+        d = json.load(open(f))
+        if "valu_busy" in d:
+            return {"valu_busy": d["valu_busy"], "l2_hit_rate": d.get("l2_hit_rate"), "l2_read_requests_per_launch": d.get("l2_read_requests"),
+                    "counters_source": Path(f).name, "counters_measured": False}
+    return None
+
+
 def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int, b: int = 4) -> float:
     """S*2*d*b + P*(2*d*b + 12 + 4 + 1) + (d_rpe*2d + 2d)*b, d = d_rpe = 128; b = 4 (fp32 tables: 1041 B per pair)
     or 2 (bfloat16 K/V tables: 529 B per pair)."""
@@ -385,6 +403,9 @@ def main():
         traffic, traffic_src = pmc_traffic(a, variant)
         if traffic is None:
             traffic, traffic_src = pmc_traffic(a, "knarpe_attn_kernel")
+        cnt = attn_counters(a)
+        if cnt and cnt.get("l2_read_requests_per_launch"):  # 128-byte L1 -> L2 read requests of a launch over its live duration
+            cnt["l2_request_frac"] = cnt["l2_read_requests_per_launch"] * 128.0 / (t_dom / n_dom) / 1e9 / L2_PEAK_GBS
         res = {
             "value": units / dt, "ms_per_step": dt / a.steps * 1e3,
             "config": {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
@@ -395,6 +416,9 @@ def main():
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured": False,  # PMC passes are separate rocprofv3 runs: the committed profile of this workload
+                         # the kernel's table rows are served by L2 / L1 (rollouts share them), so next to the HBM fraction: the
+                         # same algorithmic bytes against the aggregate L2 bandwidth, and (WOSAC shape) the measured VALU-busy
+                         "l2_frac": ach / L2_PEAK_GBS, "l2_peak": L2_PEAK_GBS,
                          "bytes_per_pair": 529 if a.kv_bf16 else 1041,
                          "launches_per_step": n_dom / a.profile_steps, "avg_launch_us": t_dom / n_dom * 1e6,
                          "algorithmic_bytes_per_launch": b_dom / n_dom, "source_rows_per_launch": rows_dom,
@@ -403,6 +427,7 @@ def main():
             "roofline_gemm": {"kernel": "rowchain_kernel", "bound": "mfma", "achieved": f_chain / t_chain / 1e12,
                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f_chain / t_chain / 1e12 / FP32_MFMA_PEAK_TF,
                               "launches_per_step": n_chain / a.profile_steps, "avg_launch_us": t_chain / n_chain * 1e6},
+            "attention_counters": cnt,  # None unless the committed counter passes are of this workload
             "fused_decoder_mid": mid_stats,  # None: the three-launch schedule ran in the timed region too
             "scene_encode_ms": t_scene * 1e3,
             # SURVEY §8d "end-to-end": the once-per-scene work (map encoder, traffic-light pre-compute, table packing; this
