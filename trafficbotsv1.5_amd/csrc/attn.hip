@@ -69,7 +69,7 @@ struct AttnArgs {
 constexpr int FOLD_ROWS = 1 + (DR / 16) * 4;  // float4 rows of the value-fold image: a bias row + 32 weight rows of [128][4]
 
 template <int WPR, bool DROP, bool KV16 = false, bool FOLD = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void knarpe_attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 2 : 1))) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
   __shared__ __attribute__((aligned(16))) float fold_s[FOLD ? FOLD_ROWS * D * 4 : 4];  // 66 KiB: the fold image, by LDS-DMA

@@ -178,121 +178,75 @@ struct RowAcc {
   }
 };
 
-// One pass of a wavefront over 8 targets of a segment (lane group tg = target slot, s8 = channel slice): what it reads...
-struct PassData {
-  float4 kq[NH], v[NH];  // the lane's K and V channel slices of its target's table row (block st == head st)
-  ESlice e;              // its slice of the pair's pose embedding
-  float rel[3];          // the pair's relative pose (segments given as relative poses: e is rebuilt from it)
-  int j;                 // the target's table row
-  uint8_t masked;        // the pair's mask byte as loaded (compared where it is used: a compare here would be a wait here)
-  bool active;           // the slot is inside the segment (t < k)
-  int t;                 // target slot within the segment
-  // the slot holds a valid, unmasked target (uniform within the 8-lane group; both sides evaluated: no branch)
-  __device__ __forceinline__ bool ok() const { return (masked == 0) & active; }
-};
-// ... gathered in two dependent steps, neither of which needs the query side - a caller may issue them long before it has the query
-// (csrc/dec_mid.hip does, for the cross attention): (a) the pair's index, mask and relative pose (or materialised embedding),
-template <bool KV16>
-__device__ __forceinline__ void gather_index(const tbx_attn_seg_t& S, int row, int base, int s8, int tg, PassData& d) {
-  const int64_t pbase = (int64_t)row * S.k;
-  const int t = base + tg;
-  const bool active = t < S.k;
-  const int64_t pi = pbase + (active ? t : S.k - 1);
-  d.j = S.idx[pi];
-  d.masked = S.invalid[pi];
-  d.active = active;
-  d.t = t;
-  if (S.emb != nullptr) {
-    d.e.load(S.emb + pi * DR, s8);
-  } else {
-    d.rel[0] = S.rel_pose[pi * 3], d.rel[1] = S.rel_pose[pi * 3 + 1], d.rel[2] = S.rel_pose[pi * 3 + 2];
-  }
-}
-// (b) the K / V slices of table row j, and the embedding rebuilt in registers.
-template <bool KV16>
-__device__ __forceinline__ void gather_rows(const tbx_attn_seg_t& S, int b, int s8, const EFreq& fq, PassData& d) {
-  // (bf16 tables: element offsets, half the bytes - the pointer is kept as float* and scaled by hand)
-  constexpr int ES = KV16 ? 2 : 1;  // table elements per float slot
-  const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-  const float* trow = (const float*)((const char*)kvb + ((int64_t)d.j * S.ld_kv) * (4 / ES));
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    d.kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
-    d.v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
-  }
-  if (S.emb == nullptr) fq.embed(d.rel, d.e);
-}
-template <bool KV16>
-__device__ __forceinline__ void gather_pass(const tbx_attn_seg_t& S, int row, int b, int base, int s8, int tg, const EFreq& fq,
-                                            PassData& d) {
-  gather_index<KV16>(S, row, base, s8, tg, d);
-  gather_rows<KV16>(S, b, s8, fq, d);
-}
-
-// ... and what it adds to the slot's online-softmax state. `a` supplies scale2 and (DROP) the dropout fields; t_off = global slot
-// of the segment's first target (the dropout counter).
-template <bool DROP, class A>
-__device__ __forceinline__ void accumulate_pass(const A& a, const PassData& d, int t_off, const DropKey& dk, const float4 (&qv)[NH],
-                                                const ESlice (&qt)[NH], const float (&qb)[NH], RowAcc& st) {
+// The target sweep of wavefront `wir` of the WPR that share source row `row` (batch entry b): segment by segment, 8 targets per
+// pass, starting at target wir * 8 with stride 8 * WPR. `a` supplies seg[], n_seg, scale2 and (DROP) the dropout fields.
+template <int WPR, bool DROP, bool KV16, class A>
+__device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s8, int tg, const float4 (&qv)[NH],
+                                      const ESlice (&qt)[NH], const float (&qb)[NH], const EFreq& fq, RowAcc& st) {
   float(&m_run)[NH] = st.m_run;
   float(&l_run)[NH] = st.l_run;
   float4(&oacc)[NH] = st.oacc;
   ESlice(&eacc)[NH] = st.eacc;
-  const bool ok = d.ok();
-  // Online softmax in the base-2 domain (scores pre-multiplied by log2(e) / sqrt(d_head), v_exp_f32 directly) with a
-  // LAZY reference: a slot's reference m is its first valid score and moves only when a later score exceeds it by more
-  // than 64 (2^64 headroom in fp32; a wave-uniform, practically never taken branch). The steady state has no
-  // rescaling of the 80 accumulator registers: ~18 % fewer VALU instructions in a loop that is VALU-issue bound.
-  float sc[NH];
-  bool jump = false;
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    sc[h] = (tbx::group8_sum(dot4(d.kq[h], qv[h]) + d.e.dot(qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
-    jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
-  }
-  if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
-        l_run[h] *= alpha;
-        scale4(oacc[h], alpha);
-        eacc[h].scale(alpha);
-        m_run[h] = sc[h];
-      }
-    }
-  }
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];  // the slot's first valid target sets the reference
-    const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
-    l_run[h] += pr;  // the normaliser is that of the un-dropped softmax
-    float pd = pr;
-    if constexpr (DROP) pd = dk.keep((uint32_t)(t_off + d.t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
-    fma4(oacc[h], pd, d.v[h]);  // K/V channel block st == h belongs to head h
-    eacc[h].fma(pd, d.e);
-  }
-}
-
-// The target sweep of wavefront `wir` of the WPR that share source row `row` (batch entry b): segment by segment, 8 targets per
-// pass, starting at target wir * 8 with stride 8 * WPR. `a` supplies seg[], n_seg, scale2 and (DROP) the dropout fields.
-// first_pass: passes before it were (or will be) done by the caller (gather_pass / accumulate_pass in the same order).
-template <int WPR, bool DROP, bool KV16, class A>
-__device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s8, int tg, const float4 (&qv)[NH],
-                                      const ESlice (&qt)[NH], const float (&qb)[NH], const EFreq& fq, RowAcc& st, int first_pass = 0) {
   DropKey dk;
   if constexpr (DROP) dk.init(a, row, b);
   int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
-  int pass = 0;
   for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
-    for (int base = wir * 8; base < S.k; base += 8 * WPR, ++pass) {
-      if (pass < first_pass) continue;
-      PassData d;
-      gather_pass<KV16>(S, row, b, base, s8, tg, fq, d);
-      accumulate_pass<DROP>(a, d, t_off, dk, qv, qt, qb, st);
+    // (bf16 tables: element offsets, half the bytes - the pointer is kept as float* and scaled by hand)
+    constexpr int ES = KV16 ? 2 : 1;  // table elements per float slot
+    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
+    const int64_t pbase = (int64_t)row * S.k;
+    for (int base = wir * 8; base < S.k; base += 8 * WPR) {
+      const int t = base + tg;
+      const bool active = t < S.k;
+      const int64_t pi = pbase + (active ? t : S.k - 1);
+      const int j = S.idx[pi];
+      const bool ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
+      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
+      float4 kq[4], v[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
+        v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
+      }
+      ESlice e;
+      load_e(S, pi, s8, fq, e);
+      // Online softmax in the base-2 domain (scores pre-multiplied by log2(e) / sqrt(d_head), v_exp_f32 directly) with a
+      // LAZY reference: a slot's reference m is its first valid score and moves only when a later score exceeds it by more
+      // than 64 (2^64 headroom in fp32; a wave-uniform, practically never taken branch). The steady state has no
+      // rescaling of the 80 accumulator registers: ~18 % fewer VALU instructions in a loop that is VALU-issue bound.
+      float sc[NH];
+      bool jump = false;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        sc[h] = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
+        jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
+      }
+      if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
+            l_run[h] *= alpha;
+            scale4(oacc[h], alpha);
+            eacc[h].scale(alpha);
+            m_run[h] = sc[h];
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];  // the slot's first valid target sets the reference
+        const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
+        l_run[h] += pr;  // the normaliser is that of the un-dropped softmax
+        float pd = pr;
+        if constexpr (DROP) pd = dk.keep((uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
+        fma4(oacc[h], pd, v[h]);  // K/V channel block st == h belongs to head h
+        eacc[h].fma(pd, e);
+      }
     }
   }
+
 }
 
 // Merge of the wavefront's 8 target slots (lanes with equal s8: xor 8, 16, 32): on return every lane holds, for its channel
