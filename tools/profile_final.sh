@@ -8,6 +8,12 @@ mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG:-r01f}_gpu_tests.log
 bash tools/profile_round.sh ${TAG:-r01f}_c2 64 1024 128 1 1
 bash tools/profile_round.sh ${TAG:-r01f}_c5 128 1024 128 1 32 --steps 40
+# the folded epilogue of the wave-per-row attention form (opt-in): bytes written per launch
+TBX_ATTN_FOLD_BIG=1 bash tools/profile_round.sh ${TAG:-r01f}_c5_foldbig 128 1024 128 1 32 --steps 40
+# one steady-state step of the default two-stream graph replay, kernel by kernel
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/tl_final -o tl -- python3 $root/bench.py --no-cpu-baseline --no-wosac-shape --no-train-shape --no-bf16-shape --profile-steps 0 > /dev/null 2>&1 )
+python3 tools/step_timeline2.py $(ls /tmp/tl_final/*.db | head -1) > gpurun_out/${TAG:-r01f}_c2_two_stream_timeline.txt 2>&1
+rm -rf /tmp/tl_final
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 cd $root
