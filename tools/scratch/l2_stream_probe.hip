@@ -24,6 +24,42 @@ __global__ __launch_bounds__(512) void probe(const float4* __restrict__ img, int
   out[blockIdx.x * 512 + tid] = acc;
 }
 
+// the same stream by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a 64 KiB LDS slot, DEPTH instructions per
+// wave per step, then "s_waitcnt vmcnt(0); s_barrier" - the live-row chain's weight path
+template <int DEPTH>
+__global__ __launch_bounds__(512) void probe_dma(const float4* __restrict__ img, int steps, float4* out, unsigned long long* cyc) {
+  extern __shared__ float4 slot[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slot);
+  __syncthreads();
+  const unsigned long long t0 = clock64();
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      const float4* src = img + ((s * DEPTH + i) * 8 + wave) * 64 + lane;
+      const uint32_t dst = lds0 + (uint32_t)((i % 8) * 8 + wave) * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  const unsigned long long t1 = clock64();
+  if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * 512 + tid] = slot[tid];
+}
+template <int DEPTH>
+void run_dma(const float4* img, int total_f4_per_thread, int grid, float4* out, unsigned long long* cyc) {
+  const int steps = total_f4_per_thread / DEPTH;
+  CK(hipFuncSetAttribute((const void*)probe_dma<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_dma<DEPTH>, dim3(grid), dim3(512), 65536, 0, img, steps, out, cyc);
+  CK(hipDeviceSynchronize());
+  unsigned long long c;
+  CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+  const double bytes = (double)total_f4_per_thread * 512 * 16;
+  printf("DMA  grid %4d depth %2d (%3d KiB per step per WG): %8llu ticks for %4.0f KiB -> %.1f B/tick\n", grid, DEPTH, DEPTH * 8, c, bytes / 1024, bytes / c);
+}
+
 template <int DEPTH>
 void run(const float4* img, int total_f4_per_thread, int grid, float4* out, unsigned long long* cyc) {
   const int steps = total_f4_per_thread / DEPTH;
@@ -87,6 +123,11 @@ int main() {
   CK(hipMemset(img, 0, (size_t)total * 512 * 16 * 128));
   CK(hipMalloc(&out, 1024 * 512 * 16));
   CK(hipMalloc(&cyc, 16));
+  for (int grid : {1, 64}) {
+    run_dma<1>(img, total, grid, out, cyc);
+    run_dma<4>(img, total, grid, out, cyc);
+    run_dma<8>(img, total, grid, out, cyc);
+  }
   for (int grid : {1, 64, 192}) {
     run_cold<4, false>(img, total, grid, out, cyc);
     run_cold<8, false>(img, total, grid, out, cyc);

@@ -64,6 +64,9 @@ class TallLinearFn(torch.autograd.Function):
                 # (the library's GEMM for [n, rows] x [rows, k] with n = 1 took 56 ms at 10^6 rows)
                 dy2 = F.pad(dy2, (0, -n % 4))
                 x2 = F.pad(x2, (0, -k % 4)) if (k % 4 or not x2.is_contiguous()) else x2
+                if x2.data_ptr() % 16:  # a contiguous view at an odd offset: the kernel reads float4 rows
+                    x2 = x2.clone()
+                assert hip.linear_wgrad_ok(dy2, x2)
             dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b)
             dw, db = dw[:n, :k], (db[:n] if db is not None else None)
         return dx, dw, db
