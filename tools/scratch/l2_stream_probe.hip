@@ -60,6 +60,97 @@ void run_dma(const float4* img, int total_f4_per_thread, int grid, float4* out, 
   printf("DMA  grid %4d depth %2d (%3d KiB per step per WG): %8llu ticks for %4.0f KiB -> %.1f B/tick\n", grid, DEPTH, DEPTH * 8, c, bytes / 1024, bytes / c);
 }
 
+// linear_gemv in isolation: two 66 KiB LDS slots; per chunk (33 rows x 2 KiB): [wait + barrier] [DMA of the next chunk into the other
+// slot, pieces dealt to the 8 waves] [threads 0..127: bias + 128-long k-ordered fma chain over the slot's 32 weight rows and an
+// activation row in LDS]. COMPUTE = false: the same without the chain.
+template <bool COMPUTE, int UNR>
+__global__ __launch_bounds__(512) void probe_gemv(const float* __restrict__ img, int chunks, float* out, unsigned long long* cyc) {
+  extern __shared__ float lds_f[];
+  float* slots = lds_f;              // 2 x 33 x 512 floats
+  float* x = lds_f + 2 * 33 * 512;   // 128 activations
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 128) x[tid] = 0.001f * tid;
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slots);
+  auto dma = [&](int chunk, int slot) {
+    const float* base = img + (size_t)chunk * 33 * 512;
+    const int w0 = (UNR >= 100) ? 2 : 0;  // UNR >= 100: the two multiplying waves issue no DMA (their lgkmcnt waits would include it?)
+    if (wave < w0) return;
+    for (int p = wave - w0; p < 66; p += 8 - w0) {
+      const float* src = base + p * 256 + lane * 4;
+      const uint32_t dst = lds0 + (uint32_t)slot * 33u * 2048u + (uint32_t)p * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  };
+  __syncthreads();
+  const unsigned long long t0 = clock64();
+  dma(0, 0);
+  float acc = 0.f;
+  for (int i = 0; i < chunks; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 1 < chunks) dma(i + 1, (i + 1) & 1);
+    if (COMPUTE && tid < 128) {
+      const float* w = slots + (i & 1) * 33 * 512 + tid * 4;
+      float a = w[0];
+      const float4* x4 = (const float4*)x;
+      const float4* w4 = (const float4*)(w + 512);
+      if (UNR == 99 || UNR == 199) {  // software pipeline: the 8 operand reads of k-block kb + 1 are issued before the 16 fmas of k-block kb
+#define RD(X, W, KB)                                                                                                   \
+  X[0] = x4[(KB) * 4], X[1] = x4[(KB) * 4 + 1], X[2] = x4[(KB) * 4 + 2], X[3] = x4[(KB) * 4 + 3];                           \
+  W[0] = w4[((KB) * 4) * 128], W[1] = w4[((KB) * 4 + 1) * 128], W[2] = w4[((KB) * 4 + 2) * 128], W[3] = w4[((KB) * 4 + 3) * 128]
+#define FM(X, W)                                                                                                       \
+  a = __builtin_fmaf(X[0].x, W[0].x, a); a = __builtin_fmaf(X[1].x, W[0].y, a); a = __builtin_fmaf(X[2].x, W[0].z, a); a = __builtin_fmaf(X[3].x, W[0].w, a); \
+  a = __builtin_fmaf(X[0].y, W[1].x, a); a = __builtin_fmaf(X[1].y, W[1].y, a); a = __builtin_fmaf(X[2].y, W[1].z, a); a = __builtin_fmaf(X[3].y, W[1].w, a); \
+  a = __builtin_fmaf(X[0].z, W[2].x, a); a = __builtin_fmaf(X[1].z, W[2].y, a); a = __builtin_fmaf(X[2].z, W[2].z, a); a = __builtin_fmaf(X[3].z, W[2].w, a); \
+  a = __builtin_fmaf(X[0].w, W[3].x, a); a = __builtin_fmaf(X[1].w, W[3].y, a); a = __builtin_fmaf(X[2].w, W[3].z, a); a = __builtin_fmaf(X[3].w, W[3].w, a)
+        float4 xa[4], wa[4], xb[4], wb[4];
+        RD(xa, wa, 0);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb += 2) {
+          RD(xb, wb, kb + 1);
+          FM(xa, wa);
+          if (kb + 2 < 8) { RD(xa, wa, kb + 2); }
+          FM(xb, wb);
+        }
+#undef RD
+#undef FM
+      } else {
+#pragma unroll (UNR % 100)
+      for (int kb = 0; kb < 8; ++kb) {
+        const float4 x0 = x4[kb * 4], x1 = x4[kb * 4 + 1], x2 = x4[kb * 4 + 2], x3 = x4[kb * 4 + 3];
+        const float4 w0 = w4[(kb * 4) * 128], w1 = w4[(kb * 4 + 1) * 128], w2 = w4[(kb * 4 + 2) * 128], w3 = w4[(kb * 4 + 3) * 128];
+        a = __builtin_fmaf(x0.x, w0.x, a); a = __builtin_fmaf(x1.x, w0.y, a); a = __builtin_fmaf(x2.x, w0.z, a); a = __builtin_fmaf(x3.x, w0.w, a);
+        a = __builtin_fmaf(x0.y, w1.x, a); a = __builtin_fmaf(x1.y, w1.y, a); a = __builtin_fmaf(x2.y, w1.z, a); a = __builtin_fmaf(x3.y, w1.w, a);
+        a = __builtin_fmaf(x0.z, w2.x, a); a = __builtin_fmaf(x1.z, w2.y, a); a = __builtin_fmaf(x2.z, w2.z, a); a = __builtin_fmaf(x3.z, w2.w, a);
+        a = __builtin_fmaf(x0.w, w3.x, a); a = __builtin_fmaf(x1.w, w3.y, a); a = __builtin_fmaf(x2.w, w3.z, a); a = __builtin_fmaf(x3.w, w3.w, a);
+      }
+      }
+      acc += a;
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = clock64();
+  if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * 512 + tid] = acc;
+}
+template <bool COMPUTE, int UNR>
+void run_gemv(const float4* img, int grid, float4* out, unsigned long long* cyc, bool cold) {
+  const int chunks = 15;  // ~1 MiB
+  const size_t lds = (2 * 33 * 512 + 128) * 4;
+  CK(hipFuncSetAttribute((const void*)probe_gemv<COMPUTE, UNR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  unsigned long long sum = 0;
+  int n = 0;
+  for (int rep = 0; rep < (cold ? 100 : 4); ++rep) {
+    const float* base = (const float*)img + (cold ? (size_t)(rep % 100) * (1 << 18) : 0);  // cold: a different MiB every launch
+    hipLaunchKernelGGL((probe_gemv<COMPUTE, UNR>), dim3(grid), dim3(512), lds, 0, base, chunks, (float*)out, cyc);
+    if (rep >= (cold ? 96 : 1)) { unsigned long long c; CK(hipDeviceSynchronize()); CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost)); sum += c; ++n; }
+  }
+  CK(hipDeviceSynchronize());
+  printf("GEMV unroll %d grid %4d compute %d %s: %8llu ticks for %d chunks of 66 KiB -> %.0f ticks per chunk, %.1f B/tick\n", UNR, grid, (int)COMPUTE, cold ? "cold" : "warm",
+         sum / n, chunks, (double)(sum / n) / chunks, 15.0 * 33 * 2048 / (double)(sum / n));
+}
+
 template <int DEPTH>
 void run(const float4* img, int total_f4_per_thread, int grid, float4* out, unsigned long long* cyc) {
   const int steps = total_f4_per_thread / DEPTH;
@@ -116,6 +207,21 @@ void run_cold(const float4* img, int total_f4_per_thread, int grid, float4* out,
   printf("COLD grid %4d depth %2d touch %d: %8llu ticks (touch phase %6llu) for %4.0f KiB -> %.1f B/tick\n", grid, DEPTH, (int)TOUCH, sum / 8, sumt / 8, bytes / 1024, bytes / (sum / 8.0));
 }
 
+// dependent v_fma latency: one wave (or all 8), N dependent fmas on register operands
+__global__ __launch_bounds__(512) void probe_fma(float* out, unsigned long long* cyc, int active_threads) {
+  const int tid = threadIdx.x;
+  float a = tid * 1e-3f, x = 1.0001f, w = 0.5f + tid * 1e-6f;
+  __syncthreads();
+  const unsigned long long t0 = clock64();
+  if (tid < active_threads) {
+#pragma unroll
+    for (int i = 0; i < 1024; ++i) a = __builtin_fmaf(x, w, a);
+  }
+  const unsigned long long t1 = clock64();
+  if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * 512 + tid] = a;
+}
+
 int main() {
   const int total = 128;  // float4 per thread = 1 MiB per WG
   float4* img; float4* out; unsigned long long* cyc;
@@ -123,6 +229,24 @@ int main() {
   CK(hipMemset(img, 0, (size_t)total * 512 * 16 * 128));
   CK(hipMalloc(&out, 1024 * 512 * 16));
   CK(hipMalloc(&cyc, 16));
+  for (int act : {64, 128, 512}) {
+    hipLaunchKernelGGL(probe_fma, dim3(64), dim3(512), 0, 0, (float*)out, cyc, act);
+    CK(hipDeviceSynchronize());
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    printf("FMA chain: %d active threads per WG: %llu ticks for 1024 dependent v_fma -> %.1f ticks each\n", act, c, c / 1024.0);
+  }
+  for (int grid : {64}) {
+    run_gemv<false, 1>(img, grid, out, cyc, false);
+    run_gemv<true, 1>(img, grid, out, cyc, false);
+    run_gemv<true, 2>(img, grid, out, cyc, false);
+    run_gemv<true, 4>(img, grid, out, cyc, false);
+    run_gemv<true, 8>(img, grid, out, cyc, false);
+    run_gemv<true, 99>(img, grid, out, cyc, false);
+    run_gemv<false, 102>(img, grid, out, cyc, false);
+    run_gemv<true, 102>(img, grid, out, cyc, false);
+    run_gemv<true, 199>(img, grid, out, cyc, false);
+    run_gemv<true, 199>(img, grid, out, cyc, true);
+  }
   for (int grid : {1, 64}) {
     run_dma<1>(img, total, grid, out, cyc);
     run_dma<4>(img, total, grid, out, cyc);

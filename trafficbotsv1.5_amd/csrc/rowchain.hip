@@ -441,12 +441,16 @@ __device__ __forceinline__ int gemv_kblocks(const uint32_t* prog, int j) { retur
 // form is invisible to its counters (which can then only over-wait: VMEM returns in order); the LDS hazard is handled by hand:
 // every consumer sits behind "s_waitcnt vmcnt(0); s_barrier" (cdna_hip_programming.md 5.7: M0 is written in the statement that
 // reads it and restored).
-__device__ __forceinline__ void gemv_dma(const float* img, int kblocks, int cb, int kc, float* slot, int lane, int wave, int nwave) {
+// The waves that multiply (the first 2 * live rows: a wave is 64 columns of one row) issue NO pieces when other waves exist: a
+// wave's later LDS reads wait behind its own DMA (measured in isolation, tools/scratch/l2_stream_probe.hip: a chunk's DMA and its
+// multiply added up - 3074 cycles per 66 KiB chunk - instead of overlapping; 2212 with the pieces left to the idle waves).
+__device__ __forceinline__ void gemv_dma(const float* img, int kblocks, int cb, int kc, float* slot, int lane, int wave, int nwave, int w0) {
+  if (wave < w0) return;
   const int kbc = (kblocks - kc * GKC) < GKC ? (kblocks - kc * GKC) : GKC;
   const int rows = kbc * 4 + (kc == 0 ? 1 : 0);
   const float* base = img + ((int64_t)cb * (1 + kblocks * 4) + (kc == 0 ? 0 : 1 + kc * GKC * 4)) * GROW;
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slot);
-  for (int p = wave; p < rows * 2; p += nwave) {
+  for (int p = wave - w0; p < rows * 2; p += nwave - w0) {
     const float* gsrc = base + p * 256 + lane * 4;
     const uint32_t dst = lds0 + (uint32_t)p * 1024u;
     uint32_t keep;
@@ -487,7 +491,8 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
   TBX_SUB(0);
   // chunk 0 is already on its way if the previous LINEAR stage (or the kernel prologue) requested it
   int slot = ws.stage == stage ? ws.slot : 0;
-  if (ws.stage != stage) gemv_dma(img, kblocks, 0, 0, wslots + slot * GSLOT, lane, wave, nwave);
+  const int w0 = 2 * t.rows_live < nwave ? 2 * t.rows_live : 0;  // waves that multiply and therefore do not fetch
+  if (ws.stage != stage) gemv_dma(img, kblocks, 0, 0, wslots + slot * GSLOT, lane, wave, nwave, w0);
   const int nj = s.pad;  // next TBX_F_WGEMV stage (0: none)
   const int n_chunks = ncb * nkc;
   const bool n_pow2 = (N & (N - 1)) == 0;
@@ -502,10 +507,10 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
     const float* w = wslots + slot * GSLOT;
     if (i + 1 < n_chunks) {
       const bool wrap = kc + 1 == nkc;
-      gemv_dma(img, kblocks, wrap ? cb + 1 : cb, wrap ? 0 : kc + 1, wslots + (1 - slot) * GSLOT, lane, wave, nwave);
+      gemv_dma(img, kblocks, wrap ? cb + 1 : cb, wrap ? 0 : kc + 1, wslots + (1 - slot) * GSLOT, lane, wave, nwave, w0);
     } else if (nj > 0) {
       const float* nimg = (const float*)(((uint64_t)prog_word(prog, nj, 17) << 32) | prog_word(prog, nj, 16));
-      gemv_dma(nimg, gemv_kblocks(prog, nj), 0, 0, wslots + (1 - slot) * GSLOT, lane, wave, nwave);
+      gemv_dma(nimg, gemv_kblocks(prog, nj), 0, 0, wslots + (1 - slot) * GSLOT, lane, wave, nwave, w0);
     }
     TBX_SUB(2);
     const int o = cb * GCOLS + cl;
@@ -525,16 +530,41 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
       const float4* xr4 = (const float4*)__builtin_assume_aligned(xr, 16);  // src_col, the row widths and the chunk offset are multiples of 4 floats
       const float4* wc4 = (const float4*)__builtin_assume_aligned(wc, 16);
       float a = acc;
-#pragma unroll 2
-      for (int kb = 0; kb < kbc; ++kb) {
-        const float4 x0 = xr4[kb * 4], x1 = xr4[kb * 4 + 1], x2 = xr4[kb * 4 + 2], x3 = xr4[kb * 4 + 3];
-        const float4 w0 = wc4[(kb * 4) * (GROW / 4)], w1 = wc4[(kb * 4 + 1) * (GROW / 4)];
-        const float4 w2 = wc4[(kb * 4 + 2) * (GROW / 4)], w3 = wc4[(kb * 4 + 3) * (GROW / 4)];
-        a = __builtin_fmaf(x0.x, w0.x, a); a = __builtin_fmaf(x1.x, w0.y, a); a = __builtin_fmaf(x2.x, w0.z, a); a = __builtin_fmaf(x3.x, w0.w, a);
-        a = __builtin_fmaf(x0.y, w1.x, a); a = __builtin_fmaf(x1.y, w1.y, a); a = __builtin_fmaf(x2.y, w1.z, a); a = __builtin_fmaf(x3.y, w1.w, a);
-        a = __builtin_fmaf(x0.z, w2.x, a); a = __builtin_fmaf(x1.z, w2.y, a); a = __builtin_fmaf(x2.z, w2.z, a); a = __builtin_fmaf(x3.z, w2.w, a);
-        a = __builtin_fmaf(x0.w, w3.x, a); a = __builtin_fmaf(x1.w, w3.y, a); a = __builtin_fmaf(x2.w, w3.z, a); a = __builtin_fmaf(x3.w, w3.w, a);
+      // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 dependent fmas of k-block kb (the compiler's
+      // own schedule re-used one register set: reads and fmas alternated; 2807 -> 1876 cycles per 128 k in isolation together
+      // with the DMA change above)
+#define TBX_RD(X, W, KB)                                                                                            \
+  X[0] = xr4[(KB) * 4], X[1] = xr4[(KB) * 4 + 1], X[2] = xr4[(KB) * 4 + 2], X[3] = xr4[(KB) * 4 + 3];                     \
+  W[0] = wc4[((KB) * 4) * (GROW / 4)], W[1] = wc4[((KB) * 4 + 1) * (GROW / 4)], W[2] = wc4[((KB) * 4 + 2) * (GROW / 4)], \
+  W[3] = wc4[((KB) * 4 + 3) * (GROW / 4)]
+#define TBX_FM(X, W)                                                                                                              \
+  a = __builtin_fmaf(X[0].x, W[0].x, a); a = __builtin_fmaf(X[1].x, W[0].y, a); a = __builtin_fmaf(X[2].x, W[0].z, a); a = __builtin_fmaf(X[3].x, W[0].w, a); \
+  a = __builtin_fmaf(X[0].y, W[1].x, a); a = __builtin_fmaf(X[1].y, W[1].y, a); a = __builtin_fmaf(X[2].y, W[1].z, a); a = __builtin_fmaf(X[3].y, W[1].w, a); \
+  a = __builtin_fmaf(X[0].z, W[2].x, a); a = __builtin_fmaf(X[1].z, W[2].y, a); a = __builtin_fmaf(X[2].z, W[2].z, a); a = __builtin_fmaf(X[3].z, W[2].w, a); \
+  a = __builtin_fmaf(X[0].w, W[3].x, a); a = __builtin_fmaf(X[1].w, W[3].y, a); a = __builtin_fmaf(X[2].w, W[3].z, a); a = __builtin_fmaf(X[3].w, W[3].w, a)
+      float4 xa[4], wa[4], xb[4], wb[4];
+      TBX_RD(xa, wa, 0);
+      if (kbc == GKC) {  // the full chunk: straight-line
+#pragma unroll
+        for (int kb = 0; kb < GKC; kb += 2) {
+          TBX_RD(xb, wb, kb + 1);
+          TBX_FM(xa, wa);
+          if (kb + 2 < GKC) { TBX_RD(xa, wa, kb + 2); }
+          TBX_FM(xb, wb);
+        }
+      } else {
+        for (int kb = 0; kb < kbc; kb += 2) {
+          const bool more = kb + 1 < kbc;  // wave-uniform
+          if (more) { TBX_RD(xb, wb, kb + 1); }
+          TBX_FM(xa, wa);
+          if (more) {
+            if (kb + 2 < kbc) { TBX_RD(xa, wa, kb + 2); }
+            TBX_FM(xb, wb);
+          }
+        }
       }
+#undef TBX_RD
+#undef TBX_FM
       acc = a;
       TBX_SUB(3);
       if (kc == nkc - 1) {
@@ -966,7 +996,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   if (LIVE && a.first_packed >= 0) {  // the first LINEAR stage's first chunk: on its way while the stages before it run
     const int j = a.first_packed;
     gemv_dma((const float*)(((uint64_t)prog_word(prog, j, 17) << 32) | prog_word(prog, j, 16)), gemv_kblocks(prog, j), 0, 0, wslots,
-             (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(blockDim.x >> 6));
+             (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(blockDim.x >> 6),
+             2 * t.rows_live < (int)(blockDim.x >> 6) ? 2 * t.rows_live : 0);
     ws.stage = j;
   }
   for (int i = 0; i < a.n_stages; ++i) {
