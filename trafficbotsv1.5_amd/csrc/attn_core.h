@@ -295,15 +295,25 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 __device__ __forceinline__ float gemv_chain(const float* blk, int c, const float* x, int kblocks, float acc) {
   const float4* wq = (const float4*)blk + c;
   const float4* x4 = (const float4*)__builtin_assume_aligned(x, 16);
-#pragma unroll 2
-  for (int kb = 0; kb < kblocks; ++kb) {
-    const float4 x0 = x4[kb * 4], x1 = x4[kb * 4 + 1], x2 = x4[kb * 4 + 2], x3 = x4[kb * 4 + 3];
-    const float4 w0 = wq[(1 + kb * 4) * D], w1 = wq[(2 + kb * 4) * D], w2 = wq[(3 + kb * 4) * D], w3 = wq[(4 + kb * 4) * D];
-    acc = __builtin_fmaf(x0.x, w0.x, acc); acc = __builtin_fmaf(x1.x, w0.y, acc); acc = __builtin_fmaf(x2.x, w0.z, acc); acc = __builtin_fmaf(x3.x, w0.w, acc);
-    acc = __builtin_fmaf(x0.y, w1.x, acc); acc = __builtin_fmaf(x1.y, w1.y, acc); acc = __builtin_fmaf(x2.y, w1.z, acc); acc = __builtin_fmaf(x3.y, w1.w, acc);
-    acc = __builtin_fmaf(x0.z, w2.x, acc); acc = __builtin_fmaf(x1.z, w2.y, acc); acc = __builtin_fmaf(x2.z, w2.z, acc); acc = __builtin_fmaf(x3.z, w2.w, acc);
-    acc = __builtin_fmaf(x0.w, w3.x, acc); acc = __builtin_fmaf(x1.w, w3.y, acc); acc = __builtin_fmaf(x2.w, w3.z, acc); acc = __builtin_fmaf(x3.w, w3.w, acc);
+  // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 dependent fmas of k-block kb
+#define TBX_RD(X, W, KB)                                                                                       \
+  X[0] = x4[(KB) * 4], X[1] = x4[(KB) * 4 + 1], X[2] = x4[(KB) * 4 + 2], X[3] = x4[(KB) * 4 + 3];                   \
+  W[0] = wq[(1 + (KB) * 4) * D], W[1] = wq[(2 + (KB) * 4) * D], W[2] = wq[(3 + (KB) * 4) * D], W[3] = wq[(4 + (KB) * 4) * D]
+#define TBX_FM(X, W)                                                                                                                      \
+  acc = __builtin_fmaf(X[0].x, W[0].x, acc); acc = __builtin_fmaf(X[1].x, W[0].y, acc); acc = __builtin_fmaf(X[2].x, W[0].z, acc); acc = __builtin_fmaf(X[3].x, W[0].w, acc); \
+  acc = __builtin_fmaf(X[0].y, W[1].x, acc); acc = __builtin_fmaf(X[1].y, W[1].y, acc); acc = __builtin_fmaf(X[2].y, W[1].z, acc); acc = __builtin_fmaf(X[3].y, W[1].w, acc); \
+  acc = __builtin_fmaf(X[0].z, W[2].x, acc); acc = __builtin_fmaf(X[1].z, W[2].y, acc); acc = __builtin_fmaf(X[2].z, W[2].z, acc); acc = __builtin_fmaf(X[3].z, W[2].w, acc); \
+  acc = __builtin_fmaf(X[0].w, W[3].x, acc); acc = __builtin_fmaf(X[1].w, W[3].y, acc); acc = __builtin_fmaf(X[2].w, W[3].z, acc); acc = __builtin_fmaf(X[3].w, W[3].w, acc)
+  float4 xa[4], wa[4], xb[4], wb[4];
+  TBX_RD(xa, wa, 0);
+  for (int kb = 0; kb < kblocks; kb += 2) {  // kblocks is even (2 or 8) at every call site
+    TBX_RD(xb, wb, kb + 1);
+    TBX_FM(xa, wa);
+    if (kb + 2 < kblocks) { TBX_RD(xa, wa, kb + 2); }
+    TBX_FM(xb, wb);
   }
+#undef TBX_RD
+#undef TBX_FM
   return acc;
 }
 

@@ -59,10 +59,14 @@ __device__ unsigned int g_mid_launch;
 #define MID_CLK(i)
 #endif
 
-// image `img` (n_pieces KiB) -> LDS `slot`, piece p by wave p % 4
-__device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane) {
+// image `img` (n_pieces KiB) -> LDS `slot`, pieces dealt to waves w0..3. w0 = 2 for an image requested right before a GEMV chain:
+// threads 0..127 (waves 0, 1) run the chains, and a wave's LDS reads wait behind its own LDS-DMA (measured:
+// tools/scratch/l2_stream_probe.hip) - the chain would stall for the image's whole flight. w0 = 0 where a sweep follows (no LDS
+// reads until the epilogue's vmcnt(0)): four issuing waves land an image sooner than two.
+__device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane, int w0) {
+  if (wave < w0) return;
   const uint32_t lds0 = lds_addr(slot);
-  for (int p = wave; p < n_pieces; p += 4) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+  for (int p = wave - w0; p < n_pieces; p += 4 - w0) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
 }
 
 // The stand-alone kernel's epilogue for 4 waves per row with the value fold (attn.hip, FOLD): per-wave partials -> red_s, the
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   MID_CLK(0);
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
-  dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane);
-  dma_image(a.wo, IMG128 / 256, slot_b, wave, lane);
+  dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane, 0);
+  dma_image(a.wo, IMG128 / 256, slot_b, wave, lane, 0);
   if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
   // LayerNorm parameters (wave 0 normalises the row): requested now - an ordinary load issued while an image DMA is in flight
   // makes the compiler wait for everything outstanding (it does not see the DMAs, vmcnt is in order)
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   }
   __syncthreads();  // o1 complete; slot A (fold1) is free
   MID_CLK(3);
-  dma_image(a.wq, IMG128 / 256, slot_a, wave, lane);
+  dma_image(a.wq, IMG128 / 256, slot_a, wave, lane, 2);
   // ---------------------------------------------------------------- x += no valid target ? 0 : out_proj(o1)   (W_o landed: waited in combine_fold)
   if (threadIdx.x < D) {
     const int c = threadIdx.x;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   }
   __syncthreads();  // xs updated; slot B (W_o) is free
   MID_CLK(4);
-  dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane);
+  dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane, 2);
   // ---------------------------------------------------------------- LN_1(x) -> o1 (one wavefront, the chain's ln_row<2> order)
   if (wave == 0) {
     float v[2];
@@ -214,9 +218,9 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) o1[lane + 64 * q] = (v[q] - mean) * rstd * ln_g[q] + ln_bt[q];
   }
-  // W_q has landed once at most the 18 pieces per wave of the image requested after it are outstanding (DMA loads only: in order)
+  // W_q has landed once at most the 36 pieces per issuing wave of the image requested after it are outstanding (DMA loads only: in order)
   MID_CLK(5);
-  asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
   __syncthreads();
   MID_CLK(6);
   // ---------------------------------------------------------------- q = W_q LN(x) + b_q
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   }
   __syncthreads();
   MID_CLK(8);
-  dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane);  // lands during the sweep
+  dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0);  // lands during the sweep
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
