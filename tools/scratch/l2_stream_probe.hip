@@ -95,7 +95,29 @@ __global__ __launch_bounds__(512) void probe_gemv(const float* __restrict__ img,
       float a = w[0];
       const float4* x4 = (const float4*)x;
       const float4* w4 = (const float4*)(w + 512);
-      if (UNR == 99 || UNR == 199) {  // software pipeline: the 8 operand reads of k-block kb + 1 are issued before the 16 fmas of k-block kb
+      if (UNR == 299) {  // activations as SGPR operands: lane l holds x[l] and x[64 + l], v_readlane per fma; weights pipelined one k-block ahead
+        const float xv0 = x[lane], xv1 = x[64 + lane];
+        const float4* w4q = w4;
+#define XK(K) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (K) < 64 ? xv0 : xv1), (K) & 63))
+#define RDW(W, KB) W[0] = w4q[((KB) * 4) * 128], W[1] = w4q[((KB) * 4 + 1) * 128], W[2] = w4q[((KB) * 4 + 2) * 128], W[3] = w4q[((KB) * 4 + 3) * 128]
+#define FMW(W, KB)                                                                                                                   \
+  a = __builtin_fmaf(XK((KB) * 16 + 0), W[0].x, a); a = __builtin_fmaf(XK((KB) * 16 + 4), W[0].y, a); a = __builtin_fmaf(XK((KB) * 16 + 8), W[0].z, a); a = __builtin_fmaf(XK((KB) * 16 + 12), W[0].w, a); \
+  a = __builtin_fmaf(XK((KB) * 16 + 1), W[1].x, a); a = __builtin_fmaf(XK((KB) * 16 + 5), W[1].y, a); a = __builtin_fmaf(XK((KB) * 16 + 9), W[1].z, a); a = __builtin_fmaf(XK((KB) * 16 + 13), W[1].w, a); \
+  a = __builtin_fmaf(XK((KB) * 16 + 2), W[2].x, a); a = __builtin_fmaf(XK((KB) * 16 + 6), W[2].y, a); a = __builtin_fmaf(XK((KB) * 16 + 10), W[2].z, a); a = __builtin_fmaf(XK((KB) * 16 + 14), W[2].w, a); \
+  a = __builtin_fmaf(XK((KB) * 16 + 3), W[3].x, a); a = __builtin_fmaf(XK((KB) * 16 + 7), W[3].y, a); a = __builtin_fmaf(XK((KB) * 16 + 11), W[3].z, a); a = __builtin_fmaf(XK((KB) * 16 + 15), W[3].w, a)
+        float4 wa[4], wb[4];
+        RDW(wa, 0);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb += 2) {
+          RDW(wb, kb + 1);
+          FMW(wa, kb);
+          if (kb + 2 < 8) { RDW(wa, kb + 2); }
+          FMW(wb, kb + 1);
+        }
+#undef XK
+#undef RDW
+#undef FMW
+      } else if (UNR == 99 || UNR == 199) {  // software pipeline: the 8 operand reads of k-block kb + 1 are issued before the 16 fmas of k-block kb
 #define RD(X, W, KB)                                                                                                   \
   X[0] = x4[(KB) * 4], X[1] = x4[(KB) * 4 + 1], X[2] = x4[(KB) * 4 + 2], X[3] = x4[(KB) * 4 + 3];                           \
   W[0] = w4[((KB) * 4) * 128], W[1] = w4[((KB) * 4 + 1) * 128], W[2] = w4[((KB) * 4 + 2) * 128], W[3] = w4[((KB) * 4 + 3) * 128]
@@ -246,6 +268,8 @@ int main() {
     run_gemv<true, 102>(img, grid, out, cyc, false);
     run_gemv<true, 199>(img, grid, out, cyc, false);
     run_gemv<true, 199>(img, grid, out, cyc, true);
+    run_gemv<true, 299>(img, grid, out, cyc, false);
+    run_gemv<true, 299>(img, grid, out, cyc, true);
   }
   for (int grid : {1, 64}) {
     run_dma<1>(img, total, grid, out, cyc);
