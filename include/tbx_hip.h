@@ -320,8 +320,11 @@ enum {
                            this is x += mask ? 0 : linear(...) in one stage (the attention / FFN output folded into the token row) */
   TBX_F_OUT_BF16 = 8192, /* STORE, and LINEAR with dst = TBX_BUF_GLOBAL: the global destination holds bfloat16 (round to nearest even);
                            ld / ld2 and dst_col count bf16 elements. For K/V tables read by tbx_knarpe_attn_fwd with seg.kv_bf16. */
-  TBX_F_WGEMV = 4096    /* LINEAR of a tbx_rowchain_live program: p0 is a tbx_pack_weight_gemv() image; a thread per output column,
+  TBX_F_WGEMV = 4096,   /* LINEAR of a tbx_rowchain_live program: p0 is a tbx_pack_weight_gemv() image; a thread per output column,
                            v_fma chains in the MFMA path's k order (bit-identical results, a fraction of the latency at 1-4 rows) */
+  TBX_F_MASKED_SUM = 16384 /* STORE (fp32 destination): p0[g * ld + dst_col + c] = sum over the `reserved` groups i whose byte
+                           p1[i * k + g] is CLEAR of src[:, src_col + i * div + c] (0 when all are set): the masked sum over per-type
+                           branches of action_head.py:89-96 in the storing stage (was ROWMASK + COPY/ADD per branch + STORE) */
 };
 enum { TBX_BUF0 = 0, TBX_BUF1 = 1, TBX_BUF_AUX = 2,
        TBX_BUF_GLOBAL = 3 /* LINEAR only: dst is global memory: p2[g * ld2 + dst_col + c] (valid rows), nothing staged in LDS */ };

@@ -381,6 +381,10 @@ def test_action_head_fused_branches_bit_identical(tb, hip, dev):
     assert not torch.equal(outs[2], outs[0])
     m.fused_branches = False
     assert torch.equal(m(x, valid, ty).mean, outs[2])
+    # the masked sum over the branches in the storing stage (TBX_F_MASKED_SUM) == ROWMASK + COPY / ADD per branch + STORE
+    m.fused_branches, m.masked_sum_store = True, False
+    assert torch.equal(m(x, valid, ty).mean, outs[2])
+    assert bool((~valid).any()) and float(m(x, valid, ty).mean[~valid].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("live", [1, 2, 4])

@@ -889,6 +889,19 @@ __device__ void op_store(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
     }
     return;
   }
+  if (s.flags & TBX_F_MASKED_SUM) {  // sum of the groups whose mask byte is clear, in group order from 0 (0 + y == y exactly)
+    const uint8_t* mask = (const uint8_t*)s.p1;
+    for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
+      float* orow = out + (t.g0 + r) * (int64_t)s.ld + s.dst_col;
+      for (int c = lane; c < n; c += 64) {
+        float v = 0.f;
+        for (int i = 0; i < s.reserved; ++i)
+          if (gld1(mask + (int64_t)i * s.k + t.g0 + r) == 0) v += src[r * lds_s + i * s.div + c];
+        gst1(orow + c, v);
+      }
+    }
+    return;
+  }
   if ((n & 3) == 0 && (s.ld & 3) == 0 && (s.dst_col & 3) == 0 && (s.src_col & 3) == 0 && ((((uintptr_t)out) & 15) == 0)) {
     const int w4 = n >> 2;
     for (int r = wave; r < ROWS && r < t.n_valid; r += nwave) {
@@ -1165,6 +1178,11 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
     } else if (!(gdst && (s.flags & (TBX_F_WPACK | TBX_F_WGEMV)) && !(s.flags & TBX_F_WSPLIT))) {
       return TBX_ERR_UNSUPPORTED;
     }
+  }
+  if (s.flags & TBX_F_MASKED_SUM) {
+    if (s.op != TBX_OP_STORE || (s.flags & TBX_F_OUT_BF16)) return TBX_ERR_UNSUPPORTED;
+    if (s.p1 == nullptr || s.reserved <= 0 || s.div <= 0 || s.k <= 0) return TBX_ERR_ARG;
+    if (s.src_col + (s.reserved - 1) * s.div + s.n > buf_ld(s.src)) return TBX_ERR_UNSUPPORTED;
   }
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;

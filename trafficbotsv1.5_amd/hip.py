@@ -24,6 +24,7 @@ F_ROWSKIP = 1024
 F_LOAD2 = 2048
 F_WGEMV = 4096
 F_OUT_BF16 = 8192
+F_MASKED_SUM = 16384
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -734,6 +735,12 @@ class Chain:
         """out[g, out_col:+n] = src[:, src_col:+n]; a bfloat16 `out` receives the values rounded to nearest even."""
         return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
                          flags=F_OUT_BF16 if out.dtype == torch.bfloat16 else 0)
+
+    def store_masked_sum(self, src, src_col, n, group_stride, masks, out, out_col=0):
+        """out[g, out_col:+n] = sum over the G groups i with masks[i, g] == 0 of src[:, src_col + i*group_stride : +n] (masks u8 [G, rows])."""
+        assert masks.dtype == torch.uint8 and masks.dim() == 2 and masks.is_contiguous() and out.dtype == torch.float32
+        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out, p1=masks,
+                         reserved=masks.shape[0], div=group_stride, k=masks.shape[1], flags=F_MASKED_SUM)
 
     def run(self, n_rows: int, group_rows: int = 0):
         if self._arr is None:

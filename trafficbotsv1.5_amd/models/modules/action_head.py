@@ -21,6 +21,7 @@ class ActionHead(nn.Module):
                                        for _ in range(n_ag_type)])
         self.log_std = nn.ParameterList([nn.Parameter(log_std * torch.ones(action_dim)) for _ in range(n_ag_type)])
         self.fused_branches = True  # emit(): the branches as 3 stacked / block-diagonal stages (False: 9 per-branch stages)
+        self.masked_sum_store = True  # ... and their masked sum in the storing stage (False: ROWMASK + COPY / ADD per branch)
 
     def emit(self, ch: Chain, type_mask: Tensor, out_mean: Tensor):
         """x in BUF1[:, 0:d]; type_mask u8 [3, rows] = ~(type_i & valid); writes the masked-sum mean to out_mean."""
@@ -39,6 +40,10 @@ class ActionHead(nn.Module):
             ch.linear(BUF1, 0, BUF0, 0, w1, b1, relu=True)
             ch.linear(BUF0, 0, BUF1, 0, w2, b2, relu=True, groups=G, src_stride=d, dst_stride=d)
             ch.linear(BUF1, 0, BUF0, 0, w3, b3, groups=G, src_stride=d, dst_stride=16)
+            if self.masked_sum_store and type_mask.is_contiguous():
+                # the masked sum over the branches in the storing stage (TBX_F_MASKED_SUM): 1 stage instead of 2 G + 1, same sums
+                ch.store_masked_sum(BUF0, 0, self.out_dim, 16, type_mask, out_mean)
+                return
             for i in range(G):
                 ch.rowmask(BUF0, 16 * i, self.out_dim, mask=type_mask[i])
                 (ch.copy if i == 0 else ch.add)(BUF0, 16 * i, AUX, 0, self.out_dim)
