@@ -95,7 +95,28 @@ __global__ __launch_bounds__(512) void probe_gemv(const float* __restrict__ img,
       float a = w[0];
       const float4* x4 = (const float4*)x;
       const float4* w4 = (const float4*)(w + 512);
-      if (UNR == 299) {  // activations as SGPR operands: lane l holds x[l] and x[64 + l], v_readlane per fma; weights pipelined one k-block ahead
+      if (UNR == 399) {  // one float4 of activations per lane per k-block (lane & 3 picks which), the other three through DPP quad broadcasts
+#define QB(V, G) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, V), (G) * 0x55, 0xf, 0xf, true))
+#define RDQ(XQ, W, KB) XQ = x4[(KB) * 4 + (lane & 3)]; W[0] = w4[((KB) * 4) * 128], W[1] = w4[((KB) * 4 + 1) * 128], W[2] = w4[((KB) * 4 + 2) * 128], W[3] = w4[((KB) * 4 + 3) * 128]
+#define FD(XC, WC, G) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #G "," #G "," #G "," #G "] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(XC), "v"(WC))
+#define FMQ(XQ, W)                                                                     \
+  FD(XQ.x, W[0].x, 0); FD(XQ.x, W[0].y, 1); FD(XQ.x, W[0].z, 2); FD(XQ.x, W[0].w, 3);      \
+  FD(XQ.y, W[1].x, 0); FD(XQ.y, W[1].y, 1); FD(XQ.y, W[1].z, 2); FD(XQ.y, W[1].w, 3);      \
+  FD(XQ.z, W[2].x, 0); FD(XQ.z, W[2].y, 1); FD(XQ.z, W[2].z, 2); FD(XQ.z, W[2].w, 3);      \
+  FD(XQ.w, W[3].x, 0); FD(XQ.w, W[3].y, 1); FD(XQ.w, W[3].z, 2); FD(XQ.w, W[3].w, 3)
+        float4 qa, qb, wa[4], wb[4];
+        RDQ(qa, wa, 0);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb += 2) {
+          RDQ(qb, wb, kb + 1);
+          FMQ(qa, wa);
+          if (kb + 2 < 8) { RDQ(qa, wa, kb + 2); }
+          FMQ(qb, wb);
+        }
+#undef QB
+#undef RDQ
+#undef FMQ
+      } else if (UNR == 299) {  // activations as SGPR operands: lane l holds x[l] and x[64 + l], v_readlane per fma; weights pipelined one k-block ahead
         const float xv0 = x[lane], xv1 = x[64 + lane];
         const float4* w4q = w4;
 #define XK(K) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (K) < 64 ? xv0 : xv1), (K) & 63))
@@ -268,6 +289,7 @@ int main() {
     run_gemv<true, 102>(img, grid, out, cyc, false);
     run_gemv<true, 199>(img, grid, out, cyc, false);
     run_gemv<true, 199>(img, grid, out, cyc, true);
+    run_gemv<true, 399>(img, grid, out, cyc, false);
     run_gemv<true, 299>(img, grid, out, cyc, false);
     run_gemv<true, 299>(img, grid, out, cyc, true);
   }

@@ -533,16 +533,22 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
       // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 dependent fmas of k-block kb (the compiler's
       // own schedule re-used one register set: reads and fmas alternated; 2807 -> 1876 cycles per 128 k in isolation together
       // with the DMA change above)
-#define TBX_RD(X, W, KB)                                                                                            \
-  X[0] = xr4[(KB) * 4], X[1] = xr4[(KB) * 4 + 1], X[2] = xr4[(KB) * 4 + 2], X[3] = xr4[(KB) * 4 + 3];                     \
+      // ... and the activations through DPP: a lane reads ONE of the k-block's four float4s (lane & 3 picks which), the fma takes
+      // its x operand from the quad lane that holds it (v_fmac_f32_dpp quad_perm:[g,g,g,g]; as inline asm - the compiler does not
+      // fold a v_mov_dpp into the fma). 5 KiB instead of 8 KiB of LDS returns per wave and k-block: the loop is bound by the LDS
+      // return path (1829 -> 1636 cycles per 128 k in isolation). Same products in the same order: bit-identical.
+#define TBX_RD(XQ, W, KB)                                                                                           \
+  XQ = xr4[(KB) * 4 + (lane & 3)];                                                                                  \
   W[0] = wc4[((KB) * 4) * (GROW / 4)], W[1] = wc4[((KB) * 4 + 1) * (GROW / 4)], W[2] = wc4[((KB) * 4 + 2) * (GROW / 4)], \
   W[3] = wc4[((KB) * 4 + 3) * (GROW / 4)]
-#define TBX_FM(X, W)                                                                                                              \
-  a = __builtin_fmaf(X[0].x, W[0].x, a); a = __builtin_fmaf(X[1].x, W[0].y, a); a = __builtin_fmaf(X[2].x, W[0].z, a); a = __builtin_fmaf(X[3].x, W[0].w, a); \
-  a = __builtin_fmaf(X[0].y, W[1].x, a); a = __builtin_fmaf(X[1].y, W[1].y, a); a = __builtin_fmaf(X[2].y, W[1].z, a); a = __builtin_fmaf(X[3].y, W[1].w, a); \
-  a = __builtin_fmaf(X[0].z, W[2].x, a); a = __builtin_fmaf(X[1].z, W[2].y, a); a = __builtin_fmaf(X[2].z, W[2].z, a); a = __builtin_fmaf(X[3].z, W[2].w, a); \
-  a = __builtin_fmaf(X[0].w, W[3].x, a); a = __builtin_fmaf(X[1].w, W[3].y, a); a = __builtin_fmaf(X[2].w, W[3].z, a); a = __builtin_fmaf(X[3].w, W[3].w, a)
-      float4 xa[4], wa[4], xb[4], wb[4];
+#define TBX_FD(XC, WC, G) \
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #G "," #G "," #G "," #G "] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(XC), "v"(WC))
+#define TBX_FM(XQ, W)                                                                                  \
+  TBX_FD(XQ.x, W[0].x, 0); TBX_FD(XQ.x, W[0].y, 1); TBX_FD(XQ.x, W[0].z, 2); TBX_FD(XQ.x, W[0].w, 3);      \
+  TBX_FD(XQ.y, W[1].x, 0); TBX_FD(XQ.y, W[1].y, 1); TBX_FD(XQ.y, W[1].z, 2); TBX_FD(XQ.y, W[1].w, 3);      \
+  TBX_FD(XQ.z, W[2].x, 0); TBX_FD(XQ.z, W[2].y, 1); TBX_FD(XQ.z, W[2].z, 2); TBX_FD(XQ.z, W[2].w, 3);      \
+  TBX_FD(XQ.w, W[3].x, 0); TBX_FD(XQ.w, W[3].y, 1); TBX_FD(XQ.w, W[3].z, 2); TBX_FD(XQ.w, W[3].w, 3)
+      float4 xa, xb, wa[4], wb[4];
       TBX_RD(xa, wa, 0);
       if (kbc == GKC) {  // the full chunk: straight-line
 #pragma unroll
@@ -564,6 +570,7 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
         }
       }
 #undef TBX_RD
+#undef TBX_FD
 #undef TBX_FM
       acc = a;
       TBX_SUB(3);
