@@ -63,14 +63,16 @@ class AgentEncoder(nn.Module):
     def encode(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, mp: Dict[str, Tensor],
                tl_invalid_u8: Tensor, tl_pose: Tensor, tl_kv: Tensor, prep: Optional[Dict[str, Tensor]] = None,
                ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1, tl_batch_div: int = 1,
-               tail: Optional[Callable[[Chain], None]] = None, aux_stream=None, navi_rpe=None) -> Tuple[Tensor, Dict[str, Tensor]]:
+               tail: Optional[Callable[[Chain], None]] = None, aux_stream=None, navi_rpe=None,
+               aux_tail: Optional[Callable[[Dict[str, Tensor]], None]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
         """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256]
         ([n/tl_batch_div * L, ..] with tl_pose / tl_invalid_u8 [n/tl_batch_div, L, ..] when the rollouts of a scene share its lights).
         -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows).
         aux_stream: the three K-nearest searches (they need the token poses only) run there while this stream runs the
         temporal PointNet of the agents' windows; their outputs live in `prep` across steps. navi_rpe: the PoseEmb of the navigation
         encoder - the embedding of the destination's relative pose (prep["navi_pe"], an input of the heads chain that depends on
-        agent_prep only) is then computed on that stream too instead of between the last layer and the heads."""
+        agent_prep only) is then computed on that stream too instead of between the last layer and the heads. aux_tail(prep): more
+        work of the caller's that needs nothing but `prep` (the navigation embedding of the heads), enqueued on that stream after it."""
         n, A, W = hist_valid.shape
         assert W == self.temp_window_size
         dev, d, rp = hist_pose.device, self.hidden_dim, self.pose_rpe
@@ -123,6 +125,8 @@ class AgentEncoder(nn.Module):
             if navi_rpe is not None and dest is not None:
                 prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
                                                  out=prep.get("navi_pe"))
+                if aux_tail is not None:
+                    aux_tail(prep)
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
                     _knn_at=(i_at, m_at, r_at))

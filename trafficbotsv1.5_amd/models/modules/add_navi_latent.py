@@ -32,6 +32,16 @@ class AddNaviLatent(nn.Module):
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
         ch.store(BUF0, 2 * d, d, out)
 
+    def emit_embed_buf(self, ch: Chain, out: Tensor):
+        """mlp_in(z) for z already in BUF0[:, d:2d] -> out [rows, d] (before the validity mask): the same three stages as in
+        `emit(z=None)`, for callers that evaluate them ahead of the chain that owns x (inference: no dropout between them)."""
+        d = self.hidden_dim
+        l_in = [t[0] for t in self.mlp_in.linear_layers()]
+        ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
+        ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
+        ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        ch.store(BUF0, 2 * d, d, out)
+
     def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None, mask_is_valid: bool = False,
              z_embedded: Optional[Tensor] = None):
         """x in BUF1[:, 0:d] (updated in place). z either already in BUF0[:, d:2d] (z=None) or loaded from `z`

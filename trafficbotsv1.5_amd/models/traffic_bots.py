@@ -4,6 +4,8 @@ fusion -> action head + tl-state head, every stage a HIP kernel launch on the cu
 from copy import deepcopy
 from typing import Dict, Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor, nn
 from torch.distributions import Categorical, Independent, Normal
@@ -89,6 +91,8 @@ class TrafficBots(nn.Module):
         out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail)
         return tl_kv
 
+    NAVI_AHEAD = os.environ.get("TBX_NAVI_AHEAD", "1") != "0"
+
     def agent_policy(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, ag_type_idx: Tensor,
                      ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
                      tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor],
@@ -102,18 +106,35 @@ class TrafficBots(nn.Module):
         # light tokens are then per scene and "ag_mp_batch_div" carries the agents' map sharing)
         div = tl_tokens.get("ag_mp_batch_div", tl_tokens.get("mp_batch_div", 1))
         tl_inv = tl_tokens["tl_token_invalid_u8"]
+        rc = rollout_consts or {}
+        mp_flat = mp_tokens["mp_token_feature"].reshape(-1, d)
+        # inference with an auxiliary stream: the navigation embedding mlp_in(navi feature) (navigation.py:65-79 +
+        # add_navi_latent.py:43-50) reads nothing the agent layers produce - it runs there, behind the K-nearest searches, instead
+        # of as the first five stages of the heads chain (same stages, same values)
+        navi_ahead = aux_stream is not None and engine.DROP_CTX is None and self.NAVI_AHEAD
+
+        def aux_tail(prep):
+            if prep.get("navi_emb") is None:
+                prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+            cn = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
+            self.navi_encoder.emit(cn, mp_flat, prep["navi_row"], prep["navi_pe"], dest_feature=rc.get("dest_feature"))
+            self.add_navi.emit_embed_buf(cn, prep["navi_emb"])
+            cn.run(n * A)
+
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
-                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe)
+                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None)
         out["prep"], out["ag_feat"] = prep, feat
         navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
-        rc = rollout_consts or {}
-        self.navi_encoder.emit(ch, mp_tokens["mp_token_feature"].reshape(-1, d), prep["navi_row"], navi_pe,
-                               dest_feature=rc.get("dest_feature"))
-        self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
+        if navi_ahead:
+            torch.cuda.current_stream().wait_stream(aux_stream)  # (long done: it ran beside the first layer)
+            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"])
+        else:
+            self.navi_encoder.emit(ch, mp_flat, prep["navi_row"], navi_pe, dest_feature=rc.get("dest_feature"))
+            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
         if engine.DROP_CTX is not None:  # training's stepping pass: 12 DROPOUT stages more than a program holds - two launches
             mid = torch.empty_like(feat)
             ch.store(BUF1, 0, d, mid)
