@@ -293,7 +293,9 @@ enum {
   TBX_OP_ADD = 4,       /* dst[:, dst_col:+n] += src[:, src_col:+n] */
   TBX_OP_COPY = 5,      /* dst[:, dst_col:+n]  = src[:, src_col:+n] */
   TBX_OP_ROWMASK = 6,   /* rows with p0[row_of(g)] != 0 (and padding rows): dst[:, dst_col:+n] = f0 */
-  TBX_OP_GROUPMAX = 7,  /* dst[r, dst_col + c] = max_r' src[r', src_col + c]  (r' over the rows of r's group; flat mode: the tile) */
+  TBX_OP_GROUPMAX = 7,  /* dst[r, dst_col + c] = max_r' src[r', src_col + c]  (r' over the rows of r's group; flat mode: the tile).
+                           p1 != NULL (a byte per global row): rows whose byte is set stay out of the maximum and come out as 0 in
+                           the src and the dst columns - [ROWMASK(-inf), GROUPMAX, ROWMASK(0)] of a PointNet layer in one stage */
   TBX_OP_POOLMAX = 8,   /* p0[group * ld + dst_col + c] = max over un-masked rows (mask p1) of src[:, src_col + c]; none -> 0 */
   TBX_OP_STORE = 9,     /* p0[g * ld + dst_col + c] = src[:, src_col + c] for valid rows */
   TBX_OP_CLAMP = 10,    /* dst[:, dst_col:+n] = clamp(dst, f0, f1) */

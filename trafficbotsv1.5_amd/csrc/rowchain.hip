@@ -833,14 +833,30 @@ __device__ void op_rowmask(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
 template <int MT, bool EXT>
 __device__ void op_groupmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   constexpr int ROWS = Tile<MT, EXT>::ROWS;
-  const float* src = t.b(s.src) + s.src_col;
+  float* src = t.b(s.src) + s.src_col;
   float* dst = t.b(s.dst) + s.dst_col;
   const int lds_s = t.l(s.src), lds_d = t.l(s.dst);
+  // p1 != NULL: the masked form - one stage for [ROWMASK(-inf) -> GROUPMAX -> ROWMASK(0) over both halves] of a PointNet layer
+  // (polyline_encoder.py:52-58): rows whose byte p1[g] is set (and padding rows) are left out of the maximum and come out as 0 in
+  // src and dst columns alike. The tile's row bytes are read once per wave (one ballot), not once per row and thread.
+  const uint8_t* mask = (const uint8_t*)s.p1;
+  unsigned long long inv = 0ull;
+  if (mask != nullptr) {
+    const int lane = threadIdx.x & 63;
+    bool m = true;
+    if (lane < ROWS && lane < t.n_valid) m = gld1(mask + t.g0 + lane) != 0;
+    inv = __ballot(m);
+  }
+  auto off = [&](int r) { return ((inv >> r) & 1ull) != 0ull; };
   if (t.ng == 1) {
     for (int c = threadIdx.x; c < s.n; c += blockDim.x) {
       float m = -INFINITY;
-      for (int r = 0; r < ROWS; ++r) m = fmaxf(m, src[r * lds_s + c]);
-      for (int r = 0; r < ROWS; ++r) dst[r * lds_d + c] = m;
+      for (int r = 0; r < ROWS; ++r)
+        if (!off(r)) m = fmaxf(m, src[r * lds_s + c]);
+      for (int r = 0; r < ROWS; ++r) {
+        dst[r * lds_d + c] = off(r) ? 0.f : m;
+        if (off(r)) src[r * lds_s + c] = 0.f;
+      }
     }
     return;
   }
@@ -849,8 +865,12 @@ __device__ void op_groupmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
   for (int e = threadIdx.x; e < s.n * t.ng; e += blockDim.x) {
     const int j = e / s.n, c = e - j * s.n;
     float m = -INFINITY;
-    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r) m = fmaxf(m, src[r * lds_s + c]);
-    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r) dst[r * lds_d + c] = m;
+    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r)
+      if (!off(r)) m = fmaxf(m, src[r * lds_s + c]);
+    for (int r = j * t.gw; r < (j + 1) * t.gw; ++r) {
+      dst[r * lds_d + c] = off(r) ? 0.f : m;
+      if (off(r)) src[r * lds_s + c] = 0.f;
+    }
   }
 }
 

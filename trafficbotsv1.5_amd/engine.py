@@ -148,6 +148,9 @@ def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_
     return cur
 
 
+MASKED_GROUPMAX = os.environ.get("TBX_MASKED_GROUPMAX", "1") != "0"
+
+
 def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.Tensor, x_buf: int = BUF1):
     """PointNet over the rows of one group (tile): polyline_encoder.py:49-61 + pooling.py:18-19,38.
     Input x at x_buf[:, 0:128]; pooled row -> out[group]."""
@@ -160,9 +163,12 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
         d = drop_site(mlp.dropout_p)
         if d is not None:
             ch.dropout(nxt, 0, half, *d)
-        ch.rowmask(nxt, 0, half, mask=row_invalid, fill=float("-inf"))
-        ch.groupmax(nxt, 0, nxt, half, half)
-        ch.rowmask(nxt, 0, 2 * half, mask=row_invalid, fill=0.0)
+        if d is None and MASKED_GROUPMAX:  # one stage: the maximum over the group's valid rows, masked rows zeroed in both halves
+            ch.groupmax(nxt, 0, nxt, half, half, mask=row_invalid)
+        else:
+            ch.rowmask(nxt, 0, half, mask=row_invalid, fill=float("-inf"))
+            ch.groupmax(nxt, 0, nxt, half, half)
+            ch.rowmask(nxt, 0, 2 * half, mask=row_invalid, fill=0.0)
         cur = nxt
     ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid)
 

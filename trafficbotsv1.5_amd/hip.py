@@ -724,8 +724,9 @@ class Chain:
         flags |= F_MASK_INV if valid_mask else 0
         return self._add(op=OP_ROWMASK, dst=dst, dst_col=dst_col, n=n, f0=fill, flags=flags, div=div, p0=mask)
 
-    def groupmax(self, src, src_col, dst, dst_col, n):
-        return self._add(op=OP_GROUPMAX, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
+    def groupmax(self, src, src_col, dst, dst_col, n, mask=None):
+        """mask u8 [rows]: masked rows stay out of the maximum and are zeroed in the src and dst columns (see include/tbx_hip.h)."""
+        return self._add(op=OP_GROUPMAX, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n, p1=mask)
 
     def poolmax(self, src, src_col, n, out, out_col=0, mask=None):
         return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
