@@ -324,6 +324,8 @@ enum {
                            ld / ld2 and dst_col count bf16 elements. For K/V tables read by tbx_knarpe_attn_fwd with seg.kv_bf16. */
   TBX_F_WGEMV = 4096,   /* LINEAR of a tbx_rowchain_live program: p0 is a tbx_pack_weight_gemv() image; a thread per output column,
                            v_fma chains in the MFMA path's k order (bit-identical results, a fraction of the latency at 1-4 rows) */
+  TBX_F_ROWZERO = 32768, /* with TBX_F_ROWSKIP: the skipped rows (and padding rows) are written as 0 instead of keeping their content:
+                           [LINEAR (+ accumulate)] followed by [ROWMASK fill 0] of the destination columns in one stage */
   TBX_F_MASKED_SUM = 16384 /* STORE (fp32 destination): p0[g * ld + dst_col + c] = sum over the `reserved` groups i whose byte
                            p1[i * k + g] is CLEAR of src[:, src_col + i * div + c] (0 when all are set): the masked sum over per-type
                            branches of action_head.py:89-96 in the storing stage (was ROWMASK + COPY/ADD per branch + STORE) */

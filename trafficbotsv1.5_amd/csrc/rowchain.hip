@@ -383,7 +383,10 @@ __device__ __forceinline__ void linear_packed(const tbx_stage_t& s, const Tile<M
               gst1(gout + (int64_t)(m * 16 + g * 4 + r) * s.ld2 + col, v);
           }
         } else if (col_ok) {
-          if (!(skip & (1u << (m * 4 + r)))) dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+          if (!(skip & (1u << (m * 4 + r))))
+            dst[(m * 16 + g * 4 + r) * lds_d + col] = v;
+          else if (s.flags & TBX_F_ROWZERO)
+            dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
         }
         else if (!accum && G == 1 && col < lds_d - s.dst_col)
           dst[(m * 16 + g * 4 + r) * lds_d + col] = 0.f;
@@ -585,7 +588,10 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
               gst1(gout0 + (int64_t)r * s.ld2 + grp * gs_dst + c, v);
           }
         } else if (live) {
-          if (!rowskip || !skip) dst0[r * lds_d + grp * gs_dst + c] = v;
+          if (!rowskip || !skip)
+            dst0[r * lds_d + grp * gs_dst + c] = v;
+          else if (s.flags & TBX_F_ROWZERO)
+            dst0[r * lds_d + grp * gs_dst + c] = 0.f;
         } else if (!accum && G == 1 && o < (N + 15) / 16 * 16 && o < lds_d - s.dst_col) {
           dst0[r * lds_d + o] = 0.f;  // K padding of the next stage, as the MFMA path leaves it
         }
@@ -1206,6 +1212,7 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
       return TBX_ERR_UNSUPPORTED;
     }
   }
+  if ((s.flags & TBX_F_ROWZERO) && !(s.op == TBX_OP_LINEAR && (s.flags & TBX_F_ROWSKIP))) return TBX_ERR_ARG;
   if (s.flags & TBX_F_MASKED_SUM) {
     if (s.op != TBX_OP_STORE || (s.flags & TBX_F_OUT_BF16)) return TBX_ERR_UNSUPPORTED;
     if (s.p1 == nullptr || s.reserved <= 0 || s.div <= 0 || s.k <= 0) return TBX_ERR_ARG;

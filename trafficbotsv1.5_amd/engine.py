@@ -107,19 +107,25 @@ def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tenso
     ch.add(AUX, 0, x_buf, 0, D)
 
 
-def emit_ffn(ch: Chain, layer, x_buf: int = BUF1, drop_hidden=None, drop_out=None):
-    """x += linear2(relu(linear1(norm2(x)))). transformer_rpe.py:234-237; drop_* = (p, seed, site, step) in training."""
+def emit_ffn(ch: Chain, layer, x_buf: int = BUF1, drop_hidden=None, drop_out=None, zero_rows: Optional[torch.Tensor] = None) -> bool:
+    """x += linear2(relu(linear1(norm2(x)))). transformer_rpe.py:234-237; drop_* = (p, seed, site, step) in training.
+    zero_rows (u8 per row): the layer's closing `x[invalid] = 0` folded into the last stage where that stage is the fused residual
+    (TBX_F_ROWZERO) - returns True if it was."""
     ch.layernorm(x_buf, 0, BUF0, 0, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     ch.linear(BUF0, 0, BUF0, D, layer.linear1.weight, layer.linear1.bias, relu=True)
     if drop_hidden is not None:
         ch.dropout(BUF0, D, layer.linear1.weight.shape[0], *drop_hidden)
     if drop_out is None and ch.pack_weights and FUSED_RESIDUAL:
+        if zero_rows is not None and ROWZERO:
+            ch.linear(BUF0, D, x_buf, 0, layer.linear2.weight, layer.linear2.bias, accum=True, skip_rows=zero_rows, zero_skipped=True)
+            return True
         ch.linear(BUF0, D, x_buf, 0, layer.linear2.weight, layer.linear2.bias, accum=True)  # x += linear2(...) in one stage
-        return
+        return False
     ch.linear(BUF0, D, AUX, 0, layer.linear2.weight, layer.linear2.bias)
     if drop_out is not None:
         ch.dropout(AUX, 0, D, *drop_out)
     ch.add(AUX, 0, x_buf, 0, D)
+    return False
 
 
 def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_col: int = 0, end_buf: Optional[int] = None):
@@ -148,6 +154,7 @@ def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_
     return cur
 
 
+ROWZERO = os.environ.get("TBX_ROWZERO", "1") != "0"  # a layer's closing x[invalid] = 0 inside its last LINEAR stage
 MASKED_GROUPMAX = os.environ.get("TBX_MASKED_GROUPMAX", "1") != "0"
 
 
@@ -327,8 +334,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                                obuf, flag, fxy, fyw)
             ch = layer_chain(rows)
             emit_attn_out(ch, a2, obuf, flag, drop=None, x=x)
-            emit_ffn(ch, layer)
-            ch.rowmask(BUF1, 0, D, mask=src_invalid)
+            if not emit_ffn(ch, layer, zero_rows=src_invalid):
+                ch.rowmask(BUF1, 0, D, mask=src_invalid)
             ch.store(BUF1, 0, D, x)
             if l + 1 < len(layers):
                 emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True, kv16=kv16)
@@ -348,8 +355,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                             fold=attn_fold_image(layer.attn) if fold else None)
             ch = layer_chain(rows)
             emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site(), x=x)
-        emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site())
-        ch.rowmask(BUF1, 0, D, mask=src_invalid)
+        if not emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site(), zero_rows=src_invalid):
+            ch.rowmask(BUF1, 0, D, mask=src_invalid)
         ch.store(BUF1, 0, D, x)
         if l + 1 < len(layers):
             emit_proj(ch, rows, first_norm(l + 1), first_attn(l + 1), qkv, with_kv=True, kv16=kv16)

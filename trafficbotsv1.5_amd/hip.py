@@ -25,6 +25,7 @@ F_LOAD2 = 2048
 F_WGEMV = 4096
 F_OUT_BF16 = 8192
 F_MASKED_SUM = 16384
+F_ROWZERO = 32768
 BUF0, BUF1, AUX, GLOBAL = 0, 1, 2, 3
 MAX_STAGES, AUX_LD = 44, 260
 
@@ -660,12 +661,13 @@ class Chain:
         return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
 
     def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False, groups=1,
-               src_stride=0, dst_stride=0, out=None, skip_rows=None, skip_is_valid=False):
+               src_stride=0, dst_stride=0, out=None, skip_rows=None, skip_is_valid=False, zero_skipped=False):
         """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt).
         groups > 1: block-diagonal; weight holds the groups' blocks stacked along dim 0, group g reads
         src_col + g*src_stride and writes dst_col + g*dst_stride.
         dst = GLOBAL with out = [rows, ld] tensor: the result goes straight to out[g, dst_col:+n] (no LDS staging).
-        skip_rows (packed weights only): u8 per global row; flagged rows (un-flagged with skip_is_valid) keep dst's old content -
+        skip_rows (packed weights only): u8 per global row; flagged rows (un-flagged with skip_is_valid) keep dst's old content
+        (zero_skipped: are written as 0 instead: LINEAR + ROWMASK in one stage) -
         with accum into the residual buffer: x += flagged ? 0 : linear(...) in one stage."""
         w = self._rows2d(weight)
         n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
@@ -677,7 +679,7 @@ class Chain:
         if self.live_rows:
             flags = (flags & ~F_WT) | F_WGEMV
             if skip_rows is not None:
-                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0)
+                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0) | (F_ROWZERO if zero_skipped else 0)
             return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
                              act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=packed_weight(w, bias, wt, groups, gemv=True),
                              p1=skip_rows, p2=out, ld2=0 if out is None else self._rows2d(out).stride(0),
@@ -687,7 +689,7 @@ class Chain:
             if self.split_bf16:
                 flags |= F_WSPLIT
             if skip_rows is not None:
-                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0)
+                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0) | (F_ROWZERO if zero_skipped else 0)
             return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
                              act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=skip_rows, p2=out,
                              ld2=0 if out is None else self._rows2d(out).stride(0),
