@@ -32,18 +32,26 @@ class AddNaviLatent(nn.Module):
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
         ch.store(BUF0, 2 * d, d, out)
 
-    def emit_embed_buf(self, ch: Chain, out: Tensor):
-        """mlp_in(z) for z already in BUF0[:, d:2d] -> out [rows, d] (before the validity mask): the same three stages as in
-        `emit(z=None)`, for callers that evaluate them ahead of the chain that owns x (inference: no dropout between them)."""
+    def emit_embed_buf(self, ch: Chain, out: Tensor, z_invalid: Optional[Tensor] = None, mask_is_valid: bool = False) -> bool:
+        """mlp_in(z) for z already in BUF0[:, d:2d] -> out [rows, d]: the same three stages as in `emit(z=None)`, for callers that
+        evaluate them ahead of the chain that owns x (inference: no dropout between them). With z_invalid the validity mask is
+        applied by the last stage (TBX_F_ROWZERO) - returns True if it was (`emit(..., z_premasked=True)` then skips its ROWMASK)."""
+        from ...engine import ROWZERO
         d = self.hidden_dim
         l_in = [t[0] for t in self.mlp_in.linear_layers()]
+        masked = z_invalid is not None and ROWZERO and ch.pack_weights
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
-        ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        if masked:
+            ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True, skip_rows=z_invalid, skip_is_valid=mask_is_valid,
+                      zero_skipped=True)
+        else:
+            ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
         ch.store(BUF0, 2 * d, d, out)
+        return masked
 
     def emit(self, ch: Chain, z_invalid: Tensor, z: Optional[Tensor] = None, mask_is_valid: bool = False,
-             z_embedded: Optional[Tensor] = None):
+             z_embedded: Optional[Tensor] = None, z_premasked: bool = False):
         """x in BUF1[:, 0:d] (updated in place). z either already in BUF0[:, d:2d] (z=None) or loaded from `z`
         [rows, in_dim], or given as `z_embedded` = mlp_in(z) [rows, d] (emit_embed; same values, three stages fewer).
         Uses BUF0 columns [0, 4d)."""
@@ -51,13 +59,19 @@ class AddNaviLatent(nn.Module):
         l_in, l_mlp = [t[0] for t in self.mlp_in.linear_layers()], [t[0] for t in self.mlp.linear_layers()]
         assert len(l_in) == 3 and len(l_mlp) == 3, "default n_layer = 3"
         if z_embedded is not None:
+            from ...engine import ROWZERO
             ch.load(z_embedded, BUF0, 2 * d, n=d)
-            ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
+            if not z_premasked:  # (the producer of z_embedded already zeroed the invalid rows)
+                ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
             ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
             ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
             ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
-            ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
-            ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
+            if ROWZERO and ch.pack_weights:  # the closing mask inside the last stage (relu, then 0 for the masked rows)
+                ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True, skip_rows=z_invalid,
+                          skip_is_valid=mask_is_valid, zero_skipped=True)
+            else:
+                ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True)
+                ch.rowmask(BUF0, 3 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
             ch.add(BUF0, 3 * d, BUF1, 0, d)
             return
         from ...engine import drop_site

@@ -118,7 +118,7 @@ class TrafficBots(nn.Module):
                 prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
             cn = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
             self.navi_encoder.emit(cn, mp_flat, prep["navi_row"], prep["navi_pe"], dest_feature=rc.get("dest_feature"))
-            self.add_navi.emit_embed_buf(cn, prep["navi_emb"])
+            prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
             cn.run(n * A)
 
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
@@ -131,7 +131,8 @@ class TrafficBots(nn.Module):
         ch.load(feat, BUF1, 0, n=d)
         if navi_ahead:
             torch.cuda.current_stream().wait_stream(aux_stream)  # (long done: it ran beside the first layer)
-            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"])
+            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"],
+                               z_premasked=bool(prep.get("_navi_premasked")))
         else:
             self.navi_encoder.emit(ch, mp_flat, prep["navi_row"], navi_pe, dest_feature=rc.get("dest_feature"))
             self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
