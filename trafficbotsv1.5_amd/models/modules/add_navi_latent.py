@@ -20,17 +20,24 @@ class AddNaviLatent(nn.Module):
             self.mlp_in = MLP([in_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
             self.mlp = MLP([2 * hidden_dim] + [hidden_dim] * n_layer, dropout_p=mlp_dropout_p)
 
-    def emit_embed(self, ch: Chain, z: Tensor, out: Tensor):
-        """mlp_in(z) alone -> out [rows, d] (before the validity mask): for inputs that stay the same over a whole rollout (the
-        latent) the engine evaluates this once and hands the result to `emit(..., z_embedded=...)` every step."""
+    def emit_embed(self, ch: Chain, z: Tensor, out: Tensor, z_invalid: Optional[Tensor] = None) -> bool:
+        """mlp_in(z) alone -> out [rows, d]: for inputs that stay the same over a whole rollout (the latent) the engine evaluates
+        this once and hands the result to `emit(..., z_embedded=...)` every step. With z_invalid (fixed over the rollout too) the
+        validity mask is applied here, by the last stage - returns True if it was (`emit(..., z_premasked=True)`)."""
+        from ...engine import ROWZERO
         d = self.hidden_dim
         l_in = [t[0] for t in self.mlp_in.linear_layers()]
         pad = ((self.in_dim + 15) // 16) * 16
+        masked = z_invalid is not None and ROWZERO and ch.pack_weights
         ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)
         ch.linear(BUF0, 0, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
-        ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
+        if masked:
+            ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True, skip_rows=z_invalid, zero_skipped=True)
+        else:
+            ch.linear(BUF0, d, BUF0, 2 * d, l_in[2].weight, l_in[2].bias, relu=True)
         ch.store(BUF0, 2 * d, d, out)
+        return masked
 
     def emit_embed_buf(self, ch: Chain, out: Tensor, z_invalid: Optional[Tensor] = None, mask_is_valid: bool = False) -> bool:
         """mlp_in(z) for z already in BUF0[:, d:2d] -> out [rows, d]: the same three stages as in `emit(z=None)`, for callers that

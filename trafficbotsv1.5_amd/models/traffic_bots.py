@@ -142,12 +142,13 @@ class TrafficBots(nn.Module):
             ch.run(n * A)
             ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
             ch.load(mid, BUF1, 0, n=d)
-        self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"))
+        self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"), z_premasked=bool(rc.get("latent_premasked")))
         self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
         ch.run(n * A)
 
     @torch.no_grad()
-    def rollout_constants(self, ag_latent: Tensor, dest: Tensor, mp_tokens: Dict[str, Tensor], mp_batch_div: int = 1) -> Dict[str, Tensor]:
+    def rollout_constants(self, ag_latent: Tensor, dest: Tensor, mp_tokens: Dict[str, Tensor], mp_batch_div: int = 1,
+                          latent_invalid: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """What the heads chain would recompute identically at every step of a rollout: mlp_in(latent) of `add_latent` and
         mlp_mp(map feature of the destination) of the navi encoder (latent and destination are fixed per rollout:
         waymo_motion.py:232-311 with pred_navi_after_reached off). Same kernels, same values - evaluated once."""
@@ -155,14 +156,15 @@ class TrafficBots(nn.Module):
         d, dev, M = self.hidden_dim, ag_latent.device, mp_tokens["mp_token_pose"].shape[1]
         lat = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         ch = Chain(16, 4 * d + 4)
-        self.add_latent.emit_embed(ch, ag_latent.reshape(n * A, -1).float().contiguous(), lat)
+        premasked = self.add_latent.emit_embed(ch, ag_latent.reshape(n * A, -1).float().contiguous(), lat,
+                                               None if latent_invalid is None else latent_invalid.reshape(-1))
         ch.run(n * A)
         rows = ((torch.arange(n, device=dev) // mp_batch_div).unsqueeze(1) * M + dest).reshape(-1).to(torch.int32).contiguous()
         dst = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         ch = Chain(16, 4 * d + 4)
         self.navi_encoder.emit_dest_feature(ch, mp_tokens["mp_token_feature"].reshape(-1, d), rows, dst)
         ch.run(n * A)
-        return {"latent_embedded": lat, "dest_feature": dst}
+        return {"latent_embedded": lat, "dest_feature": dst, "latent_premasked": premasked}
 
     # ------------------------------------------------------------------ reference per-step API
     def init(self) -> None:

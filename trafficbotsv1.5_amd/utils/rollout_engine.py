@@ -185,7 +185,8 @@ class RolloutEngine:
         self.parity = 0
         self.side, self.aux = self._side_streams(dev)
         # per-rollout constants of the heads chain (embedded latent, destination feature): once, not every step
-        self.consts = self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div) if self.hoist_constants else None
+        self.consts = (self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div, latent_invalid=self.latent_invalid)
+                       if self.hoist_constants else None)
         self._n_forward = 0
         if not stepwise:
             self._tl_ahead(0)
