@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--polylines", type=int, default=1024)
     ap.add_argument("--lights", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-steps", type=int, default=40,
+                    help="closed-loop steps per replayed hipGraph (the engine's own default is 4: this run replays one engine 80+ times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events for the roofline")
@@ -353,6 +355,7 @@ def main():
         wm, full = build(tb, a, dev, rank)
         import_module("trafficbots_amd.engine").KV_BF16 = bool(a.kv_bf16)
         import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.lights_ahead = not a.no_lights_ahead
+        import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.GRAPH_STEPS = max(1, a.graph_steps // 2 * 2)
         eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
         use_graph = not a.no_graph
         if use_graph:
@@ -411,6 +414,7 @@ def main():
             "config": {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
                                    f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
                        "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
+                       "steps_per_graph_replay": max(1, a.graph_steps // 2 * 2) if use_graph else 0,
                        "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -50,7 +50,10 @@ def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
 
 class RolloutEngine:
     lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
-    GRAPH_STEPS = max(1, int(os.environ.get("TBX_GRAPH_STEPS", "4")) // 2 * 2)  # steps per multi-step graph (even; 1: off)
+    # steps per multi-step graph (even; 1: off). A replay boundary costs a few us of idle device: 4 -> 197.9 k, 16 -> 199.4 k, 40 ->
+    # 200.4 k agent-steps/s at the 64-agent scene. Capturing g steps costs g eager steps of host time, so the default suits an engine
+    # that runs ONE 80-step rollout (`WaymoMotion.rollout`); a caller that replays an engine many times raises it (bench.py: 40).
+    GRAPH_STEPS = max(1, int(os.environ.get("TBX_GRAPH_STEPS", "4")) // 2 * 2)
     # The light recurrence (window -> light encoder -> argmax of the next-state logits, dynamics.py:143-163) reads no agent and
     # no latent, so the K rollouts of a scene (joint_future_pred, waymo_motion.py:458-462) carry K identical copies of it: with
     # share_lights the engine steps the lights once per scene and the agents of the K rollouts attend to that one copy
