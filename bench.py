@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--polylines", type=int, default=1024)
     ap.add_argument("--lights", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pre-roll-ms", type=float, default=1500.0,
+                    help="untimed device warm-up before the W warm-up steps: whole rollouts replayed and rewound for this long (0: none)")
     ap.add_argument("--graph-steps", type=int, default=40,
                     help="closed-loop steps per replayed hipGraph (the engine's own default is 4: this run replays one engine 80+ times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,6 +362,16 @@ def main():
         use_graph = not a.no_graph
         if use_graph:
             eng.capture()
+        # device pre-roll (untimed, not part of W): the timed region is ~25 ms of a chain of 20-40 us launches, and a device that
+        # was idle a moment ago runs its first hundreds of milliseconds below its steady clocks (the same binary measured 193 k,
+        # 195 k, 200 k agent-steps/s in three consecutive processes). Whole rollouts are replayed and rewound until
+        # --pre-roll-ms of wall time have passed.
+        t_pre, n_pre = time.perf_counter(), 0
+        while use_graph and (time.perf_counter() - t_pre) * 1e3 < a.pre_roll_ms:
+            eng.run(a.warmup + a.steps, use_graph=True)
+            torch.cuda.synchronize()
+            eng.restore()
+            n_pre += 1
         eng.run(a.warmup, use_graph=use_graph)  # teacher-forced prime steps (untimed)
         barrier()
         t0 = time.perf_counter()
@@ -415,6 +427,7 @@ def main():
                                    f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
                        "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
                        "steps_per_graph_replay": max(1, a.graph_steps // 2 * 2) if use_graph else 0,
+                       "pre_roll_rollouts": n_pre,  # untimed whole-rollout replays before the W warm-up steps (device at steady clocks)
                        "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
             "roofline": {"kernel": "knarpe_attn_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
