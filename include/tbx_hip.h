@@ -146,6 +146,24 @@ typedef struct tbx_dec_mid {
 } tbx_dec_mid_t;
 int tbx_knarpe_dec_mid(const tbx_dec_mid_t* args /* host */, void* stream);
 
+/* A whole dec_cross_attn layer (transformer_rpe.py:207-245) in ONE launch for launches of a few hundred rows: tbx_knarpe_dec_mid
+ * followed, in the same workgroup, by what the row chain after it did - x += row without a valid cross target ? 0 : out_proj(.),
+ * x += linear2(relu(linear1(norm2(x)))), x[src_invalid] = 0 - and, unless qkv_out is NULL (last layer), the NEXT layer's
+ * projections q | k | v = in_proj(norm_src'(x)), W_rpe_k^T q per head -> qkv_out [rows, ld_qkv_out >= 896]. mid.out2 / mid.flag2
+ * are not written. Same arithmetic as the chain's stages (bit-identical). All images are tbx_pack_weight_gemv images:
+ * out_proj2 (n 128, k 128), linear1 (n 512, k 128), linear2 (n 128, k 512), in_proj rows [0, 384) (n 384, k 128), query-side fold
+ * (linear_rpe.weight[0:128] transposed: n 128, k 32, groups 4). fp32 K/V tables only. */
+typedef struct tbx_dec_layer {
+  tbx_dec_mid_t mid;
+  const float *out_proj2_image, *linear1_image, *linear2_image, *next_in_proj_image, *next_qfold_image;
+  const float *norm2_weight, *norm2_bias, *next_norm_weight, *next_norm_bias;
+  const uint8_t* src_invalid; /* [rows] */
+  float* qkv_out;             /* NULL: last layer */
+  float norm2_eps, next_norm_eps;
+  int32_t ld_qkv_out, pad_;
+} tbx_dec_layer_t;
+int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
+
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)

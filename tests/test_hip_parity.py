@@ -566,3 +566,51 @@ def test_knn_multi_launch_equals_single_searches(hip, dev):
                 assert (a is None) == (b is None)
                 if a is not None:
                     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,Ks,T,K,n_layer", [(8, 4, 64, 8, 2), (64, 25, 1024, 64, 3)])
+def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, Ks, T, K, n_layer):
+    """tbx_knarpe_dec_layer (a whole dec_cross_attn layer per launch: attention half, out_proj, FFN, row mask, the next layer's
+    q | k | v | W_k^T q; transformer_rpe.py:207-245) through engine.run_block vs the two launches per layer it replaces
+    (tbx_knarpe_dec_mid + the row chain) and vs the 16-row MFMA schedule: the block's output rows are bit-identical, invalid
+    source rows are 0, for 2 and 3 layers (the last layer has no projections to make)."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    g = torch.Generator().manual_seed(S * 17 + n_layer)
+    blk = M.TransformerBlockRPE(n_layer=n_layer, mode="dec_cross_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.1,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 9)
+    blk = blk.to(dev).eval()
+    n, rows, D = 2, 2 * S, 128
+    x0 = torch.randn(rows, D, generator=g).to(dev)
+    src_invalid = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    x0[src_invalid.bool()] = 0.0
+
+    def knn(T_, K_):
+        rel = torch.cat([(torch.rand(n, S, K_, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K_, 1, generator=g) - 0.5) * 6], -1)
+        return (torch.randint(0, T_, (n, S, K_), generator=g).to(torch.int32).to(dev),
+                (torch.rand(n, S, K_, generator=g) < 0.3).to(torch.uint8).to(dev), rel.to(dev).contiguous())
+
+    i0, m0, r0 = knn(S, Ks)
+    m0[src_invalid.view(n, S).bool()] = 1  # an invalid source has no valid pair (as the K-nearest kernel produces)
+    ic, mc, rc = knn(T, K)
+    mc[src_invalid.view(n, S).bool()] = 1
+    kv = torch.randn(n * T, n_layer * 256, generator=g).to(dev)
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER)
+    outs = {}
+    try:
+        for name, cfg in {"mfma": (0, False, False, False), "mid": (1, True, True, False), "layer": (1, True, True, True)}.items():
+            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = cfg
+            x = x0.clone()
+            eng.run_block(blk, x, src_invalid, n, S, eng.SelfKnn(i0, m0, rel=r0),
+                          cross=lambda l: [hip.Seg(kv, l * 256, l * 256 + D, T, ic, mc, None, 1, rel=rc)], pose_rpe=pe)
+            torch.cuda.synchronize()
+            outs[name] = x
+    finally:
+        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = saved
+    assert torch.isfinite(outs["mfma"]).all() and float(outs["mfma"][src_invalid.bool()].abs().max()) == 0.0
+    assert float((outs["mfma"] - x0).abs().max()) > 1e-3
+    for name in ("mid", "layer"):
+        assert torch.equal(outs[name], outs["mfma"]), (name, float((outs[name] - outs["mfma"]).abs().max()))

@@ -258,7 +258,8 @@ def test_shared_lights_across_rollouts_are_bit_identical(tb):
 @pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
 def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
     """The schedules the engine picks for launches of a few hundred rows - live-row chains (LINEAR as v_fma chains), the
-    attention kernel's folded epilogue, and the fused attention half of a decoder layer (tbx_knarpe_dec_mid) - run the same
+    attention kernel's folded epilogue, the fused attention half of a decoder layer (tbx_knarpe_dec_mid) and the whole layer as one
+    launch (tbx_knarpe_dec_layer) - run the same
     arithmetic in the same order as the 16-row MFMA chains + separate attention launches: the rollouts must not differ by a bit."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, sizes, knn)
@@ -267,16 +268,18 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
     g = torch.Generator().manual_seed(9)
     z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
-    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID)
+    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER)
     outs = {}
     try:
-        for name, (live, fold, mid) in {"mfma": (0, False, False), "live1": (1, False, False), "live2": (2, False, False),
-                                        "fold": (1, True, False), "mid": (1, True, True), "mid2": (2, True, True)}.items():
-            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID = live, fold, mid
+        for name, (live, fold, mid, layer) in {"mfma": (0, False, False, False), "live1": (1, False, False, False),
+                                               "live2": (2, False, False, False), "fold": (1, True, False, False),
+                                               "mid": (1, True, True, False), "mid2": (2, True, True, False),
+                                               "layer": (1, True, True, True), "layer2": (2, True, True, True)}.items():
+            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = live, fold, mid, layer
             outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                             step_end=24)
     finally:
-        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID = saved
+        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = saved
     ref = outs["mfma"]
     for name, o in outs.items():
         assert torch.equal(o.pred_pose, ref.pred_pose), name

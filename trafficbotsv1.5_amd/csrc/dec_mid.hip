@@ -46,6 +46,13 @@ struct MidArgs {
   uint8_t* flag2;
   float ln_eps;
   int ld_qkv, q_off, qt_off, ld_out2, n_rows, n_src;
+  // tbx_knarpe_dec_layer: the rest of the layer in the same launch (wo2 != NULL)
+  const float *wo2, *w1, *w2, *wqkv, *wqt;  // gemv images: cross out_proj, linear1, linear2, next layer's in_proj (q|k|v), its query-side fold
+  const float *ln2_w, *ln2_b, *ln3_w, *ln3_b;
+  const uint8_t* src_invalid;
+  float* qkv_out;  // [rows, ld_qkv_out]: q | k | v | W_k^T q (896 columns) of the next layer's self attention, or NULL (last layer)
+  float ln2_eps, ln3_eps;
+  int ld_qkv_out;
 };
 
 #ifdef TBX_STAGE_CLOCK
@@ -67,6 +74,29 @@ __device__ __forceinline__ void dma_image(const float* img, int n_pieces, float*
   if (wave < w0) return;
   const uint32_t lds0 = lds_addr(slot);
   for (int p = wave - w0; p < n_pieces; p += 4 - w0) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+}
+
+// LayerNorm of a 128-float row in LDS by one wavefront, in the chain's ln_row<2> order (rowchain.hip): src -> dst
+__device__ __forceinline__ void ln_row128(const float* src, float* dst, int lane, float eps, const float (&g)[2], const float (&bt)[2]) {
+  float v[2];
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    v[q] = src[lane + 64 * q];
+    sum += v[q];
+  }
+  sum = tbx::wave_sum(sum);
+  const float mean = sum / (float)D;
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float d = v[q] - mean;
+    var += d * d;
+  }
+  var = tbx::wave_sum(var) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) dst[lane + 64 * q] = (v[q] - mean) * rstd * g[q] + bt[q];
 }
 
 // The stand-alone kernel's epilogue for 4 waves per row with the value fold (attn.hip, FOLD): per-wave partials -> red_s, the
@@ -258,12 +288,116 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     MID_CLK(9);
     bool valid2;
     const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid2);
-    if (threadIdx.x < D) {
-      a.out2[(int64_t)row * a.ld_out2 + threadIdx.x] = f;
-      a.x[(int64_t)row * D + threadIdx.x] = xs[threadIdx.x];  // the token row after the self-attention residual
+    if (a.wo2 == nullptr) {
+      if (threadIdx.x < D) {
+        a.out2[(int64_t)row * a.ld_out2 + threadIdx.x] = f;
+        a.x[(int64_t)row * D + threadIdx.x] = xs[threadIdx.x];  // the token row after the self-attention residual
+      }
+      if (threadIdx.x == 0) a.flag2[row] = valid2 ? 0 : 1;
+      MID_CLK(10);
+      return;
     }
-    if (threadIdx.x == 0) a.flag2[row] = valid2 ? 0 : 1;
-    MID_CLK(10);
+    // ================================================================ tbx_knarpe_dec_layer: the layer's second half in this launch
+    // (transformer_rpe.py:233-237 + the next layer's projections, attention_rpe.py:92-98,147) - the stages of the row chain that
+    // followed tbx_knarpe_dec_mid, in its arithmetic: LINEAR = bias (+ destination) then the k-ordered fma chain (gemv_chain),
+    // LayerNorm = ln_row128. 13 weight chunks alternate through the two LDS slots: waves 2-3 request chunk i + 1 when chunk i's
+    // multiply starts (threads 0..127 multiply; a wave's LDS reads would wait behind its own DMA).
+    if (threadIdx.x < D) o1[threadIdx.x] = f;
+    float* u = comb_s;  // FFN hidden row (512 floats)
+    const bool x_valid = a.src_invalid[row] == 0;
+    float lg2[2] = {0.f, 0.f}, lb2[2] = {0.f, 0.f}, lg3[2] = {0.f, 0.f}, lb3[2] = {0.f, 0.f};
+    if (wave == 0) {
+      lg2[0] = a.ln2_w[lane], lg2[1] = a.ln2_w[64 + lane], lb2[0] = a.ln2_b[lane], lb2[1] = a.ln2_b[64 + lane];
+      if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
+    }
+    // chunk i of the tail -> (image pointer, float4-row offset, rows); slot = B for even i, A for odd i
+    const int n_chunks = a.qkv_out != nullptr ? 13 : 9;
+    auto request = [&](int i) {
+      if (i >= n_chunks || wave < 2) return;
+      const float* img;
+      int row0, rows;
+      if (i == 0) img = a.wo2, row0 = 0, rows = 33;
+      else if (i <= 4) img = a.w1, row0 = (i - 1) * 33, rows = 33;
+      else if (i <= 8) img = a.w2, row0 = i == 5 ? 0 : 1 + (i - 5) * 32, rows = i == 5 ? 33 : 32;
+      else if (i <= 11) img = a.wqkv, row0 = (i - 9) * 33, rows = 33;
+      else img = a.wqt, row0 = 0, rows = 36;
+      const uint32_t lds0 = lds_addr((i & 1) ? slot_a : slot_b);
+      for (int p = wave - 2; p < rows * 2; p += 2) glds_1k(img + (size_t)row0 * 512 + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+    };
+    auto landed = [&]() {  // the chunk requested last has landed (requesting waves wait for their pieces; the barrier collects them)
+      if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    __syncthreads();  // o1 = f complete; both slots are free (fold2 was consumed by combine_fold)
+    request(0);
+    // ---- chunk 0: x += row without a valid cross target ? 0 : out_proj(f)
+    landed();
+    request(1);
+    if (threadIdx.x < D) {
+      const int c = threadIdx.x;
+      const float v = gemv_chain(slot_b, c, o1, D / 16, slot_b[c * 4] + xs[c]);
+      if (valid2) xs[c] = v;
+    }
+    __syncthreads();
+    if (wave == 0) ln_row128(xs, o1, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
+    // ---- chunks 1..4: u = relu(linear1(h))
+#pragma unroll 1
+    for (int i = 1; i <= 4; ++i) {
+      landed();  // (also: h / the previous block's u are complete)
+      request(i + 1);
+      if (threadIdx.x < D) {
+        const int c = threadIdx.x;
+        const float* blk = (i & 1) ? slot_a : slot_b;
+        u[(i - 1) * D + c] = fmaxf(gemv_chain(blk, c, o1, D / 16, blk[c * 4]), 0.f);
+      }
+    }
+    // ---- chunks 5..8: x += linear2(u), one k-chunk of 128 at a time; invalid source rows come out as 0
+    float acc = 0.f;
+#pragma unroll 1
+    for (int i = 5; i <= 8; ++i) {
+      landed();
+      request(i + 1);
+      if (threadIdx.x < D) {
+        const int c = threadIdx.x;
+        const float* blk = (i & 1) ? slot_a : slot_b;
+        if (i == 5) {
+          acc = gemv_chain(blk, c, u, D / 16, blk[c * 4] + xs[c]);
+        } else {
+          acc = gemv_chain(blk - 512, c, u + (i - 5) * D, D / 16, acc);  // (no bias row in this chunk: row q sits at slot row q)
+        }
+      }
+    }
+    if (threadIdx.x < D) {
+      const float v = x_valid ? acc : 0.f;
+      xs[threadIdx.x] = v;
+      a.x[(int64_t)row * D + threadIdx.x] = v;
+    }
+    if (a.qkv_out == nullptr) return;
+    __syncthreads();
+    if (wave == 0) ln_row128(xs, o1, lane, a.ln3_eps, lg3, lb3);  // the next layer's norm_src
+    float* qrow_out = a.qkv_out + (int64_t)row * a.ld_qkv_out;
+    // ---- chunks 9..11: q | k | v = in_proj(h)
+#pragma unroll 1
+    for (int i = 9; i <= 11; ++i) {
+      landed();
+      request(i + 1);
+      if (threadIdx.x < D) {
+        const int c = threadIdx.x;
+        const float* blk = (i & 1) ? slot_a : slot_b;
+        const float v = gemv_chain(blk, c, o1, D / 16, blk[c * 4]);
+        if (i == 9) q2[c] = v;
+        qrow_out[(i - 9) * D + c] = v;
+      }
+    }
+    // ---- chunk 12: W_rpe_k^T q per head: 4 x (32 -> 128), two outputs per thread
+    landed();
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int o = (int)threadIdx.x + 256 * i2;
+      const int g = o >> 7, c = o & (D - 1);
+      const float* blk = slot_b + g * (1 + 2 * 4) * 512;
+      qrow_out[3 * D + o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
+    }
   }
 }
 
@@ -276,12 +410,26 @@ int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
 
 }  // namespace
 
-extern "C" int tbx_knarpe_dec_mid(const tbx_dec_mid_t* p, void* stream) {
-  if (!p || !p->qkv || !p->x || !p->out2 || !p->flag2 || !p->rpe_k_bias_self || !p->rpe_k_bias_cross || !p->ln_weight || !p->ln_bias ||
+static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* stream);
+extern "C" int tbx_knarpe_dec_mid(const tbx_dec_mid_t* p, void* stream) { return dec_launch(p, nullptr, stream); }
+extern "C" int tbx_knarpe_dec_layer(const tbx_dec_layer_t* t, void* stream) {
+  if (!t) return TBX_ERR_ARG;
+  if (!t->out_proj2_image || !t->linear1_image || !t->linear2_image || !t->norm2_weight || !t->norm2_bias || !t->src_invalid) return TBX_ERR_ARG;
+  if (t->qkv_out && (!t->next_in_proj_image || !t->next_qfold_image || !t->next_norm_weight || !t->next_norm_bias || t->ld_qkv_out < 7 * D ||
+                     (t->ld_qkv_out % 4)))
+    return TBX_ERR_ARG;
+  if (t->mid.self_seg.kv_bf16 != 0) return TBX_ERR_UNSUPPORTED;
+  const void* al[] = {t->out_proj2_image, t->linear1_image, t->linear2_image, t->next_in_proj_image, t->next_qfold_image, t->qkv_out};
+  for (const void* q : al)
+    if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
+  return dec_launch(&t->mid, t, stream);
+}
+static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* stream) {
+  if (!p || !p->qkv || !p->x || (!t && (!p->out2 || !p->flag2)) || !p->rpe_k_bias_self || !p->rpe_k_bias_cross || !p->ln_weight || !p->ln_bias ||
       !p->fold_self_image || !p->out_proj_image || !p->q_image || !p->qfold_image || !p->fold_cross_image)
     return TBX_ERR_ARG;
   if (p->n_batch <= 0 || p->n_src <= 0 || p->n_cross < 1 || p->n_cross > 2) return TBX_ERR_ARG;
-  if ((p->ld_qkv % 4) || (p->q_off % 4) || (p->qt_off % 4) || (p->ld_out2 % 4) || p->ld_out2 < D) return TBX_ERR_ALIGN;
+  if ((p->ld_qkv % 4) || (p->q_off % 4) || (p->qt_off % 4) || (!t && ((p->ld_out2 % 4) || p->ld_out2 < D))) return TBX_ERR_ALIGN;
   const void* al[] = {p->qkv, p->x, p->out2, p->fold_self_image, p->out_proj_image, p->q_image, p->qfold_image, p->fold_cross_image,
                       p->rpe_k_bias_self, p->rpe_k_bias_cross};
   for (const void* q : al)
@@ -310,6 +458,13 @@ extern "C" int tbx_knarpe_dec_mid(const tbx_dec_mid_t* p, void* stream) {
   a.out2 = p->out2, a.flag2 = p->flag2;
   a.ld_qkv = p->ld_qkv, a.q_off = p->q_off, a.qt_off = p->qt_off, a.ld_out2 = p->ld_out2;
   a.n_rows = p->n_batch * p->n_src, a.n_src = p->n_src;
+  a.wo2 = nullptr, a.w1 = a.w2 = a.wqkv = a.wqt = nullptr, a.ln2_w = a.ln2_b = a.ln3_w = a.ln3_b = nullptr;
+  a.src_invalid = nullptr, a.qkv_out = nullptr, a.ln2_eps = a.ln3_eps = 0.f, a.ld_qkv_out = 0;
+  if (t) {
+    a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
+    a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
+    a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
+  }
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float);
   static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
   hipStream_t hs = (hipStream_t)stream;

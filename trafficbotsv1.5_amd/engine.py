@@ -74,6 +74,8 @@ ATTN_FOLD_BIG = os.environ.get("TBX_ATTN_FOLD_BIG", "0") == "1"
 # ... and a dec_cross_attn layer's [self attention -> out-proj -> LN -> q -> W_k^T q -> cross attention] runs as ONE launch
 # (tbx_knarpe_dec_mid) instead of attention kernel -> chain -> attention kernel. TBX_DEC_MID=0: the three launches.
 DEC_MID = os.environ.get("TBX_DEC_MID", "1") != "0"
+# ... and the whole layer (that launch + the chain after it) as ONE launch, tbx_knarpe_dec_layer. TBX_DEC_LAYER=0: two launches.
+DEC_LAYER = os.environ.get("TBX_DEC_LAYER", "1") != "0"
 
 
 def attn_fold_image(attn) -> torch.Tensor:
@@ -296,6 +298,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
     qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
+    # (a one-launch layer writes the next layer's q | k | v | qt rows while other workgroups still gather this layer's K / V rows)
+    qkv_alt = torch.empty_like(qkv) if DEC_LAYER and DEC_MID and ATTN_FOLD and bool(live_rows_for(rows)) else None
     kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
     fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
@@ -323,6 +327,30 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
+        whole = mid and DEC_LAYER and qkv_alt is not None and kv16 is None and (l + 1 < len(layers) or tail is None) and src_invalid is not None
+        if whole:
+            # ONE launch for the layer (tbx_knarpe_dec_layer): the attention half below, then out_proj / FFN / x[invalid] = 0 and the
+            # next layer's projections - the stages of the chain that followed tbx_knarpe_dec_mid, in the same arithmetic
+            a2 = layer.attn
+            last = l + 1 == len(layers)
+            tl_ = dict(out_proj2=hip.packed_weight(a2.out_proj_weight, a2.out_proj_bias, gemv=True),
+                       linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, gemv=True),
+                       linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, gemv=True),
+                       norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid)
+            if not last:
+                an, nn_ = first_attn(l + 1), first_norm(l + 1)
+                tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], gemv=True),
+                           next_qfold=hip.packed_weight(an.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True),
+                           next_norm=(nn_.weight, nn_.bias, nn_.eps), qkv_out=qkv_alt)
+            hip.knarpe_dec_mid(qkv, 0, 3 * D, x, self_seg, list(cross(l)), a1.linear_rpe.bias, a2.linear_rpe.bias,
+                               (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, attn_fold_image(a1),
+                               hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, gemv=True),
+                               hip.packed_weight(a2.in_proj_weight[:D], a2.in_proj_bias[:D], gemv=True),
+                               hip.packed_weight(a2.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True), attn_fold_image(a2),
+                               None, None, fxy, fyw, tail=tl_)
+            if not last:
+                qkv, qkv_alt = qkv_alt, qkv  # the next layer's q | k | v | qt went to the other buffer (this layer's K/V rows were still being read)
+            continue
         if mid:
             # one launch: self attention -> x += out_proj(.) -> LN_1 -> q -> W_k^T q -> cross attention -> obuf (128 wide) + flag
             a2 = layer.attn

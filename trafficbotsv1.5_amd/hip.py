@@ -57,6 +57,14 @@ class DecMid(C.Structure):
                 + [(n, C.c_int32) for n in ("ld_qkv", "q_off", "qt_off", "ld_out2", "n_cross", "n_batch", "n_src")])
 
 
+class DecLayer(C.Structure):
+    """tbx_dec_layer_t (include/tbx_hip.h)."""
+    _fields_ = ([("mid", DecMid)]
+                + [(n, C.c_void_p) for n in ("out_proj2_image", "linear1_image", "linear2_image", "next_in_proj_image", "next_qfold_image",
+                                             "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out")]
+                + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("pad_", C.c_int32)])
+
+
 class SimState(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
@@ -124,6 +132,7 @@ def load():
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
+    lib.tbx_knarpe_dec_layer.argtypes = [C.POINTER(DecLayer), vp]
     lib.tbx_knn_embed_multi.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
@@ -167,7 +176,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -354,10 +363,14 @@ def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_s
 
 
 def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: Sequence[Seg], bias_self, bias_cross, ln, n_batch: int,
-                   n_src: int, fold_self, out_proj, q_img, qfold, fold_cross, out2, flag2, freqs_xy=None, freqs_yaw=None):
+                   n_src: int, fold_self, out_proj, q_img, qfold, fold_cross, out2, flag2, freqs_xy=None, freqs_yaw=None, tail=None):
     """tbx_knarpe_dec_mid: folded self attention -> out-proj into x -> LN -> q -> W_k^T q -> folded cross attention, one launch.
-    ln = (weight, bias, eps); the five images are tbx_pack_weight_gemv images (include/tbx_hip.h)."""
-    a = DecMid()
+    ln = (weight, bias, eps); the five images are tbx_pack_weight_gemv images (include/tbx_hip.h).
+    tail = dict(out_proj2, linear1, linear2 (images), norm2 (w, b, eps), src_invalid, and for all but the last layer next_in_proj,
+    next_qfold (images), next_norm (w, b, eps), qkv_out): tbx_knarpe_dec_layer - the rest of the layer in the same launch
+    (out2 / flag2 may then be None)."""
+    t = DecLayer() if tail is not None else None
+    a = t.mid if t is not None else DecMid()
     a.qkv, a.x = _ptr(qkv, torch.float32), _cptr(x, torch.float32)
     a.self_seg = self_seg.c()
     cs = [sg.c() for sg in cross_segs]
@@ -368,9 +381,22 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     a.qfold_image, a.fold_cross_image = _ptr(qfold), _ptr(fold_cross)
     a.ln_weight, a.ln_bias, a.ln_eps = _ptr(ln[0], torch.float32), _ptr(ln[1], torch.float32), float(ln[2])
     a.out2, a.flag2 = _ptr(out2, torch.float32), _ptr(flag2, torch.uint8)
-    a.ld_qkv, a.q_off, a.qt_off, a.ld_out2 = qkv.stride(0), q_off, qt_off, out2.stride(0)
+    a.ld_qkv, a.q_off, a.qt_off, a.ld_out2 = qkv.stride(0), q_off, qt_off, (out2.stride(0) if out2 is not None else 0)
     a.n_cross, a.n_batch, a.n_src = len(cross_segs), n_batch, n_src
-    _check(load().tbx_knarpe_dec_mid(C.byref(a), stream_ptr()), "tbx_knarpe_dec_mid")
+    if t is None:
+        _check(load().tbx_knarpe_dec_mid(C.byref(a), stream_ptr()), "tbx_knarpe_dec_mid")
+        return
+    t.out_proj2_image, t.linear1_image, t.linear2_image = _ptr(tail["out_proj2"]), _ptr(tail["linear1"]), _ptr(tail["linear2"])
+    n2 = tail["norm2"]
+    t.norm2_weight, t.norm2_bias, t.norm2_eps = _ptr(n2[0], torch.float32), _ptr(n2[1], torch.float32), float(n2[2])
+    t.src_invalid = _cptr(tail["src_invalid"], torch.uint8)
+    qo = tail.get("qkv_out")
+    if qo is not None:
+        n3 = tail["next_norm"]
+        t.next_in_proj_image, t.next_qfold_image = _ptr(tail["next_in_proj"]), _ptr(tail["next_qfold"])
+        t.next_norm_weight, t.next_norm_bias, t.next_norm_eps = _ptr(n3[0], torch.float32), _ptr(n3[1], torch.float32), float(n3[2])
+        t.qkv_out, t.ld_qkv_out = _ptr(qo, torch.float32), qo.stride(0)
+    _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
 def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):
