@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   __syncthreads();
   MID_CLK(8);
   dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0);  // lands during the sweep
+  if (a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0);  // (slot B is free: the tail's first chunk rides along)
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -328,10 +329,8 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
       if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     };
-    __syncthreads();  // o1 = f complete; both slots are free (fold2 was consumed by combine_fold)
-    request(0);
-    // ---- chunk 0: x += row without a valid cross target ? 0 : out_proj(f)
-    landed();
+    // ---- chunk 0 (requested before the cross sweep, landed with combine_fold's vmcnt(0)): x += row without a valid cross target ? 0 : out_proj(f)
+    __syncthreads();  // o1 = f complete; slot A is free (fold2 was consumed by combine_fold)
     request(1);
     if (threadIdx.x < D) {
       const int c = threadIdx.x;
