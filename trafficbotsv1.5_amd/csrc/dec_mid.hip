@@ -70,10 +70,10 @@ __device__ unsigned int g_mid_launch;
 // threads 0..127 (waves 0, 1) run the chains, and a wave's LDS reads wait behind its own LDS-DMA (measured:
 // tools/scratch/l2_stream_probe.hip) - the chain would stall for the image's whole flight. w0 = 0 where a sweep follows (no LDS
 // reads until the epilogue's vmcnt(0)): four issuing waves land an image sooner than two.
-__device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane, int w0) {
+__device__ __forceinline__ void dma_image(const float* img, int n_pieces, float* slot, int wave, int lane, int w0, int nw) {
   if (wave < w0) return;
   const uint32_t lds0 = lds_addr(slot);
-  for (int p = wave - w0; p < n_pieces; p += 4 - w0) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+  for (int p = wave - w0; p < n_pieces; p += nw - w0) glds_1k(img + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
 }
 
 // LayerNorm of a 128-float row in LDS by one wavefront, in the chain's ln_row<2> order (rowchain.hip): src -> dst
@@ -103,15 +103,16 @@ __device__ __forceinline__ void ln_row128(const float* src, float* dst, int lane
 // waves' combination -> comb_s, then thread c < 128 runs the fold chain of output column c. Returns the folded value (threads
 // c < 128) and whether the row had a valid target. `fold_blk` must have landed (caller waited for the DMA before the barrier).
 __device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], const float (&L)[NH], float (*red_s)[RED], float* comb_s,
-                                              const float* fold_blk, int wir, int lane, int s8, int tg, bool& any_valid) {
-  if (tg == 0) {
+                                              const float* fold_blk, int wir, int lane, int s8, int tg, bool& any_valid, int nt) {
+  // (nt threads in the workgroup: 256, or 512 where waves 4..7 only fetch weight images - they hold no partials)
+  if (wir < 4 && tg == 0) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       *(float4*)(&red_s[wir][h * DH + s8 * 4]) = st.oacc[h];
       st.eacc[h].store(&red_s[wir][D + h * DR], s8);
     }
   }
-  if (lane < NH) {
+  if (wir < 4 && lane < NH) {
     red_s[wir][OUTW + lane] = M[lane];
     red_s[wir][OUTW + NH + lane] = L[lane];
   }
@@ -134,7 +135,7 @@ __device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], 
     any_valid = any_valid || mm > -INFINITY;
     inv_l[h] = (mm > -INFINITY) ? 1.0f / ll : 0.f;
   }
-  for (int c = threadIdx.x; c < OUTW; c += 256) {
+  for (int c = threadIdx.x; c < OUTW; c += nt) {
     const int h = c < D ? c / DH : (c - D) / DR;
     float acc = 0.f;
 #pragma unroll
@@ -150,8 +151,11 @@ __device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], 
   return out;
 }
 
-template <bool KV16>
-__global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
+// NW = 4: tbx_knarpe_dec_mid. NW = 8: tbx_knarpe_dec_layer - waves 4..7 take no part in the sweeps; they (and waves 2, 3) fetch the
+// tail's 13 weight chunks, six requesting waves instead of two (the tail was bound by the two waves' DMA issue: 1.46 us per chunk).
+template <bool KV16, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* slot_a = lds;                       // 66 KiB: fold1 -> W_q -> fold2
   float* slot_b = slot_a + IMG128;           // 72 KiB: W_o -> query-side fold
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   MID_CLK(0);
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
-  dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane, 0);
-  dma_image(a.wo, IMG128 / 256, slot_b, wave, lane, 0);
+  dma_image(a.fold1, IMG128 / 256, slot_a, wave, lane, 0, NW);
+  dma_image(a.wo, IMG128 / 256, slot_b, wave, lane, 0, NW);
   if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
   // LayerNorm parameters (wave 0 normalises the row): requested now - an ordinary load issued while an image DMA is in flight
   // makes the compiler wait for everything outstanding (it does not see the DMAs, vmcnt is in order)
@@ -207,16 +211,18 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   {
     RowAcc st;
     st.zero();
-    sweep<4, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
-    float M[NH], L[NH];
-    merge_slots(st, M, L);
+    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    if (NW == 4 || wave < 4) {
+      sweep<4, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+      merge_slots(st, M, L);
+    }
     MID_CLK(2);
-    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid1);
+    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid1, NT);
     if (threadIdx.x < D) o1[threadIdx.x] = f;
   }
   __syncthreads();  // o1 complete; slot A (fold1) is free
   MID_CLK(3);
-  dma_image(a.wq, IMG128 / 256, slot_a, wave, lane, 2);
+  dma_image(a.wq, IMG128 / 256, slot_a, wave, lane, 2, NW);
   // ---------------------------------------------------------------- x += no valid target ? 0 : out_proj(o1)   (W_o landed: waited in combine_fold)
   if (threadIdx.x < D) {
     const int c = threadIdx.x;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   }
   __syncthreads();  // xs updated; slot B (W_o) is free
   MID_CLK(4);
-  dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane, 2);
+  dma_image(a.wkf, IMGKF / 256, slot_b, wave, lane, 2, NW);
   // ---------------------------------------------------------------- LN_1(x) -> o1 (one wavefront, the chain's ln_row<2> order)
   if (wave == 0) {
     float v[2];
@@ -248,9 +254,12 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) o1[lane + 64 * q] = (v[q] - mean) * rstd * ln_g[q] + ln_bt[q];
   }
-  // W_q has landed once at most the 36 pieces per issuing wave of the image requested after it are outstanding (DMA loads only: in order)
+  // W_q has landed once at most the 72 / (NW - 2) pieces per issuing wave of the image requested after it are outstanding (DMA loads only: in order)
   MID_CLK(5);
-  asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+  if constexpr (NW == 4)
+    asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __syncthreads();
   MID_CLK(6);
   // ---------------------------------------------------------------- q = W_q LN(x) + b_q
@@ -263,16 +272,15 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   MID_CLK(7);
   // ---------------------------------------------------------------- qt_h = W_rpe_k,h^T q_h: 4 x (32 -> 128), two outputs per thread
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int o = (int)threadIdx.x + 256 * i;
+  for (int o = (int)threadIdx.x; o < NH * D; o += NT) {
     const int g = o >> 7, c = o & (D - 1);
     const float* blk = slot_b + g * (1 + 2 * 4) * 512;
     qt2[o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
   }
   __syncthreads();
   MID_CLK(8);
-  dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0);  // lands during the sweep
-  if (a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0);  // (slot B is free: the tail's first chunk rides along)
+  dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0, NW);  // lands during the sweep
+  if (a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0, NW);  // (slot B is free: the tail's first chunk rides along)
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -283,12 +291,14 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
   {
     RowAcc st;
     st.zero();
-    sweep<4, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
-    float M[NH], L[NH];
-    merge_slots(st, M, L);
+    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    if (NW == 4 || wave < 4) {
+      sweep<4, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+      merge_slots(st, M, L);
+    }
     MID_CLK(9);
     bool valid2;
-    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid2);
+    const float f = combine_fold(st, M, L, red_s, comb_s, slot_a, wir, lane, s8, tg, valid2, NT);
     if (a.wo2 == nullptr) {
       if (threadIdx.x < D) {
         a.out2[(int64_t)row * a.ld_out2 + threadIdx.x] = f;
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
       else if (i <= 11) img = a.wqkv, row0 = (i - 9) * 33, rows = 33;
       else img = a.wqt, row0 = 0, rows = 36;
       const uint32_t lds0 = lds_addr((i & 1) ? slot_a : slot_b);
-      for (int p = wave - 2; p < rows * 2; p += 2) glds_1k(img + (size_t)row0 * 512 + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+      for (int p = wave - 2; p < rows * 2; p += NW - 2) glds_1k(img + (size_t)row0 * 512 + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
     };
     auto landed = [&]() {  // the chunk requested last has landed (requesting waves wait for their pieces; the barrier collects them)
       if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,8 +401,7 @@ __global__ __launch_bounds__(256) void dec_mid_kernel(const MidArgs a) {
     // ---- chunk 12: W_rpe_k^T q per head: 4 x (32 -> 128), two outputs per thread
     landed();
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2) {
-      const int o = (int)threadIdx.x + 256 * i2;
+    for (int o = (int)threadIdx.x; o < NH * D; o += NT) {
       const int g = o >> 7, c = o & (D - 1);
       const float* blk = slot_b + g * (1 + 2 * 4) * 512;
       qrow_out[3 * D + o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
@@ -467,13 +476,18 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float);
   static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
   hipStream_t hs = (hipStream_t)stream;
-  if (p->self_seg.kv_bf16 != 0) {
-    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((dec_mid_kernel<true>), dim3(a.n_rows), dim3(256), lds_bytes, hs, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((dec_mid_kernel<false>), dim3(a.n_rows), dim3(256), lds_bytes, hs, a);
-  }
+#define TBX_MID_LAUNCH(KV, NWV)                                                                                                    \
+  do {                                                                                                                            \
+    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<KV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
+  } while (0)
+  if (t)
+    TBX_MID_LAUNCH(false, 8);
+  else if (p->self_seg.kv_bf16 != 0)
+    TBX_MID_LAUNCH(true, 4);
+  else
+    TBX_MID_LAUNCH(false, 4);
+#undef TBX_MID_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
