@@ -129,8 +129,7 @@ class TrafficBots(nn.Module):
         navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
-        if navi_ahead:
-            torch.cuda.current_stream().wait_stream(aux_stream)  # (long done: it ran beside the first layer)
+        if navi_ahead:  # (its stream was joined before the first attention launch - run_block - with this chain already enqueued on it)
             self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"],
                                z_premasked=bool(prep.get("_navi_premasked")))
         else:
