@@ -152,13 +152,14 @@ int tbx_knarpe_dec_mid(const tbx_dec_mid_t* args /* host */, void* stream);
  * projections q | k | v = in_proj(norm_src'(x)), W_rpe_k^T q per head -> qkv_out [rows, ld_qkv_out >= 896]. mid.out2 / mid.flag2
  * are not written. Same arithmetic as the chain's stages (bit-identical). All images are tbx_pack_weight_gemv images:
  * out_proj2 (n 128, k 128), linear1 (n 512, k 128), linear2 (n 128, k 512), in_proj rows [0, 384) (n 384, k 128), query-side fold
- * (linear_rpe.weight[0:128] transposed: n 128, k 32, groups 4). fp32 K/V tables only. */
+ * (linear_rpe.weight[0:128] transposed: n 128, k 32, groups 4). */
 typedef struct tbx_dec_layer {
   tbx_dec_mid_t mid;
   const float *out_proj2_image, *linear1_image, *linear2_image, *next_in_proj_image, *next_qfold_image;
   const float *norm2_weight, *norm2_bias, *next_norm_weight, *next_norm_bias;
   const uint8_t* src_invalid; /* [rows] */
   float* qkv_out;             /* NULL: last layer */
+  void* kv16_out;             /* bf16 K/V tables (mid.self_seg.kv_bf16): [rows, 256] bfloat16 copy of the next layer's k | v; else NULL */
   float norm2_eps, next_norm_eps;
   int32_t ld_qkv_out, pad_;
 } tbx_dec_layer_t;

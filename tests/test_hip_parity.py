@@ -568,8 +568,8 @@ def test_knn_multi_launch_equals_single_searches(hip, dev):
                     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("S,Ks,T,K,n_layer", [(8, 4, 64, 8, 2), (64, 25, 1024, 64, 3)])
-def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, Ks, T, K, n_layer):
+@pytest.mark.parametrize("S,Ks,T,K,n_layer,bf16", [(8, 4, 64, 8, 2, False), (64, 25, 1024, 64, 3, False), (33, 13, 60, 40, 2, True)])
+def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, Ks, T, K, n_layer, bf16):
     """tbx_knarpe_dec_layer (a whole dec_cross_attn layer per launch: attention half, out_proj, FFN, row mask, the next layer's
     q | k | v | W_k^T q; transformer_rpe.py:207-245) through engine.run_block vs the two launches per layer it replaces
     (tbx_knarpe_dec_mid + the row chain) and vs the 16-row MFMA schedule: the block's output rows are bit-identical, invalid
@@ -597,8 +597,11 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
     ic, mc, rc = knn(T, K)
     mc[src_invalid.view(n, S).bool()] = 1
     kv = torch.randn(n * T, n_layer * 256, generator=g).to(dev)
+    if bf16:  # bfloat16 K/V tables (engine.KV_BF16): the one-launch layer also writes the next layer's bf16 k | v copy
+        kv = kv.to(torch.bfloat16)
     pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
     saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER)
+    saved_bf16, eng.KV_BF16 = eng.KV_BF16, bf16
     outs = {}
     try:
         for name, cfg in {"mfma": (0, False, False, False), "mid": (1, True, True, False), "layer": (1, True, True, True)}.items():
@@ -610,6 +613,7 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
             outs[name] = x
     finally:
         eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = saved
+        eng.KV_BF16 = saved_bf16
     assert torch.isfinite(outs["mfma"]).all() and float(outs["mfma"][src_invalid.bool()].abs().max()) == 0.0
     assert float((outs["mfma"] - x0).abs().max()) > 1e-3
     for name in ("mid", "layer"):

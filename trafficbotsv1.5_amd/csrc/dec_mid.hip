@@ -51,6 +51,7 @@ struct MidArgs {
   const float *ln2_w, *ln2_b, *ln3_w, *ln3_b;
   const uint8_t* src_invalid;
   float* qkv_out;  // [rows, ld_qkv_out]: q | k | v | W_k^T q (896 columns) of the next layer's self attention, or NULL (last layer)
+  uint16_t* kv16_out;  // [rows, 256] bfloat16 copy of k | v (the next layer's self K/V table with bf16 tables), or NULL
   float ln2_eps, ln3_eps;
   int ld_qkv_out;
 };
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
         const float v = gemv_chain(blk, c, o1, D / 16, blk[c * 4]);
         if (i == 9) q2[c] = v;
         qrow_out[(i - 9) * D + c] = v;
+        if (i > 9 && a.kv16_out != nullptr)  // round to nearest even, as the chain's TBX_F_OUT_BF16 store
+          a.kv16_out[(int64_t)row * (2 * D) + (i - 10) * D + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
       }
     }
     // ---- chunk 12: W_rpe_k^T q per head: 4 x (32 -> 128), two outputs per thread
@@ -426,7 +429,7 @@ extern "C" int tbx_knarpe_dec_layer(const tbx_dec_layer_t* t, void* stream) {
   if (t->qkv_out && (!t->next_in_proj_image || !t->next_qfold_image || !t->next_norm_weight || !t->next_norm_bias || t->ld_qkv_out < 7 * D ||
                      (t->ld_qkv_out % 4)))
     return TBX_ERR_ARG;
-  if (t->mid.self_seg.kv_bf16 != 0) return TBX_ERR_UNSUPPORTED;
+  if ((t->mid.self_seg.kv_bf16 != 0) != (t->kv16_out != nullptr) && t->qkv_out) return TBX_ERR_ARG;  // bf16 tables <=> a bf16 k | v copy for the next layer
   const void* al[] = {t->out_proj2_image, t->linear1_image, t->linear2_image, t->next_in_proj_image, t->next_qfold_image, t->qkv_out};
   for (const void* q : al)
     if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
@@ -467,10 +470,11 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   a.ld_qkv = p->ld_qkv, a.q_off = p->q_off, a.qt_off = p->qt_off, a.ld_out2 = p->ld_out2;
   a.n_rows = p->n_batch * p->n_src, a.n_src = p->n_src;
   a.wo2 = nullptr, a.w1 = a.w2 = a.wqkv = a.wqt = nullptr, a.ln2_w = a.ln2_b = a.ln3_w = a.ln3_b = nullptr;
-  a.src_invalid = nullptr, a.qkv_out = nullptr, a.ln2_eps = a.ln3_eps = 0.f, a.ld_qkv_out = 0;
+  a.src_invalid = nullptr, a.qkv_out = nullptr, a.kv16_out = nullptr, a.ln2_eps = a.ln3_eps = 0.f, a.ld_qkv_out = 0;
   if (t) {
     a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
     a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
+    a.kv16_out = (uint16_t*)t->kv16_out;
     a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
   }
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float);
@@ -481,7 +485,9 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     (void)hipFuncSetAttribute((const void*)dec_mid_kernel<KV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
   } while (0)
-  if (t)
+  if (t && p->self_seg.kv_bf16 != 0)
+    TBX_MID_LAUNCH(true, 8);
+  else if (t)
     TBX_MID_LAUNCH(false, 8);
   else if (p->self_seg.kv_bf16 != 0)
     TBX_MID_LAUNCH(true, 4);

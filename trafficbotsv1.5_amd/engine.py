@@ -301,6 +301,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     # (a one-launch layer writes the next layer's q | k | v | qt rows while other workgroups still gather this layer's K / V rows)
     qkv_alt = torch.empty_like(qkv) if DEC_LAYER and DEC_MID and ATTN_FOLD and bool(live_rows_for(rows)) else None
     kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
+    kv16_alt = torch.empty_like(kv16) if (kv16 is not None and qkv_alt is not None) else None
     fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
@@ -327,7 +328,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
-        whole = mid and DEC_LAYER and qkv_alt is not None and kv16 is None and (l + 1 < len(layers) or tail is None) and src_invalid is not None
+        whole = mid and DEC_LAYER and qkv_alt is not None and (l + 1 < len(layers) or tail is None) and src_invalid is not None
         if whole:
             # ONE launch for the layer (tbx_knarpe_dec_layer): the attention half below, then out_proj / FFN / x[invalid] = 0 and the
             # next layer's projections - the stages of the chain that followed tbx_knarpe_dec_mid, in the same arithmetic
@@ -341,7 +342,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                 an, nn_ = first_attn(l + 1), first_norm(l + 1)
                 tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], gemv=True),
                            next_qfold=hip.packed_weight(an.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True),
-                           next_norm=(nn_.weight, nn_.bias, nn_.eps), qkv_out=qkv_alt)
+                           next_norm=(nn_.weight, nn_.bias, nn_.eps), qkv_out=qkv_alt, kv16_out=kv16_alt)
             hip.knarpe_dec_mid(qkv, 0, 3 * D, x, self_seg, list(cross(l)), a1.linear_rpe.bias, a2.linear_rpe.bias,
                                (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, attn_fold_image(a1),
                                hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, gemv=True),
@@ -350,6 +351,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                                None, None, fxy, fyw, tail=tl_)
             if not last:
                 qkv, qkv_alt = qkv_alt, qkv  # the next layer's q | k | v | qt went to the other buffer (this layer's K/V rows were still being read)
+                kv16, kv16_alt = kv16_alt, kv16
             continue
         if mid:
             # one launch: self attention -> x += out_proj(.) -> LN_1 -> q -> W_k^T q -> cross attention -> obuf (128 wide) + flag

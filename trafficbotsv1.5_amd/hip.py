@@ -61,7 +61,7 @@ class DecLayer(C.Structure):
     """tbx_dec_layer_t (include/tbx_hip.h)."""
     _fields_ = ([("mid", DecMid)]
                 + [(n, C.c_void_p) for n in ("out_proj2_image", "linear1_image", "linear2_image", "next_in_proj_image", "next_qfold_image",
-                                             "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out")]
+                                             "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out", "kv16_out")]
                 + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("pad_", C.c_int32)])
 
 
@@ -396,6 +396,9 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
         t.next_in_proj_image, t.next_qfold_image = _ptr(tail["next_in_proj"]), _ptr(tail["next_qfold"])
         t.next_norm_weight, t.next_norm_bias, t.next_norm_eps = _ptr(n3[0], torch.float32), _ptr(n3[1], torch.float32), float(n3[2])
         t.qkv_out, t.ld_qkv_out = _ptr(qo, torch.float32), qo.stride(0)
+        if tail.get("kv16_out") is not None:
+            assert tail["kv16_out"].shape[1] == 256 and tail["kv16_out"].is_contiguous()
+            t.kv16_out = _ptr(tail["kv16_out"], torch.bfloat16)
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
