@@ -166,6 +166,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   float* o1 = xs + D;          // folded self-attention output, then LN_1(x)
   float* q2 = o1 + D;          // q of the cross attention
   float* qt2 = q2 + D;         // W_k^T q, 4 x 128
+  float* bk2_s = qt2 + NH * D; // the cross attention's rpe_k_bias (128 floats), parked in LDS until the cross phase
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wir = wave;
@@ -187,10 +188,8 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
     ln_g[0] = a.ln_w[lane], ln_g[1] = a.ln_w[64 + lane];
     ln_bt[0] = a.ln_b[lane], ln_bt[1] = a.ln_b[64 + lane];
   }
-  // ... and so is the cross attention's rpe_k_bias slice (its q . b_k term)
-  float4 bk2[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) bk2[h] = *(const float4*)(a.bias_k2 + h * DH + s8 * 4);
+  // ... and so is the cross attention's rpe_k_bias (its q . b_k term): to LDS, not to 16 registers that would live across the self sweep
+  if (threadIdx.x < D) bk2_s[threadIdx.x] = a.bias_k2[threadIdx.x];
   EFreq fq;
   fq.init(a.fxy, a.fyaw, s8);
   float4 qv[NH];
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     qv[h] = *(const float4*)(q2 + h * DH + s8 * 4);
-    qb[h] = tbx::group8_sum(dot4(qv[h], bk2[h]));
+    qb[h] = tbx::group8_sum(dot4(qv[h], *(const float4*)(bk2_s + h * DH + s8 * 4)));
     qt[h].load(qt2 + h * DR, s8);
   }
   {
@@ -477,8 +476,8 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     a.kv16_out = (uint16_t*)t->kv16_out;
     a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
   }
-  const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float);
-  static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 7 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
+  const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float);
+  static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
   hipStream_t hs = (hipStream_t)stream;
 #define TBX_MID_LAUNCH(KV, NWV)                                                                                                    \
   do {                                                                                                                            \
