@@ -153,6 +153,21 @@ int tbx_knarpe_dec_mid(const tbx_dec_mid_t* args /* host */, void* stream);
  * are not written. Same arithmetic as the chain's stages (bit-identical). All images are tbx_pack_weight_gemv images:
  * out_proj2 (n 128, k 128), linear1 (n 512, k 128), linear2 (n 128, k 512), in_proj rows [0, 384) (n 384, k 128), query-side fold
  * (linear_rpe.weight[0:128] transposed: n 128, k 32, groups 4). */
+/* Optional heads of the agents' policy in the LAST layer's launch (qkv_out == NULL), traffic_bots.py:206-221: x += navi_valid ?
+ * add_navi.mlp([x | navi_emb]) : 0, x += latent valid ? add_latent.mlp([x | latent_emb]) : 0 (add_navi_latent.py:52-65; both
+ * embeddings = mlp_in(.) with their invalid rows already zeroed), then the action head's per-type branches as three stacked /
+ * block-diagonal stages and their masked sum (action_head.py:74-100) -> action_out [rows, 2]. images[0..2] = add_navi.mlp
+ * (256 -> 128, 128 -> 128, 128 -> 128), [3..5] = add_latent.mlp, [6] = the branches' first layers stacked (128 -> 384), [7] = their
+ * second layers (groups 3, 128 -> 128), [8] = their third layers zero-padded to 16 outputs (groups 3, 128 -> 16): gemv images. */
+typedef struct tbx_heads_tail {
+  const float* images[9];
+  const float *navi_emb, *latent_emb;    /* [rows, 128] */
+  const uint8_t *navi_valid, *latent_invalid; /* [rows] */
+  const uint8_t* type_mask;              /* [3, mask_stride]: byte set = the agent is not of that type (or not valid) */
+  float* action_out;                     /* [rows, 2] */
+  int32_t mask_stride, pad_;
+} tbx_heads_tail_t;
+
 typedef struct tbx_dec_layer {
   tbx_dec_mid_t mid;
   const float *out_proj2_image, *linear1_image, *linear2_image, *next_in_proj_image, *next_qfold_image;
@@ -160,6 +175,7 @@ typedef struct tbx_dec_layer {
   const uint8_t* src_invalid; /* [rows] */
   float* qkv_out;             /* NULL: last layer */
   void* kv16_out;             /* bf16 K/V tables (mid.self_seg.kv_bf16): [rows, 256] bfloat16 copy of the next layer's k | v; else NULL */
+  const tbx_heads_tail_t* heads; /* host pointer or NULL; only with qkv_out == NULL */
   float norm2_eps, next_norm_eps;
   int32_t ld_qkv_out, pad_;
 } tbx_dec_layer_t;

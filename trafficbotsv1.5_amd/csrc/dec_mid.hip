@@ -52,6 +52,13 @@ struct MidArgs {
   const uint8_t* src_invalid;
   float* qkv_out;  // [rows, ld_qkv_out]: q | k | v | W_k^T q (896 columns) of the next layer's self attention, or NULL (last layer)
   uint16_t* kv16_out;  // [rows, 256] bfloat16 copy of k | v (the next layer's self K/V table with bf16 tables), or NULL
+  // heads tail (last layer of the agents' block, tbx_heads_tail_t): hw[0..2] = add_navi.mlp, hw[3..5] = add_latent.mlp,
+  // hw[6..8] = the action head's three stacked stages (gemv images); NULL hw[0]: none
+  const float* hw[9];
+  const float *navi_emb, *latent_emb;
+  const uint8_t *navi_valid, *latent_invalid, *type_mask;
+  float* action_out;
+  int mask_stride;
   float ln2_eps, ln3_eps;
   int ld_qkv_out;
 };
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
     }
     // chunk i of the tail -> (image pointer, float4-row offset, rows); slot = B for even i, A for odd i
-    const int n_chunks = a.qkv_out != nullptr ? 13 : 9;
+    const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
+    const int n_chunks = a.qkv_out != nullptr ? 13 : (heads ? 9 + 15 : 9);
     auto request = [&](int i) {
       if (i >= n_chunks || wave < 2) return;
       const float* img;
@@ -330,7 +338,16 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       if (i == 0) img = a.wo2, row0 = 0, rows = 33;
       else if (i <= 4) img = a.w1, row0 = (i - 1) * 33, rows = 33;
       else if (i <= 8) img = a.w2, row0 = i == 5 ? 0 : 1 + (i - 5) * 32, rows = i == 5 ? 33 : 32;
-      else if (i <= 11) img = a.wqkv, row0 = (i - 9) * 33, rows = 33;
+      else if (heads) {
+        // heads chunk h = i - 9: the two adders' 256 -> 128 stages take two k-chunks, the action head's 384-wide stages three
+        // column blocks
+        const int h = i - 9;
+        const int im = h < 2 ? 0 : h < 4 ? h - 1 : h < 6 ? 3 : h < 8 ? h - 2 : h < 11 ? 6 : h < 14 ? 7 : 8;
+        img = a.hw[im];
+        const bool second = h == 1 || h == 5;
+        row0 = second ? 33 : (h >= 8 && h < 14 ? ((h - 8) % 3) * 33 : 0);
+        rows = second ? 32 : 33;
+      } else if (i <= 11) img = a.wqkv, row0 = (i - 9) * 33, rows = 33;
       else img = a.wqt, row0 = 0, rows = 36;
       const uint32_t lds0 = lds_addr((i & 1) ? slot_a : slot_b);
       for (int p = wave - 2; p < rows * 2; p += NW - 2) glds_1k(img + (size_t)row0 * 512 + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
@@ -380,6 +397,72 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       const float v = x_valid ? acc : 0.f;
       xs[threadIdx.x] = v;
       a.x[(int64_t)row * D + threadIdx.x] = v;
+    }
+    if (heads) {
+      // ============================================================ the agents' heads in the last layer's launch: the stages of the
+      // heads chain (traffic_bots.py:206-221): x += navi_valid ? mlp([x | navi_emb]) : 0 (add_navi_latent.py:52-65), the same with
+      // the latent embedding, the action head's three per-type branches as stacked / block-diagonal stages and their masked sum
+      // (action_head.py:74-100). Both embeddings arrive with their invalid rows already zeroed. Same gemv_chain arithmetic.
+      float* cat = comb_s;          // [x | z] (256), later the action head's first hidden layer (384)
+      float* hb = qt2;              // hidden rows of the adders (128), later the action head's second hidden layer (384)
+      float zn = 0.f, zl = 0.f;
+      if (threadIdx.x < D) zn = a.navi_emb[(int64_t)row * D + threadIdx.x], zl = a.latent_emb[(int64_t)row * D + threadIdx.x];
+      const bool ok_navi = a.navi_valid[row] != 0, ok_lat = a.latent_invalid[row] == 0;
+      int ci = 9;  // chunk index: slot = A for odd, B for even
+      auto blk_of = [&](int i) -> const float* { return (i & 1) ? slot_a : slot_b; };
+#pragma unroll 1
+      for (int adder = 0; adder < 2; ++adder) {
+        if (threadIdx.x < D) cat[threadIdx.x] = xs[threadIdx.x], cat[D + threadIdx.x] = adder == 0 ? zn : zl;
+        float acc2 = 0.f;
+        landed();  // chunk ci (k 0..127 of the 256 -> 128 stage); cat complete
+        request(ci + 1);
+        if (threadIdx.x < D) acc2 = gemv_chain(blk_of(ci), threadIdx.x, cat, D / 16, blk_of(ci)[threadIdx.x * 4]);
+        ++ci;
+        landed();  // k 128..255
+        request(ci + 1);
+        if (threadIdx.x < D) o1[threadIdx.x] = fmaxf(gemv_chain(blk_of(ci) - 512, threadIdx.x, cat + D, D / 16, acc2), 0.f);
+        ++ci;
+        landed();
+        request(ci + 1);
+        if (threadIdx.x < D) hb[threadIdx.x] = fmaxf(gemv_chain(blk_of(ci), threadIdx.x, o1, D / 16, blk_of(ci)[threadIdx.x * 4]), 0.f);
+        ++ci;
+        landed();
+        request(ci + 1);
+        if (threadIdx.x < D) {
+          const float v = fmaxf(gemv_chain(blk_of(ci), threadIdx.x, hb, D / 16, blk_of(ci)[threadIdx.x * 4]), 0.f);
+          xs[threadIdx.x] = xs[threadIdx.x] + ((adder == 0 ? ok_navi : ok_lat) ? v : 0.f);
+        }
+        ++ci;
+        __syncthreads();  // xs updated before it is copied / read again
+      }
+      // ---- action head layer 1: 128 -> 3 x 128 (three column blocks), relu
+#pragma unroll 1
+      for (int g = 0; g < 3; ++g, ++ci) {
+        landed();
+        request(ci + 1);
+        if (threadIdx.x < D) cat[g * D + threadIdx.x] = fmaxf(gemv_chain(blk_of(ci), threadIdx.x, xs, D / 16, blk_of(ci)[threadIdx.x * 4]), 0.f);
+      }
+      // ---- layer 2: block-diagonal 3 x (128 -> 128), relu
+#pragma unroll 1
+      for (int g = 0; g < 3; ++g, ++ci) {
+        landed();
+        request(ci + 1);
+        if (threadIdx.x < D) hb[g * D + threadIdx.x] = fmaxf(gemv_chain(blk_of(ci), threadIdx.x, cat + g * D, D / 16, blk_of(ci)[threadIdx.x * 4]), 0.f);
+      }
+      // ---- layer 3: block-diagonal 3 x (128 -> 16): output o = g * 16 + j of one 128-column block
+      landed();
+      if (threadIdx.x < D) {
+        const int o = threadIdx.x, g = o < 48 ? o >> 4 : 0;
+        o1[o] = gemv_chain(blk_of(ci), o, hb + g * D, D / 16, blk_of(ci)[o * 4]);
+      }
+      __syncthreads();
+      if (threadIdx.x < 2) {  // the masked sum over the branches, in branch order from 0 (TBX_F_MASKED_SUM)
+        float v = 0.f;
+        for (int g = 0; g < 3; ++g)
+          if (a.type_mask[(int64_t)g * a.mask_stride + row] == 0) v += o1[g * 16 + threadIdx.x];
+        a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
+      }
+      return;
     }
     if (a.qkv_out == nullptr) return;
     __syncthreads();
@@ -470,10 +553,24 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   a.n_rows = p->n_batch * p->n_src, a.n_src = p->n_src;
   a.wo2 = nullptr, a.w1 = a.w2 = a.wqkv = a.wqt = nullptr, a.ln2_w = a.ln2_b = a.ln3_w = a.ln3_b = nullptr;
   a.src_invalid = nullptr, a.qkv_out = nullptr, a.kv16_out = nullptr, a.ln2_eps = a.ln3_eps = 0.f, a.ld_qkv_out = 0;
+  for (int i = 0; i < 9; ++i) a.hw[i] = nullptr;
+  a.navi_emb = a.latent_emb = nullptr, a.navi_valid = a.latent_invalid = a.type_mask = nullptr, a.action_out = nullptr, a.mask_stride = 0;
   if (t) {
     a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
     a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
     a.kv16_out = (uint16_t*)t->kv16_out;
+    if (t->heads != nullptr) {
+      const tbx_heads_tail_t& h = *t->heads;
+      if (t->qkv_out != nullptr) return TBX_ERR_ARG;
+      for (int i = 0; i < 9; ++i) {
+        if (!h.images[i] || (((uintptr_t)h.images[i]) & 15)) return TBX_ERR_ARG;
+        a.hw[i] = h.images[i];
+      }
+      if (!h.navi_emb || !h.latent_emb || !h.navi_valid || !h.latent_invalid || !h.type_mask || !h.action_out || h.mask_stride < a.n_rows)
+        return TBX_ERR_ARG;
+      a.navi_emb = h.navi_emb, a.latent_emb = h.latent_emb, a.navi_valid = h.navi_valid, a.latent_invalid = h.latent_invalid;
+      a.type_mask = h.type_mask, a.action_out = h.action_out, a.mask_stride = h.mask_stride;
+    }
     a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
   }
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float);

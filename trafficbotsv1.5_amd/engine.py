@@ -76,6 +76,8 @@ ATTN_FOLD_BIG = os.environ.get("TBX_ATTN_FOLD_BIG", "0") == "1"
 DEC_MID = os.environ.get("TBX_DEC_MID", "1") != "0"
 # ... and the whole layer (that launch + the chain after it) as ONE launch, tbx_knarpe_dec_layer. TBX_DEC_LAYER=0: two launches.
 DEC_LAYER = os.environ.get("TBX_DEC_LAYER", "1") != "0"
+# ... and, for the agents' last layer, the heads (navigation / latent adders + action head) in that launch as well. TBX_HEADS_TAIL=0: a chain.
+HEADS_TAIL = os.environ.get("TBX_HEADS_TAIL", "1") != "0"
 
 
 def attn_fold_image(attn) -> torch.Tensor:
@@ -273,7 +275,8 @@ class SelfKnn:
 
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
-              tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None) -> None:
+              tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None,
+              heads_tail: Optional[dict] = None) -> bool:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE (join_stream: a stream the K-nearest sets are being produced on, waited for right before the
     first attention call). `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
@@ -305,6 +308,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
+    heads_done = False  # -> True if the last layer's launch also ran `heads_tail`
     layers = list(block.layers)
     dec = block.mode == "dec_cross_attn"
     if not dec and block.mode != "enc_self_attn":
@@ -338,6 +342,9 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                        linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, gemv=True),
                        linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, gemv=True),
                        norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid)
+            if last and heads_tail is not None and HEADS_TAIL:
+                tl_["heads"] = heads_tail  # the agents' heads in this launch too (tbx_heads_tail_t)
+                heads_done = True
             if not last:
                 an, nn_ = first_attn(l + 1), first_norm(l + 1)
                 tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], gemv=True),
@@ -396,6 +403,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     if drop is not None:
         drop["site"], drop["call"] = DROP_CTX["site"], DROP_CTX["call"]
         DROP_CTX = outer
+    return heads_done
 
 
 def kv_tables(x: torch.Tensor, norms_and_attns, out: Optional[torch.Tensor] = None, tile_rows: int = 16) -> torch.Tensor:

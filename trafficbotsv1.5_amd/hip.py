@@ -57,11 +57,18 @@ class DecMid(C.Structure):
                 + [(n, C.c_int32) for n in ("ld_qkv", "q_off", "qt_off", "ld_out2", "n_cross", "n_batch", "n_src")])
 
 
+class HeadsTail(C.Structure):
+    """tbx_heads_tail_t (include/tbx_hip.h)."""
+    _fields_ = ([("images", C.c_void_p * 9)]
+                + [(n, C.c_void_p) for n in ("navi_emb", "latent_emb", "navi_valid", "latent_invalid", "type_mask", "action_out")]
+                + [("mask_stride", C.c_int32), ("pad_", C.c_int32)])
+
+
 class DecLayer(C.Structure):
     """tbx_dec_layer_t (include/tbx_hip.h)."""
     _fields_ = ([("mid", DecMid)]
                 + [(n, C.c_void_p) for n in ("out_proj2_image", "linear1_image", "linear2_image", "next_in_proj_image", "next_qfold_image",
-                                             "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out", "kv16_out")]
+                                             "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out", "kv16_out", "heads")]
                 + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("pad_", C.c_int32)])
 
 
@@ -399,6 +406,16 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
         if tail.get("kv16_out") is not None:
             assert tail["kv16_out"].shape[1] == 256 and tail["kv16_out"].is_contiguous()
             t.kv16_out = _ptr(tail["kv16_out"], torch.bfloat16)
+    hd, keep = tail.get("heads"), None
+    if hd is not None:  # dict(images = 9 gemv images, navi_emb, latent_emb, navi_valid, latent_invalid, type_mask [3, rows] u8, action_out [rows, 2])
+        keep = HeadsTail()
+        for i, im in enumerate(hd["images"]):
+            keep.images[i] = _ptr(im, torch.float32)
+        keep.navi_emb, keep.latent_emb = _cptr(hd["navi_emb"], torch.float32), _cptr(hd["latent_emb"], torch.float32)
+        keep.navi_valid, keep.latent_invalid = _cptr(hd["navi_valid"], torch.uint8), _cptr(hd["latent_invalid"], torch.uint8)
+        keep.type_mask, keep.action_out = _cptr(hd["type_mask"], torch.uint8), _cptr(hd["action_out"], torch.float32)
+        keep.mask_stride = hd["type_mask"].shape[1]
+        t.heads = C.addressof(keep)
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 

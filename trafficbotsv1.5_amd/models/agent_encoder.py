@@ -64,14 +64,16 @@ class AgentEncoder(nn.Module):
                tl_invalid_u8: Tensor, tl_pose: Tensor, tl_kv: Tensor, prep: Optional[Dict[str, Tensor]] = None,
                ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1, tl_batch_div: int = 1,
                tail: Optional[Callable[[Chain], None]] = None, aux_stream=None, navi_rpe=None,
-               aux_tail: Optional[Callable[[Dict[str, Tensor]], None]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+               aux_tail: Optional[Callable[[Dict[str, Tensor]], None]] = None,
+               heads_tail: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
         """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256]
         ([n/tl_batch_div * L, ..] with tl_pose / tl_invalid_u8 [n/tl_batch_div, L, ..] when the rollouts of a scene share its lights).
         -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows).
         aux_stream: the three K-nearest searches (they need the token poses only) run there while this stream runs the
         temporal PointNet of the agents' windows; their outputs live in `prep` across steps. navi_rpe: the PoseEmb of the navigation
         encoder - the embedding of the destination's relative pose (prep["navi_pe"], an input of the heads chain that depends on
-        agent_prep only) is then computed on that stream too instead of between the last layer and the heads. aux_tail(prep): more
+        agent_prep only) is then computed on that stream too instead of between the last layer and the heads. heads_tail(prep): the
+        caller's heads as tbx_heads_tail_t fields for the last layer's launch (see engine.run_block). aux_tail(prep): more
         work of the caller's that needs nothing but `prep` (the navigation embedding of the heads), enqueued on that stream after it."""
         n, A, W = hist_valid.shape
         assert W == self.temp_window_size
@@ -132,7 +134,8 @@ class AgentEncoder(nn.Module):
                     _knn_at=(i_at, m_at, r_at))
         kv_mp = self.kv_mp(mp)
         # (the searches are joined inside run_block, right before the first attention call: the first projection chain needs x only)
-        run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa),
+        # heads_tail(prep) -> the tbx_heads_tail_t fields (or None): the caller's heads in the last layer's launch; prep["_heads_done"] tells
+        prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else heads_tail(prep),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
                                    Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
                   join_stream=aux_stream)

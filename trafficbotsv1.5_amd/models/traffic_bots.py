@@ -121,11 +121,32 @@ class TrafficBots(nn.Module):
             prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
             cn.run(n * A)
 
+        def heads_tail(prep):
+            """The heads as tbx_heads_tail_t fields when everything they read is at hand in the form the fused launch takes it:
+            navigation embedding from the auxiliary stream (masked by its producer), latent embedding of the rollout (masked once),
+            3-layer adders without layernorm, the action head's stacked branches."""
+            ah, an, al = self.action_head, self.add_navi, self.add_latent
+            if not (navi_ahead and prep.get("_navi_premasked") and rc.get("latent_premasked") and rc.get("latent_embedded") is not None
+                    and ah.fused_branches and ah.masked_sum_store and len(ah.mlp_mean) == 3 and ah.out_dim <= 16):
+                return None
+            pw = lambda w, b, **kw: hip.packed_weight(w, b, gemv=True, **kw)
+            lins = [[t[0] for t in mlp.linear_layers()] for mlp in ah.mlp_mean]
+            w1, b1 = hip.stacked_linear([l[0] for l in lins])
+            w2, b2 = hip.stacked_linear([l[1] for l in lins])
+            w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
+            imgs = [pw(t[0].weight, t[0].bias) for t in an.mlp.linear_layers()] + [pw(t[0].weight, t[0].bias) for t in al.mlp.linear_layers()]
+            imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
+            return dict(images=imgs, navi_emb=prep["navi_emb"], latent_emb=rc["latent_embedded"], navi_valid=navi_valid_u8.reshape(-1),
+                        latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"], action_out=out["action_mean"])
+
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
-                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None)
+                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None,
+                                            heads_tail=heads_tail if navi_ahead else None)
         out["prep"], out["ag_feat"] = prep, feat
+        if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
+            return
         navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
