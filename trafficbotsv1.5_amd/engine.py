@@ -78,6 +78,8 @@ DEC_MID = os.environ.get("TBX_DEC_MID", "1") != "0"
 DEC_LAYER = os.environ.get("TBX_DEC_LAYER", "1") != "0"
 # ... and, for the agents' last layer, the heads (navigation / latent adders + action head) in that launch as well. TBX_HEADS_TAIL=0: a chain.
 HEADS_TAIL = os.environ.get("TBX_HEADS_TAIL", "1") != "0"
+# A last layer whose chain carries a caller's tail (the lights' logits head): the layer as one launch + the tail as a short chain.
+TAIL_SPLIT = os.environ.get("TBX_TAIL_SPLIT", "1") != "0"
 
 
 def attn_fold_image(attn) -> torch.Tensor:
@@ -332,7 +334,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
-        whole = mid and DEC_LAYER and qkv_alt is not None and (l + 1 < len(layers) or tail is None) and src_invalid is not None
+        whole = mid and DEC_LAYER and qkv_alt is not None and (l + 1 < len(layers) or tail is None or TAIL_SPLIT) and src_invalid is not None
         if whole:
             # ONE launch for the layer (tbx_knarpe_dec_layer): the attention half below, then out_proj / FFN / x[invalid] = 0 and the
             # next layer's projections - the stages of the chain that followed tbx_knarpe_dec_mid, in the same arithmetic
@@ -359,6 +361,11 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             if not last:
                 qkv, qkv_alt = qkv_alt, qkv  # the next layer's q | k | v | qt went to the other buffer (this layer's K/V rows were still being read)
                 kv16, kv16_alt = kv16_alt, kv16
+            elif tail is not None:  # the caller's row-local stages on the finished rows: a short chain of their own
+                ch = layer_chain(rows)
+                ch.load(x, BUF1, 0, n=D)
+                tail(ch)
+                ch.run(rows)
             continue
         if mid:
             # one launch: self attention -> x += out_proj(.) -> LN_1 -> q -> W_k^T q -> cross attention -> obuf (128 wide) + flag
