@@ -357,7 +357,10 @@ def main():
         wm, full = build(tb, a, dev, rank)
         import_module("trafficbots_amd.engine").KV_BF16 = bool(a.kv_bf16)
         import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.lights_ahead = not a.no_lights_ahead
-        import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.GRAPH_STEPS = max(1, a.graph_steps // 2 * 2)
+        # (a timed region shorter than --graph-steps: one graph of all of it; after an odd number of warm-up steps the light tables'
+        # double buffer is at parity 1 and the multi-step graph, captured at parity 0, starts one step in)
+        gsteps = max(1, min(a.graph_steps, a.steps - (a.warmup % 2)) // 2 * 2)
+        import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine.GRAPH_STEPS = gsteps
         eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
         use_graph = not a.no_graph
         if use_graph:
@@ -426,7 +429,7 @@ def main():
             "config": {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
                                    f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
                        "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
-                       "steps_per_graph_replay": max(1, a.graph_steps // 2 * 2) if use_graph else 0,
+                       "steps_per_graph_replay": gsteps if use_graph else 0,
                        "pre_roll_rollouts": n_pre,  # untimed whole-rollout replays before the W warm-up steps (device at steady clocks)
                        "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
                        "weights": "random init of the 10,657,094-parameter default architecture"},
