@@ -138,7 +138,18 @@ class KernelEvents:
             e0.record()
             self._mid(*args, **kw)
             e1.record()
-            self.mid.append((e0, e1))
+            # algorithmic bytes of the launch: both attentions' pairs + every weight image once (5 of the attention half;
+            # with a tail the layer's out_proj / FFN / next projections = 13 chunks, with the heads 15 more) + token rows in and out
+            self_seg, cross = args[4], args[5]
+            rows = args[9] * args[10]
+            eb = 2 if self_seg.kv.dtype == torch.bfloat16 else 4
+            pairs = rows * (self_seg.k + sum(c.k for c in cross))
+            tail = kw.get("tail")
+            w = (4 * 33 + 36) * 2048
+            if tail is not None:
+                w += (8 * 33 + 3 * 32 + (3 * 33 + 36 if tail.get("qkv_out") is not None else 0) + (13 * 33 + 2 * 32 if tail.get("heads") else 0)) * 2048
+            b = 2 * attn_algorithmic_bytes(rows, 0, eb) + pairs * (2 * 128 * eb + 17) + w + rows * (128 * 4 * 2 + (896 * 4 if tail and tail.get("qkv_out") is not None else 0))
+            self.mid.append((e0, e1, b, rows))
 
         def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -164,8 +175,8 @@ class KernelEvents:
 
     def mid_summary(self):
         torch.cuda.synchronize()
-        tm = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in self.mid]
-        return sum(tm), len(tm)
+        tm = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in self.mid]
+        return sum(tm), len(tm), sum(b for _, _, b, _ in self.mid)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -401,9 +412,11 @@ def main():
                 torch.cuda._sleep(int(2.4e9 * (0.01 + 0.006 * a.profile_steps)))
                 with KernelEvents(hip) as ke0:
                     eng.run(a.profile_steps, use_graph=False)
-                t_mid, n_mid = ke0.mid_summary()
-                if n_mid:
-                    mid_stats = {"kernel": "dec_mid_kernel", "launches_per_step": n_mid / a.profile_steps, "avg_launch_us": t_mid / n_mid * 1e6}
+                t_mid, n_mid, b_mid = ke0.mid_summary()
+                if n_mid:  # the kernel the timed region's time goes to at this size: a whole decoder layer per launch (latency-bound)
+                    mid_stats = {"kernel": "dec_mid_kernel (tbx_knarpe_dec_layer: a decoder layer per launch)", "launches_per_step": n_mid / a.profile_steps,
+                                 "avg_launch_us": t_mid / n_mid * 1e6, "algorithmic_bytes_per_launch": b_mid / n_mid,
+                                 "achieved_GBps": b_mid / t_mid / 1e9, "frac_of_hbm_peak": b_mid / t_mid / 1e9 / HBM_PEAK_GBS}
                 E.DEC_MID = False
             # the host must be AHEAD of the device while the events are recorded: an event pair around a launch otherwise also
             # times the wait for the host to enqueue that launch (seen on a loaded box: 27 us "launches" of a 10 us kernel).
