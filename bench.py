@@ -397,6 +397,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         units = world * a.scenes * a.rollouts * a.agents * a.steps
+        if a.profile_steps <= 0:  # tooling only (timeline traces, A/B runs): the timed region without the per-kernel pass
+            return {"value": units / dt, "ms_per_step": dt / a.steps * 1e3, "roofline": None, "cpu_baseline": None,
+                    "note": "--profile-steps 0: no per-kernel timing pass, not a judged line",
+                    "finite": bool(torch.isfinite(eng.S["out_pose"]).all())}, wm, full
         # ---- live per-kernel timing: eager steps right after the timed region, same state, events on the launch stream, in
         # the engine's one-stream order so that a kernel's duration is its own (in the timed region the light and agent
         # halves share the device, which stretches the kernels of both)

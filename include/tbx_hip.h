@@ -348,6 +348,9 @@ enum {
   TBX_F_ROW_BATCH_MOD = 32, /* row_of(g) = (g / div2) * div + g % div   with div2 packed in k (LOAD only) */
   TBX_F_WPACK = 64,   /* LINEAR: p0 is the tbx_pack_weight() image of the weight (ld / TBX_F_WT are then ignored) */
   TBX_F_MASK_INV = 128, /* ROWMASK: p0 holds a validity byte: rows with p0[row_of(g)] == 0 are filled */
+  TBX_F_POOL_KEEP = 256, /* POOLMAX: the pooled rows also stay in LDS (row j of buffer `dst` != src, columns [k, k + n)) and the tile goes on
+                           as a flat tile of its groups - global row = group index: the stages after it run on the pooled rows (the first
+                           projection of the transformer that consumes them, in the launch that pooled them) */
   TBX_F_WSPLIT = 512,   /* LINEAR + TBX_F_WPACK: p0 is a tbx_pack_weight_split() image: split-bf16, three products on the bf16 MFMA */
   TBX_F_LOAD2 = 2048,   /* LOAD: a second source in the same stage (one memory round trip for both): buffer `src`, column `src_col`
                            (=) p2[row_of(g) * ld2 + c], c < reserved; whole float4s on both sides (n, ld, reserved, ld2 % 4 == 0,

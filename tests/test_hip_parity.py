@@ -618,3 +618,39 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
     assert float((outs["mfma"] - x0).abs().max()) > 1e-3
     for name in ("mid", "layer"):
         assert torch.equal(outs[name], outs["mfma"]), (name, float((outs[name] - outs["mfma"]).abs().max()))
+
+
+@pytest.mark.parametrize("tile,groups,gw", [(16, 7, 11), (32, 9, 11), (48, 10, 11), (16, 5, 16)])
+def test_pooled_rows_kept_in_lds_feed_the_same_stages(hip, dev, tile, groups, gw):
+    """TBX_F_POOL_KEEP: POOLMAX leaves the pooled rows in LDS and the tile goes on as a flat tile of its groups (several groups per
+    32 / 48-row tile, a ragged last tile) - the stages after it give what a second launch over the pooled rows gives, bit for bit."""
+    g = torch.Generator().manual_seed(tile + groups)
+    x = torch.randn(groups * gw, 128, generator=g).to(dev)
+    inv = (torch.rand(groups * gw, generator=g) < 0.3).to(torch.uint8)
+    inv[:gw] = 1  # a group without a valid row -> pooled row of zeros
+    inv = inv.to(dev)
+    w, b = torch.randn(48, 128, generator=g).to(dev), torch.randn(48, generator=g).to(dev)
+    lw, lb = torch.randn(128, generator=g).to(dev), torch.randn(128, generator=g).to(dev)
+    C, B0, B1, AUX = hip.Chain, hip.BUF0, hip.BUF1, hip.AUX
+    pooled_a, out_a = torch.empty(groups, 128, device=dev), torch.empty(groups, 48, device=dev)
+    ch = C(tile, 260)
+    ch.load(x, B0, 0, n=128)
+    ch.poolmax(B0, 0, 128, pooled_a, mask=inv, keep=(AUX, 0))
+    ch.layernorm(AUX, 0, B1, 0, lw, lb, 1e-5)
+    ch.linear(B1, 0, B0, 0, w, b, relu=True)
+    ch.store(B0, 0, 48, out_a)
+    ch.run(groups * gw, group_rows=gw)
+    pooled_b, out_b = torch.empty(groups, 128, device=dev), torch.empty(groups, 48, device=dev)
+    ch = C(tile, 260)
+    ch.load(x, B0, 0, n=128)
+    ch.poolmax(B0, 0, 128, pooled_b, mask=inv)
+    ch.run(groups * gw, group_rows=gw)
+    ch = C(16, 260)
+    ch.load(pooled_b, AUX, 0, n=128)
+    ch.layernorm(AUX, 0, B1, 0, lw, lb, 1e-5)
+    ch.linear(B1, 0, B0, 0, w, b, relu=True)
+    ch.store(B0, 0, 48, out_b)
+    ch.run(groups)
+    assert torch.equal(pooled_a, pooled_b) and float(pooled_a[0].abs().max()) == 0.0
+    assert torch.equal(out_a, out_b)
+    assert torch.isfinite(out_a).all()

@@ -268,18 +268,20 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
     g = torch.Generator().manual_seed(9)
     z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
-    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER)
+    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ)
     outs = {}
     try:
-        for name, (live, fold, mid, layer) in {"mfma": (0, False, False, False), "live1": (1, False, False, False),
-                                               "live2": (2, False, False, False), "fold": (1, True, False, False),
-                                               "mid": (1, True, True, False), "mid2": (2, True, True, False),
-                                               "layer": (1, True, True, True), "layer2": (2, True, True, True)}.items():
-            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = live, fold, mid, layer
+        # (.., pool): layer 0's projections inside the launch that pools the windows (TBX_F_POOL_KEEP) or as a launch of their own
+        for name, (live, fold, mid, layer, pool) in {"mfma": (0, False, False, False, False), "live1": (1, False, False, False, False),
+                                                     "live2": (2, False, False, False, True), "fold": (1, True, False, False, True),
+                                                     "mid": (1, True, True, False, False), "mid2": (2, True, True, False, True),
+                                                     "layer": (1, True, True, True, False), "layer2": (2, True, True, True, True),
+                                                     "layer1p": (1, True, True, True, True)}.items():
+            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = live, fold, mid, layer, pool
             outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                             step_end=24)
     finally:
-        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = saved
+        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = saved
     ref = outs["mfma"]
     for name, o in outs.items():
         assert torch.equal(o.pred_pose, ref.pred_pose), name

@@ -896,7 +896,9 @@ __device__ void op_poolmax(const tbx_stage_t& s, const Tile<MT, EXT>& t) {
       any = true;
       m = fmaxf(m, src[r * lds_s + c]);
     }
-    gst1(out + (t.group + j) * (int64_t)s.ld + s.dst_col + c, any ? m : 0.f);
+    const float v = any ? m : 0.f;
+    gst1(out + (t.group + j) * (int64_t)s.ld + s.dst_col + c, v);
+    if (s.flags & TBX_F_POOL_KEEP) t.b(s.dst)[j * t.l(s.dst) + s.k + c] = v;  // (dst != src: other threads still read the group's rows)
   }
 }
 
@@ -1085,6 +1087,14 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     // Stage barrier: orders LDS only. Weight loads issued ahead stay in flight across it, and global memory written by
     // a stage (STORE / POOLMAX / LINEAR-to-global) is an output of the launch, never read back by a later stage.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (!LIVE) {
+      if (s.op == TBX_OP_POOLMAX && (s.flags & TBX_F_POOL_KEEP)) {  // the tile goes on as a flat tile of its pooled rows
+        t.g0 = t.group;
+        t.n_valid = t.ng;
+        t.gw = ROWS;
+        t.ng = 1;
+      }
+    }
     TBX_CLK(i + 1);
   }
 #ifdef TBX_STAGE_CLOCK
@@ -1220,6 +1230,10 @@ int check_stage(const tbx_stage_t& s, int ldw0, int ldw1, int ld_aux, int tile_r
   }
   if (s.op == TBX_OP_LAYERNORM && (s.n > 512 || s.p0 == nullptr || s.p1 == nullptr)) return TBX_ERR_UNSUPPORTED;
   if ((s.op == TBX_OP_POOLMAX || s.op == TBX_OP_STORE) && (s.p0 == nullptr || s.ld <= 0)) return TBX_ERR_ARG;
+  if (s.flags & TBX_F_POOL_KEEP) {
+    if (s.op != TBX_OP_POOLMAX || s.dst == s.src || s.dst > 2) return TBX_ERR_ARG;
+    if (s.k < 0 || s.k + s.n > buf_ld(s.dst)) return TBX_ERR_UNSUPPORTED;
+  }
   if (s.op != TBX_OP_LINEAR && (s.flags & (TBX_F_ROW_DIV | TBX_F_ROW_MOD | TBX_F_ROW_BATCH_MOD)) && s.div <= 0) return TBX_ERR_ARG;
   if ((s.flags & TBX_F_ROW_BATCH_MOD) && s.k <= 0) return TBX_ERR_ARG;
   (void)tile_rows;

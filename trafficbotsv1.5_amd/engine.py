@@ -164,9 +164,10 @@ ROWZERO = os.environ.get("TBX_ROWZERO", "1") != "0"  # a layer's closing x[inval
 MASKED_GROUPMAX = os.environ.get("TBX_MASKED_GROUPMAX", "1") != "0"
 
 
-def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.Tensor, x_buf: int = BUF1):
+def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.Tensor, x_buf: int = BUF1, keep: bool = False) -> Optional[int]:
     """PointNet over the rows of one group (tile): polyline_encoder.py:49-61 + pooling.py:18-19,38.
-    Input x at x_buf[:, 0:128]; pooled row -> out[group]."""
+    Input x at x_buf[:, 0:128]; pooled row -> out[group]. keep: the pooled rows also stay in LDS and the chain goes on with them
+    (Chain.poolmax keep=) - returns the buffer they are in ([:, 0:width])."""
     cur = x_buf
     for mlp in pl_encoder.mlp_layers:
         lin = mlp.linear_layers()[0][0]
@@ -183,7 +184,12 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
             ch.groupmax(nxt, 0, nxt, half, half)
             ch.rowmask(nxt, 0, 2 * half, mask=row_invalid, fill=0.0)
         cur = nxt
-    ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid)
+    if not keep:
+        ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid)
+        return None
+    kept = BUF1 if cur != BUF1 else AUX
+    ch.poolmax(cur, 0, out.shape[1], out, mask=row_invalid, keep=(kept, 0))
+    return kept
 
 
 # LDS row widths of the transformer-layer chains: BUF0 holds the wide intermediates (attention output 640, FFN hidden
@@ -236,12 +242,12 @@ def layer_chain(rows: int) -> Chain:
     return row_chain(rows, 1028, big=(32, LAYER_LDW0, LAYER_LDW1, LAYER_AUX))
 
 
-def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool, kv16: Optional[torch.Tensor] = None):
-    """LN(x in BUF1) -> [q | k | v | qt] / [q | qt] stored to `out` (+ k | v as bfloat16 to kv16 [rows, 256] if given)."""
+def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool, kv16: Optional[torch.Tensor] = None, x_buf: int = BUF1):
+    """LN(x in x_buf) -> [q | k | v | qt] / [q | qt] stored to `out` (+ k | v as bfloat16 to kv16 [rows, 256] if given)."""
     if rows >= BIG_ROWS:
-        emit_proj_to(ch, norm, attn, out, with_kv, kv16=kv16)
+        emit_proj_to(ch, norm, attn, out, with_kv, x_buf=x_buf, kv16=kv16)
     else:
-        ch.layernorm(BUF1, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
+        ch.layernorm(x_buf, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
         w = emit_qkv(ch, attn, BUF0, 0, BUF0, D, with_kv=with_kv)
         ch.store(BUF0, D, w, out)
         if kv16 is not None:  # the self-attention K/V table as bfloat16 (q and W_k^T q stay fp32 in `out`)
@@ -265,6 +271,28 @@ def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf:
     ch.linear(BUF0, D, GLOBAL, nq, attn.linear_rpe.weight[:D], wt=True, groups=NH, src_stride=DH, dst_stride=D, out=out)
 
 
+# Small launches: the transformer's first projection (LN -> q | k | v | W_k^T q of layer 0) inside the launch that pools its input
+# rows (the temporal PointNet of the agents' / lights' windows) instead of as a launch of its own between the two.
+POOL_PROJ = os.environ.get("TBX_POOL_PROJ", "0") == "1"
+FIRST_PROJ_LDW = 1028  # BUF0 of such a chain: the LayerNorm row + the 896-wide projection
+
+
+def first_proj_buffers(rows: int, dev, tile_rows: int = 16) -> Optional[dict]:
+    """The q | k | v | qt rows (+ the bfloat16 k | v copy) run_block(first_proj=...) starts from when the producer of its input rows
+    ran emit_first_proj in its own chain; None where that form is not used (large launches, training's keyed dropout)."""
+    if not (POOL_PROJ and live_rows_for(rows)) or tile_rows != 16:  # (two 1028-wide buffers of 16 rows: 148 KB of LDS)
+        return None
+    return dict(qkv=torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev),
+                kv16=torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 else None)
+
+
+def emit_first_proj(ch: Chain, block, fp: dict, x_buf: int) -> None:
+    """Layer 0's projections of `block` on the rows in x_buf[:, 0:128] (the same stages run_block's first chain runs)."""
+    l0 = block.layers[0]
+    dec = block.mode == "dec_cross_attn"
+    emit_proj(ch, 0, l0.norm_src if dec else l0.norm1, l0.attn_src if dec else l0.attn, fp["qkv"], with_kv=True, kv16=fp["kv16"], x_buf=x_buf)
+
+
 class SelfKnn:
     """KNN set among the source tokens themselves: idx i32 / invalid u8 [n,S,K] and either the materialised pose embedding
     emb f32 [n,S,K,128] or the relative pose rel f32 [n,S,K,3] (embedding rebuilt inside the attention kernel)."""
@@ -278,7 +306,7 @@ class SelfKnn:
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
               tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None,
-              heads_tail: Optional[dict] = None) -> bool:
+              heads_tail: Optional[dict] = None, first_proj: Optional[dict] = None) -> bool:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE (join_stream: a stream the K-nearest sets are being produced on, waited for right before the
     first attention call). `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
@@ -302,10 +330,13 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     rows = n * S
     dev = x.device
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
-    qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev)
+    qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev) if first_proj is None else first_proj["qkv"]
     # (a one-launch layer writes the next layer's q | k | v | qt rows while other workgroups still gather this layer's K / V rows)
     qkv_alt = torch.empty_like(qkv) if DEC_LAYER and DEC_MID and ATTN_FOLD and bool(live_rows_for(rows)) else None
     kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
+    if first_proj is not None:  # layer 0's projections were made by the launch that produced x (emit_first_proj)
+        assert drop is None and DROP_CTX is None and (first_proj["kv16"] is not None) == (kv16 is not None)
+        kv16 = first_proj["kv16"]
     kv16_alt = torch.empty_like(kv16) if (kv16 is not None and qkv_alt is not None) else None
     fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
@@ -323,10 +354,11 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     def first_norm(l):
         return layers[l].norm_src if dec else layers[l].norm1
 
-    ch = layer_chain(rows)
-    ch.load(x, BUF1, 0, n=D)
-    emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
-    ch.run(rows)
+    if first_proj is None:
+        ch = layer_chain(rows)
+        ch.load(x, BUF1, 0, n=D)
+        emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
+        ch.run(rows)
     if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
     mid = fold and dec and DEC_MID and bool(live_rows_for(rows))  # the one-launch attention half: small launches only

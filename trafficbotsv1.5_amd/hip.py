@@ -19,6 +19,7 @@ HEADER_PATH = _PKG.parent / "include" / "tbx_hip.h"
 OP_LOAD, OP_LINEAR, OP_LAYERNORM, OP_ADD, OP_COPY, OP_ROWMASK, OP_GROUPMAX, OP_POOLMAX, OP_STORE, OP_CLAMP, OP_DROPOUT = range(1, 12)
 ACT_NONE, ACT_RELU = 0, 1
 F_ACCUM, F_WT, F_ROW_DIV, F_ROW_MOD, F_ROW_IDX, F_ROW_BATCH_MOD, F_WPACK, F_MASK_INV = 1, 2, 4, 8, 16, 32, 64, 128
+F_POOL_KEEP = 256
 F_WSPLIT = 512
 F_ROWSKIP = 1024
 F_LOAD2 = 2048
@@ -776,9 +777,15 @@ class Chain:
         """mask u8 [rows]: masked rows stay out of the maximum and are zeroed in the src and dst columns (see include/tbx_hip.h)."""
         return self._add(op=OP_GROUPMAX, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n, p1=mask)
 
-    def poolmax(self, src, src_col, n, out, out_col=0, mask=None):
+    def poolmax(self, src, src_col, n, out, out_col=0, mask=None, keep=None):
+        """out[group] = max over the group's unmasked rows. keep=(buf, col): the pooled rows also stay in LDS (row j of `buf` != src =
+        group j of the tile) and the stages after this one run on them - the tile's global rows are then its group indices."""
+        if keep is None:
+            return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
+                             p1=mask)
+        assert keep[0] != src and not self.live_rows
         return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
-                         p1=mask)
+                         p1=mask, dst=keep[0], k=keep[1], flags=F_POOL_KEEP)
 
     def store(self, src, src_col, n, out, out_col=0):
         """out[g, out_col:+n] = src[:, src_col:+n]; a bfloat16 `out` receives the values rounded to nearest even."""

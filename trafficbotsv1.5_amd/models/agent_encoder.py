@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import emit_mlp, D, SelfKnn, emit_pointnet, kv_tables, run_block
+from ..engine import emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -96,7 +96,8 @@ class AgentEncoder(nn.Module):
         if aux_stream is not None:
             aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
-        ch = Chain(hip.group_tile_rows(W, n * A), d + 4)
+        fp = first_proj_buffers(n * A, dev, hip.group_tile_rows(W, n * A))  # small launches: layer 0's projections in the windows' launch too
+        ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
         ie = self.input_encoder
         if (ie.mode == "cat" and len(ie.mlp.linear_layers()) == 3 and ie.mlp.output_dim % 16 == 0 and prep["attr"].shape[1] % 4 == 0
                 and ie.mlp.output_dim + ie.pe_dim <= d):
@@ -108,7 +109,9 @@ class AgentEncoder(nn.Module):
             assert cur == BUF1
         else:
             cur = ie.emit(ch, prep["attr"], prep["pe"])
-        emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur)
+        kept = emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur, keep=fp is not None)
+        if fp is not None:
+            emit_first_proj(ch, self.tf_ag2agmptl, fp, kept)
         ch.run(n * A * W, group_rows=W)
         # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
         # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
@@ -138,7 +141,7 @@ class AgentEncoder(nn.Module):
         prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else heads_tail(prep),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
                                    Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
-                  join_stream=aux_stream)
+                  join_stream=aux_stream, first_proj=fp)
         return x, prep
 
     @staticmethod

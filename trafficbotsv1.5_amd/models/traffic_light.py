@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import D, SelfKnn, emit_pointnet, kv_tables, run_block
+from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -83,16 +83,19 @@ class TrafficLightEncoder(nn.Module):
         row_inv = torch.empty(rows, dtype=torch.uint8, device=dev)
         hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
         x = torch.empty(n * L, d, dtype=torch.float32, device=dev)
-        ch = Chain(hip.group_tile_rows(W, n * L), d + 4)
+        fp = first_proj_buffers(n * L, dev, hip.group_tile_rows(W, n * L))  # small launches: layer 0's projections in the windows' launch too
+        ch = Chain(hip.group_tile_rows(W, n * L), d + 4 if fp is None else FIRST_PROJ_LDW)
         cur = self.input_encoder.emit(ch, attr, t["tl_token_attr"].reshape(n * L, d), pe_row_div=W)
-        emit_pointnet(ch, self.temp_encoder, row_inv, x, x_buf=cur)
+        kept = emit_pointnet(ch, self.temp_encoder, row_inv, x, x_buf=cur, keep=fp is not None)
+        if fp is not None:
+            emit_first_proj(ch, self.tf_tl2tlmp, fp, kept)
         ch.run(rows, group_rows=W)
         kv = self._kv_mp(t)
         M, div = t["n_mp"], t["mp_batch_div"]
         knn = SelfKnn(t["knn_idx_tl2tl"], t["knn_invalid_tl2tl"], t["rpe_tl2tl"], rel=t["rel_tl2tl"])
         run_block(self.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, knn,
                   cross=lambda l: [Seg(kv, l * 2 * D, l * 2 * D + D, M, t["knn_idx_tl2mp"], t["knn_invalid_tl2mp"],
-                                       t["rpe_tl2mp"], div, rel=t["rel_tl2mp"])], tail=tail, pose_rpe=self.pose_rpe)
+                                       t["rpe_tl2mp"], div, rel=t["rel_tl2mp"])], tail=tail, pose_rpe=self.pose_rpe, first_proj=fp)
         return x
 
     @staticmethod
