@@ -526,3 +526,41 @@ def test_navi_pair_first_layer_is_the_concat_linear_without_the_concat(tb):
     torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
     for got, want, name in zip((W, bias, fa, fm), ref, ("W", "bias", "f_a", "f_m")):
         torch.testing.assert_close(got.grad, want, rtol=2e-4, atol=2e-4, msg=lambda m, name=name: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("shape", [(1, 128), (7, 9, 128), (70001, 128), (16, 64, 300, 128)])
+def test_layernorm_backward_vs_float64_autograd(tb, shape):
+    """tbx_layernorm_bwd behind train_graph.layer_norm (rows of 128; the forward stays aten's) vs float64 autograd of F.layer_norm:
+    dx per element, dgamma / dbeta relative to the sum of magnitudes they accumulate; deterministic across calls."""
+    dev = torch.device("cuda:0")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 3.0 + 0.5).to(dev)
+    go = torch.randn(*shape, generator=g).to(dev)
+    m = torch.nn.LayerNorm(128).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(128, generator=g) * 0.5 + 1.0)
+        m.bias.copy_(torch.randn(128, generator=g))
+    res = []
+    for _ in range(2):
+        xx = x.clone().requires_grad_(True)
+        m.zero_grad()
+        y = TG.layer_norm(xx, m)
+        assert isinstance(y.grad_fn, TG.LayerNormFn._backward_cls)
+        (y * go).sum().backward()
+        res.append((y.detach(), xx.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    xd = x.double().requires_grad_(True)
+    wd, bd = m.weight.detach().double().requires_grad_(True), m.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.layer_norm(xd, (128,), wd, bd, m.eps)
+    (yd * go.double()).sum().backward()
+    y, dx, dw, db = res[0]
+    torch.testing.assert_close(y.double(), yd.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx.double(), xd.grad, rtol=1e-4, atol=1e-5 * float(xd.grad.abs().max()))
+    rows = x.numel() // 128
+    xh = ((xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + m.eps)).detach()
+    mag_w = (go.double().abs() * xh.abs()).reshape(rows, 128).sum(0)
+    mag_b = go.double().abs().reshape(rows, 128).sum(0)
+    assert float(((dw.double() - wd.grad).abs() / mag_w.clamp_min(1e-30)).max()) < 2e-6
+    assert float(((db.double() - bd.grad).abs() / mag_b.clamp_min(1e-30)).max()) < 2e-6

@@ -158,6 +158,8 @@ def load():
     lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
     lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
     lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
+    lib.tbx_layernorm_bwd_partials.argtypes = [i64]
+    lib.tbx_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_fwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp]
     lib.tbx_train_chain_bwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, vp, vp, vp]
     lib.tbx_knn_inverse.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
@@ -184,7 +186,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -334,6 +336,26 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
     _check(lib.tbx_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits,
                                 stream_ptr()), "tbx_linear_wgrad")
     return dw, db
+
+
+def layernorm_bwd_ok(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 128 and x.numel() > 0
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+    """(dx, dgamma, dbeta) of y = LayerNorm_128(x) * gamma + beta given dy, with the forward's per-row mean / rstd (tbx_layernorm_bwd)."""
+    assert layernorm_bwd_ok(x) and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and dy.dtype == torch.float32
+    rows = x.numel() // 128
+    assert mean.numel() == rows and rstd.numel() == rows and mean.is_contiguous() and rstd.is_contiguous()
+    lib = load()
+    n = lib.tbx_layernorm_bwd_partials(rows)
+    scratch = torch.empty(n, 256, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dg = torch.empty(128, dtype=torch.float32, device=x.device)
+    db = torch.empty(128, dtype=torch.float32, device=x.device)
+    _check(lib.tbx_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma.contiguous(), torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
+                                 rows, 128, _ptr(dx), _ptr(dg), _ptr(db), _ptr(scratch), stream_ptr()), "tbx_layernorm_bwd")
+    return dx, dg, db
 
 
 def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid,

@@ -19,6 +19,7 @@ one), followed by the tiny per-step dynamics / reward chain on the batched means
 autograd (`training_rollout`, kept as the checked reference of the restructure), but ~25 large launches per layer
 instead of 90 x as many small ones.
 """
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -169,6 +170,34 @@ class _DropScope:
         return False
 
 
+class LayerNormFn(torch.autograd.Function):
+    """F.layer_norm over rows of 128 whose backward is tbx_layernorm_bwd (x and dy read once, dx written once, deterministic dgamma /
+    dbeta) instead of aten's three kernels; the forward stays aten's (it hands over the per-row mean / rstd)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        y, mean, rstd = torch.native_layer_norm(x, (x.shape[-1],), w, b, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = hip.layernorm_bwd(x, dy.contiguous(), w, mean, rstd)
+        return dx, dw, db, None
+
+
+LN_BWD = os.environ.get("TBX_LN_BWD", "1") != "0"
+
+
+def layer_norm(x: Tensor, m) -> Tensor:
+    """m = an nn.LayerNorm over the last dimension."""
+    if LN_BWD and m.weight.shape == (D,) and hip.layernorm_bwd_ok(x) and torch.is_grad_enabled():
+        return LayerNormFn.apply(x, m.weight, m.bias, m.eps)
+    return F.layer_norm(x, m.weight.shape, m.weight, m.bias, m.eps)
+
+
 class KeyedDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed, site, rows_per_scene, tb, t0):
@@ -206,7 +235,7 @@ def fold_attention_weights(attn):
 def kv_table(attn, norm, t: Targets) -> Tensor:
     """K|V table [tokens, 256] of a target set for one attention layer (LayerNorm + projection, before the gather)."""
     f = fold_attention_weights(attn)
-    make = lambda: linear(F.layer_norm(t.tokens, (D,), norm.weight, norm.bias, norm.eps) if norm is not None else t.tokens,
+    make = lambda: linear(layer_norm(t.tokens, norm) if norm is not None else t.tokens,
                             f["w_kv"], f["b_kv"])
     if t.cache is None or t.key is None:
         return make()
@@ -288,7 +317,7 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
     cross(layer) -> list[Targets] with UN-normalised tokens (norm_tgt is applied here)."""
     if _chains_ok(x):
         return _transformer_block_chains(block, x, src_invalid, n, S, self_knn, cross, p, training)
-    ln = lambda m, t: F.layer_norm(t, (D,), m.weight, m.bias, m.eps)
+    ln = lambda m, t: layer_norm(t, m)
     inv = src_invalid.reshape(-1).bool().unsqueeze(-1)
     for layer in block.layers:
         if block.mode == "dec_cross_attn":
@@ -315,7 +344,7 @@ def mlp(m, x: Tensor, training: bool = False) -> Tensor:
     for lin, lnm, act in m.linear_layers():
         x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
-            x = F.layer_norm(x, lnm.weight.shape, lnm.weight, lnm.bias, lnm.eps)
+            x = layer_norm(x, lnm)
         if act:
             x = F.relu(x)
         x = _drop(x, p, training)
@@ -587,14 +616,14 @@ def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
     pm = linear(mpf, w1[:, d:2 * d], lin1.bias)
     x = NaviPairFirstLayer.apply(rel, w1[:, 2 * d:], pa, pm, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs)
     if ln1 is not None:
-        x = F.layer_norm(x, ln1.weight.shape, ln1.weight, ln1.bias, ln1.eps)
+        x = layer_norm(x, ln1)
     if act1:
         x = F.relu(x)
     x = _drop(x, npd.mlp.dropout_p, training)
     for lin, lnm, act in rest:
         x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
-            x = F.layer_norm(x, lnm.weight.shape, lnm.weight, lnm.bias, lnm.eps)
+            x = layer_norm(x, lnm)
         if act:
             x = F.relu(x)
         x = _drop(x, npd.mlp.dropout_p, training)
