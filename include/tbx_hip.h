@@ -274,6 +274,27 @@ int tbx_layernorm_bwd_partials(int64_t rows);
 int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, int64_t rows, int cols,
                       float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
 
+/* The glue of a PointNet layer over the time-batched windows, forward and backward (training; autograd of polyline_encoder.py:49-61 and
+ * pooling.py:18-19,38: relu / dropout / masked_fill / amax / expand / cat and their backward kernels). A wavefront per group of
+ * group_rows <= 16 rows; every tensor is read or written once.
+ *   tbx_pointnet_tail_fwd: z [n_groups, group_rows, 64] = the layer's Linear output, invalid [n_groups, group_rows] u8 ->
+ *     out [n_groups, group_rows, 128] = [h | max over the group's valid rows of h], invalid rows zeroed, h = dropout(relu(z)) with
+ *     tbx_keyed_dropout's mask for the [n_groups * group_rows, 64] view (p_drop = 0: none; site / rows_per_scene / time_batch / time0
+ *     as there).
+ *   tbx_pointnet_tail_bwd: dz from dout and the forward's `out` (the maximum's gradient split evenly among tied rows, as aten's
+ *     amax backward does; relu' and the dropout mask are read off h > 0).
+ *   tbx_masked_maxpool_fwd / _bwd: y [n_groups, 128] = max over the valid rows of x [n_groups, group_rows, 128] (0 for a group without
+ *     one); dx from dy and x, ties split evenly.
+ * cols must be 64 (tail) / 128 (pool): anything else is TBX_ERR_UNSUPPORTED. */
+int tbx_pointnet_tail_fwd(const float* z, const uint8_t* invalid, int64_t n_groups, int group_rows, int cols, float p_drop,
+                          const uint64_t* drop_seed /* device */, uint32_t site, int rows_per_scene, int time_batch, int time0, float* out,
+                          void* stream);
+int tbx_pointnet_tail_bwd(const float* dout, const float* out, const uint8_t* invalid, int64_t n_groups, int group_rows, int cols,
+                          float p_drop, float* dz, void* stream);
+int tbx_masked_maxpool_fwd(const float* x, const uint8_t* invalid, int64_t n_groups, int group_rows, int cols, float* y, void* stream);
+int tbx_masked_maxpool_bwd(const float* dy, const float* x, const uint8_t* invalid, int64_t n_groups, int group_rows, int cols, float* dx,
+                           void* stream);
+
 /* The per-step state machine of the TRAINING rollout (waymo_motion.py:206-311 with training=True; utils/dynamics.py:66-204,
  * 237-274, utils/teacher_forcing.py:108-167, utils/traffic_rule_checker.py:109-120,300-330, utils/rewards.py:35-85,
  * utils/buffer.py:39-78) for steps t in [t0, t1) (step number s = t + 1 = ground-truth index): action = tanh(mean) * lim,

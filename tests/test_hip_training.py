@@ -564,3 +564,47 @@ def test_layernorm_backward_vs_float64_autograd(tb, shape):
     mag_b = go.double().abs().reshape(rows, 128).sum(0)
     assert float(((dw.double() - wd.grad).abs() / mag_w.clamp_min(1e-30)).max()) < 2e-6
     assert float(((db.double() - bd.grad).abs() / mag_b.clamp_min(1e-30)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("G,W,dropout", [(5, 11, False), (3000, 11, True), (777, 16, True), (64, 1, False)])
+def test_fused_pointnet_glue_equals_the_aten_ops(tb, G, W, dropout):
+    """train_graph.pointnet with tbx_pointnet_tail_* / tbx_masked_maxpool_* (one launch per layer for relu / keyed dropout / masked max /
+    concat / zeroing, one for their backward) vs the same function on aten ops: forward bit-identical (same masks: the dropout ids
+    agree), input and parameter gradients at fp32 summation level - with ties (ReLU zeros, repeated rows), invalid rows and groups
+    without a valid row."""
+    dev = torch.device("cuda:0")
+    W_ = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    TG = import_module("trafficbots_amd.train_graph")
+    wm = W_.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    enc = wm.model.ag_encoder.temp_encoder.to(dev)
+    g = torch.Generator().manual_seed(G + W)
+    x = torch.randn(G, W, 128, generator=g)
+    if W > 2:
+        x[:, 2] = x[:, 1]  # tied maxima
+    invalid = torch.rand(G, W, generator=g) < 0.3
+    invalid[0] = True  # a group without a valid row
+    go = torch.randn(G, 128, generator=g).to(dev)
+    x, invalid = x.to(dev), invalid.to(dev)
+    res = {}
+    saved = (TG.POINTNET_FUSED, TG._DROP)
+    try:
+        for fused in (True, False):
+            TG.POINTNET_FUSED = fused
+            TG._DROP = {"seed": torch.tensor([1234], dtype=torch.int64, device=dev), "call": 0, "site": 7, "n_batch": 1, "tb": 1, "t0": 3}
+            xx = x.clone().requires_grad_(True)
+            enc.zero_grad()
+            y = TG.pointnet(enc, xx, invalid, training=dropout)
+            assert isinstance(y.grad_fn, TG.MaskedMaxPoolFn._backward_cls) == fused
+            (y * go).sum().backward()
+            res[fused] = (y.detach(), xx.grad.clone(), [p.grad.clone() for p in enc.parameters()], TG._DROP["site"])
+    finally:
+        TG.POINTNET_FUSED, TG._DROP = saved
+    (ya, dxa, dpa, sa), (yb, dxb, dpb, sb) = res[True], res[False]
+    assert sa == sb  # the dropout site ids advance alike
+    assert torch.equal(ya, yb) and float(ya[0].abs().max()) == 0.0
+    if dropout:
+        assert bool((ya == 0).any())
+    torch.testing.assert_close(dxa, dxb, rtol=1e-4, atol=1e-5 * float(dxb.abs().max()))
+    for a, b in zip(dpa, dpb):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()) + 1e-12)

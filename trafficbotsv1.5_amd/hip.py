@@ -158,6 +158,10 @@ def load():
     lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
     lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
     lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
+    lib.tbx_pointnet_tail_fwd.argtypes = [vp, vp, i64, i32, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
+    lib.tbx_pointnet_tail_bwd.argtypes = [vp, vp, vp, i64, i32, i32, C.c_float, vp, vp]
+    lib.tbx_masked_maxpool_fwd.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    lib.tbx_masked_maxpool_bwd.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
     lib.tbx_layernorm_bwd_partials.argtypes = [i64]
     lib.tbx_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_fwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp]
@@ -186,7 +190,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -336,6 +340,49 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
     _check(lib.tbx_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits,
                                 stream_ptr()), "tbx_linear_wgrad")
     return dw, db
+
+
+def pointnet_tail_ok(z: torch.Tensor) -> bool:
+    """z [G, W, 64] fp32 on the device, W <= 16: the shapes tbx_pointnet_tail_* / tbx_masked_maxpool_* take."""
+    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[2] == 64 and 0 < z.shape[1] <= 16 and z.shape[0] > 0
+
+
+def pointnet_tail_fwd(z: torch.Tensor, invalid_u8: torch.Tensor, drop=None) -> torch.Tensor:
+    """[relu(z) (* keyed dropout) | its max over the group's valid rows], invalid rows zeroed. drop = None or (p, seed int64[1] device
+    tensor, site, rows_per_scene, time_batch, time0) - tbx_keyed_dropout's arguments for the [G * W, 64] view."""
+    assert pointnet_tail_ok(z) and z.is_contiguous() and invalid_u8.dtype == torch.uint8 and invalid_u8.is_contiguous()
+    G, W, Cc = z.shape
+    assert invalid_u8.numel() == G * W
+    out = torch.empty(G, W, 2 * Cc, dtype=torch.float32, device=z.device)
+    p, seed, site, rps, tb, t0 = drop if drop is not None else (0.0, None, 0, 1, 1, 0)
+    _check(load().tbx_pointnet_tail_fwd(_ptr(z), _ptr(invalid_u8), G, W, Cc, float(p), _ptr(seed, torch.int64) if seed is not None else None,
+                                        int(site), int(rps), int(tb), int(t0), _ptr(out), stream_ptr()), "tbx_pointnet_tail_fwd")
+    return out
+
+
+def pointnet_tail_bwd(dout: torch.Tensor, out: torch.Tensor, invalid_u8: torch.Tensor, p: float) -> torch.Tensor:
+    G, W, C2 = out.shape
+    assert dout.shape == out.shape and dout.is_contiguous() and dout.dtype == torch.float32
+    dz = torch.empty(G, W, C2 // 2, dtype=torch.float32, device=out.device)
+    _check(load().tbx_pointnet_tail_bwd(_ptr(dout), _ptr(out), _ptr(invalid_u8), G, W, C2 // 2, float(p), _ptr(dz), stream_ptr()),
+           "tbx_pointnet_tail_bwd")
+    return dz
+
+
+def masked_maxpool_fwd(x: torch.Tensor, invalid_u8: torch.Tensor) -> torch.Tensor:
+    G, W, C2 = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32 and invalid_u8.numel() == G * W
+    y = torch.empty(G, C2, dtype=torch.float32, device=x.device)
+    _check(load().tbx_masked_maxpool_fwd(_ptr(x), _ptr(invalid_u8), G, W, C2, _ptr(y), stream_ptr()), "tbx_masked_maxpool_fwd")
+    return y
+
+
+def masked_maxpool_bwd(dy: torch.Tensor, x: torch.Tensor, invalid_u8: torch.Tensor) -> torch.Tensor:
+    G, W, C2 = x.shape
+    assert dy.is_contiguous() and dy.shape == (G, C2) and dy.dtype == torch.float32
+    dx = torch.empty_like(x)
+    _check(load().tbx_masked_maxpool_bwd(_ptr(dy), _ptr(x), _ptr(invalid_u8), G, W, C2, _ptr(dx), stream_ptr()), "tbx_masked_maxpool_bwd")
+    return dx
 
 
 def layernorm_bwd_ok(x: torch.Tensor) -> bool:

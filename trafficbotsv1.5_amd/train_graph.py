@@ -351,8 +351,66 @@ def mlp(m, x: Tensor, training: bool = False) -> Tensor:
     return x
 
 
+class PointNetTailFn(torch.autograd.Function):
+    """[h | max over the group's valid rows of h] with invalid rows zeroed, h = dropout(relu(z)): tbx_pointnet_tail_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, z, inv8, p, seed, site, rows_per_scene, tb, t0):
+        out = hip.pointnet_tail_fwd(z.contiguous(), inv8, None if p <= 0 else (p, seed, site, rows_per_scene, tb, t0))
+        ctx.save_for_backward(out, inv8)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, inv8 = ctx.saved_tensors
+        return hip.pointnet_tail_bwd(dout.contiguous(), out, inv8, ctx.p), None, None, None, None, None, None, None
+
+
+class MaskedMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inv8):
+        x = x.contiguous()
+        ctx.save_for_backward(x, inv8)
+        return hip.masked_maxpool_fwd(x, inv8)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, inv8 = ctx.saved_tensors
+        return hip.masked_maxpool_bwd(dy.contiguous(), x, inv8), None
+
+
+POINTNET_FUSED = os.environ.get("TBX_POINTNET_FUSED", "1") != "0"
+
+
+def _pointnet_fused_ok(enc, x: Tensor, training: bool) -> bool:
+    if not (POINTNET_FUSED and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and 0 < x.shape[1] <= 16 and x.shape[0] > 0):
+        return False
+    for m in enc.mlp_layers:
+        ll = m.linear_layers()
+        if len(ll) != 1 or ll[0][1] is not None or not ll[0][2] or ll[0][0].weight.shape[0] != 64:
+            return False
+        if training and m.dropout_p > 0 and _DROP is None:  # torch's generator (unit tests of single modules): the plain ops
+            return False
+    return True
+
+
 def pointnet(enc, x: Tensor, invalid: Tensor, training: bool = False) -> Tensor:
     """polyline_encoder.py:49-61 + pooling.py:18-19,38. x [G, W, 128], invalid [G, W] bool -> [G, 128]."""
+    if _pointnet_fused_ok(enc, x, training):
+        # per layer: the Linear, then ONE launch for relu / dropout / masked max / concat / zeroing (and one for their backward)
+        inv8 = invalid.to(torch.uint8).contiguous()
+        for m in enc.mlp_layers:
+            lin = m.linear_layers()[0][0]
+            z = linear(x, lin.weight, lin.bias)
+            drop = (0.0, None, 0, 1, 1, 0)
+            if training and m.dropout_p > 0:
+                _DROP["site"] += 1  # the id _drop would have given this layer's dropout
+                rows = z.shape[0] * z.shape[1]
+                assert rows % _DROP["n_batch"] == 0
+                drop = (float(m.dropout_p), _DROP["seed"], _DROP["site"], rows // _DROP["n_batch"], _DROP["tb"], _DROP["t0"])
+            x = PointNetTailFn.apply(z, inv8, *drop)
+        return MaskedMaxPoolFn.apply(x, inv8)
     im = invalid.unsqueeze(-1)
     for m in enc.mlp_layers:
         h = mlp(m, x, training).masked_fill(im, float("-inf"))
