@@ -265,11 +265,14 @@ int tbx_linear_wgrad_splits(int64_t rows, int n, int k);
 int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
                      float* scratch, int splits, void* stream);
 
-/* Backward of a LayerNorm over rows of 128 (training; autograd of F.layer_norm at modules/transformer_rpe.py:207-245 - norm1 / norm2 /
+/* Forward and backward of a LayerNorm over rows of 128 (training; autograd of F.layer_norm at modules/transformer_rpe.py:207-245 - norm1 / norm2 /
  * norm_src / norm_tgt - over the time-batched rows): x, dy, dx [rows, 128] contiguous, gamma [128], mean / rstd [rows] as the forward
  * (torch.native_layer_norm) produced them; dgamma / dbeta [128]. x and dy are read once, dx written once; `scratch` holds
  * tbx_layernorm_bwd_partials(rows) x 256 floats, summed by a second kernel in a fixed order (deterministic). cols != 128:
  * TBX_ERR_UNSUPPORTED. */
+int tbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int cols, float* y, float* mean,
+                      float* rstd, void* stream); /* y = (x - mean) * rstd * gamma + beta, rstd = 1 / sqrtf(var + eps) (biased variance,
+                                                     two passes): the arithmetic of the row chains' TBX_OP_LAYERNORM stage */
 int tbx_layernorm_bwd_partials(int64_t rows);
 int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, int64_t rows, int cols,
                       float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);

@@ -1,4 +1,4 @@
-// tbx_layernorm_bwd (include/tbx_hip.h): backward of the 128-wide LayerNorms of the time-batched training pass (autograd of
+// tbx_layernorm_fwd / tbx_layernorm_bwd (include/tbx_hip.h): the 128-wide LayerNorms of the time-batched training pass (autograd of
 // F.layer_norm at modules/transformer_rpe.py:207-245, attention_rpe.py:92-98 norm_tgt, in the reference's training_step).
 // HBM-bound: x and dy read once, dx written once (1.5 KB per row); a wavefront per row (float2 per lane = one 512-byte row per
 // load), four rows in flight per wavefront, dgamma / dbeta accumulated per lane across the wavefront's rows and combined in a
@@ -72,6 +72,47 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
   }
 }
 
+struct LnFwdArgs {
+  const float *x, *gamma, *beta;
+  float *y, *mean, *rstd;
+  int64_t rows;
+  float eps;
+};
+
+// Forward: the arithmetic of the row chains' LAYERNORM stage (csrc/rowchain.hip ln_row: two-pass mean / variance, 1 / sqrtf), so the
+// time-batched pass normalises a row exactly as the stepping pass did.
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t w0 = (int64_t)blockIdx.x * LN_WAVES + wave, tw = (int64_t)gridDim.x * LN_WAVES;
+  const float2 gm = *(const float2*)(a.gamma + 2 * lane), bt = *(const float2*)(a.beta + 2 * lane);
+  for (int64_t r = w0; r < a.rows; r += tw * LN_UNROLL) {
+    float2 xv[LN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int64_t rr = r + u * tw;
+      xv[u] = *(const float2*)(a.x + (rr < a.rows ? rr : r) * LN_D + 2 * lane);
+    }
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int64_t rr = r + u * tw;
+      if (rr >= a.rows) break;
+      const float mean = tbx::wave_sum(xv[u].x + xv[u].y) / (float)LN_D;
+      const float dx = xv[u].x - mean, dy = xv[u].y - mean;
+      const float var = tbx::wave_sum(dx * dx + dy * dy) / (float)LN_D;
+      const float rstd = 1.0f / sqrtf(var + a.eps);
+      float2 o;
+      o.x = dx * rstd * gm.x + bt.x;
+      o.y = dy * rstd * gm.y + bt.y;
+      *(float2*)(a.y + rr * LN_D + 2 * lane) = o;
+      if (lane == 0) {
+        a.mean[rr] = mean;
+        a.rstd[rr] = rstd;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
   __shared__ float red[4][2 * LN_D];
@@ -95,6 +136,16 @@ int ln_workgroups(int64_t rows) {
 }
 
 }  // namespace
+
+extern "C" int tbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int cols, float* y,
+                                 float* mean, float* rstd, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return TBX_ERR_ARG;
+  if (cols != LN_D) return TBX_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 7) return TBX_ERR_ALIGN;
+  LnFwdArgs a{x, gamma, beta, y, mean, rstd, rows, eps};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_workgroups(rows)), dim3(LN_WAVES * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
 
 extern "C" int tbx_layernorm_bwd_partials(int64_t rows) { return ln_workgroups(rows); }
 

@@ -171,13 +171,16 @@ class _DropScope:
 
 
 class LayerNormFn(torch.autograd.Function):
-    """F.layer_norm over rows of 128 whose backward is tbx_layernorm_bwd (x and dy read once, dx written once, deterministic dgamma /
-    dbeta) instead of aten's three kernels; the forward stays aten's (it hands over the per-row mean / rstd)."""
+    """F.layer_norm over rows of 128 as tbx_layernorm_fwd (the row chains' arithmetic) / tbx_layernorm_bwd (x and dy read once, dx
+    written once, deterministic dgamma / dbeta) instead of aten's four kernels."""
 
     @staticmethod
     def forward(ctx, x, w, b, eps):
         x = x.contiguous()
-        y, mean, rstd = torch.native_layer_norm(x, (x.shape[-1],), w, b, eps)
+        if LN_FWD:
+            y, mean, rstd = hip.layernorm_fwd(x, w, b, eps)
+        else:  # aten's forward (it hands over the per-row mean / rstd too)
+            y, mean, rstd = torch.native_layer_norm(x, (x.shape[-1],), w, b, eps)
         ctx.save_for_backward(x, w, mean, rstd)
         return y
 
@@ -189,6 +192,7 @@ class LayerNormFn(torch.autograd.Function):
 
 
 LN_BWD = os.environ.get("TBX_LN_BWD", "1") != "0"
+LN_FWD = os.environ.get("TBX_LN_FWD", "1") != "0"
 
 
 def layer_norm(x: Tensor, m) -> Tensor:
@@ -220,13 +224,16 @@ def fold_attention_weights(attn):
         return _FOLD_CACHE[ck]
     W, b = attn.in_proj_weight, attn.in_proj_bias
     wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
-    eye = torch.eye(D, dtype=W.dtype, device=W.device)
-    bk = torch.block_diag(*[wr[h * DH:(h + 1) * DH] for h in range(NH)])              # [128, 512]
-    bv_t = torch.block_diag(*[wr[D + h * DH:D + (h + 1) * DH] for h in range(NH)])    # [128, 512] = B_v^T
-    sel_in = torch.cat([eye, bk], 1)                                                   # [128, 640]
-    sel_out = torch.cat([eye, bv_t], 1)                                                # [128, 640]
-    f = dict(w_in=sel_in.t() @ W[:D], b_in=sel_in.t() @ b[:D], w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
-             w_out=attn.out_proj_weight @ sel_out, b_out=attn.out_proj_weight @ br[D:] + attn.out_proj_bias)
+    # the block-diagonal products head by head as batched GEMMs (B_k / B_v are never materialised: building them with
+    # torch.block_diag cost 8 slice copies per module forward and ~24 tiny kernels backward, x 40 attention modules per step)
+    wq, wo = W[:D], attn.out_proj_weight
+    wk_h = wr[:D].view(NH, DH, D)                                                       # B_k's blocks  [h][32, 128]
+    wv_h = wr[D:].view(NH, DH, D)                                                       # B_v^T's blocks
+    bk_wq = torch.bmm(wk_h.transpose(1, 2), wq.view(NH, DH, D)).reshape(NH * D, D)      # B_k^T W_q   [512, 128]
+    bk_bq = torch.bmm(wk_h.transpose(1, 2), b[:D].view(NH, DH, 1)).reshape(NH * D)      # B_k^T b_q   [512]
+    wo_bv = torch.bmm(wo.view(D, NH, DH).transpose(0, 1), wv_h).transpose(0, 1).reshape(D, NH * D)  # W_o B_v^T  [128, 512]
+    f = dict(w_in=torch.cat([wq, bk_wq], 0), b_in=torch.cat([b[:D], bk_bq], 0), w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
+             w_out=torch.cat([wo, wo_bv], 1), b_out=wo @ br[D:] + attn.out_proj_bias)
     if _FOLD_CACHE is not None:
         _FOLD_CACHE[ck] = f
     return f
