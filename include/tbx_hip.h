@@ -256,6 +256,22 @@ int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_off, int qt_
 int tbx_keyed_dropout(const float* x, float* y, int64_t rows, int cols, int rows_per_scene, float p_drop,
                       const uint64_t* drop_seed /* device */, uint32_t site, int time_batch, int time0, void* stream);
 
+/* The elementwise glue of a transformer layer over the time-batched rows, one pass per tensor (training; autograd of
+ * transformer_rpe.py:93-131: masked_fill / dropout / add / masked_fill and relu / dropout, each an HBM pass of its own in aten).
+ * The dropout is tbx_keyed_dropout's for the tensor's [rows, cols] view (p_drop = 0: none); cols % 4 == 0, 16-byte aligned.
+ *   tbx_residual_drop_fwd: out = zero_out[row] ? 0 : x + dropout(zero_y[row] ? 0 : y)   (zero_y / zero_out: u8 per row, may be NULL)
+ *   tbx_residual_drop_bwd: dy = (zero_out | zero_y)[row] ? 0 : dout * mask / (1 - p); dx (may be NULL: then dx = dout) = zero_out[row] ? 0 : dout
+ *   tbx_relu_drop_fwd:     h = dropout(relu(z));   tbx_relu_drop_bwd: dz = h > 0 ? dh / (1 - p) : 0 */
+int tbx_residual_drop_fwd(const float* x, const float* y, const uint8_t* zero_y, const uint8_t* zero_out, int64_t rows, int cols, float p_drop,
+                          const uint64_t* drop_seed /* device */, uint32_t site, int rows_per_scene, int time_batch, int time0, float* out,
+                          void* stream);
+int tbx_residual_drop_bwd(const float* dout, const uint8_t* zero_y, const uint8_t* zero_out, int64_t rows, int cols, float p_drop,
+                          const uint64_t* drop_seed /* device */, uint32_t site, int rows_per_scene, int time_batch, int time0, float* dy,
+                          float* dx, void* stream);
+int tbx_relu_drop_fwd(const float* z, int64_t rows, int cols, float p_drop, const uint64_t* drop_seed /* device */, uint32_t site,
+                      int rows_per_scene, int time_batch, int time0, float* h, void* stream);
+int tbx_relu_drop_bwd(const float* dh, const float* h, int64_t rows, int cols, float p_drop, float* dz, void* stream);
+
 /* Weight gradient of a LINEAR over very many rows (training; autograd of F.linear at modules/mlp.py:69-72,
  * attention_rpe.py:95-120,190, transformer_rpe.py:119-131 in the time-batched pass): dw[n,k] = dy[rows,n]^T x[rows,k],
  * db[n] = sum_rows dy (db may be NULL). dy / x row-major with leading dimensions ld_dy / ld_x; n, k and both ld multiples of 4,

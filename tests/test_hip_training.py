@@ -612,3 +612,36 @@ def test_fused_pointnet_glue_equals_the_aten_ops(tb, G, W, dropout):
     torch.testing.assert_close(dxa, dxb, rtol=1e-4, atol=1e-5 * float(dxb.abs().max()))
     for a, b in zip(dpa, dpb):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("rows,cols,dropout", [(1000, 128, True), (3, 512, True), (50000, 128, False), (4097, 512, True)])
+def test_fused_transformer_glue_equals_the_aten_ops(tb, rows, cols, dropout):
+    """train_graph.residual / relu_drop as tbx_residual_drop_* / tbx_relu_drop_* (one pass per tensor) vs the aten sequence they replace
+    (masked_fill, keyed dropout, add, masked_fill; relu, keyed dropout): values and input gradients bit-identical - the same keyed masks
+    (site ids advance alike), the same products."""
+    dev = torch.device("cuda:0")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(rows + cols)
+    x, y = torch.randn(rows, cols, generator=g).to(dev), torch.randn(rows, cols, generator=g).to(dev)
+    zy = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    zo = (torch.rand(rows, generator=g) < 0.2).to(dev)
+    go = torch.randn(rows, cols, generator=g).to(dev)
+    p = 0.1
+    res = {}
+    saved = (TG.GLUE_FUSED, TG._DROP)
+    try:
+        for fused in (True, False):
+            TG.GLUE_FUSED = fused
+            TG._DROP = {"seed": torch.tensor([77], dtype=torch.int64, device=dev), "call": 0, "site": 3, "n_batch": 1, "tb": 1, "t0": 5}
+            xx, yy = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            a = TG.residual(xx, yy, p, dropout, zero_y=zy)                  # attention residual
+            b = TG.residual(a, TG.relu_drop(yy, p, dropout), p, dropout, zero_out=zo)   # FFN tail with the closing row mask
+            assert isinstance(b.grad_fn, TG.ResidualDropFn._backward_cls) == fused
+            (b * go).sum().backward()
+            res[fused] = (a.detach(), b.detach(), xx.grad.clone(), yy.grad.clone(), TG._DROP["site"])
+    finally:
+        TG.GLUE_FUSED, TG._DROP = saved
+    assert res[True][4] == res[False][4] == (6 if dropout else 3)
+    for u, v in zip(res[True][:4], res[False][:4]):
+        assert torch.equal(u, v)
+    assert bool((res[True][1][zo] == 0).all())

@@ -158,6 +158,10 @@ def load():
     lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
     lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
     lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
+    lib.tbx_residual_drop_fwd.argtypes = [vp, vp, vp, vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
+    lib.tbx_residual_drop_bwd.argtypes = [vp, vp, vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp, vp]
+    lib.tbx_relu_drop_fwd.argtypes = [vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
+    lib.tbx_relu_drop_bwd.argtypes = [vp, vp, i64, i32, C.c_float, vp, vp]
     lib.tbx_pointnet_tail_fwd.argtypes = [vp, vp, i64, i32, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
     lib.tbx_pointnet_tail_bwd.argtypes = [vp, vp, vp, i64, i32, i32, C.c_float, vp, vp]
     lib.tbx_masked_maxpool_fwd.argtypes = [vp, vp, i64, i32, i32, vp, vp]
@@ -191,7 +195,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -341,6 +345,63 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
     _check(lib.tbx_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits,
                                 stream_ptr()), "tbx_linear_wgrad")
     return dw, db
+
+
+NO_DROP = (0.0, None, 0, 1, 1, 0)  # (p, seed, site, rows_per_scene, time_batch, time0) of the glue ops without dropout
+
+
+def glue_ok(x: torch.Tensor) -> bool:
+    """Tensors the one-pass glue kernels (tbx_residual_drop_*, tbx_relu_drop_*) take: fp32 on the device, last dimension % 4 == 0."""
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[-1] % 4 == 0 and x.numel() > 0
+
+
+def _drop6(drop):
+    p, seed, site, rps, tb, t0 = drop
+    return float(p), (_ptr(seed, torch.int64) if seed is not None else None), int(site), int(rps), int(tb), int(t0)
+
+
+def residual_drop_fwd(x, y, zero_y, zero_out, drop=NO_DROP):
+    """zero_out[row] ? 0 : x + dropout(zero_y[row] ? 0 : y); zero_* u8 per row or None."""
+    assert glue_ok(x) and x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.dtype == torch.float32
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    for z in (zero_y, zero_out):
+        assert z is None or (z.dtype == torch.uint8 and z.is_contiguous() and z.numel() == rows)
+    out = torch.empty_like(x)
+    p, seed, site, rps, tb, t0 = _drop6(drop)
+    _check(load().tbx_residual_drop_fwd(_ptr(x), _ptr(y), _ptr(zero_y), _ptr(zero_out), rows, cols, p, seed, site, rps, tb, t0, _ptr(out),
+                                        stream_ptr()), "tbx_residual_drop_fwd")
+    return out
+
+
+def residual_drop_bwd(dout, zero_y, zero_out, drop=NO_DROP):
+    """-> (dy, dx); dx is dout itself when there is no zero_out mask."""
+    assert glue_ok(dout) and dout.is_contiguous()
+    cols = dout.shape[-1]
+    rows = dout.numel() // cols
+    dy = torch.empty_like(dout)
+    dx = torch.empty_like(dout) if zero_out is not None else None
+    p, seed, site, rps, tb, t0 = _drop6(drop)
+    _check(load().tbx_residual_drop_bwd(_ptr(dout), _ptr(zero_y), _ptr(zero_out), rows, cols, p, seed, site, rps, tb, t0, _ptr(dy), _ptr(dx),
+                                        stream_ptr()), "tbx_residual_drop_bwd")
+    return dy, (dx if dx is not None else dout)
+
+
+def relu_drop_fwd(z, drop=NO_DROP):
+    assert glue_ok(z) and z.is_contiguous()
+    cols = z.shape[-1]
+    h = torch.empty_like(z)
+    p, seed, site, rps, tb, t0 = _drop6(drop)
+    _check(load().tbx_relu_drop_fwd(_ptr(z), z.numel() // cols, cols, p, seed, site, rps, tb, t0, _ptr(h), stream_ptr()), "tbx_relu_drop_fwd")
+    return h
+
+
+def relu_drop_bwd(dh, h, p: float):
+    assert glue_ok(dh) and dh.is_contiguous() and h.is_contiguous() and h.shape == dh.shape
+    cols = dh.shape[-1]
+    dz = torch.empty_like(dh)
+    _check(load().tbx_relu_drop_bwd(_ptr(dh), _ptr(h), dh.numel() // cols, cols, float(p), _ptr(dz), stream_ptr()), "tbx_relu_drop_bwd")
+    return dz
 
 
 def pointnet_tail_ok(z: torch.Tensor) -> bool:

@@ -214,6 +214,73 @@ class KeyedDropoutFn(torch.autograd.Function):
         return hip.keyed_dropout(dy.contiguous(), p, seed, site, rows_per_scene, tb, t0), None, None, None, None, None, None
 
 
+class ResidualDropFn(torch.autograd.Function):
+    """zero_out[row] ? 0 : x + dropout(zero_y[row] ? 0 : y) in one pass (tbx_residual_drop_fwd / _bwd); the backward regenerates the mask."""
+
+    @staticmethod
+    def forward(ctx, x, y, zero_y, zero_out, p, seed, site, rows_per_scene, tb, t0):
+        ctx.drop = (p, seed, site, rows_per_scene, tb, t0)
+        ctx.save_for_backward(zero_y, zero_out)
+        return hip.residual_drop_fwd(x.contiguous(), y.contiguous(), zero_y, zero_out, ctx.drop)
+
+    @staticmethod
+    def backward(ctx, dout):
+        zero_y, zero_out = ctx.saved_tensors
+        dy, dx = hip.residual_drop_bwd(dout.contiguous(), zero_y, zero_out, ctx.drop)
+        return dx, dy, None, None, None, None, None, None, None, None
+
+
+class ReluDropFn(torch.autograd.Function):
+    """dropout(relu(z)) in one pass (tbx_relu_drop_fwd / _bwd); relu' and the mask are read off h > 0."""
+
+    @staticmethod
+    def forward(ctx, z, p, seed, site, rows_per_scene, tb, t0):
+        h = hip.relu_drop_fwd(z.contiguous(), (p, seed, site, rows_per_scene, tb, t0))
+        ctx.p = p
+        ctx.save_for_backward(h)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (h,) = ctx.saved_tensors
+        return hip.relu_drop_bwd(dh.contiguous(), h, ctx.p), None, None, None, None, None, None
+
+
+GLUE_FUSED = os.environ.get("TBX_GLUE_FUSED", "1") != "0"
+
+
+def _glue_ok(x: Tensor, p: float, training: bool) -> bool:
+    """The one-pass glue ops apply: device tensor, and a live dropout has its keyed scope (else torch's generator: the plain ops)."""
+    return GLUE_FUSED and hip.glue_ok(x) and not (training and p > 0 and _DROP is None)
+
+
+def _drop_args(x: Tensor, p: float, training: bool):
+    """tbx_keyed_dropout's arguments for x [..., cols] with the id _drop would give this site (advances it), or hip.NO_DROP."""
+    if not (training and p > 0):
+        return hip.NO_DROP
+    _DROP["site"] += 1
+    rows = x.numel() // x.shape[-1]
+    assert rows % _DROP["n_batch"] == 0
+    return (float(p), _DROP["seed"], _DROP["site"], rows // _DROP["n_batch"], _DROP["tb"], _DROP["t0"])
+
+
+def residual(x: Tensor, y: Tensor, p: float, training: bool, zero_y: Optional[Tensor] = None, zero_out: Optional[Tensor] = None) -> Tensor:
+    """(x + dropout(y.masked_fill(zero_y, 0))).masked_fill(zero_out, 0); zero_* u8 / bool per row ([rows]) or None."""
+    if _glue_ok(x, p, training):
+        u8 = lambda m: None if m is None else m.reshape(-1).to(torch.uint8).contiguous()
+        return ResidualDropFn.apply(x, y, u8(zero_y), u8(zero_out), *_drop_args(y, p, training))
+    if zero_y is not None:
+        y = y.masked_fill(zero_y.reshape(-1).bool().unsqueeze(-1), 0.0)
+    x = x + _drop(y, p, training)
+    return x if zero_out is None else x.masked_fill(zero_out.reshape(-1).bool().unsqueeze(-1), 0.0)
+
+
+def relu_drop(z: Tensor, p: float, training: bool) -> Tensor:
+    if _glue_ok(z, p, training):
+        return ReluDropFn.apply(z, *_drop_args(z, p, training))
+    return _drop(F.relu(z), p, training)
+
+
 def fold_attention_weights(attn):
     """The exact algebra of DESIGN.md §3 as GEMM weights:
       [q | qt] = x W_in^T + b_in        with  W_in  = [I | B_k]^T W_q           (640 x 128),  b_in  = [I | B_k]^T b_q
@@ -252,8 +319,9 @@ def kv_table(attn, norm, t: Targets) -> Tensor:
     return t.cache[k]
 
 
-def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor], n: int, S: int) -> Tensor:
-    """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source."""
+def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor], n: int, S: int, raw: bool = False):
+    """attention_rpe.py:83-198 (rpe branch) in the factorised table form; xq [n*S, 128] is the normalised source.
+    raw: -> (out-projection of every row, u8 flag of the rows without a valid target) for a caller that zeroes those rows itself."""
     f = fold_attention_weights(attn)
     qbuf = linear(xq, f["w_in"], f["b_in"])
     meta = [(t.idx, t.invalid, t.emb, t.rel, t.n_tgt, t.batch_div, t.inv) for t in targets]
@@ -265,6 +333,8 @@ def attention(attn, xq: Tensor, targets: Sequence[Targets], kvs: Sequence[Tensor
         drop = (float(attn.dropout_p), _DROP["seed"], _DROP["call"], _DROP["tb"], _DROP["t0"])
     out, flag = KnarpeAttnFn.apply(qbuf, f["bias_k"], n, S, meta, freqs, drop, *kvs)
     y = linear(out, f["w_out"], f["b_out"])
+    if raw:
+        return y, flag
     return y.masked_fill(flag.bool().unsqueeze(-1), 0.0)
 
 
@@ -318,6 +388,12 @@ def _drop(x: Tensor, p: float, training: bool) -> Tensor:
     return KeyedDropoutFn.apply(x, float(p), _DROP["seed"], _DROP["site"], rows // _DROP["n_batch"], _DROP["tb"], _DROP["t0"])
 
 
+def _attn_residual(x: Tensor, y_flag, p: float, training: bool) -> Tensor:
+    """x + dropout(y with the rows that had no valid target zeroed) (transformer_rpe.py:93-131 around attention_rpe.py:188-190)."""
+    y, flag = y_flag
+    return residual(x, y, p, training, zero_y=flag)
+
+
 def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, self_knn, cross=None, p: float = 0.0,
                       training: bool = False) -> Tensor:
     """transformer_rpe.py:48-135,207-245. x [n*S,128]; self_knn = Targets kwargs (idx, invalid, emb | rel, freqs) among the sources;
@@ -325,22 +401,23 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
     if _chains_ok(x):
         return _transformer_block_chains(block, x, src_invalid, n, S, self_knn, cross, p, training)
     ln = lambda m, t: layer_norm(t, m)
-    inv = src_invalid.reshape(-1).bool().unsqueeze(-1)
+    inv = src_invalid.reshape(-1).to(torch.uint8)
+    # the glue between the GEMMs / attention calls (zeroing of rows without a valid target, dropout, residual add, relu, the closing
+    # row mask) as one pass per tensor: residual() / relu_drop() - the dropout sites keep the order of the reference's modules
     for layer in block.layers:
         if block.mode == "dec_cross_attn":
             s = ln(layer.norm_src, x)
             ts = Targets(s, n_tgt=S, **self_knn)
-            x = x + _drop(attention(layer.attn_src, s, [ts], [kv_table(layer.attn_src, None, ts)], n, S), p, training)
+            x = _attn_residual(x, attention(layer.attn_src, s, [ts], [kv_table(layer.attn_src, None, ts)], n, S, raw=True), p, training)
             s2 = ln(layer.norm1, x)
             tg = list(cross(layer))
-            x = x + _drop(attention(layer.attn, s2, tg, [kv_table(layer.attn, layer.norm_tgt, t) for t in tg], n, S), p, training)
+            x = _attn_residual(x, attention(layer.attn, s2, tg, [kv_table(layer.attn, layer.norm_tgt, t) for t in tg], n, S, raw=True), p, training)
         else:  # enc_self_attn: gathered targets share norm1 with the source
             s2 = ln(layer.norm1, x)
             ts = Targets(s2, n_tgt=S, **self_knn)
-            x = x + _drop(attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S), p, training)
-        h = F.relu(linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias))
-        x = x + _drop(linear(_drop(h, p, training), layer.linear2.weight, layer.linear2.bias), p, training)
-        x = x.masked_fill(inv, 0.0)
+            x = _attn_residual(x, attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S, raw=True), p, training)
+        h = relu_drop(linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias), p, training)
+        x = residual(x, linear(h, layer.linear2.weight, layer.linear2.bias), p, training, zero_out=inv)
     return x
 
 
