@@ -71,6 +71,18 @@ typedef struct tbx_knn_job {
 } tbx_knn_job_t;
 int tbx_knn_embed_multi(const tbx_knn_job_t* jobs /* host */, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
                         void* stream);
+/* ... with a tbx_pose_embed of explicit triples riding on the same launch (its blocks come after the searches'; the agents' destination
+ * embedding of a simulation step, navigation.py:65-79, needs the same inputs as the searches and nothing they produce). pe may be NULL. */
+typedef struct tbx_pose_embed_job {
+  const float* pose3;      /* [n, 3] */
+  const float* freqs_xy;
+  const float* freqs_yaw;
+  float* out;              /* out[i, col_off : col_off + pe_dim] */
+  int64_t n;
+  int32_t pe_dim, ld_out, col_off, reserved;
+} tbx_pose_embed_job_t;
+int tbx_knn_embed_multi_pe(const tbx_knn_job_t* jobs /* host */, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
+                           const tbx_pose_embed_job_t* pe /* host, may be NULL */, void* stream);
 
 /* Pose embedding of explicit (x,y,yaw) triples (utils/pose_emb.py:50-55); out[i, col_off : col_off+pe_dim]. */
 int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim, float* out,
@@ -589,6 +601,12 @@ enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4,
        /* ... and a part of its own: append the current agent / light state to the windows (no step is simulated) */
        TBX_SIM_APPEND = 32 };
 int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* stream);
+/* tbx_sim_step_parts with TBX_SIM_LIGHTS (appending), and tbx_tl_prep of the lights' new windows in the same launch: a light's thread
+ * writes the ld_attr-wide one-hot rows and the row mask of its own window (traffic_light.py:219-226) right after shifting it.
+ * tl_invalid [n_batch * n_tl] u8, attr [n_batch * n_tl * window, ld_attr], row_invalid [n_batch * n_tl * window]. tl_invalid NULL:
+ * tbx_sim_step_parts. */
+int tbx_sim_step_tl_prep(const tbx_sim_state_t* st /* host */, int parts, const uint8_t* tl_invalid, int ld_attr, float* attr,
+                         uint8_t* row_invalid, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ def test_ctypes_mirrors_have_the_layout_gcc_gives_the_header(hip, tmp_path):
     import subprocess
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    pairs = [("tbx_stage_t", hip.Stage), ("tbx_attn_seg_t", hip.AttnSeg), ("tbx_dec_mid_t", hip.DecMid), ("tbx_dec_layer_t", hip.DecLayer), ("tbx_heads_tail_t", hip.HeadsTail), ("tbx_knn_job_t", hip.KnnJob), ("tbx_sim_state_t", hip.SimState),
+    pairs = [("tbx_stage_t", hip.Stage), ("tbx_attn_seg_t", hip.AttnSeg), ("tbx_dec_mid_t", hip.DecMid), ("tbx_dec_layer_t", hip.DecLayer), ("tbx_heads_tail_t", hip.HeadsTail), ("tbx_knn_job_t", hip.KnnJob), ("tbx_pose_embed_job_t", hip.PoseEmbedJob), ("tbx_sim_state_t", hip.SimState),
              ("tbx_train_chain_t", hip.TrainChainArgs), ("tbx_rule_ctx_t", hip.RuleCtx)]
     src = tmp_path / "sz.c"
     src.write_text('#include "tbx_hip.h"\n#include <stdio.h>\nint main(void){' +

@@ -269,6 +269,9 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
     z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
     saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ)
+    AE = import_module("trafficbots_amd.models.agent_encoder")
+    RE = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    saved_rides = (AE.PE_RIDES, RE.TL_PREP_RIDES)
     outs = {}
     try:
         # (.., pool): layer 0's projections inside the launch that pools the windows (TBX_F_POOL_KEEP) or as a launch of their own
@@ -278,10 +281,13 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
                                                      "layer": (1, True, True, True, False), "layer2": (2, True, True, True, True),
                                                      "layer1p": (1, True, True, True, True)}.items():
             eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = live, fold, mid, layer, pool
+            # riders: the destination's pose embedding in the searches' launch, tbx_tl_prep in the lights' tbx_sim_step launch
+            AE.PE_RIDES = RE.TL_PREP_RIDES = name not in ("mfma", "live1", "mid")
             outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                             step_end=24)
     finally:
         eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = saved
+        AE.PE_RIDES, RE.TL_PREP_RIDES = saved_rides
     ref = outs["mfma"]
     for name, o in outs.items():
         assert torch.equal(o.pred_pose, ref.pred_pose), name

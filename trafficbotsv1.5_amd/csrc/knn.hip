@@ -154,12 +154,30 @@ __global__ __launch_bounds__(256) void knn_embed_kernel(const KnnArgs a) {
 // launches on the auxiliary stream). A workgroup = one source row of one job (the 4-waves-per-row form); jobs are laid out
 // back to back over blockIdx.x in the order given (the longest search first, so that its rows are dispatched first).
 constexpr int KNN_MAX_JOBS = 4;
+struct PoseEmbedArgs {  // tbx_pose_embed riding on the searches' launch (tbx_knn_embed_multi_pe): the blocks past the last search
+  const float* pose3;
+  const float *fxy, *fyaw;
+  float* out;
+  int64_t n;
+  int pe_dim, ld, col_off;
+};
 struct KnnMulti {
   KnnArgs job[KNN_MAX_JOBS];
   int first_block[KNN_MAX_JOBS + 1];
   int n_jobs;
+  PoseEmbedArgs pe;  // pe.n == 0: none
 };
 __global__ __launch_bounds__(256) void knn_multi_kernel(const KnnMulti m) {
+  if ((int)blockIdx.x >= m.first_block[KNN_MAX_JOBS]) {  // one thread per (pose, argument) as pose_embed_kernel
+    const int half = m.pe.pe_dim >> 1;
+    const int64_t e = (int64_t)((int)blockIdx.x - m.first_block[KNN_MAX_JOBS]) * blockDim.x + threadIdx.x;
+    if (e >= m.pe.n * half) return;
+    const int64_t i = e / half;
+    const int c = (int)(e - i * half);
+    tbx::pose_emb_write(m.pe.out + i * m.pe.ld + m.pe.col_off, m.pe.pe_dim, m.pe.pose3[i * 3], m.pe.pose3[i * 3 + 1], m.pe.pose3[i * 3 + 2],
+                        m.pe.fxy, m.pe.fyaw, c, half);
+    return;
+  }
   int j = 0;
   while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
   const KnnArgs& a = m.job[j];
@@ -217,9 +235,20 @@ extern "C" int tbx_knn_embed(const float* src_pose, const uint8_t* src_invalid, 
 
 extern "C" int tbx_knn_embed_multi(const tbx_knn_job_t* jobs, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
                                    void* stream) {
+  return tbx_knn_embed_multi_pe(jobs, n_jobs, freqs_xy, freqs_yaw, pe_dim, nullptr, stream);
+}
+
+extern "C" int tbx_knn_embed_multi_pe(const tbx_knn_job_t* jobs, int n_jobs, const float* freqs_xy, const float* freqs_yaw, int pe_dim,
+                                      const tbx_pose_embed_job_t* pe, void* stream) {
   if (!jobs || n_jobs <= 0 || n_jobs > KNN_MAX_JOBS) return TBX_ERR_ARG;
   KnnMulti m;
   m.n_jobs = n_jobs;
+  m.pe = PoseEmbedArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  if (pe != nullptr) {
+    if (!pe->pose3 || !pe->freqs_xy || !pe->freqs_yaw || !pe->out || pe->n <= 0) return TBX_ERR_ARG;
+    if ((pe->pe_dim != 64 && pe->pe_dim != 128) || pe->ld_out < pe->col_off + pe->pe_dim) return TBX_ERR_UNSUPPORTED;
+    m.pe = PoseEmbedArgs{pe->pose3, pe->freqs_xy, pe->freqs_yaw, pe->out, pe->n, pe->pe_dim, pe->ld_out, pe->col_off};
+  }
   int blocks = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const tbx_knn_job_t& q = jobs[j];
@@ -234,6 +263,7 @@ extern "C" int tbx_knn_embed_multi(const tbx_knn_job_t* jobs, int n_jobs, const 
   }
   for (int j = n_jobs; j <= KNN_MAX_JOBS; ++j) m.first_block[j] = blocks;
   for (int j = n_jobs; j < KNN_MAX_JOBS; ++j) m.job[j] = m.job[0];
+  if (m.pe.n > 0) blocks += (int)((m.pe.n * (m.pe.pe_dim >> 1) + 255) / 256);  // the pose embedding's blocks come last
   hipLaunchKernelGGL(knn_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

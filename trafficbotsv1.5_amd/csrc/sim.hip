@@ -21,7 +21,15 @@ __device__ __forceinline__ float sim_sl1(float d) {  // F.smooth_l1_loss, beta =
   return a < 1.f ? 0.5f * d * d : a - 0.5f;
 }
 
-__global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
+// tbx_tl_prep of the lights' new windows riding on their update (tbx_sim_step_tl_prep): a light's thread writes its own W rows
+struct TlPrepArgs {
+  const uint8_t* tl_invalid;  // NULL: off
+  float* attr;
+  uint8_t* row_invalid;
+  int ld_attr;
+};
+
+__global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts, const TlPrepArgs tp) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i_ag = gid / LPA, sub = gid % LPA;
   const int t = *s.step;  // step being simulated: model saw the state of step t-1
@@ -230,6 +238,24 @@ __global__ void sim_step_kernel(const tbx_sim_state_t s, const int parts) {
       for (int w = 0; w < W - 1; ++w) ht[w] = ht[w + 1];
       ht[W - 1] = st;
     }
+    if (tp.tl_invalid != nullptr) {  // csrc/prep.hip tl_prep_kernel for rows (i, 0 .. W-1) of the window just written
+      const uint8_t* ht = s.hist_tl + (int64_t)i * W;
+      const bool tok_bad = tp.tl_invalid[i] != 0;
+      for (int w = 0; w < W; ++w) {
+        const uint8_t hs = ht[w];
+        const bool missing = hs == 0xFF;
+        const int64_t r = (int64_t)i * W + w;
+        for (int c = 0; c < tp.ld_attr; ++c) {
+          float v = 0.f;
+          if (c < 5)
+            v = (!missing && ((hs >> c) & 1)) ? 1.f : 0.f;
+          else if (c - 5 == w)
+            v = 1.f;
+          tp.attr[r * tp.ld_attr + c] = v;
+        }
+        tp.row_invalid[r] = (missing || tok_bad) ? 1 : 0;
+      }
+    }
   }
   if (parts & TBX_SIM_ADVANCE) {
     // every thread of this workgroup has read *step above; the last workgroup to arrive advances it
@@ -277,6 +303,16 @@ extern "C" int tbx_sim_step(const tbx_sim_state_t* st, void* stream) {
 }
 
 extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* stream) {
+  return tbx_sim_step_tl_prep(st, parts, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int tbx_sim_step_tl_prep(const tbx_sim_state_t* st, int parts, const uint8_t* tl_invalid, int ld_attr, float* attr,
+                                    uint8_t* row_invalid, void* stream) {
+  TlPrepArgs tp{nullptr, nullptr, nullptr, 0};
+  if (tl_invalid != nullptr) {
+    if (!st || !(parts & TBX_SIM_LIGHTS) || (parts & TBX_SIM_NO_APPEND) || !attr || !row_invalid || ld_attr < 5 + st->window) return TBX_ERR_ARG;
+    tp = TlPrepArgs{tl_invalid, attr, row_invalid, ld_attr};
+  }
   const int known = TBX_SIM_AGENTS | TBX_SIM_LIGHTS | TBX_SIM_ADVANCE | TBX_SIM_NO_DISABLE | TBX_SIM_NO_APPEND | TBX_SIM_APPEND;
   if (!st || (parts & ~known) || parts == 0) return TBX_ERR_ARG;
   if ((parts & TBX_SIM_APPEND) && parts != TBX_SIM_APPEND) return TBX_ERR_ARG;  // a part of its own
@@ -302,7 +338,7 @@ extern "C" int tbx_sim_step_parts(const tbx_sim_state_t* st, int parts, void* st
   const int64_t n = th_ag > th_tl ? th_ag : th_tl;
   hipStream_t hs = (hipStream_t)stream;
   if (parts & (TBX_SIM_AGENTS | TBX_SIM_LIGHTS))
-    hipLaunchKernelGGL(sim_step_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, hs, s, parts);
+    hipLaunchKernelGGL(sim_step_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, hs, s, parts, tp);
   else
     hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

@@ -48,6 +48,12 @@ class KnnJob(C.Structure):
                 + [(n, C.c_int32) for n in ("n_batch", "n_src", "n_tgt", "tgt_batch_div", "k")] + [("dist_limit", C.c_float)])
 
 
+class PoseEmbedJob(C.Structure):
+    """tbx_pose_embed_job_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("pose3", "freqs_xy", "freqs_yaw", "out")] + [("n", C.c_int64)]
+                + [(n, C.c_int32) for n in ("pe_dim", "ld_out", "col_off", "reserved")])
+
+
 class DecMid(C.Structure):
     """tbx_dec_mid_t (include/tbx_hip.h)."""
     _fields_ = ([("qkv", C.c_void_p), ("x", C.c_void_p), ("self_seg", AttnSeg), ("cross_seg", AttnSeg * 2)]
@@ -142,6 +148,7 @@ def load():
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
     lib.tbx_knarpe_dec_layer.argtypes = [C.POINTER(DecLayer), vp]
     lib.tbx_knn_embed_multi.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, vp]
+    lib.tbx_knn_embed_multi_pe.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, C.POINTER(PoseEmbedJob), vp]
     lib.tbx_knarpe_attn_bwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
                                         C.POINTER(C.c_void_p), vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_dropout.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp,
@@ -191,12 +198,13 @@ def load():
     lib.tbx_map_prep.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_sim_step.argtypes = [C.POINTER(SimState), vp]
     lib.tbx_sim_step_parts.argtypes = [C.POINTER(SimState), i32, vp]
+    lib.tbx_sim_step_tl_prep.argtypes = [C.POINTER(SimState), i32, vp, i32, vp, vp, vp]
     lib.tbx_rule_tables.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
+    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -252,9 +260,10 @@ def knn_embed(src_pose, src_invalid, tgt_pose, tgt_invalid, k: int, dist_limit: 
     return idx, inv, rel, emb
 
 
-def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128):
+def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128, pose_embed_job=None):
     """Several `knn_embed` searches in one launch. jobs: dicts with knn_embed's arguments (src_pose, src_invalid, tgt_pose,
-    tgt_invalid, k, dist_limit, tgt_batch_div, want_rel_pose, want_emb, out) -> list of (idx, invalid, rel_pose, emb)."""
+    tgt_invalid, k, dist_limit, tgt_batch_div, want_rel_pose, want_emb, out) -> list of (idx, invalid, rel_pose, emb).
+    pose_embed_job = dict(pose3, freqs_xy, freqs_yaw, pe_dim, out[, col_off]): a `pose_embed` in the same launch (tbx_knn_embed_multi_pe)."""
     outs, cj = [], (KnnJob * len(jobs))()
     for j, q in enumerate(jobs):
         n, S, _ = q["src_pose"].shape
@@ -272,6 +281,13 @@ def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128):
                        _cptr(q["tgt_invalid"], torch.uint8), _ptr(idx), _ptr(inv), _ptr(rel), _ptr(emb), n, S, T,
                        q.get("tgt_batch_div", 1), k, float(q["dist_limit"]))
         outs.append((idx, inv, rel, emb))
+    if pose_embed_job is not None:
+        q, out = pose_embed_job, pose_embed_job["out"]
+        pj = PoseEmbedJob(_cptr(q["pose3"], torch.float32), _cptr(q["freqs_xy"]), _cptr(q["freqs_yaw"]), _ptr(out, torch.float32),
+                          q["pose3"].numel() // 3, int(q["pe_dim"]), out.stride(0), int(q.get("col_off", 0)), 0)
+        _check(load().tbx_knn_embed_multi_pe(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, C.byref(pj), stream_ptr()),
+               "tbx_knn_embed_multi_pe")
+        return outs
     _check(load().tbx_knn_embed_multi(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr()), "tbx_knn_embed_multi")
     return outs
 
@@ -656,7 +672,14 @@ def train_chain_bwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, str
                                       _ptr(d_mean, torch.float32), stream_ptr()), "tbx_train_chain_bwd")
 
 
-def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE):
+def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE, tl_prep=None):
+    """tl_prep = (tl_invalid u8 [n*L], attr f32 [n*L*W, ld], row_invalid u8 [n*L*W]): the lights' update also writes the tbx_tl_prep
+    rows of their new windows (tbx_sim_step_tl_prep)."""
+    if tl_prep is not None:
+        inv, attr, row_inv = tl_prep
+        _check(load().tbx_sim_step_tl_prep(C.byref(state), parts, _cptr(inv, torch.uint8), attr.stride(0), _ptr(attr, torch.float32),
+                                           _ptr(row_inv, torch.uint8), stream_ptr()), "tbx_sim_step_tl_prep")
+        return
     _check(load().tbx_sim_step_parts(C.byref(state), parts, stream_ptr()), "tbx_sim_step_parts")
 
 

@@ -1,6 +1,7 @@
 """`AgentEncoder` (models/agent_encoder.py:15-466), HPTR variant (`_forward_hptr`): per step, the agents' W-step
 windows -> local-frame PointNet tokens -> 4 dec_cross_attn layers over [K nearest agents | K nearest map tokens ++
 K nearest traffic lights]."""
+import os
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -13,6 +14,9 @@ from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
 from .modules.polyline_encoder import PolylineEncoder
 from .modules.transformer_rpe import TransformerBlockRPE
+
+
+PE_RIDES = os.environ.get("TBX_PE_RIDES", "1") != "0"  # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
 
 
 class AgentEncoder(nn.Module):
@@ -123,13 +127,20 @@ class AgentEncoder(nn.Module):
                     dict(common, tgt_pose=tok_pose, tgt_invalid=tok_inv, k=self.n_tgt_knn_ag2ag, out=prep.get("_knn_aa")),
                     dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
                          out=prep.get("_knn_at"))]
+            want_pe = navi_rpe is not None and dest is not None
+            pe_rides = want_pe and PE_RIDES and n * A < 4096  # the destination's pose embedding in the searches' launch
+            if pe_rides and prep.get("navi_pe") is None:
+                prep["navi_pe"] = torch.empty(n * A, navi_rpe.out_dim, dtype=torch.float32, device=dev)
             if n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
-                (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs)
+                pj = dict(pose3=prep["navi_pose3"], freqs_xy=navi_rpe.pe_xy.freqs, freqs_yaw=navi_rpe.pe_yaw.freqs, pe_dim=navi_rpe.out_dim,
+                          out=prep["navi_pe"]) if pe_rides else None
+                (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs, pose_embed_job=pj)
             else:
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = (hip.knn_embed(**q) for q in jobs)
-            if navi_rpe is not None and dest is not None:
-                prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
-                                                 out=prep.get("navi_pe"))
+            if want_pe:
+                if not pe_rides:
+                    prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
+                                                     out=prep.get("navi_pe"))
                 if aux_tail is not None:
                     aux_tail(prep)
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,

@@ -72,7 +72,7 @@ class TrafficBots(nn.Module):
         self.agent_policy(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, ag_latent, latent_invalid, dest,
                           navi_valid_u8, tl_tokens, mp_tokens, tl_kv, out)
 
-    def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor]) -> Tensor:
+    def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor], prepared=None) -> Tensor:
         """The traffic-light half (traffic_bots.py:188-199): tl tokens of the window -> next-state logits in
         out['tl_logits'] and the per-layer K/V tables the agents' tl cross-attention reads (returned, out['tl_kv']).
         Reads no agent state, so the rollout engine runs it one step ahead on its own stream."""
@@ -88,7 +88,7 @@ class TrafficBots(nn.Module):
             emit_kv_tables(ch, self.ag_encoder.tl_kv_layers(), tl_kv)
             self.tl_state_predictor.emit(ch, tl_inv, out["tl_logits"])
 
-        out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail)
+        out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail, prepared=prepared)  # prepared: TlEncoder.encode
         return tl_kv
 
     NAVI_AHEAD = os.environ.get("TBX_NAVI_AHEAD", "1") != "0"

@@ -72,16 +72,24 @@ class TrafficLightEncoder(nn.Module):
             cache[id(self)] = kv_tables(t["mp_feat_flat"].contiguous(), [(l.norm_tgt, l.attn) for l in self.tf_tl2tlmp.layers])
         return cache[id(self)]
 
-    def encode(self, hist_tl: Tensor, t: Dict[str, Tensor], tail: Optional[Callable[[Chain], None]] = None) -> Tensor:
-        """hist_tl [n,L,W] u8 state masks (0xFF = step not yet seen), oldest first -> tl_token_feature [n*L, d]."""
+    def prep_buffers(self, n: int, L: int, dev):
+        """(attr [n*L*W, 16 | 32] f32, row_invalid [n*L*W] u8): what tbx_tl_prep writes for `encode`."""
+        rows = n * L * self.temp_window_size
+        ld_attr = 16 if 5 + self.temp_window_size <= 16 else 32
+        return torch.empty(rows, ld_attr, dtype=torch.float32, device=dev), torch.empty(rows, dtype=torch.uint8, device=dev)
+
+    def encode(self, hist_tl: Tensor, t: Dict[str, Tensor], tail: Optional[Callable[[Chain], None]] = None, prepared=None) -> Tensor:
+        """hist_tl [n,L,W] u8 state masks (0xFF = step not yet seen), oldest first -> tl_token_feature [n*L, d].
+        prepared = the prep_buffers() already filled for this window (by the launch that updated the lights, hip.sim_step(tl_prep=))."""
         n, L, W = hist_tl.shape
         assert W == self.temp_window_size
         dev, d = hist_tl.device, self.hidden_dim
         rows = n * L * W
-        ld_attr = 16 if 5 + W <= 16 else 32
-        attr = torch.empty(rows, ld_attr, dtype=torch.float32, device=dev)
-        row_inv = torch.empty(rows, dtype=torch.uint8, device=dev)
-        hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
+        if prepared is not None:
+            attr, row_inv = prepared
+        else:
+            attr, row_inv = self.prep_buffers(n, L, dev)
+            hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
         x = torch.empty(n * L, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * L, dev, hip.group_tile_rows(W, n * L))  # small launches: layer 0's projections in the windows' launch too
         ch = Chain(hip.group_tile_rows(W, n * L), d + 4 if fp is None else FIRST_PROJ_LDW)

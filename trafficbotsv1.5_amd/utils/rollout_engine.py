@@ -49,6 +49,7 @@ def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
 
 
 class RolloutEngine:
+    TL_PREP_RIDES = os.environ.get("TBX_TL_PREP_RIDES", "1") != "0"  # tbx_tl_prep inside the lights' tbx_sim_step launch
     lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
     # steps per multi-step graph (even; 1: off). A replay boundary costs a few us of idle device: 4 -> 197.9 k, 16 -> 199.4 k, 40 ->
     # 200.4 k agent-steps/s at the 64-agent scene. Capturing g steps costs g eager steps of host time, so the default suits an engine
@@ -184,6 +185,7 @@ class RolloutEngine:
             self.sim_state_tl = stl
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
         self.graph = self.graph_multi = None
+        self._tl_prep = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
         self.side, self.aux = self._side_streams(dev)
@@ -202,16 +204,16 @@ class RolloutEngine:
         self.parity = 0
         self._tl_ahead(0)
 
-    def _tl_ahead(self, slot: int) -> None:
+    def _tl_ahead(self, slot: int, prepared=None) -> None:
         """tl encoder on the current light window: logits for the next lights update, K/V tables (into buffer `slot`)
-        for the next agent step."""
+        for the next agent step. prepared: the window's tbx_tl_prep rows were written by the lights' update (step())."""
         if self.tl_kv is None:
             self.policy_out.pop("tl_kv", None)
             kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
             self.tl_kv = [kv, torch.empty_like(kv)] if slot == 0 else [torch.empty_like(kv), kv]
             return
         self.policy_out["tl_kv"] = self.tl_kv[slot]
-        self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
+        self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out, prepared=prepared)
 
     # ------------------------------------------------------------------ stepping
     @torch.no_grad()
@@ -230,8 +232,16 @@ class RolloutEngine:
         p = self.parity
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)  # logits of the previous tl encoder pass -> lights of this step
-            self._tl_ahead(1 - p)
+            # logits of the previous tl encoder pass -> lights of this step (+ the one-hot rows of their new windows: tbx_sim_step_tl_prep)
+            if self.TL_PREP_RIDES:
+                if self._tl_prep is None:
+                    hist = self.S["hist_tl"]
+                    self._tl_prep = self.model.tl_encoder.prep_buffers(hist.shape[0], hist.shape[1], hist.device)
+                hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS, tl_prep=(self.tl_tokens["tl_token_invalid_u8"], *self._tl_prep))
+                self._tl_ahead(1 - p, prepared=self._tl_prep)
+            else:
+                hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)
+                self._tl_ahead(1 - p)
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
                                 self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux, rollout_consts=self.consts)
