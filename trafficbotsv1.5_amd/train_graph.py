@@ -19,6 +19,7 @@ one), followed by the tiny per-step dynamics / reward chain on the batched means
 autograd (`training_rollout`, kept as the checked reference of the restructure), but ~25 large launches per layer
 instead of 90 x as many small ones.
 """
+import contextlib
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -1011,6 +1012,17 @@ def tl_nll_all_steps(logits: Tensor, tl_gt: Tensor, tl_invalid: Tensor):
     return nll.permute(0, 2, 1), inv.permute(0, 2, 1)
 
 
+TL_CHUNKS = int(os.environ.get("TBX_TL_CHUNKS", "3"))  # pieces of the ahead-of-time light encoder (1: all steps at once, one stream)
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
     """The same rollout, time-batched (module docstring): a step-by-step pass without autograd that records every step's
     policy inputs, then the T policy evaluations of every scene as one differentiated batch of n x T entries in [scene][step]
@@ -1032,20 +1044,50 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
         pad = torch.full((n, L, W), 0xFF, dtype=torch.uint8, device=tl_gt.device)
         ht_all = torch.cat([pad, _bits(tl_gt)[:, :, :T]], 2).unfold(2, W, 1)[:, :, 1:T + 1]  # [n, L, T, W]: window of step s = states s-W .. s-1
         ht_all = ht_all.permute(0, 2, 1, 3).reshape(n * T, L, W).contiguous()
+    tl_chunks = None  # [(first step index, [n, Tc, L, d] detached features, event or None)]
     if ht_all is not None and getattr(wm, "tl_encoder_ahead", True):
-        with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
-            tl_feat_all = tl_encoder(model.tl_encoder, ht_all, tl_T, model.training)
-            ids = (_DROP["site"], _DROP["call"]) if _DROP is not None else None
-        tl_pre = (tl_feat_all, ids)
-        tl_steps = tl_feat_all.detach().view(n, T, L, -1)
+        # ... in TL_CHUNKS pieces along time: the first on this stream, the others on a side stream WHILE the stepping pass below runs
+        # (its launches are latency-bound on a quarter of the CUs; the light encoder's are the big-batch kind). The stepping pass waits
+        # for a piece's event before its first step. Same keyed masks (they are keyed by the absolute step), same per-row arithmetic.
+        n_chunk = TL_CHUNKS if (ht_all.is_cuda and T >= 3 * TL_CHUNKS) else 1
+        bounds = [round(i * T / n_chunk) for i in range(n_chunk + 1)]
+        main, side = (torch.cuda.current_stream(), _side_stream(ht_all.device)) if n_chunk > 1 else (None, None)
+        ht4, shared_kv, feats, tl_chunks, ids = ht_all.view(n, T, L, W), {}, [], [], None
+        for c in range(n_chunk):
+            c0, Tc = bounds[c], bounds[c + 1] - bounds[c]
+            if c == 1:
+                side.wait_stream(main)  # fork: the map K/V tables of the lights' cross attention were made (and cached) by piece 0
+            with torch.cuda.stream(side) if c > 0 else contextlib.nullcontext():
+                tl_Tc = tl_T
+                if n_chunk > 1:
+                    tl_Tc = expand_tl_tokens(model.tl_encoder, tl_tokens, mp, Tc)
+                    tl_Tc["_kv_cache"] = shared_kv
+                with _DropScope(n * Tc, Tc, 1 + c0, restart=_POLICY_SITE0):
+                    f = tl_encoder(model.tl_encoder, ht4[:, c0:c0 + Tc].reshape(n * Tc, L, W).contiguous(), tl_Tc, model.training)
+                    ids = (_DROP["site"], _DROP["call"]) if _DROP is not None else None
+                ev = None
+                if c > 0:
+                    ev = torch.cuda.Event()
+                    ev.record()
+            feats.append(f.view(n, Tc, L, -1))
+            tl_chunks.append((c0, feats[-1].detach(), ev))
     fused = getattr(wm, "fused_train_chain", True) and ht_all is not None  # (lights from their own logits: the torch state machine)
     chain = TrainChain(wm, b, tf_mask, T) if fused else None
     rec: Dict[str, List[Tensor]] = {}
     with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
         mp1, tl1 = dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={})
 
+        def tl_of(step):  # the light tokens of `step` from the piece that holds it (joined on first use)
+            for i in range(len(tl_chunks) - 1, -1, -1):
+                c0, f, ev = tl_chunks[i]
+                if step - 1 >= c0:
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                        tl_chunks[i] = (c0, f, None)
+                    return f[:, step - 1 - c0].reshape(n * L, -1)
+
         def policy1(step, hist, valid_, pose_, navi_valid_):
-            pre = None if tl_steps is None else (tl_steps[:, step - 1].reshape(n * L, -1), tl_pre[1])
+            pre = None if tl_chunks is None else (tl_of(step), ids)
             with _DropScope(n, 1, step, restart=_POLICY_SITE0):
                 return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z.detach(), z_valid, dest, navi_valid_, tl1, mp1,
                                    model.training, tl_pre=pre, want_logits=not fused)
@@ -1061,6 +1103,11 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
             training_rollout(wm, b, mp1, tl1, z.detach(), z_valid, tf_mask, step_end, policy=policy1, record=rec)
             st = {k: torch.stack(v, 1) for k, v in rec.items()}  # [n, T, ...]
             inputs = (flat(st["hv"]), flat(st["hp"]), flat(st["hm"]), flat(st["valid"]), flat(st["pose"]), flat(st["navi_valid"]))
+    if tl_chunks is not None:
+        if len(tl_chunks) > 1:
+            torch.cuda.current_stream().wait_stream(_side_stream(ht_all.device))  # join
+        tl_feat_all = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
+        tl_pre = (tl_feat_all.reshape(n * T * L, -1), ids)
     hv, hp, hm, valid_all, pose_all, navi_all = inputs
     ht_in = ht_all if ht_all is not None else flat(st["ht"])
     with _DropScope(n * T, T, 1, restart=_POLICY_SITE0):
