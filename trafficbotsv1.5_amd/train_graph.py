@@ -1012,7 +1012,10 @@ def tl_nll_all_steps(logits: Tensor, tl_gt: Tensor, tl_invalid: Tensor):
     return nll.permute(0, 2, 1), inv.permute(0, 2, 1)
 
 
-TL_CHUNKS = int(os.environ.get("TBX_TL_CHUNKS", "3"))  # pieces of the ahead-of-time light encoder (1: all steps at once, one stream)
+# Pieces of the ahead-of-time light encoder (1: all steps at once on the one stream). Measured (bench.py --mode train): 1 -> 68.8,
+# 2 -> 68.7, 3 -> 67.1, 5 -> 65.5 scenes/s - the light encoder's full-chip launches on the side stream do not fill the CUs the
+# stepping pass leaves idle, they queue in front of its small launches (no preemption), so the overlap loses. Kept as an opt-in.
+TL_CHUNKS = int(os.environ.get("TBX_TL_CHUNKS", "1"))
 _SIDE = {}
 
 
