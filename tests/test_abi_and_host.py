@@ -102,12 +102,17 @@ def test_ctypes_mirrors_have_the_layout_gcc_gives_the_header(hip, tmp_path):
     pairs = [("tbx_stage_t", hip.Stage), ("tbx_attn_seg_t", hip.AttnSeg), ("tbx_dec_mid_t", hip.DecMid), ("tbx_dec_layer_t", hip.DecLayer), ("tbx_heads_tail_t", hip.HeadsTail), ("tbx_knn_job_t", hip.KnnJob), ("tbx_pose_embed_job_t", hip.PoseEmbedJob), ("tbx_sim_state_t", hip.SimState),
              ("tbx_train_chain_t", hip.TrainChainArgs), ("tbx_rule_ctx_t", hip.RuleCtx)]
     src = tmp_path / "sz.c"
-    src.write_text('#include "tbx_hip.h"\n#include <stdio.h>\nint main(void){' +
-                   "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n")
+    # ... and offsetof of every field (same names on both sides): runs of same-sized pointers keep sizeof when two fields swap
+    fields = [(c, t, f[0]) for c, t in pairs for f in t._fields_]
+    src.write_text('#include "tbx_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) +
+                   "".join(f'printf("%zu\\n", offsetof({c}, {f}));' for c, _, f in fields) + "return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", str(root / "include"), str(src), "-o", str(exe)], check=True)
-    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert sizes == [C.sizeof(t) for _, t in pairs]
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[:len(pairs)] == [C.sizeof(t) for _, t in pairs]
+    for (c, t, f), off in zip(fields, out[len(pairs):]):
+        assert getattr(t, f).offset == off, (c, f, getattr(t, f).offset, off)
 
 
 def test_new_entry_points_validate_arguments_without_a_gpu(hip):

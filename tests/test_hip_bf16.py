@@ -1,4 +1,4 @@
-"""BASELINE config 2 names bf16: the K/V tables the relative-pose attention gathers from stored as bfloat16 (engine.KV_BF16;
+"""BASELINE config 2 names bf16: the K/V tables the relative-pose attention gathers from stored as bfloat16 (engine.Schedule.kv_bf16;
 529 B per (source, target) pair instead of 1041), everything else fp32. Stated tolerances vs the fp32 path / oracle:
   * the tables themselves: round-to-nearest-even bf16 of the fp32 tables (bit-exact against torch's conversion);
   * one attention call: |out - out_fp32| <= 1.5e-2 * max|out_fp32| (K and V carry 2^-9 relative rounding each; the softmax is fp32);
@@ -22,9 +22,8 @@ DEV = "cuda:0"
 @pytest.fixture()
 def bf16_tables():
     eng = import_module("trafficbots_amd.engine")
-    eng.KV_BF16 = True
-    yield eng
-    eng.KV_BF16 = False
+    with eng.use(eng.DEFAULT.replace(kv_bf16=True)):
+        yield eng
 
 
 def test_bf16_store_and_attention_vs_fp32(tb):
@@ -88,9 +87,8 @@ def test_bf16_tables_closed_loop_vs_fp32_oracle(tb, bf16_tables, sizes, knn):
     # the tables really are bfloat16, the K-nearest sets are those of the fp32 path
     kv_mp = wm.model.ag_encoder.kv_mp(mp)
     assert kv_mp.dtype == torch.bfloat16 and wm.model.tl_encoder._kv_mp(tl).dtype == torch.bfloat16
-    bf16_tables.KV_BF16 = False
-    mp32, tl32 = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
-    bf16_tables.KV_BF16 = True
+    with bf16_tables.use(bf16_tables.DEFAULT.replace(kv_bf16=False)):
+        mp32, tl32 = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
     for k in ("knn_idx_tl2tl", "knn_invalid_tl2tl"):
         if k in tl:
             assert torch.equal(tl[k], tl32[k]), k

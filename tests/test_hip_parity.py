@@ -600,20 +600,14 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
     if bf16:  # bfloat16 K/V tables (engine.KV_BF16): the one-launch layer also writes the next layer's bf16 k | v copy
         kv = kv.to(torch.bfloat16)
     pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
-    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER)
-    saved_bf16, eng.KV_BF16 = eng.KV_BF16, bf16
     outs = {}
-    try:
-        for name, cfg in {"mfma": (0, False, False, False), "mid": (1, True, True, False), "layer": (1, True, True, True)}.items():
-            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = cfg
-            x = x0.clone()
+    for name, (live, fold, mid, layer) in {"mfma": (0, False, False, False), "mid": (1, True, True, False), "layer": (1, True, True, True)}.items():
+        x = x0.clone()
+        with eng.use(eng.DEFAULT.replace(live_rows=live, attn_fold=fold, dec_mid=mid, dec_layer=layer, kv_bf16=bf16, split_bf16=False)):
             eng.run_block(blk, x, src_invalid, n, S, eng.SelfKnn(i0, m0, rel=r0),
                           cross=lambda l: [hip.Seg(kv, l * 256, l * 256 + D, T, ic, mc, None, 1, rel=rc)], pose_rpe=pe)
-            torch.cuda.synchronize()
-            outs[name] = x
-    finally:
-        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER = saved
-        eng.KV_BF16 = saved_bf16
+        torch.cuda.synchronize()
+        outs[name] = x
     assert torch.isfinite(outs["mfma"]).all() and float(outs["mfma"][src_invalid.bool()].abs().max()) == 0.0
     assert float((outs["mfma"] - x0).abs().max()) > 1e-3
     for name in ("mid", "layer"):

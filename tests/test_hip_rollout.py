@@ -171,21 +171,18 @@ def test_lights_one_step_ahead_equals_sequential_order(tb):
     the inputs of the sequential order, so the rollout must be bit-identical to it, eager and as a graph."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
-    E = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    E = import_module("trafficbots_amd.engine")
     mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
     g = torch.Generator().manual_seed(0)
     z = torch.randn(1, 8, 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
     outs = {}
-    try:
-        for ahead in (True, False):
-            for use_graph in (False, True):
-                E.lights_ahead = ahead
-                outs[ahead, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid,
-                                                            wm.teacher_forcing_joint_future_pred, True, step_end=40,
-                                                            use_graph=use_graph)
-    finally:
-        E.lights_ahead = True
+    for ahead in (True, False):
+        for use_graph in (False, True):
+            wm.schedule = E.DEFAULT.replace(lights_ahead=ahead)
+            outs[ahead, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid,
+                                                        wm.teacher_forcing_joint_future_pred, True, step_end=40,
+                                                        use_graph=use_graph)
     ref = outs[False, False]
     for k, o in outs.items():
         assert torch.equal(o.pred_pose, ref.pred_pose), k
@@ -199,19 +196,16 @@ def test_hoisted_rollout_constants_are_bit_identical(tb):
     (TrafficBots.rollout_constants): same kernels on the same inputs, so the rollout must not change by a bit."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
-    E = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    E = import_module("trafficbots_amd.engine")
     mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
     g = torch.Generator().manual_seed(5)
     z = torch.randn(1, 8, 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
     outs = {}
-    try:
-        for hoist in (True, False):
-            E.hoist_constants = hoist
-            outs[hoist] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
-                                             step_end=30)
-    finally:
-        E.hoist_constants = True
+    for hoist in (True, False):
+        wm.schedule = E.DEFAULT.replace(hoist_constants=hoist)
+        outs[hoist] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
+                                         step_end=30)
     assert torch.equal(outs[True].pred_pose, outs[False].pred_pose)
     assert torch.equal(outs[True].vis_dict["action"], outs[False].vis_dict["action"])
 
@@ -223,7 +217,7 @@ def test_shared_lights_across_rollouts_are_bit_identical(tb):
     bit for bit - eager, as a graph, and in the one-stream order."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
-    E = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    E = import_module("trafficbots_amd.engine")
     D = import_module("trafficbots_amd.models.modules.distributions")
     n, A = bd["sc/ag_valid"].shape[:2]
     valid = bd["sc/ag_valid"].any(-1)
@@ -232,18 +226,15 @@ def test_shared_lights_across_rollouts_are_bit_identical(tb):
     onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], bd["sc/mp_valid"].shape[1]).float()
     wm.hp.joint_future_pred_deterministic_k0 = False
     outs = {}
-    try:
-        for share in (False, True):
-            for ahead, use_graph in ((True, True), (True, False), (False, False)):
-                E.share_lights, E.lights_ahead = share, ahead
-                torch.manual_seed(5)  # the K latent samples of a scene differ from each other, and are the same in every variant
-                lat = D.DiagGaussian(torch.zeros(n, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)
-                nav = D.DestCategorical(probs=onehot, valid=valid)
-                _, tl = wm.encode_scene(bd, n_rollout=K)
-                outs[share, ahead, use_graph] = (wm.joint_future_pred(bd, mp, tl, lat, nav, wm.teacher_forcing_joint_future_pred, K, step_end=30,
-                                                                      use_graph=use_graph), wm._engine.tl_div)
-    finally:
-        E.share_lights, E.lights_ahead = True, True
+    for share in (False, True):
+        for ahead, use_graph in ((True, True), (True, False), (False, False)):
+            wm.schedule = E.DEFAULT.replace(share_lights=share, lights_ahead=ahead)
+            torch.manual_seed(5)  # the K latent samples of a scene differ from each other, and are the same in every variant
+            lat = D.DiagGaussian(torch.zeros(n, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)
+            nav = D.DestCategorical(probs=onehot, valid=valid)
+            _, tl = wm.encode_scene(bd, n_rollout=K)
+            outs[share, ahead, use_graph] = (wm.joint_future_pred(bd, mp, tl, lat, nav, wm.teacher_forcing_joint_future_pred, K, step_end=30,
+                                                                  use_graph=use_graph), wm._engine.tl_div)
     ref, div0 = outs[False, False, False]
     assert div0 == 1
     assert not torch.equal(ref.pred_pose[:, 0], ref.pred_pose[:, 1])  # the rollouts of a scene do differ
@@ -268,26 +259,20 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
     g = torch.Generator().manual_seed(9)
     z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
-    saved = (eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ)
-    AE = import_module("trafficbots_amd.models.agent_encoder")
-    RE = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
-    saved_rides = (AE.PE_RIDES, RE.TL_PREP_RIDES)
     outs = {}
-    try:
+    if True:
         # (.., pool): layer 0's projections inside the launch that pools the windows (TBX_F_POOL_KEEP) or as a launch of their own
         for name, (live, fold, mid, layer, pool) in {"mfma": (0, False, False, False, False), "live1": (1, False, False, False, False),
                                                      "live2": (2, False, False, False, True), "fold": (1, True, False, False, True),
                                                      "mid": (1, True, True, False, False), "mid2": (2, True, True, False, True),
                                                      "layer": (1, True, True, True, False), "layer2": (2, True, True, True, True),
                                                      "layer1p": (1, True, True, True, True)}.items():
-            eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = live, fold, mid, layer, pool
             # riders: the destination's pose embedding in the searches' launch, tbx_tl_prep in the lights' tbx_sim_step launch
-            AE.PE_RIDES = RE.TL_PREP_RIDES = name not in ("mfma", "live1", "mid")
+            rides = name not in ("mfma", "live1", "mid")
+            wm.schedule = eng.DEFAULT.replace(live_rows=live, attn_fold=fold, dec_mid=mid, dec_layer=layer, pool_proj=pool,
+                                              pe_rides=rides, tl_prep_rides=rides, split_bf16=False)
             outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                             step_end=24)
-    finally:
-        eng.LIVE_ROWS, eng.ATTN_FOLD, eng.DEC_MID, eng.DEC_LAYER, eng.POOL_PROJ = saved
-        AE.PE_RIDES, RE.TL_PREP_RIDES = saved_rides
     ref = outs["mfma"]
     for name, o in outs.items():
         assert torch.equal(o.pred_pose, ref.pred_pose), name

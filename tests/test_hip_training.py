@@ -319,15 +319,19 @@ def test_time_batched_training_rollout_equals_step_by_step_autograd(tb, dropout,
     assert res[True][1].keys() == res[False][1].keys()
     for k, gs in res[False][1].items():
         gb = res[True][1][k]
-        # 2e-3 of the parameter's largest gradient entry: the two schedules sum the same per-row terms in different orders (fp32
-        # atomics, split-K weight gradients), and at the C3 size the small-gradient parameters (|g| ~ 5e-5) sit at ~1e-3. A
-        # parameter whose whole gradient is a ~1e-6 residue of cancelling terms (the posterior's log_std) is compared on the
-        # absolute scale of those terms. Measured spread over scene seeds (tools/scratch/batched_vs_stepwise_spread.py): the worst
-        # parameter typically sits at 2e-6 .. 5e-6 of its largest entry; isolated 6e-4 .. 5e-3 outliers appear on the weights feeding
-        # a ReLU (transformer linear1) when one unit's pre-activation changes sign between the two schedules (fp32-level
-        # differences of the closed loop at a kink) - which scene shows one moves with any change of the arithmetic (aten's vs this
-        # repo's LayerNorm forward: seeds 5, 6 vs seeds 1, 5). A wrong mask or a missing term is an O(0.1 .. 1) difference.
-        assert float((gb - gs).abs().max()) <= 1e-2 * max(float(gs.abs().max()), 3e-5), k
+        # Robust metric: the relative L2 error of the whole parameter gradient at 1e-3. The two schedules sum the
+        # same per-row terms in different orders (fp32 atomics, split-K weight gradients): measured 2e-6 .. 5e-6 per entry
+        # (tools/scratch/batched_vs_stepwise_spread.py). The only known legitimate outliers are the weights feeding a ReLU
+        # (transformer linear1 / its bias / the norm in front of it) when ONE unit's pre-activation changes sign between the two
+        # schedules: those - and only those - get the looser per-entry bound; a parameter whose whole gradient is a ~1e-6 residue
+        # of cancelling terms (the posterior's log_std) is compared on the absolute scale of those terms. A wrong mask or a missing
+        # term is an O(0.1 .. 1) difference in either metric.
+        err = (gb - gs).double()
+        rel_l2 = float(err.norm()) / max(float(gs.double().norm()), 1e-6 * gs.numel() ** 0.5)
+        relu_fed = any(t in k for t in (".linear1.", ".norm2.", "log_std"))
+        assert rel_l2 <= (1e-2 if relu_fed else 1e-3), (k, rel_l2, float(err.abs().max()), float(gs.abs().max()))
+        n_big = int((err.abs() > 1e-3 * max(float(gs.abs().max()), 1e-6)).sum())
+        assert relu_fed or n_big <= max(2, gs.numel() // 200), (k, n_big, gs.numel())
 
 
 @pytest.mark.parametrize("rows,n,k,ld_pad", [(20000, 128, 128, 0), (70001, 640, 128, 0), (33333, 128, 640, 0), (16390, 64, 20, 12), (50000, 4, 256, 0),

@@ -33,7 +33,7 @@ def main():
     lib.tbx_debug_mid_dump.argtypes = [C.c_void_p, C.c_int]
     wm, full = bench.build(tb, args, dev, 0)
     eng, _ = bench.gpu_rollout_setup(tb, wm, full, args, dev)
-    type(eng).lights_ahead = False
+    eng.sched = eng.sched.replace(lights_ahead=False)
     eng.run(args.warmup + 3, use_graph=False)
     torch.cuda.synchronize()
     buf = (C.c_uint64 * (256 * 16))()

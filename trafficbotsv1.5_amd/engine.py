@@ -9,7 +9,10 @@ Formulation (exact restatements of modules/attention_rpe.py, SURVEY.md §0 findi
   * `linear_rpe` is folded into the query side (qt_h = W_rpe_k,h^T q_h) and into the weighted sum
     (sum_t a_t (W_rpe_v e_t + b) = W_rpe_v (sum_t a_t e_t) + b  with sum_t a_t = 1 in eval mode).
 """
+import contextlib
+import dataclasses
 import os
+import threading
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -25,14 +28,100 @@ def _u8(mask: torch.Tensor) -> torch.Tensor:
     return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
 
 
+def _env(name: str, default: str) -> str:
+    return os.environ.get(name, default)
+
+
+@dataclasses.dataclass
+class Schedule:
+    """Which launches a piece of the hot path is scheduled as. One object per owner (a `WaymoMotion` module, a `RolloutEngine`, a
+    test), made current for the duration of that owner's calls by `use(...)`: nothing here is process-wide state, so engines with
+    different schedules (fp32 and bf16 tables, one-stream and two-stream order) live side by side in one process / on 8 ranks. Every
+    choice yields the same results up to the tolerances stated in tests/ (most of them bit-identical: see the field comments).
+    The defaults come from the TBX_* environment variables, read once at import (`Schedule.from_env`)."""
+    # residual updates folded into the producing LINEAR stage (accumulate into the token row, masked rows skipped): 5 stages fewer
+    # per decoder layer. False: separate ROWMASK / ADD stages (results differ by fp32 rounding order only).
+    fused_residual: bool = True
+    load2: bool = True  # token rows + attention output loaded by one stage
+    # inference: the attention kernel applies the value half of linear_rpe in its epilogue (tbx_knarpe_attn_fwd_folded): 128 floats
+    # per row leave it instead of 640 and the grouped fold stage of the following chain disappears.
+    attn_fold: bool = True
+    # the wave-per-row form of the kernel (>= 1024 rows) has the folded epilogue too. Measured at the WOSAC shape (4096 rows x 104
+    # pairs): 52.2 us per launch instead of 46.3, the following chain 39.8 us instead of 42.4: 1.159 ms per step instead of 1.143.
+    attn_fold_big: bool = False
+    # a dec_cross_attn layer's [self attention -> out-proj -> LN -> q -> W_k^T q -> cross attention] as ONE launch (tbx_knarpe_dec_mid)
+    dec_mid: bool = True
+    dec_layer: bool = True   # ... and the whole layer (that launch + the chain after it) as ONE launch, tbx_knarpe_dec_layer
+    heads_tail: bool = True  # ... and, for the agents' last layer, the heads (navigation / latent adders + action head) in that launch
+    tail_split: bool = True  # a last layer whose chain carries a caller's tail: the layer as one launch + the tail as a short chain
+    rowzero: bool = True     # a layer's closing x[invalid] = 0 inside its last LINEAR stage
+    masked_groupmax: bool = True
+    big_rows: int = 16384    # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
+    # launches of a few hundred rows in all (one 64-agent scene) are latency-bound: they run as tbx_rowchain_live programs - tiles
+    # of live_rows rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA tiles) - up to live_max rows.
+    live_rows: int = 1
+    live_max: int = 512
+    # BASELINE config 2 names bf16: the K/V tables every attention call gathers from stored as bfloat16 (529 B per pair instead of
+    # 1041); queries, pose embeddings, scores, softmax and all sums stay fp32. Off: the fp32 parity path.
+    kv_bf16: bool = False
+    # small launches: the transformer's first projection inside the launch that pools its input rows (TBX_F_POOL_KEEP)
+    pool_proj: bool = False
+    # LINEAR stages of MFMA row chains (launches past live_max rows) on the split-bf16 matrix path: activations and weights as bf16
+    # hi + lo, three products per k on the bf16 MFMA (< 3e-5 of sum |x||w|; tests/test_hip_parity.py)
+    split_bf16: bool = False
+    pe_rides: bool = True       # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
+    # ---- RolloutEngine
+    tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
+    lights_ahead: bool = True   # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step)
+    # steps per multi-step graph (even; 1: off). A replay boundary costs a few us of idle device: 4 -> 197.9 k, 16 -> 199.4 k, 40 ->
+    # 200.4 k agent-steps/s at the 64-agent scene. Capturing g steps costs g eager steps of host time, so the default suits an engine
+    # that runs ONE 80-step rollout; a caller that replays an engine many times raises it (bench.py: 40).
+    graph_steps: int = 4
+    # the light recurrence reads no agent and no latent, so the K rollouts of a scene carry K identical copies of it: the engine
+    # steps the lights once per scene and the agents of the K rollouts attend to that one copy. Bit-identical rollouts.
+    share_lights: bool = True
+    hoist_constants: bool = True  # False: the heads chain re-embeds the latent / destination feature every step (same values)
+
+    @classmethod
+    def from_env(cls) -> "Schedule":
+        on = lambda name, d="1": _env(name, d) != "0"
+        return cls(fused_residual=on("TBX_FUSED_RESIDUAL"), load2=on("TBX_LOAD2"), attn_fold=on("TBX_ATTN_FOLD"),
+                   attn_fold_big=_env("TBX_ATTN_FOLD_BIG", "0") == "1", dec_mid=on("TBX_DEC_MID"), dec_layer=on("TBX_DEC_LAYER"),
+                   heads_tail=on("TBX_HEADS_TAIL"), tail_split=on("TBX_TAIL_SPLIT"), rowzero=on("TBX_ROWZERO"),
+                   masked_groupmax=on("TBX_MASKED_GROUPMAX"), big_rows=int(_env("TBX_BIG_ROWS", "16384")),
+                   live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
+                   kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
+                   split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
+
+    def replace(self, **kw) -> "Schedule":
+        return dataclasses.replace(self, **kw)
+
+
+DEFAULT = Schedule.from_env()
+_tls = threading.local()
+
+
+def current() -> Schedule:
+    """The schedule of whoever is running (innermost `use`), else the process default."""
+    return getattr(_tls, "sched", None) or DEFAULT
+
+
+@contextlib.contextmanager
+def use(sched: Optional[Schedule]):
+    """Make `sched` current for the calls inside the block (None: leave the current one)."""
+    prev = getattr(_tls, "sched", None)
+    _tls.sched = sched if sched is not None else prev
+    try:
+        yield current()
+    finally:
+        _tls.sched = prev
+
+
 # Keyed dropouts of training for whoever emits chains while it is set (train_graph's stepping pass; None in inference):
 # dict(seed=int64[1] device tensor, site=last elementwise site id used, call=last attention call id used, step=closed-loop step).
 # The emitters below take their ids from it in execution order - the order train_graph's torch ops take theirs.
 DROP_CTX: Optional[dict] = None
-# Residual updates folded into the producing LINEAR stage (accumulate into the token row, masked rows skipped): 5 stages fewer per
-# decoder layer. False: separate ROWMASK / ADD stages (the previous schedule; results differ by fp32 rounding order only).
-FUSED_RESIDUAL = os.environ.get("TBX_FUSED_RESIDUAL", "1") != "0"
-LOAD2 = os.environ.get("TBX_LOAD2", "1") != "0"  # token rows + attention output loaded by one stage
 
 
 def drop_site(p: float):
@@ -61,25 +150,8 @@ def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col:
     return nq + NH * D
 
 
-# Inference: the attention kernel applies the value half of linear_rpe in its epilogue (tbx_knarpe_attn_fwd_folded): 128 floats
-# per row leave it instead of 640 and the grouped fold stage of the following chain disappears. TBX_ATTN_FOLD=0: off.
-ATTN_FOLD = os.environ.get("TBX_ATTN_FOLD", "1") != "0"
-# The wave-per-row form of the kernel (>= 1024 rows) has the folded epilogue too (4 rows per workgroup share the fold image, a
-# workgroup walks several row quads). Measured at the WOSAC shape (4096 rows x 104 pairs): 52.2 us per launch instead of 46.3
-# (the 4 waves of a workgroup meet at a barrier and run two 128-long fma chains each), the following chain 39.8 us instead of
-# 42.4: 1.159 ms per step instead of 1.143. 10.5 -> 2.1 MB written per launch, but not faster: off unless TBX_ATTN_FOLD_BIG=1.
-ATTN_FOLD_BIG = os.environ.get("TBX_ATTN_FOLD_BIG", "0") == "1"
 
 
-# ... and a dec_cross_attn layer's [self attention -> out-proj -> LN -> q -> W_k^T q -> cross attention] runs as ONE launch
-# (tbx_knarpe_dec_mid) instead of attention kernel -> chain -> attention kernel. TBX_DEC_MID=0: the three launches.
-DEC_MID = os.environ.get("TBX_DEC_MID", "1") != "0"
-# ... and the whole layer (that launch + the chain after it) as ONE launch, tbx_knarpe_dec_layer. TBX_DEC_LAYER=0: two launches.
-DEC_LAYER = os.environ.get("TBX_DEC_LAYER", "1") != "0"
-# ... and, for the agents' last layer, the heads (navigation / latent adders + action head) in that launch as well. TBX_HEADS_TAIL=0: a chain.
-HEADS_TAIL = os.environ.get("TBX_HEADS_TAIL", "1") != "0"
-# A last layer whose chain carries a caller's tail (the lights' logits head): the layer as one launch + the tail as a short chain.
-TAIL_SPLIT = os.environ.get("TBX_TAIL_SPLIT", "1") != "0"
 
 
 def attn_fold_image(attn) -> torch.Tensor:
@@ -92,7 +164,7 @@ def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tenso
     (transformer_rpe.py:56-60) as a keyed DROPOUT stage. x: the token rows [rows, 128] are not in x_buf yet - they are loaded in the
     same stage as the attention output (TBX_F_LOAD2: one memory round trip for both)."""
     folded = obuf.shape[1] == D  # the attention kernel already applied the fold
-    if x is not None and LOAD2:
+    if x is not None and current().load2:
         ch.load2(obuf, BUF0, 0, x, x_buf, 0)
     else:
         if x is not None:
@@ -102,7 +174,7 @@ def emit_attn_out(ch: Chain, attn, obuf: torch.Tensor, row_no_valid: torch.Tenso
         # per head: (sum a v)_h += W_rpe_v,h (sum a e)_h + b_rpe_v,h, one block-diagonal stage
         ch.linear(BUF0, D, BUF0, 0, attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], accum=True, groups=NH, src_stride=D,
                   dst_stride=DH)
-    if drop is None and ch.pack_weights and FUSED_RESIDUAL:
+    if drop is None and ch.pack_weights and current().fused_residual:
         # one stage: x += rows without a valid target ? 0 : out_proj(...)  (TBX_F_ROWSKIP + accumulate into the token row)
         ch.linear(BUF0, 0, x_buf, 0, attn.out_proj_weight, attn.out_proj_bias, accum=True, skip_rows=row_no_valid)
         return
@@ -121,8 +193,8 @@ def emit_ffn(ch: Chain, layer, x_buf: int = BUF1, drop_hidden=None, drop_out=Non
     ch.linear(BUF0, 0, BUF0, D, layer.linear1.weight, layer.linear1.bias, relu=True)
     if drop_hidden is not None:
         ch.dropout(BUF0, D, layer.linear1.weight.shape[0], *drop_hidden)
-    if drop_out is None and ch.pack_weights and FUSED_RESIDUAL:
-        if zero_rows is not None and ROWZERO:
+    if drop_out is None and ch.pack_weights and current().fused_residual:
+        if zero_rows is not None and current().rowzero:
             ch.linear(BUF0, D, x_buf, 0, layer.linear2.weight, layer.linear2.bias, accum=True, skip_rows=zero_rows, zero_skipped=True)
             return True
         ch.linear(BUF0, D, x_buf, 0, layer.linear2.weight, layer.linear2.bias, accum=True)  # x += linear2(...) in one stage
@@ -160,8 +232,6 @@ def emit_mlp(ch: Chain, mlp, src_buf: int, src_col: int, bufs=(BUF0, BUF1), out_
     return cur
 
 
-ROWZERO = os.environ.get("TBX_ROWZERO", "1") != "0"  # a layer's closing x[invalid] = 0 inside its last LINEAR stage
-MASKED_GROUPMAX = os.environ.get("TBX_MASKED_GROUPMAX", "1") != "0"
 
 
 def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.Tensor, x_buf: int = BUF1, keep: bool = False) -> Optional[int]:
@@ -177,7 +247,7 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
         d = drop_site(mlp.dropout_p)
         if d is not None:
             ch.dropout(nxt, 0, half, *d)
-        if d is None and MASKED_GROUPMAX:  # one stage: the maximum over the group's valid rows, masked rows zeroed in both halves
+        if d is None and current().masked_groupmax:  # one stage: the maximum over the group's valid rows, masked rows zeroed in both halves
             ch.groupmax(nxt, 0, nxt, half, half, mask=row_invalid)
         else:
             ch.rowmask(nxt, 0, half, mask=row_invalid, fill=float("-inf"))
@@ -198,44 +268,34 @@ def emit_pointnet(ch: Chain, pl_encoder, row_invalid: torch.Tensor, out: torch.T
 LAYER_LDW0, LAYER_LDW1, LAYER_AUX = 644, 132, 132
 
 
-BIG_ROWS = int(os.environ.get("TBX_BIG_ROWS", "16384"))  # from here on 32-row tiles + direct-to-global outputs win (measured: +8 % at 16k rows, -10 % at 4k / 64)
 
 
-# Launches of a few hundred rows in all (one 64-agent scene: 64 agent rows, 128 light rows) are latency-bound: they run as
-# tbx_rowchain_live programs - tiles of LIVE_ROWS rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA
-# tiles, see csrc/rowchain.hip linear_gemv) - up to LIVE_MAX rows. TBX_LIVE_ROWS=0 turns the mode off.
-LIVE_ROWS = int(os.environ.get("TBX_LIVE_ROWS", "1"))
-LIVE_MAX = int(os.environ.get("TBX_LIVE_MAX", "512"))
 
 
-# BASELINE config 2 names bf16: with KV_BF16 the K/V tables every attention call gathers from (the per-layer self tables, the
-# static map tables, the per-step light tables) are stored as bfloat16 - half the bytes per gathered row (529 B per pair instead
-# of 1041) - while queries, pose embeddings, scores, softmax and all sums stay fp32. Off: the fp32 parity path. (TBX_KV_BF16=1)
-KV_BF16 = os.environ.get("TBX_KV_BF16", "0") == "1"
 
 
 def kv_dtype():
-    return torch.bfloat16 if KV_BF16 else torch.float32
+    return torch.bfloat16 if current().kv_bf16 else torch.float32
 
 
 def live_rows_for(rows: int) -> int:
-    return LIVE_ROWS if (LIVE_ROWS and rows <= LIVE_MAX and DROP_CTX is None) else 0
+    return current().live_rows if (current().live_rows and rows <= current().live_max and DROP_CTX is None) else 0
 
 
 def row_chain(rows: int, ldw: int, ldw1: Optional[int] = None, ld_aux: Optional[int] = None, big: Optional[tuple] = None) -> Chain:
     """A flat (un-grouped) chain for `rows` rows: live-row tiles for small launches, 16-row MFMA tiles otherwise, `big` = the
-    (tile_rows, ldw0, ldw1, ld_aux) layout of grids past BIG_ROWS if the caller has one."""
+    (tile_rows, ldw0, ldw1, ld_aux) layout of grids past current().big_rows if the caller has one."""
     live = live_rows_for(rows)
     if live:  # 4-row LDS tiles + 128 KiB of weight slots: narrow side buffers unless the caller asks for more
         return Chain(16, ldw, ldw if ldw1 is None else ldw1, 132 if ld_aux is None else ld_aux, live_rows=live)
-    if big is not None and rows >= BIG_ROWS:
+    if big is not None and rows >= current().big_rows:
         return Chain(*big)
     return Chain(16, ldw, ldw1, ld_aux)
 
 
 def layer_chain(rows: int) -> Chain:
     """Small grids: 16-row tiles, everything staged in LDS (2 x 1028-float buffers, 1 workgroup per CU, fewest stages) - as
-    live-row tiles up to LIVE_MAX rows. Large grids: 32-row tiles with asymmetric buffers (116 KB) and wide outputs written
+    live-row tiles up to current().live_max rows. Large grids: 32-row tiles with asymmetric buffers (116 KB) and wide outputs written
     straight to global memory."""
     if live_rows_for(rows):
         return Chain(16, 1028, 132, 132, live_rows=live_rows_for(rows))  # BUF1 holds the token row only, AUX one 128-wide temporary
@@ -244,7 +304,7 @@ def layer_chain(rows: int) -> Chain:
 
 def emit_proj(ch: Chain, rows: int, norm, attn, out: torch.Tensor, with_kv: bool, kv16: Optional[torch.Tensor] = None, x_buf: int = BUF1):
     """LN(x in x_buf) -> [q | k | v | qt] / [q | qt] stored to `out` (+ k | v as bfloat16 to kv16 [rows, 256] if given)."""
-    if rows >= BIG_ROWS:
+    if rows >= current().big_rows:
         emit_proj_to(ch, norm, attn, out, with_kv, x_buf=x_buf, kv16=kv16)
     else:
         ch.layernorm(x_buf, 0, BUF0, 0, norm.weight, norm.bias, norm.eps)
@@ -271,19 +331,16 @@ def emit_proj_to(ch: Chain, norm, attn, out: torch.Tensor, with_kv: bool, x_buf:
     ch.linear(BUF0, D, GLOBAL, nq, attn.linear_rpe.weight[:D], wt=True, groups=NH, src_stride=DH, dst_stride=D, out=out)
 
 
-# Small launches: the transformer's first projection (LN -> q | k | v | W_k^T q of layer 0) inside the launch that pools its input
-# rows (the temporal PointNet of the agents' / lights' windows) instead of as a launch of its own between the two.
-POOL_PROJ = os.environ.get("TBX_POOL_PROJ", "0") == "1"
 FIRST_PROJ_LDW = 1028  # BUF0 of such a chain: the LayerNorm row + the 896-wide projection
 
 
 def first_proj_buffers(rows: int, dev, tile_rows: int = 16) -> Optional[dict]:
     """The q | k | v | qt rows (+ the bfloat16 k | v copy) run_block(first_proj=...) starts from when the producer of its input rows
     ran emit_first_proj in its own chain; None where that form is not used (large launches, training's keyed dropout)."""
-    if not (POOL_PROJ and live_rows_for(rows)) or tile_rows != 16:  # (two 1028-wide buffers of 16 rows: 148 KB of LDS)
+    if not (current().pool_proj and live_rows_for(rows)) or tile_rows != 16:  # (two 1028-wide buffers of 16 rows: 148 KB of LDS)
         return None
     return dict(qkv=torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev),
-                kv16=torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 else None)
+                kv16=torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if current().kv_bf16 else None)
 
 
 def emit_first_proj(ch: Chain, block, fp: dict, x_buf: int) -> None:
@@ -332,13 +389,13 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     src_invalid = _u8(src_invalid).reshape(-1).contiguous()
     qkv = torch.empty(rows, QKV_LD, dtype=torch.float32, device=dev) if first_proj is None else first_proj["qkv"]
     # (a one-launch layer writes the next layer's q | k | v | qt rows while other workgroups still gather this layer's K / V rows)
-    qkv_alt = torch.empty_like(qkv) if DEC_LAYER and DEC_MID and ATTN_FOLD and bool(live_rows_for(rows)) else None
-    kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if KV_BF16 and drop is None and DROP_CTX is None else None
+    qkv_alt = torch.empty_like(qkv) if current().dec_layer and current().dec_mid and current().attn_fold and bool(live_rows_for(rows)) else None
+    kv16 = torch.empty(rows, 2 * D, dtype=torch.bfloat16, device=dev) if current().kv_bf16 and drop is None and DROP_CTX is None else None
     if first_proj is not None:  # layer 0's projections were made by the launch that produced x (emit_first_proj)
         assert drop is None and DROP_CTX is None and (first_proj["kv16"] is not None) == (kv16 is not None)
         kv16 = first_proj["kv16"]
     kv16_alt = torch.empty_like(kv16) if (kv16 is not None and qkv_alt is not None) else None
-    fold = ATTN_FOLD and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or ATTN_FOLD_BIG)
+    fold = current().attn_fold and drop is None and DROP_CTX is None and (bool(live_rows_for(rows)) or current().attn_fold_big)
     obuf = torch.empty(rows, D if fold else O_LD, dtype=torch.float32, device=dev)
     flag = torch.empty(rows, dtype=torch.uint8, device=dev)
     heads_done = False  # -> True if the last layer's launch also ran `heads_tail`
@@ -361,12 +418,12 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         ch.run(rows)
     if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
-    mid = fold and dec and DEC_MID and bool(live_rows_for(rows))  # the one-launch attention half: small launches only
+    mid = fold and dec and current().dec_mid and bool(live_rows_for(rows))  # the one-launch attention half: small launches only
     for l, layer in enumerate(layers):
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
-        whole = mid and DEC_LAYER and qkv_alt is not None and (l + 1 < len(layers) or tail is None or TAIL_SPLIT) and src_invalid is not None
+        whole = mid and current().dec_layer and qkv_alt is not None and (l + 1 < len(layers) or tail is None or current().tail_split) and src_invalid is not None
         if whole:
             # ONE launch for the layer (tbx_knarpe_dec_layer): the attention half below, then out_proj / FFN / x[invalid] = 0 and the
             # next layer's projections - the stages of the chain that followed tbx_knarpe_dec_mid, in the same arithmetic
@@ -376,7 +433,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                        linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, gemv=True),
                        linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, gemv=True),
                        norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid)
-            if last and heads_tail is not None and HEADS_TAIL:
+            if last and heads_tail is not None and current().heads_tail:
                 tl_["heads"] = heads_tail  # the agents' heads in this launch too (tbx_heads_tail_t)
                 heads_done = True
             if not last:

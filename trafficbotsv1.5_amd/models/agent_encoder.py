@@ -1,22 +1,18 @@
 """`AgentEncoder` (models/agent_encoder.py:15-466), HPTR variant (`_forward_hptr`): per step, the agents' W-step
 windows -> local-frame PointNet tokens -> 4 dec_cross_attn layers over [K nearest agents | K nearest map tokens ++
 K nearest traffic lights]."""
-import os
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
+from ..engine import current as engine_current, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
 from .modules.polyline_encoder import PolylineEncoder
 from .modules.transformer_rpe import TransformerBlockRPE
-
-
-PE_RIDES = os.environ.get("TBX_PE_RIDES", "1") != "0"  # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
 
 
 class AgentEncoder(nn.Module):
@@ -128,7 +124,7 @@ class AgentEncoder(nn.Module):
                     dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
                          out=prep.get("_knn_at"))]
             want_pe = navi_rpe is not None and dest is not None
-            pe_rides = want_pe and PE_RIDES and n * A < 4096  # the destination's pose embedding in the searches' launch
+            pe_rides = want_pe and engine_current().pe_rides and n * A < 4096  # the destination's pose embedding in the searches' launch
             if pe_rides and prep.get("navi_pe") is None:
                 prep["navi_pe"] = torch.empty(n * A, navi_rpe.out_dim, dtype=torch.float32, device=dev)
             if n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)

@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor, nn
 
+from .. import engine
 from ..config import AttrDict, to_attr
 from ..data_modules.scene_centric import SceneCentricPreProcessing
 from ..models.modules.distributions import MyDist
@@ -58,6 +59,16 @@ class WaymoMotion(LightningModule):
         if pred_navi_after_reached:
             raise NotImplementedError("pred_navi_after_reached=False is the default (no per-step host branch)")
         self.save_hyperparameters()  # self.hparams.<constructor argument>, as in the reference (waymo_motion.py:66)
+        # tbx_sim_step / tbx_train_chain log the DEFAULT DifferentiableReward (rewards.py:35-85: SmoothL1 position / speed terms, a
+        # cosine SmoothL1 rotation term, no collision approximation); anything else would yield a plausible but wrong RolloutBuffer
+        rc = to_attr(dict(differentiable_reward))
+        if not rc.get("is_enabled", True) or rc.get("w_collision", 0) > 0 or not rc.get("use_il_loss", True):
+            raise NotImplementedError("differentiable_reward: only the default configuration (is_enabled, use_il_loss, w_collision = 0) "
+                                      "is implemented in the HIP state machine")
+        for term, ang in (("l_pos", None), ("l_rot", "cosine"), ("l_spd", None)):
+            t = rc[term]
+            if t.get("criterion", "SmoothL1Loss") != "SmoothL1Loss" or (ang is not None and t.get("angular_type", ang) != ang):
+                raise NotImplementedError(f"differentiable_reward.{term}: only SmoothL1Loss" + (" with angular_type=cosine" if ang else "") + " is implemented")
         pp = [(k, SceneCentricPreProcessing(time_step_current=time_step_current, data_size=data_size, **_strip_target(v)))
               for k, v in pre_processing.items()]
         kwargs = {"time_step_gt": time_step_gt}
@@ -71,6 +82,9 @@ class WaymoMotion(LightningModule):
         self.teacher_forcing_reactive_replay = TeacherForcing(**teacher_forcing_reactive_replay)
         self.teacher_forcing_joint_future_pred = TeacherForcing(**teacher_forcing_joint_future_pred)
         self._engine: Optional[RolloutEngine] = None
+        # which launches this module's hot path runs as (engine.Schedule): per module, not per process - e.g. a module with
+        # bfloat16 K/V tables beside an fp32 one. Callers may assign a new one before encode_scene / rollout.
+        self.schedule: Optional[engine.Schedule] = None
 
     @property
     def hp(self):
@@ -80,10 +94,11 @@ class WaymoMotion(LightningModule):
     def encode_scene(self, batch: Dict[str, Tensor], tl_valid_key: str = "sc/tl_valid", n_rollout: int = 1):
         """Map tokens + static traffic-light tokens (waymo_motion.py:316-323, 528-535). With n_rollout > 1 the
         traffic-light tokens are expanded per rollout while the map tokens stay shared (mp_batch_div)."""
-        mp = self.model.mp_encoder(batch["sc/mp_valid"], batch["sc/mp_attr"], batch["sc/mp_pose"], batch["ref/mp_type"])
-        r = lambda t: t.repeat_interleave(n_rollout, 0) if n_rollout > 1 else t
-        tl = self.model.tl_encoder.pre_compute(tl_valid=r(batch[tl_valid_key]), tl_attr=r(batch["sc/tl_attr"]),
-                                               tl_pose=r(batch["sc/tl_pose"]), mp_batch_div=n_rollout, **mp)
+        with engine.use(self.schedule):
+            mp = self.model.mp_encoder(batch["sc/mp_valid"], batch["sc/mp_attr"], batch["sc/mp_pose"], batch["ref/mp_type"])
+            r = lambda t: t.repeat_interleave(n_rollout, 0) if n_rollout > 1 else t
+            tl = self.model.tl_encoder.pre_compute(tl_valid=r(batch[tl_valid_key]), tl_attr=r(batch["sc/tl_attr"]),
+                                                   tl_pose=r(batch["sc/tl_pose"]), mp_batch_div=n_rollout, **mp)
         return mp, tl
 
     # ------------------------------------------------------------------ rollout
@@ -96,14 +111,14 @@ class WaymoMotion(LightningModule):
                              tl_state=tl_state_gt, current_epoch=self.current_epoch)
         dev = ag_tokens["gt_pose"].device
         rc = self.hparams.differentiable_reward
-        eng = RolloutEngine(self.model, self.dynamics, dev)
+        eng = RolloutEngine(self.model, self.dynamics, dev, schedule=self.schedule)
         eng.reset(gt_valid=ag_tokens["gt_valid"], gt_pose=ag_tokens["gt_pose"], gt_motion=ag_tokens["gt_motion"],
                   tl_state_gt=tl_state_gt, tf_mask=teacher_forcing.ag_teacher_forcing, ag_type=ag_tokens["ag_type"],
                   ag_attr=ag_tokens["ag_attr"], ag_latent=ag_tokens["ag_latent"], ag_latent_valid=ag_tokens["ag_latent_valid"],
                   ag_navi=ag_tokens["ag_navi"], ag_navi_valid=ag_tokens["ag_navi_valid"], mp_tokens=mp_tokens,
                   tl_tokens=tl_tokens, map_valid=rule_checker.mp_valid, map_type=rule_checker.mp_type,
                   map_pos=rule_checker.mp_pos, map_dir=rule_checker.mp_dir, map_boundary=rule_checker.mp_boundary,
-                  n_step=step_end, reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight) if rc.use_il_loss else (0, 0, 0),
+                  n_step=step_end, reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight),
                   ag_navi_log_prob=ag_tokens.get("ag_navi_log_prob"), stepwise=stepwise)
         self._engine = eng
         self.dynamics.bind(eng)
@@ -241,7 +256,8 @@ class WaymoMotion(LightningModule):
         are library GEMMs; see train_graph.py for what is (not yet) fused."""
         from .. import train_graph
 
-        out = train_graph.training_step(self, batch, noise=noise, use_prior=use_prior)
+        with engine.use(self.schedule):
+            out = train_graph.training_step(self, batch, noise=noise, use_prior=use_prior)
         for k, v in out.items():
             self.log(f"training/{k}", v, on_step=True)
         self.last_metrics = out

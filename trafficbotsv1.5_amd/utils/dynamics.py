@@ -38,6 +38,9 @@ class Dynamics:
     def _s(self, key: str) -> Tensor:
         if self._eng is None:
             raise RuntimeError("no rollout in progress: WaymoMotion.rollout / begin_rollout binds the simulation state")
+        if key not in self._eng.S:
+            raise RuntimeError(f"Dynamics.{key}: only a step-wise rollout keeps this per-step state "
+                               "(WaymoMotion.rollout(..., stepwise=True) / begin_rollout(..., stepwise=True))")
         return self._eng.S[key]
 
     ag_valid = property(lambda self: self._s("ag_valid").bool())
@@ -57,10 +60,16 @@ class Dynamics:
         m = self._s("tl_state")
         return ((m.to(torch.int32).unsqueeze(-1) >> torch.arange(5, device=m.device, dtype=torch.int32)) & 1).bool()
 
+    def _stepwise(self) -> None:
+        if self._eng is None or not self._eng.stepwise:
+            raise RuntimeError("disable_ag / disable_navi act on a step-wise rollout (the engine's own loop applies them on the device)")
+
     def disable_ag(self, traffic_rule_violation: Dict[str, Tensor], gt_valid: Optional[Tensor] = None) -> None:
         """dynamics.py:165-183."""
+        self._stepwise()
         self._eng.disable(outside=traffic_rule_violation["outside_map_this_step"], gt_valid=gt_valid)
 
     def disable_navi(self, traffic_rule_violation: Dict[str, Tensor]) -> None:
         """dynamics.py:185-204 (navi_mode dest)."""
+        self._stepwise()
         self._eng.disable(reached=traffic_rule_violation["dest_reached_this_step"])

@@ -19,7 +19,7 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor
 
-from .. import hip
+from .. import engine, hip
 from .buffer import RolloutBuffer
 
 
@@ -31,6 +31,18 @@ def _state_bits(one_hot: Tensor) -> Tensor:
     """[..., 5] one-hot bool -> u8 bit mask."""
     w = (1 << torch.arange(one_hot.shape[-1], device=one_hot.device, dtype=torch.int32))
     return (one_hot.to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+
+
+def _scheduled(fn):
+    """Run an engine method under the engine's own schedule (engine.use) and without autograd."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with engine.use(self.sched), torch.no_grad():
+            return fn(self, *a, **kw)
+
+    return wrapped
 
 
 def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
@@ -49,19 +61,8 @@ def lights_per_scene(tl_tokens: Dict[str, Tensor], k: int) -> Dict[str, Tensor]:
 
 
 class RolloutEngine:
-    TL_PREP_RIDES = os.environ.get("TBX_TL_PREP_RIDES", "1") != "0"  # tbx_tl_prep inside the lights' tbx_sim_step launch
-    lights_ahead = True  # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step), for tests
-    # steps per multi-step graph (even; 1: off). A replay boundary costs a few us of idle device: 4 -> 197.9 k, 16 -> 199.4 k, 40 ->
-    # 200.4 k agent-steps/s at the 64-agent scene. Capturing g steps costs g eager steps of host time, so the default suits an engine
-    # that runs ONE 80-step rollout (`WaymoMotion.rollout`); a caller that replays an engine many times raises it (bench.py: 40).
-    GRAPH_STEPS = max(1, int(os.environ.get("TBX_GRAPH_STEPS", "4")) // 2 * 2)
-    # The light recurrence (window -> light encoder -> argmax of the next-state logits, dynamics.py:143-163) reads no agent and
-    # no latent, so the K rollouts of a scene (joint_future_pred, waymo_motion.py:458-462) carry K identical copies of it: with
-    # share_lights the engine steps the lights once per scene and the agents of the K rollouts attend to that one copy
-    # (batch_div = K on the light K/V tables, like the map's). Same kernels on the same rows' inputs: bit-identical rollouts.
-    share_lights = True
-    hoist_constants = os.environ.get("TBX_NO_HOIST") is None  # False: the heads chain re-embeds the latent / destination feature every step (same values)
-
+    """`schedule` (engine.Schedule; default: the caller's current one) is fixed at construction and made current for every call
+    into the engine: two engines with different schedules (fp32 / bf16 tables, one / two streams) coexist in one process."""
     _streams: Dict[int, tuple] = {}
 
     @classmethod
@@ -74,13 +75,15 @@ class RolloutEngine:
             cls._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         return cls._streams[key]
 
-    def __init__(self, model, dynamics, device) -> None:
+    def __init__(self, model, dynamics, device, schedule: Optional[engine.Schedule] = None) -> None:
         self.model, self.dyn, self.dev = model, dynamics, device
+        self.sched = schedule if schedule is not None else engine.current()
+        self._graph_steps = 1  # steps per replay of graph_multi, fixed when it is captured
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graph_multi: Optional[torch.cuda.CUDAGraph] = None
 
     # ------------------------------------------------------------------ setup
-    @torch.no_grad()
+    @_scheduled
     def reset(self, *, gt_valid: Tensor, gt_pose: Tensor, gt_motion: Tensor, tl_state_gt: Tensor, tf_mask: Tensor,
               ag_type: Tensor, ag_attr: Tensor, ag_latent: Tensor, ag_latent_valid: Tensor, ag_navi: Tensor,
               ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
@@ -101,7 +104,7 @@ class RolloutEngine:
         self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
         # lights once per scene when the K = div rollouts of every scene were given identical lights (one host check per reset)
         kl = 1
-        if self.share_lights and not stepwise and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
+        if self.sched.share_lights and not stepwise and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
             g = tl_state_gt.reshape(n // div, div, *tl_state_gt.shape[1:])
             tv = tl_tokens["tl_token_valid"].reshape(n // div, div, L)
             tp = tl_tokens["tl_token_pose"].reshape(n // div, div, L, 3)
@@ -191,18 +194,20 @@ class RolloutEngine:
         self.side, self.aux = self._side_streams(dev)
         # per-rollout constants of the heads chain (embedded latent, destination feature): once, not every step
         self.consts = (self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div, latent_invalid=self.latent_invalid)
-                       if self.hoist_constants else None)
+                       if self.sched.hoist_constants else None)
         self._n_forward = 0
         if not stepwise:
             self._tl_ahead(0)
 
-    @torch.no_grad()
+    @_scheduled
     def restore(self) -> None:
         """Back to step 1 without re-allocating (pointers captured in the graph stay valid)."""
         for k, v in self.init_state.items():
             self.S[k].copy_(v)
         self.parity = 0
-        self._tl_ahead(0)
+        self._n_forward = 0
+        if not self.stepwise:
+            self._tl_ahead(0)
 
     def _tl_ahead(self, slot: int, prepared=None) -> None:
         """tl encoder on the current light window: logits for the next lights update, K/V tables (into buffer `slot`)
@@ -216,10 +221,10 @@ class RolloutEngine:
         self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out, prepared=prepared)
 
     # ------------------------------------------------------------------ stepping
-    @torch.no_grad()
+    @_scheduled
     def step(self) -> None:
         S, main = self.S, torch.cuda.current_stream()
-        if not self.lights_ahead:
+        if not self.sched.lights_ahead:
             self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6,
                                    S["ag_type_idx"], self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"],
                                    self.tl_tokens, self.mp_tokens, self.policy_out)
@@ -233,7 +238,7 @@ class RolloutEngine:
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             # logits of the previous tl encoder pass -> lights of this step (+ the one-hot rows of their new windows: tbx_sim_step_tl_prep)
-            if self.TL_PREP_RIDES:
+            if self.sched.tl_prep_rides:
                 if self._tl_prep is None:
                     hist = self.S["hist_tl"]
                     self._tl_prep = self.model.tl_encoder.prep_buffers(hist.shape[0], hist.shape[1], hist.device)
@@ -249,7 +254,7 @@ class RolloutEngine:
         hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
         self.parity = 1 - p
 
-    @torch.no_grad()
+    @_scheduled
     def capture(self) -> None:
         """Warm up one eager step, restore, then capture the step into hipGraphs (one per parity of the light-table
         double buffer; capturing executes nothing, so the state stays at the restored start)."""
@@ -257,26 +262,27 @@ class RolloutEngine:
         torch.cuda.synchronize()
         self.restore()
         graphs = []
-        for p in ((0, 1) if self.lights_ahead else (0,)):
+        for p in ((0, 1) if self.sched.lights_ahead else (0,)):
             self.parity = p
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.step()
             graphs.append(g)
-        # ... and GRAPH_STEPS consecutive steps as one graph (starting at parity 0): a replay boundary costs ~9 us of idle device
+        # ... and sched.graph_steps consecutive steps as one graph (starting at parity 0): a replay boundary costs ~9 us of idle device
         # (the next graph's first kernel starts that long after the last one's last), a kernel boundary inside a graph ~1 us
         self.graph_multi = None
-        if self.GRAPH_STEPS > 1:
+        self._graph_steps = max(1, int(self.sched.graph_steps) // 2 * 2) if self.sched.graph_steps > 1 else 1
+        if self._graph_steps > 1:
             self.parity = 0
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _ in range(self.GRAPH_STEPS):
+                for _ in range(self._graph_steps):
                     self.step()
             self.graph_multi = g
         self.parity = 0
         self.graph = graphs
 
-    @torch.no_grad()
+    @_scheduled
     def run(self, n_steps: Optional[int] = None, use_graph: bool = True) -> None:
         n_steps = self.T if n_steps is None else n_steps
         if use_graph and self.graph is None:
@@ -286,16 +292,16 @@ class RolloutEngine:
             if not use_graph:
                 self.step()
                 done += 1
-            elif self.graph_multi is not None and n_steps - done >= self.GRAPH_STEPS and self.parity % len(self.graph) == 0:
+            elif self.graph_multi is not None and n_steps - done >= self._graph_steps and self.parity % len(self.graph) == 0:
                 self.graph_multi.replay()  # an even number of steps: the parity is back where it was
-                done += self.GRAPH_STEPS
+                done += self._graph_steps
             else:
                 self.graph[self.parity % len(self.graph)].replay()
                 self.parity = 1 - self.parity
                 done += 1
 
     # ------------------------------------------------------------------ step-wise driving (WaymoMotion.forward)
-    @torch.no_grad()
+    @_scheduled
     def forward_step(self, ag_override: Dict[str, Tensor], tl_override: Dict[str, Tensor],
                      player_override: Optional[Dict[str, Tensor]] = None) -> int:
         """One `WaymoMotion.forward` (waymo_motion.py:118-204): append the current state to the windows (from the second call on:
