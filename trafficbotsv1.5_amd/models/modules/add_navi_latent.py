@@ -24,11 +24,11 @@ class AddNaviLatent(nn.Module):
         """mlp_in(z) alone -> out [rows, d]: for inputs that stay the same over a whole rollout (the latent) the engine evaluates
         this once and hands the result to `emit(..., z_embedded=...)` every step. With z_invalid (fixed over the rollout too) the
         validity mask is applied here, by the last stage - returns True if it was (`emit(..., z_premasked=True)`)."""
-        from ...engine import ROWZERO
+        from ...engine import current as _sched
         d = self.hidden_dim
         l_in = [t[0] for t in self.mlp_in.linear_layers()]
         pad = ((self.in_dim + 15) // 16) * 16
-        masked = z_invalid is not None and ROWZERO and ch.pack_weights
+        masked = z_invalid is not None and _sched().rowzero and ch.pack_weights
         ch.load(z, BUF0, 0, n=self.in_dim, pad_to=pad)
         ch.linear(BUF0, 0, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
@@ -43,10 +43,10 @@ class AddNaviLatent(nn.Module):
         """mlp_in(z) for z already in BUF0[:, d:2d] -> out [rows, d]: the same three stages as in `emit(z=None)`, for callers that
         evaluate them ahead of the chain that owns x (inference: no dropout between them). With z_invalid the validity mask is
         applied by the last stage (TBX_F_ROWZERO) - returns True if it was (`emit(..., z_premasked=True)` then skips its ROWMASK)."""
-        from ...engine import ROWZERO
+        from ...engine import current as _sched
         d = self.hidden_dim
         l_in = [t[0] for t in self.mlp_in.linear_layers()]
-        masked = z_invalid is not None and ROWZERO and ch.pack_weights
+        masked = z_invalid is not None and _sched().rowzero and ch.pack_weights
         ch.linear(BUF0, d, BUF0, 2 * d, l_in[0].weight, l_in[0].bias, relu=True)
         ch.linear(BUF0, 2 * d, BUF0, d, l_in[1].weight, l_in[1].bias, relu=True)
         if masked:
@@ -66,14 +66,14 @@ class AddNaviLatent(nn.Module):
         l_in, l_mlp = [t[0] for t in self.mlp_in.linear_layers()], [t[0] for t in self.mlp.linear_layers()]
         assert len(l_in) == 3 and len(l_mlp) == 3, "default n_layer = 3"
         if z_embedded is not None:
-            from ...engine import ROWZERO
+            from ...engine import current as _sched
             ch.load(z_embedded, BUF0, 2 * d, n=d)
             if not z_premasked:  # (the producer of z_embedded already zeroed the invalid rows)
                 ch.rowmask(BUF0, 2 * d, d, mask=z_invalid, valid_mask=mask_is_valid)
             ch.copy(BUF1, 0, BUF0, d, d)  # [x | z] at BUF0[:, d:3d]
             ch.linear(BUF0, d, BUF0, 3 * d, l_mlp[0].weight, l_mlp[0].bias, relu=True)
             ch.linear(BUF0, 3 * d, BUF0, 0, l_mlp[1].weight, l_mlp[1].bias, relu=True)
-            if ROWZERO and ch.pack_weights:  # the closing mask inside the last stage (relu, then 0 for the masked rows)
+            if _sched().rowzero and ch.pack_weights:  # the closing mask inside the last stage (relu, then 0 for the masked rows)
                 ch.linear(BUF0, 0, BUF0, 3 * d, l_mlp[2].weight, l_mlp[2].bias, relu=True, skip_rows=z_invalid,
                           skip_is_valid=mask_is_valid, zero_skipped=True)
             else:
