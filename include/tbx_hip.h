@@ -193,6 +193,41 @@ typedef struct tbx_dec_layer {
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * tbx_layer_tile: the row-local part of a transformer layer for LARGE launches (>= ~1000 rows; 16-row tiles, one launch) -
+ * what a tbx_rowchain program does between two attention launches, as one straight-line kernel whose LINEAR stages run on the
+ * split-bf16 matrix path (v_mfma_f32_16x16x32_bf16 on bf16 hi + lo halves of activations and weights, three products, fp32
+ * accumulation: error < 3e-5 of sum |x||w| per output; the tbx_rowchain / tbx_knarpe_dec_layer paths stay exact fp32).
+ * The three optional parts run in this order on the token rows x [n_rows, 128] (updated in place when store_x != 0):
+ *   attn_out != NULL   x += row_no_valid ? 0 : out_proj(sum a v + W_rpe_v (sum a e) + b_rpe_v), attn_out [n_rows, ld_attn >= 640]
+ *                      = tbx_knarpe_attn_fwd's output (attention_rpe.py:152,182-190; transformer_rpe.py:212-213,233)
+ *   linear1_image      x += linear2(relu(linear1(norm2 x))); x[src_invalid] = 0 (transformer_rpe.py:234-237,242)
+ *   proj_image         q [| k | v] = in_proj(proj_norm x), qt_h = W_rpe_k,h^T q_h of the next attention call (attention_rpe.py:92-98,
+ *                      147) -> proj_out [n_rows, ld_proj]: q | qt (proj_n = 128, ld_proj >= 640) or q | k | v | qt (proj_n = 384,
+ *                      ld_proj >= 896); with kv16_out the k | v columns go to that bfloat16 table [n_rows, 256] instead.
+ * Weights are tbx_pack_weight_mfma32 images: fold (groups 4, n 32, k 128: linear_rpe's value half), out_proj (128 x 128), linear1
+ * (512 x 128), linear2 (128 x 512), proj (proj_n x 128), qfold (linear_rpe.weight[0:128] transposed: groups 4, n 128, k 32, no bias). */
+#define TBX_MFMA32_UNIT_FLOATS 2064 /* a wave's unit of a tbx_pack_weight_mfma32 image: 4 x (1 KiB hi + 1 KiB lo) + 16 bias floats */
+typedef struct tbx_layer_tile {
+  float* x;
+  const float* attn_out;
+  const uint8_t* row_no_valid;
+  const float *fold_image, *out_proj_image;
+  const float *norm2_weight, *norm2_bias, *linear1_image, *linear2_image;
+  const uint8_t* src_invalid; /* or NULL */
+  const float *proj_norm_weight, *proj_norm_bias, *proj_image, *qfold_image;
+  float* proj_out;
+  void* kv16_out;             /* bfloat16 [n_rows, 256] or NULL */
+  float norm2_eps, proj_norm_eps;
+  int32_t ld_attn, ld_proj, proj_n, store_x;
+  int64_t n_rows;
+} tbx_layer_tile_t;
+int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
+/* Image for tbx_layer_tile of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32 or a multiple
+ * of 128, n % 16 == 0, (units) % 8 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
+int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups);
+int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
+
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)

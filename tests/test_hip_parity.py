@@ -648,3 +648,95 @@ def test_pooled_rows_kept_in_lds_feed_the_same_stages(hip, dev, tile, groups, gw
     assert torch.equal(pooled_a, pooled_b) and float(pooled_a[0].abs().max()) == 0.0
     assert torch.equal(out_a, out_b)
     assert torch.isfinite(out_a).all()
+
+
+@pytest.mark.parametrize("mode,S,Ks,T,K,n_layer,bf16", [("dec_cross_attn", 600, 12, 300, 40, 2, False), ("enc_self_attn", 1031, 16, 0, 0, 3, False),
+                                                       ("dec_cross_attn", 520, 9, 128, 24, 2, True)])
+def test_layer_tile_equals_row_chains(tb, hip, dev, mode, S, Ks, T, K, n_layer, bf16):
+    """tbx_layer_tile (large launches: a layer's row-local chains as straight-line 16-row tiles on the split-bf16 matrix path) through
+    engine.run_block vs the exact-fp32 tbx_rowchain schedule, transformer_rpe.py:207-245. Tolerance: the split drops < 3e-5 of
+    sum |x||w| per LINEAR output; over 2-3 layers the token rows agree to 2e-4 of their largest entry (the suite's fp32 tolerance).
+    Invalid source rows are exactly 0 on both paths; the ragged last tile (rows % 16 != 0) is covered."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    g = torch.Generator().manual_seed(S + n_layer)
+    blk = M.TransformerBlockRPE(n_layer=n_layer, mode=mode, d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.1,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 11)
+    blk = blk.to(dev).eval()
+    n, rows, D = 2, 2 * S, 128
+    x0 = torch.randn(rows, D, generator=g).to(dev)
+    src_invalid = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    x0[src_invalid.bool()] = 0.0
+
+    def knn(T_, K_):
+        rel = torch.cat([(torch.rand(n, S, K_, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K_, 1, generator=g) - 0.5) * 6], -1)
+        m = (torch.rand(n, S, K_, generator=g) < 0.3).to(torch.uint8).to(dev)
+        m[src_invalid.view(n, S).bool()] = 1
+        m[0, 3] = 1  # a valid source without any valid target: its attention update is skipped
+        return torch.randint(0, T_, (n, S, K_), generator=g).to(torch.int32).to(dev), m, rel.to(dev).contiguous()
+
+    i0, m0, r0 = knn(S, Ks)
+    cross = None
+    if mode == "dec_cross_attn":
+        ic, mc, rc = knn(T, K)
+        kv = torch.randn(n * T, n_layer * 256, generator=g).to(dev)
+        if bf16:
+            kv = kv.to(torch.bfloat16)
+        cross = lambda l: [hip.Seg(kv, l * 256, l * 256 + D, T, ic, mc, None, 1, rel=rc)]
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    outs = {}
+    for name, tile in (("chain", False), ("tile", True)):
+        x = x0.clone()
+        with eng.use(eng.DEFAULT.replace(tile_layer=tile, tile_min_rows=1024, kv_bf16=bf16, attn_fold_big=False)):
+            assert eng.tile_rows_ok(rows) == tile
+            eng.run_block(blk, x, src_invalid, n, S, eng.SelfKnn(i0, m0, rel=r0), cross=cross, pose_rpe=pe)
+        torch.cuda.synchronize()
+        outs[name] = x
+    ref, got = outs["chain"], outs["tile"]
+    assert torch.isfinite(ref).all() and float((ref - x0).abs().max()) > 1e-3
+    assert float(got[src_invalid.bool()].abs().max()) == 0.0 and float(ref[src_invalid.bool()].abs().max()) == 0.0
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= (2e-4 if not bf16 else 2e-3) * scale, (err, scale)  # (bf16 tables: the k | v rows are rounded to bf16 AFTER a slightly different fp32 value)
+    assert err > 0.0  # the two paths really are different arithmetic
+
+
+@pytest.mark.parametrize("n,k,groups,wt", [(128, 128, 1, False), (512, 128, 1, False), (128, 512, 1, False), (384, 128, 1, False),
+                                           (32, 128, 4, False), (128, 32, 4, True)])
+def test_pack_weight_mfma32_layout(hip, dev, n, k, groups, wt):
+    """The tbx_pack_weight_mfma32 image, decoded on the host by the layout rule of csrc/tile_layer.hip, gives back bf16 hi + lo
+    halves with hi + lo == w to 2^-16 relative, every (output channel, k) exactly once, and the bias per 16-channel tile."""
+    g = torch.Generator().manual_seed(n + k)
+    w = (torch.randn(groups * (k if wt else n), n if wt else k, generator=g)).to(dev)
+    bias = None if k == 32 else torch.randn(groups * n, generator=g).to(dev)
+    img = hip.packed_weight(w, bias, wt=wt, groups=groups, mfma32=True).cpu()
+    U = 2064
+    units = img.numel() // U
+    T = groups * n // 16
+    Wd = torch.zeros(groups * n, k)
+    seen = torch.zeros(groups * n, k)
+    wc = w.cpu()
+    for u in range(units):
+        blk = img[u * U:(u + 1) * U]
+        raw = blk[:2048].view(torch.int32).view(4, 2, 64, 4)  # group, hi/lo, lane, dword
+        lo16 = (raw & 0xFFFF).to(torch.int32)
+        hi16 = ((raw >> 16) & 0xFFFF).to(torch.int32)
+        el = torch.stack([lo16, hi16], -1).reshape(4, 2, 64, 8)  # 8 bf16 bit patterns per lane
+        val = (el << 16).view(torch.float32)
+        full = val[:, 0] + val[:, 1]  # hi + lo: [group, lane, 8]
+        for s in range(4):
+            tile, step = (u * 4 + s, 0) if k == 32 else (u % T, 4 * (u // T) + s)
+            for l in range(64):
+                oc = tile * 16 + (l & 15)
+                kk = step * 32 + (l >> 4) * 8
+                Wd[oc, kk:kk + 8] = full[s, l]
+                seen[oc, kk:kk + 8] += 1
+        if bias is not None:
+            torch.testing.assert_close(blk[2048:], bias.cpu()[(u % T) * 16:(u % T) * 16 + 16], rtol=0, atol=0)
+    assert bool((seen == 1).all())
+    ref = torch.zeros(groups * n, k)
+    for grp in range(groups):
+        ref[grp * n:(grp + 1) * n] = wc[grp * k:(grp + 1) * k].t() if wt else wc[grp * n:(grp + 1) * n]
+    assert float((Wd - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())

@@ -1,0 +1,456 @@
+// tbx_layer_tile: the row-local half of a transformer layer for LARGE launches (>= ~1000 rows), as ONE straight-line kernel per
+// chain of the three-launch schedule [attention -> chain -> attention -> chain] instead of a tbx_rowchain program:
+//   ATTN  x += rows without a valid target ? 0 : out_proj(sum a v + W_rpe_v (sum a e) + b)          attention_rpe.py:152,182-190
+//   FFN   x += linear2(relu(linear1(norm2 x))); x[invalid] = 0                                     transformer_rpe.py:234-237
+//   PROJ  q [| k | v] = in_proj(norm x), qt_h = W_rpe_k,h^T q_h of the NEXT attention call           attention_rpe.py:92-98,147
+// Why a kernel of its own: at 4096 rows a chain launch is 256 tiles of 16 rows = one workgroup per CU, every stage
+// a dependent step; the interpreter spends 2.9 us per 128x128 stage (1.3 us of it decode / epilogue / barrier, 1.6 us in 32
+// dependent exact-fp32 MFMAs) where the stage's weights (64 KiB per workgroup through a 64 B/clk L2 port: ~0.43 us) are the only
+// thing that cannot be avoided. Here:
+//   * LINEAR = split-bf16 on v_mfma_f32_16x16x32_bf16: x = x_hi + x_lo, w = w_hi + w_lo (bf16, RNE), three products hi*hi + hi*lo
+//     + lo*hi with fp32 accumulation (error < 3e-5 of sum |x||w|: lo*lo and the second-order residue are dropped) - 12 matrix
+//     instructions of ~17 cycles per 16x16x128 tile instead of 32 of 32-40 cycles;
+//   * activations are split ONCE, by whoever produces them (load, LayerNorm, a LINEAR epilogue), into bf16 hi / lo planes in LDS,
+//     laid out so that an MFMA operand is one conflict-free ds_read_b128;
+//   * the products are formed TRANSPOSED (D = W x^T: A operand = 16 output channels x 32 k of the weight image, B operand =
+//     32 k x 16 rows of activations): a lane ends up with 4 consecutive output channels of ONE row - one 8-byte LDS write per plane,
+//     one 16-byte global store - instead of 4 scattered elements;
+//   * weights come as a per-wave stream of 8 KiB units (tbx_pack_weight_mfma32: the fragments of [16 channels x 128 k] in register
+//     order), double-buffered in registers one unit ahead across stage boundaries;
+//   * no program to decode: the stage list is the template instantiation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define TBX_GLOBAL __attribute__((address_space(1)))
+
+constexpr int ROWS = 16, NWAVE = 8, NT = NWAVE * 64, D = 128;
+// bf16 planes: element (row, k) of a plane lives at byte  ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2:
+// the four 8-element octets of a 32-k step go to four regions (a multiple of 256 B apart, so the octet does not move the bank),
+// inside a region a row is PRS bytes with PRS / 16 odd: the 16 rows of an operand read land in 16 distinct 16-byte bank groups
+// whichever 16 lanes the LDS serves together (MI355X_MICROARCH.md, LDS: ds_read_b128 = 4 groups of 16 lanes).
+constexpr int PSTEPS = 20;                 // K <= 640 (the attention output: sum a v | sum a e of 4 heads)
+constexpr int PRS = 16 * (PSTEPS + 1);     // 336
+constexpr int PREG = ROWS * PRS;           // 5376 = 21 * 256
+constexpr int PLANE = 4 * PREG;            // 21504
+constexpr int XLD = 132;                   // floats per row of the fp32 buffers X (token rows) and Y (sum a v)
+constexpr int UNIT = TBX_MFMA32_UNIT_FLOATS;  // 2064 floats: 4 x (hi 1 KiB | lo 1 KiB) + 16 bias floats
+constexpr size_t LDS_BYTES = 2 * ROWS * XLD * sizeof(float) + 4 * PLANE;
+
+__device__ __forceinline__ int plane_off(int row, int k) { return ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2; }
+
+struct Entry {
+  const float* img;
+  int32_t unit0, pad;
+};
+
+struct TileArgs {
+  tbx_layer_tile_t t;
+  Entry ent[16];
+};
+
+// one wave's unit of weights: 4 groups of (hi, lo) A fragments + the tile's bias for the lane's 4 output channels
+struct W {
+  bf16x8 hi[4], lo[4];
+  f32x4 bias;
+};
+
+__device__ __forceinline__ void load_unit(W& w, const Entry& e, int wave, int lane) {
+  const TBX_GLOBAL float* base = (const TBX_GLOBAL float*)e.img + (int64_t)(e.unit0 + wave) * UNIT;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + lane * 4);
+    w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256 + lane * 4);
+  }
+  w.bias = *(const TBX_GLOBAL f32x4*)(base + 2048 + (lane >> 4) * 4);
+}
+
+struct Acc {
+  f32x4 hh, hl, lh;
+  __device__ __forceinline__ void zero() { hh = hl = lh = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ f32x4 sum() const { return hh + (hl + lh); }
+};
+
+// D[channel][row] += W[channel][k] x[row][k] over the 32 k of one step: A = weight fragment, B = activation fragment read from
+// the planes at `act` (= plane + the lane's (octet, row) offset) + step * 16
+__device__ __forceinline__ void mfma_step(Acc& a, const bf16x8 whi, const bf16x8 wlo, const char* act_hi, int step) {
+  const bf16x8 xh = *(const bf16x8*)(act_hi + step * 16);
+  const bf16x8 xl = *(const bf16x8*)(act_hi + PLANE + step * 16);
+  a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
+  a.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, a.hl, 0, 0, 0);
+  a.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, a.lh, 0, 0, 0);
+}
+
+// 4 fp32 values -> bf16 hi (RNE) and lo = bf16(v - hi), 8 bytes each
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  const bf16x4 h = __builtin_convertvector(v, bf16x4);
+  const f32x4 r = v - __builtin_convertvector(h, f32x4);
+  const bf16x4 l = __builtin_convertvector(r, bf16x4);
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+// the lane's 4 consecutive channels [c, c + 4) of row j into a plane pair (hi at p, lo at p + PLANE)
+__device__ __forceinline__ void planes_write4(char* p, int j, int c, const f32x4 v) {
+  u32x2 hi, lo;
+  split4(v, hi, lo);
+  const int o = plane_off(j, c);
+  *(u32x2*)(p + o) = hi;
+  *(u32x2*)(p + PLANE + o) = lo;
+}
+
+__device__ __forceinline__ f32x4 gld4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
+__device__ __forceinline__ void gst4(float* p, const f32x4 v) { *(TBX_GLOBAL f32x4*)p = v; }
+
+// LayerNorm_128 of row X[r] -> planes (k = 0..127), a wavefront per row, in rowchain.hip's ln_row order (bit-identical values
+// before the split)
+__device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int lane, const float* gamma, const float* beta, float eps) {
+  float v[2], gm[2], bt[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    v[q] = X[r * XLD + lane + 64 * q];
+    gm[q] = *(const TBX_GLOBAL float*)(gamma + lane + 64 * q);
+    bt[q] = *(const TBX_GLOBAL float*)(beta + lane + 64 * q);
+  }
+  const float mean = tbx::wave_sum(v[0] + v[1]) / 128.f;
+  const float d0 = v[0] - mean, d1 = v[1] - mean;
+  const float var = tbx::wave_sum(d0 * d0 + d1 * d1) / 128.f;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float y = (v[q] - mean) * rstd * gm[q] + bt[q];
+    const __bf16 h = (__bf16)y;
+    const __bf16 l = (__bf16)(y - (float)h);
+    const int o = plane_off(r, lane + 64 * q);
+    *(__bf16*)(P + o) = h;
+    *(__bf16*)(P + PLANE + o) = l;
+  }
+}
+
+template <bool ATTN, bool FFN, int PROJ>
+__global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* X = lds;
+  float* Y = X + ROWS * XLD;
+  char* Pa = (char*)(Y + ROWS * XLD);
+  char* Pb = Pa + 2 * PLANE;
+  const tbx_layer_tile_t& t = a.t;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int nv = (t.n_rows - row0) < ROWS ? (int)(t.n_rows - row0) : ROWS;
+  const bool row_ok = j < nv;
+  const int64_t grow = row0 + (row_ok ? j : 0);
+  const int aoff = g * PREG + j * PRS;  // the lane's (octet, row) offset inside a plane
+  const int c_out = 16 * wave + 4 * g;  // the lane's 4 output channels of a 128-wide stage
+
+  constexpr int E_FOLD = 0, E_OUT = 1, E_L1 = ATTN ? 2 : 0, E_L2 = E_L1 + 4, E_Q = (ATTN ? 2 : 0) + (FFN ? 8 : 0);
+  constexpr int E_KV = E_Q + 1, E_QF = E_Q + (PROJ == 2 ? 3 : 1), E_END = E_Q + (PROJ == 2 ? 4 : (PROJ == 1 ? 2 : 0));
+  W wb[2];
+  load_unit(wb[0], a.ent[0], wave, lane);
+#define TBX_NEXT(E)                                                          \
+  do {                                                                       \
+    if constexpr ((E) + 1 < E_END) load_unit(wb[((E) + 1) & 1], a.ent[(E) + 1], wave, lane); \
+  } while (0)
+
+  uint8_t f_nov = 0, f_inv = 0;
+  if (ATTN) f_nov = *(const TBX_GLOBAL uint8_t*)(t.row_no_valid + grow);
+  if (FFN && t.src_invalid != nullptr) f_inv = *(const TBX_GLOBAL uint8_t*)(t.src_invalid + grow);
+
+  // ---- the tile's token rows (and the attention output, split into planes; its first 128 columns also as fp32: the fold's addend)
+  {
+    const int r = tid >> 5, c4 = tid & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < nv) v = gld4(t.x + (row0 + r) * D + c4 * 4);
+    *(f32x4*)(X + r * XLD + c4 * 4) = v;
+  }
+  if constexpr (ATTN) {
+    f32x4 v[5];
+    int rr[5], cc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int f = tid + NT * i;  // 16 rows x 160 float4
+      rr[i] = f / 160;
+      cc[i] = f - rr[i] * 160;
+      v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rr[i] < nv) v[i] = gld4(t.attn_out + (row0 + rr[i]) * (int64_t)t.ld_attn + cc[i] * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      planes_write4(Pa, rr[i], cc[i] * 4, v[i]);
+      if (cc[i] < 32) *(f32x4*)(Y + rr[i] * XLD + cc[i] * 4) = v[i];
+    }
+  }
+  __syncthreads();
+
+  if constexpr (ATTN) {
+    {  // value half of linear_rpe: y_h = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_h; wave w = head w / 2, 16 of its 32 channels
+      TBX_NEXT(E_FOLD);
+      const W& w = wb[E_FOLD & 1];
+      Acc acc;
+      acc.zero();
+      const int step0 = 4 + 4 * (wave >> 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, step0 + s);
+      const f32x4 y = acc.sum() + w.bias + *(const f32x4*)(Y + j * XLD + c_out);
+      planes_write4(Pb, j, c_out, y);
+    }
+    __syncthreads();
+    {  // x += row without a valid target ? 0 : out_proj(y)
+      TBX_NEXT(E_OUT);
+      const W& w = wb[E_OUT & 1];
+      Acc acc;
+      acc.zero();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, s);
+      f32x4 xv = *(const f32x4*)(X + j * XLD + c_out);
+      if (!f_nov) xv += acc.sum() + w.bias;
+      *(f32x4*)(X + j * XLD + c_out) = xv;
+      if (!FFN && t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
+    }
+    __syncthreads();
+  }
+
+  if constexpr (FFN) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.norm2_weight, t.norm2_bias, t.norm2_eps);
+    __syncthreads();
+    // h = relu(linear1(.)): 4 rounds of 128 channels
+#define TBX_L1(R)                                                                               \
+  do {                                                                                          \
+    TBX_NEXT(E_L1 + (R));                                                                       \
+    const W& w = wb[(E_L1 + (R)) & 1];                                                          \
+    Acc acc;                                                                                    \
+    acc.zero();                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    f32x4 h = acc.sum() + w.bias;                                                               \
+    h[0] = fmaxf(h[0], 0.f), h[1] = fmaxf(h[1], 0.f), h[2] = fmaxf(h[2], 0.f), h[3] = fmaxf(h[3], 0.f); \
+    planes_write4(Pb, j, (R) * D + c_out, h);                                                   \
+  } while (0)
+    TBX_L1(0);
+    TBX_L1(1);
+    TBX_L1(2);
+    TBX_L1(3);
+#undef TBX_L1
+    __syncthreads();
+    {  // x += linear2(h): K = 512 in 4 units into one accumulator triple; x[invalid] = 0
+      Acc acc;
+      acc.zero();
+      f32x4 bias;
+#define TBX_L2(R)                                                                                         \
+  do {                                                                                                    \
+    TBX_NEXT(E_L2 + (R));                                                                                 \
+    const W& w = wb[(E_L2 + (R)) & 1];                                                                    \
+    if ((R) == 0) bias = w.bias;                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
+  } while (0)
+      TBX_L2(0);
+      TBX_L2(1);
+      TBX_L2(2);
+      TBX_L2(3);
+#undef TBX_L2
+      f32x4 xv = *(const f32x4*)(X + j * XLD + c_out) + (acc.sum() + bias);
+      if (f_inv) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(X + j * XLD + c_out) = xv;
+      if (t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
+    }
+    __syncthreads();
+  }
+
+  if constexpr (PROJ != 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.proj_norm_weight, t.proj_norm_bias, t.proj_norm_eps);
+    __syncthreads();
+    {  // q
+      TBX_NEXT(E_Q);
+      const W& w = wb[E_Q & 1];
+      Acc acc;
+      acc.zero();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s);
+      const f32x4 q = acc.sum() + w.bias;
+      planes_write4(Pb, j, c_out, q);
+      if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + c_out, q);
+    }
+    if constexpr (PROJ == 2) {  // k | v: straight to the table (fp32 columns [128, 384) of proj_out, or the bfloat16 table)
+#define TBX_KV(R)                                                                               \
+  do {                                                                                          \
+    TBX_NEXT(E_KV + (R));                                                                       \
+    const W& w = wb[(E_KV + (R)) & 1];                                                          \
+    Acc acc;                                                                                    \
+    acc.zero();                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    const f32x4 kv = acc.sum() + w.bias;                                                        \
+    if (row_ok) {                                                                               \
+      if (t.kv16_out != nullptr) {                                                              \
+        const bf16x4 h = __builtin_convertvector(kv, bf16x4);                                   \
+        *(TBX_GLOBAL u32x2*)((TBX_GLOBAL uint16_t*)t.kv16_out + grow * 256 + (R) * D + c_out) = __builtin_bit_cast(u32x2, h); \
+      } else {                                                                                  \
+        gst4(t.proj_out + grow * (int64_t)t.ld_proj + D + (R) * D + c_out, kv);                 \
+      }                                                                                         \
+    }                                                                                           \
+  } while (0)
+      TBX_KV(0);
+      TBX_KV(1);
+#undef TBX_KV
+    }
+    __syncthreads();
+    {  // qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (one step, the head's own)
+      TBX_NEXT(E_QF);
+      const W& w = wb[E_QF & 1];
+      const int h = wave >> 1;
+      const int qt_off = PROJ == 2 ? 3 * D : D;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Acc acc;
+        acc.zero();
+        mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, h);
+        const f32x4 v = acc.sum();
+        if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + qt_off + h * D + ((wave & 1) * 4 + s) * 16 + 4 * g, v);
+      }
+    }
+  }
+#undef TBX_NEXT
+}
+
+// tbx_pack_weight_mfma32 image of W_g [n x k] (g < groups; [k x n] with wt): T = groups * n / 16 tiles of 16 output channels.
+//   k % 128 == 0: unit u = (tile u % T, k-chunk u / T of 128): group s = k-step 4 * chunk + s of that tile, bias = the tile's;
+//   k == 32:      unit u = tiles 4u .. 4u + 3, group s = tile 4u + s (its one k-step); no bias.
+// A group = [64 lanes x 8 bf16 hi][64 lanes x 8 bf16 lo]: lane l, element e = W[tile * 16 + (l & 15)][step * 32 + (l >> 4) * 8 + e].
+__global__ void pack_mfma32_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld, int groups, int wt,
+                                   float* __restrict__ out, int64_t total) {
+  const int T = groups * n / 16;
+  uint16_t* o16 = (uint16_t*)out;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = e / UNIT;
+    const int f = (int)(e - u * UNIT);
+    if (f >= 2048) {  // bias floats
+      const int i = f - 2048;
+      float b = 0.f;
+      if (k != 32 && bias != nullptr) b = bias[(int)(u % T) * 16 + i];
+      out[e] = b;
+      continue;
+    }
+    // float slot f of the unit's 8 KiB: group s, half (hi / lo), lane l, dword q of the lane's 16 bytes (elements 2q, 2q + 1)
+    const int s = f >> 9, half = (f >> 8) & 1, l = (f >> 2) & 63, q = f & 3;
+    int tile, step;
+    if (k == 32) {
+      tile = (int)u * 4 + s;
+      step = 0;
+    } else {
+      tile = (int)(u % T);
+      step = 4 * (int)(u / T) + s;
+    }
+    const int oc = tile * 16 + (l & 15);
+    const int grp = oc / n, col = oc - grp * n;
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      const int kk = step * 32 + (l >> 4) * 8 + 2 * q + z;
+      const float v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+      const __bf16 hi = (__bf16)v;
+      const __bf16 x = half ? (__bf16)(v - (float)hi) : hi;
+      bits |= (uint32_t)__builtin_bit_cast(unsigned short, x) << (16 * z);
+    }
+    out[e] = __uint_as_float(bits);
+    (void)o16;
+  }
+}
+
+int64_t mfma32_units(int n, int k, int groups) {
+  if (n <= 0 || k <= 0 || groups <= 0 || n % 16 != 0) return TBX_ERR_UNSUPPORTED;
+  const int64_t T = (int64_t)groups * n / 16;
+  if (k == 32) return T % 4 == 0 ? T / 4 : TBX_ERR_UNSUPPORTED;
+  if (k % 128 != 0) return TBX_ERR_UNSUPPORTED;
+  return T * (k / 128);
+}
+
+template <bool ATTN, bool FFN, int PROJ>
+int launch(const TileArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)tile_layer_kernel<ATTN, FFN, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
+      return TBX_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((a.t.n_rows + ROWS - 1) / ROWS);
+  hipLaunchKernelGGL((tile_layer_kernel<ATTN, FFN, PROJ>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups) {
+  const int64_t u = mfma32_units(n, k, groups);
+  return u < 0 ? u : u * UNIT;
+}
+
+extern "C" int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out,
+                                      void* stream) {
+  if (w == nullptr || out == nullptr || ld <= 0) return TBX_ERR_ARG;
+  const int64_t total = tbx_pack_weight_mfma32_size(n, k, groups);
+  if (total < 0) return (int)total;
+  if ((total / UNIT) % NWAVE != 0) return TBX_ERR_UNSUPPORTED;  // a round = one unit per wave
+  if (k == 32 && bias != nullptr) return TBX_ERR_UNSUPPORTED;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_mfma32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out, total);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
+  if (args == nullptr || args->x == nullptr || args->n_rows <= 0) return TBX_ERR_ARG;
+  const tbx_layer_tile_t& t = *args;
+  const bool attn = t.attn_out != nullptr, ffn = t.linear1_image != nullptr;
+  const int proj = t.proj_image == nullptr ? 0 : (t.proj_n == 3 * D ? 2 : (t.proj_n == D ? 1 : -1));
+  if (proj < 0 || (!attn && !ffn && proj == 0)) return TBX_ERR_ARG;
+  if (attn && (t.row_no_valid == nullptr || t.fold_image == nullptr || t.out_proj_image == nullptr || t.ld_attn < 5 * D || t.ld_attn % 4 != 0))
+    return TBX_ERR_ARG;
+  if (ffn && (t.linear2_image == nullptr || t.norm2_weight == nullptr || t.norm2_bias == nullptr)) return TBX_ERR_ARG;
+  if (proj && (t.qfold_image == nullptr || t.proj_norm_weight == nullptr || t.proj_norm_bias == nullptr || t.proj_out == nullptr ||
+               t.ld_proj < (proj == 2 ? 7 * D : 5 * D) || t.ld_proj % 4 != 0))
+    return TBX_ERR_ARG;
+  if (t.kv16_out != nullptr && proj != 2) return TBX_ERR_ARG;
+  if ((((uintptr_t)t.x) | ((uintptr_t)t.attn_out) | ((uintptr_t)t.proj_out)) & 15) return TBX_ERR_ALIGN;
+  TileArgs a;
+  a.t = t;
+  int e = 0;
+  auto put = [&](const float* img, int unit0) {
+    a.ent[e].img = img, a.ent[e].unit0 = unit0, a.ent[e].pad = 0;
+    ++e;
+  };
+  if (attn) put(t.fold_image, 0), put(t.out_proj_image, 0);
+  if (ffn) {
+    for (int r = 0; r < 4; ++r) put(t.linear1_image, 8 * r);
+    for (int r = 0; r < 4; ++r) put(t.linear2_image, 8 * r);
+  }
+  if (proj) {
+    put(t.proj_image, 0);
+    if (proj == 2) put(t.proj_image, 8), put(t.proj_image, 16);
+    put(t.qfold_image, 0);
+  }
+  for (; e < 16; ++e) a.ent[e].img = nullptr, a.ent[e].unit0 = 0, a.ent[e].pad = 0;
+  hipStream_t s = (hipStream_t)stream;
+#define TBX_TL(A, F, P) \
+  if (attn == A && ffn == F && proj == P) return launch<A, F, P>(a, s)
+  TBX_TL(true, false, 1);   // after the self attention of a decoder layer: out_proj -> q | qt of the cross attention
+  TBX_TL(true, true, 2);    // after the (cross) attention: out_proj -> FFN -> the next layer's q | k | v | qt
+  TBX_TL(true, true, 0);    // ... of the last layer
+  TBX_TL(false, false, 2);  // the first projection
+  TBX_TL(false, false, 1);
+  TBX_TL(true, false, 2);
+  TBX_TL(true, false, 0);
+#undef TBX_TL
+  return TBX_ERR_UNSUPPORTED;
+}

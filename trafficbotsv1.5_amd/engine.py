@@ -69,6 +69,10 @@ class Schedule:
     # LINEAR stages of MFMA row chains (launches past live_max rows) on the split-bf16 matrix path: activations and weights as bf16
     # hi + lo, three products per k on the bf16 MFMA (< 3e-5 of sum |x||w|; tests/test_hip_parity.py)
     split_bf16: bool = False
+    # launches past live_max rows (no keyed dropout): a layer's row-local chains as tbx_layer_tile launches - straight-line 16-row
+    # tiles, LINEAR on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) - instead of tbx_rowchain programs (exact fp32)
+    tile_layer: bool = True
+    tile_min_rows: int = 1024
     pe_rides: bool = True       # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
     # ---- RolloutEngine
     tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
@@ -91,7 +95,8 @@ class Schedule:
                    masked_groupmax=on("TBX_MASKED_GROUPMAX"), big_rows=int(_env("TBX_BIG_ROWS", "16384")),
                    live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
                    kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
-                   split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
+                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
                    graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
 
     def replace(self, **kw) -> "Schedule":
@@ -350,6 +355,32 @@ def emit_first_proj(ch: Chain, block, fp: dict, x_buf: int) -> None:
     emit_proj(ch, 0, l0.norm_src if dec else l0.norm1, l0.attn_src if dec else l0.attn, fp["qkv"], with_kv=True, kv16=fp["kv16"], x_buf=x_buf)
 
 
+def tile_rows_ok(rows: int) -> bool:
+    """Launches whose row-local chains run as tbx_layer_tile (inference, past the live-row sizes)."""
+    c = current()
+    return c.tile_layer and DROP_CTX is None and not live_rows_for(rows) and rows >= c.tile_min_rows and not c.attn_fold_big
+
+
+def _img(w, b=None, **kw):
+    return hip.packed_weight(w, b, mfma32=True, **kw)
+
+
+def tile_attn_part(attn, obuf, flag) -> dict:
+    return dict(out=obuf, row_no_valid=flag, fold=_img(attn.linear_rpe.weight[D:], attn.linear_rpe.bias[D:], groups=NH),
+                out_proj=_img(attn.out_proj_weight, attn.out_proj_bias))
+
+
+def tile_ffn_part(layer, src_invalid) -> dict:
+    return dict(norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), linear1=_img(layer.linear1.weight, layer.linear1.bias),
+                linear2=_img(layer.linear2.weight, layer.linear2.bias), src_invalid=src_invalid)
+
+
+def tile_proj_part(norm, attn, out, with_kv: bool, kv16=None) -> dict:
+    nq = 3 * D if with_kv else D
+    return dict(norm=(norm.weight, norm.bias, norm.eps), image=_img(attn.in_proj_weight[:nq], attn.in_proj_bias[:nq]),
+                qfold=_img(attn.linear_rpe.weight[:D], None, wt=True, groups=NH), n=nq, out=out, kv16=kv16)
+
+
 class SelfKnn:
     """KNN set among the source tokens themselves: idx i32 / invalid u8 [n,S,K] and either the materialised pose embedding
     emb f32 [n,S,K,128] or the relative pose rel f32 [n,S,K,3] (embedding rebuilt inside the attention kernel)."""
@@ -411,7 +442,10 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     def first_norm(l):
         return layers[l].norm_src if dec else layers[l].norm1
 
-    if first_proj is None:
+    tile = drop is None and tile_rows_ok(rows)
+    if first_proj is None and tile:
+        hip.layer_tile(x, proj=tile_proj_part(first_norm(0), first_attn(0), qkv, True, kv16), store_x=False)
+    elif first_proj is None:
         ch = layer_chain(rows)
         ch.load(x, BUF1, 0, n=D)
         emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
@@ -478,6 +512,21 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             continue
         hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1),
                         fold=attn_fold_image(a1) if fold else None)
+        if tile:  # the layer's row-local chains as tbx_layer_tile launches (split-bf16 MFMA stages, no program to interpret)
+            a_last = a1
+            if dec:
+                hip.layer_tile(x, attn=tile_attn_part(a1, obuf, flag), proj=tile_proj_part(layer.norm1, layer.attn, q2, False))
+                hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw)
+                a_last = layer.attn
+            last = l + 1 == len(layers)
+            hip.layer_tile(x, attn=tile_attn_part(a_last, obuf, flag), ffn=tile_ffn_part(layer, src_invalid),
+                           proj=None if last else tile_proj_part(first_norm(l + 1), first_attn(l + 1), qkv, True, kv16))
+            if last and tail is not None:  # the caller's row-local stages on the finished rows: a short chain of their own
+                ch = layer_chain(rows)
+                ch.load(x, BUF1, 0, n=D)
+                tail(ch)
+                ch.run(rows)
+            continue
         ch = layer_chain(rows)
         emit_attn_out(ch, a1, obuf, flag, drop=next_site(), x=x)
         if dec:

@@ -79,6 +79,15 @@ class DecLayer(C.Structure):
                 + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("pad_", C.c_int32)])
 
 
+class LayerTile(C.Structure):
+    """tbx_layer_tile_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("x", "attn_out", "row_no_valid", "fold_image", "out_proj_image", "norm2_weight", "norm2_bias",
+                                           "linear1_image", "linear2_image", "src_invalid", "proj_norm_weight", "proj_norm_bias", "proj_image",
+                                           "qfold_image", "proj_out", "kv16_out")]
+                + [("norm2_eps", C.c_float), ("proj_norm_eps", C.c_float)]
+                + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)])
+
+
 class SimState(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
@@ -189,6 +198,10 @@ def load():
     lib.tbx_pack_weight_gemv_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_gemv_size.restype = C.c_int64
     lib.tbx_pack_weight_gemv.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_layer_tile.argtypes = [C.POINTER(LayerTile), vp]
+    lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
+    lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
+    lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_rowchain_live.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
@@ -203,7 +216,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -579,6 +592,38 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
+def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True):
+    """tbx_layer_tile on the token rows x [rows, 128] (in place). Each part is None or a dict:
+    attn = dict(out [rows, >= 640], row_no_valid u8 [rows], fold, out_proj (mfma32 images));
+    ffn = dict(norm2 (w, b, eps), linear1, linear2 (images), src_invalid u8 [rows] | None);
+    proj = dict(norm (w, b, eps), image, qfold (images), n = 128 | 384, out [rows, >= 640 | 896], kv16 = bf16 [rows, 256] | None)."""
+    a = LayerTile()
+    a.x, a.n_rows, a.store_x = _cptr(x, torch.float32), x.shape[0], int(store_x)
+    assert x.dim() == 2 and x.shape[1] == 128
+    if attn is not None:
+        o = attn["out"]
+        assert o.dim() == 2 and o.stride(1) == 1 and o.shape[0] == x.shape[0]
+        a.attn_out, a.ld_attn, a.row_no_valid = _ptr(o, torch.float32), o.stride(0), _cptr(attn["row_no_valid"], torch.uint8)
+        a.fold_image, a.out_proj_image = _ptr(attn["fold"], torch.float32), _ptr(attn["out_proj"], torch.float32)
+    if ffn is not None:
+        w, b, eps = ffn["norm2"]
+        a.norm2_weight, a.norm2_bias, a.norm2_eps = _cptr(w, torch.float32), _cptr(b, torch.float32), float(eps)
+        a.linear1_image, a.linear2_image = _ptr(ffn["linear1"], torch.float32), _ptr(ffn["linear2"], torch.float32)
+        a.src_invalid = _cptr(ffn.get("src_invalid"), torch.uint8)
+    if proj is not None:
+        w, b, eps = proj["norm"]
+        a.proj_norm_weight, a.proj_norm_bias, a.proj_norm_eps = _cptr(w, torch.float32), _cptr(b, torch.float32), float(eps)
+        a.proj_image, a.qfold_image, a.proj_n = _ptr(proj["image"], torch.float32), _ptr(proj["qfold"], torch.float32), int(proj["n"])
+        o = proj["out"]
+        assert o.dim() == 2 and o.stride(1) == 1 and o.shape[0] == x.shape[0]
+        a.proj_out, a.ld_proj = _ptr(o, torch.float32), o.stride(0)
+        kv16 = proj.get("kv16")
+        if kv16 is not None:
+            assert kv16.shape == (x.shape[0], 256) and kv16.is_contiguous()
+            a.kv16_out = _ptr(kv16, torch.bfloat16)
+    _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
+
+
 def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):
     """Inverse lists of a K-nearest set idx / invalid [n_batch, n_src, k] -> (inv_ptr [n_tables, n_tgt+1], inv_list [n_tables, cap])."""
     n, S, k = idx.shape
@@ -736,16 +781,17 @@ PACK_SCOPE: Optional[dict] = None
 
 
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
-                  split: bool = False, gemv: bool = False) -> torch.Tensor:
+                  split: bool = False, gemv: bool = False, mfma32: bool = False) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
     per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused
     otherwise - chains are rebuilt every eager step - and dropped with the parameter.
     split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT.
-    gemv=True: the tbx_pack_weight_gemv image (column streams) for the F_WGEMV stages of live-row chains."""
+    gemv=True: the tbx_pack_weight_gemv image (column streams) for the F_WGEMV stages of live-row chains.
+    mfma32=True: the tbx_pack_weight_mfma32 image (per-wave units of bf16 hi + lo fragments) for tbx_layer_tile."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
     base = w._base if w._base is not None else w
     bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv)
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv, mfma32)
     if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
         cache, key = PACK_SCOPE, (id(base),) + key
         PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
@@ -759,11 +805,11 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     if bias is not None:
         assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n
     lib = load()
-    size = (lib.tbx_pack_weight_gemv_size if gemv else lib.tbx_pack_weight_size)(n, k, groups)
+    size = (lib.tbx_pack_weight_mfma32_size if mfma32 else (lib.tbx_pack_weight_gemv_size if gemv else lib.tbx_pack_weight_size))(n, k, groups)
     if size <= 0:
         _check(int(size), "tbx_pack_weight_size")
     out = torch.empty(size, dtype=torch.float32, device=w.device)
-    fn = lib.tbx_pack_weight_gemv if gemv else (lib.tbx_pack_weight_split if split else lib.tbx_pack_weight)
+    fn = lib.tbx_pack_weight_mfma32 if mfma32 else (lib.tbx_pack_weight_gemv if gemv else (lib.tbx_pack_weight_split if split else lib.tbx_pack_weight))
     _check(fn(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
     cache[key] = (stamp, out)
     return out
