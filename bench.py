@@ -103,7 +103,7 @@ def pmc_traffic(args, prefixes):
             continue
         if bool(w.get("kv_bf16", False)) != bool(args.kv_bf16):
             continue
-        hits = [(v.get("launches", 0), k, v) for k, v in d.get("kernels", {}).items() if "<" in k and any(k.startswith(p) for p in prefixes)]
+        hits = [(v.get("launches", 0), k, v) for k, v in d.get("kernels", {}).items() if ("<" in k or k in prefixes) and any(k.startswith(p) for p in prefixes)]
         if hits:
             _, k, v = max(hits)
             return v["traffic_bytes_per_launch"], Path(f).name, k
@@ -159,7 +159,7 @@ class KernelEvents:
     def __enter__(self):
         hip, T = self.hip, self._time
         sv = self._saved = {n: getattr(hip, n) for n in ("knarpe_attn", "knarpe_dec_mid", "knn_embed", "knn_embed_multi", "agent_prep",
-                                                         "tl_prep", "sim_step", "pose_embed")}
+                                                         "tl_prep", "sim_step", "pose_embed", "layer_tile", "heads_tile", "window_tile")}
         sv["Chain.run"] = hip.Chain.run
 
         def mid(*args, **kw):
@@ -187,10 +187,25 @@ class KernelEvents:
                 return T("chain_live", 0, fl, sv["Chain.run"], ch, n_rows, group_rows)
             return T("chain", ch.tile_rows, fl, sv["Chain.run"], ch, n_rows, group_rows)
 
+        def lt(x, attn=None, ffn=None, proj=None, store_x=True):
+            rows = x.shape[0]
+            mac = (2 * 128 * 128 if attn is not None else 0) + (2 * 128 * 512 if ffn is not None else 0)
+            if proj is not None:
+                mac += 128 * proj["n"] + 128 * 128
+            return T("tile", "layer", 2.0 * rows * mac, sv["layer_tile"], x, attn=attn, ffn=ffn, proj=proj, store_x=store_x)
+
+        def ht(x, hd):
+            return T("tile", "heads", 2.0 * x.shape[0] * (2 * (256 * 128 + 2 * 128 * 128) + 128 * 384 + 3 * 128 * 128 + 3 * 128 * 16), sv["heads_tile"], x, hd)
+
+        def wt(attr, pe, row_invalid, in_images, pn_images, window, out):
+            return T("tile", "window", 2.0 * attr.shape[0] * (32 * 64 + 2 * 64 * 64 + 3 * 128 * 64), sv["window_tile"], attr, pe, row_invalid, in_images,
+                     pn_images, window, out)
+
         def other(name):
             return lambda *a, **kw: T("other", name, 0.0, sv[name], *a, **kw)
 
         hip.knarpe_attn, hip.Chain.run, hip.knarpe_dec_mid = attn, run, mid
+        hip.layer_tile, hip.heads_tile, hip.window_tile = lt, ht, wt
         for n in ("knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed"):
             setattr(hip, n, other(n))
         return self
@@ -233,13 +248,17 @@ def kernel_entry(args, c):
         if cls == "dec_layer" or key < 1024:
             e["note"] = ("latency-bound at this size: a launch has one workgroup per source row (64-128 of them on 256 CUs) and the "
                          "step is a chain of dependent launches; frac is bytes over time, not a bandwidth-limited figure")
-    elif cls in ("chain", "chain_live"):
+    elif cls in ("chain", "chain_live", "tile"):
         ach = c["work"] / c["t"] / 1e12
-        name = "rowchain_kernel"
-        pre = ["rowchain_kernel<0,1,0,1>"] if cls == "chain_live" else [f"rowchain_kernel<{key // 16},"]
-        e.update(kernel=name + ("<live>" if cls == "chain_live" else f"<{key}-row tiles>"), bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TF,
+        if cls == "tile":
+            name, pre = f"tile_{key}_kernel", [f"tile_{key}_kernel"]
+        else:
+            name = "rowchain_kernel" + ("<live>" if cls == "chain_live" else f"<{key}-row tiles>")
+            pre = ["rowchain_kernel<0,1,0,1>"] if cls == "chain_live" else [f"rowchain_kernel<{key // 16},"]
+        e.update(kernel=name, bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TF,
                  unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TF, flops_per_launch=c["work"] / c["n"],
-                 peak_note="dense fp32 MFMA peak (the exact-fp32 parity arithmetic; split-bf16 stages are priced against the same fp32 peak)")
+                 peak_note="dense fp32 MFMA peak: the work is fp32 LINEAR stages (exact-fp32 MFMA in the row chains; the tile kernels form "
+                           "each fp32 product from three bf16 MFMA products, priced against the same fp32 peak, not the bf16 one)")
     else:
         e.update(kernel=f"tbx_{key}", bound="latency", achieved=None, peak=None, unit=None, frac=None)
         return e

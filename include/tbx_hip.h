@@ -207,7 +207,7 @@ int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
  *                      ld_proj >= 896); with kv16_out the k | v columns go to that bfloat16 table [n_rows, 256] instead.
  * Weights are tbx_pack_weight_mfma32 images: fold (groups 4, n 32, k 128: linear_rpe's value half), out_proj (128 x 128), linear1
  * (512 x 128), linear2 (128 x 512), proj (proj_n x 128), qfold (linear_rpe.weight[0:128] transposed: groups 4, n 128, k 32, no bias). */
-#define TBX_MFMA32_UNIT_FLOATS 2064 /* a wave's unit of a tbx_pack_weight_mfma32 image: 4 x (1 KiB hi + 1 KiB lo) + 16 bias floats */
+#define TBX_MFMA32_UNIT_FLOATS 2112 /* a wave's unit of a tbx_pack_weight_mfma32 image: 4 groups x (1 KiB hi + 1 KiB lo) + 4 x 16 bias floats */
 typedef struct tbx_layer_tile {
   float* x;
   const float* attn_out;
@@ -223,8 +223,43 @@ typedef struct tbx_layer_tile {
   int64_t n_rows;
 } tbx_layer_tile_t;
 int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
-/* Image for tbx_layer_tile of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32 or a multiple
- * of 128, n % 16 == 0, (units) % 8 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
+/* tbx_heads_tile: the agents' heads (traffic_bots.py:206-221) for large launches, same arithmetic class as tbx_layer_tile:
+ * x' = x + (navi_valid ? add_navi.mlp([x | navi_emb]) : 0); x'' = x' + (latent_invalid ? 0 : add_latent.mlp([x' | latent_emb]));
+ * action_out [n_rows, 2] = sum over the branches g with type_mask[g, row] == 0 of branch_g(x'') (action_head.py:74-100). x is not
+ * written. images (tbx_pack_weight_mfma32): [0..2] add_navi.mlp (n 128 k 256, n 128 k 128, n 128 k 128), [3..5] add_latent.mlp,
+ * [6] the branches' first layers stacked (n 384 k 128), [7] their second layers (groups 3, n 128, k 128), [8] their third layers
+ * zero-padded to 16 outputs (groups 3, n 16, k 128). Both embeddings = mlp_in(.) with their invalid rows already zeroed. */
+typedef struct tbx_heads_tile {
+  const float* x;
+  const float *navi_emb, *latent_emb;          /* [n_rows, 128] */
+  const uint8_t *navi_valid, *latent_invalid;  /* [n_rows] */
+  const uint8_t* type_mask;                    /* [3, mask_stride] */
+  const float* images[9];
+  float* action_out;
+  int32_t mask_stride, pad_;
+  int64_t n_rows;
+} tbx_heads_tile_t;
+int tbx_heads_tile(const tbx_heads_tile_t* args /* host */, void* stream);
+
+/* tbx_window_tile: the temporal PointNet of the agents' windows for large launches (agent_encoder.py:130-159: input encoder in
+ * "cat" mode; polyline_encoder.py:49-61; pooling.py:18-19,38): per row f = [mlp(attr) | pe], three layers of
+ * { h = relu(W f + b); f = [h | max of h over the window's valid rows] (invalid rows 0) }, out[window] = max of f over its valid
+ * rows (0 for a window without one). attr [n_groups * window, ld_attr >= 32] (the first 32 columns are read: the producer zero-pads),
+ * pe [n_groups * window, 64], row_invalid u8 [n_groups * window], out [n_groups, 128], window <= 16.
+ * in_images: the input MLP as (n 64, k 32 - the weight zero-padded to 32 columns), (n 64, k 64), (n 64, k 64); pn_images: the
+ * three PointNet layers (n 64, k 128): tbx_pack_weight_mfma32 images. */
+typedef struct tbx_window_tile {
+  const float *attr, *pe;
+  const uint8_t* row_invalid;
+  const float* in_images[3];
+  const float* pn_images[3];
+  float* out;
+  int32_t window, ld_attr;
+  int64_t n_groups;
+} tbx_window_tile_t;
+int tbx_window_tile(const tbx_window_tile_t* args /* host */, void* stream);
+/* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
+ * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
 int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups);
 int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
 

@@ -740,3 +740,83 @@ def test_pack_weight_mfma32_layout(hip, dev, n, k, groups, wt):
     for grp in range(groups):
         ref[grp * n:(grp + 1) * n] = wc[grp * k:(grp + 1) * k].t() if wt else wc[grp * n:(grp + 1) * n]
     assert float((Wd - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
+
+
+def _default_model(tb, dev):
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 3)
+    return wm.to(dev).eval()
+
+
+@pytest.mark.parametrize("G,W", [(1031, 11), (200, 11), (64, 7)])
+def test_window_tile_equals_grouped_chain(tb, hip, dev, G, W):
+    """tbx_window_tile (the agents' temporal PointNet as one launch: input MLP, 3 PointNet layers with the window maximum taken across
+    the lanes of a DPP row, pooled row; agent_encoder.py:130-159, polyline_encoder.py:49-61) vs the grouped tbx_rowchain program it
+    replaces for large launches: 2e-4 of the largest pooled entry (split-bf16 stages vs exact fp32); windows without a valid row
+    are exactly 0; a ragged last workgroup (odd G) and short windows (W = 7) are covered."""
+    eng = import_module("trafficbots_amd.engine")
+    ae = _default_model(tb, dev).model.ag_encoder
+    g = torch.Generator().manual_seed(G)
+    attr = torch.zeros(G * W, 32)
+    attr[:, :20] = torch.randn(G * W, 20, generator=g)
+    pe = torch.randn(G * W, 64, generator=g)
+    inv = (torch.rand(G, W, generator=g) < 0.3)
+    inv[5] = True  # a window without a valid row
+    inv[7, 1:] = True
+    attr, pe, inv8 = attr.to(dev), pe.to(dev), inv.reshape(-1).to(torch.uint8).to(dev)
+    ref = torch.empty(G, 128, device=dev)
+    ch = hip.Chain(hip.group_tile_rows(W, G), 132)
+    ch.load2(attr, hip.BUF0, 0, pe, hip.BUF1, 64)
+    cur = eng.emit_mlp(ch, ae.input_encoder.mlp, hip.BUF0, 0)
+    eng.emit_pointnet(ch, ae.temp_encoder, inv8, ref, x_buf=cur)
+    ch.run(G * W, group_rows=W)
+    imgs = ae._window_tile_images(32)
+    assert imgs is not None
+    out = torch.full((G, 128), 7.0, device=dev)
+    hip.window_tile(attr, pe, inv8, imgs[0], imgs[1], W, out)
+    torch.cuda.synchronize()
+    assert float(out[5].abs().max()) == 0.0 and float(ref[5].abs().max()) == 0.0
+    scale = float(ref.abs().max())
+    assert scale > 1e-2
+    assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("rows", [1030, 100])
+def test_heads_tile_equals_heads_chain(tb, hip, dev, rows):
+    """tbx_heads_tile (navigation / latent adders + the action head's stacked branches + masked sum in one launch,
+    traffic_bots.py:206-221) vs the heads chain: actions within 2e-4 of the largest one; rows of no agent type sum to exactly 0."""
+    eng = import_module("trafficbots_amd.engine")
+    m = _default_model(tb, dev).model
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 128, generator=g).to(dev)
+    navi_emb, lat_emb = torch.relu(torch.randn(rows, 128, generator=g)).to(dev), torch.relu(torch.randn(rows, 128, generator=g)).to(dev)
+    navi_valid = (torch.rand(rows, generator=g) < 0.8).to(torch.uint8).to(dev)
+    lat_inv = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    navi_emb[navi_valid == 0] = 0.0
+    lat_emb[lat_inv != 0] = 0.0
+    ty = torch.randint(0, 4, (rows,), generator=g)  # 3: no type (an invalid agent)
+    type_mask = torch.stack([(ty != i) for i in range(3)]).to(torch.uint8).contiguous().to(dev)
+    ref = torch.empty(rows, 2, device=dev)
+    ch = hip.Chain(16, 4 * 128 + 4)
+    ch.load(x, hip.BUF1, 0, n=128)
+    m.add_navi.emit(ch, navi_valid, mask_is_valid=True, z_embedded=navi_emb, z_premasked=True)
+    m.add_latent.emit(ch, lat_inv, None, z_embedded=lat_emb, z_premasked=True)
+    m.action_head.emit(ch, type_mask, ref)
+    ch.run(rows)
+    pw = lambda w, b, **kw: hip.packed_weight(w, b, mfma32=True, **kw)
+    lins = [[t[0] for t in mlp.linear_layers()] for mlp in m.action_head.mlp_mean]
+    w1, b1 = hip.stacked_linear([l[0] for l in lins])
+    w2, b2 = hip.stacked_linear([l[1] for l in lins])
+    w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
+    imgs = [pw(t[0].weight, t[0].bias) for t in m.add_navi.mlp.linear_layers()] + [pw(t[0].weight, t[0].bias) for t in m.add_latent.mlp.linear_layers()]
+    imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
+    out = torch.full((rows, 2), 7.0, device=dev)
+    hip.heads_tile(x, dict(images=imgs, navi_emb=navi_emb, latent_emb=lat_emb, navi_valid=navi_valid, latent_invalid=lat_inv,
+                           type_mask=type_mask, action_out=out))
+    torch.cuda.synchronize()
+    none = (ty == 3).to(dev)
+    assert float(out[none].abs().max()) == 0.0 and float(ref[none].abs().max()) == 0.0
+    scale = float(ref.abs().max())
+    assert scale > 1e-3
+    assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)

@@ -600,7 +600,7 @@ int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t d
 static int fold_grid_max() {  // 2 workgroups (78 KiB of LDS each) per CU
   static const int g = [] {
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("TBX_FOLD_WG_PER_CU");
     const int per = e && atoi(e) > 0 ? atoi(e) : 2;
     return per * (cus > 0 ? cus : 256);

@@ -1,0 +1,112 @@
+// Device building blocks of the tile kernels (tile_layer.hip, tile_heads.hip, tile_window.hip): LINEAR stages on the split-bf16
+// matrix path over 16-row tiles whose activations live in LDS as bf16 hi / lo planes. See tile_layer.hip for the design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tbx_hip.h"
+#include "tbx_common.h"
+
+namespace tbx_tile {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define TBX_GLOBAL __attribute__((address_space(1)))
+
+constexpr int NWAVE = 8, NT = NWAVE * 64, D = 128;
+constexpr int UNIT = TBX_MFMA32_UNIT_FLOATS;  // 2112 floats: 4 groups x (hi 1 KiB | lo 1 KiB) + 4 x 16 bias floats
+
+// bf16 planes of R rows x (32 * STEPS) channels: element (row, k) of a plane lives at byte
+//   ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2:
+// the four 8-element octets of a 32-k step go to four regions (a multiple of 256 B apart, so the octet does not move the bank),
+// inside a region a row is PRS bytes with PRS / 16 odd: the 16 rows of an operand read land in 16 distinct 16-byte bank groups
+// whichever 16 lanes the LDS serves together (MI355X_MICROARCH.md, LDS: ds_read_b128 = 4 groups of 16 lanes). The lo plane
+// follows the hi plane at + PLANE.
+template <int R, int STEPS>
+struct Planes {
+  static constexpr int PRS = 16 * (STEPS | 1);  // odd number of 16-byte slots per row
+  static constexpr int PREG = ((R * PRS + 255) / 256) * 256;
+  static constexpr int PLANE = 4 * PREG;
+  static __device__ __forceinline__ int off(int row, int k) { return ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2; }
+  // the (octet, row) offset of MFMA lane l for the row tile starting at row r0: B operand element [k-octet l >> 4][row l & 15]
+  static __device__ __forceinline__ int lane_off(int lane, int r0) { return (lane >> 4) * PREG + (r0 + (lane & 15)) * PRS; }
+};
+
+struct Entry {
+  const float* img;
+  int32_t unit0, pad;
+};
+
+// one wave's unit of weights: 4 groups of (hi, lo) A fragments (lane l, element e = W[tile * 16 + (l & 15)][step * 32 + (l >> 4) * 8 + e])
+struct W {
+  bf16x8 hi[4], lo[4];
+  f32x4 bias;  // group 0's tile: the lane's 4 output channels
+};
+
+__device__ __forceinline__ const TBX_GLOBAL float* unit_ptr(const float* img, int unit) {
+  return (const TBX_GLOBAL float*)img + (int64_t)unit * UNIT;
+}
+__device__ __forceinline__ void load_unit(W& w, const float* img, int unit, int lane) {
+  const TBX_GLOBAL float* base = unit_ptr(img, unit);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + lane * 4);
+    w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256 + lane * 4);
+  }
+  w.bias = *(const TBX_GLOBAL f32x4*)(base + 2048 + (lane >> 4) * 4);
+}
+__device__ __forceinline__ void load_unit(W& w, const Entry& e, int wave, int lane) { load_unit(w, e.img, e.unit0 + wave, lane); }
+// the lane's bias of group s (units whose groups are different tiles: k = 32 / 64 images)
+__device__ __forceinline__ f32x4 unit_bias(const float* img, int unit, int s, int lane) {
+  return *(const TBX_GLOBAL f32x4*)(unit_ptr(img, unit) + 2048 + s * 16 + (lane >> 4) * 4);
+}
+
+struct Acc {
+  f32x4 hh, hl, lh;
+  __device__ __forceinline__ void zero() { hh = hl = lh = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ f32x4 sum() const { return hh + (hl + lh); }
+};
+
+// D[channel][row] += W[channel][k] x[row][k] over the 32 k of one step: A = weight fragment, B = activation fragment read from
+// the planes at `act_hi` (= hi plane + the lane's (octet, row) offset) + step * 16; the lo plane is PLANE bytes behind
+template <int PLANE>
+__device__ __forceinline__ void mfma_step(Acc& a, const bf16x8 whi, const bf16x8 wlo, const char* act_hi, int step) {
+  const bf16x8 xh = *(const bf16x8*)(act_hi + step * 16);
+  const bf16x8 xl = *(const bf16x8*)(act_hi + PLANE + step * 16);
+  a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
+  a.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, a.hl, 0, 0, 0);
+  a.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, a.lh, 0, 0, 0);
+}
+
+// 4 fp32 values -> bf16 hi (RNE) and lo = bf16(v - hi), 8 bytes each
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  const bf16x4 h = __builtin_convertvector(v, bf16x4);
+  const f32x4 r = v - __builtin_convertvector(h, f32x4);
+  const bf16x4 l = __builtin_convertvector(r, bf16x4);
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+// 4 consecutive channels [c, c + 4) (c % 4 == 0) of plane row `row` into a plane pair (hi at p, lo at p + PLANE)
+template <class PL>
+__device__ __forceinline__ void planes_write4(char* p, int row, int c, const f32x4 v) {
+  u32x2 hi, lo;
+  split4(v, hi, lo);
+  const int o = PL::off(row, c);
+  *(u32x2*)(p + o) = hi;
+  *(u32x2*)(p + PL::PLANE + o) = lo;
+}
+
+__device__ __forceinline__ f32x4 gld4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
+__device__ __forceinline__ void gst4(float* p, const f32x4 v) { *(TBX_GLOBAL f32x4*)p = v; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  v[0] = fmaxf(v[0], 0.f), v[1] = fmaxf(v[1], 0.f), v[2] = fmaxf(v[2], 0.f), v[3] = fmaxf(v[3], 0.f);
+  return v;
+}
+
+}  // namespace tbx_tile

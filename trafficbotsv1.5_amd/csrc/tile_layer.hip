@@ -18,100 +18,22 @@
 //   * weights come as a per-wave stream of 8 KiB units (tbx_pack_weight_mfma32: the fragments of [16 channels x 128 k] in register
 //     order), double-buffered in registers one unit ahead across stage boundaries;
 //   * no program to decode: the stage list is the template instantiation.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "tile_core.h"
 
-#include "../../include/tbx_hip.h"
-#include "tbx_common.h"
+using namespace tbx_tile;
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-#define TBX_GLOBAL __attribute__((address_space(1)))
-
-constexpr int ROWS = 16, NWAVE = 8, NT = NWAVE * 64, D = 128;
-// bf16 planes: element (row, k) of a plane lives at byte  ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2:
-// the four 8-element octets of a 32-k step go to four regions (a multiple of 256 B apart, so the octet does not move the bank),
-// inside a region a row is PRS bytes with PRS / 16 odd: the 16 rows of an operand read land in 16 distinct 16-byte bank groups
-// whichever 16 lanes the LDS serves together (MI355X_MICROARCH.md, LDS: ds_read_b128 = 4 groups of 16 lanes).
-constexpr int PSTEPS = 20;                 // K <= 640 (the attention output: sum a v | sum a e of 4 heads)
-constexpr int PRS = 16 * (PSTEPS + 1);     // 336
-constexpr int PREG = ROWS * PRS;           // 5376 = 21 * 256
-constexpr int PLANE = 4 * PREG;            // 21504
-constexpr int XLD = 132;                   // floats per row of the fp32 buffers X (token rows) and Y (sum a v)
-constexpr int UNIT = TBX_MFMA32_UNIT_FLOATS;  // 2064 floats: 4 x (hi 1 KiB | lo 1 KiB) + 16 bias floats
+constexpr int ROWS = 16;
+typedef Planes<ROWS, 20> PL;  // K <= 640 (the attention output: sum a v | sum a e of 4 heads)
+constexpr int PLANE = PL::PLANE;
+constexpr int XLD = 132;      // floats per row of the fp32 buffers X (token rows) and Y (sum a v)
 constexpr size_t LDS_BYTES = 2 * ROWS * XLD * sizeof(float) + 4 * PLANE;
-
-__device__ __forceinline__ int plane_off(int row, int k) { return ((k >> 3) & 3) * PREG + row * PRS + (k >> 5) * 16 + (k & 7) * 2; }
-
-struct Entry {
-  const float* img;
-  int32_t unit0, pad;
-};
 
 struct TileArgs {
   tbx_layer_tile_t t;
   Entry ent[16];
 };
-
-// one wave's unit of weights: 4 groups of (hi, lo) A fragments + the tile's bias for the lane's 4 output channels
-struct W {
-  bf16x8 hi[4], lo[4];
-  f32x4 bias;
-};
-
-__device__ __forceinline__ void load_unit(W& w, const Entry& e, int wave, int lane) {
-  const TBX_GLOBAL float* base = (const TBX_GLOBAL float*)e.img + (int64_t)(e.unit0 + wave) * UNIT;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + lane * 4);
-    w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256 + lane * 4);
-  }
-  w.bias = *(const TBX_GLOBAL f32x4*)(base + 2048 + (lane >> 4) * 4);
-}
-
-struct Acc {
-  f32x4 hh, hl, lh;
-  __device__ __forceinline__ void zero() { hh = hl = lh = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  __device__ __forceinline__ f32x4 sum() const { return hh + (hl + lh); }
-};
-
-// D[channel][row] += W[channel][k] x[row][k] over the 32 k of one step: A = weight fragment, B = activation fragment read from
-// the planes at `act` (= plane + the lane's (octet, row) offset) + step * 16
-__device__ __forceinline__ void mfma_step(Acc& a, const bf16x8 whi, const bf16x8 wlo, const char* act_hi, int step) {
-  const bf16x8 xh = *(const bf16x8*)(act_hi + step * 16);
-  const bf16x8 xl = *(const bf16x8*)(act_hi + PLANE + step * 16);
-  a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
-  a.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, a.hl, 0, 0, 0);
-  a.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, a.lh, 0, 0, 0);
-}
-
-// 4 fp32 values -> bf16 hi (RNE) and lo = bf16(v - hi), 8 bytes each
-__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-  const bf16x4 h = __builtin_convertvector(v, bf16x4);
-  const f32x4 r = v - __builtin_convertvector(h, f32x4);
-  const bf16x4 l = __builtin_convertvector(r, bf16x4);
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
-}
-
-// the lane's 4 consecutive channels [c, c + 4) of row j into a plane pair (hi at p, lo at p + PLANE)
-__device__ __forceinline__ void planes_write4(char* p, int j, int c, const f32x4 v) {
-  u32x2 hi, lo;
-  split4(v, hi, lo);
-  const int o = plane_off(j, c);
-  *(u32x2*)(p + o) = hi;
-  *(u32x2*)(p + PLANE + o) = lo;
-}
-
-__device__ __forceinline__ f32x4 gld4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
-__device__ __forceinline__ void gst4(float* p, const f32x4 v) { *(TBX_GLOBAL f32x4*)p = v; }
 
 // LayerNorm_128 of row X[r] -> planes (k = 0..127), a wavefront per row, in rowchain.hip's ln_row order (bit-identical values
 // before the split)
@@ -132,7 +54,7 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
     const float y = (v[q] - mean) * rstd * gm[q] + bt[q];
     const __bf16 h = (__bf16)y;
     const __bf16 l = (__bf16)(y - (float)h);
-    const int o = plane_off(r, lane + 64 * q);
+    const int o = PL::off(r, lane + 64 * q);
     *(__bf16*)(P + o) = h;
     *(__bf16*)(P + PLANE + o) = l;
   }
@@ -153,7 +75,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   const int nv = (t.n_rows - row0) < ROWS ? (int)(t.n_rows - row0) : ROWS;
   const bool row_ok = j < nv;
   const int64_t grow = row0 + (row_ok ? j : 0);
-  const int aoff = g * PREG + j * PRS;  // the lane's (octet, row) offset inside a plane
+  const int aoff = PL::lane_off(lane, 0);  // the lane's (octet, row) offset inside a plane
   const int c_out = 16 * wave + 4 * g;  // the lane's 4 output channels of a 128-wide stage
 
   constexpr int E_FOLD = 0, E_OUT = 1, E_L1 = ATTN ? 2 : 0, E_L2 = E_L1 + 4, E_Q = (ATTN ? 2 : 0) + (FFN ? 8 : 0);
@@ -189,7 +111,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      planes_write4(Pa, rr[i], cc[i] * 4, v[i]);
+      planes_write4<PL>(Pa, rr[i], cc[i] * 4, v[i]);
       if (cc[i] < 32) *(f32x4*)(Y + rr[i] * XLD + cc[i] * 4) = v[i];
     }
   }
@@ -203,9 +125,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       acc.zero();
       const int step0 = 4 + 4 * (wave >> 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, step0 + s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, step0 + s);
       const f32x4 y = acc.sum() + w.bias + *(const f32x4*)(Y + j * XLD + c_out);
-      planes_write4(Pb, j, c_out, y);
+      planes_write4<PL>(Pb, j, c_out, y);
     }
     __syncthreads();
     {  // x += row without a valid target ? 0 : out_proj(y)
@@ -214,7 +136,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       Acc acc;
       acc.zero();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, s);
       f32x4 xv = *(const f32x4*)(X + j * XLD + c_out);
       if (!f_nov) xv += acc.sum() + w.bias;
       *(f32x4*)(X + j * XLD + c_out) = xv;
@@ -234,10 +156,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     const W& w = wb[(E_L1 + (R)) & 1];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
-    f32x4 h = acc.sum() + w.bias;                                                               \
-    h[0] = fmaxf(h[0], 0.f), h[1] = fmaxf(h[1], 0.f), h[2] = fmaxf(h[2], 0.f), h[3] = fmaxf(h[3], 0.f); \
-    planes_write4(Pb, j, (R) * D + c_out, h);                                                   \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    const f32x4 h = relu4(acc.sum() + w.bias);                                                  \
+    planes_write4<PL>(Pb, j, (R) * D + c_out, h);                                                   \
   } while (0)
     TBX_L1(0);
     TBX_L1(1);
@@ -254,7 +175,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TBX_NEXT(E_L2 + (R));                                                                                 \
     const W& w = wb[(E_L2 + (R)) & 1];                                                                    \
     if ((R) == 0) bias = w.bias;                                                                          \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
   } while (0)
       TBX_L2(0);
       TBX_L2(1);
@@ -279,9 +200,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       Acc acc;
       acc.zero();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s);
       const f32x4 q = acc.sum() + w.bias;
-      planes_write4(Pb, j, c_out, q);
+      planes_write4<PL>(Pb, j, c_out, q);
       if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + c_out, q);
     }
     if constexpr (PROJ == 2) {  // k | v: straight to the table (fp32 columns [128, 384) of proj_out, or the bfloat16 table)
@@ -291,7 +212,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     const W& w = wb[(E_KV + (R)) & 1];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
     const f32x4 kv = acc.sum() + w.bias;                                                        \
     if (row_ok) {                                                                               \
       if (t.kv16_out != nullptr) {                                                              \
@@ -316,7 +237,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       for (int s = 0; s < 4; ++s) {
         Acc acc;
         acc.zero();
-        mfma_step(acc, w.hi[s], w.lo[s], Pb + aoff, h);
+        mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, h);
         const f32x4 v = acc.sum();
         if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + qt_off + h * D + ((wave & 1) * 4 + s) * 16 + 4 * g, v);
       }
@@ -325,54 +246,61 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #undef TBX_NEXT
 }
 
-// tbx_pack_weight_mfma32 image of W_g [n x k] (g < groups; [k x n] with wt): T = groups * n / 16 tiles of 16 output channels.
-//   k % 128 == 0: unit u = (tile u % T, k-chunk u / T of 128): group s = k-step 4 * chunk + s of that tile, bias = the tile's;
-//   k == 32:      unit u = tiles 4u .. 4u + 3, group s = tile 4u + s (its one k-step); no bias.
-// A group = [64 lanes x 8 bf16 hi][64 lanes x 8 bf16 lo]: lane l, element e = W[tile * 16 + (l & 15)][step * 32 + (l >> 4) * 8 + e].
+// tbx_pack_weight_mfma32 image of W_g [n x k] (g < groups; [k x n] with wt): T = groups * n / 16 tiles of 16 output channels, a
+// unit = 4 groups of one (tile, 32-k step) each + the 4 groups' tile biases:
+//   k % 128 == 0: unit u = (tile u % T, k-chunk u / T of 128): group s = k-step 4 * chunk + s of that tile;
+//   k == 64:      unit u = tiles 2u, 2u + 1: group s = (tile 2u + (s >> 1), step s & 1);
+//   k == 32:      unit u = tiles 4u .. 4u + 3: group s = tile 4u + s (its one k-step).
+// A group = [64 lanes x 8 bf16 hi][64 lanes x 8 bf16 lo]: lane l, element e = W[tile * 16 + (l & 15)][step * 32 + (l >> 4) * 8 + e];
+// tiles past T (a last partial unit) are zero.
+__device__ __forceinline__ void unit_group(int k, int T, int64_t u, int s, int& tile, int& step) {
+  if (k == 32) {
+    tile = (int)u * 4 + s, step = 0;
+  } else if (k == 64) {
+    tile = (int)u * 2 + (s >> 1), step = s & 1;
+  } else {
+    tile = (int)(u % T), step = 4 * (int)(u / T) + s;
+  }
+}
+
 __global__ void pack_mfma32_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld, int groups, int wt,
                                    float* __restrict__ out, int64_t total) {
   const int T = groups * n / 16;
-  uint16_t* o16 = (uint16_t*)out;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t u = e / UNIT;
     const int f = (int)(e - u * UNIT);
-    if (f >= 2048) {  // bias floats
-      const int i = f - 2048;
-      float b = 0.f;
-      if (k != 32 && bias != nullptr) b = bias[(int)(u % T) * 16 + i];
-      out[e] = b;
+    int tile, step;
+    if (f >= 2048) {  // bias floats: 16 per group
+      const int s = (f - 2048) >> 4, i = (f - 2048) & 15;
+      unit_group(k, T, u, s, tile, step);
+      out[e] = (bias != nullptr && tile < T) ? bias[tile * 16 + i] : 0.f;
       continue;
     }
     // float slot f of the unit's 8 KiB: group s, half (hi / lo), lane l, dword q of the lane's 16 bytes (elements 2q, 2q + 1)
     const int s = f >> 9, half = (f >> 8) & 1, l = (f >> 2) & 63, q = f & 3;
-    int tile, step;
-    if (k == 32) {
-      tile = (int)u * 4 + s;
-      step = 0;
-    } else {
-      tile = (int)(u % T);
-      step = 4 * (int)(u / T) + s;
-    }
-    const int oc = tile * 16 + (l & 15);
-    const int grp = oc / n, col = oc - grp * n;
+    unit_group(k, T, u, s, tile, step);
     uint32_t bits = 0u;
+    if (tile < T) {
+      const int oc = tile * 16 + (l & 15);
+      const int grp = oc / n, col = oc - grp * n;
 #pragma unroll
-    for (int z = 0; z < 2; ++z) {
-      const int kk = step * 32 + (l >> 4) * 8 + 2 * q + z;
-      const float v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
-      const __bf16 hi = (__bf16)v;
-      const __bf16 x = half ? (__bf16)(v - (float)hi) : hi;
-      bits |= (uint32_t)__builtin_bit_cast(unsigned short, x) << (16 * z);
+      for (int z = 0; z < 2; ++z) {
+        const int kk = step * 32 + (l >> 4) * 8 + 2 * q + z;
+        const float v = wt ? w[((int64_t)grp * k + kk) * ld + col] : w[((int64_t)grp * n + col) * ld + kk];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 x = half ? (__bf16)(v - (float)hi) : hi;
+        bits |= (uint32_t)__builtin_bit_cast(unsigned short, x) << (16 * z);
+      }
     }
     out[e] = __uint_as_float(bits);
-    (void)o16;
   }
 }
 
 int64_t mfma32_units(int n, int k, int groups) {
   if (n <= 0 || k <= 0 || groups <= 0 || n % 16 != 0) return TBX_ERR_UNSUPPORTED;
   const int64_t T = (int64_t)groups * n / 16;
-  if (k == 32) return T % 4 == 0 ? T / 4 : TBX_ERR_UNSUPPORTED;
+  if (k == 32) return (T + 3) / 4;
+  if (k == 64) return (T + 1) / 2;
   if (k % 128 != 0) return TBX_ERR_UNSUPPORTED;
   return T * (k / 128);
 }
@@ -402,8 +330,6 @@ extern "C" int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, 
   if (w == nullptr || out == nullptr || ld <= 0) return TBX_ERR_ARG;
   const int64_t total = tbx_pack_weight_mfma32_size(n, k, groups);
   if (total < 0) return (int)total;
-  if ((total / UNIT) % NWAVE != 0) return TBX_ERR_UNSUPPORTED;  // a round = one unit per wave
-  if (k == 32 && bias != nullptr) return TBX_ERR_UNSUPPORTED;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_mfma32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out, total);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

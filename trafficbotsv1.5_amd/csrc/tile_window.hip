@@ -1,0 +1,153 @@
+// tbx_window_tile: the temporal PointNet over the agents' W-step windows (agent_encoder.py:130-159 input encoder in "cat" mode +
+// polyline_encoder.py:49-61 + pooling.py:18-19,38) for LARGE launches, on the building blocks of tile_core.h:
+//   f = [mlp(attr) (3 layers: d_in -> 64 -> 64 -> 64, relu after the first two) | pose embedding (64)]          per row
+//   3 x { h = relu(W f + b) (128 -> 64);  f = [h | max over the window's valid rows of h], invalid rows 0 }   per window
+//   out[window] = max over the valid rows of f (= [m | m] of the last layer's maximum m; 0 for a window without a valid row)
+// A workgroup (8 waves) owns 2 windows = two 16-row tiles (rows >= W are padding); wave w = output tile w & 3 of the 64 channels
+// of row tile w >> 2. In the transposed product a lane holds 4 channels of ONE row and the 16 rows of a window are the 16 lanes
+// of a DPP row: the masked maximum over a window is 4 DPP steps in registers - no LDS pass, no GROUPMAX stage.
+// Replaces a ~20-stage grouped tbx_rowchain program (48-row tiles, 158-167 us at 4096 windows).
+#include "tile_core.h"
+
+using namespace tbx_tile;
+
+namespace {
+
+constexpr int RT = 2;           // windows (16-row tiles) per workgroup
+constexpr int ROWS = 16 * RT;
+typedef Planes<ROWS, 4> PL;     // K <= 128
+constexpr int PLANE = PL::PLANE;
+constexpr size_t LDS_BYTES = 4 * PLANE;
+
+struct WindowArgs {
+  tbx_window_tile_t t;
+};
+
+__device__ __forceinline__ float row16_max(float v) {  // maximum over the 16 lanes of a DPP row, in every lane
+  v = fmaxf(v, tbx::dpp<tbx::DPP_XOR1>(v));
+  v = fmaxf(v, tbx::dpp<tbx::DPP_XOR2>(v));
+  v = fmaxf(v, tbx::dpp<tbx::DPP_HALF_MIRROR>(v));
+  return fmaxf(v, tbx::dpp<tbx::DPP_MIRROR>(v));
+}
+
+__global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_c[];
+  char* P0 = lds_c;             // ping: hi, lo
+  char* P1 = P0 + 2 * PLANE;    // pong
+  const tbx_window_tile_t& t = a.t;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int nt = wave & 3, rt = wave >> 2;  // the wave's output tile (16 of 64 channels) and row tile (window)
+  const int64_t grp0 = (int64_t)blockIdx.x * RT;
+  const int Wn = t.window;
+  const int aoff = PL::lane_off(lane, rt * 16);
+  const int c_out = 16 * nt + 4 * g;
+  // the lane's row: step j of window grp0 + rt
+  const int64_t grp = grp0 + rt;
+  const bool grp_ok = grp < t.n_groups;
+  bool inv = true;
+  if (grp_ok && j < Wn) inv = *(const TBX_GLOBAL uint8_t*)(t.row_invalid + grp * Wn + j) != 0;
+
+  // weights: input MLP 32 -> 64 (one unit of 4 tiles), 64 -> 64 twice (2 units of 2 tiles x 2 steps), PointNet 128 -> 64 three times
+  W wb[2];
+  load_unit(wb[0], t.in_images[0], 0, lane);
+  const f32x4 b_in0 = unit_bias(t.in_images[0], 0, nt, lane);
+
+  // ---- inputs: attribute rows (32 columns, zero-padded by their producer) -> P0[k 0..31]; pose embedding (64) -> P1[k 64..127]
+  if (tid < ROWS * 8) {
+    const int r = tid >> 3, c4 = tid & 7;
+    const int64_t gq = grp0 + (r >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gq < t.n_groups && (r & 15) < Wn) v = gld4(t.attr + (gq * Wn + (r & 15)) * (int64_t)t.ld_attr + c4 * 4);
+    planes_write4<PL>(P0, r, c4 * 4, v);
+  }
+  {
+    const int r = tid >> 4, c4 = tid & 15;
+    const int64_t gq = grp0 + (r >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gq < t.n_groups && (r & 15) < Wn) v = gld4(t.pe + (gq * Wn + (r & 15)) * (int64_t)64 + c4 * 4);
+    planes_write4<PL>(P1, r, 64 + c4 * 4, v);
+  }
+  __syncthreads();
+  {  // input MLP layer 1: K = 32 (step 0), the wave's tile = group nt of unit 0
+    load_unit(wb[1], t.in_images[1], nt >> 1, lane);
+    Acc acc;
+    acc.zero();
+    const W& w = wb[0];
+    // (groups are indexed with a wave-uniform runtime value: select by hand so the fragments stay in registers)
+    const bf16x8 wh = nt == 0 ? w.hi[0] : (nt == 1 ? w.hi[1] : (nt == 2 ? w.hi[2] : w.hi[3]));
+    const bf16x8 wl = nt == 0 ? w.lo[0] : (nt == 1 ? w.lo[1] : (nt == 2 ? w.lo[2] : w.lo[3]));
+    mfma_step<PLANE>(acc, wh, wl, P0 + aoff, 0);
+    planes_write4<PL>(P1, rt * 16 + j, c_out, relu4(acc.sum() + b_in0));
+  }
+  __syncthreads();
+#define TBX_IN64(CUR, SRC, DST, RELU, NEXT_IMG, NEXT_UNIT, BIAS_IMG)                                      \
+  do {                                                                                                    \
+    const f32x4 bias = unit_bias(BIAS_IMG, nt >> 1, 2 * (nt & 1), lane);                                  \
+    load_unit(wb[1 - (CUR)], NEXT_IMG, NEXT_UNIT, lane);                                                  \
+    Acc acc;                                                                                              \
+    acc.zero();                                                                                           \
+    const W& w = wb[CUR];                                                                                 \
+    const bool odd = (nt & 1) != 0;                                                                       \
+    mfma_step<PLANE>(acc, odd ? w.hi[2] : w.hi[0], odd ? w.lo[2] : w.lo[0], (SRC) + aoff, 0);             \
+    mfma_step<PLANE>(acc, odd ? w.hi[3] : w.hi[1], odd ? w.lo[3] : w.lo[1], (SRC) + aoff, 1);             \
+    f32x4 v = acc.sum() + bias;                                                                           \
+    if (RELU) v = relu4(v);                                                                               \
+    planes_write4<PL>(DST, rt * 16 + j, c_out, v);                                                        \
+  } while (0)
+  TBX_IN64(1, P1, P0, true, t.in_images[2], nt >> 1, t.in_images[1]);
+  __syncthreads();
+  TBX_IN64(0, P0, P1, false, t.pn_images[0], nt, t.in_images[2]);
+#undef TBX_IN64
+  __syncthreads();
+  // ---- PointNet layers: P1 -> P0 -> P1 -> out
+#define TBX_PN(CUR, SRC, DST, LAST, NEXT_IMG)                                                             \
+  do {                                                                                                    \
+    if (!(LAST)) load_unit(wb[1 - (CUR)], NEXT_IMG, nt, lane);                                            \
+    Acc acc;                                                                                              \
+    acc.zero();                                                                                           \
+    const W& w = wb[CUR];                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], (SRC) + aoff, s); \
+    f32x4 h = relu4(acc.sum() + w.bias);                                                                  \
+    f32x4 m;                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] = row16_max(inv ? -INFINITY : h[r]);               \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] = m[r] == -INFINITY ? 0.f : m[r];                  \
+    if (!(LAST)) {                                                                                        \
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                               \
+      planes_write4<PL>(DST, rt * 16 + j, c_out, inv ? z : h);                                            \
+      planes_write4<PL>(DST, rt * 16 + j, 64 + c_out, inv ? z : m);                                       \
+    } else if (j == 0 && grp_ok) {                                                                        \
+      gst4(t.out + grp * D + c_out, m);                                                                   \
+      gst4(t.out + grp * D + 64 + c_out, m);                                                              \
+    }                                                                                                     \
+  } while (0)
+  TBX_PN(1, P1, P0, false, t.pn_images[1]);
+  __syncthreads();
+  TBX_PN(0, P0, P1, false, t.pn_images[2]);
+  __syncthreads();
+  TBX_PN(1, P1, P0, true, t.pn_images[2]);
+#undef TBX_PN
+}
+
+}  // namespace
+
+extern "C" int tbx_window_tile(const tbx_window_tile_t* args, void* stream) {
+  if (args == nullptr || args->n_groups <= 0) return TBX_ERR_ARG;
+  const tbx_window_tile_t& t = *args;
+  if (t.attr == nullptr || t.pe == nullptr || t.row_invalid == nullptr || t.out == nullptr) return TBX_ERR_ARG;
+  for (int i = 0; i < 3; ++i)
+    if (t.in_images[i] == nullptr || t.pn_images[i] == nullptr) return TBX_ERR_ARG;
+  if (t.window <= 0 || t.window > 16 || t.ld_attr < 32 || t.ld_attr % 4 != 0) return TBX_ERR_UNSUPPORTED;
+  if ((((uintptr_t)t.attr) | ((uintptr_t)t.pe) | ((uintptr_t)t.out)) & 15) return TBX_ERR_ALIGN;
+  WindowArgs a;
+  a.t = t;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)tile_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
+      return TBX_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tile_window_kernel, dim3((unsigned)((t.n_groups + RT - 1) / RT)), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

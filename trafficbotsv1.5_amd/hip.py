@@ -88,6 +88,18 @@ class LayerTile(C.Structure):
                 + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)])
 
 
+class HeadsTile(C.Structure):
+    """tbx_heads_tile_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("x", "navi_emb", "latent_emb", "navi_valid", "latent_invalid", "type_mask")]
+                + [("images", C.c_void_p * 9), ("action_out", C.c_void_p), ("mask_stride", C.c_int32), ("pad_", C.c_int32), ("n_rows", C.c_int64)])
+
+
+class WindowTile(C.Structure):
+    """tbx_window_tile_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("attr", "pe", "row_invalid")] + [("in_images", C.c_void_p * 3), ("pn_images", C.c_void_p * 3),
+                ("out", C.c_void_p), ("window", C.c_int32), ("ld_attr", C.c_int32), ("n_groups", C.c_int64)])
+
+
 class SimState(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
@@ -199,6 +211,8 @@ def load():
     lib.tbx_pack_weight_gemv_size.restype = C.c_int64
     lib.tbx_pack_weight_gemv.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.tbx_layer_tile.argtypes = [C.POINTER(LayerTile), vp]
+    lib.tbx_heads_tile.argtypes = [C.POINTER(HeadsTile), vp]
+    lib.tbx_window_tile.argtypes = [C.POINTER(WindowTile), vp]
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
     lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -216,7 +230,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_layer_tile", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -622,6 +636,51 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True):
             assert kv16.shape == (x.shape[0], 256) and kv16.is_contiguous()
             a.kv16_out = _ptr(kv16, torch.bfloat16)
     _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
+
+
+def heads_tile(x, hd: dict):
+    """tbx_heads_tile: hd = dict(images = 9 mfma32 images, navi_emb, latent_emb [rows, 128], navi_valid, latent_invalid u8 [rows],
+    type_mask u8 [3, rows], action_out [rows, 2])."""
+    a = HeadsTile()
+    a.x, a.n_rows = _cptr(x, torch.float32), x.shape[0]
+    a.navi_emb, a.latent_emb = _cptr(hd["navi_emb"], torch.float32), _cptr(hd["latent_emb"], torch.float32)
+    a.navi_valid, a.latent_invalid = _cptr(hd["navi_valid"], torch.uint8), _cptr(hd["latent_invalid"], torch.uint8)
+    a.type_mask, a.mask_stride, a.action_out = _cptr(hd["type_mask"], torch.uint8), hd["type_mask"].shape[1], _cptr(hd["action_out"], torch.float32)
+    assert len(hd["images"]) == 9 and hd["action_out"].shape == (x.shape[0], 2)
+    for i, im in enumerate(hd["images"]):
+        a.images[i] = _ptr(im, torch.float32)
+    _check(load().tbx_heads_tile(C.byref(a), stream_ptr()), "tbx_heads_tile")
+
+
+def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out):
+    """tbx_window_tile: attr [G * window, >= 32], pe [G * window, 64], row_invalid u8 [G * window] -> out [G, 128]."""
+    a = WindowTile()
+    assert attr.dim() == 2 and attr.stride(1) == 1 and pe.shape[1] == 64 and pe.is_contiguous() and out.shape[1] == 128 and out.is_contiguous()
+    a.attr, a.ld_attr, a.pe, a.row_invalid = _ptr(attr, torch.float32), attr.stride(0), _ptr(pe, torch.float32), _cptr(row_invalid, torch.uint8)
+    for i in range(3):
+        a.in_images[i], a.pn_images[i] = _ptr(in_images[i], torch.float32), _ptr(pn_images[i], torch.float32)
+    a.out, a.window, a.n_groups = _ptr(out, torch.float32), int(window), out.shape[0]
+    assert attr.shape[0] == out.shape[0] * window
+    _check(load().tbx_window_tile(C.byref(a), stream_ptr()), "tbx_window_tile")
+
+
+def padded_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """w [n, k] zero-padded to k_pad columns; cached like packed_weight (per parameter version, or per training step in PACK_SCOPE)."""
+    if w.shape[1] == k_pad:
+        return w
+    key = ("padded", id(w), k_pad)
+    stamp = (w._version, w.data_ptr())
+    cache = PACK_SCOPE if PACK_SCOPE is not None else w.__dict__.setdefault("_tbx_padded", {})
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        out = torch.zeros(w.shape[0], k_pad, dtype=torch.float32, device=w.device)
+        out[:, :w.shape[1]].copy_(w)
+    cache[key] = (stamp, out)
+    if PACK_SCOPE is not None:
+        PACK_SCOPE.setdefault("_keep", {})[id(w)] = w
+    return out
 
 
 def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):

@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import current as engine_current, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
+from ..engine import current as engine_current, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -97,9 +97,13 @@ class AgentEncoder(nn.Module):
             aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * A, dev, hip.group_tile_rows(W, n * A))  # small launches: layer 0's projections in the windows' launch too
-        ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
         ie = self.input_encoder
-        if (ie.mode == "cat" and len(ie.mlp.linear_layers()) == 3 and ie.mlp.output_dim % 16 == 0 and prep["attr"].shape[1] % 4 == 0
+        wt_ = self._window_tile_images(prep["attr"].shape[1]) if (fp is None and W <= 16 and tile_rows_ok(n * A)) else None
+        ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
+        if wt_ is not None:  # large launches: the whole temporal PointNet as one tbx_window_tile launch
+            hip.window_tile(prep["attr"], prep["pe"], prep["row_invalid"], wt_[0], wt_[1], W, x)
+            ch = None
+        elif (ie.mode == "cat" and len(ie.mlp.linear_layers()) == 3 and ie.mlp.output_dim % 16 == 0 and prep["attr"].shape[1] % 4 == 0
                 and ie.mlp.output_dim + ie.pe_dim <= d):
             # attribute rows (agent_prep zero-fills them to 32 columns) and pose embeddings in ONE load stage; the embedding
             # goes straight to where the concatenation wants it (BUF1[:, out:out+pe] - the three MLP stages ping-pong
@@ -107,12 +111,13 @@ class AgentEncoder(nn.Module):
             ch.load2(prep["attr"], BUF0, 0, prep["pe"], BUF1, ie.mlp.output_dim)
             cur = emit_mlp(ch, ie.mlp, BUF0, 0)
             assert cur == BUF1
-        else:
+        elif ch is not None:
             cur = ie.emit(ch, prep["attr"], prep["pe"])
-        kept = emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur, keep=fp is not None)
-        if fp is not None:
-            emit_first_proj(ch, self.tf_ag2agmptl, fp, kept)
-        ch.run(n * A * W, group_rows=W)
+        if ch is not None:
+            kept = emit_pointnet(ch, self.temp_encoder, prep["row_invalid"], x, x_buf=cur, keep=fp is not None)
+            if fp is not None:
+                emit_first_proj(ch, self.tf_ag2agmptl, fp, kept)
+            ch.run(n * A * W, group_rows=W)
         # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
         # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
         kw = dict(want_rel_pose=True, want_emb=False)
@@ -150,6 +155,25 @@ class AgentEncoder(nn.Module):
                                    Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
                   join_stream=aux_stream, first_proj=fp)
         return x, prep
+
+    def _window_tile_images(self, attr_cols: int):
+        """(input MLP images, PointNet images) for tbx_window_tile, or None where the module is not of the shape that kernel is
+        built for (the default: "cat" input encoder 20 -> 64 -> 64 -> 64 + 64-d pose embedding, three 128 -> 64 PointNet layers)."""
+        ie, te = self.input_encoder, self.temp_encoder
+        lins = ie.mlp.linear_layers()
+        if not (ie.mode == "cat" and len(lins) == 3 and ie.mlp.output_dim == 64 and ie.pe_dim == 64 and ie.mlp.input_dim <= 32
+                and attr_cols >= 32 and all(ln is None for _, ln, _ in lins) and [a for _, _, a in lins] == [True, True, False]
+                and len(te.mlp_layers) == 3):
+            return None
+        pn = []
+        for mlp in te.mlp_layers:
+            ll = mlp.linear_layers()
+            if len(ll) != 1 or ll[0][1] is not None or tuple(ll[0][0].weight.shape) != (64, 128):
+                return None
+            pn.append(hip.packed_weight(ll[0][0].weight, ll[0][0].bias, mfma32=True))
+        ins = [hip.packed_weight(hip.padded_weight(lins[0][0].weight, 32), lins[0][0].bias, mfma32=True)]
+        ins += [hip.packed_weight(l.weight, l.bias, mfma32=True) for l, _, _ in lins[1:]]
+        return ins, pn
 
     @staticmethod
     def pad_hist(ag_valid: Tensor, ag_pose: Tensor, ag_motion: Tensor, window: int):

@@ -111,7 +111,8 @@ class TrafficBots(nn.Module):
         # inference with an auxiliary stream: the navigation embedding mlp_in(navi feature) (navigation.py:65-79 +
         # add_navi_latent.py:43-50) reads nothing the agent layers produce - it runs there, behind the K-nearest searches, instead
         # of as the first five stages of the heads chain (same stages, same values)
-        navi_ahead = aux_stream is not None and engine.DROP_CTX is None and self.NAVI_AHEAD
+        tile = engine.tile_rows_ok(n * A)  # large launches: the heads as one tbx_heads_tile launch (needs the embedding made ahead)
+        navi_ahead = (aux_stream is not None or tile) and engine.DROP_CTX is None and self.NAVI_AHEAD
 
         def aux_tail(prep):
             if prep.get("navi_emb") is None:
@@ -121,15 +122,16 @@ class TrafficBots(nn.Module):
             prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
             cn.run(n * A)
 
-        def heads_tail(prep):
-            """The heads as tbx_heads_tail_t fields when everything they read is at hand in the form the fused launch takes it:
-            navigation embedding from the auxiliary stream (masked by its producer), latent embedding of the rollout (masked once),
-            3-layer adders without layernorm, the action head's stacked branches."""
+        def heads_tail(prep, mfma32: bool = False):
+            """The heads as tbx_heads_tail_t / tbx_heads_tile_t fields when everything they read is at hand in the form the fused
+            launch takes it: navigation embedding from the auxiliary stream (masked by its producer), latent embedding of the
+            rollout (masked once), 3-layer adders without layernorm, the action head's stacked branches. mfma32: the images of
+            tbx_heads_tile (large launches) instead of the gemv images of tbx_knarpe_dec_layer's tail."""
             ah, an, al = self.action_head, self.add_navi, self.add_latent
             if not (navi_ahead and prep.get("_navi_premasked") and rc.get("latent_premasked") and rc.get("latent_embedded") is not None
                     and ah.fused_branches and ah.masked_sum_store and len(ah.mlp_mean) == 3 and ah.out_dim <= 16):
                 return None
-            pw = lambda w, b, **kw: hip.packed_weight(w, b, gemv=True, **kw)
+            pw = lambda w, b, **kw: hip.packed_weight(w, b, **(dict(mfma32=True) if mfma32 else dict(gemv=True)), **kw)
             lins = [[t[0] for t in mlp.linear_layers()] for mlp in ah.mlp_mean]
             w1, b1 = hip.stacked_linear([l[0] for l in lins])
             w2, b2 = hip.stacked_linear([l[1] for l in lins])
@@ -147,6 +149,11 @@ class TrafficBots(nn.Module):
         out["prep"], out["ag_feat"] = prep, feat
         if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
             return
+        if tile:
+            hd = heads_tail(prep, mfma32=True)
+            if hd is not None:
+                hip.heads_tile(feat, hd)
+                return
         navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
