@@ -704,37 +704,43 @@ def test_layer_tile_equals_row_chains(tb, hip, dev, mode, S, Ks, T, K, n_layer, 
 
 
 @pytest.mark.parametrize("n,k,groups,wt", [(128, 128, 1, False), (512, 128, 1, False), (128, 512, 1, False), (384, 128, 1, False),
-                                           (32, 128, 4, False), (128, 32, 4, True)])
+                                           (32, 128, 4, False), (128, 32, 4, True), (64, 64, 1, False), (64, 32, 1, False), (16, 128, 3, False)])
 def test_pack_weight_mfma32_layout(hip, dev, n, k, groups, wt):
-    """The tbx_pack_weight_mfma32 image, decoded on the host by the layout rule of csrc/tile_layer.hip, gives back bf16 hi + lo
-    halves with hi + lo == w to 2^-16 relative, every (output channel, k) exactly once, and the bias per 16-channel tile."""
+    """The tbx_pack_weight_mfma32 image, decoded on the host by the layout rule of csrc/tile_layer.hip (units of 4 groups of one
+    (16-channel tile, 32-k step) each + the groups' tile biases), gives back bf16 hi + lo halves with hi + lo == w to 2^-15 relative,
+    every (output channel, k) exactly once, and each group's bias."""
     g = torch.Generator().manual_seed(n + k)
     w = (torch.randn(groups * (k if wt else n), n if wt else k, generator=g)).to(dev)
-    bias = None if k == 32 else torch.randn(groups * n, generator=g).to(dev)
+    bias = torch.randn(groups * n, generator=g).to(dev)
     img = hip.packed_weight(w, bias, wt=wt, groups=groups, mfma32=True).cpu()
-    U = 2064
+    U = 2112
     units = img.numel() // U
     T = groups * n // 16
     Wd = torch.zeros(groups * n, k)
     seen = torch.zeros(groups * n, k)
-    wc = w.cpu()
+    wc, bc = w.cpu(), bias.cpu()
     for u in range(units):
         blk = img[u * U:(u + 1) * U]
-        raw = blk[:2048].view(torch.int32).view(4, 2, 64, 4)  # group, hi/lo, lane, dword
-        lo16 = (raw & 0xFFFF).to(torch.int32)
-        hi16 = ((raw >> 16) & 0xFFFF).to(torch.int32)
-        el = torch.stack([lo16, hi16], -1).reshape(4, 2, 64, 8)  # 8 bf16 bit patterns per lane
+        raw = blk[:2048].view(torch.int32).view(4, 2, 64, 4)  # group, hi / lo, lane, dword
+        el = torch.stack([raw & 0xFFFF, (raw >> 16) & 0xFFFF], -1).reshape(4, 2, 64, 8)  # 8 bf16 bit patterns per lane
         val = (el << 16).view(torch.float32)
         full = val[:, 0] + val[:, 1]  # hi + lo: [group, lane, 8]
         for s in range(4):
-            tile, step = (u * 4 + s, 0) if k == 32 else (u % T, 4 * (u // T) + s)
+            if k == 32:
+                tile, step = u * 4 + s, 0
+            elif k == 64:
+                tile, step = u * 2 + (s >> 1), s & 1
+            else:
+                tile, step = u % T, 4 * (u // T) + s
+            if tile >= T:
+                assert float(full[s].abs().max()) == 0.0
+                continue
             for l in range(64):
                 oc = tile * 16 + (l & 15)
                 kk = step * 32 + (l >> 4) * 8
                 Wd[oc, kk:kk + 8] = full[s, l]
                 seen[oc, kk:kk + 8] += 1
-        if bias is not None:
-            torch.testing.assert_close(blk[2048:], bias.cpu()[(u % T) * 16:(u % T) * 16 + 16], rtol=0, atol=0)
+            assert torch.equal(blk[2048 + 16 * s:2048 + 16 * s + 16], bc[tile * 16:tile * 16 + 16])
     assert bool((seen == 1).all())
     ref = torch.zeros(groups * n, k)
     for grp in range(groups):

@@ -64,13 +64,14 @@ class TrafficBots(nn.Module):
     # ------------------------------------------------------------------ fused per-step policy on raw windows
     def policy_step(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, hist_tl: Tensor, ag_attr6: Tensor,
                     ag_type_idx: Tensor, ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
-                    tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], out: Dict[str, Tensor]) -> None:
+                    tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], out: Dict[str, Tensor],
+                    rollout_consts: Optional[Dict[str, Tensor]] = None) -> None:
         """One policy evaluation for all agents / lights. Inputs are the device-resident sliding windows (oldest first);
         writes out['action_mean'] [n*A,2], out['tl_logits'] [n*L,5] (+ out['ag_feat'], out['tl_feat']).
         No host synchronisation: capturable in a hipGraph. traffic_bots.py:188-221."""
         tl_kv = self.tl_policy(hist_tl, tl_tokens, out)
         self.agent_policy(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, ag_latent, latent_invalid, dest,
-                          navi_valid_u8, tl_tokens, mp_tokens, tl_kv, out)
+                          navi_valid_u8, tl_tokens, mp_tokens, tl_kv, out, rollout_consts=rollout_consts)
 
     def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor], prepared=None) -> Tensor:
         """The traffic-light half (traffic_bots.py:188-199): tl tokens of the window -> next-state logits in

@@ -227,7 +227,7 @@ class RolloutEngine:
         if not self.sched.lights_ahead:
             self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6,
                                    S["ag_type_idx"], self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"],
-                                   self.tl_tokens, self.mp_tokens, self.policy_out)
+                                   self.tl_tokens, self.mp_tokens, self.policy_out, rollout_consts=self.consts)
             if self.tl_div > 1:
                 hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)
                 hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
