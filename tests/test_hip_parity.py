@@ -826,3 +826,46 @@ def test_heads_tile_equals_heads_chain(tb, hip, dev, rows):
     scale = float(ref.abs().max())
     assert scale > 1e-3
     assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("bf16,K0,K1", [(False, 25, 64), (False, 70, 0), (True, 24, 88), (False, 8, 3)])
+def test_attention_lds_ring_equals_small_launches(hip, dev, bf16, K0, K1):
+    """The LDS-ring form of the wave-per-row attention kernel (large launches: K / V rows of the next passes in flight as LDS-DMA
+    gathers into a per-wave ring, target indices held in registers; csrc/attn.hip) against the same rows launched in chunks below
+    1024 rows (4 wavefronts per row, plain gathers): the same per-pair arithmetic, merged in a different order - 1e-5 of the largest
+    output. One or two segments, segments past 64 targets (second index register), shared tables (batch_div), bf16 tables,
+    rows without a valid target (exact zeros + flag)."""
+    g = torch.Generator().manual_seed(K0 * 7 + K1)
+    n, S, T0, T1, D = 4, 300, 300, 500, 128
+    rows = n * S
+    qbuf = torch.randn(rows, 640, generator=g).to(dev)
+    bias = torch.randn(128, generator=g).to(dev)
+    fxy, fyw = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
+
+    def seg(T, K, div):
+        kv = torch.randn((n // div) * T, 256, generator=g)
+        kv = (kv.to(torch.bfloat16) if bf16 else kv).to(dev)
+        idx = torch.randint(0, T, (n, S, K), generator=g).to(torch.int32).to(dev)
+        inv = (torch.rand(n, S, K, generator=g) < 0.3).to(torch.uint8)
+        inv[1, 5] = 1
+        rel = torch.cat([(torch.rand(n, S, K, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
+        return kv, idx, inv.to(dev), rel, T, div
+
+    specs = [seg(T0, K0, 1)] + ([seg(T1, K1, 2)] if K1 else [])
+
+    def run(r0, r1, out, flag):
+        nb = (r1 - r0) // S
+        segs = [hip.Seg(kv[(r0 // S // div) * T:], 0, D, T, idx[r0 // S:r1 // S].contiguous(), inv[r0 // S:r1 // S].contiguous(), None, div,
+                        rel=rel[r0 // S:r1 // S].contiguous()) for kv, idx, inv, rel, T, div in specs]
+        hip.knarpe_attn(qbuf[r0:r1], 0, D, bias, nb, S, segs, out[r0:r1], flag[r0:r1], fxy, fyw)
+
+    big, bflag = torch.full((rows, 640), 3.0, device=dev), torch.full((rows,), 9, dtype=torch.uint8, device=dev)
+    run(0, rows, big, bflag)  # 1200 rows: the ring kernel
+    small, sflag = torch.full((rows, 640), 5.0, device=dev), torch.full((rows,), 9, dtype=torch.uint8, device=dev)
+    for r0 in range(0, rows, 2 * S):  # 600 rows per launch: 4 waves per row (batch entries in pairs: batch_div = 2 stays aligned)
+        run(r0, r0 + 2 * S, small, sflag)
+    torch.cuda.synchronize()
+    assert torch.equal(bflag, sflag) and int(bflag[S + 5]) == 1
+    assert float(big[S + 5].abs().max()) == 0.0
+    scale = float(small.abs().max())
+    assert float((big - small).abs().max()) <= 1e-5 * scale, (float((big - small).abs().max()), scale)

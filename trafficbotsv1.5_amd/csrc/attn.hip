@@ -257,6 +257,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 
 }
 
 // =====================================================================================================================
+// LDS-ring form of the wave-per-row forward (large launches, inference). Why: at 4096 rows x 104 pairs the sweep above runs
+// 13 dependent passes per wave - index -> 8 K/V row gathers (L2 / HBM, ~1-1.5 us under load) -> ~650 VALU cycles - with
+// one pass in flight per wave and 2 waves per SIMD (250 VGPRs): 4096 waves / 2048 slots x 13 passes x ~1.7 us = the measured 46 us
+// with the VALU < 50 % busy, whatever the bytes per pair (fp32 and bf16 tables cost the same). Memory-level parallelism per wave is
+// what is missing, and registers cannot hold a second pass of K/V rows. Here the rows of the NEXT R - 1 passes are in flight as
+// LDS-DMA gathers (global_load_lds_dwordx4: per-lane global address, 1 KiB per instruction straight into the wave's private ring of
+// R slots in LDS, no destination registers), issued from target indices that were loaded ONCE per row into registers (lane l
+// holds targets l and l + 64 of each segment; a pass fetches its 8 indices with ds_bpermute) - no index -> row dependency left in
+// the loop. A pass then reads its K / V fragments and relative poses back from its slot (each lane exactly the bytes its own DMA
+// lane wrote: conflict-free) and runs the same arithmetic as `sweep` (attn_core.h), in the same order: bit-identical rows.
+// fp32 tables: 8.25 KiB per slot, R = 4, one wave per SIMD (4 waves = 132 KiB per CU); bf16 tables: 4.25 KiB per slot, R = 4, two
+// waves per SIMD. Completion = the issuing wave's own vmcnt (VMEM returns in order): no barriers anywhere.
+__device__ __forceinline__ void glds_4(const void* gsrc_lane, uint32_t lds_byte_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_byte_addr)
+               : "memory");
+}
+
+template <bool KV16>
+struct RingGeom {
+  static constexpr int KVB = KV16 ? 4096 : 8192;  // K then V fragments of a pass
+  static constexpr int SLOT = KVB + 256;          // + 8 targets x 8 lanes x 4 B of relative poses (3 of 8 lanes used)
+  static constexpr int NDMA = (KV16 ? 4 : 8) + 1;
+};
+
+template <bool KV16, int R, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void knarpe_attn_ring_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ring_s[];
+  using G = RingGeom<KV16>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  if (row >= a.n_rows) return;
+  const int b = row / a.n_src;
+  const int s8 = lane & 7, tg = lane >> 3;
+  char* ring = ring_s + wave * R * G::SLOT;
+  const uint32_t ring_lds = lds_addr(ring);
+
+  // ---- the row's target indices / masks, once: lane l holds targets l and l + 64 of each segment
+  int idx_lo[2] = {0, 0}, idx_hi[2] = {0, 0}, inv_lo[2] = {1, 1}, inv_hi[2] = {1, 1};
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg) {
+    if (sg < a.n_seg) {
+      const tbx_attn_seg_t& S = a.seg[sg];
+      const int64_t pb = (int64_t)row * S.k;
+      if (lane < S.k) idx_lo[sg] = S.idx[pb + lane], inv_lo[sg] = S.invalid[pb + lane];
+      if (lane + 64 < S.k) idx_hi[sg] = S.idx[pb + lane + 64], inv_hi[sg] = S.invalid[pb + lane + 64];
+    }
+  }
+  // ---- query side in registers
+  const float* qrow = a.qbuf + (int64_t)row * a.ldq;
+  float4 qv[NH];
+  ESlice qt[NH];
+  float qb[NH];
+  EFreq fq;
+  fq.init(a.fxy, a.fyaw, s8);
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
+    const float4 bk = *(const float4*)(a.rpe_k_bias + h * DH + s8 * 4);
+    qb[h] = tbx::group8_sum(dot4(qv[h], bk));
+    qt[h].load(qrow + a.qt_off + h * DR, s8);
+  }
+  RowAcc st;
+  st.zero();
+  float(&m_run)[NH] = st.m_run;
+  float(&l_run)[NH] = st.l_run;
+  float4(&oacc)[NH] = st.oacc;
+  ESlice(&eacc)[NH] = st.eacc;
+
+  // the 8 lanes of target group tg fetch that target's index / mask from the lane that holds it
+  auto pick = [&](int sg, int tt, const int (&lo)[2], const int (&hi)[2]) -> int {
+    const int src = (tt & 63) * 4;
+    const int vlo = __builtin_amdgcn_ds_bpermute(src, sg == 0 ? lo[0] : lo[1]);
+    const int vhi = __builtin_amdgcn_ds_bpermute(src, sg == 0 ? hi[0] : hi[1]);
+    return tt < 64 ? vlo : vhi;
+  };
+  auto issue = [&](int sg, int base, int slot) {
+    const tbx_attn_seg_t& S = a.seg[sg];
+    const int t = base + tg;
+    const int tt = t < S.k ? t : S.k - 1;
+    const int j = pick(sg, tt, idx_lo, idx_hi);
+    constexpr int EB = KV16 ? 2 : 4;  // bytes per table element
+    const char* trow = (const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt + j) * (int64_t)S.ld_kv * EB;
+    const uint32_t dst = ring_lds + (uint32_t)(slot * G::SLOT);
+    if constexpr (!KV16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds_1k((const float*)(trow + (S.k_off + q * 32 + s8 * 4) * 4), dst + q * 1024);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds_1k((const float*)(trow + (S.v_off + q * 32 + s8 * 4) * 4), dst + 4096 + q * 1024);
+    } else {  // 8 bf16 channels per lane: a DMA covers 64 channels (two heads) of the pass's 8 rows
+#pragma unroll
+      for (int q = 0; q < 2; ++q) glds_1k((const float*)(trow + (S.k_off + q * 64 + s8 * 8) * 2), dst + q * 1024);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) glds_1k((const float*)(trow + (S.v_off + q * 64 + s8 * 8) * 2), dst + 2048 + q * 1024);
+    }
+    glds_4(S.rel_pose + ((int64_t)row * S.k + tt) * 3 + (s8 < 3 ? s8 : 0), dst + G::KVB);
+  };
+  auto consume = [&](int sg, int base, int slot) {
+#pragma clang fp contract(off)
+    const tbx_attn_seg_t& S = a.seg[sg];
+    const int t = base + tg;
+    const bool active = t < S.k;
+    const int tt = active ? t : S.k - 1;
+    const bool ok = (pick(sg, tt, inv_lo, inv_hi) == 0) & active;
+    const char* sl = ring + slot * G::SLOT;
+    float4 kq[4], v[4];
+    if constexpr (!KV16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        kq[q] = *(const float4*)(sl + q * 1024 + lane * 16);
+        v[q] = *(const float4*)(sl + 4096 + q * 1024 + lane * 16);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // channels q * 32 + s8 * 4 .. + 4: the half (s8 & 1) of DMA lane (q & 1) * 4 + s8 / 2 of DMA q / 2
+        const int o = (q >> 1) * 1024 + (tg * 8 + (q & 1) * 4 + (s8 >> 1)) * 16 + (s8 & 1) * 8;
+        const uint2 rk = *(const uint2*)(sl + o), rv = *(const uint2*)(sl + 2048 + o);
+        kq[q] = make_float4(__uint_as_float(rk.x << 16), __uint_as_float(rk.x & 0xffff0000u), __uint_as_float(rk.y << 16),
+                            __uint_as_float(rk.y & 0xffff0000u));
+        v[q] = make_float4(__uint_as_float(rv.x << 16), __uint_as_float(rv.x & 0xffff0000u), __uint_as_float(rv.y << 16),
+                           __uint_as_float(rv.y & 0xffff0000u));
+      }
+    }
+    ESlice e;
+    const float4 rel = *(const float4*)(sl + G::KVB + tg * 32);
+    const float rel3[3] = {rel.x, rel.y, rel.z};
+    fq.embed(rel3, e);
+    // ---- the arithmetic of attn_core.h's sweep (no dropout), statement for statement
+    float sc[NH];
+    bool jump = false;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      sc[h] = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;
+      jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
+    }
+    if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
+          l_run[h] *= alpha;
+          scale4(oacc[h], alpha);
+          eacc[h].scale(alpha);
+          m_run[h] = sc[h];
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];
+      const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
+      l_run[h] += pr;
+      fma4(oacc[h], pr, v[h]);
+      eacc[h].fma(pr, e);
+    }
+  };
+
+  // ---- the pass stream: (segment, base) cursors; the issue cursor runs R - 1 passes ahead of the consume cursor
+  int isg = 0, ibase = 0, islot = 0, ahead = 0;
+  auto issue_next = [&]() {
+    while (isg < a.n_seg && ibase >= a.seg[isg].k) ++isg, ibase = 0;
+    if (isg >= a.n_seg) return;
+    issue(isg, ibase, islot);
+    ibase += 8;
+    islot = islot + 1 == R ? 0 : islot + 1;
+    ++ahead;
+  };
+#pragma unroll 1
+  for (int i = 0; i < R - 1; ++i) issue_next();
+  int cslot = 0;
+  for (int sg = 0; sg < a.n_seg; ++sg) {
+    const int ks = a.seg[sg].k;
+#pragma unroll 1
+    for (int base = 0; base < ks; base += 8) {
+      issue_next();  // into the slot consumed in the previous pass (its fragments are in registers / used: lgkmcnt is waited below)
+      // passes issued and not yet consumed: `ahead` (this one included). The oldest outstanding DMA group is this pass's.
+      if (ahead == R)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * G::NDMA) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      consume(sg, base, cslot);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's bytes are in registers before a later DMA may overwrite it
+      cslot = cslot + 1 == R ? 0 : cslot + 1;
+      --ahead;
+    }
+  }
+
+  float M[NH], L[NH];
+  merge_slots(st, M, L);
+  float* orow = a.out + (int64_t)row * a.ldo;
+  const bool any_valid = M[0] > -INFINITY;
+  if (tg == 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
+      float4 o = oacc[h];
+      scale4(o, inv_l);
+      *(float4*)(orow + h * DH + s8 * 4) = o;
+      ESlice ev = eacc[h];
+      ev.scale(inv_l);
+      ev.store(orow + D + h * DR, s8);
+    }
+  }
+  if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+}
+
+// =====================================================================================================================
 // Backward (training). Same factorised math as the forward:
 //   s[h,t] = q_h.(k_h[idx_t] + bk_h) + qt_h.e_t ;  a = softmax(s * scale) (masked) ;  out = [sum_t a v_h | sum_t a e_t]
 // Given dout = [dO (128) | dE (4 x 128)] per row it produces dq, dqt (written to dqbuf at q_off / qt_off), dK / dV
@@ -634,6 +844,32 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
+  // the LDS-ring form: large launches without dropout whose segments are all given as relative poses (TBX_ATTN_RING=0: off)
+  static const int ring_mode = [] { const char* e = getenv("TBX_ATTN_RING"); return e ? atoi(e) : 1; }();
+  bool ring_ok = big && ring_mode != 0 && a.drop_thresh == 0u;
+  for (int i = 0; i < n_seg; ++i) ring_ok = ring_ok && segs[i].rel_pose != nullptr && segs[i].emb == nullptr && segs[i].k <= 128 && segs[i].k > 0;
+  if (ring_ok) {
+#define TBX_RING_LAUNCH(KV16F, RF, WPEF)                                                                                          \
+  do {                                                                                                                            \
+    constexpr int bytes = 4 * (RF) * RingGeom<KV16F>::SLOT;                                                                       \
+    static bool set = false;                                                                                                      \
+    if (!set) {                                                                                                                   \
+      if (hipFuncSetAttribute((const void*)knarpe_attn_ring_kernel<KV16F, RF, WPEF>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              bytes) != hipSuccess)                                                                               \
+        return TBX_ERR_LAUNCH;                                                                                                    \
+      set = true;                                                                                                                 \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((knarpe_attn_ring_kernel<KV16F, RF, WPEF>), grid, block, bytes, hs, a);                                    \
+  } while (0)
+    if (segs[0].kv_bf16 != 0)
+      TBX_RING_LAUNCH(true, 4, 2);
+    else if (ring_mode == 2)
+      TBX_RING_LAUNCH(false, 2, 2);
+    else
+      TBX_RING_LAUNCH(false, 4, 1);
+#undef TBX_RING_LAUNCH
+    return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+  }
   if (segs[0].kv_bf16 != 0) {  // bf16 K/V tables: inference only
     if (a.drop_thresh != 0u) return TBX_ERR_UNSUPPORTED;
     if (big)
