@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     bool jump = false;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      sc[h] = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;
+      sc[h] = (tbx::group8_sum(pair_score(kq[h], qv[h], e, qt[h])) + qb[h]) * a.scale2;
       jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
     }
     if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
@@ -546,8 +546,8 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
         for (int h = 0; h < NH; ++h) {
           const float4 kq = *(const float4*)(trow + S.k_off + h * 32 + s8 * 4);
           const float4 vv = *(const float4*)(trow + S.v_off + h * 32 + s8 * 4);
-          sc[h] = tbx::group8_sum(dot4(kq, qv[h]) + e.dot(qt[h])) + qb[h];
-          da[h] = tbx::group8_sum(dot4(vv, dov[h]) + e.dot(dev[h]));
+          sc[h] = tbx::group8_sum(pair_score(kq, qv[h], e, qt[h])) + qb[h];
+          da[h] = tbx::group8_sum(pair_score(vv, dov[h], e, dev[h]));
         }
         if (active && s8 == 0) {
           const int t = t_off + tl;
@@ -844,8 +844,8 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
-  // the LDS-ring form: large launches without dropout whose segments are all given as relative poses (TBX_ATTN_RING=0: off)
-  static const int ring_mode = [] { const char* e = getenv("TBX_ATTN_RING"); return e ? atoi(e) : 1; }();
+  // the LDS-ring form (opt-in, TBX_ATTN_RING=1 / 2): large launches without dropout whose segments are all given as relative poses
+  static const int ring_mode = [] { const char* e = getenv("TBX_ATTN_RING"); return e ? atoi(e) : 0; }();  // measured: no gain, opt-in
   bool ring_ok = big && ring_mode != 0 && a.drop_thresh == 0u;
   for (int i = 0; i < n_seg; ++i) ring_ok = ring_ok && segs[i].rel_pose != nullptr && segs[i].emb == nullptr && segs[i].k <= 128 && segs[i].k > 0;
   if (ring_ok) {

@@ -162,6 +162,26 @@ __device__ __forceinline__ float4 kv_load4(const float* __restrict__ table_row, 
 }
 
 
+// q_h . k_h + qt_h . e of one (pair, head) for the lane's channel slices: 20 products as TWO interleaved fma chains (even / odd
+// elements) on v_pk_fma_f32 - 10 packed instructions + one add instead of a 20-long scalar chain (the sweep is VALU-issue bound:
+// profiles/r02_attn_counters.json). Shared by every kernel that forms scores (forward, ring, fused decoder layer, backward), so
+// they all round alike.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk2(const float2 v) { return (f32x2_t){v.x, v.y}; }
+__device__ __forceinline__ float pair_score(const float4 k, const float4 q, const ESlice& e, const ESlice& t) {
+  f32x2_t s = (f32x2_t){k.x, k.y} * (f32x2_t){q.x, q.y};
+  s = __builtin_elementwise_fma((f32x2_t){k.z, k.w}, (f32x2_t){q.z, q.w}, s);
+  s = __builtin_elementwise_fma(pk2(e.xc), pk2(t.xc), s);
+  s = __builtin_elementwise_fma(pk2(e.xs), pk2(t.xs), s);
+  s = __builtin_elementwise_fma(pk2(e.yc), pk2(t.yc), s);
+  s = __builtin_elementwise_fma(pk2(e.ys), pk2(t.ys), s);
+  s = __builtin_elementwise_fma((f32x2_t){e.wc.x, e.wc.y}, (f32x2_t){t.wc.x, t.wc.y}, s);
+  s = __builtin_elementwise_fma((f32x2_t){e.wc.z, e.wc.w}, (f32x2_t){t.wc.z, t.wc.w}, s);
+  s = __builtin_elementwise_fma((f32x2_t){e.ws.x, e.ws.y}, (f32x2_t){t.ws.x, t.ws.y}, s);
+  s = __builtin_elementwise_fma((f32x2_t){e.ws.z, e.ws.w}, (f32x2_t){t.ws.z, t.ws.w}, s);
+  return s[0] + s[1];
+}
+
 // Per-slot online softmax state and partial sums of one wavefront's share of a source row's targets.
 struct RowAcc {
   float m_run[NH], l_run[NH];
@@ -219,7 +239,7 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
       bool jump = false;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        sc[h] = (tbx::group8_sum(dot4(kq[h], qv[h]) + e.dot(qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
+        sc[h] = (tbx::group8_sum(pair_score(kq[h], qv[h], e, qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
         jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
       }
       if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
