@@ -279,3 +279,52 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
         assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), name
         assert torch.equal(o.vis_dict["tl_state"], ref.vis_dict["tl_state"]), name
         assert torch.equal(o.tl_state_nll, ref.tl_state_nll), name
+
+
+@pytest.mark.parametrize("sizes,knn,K", [((8, 64, 8), 4, 1), ((16, 64, 8), 4, 4)])
+def test_cached_engine_refilled_in_place_equals_fresh_engines(tb, sizes, knn, K):
+    """WaymoMotion keeps ONE rollout engine (device state + captured hipGraphs) per shape and refills it in place for the next
+    scene (RolloutEngine.refill; the reference's validation_step loops over scenes, waymo_motion.py:526): three different scenes
+    through the cached engine give, bit for bit, the buffers of three fresh engines (engine_cache = 0), for single rollouts and
+    for K joint futures sharing a scene's map and lights - and an earlier buffer is not disturbed by a later rollout."""
+    dev = torch.device("cuda:0")
+    wm, P, _, _ = _setup(tb, dev, sizes, knn)
+    D = import_module("trafficbots_amd.models.modules.distributions")
+
+    def scene(seed):
+        batch = tb.synthetic.make_scene(1, *sizes, seed=seed)
+        full = {**batch, **tb.synthetic.to_history_batch(batch)}
+        return wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+
+    def roll(bd):
+        valid = bd["sc/ag_valid"].any(-1)
+        n, A = valid.shape
+        torch.manual_seed(3)
+        if K == 1:
+            mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+            z = torch.randn(1, A, 16, generator=torch.Generator().manual_seed(1)).to(dev)
+            v2 = bd["gt/ag_valid"].any(-1)
+            return wm.reactive_replay(bd, mp, tl, z, v2, bd["gt/ag_navi"], v2, wm.teacher_forcing_joint_future_pred, True, step_end=24)
+        mp, tl = wm.encode_scene(bd, n_rollout=K)
+        lat = D.DiagGaussian(torch.zeros(n, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)
+        nav = D.DestCategorical(probs=torch.nn.functional.one_hot(bd["gt/ag_navi"], bd["sc/mp_valid"].shape[1]).float(), valid=valid)
+        return wm.joint_future_pred(bd, mp, tl, lat, nav, wm.teacher_forcing_joint_future_pred, K, step_end=24)
+
+    scenes = [scene(s) for s in (11, 12, 13)]
+    wm.engine_cache = 0
+    fresh = [roll(bd) for bd in scenes]
+    wm.engine_cache = 2
+    cached, engines = [], []
+    for bd in scenes:
+        cached.append(roll(bd))
+        engines.append(wm._engine)
+    assert engines[0] is engines[1] is engines[2] and len(wm._engines) == 1  # one engine, one capture
+    assert not torch.equal(fresh[0].pred_pose, fresh[1].pred_pose)  # the scenes do differ
+    for f, c in zip(fresh, cached):
+        assert torch.equal(f.pred_pose, c.pred_pose) and torch.equal(f.pred_valid, c.pred_valid)
+        assert torch.equal(f.vis_dict["action"], c.vis_dict["action"]) and torch.equal(f.vis_dict["tl_state"], c.vis_dict["tl_state"])
+        assert torch.equal(f.tl_state_nll, c.tl_state_nll)
+        for k in f.violation:
+            assert torch.equal(f.violation[k], c.violation[k]), k
+        for k in f.diffbar_reward:
+            assert torch.equal(f.diffbar_reward[k], c.diffbar_reward[k]), k

@@ -38,12 +38,13 @@ class AgentEncoder(nn.Module):
         self.input_encoder = InputEncoder(hidden_dim=hidden_dim, attr_dim=attr_dim, pe_dim=self.pose_emb.out_dim, **input_encoder)
 
     # ---- static per scene
-    def kv_mp(self, mp: Dict[str, Tensor]) -> Tensor:
-        """K/V tables of the map tokens for this encoder's ag2mp layers; cached in the map-token dict."""
+    def kv_mp(self, mp: Dict[str, Tensor], refresh: bool = False) -> Tensor:
+        """K/V tables of the map tokens for this encoder's ag2mp layers; cached in the map-token dict (refresh: recomputed into the
+        cached tensor - the token features were overwritten in place, RolloutEngine.refill)."""
         cache = mp.setdefault("_kv_ag", {})
-        if id(self) not in cache:
+        if id(self) not in cache or refresh:
             feat = mp["mp_token_feature"].reshape(-1, self.hidden_dim).contiguous()
-            cache[id(self)] = kv_tables(feat, [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers])
+            cache[id(self)] = kv_tables(feat, [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers], out=cache.get(id(self)))
         return cache[id(self)]
 
     def tl_kv_layers(self):

@@ -65,11 +65,13 @@ class TrafficLightEncoder(nn.Module):
                  knn_invalid_tl2mp=m_tm, rpe_tl2mp=e_tm, rel_tl2mp=r_tm, mp_batch_div=mp_batch_div, n_mp=M, mp_feat_flat=mp_feat)
         return t
 
-    def _kv_mp(self, t: Dict[str, Tensor]) -> Tensor:
-        """K/V tables of the map tokens for this encoder's tl2mp layers (static per scene, cached in the token dict)."""
+    def _kv_mp(self, t: Dict[str, Tensor], refresh: bool = False) -> Tensor:
+        """K/V tables of the map tokens for this encoder's tl2mp layers (static per scene, cached in the token dict; refresh:
+        recomputed into the cached tensor after the token features were overwritten in place)."""
         cache = t.setdefault("_kv_mp", {})
-        if id(self) not in cache:
-            cache[id(self)] = kv_tables(t["mp_feat_flat"].contiguous(), [(l.norm_tgt, l.attn) for l in self.tf_tl2tlmp.layers])
+        if id(self) not in cache or refresh:
+            cache[id(self)] = kv_tables(t["mp_feat_flat"].contiguous(), [(l.norm_tgt, l.attn) for l in self.tf_tl2tlmp.layers],
+                                        out=cache.get(id(self)))
         return cache[id(self)]
 
     def prep_buffers(self, n: int, L: int, dev):

@@ -5,6 +5,7 @@ The rollout is a device-resident state machine (utils/rollout_engine.py) replayi
 rollouts are independent, so multi-GPU inference shards them over ranks with no collective.
 WOMD / WOSAC metrics, submission writers and video logging of the reference are out of scope.
 """
+import dataclasses
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -82,6 +83,8 @@ class WaymoMotion(LightningModule):
         self.teacher_forcing_reactive_replay = TeacherForcing(**teacher_forcing_reactive_replay)
         self.teacher_forcing_joint_future_pred = TeacherForcing(**teacher_forcing_joint_future_pred)
         self._engine: Optional[RolloutEngine] = None
+        self._engines: "OrderedDict[tuple, RolloutEngine]" = OrderedDict()  # engines by (shapes, schedule, weights version): begin_rollout
+        self.engine_cache = 2  # engines kept (least recently used dropped); 0: a fresh engine + graph capture per rollout
         # which launches this module's hot path runs as (engine.Schedule): per module, not per process - e.g. a module with
         # bfloat16 K/V tables beside an fp32 one. Callers may assign a new one before encode_scene / rollout.
         self.schedule: Optional[engine.Schedule] = None
@@ -111,8 +114,7 @@ class WaymoMotion(LightningModule):
                              tl_state=tl_state_gt, current_epoch=self.current_epoch)
         dev = ag_tokens["gt_pose"].device
         rc = self.hparams.differentiable_reward
-        eng = RolloutEngine(self.model, self.dynamics, dev, schedule=self.schedule)
-        eng.reset(gt_valid=ag_tokens["gt_valid"], gt_pose=ag_tokens["gt_pose"], gt_motion=ag_tokens["gt_motion"],
+        kw = dict(gt_valid=ag_tokens["gt_valid"], gt_pose=ag_tokens["gt_pose"], gt_motion=ag_tokens["gt_motion"],
                   tl_state_gt=tl_state_gt, tf_mask=teacher_forcing.ag_teacher_forcing, ag_type=ag_tokens["ag_type"],
                   ag_attr=ag_tokens["ag_attr"], ag_latent=ag_tokens["ag_latent"], ag_latent_valid=ag_tokens["ag_latent_valid"],
                   ag_navi=ag_tokens["ag_navi"], ag_navi_valid=ag_tokens["ag_navi_valid"], mp_tokens=mp_tokens,
@@ -120,6 +122,23 @@ class WaymoMotion(LightningModule):
                   map_pos=rule_checker.mp_pos, map_dir=rule_checker.mp_dir, map_boundary=rule_checker.mp_boundary,
                   n_step=step_end, reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight),
                   ag_navi_log_prob=ag_tokens.get("ag_navi_log_prob"), stepwise=stepwise)
+        # One engine per (shapes, schedule, weights), refilled in place: a loop over scenes (validation_step, waymo_motion.py:526)
+        # captures its hipGraphs once. `engine_cache = 0` turns the cache off (a fresh engine per rollout).
+        sched = self.schedule if self.schedule is not None else engine.current()
+        key = (RolloutEngine.shape_key(**kw), dataclasses.astuple(sched), str(dev), self.training,
+               sum(p._version for p in self.model.parameters()))
+        eng = self._engines.get(key) if self.engine_cache > 0 else None
+        if eng is not None:
+            eng.refill(**kw)
+            self._engines.move_to_end(key)
+        else:
+            eng = RolloutEngine(self.model, self.dynamics, dev, schedule=sched)
+            eng.reset(**kw)
+            if self.engine_cache > 0:
+                eng.reused = True
+                self._engines[key] = eng
+                while len(self._engines) > self.engine_cache:
+                    self._engines.popitem(last=False)
         self._engine = eng
         self.dynamics.bind(eng)
         return eng

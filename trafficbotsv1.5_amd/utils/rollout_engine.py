@@ -79,6 +79,7 @@ class RolloutEngine:
         self.model, self.dyn, self.dev = model, dynamics, device
         self.sched = schedule if schedule is not None else engine.current()
         self._graph_steps = 1  # steps per replay of graph_multi, fixed when it is captured
+        self.reused = False    # True: kept by its owner across rollouts (refill): buffer() hands out copies of the logs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graph_multi: Optional[torch.cuda.CUDAGraph] = None
 
@@ -88,7 +89,8 @@ class RolloutEngine:
               ag_type: Tensor, ag_attr: Tensor, ag_latent: Tensor, ag_latent_valid: Tensor, ag_navi: Tensor,
               ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
               map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int,
-              reward_weights=(0.1, 10.0, 0.1), ag_navi_log_prob: Optional[Tensor] = None, stepwise: bool = False) -> None:
+              reward_weights=(0.1, 10.0, 0.1), ag_navi_log_prob: Optional[Tensor] = None, stepwise: bool = False,
+              _lights_ahead_pass: bool = True) -> None:
         """All tensors on the device. gt_* [n,A,Tg(,3)], tl_state_gt [n,L,Tt,5] bool, tf_mask [n,A,Tg] bool
         (TeacherForcing.ag_teacher_forcing), ag_navi [n,A] int64 dest; map_* are the raw polylines of the scene(s)
         ([n/div, M, N, ..]) for the destination check. reward_weights = (l_pos, l_rot, l_spd).weight of the
@@ -196,8 +198,70 @@ class RolloutEngine:
         self.consts = (self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div, latent_invalid=self.latent_invalid)
                        if self.sched.hoist_constants else None)
         self._n_forward = 0
-        if not stepwise:
+        self._shape_key = self.shape_key(gt_valid=gt_valid, tl_state_gt=tl_state_gt, map_valid=map_valid, n_step=n_step, stepwise=stepwise,
+                                         mp_tokens=mp_tokens, tl_tokens=tl_tokens, ag_latent=ag_latent)
+        if not stepwise and _lights_ahead_pass:
             self._tl_ahead(0)
+
+    @staticmethod
+    def shape_key(*, gt_valid, tl_state_gt, map_valid, n_step, stepwise, mp_tokens, tl_tokens, ag_latent, **_):
+        """What must agree for `refill` (same buffers, same captured graphs): every shape the engine's buffers depend on."""
+        tok = lambda d: tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items() if torch.is_tensor(v))) + tuple(
+            sorted((k, v) for k, v in d.items() if isinstance(v, int)))
+        return (tuple(gt_valid.shape), tuple(tl_state_gt.shape), tuple(map_valid.shape), int(n_step), bool(stepwise), tuple(ag_latent.shape),
+                tok(mp_tokens), tok(tl_tokens))
+
+    @_scheduled
+    def refill(self, **kw) -> None:
+        """ANOTHER scene of the same shapes (reset's arguments) into this engine's buffers, in place: every pointer the captured
+        hipGraphs hold stays valid, so a loop over scenes (the reference's validation_step, waymo_motion.py:526) pays the capture
+        once per shape instead of once per rollout. The engine owns the token dicts it was first reset with: their tensors are
+        overwritten. Results are those of a fresh engine, bit for bit (tests/test_hip_rollout.py)."""
+        key = self.shape_key(**kw)
+        if key != self._shape_key:
+            raise ValueError("refill: shapes differ from the ones this engine was built for (use a new engine)")
+        fresh = RolloutEngine(self.model, self.dyn, self.dev, schedule=self.sched)
+        RolloutEngine.reset.__wrapped__(fresh, _lights_ahead_pass=False, **kw)
+        assert fresh.tl_div == self.tl_div, "refill: the new scene's lights are (not) shared across its rollouts unlike the first scene's"
+        assert fresh.S.keys() == self.S.keys()
+        for k, v in fresh.S.items():
+            self.S[k].copy_(v)
+        for k, v in fresh.init_state.items():
+            self.init_state[k].copy_(v)
+        for name in ("ag_attr6", "ag_latent", "latent_invalid", "dest"):
+            getattr(self, name).copy_(getattr(fresh, name))
+        if torch.is_tensor(self.tl_invalid_full):
+            self.tl_invalid_full = fresh.tl_invalid_full  # (host-side use only: buffer())
+        self.ag_type, self.navi_log_prob0, self.navi_valid0 = fresh.ag_type, fresh.navi_log_prob0, fresh.navi_valid0
+        self._copy_tokens(self.mp_tokens, fresh.mp_tokens)
+        self._copy_tokens(self.tl_tokens, fresh.tl_tokens)
+        # per-scene K/V tables of the map tokens (cached in the token dicts): recomputed into the tables the graphs read
+        self.model.ag_encoder.kv_mp(self.mp_tokens, refresh=True)
+        self.model.tl_encoder._kv_mp(self.tl_tokens, refresh=True)
+        if self.consts is not None:
+            for k, v in fresh.consts.items():
+                if torch.is_tensor(v):
+                    self.consts[k].copy_(v)
+                else:
+                    assert self.consts[k] == v
+        self.parity = 0
+        self._n_forward = 0
+        if not self.stepwise:
+            self._tl_ahead(0)
+
+    @staticmethod
+    def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor]) -> None:
+        for k, v in src.items():
+            if k.startswith("_"):
+                continue  # caches: rebuilt by their owners
+            if torch.is_tensor(v):
+                if dst[k].data_ptr() != v.data_ptr():
+                    dst[k].copy_(v)
+            elif isinstance(v, (int, float, bool)):
+                assert dst[k] == v, (k, dst[k], v)
+        for k in dst:  # u8 copies of a mask that a consumer added lazily (e.g. mp_token_invalid_u8): refreshed from their source
+            if k.endswith("_u8") and k not in src and torch.is_tensor(dst.get(k[:-3])):
+                dst[k].copy_(dst[k[:-3]].to(torch.uint8))
 
     @_scheduled
     def restore(self) -> None:
@@ -360,6 +424,8 @@ class RolloutEngine:
         (collided, collided_wosac, run_road_edge, run_red_light, passive: waymo_motion.py:250 in the reference's loop) are
         evaluated here for all steps at once from the device-resident log (tbx_rule_check over n x T frames)."""
         S, buf = self.S, RolloutBuffer(self.T, step_current)
+        if self.reused:  # the log tensors are rewritten by this engine's next rollout: the buffer gets its own copies
+            S = {k: (v.clone() if k.startswith("out_") else v) for k, v in S.items()}
         buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
         buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
         rep = (lambda t: t) if self.tl_div == 1 else (lambda t: t.repeat_interleave(self.tl_div, 0))  # per rollout again
