@@ -97,6 +97,8 @@ class RolloutEngine:
         differentiable reward logged per step. stepwise: the engine is driven through `forward_step` (WaymoMotion.forward)
         with explicit overrides instead of `run`."""
         dev = self.dev
+        self._shape_key = self.shape_key(gt_valid=gt_valid, tl_state_gt=tl_state_gt, map_valid=map_valid, n_step=n_step, stepwise=stepwise,
+                                         mp_tokens=mp_tokens, tl_tokens=tl_tokens, ag_latent=ag_latent)
         n, A, Tg = gt_valid.shape
         L, Tt = tl_state_gt.shape[1], tl_state_gt.shape[2]
         W = self.model.temp_window_size
@@ -198,8 +200,6 @@ class RolloutEngine:
         self.consts = (self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div, latent_invalid=self.latent_invalid)
                        if self.sched.hoist_constants else None)
         self._n_forward = 0
-        self._shape_key = self.shape_key(gt_valid=gt_valid, tl_state_gt=tl_state_gt, map_valid=map_valid, n_step=n_step, stepwise=stepwise,
-                                         mp_tokens=mp_tokens, tl_tokens=tl_tokens, ag_latent=ag_latent)
         if not stepwise and _lights_ahead_pass:
             self._tl_ahead(0)
 
