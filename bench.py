@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--polylines", type=int, default=1024)
     ap.add_argument("--lights", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--new-scenes", type=int, default=8, help="further scenes rolled through the same engine after the headline (end-to-end figure)")
     ap.add_argument("--repeats", type=int, default=3, help="times the timed region (W prime + K timed steps) is run; value = median")
     ap.add_argument("--pre-roll-ms", type=float, default=1500.0,
                     help="untimed device warm-up before the W warm-up steps: whole rollouts replayed and rewound for this long (0: none)")
@@ -282,13 +283,17 @@ def build(tb, args, dev, rank):
     return wm, full
 
 
-def gpu_rollout_setup(tb, wm, full, args, dev):
-    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+def scene_on_device(tb, wm, args, dev, seed):
+    """A synthetic scene batch of this workload's shape (seed = scene id), pre-processed, resident in HBM."""
+    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=seed)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    return wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+
+
+def engine_inputs(wm, bd, args, dev, n_step):
+    """Once-per-scene work (map encoder, traffic-light pre-compute, K/V tables) + the arguments of RolloutEngine.reset / refill."""
     R = args.rollouts
-    t0 = time.perf_counter()
     mp, tl = wm.encode_scene(bd, n_rollout=R)
-    torch.cuda.synchronize()
-    t_scene = time.perf_counter() - t0
     r = (lambda t: t.repeat_interleave(R, 0)) if R > 1 else (lambda t: t)
     n, A = args.scenes * R, args.agents
     g = torch.Generator().manual_seed(0)
@@ -297,13 +302,22 @@ def gpu_rollout_setup(tb, wm, full, args, dev):
     tf = wm.teacher_forcing_joint_future_pred
     tf.init(ag_valid=r(bd["sc/ag_valid"]), ag_pose=r(bd["sc/ag_pose"]), ag_motion=r(bd["sc/ag_motion"]),
             tl_state=r(bd["sc/tl_state"]), current_epoch=0)
+    return dict(gt_valid=r(bd["sc/ag_valid"]), gt_pose=r(bd["sc/ag_pose"]), gt_motion=r(bd["sc/ag_motion"]),
+                tl_state_gt=r(bd["sc/tl_state"]), tf_mask=tf.ag_teacher_forcing, ag_type=r(bd["ref/ag_type"]),
+                ag_attr=r(bd["sc/ag_attr"]), ag_latent=z, ag_latent_valid=valid, ag_navi=r(bd["gt/ag_navi"]), ag_navi_valid=valid,
+                mp_tokens=mp, tl_tokens=tl, map_valid=bd["map/valid"], map_type=bd["map/type"], map_pos=bd["map/pos"],
+                map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=n_step)
+
+
+def gpu_rollout_setup(tb, wm, full, args, dev):
+    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+    t0 = time.perf_counter()
+    kw = engine_inputs(wm, bd, args, dev, args.warmup + args.steps + 2 * args.profile_steps)
+    torch.cuda.synchronize()
+    t_scene = time.perf_counter() - t0
     Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
     eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
-    eng.reset(gt_valid=r(bd["sc/ag_valid"]), gt_pose=r(bd["sc/ag_pose"]), gt_motion=r(bd["sc/ag_motion"]),
-              tl_state_gt=r(bd["sc/tl_state"]), tf_mask=tf.ag_teacher_forcing, ag_type=r(bd["ref/ag_type"]),
-              ag_attr=r(bd["sc/ag_attr"]), ag_latent=z, ag_latent_valid=valid, ag_navi=r(bd["gt/ag_navi"]), ag_navi_valid=valid,
-              mp_tokens=mp, tl_tokens=tl, map_valid=bd["map/valid"], map_type=bd["map/type"], map_pos=bd["map/pos"],
-              map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=args.warmup + args.steps + 2 * args.profile_steps)
+    eng.reset(**kw)
     return eng, t_scene
 
 
@@ -577,6 +591,31 @@ def main():
         units = world * a.scenes * a.rollouts * a.agents * a.steps
         timing = {"value": units / dt, "ms_per_step": dt / a.steps * 1e3, "repeats": len(dts), "ms_per_step_min": min(dts) / a.steps * 1e3,
                   "ms_per_step_all": [d / a.steps * 1e3 for d in dts], "value_best": units / min(dts)}
+        # ---- scene-to-scene reuse (the reference's validation_step loops over scenes, waymo_motion.py:526): NEW scenes through the
+        # same engine - once-per-scene encoders + RolloutEngine.refill (in place: the captured graphs stay valid) + the W prime and K
+        # closed-loop steps, everything timed; scene tensors resident in HBM as in the headline. No graph capture in this loop.
+        reuse = None
+        if use_graph and a.new_scenes > 0 and world == 1:
+            first = shard_scenes(a.scenes * world, rank, world)[0]
+            bds = [scene_on_device(tb, wm, a, dev, first + 1000 + i) for i in range(a.new_scenes)]
+            torch.cuda.synchronize()
+            t_enc, t_all = [], time.perf_counter()
+            with E.use(wm.schedule):
+                for bd in bds:
+                    t0 = time.perf_counter()
+                    eng.refill(**engine_inputs(wm, bd, a, dev, a.warmup + a.steps + 2 * a.profile_steps))
+                    torch.cuda.synchronize()
+                    t_enc.append(time.perf_counter() - t0)
+                    eng.run(a.warmup + a.steps, use_graph=True)
+                torch.cuda.synchronize()
+            t_all = time.perf_counter() - t_all
+            reuse = {"scenes": a.new_scenes, "new_scene_ms": sorted(t_enc)[len(t_enc) // 2] * 1e3, "new_scene_ms_all": [t * 1e3 for t in t_enc],
+                     "end_to_end_value": a.new_scenes * a.scenes * a.rollouts * a.agents * a.steps / t_all,
+                     "ms_per_scene": t_all / a.new_scenes * 1e3,
+                     "note": "per new scene: map encoder + light pre-compute + K/V tables + RolloutEngine.refill (new_scene_ms), then W prime + K "
+                             "closed-loop steps on the graphs captured once for this shape; end_to_end_value counts the K steps' agent-steps "
+                             "over ALL of that time"}
+            eng.restore()
         if a.profile_steps <= 0:  # tooling only (timeline traces, A/B runs): the timed region without the per-kernel pass
             return {**timing, "roofline": None, "cpu_baseline": None,
                     "note": "--profile-steps 0: no per-kernel timing pass, not a judged line",
@@ -617,9 +656,12 @@ def main():
                                                     "achieved": sum(k["flops_per_launch"] * k["launches_per_step"] for k in mfma) /
                                                                 sum(k["avg_launch_us"] * 1e-6 * k["launches_per_step"] for k in mfma) / 1e12},
             "scene_encode_ms": t_scene * 1e3, "graph_capture_ms": t_cap * 1e3,
-            # SURVEY §8d "end-to-end": the once-per-scene work (map encoder, traffic-light pre-compute, table packing; this
-            # first call also pays one-time allocations) counted into the same units
-            "end_to_end_value": units / (dt + t_scene),
+            # SURVEY §8d "end-to-end": the once-per-scene work (map encoder, traffic-light pre-compute, K/V tables, engine refill)
+            # counted into the same units, over new scenes rolled through the SAME engine; the first scene of a process additionally
+            # pays scene_encode_ms (cold: allocations, weight packing) and graph_capture_ms once per shape
+            "end_to_end_value": reuse["end_to_end_value"] if reuse else units / (dt + t_scene),
+            "scene_reuse": reuse,
+            "first_scene_value": units / (dt + t_scene + t_cap),
             "finite": bool(torch.isfinite(eng.S["out_pose"]).all()),
         }
         if res["roofline_gemm"]:

@@ -221,6 +221,13 @@ typedef struct tbx_layer_tile {
   float norm2_eps, proj_norm_eps;
   int32_t ld_attn, ld_proj, proj_n, store_x;
   int64_t n_rows;
+  /* keyed dropouts of training's stepping pass (tbx_keyed_dropout's mask of (seed, site, step, row, column); drop_thresh = 0: none):
+   * site[0] on out_proj(.) before it is added to x (transformer_rpe.py:56-60,212-213), site[1] on the FFN's hidden rows (width 512),
+   * site[2] on linear2(.) before it is added (transformer_rpe.py:234-237). A site < 0 is skipped. */
+  const uint64_t* drop_seed;
+  uint32_t drop_thresh;
+  float drop_scale;
+  int32_t drop_site[3], drop_step;
 } tbx_layer_tile_t;
 int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
 /* tbx_heads_tile: the agents' heads (traffic_bots.py:206-221) for large launches, same arithmetic class as tbx_layer_tile:

@@ -438,7 +438,7 @@ def test_train_chain_kernels_vs_torch_state_machine(tb):
     assert bool((~navi.view(n, T, A)[:, -1] & navi.view(n, T, A)[:, 0]).any())  # some destinations were reached
 
 
-@pytest.mark.parametrize("sizes,knn", [((2, 8, 64, 8), 4), ((1, 64, 1024, 128), None)])
+@pytest.mark.parametrize("sizes,knn", [((2, 8, 64, 8), 4), ((1, 64, 1024, 128), None), ((16, 64, 64, 8), 4)])  # last: 1024 agent rows -> tbx_layer_tile with its keyed dropouts
 def test_nograd_policy_step_on_chain_kernels_equals_torch_ops_with_dropout(tb, sizes, knn):
     """The stepping pass of the time-batched rollout: with autograd off, train_graph runs whole layers as the inference engine's
     chain kernels (keyed dropouts as DROPOUT stages / inside the attention kernels). Same action means and light logits as the

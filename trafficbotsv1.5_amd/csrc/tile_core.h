@@ -102,6 +102,35 @@ __device__ __forceinline__ void planes_write4(char* p, int row, int c, const f32
   *(u32x2*)(p + PL::PLANE + o) = lo;
 }
 
+// tbx_keyed_dropout's mask (csrc/dropout.hip, rowchain.hip op_dropout) on the lane's 4 consecutive columns [c, c + 4) of global
+// row `row` of an n-wide block: keep = hash(seed, site, step, row * n + column) >= thresh
+struct DropKey4 {
+  uint32_t lo, hi, thresh;
+  float scale;
+  __device__ __forceinline__ void init(const uint64_t* seed, uint32_t site, uint32_t step, uint32_t thresh_, float scale_) {
+    const uint64_t sd = *(const TBX_GLOBAL uint64_t*)seed;
+    lo = (uint32_t)sd ^ (site * 0x85EBCA6Bu) ^ (step * 0x27D4EB2Fu);
+    hi = (uint32_t)(sd >> 32) + site * 0xC2B2AE35u + step * 0x165667B1u;
+    thresh = thresh_, scale = scale_;
+  }
+  __device__ __forceinline__ f32x4 apply(f32x4 v, int64_t row, int c, int n) const {
+    const uint32_t base = (uint32_t)row * (uint32_t)n + (uint32_t)c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t x = (base + (uint32_t)r) ^ lo;
+      x *= 0x9E3779B1u;
+      x ^= hi;
+      x ^= x >> 16;
+      x *= 0x7feb352du;
+      x ^= x >> 15;
+      x *= 0x846ca68bu;
+      x ^= x >> 16;
+      v[r] = x >= thresh ? v[r] * scale : 0.f;
+    }
+    return v;
+  }
+};
+
 __device__ __forceinline__ f32x4 gld4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
 __device__ __forceinline__ void gst4(float* p, const f32x4 v) { *(TBX_GLOBAL f32x4*)p = v; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {

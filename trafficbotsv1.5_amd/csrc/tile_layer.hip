@@ -138,7 +138,13 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, s);
       f32x4 xv = *(const f32x4*)(X + j * XLD + c_out);
-      if (!f_nov) xv += acc.sum() + w.bias;
+      f32x4 upd = acc.sum() + w.bias;
+      if (t.drop_thresh != 0u && t.drop_site[0] >= 0) {
+        DropKey4 dk;
+        dk.init(t.drop_seed, (uint32_t)t.drop_site[0], (uint32_t)t.drop_step, t.drop_thresh, t.drop_scale);
+        upd = dk.apply(upd, row0 + j, c_out, D);
+      }
+      if (!f_nov) xv += upd;
       *(f32x4*)(X + j * XLD + c_out) = xv;
       if (!FFN && t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
     }
@@ -149,6 +155,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.norm2_weight, t.norm2_bias, t.norm2_eps);
     __syncthreads();
+    const bool drop_h = t.drop_thresh != 0u && t.drop_site[1] >= 0;
+    DropKey4 dkh;
+    if (drop_h) dkh.init(t.drop_seed, (uint32_t)t.drop_site[1], (uint32_t)t.drop_step, t.drop_thresh, t.drop_scale);
     // h = relu(linear1(.)): 4 rounds of 128 channels
 #define TBX_L1(R)                                                                               \
   do {                                                                                          \
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
-    const f32x4 h = relu4(acc.sum() + w.bias);                                                  \
+    f32x4 h = relu4(acc.sum() + w.bias);                                                        \
+    if (drop_h) h = dkh.apply(h, row0 + j, (R) * D + c_out, 4 * D);                             \
     planes_write4<PL>(Pb, j, (R) * D + c_out, h);                                                   \
   } while (0)
     TBX_L1(0);
@@ -182,7 +192,13 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       TBX_L2(2);
       TBX_L2(3);
 #undef TBX_L2
-      f32x4 xv = *(const f32x4*)(X + j * XLD + c_out) + (acc.sum() + bias);
+      f32x4 upd = acc.sum() + bias;
+      if (t.drop_thresh != 0u && t.drop_site[2] >= 0) {
+        DropKey4 dk;
+        dk.init(t.drop_seed, (uint32_t)t.drop_site[2], (uint32_t)t.drop_step, t.drop_thresh, t.drop_scale);
+        upd = dk.apply(upd, row0 + j, c_out, D);
+      }
+      f32x4 xv = *(const f32x4*)(X + j * XLD + c_out) + upd;
       if (f_inv) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(X + j * XLD + c_out) = xv;
       if (t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
@@ -348,6 +364,7 @@ extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
                t.ld_proj < (proj == 2 ? 7 * D : 5 * D) || t.ld_proj % 4 != 0))
     return TBX_ERR_ARG;
   if (t.kv16_out != nullptr && proj != 2) return TBX_ERR_ARG;
+  if (t.drop_thresh != 0u && t.drop_seed == nullptr) return TBX_ERR_ARG;
   if ((((uintptr_t)t.x) | ((uintptr_t)t.attn_out) | ((uintptr_t)t.proj_out)) & 15) return TBX_ERR_ALIGN;
   TileArgs a;
   a.t = t;

@@ -355,10 +355,22 @@ def emit_first_proj(ch: Chain, block, fp: dict, x_buf: int) -> None:
     emit_proj(ch, 0, l0.norm_src if dec else l0.norm1, l0.attn_src if dec else l0.attn, fp["qkv"], with_kv=True, kv16=fp["kv16"], x_buf=x_buf)
 
 
-def tile_rows_ok(rows: int) -> bool:
-    """Launches whose row-local chains run as tbx_layer_tile (inference, past the live-row sizes)."""
+def tile_rows_ok(rows: int, keyed_dropout: bool = False) -> bool:
+    """Launches whose row-local work runs as tile kernels (past the live-row sizes). keyed_dropout: the caller's kernel takes the
+    keyed dropouts of training's stepping pass (tbx_layer_tile does; the heads / window kernels are inference only)."""
     c = current()
-    return c.tile_layer and DROP_CTX is None and not live_rows_for(rows) and rows >= c.tile_min_rows and not c.attn_fold_big
+    if DROP_CTX is not None and not keyed_dropout:
+        return False
+    return c.tile_layer and not live_rows_for(rows) and rows >= c.tile_min_rows and not c.attn_fold_big
+
+
+def _tile_drop(*sites) -> Optional[dict]:
+    """hip.layer_tile's `drop` from up to three drop_site() results (attention residual, FFN hidden, FFN output)."""
+    live = [d for d in sites if d is not None]
+    if not live:
+        return None
+    p, seed, _, step = live[0]
+    return dict(p=p, seed=seed, step=step, sites=tuple(None if d is None else d[2] for d in sites) + (None,) * (3 - len(sites)))
 
 
 def _img(w, b=None, **kw):
@@ -442,7 +454,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
     def first_norm(l):
         return layers[l].norm_src if dec else layers[l].norm1
 
-    tile = drop is None and tile_rows_ok(rows)
+    tile = tile_rows_ok(rows, keyed_dropout=True)
     if first_proj is None and tile:
         hip.layer_tile(x, proj=tile_proj_part(first_norm(0), first_attn(0), qkv, True, kv16), store_x=False)
     elif first_proj is None:
@@ -515,12 +527,14 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         if tile:  # the layer's row-local chains as tbx_layer_tile launches (split-bf16 MFMA stages, no program to interpret)
             a_last = a1
             if dec:
-                hip.layer_tile(x, attn=tile_attn_part(a1, obuf, flag), proj=tile_proj_part(layer.norm1, layer.attn, q2, False))
-                hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw)
+                hip.layer_tile(x, attn=tile_attn_part(a1, obuf, flag), proj=tile_proj_part(layer.norm1, layer.attn, q2, False),
+                               drop=_tile_drop(next_site()))
+                hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
                 a_last = layer.attn
             last = l + 1 == len(layers)
             hip.layer_tile(x, attn=tile_attn_part(a_last, obuf, flag), ffn=tile_ffn_part(layer, src_invalid),
-                           proj=None if last else tile_proj_part(first_norm(l + 1), first_attn(l + 1), qkv, True, kv16))
+                           proj=None if last else tile_proj_part(first_norm(l + 1), first_attn(l + 1), qkv, True, kv16),
+                           drop=_tile_drop(next_site(), next_site(), next_site()))
             if last and tail is not None:  # the caller's row-local stages on the finished rows: a short chain of their own
                 ch = layer_chain(rows)
                 ch.load(x, BUF1, 0, n=D)

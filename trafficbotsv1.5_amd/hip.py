@@ -85,7 +85,9 @@ class LayerTile(C.Structure):
                                            "linear1_image", "linear2_image", "src_invalid", "proj_norm_weight", "proj_norm_bias", "proj_image",
                                            "qfold_image", "proj_out", "kv16_out")]
                 + [("norm2_eps", C.c_float), ("proj_norm_eps", C.c_float)]
-                + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)])
+                + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)]
+                + [("drop_seed", C.c_void_p), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_site", C.c_int32 * 3),
+                   ("drop_step", C.c_int32)])
 
 
 class HeadsTile(C.Structure):
@@ -606,11 +608,12 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
-def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True):
+def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None):
     """tbx_layer_tile on the token rows x [rows, 128] (in place). Each part is None or a dict:
     attn = dict(out [rows, >= 640], row_no_valid u8 [rows], fold, out_proj (mfma32 images));
     ffn = dict(norm2 (w, b, eps), linear1, linear2 (images), src_invalid u8 [rows] | None);
-    proj = dict(norm (w, b, eps), image, qfold (images), n = 128 | 384, out [rows, >= 640 | 896], kv16 = bf16 [rows, 256] | None)."""
+    proj = dict(norm (w, b, eps), image, qfold (images), n = 128 | 384, out [rows, >= 640 | 896], kv16 = bf16 [rows, 256] | None);
+    drop = the keyed dropouts of training's stepping pass (see below)."""
     a = LayerTile()
     a.x, a.n_rows, a.store_x = _cptr(x, torch.float32), x.shape[0], int(store_x)
     assert x.dim() == 2 and x.shape[1] == 128
@@ -635,6 +638,13 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True):
         if kv16 is not None:
             assert kv16.shape == (x.shape[0], 256) and kv16.is_contiguous()
             a.kv16_out = _ptr(kv16, torch.bfloat16)
+    if drop is not None:  # dict(p, seed int64[1] device tensor, step, sites = (attention residual, FFN hidden, FFN output) | None each)
+        th = drop["p"] * 4294967296.0
+        a.drop_thresh = 1 if 0 < th < 1 else int(th)
+        a.drop_scale = 1.0 / (1.0 - drop["p"])
+        a.drop_seed, a.drop_step = _ptr(drop["seed"], torch.int64), int(drop["step"])
+        for i, st in enumerate(drop["sites"]):
+            a.drop_site[i] = -1 if st is None else int(st)
     _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
 
 
