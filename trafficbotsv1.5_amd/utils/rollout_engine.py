@@ -204,7 +204,7 @@ class RolloutEngine:
             self._tl_ahead(0)
 
     @staticmethod
-    def shape_key(*, gt_valid, tl_state_gt, map_valid, n_step, stepwise, mp_tokens, tl_tokens, ag_latent, **_):
+    def shape_key(*, gt_valid, tl_state_gt, map_valid, n_step, mp_tokens, tl_tokens, ag_latent, stepwise=False, **_):
         """What must agree for `refill` (same buffers, same captured graphs): every shape the engine's buffers depend on."""
         tok = lambda d: tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items() if torch.is_tensor(v))) + tuple(
             sorted((k, v) for k, v in d.items() if isinstance(v, int)))
