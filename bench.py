@@ -188,12 +188,12 @@ class KernelEvents:
                 return T("chain_live", 0, fl, sv["Chain.run"], ch, n_rows, group_rows)
             return T("chain", ch.tile_rows, fl, sv["Chain.run"], ch, n_rows, group_rows)
 
-        def lt(x, attn=None, ffn=None, proj=None, store_x=True):
+        def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None):
             rows = x.shape[0]
             mac = (2 * 128 * 128 if attn is not None else 0) + (2 * 128 * 512 if ffn is not None else 0)
             if proj is not None:
                 mac += 128 * proj["n"] + 128 * 128
-            return T("tile", "layer", 2.0 * rows * mac, sv["layer_tile"], x, attn=attn, ffn=ffn, proj=proj, store_x=store_x)
+            return T("tile", "layer", 2.0 * rows * mac, sv["layer_tile"], x, attn=attn, ffn=ffn, proj=proj, store_x=store_x, drop=drop)
 
         def ht(x, hd):
             return T("tile", "heads", 2.0 * x.shape[0] * (2 * (256 * 128 + 2 * 128 * 128) + 128 * 384 + 3 * 128 * 128 + 3 * 128 * 16), sv["heads_tile"], x, hd)
