@@ -602,6 +602,7 @@ def main():
             t_enc, t_all = [], time.perf_counter()
             with E.use(wm.schedule):
                 for bd in bds:
+                    torch.cuda.synchronize()  # (attribution only: the previous scene's rollout is done before this one's clock starts)
                     t0 = time.perf_counter()
                     eng.refill(**engine_inputs(wm, bd, a, dev, a.warmup + a.steps + 2 * a.profile_steps))
                     torch.cuda.synchronize()

@@ -22,7 +22,8 @@ rm -rf "$out/kt_$tag"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace -d "$out/pmc_${tag}_$ctr" -o p -- python3 $pmc > "$out/${tag}_pmc_$ctr.log" 2>&1
 done
-python3 tools/rocpd_pmc.py $wl --cmd "python3 $pmc" $(find "$out/pmc_${tag}_FETCH_SIZE" "$out/pmc_${tag}_WRITE_SIZE" -name '*.db') \
+bf=""; case " $* " in *" --kv-bf16 "*) bf="--kv-bf16";; esac
+python3 tools/rocpd_pmc.py $wl $bf --cmd "python3 $pmc" $(find "$out/pmc_${tag}_FETCH_SIZE" "$out/pmc_${tag}_WRITE_SIZE" -name '*.db') \
   > "$out/${tag}_pmc.json" 2>> "$out/${tag}_bench.log"
 rm -rf "$out/pmc_${tag}_FETCH_SIZE" "$out/pmc_${tag}_WRITE_SIZE"
 grep -h '"metric"' "$out/${tag}_bench.log" | cut -c1-200
