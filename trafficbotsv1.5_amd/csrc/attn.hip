@@ -69,7 +69,7 @@ struct AttnArgs {
 constexpr int FOLD_ROWS = 1 + (DR / 16) * 4;  // float4 rows of the value-fold image: a bias row + 32 weight rows of [128][4]
 
 template <int WPR, bool DROP, bool KV16 = false, bool FOLD = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR <= 2 ? 2 : 1))) void knarpe_attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 2 : 1))) void knarpe_attn_kernel(const AttnArgs a) {
   constexpr int OUTW = D + NH * DR;  // 640
   __shared__ float red_s[WPR > 1 ? WPR : 1][WPR > 1 ? (OUTW + 2 * NH) : 1];
   __shared__ __attribute__((aligned(16))) float fold_s[FOLD ? FOLD_ROWS * D * 4 : 4];  // 66 KiB: the fold image, by LDS-DMA
@@ -842,22 +842,8 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   a.out = out;
   a.row_no_valid = row_no_valid;
   const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on (below: 4 waves split a row's targets)
-  // in between (a wave per row would leave SIMDs with one wave or none: 1024 rows = 1024 waves on 1024 SIMDs): two waves per row
-  static const int mid_rows = [] { const char* e = getenv("TBX_ATTN_WPR2_ROWS"); return e ? atoi(e) : 3072; }();
-  const bool mid = big && a.n_rows < mid_rows;
-  const dim3 grid(mid ? (a.n_rows + 1) / 2 : (big ? (a.n_rows + 3) / 4 : a.n_rows)), block(256);
+  const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
-  if (mid) {
-    if (segs[0].kv_bf16 != 0) {
-      if (a.drop_thresh != 0u) return TBX_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((knarpe_attn_kernel<2, false, true>), grid, block, 0, hs, a);
-    } else if (a.drop_thresh != 0u) {
-      hipLaunchKernelGGL((knarpe_attn_kernel<2, true>), grid, block, 0, hs, a);
-    } else {
-      hipLaunchKernelGGL((knarpe_attn_kernel<2, false>), grid, block, 0, hs, a);
-    }
-    return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
-  }
   // the LDS-ring form (opt-in, TBX_ATTN_RING=1 / 2): large launches without dropout whose segments are all given as relative poses
   static const int ring_mode = [] { const char* e = getenv("TBX_ATTN_RING"); return e ? atoi(e) : 0; }();  // measured: no gain, opt-in
   bool ring_ok = big && ring_mode != 0 && a.drop_thresh == 0u;
