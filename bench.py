@@ -472,10 +472,12 @@ def train_main(args, tb, dev, rank, world, dist):
 
     live = None
     if args.no_train_graph:
-        step = lambda: DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live)
+        state = {"live": None}
+        step = lambda: DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=state["live"])
         for _ in range(args.warmup):
             step()
-            live = live or DP.live_parameters(wm.model)
+            state["live"] = state["live"] or DP.FlatGrads(DP.live_parameters(wm.model))  # gradients accumulate into ONE buffer from here on
+        live = state["live"].params
     else:
         # forward + backward replayed as one hipGraph (the eager step is bound by the host's launch rate); the gradient
         # all-reduce, the clip and AdamW stay outside the graph. Capture (2 eager warm-up steps inside) is untimed.

@@ -651,3 +651,106 @@ def test_fused_transformer_glue_equals_the_aten_ops(tb, rows, cols, dropout):
     for u, v in zip(res[True][:4], res[False][:4]):
         assert torch.equal(u, v)
     assert bool((res[True][1][zo] == 0).all())
+
+
+def test_modules_in_train_mode_run_the_differentiable_path(tb):
+    """The reference's modules run in train() with their default dropouts (transformer_rpe.py:207-245, mlp.py:58-72,
+    polyline_encoder.py:49-61, add_navi_latent.py:52-65): here `TransformerBlockRPE / AttentionRPE / MLP / PolylineEncoder /
+    AddNaviLatent.forward` in train mode take the training path (HIP attention forward / backward, keyed dropout, autograd).
+    Checked through the reference signatures: p = 0 in train mode == eval mode (values), gradients == the oracle's autograd;
+    p = 0.1: masks are live (outputs differ from eval, about 10 % of an MLP's outputs are zeroed), reproducible under
+    torch.manual_seed, gradients finite and flowing to every parameter."""
+    from oracle import hptr_ops as H
+
+    dev = torch.device("cuda:0")
+    M = import_module("trafficbots_amd.models.modules")
+    g = torch.Generator().manual_seed(3)
+    n, S, K, Ks, d = 2, 19, 9, 5, 128
+    src = torch.randn(n, S, d, generator=g)
+    tgt = torch.randn(n, S, K, d, generator=g)
+    rpe = torch.randn(n, S, K, d, generator=g)
+    m = torch.rand(n, S, K, generator=g) < 0.3
+    src_inv = torch.rand(n, S, generator=g) < 0.2
+    m[src_inv] = True
+    idx_self = torch.randint(0, S, (n, S, Ks), generator=g)
+    m_self = torch.rand(n, S, Ks, generator=g) < 0.3
+    m_self[src_inv] = True
+    rpe_self = torch.randn(n, S, Ks, d, generator=g)
+    to = lambda t: t.to(dev)
+
+    def build(p):
+        blk = M.transformer_rpe.TransformerBlockRPE(n_layer=2, mode="dec_cross_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4,
+                                                    dropout_p=p, bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+        tb.utils.det_fill(blk, 5)
+        return blk.to(dev)
+
+    def call(blk, x):
+        return blk(src=x, src_padding_mask=to(src_inv), tgt=to(tgt), tgt_padding_mask=to(m), rpe=to(rpe), decoder_tgt=to(idx_self),
+                   decoder_tgt_padding_mask=to(m_self), decoder_rpe=to(rpe_self))[0]
+
+    blk0 = build(0.0)
+    y_eval = call(blk0.eval(), to(src))
+    x = to(src).requires_grad_(True)
+    y_tr = call(blk0.train(), x)
+    torch.testing.assert_close(y_tr.detach(), y_eval, rtol=2e-4, atol=2e-5 + 2e-4 * float(y_eval.abs().max()))
+    y_tr.square().sum().backward()
+    # oracle autograd on the CPU
+    P = {"t." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk0.state_dict().items()}
+    xs = src.clone().requires_grad_(True)
+    ref = H.transformer_block(P, "t", "dec_cross_attn", 2, 4, xs, src_inv, tgt, m, rpe, idx_self, m_self, rpe_self)
+    ref.square().sum().backward()
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+    assert close(x.grad.cpu(), xs.grad, 2e-3)
+    for k, p_ in blk0.named_parameters():
+        gref = P["t." + k].grad
+        if gref is None:
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+        else:
+            assert close(p_.grad.cpu(), gref, 2e-3), k
+    # p = 0.1: live, reproducible masks
+    blk = build(0.1).train()
+    torch.manual_seed(7)
+    y1 = call(blk, to(src))
+    torch.manual_seed(7)
+    y2 = call(blk, to(src))
+    torch.manual_seed(8)
+    y3 = call(blk, to(src))
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    assert float((y1 - call(blk.eval(), to(src))).abs().max()) > 1e-3
+    blk.train()
+    xg = to(src).requires_grad_(True)
+    call(blk, xg).square().sum().backward()
+    assert torch.isfinite(xg.grad).all() and all(p_.grad is None or torch.isfinite(p_.grad).all() for p_ in blk.parameters())
+
+    # AttentionRPE / MLP / PolylineEncoder / AddNaviLatent in train mode
+    att = M.attention_rpe.AttentionRPE(d_model=128, n_head=4, dropout_p=0.1, d_rpe=128)
+    tb.utils.det_fill(att, 6)
+    att = att.to(dev).train()
+    xa = to(src).requires_grad_(True)
+    ya = att(xa, to(tgt), tgt_padding_mask=to(m), rpe=to(rpe))[0]
+    ya.sum().backward()
+    assert torch.isfinite(ya).all() and torch.isfinite(xa.grad).all() and att.in_proj_weight.grad is not None
+    assert float((ya - att.eval()(to(src), to(tgt), tgt_padding_mask=to(m), rpe=to(rpe))[0]).abs().max()) > 1e-4
+    mlp = M.mlp.MLP([64, 128, 128], dropout_p=0.1).to(dev).train()
+    xm = torch.randn(500, 64, generator=g).to(dev).requires_grad_(True)
+    ym = mlp(xm)
+    frac0 = float((ym == 0).float().mean())
+    assert 0.05 < frac0 < 0.75  # relu zeros + ~10 % dropped
+    ym.sum().backward()
+    assert torch.isfinite(xm.grad).all()
+    pe = M.polyline_encoder.PolylineEncoder(hidden_dim=128, n_layer=3, mlp_use_layernorm=False, mlp_dropout_p=0.1, use_pointnet=True,
+                                            pooling_mode="max_valid").to(dev).train()
+    xp = torch.randn(2, 30, 11, 128, generator=g).to(dev).requires_grad_(True)
+    ip = (torch.rand(2, 30, 11, generator=g) < 0.3).to(dev)
+    yp = pe(xp, ip)
+    yp.sum().backward()
+    assert yp.shape == (2, 30, 128) and torch.isfinite(xp.grad).all()
+    an = M.add_navi_latent.AddNaviLatent(hidden_dim=128, in_dim=16, dummy=False, mode="cat", n_layer=3, mlp_use_layernorm=False,
+                                         mlp_dropout_p=0.1, res_add=True).to(dev).train()
+    xn = torch.randn(2, 9, 128, generator=g).to(dev).requires_grad_(True)
+    zn = torch.randn(2, 9, 16, generator=g).to(dev)
+    zv = (torch.rand(2, 9, generator=g) < 0.8).to(dev)
+    yn = an(xn, zn, zv)
+    yn.sum().backward()
+    assert torch.isfinite(yn).all() and torch.isfinite(xn.grad).all()
+    torch.testing.assert_close(yn[~zv], xn.detach()[~zv])  # rows without a valid z pass through

@@ -100,3 +100,44 @@ def test_gradient_allreduce_equals_full_batch(tmp_path):
     for a, b, p in zip(g0, g1, net.parameters()):
         assert torch.equal(a, b)  # every rank ends with the same averaged gradient
         torch.testing.assert_close(a, p.grad, rtol=1e-6, atol=1e-7)  # = gradient of the full batch
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from importlib import import_module
+
+    from __graft_entry__ import load_package
+
+    load_package()
+    dp = import_module("trafficbots_amd.pl_modules.data_parallel")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    x = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    xs = x[rank * 2:(rank + 1) * 2]
+    net(xs).pow(2).mean().backward()  # first backward: finds the live parameters
+    fg = dp.FlatGrads(dp.live_parameters(net))
+    for _ in range(2):  # two further steps: backward accumulates straight into the flat buffer, which is what travels
+        fg.zero()
+        fg.attach()
+        net(xs).pow(2).mean().backward()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(fg.params, fg.views))  # still views: nothing was re-allocated
+        nbytes = dp.allreduce_gradients(fg)
+    assert nbytes == fg.nbytes == sum(p.numel() for p in net.parameters()) * 4
+    torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f"f{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_buffer_allreduce_equals_full_batch(tmp_path):
+    """FlatGrads (the live gradients as views of one persistent buffer, all-reduced in place): 2 ranks x half the batch each ==
+    the full batch's gradient, on every rank, with no gather / scatter copies."""
+    world, port = 2, 29547
+    mp.spawn(_flat_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = torch.load(tmp_path / "f0.pt"), torch.load(tmp_path / "f1.pt")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    x = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    net(x).pow(2).mean().backward()
+    for a, b, p in zip(g0, g1, net.parameters()):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, p.grad, rtol=1e-6, atol=1e-7)

@@ -113,8 +113,16 @@ class AddNaviLatent(nn.Module):
     def forward(self, x: Tensor, z: Optional[Tensor], z_valid: Optional[Tensor] = None) -> Tensor:
         if self.dummy:
             return x
-        if self.training and self.mlp_dropout_p > 0:
-            raise NotImplementedError("dropout inside the HIP chain is not implemented yet (train with p = 0)")
+        if self.training:  # add_navi_latent.py:52-65 in train mode (train_graph.add_navi_latent)
+            from ... import train_graph as TG
+
+            lead0 = x.shape[:-1]
+            x0 = x.reshape(-1, self.hidden_dim).contiguous().float()
+            z0 = z.reshape(-1, self.in_dim).contiguous().float()
+            zi0 = torch.zeros(x0.shape[0], dtype=torch.bool, device=x.device) if z_valid is None else (~z_valid).reshape(-1)
+            with TG.module_scope(1, x.device):
+                y = TG.add_navi_latent(self, x0, z0, zi0, True)
+            return y.view(*lead0, self.hidden_dim)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.hidden_dim).contiguous().float()
         z2 = z.reshape(-1, self.in_dim).contiguous().float()

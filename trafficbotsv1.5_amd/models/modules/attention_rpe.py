@@ -38,6 +38,15 @@ class AttentionRPE(nn.Module):
         n, S, K, d = tgt.shape
         dev = src.device
         x = src.reshape(n * S, d).contiguous().float()
+        if self.training:  # attention_rpe.py:83-198 in train mode: autograd + keyed probability dropout (train_graph.attention)
+            from ... import train_graph as TG
+
+            idx = torch.arange(S * K, dtype=torch.int32, device=dev).view(1, S, K).expand(n, -1, -1).contiguous()
+            t = TG.Targets(tgt.reshape(n * S * K, d).contiguous().float(), idx, tgt_padding_mask.to(torch.uint8).contiguous(),
+                           rpe.contiguous().float(), S * K)
+            with TG.module_scope(n, dev):
+                y = TG.attention(self, x, [t], [TG.kv_table(self, None, t)], n, S)
+            return y.view(n, S, d), None
         # per-pair K/V projection (what the reference does): a table with one row per (src, tgt) pair
         t2 = tgt.reshape(n * S * K, d).contiguous().float()
         kv = torch.empty(n * S * K, 2 * d, dtype=torch.float32, device=dev)

@@ -54,8 +54,16 @@ class MLP(nn.Module):
         return out
 
     def forward(self, x: Tensor, mask_invalid: Optional[Tensor] = None, fill_invalid: float = 0.0) -> Tensor:
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout inside the HIP chain is not implemented yet (train with p = 0)")
+        if self.training:  # mlp.py:58-72 in train mode: library GEMMs + autograd, keyed dropout (train_graph.mlp)
+            from ... import train_graph as TG
+
+            lead0 = x.shape[:-1]
+            x0 = x.reshape(-1, self.input_dim).contiguous().float()
+            with TG.module_scope(1, x.device):
+                y = TG.mlp(self, x0, True)
+            if mask_invalid is not None:
+                y = y.masked_fill(mask_invalid.reshape(-1, 1).bool(), fill_invalid)
+            return y.view(*lead0, self.output_dim)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.input_dim).contiguous().float()
         rows = x2.shape[0]

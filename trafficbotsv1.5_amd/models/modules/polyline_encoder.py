@@ -20,9 +20,13 @@ class PolylineEncoder(nn.Module):
 
     def forward(self, x: Tensor, invalid: Tensor) -> Tensor:
         """x [n_sc, n_mp, n_node, d], invalid [n_sc, n_mp, n_node] -> [n_sc, n_mp, d]."""
-        if self.training and self.mlp_dropout_p > 0:
-            raise NotImplementedError("dropout inside the HIP chain is not implemented yet (train with p = 0)")
         n_sc, n_mp, n_node, d = x.shape
+        if self.training:  # polyline_encoder.py:49-61 in train mode (train_graph.pointnet: fused relu / dropout / masked max + autograd)
+            from ... import train_graph as TG
+
+            with TG.module_scope(n_sc, x.device):
+                y = TG.pointnet(self, x.reshape(n_sc * n_mp, n_node, d).contiguous().float(), invalid.reshape(n_sc * n_mp, n_node).bool(), True)
+            return y.view(n_sc, n_mp, d)
         x2 = x.reshape(-1, d).contiguous().float()
         inv = invalid.reshape(-1).to(torch.uint8).contiguous()
         out = torch.empty(n_sc * n_mp, d, dtype=torch.float32, device=x.device)

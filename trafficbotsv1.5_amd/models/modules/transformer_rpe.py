@@ -41,9 +41,31 @@ class TransformerBlockRPE(nn.Module):
             TransformerRPE(d_model, n_head, k_feedforward, dropout_p, bias, activation, mode, d_rpe, apply_q_rpe)
             for _ in range(n_layer)])
 
-    def _check_mode(self):
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout inside the HIP kernels is not implemented yet (train with p = 0)")
+    def _forward_train(self, src, src_padding_mask, tgt, tgt_padding_mask, rpe, decoder_tgt, decoder_tgt_padding_mask, decoder_rpe):
+        """train(): the differentiable path of training (train_graph.transformer_block: HIP attention forward / backward with keyed
+        probability dropout, keyed residual / FFN dropouts, autograd through the projections) - transformer_rpe.py:207-245."""
+        from ... import train_graph as TG
+
+        n, S, d = src.shape
+        dev = src.device
+        x = src.reshape(n * S, d).contiguous().float()
+        inv = src_padding_mask if src_padding_mask is not None else torch.zeros(n, S, dtype=torch.bool, device=dev)
+        u8 = lambda m: m.to(torch.uint8).contiguous()
+        if self.mode == "enc_self_attn":
+            knn = dict(idx=tgt.to(torch.int32).contiguous(), invalid=u8(tgt_padding_mask), emb=rpe.float().contiguous())
+            cross = None
+        elif self.mode == "dec_cross_attn":
+            knn = dict(idx=decoder_tgt.to(torch.int32).contiguous(), invalid=u8(decoder_tgt_padding_mask), emb=decoder_rpe.float().contiguous())
+            K = tgt.shape[2]
+            tokens = tgt.reshape(n * S * K, d).contiguous().float()  # the gathered cross targets as a table of S * K rows per entry
+            idx = torch.arange(S * K, dtype=torch.int32, device=dev).view(1, S, K).expand(n, -1, -1).contiguous()
+            m, e = u8(tgt_padding_mask), rpe.float().contiguous()
+            cross = lambda layer: [TG.Targets(tokens, idx, m, e, S * K)]
+        else:
+            raise NotImplementedError("enc_cross_attn is only used by the non-default RNN variant")
+        with TG.module_scope(n, dev):
+            y = TG.transformer_block(self, x, inv, n, S, knn, cross, p=self.dropout_p, training=True)
+        return y.view(n, S, d), None
 
     def forward(self, src: Tensor, src_padding_mask: Optional[Tensor] = None, tgt: Optional[Tensor] = None,
                 tgt_padding_mask: Optional[Tensor] = None, rpe: Optional[Tensor] = None, decoder_tgt: Optional[Tensor] = None,
@@ -51,9 +73,10 @@ class TransformerBlockRPE(nn.Module):
                 attn_mask: Optional[Tensor] = None, need_weights: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference signature (transformer_rpe.py:48-81). `tgt` (enc_self_attn) / `decoder_tgt` (dec_cross_attn) are
         integer KNN indices [n,S,K]; the cross targets of dec_cross_attn are gathered features [n,S,K,d]."""
-        self._check_mode()
         if attn_mask is not None or need_weights:
             raise NotImplementedError
+        if self.training:
+            return self._forward_train(src, src_padding_mask, tgt, tgt_padding_mask, rpe, decoder_tgt, decoder_tgt_padding_mask, decoder_rpe)
         n, S, d = src.shape
         x = src.reshape(n * S, d).contiguous().float().clone()
         inv = src_padding_mask if src_padding_mask is not None else torch.zeros(n, S, dtype=torch.bool, device=src.device)

@@ -22,21 +22,70 @@ def live_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
     return [p for p in module.parameters() if p.requires_grad and p.grad is not None]
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: Optional[int] = None, group=None) -> int:
-    """Average the gradients of `params` across ranks in place with one flat all-reduce. Returns the bytes exchanged."""
+class FlatGrads:
+    """ONE persistent fp32 buffer whose slices ARE the live parameters' `.grad` tensors (what DDP calls gradient_as_bucket_view):
+    backward accumulates straight into it, the exchange is one all-reduce on the buffer itself - no gather copy before it, no
+    per-parameter copy back after it - and a captured training step writes the same addresses at every replay.
+    Zeroed by `zero()` (a fill kernel: capturable, unlike a memset node on this runtime) before each backward."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]) -> None:
+        self.params = [p for p in params]
+        assert self.params, "no live parameters"
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is not None:
+                v.copy_(p.grad)
+            self.views.append(v)
+            off += p.numel()
+        self.attach()
+
+    def attach(self) -> None:
+        """(Re-)point every parameter's .grad at its slice (a zero_grad(set_to_none=True) elsewhere detaches them)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def zero(self) -> None:
+        self.flat.fill_(0.0)
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def allreduce(self, world_size: Optional[int] = None, group=None) -> int:
+        """Average across ranks, in place: one all-reduce on the buffer (RCCL over xGMI) + one scale. Returns the bytes exchanged."""
+        if not dist.is_available() or not dist.is_initialized():
+            return 0
+        world_size = world_size or dist.get_world_size(group)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if world_size > 1:
+            self.flat.mul_(1.0 / world_size)
+        return self.nbytes
+
+
+def allreduce_gradients(params, world_size: Optional[int] = None, group=None) -> int:
+    """Average the gradients of `params` across ranks in place with one flat all-reduce. Returns the bytes exchanged.
+    `params`: a FlatGrads (the gradients already live in one buffer: nothing is copied) or an iterable of parameters (their
+    gradients are gathered into a temporary flat buffer and scattered back by two multi-tensor copies)."""
+    if isinstance(params, FlatGrads):
+        return params.allreduce(world_size, group)
     params = [p for p in params if p.grad is not None]
     if not params or not dist.is_available() or not dist.is_initialized():
         return 0
     world_size = world_size or dist.get_world_size(group)
     # (a one-rank group still takes the exchange: the flat buffer, the RCCL call and the copy back are then exercised on one GPU)
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    flat = torch.empty(sum(p.grad.numel() for p in params), dtype=params[0].grad.dtype, device=params[0].grad.device)
+    views, off = [], 0
+    for p in params:
+        views.append(flat[off:off + p.grad.numel()].view_as(p.grad))
+        off += p.grad.numel()
+    grads = [p.grad for p in params]
+    torch._foreach_copy_(views, grads)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    torch._foreach_copy_(grads, views)
     return flat.numel() * flat.element_size()
 
 
@@ -79,15 +128,23 @@ def parameters_checksum(module: torch.nn.Module) -> Tensor:
 
 
 def train_step(wm, optimizer: torch.optim.Optimizer, batch: Dict[str, Tensor], clip_grad_norm: float = 5.0,
-               live: Optional[List[torch.nn.Parameter]] = None) -> Dict[str, Tensor]:
-    """fwd + bwd + gradient all-reduce + clip (trainer/default.yaml:13 gradient_clip_val 5.0) + optimizer step."""
-    optimizer.zero_grad(set_to_none=True)
+               live=None) -> Dict[str, Tensor]:
+    """fwd + bwd + gradient all-reduce + clip (trainer/default.yaml:13 gradient_clip_val 5.0) + optimizer step.
+    live: None (first step: the live parameters are found after the backward), a list of parameters, or a FlatGrads over them
+    (gradients accumulate into its buffer, which is what travels)."""
+    if isinstance(live, FlatGrads):
+        optimizer.zero_grad(set_to_none=True)  # (the parameters without a gradient path stay None)
+        live.zero()
+        live.attach()
+    else:
+        optimizer.zero_grad(set_to_none=True)
     loss = wm.training_step(batch, 0)
     loss.backward()
     params = live if live is not None else live_parameters(wm.model)
     allreduce_gradients(params)
+    plist = params.params if isinstance(params, FlatGrads) else params
     if clip_grad_norm and clip_grad_norm > 0:
-        torch.nn.utils.clip_grad_norm_(params, clip_grad_norm)
+        torch.nn.utils.clip_grad_norm_(plist, clip_grad_norm)
     optimizer.step()
     return wm.last_metrics
 
@@ -147,8 +204,12 @@ class GraphedTrainStep:
             threading.stack_size(old)
         if err:
             raise err[0]
-        self.grads = [p.grad for p in self.live]  # the graph's static gradient buffers
         self.metrics = dict(wm.last_metrics)
+
+    @property
+    def grads(self) -> List[Tensor]:
+        """The live parameters' gradients: slices of the static flat buffer every replay rewrites."""
+        return self.flat.views
 
     def _capture(self, optimizer, dev, warmup: int) -> None:
         wm, say = self.wm, self._say
@@ -166,6 +227,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
+        # the live gradients as views of ONE static buffer: the captured backward accumulates into it, the exchange runs on it
+        self.flat = FlatGrads(self.live)
         wm.last_metrics = None
         getattr(wm, "logged", {}).clear()
         self.graph = torch.cuda.CUDAGraph()
@@ -174,7 +237,8 @@ class GraphedTrainStep:
         # initialised process group may query events at any time); the autograd engine's launches still land on the capturing
         # stream and are captured
         with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
-            self._fwd_bwd()  # gradients are allocated from the graph's pool: static addresses, rewritten by every replay
+            self.flat.zero()
+            self._fwd_bwd()  # gradients accumulate into the flat buffer's slices: static addresses, rewritten by every replay
         say("capture done")
 
     @torch.no_grad()
@@ -197,9 +261,8 @@ class GraphedTrainStep:
             v.copy_(b[k])
         self._refill()
         self.graph.replay()
-        for p, g in zip(self.live, self.grads):  # a zero_grad(set_to_none=True) elsewhere must not detach the static buffers
-            p.grad = g
-        allreduce_gradients(self.live)
+        self.flat.attach()  # a zero_grad(set_to_none=True) elsewhere must not detach the static buffer's views
+        allreduce_gradients(self.flat)
         if self.clip and self.clip > 0:
             torch.nn.utils.clip_grad_norm_(self.live, self.clip)
         self.opt.step()

@@ -171,6 +171,25 @@ class _DropScope:
         return False
 
 
+@contextlib.contextmanager
+def module_scope(n_batch: int, device):
+    """Dropout scope of ONE module call in train() outside a training step (the reference's modules run in train mode,
+    modules/transformer_rpe.py:207-245, mlp.py:58-72): the keyed masks of this call hang off a seed drawn from torch's generator
+    (torch.manual_seed reproduces them), elementwise sites and attention calls are numbered from 0. Inside a training step the
+    step's own scope stays in force."""
+    global _DROP
+    if _DROP is not None:
+        with _DropScope(n_batch):
+            yield
+        return
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+    _DROP = {"seed": seed, "call": 0, "site": 0, "n_batch": n_batch, "tb": 1, "t0": 0}
+    try:
+        yield
+    finally:
+        _DROP = None
+
+
 class LayerNormFn(torch.autograd.Function):
     """F.layer_norm over rows of 128 as tbx_layernorm_fwd (the row chains' arithmetic) / tbx_layernorm_bwd (x and dy read once, dx
     written once, deterministic dgamma / dbeta) instead of aten's four kernels."""
