@@ -738,7 +738,7 @@ def test_modules_in_train_mode_run_the_differentiable_path(tb):
     assert 0.05 < frac0 < 0.75  # relu zeros + ~10 % dropped
     ym.sum().backward()
     assert torch.isfinite(xm.grad).all()
-    pe = M.polyline_encoder.PolylineEncoder(hidden_dim=128, n_layer=3, mlp_use_layernorm=False, mlp_dropout_p=0.1, use_pointnet=True,
+    pe = M.polyline_encoder.PolylineEncoder(hidden_dim=128, tf_cfg=None, n_layer=3, mlp_use_layernorm=False, mlp_dropout_p=0.1, use_pointnet=True,
                                             pooling_mode="max_valid").to(dev).train()
     xp = torch.randn(2, 30, 11, 128, generator=g).to(dev).requires_grad_(True)
     ip = (torch.rand(2, 30, 11, generator=g) < 0.3).to(dev)
