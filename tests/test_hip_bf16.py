@@ -98,3 +98,43 @@ def test_bf16_tables_closed_loop_vs_fp32_oracle(tb, bf16_tables, sizes, knn):
     torch.testing.assert_close(buf.pred_pose[:, 0].cpu(), ro["pred_pose"], rtol=1e-3, atol=5e-2)
     torch.testing.assert_close(buf.vis_dict["action"][:, 0].cpu(), ro["action"], rtol=1e-2, atol=5e-2)
     assert torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])
+
+
+@pytest.mark.parametrize("sizes,knn", [((64, 1024, 128), 32)])
+def test_bf16_closed_loop_gathers_the_rows_the_fp32_path_gathers(tb, sizes, knn):
+    """bf16 K/V tables must only ROUND the gathered rows, never change which rows are gathered: over the 10 teacher-forced
+    warm-start steps (identical poses in both runs) the three K-nearest sets of every step - agent -> agent / map / light, indices
+    and masks - are bit-identical between the fp32 and the bf16 engine (the searches run on fp32 poses), and the policy's action
+    means stay within 2e-2 of the fp32 ones (table rounding only; a wrong-row gather that lands on a nearby polyline would not
+    show in the loose closed-loop tolerance but does here and in the kernel-level check against the rounded table above)."""
+    dev = torch.device(DEV)
+    eng_mod = import_module("trafficbots_amd.engine")
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, sizes[0], 16, generator=g).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    runs = {}
+    for name, bf16 in (("fp32", False), ("bf16", True)):
+        wm.schedule = eng_mod.DEFAULT.replace(kv_bf16=bf16)
+        wm.engine_cache = 0
+        mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+        ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["gt/ag_valid"],
+                     "gt_pose": bd["gt/ag_pose"], "gt_motion": bd["gt/ag_motion"], "ag_latent": z, "ag_latent_valid": valid,
+                     "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid}
+        eng = wm.begin_rollout(ag_tokens, mp, tl, bd["gt/tl_state"], wm.teacher_forcing_joint_future_pred,
+                               wm._rule_checker(bd, bd["gt/ag_navi"], tl), 12)
+        steps = []
+        for _ in range(10):
+            eng.step()
+            torch.cuda.synchronize()
+            prep = eng.policy_out["prep"]
+            steps.append({k: prep[k].clone() for k in ("knn_idx_ag2ag", "knn_invalid_ag2ag", "knn_idx_ag2mp", "knn_invalid_ag2mp",
+                                                        "knn_idx_ag2tl", "knn_invalid_ag2tl")} | {"action": eng.S["action_mean"].clone()})
+        runs[name] = steps
+    scale = max(float(s["action"].abs().max()) for s in runs["fp32"])
+    for t, (a, c) in enumerate(zip(runs["fp32"], runs["bf16"])):
+        for k in a:
+            if k != "action":
+                assert torch.equal(a[k], c[k]), (t, k)
+        assert float((a["action"] - c["action"]).abs().max()) <= 2e-2 * max(scale, 1e-3), t
+    assert not torch.equal(runs["fp32"][3]["action"], runs["bf16"][3]["action"])  # the tables really were rounded

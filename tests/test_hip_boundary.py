@@ -250,6 +250,21 @@ def test_wosac_shape_joint_futures_vs_oracle(tb):
         torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=3e-3)
         torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=3e-3)
         torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=1e-4)
+    # ALL 32 rollouts over the 10 warm-start steps (poses are teacher-forced there, so the oracle runs the 32 rollouts as one
+    # batch of 32 scene copies, each with its rollout's latent and destination): every rollout's action means and light states
+    rep = lambda t: t.repeat_interleave(K, 0) if torch.is_tensor(t) and t.shape[0] == 1 else t
+    bK = {k: rep(v) for k, v in bh.items()}
+    mpK = {k: rep(v) for k, v in mp_o.items()}
+    tlK = {k: rep(v) for k, v in tl_o.items()}
+    with torch.no_grad():
+        roK = sim.rollout(bK, mpK, tlK, z_all, vc.expand(K, -1), dest_all, vc.expand(K, -1), scfg.teacher_forcing_joint_future_pred, 10,
+                          gt_prefix="hist", tl_gt_key="sc/tl_state")
+    sl = slice(0, 10)
+    assert torch.equal(buf.pred_valid[0, :, :, sl].cpu(), roK["pred_valid"][:, :, sl])
+    assert torch.equal(buf.vis_dict["tl_state"][0, :, :, sl].cpu(), roK["tl_state"][:, :, sl])
+    torch.testing.assert_close(buf.pred_pose[0, :, :, sl].cpu(), roK["pred_pose"][:, :, sl], rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(buf.vis_dict["action"][0, :, :, sl].cpu(), roK["action"][:, :, sl], rtol=1e-3, atol=2e-3)
+    assert float((roK["action"][0] - roK["action"][1]).abs().max()) > 1e-3  # the rollouts' policies do differ (their latents do)
     # rule flags of three rollouts, bit-exact against the oracle's checks on the logged trajectories
     ks = [0, 13, 31]
     r = lambda t: t.repeat_interleave(len(ks), 0).cpu()

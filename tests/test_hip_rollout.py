@@ -328,3 +328,38 @@ def test_cached_engine_refilled_in_place_equals_fresh_engines(tb, sizes, knn, K)
             assert torch.equal(f.violation[k], c.violation[k]), k
         for k in f.diffbar_reward:
             assert torch.equal(f.diffbar_reward[k], c.diffbar_reward[k]), k
+
+
+def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
+    """A closed loop at FULL action gain whose weights make it contractive: every residual branch of every transformer layer
+    (attention out_proj, FFN linear2) scaled by 0.3 - in the model and in the oracle's copy - instead of the action head x 0.02 of
+    the damped tests. 10 warm-start + 80 free-running steps, hipGraph replay, compared point-wise with the oracle over the whole
+    horizon (spawns, agents leaving the map, destinations, predicted light states)."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, (8, 64, 8), 4)
+    with torch.no_grad():
+        for k, p in wm.model.state_dict().items():
+            if k.endswith(("linear2.weight", "linear2.bias", "out_proj_weight", "out_proj_bias")):
+                p.mul_(0.3)
+                P[k] = P[k] * 0.3
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=4), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    mp_o, tl_o = _oracle_tokens(om, b)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 8, 16, generator=g)
+    valid = b["sc/ag_valid"].any(-1)
+    bh = dict(b)
+    bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
+    with torch.no_grad():
+        ro = O.Sim(om, scfg, False).rollout(bh, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred,
+                                            90, gt_prefix="hist", tl_gt_key="sc/tl_state")
+    mp, tl = wm.encode_scene(bd)
+    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
+                 "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
+                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid.to(dev)}
+    buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
+                     wm._rule_checker(bd, bd["gt/ag_navi"], tl), 90, True)
+    buf.flatten_joint_future(1)
+    # the loop does move at full gain (it is not the damped head): actions of the free steps are not tiny
+    assert float(ro["action"][:, :, 12:].abs().max()) > 0.05
+    _compare(buf, ro, 90, 5e-3)
