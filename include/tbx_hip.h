@@ -263,6 +263,10 @@ typedef struct tbx_window_tile {
   float* out;
   int32_t window, ld_attr;
   int64_t n_groups;
+  int32_t attr_cols; /* columns of attr that are read (<= 32, % 4 == 0; the rest of the 32-wide first layer sees zeros) */
+  int32_t d_mlp;     /* 64: "cat" mode (agents); 128: "add" mode (traffic lights: traffic_light.py:219-226 - the input MLP is
+                      * 32 -> 128 -> 128 -> 128 and `pe` is ONE feature row per window [n_groups, 128] added to its output) */
+  int32_t add_mode, pad_;
 } tbx_window_tile_t;
 int tbx_window_tile(const tbx_window_tile_t* args /* host */, void* stream);
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple

@@ -788,6 +788,35 @@ def test_window_tile_equals_grouped_chain(tb, hip, dev, G, W):
     assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
 
 
+@pytest.mark.parametrize("G,W", [(300, 11), (128, 11), (33, 5)])
+def test_window_tile_add_mode_equals_grouped_chain(tb, hip, dev, G, W):
+    """tbx_window_tile in "add" mode = the traffic lights' temporal encoder (traffic_light.py:219-226: input MLP 16 -> 128 -> 128 ->
+    128 on the one-hot state / window rows, + the light's lane feature, then the 3 PointNet layers and the pooled row) vs the
+    grouped tbx_rowchain program: 2e-4 of the largest entry; 16-column attribute rows (the kernel reads the 32-wide first layer's
+    missing columns as zeros)."""
+    eng = import_module("trafficbots_amd.engine")
+    te = _default_model(tb, dev).model.tl_encoder
+    g = torch.Generator().manual_seed(G + W)
+    attr = torch.randn(G * W, 16, generator=g).to(dev)
+    feat = torch.randn(G, 128, generator=g).to(dev)
+    inv = (torch.rand(G, W, generator=g) < 0.3)
+    inv[2] = True
+    inv8 = inv.reshape(-1).to(torch.uint8).to(dev)
+    ref = torch.empty(G, 128, device=dev)
+    ch = hip.Chain(hip.group_tile_rows(W, G), 132)
+    cur = te.input_encoder.emit(ch, attr, feat, pe_row_div=W)
+    eng.emit_pointnet(ch, te.temp_encoder, inv8, ref, x_buf=cur)
+    ch.run(G * W, group_rows=W)
+    imgs = te._window_tile_images()
+    assert imgs is not None
+    out = torch.full((G, 128), 7.0, device=dev)
+    hip.window_tile(attr, feat, inv8, imgs[0], imgs[1], W, out, add_mode=True)
+    torch.cuda.synchronize()
+    assert float(out[2].abs().max()) == 0.0 and float(ref[2].abs().max()) == 0.0
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
+
+
 @pytest.mark.parametrize("rows", [1030, 100])
 def test_heads_tile_equals_heads_chain(tb, hip, dev, rows):
     """tbx_heads_tile (navigation / latent adders + the action head's stacked branches + masked sum in one launch,

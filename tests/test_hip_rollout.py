@@ -269,8 +269,10 @@ def test_small_launch_schedules_are_bit_identical(tb, sizes, knn):
                                                      "layer1p": (1, True, True, True, True)}.items():
             # riders: the destination's pose embedding in the searches' launch, tbx_tl_prep in the lights' tbx_sim_step launch
             rides = name not in ("mfma", "live1", "mid")
+            # (tile_small off: the window PointNets / first projections as exact-fp32 chains in every variant - the tile kernels'
+            # split-bf16 stages are compared with the chains at tolerance in tests/test_hip_parity.py)
             wm.schedule = eng.DEFAULT.replace(live_rows=live, attn_fold=fold, dec_mid=mid, dec_layer=layer, pool_proj=pool,
-                                              pe_rides=rides, tl_prep_rides=rides, split_bf16=False)
+                                              pe_rides=rides, tl_prep_rides=rides, split_bf16=False, tile_small=False)
             outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                             step_end=24)
     ref = outs["mfma"]

@@ -30,6 +30,9 @@ __device__ __forceinline__ float row16_max(float v) {  // maximum over the 16 la
   return fmaxf(v, tbx::dpp<tbx::DPP_MIRROR>(v));
 }
 
+// DM = width of the input MLP (64: "cat" mode, the pose embedding fills channels [64, 128); 128: "add" mode, a per-window
+// feature row is added to the MLP's output)
+template <int DM, bool ADD>
 __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_c[];
   char* P0 = lds_c;             // ping: hi, lo
@@ -38,50 +41,50 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int nt = wave & 3, rt = wave >> 2;  // the wave's output tile (16 of 64 channels) and row tile (window)
+  const int nt = wave & 3, rt = wave >> 2;  // PointNet layers: the wave's output tile (16 of 64 channels) and row tile (window)
   const int64_t grp0 = (int64_t)blockIdx.x * RT;
   const int Wn = t.window;
   const int aoff = PL::lane_off(lane, rt * 16);
   const int c_out = 16 * nt + 4 * g;
-  // the lane's row: step j of window grp0 + rt
+  // the lane's row in the PointNet layers: step j of window grp0 + rt
   const int64_t grp = grp0 + rt;
   const bool grp_ok = grp < t.n_groups;
   bool inv = true;
   if (grp_ok && j < Wn) inv = *(const TBX_GLOBAL uint8_t*)(t.row_invalid + grp * Wn + j) != 0;
 
-  // weights: input MLP 32 -> 64 (one unit of 4 tiles), 64 -> 64 twice (2 units of 2 tiles x 2 steps), PointNet 128 -> 64 three times
   W wb[2];
-  load_unit(wb[0], t.in_images[0], 0, lane);
-  const f32x4 b_in0 = unit_bias(t.in_images[0], 0, nt, lane);
-
-  // ---- inputs: attribute rows (32 columns, zero-padded by their producer) -> P0[k 0..31]; pose embedding (64) -> P1[k 64..127]
+  // ---- inputs: attribute rows (first 32 columns; columns past attr_cols read as 0) -> P0[k 0..31]; cat mode: pose embedding -> P1[k 64..127]
   if (tid < ROWS * 8) {
     const int r = tid >> 3, c4 = tid & 7;
     const int64_t gq = grp0 + (r >> 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (gq < t.n_groups && (r & 15) < Wn) v = gld4(t.attr + (gq * Wn + (r & 15)) * (int64_t)t.ld_attr + c4 * 4);
+    if (gq < t.n_groups && (r & 15) < Wn && c4 * 4 < t.attr_cols) v = gld4(t.attr + (gq * Wn + (r & 15)) * (int64_t)t.ld_attr + c4 * 4);
     planes_write4<PL>(P0, r, c4 * 4, v);
   }
-  {
+  if constexpr (!ADD) {
     const int r = tid >> 4, c4 = tid & 15;
     const int64_t gq = grp0 + (r >> 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (gq < t.n_groups && (r & 15) < Wn) v = gld4(t.pe + (gq * Wn + (r & 15)) * (int64_t)64 + c4 * 4);
     planes_write4<PL>(P1, r, 64 + c4 * 4, v);
   }
-  __syncthreads();
-  {  // input MLP layer 1: K = 32 (step 0), the wave's tile = group nt of unit 0
-    load_unit(wb[1], t.in_images[1], nt >> 1, lane);
-    Acc acc;
-    acc.zero();
-    const W& w = wb[0];
-    // (groups are indexed with a wave-uniform runtime value: select by hand so the fragments stay in registers)
-    const bf16x8 wh = nt == 0 ? w.hi[0] : (nt == 1 ? w.hi[1] : (nt == 2 ? w.hi[2] : w.hi[3]));
-    const bf16x8 wl = nt == 0 ? w.lo[0] : (nt == 1 ? w.lo[1] : (nt == 2 ? w.lo[2] : w.lo[3]));
-    mfma_step<PLANE>(acc, wh, wl, P0 + aoff, 0);
-    planes_write4<PL>(P1, rt * 16 + j, c_out, relu4(acc.sum() + b_in0));
-  }
-  __syncthreads();
+  if constexpr (DM == 64) {
+    // input MLP 32 -> 64 (one unit of 4 tiles), 64 -> 64 twice (2 units of 2 tiles x 2 steps); wave = (tile nt, row tile rt)
+    load_unit(wb[0], t.in_images[0], 0, lane);
+    const f32x4 b_in0 = unit_bias(t.in_images[0], 0, nt, lane);
+    __syncthreads();
+    {
+      load_unit(wb[1], t.in_images[1], nt >> 1, lane);
+      Acc acc;
+      acc.zero();
+      const W& w = wb[0];
+      // (groups are indexed with a wave-uniform runtime value: select by hand so the fragments stay in registers)
+      const bf16x8 wh = nt == 0 ? w.hi[0] : (nt == 1 ? w.hi[1] : (nt == 2 ? w.hi[2] : w.hi[3]));
+      const bf16x8 wl = nt == 0 ? w.lo[0] : (nt == 1 ? w.lo[1] : (nt == 2 ? w.lo[2] : w.lo[3]));
+      mfma_step<PLANE>(acc, wh, wl, P0 + aoff, 0);
+      planes_write4<PL>(P1, rt * 16 + j, c_out, relu4(acc.sum() + b_in0));
+    }
+    __syncthreads();
 #define TBX_IN64(CUR, SRC, DST, RELU, NEXT_IMG, NEXT_UNIT, BIAS_IMG)                                      \
   do {                                                                                                    \
     const f32x4 bias = unit_bias(BIAS_IMG, nt >> 1, 2 * (nt & 1), lane);                                  \
@@ -96,12 +99,64 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
     if (RELU) v = relu4(v);                                                                               \
     planes_write4<PL>(DST, rt * 16 + j, c_out, v);                                                        \
   } while (0)
-  TBX_IN64(1, P1, P0, true, t.in_images[2], nt >> 1, t.in_images[1]);
-  __syncthreads();
-  TBX_IN64(0, P0, P1, false, t.pn_images[0], nt, t.in_images[2]);
+    TBX_IN64(1, P1, P0, true, t.in_images[2], nt >> 1, t.in_images[1]);
+    __syncthreads();
+    TBX_IN64(0, P0, P1, false, t.pn_images[0], nt, t.in_images[2]);
 #undef TBX_IN64
-  __syncthreads();
-  // ---- PointNet layers: P1 -> P0 -> P1 -> out
+    __syncthreads();
+  } else {
+    // input MLP 32 -> 128 (2 units of 4 tiles), 128 -> 128 twice (8 units of 4 steps); wave w = output tile w (16 of 128 channels),
+    // BOTH row tiles (the weight fragments serve the two windows)
+    const int c8 = 16 * wave + 4 * g;
+    load_unit(wb[0], t.in_images[0], wave >> 2, lane);
+    const f32x4 b_in0 = unit_bias(t.in_images[0], wave >> 2, wave & 3, lane);
+    __syncthreads();
+    {
+      load_unit(wb[1], t.in_images[1], wave, lane);
+      const W& w = wb[0];
+      const int q = wave & 3;
+      const bf16x8 wh = q == 0 ? w.hi[0] : (q == 1 ? w.hi[1] : (q == 2 ? w.hi[2] : w.hi[3]));
+      const bf16x8 wl = q == 0 ? w.lo[0] : (q == 1 ? w.lo[1] : (q == 2 ? w.lo[2] : w.lo[3]));
+#pragma unroll
+      for (int r2 = 0; r2 < RT; ++r2) {
+        Acc acc;
+        acc.zero();
+        mfma_step<PLANE>(acc, wh, wl, P0 + PL::lane_off(lane, r2 * 16), 0);
+        planes_write4<PL>(P1, r2 * 16 + j, c8, relu4(acc.sum() + b_in0));
+      }
+    }
+    __syncthreads();
+    {  // layer 2: P1 -> P0, relu
+      load_unit(wb[0], t.in_images[2], wave, lane);
+      const W& w = wb[1];
+#pragma unroll
+      for (int r2 = 0; r2 < RT; ++r2) {
+        Acc acc;
+        acc.zero();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) mfma_step<PLANE>(acc, w.hi[s2], w.lo[s2], P1 + PL::lane_off(lane, r2 * 16), s2);
+        planes_write4<PL>(P0, r2 * 16 + j, c8, relu4(acc.sum() + w.bias));
+      }
+    }
+    __syncthreads();
+    {  // layer 3: P0 -> P1, no activation, + the window's feature row (input encoder "add" mode)
+      load_unit(wb[1], t.pn_images[0], nt, lane);
+      const W& w = wb[0];
+#pragma unroll
+      for (int r2 = 0; r2 < RT; ++r2) {
+        Acc acc;
+        acc.zero();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) mfma_step<PLANE>(acc, w.hi[s2], w.lo[s2], P0 + PL::lane_off(lane, r2 * 16), s2);
+        f32x4 v = acc.sum() + w.bias;
+        const int64_t gq = grp0 + r2;
+        if (gq < t.n_groups) v += gld4(t.pe + gq * (int64_t)D + c8);
+        planes_write4<PL>(P1, r2 * 16 + j, c8, v);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- PointNet layers: P1 -> P0 -> P1 -> out (wb[1] holds layer 1's unit)
 #define TBX_PN(CUR, SRC, DST, LAST, NEXT_IMG)                                                             \
   do {                                                                                                    \
     if (!(LAST)) load_unit(wb[1 - (CUR)], NEXT_IMG, nt, lane);                                            \
@@ -138,16 +193,24 @@ extern "C" int tbx_window_tile(const tbx_window_tile_t* args, void* stream) {
   if (t.attr == nullptr || t.pe == nullptr || t.row_invalid == nullptr || t.out == nullptr) return TBX_ERR_ARG;
   for (int i = 0; i < 3; ++i)
     if (t.in_images[i] == nullptr || t.pn_images[i] == nullptr) return TBX_ERR_ARG;
-  if (t.window <= 0 || t.window > 16 || t.ld_attr < 32 || t.ld_attr % 4 != 0) return TBX_ERR_UNSUPPORTED;
+  if (t.window <= 0 || t.window > 16 || t.ld_attr % 4 != 0 || t.attr_cols <= 0 || t.attr_cols > 32 || t.attr_cols % 4 != 0 ||
+      t.attr_cols > t.ld_attr)
+    return TBX_ERR_UNSUPPORTED;
+  if (!((t.d_mlp == 64 && t.add_mode == 0) || (t.d_mlp == 128 && t.add_mode == 1))) return TBX_ERR_UNSUPPORTED;
   if ((((uintptr_t)t.attr) | ((uintptr_t)t.pe) | ((uintptr_t)t.out)) & 15) return TBX_ERR_ALIGN;
   WindowArgs a;
   a.t = t;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tile_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)tile_window_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tile_window_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
       return TBX_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(tile_window_kernel, dim3((unsigned)((t.n_groups + RT - 1) / RT)), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((t.n_groups + RT - 1) / RT));
+  if (t.d_mlp == 64)
+    hipLaunchKernelGGL((tile_window_kernel<64, false>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((tile_window_kernel<128, true>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

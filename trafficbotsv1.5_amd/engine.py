@@ -73,6 +73,9 @@ class Schedule:
     # tiles, LINEAR on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) - instead of tbx_rowchain programs (exact fp32)
     tile_layer: bool = True
     tile_min_rows: int = 1024
+    # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
+    # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
+    tile_small: bool = True
     pe_rides: bool = True       # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
     # ---- RolloutEngine
     tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
@@ -96,7 +99,7 @@ class Schedule:
                    live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
                    kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
                    split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
-                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
                    graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
 
     def replace(self, **kw) -> "Schedule":
@@ -364,6 +367,12 @@ def tile_rows_ok(rows: int, keyed_dropout: bool = False) -> bool:
     return c.tile_layer and not live_rows_for(rows) and rows >= c.tile_min_rows and not c.attn_fold_big
 
 
+def tile_small_ok() -> bool:
+    """Inference launches of any size whose window PointNet / first projection run as tile kernels."""
+    c = current()
+    return c.tile_layer and c.tile_small and DROP_CTX is None and not c.pool_proj
+
+
 def _tile_drop(*sites) -> Optional[dict]:
     """hip.layer_tile's `drop` from up to three drop_site() results (attention residual, FFN hidden, FFN output)."""
     live = [d for d in sites if d is not None]
@@ -455,7 +464,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         return layers[l].norm_src if dec else layers[l].norm1
 
     tile = tile_rows_ok(rows, keyed_dropout=True)
-    if first_proj is None and tile:
+    if first_proj is None and (tile or tile_small_ok()):
         hip.layer_tile(x, proj=tile_proj_part(first_norm(0), first_attn(0), qkv, True, kv16), store_x=False)
     elif first_proj is None:
         ch = layer_chain(rows)

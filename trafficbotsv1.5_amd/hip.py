@@ -99,7 +99,8 @@ class HeadsTile(C.Structure):
 class WindowTile(C.Structure):
     """tbx_window_tile_t (include/tbx_hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("attr", "pe", "row_invalid")] + [("in_images", C.c_void_p * 3), ("pn_images", C.c_void_p * 3),
-                ("out", C.c_void_p), ("window", C.c_int32), ("ld_attr", C.c_int32), ("n_groups", C.c_int64)])
+                ("out", C.c_void_p), ("window", C.c_int32), ("ld_attr", C.c_int32), ("n_groups", C.c_int64)]
+                + [(n, C.c_int32) for n in ("attr_cols", "d_mlp", "add_mode", "pad_")])
 
 
 class SimState(C.Structure):
@@ -662,10 +663,13 @@ def heads_tile(x, hd: dict):
     _check(load().tbx_heads_tile(C.byref(a), stream_ptr()), "tbx_heads_tile")
 
 
-def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out):
-    """tbx_window_tile: attr [G * window, >= 32], pe [G * window, 64], row_invalid u8 [G * window] -> out [G, 128]."""
+def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False):
+    """tbx_window_tile. cat mode: attr [G * window, >= 4 cols], pe [G * window, 64]; add mode: pe = one feature row per window
+    [G, 128], the input MLP is 128 wide. row_invalid u8 [G * window] -> out [G, 128]."""
     a = WindowTile()
-    assert attr.dim() == 2 and attr.stride(1) == 1 and pe.shape[1] == 64 and pe.is_contiguous() and out.shape[1] == 128 and out.is_contiguous()
+    assert attr.dim() == 2 and attr.stride(1) == 1 and pe.is_contiguous() and out.shape[1] == 128 and out.is_contiguous()
+    assert pe.shape == ((out.shape[0], 128) if add_mode else (attr.shape[0], 64))
+    a.attr_cols, a.d_mlp, a.add_mode = min(32, attr.shape[1] // 4 * 4), (128 if add_mode else 64), int(add_mode)
     a.attr, a.ld_attr, a.pe, a.row_invalid = _ptr(attr, torch.float32), attr.stride(0), _ptr(pe, torch.float32), _cptr(row_invalid, torch.uint8)
     for i in range(3):
         a.in_images[i], a.pn_images[i] = _ptr(in_images[i], torch.float32), _ptr(pn_images[i], torch.float32)

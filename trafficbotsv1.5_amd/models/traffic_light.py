@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block
+from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -74,6 +74,24 @@ class TrafficLightEncoder(nn.Module):
                                         out=cache.get(id(self)))
         return cache[id(self)]
 
+    def _window_tile_images(self):
+        """(input MLP images, PointNet images) for tbx_window_tile in "add" mode, or None where the module is not of the default shape
+        (input encoder "add": d_in <= 32 -> 128 -> 128 -> 128 without layernorm; three 128 -> 64 PointNet layers)."""
+        ie, te = self.input_encoder, self.temp_encoder
+        lins = ie.mlp.linear_layers()
+        if not (ie.mode == "add" and len(lins) == 3 and ie.mlp.output_dim == 128 and ie.mlp.input_dim <= 32 and self.hidden_dim == 128
+                and all(ln is None for _, ln, _ in lins) and [a for _, _, a in lins] == [True, True, False] and len(te.mlp_layers) == 3):
+            return None
+        pn = []
+        for mlp in te.mlp_layers:
+            ll = mlp.linear_layers()
+            if len(ll) != 1 or ll[0][1] is not None or tuple(ll[0][0].weight.shape) != (64, 128):
+                return None
+            pn.append(hip.packed_weight(ll[0][0].weight, ll[0][0].bias, mfma32=True))
+        ins = [hip.packed_weight(hip.padded_weight(lins[0][0].weight, 32), lins[0][0].bias, mfma32=True)]
+        ins += [hip.packed_weight(l.weight, l.bias, mfma32=True) for l, _, _ in lins[1:]]
+        return ins, pn
+
     def prep_buffers(self, n: int, L: int, dev):
         """(attr [n*L*W, 16 | 32] f32, row_invalid [n*L*W] u8): what tbx_tl_prep writes for `encode`."""
         rows = n * L * self.temp_window_size
@@ -94,12 +112,16 @@ class TrafficLightEncoder(nn.Module):
             hip.tl_prep(hist_tl, t["tl_token_invalid_u8"], attr, row_inv)
         x = torch.empty(n * L, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * L, dev, hip.group_tile_rows(W, n * L))  # small launches: layer 0's projections in the windows' launch too
-        ch = Chain(hip.group_tile_rows(W, n * L), d + 4 if fp is None else FIRST_PROJ_LDW)
-        cur = self.input_encoder.emit(ch, attr, t["tl_token_attr"].reshape(n * L, d), pe_row_div=W)
-        kept = emit_pointnet(ch, self.temp_encoder, row_inv, x, x_buf=cur, keep=fp is not None)
-        if fp is not None:
-            emit_first_proj(ch, self.tf_tl2tlmp, fp, kept)
-        ch.run(rows, group_rows=W)
+        wt_ = self._window_tile_images() if (fp is None and W <= 16 and (tile_rows_ok(n * L) or tile_small_ok())) else None
+        if wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch ("add" mode: + the light's lane feature)
+            hip.window_tile(attr, t["tl_token_attr"].reshape(n * L, d), row_inv, wt_[0], wt_[1], W, x, add_mode=True)
+        else:
+            ch = Chain(hip.group_tile_rows(W, n * L), d + 4 if fp is None else FIRST_PROJ_LDW)
+            cur = self.input_encoder.emit(ch, attr, t["tl_token_attr"].reshape(n * L, d), pe_row_div=W)
+            kept = emit_pointnet(ch, self.temp_encoder, row_inv, x, x_buf=cur, keep=fp is not None)
+            if fp is not None:
+                emit_first_proj(ch, self.tf_tl2tlmp, fp, kept)
+            ch.run(rows, group_rows=W)
         kv = self._kv_mp(t)
         M, div = t["n_mp"], t["mp_batch_div"]
         knn = SelfKnn(t["knn_idx_tl2tl"], t["knn_invalid_tl2tl"], t["rpe_tl2tl"], rel=t["rel_tl2tl"])
