@@ -359,14 +359,19 @@ def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
     with torch.no_grad():
         ro = O.Sim(om, scfg, False).rollout(bh, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred,
                                             90, gt_prefix="hist", tl_gt_key="sc/tl_state")
-    mp, tl = wm.encode_scene(bd)
-    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
-                 "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
-                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid.to(dev)}
-    buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
-                     wm._rule_checker(bd, bd["gt/ag_navi"], tl), 90, True)
-    buf.flatten_joint_future(1)
-    # the loop does move at full gain (it is not the damped head): actions of the free steps are not tiny
+    E = import_module("trafficbots_amd.engine")
+    # the loop does move (it is not the damped head): actions of the free steps are not tiny
     assert float(ro["action"][:, :, 12:].abs().max()) > 1.0
-    _compare(buf, ro, 70, 5e-3)
-    _compare(buf, ro, 80, 5e-2)
+    # exact-fp32 schedule (window PointNets / first projections as row chains), then the default one (tile kernels: their split-bf16
+    # stages start the same amplification from ~1e-5 instead of ~1e-7, so the point-wise horizon is shorter)
+    for tile_small, checks in ((False, ((70, 5e-3), (80, 5e-2))), (True, ((40, 5e-3), (60, 5e-2)))):
+        wm.schedule = E.DEFAULT.replace(tile_small=tile_small)
+        mp, tl = wm.encode_scene(bd)
+        ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
+                     "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
+                     "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid.to(dev)}
+        buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
+                         wm._rule_checker(bd, bd["gt/ag_navi"], tl), 90, True)
+        buf.flatten_joint_future(1)
+        for n_cmp, tol in checks:
+            _compare(buf, ro, n_cmp, tol)
