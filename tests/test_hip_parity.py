@@ -27,12 +27,6 @@ def hip(tb):
     return h
 
 
-def _same(a, b, tol=2e-5):
-    """Two schedules of the same fp32 arithmetic whose summation orders differ (4-accumulator GEMV stages vs the MFMA k order): equal
-    to `tol` of the largest entry (exact zeros stay exact)."""
-    return float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
-
-
 def _poses(g, n, S, span=200.0):
     return torch.cat([(torch.rand(n, S, 2, generator=g) - 0.5) * span, (torch.rand(n, S, 1, generator=g) - 0.5) * 6.28], -1)
 
@@ -395,12 +389,11 @@ def test_action_head_fused_branches_bit_identical(tb, hip, dev):
 
 @pytest.mark.parametrize("live", [1, 2, 4])
 @pytest.mark.parametrize("rows", [1, 7, 64, 130])
-def test_live_row_chain_equals_mfma_tiles(tb, live, rows):
+def test_live_row_chain_is_bit_identical_to_mfma_tiles(tb, live, rows):
     """tbx_rowchain_live (tiles of 1 / 2 / 4 rows, LINEAR = a thread per output column running the MFMA sequence's k order as a
     v_fma chain) vs the 16-row MFMA tiles on the same program: every stage kind the transformer-layer and head chains use -
     LN, 128->128 / 128->384 / 128->512 / 512->128, block-diagonal per-head folds in both orientations, accumulate + row skip into
-    the residual, odd widths (20 -> 64 -> 2), straight-to-global outputs. Equal to 2e-5 of the largest entry: the thread-per-column
-    stages sum each output in four interleaved chains (the MFMA tiles in one k-ordered chain)."""
+    the residual, odd widths (20 -> 64 -> 2), straight-to-global outputs. Bit for bit."""
     hip = import_module("trafficbots_amd.hip")
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(rows * 10 + live)
@@ -442,15 +435,15 @@ def test_live_row_chain_equals_mfma_tiles(tb, live, rows):
     torch.cuda.synchronize()
     for a, b, name in zip(outs[0], outs[live], ("qkv|qt", "x", "kv (global)", "small")):
         assert torch.isfinite(a).all()
-        assert _same(a, b), (name, float((a - b).abs().max()))
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("S", [33, 1030])  # 1030: n * S >= 1024 rows -> the wave-per-row form (4 rows per workgroup, ragged tail)
 @pytest.mark.parametrize("bf16", [False, True])
 def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16, S):
     """tbx_knarpe_attn_fwd_folded (the value half of linear_rpe applied in the attention kernel's epilogue, 128 floats per row
-    out) vs tbx_knarpe_attn_fwd's 640-wide row followed by the grouped LINEAR stage that applied the fold so far: equal to 2e-5 (the
-    epilogue's GEMV sums in four interleaved chains), rows without a valid target flagged the same - for a one-segment and a two-segment call."""
+    out) vs tbx_knarpe_attn_fwd's 640-wide row followed by the grouped LINEAR stage that applied the fold so far: bit-identical
+    (same fma order), rows without a valid target flagged the same - for a one-segment and a two-segment call."""
     hip = import_module("trafficbots_amd.hip")
     eng = import_module("trafficbots_amd.engine")
     M = import_module("trafficbots_amd.models.modules")
@@ -481,7 +474,7 @@ def test_folded_attention_epilogue_equals_the_fold_stage(tb, bf16, S):
         o128, f128 = torch.full((n * S, d), 7.0, device=dev), torch.empty(n * S, dtype=torch.uint8, device=dev)
         hip.knarpe_attn(q, 0, 128, att.linear_rpe.bias, n, S, segs, o128, f128, fold=eng.attn_fold_image(att))
         assert torch.equal(f128, f640) and int(f640.sum()) >= 1
-        assert _same(o128, want), float((o128 - want).abs().max())
+        assert torch.equal(o128, want), float((o128 - want).abs().max())
 
 
 @pytest.mark.parametrize("S,Ks,T,K,n_cross,bf16", [(8, 4, 64, 8, 1, False), (64, 25, 1024, 64, 1, False), (64, 36, 128, 24, 2, False),
@@ -548,8 +541,8 @@ def test_fused_decoder_mid_launch_equals_its_three_launches(tb, hip, dev, S, Ks,
     torch.cuda.synchronize()
     assert int(f1.sum()) >= 1 and int(f_want.sum()) >= 1
     assert torch.equal(f_got, f_want)
-    assert _same(x_got, x_want), float((x_got - x_want).abs().max())
-    assert _same(o_got, o_want), float((o_got - o_want).abs().max())
+    assert torch.equal(x_got, x_want), float((x_got - x_want).abs().max())
+    assert torch.equal(o_got, o_want), float((o_got - o_want).abs().max())
 
 
 def test_knn_multi_launch_equals_single_searches(hip, dev):
@@ -617,9 +610,8 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
         outs[name] = x
     assert torch.isfinite(outs["mfma"]).all() and float(outs["mfma"][src_invalid.bool()].abs().max()) == 0.0
     assert float((outs["mfma"] - x0).abs().max()) > 1e-3
-    for name in ("mid", "layer"):  # (bf16 tables: a k | v entry may round the other way after an fp32-level difference)
-        assert _same(outs[name], outs["mfma"], 3e-3 if bf16 else 5e-5), (name, float((outs[name] - outs["mfma"]).abs().max()))
-        assert float(outs[name][src_invalid.bool()].abs().max()) == 0.0
+    for name in ("mid", "layer"):
+        assert torch.equal(outs[name], outs["mfma"]), (name, float((outs[name] - outs["mfma"]).abs().max()))
 
 
 @pytest.mark.parametrize("tile,groups,gw", [(16, 7, 11), (32, 9, 11), (48, 10, 11), (16, 5, 16)])

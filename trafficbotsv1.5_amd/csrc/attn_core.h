@@ -308,26 +308,22 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p);
 }
 
-// One output of a LINEAR stage: column `c` of the 128-column block of a tbx_pack_weight_gemv image at `blk` in LDS (row 0 = bias,
-// row 1 + kb*4 + t = weights of k = kb*16 + {0,4,8,12} + t), inputs x[0 .. kblocks*16) in LDS, 16-byte aligned: the k-block's 16
-// activations come as 4 broadcast ds_read_b128 (element [g*4 + t] multiplies W[c][kb*16 + g*4 + t]).
-// FOUR independent accumulators (g = 0..3: the k residues 4g..4g+3 of every k-block), summed at the end: a dependent v_fma_f32
-// issues every ~5.4 cycles, so ONE 128-long chain cost >= 690 cycles per output and was the floor of every GEMV stage of the
-// one-launch decoder layer (round 2 kept that chain to stay bit-identical with the MFMA k order; results now agree with the
-// MFMA tiles to fp32 rounding - tests compare at 1e-5 - and the weight stream, not the chain, bounds a stage).
+// One output of a LINEAR stage as the k-ordered fma chain of the packed MFMA path: column `c` of the 128-column block of a
+// tbx_pack_weight_gemv image at `blk` in LDS (row 0 = bias, row 1 + kb*4 + t = weights of k = kb*16 + {0,4,8,12} + t), inputs
+// x[0 .. kblocks*16) in LDS, 16-byte aligned: the k-block's 16 activations come as 4 broadcast ds_read_b128 (element [g*4 + t]
+// multiplies W[c][kb*16 + g*4 + t]) - one LDS instruction per 2 fmas instead of 5 per 4.
 __device__ __forceinline__ float gemv_chain(const float* blk, int c, const float* x, int kblocks, float acc) {
   const float4* wq = (const float4*)blk + c;
   const float4* x4 = (const float4*)__builtin_assume_aligned(x, 16);
-  float a0 = acc, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 fmas of k-block kb
+  // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 dependent fmas of k-block kb
 #define TBX_RD(X, W, KB)                                                                                       \
   X[0] = x4[(KB) * 4], X[1] = x4[(KB) * 4 + 1], X[2] = x4[(KB) * 4 + 2], X[3] = x4[(KB) * 4 + 3];                   \
   W[0] = wq[(1 + (KB) * 4) * D], W[1] = wq[(2 + (KB) * 4) * D], W[2] = wq[(3 + (KB) * 4) * D], W[3] = wq[(4 + (KB) * 4) * D]
 #define TBX_FM(X, W)                                                                                                                      \
-  a0 = __builtin_fmaf(X[0].x, W[0].x, a0); a1 = __builtin_fmaf(X[1].x, W[0].y, a1); a2 = __builtin_fmaf(X[2].x, W[0].z, a2); a3 = __builtin_fmaf(X[3].x, W[0].w, a3); \
-  a0 = __builtin_fmaf(X[0].y, W[1].x, a0); a1 = __builtin_fmaf(X[1].y, W[1].y, a1); a2 = __builtin_fmaf(X[2].y, W[1].z, a2); a3 = __builtin_fmaf(X[3].y, W[1].w, a3); \
-  a0 = __builtin_fmaf(X[0].z, W[2].x, a0); a1 = __builtin_fmaf(X[1].z, W[2].y, a1); a2 = __builtin_fmaf(X[2].z, W[2].z, a2); a3 = __builtin_fmaf(X[3].z, W[2].w, a3); \
-  a0 = __builtin_fmaf(X[0].w, W[3].x, a0); a1 = __builtin_fmaf(X[1].w, W[3].y, a1); a2 = __builtin_fmaf(X[2].w, W[3].z, a2); a3 = __builtin_fmaf(X[3].w, W[3].w, a3)
+  acc = __builtin_fmaf(X[0].x, W[0].x, acc); acc = __builtin_fmaf(X[1].x, W[0].y, acc); acc = __builtin_fmaf(X[2].x, W[0].z, acc); acc = __builtin_fmaf(X[3].x, W[0].w, acc); \
+  acc = __builtin_fmaf(X[0].y, W[1].x, acc); acc = __builtin_fmaf(X[1].y, W[1].y, acc); acc = __builtin_fmaf(X[2].y, W[1].z, acc); acc = __builtin_fmaf(X[3].y, W[1].w, acc); \
+  acc = __builtin_fmaf(X[0].z, W[2].x, acc); acc = __builtin_fmaf(X[1].z, W[2].y, acc); acc = __builtin_fmaf(X[2].z, W[2].z, acc); acc = __builtin_fmaf(X[3].z, W[2].w, acc); \
+  acc = __builtin_fmaf(X[0].w, W[3].x, acc); acc = __builtin_fmaf(X[1].w, W[3].y, acc); acc = __builtin_fmaf(X[2].w, W[3].z, acc); acc = __builtin_fmaf(X[3].w, W[3].w, acc)
   float4 xa[4], wa[4], xb[4], wb[4];
   TBX_RD(xa, wa, 0);
   for (int kb = 0; kb < kblocks; kb += 2) {  // kblocks is even (2 or 8) at every call site
@@ -338,7 +334,7 @@ __device__ __forceinline__ float gemv_chain(const float* blk, int c, const float
   }
 #undef TBX_RD
 #undef TBX_FM
-  return (a0 + a1) + (a2 + a3);
+  return acc;
 }
 
 #pragma clang fp contract(fast)

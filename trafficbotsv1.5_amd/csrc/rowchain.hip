@@ -500,10 +500,7 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
   const int n_chunks = ncb * nkc;
   const bool n_pow2 = (N & (N - 1)) == 0;
   const int n_shift = __builtin_ctz((unsigned)N);
-  // four independent accumulators (one per quad-broadcast lane g = the k residues 4g..4g+3 of a k-block), summed when the
-  // output is complete: one dependent 128-long v_fmac chain per output was >= 690 cycles of every 128-k stage (a dependent v_fma
-  // issues every ~5.4 cycles); the results agree with the MFMA tiles to fp32 rounding (tests: 1e-5), not bit for bit any more
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  float acc = 0.f;
   int cb = 0, kc = 0;  // chunk i = (cb, kc), walked without divisions
   for (int i = 0; i < n_chunks; ++i) {
     // chunk i has landed (every wave waits for its own pieces, the barrier collects all waves'); everybody is also done with the
@@ -527,16 +524,15 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
     if (row_on) {
       const float* wc = w + cl * 4;
       if (kc == 0) {
-        acc0 = wc[0];  // the block's bias row
-        if (accum && live) acc0 += dst0[r * lds_d + grp * gs_dst + c];
-        acc1 = acc2 = acc3 = 0.f;
+        acc = wc[0];  // the block's bias row
+        if (accum && live) acc += dst0[r * lds_d + grp * gs_dst + c];
         wc += GROW;
       }
       const float* xr = src0 + grp * gs_src + r * lds_s + kc * GKC * 16;
       const int kbc = (kblocks - kc * GKC) < GKC ? (kblocks - kc * GKC) : GKC;
       const float4* xr4 = (const float4*)__builtin_assume_aligned(xr, 16);  // src_col, the row widths and the chunk offset are multiples of 4 floats
       const float4* wc4 = (const float4*)__builtin_assume_aligned(wc, 16);
-      float a0 = acc0, a1 = acc1, a2 = acc2, a3 = acc3;
+      float a = acc;
       // software pipeline: the 8 operand reads of k-block kb + 1 go out before the 16 dependent fmas of k-block kb (the compiler's
       // own schedule re-used one register set: reads and fmas alternated; 2807 -> 1876 cycles per 128 k in isolation together
       // with the DMA change above)
@@ -549,7 +545,7 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
   W[0] = wc4[((KB) * 4) * (GROW / 4)], W[1] = wc4[((KB) * 4 + 1) * (GROW / 4)], W[2] = wc4[((KB) * 4 + 2) * (GROW / 4)], \
   W[3] = wc4[((KB) * 4 + 3) * (GROW / 4)]
 #define TBX_FD(XC, WC, G) \
-  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #G "," #G "," #G "," #G "] row_mask:0xf bank_mask:0xf" : "+v"(a##G) : "v"(XC), "v"(WC))
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #G "," #G "," #G "," #G "] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(XC), "v"(WC))
 #define TBX_FM(XQ, W)                                                                                  \
   TBX_FD(XQ.x, W[0].x, 0); TBX_FD(XQ.x, W[0].y, 1); TBX_FD(XQ.x, W[0].z, 2); TBX_FD(XQ.x, W[0].w, 3);      \
   TBX_FD(XQ.y, W[1].x, 0); TBX_FD(XQ.y, W[1].y, 1); TBX_FD(XQ.y, W[1].z, 2); TBX_FD(XQ.y, W[1].w, 3);      \
@@ -579,10 +575,10 @@ __device__ __forceinline__ void linear_gemv(const tbx_stage_t& s, const Tile<MT,
 #undef TBX_RD
 #undef TBX_FD
 #undef TBX_FM
-      acc0 = a0, acc1 = a1, acc2 = a2, acc3 = a3;
+      acc = a;
       TBX_SUB(3);
       if (kc == nkc - 1) {
-        float v = (acc0 + acc1) + (acc2 + acc3);
+        float v = acc;
         if (s.act == TBX_ACT_RELU) v = fmaxf(v, 0.f);
         if (to_global) {
           if (live && r < t.n_valid) {
