@@ -46,6 +46,11 @@ if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
 if "TCP_TCC_READ_REQ_sum" in c:
     out["l2_read_requests"] = c["TCP_TCC_READ_REQ_sum"]
+if "SQ_INSTS_VALU" in c:
+    # the agents' launches of a step: 4 self launches (25 pairs per row) + 4 cross launches (64 map + 25 light pairs): 57 pairs per row on average
+    out["valu_insts_per_pair"] = c["SQ_INSTS_VALU"] * 64.0 / (4096 * 57.0) / 64.0
+    out["valu_insts_per_wave_pass"] = c["SQ_INSTS_VALU"] / 4096.0 / (57.0 / 8.0)
+out["kv_bf16"] = False
 print(json.dumps(out, indent=1))
 PY
 cat gpurun_out/${tag}_attn_counters.json | head -50
