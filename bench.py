@@ -198,10 +198,10 @@ class KernelEvents:
         def ht(x, hd):
             return T("tile", "heads", 2.0 * x.shape[0] * (2 * (256 * 128 + 2 * 128 * 128) + 128 * 384 + 3 * 128 * 128 + 3 * 128 * 16), sv["heads_tile"], x, hd)
 
-        def wt(attr, pe, row_invalid, in_images, pn_images, window, out, add_mode=False):
+        def wt(attr, pe, row_invalid, in_images, pn_images, window, out, add_mode=False, drop=None):
             mac = (32 * 128 + 2 * 128 * 128 if add_mode else 32 * 64 + 2 * 64 * 64) + 3 * 128 * 64
             return T("tile", "window", 2.0 * attr.shape[0] * mac, sv["window_tile"], attr, pe, row_invalid, in_images, pn_images, window, out,
-                     add_mode=add_mode)
+                     add_mode=add_mode, drop=drop)
 
         def other(name):
             return lambda *a, **kw: T("other", name, 0.0, sv[name], *a, **kw)

@@ -267,6 +267,12 @@ typedef struct tbx_window_tile {
   int32_t d_mlp;     /* 64: "cat" mode (agents); 128: "add" mode (traffic lights: traffic_light.py:219-226 - the input MLP is
                       * 32 -> 128 -> 128 -> 128 and `pe` is ONE feature row per window [n_groups, 128] added to its output) */
   int32_t add_mode, pad_;
+  /* keyed dropouts of training's stepping pass on the three PointNet layers' relu outputs (polyline_encoder.py:52-58 through
+   * mlp.py:60-61; tbx_keyed_dropout's mask of (seed, site, step, row, column of 64)); drop_thresh = 0: none */
+  const uint64_t* drop_seed;
+  uint32_t drop_thresh;
+  float drop_scale;
+  int32_t drop_site[3], drop_step;
 } tbx_window_tile_t;
 int tbx_window_tile(const tbx_window_tile_t* args /* host */, void* stream);
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple

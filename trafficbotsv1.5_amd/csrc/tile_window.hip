@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
     __syncthreads();
   }
   // ---- PointNet layers: P1 -> P0 -> P1 -> out (wb[1] holds layer 1's unit)
-#define TBX_PN(CUR, SRC, DST, LAST, NEXT_IMG)                                                             \
+#define TBX_PN(CUR, SRC, DST, LAST, NEXT_IMG, LAYER)                                                      \
   do {                                                                                                    \
     if (!(LAST)) load_unit(wb[1 - (CUR)], NEXT_IMG, nt, lane);                                            \
     Acc acc;                                                                                              \
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
     const W& w = wb[CUR];                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], (SRC) + aoff, s); \
     f32x4 h = relu4(acc.sum() + w.bias);                                                                  \
+    if (t.drop_thresh != 0u && j < Wn) {                                                                  \
+      DropKey4 dk;                                                                                        \
+      dk.init(t.drop_seed, (uint32_t)t.drop_site[LAYER], (uint32_t)t.drop_step, t.drop_thresh, t.drop_scale); \
+      h = dk.apply(h, grp * Wn + j, c_out, 64);                                                           \
+    }                                                                                                     \
     f32x4 m;                                                                                              \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] = row16_max(inv ? -INFINITY : h[r]);               \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] = m[r] == -INFINITY ? 0.f : m[r];                  \
@@ -177,11 +182,11 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
       gst4(t.out + grp * D + 64 + c_out, m);                                                              \
     }                                                                                                     \
   } while (0)
-  TBX_PN(1, P1, P0, false, t.pn_images[1]);
+  TBX_PN(1, P1, P0, false, t.pn_images[1], 0);
   __syncthreads();
-  TBX_PN(0, P0, P1, false, t.pn_images[2]);
+  TBX_PN(0, P0, P1, false, t.pn_images[2], 1);
   __syncthreads();
-  TBX_PN(1, P1, P0, true, t.pn_images[2]);
+  TBX_PN(1, P1, P0, true, t.pn_images[2], 2);
 #undef TBX_PN
 }
 
@@ -198,6 +203,7 @@ extern "C" int tbx_window_tile(const tbx_window_tile_t* args, void* stream) {
     return TBX_ERR_UNSUPPORTED;
   if (!((t.d_mlp == 64 && t.add_mode == 0) || (t.d_mlp == 128 && t.add_mode == 1))) return TBX_ERR_UNSUPPORTED;
   if ((((uintptr_t)t.attr) | ((uintptr_t)t.pe) | ((uintptr_t)t.out)) & 15) return TBX_ERR_ALIGN;
+  if (t.drop_thresh != 0u && t.drop_seed == nullptr) return TBX_ERR_ARG;
   WindowArgs a;
   a.t = t;
   static bool attr_set = false;

@@ -100,7 +100,9 @@ class WindowTile(C.Structure):
     """tbx_window_tile_t (include/tbx_hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("attr", "pe", "row_invalid")] + [("in_images", C.c_void_p * 3), ("pn_images", C.c_void_p * 3),
                 ("out", C.c_void_p), ("window", C.c_int32), ("ld_attr", C.c_int32), ("n_groups", C.c_int64)]
-                + [(n, C.c_int32) for n in ("attr_cols", "d_mlp", "add_mode", "pad_")])
+                + [(n, C.c_int32) for n in ("attr_cols", "d_mlp", "add_mode", "pad_")]
+                + [("drop_seed", C.c_void_p), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_site", C.c_int32 * 3),
+                   ("drop_step", C.c_int32)])
 
 
 class SimState(C.Structure):
@@ -663,7 +665,7 @@ def heads_tile(x, hd: dict):
     _check(load().tbx_heads_tile(C.byref(a), stream_ptr()), "tbx_heads_tile")
 
 
-def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False):
+def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None):
     """tbx_window_tile. cat mode: attr [G * window, >= 4 cols], pe [G * window, 64]; add mode: pe = one feature row per window
     [G, 128], the input MLP is 128 wide. row_invalid u8 [G * window] -> out [G, 128]."""
     a = WindowTile()
@@ -675,6 +677,12 @@ def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, a
         a.in_images[i], a.pn_images[i] = _ptr(in_images[i], torch.float32), _ptr(pn_images[i], torch.float32)
     a.out, a.window, a.n_groups = _ptr(out, torch.float32), int(window), out.shape[0]
     assert attr.shape[0] == out.shape[0] * window
+    if drop is not None:  # dict(p, seed, step, sites = the three PointNet layers' dropout site ids): training's stepping pass
+        th = drop["p"] * 4294967296.0
+        a.drop_thresh, a.drop_scale = (1 if 0 < th < 1 else int(th)), 1.0 / (1.0 - drop["p"])
+        a.drop_seed, a.drop_step = _ptr(drop["seed"], torch.int64), int(drop["step"])
+        for i, st in enumerate(drop["sites"]):
+            a.drop_site[i] = int(st)
     _check(load().tbx_window_tile(C.byref(a), stream_ptr()), "tbx_window_tile")
 
 

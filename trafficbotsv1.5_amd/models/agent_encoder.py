@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import current as engine_current, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok, tile_small_ok
+from ..engine import current as engine_current, drop_site, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -99,10 +99,15 @@ class AgentEncoder(nn.Module):
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * A, dev, hip.group_tile_rows(W, n * A))  # small launches: layer 0's projections in the windows' launch too
         ie = self.input_encoder
-        wt_ = self._window_tile_images(prep["attr"].shape[1]) if (fp is None and W <= 16 and (tile_rows_ok(n * A) or tile_small_ok())) else None
+        wt_ = self._window_tile_images(prep["attr"].shape[1]) if (fp is None and W <= 16 and (tile_rows_ok(n * A, keyed_dropout=True) or tile_small_ok())) else None
         ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
-        if wt_ is not None:  # large launches: the whole temporal PointNet as one tbx_window_tile launch
-            hip.window_tile(prep["attr"], prep["pe"], prep["row_invalid"], wt_[0], wt_[1], W, x)
+        if wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch (training's stepping pass: with its keyed dropouts)
+            sites = [drop_site(m.dropout_p) for m in self.temp_encoder.mlp_layers]  # the ids emit_pointnet's DROPOUT stages would take
+            drop = None
+            if any(s_ is not None for s_ in sites):
+                assert all(s_ is not None for s_ in sites)
+                drop = dict(p=sites[0][0], seed=sites[0][1], step=sites[0][3], sites=[s_[2] for s_ in sites])
+            hip.window_tile(prep["attr"], prep["pe"], prep["row_invalid"], wt_[0], wt_[1], W, x, drop=drop)
             ch = None
         elif (ie.mode == "cat" and len(ie.mlp.linear_layers()) == 3 and ie.mlp.output_dim % 16 == 0 and prep["attr"].shape[1] % 4 == 0
                 and ie.mlp.output_dim + ie.pe_dim <= d):
