@@ -306,14 +306,15 @@ def test_split_bf16_linear_close_to_exact_fp32_linear(hip, dev, rows, k, n, grou
     assert float((err / mag).max()) < 3e-5, float((err / mag).max())
 
 
+@pytest.mark.parametrize("n", [32, 16])  # 2048 rows: a wave per row, plain gathers; 1024 rows: one wave per SIMD -> the LDS-ring kernel
 @pytest.mark.parametrize("mode", ["rel", "emb", "rel_dropout"])
-def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mode):
+def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mode, n):
     """Grids of >= 1024 rows run one wavefront per row, smaller ones four wavefronts per row merged through LDS (checked
     against the oracle above): the same 2048 rows as one launch and as four 512-row launches must agree - two segments with
     shared tables (batch_div), masked pairs, a row without a valid target, in-register and materialised embeddings, and the
     dropout mask (keyed by the launch-local row index, hence compared on the first quarter only)."""
     g = torch.Generator().manual_seed(12)
-    n, S, T1, T2, K1, K2, div = 32, 64, 128, 96, 25, 9, 8
+    S, T1, T2, K1, K2, div = 64, 128, 96, 25, 9, 8
     rows = n * S
     P = import_module("trafficbots_amd.utils.pose_emb")
     pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
@@ -348,7 +349,7 @@ def test_attention_large_grid_kernel_matches_small_grid_kernel(tb, hip, dev, mod
                         drop=drop)
         return out, flag
 
-    big, flag_big = run(0, n)                      # 2048 rows: a wave per row
+    big, flag_big = run(0, n)                      # 2048 / 1024 rows: a wave per row
     parts = [run(b0, 8) for b0 in range(0, n, 8)]  # 512 rows each: four waves per row
     n_cmp = 1 if drop is not None else len(parts)  # the dropout counter uses the launch's own row numbering
     small = torch.cat([p[0] for p in parts[:n_cmp]])

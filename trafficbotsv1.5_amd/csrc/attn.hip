@@ -284,7 +284,7 @@ struct RingGeom {
   static constexpr int NDMA = (KV16 ? 4 : 8) + 1;
 };
 
-template <bool KV16, int R, int WPE>
+template <bool KV16, int R, int WPE, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void knarpe_attn_ring_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ring_s[];
   using G = RingGeom<KV16>;
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     }
     glds_4(S.rel_pose + ((int64_t)row * S.k + tt) * 3 + (s8 < 3 ? s8 : 0), dst + G::KVB);
   };
-  auto consume = [&](int sg, int base, int slot) {
+  DropKey dk;
+  if constexpr (DROP) dk.init(a, row, b);
+  auto consume = [&](int sg, int base, int slot, int t_off) {
 #pragma clang fp contract(off)
     const tbx_attn_seg_t& S = a.seg[sg];
     const int t = base + tg;
@@ -411,9 +413,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     for (int h = 0; h < NH; ++h) {
       m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];
       const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
-      l_run[h] += pr;
-      fma4(oacc[h], pr, v[h]);
-      eacc[h].fma(pr, e);
+      l_run[h] += pr;  // the normaliser is that of the un-dropped softmax
+      float pd = pr;
+      if constexpr (DROP) pd = dk.keep((uint32_t)(t_off + t), (uint32_t)h, a.drop_thresh) ? pr * a.drop_scale : 0.f;
+      fma4(oacc[h], pd, v[h]);
+      eacc[h].fma(pd, e);
     }
   };
 
@@ -429,8 +433,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
   };
 #pragma unroll 1
   for (int i = 0; i < R - 1; ++i) issue_next();
-  int cslot = 0;
-  for (int sg = 0; sg < a.n_seg; ++sg) {
+  int cslot = 0, t_off = 0;
+  for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const int ks = a.seg[sg].k;
 #pragma unroll 1
     for (int base = 0; base < ks; base += 8) {
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * G::NDMA) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      consume(sg, base, cslot);
+      consume(sg, base, cslot, t_off);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's bytes are in registers before a later DMA may overwrite it
       cslot = cslot + 1 == R ? 0 : cslot + 1;
       --ahead;
@@ -846,27 +850,33 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   hipStream_t hs = (hipStream_t)stream;
   // the LDS-ring form (opt-in, TBX_ATTN_RING=1 / 2): large launches without dropout whose segments are all given as relative poses
   static const int ring_mode = [] { const char* e = getenv("TBX_ATTN_RING"); return e ? atoi(e) : 0; }();  // measured: no gain, opt-in
-  bool ring_ok = big && ring_mode != 0 && a.drop_thresh == 0u;
+  // ... and, by default, launches that leave every SIMD with at most ONE wave (<= 1024 rows a wave per row: training's stepping pass,
+  // 16 scenes x 64 agents): a lone wave has no partner to hide its gathers behind, the ring does (24 -> ~9 us per launch)
+  static const int ring_lone_rows = [] { const char* e = getenv("TBX_ATTN_RING_LONE_ROWS"); return e ? atoi(e) : 1536; }();
+  const bool lone = big && a.n_rows <= ring_lone_rows && segs[0].kv_bf16 == 0;
+  bool ring_ok = big && (ring_mode != 0 || lone) && (a.drop_thresh == 0u || segs[0].kv_bf16 == 0);
   for (int i = 0; i < n_seg; ++i) ring_ok = ring_ok && segs[i].rel_pose != nullptr && segs[i].emb == nullptr && segs[i].k <= 128 && segs[i].k > 0;
   if (ring_ok) {
-#define TBX_RING_LAUNCH(KV16F, RF, WPEF)                                                                                          \
+#define TBX_RING_LAUNCH(KV16F, RF, WPEF, DROPF)                                                                                   \
   do {                                                                                                                            \
     constexpr int bytes = 4 * (RF) * RingGeom<KV16F>::SLOT;                                                                       \
     static bool set = false;                                                                                                      \
     if (!set) {                                                                                                                   \
-      if (hipFuncSetAttribute((const void*)knarpe_attn_ring_kernel<KV16F, RF, WPEF>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                              bytes) != hipSuccess)                                                                               \
+      if (hipFuncSetAttribute((const void*)knarpe_attn_ring_kernel<KV16F, RF, WPEF, DROPF>,                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)                                   \
         return TBX_ERR_LAUNCH;                                                                                                    \
       set = true;                                                                                                                 \
     }                                                                                                                             \
-    hipLaunchKernelGGL((knarpe_attn_ring_kernel<KV16F, RF, WPEF>), grid, block, bytes, hs, a);                                    \
+    hipLaunchKernelGGL((knarpe_attn_ring_kernel<KV16F, RF, WPEF, DROPF>), grid, block, bytes, hs, a);                             \
   } while (0)
     if (segs[0].kv_bf16 != 0)
-      TBX_RING_LAUNCH(true, 4, 2);
+      TBX_RING_LAUNCH(true, 4, 2, false);
+    else if (a.drop_thresh != 0u)
+      TBX_RING_LAUNCH(false, 4, 1, true);
     else if (ring_mode == 2)
-      TBX_RING_LAUNCH(false, 2, 2);
+      TBX_RING_LAUNCH(false, 2, 2, false);
     else
-      TBX_RING_LAUNCH(false, 4, 1);
+      TBX_RING_LAUNCH(false, 4, 1, false);
 #undef TBX_RING_LAUNCH
     return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
   }
