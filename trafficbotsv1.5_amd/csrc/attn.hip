@@ -21,6 +21,18 @@
 #include "attn_core.h"
 #include "tbx_common.h"
 
+#ifdef TBX_ATTN_CLOCK
+namespace tbx_attn {
+__device__ unsigned long long g_attn_clk[8];
+}
+extern "C" int tbx_debug_attn_clock(unsigned long long* host_out) {  // copies and clears the phase sums (profiling build only)
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tbx_attn::g_attn_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(tbx_attn::g_attn_clk), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 using namespace tbx_attn;

@@ -198,6 +198,13 @@ struct RowAcc {
   }
 };
 
+#ifdef TBX_ATTN_CLOCK
+// Profiling build only (libtbx_hip_clk.so, tools/attn_clock.py): wave 0 of workgroup 0 sums the 100 MHz s_memtime ticks it spends in
+// each phase of a pass: [0] index / mask / pose loads -> embedding, [1] -> scores (K rows), [2] -> softmax, [3] -> accumulate (V rows), [4] passes
+extern __device__ unsigned long long g_attn_clk[8];
+#define TBX_ACLK(VAR, DEP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR) : "v"(DEP) : "memory")
+#endif
+
 // The target sweep of wavefront `wir` of the WPR that share source row `row` (batch entry b): segment by segment, 8 targets per
 // pass, starting at target wir * 8 with stride 8 * WPR. `a` supplies seg[], n_seg, scale2 and (DROP) the dropout fields.
 template <int WPR, bool DROP, bool KV16, class A>
@@ -217,6 +224,10 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
     const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
     const int64_t pbase = (int64_t)row * S.k;
     for (int base = wir * 8; base < S.k; base += 8 * WPR) {
+#ifdef TBX_ATTN_CLOCK
+      unsigned long long c0, c1, c2, c3, c4;
+      TBX_ACLK(c0, l_run[0]);
+#endif
       const int t = base + tg;
       const bool active = t < S.k;
       const int64_t pi = pbase + (active ? t : S.k - 1);
@@ -237,11 +248,17 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
       // rescaling of the 80 accumulator registers: ~18 % fewer VALU instructions in a loop that is VALU-issue bound.
       float sc[NH];
       bool jump = false;
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(c1, ((e.xc.x + e.xs.y) + (e.yc.x + e.ys.y)) + ((e.wc.x + e.wc.w) + (e.ws.y + e.ws.z)));
+#endif
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         sc[h] = (tbx::group8_sum(pair_score(kq[h], qv[h], e, qt[h])) + qb[h]) * a.scale2;  // scaled after masking as the reference does
         jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
       }
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(c2, (sc[0] + sc[1]) + (sc[2] + sc[3]));
+#endif
       if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -254,6 +271,12 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
           }
         }
       }
+#ifdef TBX_ATTN_CLOCK
+      float prs = 0.f;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) prs += ok ? __builtin_amdgcn_exp2f(sc[h] - ((ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h])) : 0.f;
+      TBX_ACLK(c3, prs);
+#endif
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];  // the slot's first valid target sets the reference
@@ -264,6 +287,12 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
         fma4(oacc[h], pd, v[h]);  // K/V channel block st == h belongs to head h
         eacc[h].fma(pd, e);
       }
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(c4, ((oacc[0].x + oacc[1].y) + (oacc[2].z + oacc[3].w)) + ((eacc[0].xc.x + eacc[1].ws.w) + (eacc[2].yc.y + eacc[3].wc.z)));
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_attn_clk[0] += c1 - c0, g_attn_clk[1] += c2 - c1, g_attn_clk[2] += c3 - c2, g_attn_clk[3] += c4 - c3, g_attn_clk[4] += 1;
+      }
+#endif
     }
   }
 
