@@ -11,6 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ["TBX_HIP_LIB"] = str(ROOT / "trafficbotsv1.5_amd" / "csrc" / "libtbx_hip_clk.so")
+os.environ["TBX_ATTN_RING_LONE_ROWS"] = "0"  # the plain sweep (the instrumented one) at every size
 import torch  # noqa: E402
 
 from __graft_entry__ import load_package  # noqa: E402
