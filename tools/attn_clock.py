@@ -11,7 +11,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ["TBX_HIP_LIB"] = str(ROOT / "trafficbotsv1.5_amd" / "csrc" / "libtbx_hip_clk.so")
-os.environ["TBX_ATTN_RING_LONE_ROWS"] = "0"  # the plain sweep (the instrumented one) at every size
+RING = len(sys.argv) > 1 and sys.argv[1] == "ring"
+os.environ["TBX_ATTN_RING_LONE_ROWS"] = "0"  # the plain sweep at every size ...
+if RING:
+    os.environ["TBX_ATTN_RING"] = "1"  # ... or the LDS-ring kernel (python tools/attn_clock.py ring)
 import torch  # noqa: E402
 
 from __graft_entry__ import load_package  # noqa: E402
@@ -50,10 +53,10 @@ for n, S in ((16, 64), (32, 128)):
         hip.knarpe_attn(q, 0, 128, bias, n, S, segs, out, flag, fxy, fyw)
     lib.tbx_debug_attn_clock(buf)
     passes = buf[4]
-    print(f"rows {rows}: {passes / reps:.0f} passes per launch of wave 0; per pass:")
+    print(f"rows {rows}: {passes / reps:.0f} passes per launch of wave 0; shader cycles per pass:")
+    names, vals = (["issue the DMAs of pass p + R - 1", "wait for pass p's DMAs", "LDS reads + the pass's arithmetic"], buf[5:8]) if RING else (PH, buf[:4])
     tot = 0.0
-    for name, v in zip(PH, buf[:4]):
-        us = v / 100.0 / passes
-        tot += us
-        print(f"    {name:60s} {us:6.3f} us")
-    print(f"    {'sum':60s} {tot:6.3f} us")
+    for name, v in zip(names, vals):
+        tot += v / passes
+        print(f"    {name:60s} {v / passes:8.0f}")
+    print(f"    {'sum':60s} {tot:8.0f}")

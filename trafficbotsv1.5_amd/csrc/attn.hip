@@ -450,14 +450,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     const int ks = a.seg[sg].k;
 #pragma unroll 1
     for (int base = 0; base < ks; base += 8) {
+#ifdef TBX_ATTN_CLOCK
+      unsigned long long r0, r1, r2, r3;
+      TBX_ACLK(r0, l_run[0]);
+#endif
       issue_next();  // into the slot consumed in the previous pass (its fragments are in registers / used: lgkmcnt is waited below)
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(r1, l_run[0]);
+#endif
       // passes issued and not yet consumed: `ahead` (this one included). The oldest outstanding DMA group is this pass's.
       if (ahead == R)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * G::NDMA) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(r2, l_run[0]);
+#endif
       consume(sg, base, cslot, t_off);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's bytes are in registers before a later DMA may overwrite it
+#ifdef TBX_ATTN_CLOCK
+      TBX_ACLK(r3, (oacc[0].x + l_run[1]) + (eacc[3].ws.w + eacc[0].xc.x));
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        g_attn_clk[5] += r1 - r0, g_attn_clk[6] += r2 - r1, g_attn_clk[7] += r3 - r2, g_attn_clk[4] += 1;
+#endif
       cslot = cslot + 1 == R ? 0 : cslot + 1;
       --ahead;
     }
