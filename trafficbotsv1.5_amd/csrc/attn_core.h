@@ -216,51 +216,24 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
   ESlice(&eacc)[NH] = st.eacc;
   DropKey dk;
   if constexpr (DROP) dk.init(a, row, b);
-  // The lane's target of a pass: its table row index and validity are fetched ONE PASS AHEAD (2 registers), its relative pose FIRST in
-  // the pass. The phase clock of a pass (tools/attn_clock.py, a lone wave at 1024 rows) read 2350 of 3600 cycles from the top of the
-  // pass to the embedding: index load -> (dependent) K / V row gathers -> relative pose (issued behind them; VMEM returns in order) ->
-  // 8 sincos. Now a pass issues [pose, 8 row gathers, next index / mask] back to back and rebuilds the embedding while the rows fly.
-  struct Pre {
-    int j;
-    bool ok;
-  };
-  auto fetch = [&](int sg, int base, Pre& p) {
-    const tbx_attn_seg_t& S = a.seg[sg];
-    const int t = base + tg;
-    const bool active = t < S.k;
-    const int64_t pi = (int64_t)row * S.k + (active ? t : S.k - 1);
-    p.j = S.idx[pi];
-    p.ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
-  };
-  // pass cursor: (segment, base) of this wave's passes in order; sg == n_seg: no pass left
-  auto first_in = [&](int& sg, int& base) {
-    base = wir * 8;
-    while (sg < a.n_seg && base >= a.seg[sg].k) ++sg;
-  };
-  int sg = 0, base = 0;
-  first_in(sg, base);
-  Pre cur, nxt;
-  cur.j = 0, cur.ok = false;
-  nxt = cur;
-  if (sg < a.n_seg) fetch(sg, base, cur);
-  int t_off = 0, t_off_sg = 0;  // global slot of segment sg's first target (the dropout counter and the backward index targets 0..ktot)
-  while (sg < a.n_seg) {
-    for (; t_off_sg < sg; ++t_off_sg) t_off += a.seg[t_off_sg].k;
+  int t_off = 0;  // global slot of the segment's first target (the dropout counter and the backward index targets 0..ktot)
+  for (int sg = 0; sg < a.n_seg; t_off += a.seg[sg].k, ++sg) {
     const tbx_attn_seg_t& S = a.seg[sg];
     // (bf16 tables: element offsets, half the bytes - the pointer is kept as float* and scaled by hand)
     constexpr int ES = KV16 ? 2 : 1;  // table elements per float slot
     const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-    {
+    const int64_t pbase = (int64_t)row * S.k;
+    for (int base = wir * 8; base < S.k; base += 8 * WPR) {
 #ifdef TBX_ATTN_CLOCK
       unsigned long long c0, c1, c2, c3, c4;
       TBX_ACLK(c0, l_run[0]);
 #endif
       const int t = base + tg;
-      const bool ok = cur.ok;
-      const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
-      float rel[3] = {0.f, 0.f, 0.f};
-      if (S.emb == nullptr) rel[0] = S.rel_pose[pi * 3], rel[1] = S.rel_pose[pi * 3 + 1], rel[2] = S.rel_pose[pi * 3 + 2];
-      const float* trow = (const float*)((const char*)kvb + ((int64_t)cur.j * S.ld_kv) * (4 / ES));
+      const bool active = t < S.k;
+      const int64_t pi = pbase + (active ? t : S.k - 1);
+      const int j = S.idx[pi];
+      const bool ok = (S.invalid[pi] == 0) & active;  // uniform within the 8-lane group (both sides evaluated: no branch)
+      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
       float4 kq[4], v[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
@@ -268,15 +241,7 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
         v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
       }
       ESlice e;
-      if (S.emb != nullptr) e.load(S.emb + pi * DR, s8);
-      // the next pass's small loads, behind this pass's row gathers
-      int nsg = sg, nbase = base + 8 * WPR;
-      if (nbase >= S.k) {
-        ++nsg;
-        first_in(nsg, nbase);
-      }
-      if (nsg < a.n_seg) fetch(nsg, nbase, nxt);
-      if (S.emb == nullptr) fq.embed(rel, e);
+      load_e(S, pi, s8, fq, e);
       // Online softmax in the base-2 domain (scores pre-multiplied by log2(e) / sqrt(d_head), v_exp_f32 directly) with a
       // LAZY reference: a slot's reference m is its first valid score and moves only when a later score exceeds it by more
       // than 64 (2^64 headroom in fp32; a wave-uniform, practically never taken branch). The steady state has no
@@ -328,10 +293,9 @@ __device__ __forceinline__ void sweep(const A& a, int row, int b, int wir, int s
         g_attn_clk[0] += c1 - c0, g_attn_clk[1] += c2 - c1, g_attn_clk[2] += c3 - c2, g_attn_clk[3] += c4 - c3, g_attn_clk[4] += 1;
       }
 #endif
-      sg = nsg, base = nbase;
-      cur = nxt;
     }
   }
+
 }
 
 // Merge of the wavefront's 8 target slots (lanes with equal s8: xor 8, 16, 32): on return every lane holds, for its channel
