@@ -80,14 +80,11 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 
   constexpr int E_FOLD = 0, E_OUT = 1, E_L1 = ATTN ? 2 : 0, E_L2 = E_L1 + 4, E_Q = (ATTN ? 2 : 0) + (FFN ? 8 : 0);
   constexpr int E_KV = E_Q + 1, E_QF = E_Q + (PROJ == 2 ? 3 : 1), E_END = E_Q + (PROJ == 2 ? 4 : (PROJ == 1 ? 2 : 0));
-  // weight units: a ring of three register buffers, TWO units in flight behind the one being multiplied (a unit requested one
-  // round ahead arrived ~a loaded-memory round trip later - about the length of a round: every round waited for its weights)
-  W wb[3];
+  W wb[2];
   load_unit(wb[0], a.ent[0], wave, lane);
-  if constexpr (E_END > 1) load_unit(wb[1], a.ent[1], wave, lane);
 #define TBX_NEXT(E)                                                          \
   do {                                                                       \
-    if constexpr ((E) + 2 < E_END) load_unit(wb[((E) + 2) % 3], a.ent[(E) + 2], wave, lane); \
+    if constexpr ((E) + 1 < E_END) load_unit(wb[((E) + 1) & 1], a.ent[(E) + 1], wave, lane); \
   } while (0)
 
   uint8_t f_nov = 0, f_inv = 0;
@@ -123,7 +120,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   if constexpr (ATTN) {
     {  // value half of linear_rpe: y_h = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_h; wave w = head w / 2, 16 of its 32 channels
       TBX_NEXT(E_FOLD);
-      const W& w = wb[E_FOLD % 3];
+      const W& w = wb[E_FOLD & 1];
       Acc acc;
       acc.zero();
       const int step0 = 4 + 4 * (wave >> 1);
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     __syncthreads();
     {  // x += row without a valid target ? 0 : out_proj(y)
       TBX_NEXT(E_OUT);
-      const W& w = wb[E_OUT % 3];
+      const W& w = wb[E_OUT & 1];
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_L1(R)                                                                               \
   do {                                                                                          \
     TBX_NEXT(E_L1 + (R));                                                                       \
-    const W& w = wb[(E_L1 + (R)) % 3];                                                          \
+    const W& w = wb[(E_L1 + (R)) & 1];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
@@ -186,7 +183,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_L2(R)                                                                                         \
   do {                                                                                                    \
     TBX_NEXT(E_L2 + (R));                                                                                 \
-    const W& w = wb[(E_L2 + (R)) % 3];                                                                    \
+    const W& w = wb[(E_L2 + (R)) & 1];                                                                    \
     if ((R) == 0) bias = w.bias;                                                                          \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
   } while (0)
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     __syncthreads();
     {  // q
       TBX_NEXT(E_Q);
-      const W& w = wb[E_Q % 3];
+      const W& w = wb[E_Q & 1];
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_KV(R)                                                                               \
   do {                                                                                          \
     TBX_NEXT(E_KV + (R));                                                                       \
-    const W& w = wb[(E_KV + (R)) % 3];                                                          \
+    const W& w = wb[(E_KV + (R)) & 1];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
@@ -249,7 +246,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     __syncthreads();
     {  // qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (one step, the head's own)
       TBX_NEXT(E_QF);
-      const W& w = wb[E_QF % 3];
+      const W& w = wb[E_QF & 1];
       const int h = wave >> 1;
       const int qt_off = PROJ == 2 ? 3 * D : D;
 #pragma unroll
