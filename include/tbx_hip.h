@@ -189,7 +189,10 @@ typedef struct tbx_dec_layer {
   void* kv16_out;             /* bf16 K/V tables (mid.self_seg.kv_bf16): [rows, 256] bfloat16 copy of the next layer's k | v; else NULL */
   const tbx_heads_tail_t* heads; /* host pointer or NULL; only with qkv_out == NULL */
   float norm2_eps, next_norm_eps;
-  int32_t ld_qkv_out, pad_;
+  int32_t ld_qkv_out;
+  int32_t tail_mfma32; /* != 0: out_proj2 / linear1 / linear2 / next_in_proj / next_qfold are tbx_pack_weight_mfma32 images and the
+                        * tail's LINEAR stages run on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32
+                        * fma chains; the heads' images stay tbx_pack_weight_gemv images */
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
 
@@ -228,6 +231,17 @@ typedef struct tbx_layer_tile {
   uint32_t drop_thresh;
   float drop_scale;
   int32_t drop_site[3], drop_step;
+  /* rider (rider_rows > 0; first-projection launches only: no attn_out, no linear1_image, proj_n = 384): an independent 4-stage
+   * MLP over rider_rows OTHER rows in extra workgroups of the same launch - the heads' navigation embedding (navigation.py:65-79 +
+   * add_navi_latent.py:43-50), which depends on nothing the layers produce: a launch of its own on another stream costs a
+   * cross-queue signal and a wait (~11 us of idle queue on the stepping stream, measured) -
+   *   y = rider_add + (W0 rider_in + b0);  h = relu(W1 y + b1);  h = relu(W2 h + b2);  h = relu(W3 h + b3);
+   *   rider_out[row] = rider_valid[row] ? h : 0.   All [rider_rows, 128]; images: tbx_pack_weight_mfma32 (n 128, k 128). */
+  const float *rider_in, *rider_add;
+  const float* rider_images[4];
+  const uint8_t* rider_valid;
+  float* rider_out;
+  int64_t rider_rows;
 } tbx_layer_tile_t;
 int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
 /* tbx_heads_tile: the agents' heads (traffic_bots.py:206-221) for large launches, same arithmetic class as tbx_layer_tile:

@@ -602,9 +602,12 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
         kv = kv.to(torch.bfloat16)
     pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
     outs = {}
-    for name, (live, fold, mid, layer) in {"mfma": (0, False, False, False), "mid": (1, True, True, False), "layer": (1, True, True, True)}.items():
+    # "layer_mf": the one-launch layer with its tail's LINEAR stages on the split-bf16 matrix path (Schedule.dec_tail_mfma, the default)
+    for name, (live, fold, mid, layer, mf) in {"mfma": (0, False, False, False, False), "mid": (1, True, True, False, False),
+                                               "layer": (1, True, True, True, False), "layer_mf": (1, True, True, True, True)}.items():
         x = x0.clone()
-        with eng.use(eng.DEFAULT.replace(live_rows=live, attn_fold=fold, dec_mid=mid, dec_layer=layer, kv_bf16=bf16, split_bf16=False)):
+        with eng.use(eng.DEFAULT.replace(live_rows=live, attn_fold=fold, dec_mid=mid, dec_layer=layer, kv_bf16=bf16, split_bf16=False,
+                                         dec_tail_mfma=mf)):
             eng.run_block(blk, x, src_invalid, n, S, eng.SelfKnn(i0, m0, rel=r0),
                           cross=lambda l: [hip.Seg(kv, l * 256, l * 256 + D, T, ic, mc, None, 1, rel=rc)], pose_rpe=pe)
         torch.cuda.synchronize()
@@ -613,6 +616,11 @@ def test_one_launch_decoder_layer_equals_mid_launch_plus_chain(tb, hip, dev, S, 
     assert float((outs["mfma"] - x0).abs().max()) > 1e-3
     for name in ("mid", "layer"):
         assert torch.equal(outs[name], outs["mfma"]), (name, float((outs[name] - outs["mfma"]).abs().max()))
+    # split-bf16 LINEAR stages: < 3e-5 of sum |x||w| per output; through 2-3 layers (LayerNorm, softmax over the changed q | k | v)
+    # the rows stay within 2e-4 of the largest entry, and are not bit-identical (the matrix path did run)
+    err = float((outs["layer_mf"] - outs["mfma"]).abs().max())
+    assert 0.0 < err <= 2e-4 * float(outs["mfma"].abs().max()), err
+    assert float(outs["layer_mf"][src_invalid.bool()].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("tile,groups,gw", [(16, 7, 11), (32, 9, 11), (48, 10, 11), (16, 5, 16)])
@@ -702,6 +710,50 @@ def test_layer_tile_equals_row_chains(tb, hip, dev, mode, S, Ks, T, K, n_layer, 
     err = float((got - ref).abs().max())
     assert err <= (2e-4 if not bf16 else 2e-3) * scale, (err, scale)  # (bf16 tables: the k | v rows are rounded to bf16 AFTER a slightly different fp32 value)
     assert err > 0.0  # the two paths really are different arithmetic
+
+
+@pytest.mark.parametrize("rows,r_rows", [(64, 64), (40, 21), (16, 130)])
+def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows):
+    """tbx_layer_tile_t's rider (extra workgroups of the first-projection launch): y = add + W0 in + b0, three relu LINEARs, invalid
+    rows 0 - against the row chain the engine runs for the heads' navigation embedding (navigation.py:65-79 +
+    add_navi_latent.py:43-50: LINEAR accumulate, three LINEAR + relu, the last with its row mask), on ragged row counts that differ
+    from the main rows'; the main rows' projections are the same bits with and without the rider."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    g = torch.Generator().manual_seed(rows + r_rows)
+    blk = M.TransformerBlockRPE(n_layer=1, mode="enc_self_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.0,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 5)
+    blk = blk.to(dev).eval()
+    l0 = blk.layers[0]
+    D = 128
+    x = torch.randn(rows, D, generator=g).to(dev)
+    Ws = [(torch.randn(D, D, generator=g) / 8).to(dev) for _ in range(4)]
+    bs = [torch.randn(D, generator=g).to(dev) for _ in range(4)]
+    inp, add = torch.randn(r_rows, D, generator=g).to(dev), torch.randn(r_rows, D, generator=g).to(dev)
+    valid = (torch.rand(r_rows, generator=g) < 0.7).to(torch.uint8).to(dev)
+    out = torch.full((r_rows, D), 7.0, device=dev)
+    qkv = [torch.zeros(rows, eng.QKV_LD, device=dev) for _ in range(2)]
+    with eng.use(eng.DEFAULT):
+        proj = lambda o: eng.tile_proj_part(l0.norm1, l0.attn, o, True, None)
+        hip.layer_tile(x, proj=proj(qkv[0]), store_x=False)
+        hip.layer_tile(x, proj=proj(qkv[1]), store_x=False,
+                       rider=dict(inp=inp, add=add, out=out, valid=valid, images=[hip.packed_weight(w, b, mfma32=True) for w, b in zip(Ws, bs)]))
+    ref = torch.empty(r_rows, D, device=dev)
+    C, B0 = hip.Chain, hip.BUF0
+    ch = C(16, 4 * D + 4)
+    ch.load2(inp, B0, 0, add, B0, D)
+    ch.linear(B0, 0, B0, D, Ws[0], bs[0], accum=True)
+    ch.linear(B0, D, B0, 2 * D, Ws[1], bs[1], relu=True)
+    ch.linear(B0, 2 * D, B0, D, Ws[2], bs[2], relu=True)
+    ch.linear(B0, D, B0, 2 * D, Ws[3], bs[3], relu=True, skip_rows=valid, skip_is_valid=True, zero_skipped=True)
+    ch.store(B0, 2 * D, D, ref)
+    ch.run(r_rows)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv[0], qkv[1]) and float(qkv[0].abs().max()) > 0
+    assert float(out[~valid.bool()].abs().max()) == 0.0 and float(ref[~valid.bool()].abs().max()) == 0.0
+    err, scale = float((out - ref).abs().max()), float(ref.abs().max())
+    assert 0.0 < err <= 1e-4 * scale, (err, scale)
 
 
 @pytest.mark.parametrize("n,k,groups,wt", [(128, 128, 1, False), (512, 128, 1, False), (128, 512, 1, False), (384, 128, 1, False),

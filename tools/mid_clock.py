@@ -19,7 +19,9 @@ from __graft_entry__ import load_package  # noqa: E402
 
 PH = ["prologue (DMA requests, x, LN params, q loads)", "self sweep + slot merge", "combine + value fold",
       "out_proj GEMV (+ W_q request)", "LayerNorm (+ W_kf request)", "wait for W_q", "q GEMV", "W_k^T q GEMV",
-      "cross sweep + slot merge", "combine + value fold + stores"]
+      "cross sweep + slot merge", "combine + value fold + stores",
+      "tail: out_proj2", "tail: LayerNorm 2 (+ planes)", "tail: linear1 + relu", "tail: linear2 + store x", "tail: next q | k | v",
+      "tail: next W_k^T q"]
 
 
 def main():
@@ -43,7 +45,7 @@ def main():
     n = lib.tbx_debug_mid_dump(buf, 256)
     for i in range(n):
         c = buf[i * 16:(i + 1) * 16]
-        d = [(c[j + 1] - c[j]) / 100.0 for j in range(10)]  # clock64 = s_memtime: 100 MHz on gfx950
+        d = [(c[j + 1] - c[j]) / 100.0 if c[j + 1] > c[j] else 0.0 for j in range(15)]  # clock64 = s_memtime: 100 MHz on gfx950
         print(f"launch {i}: {sum(d):6.2f} us in workgroup 0")
         for name, v in zip(PH, d):
             print(f"    {name:70s} {v:6.2f} us")

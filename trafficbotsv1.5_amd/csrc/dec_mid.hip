@@ -19,6 +19,7 @@
 #include "../../include/tbx_hip.h"
 #include "attn_core.h"
 #include "tbx_common.h"
+#include "tile_core.h"
 
 namespace {
 
@@ -61,6 +62,7 @@ struct MidArgs {
   int mask_stride;
   float ln2_eps, ln3_eps;
   int ld_qkv_out;
+  int tail_mfma;  // the tail's LINEAR stages on the split-bf16 matrix path: wo2 / w1 / w2 / wqkv / wqt are tbx_pack_weight_mfma32 images
 };
 
 #ifdef TBX_STAGE_CLOCK
@@ -161,7 +163,12 @@ __device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], 
 
 // NW = 4: tbx_knarpe_dec_mid. NW = 8: tbx_knarpe_dec_layer - waves 4..7 take no part in the sweeps; they (and waves 2, 3) fetch the
 // tail's 13 weight chunks, six requesting waves instead of two (the tail was bound by the two waves' DMA issue: 1.46 us per chunk).
-template <bool KV16, int NW>
+// MF (NW = 8 only): the tail's 9 / 13 LINEAR chunks (out_proj, FFN, the next layer's projections) on the split-bf16 matrix path of
+// tile_core.h instead of thread-per-output fma chains fed through two LDS slots by LDS-DMA: the single row is the B operand of a
+// v_mfma_f32_16x16x32_bf16 (its 16 columns all read the same row: column 0 is kept), wave w owns output tile w, its weights come
+// as 8 KiB register units from global memory one unit ahead - all 8 waves multiply, no chunk passes through LDS, a chunk costs its
+// 64 KiB weight stream (~0.5 us) instead of DMA + a 128-long dependent chain (1.15 us).
+template <bool KV16, int NW, bool MF = false>
 __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   __syncthreads();
   MID_CLK(8);
   dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0, NW);  // lands during the sweep
-  if (a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0, NW);  // (slot B is free: the tail's first chunk rides along)
+  if (!MF && a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0, NW);  // (slot B is free: the tail's first chunk rides along)
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -328,6 +335,157 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       lg2[0] = a.ln2_w[lane], lg2[1] = a.ln2_w[64 + lane], lb2[0] = a.ln2_b[lane], lb2[1] = a.ln2_b[64 + lane];
       if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
     }
+    if constexpr (MF) {
+      using tbx_tile::Acc, tbx_tile::W, tbx_tile::load_unit, tbx_tile::split4, tbx_tile::relu4;
+      using tbx_tile::bf16x8, tbx_tile::bf16x4, tbx_tile::f32x4, tbx_tile::u32x2;
+      // one row's bf16 planes: hi at P + 2 k, lo 1 KiB behind; three buffers in slot B (free: nothing is DMA'd there in this mode)
+      char* Ph = (char*)slot_b;  // f, then norm2(x), then the next layer's norm(x) (K = 128)
+      char* Pu = Ph + 2048;      // FFN hidden row (K = 512)
+      char* Pq = Pu + 2048;      // the next layer's q (K = 128)
+      const int g4 = lane >> 4;
+      const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row's outputs: channels c_out .. c_out + 3
+      const int c_out = 16 * wave + 4 * g4;
+      auto put = [&](char* P, int c, const f32x4 v) {
+        u32x2 hi, lo;
+        split4(v, hi, lo);
+        *(u32x2*)(P + c * 2) = hi;
+        *(u32x2*)(P + 1024 + c * 2) = lo;
+      };
+      auto row_planes = [&](char* P, const float* src) {  // a 128-float LDS row -> planes (threads 0..31: 4 values each)
+        if (threadIdx.x < 32) put(P, (int)threadIdx.x * 4, *(const f32x4*)(src + threadIdx.x * 4));
+      };
+      auto step = [&](Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int st) {
+        const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
+        const bf16x8 xl = *(const bf16x8*)(P + 1024 + (st * 32 + g4 * 8) * 2);
+        acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
+        acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
+        acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
+      };
+      const bool heads_mf = a.hw[0] != nullptr && a.qkv_out == nullptr;
+      W wb[2];
+      load_unit(wb[0], a.wo2, wave, lane);
+      load_unit(wb[1], a.w1, wave, lane);
+      __syncthreads();  // o1 = f complete; slot A is free (fold2 was consumed by combine_fold)
+      if (heads_mf && wave >= 2) {  // the heads' first gemv chunk (index 9 -> slot A) rides behind the tail
+        const uint32_t lds0 = lds_addr(slot_a);
+        for (int p = wave - 2; p < 33 * 2; p += NW - 2) glds_1k(a.hw[0] + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
+      }
+      row_planes(Ph, o1);
+      __syncthreads();
+      {  // x += row without a valid cross target ? 0 : out_proj(f)
+        Acc acc;
+        acc.zero();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Ph, st);
+        if (col0) {
+          const f32x4 xv = *(const f32x4*)(xs + c_out);
+          if (valid2) *(f32x4*)(xs + c_out) = xv + (acc.sum() + wb[0].bias);
+        }
+        load_unit(wb[0], a.w1, 8 + wave, lane);
+      }
+      MID_CLK(10);
+      __syncthreads();
+      if (wave == 0) ln_row128(xs, o1, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
+      __syncthreads();
+      row_planes(Ph, o1);
+      __syncthreads();
+      MID_CLK(11);
+      // u = relu(linear1(h)): 4 rounds of 128 channels, no barrier in between (they read Ph, write disjoint parts of Pu)
+#define TBX_MF_L1(R, CUR, NEXT_IMG, NEXT_UNIT)                                                        \
+  do {                                                                                                \
+    Acc acc;                                                                                          \
+    acc.zero();                                                                                       \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, wb[CUR].hi[st], wb[CUR].lo[st], Ph, st); \
+    if (col0) put(Pu, (R) * D + c_out, relu4(acc.sum() + wb[CUR].bias));                              \
+    load_unit(wb[CUR], NEXT_IMG, (NEXT_UNIT) + wave, lane);                                           \
+  } while (0)
+      TBX_MF_L1(0, 1, a.w1, 16);
+      TBX_MF_L1(1, 0, a.w1, 24);
+      TBX_MF_L1(2, 1, a.w2, 0);
+      TBX_MF_L1(3, 0, a.w2, 8);
+#undef TBX_MF_L1
+      __syncthreads();
+      MID_CLK(12);
+      {  // x += linear2(u): K = 512 as 4 units into one accumulator triple; invalid source rows come out as 0
+        Acc acc;
+        acc.zero();
+        const f32x4 bias = wb[1].bias;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Pu, st);
+        load_unit(wb[1], a.w2, 16 + wave, lane);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Pu, 4 + st);
+        load_unit(wb[0], a.w2, 24 + wave, lane);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Pu, 8 + st);
+        if (a.qkv_out != nullptr) load_unit(wb[1], a.wqkv, wave, lane);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Pu, 12 + st);
+        if (a.qkv_out != nullptr) load_unit(wb[0], a.wqkv, 8 + wave, lane);
+        if (col0) {
+          f32x4 v = *(const f32x4*)(xs + c_out) + (acc.sum() + bias);
+          if (!x_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)(xs + c_out) = v;
+          *(TBX_GLOBAL f32x4*)(a.x + (int64_t)row * D + c_out) = v;
+        }
+      }
+      MID_CLK(13);
+      if (!heads_mf) {
+        if (a.qkv_out == nullptr) return;
+        __syncthreads();
+        if (wave == 0) ln_row128(xs, o1, lane, a.ln3_eps, lg3, lb3);  // the next layer's norm_src
+        __syncthreads();
+        row_planes(Ph, o1);
+        __syncthreads();
+        float* qrow_out = a.qkv_out + (int64_t)row * a.ld_qkv_out;
+        {  // q
+          Acc acc;
+          acc.zero();
+#pragma unroll
+          for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Ph, st);
+          const f32x4 q = acc.sum() + wb[1].bias;
+          if (col0) {
+            put(Pq, c_out, q);
+            *(TBX_GLOBAL f32x4*)(qrow_out + c_out) = q;
+          }
+          load_unit(wb[1], a.wqkv, 16 + wave, lane);
+        }
+#define TBX_MF_KV(R, CUR)                                                                             \
+  do {                                                                                                \
+    Acc acc;                                                                                          \
+    acc.zero();                                                                                       \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, wb[CUR].hi[st], wb[CUR].lo[st], Ph, st); \
+    const f32x4 kv = acc.sum() + wb[CUR].bias;                                                        \
+    if (col0) {                                                                                       \
+      *(TBX_GLOBAL f32x4*)(qrow_out + D + (R) * D + c_out) = kv;                                      \
+      if (a.kv16_out != nullptr) {                                                                    \
+        const bf16x4 h16 = __builtin_convertvector(kv, bf16x4);                                       \
+        *(TBX_GLOBAL u32x2*)(a.kv16_out + (int64_t)row * (2 * D) + (R) * D + c_out) = __builtin_bit_cast(u32x2, h16); \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+        TBX_MF_KV(0, 0);
+        load_unit(wb[0], a.wqt, wave, lane);
+        TBX_MF_KV(1, 1);
+#undef TBX_MF_KV
+        __syncthreads();  // q's planes complete
+        MID_CLK(14);
+        {  // W_rpe_k^T q per head: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (the head's own step)
+          const int h = wave >> 1;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            Acc acc;
+            acc.zero();
+            step(acc, wb[0].hi[st], wb[0].lo[st], Pq, h);
+            if (col0) *(TBX_GLOBAL f32x4*)(qrow_out + 3 * D + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
+          }
+        }
+        MID_CLK(15);
+        return;
+      }
+      __syncthreads();  // xs complete: the heads go on with the gemv chunks (index 9 is in flight into slot A)
+    }
+    const bool mf_done = MF;
     // chunk i of the tail -> (image pointer, float4-row offset, rows); slot = B for even i, A for odd i
     const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
     const int n_chunks = a.qkv_out != nullptr ? 13 : (heads ? 9 + 15 : 9);
@@ -356,6 +514,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     };
+    if (!mf_done) {
     // ---- chunk 0 (requested before the cross sweep, landed with combine_fold's vmcnt(0)): x += row without a valid cross target ? 0 : out_proj(f)
     __syncthreads();  // o1 = f complete; slot A is free (fold2 was consumed by combine_fold)
     request(1);
@@ -365,7 +524,9 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       if (valid2) xs[c] = v;
     }
     __syncthreads();
+    MID_CLK(10);
     if (wave == 0) ln_row128(xs, o1, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
+    MID_CLK(11);
     // ---- chunks 1..4: u = relu(linear1(h))
 #pragma unroll 1
     for (int i = 1; i <= 4; ++i) {
@@ -377,6 +538,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
         u[(i - 1) * D + c] = fmaxf(gemv_chain(blk, c, o1, D / 16, blk[c * 4]), 0.f);
       }
     }
+    MID_CLK(12);
     // ---- chunks 5..8: x += linear2(u), one k-chunk of 128 at a time; invalid source rows come out as 0
     float acc = 0.f;
 #pragma unroll 1
@@ -398,6 +560,8 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       xs[threadIdx.x] = v;
       a.x[(int64_t)row * D + threadIdx.x] = v;
     }
+    MID_CLK(13);
+    }  // !mf_done
     if (heads) {
       // ============================================================ the agents' heads in the last layer's launch: the stages of the
       // heads chain (traffic_bots.py:206-221): x += navi_valid ? mlp([x | navi_emb]) : 0 (add_navi_latent.py:52-65), the same with
@@ -485,12 +649,14 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
     }
     // ---- chunk 12: W_rpe_k^T q per head: 4 x (32 -> 128), two outputs per thread
     landed();
+    MID_CLK(14);
 #pragma unroll
     for (int o = (int)threadIdx.x; o < NH * D; o += NT) {
       const int g = o >> 7, c = o & (D - 1);
       const float* blk = slot_b + g * (1 + 2 * 4) * 512;
       qrow_out[3 * D + o] = gemv_chain(blk, c, q2 + g * DH, 2, blk[c * 4]);
     }
+    MID_CLK(15);
   }
 }
 
@@ -581,7 +747,14 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     (void)hipFuncSetAttribute((const void*)dec_mid_kernel<KV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
   } while (0)
-  if (t && p->self_seg.kv_bf16 != 0)
+  a.tail_mfma = t ? t->tail_mfma32 : 0;
+  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0) {
+    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((dec_mid_kernel<true, 8, true>), dim3(a.n_rows), dim3(8 * 64), lds_bytes, hs, a);
+  } else if (t && a.tail_mfma) {
+    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((dec_mid_kernel<false, 8, true>), dim3(a.n_rows), dim3(8 * 64), lds_bytes, hs, a);
+  } else if (t && p->self_seg.kv_bf16 != 0)
     TBX_MID_LAUNCH(true, 8);
   else if (t)
     TBX_MID_LAUNCH(false, 8);

@@ -60,6 +60,66 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
   }
 }
 
+// the rider's tile (tbx_layer_tile_t.rider_*): four 128 -> 128 stages on 16 rows of its own, planes ping-pong Pa <-> Pb
+__device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, char* Pa, char* Pb) {
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)tile * ROWS;
+  const int nv = (t.rider_rows - row0) < ROWS ? (int)(t.rider_rows - row0) : ROWS;
+  const bool row_ok = j < nv;
+  const int64_t grow = row0 + (row_ok ? j : 0);
+  const int aoff = PL::lane_off(lane, 0);
+  const int c_out = 16 * wave + 4 * g;
+  W wb[2];
+  load_unit(wb[0], t.rider_images[0], wave, lane);
+  load_unit(wb[1], t.rider_images[1], wave, lane);
+  const f32x4 add = gld4(t.rider_add + grow * D + c_out);
+  const bool ok = *(const TBX_GLOBAL uint8_t*)(t.rider_valid + grow) != 0;
+  {
+    const int r = tid >> 5, c4 = tid & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < nv) v = gld4(t.rider_in + (row0 + r) * D + c4 * 4);
+    planes_write4<PL>(Pa, r, c4 * 4, v);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
+    planes_write4<PL>(Pb, j, c_out, add + (acc.sum() + wb[0].bias));
+    load_unit(wb[0], t.rider_images[2], wave, lane);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
+    planes_write4<PL>(Pa, j, c_out, relu4(acc.sum() + wb[1].bias));
+    load_unit(wb[1], t.rider_images[3], wave, lane);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
+    planes_write4<PL>(Pb, j, c_out, relu4(acc.sum() + wb[0].bias));
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
+    f32x4 v = relu4(acc.sum() + wb[1].bias);
+    if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (row_ok) gst4(t.rider_out + grow * D + c_out, v);
+  }
+}
+
 template <bool ATTN, bool FFN, int PROJ>
 __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -68,6 +128,13 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   char* Pa = (char*)(Y + ROWS * XLD);
   char* Pb = Pa + 2 * PLANE;
   const tbx_layer_tile_t& t = a.t;
+  if constexpr (!ATTN && !FFN && PROJ == 2) {
+    const int main_tiles = (int)((t.n_rows + ROWS - 1) / ROWS);
+    if ((int)blockIdx.x >= main_tiles) {  // (only launched with rider_rows > 0)
+      rider_tile(t, (int)blockIdx.x - main_tiles, Pa, Pb);
+      return;
+    }
+  }
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -329,7 +396,7 @@ int launch(const TileArgs& a, hipStream_t s) {
       return TBX_ERR_LAUNCH;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((a.t.n_rows + ROWS - 1) / ROWS);
+  const unsigned grid = (unsigned)((a.t.n_rows + ROWS - 1) / ROWS) + (unsigned)((a.t.rider_rows + ROWS - 1) / ROWS);
   hipLaunchKernelGGL((tile_layer_kernel<ATTN, FFN, PROJ>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
@@ -366,6 +433,14 @@ extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
   if (t.kv16_out != nullptr && proj != 2) return TBX_ERR_ARG;
   if (t.drop_thresh != 0u && t.drop_seed == nullptr) return TBX_ERR_ARG;
   if ((((uintptr_t)t.x) | ((uintptr_t)t.attn_out) | ((uintptr_t)t.proj_out)) & 15) return TBX_ERR_ALIGN;
+  if (t.rider_rows < 0) return TBX_ERR_ARG;
+  if (t.rider_rows > 0) {
+    if (attn || ffn || proj != 2) return TBX_ERR_UNSUPPORTED;
+    if (t.rider_in == nullptr || t.rider_add == nullptr || t.rider_valid == nullptr || t.rider_out == nullptr) return TBX_ERR_ARG;
+    for (int i = 0; i < 4; ++i)
+      if (t.rider_images[i] == nullptr) return TBX_ERR_ARG;
+    if ((((uintptr_t)t.rider_in) | ((uintptr_t)t.rider_add) | ((uintptr_t)t.rider_out)) & 15) return TBX_ERR_ALIGN;
+  }
   TileArgs a;
   a.t = t;
   int e = 0;

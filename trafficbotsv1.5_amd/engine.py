@@ -76,6 +76,10 @@ class Schedule:
     # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
     # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
     tile_small: bool = True
+    navi_rider: bool = True  # small launches: the heads' navigation embedding in extra workgroups of the agents' first-projection launch (no auxiliary stream in the step)
+    knn_main: bool = True  # the agents' K-nearest searches on the stepping stream (no cross-queue wait in front of the first attention launch); the auxiliary stream keeps the navigation embedding, joined before the LAST layer
+    sim_before_join: bool = True  # the agents' tbx_sim_step on their own stream before the lights' stream is joined
+    dec_tail_mfma: bool = True  # tbx_knarpe_dec_layer's tail (out_proj / FFN / next projections) on the split-bf16 matrix path
     pe_rides: bool = True       # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
     # ---- RolloutEngine
     tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
@@ -99,7 +103,7 @@ class Schedule:
                    live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
                    kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
                    split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
-                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
                    graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
 
     def replace(self, **kw) -> "Schedule":
@@ -415,7 +419,8 @@ class SelfKnn:
 def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int, self_knn: Optional[SelfKnn],
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
               tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None,
-              heads_tail: Optional[dict] = None, first_proj: Optional[dict] = None) -> bool:
+              heads_tail: Optional[dict] = None, first_proj: Optional[dict] = None, join_late: bool = False,
+              after_first_proj=None, proj_rider=None) -> bool:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE (join_stream: a stream the K-nearest sets are being produced on, waited for right before the
     first attention call). `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
@@ -465,16 +470,27 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
 
     tile = tile_rows_ok(rows, keyed_dropout=True)
     if first_proj is None and (tile or tile_small_ok()):
-        hip.layer_tile(x, proj=tile_proj_part(first_norm(0), first_attn(0), qkv, True, kv16), store_x=False)
+        r = proj_rider() if callable(proj_rider) else proj_rider  # (a side job of the caller's in the same launch: tbx_layer_tile_t.rider_*)
+        hip.layer_tile(x, proj=tile_proj_part(first_norm(0), first_attn(0), qkv, True, kv16), store_x=False, rider=r)
     elif first_proj is None:
+        assert proj_rider is None
         ch = layer_chain(rows)
         ch.load(x, BUF1, 0, n=D)
         emit_proj(ch, rows, first_norm(0), first_attn(0), qkv, with_kv=True, kv16=kv16)
         ch.run(rows)
-    if join_stream is not None:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
+    if after_first_proj is not None:
+        # the caller forks its auxiliary stream HERE: hipGraph's executor keeps the first-captured child of a node on the node's queue
+        # and moves later ones to another (measured, profiles/r03_c2_two_stream_timeline.txt), so this stream's next launch has to
+        # be captured before the side work or the whole layer sequence moves queues behind a ~12 us cross-queue wait
+        after_first_proj()
+    if callable(heads_tail):  # (resolved late: the caller's side work above may be what makes the heads' inputs)
+        heads_tail = heads_tail()
+    if join_stream is not None and not join_late:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
     mid = fold and dec and current().dec_mid and bool(live_rows_for(rows))  # the one-launch attention half: small launches only
     for l, layer in enumerate(layers):
+        if join_stream is not None and join_late and l + 1 == len(layers):  # (join_late: that stream only made inputs of the heads)
+            torch.cuda.current_stream().wait_stream(join_stream)
         a1 = first_attn(l)
         self_seg = (Seg(qkv, D, 2 * D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel) if kv16 is None else
                     Seg(kv16, 0, D, S, self_knn.idx, self_knn.invalid, self_knn.emb, rel=self_knn.rel))
@@ -484,17 +500,19 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             # next layer's projections - the stages of the chain that followed tbx_knarpe_dec_mid, in the same arithmetic
             a2 = layer.attn
             last = l + 1 == len(layers)
-            tl_ = dict(out_proj2=hip.packed_weight(a2.out_proj_weight, a2.out_proj_bias, gemv=True),
-                       linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, gemv=True),
-                       linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, gemv=True),
-                       norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid)
+            tmf = current().dec_tail_mfma and DROP_CTX is None
+            tkw = dict(mfma32=True) if tmf else dict(gemv=True)
+            tl_ = dict(out_proj2=hip.packed_weight(a2.out_proj_weight, a2.out_proj_bias, **tkw),
+                       linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, **tkw),
+                       linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, **tkw),
+                       norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid, mfma32=tmf)
             if last and heads_tail is not None and current().heads_tail:
                 tl_["heads"] = heads_tail  # the agents' heads in this launch too (tbx_heads_tail_t)
                 heads_done = True
             if not last:
                 an, nn_ = first_attn(l + 1), first_norm(l + 1)
-                tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], gemv=True),
-                           next_qfold=hip.packed_weight(an.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True),
+                tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], **tkw),
+                           next_qfold=hip.packed_weight(an.linear_rpe.weight[:D], None, wt=True, groups=NH, **tkw),
                            next_norm=(nn_.weight, nn_.bias, nn_.eps), qkv_out=qkv_alt, kv16_out=kv16_alt)
             hip.knarpe_dec_mid(qkv, 0, 3 * D, x, self_seg, list(cross(l)), a1.linear_rpe.bias, a2.linear_rpe.bias,
                                (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, attn_fold_image(a1),

@@ -76,7 +76,7 @@ class DecLayer(C.Structure):
     _fields_ = ([("mid", DecMid)]
                 + [(n, C.c_void_p) for n in ("out_proj2_image", "linear1_image", "linear2_image", "next_in_proj_image", "next_qfold_image",
                                              "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out", "kv16_out", "heads")]
-                + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("pad_", C.c_int32)])
+                + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("tail_mfma32", C.c_int32)])
 
 
 class LayerTile(C.Structure):
@@ -87,7 +87,9 @@ class LayerTile(C.Structure):
                 + [("norm2_eps", C.c_float), ("proj_norm_eps", C.c_float)]
                 + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)]
                 + [("drop_seed", C.c_void_p), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_site", C.c_int32 * 3),
-                   ("drop_step", C.c_int32)])
+                   ("drop_step", C.c_int32)]
+                + [("rider_in", C.c_void_p), ("rider_add", C.c_void_p), ("rider_images", C.c_void_p * 4), ("rider_valid", C.c_void_p),
+                   ("rider_out", C.c_void_p), ("rider_rows", C.c_int64)])
 
 
 class HeadsTile(C.Structure):
@@ -589,6 +591,7 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     n2 = tail["norm2"]
     t.norm2_weight, t.norm2_bias, t.norm2_eps = _ptr(n2[0], torch.float32), _ptr(n2[1], torch.float32), float(n2[2])
     t.src_invalid = _cptr(tail["src_invalid"], torch.uint8)
+    t.tail_mfma32 = int(bool(tail.get("mfma32")))
     qo = tail.get("qkv_out")
     if qo is not None:
         n3 = tail["next_norm"]
@@ -611,12 +614,13 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
-def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None):
+def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None):
     """tbx_layer_tile on the token rows x [rows, 128] (in place). Each part is None or a dict:
     attn = dict(out [rows, >= 640], row_no_valid u8 [rows], fold, out_proj (mfma32 images));
     ffn = dict(norm2 (w, b, eps), linear1, linear2 (images), src_invalid u8 [rows] | None);
     proj = dict(norm (w, b, eps), image, qfold (images), n = 128 | 384, out [rows, >= 640 | 896], kv16 = bf16 [rows, 256] | None);
-    drop = the keyed dropouts of training's stepping pass (see below)."""
+    drop = the keyed dropouts of training's stepping pass (see below);
+    rider = dict(inp, add, out [r, 128], valid u8 [r], images = 4 mfma32 images): tbx_layer_tile_t's rider_* (a first-projection launch only)."""
     a = LayerTile()
     a.x, a.n_rows, a.store_x = _cptr(x, torch.float32), x.shape[0], int(store_x)
     assert x.dim() == 2 and x.shape[1] == 128
@@ -648,6 +652,15 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=Non
         a.drop_seed, a.drop_step = _ptr(drop["seed"], torch.int64), int(drop["step"])
         for i, st in enumerate(drop["sites"]):
             a.drop_site[i] = -1 if st is None else int(st)
+    if rider is not None:
+        r = rider["out"].shape[0]
+        for k in ("inp", "add", "out"):
+            assert rider[k].shape == (r, 128) and rider[k].is_contiguous()
+        a.rider_in, a.rider_add, a.rider_out = _ptr(rider["inp"], torch.float32), _ptr(rider["add"], torch.float32), _ptr(rider["out"], torch.float32)
+        assert rider["valid"].numel() == r and len(rider["images"]) == 4
+        a.rider_valid, a.rider_rows = _cptr(rider["valid"], torch.uint8), r
+        for i, im in enumerate(rider["images"]):
+            a.rider_images[i] = _ptr(im, torch.float32)
     _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
 
 

@@ -66,7 +66,8 @@ class AgentEncoder(nn.Module):
                ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1, tl_batch_div: int = 1,
                tail: Optional[Callable[[Chain], None]] = None, aux_stream=None, navi_rpe=None,
                aux_tail: Optional[Callable[[Dict[str, Tensor]], None]] = None,
-               heads_tail: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+               heads_tail: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None,
+               navi_rider: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
         """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256]
         ([n/tl_batch_div * L, ..] with tl_pose / tl_invalid_u8 [n/tl_batch_div, L, ..] when the rollouts of a scene share its lights).
         -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows).
@@ -75,7 +76,10 @@ class AgentEncoder(nn.Module):
         encoder - the embedding of the destination's relative pose (prep["navi_pe"], an input of the heads chain that depends on
         agent_prep only) is then computed on that stream too instead of between the last layer and the heads. heads_tail(prep): the
         caller's heads as tbx_heads_tail_t fields for the last layer's launch (see engine.run_block). aux_tail(prep): more
-        work of the caller's that needs nothing but `prep` (the navigation embedding of the heads), enqueued on that stream after it."""
+        work of the caller's that needs nothing but `prep` (the navigation embedding of the heads), enqueued on that stream after it.
+        navi_rider(prep) -> that same work as the rider of the first projection's tbx_layer_tile launch (small launches,
+        Schedule.navi_rider): everything then runs on this stream - a cross-queue edge of the captured graph costs ~5 us of idle
+        queue at its source and ~6-12 us at its destination (profiles/r03_c2_two_stream_timeline.txt)."""
         n, A, W = hist_valid.shape
         assert W == self.temp_window_size
         dev, d, rp = hist_pose.device, self.hidden_dim, self.pose_rpe
@@ -94,10 +98,25 @@ class AgentEncoder(nn.Module):
         # stream, which are only needed by the first attention call (measured on the two-stream timeline: the chain started 20 us
         # after agent_prep ended because the three searches were launched ahead of it).
         main = torch.cuda.current_stream()
-        if aux_stream is not None:
-            aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
+        # Schedule.knn_main: the searches stay on this stream (a cross-queue dependency costs ~10 us of idle queue on each side of
+        # it - measured on the two-stream timeline - more than the 15 us launch it hides); the auxiliary stream then only makes the
+        # heads' navigation embedding and is joined before the last layer
         x = torch.empty(n * A, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * A, dev, hip.group_tile_rows(W, n * A))  # small launches: layer 0's projections in the windows' launch too
+        want_pe = navi_rpe is not None and dest is not None
+        pe_rides = want_pe and engine_current().pe_rides and n * A < 4096  # the destination's pose embedding in the searches' launch
+        if pe_rides and prep.get("navi_pe") is None:
+            prep["navi_pe"] = torch.empty(n * A, navi_rpe.out_dim, dtype=torch.float32, device=dev)
+        rider = None
+        if (navi_rider is not None and engine_current().navi_rider and pe_rides and aux_tail is not None and tile_small_ok()
+                and not tile_rows_ok(n * A, keyed_dropout=True) and fp is None):
+            rider = navi_rider(prep)  # (None: the modules are not of the shape the rider is built for)
+        use_rider = rider is not None
+        if use_rider:
+            aux_stream = None  # nothing of this step runs beside this stream
+        knn_main = aux_stream is not None and engine_current().knn_main
+        if aux_stream is not None and not knn_main:
+            aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
         ie = self.input_encoder
         wt_ = self._window_tile_images(prep["attr"].shape[1]) if (fp is None and W <= 16 and (tile_rows_ok(n * A, keyed_dropout=True) or tile_small_ok())) else None
         ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
@@ -127,39 +146,45 @@ class AgentEncoder(nn.Module):
         # the agents' KNN sets change every step: only the relative poses are produced (12 B per pair); the attention
         # kernel rebuilds the 128-d embedding in registers in each of the 4 layers
         kw = dict(want_rel_pose=True, want_emb=False)
-        with torch.cuda.stream(aux_stream if aux_stream is not None else main):
+        with torch.cuda.stream(aux_stream if aux_stream is not None and not knn_main else main):
             common = dict(src_pose=tok_pose, src_invalid=tok_inv, dist_limit=self.dist_limit, **kw)
             jobs = [dict(common, tgt_pose=mp["mp_token_pose"], tgt_invalid=mp_inv, k=self.n_tgt_knn_ag2mp, tgt_batch_div=mp_batch_div,
                          out=prep.get("_knn_am")),  # the longest search first
                     dict(common, tgt_pose=tok_pose, tgt_invalid=tok_inv, k=self.n_tgt_knn_ag2ag, out=prep.get("_knn_aa")),
                     dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
                          out=prep.get("_knn_at"))]
-            want_pe = navi_rpe is not None and dest is not None
-            pe_rides = want_pe and engine_current().pe_rides and n * A < 4096  # the destination's pose embedding in the searches' launch
-            if pe_rides and prep.get("navi_pe") is None:
-                prep["navi_pe"] = torch.empty(n * A, navi_rpe.out_dim, dtype=torch.float32, device=dev)
             if n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
                 pj = dict(pose3=prep["navi_pose3"], freqs_xy=navi_rpe.pe_xy.freqs, freqs_yaw=navi_rpe.pe_yaw.freqs, pe_dim=navi_rpe.out_dim,
                           out=prep["navi_pe"]) if pe_rides else None
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs, pose_embed_job=pj)
             else:
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = (hip.knn_embed(**q) for q in jobs)
-            if want_pe:
-                if not pe_rides:
-                    prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
-                                                     out=prep.get("navi_pe"))
-                if aux_tail is not None:
-                    aux_tail(prep)
+        knn_done = main.record_event() if knn_main else None
+
+        def side_work():
+            if knn_main:
+                aux_stream.wait_event(knn_done)  # fork behind the searches' launch (the destination's pose embedding rides in it)
+            with torch.cuda.stream(aux_stream if aux_stream is not None else main):
+                if want_pe:
+                    if not pe_rides:
+                        prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
+                                                         out=prep.get("navi_pe"))
+                    if aux_tail is not None and not use_rider:
+                        aux_tail(prep)
+
+        if not knn_main:
+            side_work()
         prep.update(knn_idx_ag2ag=i_aa, knn_invalid_ag2ag=m_aa, knn_idx_ag2mp=i_am, knn_invalid_ag2mp=m_am,
                     knn_idx_ag2tl=i_at, knn_invalid_ag2tl=m_at, _knn_aa=(i_aa, m_aa, r_aa), _knn_am=(i_am, m_am, r_am),
                     _knn_at=(i_at, m_at, r_at))
         kv_mp = self.kv_mp(mp)
         # (the searches are joined inside run_block, right before the first attention call: the first projection chain needs x only)
         # heads_tail(prep) -> the tbx_heads_tail_t fields (or None): the caller's heads in the last layer's launch; prep["_heads_done"] tells
-        prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else heads_tail(prep),
+        prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else (lambda: heads_tail(prep)),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
                                    Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
-                  join_stream=aux_stream, first_proj=fp)
+                  join_stream=aux_stream, first_proj=fp, join_late=knn_main, after_first_proj=side_work if knn_main else None,
+                  proj_rider=rider)
         return x, prep
 
     def _window_tile_images(self, attr_cols: int):

@@ -113,7 +113,8 @@ class TrafficBots(nn.Module):
         # add_navi_latent.py:43-50) reads nothing the agent layers produce - it runs there, behind the K-nearest searches, instead
         # of as the first five stages of the heads chain (same stages, same values)
         tile = engine.tile_rows_ok(n * A)  # large launches: the heads as one tbx_heads_tile launch (needs the embedding made ahead)
-        navi_ahead = (aux_stream is not None or tile) and engine.DROP_CTX is None and self.NAVI_AHEAD
+        # (Schedule.navi_rider: on small launches it rides in the agents' first-projection launch instead, with or without that stream)
+        navi_ahead = (aux_stream is not None or tile or engine.current().navi_rider) and engine.DROP_CTX is None and self.NAVI_AHEAD
 
         def aux_tail(prep):
             if prep.get("navi_emb") is None:
@@ -122,6 +123,19 @@ class TrafficBots(nn.Module):
             self.navi_encoder.emit(cn, mp_flat, prep["navi_row"], prep["navi_pe"], dest_feature=rc.get("dest_feature"))
             prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
             cn.run(n * A)
+
+        def navi_rider(prep):
+            """The same four stages as `aux_tail` as tbx_layer_tile_t's rider (agent_encoder.encode), or None."""
+            l_pe = self.navi_encoder.mlp_pe.linear_layers()
+            l_in = self.add_navi.mlp_in.linear_layers()
+            if (rc.get("dest_feature") is None or len(l_pe) != 1 or len(l_in) != 3 or any(ln is not None for _, ln, _ in l_pe + l_in)
+                    or any(tuple(t[0].weight.shape) != (d, d) for t in l_pe + l_in) or not all(act for _, _, act in l_in) or l_pe[0][2]):
+                return None
+            if prep.get("navi_emb") is None:
+                prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+            prep["_navi_premasked"] = True
+            return dict(inp=prep["navi_pe"], add=rc["dest_feature"], out=prep["navi_emb"], valid=navi_valid_u8.reshape(-1),
+                        images=[hip.packed_weight(t[0].weight, t[0].bias, mfma32=True) for t in l_pe + l_in])
 
         def heads_tail(prep, mfma32: bool = False):
             """The heads as tbx_heads_tail_t / tbx_heads_tile_t fields when everything they read is at hand in the form the fused
@@ -146,7 +160,8 @@ class TrafficBots(nn.Module):
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
                                             aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None,
-                                            heads_tail=heads_tail if navi_ahead else None)
+                                            heads_tail=heads_tail if navi_ahead else None,
+                                            navi_rider=navi_rider if navi_ahead else None)
         out["prep"], out["ag_feat"] = prep, feat
         if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
             return

@@ -146,6 +146,7 @@ class RolloutEngine:
         # ---- initial dynamic state (Dynamics.init, dynamics.py:29-64) and its pristine copy
         init = dict(
             step=torch.tensor([1, 0], dtype=torch.int32, device=dev),  # [step index, arrival counter of the fused advance]
+            step_tl=torch.tensor([1, 0], dtype=torch.int32, device=dev),  # the lights' own copy (sim_state_tl_own below)
             ag_valid=_u8(gt_valid[:, :, 0]), ag_disabled=z(n, A, dt=u8), ag_pose=gt_pose[:, :, 0].float().contiguous(),
             ag_motion=gt_motion[:, :, 0].float().contiguous(), navi_valid=_u8(ag_navi_valid), outside_map=z(n, A, dt=u8),
             dest_reached=z(n, A, dt=u8), tl_state=S["tl_gt"][:, :, 0].contiguous(),
@@ -190,6 +191,13 @@ class RolloutEngine:
             C.memmove(C.byref(stl), C.byref(st), C.sizeof(hip.SimState))
             stl.n_batch = nl
             self.sim_state_tl = stl
+        # Schedule.sim_before_join: the lights' stream counts its steps itself (TBX_SIM_LIGHTS | TBX_SIM_ADVANCE on `step_tl`) - with one
+        # shared counter the agents' advance has to be ordered behind the lights' read of it, a cross-queue wait (~6 us of idle
+        # queue even when long since satisfied) in front of the launch that closes every step
+        own = hip.SimState()
+        C.memmove(C.byref(own), C.byref(self.sim_state_tl), C.sizeof(hip.SimState))
+        own.step = S["step_tl"].data_ptr()
+        self.sim_state_tl_own = own
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
         self.graph = self.graph_multi = None
         self._tl_prep = None
@@ -299,6 +307,10 @@ class RolloutEngine:
                 hip.sim_step(self.sim_state)
             return
         p = self.parity
+        early = self.sched.sim_before_join
+        st_tl, parts_tl = (self.sim_state_tl_own, hip.SIM_LIGHTS | hip.SIM_ADVANCE) if early else (self.sim_state_tl, hip.SIM_LIGHTS)
+        if early:  # (both counters advance once per step; a caller that mixed this with the one-stream forms would desynchronise them)
+            assert not self.stepwise
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             # logits of the previous tl encoder pass -> lights of this step (+ the one-hot rows of their new windows: tbx_sim_step_tl_prep)
@@ -306,16 +318,22 @@ class RolloutEngine:
                 if self._tl_prep is None:
                     hist = self.S["hist_tl"]
                     self._tl_prep = self.model.tl_encoder.prep_buffers(hist.shape[0], hist.shape[1], hist.device)
-                hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS, tl_prep=(self.tl_tokens["tl_token_invalid_u8"], *self._tl_prep))
+                hip.sim_step(st_tl, parts_tl, tl_prep=(self.tl_tokens["tl_token_invalid_u8"], *self._tl_prep))
                 self._tl_ahead(1 - p, prepared=self._tl_prep)
             else:
-                hip.sim_step(self.sim_state_tl, hip.SIM_LIGHTS)
+                hip.sim_step(st_tl, parts_tl)
                 self._tl_ahead(1 - p)
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
                                 self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux, rollout_consts=self.consts)
-        main.wait_stream(self.side)
-        hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
+        if early:
+            # the agents' launch closes their step on their own stream; the join moves behind it (hipGraph's executor puts a node
+            # on the queue of the parent it reaches first: joined first, this launch ran on the lights' queue behind a ~12 us wait)
+            hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
+            main.wait_stream(self.side)
+        else:
+            main.wait_stream(self.side)
+            hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
         self.parity = 1 - p
 
     @_scheduled
@@ -388,7 +406,7 @@ class RolloutEngine:
             S["player_valid"].zero_()
         self.model.policy_step(S["hist_valid"], S["hist_pose"], S["hist_motion"], S["hist_tl"], self.ag_attr6, S["ag_type_idx"],
                                self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens,
-                               self.policy_out)
+                               self.policy_out, rollout_consts=self.consts)  # (latent and destinations are fixed by begin_rollout here too)
         slot = self._n_forward
         hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_LIGHTS | hip.SIM_ADVANCE | hip.SIM_NO_DISABLE | hip.SIM_NO_APPEND)
         self._n_forward += 1
