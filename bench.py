@@ -10,7 +10,7 @@ One process per GPU; scenes / rollouts are independent, so ranks never communica
 every rank simulates its own scenes); the only collectives are the timing barrier and a MAX over ranks of the wall time.
 Rank 0 prints ONE JSON line. The timed region (W prime steps + K closed-loop steps) is run `--repeats` times (default 3) on the
 same engine, rewound in between: `value` / `ms_per_step` are the MEDIAN repeat, the minimum rides along (`ms_per_step_min`).
-`roofline` describes the kernel class with the largest share of the timed schedule (dec_mid_kernel at the 64-agent scene, the row
+`roofline` describes the kernel class with the largest share of the timed schedule (dec_layer_mf_kernel at the 64-agent scene, the row
 chains / attention at the WOSAC shape; every class is listed under `kernels`), measured live with HIP events around every launch
 of a few extra eager steps on the launch stream; `traffic` / `hbm_measured_frac` come from this round's committed PMC passes
 (profiles/*pmc*.json, separate rocprofv3 --pmc runs); `cpu_baseline` times the oracle (CPU port of the reference formulation)
@@ -139,7 +139,7 @@ def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int, b: int = 4) -> float:
 class KernelEvents:
     """Brackets every launch of the hot path's kernel classes with HIP events on the launch stream and keeps, per class, the
     algorithmic bytes (HBM-bound classes) or flops (MFMA-bound classes) of each launch:
-      dec_layer  tbx_knarpe_dec_mid / tbx_knarpe_dec_layer (dec_mid_kernel: a decoder layer's attention half or the whole layer)
+      dec_layer  tbx_knarpe_dec_mid / tbx_knarpe_dec_layer (dec_layer_mf_kernel / dec_mid_kernel: a whole decoder layer, or its attention half)
       attn       tbx_knarpe_attn_* (knarpe_attn_kernel), grouped by source rows
       chain      tbx_rowchain / tbx_rowchain_ex (rowchain_kernel<MT,..>: MFMA row chains), grouped by tile rows
       chain_live tbx_rowchain_live (rowchain_kernel<0,1,0,1>: thread-per-column chains of small launches)
@@ -188,12 +188,13 @@ class KernelEvents:
                 return T("chain_live", 0, fl, sv["Chain.run"], ch, n_rows, group_rows)
             return T("chain", ch.tile_rows, fl, sv["Chain.run"], ch, n_rows, group_rows)
 
-        def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None):
+        def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None, rider=None):
             rows = x.shape[0]
             mac = (2 * 128 * 128 if attn is not None else 0) + (2 * 128 * 512 if ffn is not None else 0)
             if proj is not None:
                 mac += 128 * proj["n"] + 128 * 128
-            return T("tile", "layer", 2.0 * rows * mac, sv["layer_tile"], x, attn=attn, ffn=ffn, proj=proj, store_x=store_x, drop=drop)
+            fl = 2.0 * rows * mac + (0.0 if rider is None else 2.0 * rider["out"].shape[0] * 4 * 128 * 128)
+            return T("tile", "layer", fl, sv["layer_tile"], x, attn=attn, ffn=ffn, proj=proj, store_x=store_x, drop=drop, rider=rider)
 
         def ht(x, hd):
             return T("tile", "heads", 2.0 * x.shape[0] * (2 * (256 * 128 + 2 * 128 * 128) + 128 * 384 + 3 * 128 * 128 + 3 * 128 * 16), sv["heads_tile"], x, hd)
@@ -240,8 +241,8 @@ def kernel_entry(args, c):
     e = {"class": cls, "share_of_step_kernel_time": c["share"], "launches_per_step": c["per_step"], "avg_launch_us": avg * 1e6}
     if cls in ("dec_layer", "attn"):
         ach = c["work"] / c["t"] / 1e9
-        name = "dec_mid_kernel" if cls == "dec_layer" else "knarpe_attn_kernel"
-        pre = ["dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_kernel<1,"] if key >= 1024 else ["knarpe_attn_kernel<4,"])
+        name = "dec_layer_mf_kernel" if cls == "dec_layer" else "knarpe_attn_kernel"  # (dec_mid_kernel with Schedule.dec_tail_mfma off)
+        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_kernel<1,"] if key >= 1024 else ["knarpe_attn_kernel<4,"])
         e.update(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                  algorithmic_bytes_per_launch=c["work"] / c["n"], source_rows_per_launch=key,
                  bytes_per_pair=529 if args.kv_bf16 else 1041)

@@ -190,9 +190,9 @@ typedef struct tbx_dec_layer {
   const tbx_heads_tail_t* heads; /* host pointer or NULL; only with qkv_out == NULL */
   float norm2_eps, next_norm_eps;
   int32_t ld_qkv_out;
-  int32_t tail_mfma32; /* != 0: out_proj2 / linear1 / linear2 / next_in_proj / next_qfold are tbx_pack_weight_mfma32 images and the
-                        * tail's LINEAR stages run on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32
-                        * fma chains; the heads' images stay tbx_pack_weight_gemv images */
+  int32_t tail_mfma32; /* != 0: EVERY image of the call (mid.fold_self / out_proj / q / qfold / fold_cross, out_proj2 / linear1 / linear2 /
+                        * next_in_proj / next_qfold, heads->images) is a tbx_pack_weight_mfma32 image and every LINEAR stage runs on
+                        * the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32 fma chains */
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
 

@@ -74,14 +74,25 @@ def test_reactive_replay_vs_oracle_and_reference(tb, golden_dir, sizes, knn, n_r
     with torch.no_grad():
         ro = sim.rollout(b, mp_o, tl_o, z, zv, b["gt/ag_navi"], navi_v, scfg.teacher_forcing_joint_future_pred, n_roll)
     n_cmp = min(n_roll, 16)
+    E = import_module("trafficbots_amd.engine")
+    # the exact-fp32 small-launch schedule (every LINEAR as fp32 products) over all n_cmp steps (6 / 4 of them free-running), then
+    # the default schedule - decoder layers, window PointNets and heads on the split-bf16 matrix path, a ~5 x larger rounding
+    # difference on the first free action, doubling per free step like any other (NOTE above) - over the first 3 free steps at
+    # the same tolerance and over all n_cmp at 1e-2
+    wm.schedule = E.DEFAULT.replace(dec_tail_mfma=False, tile_small=False, navi_rider=False)
+    exact = run(wm.teacher_forcing_joint_future_pred, True)
+    _compare(exact, ro, n_cmp, 2e-3)
+    wm.schedule = E.DEFAULT
     outs = {g_: run(wm.teacher_forcing_joint_future_pred, g_) for g_ in (False, True)}
     for g_ in (False, True):
-        _compare(outs[g_], ro, n_cmp, 2e-3)
+        _compare(outs[g_], ro, min(n_cmp, 13), 2e-3)
+        _compare(outs[g_], ro, n_cmp, 1e-2)
     assert torch.equal(outs[True].pred_pose, outs[False].pred_pose)  # hipGraph replay is the same arithmetic
-    g = np.load(golden_dir / f"model_{tag}.npz")
-    assert np.array_equal(outs[True].pred_valid[:, 0, :, :n_cmp].cpu().numpy(), g["rr_pred_valid"][:, :, :n_cmp])
-    np.testing.assert_allclose(outs[True].pred_pose[:, 0, :, :n_cmp].cpu().numpy(), g["rr_pred_pose"][:, :, :n_cmp], rtol=1e-4, atol=5e-3)
-    assert np.array_equal(outs[True].violation["outside_map"][:, 0, :, :n_cmp].cpu().numpy(), g["rr_outside_map"][:, :, :n_cmp])
+    g = np.load(golden_dir / f"model_{tag}.npz")  # the reference's own trajectory (tests/golden/make_golden.py)
+    for o, nc in ((exact, n_cmp), (outs[True], min(n_cmp, 13))):
+        assert np.array_equal(o.pred_valid[:, 0, :, :nc].cpu().numpy(), g["rr_pred_valid"][:, :, :nc])
+        np.testing.assert_allclose(o.pred_pose[:, 0, :, :nc].cpu().numpy(), g["rr_pred_pose"][:, :, :nc], rtol=1e-4, atol=5e-3)
+        assert np.array_equal(o.violation["outside_map"][:, 0, :, :nc].cpu().numpy(), g["rr_outside_map"][:, :, :nc])
 
 
 @pytest.mark.parametrize("sizes,knn,n_roll", [((8, 64, 8), 4, 90), ((64, 1024, 128), 32, 24)])
@@ -203,9 +214,10 @@ def test_hoisted_rollout_constants_are_bit_identical(tb):
     valid = bd["gt/ag_valid"].any(-1)
     outs = {}
     for hoist in (True, False):
-        # (navi_rider off: the rider of the first projection's launch takes the hoisted destination feature - without the hoisting
-        # the same stages run as an exact-fp32 chain, a different arithmetic; compared at tolerance in tests/test_hip_parity.py)
-        wm.schedule = E.DEFAULT.replace(hoist_constants=hoist, navi_rider=False)
+        # (navi_rider / dec_tail_mfma off: the rider of the first projection's launch and the heads inside the last layer's launch take
+        # the hoisted constants - without the hoisting the same stages run as exact-fp32 chains, a different arithmetic; those are
+        # compared at tolerance in tests/test_hip_parity.py)
+        wm.schedule = E.DEFAULT.replace(hoist_constants=hoist, navi_rider=False, dec_tail_mfma=False)
         outs[hoist] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                          step_end=30)
     assert torch.equal(outs[True].pred_pose, outs[False].pred_pose)

@@ -19,9 +19,13 @@ from __graft_entry__ import load_package  # noqa: E402
 
 PH = ["prologue (DMA requests, x, LN params, q loads)", "self sweep + slot merge", "combine + value fold",
       "out_proj GEMV (+ W_q request)", "LayerNorm (+ W_kf request)", "wait for W_q", "q GEMV", "W_k^T q GEMV",
-      "cross sweep + slot merge", "combine + value fold + stores",
-      "tail: out_proj2", "tail: LayerNorm 2 (+ planes)", "tail: linear1 + relu", "tail: linear2 + store x", "tail: next q | k | v",
-      "tail: next W_k^T q"]
+      "cross sweep + slot merge", "combine + value fold + out_proj2", "LayerNorm 2", "linear1 + relu", "linear2 + store x",
+      "LayerNorm 3 + next q | k | v", "next W_k^T q"]
+# the all-matrix-path kernel (Schedule.dec_tail_mfma, the default): dec_layer_mf_kernel's stamps
+PH_MF = ["prologue (weight units 0, 1 requested, x, LN params, q loads)", "self sweep + slot merge", "combine + value fold",
+         "out_proj", "LayerNorm 1", "q", "W_k^T q", "q / qt loads of the cross sweep", "cross sweep + slot merge",
+         "combine + value fold + out_proj2", "LayerNorm 2", "linear1 + relu", "linear2 + store x", "LayerNorm 3 + next q | k | v",
+         "next W_k^T q"]
 
 
 def main():
@@ -45,10 +49,10 @@ def main():
     n = lib.tbx_debug_mid_dump(buf, 256)
     for i in range(n):
         c = buf[i * 16:(i + 1) * 16]
-        d = [(c[j + 1] - c[j]) / 100.0 if c[j + 1] > c[j] else 0.0 for j in range(15)]  # clock64 = s_memtime: 100 MHz on gfx950
-        print(f"launch {i}: {sum(d):6.2f} us in workgroup 0")
-        for name, v in zip(PH, d):
-            print(f"    {name:70s} {v:6.2f} us")
+        d = [(c[j + 1] - c[j]) / 100.0 if c[j + 1] > c[j] else 0.0 for j in range(15)]  # clock64 = s_memtime = shader clocks here (~2.4 GHz: 100 clocks = 0.042 us)
+        print(f"launch {i}: {sum(d):6.2f} x 100 shader clocks in workgroup 0")
+        for name, v in zip(PH if os.environ.get("TBX_DEC_TAIL_MFMA") == "0" else PH_MF, d):
+            print(f"    {name:70s} {v:6.2f}")
 
 
 if __name__ == "__main__":

@@ -163,12 +163,7 @@ __device__ __forceinline__ float combine_fold(RowAcc& st, const float (&M)[NH], 
 
 // NW = 4: tbx_knarpe_dec_mid. NW = 8: tbx_knarpe_dec_layer - waves 4..7 take no part in the sweeps; they (and waves 2, 3) fetch the
 // tail's 13 weight chunks, six requesting waves instead of two (the tail was bound by the two waves' DMA issue: 1.46 us per chunk).
-// MF (NW = 8 only): the tail's 9 / 13 LINEAR chunks (out_proj, FFN, the next layer's projections) on the split-bf16 matrix path of
-// tile_core.h instead of thread-per-output fma chains fed through two LDS slots by LDS-DMA: the single row is the B operand of a
-// v_mfma_f32_16x16x32_bf16 (its 16 columns all read the same row: column 0 is kept), wave w owns output tile w, its weights come
-// as 8 KiB register units from global memory one unit ahead - all 8 waves multiply, no chunk passes through LDS, a chunk costs its
-// 64 KiB weight stream (~0.5 us) instead of DMA + a 128-long dependent chain (1.15 us).
-template <bool KV16, int NW, bool MF = false>
+template <bool KV16, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -294,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   __syncthreads();
   MID_CLK(8);
   dma_image(a.fold2, IMG128 / 256, slot_a, wave, lane, 0, NW);  // lands during the sweep
-  if (!MF && a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0, NW);  // (slot B is free: the tail's first chunk rides along)
+  if (a.wo2 != nullptr) dma_image(a.wo2, IMG128 / 256, slot_b, wave, lane, 0, NW);  // (slot B is free: the tail's first chunk rides along)
   // ---------------------------------------------------------------- cross attention
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -335,157 +330,6 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       lg2[0] = a.ln2_w[lane], lg2[1] = a.ln2_w[64 + lane], lb2[0] = a.ln2_b[lane], lb2[1] = a.ln2_b[64 + lane];
       if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
     }
-    if constexpr (MF) {
-      using tbx_tile::Acc, tbx_tile::W, tbx_tile::load_unit, tbx_tile::split4, tbx_tile::relu4;
-      using tbx_tile::bf16x8, tbx_tile::bf16x4, tbx_tile::f32x4, tbx_tile::u32x2;
-      // one row's bf16 planes: hi at P + 2 k, lo 1 KiB behind; three buffers in slot B (free: nothing is DMA'd there in this mode)
-      char* Ph = (char*)slot_b;  // f, then norm2(x), then the next layer's norm(x) (K = 128)
-      char* Pu = Ph + 2048;      // FFN hidden row (K = 512)
-      char* Pq = Pu + 2048;      // the next layer's q (K = 128)
-      const int g4 = lane >> 4;
-      const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row's outputs: channels c_out .. c_out + 3
-      const int c_out = 16 * wave + 4 * g4;
-      auto put = [&](char* P, int c, const f32x4 v) {
-        u32x2 hi, lo;
-        split4(v, hi, lo);
-        *(u32x2*)(P + c * 2) = hi;
-        *(u32x2*)(P + 1024 + c * 2) = lo;
-      };
-      auto row_planes = [&](char* P, const float* src) {  // a 128-float LDS row -> planes (threads 0..31: 4 values each)
-        if (threadIdx.x < 32) put(P, (int)threadIdx.x * 4, *(const f32x4*)(src + threadIdx.x * 4));
-      };
-      auto step = [&](Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int st) {
-        const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
-        const bf16x8 xl = *(const bf16x8*)(P + 1024 + (st * 32 + g4 * 8) * 2);
-        acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
-        acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
-        acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
-      };
-      const bool heads_mf = a.hw[0] != nullptr && a.qkv_out == nullptr;
-      W wb[2];
-      load_unit(wb[0], a.wo2, wave, lane);
-      load_unit(wb[1], a.w1, wave, lane);
-      __syncthreads();  // o1 = f complete; slot A is free (fold2 was consumed by combine_fold)
-      if (heads_mf && wave >= 2) {  // the heads' first gemv chunk (index 9 -> slot A) rides behind the tail
-        const uint32_t lds0 = lds_addr(slot_a);
-        for (int p = wave - 2; p < 33 * 2; p += NW - 2) glds_1k(a.hw[0] + p * 256 + lane * 4, lds0 + (uint32_t)p * 1024u);
-      }
-      row_planes(Ph, o1);
-      __syncthreads();
-      {  // x += row without a valid cross target ? 0 : out_proj(f)
-        Acc acc;
-        acc.zero();
-#pragma unroll
-        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Ph, st);
-        if (col0) {
-          const f32x4 xv = *(const f32x4*)(xs + c_out);
-          if (valid2) *(f32x4*)(xs + c_out) = xv + (acc.sum() + wb[0].bias);
-        }
-        load_unit(wb[0], a.w1, 8 + wave, lane);
-      }
-      MID_CLK(10);
-      __syncthreads();
-      if (wave == 0) ln_row128(xs, o1, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
-      __syncthreads();
-      row_planes(Ph, o1);
-      __syncthreads();
-      MID_CLK(11);
-      // u = relu(linear1(h)): 4 rounds of 128 channels, no barrier in between (they read Ph, write disjoint parts of Pu)
-#define TBX_MF_L1(R, CUR, NEXT_IMG, NEXT_UNIT)                                                        \
-  do {                                                                                                \
-    Acc acc;                                                                                          \
-    acc.zero();                                                                                       \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, wb[CUR].hi[st], wb[CUR].lo[st], Ph, st); \
-    if (col0) put(Pu, (R) * D + c_out, relu4(acc.sum() + wb[CUR].bias));                              \
-    load_unit(wb[CUR], NEXT_IMG, (NEXT_UNIT) + wave, lane);                                           \
-  } while (0)
-      TBX_MF_L1(0, 1, a.w1, 16);
-      TBX_MF_L1(1, 0, a.w1, 24);
-      TBX_MF_L1(2, 1, a.w2, 0);
-      TBX_MF_L1(3, 0, a.w2, 8);
-#undef TBX_MF_L1
-      __syncthreads();
-      MID_CLK(12);
-      {  // x += linear2(u): K = 512 as 4 units into one accumulator triple; invalid source rows come out as 0
-        Acc acc;
-        acc.zero();
-        const f32x4 bias = wb[1].bias;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Pu, st);
-        load_unit(wb[1], a.w2, 16 + wave, lane);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Pu, 4 + st);
-        load_unit(wb[0], a.w2, 24 + wave, lane);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Pu, 8 + st);
-        if (a.qkv_out != nullptr) load_unit(wb[1], a.wqkv, wave, lane);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) step(acc, wb[0].hi[st], wb[0].lo[st], Pu, 12 + st);
-        if (a.qkv_out != nullptr) load_unit(wb[0], a.wqkv, 8 + wave, lane);
-        if (col0) {
-          f32x4 v = *(const f32x4*)(xs + c_out) + (acc.sum() + bias);
-          if (!x_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          *(f32x4*)(xs + c_out) = v;
-          *(TBX_GLOBAL f32x4*)(a.x + (int64_t)row * D + c_out) = v;
-        }
-      }
-      MID_CLK(13);
-      if (!heads_mf) {
-        if (a.qkv_out == nullptr) return;
-        __syncthreads();
-        if (wave == 0) ln_row128(xs, o1, lane, a.ln3_eps, lg3, lb3);  // the next layer's norm_src
-        __syncthreads();
-        row_planes(Ph, o1);
-        __syncthreads();
-        float* qrow_out = a.qkv_out + (int64_t)row * a.ld_qkv_out;
-        {  // q
-          Acc acc;
-          acc.zero();
-#pragma unroll
-          for (int st = 0; st < 4; ++st) step(acc, wb[1].hi[st], wb[1].lo[st], Ph, st);
-          const f32x4 q = acc.sum() + wb[1].bias;
-          if (col0) {
-            put(Pq, c_out, q);
-            *(TBX_GLOBAL f32x4*)(qrow_out + c_out) = q;
-          }
-          load_unit(wb[1], a.wqkv, 16 + wave, lane);
-        }
-#define TBX_MF_KV(R, CUR)                                                                             \
-  do {                                                                                                \
-    Acc acc;                                                                                          \
-    acc.zero();                                                                                       \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, wb[CUR].hi[st], wb[CUR].lo[st], Ph, st); \
-    const f32x4 kv = acc.sum() + wb[CUR].bias;                                                        \
-    if (col0) {                                                                                       \
-      *(TBX_GLOBAL f32x4*)(qrow_out + D + (R) * D + c_out) = kv;                                      \
-      if (a.kv16_out != nullptr) {                                                                    \
-        const bf16x4 h16 = __builtin_convertvector(kv, bf16x4);                                       \
-        *(TBX_GLOBAL u32x2*)(a.kv16_out + (int64_t)row * (2 * D) + (R) * D + c_out) = __builtin_bit_cast(u32x2, h16); \
-      }                                                                                               \
-    }                                                                                                 \
-  } while (0)
-        TBX_MF_KV(0, 0);
-        load_unit(wb[0], a.wqt, wave, lane);
-        TBX_MF_KV(1, 1);
-#undef TBX_MF_KV
-        __syncthreads();  // q's planes complete
-        MID_CLK(14);
-        {  // W_rpe_k^T q per head: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (the head's own step)
-          const int h = wave >> 1;
-#pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            Acc acc;
-            acc.zero();
-            step(acc, wb[0].hi[st], wb[0].lo[st], Pq, h);
-            if (col0) *(TBX_GLOBAL f32x4*)(qrow_out + 3 * D + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
-          }
-        }
-        MID_CLK(15);
-        return;
-      }
-      __syncthreads();  // xs complete: the heads go on with the gemv chunks (index 9 is in flight into slot A)
-    }
-    const bool mf_done = MF;
     // chunk i of the tail -> (image pointer, float4-row offset, rows); slot = B for even i, A for odd i
     const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
     const int n_chunks = a.qkv_out != nullptr ? 13 : (heads ? 9 + 15 : 9);
@@ -514,7 +358,6 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     };
-    if (!mf_done) {
     // ---- chunk 0 (requested before the cross sweep, landed with combine_fold's vmcnt(0)): x += row without a valid cross target ? 0 : out_proj(f)
     __syncthreads();  // o1 = f complete; slot A is free (fold2 was consumed by combine_fold)
     request(1);
@@ -561,7 +404,6 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
       a.x[(int64_t)row * D + threadIdx.x] = v;
     }
     MID_CLK(13);
-    }  // !mf_done
     if (heads) {
       // ============================================================ the agents' heads in the last layer's launch: the stages of the
       // heads chain (traffic_bots.py:206-221): x += navi_valid ? mlp([x | navi_emb]) : 0 (add_navi_latent.py:52-65), the same with
@@ -660,6 +502,471 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
   }
 }
 
+// ================================================================================================================================
+// tbx_knarpe_dec_layer with tail_mfma32: the WHOLE layer's row-local arithmetic on the split-bf16 matrix path of tile_core.h.
+// One workgroup (8 wavefronts) per source row as above; waves 0..3 run the two target sweeps (attn_core.h, unchanged). Every LINEAR
+// - the two value folds, out_proj, q, W_k^T q, out_proj2, the FFN, the next layer's q | k | v | W_k^T q or the agents' heads - is a
+// v_mfma_f32_16x16x32_bf16 product D = W x^T whose B operand is the ONE row (bf16 hi / lo planes in LDS: hi at P + 2 k, lo `lo`
+// bytes behind; all 16 columns read the same row, column 0 is kept): wave w owns output tile w (channels 16 w .. 16 w + 15), its
+// weights come as 8 KiB register units (tbx_pack_weight_mfma32) straight from global memory, TWO units ahead of their use through
+// three register slots (not across a sweep: its state takes ~190 VGPRs of the 256 - the two units behind a sweep are requested
+// when its partial sums have left the registers, and land under the waves' combination). No weight passes through LDS (the exact-
+// fp32 form above stages 66 - 72 KiB images by LDS-DMA and runs 128-long dependent fma chains on 128 threads: ~1.15 us per 128 x 128
+// stage); a stage costs its 64 KiB of weights through the CU's 64 B/clk L2 port (~0.43 us) - measured per stage in
+// profiles/r03_dec_layer_phase_clock.txt.
+// Unit sequence: 0 fold_self, 1 out_proj, 2 q, 3 qfold, 4 fold_cross, 5 out_proj2, 6..9 linear1, 10..13 linear2, then either
+// 14..16 next in_proj (q, k, v), 17 next qfold, or the heads: 14..17 add_navi (k-chunk x, k-chunk embedding, layer 2, layer 3),
+// 18..21 add_latent, 22..24 / 25..27 / 28 the action head's three stacked stages (csrc/tile_heads.hip's entries), or nothing.
+namespace mf {
+using tbx_tile::Acc;
+using tbx_tile::bf16x4;
+using tbx_tile::bf16x8;
+using tbx_tile::f32x4;
+using tbx_tile::u32x2;
+using tbx_tile::W;
+
+constexpr int NSW = 8;  // all 8 waves sweep: a row's targets 8 per pass per wave, two waves per SIMD hide each other's load latencies
+constexpr int LO128 = 256, LO384 = 768, LO512 = 1024, LO640 = 1280;  // byte offset of the lo plane behind a K-wide hi plane
+
+template <int N>
+__device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wave, int lane) {
+  using tbx_tile::load_unit;
+  if constexpr (N == 0) load_unit(w, a.fold1, wave, lane);
+  else if constexpr (N == 1) load_unit(w, a.wo, wave, lane);
+  else if constexpr (N == 2) load_unit(w, a.wq, wave, lane);
+  else if constexpr (N == 3) load_unit(w, a.wkf, wave, lane);
+  else if constexpr (N == 4) load_unit(w, a.fold2, wave, lane);
+  else if constexpr (N == 5) load_unit(w, a.wo2, wave, lane);
+  else if constexpr (N <= 9) load_unit(w, a.w1, 8 * (N - 6) + wave, lane);
+  else if constexpr (N <= 13) load_unit(w, a.w2, 8 * (N - 10) + wave, lane);
+  else if (a.qkv_out != nullptr) {
+    if constexpr (N <= 16) load_unit(w, a.wqkv, 8 * (N - 14) + wave, lane);
+    else if constexpr (N == 17) load_unit(w, a.wqt, wave, lane);
+  } else if (heads) {
+    if constexpr (N == 14 || N == 18) load_unit(w, a.hw[N == 14 ? 0 : 3], wave, lane);
+    else if constexpr (N == 15 || N == 19) load_unit(w, a.hw[N == 15 ? 0 : 3], 8 + wave, lane);
+    else if constexpr (N == 16 || N == 17) load_unit(w, a.hw[N - 15], wave, lane);
+    else if constexpr (N == 20 || N == 21) load_unit(w, a.hw[N - 16], wave, lane);
+    else if constexpr (N >= 22 && N <= 24) load_unit(w, a.hw[6], 8 * (N - 22) + wave, lane);
+    else if constexpr (N >= 25 && N <= 27) load_unit(w, a.hw[7], 8 * (N - 25) + wave, lane);
+    else if constexpr (N == 28) load_unit(w, a.hw[8], wave < 3 ? wave : 2, lane);
+  }
+}
+
+// 4 values of the row -> planes (hi at P + 2 c, lo `lo` bytes behind)
+__device__ __forceinline__ void put4(char* P, int lo, int c, const f32x4 v) {
+  u32x2 hi, l;
+  tbx_tile::split4(v, hi, l);
+  *(u32x2*)(P + c * 2) = hi;
+  *(u32x2*)(P + lo + c * 2) = l;
+}
+
+// one 32-k step of D += W x^T with the row's planes as the B operand
+__device__ __forceinline__ void step(Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int lo, int st, int g4) {
+  const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
+  const bf16x8 xl = *(const bf16x8*)(P + lo + (st * 32 + g4 * 8) * 2);
+  acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
+  acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
+  acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 gemv4(const W& w, const char* P, int lo, int st0, int g4) {
+  Acc acc;
+  acc.zero();
+#pragma unroll
+  for (int st = 0; st < 4; ++st) step(acc, w.hi[st], w.lo[st], P, lo, st0 + st, g4);
+  return acc.sum();
+}
+
+// LayerNorm of the 128-float row `src` by one wavefront (ln_row128's order) -> planes
+__device__ __forceinline__ void ln_planes(const float* src, char* P, int lane, float eps, const float (&g)[2], const float (&bt)[2]) {
+  float v[2];
+  v[0] = src[lane], v[1] = src[lane + 64];
+  const float mean = tbx::wave_sum(v[0] + v[1]) / (float)D;
+  const float d0 = v[0] - mean, d1 = v[1] - mean;
+  const float var = tbx::wave_sum(d0 * d0 + d1 * d1) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float y = (v[q] - mean) * rstd * g[q] + bt[q];
+    const __bf16 h = (__bf16)y;
+    *(__bf16*)(P + 2 * (lane + 64 * q)) = h;
+    *(__bf16*)(P + LO128 + 2 * (lane + 64 * q)) = (__bf16)(y - (float)h);
+  }
+}
+
+// combine_fold's first half for 8 sweeping waves: their partials -> the row's normalised sums comb_s [640] (fp32) and their planes Pc
+template <class F>
+__device__ __forceinline__ void combine(RowAcc& st, const float (&M)[NH], const float (&L)[NH], float (*red_s)[RED], float* comb_s, char* Pc,
+                                        int wir, int lane, int s8, int tg, bool& any_valid, F&& request) {
+  if (tg == 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      *(float4*)(&red_s[wir][h * DH + s8 * 4]) = st.oacc[h];
+      st.eacc[h].store(&red_s[wir][D + h * DR], s8);
+    }
+  }
+  if (lane < NH) {
+    red_s[wir][OUTW + lane] = M[lane];
+    red_s[wir][OUTW + NH + lane] = L[lane];
+  }
+  request();  // (the sweep's sums have left the registers: the next two weight units fly under the combination)
+  __syncthreads();
+  {  // (a valid target gives every head a score: head 0's maxima tell)
+    float mm0 = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NSW; ++w) mm0 = fmaxf(mm0, red_s[w][OUTW]);
+    any_valid = mm0 > -INFINITY;
+  }
+  if (threadIdx.x < OUTW / 4) {  // 160 threads, 4 consecutive columns each (one head's)
+    const int c = (int)threadIdx.x * 4;
+    const int h = c < D ? c / DH : (c - D) / DR;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NSW; ++w) mm = fmaxf(mm, red_s[w][OUTW + h]);
+    float ll = 0.f, fw[NSW];
+#pragma unroll
+    for (int w = 0; w < NSW; ++w) {
+      const float mw = red_s[w][OUTW + h];
+      fw[w] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+      ll = __builtin_fmaf(fw[w], red_s[w][OUTW + NH + h], ll);
+    }
+    const float inv_l = (mm > -INFINITY) ? 1.0f / ll : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NSW; ++w) {
+      const f32x4 r = *(const f32x4*)(&red_s[w][c]);
+      acc[0] = __builtin_fmaf(fw[w], r[0], acc[0]), acc[1] = __builtin_fmaf(fw[w], r[1], acc[1]);
+      acc[2] = __builtin_fmaf(fw[w], r[2], acc[2]), acc[3] = __builtin_fmaf(fw[w], r[3], acc[3]);
+    }
+    acc *= inv_l;
+    if (c < D) *(f32x4*)(comb_s + c) = acc;  // (sum a v: the fold's fp32 addend)
+    put4(Pc, LO640, c, acc);
+  }
+  __syncthreads();
+}
+}  // namespace mf
+
+template <bool KV16>
+__global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
+  using namespace mf;
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) float red_s[NSW][RED];
+  __shared__ __attribute__((aligned(16))) float comb_s[D], xs[D], q2[D], qt2[NH * D], bk2_s[D], head_o[3 * 2];
+  __shared__ __attribute__((aligned(16))) char Pc[2 * LO640], Ph[2 * LO128], Pq[2 * LO128], Pu[2 * LO512], Pv[2 * LO384];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wir = wave;
+  const int row = blockIdx.x;
+#ifdef TBX_STAGE_CLOCK
+  unsigned mid_slot = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) mid_slot = atomicAdd(&g_mid_launch, 1u);
+#endif
+  MID_CLK(0);
+  const int b = row / a.n_src;
+  const int s8 = lane & 7, tg = lane >> 3;
+  const int g4 = lane >> 4;
+  const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row: channels c_out .. c_out + 3 of a 128-wide stage
+  const int c_out = 16 * wave + 4 * g4;
+  const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
+  W wb[3];
+  if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
+  if (threadIdx.x < D) bk2_s[threadIdx.x] = a.bias_k2[threadIdx.x];
+  float lg1[2] = {0.f, 0.f}, lb1[2] = {0.f, 0.f}, lg2[2] = {0.f, 0.f}, lb2[2] = {0.f, 0.f}, lg3[2] = {0.f, 0.f}, lb3[2] = {0.f, 0.f};
+  // (LayerNorm parameters: requested with the weight units behind each sweep - nothing is kept in registers across one)
+  EFreq fq;
+  fq.init(a.fxy, a.fyaw, s8);
+  float4 qv[NH];
+  ESlice qt[NH];
+  float qb[NH];
+  // ---------------------------------------------------------------- self attention
+  {
+    const float* qrow = a.qkv + (int64_t)row * a.ld_qkv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
+      const float4 bk = *(const float4*)(a.bias_k1 + h * DH + s8 * 4);
+      qb[h] = tbx::group8_sum(dot4(qv[h], bk));
+      qt[h].load(qrow + a.qt_off + h * DR, s8);
+    }
+  }
+  bool valid1, valid2;
+  MID_CLK(1);
+  {
+    RowAcc st;
+    st.zero();
+    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    sweep<NSW, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    merge_slots(st, M, L);
+    MID_CLK(2);
+    combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid1, [&]() {
+      issue<0>(wb[0], a, heads, wave, lane);
+      issue<1>(wb[1], a, heads, wave, lane);
+      if (wave == 0) lg1[0] = a.ln_w[lane], lg1[1] = a.ln_w[64 + lane], lb1[0] = a.ln_b[lane], lb1[1] = a.ln_b[64 + lane];
+    });
+  }
+  // ---- 0: y = sum a v + W_rpe_v (sum a e) + b (wave w: head w / 2, 16 of its 32 channels)
+  issue<2>(wb[2], a, heads, wave, lane);
+  {
+    const f32x4 y = gemv4(wb[0], Pc, LO640, 4 + 4 * (wave >> 1), g4) + wb[0].bias + *(const f32x4*)(comb_s + c_out);
+    if (col0) put4(Ph, LO128, c_out, y);
+  }
+  __syncthreads();
+  MID_CLK(3);
+  // ---- 1: x += no valid target ? 0 : out_proj(y)
+  issue<3>(wb[0], a, heads, wave, lane);
+  {
+    const f32x4 u = gemv4(wb[1], Ph, LO128, 0, g4) + wb[1].bias;
+    if (col0 && valid1) *(f32x4*)(xs + c_out) = *(const f32x4*)(xs + c_out) + u;
+  }
+  __syncthreads();
+  MID_CLK(4);
+  if (wave == 0) ln_planes(xs, Ph, lane, a.ln_eps, lg1, lb1);  // LN_1(x)
+  __syncthreads();
+  MID_CLK(5);
+  // ---- 2: q = W_q LN(x) + b_q
+  {
+    const f32x4 q = gemv4(wb[2], Ph, LO128, 0, g4) + wb[2].bias;
+    if (col0) {
+      *(f32x4*)(q2 + c_out) = q;
+      put4(Pq, LO128, c_out, q);
+    }
+  }
+  __syncthreads();
+  MID_CLK(6);
+  // ---- 3: qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (the head's own step)
+  {
+    const int h = wave >> 1;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      Acc acc;
+      acc.zero();
+      step(acc, wb[0].hi[st], wb[0].lo[st], Pq, LO128, h, g4);
+      if (col0) *(f32x4*)(qt2 + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
+    }
+  }
+  __syncthreads();
+  MID_CLK(7);
+  // ---------------------------------------------------------------- cross attention
+  {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      qv[h] = *(const float4*)(q2 + h * DH + s8 * 4);
+      qb[h] = tbx::group8_sum(dot4(qv[h], *(const float4*)(bk2_s + h * DH + s8 * 4)));
+      qt[h].load(qt2 + h * DR, s8);
+    }
+  }
+  MID_CLK(8);
+  {
+    RowAcc st;
+    st.zero();
+    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    sweep<NSW, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    merge_slots(st, M, L);
+    MID_CLK(9);
+    combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid2, [&]() {
+      issue<4>(wb[1], a, heads, wave, lane);
+      issue<5>(wb[2], a, heads, wave, lane);
+      if (wave == 0) {
+        lg2[0] = a.ln2_w[lane], lg2[1] = a.ln2_w[64 + lane], lb2[0] = a.ln2_b[lane], lb2[1] = a.ln2_b[64 + lane];
+        if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
+      }
+    });
+  }
+  const bool x_valid = a.src_invalid[row] == 0;
+  // ---- 4: the cross attention's value fold
+  issue<6>(wb[0], a, heads, wave, lane);
+  {
+    const f32x4 y = gemv4(wb[1], Pc, LO640, 4 + 4 * (wave >> 1), g4) + wb[1].bias + *(const f32x4*)(comb_s + c_out);
+    if (col0) put4(Ph, LO128, c_out, y);
+  }
+  __syncthreads();
+  // ---- 5: x += no valid cross target ? 0 : out_proj2(y)
+  issue<7>(wb[1], a, heads, wave, lane);
+  {
+    const f32x4 u = gemv4(wb[2], Ph, LO128, 0, g4) + wb[2].bias;
+    if (col0 && valid2) *(f32x4*)(xs + c_out) = *(const f32x4*)(xs + c_out) + u;
+  }
+  __syncthreads();
+  MID_CLK(10);
+  if (wave == 0) ln_planes(xs, Ph, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
+  __syncthreads();
+  MID_CLK(11);
+  // ---- 6..9: u = relu(linear1(h)), 4 rounds of 128 channels (no barrier between them: they read Ph and write disjoint parts of Pu)
+#define TBX_MF_L1(N)                                                                 \
+  do {                                                                               \
+    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
+    const W& w = wb[(N) % 3];                                                        \
+    const f32x4 u = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);            \
+    if (col0) put4(Pu, LO512, ((N) - 6) * D + c_out, u);                             \
+  } while (0)
+  TBX_MF_L1(6);
+  TBX_MF_L1(7);
+  TBX_MF_L1(8);
+  TBX_MF_L1(9);
+#undef TBX_MF_L1
+  __syncthreads();
+  MID_CLK(12);
+  {  // ---- 10..13: x += linear2(u), K = 512 as 4 units into one accumulator triple; invalid source rows come out as 0
+    Acc acc;
+    acc.zero();
+    const f32x4 bias = wb[10 % 3].bias;
+#define TBX_MF_L2(N)                                                                 \
+  do {                                                                               \
+    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
+    const W& w = wb[(N) % 3];                                                        \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w.hi[st], w.lo[st], Pu, LO512, 4 * ((N) - 10) + st, g4); \
+  } while (0)
+    TBX_MF_L2(10);
+    TBX_MF_L2(11);
+    TBX_MF_L2(12);
+    TBX_MF_L2(13);
+#undef TBX_MF_L2
+    if (col0) {
+      f32x4 v = *(const f32x4*)(xs + c_out) + (acc.sum() + bias);
+      if (!x_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(xs + c_out) = v;
+      *(TBX_GLOBAL f32x4*)(a.x + (int64_t)row * D + c_out) = v;
+    }
+  }
+  MID_CLK(13);
+  if (a.qkv_out != nullptr) {
+    // ================================================================ the next layer's projections (attention_rpe.py:92-98,147)
+    __syncthreads();
+    if (wave == 0) ln_planes(xs, Ph, lane, a.ln3_eps, lg3, lb3);
+    __syncthreads();
+    float* qrow_out = a.qkv_out + (int64_t)row * a.ld_qkv_out;
+    {  // 14: q
+      issue<16>(wb[16 % 3], a, heads, wave, lane);
+      const W& w = wb[14 % 3];
+      const f32x4 q = gemv4(w, Ph, LO128, 0, g4) + w.bias;
+      if (col0) {
+        put4(Pq, LO128, c_out, q);
+        *(TBX_GLOBAL f32x4*)(qrow_out + c_out) = q;
+      }
+    }
+#define TBX_MF_KV(N)                                                                                  \
+  do {                                                                                                \
+    const W& w = wb[(N) % 3];                                                                         \
+    const f32x4 kv = gemv4(w, Ph, LO128, 0, g4) + w.bias;                                             \
+    if (col0) {                                                                                       \
+      *(TBX_GLOBAL f32x4*)(qrow_out + ((N) - 14) * D + c_out) = kv;                                   \
+      if (a.kv16_out != nullptr) {                                                                    \
+        const bf16x4 h16 = __builtin_convertvector(kv, bf16x4);                                       \
+        *(TBX_GLOBAL u32x2*)(a.kv16_out + (int64_t)row * (2 * D) + ((N) - 15) * D + c_out) = __builtin_bit_cast(u32x2, h16); \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+    issue<17>(wb[17 % 3], a, heads, wave, lane);
+    TBX_MF_KV(15);
+    TBX_MF_KV(16);
+#undef TBX_MF_KV
+    __syncthreads();  // q's planes complete
+    MID_CLK(14);
+    {  // 17: W_rpe_k^T q per head
+      const W& w = wb[17 % 3];
+      const int h = wave >> 1;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        Acc acc;
+        acc.zero();
+        step(acc, w.hi[st], w.lo[st], Pq, LO128, h, g4);
+        if (col0) *(TBX_GLOBAL f32x4*)(qrow_out + 3 * D + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
+      }
+    }
+    MID_CLK(15);
+    return;
+  }
+  if (!heads) return;
+  // ================================================================ the agents' heads (traffic_bots.py:206-221; csrc/tile_heads.hip's
+  // stages on one row): Pv = [x | navi_emb | latent_emb] planes, the adders' hidden rows in Ph / Pq, the action head's in Pu / Pv
+  if (threadIdx.x < 64) {
+    const int c = ((int)threadIdx.x & 31) * 4;
+    const float* src = threadIdx.x < 32 ? a.navi_emb : a.latent_emb;
+    put4(Pv, LO384, (threadIdx.x < 32 ? D : 2 * D) + c, *(const TBX_GLOBAL f32x4*)(src + (int64_t)row * D + c));
+  }
+  if (col0) put4(Pv, LO384, c_out, *(const f32x4*)(xs + c_out));  // (this lane's own 4 channels of x, written above)
+  const bool ok_navi = a.navi_valid[row] != 0, ok_lat = a.latent_invalid[row] == 0;
+  __syncthreads();
+#define TBX_MF_ADDER(N, ZSTEP, OK)                                                                    \
+  do {                                                                                                \
+    {                                                                                                 \
+      Acc acc;                                                                                        \
+      acc.zero();                                                                                     \
+      issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                                        \
+      const W& w0 = wb[(N) % 3];                                                                      \
+      const f32x4 bias = w0.bias;                                                                     \
+      _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w0.hi[st], w0.lo[st], Pv, LO384, st, g4); \
+      issue<(N) + 3>(wb[((N) + 3) % 3], a, heads, wave, lane);                                        \
+      const W& w1 = wb[((N) + 1) % 3];                                                                \
+      _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w1.hi[st], w1.lo[st], Pv, LO384, (ZSTEP) + st, g4); \
+      if (col0) put4(Ph, LO128, c_out, tbx_tile::relu4(acc.sum() + bias));                            \
+    }                                                                                                 \
+    __syncthreads();                                                                                  \
+    {                                                                                                 \
+      issue<(N) + 4>(wb[((N) + 4) % 3], a, heads, wave, lane);                                        \
+      const W& w = wb[((N) + 2) % 3];                                                                 \
+      const f32x4 hdn = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);                         \
+      if (col0) put4(Pq, LO128, c_out, hdn);                                                          \
+    }                                                                                                 \
+    __syncthreads();                                                                                  \
+    {                                                                                                 \
+      issue<(N) + 5>(wb[((N) + 5) % 3], a, heads, wave, lane);                                        \
+      const W& w = wb[((N) + 3) % 3];                                                                 \
+      const f32x4 upd = tbx_tile::relu4(gemv4(w, Pq, LO128, 0, g4) + w.bias);                         \
+      if (col0) {                                                                                     \
+        f32x4 xv = *(const f32x4*)(xs + c_out);                                                       \
+        if (OK) xv += upd;                                                                            \
+        *(f32x4*)(xs + c_out) = xv;                                                                   \
+        put4(Pv, LO384, c_out, xv);                                                                   \
+      }                                                                                               \
+    }                                                                                                 \
+    __syncthreads();                                                                                  \
+  } while (0)
+  TBX_MF_ADDER(14, 4, ok_navi);
+  TBX_MF_ADDER(18, 8, ok_lat);
+#undef TBX_MF_ADDER
+  // ---- action head layer 1: 128 -> 3 x 128 (units 22..24), relu -> Pu[g * 128 ..]
+#define TBX_MF_A1(N)                                                                 \
+  do {                                                                               \
+    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
+    const W& w = wb[(N) % 3];                                                        \
+    const f32x4 u = tbx_tile::relu4(gemv4(w, Pv, LO384, 0, g4) + w.bias);            \
+    if (col0) put4(Pu, LO512, ((N) - 22) * D + c_out, u);                            \
+  } while (0)
+  TBX_MF_A1(22);
+  TBX_MF_A1(23);
+  TBX_MF_A1(24);
+#undef TBX_MF_A1
+  __syncthreads();
+  // ---- layer 2: block-diagonal 3 x (128 -> 128) (units 25..27), relu: branch g reads Pu[g * 128 ..] -> Pv[g * 128 ..]
+#define TBX_MF_A2(N)                                                                 \
+  do {                                                                               \
+    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
+    const W& w = wb[(N) % 3];                                                        \
+    const f32x4 u = tbx_tile::relu4(gemv4(w, Pu, LO512, 4 * ((N) - 25), g4) + w.bias); \
+    if (col0) put4(Pv, LO384, ((N) - 25) * D + c_out, u);                            \
+  } while (0)
+  TBX_MF_A2(25);
+  TBX_MF_A2(26);
+  TBX_MF_A2(27);
+#undef TBX_MF_A2
+  __syncthreads();
+  // ---- layer 3 (unit 28): wave g < 3 = branch g, 16 zero-padded outputs of which the first 2 are the action
+  if (wave < 3) {
+    const W& w = wb[28 % 3];
+    const f32x4 o = gemv4(w, Pv, LO384, 4 * wave, g4) + w.bias;
+    if (lane == 0) head_o[wave * 2] = o[0], head_o[wave * 2 + 1] = o[1];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {  // the masked sum over the branches, in branch order from 0
+    float v = 0.f;
+    for (int g = 0; g < 3; ++g)
+      if (a.type_mask[(int64_t)g * a.mask_stride + row] == 0) v += head_o[g * 2 + threadIdx.x];
+    a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
+  }
+}
+
 int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
   if (!s.kv || !s.idx || !s.invalid || (!s.emb && !s.rel_pose) || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
   if (!s.emb && (!fxy || !fyaw)) return TBX_ERR_ARG;
@@ -748,13 +1055,11 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
   } while (0)
   a.tail_mfma = t ? t->tail_mfma32 : 0;
-  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0) {
-    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((dec_mid_kernel<true, 8, true>), dim3(a.n_rows), dim3(8 * 64), lds_bytes, hs, a);
-  } else if (t && a.tail_mfma) {
-    (void)hipFuncSetAttribute((const void*)dec_mid_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((dec_mid_kernel<false, 8, true>), dim3(a.n_rows), dim3(8 * 64), lds_bytes, hs, a);
-  } else if (t && p->self_seg.kv_bf16 != 0)
+  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0)
+    hipLaunchKernelGGL((dec_layer_mf_kernel<true>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  else if (t && a.tail_mfma)
+    hipLaunchKernelGGL((dec_layer_mf_kernel<false>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  else if (t && p->self_seg.kv_bf16 != 0)
     TBX_MID_LAUNCH(true, 8);
   else if (t)
     TBX_MID_LAUNCH(false, 8);

@@ -79,7 +79,7 @@ class Schedule:
     navi_rider: bool = True  # small launches: the heads' navigation embedding in extra workgroups of the agents' first-projection launch (no auxiliary stream in the step)
     knn_main: bool = True  # the agents' K-nearest searches on the stepping stream (no cross-queue wait in front of the first attention launch); the auxiliary stream keeps the navigation embedding, joined before the LAST layer
     sim_before_join: bool = True  # the agents' tbx_sim_step on their own stream before the lights' stream is joined
-    dec_tail_mfma: bool = True  # tbx_knarpe_dec_layer's tail (out_proj / FFN / next projections) on the split-bf16 matrix path
+    dec_tail_mfma: bool = True  # tbx_knarpe_dec_layer's LINEAR stages (folds, projections, FFN, heads) on the split-bf16 matrix path
     pe_rides: bool = True       # tbx_knn_embed_multi_pe: the navigation pose embedding in the searches' launch
     # ---- RolloutEngine
     tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
@@ -484,7 +484,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
         # be captured before the side work or the whole layer sequence moves queues behind a ~12 us cross-queue wait
         after_first_proj()
     if callable(heads_tail):  # (resolved late: the caller's side work above may be what makes the heads' inputs)
-        heads_tail = heads_tail()
+        heads_tail = heads_tail(mfma32=current().dec_tail_mfma and DROP_CTX is None)
     if join_stream is not None and not join_late:  # whoever produced the K-nearest sets on another stream is joined here, not before the projection
         torch.cuda.current_stream().wait_stream(join_stream)
     mid = fold and dec and current().dec_mid and bool(live_rows_for(rows))  # the one-launch attention half: small launches only
@@ -514,11 +514,12 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                 tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], **tkw),
                            next_qfold=hip.packed_weight(an.linear_rpe.weight[:D], None, wt=True, groups=NH, **tkw),
                            next_norm=(nn_.weight, nn_.bias, nn_.eps), qkv_out=qkv_alt, kv16_out=kv16_alt)
+            fold_img = (lambda at: hip.packed_weight(at.linear_rpe.weight[D:], at.linear_rpe.bias[D:], groups=NH, mfma32=True)) if tmf else attn_fold_image
             hip.knarpe_dec_mid(qkv, 0, 3 * D, x, self_seg, list(cross(l)), a1.linear_rpe.bias, a2.linear_rpe.bias,
-                               (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, attn_fold_image(a1),
-                               hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, gemv=True),
-                               hip.packed_weight(a2.in_proj_weight[:D], a2.in_proj_bias[:D], gemv=True),
-                               hip.packed_weight(a2.linear_rpe.weight[:D], None, wt=True, groups=NH, gemv=True), attn_fold_image(a2),
+                               (layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), n, S, fold_img(a1),
+                               hip.packed_weight(a1.out_proj_weight, a1.out_proj_bias, **tkw),
+                               hip.packed_weight(a2.in_proj_weight[:D], a2.in_proj_bias[:D], **tkw),
+                               hip.packed_weight(a2.linear_rpe.weight[:D], None, wt=True, groups=NH, **tkw), fold_img(a2),
                                None, None, fxy, fyw, tail=tl_)
             if not last:
                 qkv, qkv_alt = qkv_alt, qkv  # the next layer's q | k | v | qt went to the other buffer (this layer's K/V rows were still being read)

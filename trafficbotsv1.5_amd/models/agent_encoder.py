@@ -180,7 +180,7 @@ class AgentEncoder(nn.Module):
         kv_mp = self.kv_mp(mp)
         # (the searches are joined inside run_block, right before the first attention call: the first projection chain needs x only)
         # heads_tail(prep) -> the tbx_heads_tail_t fields (or None): the caller's heads in the last layer's launch; prep["_heads_done"] tells
-        prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else (lambda: heads_tail(prep)),
+        prep["_heads_done"] = run_block(self.tf_ag2agmptl, x, tok_inv, n, A, SelfKnn(i_aa, m_aa, rel=r_aa), heads_tail=None if heads_tail is None else (lambda **kw: heads_tail(prep, **kw)),
                   cross=lambda l: [Seg(kv_mp, l * 2 * D, l * 2 * D + D, M, i_am, m_am, None, mp_batch_div, rel=r_am),
                                    Seg(tl_kv, l * 2 * D, l * 2 * D + D, L, i_at, m_at, None, tl_batch_div, rel=r_at)], tail=tail, pose_rpe=rp,
                   join_stream=aux_stream, first_proj=fp, join_late=knn_main, after_first_proj=side_work if knn_main else None,
