@@ -595,6 +595,109 @@ __device__ __forceinline__ void ln_planes(const float* src, char* P, int lane, f
   }
 }
 
+// attn_core.h's `sweep` for NSW waves per row with the FIRST pass of segment 0 handed in: its target index / mask are fetched at
+// the top of the kernel and its K / V rows and embedding slice while the previous phase finishes (`Pre`), so the sweep starts on
+// operands that are already in registers instead of behind two dependent memory round trips (~2500 shader clocks each at this
+// occupancy, profiles/r03_attn_phase_clock.txt). Same passes in the same order as sweep<NSW>: the same sums.
+struct Pre {
+  float4 kq[4], v[4];
+  ESlice e;  // the materialised embedding slice (seg.emb), or - in e.wc.x / y / z - the relative pose it is rebuilt from when the pass
+             // runs (rebuilding it where it is requested would wait for the pose there)
+};
+__device__ __forceinline__ void pre_index(const Sweep& a, int row, int wir, int tg, int& j, bool& ok) {
+  const tbx_attn_seg_t& S = a.seg[0];
+  const int t = wir * 8 + tg;
+  const bool active = t < S.k;
+  const int64_t pi = (int64_t)row * S.k + (active ? t : S.k - 1);
+  j = S.idx[pi];
+  ok = (S.invalid[pi] == 0) & active;
+}
+template <bool KV16>
+__device__ __forceinline__ void pre_rows(const Sweep& a, int row, int b, int wir, int s8, int tg, int j, const EFreq& fq, Pre& p) {
+  const tbx_attn_seg_t& S = a.seg[0];
+  constexpr int ES = KV16 ? 2 : 1;
+  const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
+  const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
+  const int t = wir * 8 + tg;
+  const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    p.kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
+    p.v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
+  }
+  if (S.emb != nullptr)
+    p.e.load(S.emb + pi * DR, s8);
+  else
+    p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
+}
+template <bool KV16>
+__device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir, int s8, int tg, const float4 (&qv)[NH], const ESlice (&qt)[NH],
+                                         const float (&qb)[NH], const EFreq& fq, Pre& pre, bool pre_ok, RowAcc& st) {
+  float(&m_run)[NH] = st.m_run;
+  float(&l_run)[NH] = st.l_run;
+  float4(&oacc)[NH] = st.oacc;
+  ESlice(&eacc)[NH] = st.eacc;
+  auto pass = [&](const bool ok, const float4(&kq)[4], const float4(&v)[4], const ESlice& e) {
+    float sc[NH];
+    bool jump = false;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      sc[h] = (tbx::group8_sum(pair_score(kq[h], qv[h], e, qt[h])) + qb[h]) * a.scale2;
+      jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
+    }
+    if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
+          l_run[h] *= alpha;
+          scale4(oacc[h], alpha);
+          eacc[h].scale(alpha);
+          m_run[h] = sc[h];
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];
+      const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
+      l_run[h] += pr;
+      fma4(oacc[h], pr, v[h]);
+      eacc[h].fma(pr, e);
+    }
+  };
+  if (wir * 8 < a.seg[0].k) {
+    if (a.seg[0].emb == nullptr) {
+      const float rel[3] = {pre.e.wc.x, pre.e.wc.y, pre.e.wc.z};
+      fq.embed(rel, pre.e);
+    }
+    pass(pre_ok, pre.kq, pre.v, pre.e);
+  }
+  for (int sg = 0; sg < a.n_seg; ++sg) {
+    const tbx_attn_seg_t& S = a.seg[sg];
+    constexpr int ES = KV16 ? 2 : 1;
+    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
+    const int64_t pbase = (int64_t)row * S.k;
+    for (int base = wir * 8 + (sg == 0 ? 8 * NSW : 0); base < S.k; base += 8 * NSW) {
+      const int t = base + tg;
+      const bool active = t < S.k;
+      const int64_t pi = pbase + (active ? t : S.k - 1);
+      const int j = S.idx[pi];
+      const bool ok = (S.invalid[pi] == 0) & active;
+      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
+      float4 kq[4], v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        kq[q] = kv_load4<KV16>(trow, S.k_off + q * 32 + s8 * 4);
+        v[q] = kv_load4<KV16>(trow, S.v_off + q * 32 + s8 * 4);
+      }
+      ESlice e;
+      load_e(S, pi, s8, fq, e);
+      pass(ok, kq, v, e);
+    }
+  }
+}
+
 // combine_fold's first half for 8 sweeping waves: their partials -> the row's normalised sums comb_s [640] (fp32) and their planes Pc
 template <class F>
 __device__ __forceinline__ void combine(RowAcc& st, const float (&M)[NH], const float (&L)[NH], float (*red_s)[RED], float* comb_s, char* Pc,
@@ -679,6 +782,11 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   float4 qv[NH];
   ESlice qt[NH];
   float qb[NH];
+  // the target index / mask of the cross sweep's first pass (the K-nearest sets are inputs of the launch)
+  int j2;
+  bool ok2;
+  pre_index(a.cross, row, wir, tg, j2, ok2);
+  Pre pre;
   // ---------------------------------------------------------------- self attention
   {
     const float* qrow = a.qkv + (int64_t)row * a.ld_qkv;
@@ -703,6 +811,7 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
       issue<0>(wb[0], a, heads, wave, lane);
       issue<1>(wb[1], a, heads, wave, lane);
       if (wave == 0) lg1[0] = a.ln_w[lane], lg1[1] = a.ln_w[64 + lane], lb1[0] = a.ln_b[lane], lb1[1] = a.ln_b[64 + lane];
+      pre_rows<KV16>(a.cross, row, b, wir, s8, tg, j2, fq, pre);  // the cross sweep's first pass: in flight under the layer's middle
     });
   }
   // ---- 0: y = sum a v + W_rpe_v (sum a e) + b (wave w: head w / 2, 16 of its 32 channels)
@@ -761,7 +870,7 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     RowAcc st;
     st.zero();
     float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
-    sweep<NSW, false, KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    sweep_pf<KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok2, st);
     merge_slots(st, M, L);
     MID_CLK(9);
     combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid2, [&]() {
