@@ -238,6 +238,9 @@ typedef struct tbx_layer_tile {
    *   y = rider_add + (W0 rider_in + b0);  h = relu(W1 y + b1);  h = relu(W2 h + b2);  h = relu(W3 h + b3);
    *   rider_out[row] = rider_valid[row] ? h : 0.   All [rider_rows, 128]; images: tbx_pack_weight_mfma32 (n 128, k 128). */
   const float *rider_in, *rider_add;
+  /* rider_pose3 != NULL: rider_in is not read - the stage-0 input is the 128-d pose embedding (tbx_pose_embed's) of rider_pose3
+   * [rider_rows, 3], built in the kernel from the frequency tables rider_freqs_xy / rider_freqs_yaw */
+  const float *rider_pose3, *rider_freqs_xy, *rider_freqs_yaw;
   const float* rider_images[4];
   const uint8_t* rider_valid;
   float* rider_out;

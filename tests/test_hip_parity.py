@@ -718,12 +718,13 @@ def test_layer_tile_equals_row_chains(tb, hip, dev, mode, S, Ks, T, K, n_layer, 
     assert err > 0.0  # the two paths really are different arithmetic
 
 
-@pytest.mark.parametrize("rows,r_rows", [(64, 64), (40, 21), (16, 130)])
-def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows):
+@pytest.mark.parametrize("rows,r_rows,pose3", [(64, 64, False), (40, 21, False), (16, 130, True), (48, 33, True)])
+def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows, pose3):
     """tbx_layer_tile_t's rider (extra workgroups of the first-projection launch): y = add + W0 in + b0, three relu LINEARs, invalid
     rows 0 - against the row chain the engine runs for the heads' navigation embedding (navigation.py:65-79 +
     add_navi_latent.py:43-50: LINEAR accumulate, three LINEAR + relu, the last with its row mask), on ragged row counts that differ
-    from the main rows'; the main rows' projections are the same bits with and without the rider."""
+    from the main rows'; the main rows' projections are the same bits with and without the rider. pose3: the stage-0 input is the
+    pose embedding the rider builds itself from [rows, 3] poses (large launches) - the chain reads tbx_pose_embed's."""
     eng = import_module("trafficbots_amd.engine")
     M = import_module("trafficbots_amd.models.modules.transformer_rpe")
     g = torch.Generator().manual_seed(rows + r_rows)
@@ -737,6 +738,12 @@ def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows
     Ws = [(torch.randn(D, D, generator=g) / 8).to(dev) for _ in range(4)]
     bs = [torch.randn(D, generator=g).to(dev) for _ in range(4)]
     inp, add = torch.randn(r_rows, D, generator=g).to(dev), torch.randn(r_rows, D, generator=g).to(dev)
+    src = dict(inp=inp)
+    if pose3:
+        p3 = torch.cat([(torch.rand(r_rows, 2, generator=g) - 0.5) * 300, (torch.rand(r_rows, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
+        fxy, fyw = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
+        inp = hip.pose_embed(p3, fxy, fyw, D)
+        src = dict(pose3=p3, freqs=(fxy, fyw))
     valid = (torch.rand(r_rows, generator=g) < 0.7).to(torch.uint8).to(dev)
     out = torch.full((r_rows, D), 7.0, device=dev)
     qkv = [torch.zeros(rows, eng.QKV_LD, device=dev) for _ in range(2)]
@@ -744,7 +751,7 @@ def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows
         proj = lambda o: eng.tile_proj_part(l0.norm1, l0.attn, o, True, None)
         hip.layer_tile(x, proj=proj(qkv[0]), store_x=False)
         hip.layer_tile(x, proj=proj(qkv[1]), store_x=False,
-                       rider=dict(inp=inp, add=add, out=out, valid=valid, images=[hip.packed_weight(w, b, mfma32=True) for w, b in zip(Ws, bs)]))
+                       rider=dict(add=add, out=out, valid=valid, images=[hip.packed_weight(w, b, mfma32=True) for w, b in zip(Ws, bs)], **src))
     ref = torch.empty(r_rows, D, device=dev)
     C, B0 = hip.Chain, hip.BUF0
     ch = C(16, 4 * D + 4)

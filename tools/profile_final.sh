@@ -24,6 +24,10 @@ rocprofv3 --kernel-trace --stats -d $out/kt_train -o kt -- python3 bench.py --mo
 db=$(find $out/kt_train -name '*.db' | head -1)
 { echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --no-cpu-baseline --no-train-graph --steps 1 --warmup 1 --profile-steps 0  (2 eager training steps of 16 scenes; a graph replay takes the GPU-busy time of one)"; echo; tail -1 $out/${tag}_train_eager.log | cut -c1-300; echo; python3 tools/rocpd_stats.py $db 2>/dev/null | head -42; } > $out/${tag}_train_kernel_stats.md
 rm -rf $out/kt_train
+# phase clock inside the one-launch decoder layer (profiling build: make -C trafficbotsv1.5_amd/csrc clk)
+if [ -f trafficbotsv1.5_amd/csrc/libtbx_hip_clk.so ]; then
+  { echo "tools/mid_clock.py: s_memtime stamps of workgroup 0 in every dec_layer_mf_kernel launch of one eager step (launches 0-3: the lights' 128 rows, 4-7: the agents' 64 rows; unit = 100 shader clocks, ~0.042 us)"; python3 tools/mid_clock.py 2>/dev/null | grep -v amdgpu.ids; } > $out/${tag}_dec_layer_phase_clock.txt
+fi
 python bench.py > $out/${tag}_bench_default.log 2>&1
 tail -1 $out/${tag}_bench_default.log | cut -c1-200
 cat $out/${tag}_gpu_tests.log

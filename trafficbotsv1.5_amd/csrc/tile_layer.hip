@@ -61,7 +61,7 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
 }
 
 // the rider's tile (tbx_layer_tile_t.rider_*): four 128 -> 128 stages on 16 rows of its own, planes ping-pong Pa <-> Pb
-__device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, char* Pa, char* Pb) {
+__device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, float* X, char* Pa, char* Pb) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -79,7 +79,16 @@ __device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, 
   {
     const int r = tid >> 5, c4 = tid & 31;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < nv) v = gld4(t.rider_in + (row0 + r) * D + c4 * 4);
+    if (t.rider_pose3 != nullptr) {  // the rows' pose embeddings (tbx_common.h pose_emb_write: the stand-alone kernel's values)
+      if (r < nv) {
+        const TBX_GLOBAL float* p3 = (const TBX_GLOBAL float*)t.rider_pose3 + (row0 + r) * 3;
+        tbx::pose_emb_write(X + r * XLD, D, p3[0], p3[1], p3[2], t.rider_freqs_xy, t.rider_freqs_yaw, c4, 32);
+      }
+      __syncthreads();
+      if (r < nv) v = *(const f32x4*)(X + r * XLD + c4 * 4);
+    } else if (r < nv) {
+      v = gld4(t.rider_in + (row0 + r) * D + c4 * 4);
+    }
     planes_write4<PL>(Pa, r, c4 * 4, v);
   }
   __syncthreads();
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   if constexpr (!ATTN && !FFN && PROJ == 2) {
     const int main_tiles = (int)((t.n_rows + ROWS - 1) / ROWS);
     if ((int)blockIdx.x >= main_tiles) {  // (only launched with rider_rows > 0)
-      rider_tile(t, (int)blockIdx.x - main_tiles, Pa, Pb);
+      rider_tile(t, (int)blockIdx.x - main_tiles, X, Pa, Pb);
       return;
     }
   }
@@ -436,7 +445,9 @@ extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
   if (t.rider_rows < 0) return TBX_ERR_ARG;
   if (t.rider_rows > 0) {
     if (attn || ffn || proj != 2) return TBX_ERR_UNSUPPORTED;
-    if (t.rider_in == nullptr || t.rider_add == nullptr || t.rider_valid == nullptr || t.rider_out == nullptr) return TBX_ERR_ARG;
+    if ((t.rider_in == nullptr && t.rider_pose3 == nullptr) || t.rider_add == nullptr || t.rider_valid == nullptr || t.rider_out == nullptr)
+      return TBX_ERR_ARG;
+    if (t.rider_pose3 != nullptr && (t.rider_freqs_xy == nullptr || t.rider_freqs_yaw == nullptr)) return TBX_ERR_ARG;
     for (int i = 0; i < 4; ++i)
       if (t.rider_images[i] == nullptr) return TBX_ERR_ARG;
     if ((((uintptr_t)t.rider_in) | ((uintptr_t)t.rider_add) | ((uintptr_t)t.rider_out)) & 15) return TBX_ERR_ALIGN;

@@ -88,7 +88,8 @@ class LayerTile(C.Structure):
                 + [(n, C.c_int32) for n in ("ld_attn", "ld_proj", "proj_n", "store_x")] + [("n_rows", C.c_int64)]
                 + [("drop_seed", C.c_void_p), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_site", C.c_int32 * 3),
                    ("drop_step", C.c_int32)]
-                + [("rider_in", C.c_void_p), ("rider_add", C.c_void_p), ("rider_images", C.c_void_p * 4), ("rider_valid", C.c_void_p),
+                + [("rider_in", C.c_void_p), ("rider_add", C.c_void_p), ("rider_pose3", C.c_void_p), ("rider_freqs_xy", C.c_void_p),
+                   ("rider_freqs_yaw", C.c_void_p), ("rider_images", C.c_void_p * 4), ("rider_valid", C.c_void_p),
                    ("rider_out", C.c_void_p), ("rider_rows", C.c_int64)])
 
 
@@ -620,7 +621,8 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=Non
     ffn = dict(norm2 (w, b, eps), linear1, linear2 (images), src_invalid u8 [rows] | None);
     proj = dict(norm (w, b, eps), image, qfold (images), n = 128 | 384, out [rows, >= 640 | 896], kv16 = bf16 [rows, 256] | None);
     drop = the keyed dropouts of training's stepping pass (see below);
-    rider = dict(inp, add, out [r, 128], valid u8 [r], images = 4 mfma32 images): tbx_layer_tile_t's rider_* (a first-projection launch only)."""
+    rider = dict(inp [r, 128] | pose3 [r, 3] + freqs, add, out [r, 128], valid u8 [r], images = 4 mfma32 images): tbx_layer_tile_t's rider_* (a
+    first-projection launch only)."""
     a = LayerTile()
     a.x, a.n_rows, a.store_x = _cptr(x, torch.float32), x.shape[0], int(store_x)
     assert x.dim() == 2 and x.shape[1] == 128
@@ -654,9 +656,15 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=Non
             a.drop_site[i] = -1 if st is None else int(st)
     if rider is not None:
         r = rider["out"].shape[0]
-        for k in ("inp", "add", "out"):
+        for k in ("add", "out") + (("inp",) if rider.get("pose3") is None else ()):
             assert rider[k].shape == (r, 128) and rider[k].is_contiguous()
-        a.rider_in, a.rider_add, a.rider_out = _ptr(rider["inp"], torch.float32), _ptr(rider["add"], torch.float32), _ptr(rider["out"], torch.float32)
+        a.rider_add, a.rider_out = _ptr(rider["add"], torch.float32), _ptr(rider["out"], torch.float32)
+        if rider.get("pose3") is not None:  # stage 0 on the pose embedding of pose3 [r, 3], built in the kernel (freqs = (xy, yaw) tables)
+            assert rider["pose3"].shape == (r, 3)
+            a.rider_pose3 = _cptr(rider["pose3"], torch.float32)
+            a.rider_freqs_xy, a.rider_freqs_yaw = _cptr(rider["freqs"][0], torch.float32), _cptr(rider["freqs"][1], torch.float32)
+        else:
+            a.rider_in = _ptr(rider["inp"], torch.float32)
         assert rider["valid"].numel() == r and len(rider["images"]) == 4
         a.rider_valid, a.rider_rows = _cptr(rider["valid"], torch.uint8), r
         for i, im in enumerate(rider["images"]):

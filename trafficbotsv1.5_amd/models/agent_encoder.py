@@ -108,9 +108,10 @@ class AgentEncoder(nn.Module):
         if pe_rides and prep.get("navi_pe") is None:
             prep["navi_pe"] = torch.empty(n * A, navi_rpe.out_dim, dtype=torch.float32, device=dev)
         rider = None
-        if (navi_rider is not None and engine_current().navi_rider and pe_rides and aux_tail is not None and tile_small_ok()
-                and not tile_rows_ok(n * A, keyed_dropout=True) and fp is None):
-            rider = navi_rider(prep)  # (None: the modules are not of the shape the rider is built for)
+        if (navi_rider is not None and engine_current().navi_rider and want_pe and aux_tail is not None and fp is None
+                and (tile_small_ok() or tile_rows_ok(n * A, keyed_dropout=True))):
+            # (large launches: the destination's pose embedding is built inside the rider - nothing of it rides on the searches)
+            rider = navi_rider(prep, pose3=not pe_rides)  # (None: the modules are not of the shape the rider is built for)
         use_rider = rider is not None
         if use_rider:
             aux_stream = None  # nothing of this step runs beside this stream
@@ -165,7 +166,7 @@ class AgentEncoder(nn.Module):
             if knn_main:
                 aux_stream.wait_event(knn_done)  # fork behind the searches' launch (the destination's pose embedding rides in it)
             with torch.cuda.stream(aux_stream if aux_stream is not None else main):
-                if want_pe:
+                if want_pe and not use_rider:
                     if not pe_rides:
                         prep["navi_pe"] = hip.pose_embed(prep["navi_pose3"], navi_rpe.pe_xy.freqs, navi_rpe.pe_yaw.freqs, navi_rpe.out_dim,
                                                          out=prep.get("navi_pe"))

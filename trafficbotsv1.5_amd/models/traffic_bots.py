@@ -124,8 +124,9 @@ class TrafficBots(nn.Module):
             prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
             cn.run(n * A)
 
-        def navi_rider(prep):
-            """The same four stages as `aux_tail` as tbx_layer_tile_t's rider (agent_encoder.encode), or None."""
+        def navi_rider(prep, pose3: bool = False):
+            """The same four stages as `aux_tail` as tbx_layer_tile_t's rider (agent_encoder.encode), or None. pose3: stage 0 reads the
+            pose embedding the rider builds itself from prep["navi_pose3"] instead of prep["navi_pe"]."""
             l_pe = self.navi_encoder.mlp_pe.linear_layers()
             l_in = self.add_navi.mlp_in.linear_layers()
             if (rc.get("dest_feature") is None or len(l_pe) != 1 or len(l_in) != 3 or any(ln is not None for _, ln, _ in l_pe + l_in)
@@ -134,8 +135,12 @@ class TrafficBots(nn.Module):
             if prep.get("navi_emb") is None:
                 prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
             prep["_navi_premasked"] = True
-            return dict(inp=prep["navi_pe"], add=rc["dest_feature"], out=prep["navi_emb"], valid=navi_valid_u8.reshape(-1),
-                        images=[hip.packed_weight(t[0].weight, t[0].bias, mfma32=True) for t in l_pe + l_in])
+            src = (dict(pose3=prep["navi_pose3"], freqs=(self.pose_rpe.pe_xy.freqs, self.pose_rpe.pe_yaw.freqs)) if pose3
+                   else dict(inp=prep["navi_pe"]))
+            if pose3 and self.pose_rpe.out_dim != d:
+                return None
+            return dict(add=rc["dest_feature"], out=prep["navi_emb"], valid=navi_valid_u8.reshape(-1),
+                        images=[hip.packed_weight(t[0].weight, t[0].bias, mfma32=True) for t in l_pe + l_in], **src)
 
         def heads_tail(prep, mfma32: bool = False):
             """The heads as tbx_heads_tail_t / tbx_heads_tile_t fields when everything they read is at hand in the form the fused
