@@ -171,13 +171,23 @@ int tbx_knarpe_dec_mid(const tbx_dec_mid_t* args /* host */, void* stream);
  * block-diagonal stages and their masked sum (action_head.py:74-100) -> action_out [rows, 2]. images[0..2] = add_navi.mlp
  * (256 -> 128, 128 -> 128, 128 -> 128), [3..5] = add_latent.mlp, [6] = the branches' first layers stacked (128 -> 384), [7] = their
  * second layers (groups 3, 128 -> 128), [8] = their third layers zero-padded to 16 outputs (groups 3, 128 -> 16): gemv images. */
+struct tbx_sim_state;       /* defined below (K10) */
+struct tbx_agent_prep_args; /* defined below (tbx_agent_prep) */
 typedef struct tbx_heads_tail {
   const float* images[9];
   const float *navi_emb, *latent_emb;    /* [rows, 128] */
   const uint8_t *navi_valid, *latent_invalid; /* [rows] */
   const uint8_t* type_mask;              /* [3, mask_stride]: byte set = the agent is not of that type (or not valid) */
   float* action_out;                     /* [rows, 2] */
-  int32_t mask_stride, pad_;
+  int32_t mask_stride;
+  /* Fused step tail (tail_mfma32 launches; sim_state and next_prep both or neither; host pointers): behind a row's action the
+   * launch runs that agent's tbx_sim_step_parts(sim_state, sim_parts) - sim_parts = TBX_SIM_AGENTS [| TBX_SIM_ADVANCE], the agents'
+   * part only, rows = sim_state's n_batch * n_ag agents - and then tbx_agent_prep (*next_prep) of the NEXT step for that agent: an
+   * agent's step and its window features read nothing of another agent's, so the two launches that close and open every step of the
+   * closed loop are the tail of the launch that produced the action. */
+  int32_t sim_parts;
+  const struct tbx_sim_state* sim_state;
+  const struct tbx_agent_prep_args* next_prep;
 } tbx_heads_tail_t;
 
 typedef struct tbx_dec_layer {
@@ -599,6 +609,22 @@ int tbx_rowchain_live(const tbx_stage_t* stages /* host */, int n_stages, int64_
  *   type_mask [3, n*A] u8: ~(type_i & valid_now)
  *   navi_pose3 [n*A, 3]: dest token pose relative to the agent's current pose; navi_row [n*A] i32 = b*M + dest
  */
+/* tbx_agent_prep's arguments as a structure (tbx_heads_tail_t.next_prep): n_tok = n_batch * n_ag */
+typedef struct tbx_agent_prep_args {
+  const uint8_t* hist_valid;
+  const float *hist_pose, *hist_motion, *ag_attr6;
+  const uint8_t* ag_type_idx;
+  const float *freqs_xy, *freqs_yaw;
+  float* tok_pose;
+  uint8_t* tok_invalid;
+  float *attr, *pe;
+  uint8_t *row_invalid, *type_mask;
+  const int64_t* dest;
+  const float* mp_tok_pose;
+  float* navi_pose3;
+  int32_t* navi_row;
+  int32_t n_tok, n_ag, window, pe_dim, n_mp, mp_batch_div;
+} tbx_agent_prep_args_t;
 int tbx_agent_prep(const uint8_t* hist_valid, const float* hist_pose, const float* hist_motion, const float* ag_attr6,
                    const uint8_t* ag_type_idx, int n_batch, int n_ag, int window, const float* freqs_xy,
                    const float* freqs_yaw, int pe_dim, float* tok_pose, uint8_t* tok_invalid, float* attr, float* pe,

@@ -202,6 +202,40 @@ def test_lights_one_step_ahead_equals_sequential_order(tb):
         assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), k
 
 
+@pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
+def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
+    """Schedule.fused_tail: the agents' tbx_sim_step and the next step's tbx_agent_prep run in the tail of the last decoder layer's
+    launch (tbx_heads_tail_t.sim_state / next_prep: the same device functions, csrc/step_core.h) instead of as two launches - the
+    whole rollout log (poses, validity, actions, rewards, rule flags, light states) must not differ by a bit, eager and as graphs,
+    over teacher-forced and free steps, and a cached engine refilled with another scene must start from freshly prepared windows."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    E = import_module("trafficbots_amd.engine")
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    z = torch.randn(1, sizes[0], 16, generator=torch.Generator().manual_seed(4)).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    outs = {}
+    for fused in (False, True):
+        for use_graph in (False, True):
+            wm.schedule = E.DEFAULT.replace(fused_tail=fused)
+            outs[fused, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
+                                                        step_end=30, use_graph=use_graph)
+            if fused and use_graph:  # the same (cached) engine again: restore() re-prepares the first step's windows
+                again = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
+                                           step_end=30, use_graph=True)
+                assert torch.equal(again.pred_pose, outs[fused, use_graph].pred_pose)
+    ref = outs[False, False]
+    for k, o in outs.items():
+        for name in ("pred_pose", "pred_valid", "pred_motion", "action_log_prob", "mask_teacher_forcing"):
+            assert torch.equal(getattr(o, name), getattr(ref, name)), (k, name)
+        for name in ("action", "tl_state"):
+            assert torch.equal(o.vis_dict[name], ref.vis_dict[name]), (k, name)
+        for name in ref.violation:
+            assert torch.equal(o.violation[name], ref.violation[name]), (k, name)
+        for name in ref.diffbar_reward:
+            assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
+
+
 def test_hoisted_rollout_constants_are_bit_identical(tb):
     """The engine embeds the latent and the destination feature once per rollout instead of in every step's heads chain
     (TrafficBots.rollout_constants): same kernels on the same inputs, so the rollout must not change by a bit."""

@@ -15,8 +15,13 @@ rows = db.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.workg
                   f"on d.kernel_id=s.id order by d.start").fetchall()
 minb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 idx = [i for i, r in enumerate(rows) if "sim_step_kernel" in r[0] and r[3] // max(r[4], 1) >= minb]
-a, b = idx[-4], idx[-3]
-step = rows[a + 1:b + 1]
+if len(idx) >= 4:
+    a, b = idx[-4], idx[-3]
+    step = rows[a + 1:b + 1]
+else:  # Schedule.fused_tail: the agents' step runs inside the last decoder layer's launch - a step = one searches' launch to the next
+    idx = [i for i, r in enumerate(rows) if "knn_multi_kernel" in r[0]]
+    a, b = idx[-4], idx[-3]
+    step = rows[a:b]
 t0 = step[0][1]
 last_end = {}
 busy = {}

@@ -14,12 +14,14 @@
 // between the two attentions, and q / W_k^T q / the first attention's output make no round trip through global memory.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "../../include/tbx_hip.h"
 #include "attn_core.h"
 #include "tbx_common.h"
 #include "tile_core.h"
+#include "step_core.h"
 
 namespace {
 
@@ -62,7 +64,11 @@ struct MidArgs {
   int mask_stride;
   float ln2_eps, ln3_eps;
   int ld_qkv_out;
-  int tail_mfma;  // the tail's LINEAR stages on the split-bf16 matrix path: wo2 / w1 / w2 / wqkv / wqt are tbx_pack_weight_mfma32 images
+  int tail_mfma;  // every LINEAR stage on the split-bf16 matrix path: all images are tbx_pack_weight_mfma32 images (dec_layer_mf_kernel)
+  // fused step tail (tbx_heads_tail_t.sim_state / next_prep): the row's agent's simulation step and next feature preparation
+  int fused_tail, sim_parts;
+  tbx_sim_state_t sim;
+  tbx_agent_prep_args_t prep;
 };
 
 #ifdef TBX_STAGE_CLOCK
@@ -1074,6 +1080,17 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
       if (a.type_mask[(int64_t)g * a.mask_stride + row] == 0) v += head_o[g * 2 + threadIdx.x];
     a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
   }
+  if (a.fused_tail) {
+    // ============================================================== the step's tail for this row's agent (csrc/step_core.h): its
+    // tbx_sim_step (dynamics, rule checks, overrides, log, window append: 32 lanes) on the action just written, then the NEXT
+    // step's tbx_agent_prep of its new window (4 waves) - neither reads anything of another agent's
+    const int t_step = *a.sim.step;
+    __syncthreads();  // the action is in memory (workgroup scope)
+    if (wave == 0 && lane < tbx_step::LPA) tbx_step::sim_agent(a.sim, a.sim_parts, t_step, row, lane, 0);
+    if (a.sim_parts & TBX_SIM_ADVANCE) tbx_step::sim_advance(a.sim, t_step, gridDim.x);
+    __syncthreads();  // the appended window is
+    if (threadIdx.x < 256) tbx_step::agent_prep(a.prep, row, (int)threadIdx.x);
+  }
 }
 
 int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
@@ -1137,6 +1154,9 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   a.src_invalid = nullptr, a.qkv_out = nullptr, a.kv16_out = nullptr, a.ln2_eps = a.ln3_eps = 0.f, a.ld_qkv_out = 0;
   for (int i = 0; i < 9; ++i) a.hw[i] = nullptr;
   a.navi_emb = a.latent_emb = nullptr, a.navi_valid = a.latent_invalid = a.type_mask = nullptr, a.action_out = nullptr, a.mask_stride = 0;
+  a.fused_tail = 0, a.sim_parts = 0;
+  memset(&a.sim, 0, sizeof(a.sim));
+  memset(&a.prep, 0, sizeof(a.prep));
   if (t) {
     a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
     a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
@@ -1152,6 +1172,14 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
         return TBX_ERR_ARG;
       a.navi_emb = h.navi_emb, a.latent_emb = h.latent_emb, a.navi_valid = h.navi_valid, a.latent_invalid = h.latent_invalid;
       a.type_mask = h.type_mask, a.action_out = h.action_out, a.mask_stride = h.mask_stride;
+      if ((h.sim_state != nullptr) != (h.next_prep != nullptr)) return TBX_ERR_ARG;
+      if (h.sim_state != nullptr) {
+        if (!t->tail_mfma32) return TBX_ERR_UNSUPPORTED;
+        a.sim = *h.sim_state, a.prep = *h.next_prep, a.sim_parts = h.sim_parts, a.fused_tail = 1;
+        if ((a.sim_parts & ~TBX_SIM_ADVANCE) != TBX_SIM_AGENTS) return TBX_ERR_ARG;
+        if (a.sim.n_batch * a.sim.n_ag != a.n_rows || a.prep.n_tok != a.n_rows || a.sim.action_mean != h.action_out) return TBX_ERR_ARG;
+        if (!a.sim.step || !a.prep.hist_valid || !a.prep.tok_pose || !a.prep.attr || !a.prep.pe || !a.prep.row_invalid) return TBX_ERR_ARG;
+      }
     }
     a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
   }

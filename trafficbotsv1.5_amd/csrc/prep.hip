@@ -7,98 +7,16 @@
 
 #include "../../include/tbx_hip.h"
 #include "tbx_common.h"
+#include "step_core.h"
 
 namespace {
 
-struct AgentPrepArgs {
-  const uint8_t* hist_valid;
-  const float* hist_pose;
-  const float* hist_motion;
-  const float* ag_attr6;
-  const uint8_t* ag_type_idx;
-  const float* fxy;
-  const float* fyaw;
-  float* tok_pose;
-  uint8_t* tok_invalid;
-  float* attr;
-  float* pe;
-  uint8_t* row_invalid;
-  uint8_t* type_mask;
-  const int64_t* dest;
-  const float* mp_tok_pose;
-  float* navi_pose3;
-  int32_t* navi_row;
-  int n_tok, n_ag, window, pe_dim, n_mp, mp_batch_div;
-};
-
-__device__ __forceinline__ void to_local(float x0, float y0, float c, float s, float x, float y, float& rx, float& ry) {
-  const float dx = __fsub_rn(x, x0), dy = __fsub_rn(y, y0);
-  rx = __fadd_rn(__fmul_rn(dx, c), __fmul_rn(dy, s));
-  ry = __fadd_rn(__fmul_rn(dx, -s), __fmul_rn(dy, c));
-}
+using tbx_step::AgentPrepArgs;
+using tbx_step::to_local;
 
 // One workgroup (4 wavefronts) per agent: the window's steps are dealt to the wavefronts, the last valid step comes from one
 // ballot over the validity bytes (the kernel opens every agent step: 14 -> ~6 us at 64 agents).
-__global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int i = blockIdx.x;
-  if (i >= a.n_tok) return;
-  const int W = a.window;  // <= 23 (attribute row: 9 + W <= 32)
-  const uint8_t* hv = a.hist_valid + (int64_t)i * W;
-  const float* hp = a.hist_pose + (int64_t)i * W * 3;
-  const float* hm = a.hist_motion + (int64_t)i * W * 3;
-  const unsigned long long vmask = __ballot(lane < W && hv[lane < W ? lane : 0] != 0);
-  const int last = vmask ? 63 - __builtin_clzll(vmask) : -1;
-  float x0 = 0.f, y0 = 0.f, yaw0 = 0.f;
-  if (last >= 0) {
-    x0 = hp[last * 3];
-    y0 = hp[last * 3 + 1];
-    yaw0 = hp[last * 3 + 2];
-  }
-  if (threadIdx.x == 0) {
-    a.tok_pose[i * 3] = x0;
-    a.tok_pose[i * 3 + 1] = y0;
-    a.tok_pose[i * 3 + 2] = yaw0;
-    a.tok_invalid[i] = last < 0 ? 1 : 0;
-  }
-  const float c = cosf(yaw0), s = sinf(yaw0);
-  for (int w = wave; w < W; w += 4) {
-    const int64_t r = (int64_t)i * W + w;
-    float rx, ry;
-    to_local(x0, y0, c, s, hp[w * 3], hp[w * 3 + 1], rx, ry);
-    const float ryaw = __fsub_rn(hp[w * 3 + 2], yaw0);
-    tbx::pose_emb_write(a.pe + r * a.pe_dim, a.pe_dim, rx, ry, ryaw, a.fxy, a.fyaw, lane, 64);
-    if (lane < 32) {
-      float v = 0.f;
-      if (lane < 6)
-        v = a.ag_attr6[(int64_t)i * 6 + lane];
-      else if (lane < 9)
-        v = hm[w * 3 + lane - 6];
-      else if (lane - 9 == w)
-        v = 1.f;
-      a.attr[r * 32 + lane] = v;
-    }
-    if (lane == 32) a.row_invalid[r] = ((vmask >> w) & 1ull) ? 0 : 1;
-  }
-  if (wave != 0) return;
-  if (a.type_mask != nullptr && lane < 3) {
-    const bool now = hv[W - 1] != 0;
-    a.type_mask[(int64_t)lane * a.n_tok + i] = (now && a.ag_type_idx[i] == lane) ? 0 : 1;
-  }
-  if (a.dest != nullptr && lane == 0) {
-    const int b = i / a.n_ag;
-    const int64_t mrow = (int64_t)(b / a.mp_batch_div) * a.n_mp + a.dest[i];
-    const float ax = hp[(W - 1) * 3], ay = hp[(W - 1) * 3 + 1], ayaw = hp[(W - 1) * 3 + 2];
-    const float cc = cosf(ayaw), ss = sinf(ayaw);
-    float rx, ry;
-    to_local(ax, ay, cc, ss, a.mp_tok_pose[mrow * 3], a.mp_tok_pose[mrow * 3 + 1], rx, ry);
-    a.navi_pose3[i * 3] = rx;
-    a.navi_pose3[i * 3 + 1] = ry;
-    a.navi_pose3[i * 3 + 2] = __fsub_rn(a.mp_tok_pose[mrow * 3 + 2], ayaw);
-    a.navi_row[i] = (int32_t)mrow;
-  }
-}
+__global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) { tbx_step::agent_prep(a, (int)blockIdx.x, (int)threadIdx.x); }
 
 __global__ void tl_prep_kernel(const uint8_t* __restrict__ hist_tl, const uint8_t* __restrict__ tl_invalid, int n_tok,
                                int window, int ld_attr, float* __restrict__ attr, uint8_t* __restrict__ row_invalid) {

@@ -68,7 +68,14 @@ class HeadsTail(C.Structure):
     """tbx_heads_tail_t (include/tbx_hip.h)."""
     _fields_ = ([("images", C.c_void_p * 9)]
                 + [(n, C.c_void_p) for n in ("navi_emb", "latent_emb", "navi_valid", "latent_invalid", "type_mask", "action_out")]
-                + [("mask_stride", C.c_int32), ("pad_", C.c_int32)])
+                + [("mask_stride", C.c_int32), ("sim_parts", C.c_int32), ("sim_state", C.c_void_p), ("next_prep", C.c_void_p)])
+
+
+class AgentPrepArgs(C.Structure):
+    """tbx_agent_prep_args_t (include/tbx_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("hist_valid", "hist_pose", "hist_motion", "ag_attr6", "ag_type_idx", "freqs_xy", "freqs_yaw", "tok_pose",
+                                           "tok_invalid", "attr", "pe", "row_invalid", "type_mask", "dest", "mp_tok_pose", "navi_pose3", "navi_row")]
+                + [(n, C.c_int32) for n in ("n_tok", "n_ag", "window", "pe_dim", "n_mp", "mp_batch_div")])
 
 
 class DecLayer(C.Structure):
@@ -611,6 +618,9 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
         keep.navi_valid, keep.latent_invalid = _cptr(hd["navi_valid"], torch.uint8), _cptr(hd["latent_invalid"], torch.uint8)
         keep.type_mask, keep.action_out = _cptr(hd["type_mask"], torch.uint8), _cptr(hd["action_out"], torch.float32)
         keep.mask_stride = hd["type_mask"].shape[1]
+        if hd.get("sim_state") is not None:  # the fused step tail: (SimState, parts) + the next step's AgentPrepArgs
+            keep.sim_state, keep.sim_parts = C.addressof(hd["sim_state"]), int(hd["sim_parts"])
+            keep.next_prep = C.addressof(hd["next_prep"])
         t.heads = C.addressof(keep)
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
@@ -779,6 +789,21 @@ def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n
     th = p * 4294967296.0
     th = np.uint32(1 if 0 < th < 1 else int(th))
     return torch.from_numpy(x >= th)
+
+
+def agent_prep_args(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,
+                    mp_tok_pose=None, n_mp=0, mp_batch_div=1) -> AgentPrepArgs:
+    """agent_prep's arguments as tbx_agent_prep_args_t (the fused step tail of tbx_knarpe_dec_layer)."""
+    n, A, W = hist_valid.shape
+    a = AgentPrepArgs()
+    a.hist_valid, a.hist_pose, a.hist_motion = _cptr(hist_valid, torch.uint8), _cptr(hist_pose, torch.float32), _cptr(hist_motion, torch.float32)
+    a.ag_attr6, a.ag_type_idx = _cptr(ag_attr6, torch.float32), _cptr(ag_type_idx, torch.uint8)
+    a.freqs_xy, a.freqs_yaw = _cptr(freqs_xy), _cptr(freqs_yaw)
+    a.tok_pose, a.tok_invalid, a.attr, a.pe, a.row_invalid = (_ptr(out[k]) for k in ("tok_pose", "tok_invalid", "attr", "pe", "row_invalid"))
+    a.type_mask, a.dest, a.mp_tok_pose = _ptr(out.get("type_mask")), _cptr(dest, torch.int64), _cptr(mp_tok_pose, torch.float32)
+    a.navi_pose3, a.navi_row = _ptr(out.get("navi_pose3")), _ptr(out.get("navi_row"))
+    a.n_tok, a.n_ag, a.window, a.pe_dim, a.n_mp, a.mp_batch_div = n * A, A, W, pe_dim, n_mp, mp_batch_div
+    return a
 
 
 def agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,

@@ -61,13 +61,30 @@ class AgentEncoder(nn.Module):
                        navi_row=torch.empty(n * A, dtype=torch.int32, device=dev))
         return out
 
+    def _prep_call(self, hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, prep, dest, mp, mp_batch_div):
+        return ((hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, self.pose_emb.pe_xy.freqs, self.pose_emb.pe_yaw.freqs,
+                 self.pose_emb.out_dim, prep),
+                dict(dest=dest, mp_tok_pose=mp["mp_token_pose"] if dest is not None else None, n_mp=mp["mp_token_pose"].shape[1],
+                     mp_batch_div=mp_batch_div))
+
+    def run_prep(self, *a) -> None:
+        """tbx_agent_prep of the windows into `prep` (agent_encoder.py:130-159's inputs + token poses, type masks, navi rows)."""
+        args, kw = self._prep_call(*a)
+        hip.agent_prep(*args, **kw)
+
+    def prep_args(self, *a):
+        """The same call as a tbx_agent_prep_args_t (the fused step tail of tbx_knarpe_dec_layer runs it for the next step)."""
+        args, kw = self._prep_call(*a)
+        return hip.agent_prep_args(*args, **kw)
+
     def encode(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, mp: Dict[str, Tensor],
                tl_invalid_u8: Tensor, tl_pose: Tensor, tl_kv: Tensor, prep: Optional[Dict[str, Tensor]] = None,
                ag_type_idx: Optional[Tensor] = None, dest: Optional[Tensor] = None, mp_batch_div: int = 1, tl_batch_div: int = 1,
                tail: Optional[Callable[[Chain], None]] = None, aux_stream=None, navi_rpe=None,
                aux_tail: Optional[Callable[[Dict[str, Tensor]], None]] = None,
                heads_tail: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None,
-               navi_rider: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+               navi_rider: Optional[Callable[[Dict[str, Tensor]], Optional[dict]]] = None,
+               prep_ready: bool = False) -> Tuple[Tensor, Dict[str, Tensor]]:
         """hist_* [n,A,W(,3)] oldest first (u8 / f32); tl_kv = K/V tables of this step's tl tokens [n*L, 4*256]
         ([n/tl_batch_div * L, ..] with tl_pose / tl_invalid_u8 [n/tl_batch_div, L, ..] when the rollouts of a scene share its lights).
         -> ag_token_feature [n*A, d] and the prep dict (token pose/invalid, type masks, navi rows).
@@ -85,10 +102,10 @@ class AgentEncoder(nn.Module):
         dev, d, rp = hist_pose.device, self.hidden_dim, self.pose_rpe
         M, L = mp["mp_token_pose"].shape[1], tl_pose.shape[1]
         if prep is None:
+            assert not prep_ready
             prep = self.alloc_prep(n, A, dev, with_heads=dest is not None)
-        hip.agent_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, self.pose_emb.pe_xy.freqs,
-                       self.pose_emb.pe_yaw.freqs, self.pose_emb.out_dim, prep, dest=dest,
-                       mp_tok_pose=mp["mp_token_pose"] if dest is not None else None, n_mp=M, mp_batch_div=mp_batch_div)
+        if not prep_ready:  # (prep_ready: the previous step's last launch already ran this step's tbx_agent_prep - its fused tail)
+            self.run_prep(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, prep, dest, mp, mp_batch_div)
         tok_pose, tok_inv = prep["tok_pose"], prep["tok_invalid"]
         mp_inv = mp.get("mp_token_invalid_u8")
         if mp_inv is None:

@@ -97,9 +97,13 @@ class TrafficBots(nn.Module):
     def agent_policy(self, hist_valid: Tensor, hist_pose: Tensor, hist_motion: Tensor, ag_attr6: Tensor, ag_type_idx: Tensor,
                      ag_latent: Tensor, latent_invalid: Tensor, dest: Tensor, navi_valid_u8: Tensor,
                      tl_tokens: Dict[str, Tensor], mp_tokens: Dict[str, Tensor], tl_kv: Tensor, out: Dict[str, Tensor],
-                     aux_stream=None, rollout_consts: Optional[Dict[str, Tensor]] = None) -> None:
+                     aux_stream=None, rollout_consts: Optional[Dict[str, Tensor]] = None, fused_tail: Optional[dict] = None,
+                     prep_ready: bool = False) -> None:
         """The agent half (traffic_bots.py:200-221): agent tokens attending to agents / map / tl K/V tables `tl_kv`, then
-        navi + latent + action head -> out['action_mean']."""
+        navi + latent + action head -> out['action_mean'].
+        fused_tail = dict(sim_state, parts): the rollout engine's request to run the agents' tbx_sim_step_parts and the NEXT step's
+        tbx_agent_prep in the tail of the launch that produces the actions (tbx_heads_tail_t.sim_state / next_prep); whether it
+        happened is reported in out["prep"]["_tail_fused"]. prep_ready: this step's tbx_agent_prep already ran (that tail)."""
         n, A, W = hist_valid.shape
         d = self.hidden_dim
         dev = hist_pose.device
@@ -158,16 +162,23 @@ class TrafficBots(nn.Module):
             w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
             imgs = [pw(t[0].weight, t[0].bias) for t in an.mlp.linear_layers()] + [pw(t[0].weight, t[0].bias) for t in al.mlp.linear_layers()]
             imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
-            return dict(images=imgs, navi_emb=prep["navi_emb"], latent_emb=rc["latent_embedded"], navi_valid=navi_valid_u8.reshape(-1),
-                        latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"], action_out=out["action_mean"])
+            hd = dict(images=imgs, navi_emb=prep["navi_emb"], latent_emb=rc["latent_embedded"], navi_valid=navi_valid_u8.reshape(-1),
+                      latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"], action_out=out["action_mean"])
+            if fused_tail is not None and mfma32 and engine.current().fused_tail:
+                fused["args"] = self.ag_encoder.prep_args(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, prep, dest, mp_tokens, div)
+                hd.update(sim_state=fused_tail["sim_state"], sim_parts=fused_tail["parts"], next_prep=fused["args"])
+            return hd
 
+        fused = {}
         feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
                                             tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
                                             dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
                                             aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None,
                                             heads_tail=heads_tail if navi_ahead else None,
-                                            navi_rider=navi_rider if navi_ahead else None)
+                                            navi_rider=navi_rider if navi_ahead else None, prep_ready=prep_ready)
         out["prep"], out["ag_feat"] = prep, feat
+        prep["_tail_fused"] = bool(prep.get("_heads_done")) and "args" in fused
+        prep["_tail_keep"] = fused.get("args")  # (the ctypes structure outlives the launch call anyway; kept for clarity)
         if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
             return
         if tile:

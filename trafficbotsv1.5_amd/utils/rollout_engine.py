@@ -203,6 +203,7 @@ class RolloutEngine:
         self._tl_prep = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
+        self._prep_ready = False  # this step's tbx_agent_prep already ran in the previous step's fused tail (step())
         self.side, self.aux = self._side_streams(dev)
         # per-rollout constants of the heads chain (embedded latent, destination feature): once, not every step
         self.consts = (self.model.rollout_constants(self.ag_latent, self.dest, mp_tokens, div, latent_invalid=self.latent_invalid)
@@ -256,6 +257,7 @@ class RolloutEngine:
         self._n_forward = 0
         if not self.stepwise:
             self._tl_ahead(0)
+        self._prime_prep()
 
     @staticmethod
     def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor]) -> None:
@@ -280,6 +282,20 @@ class RolloutEngine:
         self._n_forward = 0
         if not self.stepwise:
             self._tl_ahead(0)
+        self._prime_prep()
+
+    def _prime_prep(self) -> None:
+        """Schedule.fused_tail: a step's tbx_agent_prep is run by the previous step's last launch - for the first step after the state
+        was (re)set it is run here, eagerly, so that every captured step starts from prepared windows."""
+        prep = self.policy_out.get("prep")
+        self._prep_ready = False
+        if prep is None or not prep.get("_tail_fused") or self.stepwise:
+            return  # (no step has run yet: the first one prepares its windows itself; or this schedule does not fuse the tail)
+        S = self.S
+        div = self.tl_tokens.get("ag_mp_batch_div", self.tl_tokens.get("mp_batch_div", 1))
+        self.model.ag_encoder.run_prep(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"], prep, self.dest,
+                                       self.mp_tokens, div)
+        self._prep_ready = True
 
     def _tl_ahead(self, slot: int, prepared=None) -> None:
         """tl encoder on the current light window: logits for the next lights update, K/V tables (into buffer `slot`)
@@ -323,10 +339,18 @@ class RolloutEngine:
             else:
                 hip.sim_step(st_tl, parts_tl)
                 self._tl_ahead(1 - p)
+        fuse = early and self.sched.fused_tail
         self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"],
                                 self.ag_latent, self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens,
-                                self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux, rollout_consts=self.consts)
-        if early:
+                                self.mp_tokens, self.tl_kv[p], self.policy_out, aux_stream=self.aux, rollout_consts=self.consts,
+                                fused_tail=dict(sim_state=self.sim_state, parts=hip.SIM_AGENTS | hip.SIM_ADVANCE) if fuse else None,
+                                prep_ready=fuse and self._prep_ready)
+        if fuse and self.policy_out["prep"].get("_tail_fused"):
+            # the last layer's launch ran the agents' step and the next step's tbx_agent_prep (tbx_heads_tail_t.sim_state / next_prep)
+            self._prep_ready = True
+            main.wait_stream(self.side)
+        elif early:
+            self._prep_ready = False
             # the agents' launch closes their step on their own stream; the join moves behind it (hipGraph's executor puts a node
             # on the queue of the parent it reaches first: joined first, this launch ran on the lights' queue behind a ~12 us wait)
             hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
