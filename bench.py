@@ -160,7 +160,7 @@ class KernelEvents:
     def __enter__(self):
         hip, T = self.hip, self._time
         sv = self._saved = {n: getattr(hip, n) for n in ("knarpe_attn", "knarpe_dec_mid", "knn_embed", "knn_embed_multi", "agent_prep",
-                                                         "tl_prep", "sim_step", "pose_embed", "layer_tile", "heads_tile", "window_tile")}
+                                                         "tl_prep", "sim_step", "pose_embed", "layer_tile", "heads_tile", "window_tile", "front")}
         sv["Chain.run"] = hip.Chain.run
 
         def mid(*args, **kw):
@@ -204,11 +204,18 @@ class KernelEvents:
             return T("tile", "window", 2.0 * attr.shape[0] * mac, sv["window_tile"], attr, pe, row_invalid, in_images, pn_images, window, out,
                      add_mode=add_mode, drop=drop)
 
+        def fr(window, proj, rider=None, jobs=None, pose_embed_job=None):
+            rows = window["out"].shape[0]
+            add = bool(window.get("add_mode"))
+            mac_w = (32 * 128 + 2 * 128 * 128 if add else 32 * 64 + 2 * 64 * 64) + 3 * 128 * 64
+            fl = 2.0 * window["attr"].shape[0] * mac_w + 2.0 * rows * (128 * 384 + 128 * 128) + (0.0 if rider is None else 2.0 * rider["out"].shape[0] * 4 * 128 * 128)
+            return T("tile", "front", fl, sv["front"], window, proj, rider=rider, jobs=jobs, pose_embed_job=pose_embed_job)
+
         def other(name):
             return lambda *a, **kw: T("other", name, 0.0, sv[name], *a, **kw)
 
         hip.knarpe_attn, hip.Chain.run, hip.knarpe_dec_mid = attn, run, mid
-        hip.layer_tile, hip.heads_tile, hip.window_tile = lt, ht, wt
+        hip.layer_tile, hip.heads_tile, hip.window_tile, hip.front = lt, ht, wt, fr
         for n in ("knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed"):
             setattr(hip, n, other(n))
         return self
@@ -254,7 +261,8 @@ def kernel_entry(args, c):
     elif cls in ("chain", "chain_live", "tile"):
         ach = c["work"] / c["t"] / 1e12
         if cls == "tile":
-            name, pre = f"tile_{key}_kernel", [f"tile_{key}_kernel"]
+            name = "front_kernel" if key == "front" else f"tile_{key}_kernel"  # (tbx_front: window tile + first projection + searches)
+            pre = [name]
         else:
             name = "rowchain_kernel" + ("<live>" if cls == "chain_live" else f"<{key}-row tiles>")
             pre = ["rowchain_kernel<0,1,0,1>"] if cls == "chain_live" else [f"rowchain_kernel<{key // 16},"]

@@ -302,6 +302,27 @@ typedef struct tbx_window_tile {
   int32_t drop_site[3], drop_step;
 } tbx_window_tile_t;
 int tbx_window_tile(const tbx_window_tile_t* args /* host */, void* stream);
+/* tbx_front: everything between the feature preparation and a block's first decoder layer as ONE launch (small launches: the
+ * closed loop at a few scenes), instead of tbx_window_tile -> tbx_knn_embed_multi_pe -> tbx_layer_tile one after the other:
+ *   win    the block's window PointNet (tbx_window_tile's arguments; no dropout);
+ *   layer  the block's FIRST PROJECTION as a tbx_layer_tile_t: x = win.out, n_rows = win.n_groups, no attn_out / linear1_image,
+ *          proj_n = 384 (q | k | v | W_k^T q into proj_out, + kv16_out), and its rider_* (or rider_rows = 0);
+ *   jobs   n_jobs (0..4) K-nearest searches in the relative-pose form (emb = NULL) + the pose-embedding job `pe` (or NULL), as
+ *          tbx_knn_embed_multi_pe takes them.
+ * The parts run in separate workgroups of the one launch; results are those of the three launches (the projection of a window's
+ * pooled row on the split-bf16 matrix path as tbx_layer_tile's). */
+struct tbx_knn_job;
+struct tbx_pose_embed_job;
+typedef struct tbx_front {
+  tbx_window_tile_t win;
+  tbx_layer_tile_t layer;
+  const struct tbx_knn_job* jobs; /* host array */
+  const struct tbx_pose_embed_job* pe; /* host pointer or NULL */
+  const float *freqs_xy, *freqs_yaw;  /* (only read by jobs with emb != NULL: unused here) */
+  int32_t n_jobs, pe_dim;
+} tbx_front_t;
+int tbx_front(const tbx_front_t* args /* host */, void* stream);
+
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
 int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups);

@@ -215,16 +215,18 @@ def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
     z = torch.randn(1, sizes[0], 16, generator=torch.Generator().manual_seed(4)).to(dev)
     valid = bd["gt/ag_valid"].any(-1)
     outs = {}
-    for fused in (False, True):
+    # ... and Schedule.front_fused (tbx_front: window PointNet + first projection + rider + K-nearest searches as ONE launch instead of
+    # three - the same device functions on the same operands): every combination of the two gives the same bits
+    for fused, front in ((False, False), (True, False), (False, True), (True, True)):
         for use_graph in (False, True):
-            wm.schedule = E.DEFAULT.replace(fused_tail=fused)
-            outs[fused, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
-                                                        step_end=30, use_graph=use_graph)
+            wm.schedule = E.DEFAULT.replace(fused_tail=fused, front_fused=front)
+            outs[fused, front, use_graph] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred,
+                                                               True, step_end=30, use_graph=use_graph)
             if fused and use_graph:  # the same (cached) engine again: restore() re-prepares the first step's windows
                 again = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True,
                                            step_end=30, use_graph=True)
-                assert torch.equal(again.pred_pose, outs[fused, use_graph].pred_pose)
-    ref = outs[False, False]
+                assert torch.equal(again.pred_pose, outs[fused, front, use_graph].pred_pose)
+    ref = outs[False, False, False]
     for k, o in outs.items():
         for name in ("pred_pose", "pred_valid", "pred_motion", "action_log_prob", "mask_teacher_forcing"):
             assert torch.equal(getattr(o, name), getattr(ref, name)), (k, name)

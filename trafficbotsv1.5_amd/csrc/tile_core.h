@@ -138,4 +138,126 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return v;
 }
 
+
+// ---- ONE row as the B operand (all 16 columns read the same row; column 0 = lanes with (lane & 15) == 0 is kept): bf16 planes of a
+// single row, hi at P + 2 k, lo `lo` bytes behind. Used where a workgroup owns one or two rows (csrc/front.hip; csrc/dec_mid.hip
+// has its own copies next to the kernel they were written for).
+namespace row1 {
+__device__ __forceinline__ void put4(char* P, int lo, int c, const f32x4 v) {
+  u32x2 hi, l;
+  split4(v, hi, l);
+  *(u32x2*)(P + c * 2) = hi;
+  *(u32x2*)(P + lo + c * 2) = l;
+}
+__device__ __forceinline__ void step(Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int lo, int st, int g4) {
+  const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
+  const bf16x8 xl = *(const bf16x8*)(P + lo + (st * 32 + g4 * 8) * 2);
+  acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
+  acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
+  acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 gemv4(const W& w, const char* P, int lo, int st0, int g4) {
+  Acc acc;
+  acc.zero();
+#pragma unroll
+  for (int st = 0; st < 4; ++st) step(acc, w.hi[st], w.lo[st], P, lo, st0 + st, g4);
+  return acc.sum();
+}
+// LayerNorm of the 128-float row `src` (LDS) by one wavefront, in rowchain.hip's ln_row order -> planes (lo 256 bytes behind)
+__device__ __forceinline__ void ln_planes(const float* src, char* P, int lane, float eps, const float* gamma, const float* beta) {
+  float v[2], gm[2], bt[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    v[q] = src[lane + 64 * q];
+    gm[q] = *(const TBX_GLOBAL float*)(gamma + lane + 64 * q);
+    bt[q] = *(const TBX_GLOBAL float*)(beta + lane + 64 * q);
+  }
+  const float mean = tbx::wave_sum(v[0] + v[1]) / 128.f;
+  const float d0 = v[0] - mean, d1 = v[1] - mean;
+  const float var = tbx::wave_sum(d0 * d0 + d1 * d1) / 128.f;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float y = (v[q] - mean) * rstd * gm[q] + bt[q];
+    const __bf16 h = (__bf16)y;
+    *(__bf16*)(P + 2 * (lane + 64 * q)) = h;
+    *(__bf16*)(P + 256 + 2 * (lane + 64 * q)) = (__bf16)(y - (float)h);
+  }
+}
+}  // namespace row1
+
+// the rider's tile (tbx_layer_tile_t.rider_*): four 128 -> 128 stages on 16 rows of its own, planes ping-pong Pa <-> Pb
+// (PL = the caller's plane geometry for 16 rows, K >= 128; X = 16 rows of XLD floats of LDS; Pa, Pb = plane pairs)
+template <class PL, int XLD>
+__device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, float* X, char* Pa, char* Pb) {
+  constexpr int ROWS = 16;
+  constexpr int PLANE = PL::PLANE;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)tile * ROWS;
+  const int nv = (t.rider_rows - row0) < ROWS ? (int)(t.rider_rows - row0) : ROWS;
+  const bool row_ok = j < nv;
+  const int64_t grow = row0 + (row_ok ? j : 0);
+  const int aoff = PL::lane_off(lane, 0);
+  const int c_out = 16 * wave + 4 * g;
+  W wb[2];
+  load_unit(wb[0], t.rider_images[0], wave, lane);
+  load_unit(wb[1], t.rider_images[1], wave, lane);
+  const f32x4 add = gld4(t.rider_add + grow * D + c_out);
+  const bool ok = *(const TBX_GLOBAL uint8_t*)(t.rider_valid + grow) != 0;
+  {
+    const int r = tid >> 5, c4 = tid & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t.rider_pose3 != nullptr) {  // the rows' pose embeddings (tbx_common.h pose_emb_write: the stand-alone kernel's values)
+      if (r < nv) {
+        const TBX_GLOBAL float* p3 = (const TBX_GLOBAL float*)t.rider_pose3 + (row0 + r) * 3;
+        tbx::pose_emb_write(X + r * XLD, D, p3[0], p3[1], p3[2], t.rider_freqs_xy, t.rider_freqs_yaw, c4, 32);
+      }
+      __syncthreads();
+      if (r < nv) v = *(const f32x4*)(X + r * XLD + c4 * 4);
+    } else if (r < nv) {
+      v = gld4(t.rider_in + (row0 + r) * D + c4 * 4);
+    }
+    planes_write4<PL>(Pa, r, c4 * 4, v);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
+    planes_write4<PL>(Pb, j, c_out, add + (acc.sum() + wb[0].bias));
+    load_unit(wb[0], t.rider_images[2], wave, lane);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
+    planes_write4<PL>(Pa, j, c_out, relu4(acc.sum() + wb[1].bias));
+    load_unit(wb[1], t.rider_images[3], wave, lane);
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
+    planes_write4<PL>(Pb, j, c_out, relu4(acc.sum() + wb[0].bias));
+  }
+  __syncthreads();
+  {
+    Acc acc;
+    acc.zero();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
+    f32x4 v = relu4(acc.sum() + wb[1].bias);
+    if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (row_ok) gst4(t.rider_out + grow * D + c_out, v);
+  }
+}
+
+
 }  // namespace tbx_tile

@@ -60,75 +60,6 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
   }
 }
 
-// the rider's tile (tbx_layer_tile_t.rider_*): four 128 -> 128 stages on 16 rows of its own, planes ping-pong Pa <-> Pb
-__device__ __forceinline__ void rider_tile(const tbx_layer_tile_t& t, int tile, float* X, char* Pa, char* Pb) {
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)tile * ROWS;
-  const int nv = (t.rider_rows - row0) < ROWS ? (int)(t.rider_rows - row0) : ROWS;
-  const bool row_ok = j < nv;
-  const int64_t grow = row0 + (row_ok ? j : 0);
-  const int aoff = PL::lane_off(lane, 0);
-  const int c_out = 16 * wave + 4 * g;
-  W wb[2];
-  load_unit(wb[0], t.rider_images[0], wave, lane);
-  load_unit(wb[1], t.rider_images[1], wave, lane);
-  const f32x4 add = gld4(t.rider_add + grow * D + c_out);
-  const bool ok = *(const TBX_GLOBAL uint8_t*)(t.rider_valid + grow) != 0;
-  {
-    const int r = tid >> 5, c4 = tid & 31;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t.rider_pose3 != nullptr) {  // the rows' pose embeddings (tbx_common.h pose_emb_write: the stand-alone kernel's values)
-      if (r < nv) {
-        const TBX_GLOBAL float* p3 = (const TBX_GLOBAL float*)t.rider_pose3 + (row0 + r) * 3;
-        tbx::pose_emb_write(X + r * XLD, D, p3[0], p3[1], p3[2], t.rider_freqs_xy, t.rider_freqs_yaw, c4, 32);
-      }
-      __syncthreads();
-      if (r < nv) v = *(const f32x4*)(X + r * XLD + c4 * 4);
-    } else if (r < nv) {
-      v = gld4(t.rider_in + (row0 + r) * D + c4 * 4);
-    }
-    planes_write4<PL>(Pa, r, c4 * 4, v);
-  }
-  __syncthreads();
-  {
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
-    planes_write4<PL>(Pb, j, c_out, add + (acc.sum() + wb[0].bias));
-    load_unit(wb[0], t.rider_images[2], wave, lane);
-  }
-  __syncthreads();
-  {
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
-    planes_write4<PL>(Pa, j, c_out, relu4(acc.sum() + wb[1].bias));
-    load_unit(wb[1], t.rider_images[3], wave, lane);
-  }
-  __syncthreads();
-  {
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[0].hi[s], wb[0].lo[s], Pa + aoff, s);
-    planes_write4<PL>(Pb, j, c_out, relu4(acc.sum() + wb[0].bias));
-  }
-  __syncthreads();
-  {
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, wb[1].hi[s], wb[1].lo[s], Pb + aoff, s);
-    f32x4 v = relu4(acc.sum() + wb[1].bias);
-    if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (row_ok) gst4(t.rider_out + grow * D + c_out, v);
-  }
-}
-
 template <bool ATTN, bool FFN, int PROJ>
 __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -140,7 +71,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   if constexpr (!ATTN && !FFN && PROJ == 2) {
     const int main_tiles = (int)((t.n_rows + ROWS - 1) / ROWS);
     if ((int)blockIdx.x >= main_tiles) {  // (only launched with rider_rows > 0)
-      rider_tile(t, (int)blockIdx.x - main_tiles, X, Pa, Pb);
+      rider_tile<PL, XLD>(t, (int)blockIdx.x - main_tiles, X, Pa, Pb);
       return;
     }
   }

@@ -115,6 +115,12 @@ class WindowTile(C.Structure):
                    ("drop_step", C.c_int32)])
 
 
+class Front(C.Structure):
+    """tbx_front_t (include/tbx_hip.h)."""
+    _fields_ = [("win", WindowTile), ("layer", LayerTile), ("jobs", C.c_void_p), ("pe", C.c_void_p), ("freqs_xy", C.c_void_p),
+                ("freqs_yaw", C.c_void_p), ("n_jobs", C.c_int32), ("pe_dim", C.c_int32)]
+
+
 class SimState(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("n_batch", "n_ag", "n_tl", "window", "n_step_gt", "n_step_tl_gt", "n_step_out", "n_node")]
@@ -228,6 +234,7 @@ def load():
     lib.tbx_layer_tile.argtypes = [C.POINTER(LayerTile), vp]
     lib.tbx_heads_tile.argtypes = [C.POINTER(HeadsTile), vp]
     lib.tbx_window_tile.argtypes = [C.POINTER(WindowTile), vp]
+    lib.tbx_front.argtypes = [C.POINTER(Front), vp]
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
     lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -245,7 +252,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -306,6 +313,24 @@ def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128, pose
     """Several `knn_embed` searches in one launch. jobs: dicts with knn_embed's arguments (src_pose, src_invalid, tgt_pose,
     tgt_invalid, k, dist_limit, tgt_batch_div, want_rel_pose, want_emb, out) -> list of (idx, invalid, rel_pose, emb).
     pose_embed_job = dict(pose3, freqs_xy, freqs_yaw, pe_dim, out[, col_off]): a `pose_embed` in the same launch (tbx_knn_embed_multi_pe)."""
+    outs, cj = _knn_jobs(jobs, pe_dim)
+    if pose_embed_job is not None:
+        pj = _pose_job(pose_embed_job)
+        _check(load().tbx_knn_embed_multi_pe(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, C.byref(pj), stream_ptr()),
+               "tbx_knn_embed_multi_pe")
+        return outs
+    _check(load().tbx_knn_embed_multi(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr()), "tbx_knn_embed_multi")
+    return outs
+
+
+def _pose_job(q) -> "PoseEmbedJob":
+    out = q["out"]
+    return PoseEmbedJob(_cptr(q["pose3"], torch.float32), _cptr(q["freqs_xy"]), _cptr(q["freqs_yaw"]), _ptr(out, torch.float32),
+                        q["pose3"].numel() // 3, int(q["pe_dim"]), out.stride(0), int(q.get("col_off", 0)), 0)
+
+
+def _knn_jobs(jobs, pe_dim: int = 128):
+    """-> ([(idx, invalid, rel_pose, emb)], tbx_knn_job_t array) for knn_embed_multi's job dicts."""
     outs, cj = [], (KnnJob * len(jobs))()
     for j, q in enumerate(jobs):
         n, S, _ = q["src_pose"].shape
@@ -323,15 +348,7 @@ def knn_embed_multi(jobs, freqs_xy=None, freqs_yaw=None, pe_dim: int = 128, pose
                        _cptr(q["tgt_invalid"], torch.uint8), _ptr(idx), _ptr(inv), _ptr(rel), _ptr(emb), n, S, T,
                        q.get("tgt_batch_div", 1), k, float(q["dist_limit"]))
         outs.append((idx, inv, rel, emb))
-    if pose_embed_job is not None:
-        q, out = pose_embed_job, pose_embed_job["out"]
-        pj = PoseEmbedJob(_cptr(q["pose3"], torch.float32), _cptr(q["freqs_xy"]), _cptr(q["freqs_yaw"]), _ptr(out, torch.float32),
-                          q["pose3"].numel() // 3, int(q["pe_dim"]), out.stride(0), int(q.get("col_off", 0)), 0)
-        _check(load().tbx_knn_embed_multi_pe(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, C.byref(pj), stream_ptr()),
-               "tbx_knn_embed_multi_pe")
-        return outs
-    _check(load().tbx_knn_embed_multi(cj, len(jobs), _cptr(freqs_xy), _cptr(freqs_yaw), pe_dim, stream_ptr()), "tbx_knn_embed_multi")
-    return outs
+    return outs, cj
 
 
 def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int = 0):
@@ -625,7 +642,7 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
-def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None):
+def _layer_tile_args(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None) -> "LayerTile":
     """tbx_layer_tile on the token rows x [rows, 128] (in place). Each part is None or a dict:
     attn = dict(out [rows, >= 640], row_no_valid u8 [rows], fold, out_proj (mfma32 images));
     ffn = dict(norm2 (w, b, eps), linear1, linear2 (images), src_invalid u8 [rows] | None);
@@ -679,6 +696,12 @@ def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=Non
         a.rider_valid, a.rider_rows = _cptr(rider["valid"], torch.uint8), r
         for i, im in enumerate(rider["images"]):
             a.rider_images[i] = _ptr(im, torch.float32)
+    return a
+
+
+def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None):
+    """tbx_layer_tile (arguments: _layer_tile_args)."""
+    a = _layer_tile_args(x, attn, ffn, proj, store_x, drop, rider)
     _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
 
 
@@ -696,7 +719,7 @@ def heads_tile(x, hd: dict):
     _check(load().tbx_heads_tile(C.byref(a), stream_ptr()), "tbx_heads_tile")
 
 
-def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None):
+def _window_tile_args(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None) -> "WindowTile":
     """tbx_window_tile. cat mode: attr [G * window, >= 4 cols], pe [G * window, 64]; add mode: pe = one feature row per window
     [G, 128], the input MLP is 128 wide. row_invalid u8 [G * window] -> out [G, 128]."""
     a = WindowTile()
@@ -714,7 +737,34 @@ def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, a
         a.drop_seed, a.drop_step = _ptr(drop["seed"], torch.int64), int(drop["step"])
         for i, st in enumerate(drop["sites"]):
             a.drop_site[i] = int(st)
+    return a
+
+
+def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None):
+    """tbx_window_tile (arguments: _window_tile_args)."""
+    a = _window_tile_args(attr, pe, row_invalid, in_images, pn_images, window, out, add_mode, drop)
     _check(load().tbx_window_tile(C.byref(a), stream_ptr()), "tbx_window_tile")
+
+
+def front(window: dict, proj: dict, rider=None, jobs=None, pose_embed_job=None):
+    """tbx_front: the window PointNet (window = window_tile's arguments as a dict), the first projection of its pooled rows (proj =
+    layer_tile's proj dict) + rider, and the K-nearest searches `jobs` (knn_embed_multi's job dicts, relative-pose form) + pose-
+    embedding job in ONE launch. -> the searches' [(idx, invalid, rel_pose, None)]."""
+    f = Front()
+    f.win = _window_tile_args(**window)
+    f.layer = _layer_tile_args(window["out"], proj=proj, store_x=False, rider=rider)
+    outs, keep = [], []
+    if jobs:
+        assert all(not q.get("want_emb", True) for q in jobs)
+        outs, cj = _knn_jobs(jobs)
+        keep.append(cj)
+        f.jobs, f.n_jobs, f.pe_dim = C.addressof(cj), len(jobs), 128
+        if pose_embed_job is not None:
+            pj = _pose_job(pose_embed_job)
+            keep.append(pj)
+            f.pe = C.addressof(pj)
+    _check(load().tbx_front(C.byref(f), stream_ptr()), "tbx_front")
+    return outs
 
 
 def padded_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:

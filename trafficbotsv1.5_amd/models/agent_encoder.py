@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import current as engine_current, drop_site, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok, tile_small_ok
+from ..engine import current as engine_current, drop_site, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -138,8 +138,19 @@ class AgentEncoder(nn.Module):
         ie = self.input_encoder
         wt_ = self._window_tile_images(prep["attr"].shape[1]) if (fp is None and W <= 16 and (tile_rows_ok(n * A, keyed_dropout=True) or tile_small_ok())) else None
         ch = Chain(hip.group_tile_rows(W, n * A), d + 4 if fp is None else FIRST_PROJ_LDW)
-        if wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch (training's stepping pass: with its keyed dropouts)
-            sites = [drop_site(m.dropout_p) for m in self.temp_encoder.mlp_layers]  # the ids emit_pointnet's DROPOUT stages would take
+        # tbx_front: window PointNet + first projection (+ rider) + the searches as ONE launch - when nothing of this step runs beside
+        # this stream (the navigation embedding rides, or is not wanted here) and no keyed dropout is asked for
+        sites0 = [drop_site(m.dropout_p) for m in self.temp_encoder.mlp_layers] if wt_ is not None else []
+        fused_front = (wt_ is not None and front_ok(n * A) and aux_stream is None and all(s_ is None for s_ in sites0)
+                       and (use_rider or aux_tail is None))
+        if fused_front:
+            if use_rider and rider.get("pose3") is None:
+                rider = navi_rider(prep, pose3=True)  # (the searches' pose-embedding job runs in the SAME launch: not an input of it)
+                fused_front = rider is not None
+        if fused_front:
+            ch = None
+        elif wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch (training's stepping pass: with its keyed dropouts)
+            sites = sites0  # the ids emit_pointnet's DROPOUT stages would take
             drop = None
             if any(s_ is not None for s_ in sites):
                 assert all(s_ is not None for s_ in sites)
@@ -171,7 +182,14 @@ class AgentEncoder(nn.Module):
                     dict(common, tgt_pose=tok_pose, tgt_invalid=tok_inv, k=self.n_tgt_knn_ag2ag, out=prep.get("_knn_aa")),
                     dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
                          out=prep.get("_knn_at"))]
-            if n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
+            if fused_front:
+                l0 = self.tf_ag2agmptl.layers[0]
+                fp = front_proj_buffers(n * A, dev)
+                (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.front(
+                    window=dict(attr=prep["attr"], pe=prep["pe"], row_invalid=prep["row_invalid"], in_images=wt_[0], pn_images=wt_[1], window=W, out=x),
+                    proj=tile_proj_part(l0.norm_src, l0.attn_src, fp["qkv"], True, fp["kv16"]), rider=rider if use_rider else None, jobs=jobs)
+                rider = None  # (ran in that launch)
+            elif n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
                 pj = dict(pose3=prep["navi_pose3"], freqs_xy=navi_rpe.pe_xy.freqs, freqs_yaw=navi_rpe.pe_yaw.freqs, pe_dim=navi_rpe.out_dim,
                           out=prep["navi_pe"]) if pe_rides else None
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs, pose_embed_job=pj)

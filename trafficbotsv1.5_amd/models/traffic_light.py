@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, kv_tables, run_block, tile_rows_ok, tile_small_ok
+from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -113,7 +113,14 @@ class TrafficLightEncoder(nn.Module):
         x = torch.empty(n * L, d, dtype=torch.float32, device=dev)
         fp = first_proj_buffers(n * L, dev, hip.group_tile_rows(W, n * L))  # small launches: layer 0's projections in the windows' launch too
         wt_ = self._window_tile_images() if (fp is None and W <= 16 and (tile_rows_ok(n * L) or tile_small_ok())) else None
-        if wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch ("add" mode: + the light's lane feature)
+        if wt_ is not None and front_ok(n * L):  # ... and the block's first projection of the pooled rows in the same launch (tbx_front)
+            l0 = self.tf_tl2tlmp.layers[0]
+            dec = self.tf_tl2tlmp.mode == "dec_cross_attn"
+            fp = front_proj_buffers(n * L, dev)
+            hip.front(window=dict(attr=attr, pe=t["tl_token_attr"].reshape(n * L, d), row_invalid=row_inv, in_images=wt_[0], pn_images=wt_[1],
+                                  window=W, out=x, add_mode=True),
+                      proj=tile_proj_part(l0.norm_src if dec else l0.norm1, l0.attn_src if dec else l0.attn, fp["qkv"], True, fp["kv16"]))
+        elif wt_ is not None:  # the whole temporal PointNet as one tbx_window_tile launch ("add" mode: + the light's lane feature)
             hip.window_tile(attr, t["tl_token_attr"].reshape(n * L, d), row_inv, wt_[0], wt_[1], W, x, add_mode=True)
         else:
             ch = Chain(hip.group_tile_rows(W, n * L), d + 4 if fp is None else FIRST_PROJ_LDW)
