@@ -190,6 +190,21 @@ typedef struct tbx_heads_tail {
   const struct tbx_agent_prep_args* next_prep;
 } tbx_heads_tail_t;
 
+/* The traffic lights' tail behind their LAST layer (tail_mfma32 launches; traffic_bots.py:188-199): for each of the 4 layers of the
+ * agents' block the K/V rows its tl cross-attention reads, k | v = in_proj_kv,l(norm_tgt,l(x)) -> kv_out[row, l * 256 ..] (fp32, or
+ * bfloat16 with kv_bf16), and the next-state logits clamp(mlp(x) masked, -3, 3) (traffic_light.py:249-286) -> logits_out [rows, n_state]. */
+typedef struct tbx_tl_tail {
+  const float* kv_images[4];             /* tbx_pack_weight_mfma32 (n 256, k 128): in_proj rows [128, 384) of layer l */
+  const float *norm_weight[4], *norm_bias[4];
+  float norm_eps[4];
+  void* kv_out;                          /* [rows, ld_kv] */
+  const float* mlp_images[3];            /* n 128 k 128, n 128 k 128, n 16 k 128 (the n_state outputs zero-padded to 16) */
+  const uint8_t* tl_invalid;             /* [rows] */
+  float* logits_out;                     /* [rows, n_state] */
+  int32_t ld_kv, kv_bf16, n_state, pad_;
+  float clamp_lo, clamp_hi;
+} tbx_tl_tail_t;
+
 typedef struct tbx_dec_layer {
   tbx_dec_mid_t mid;
   const float *out_proj2_image, *linear1_image, *linear2_image, *next_in_proj_image, *next_qfold_image;
@@ -203,6 +218,7 @@ typedef struct tbx_dec_layer {
   int32_t tail_mfma32; /* != 0: EVERY image of the call (mid.fold_self / out_proj / q / qfold / fold_cross, out_proj2 / linear1 / linear2 /
                         * next_in_proj / next_qfold, heads->images) is a tbx_pack_weight_mfma32 image and every LINEAR stage runs on
                         * the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32 fma chains */
+  const tbx_tl_tail_t* lights; /* host pointer or NULL; only with qkv_out == NULL, heads == NULL and tail_mfma32 */
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
 

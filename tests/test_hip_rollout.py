@@ -238,6 +238,35 @@ def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
             assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_lights_tail_in_the_last_layers_launch_equals_the_chain(tb, bf16):
+    """tbx_tl_tail_t: the lights' tail - the K/V rows the agents' four layers read and the next-state logits (traffic_bots.py:188-199,
+    traffic_light.py:249-286) - inside their last decoder layer's launch on the split-bf16 matrix path, against the exact-fp32 small-
+    launch schedule (the tail as a row chain of its own): K/V tables to 2e-4 of their largest entry (bf16 tables: one bf16 ulp on
+    top), logits to 1e-3, invalid lights' logits exactly 0, and really a different arithmetic."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, (64, 1024, 128), 32)
+    E = import_module("trafficbots_amd.engine")
+    TL = import_module("trafficbots_amd.models.traffic_light")
+    outs = {}
+    for name, sched in (("exact", E.DEFAULT.replace(dec_tail_mfma=False, tile_small=False, kv_bf16=bf16)), ("mf", E.DEFAULT.replace(kv_bf16=bf16))):
+        with E.use(sched):
+            mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+            hist = TL.TrafficLightEncoder.states_to_hist(bd["gt/tl_state"][:, :, :5], wm.model.tl_encoder.temp_window_size).to(dev)
+            out = dict(tl_logits=torch.full((hist.shape[0] * hist.shape[1], 5), 9.0, device=dev))
+            kv = wm.model.tl_policy(hist, tl, out)
+            torch.cuda.synchronize()
+            outs[name] = (kv.float().clone(), out["tl_logits"].clone(), tl["tl_token_invalid_u8"].reshape(-1).bool().clone())
+    (kv0, lg0, inv), (kv1, lg1, _) = outs["exact"], outs["mf"]
+    scale = float(kv0.abs().max())
+    err = float((kv1 - kv0).abs().max())
+    assert 0.0 < err <= (2e-4 if not bf16 else 1e-2) * scale, (err, scale)
+    assert float((lg1 - lg0).abs().max()) <= 1e-3 and float(lg0.abs().max()) > 0.1
+    if bool(inv.any()):
+        assert float(lg1[inv].abs().max()) == 0.0 and float(lg0[inv].abs().max()) == 0.0
+    assert float(lg1.abs().max()) <= 3.0
+
+
 def test_hoisted_rollout_constants_are_bit_identical(tb):
     """The engine embeds the latent and the destination feature once per rollout instead of in every step's heads chain
     (TrafficBots.rollout_constants): same kernels on the same inputs, so the rollout must not change by a bit."""

@@ -69,6 +69,8 @@ struct MidArgs {
   int fused_tail, sim_parts;
   tbx_sim_state_t sim;
   tbx_agent_prep_args_t prep;
+  // the lights' tail (tbx_tl_tail_t): tl.kv_out != NULL
+  tbx_tl_tail_t tl;
 };
 
 #ifdef TBX_STAGE_CLOCK
@@ -522,7 +524,8 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
 // profiles/r03_dec_layer_phase_clock.txt.
 // Unit sequence: 0 fold_self, 1 out_proj, 2 q, 3 qfold, 4 fold_cross, 5 out_proj2, 6..9 linear1, 10..13 linear2, then either
 // 14..16 next in_proj (q, k, v), 17 next qfold, or the heads: 14..17 add_navi (k-chunk x, k-chunk embedding, layer 2, layer 3),
-// 18..21 add_latent, 22..24 / 25..27 / 28 the action head's three stacked stages (csrc/tile_heads.hip's entries), or nothing.
+// 18..21 add_latent, 22..24 / 25..27 / 28 the action head's three stacked stages (csrc/tile_heads.hip's entries), or the lights' tail:
+// 14..21 k, v of the agents' 4 layers, 22..24 the next-state predictor, or nothing.
 namespace mf {
 using tbx_tile::Acc;
 using tbx_tile::bf16x4;
@@ -548,6 +551,10 @@ __device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wa
   else if (a.qkv_out != nullptr) {
     if constexpr (N <= 16) load_unit(w, a.wqkv, 8 * (N - 14) + wave, lane);
     else if constexpr (N == 17) load_unit(w, a.wqt, wave, lane);
+  } else if (a.tl.kv_out != nullptr) {  // 14..21: k, v of the agents' 4 layers; 22..24: the state predictor
+    if constexpr (N >= 14 && N <= 21) load_unit(w, a.tl.kv_images[(N - 14) >> 1], 8 * ((N - 14) & 1) + wave, lane);
+    else if constexpr (N == 22 || N == 23) load_unit(w, a.tl.mlp_images[N - 22], wave, lane);
+    else if constexpr (N == 24) load_unit(w, a.tl.mlp_images[2], 0, lane);
   } else if (heads) {
     if constexpr (N == 14 || N == 18) load_unit(w, a.hw[N == 14 ? 0 : 3], wave, lane);
     else if constexpr (N == 15 || N == 19) load_unit(w, a.hw[N == 15 ? 0 : 3], 8 + wave, lane);
@@ -992,6 +999,71 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     MID_CLK(15);
     return;
   }
+  if (a.tl.kv_out != nullptr) {
+    // ================================================================ the lights' tail (traffic_bots.py:188-199): the K/V rows the agents'
+    // 4 layers read (emit_kv_tables: LayerNorm_l + in_proj_kv,l) and the next-state logits (traffic_light.py:249-286)
+    __shared__ __attribute__((aligned(16))) char Pl[4][2 * LO128];
+    __syncthreads();  // xs complete
+    if (wave < 4) {   // the four layers' LayerNorms at once, a wave each
+      float g[2], bt[2];
+      g[0] = a.tl.norm_weight[wave][lane], g[1] = a.tl.norm_weight[wave][64 + lane];
+      bt[0] = a.tl.norm_bias[wave][lane], bt[1] = a.tl.norm_bias[wave][64 + lane];
+      ln_planes(xs, Pl[wave], lane, a.tl.norm_eps[wave], g, bt);
+    }
+    if (col0) put4(Ph, LO128, c_out, *(const f32x4*)(xs + c_out));  // (the predictor reads x itself; this lane wrote these 4 channels)
+    __syncthreads();
+    const int64_t kv_row = (int64_t)row * a.tl.ld_kv;
+#define TBX_MF_TLKV(N)                                                                                    \
+  do {                                                                                                    \
+    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                                              \
+    const W& w = wb[(N) % 3];                                                                             \
+    const f32x4 y = gemv4(w, Pl[((N) - 14) >> 1], LO128, 0, g4) + w.bias;                                 \
+    if (col0) {                                                                                           \
+      const int64_t o = kv_row + (((N) - 14) >> 1) * 2 * D + (((N) - 14) & 1) * D + c_out;                \
+      if (a.tl.kv_bf16) {                                                                                 \
+        const bf16x4 h16 = __builtin_convertvector(y, bf16x4);                                            \
+        *(TBX_GLOBAL u32x2*)((uint16_t*)a.tl.kv_out + o) = __builtin_bit_cast(u32x2, h16);                \
+      } else {                                                                                            \
+        *(TBX_GLOBAL f32x4*)((float*)a.tl.kv_out + o) = y;                                                \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+    TBX_MF_TLKV(14);
+    TBX_MF_TLKV(15);
+    TBX_MF_TLKV(16);
+    TBX_MF_TLKV(17);
+    TBX_MF_TLKV(18);
+    TBX_MF_TLKV(19);
+    TBX_MF_TLKV(20);
+    TBX_MF_TLKV(21);
+#undef TBX_MF_TLKV
+    {  // 22, 23: the predictor's hidden layers (Ph -> Pq -> Ph)
+      issue<24>(wb[24 % 3], a, heads, wave, lane);
+      const W& w = wb[22 % 3];
+      const f32x4 h1 = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);
+      if (col0) put4(Pq, LO128, c_out, h1);
+    }
+    __syncthreads();
+    {
+      const W& w = wb[23 % 3];
+      const f32x4 h2 = tbx_tile::relu4(gemv4(w, Pq, LO128, 0, g4) + w.bias);
+      if (col0) put4(Ph, LO128, c_out, h2);
+    }
+    __syncthreads();
+    if (wave == 0) {  // 24: n_state <= 16 logits (zero-padded tile 0): masked, clamped
+      const W& w = wb[24 % 3];
+      const f32x4 o = gemv4(w, Ph, LO128, 0, g4) + w.bias;
+      const bool bad = a.tl.tl_invalid[row] != 0;
+      if (col0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * g4 + r;
+          if (c < a.tl.n_state) a.tl.logits_out[(int64_t)row * a.tl.n_state + c] = fminf(fmaxf(bad ? 0.f : o[r], a.tl.clamp_lo), a.tl.clamp_hi);
+        }
+      }
+    }
+    return;
+  }
   if (!heads) return;
   // ================================================================ the agents' heads (traffic_bots.py:206-221; csrc/tile_heads.hip's
   // stages on one row): Pv = [x | navi_emb | latent_emb] planes, the adders' hidden rows in Ph / Pq, the action head's in Pu / Pv
@@ -1157,6 +1229,7 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   a.fused_tail = 0, a.sim_parts = 0;
   memset(&a.sim, 0, sizeof(a.sim));
   memset(&a.prep, 0, sizeof(a.prep));
+  memset(&a.tl, 0, sizeof(a.tl));
   if (t) {
     a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
     a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
@@ -1182,6 +1255,17 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
       }
     }
     a.src_invalid = t->src_invalid, a.qkv_out = t->qkv_out, a.ln2_eps = t->norm2_eps, a.ln3_eps = t->next_norm_eps, a.ld_qkv_out = t->ld_qkv_out;
+    if (t->lights != nullptr) {
+      const tbx_tl_tail_t& L = *t->lights;
+      if (!t->tail_mfma32 || t->qkv_out != nullptr || t->heads != nullptr) return TBX_ERR_ARG;
+      for (int i = 0; i < 4; ++i)
+        if (!L.kv_images[i] || !L.norm_weight[i] || !L.norm_bias[i] || (((uintptr_t)L.kv_images[i]) & 15)) return TBX_ERR_ARG;
+      for (int i = 0; i < 3; ++i)
+        if (!L.mlp_images[i] || (((uintptr_t)L.mlp_images[i]) & 15)) return TBX_ERR_ARG;
+      if (!L.kv_out || !L.tl_invalid || !L.logits_out || L.ld_kv < 8 * D || (L.ld_kv % 4) || L.n_state <= 0 || L.n_state > 16) return TBX_ERR_ARG;
+      if (((uintptr_t)L.kv_out) & 15) return TBX_ERR_ALIGN;
+      a.tl = L;
+    }
   }
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float);
   static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float) <= 160 * 1024, "LDS budget");

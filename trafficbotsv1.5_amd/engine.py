@@ -434,7 +434,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
               cross: Optional[Callable[[int], Sequence[Seg]]] = None, tail: Optional[Callable[[Chain], None]] = None,
               tile_rows: int = 16, pose_rpe=None, drop: Optional[dict] = None, freqs=None, join_stream=None,
               heads_tail: Optional[dict] = None, first_proj: Optional[dict] = None, join_late: bool = False,
-              after_first_proj=None, proj_rider=None) -> bool:
+              after_first_proj=None, proj_rider=None, tail_mf=None) -> bool:
     """Runs a TransformerBlockRPE (modes enc_self_attn / dec_cross_attn, transformer_rpe.py:48-135,207-245) over the
     token matrix x [n*S, 128] IN PLACE (join_stream: a stream the K-nearest sets are being produced on, waited for right before the
     first attention call). `cross(l)` yields the cross-attention segments of layer l; `tail(chain)`
@@ -523,6 +523,13 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             if last and heads_tail is not None and current().heads_tail:
                 tl_["heads"] = heads_tail  # the agents' heads in this launch too (tbx_heads_tail_t)
                 heads_done = True
+            tail_in_launch = False
+            if last and tmf and tail_mf is not None and "heads" not in tl_:
+                # the caller's tail as tbx_tl_tail_t fields (a callable: built only where it is used; None: not of that shape)
+                lights = tail_mf() if callable(tail_mf) else tail_mf
+                if lights is not None:
+                    tl_["lights"] = lights
+                    tail_in_launch = True
             if not last:
                 an, nn_ = first_attn(l + 1), first_norm(l + 1)
                 tl_.update(next_in_proj=hip.packed_weight(an.in_proj_weight[:3 * D], an.in_proj_bias[:3 * D], **tkw),
@@ -538,7 +545,7 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             if not last:
                 qkv, qkv_alt = qkv_alt, qkv  # the next layer's q | k | v | qt went to the other buffer (this layer's K/V rows were still being read)
                 kv16, kv16_alt = kv16_alt, kv16
-            elif tail is not None:  # the caller's row-local stages on the finished rows: a short chain of their own
+            elif tail is not None and not tail_in_launch:  # the caller's row-local stages on the finished rows: a short chain of their own
                 ch = layer_chain(rows)
                 ch.load(x, BUF1, 0, n=D)
                 tail(ch)

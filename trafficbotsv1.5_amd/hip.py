@@ -83,7 +83,16 @@ class DecLayer(C.Structure):
     _fields_ = ([("mid", DecMid)]
                 + [(n, C.c_void_p) for n in ("out_proj2_image", "linear1_image", "linear2_image", "next_in_proj_image", "next_qfold_image",
                                              "norm2_weight", "norm2_bias", "next_norm_weight", "next_norm_bias", "src_invalid", "qkv_out", "kv16_out", "heads")]
-                + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("tail_mfma32", C.c_int32)])
+                + [("norm2_eps", C.c_float), ("next_norm_eps", C.c_float), ("ld_qkv_out", C.c_int32), ("tail_mfma32", C.c_int32),
+                   ("lights", C.c_void_p)])
+
+
+class TlTail(C.Structure):
+    """tbx_tl_tail_t (include/tbx_hip.h)."""
+    _fields_ = [("kv_images", C.c_void_p * 4), ("norm_weight", C.c_void_p * 4), ("norm_bias", C.c_void_p * 4), ("norm_eps", C.c_float * 4),
+                ("kv_out", C.c_void_p), ("mlp_images", C.c_void_p * 3), ("tl_invalid", C.c_void_p), ("logits_out", C.c_void_p),
+                ("ld_kv", C.c_int32), ("kv_bf16", C.c_int32), ("n_state", C.c_int32), ("pad_", C.c_int32),
+                ("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
 
 
 class LayerTile(C.Structure):
@@ -639,6 +648,24 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
             keep.sim_state, keep.sim_parts = C.addressof(hd["sim_state"]), int(hd["sim_parts"])
             keep.next_prep = C.addressof(hd["next_prep"])
         t.heads = C.addressof(keep)
+    lt_, keep_l = tail.get("lights"), None
+    if lt_ is not None:  # dict(kv_images[4], norms [(w, b, eps)] * 4, kv_out, mlp_images[3], tl_invalid, logits_out, clamp)
+        keep_l = TlTail()
+        for i in range(4):
+            keep_l.kv_images[i] = _ptr(lt_["kv_images"][i], torch.float32)
+            w_, b_, e_ = lt_["norms"][i]
+            keep_l.norm_weight[i], keep_l.norm_bias[i], keep_l.norm_eps[i] = _ptr(w_, torch.float32), _ptr(b_, torch.float32), float(e_)
+        for i in range(3):
+            keep_l.mlp_images[i] = _ptr(lt_["mlp_images"][i], torch.float32)
+        kvo = lt_["kv_out"]
+        assert kvo.dim() == 2 and kvo.stride(1) == 1 and kvo.shape[0] == x.shape[0]
+        keep_l.kv_out, keep_l.ld_kv, keep_l.kv_bf16 = kvo.data_ptr(), kvo.stride(0), int(kvo.dtype == torch.bfloat16)
+        assert kvo.dtype in (torch.bfloat16, torch.float32)
+        lo = lt_["logits_out"]
+        assert lo.is_contiguous() and lo.shape[0] == x.shape[0]
+        keep_l.tl_invalid, keep_l.logits_out, keep_l.n_state = _cptr(lt_["tl_invalid"], torch.uint8), _ptr(lo, torch.float32), lo.shape[1]
+        keep_l.clamp_lo, keep_l.clamp_hi = (float(v) for v in lt_["clamp"])
+        t.lights = C.addressof(keep_l)
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 

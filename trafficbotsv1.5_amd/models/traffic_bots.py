@@ -89,7 +89,23 @@ class TrafficBots(nn.Module):
             emit_kv_tables(ch, self.ag_encoder.tl_kv_layers(), tl_kv)
             self.tl_state_predictor.emit(ch, tl_inv, out["tl_logits"])
 
-        out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail, prepared=prepared)  # prepared: TlEncoder.encode
+        def tl_tail_mf():
+            """`tl_tail` as tbx_tl_tail_t fields (the last layer's launch on the matrix path runs it), or None."""
+            layers = self.ag_encoder.tl_kv_layers()
+            lins = [t[0] for t in self.tl_state_predictor.mlp.linear_layers()]
+            acts = [t[2] for t in self.tl_state_predictor.mlp.linear_layers()]
+            if (len(layers) != 4 or len(lins) != 3 or acts != [True, True, False] or self.tl_state_predictor.tl_state_dim > 16
+                    or any(tuple(l.weight.shape) != (d, d) for l in lins[:2]) or lins[2].weight.shape[1] != d
+                    or any(ln is not None for _, ln, _ in self.tl_state_predictor.mlp.linear_layers())):
+                return None
+            pw = lambda w, b: hip.packed_weight(w, b, mfma32=True)
+            w3, b3 = hip.stacked_linear([lins[2]], pad_out_to=16)
+            return dict(kv_images=[pw(at.in_proj_weight[d:], at.in_proj_bias[d:]) for _, at in layers],
+                        norms=[(nm.weight, nm.bias, nm.eps) for nm, _ in layers], kv_out=tl_kv,
+                        mlp_images=[pw(lins[0].weight, lins[0].bias), pw(lins[1].weight, lins[1].bias), pw(w3, b3)], tl_invalid=tl_inv,
+                        logits_out=out["tl_logits"], clamp=(-3.0, 3.0))
+
+        out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail, prepared=prepared, tail_mf=tl_tail_mf)  # prepared: TlEncoder.encode
         return tl_kv
 
     NAVI_AHEAD = os.environ.get("TBX_NAVI_AHEAD", "1") != "0"

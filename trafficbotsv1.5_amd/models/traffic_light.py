@@ -98,7 +98,8 @@ class TrafficLightEncoder(nn.Module):
         ld_attr = 16 if 5 + self.temp_window_size <= 16 else 32
         return torch.empty(rows, ld_attr, dtype=torch.float32, device=dev), torch.empty(rows, dtype=torch.uint8, device=dev)
 
-    def encode(self, hist_tl: Tensor, t: Dict[str, Tensor], tail: Optional[Callable[[Chain], None]] = None, prepared=None) -> Tensor:
+    def encode(self, hist_tl: Tensor, t: Dict[str, Tensor], tail: Optional[Callable[[Chain], None]] = None, prepared=None,
+               tail_mf=None) -> Tensor:
         """hist_tl [n,L,W] u8 state masks (0xFF = step not yet seen), oldest first -> tl_token_feature [n*L, d].
         prepared = the prep_buffers() already filled for this window (by the launch that updated the lights, hip.sim_step(tl_prep=))."""
         n, L, W = hist_tl.shape
@@ -134,7 +135,8 @@ class TrafficLightEncoder(nn.Module):
         knn = SelfKnn(t["knn_idx_tl2tl"], t["knn_invalid_tl2tl"], t["rpe_tl2tl"], rel=t["rel_tl2tl"])
         run_block(self.tf_tl2tlmp, x, t["tl_token_invalid_u8"], n, L, knn,
                   cross=lambda l: [Seg(kv, l * 2 * D, l * 2 * D + D, M, t["knn_idx_tl2mp"], t["knn_invalid_tl2mp"],
-                                       t["rpe_tl2mp"], div, rel=t["rel_tl2mp"])], tail=tail, pose_rpe=self.pose_rpe, first_proj=fp)
+                                       t["rpe_tl2mp"], div, rel=t["rel_tl2mp"])], tail=tail, pose_rpe=self.pose_rpe, first_proj=fp,
+                  tail_mf=tail_mf)  # (tail_mf: the same tail as tbx_tl_tail_t fields, for the last layer's one-launch form)
         return x
 
     @staticmethod
