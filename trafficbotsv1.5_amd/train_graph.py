@@ -636,18 +636,31 @@ def _agent_policy_engine(model, hv, hp, hm, ag_attr6, ag_type, z, z_valid, dest,
     from . import engine
 
     n, A, _ = hv.shape
-    tl_feat, ids = tl_pre
+    tl_feat, ids = tl_pre[0], tl_pre[1]
     u8 = torch.uint8
     out = dict(action_mean=torch.empty(n * A, 2, dtype=torch.float32, device=hp.device))
-    tl_kv = engine.kv_tables(tl_feat.contiguous(), model.ag_encoder.tl_kv_layers())
+    # (tl_pre[2]: this step's K/V tables, made for all steps of the piece in one launch - the same row-local stages)
+    tl_kv = tl_pre[2] if len(tl_pre) > 2 and tl_pre[2] is not None else engine.kv_tables(tl_feat.contiguous(), model.ag_encoder.tl_kv_layers())
     ctx = None
     if training and _DROP is not None:
         ctx = dict(seed=_DROP["seed"], site=ids[0], call=ids[1], step=_DROP["t0"])
+    # per-rollout constants in the form the engine takes them: converted once per pass, not in each of its 90 steps (the pass's
+    # map dict lives as long as the pass: ~8 small launches per step less)
+    sc = mp.setdefault("_step_consts", {})
+
+    def const(name, t, fn):
+        k = (name, t.data_ptr(), tuple(t.shape))
+        if k not in sc:
+            sc[k] = fn(t)
+        return sc[k]
+
+    type_idx = const("type", ag_type, lambda t: t.to(u8).argmax(-1).to(u8).contiguous())
+    zz = const("z", z, lambda t: t.reshape(n * A, -1).float().contiguous())
+    zi = const("zi", z_valid, lambda t: (~t).reshape(-1).to(u8).contiguous())
+    dd = const("dest", dest, lambda t: t.contiguous())
     engine.DROP_CTX = ctx
     try:
-        model.agent_policy(hv, hp, hm, ag_attr6, ag_type.to(u8).argmax(-1).to(u8).contiguous(), z.reshape(n * A, -1).float().contiguous(),
-                           (~z_valid).reshape(-1).to(u8).contiguous(), dest.contiguous(), navi_valid.to(u8).contiguous(), tl_tokens, mp,
-                           tl_kv, out)
+        model.agent_policy(hv, hp, hm, ag_attr6, type_idx, zz, zi, dd, navi_valid.to(u8).contiguous(), tl_tokens, mp, tl_kv, out)
     finally:
         engine.DROP_CTX = None
     if ctx is not None:
@@ -672,7 +685,7 @@ def policy_step(model, hist, ag_attr6, ag_type, ag_valid, ag_pose, z, z_valid, d
     if tl_pre is None:
         tl_feat = tl_encoder(model.tl_encoder, ht, tl_tokens, training)
     else:
-        tl_feat = tl_pre[0]
+        tl_feat = tl_pre[0].reshape(-1, d)
         if _DROP is not None:  # the agents' dropout sites keep the ids they have when the light encoder runs in place
             _DROP["site"], _DROP["call"] = tl_pre[1]
     feat, _ = agent_encoder(model.ag_encoder, hv, hp, hm, ag_attr6, mp, tl_tokens["tl_token_invalid_u8"], tl_tokens["tl_token_pose"],
@@ -1099,17 +1112,31 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
     with torch.no_grad():  # pass 1: own K/V caches (its graph-less tables must not reach the differentiated pass)
         mp1, tl1 = dict(mp, _kv_cache={}), dict(tl_tokens, _kv_cache={})
 
-        def tl_of(step):  # the light tokens of `step` from the piece that holds it (joined on first use)
+        kv_pieces: Dict[int, Tensor] = {}
+
+        def tl_of(step):  # the light tokens of `step` from the piece that holds it (joined on first use) + their K/V tables
             for i in range(len(tl_chunks) - 1, -1, -1):
                 c0, f, ev = tl_chunks[i]
                 if step - 1 >= c0:
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                         tl_chunks[i] = (c0, f, None)
-                    return f[:, step - 1 - c0].reshape(n * L, -1)
+                    if i not in kv_pieces and NOGRAD_CHAINS and f.is_cuda and not torch.is_grad_enabled():
+                        # the K/V rows the agents' layers read, for ALL steps of the piece in one launch (time-major: a step's
+                        # tables are then a contiguous [n * L, 1024] block) instead of one launch per step (90 x 37 us)
+                        from . import engine
+
+                        ft = f.permute(1, 0, 2, 3).contiguous()  # [Tc, n, L, d]
+                        kv_pieces[i] = engine.kv_tables(ft.view(-1, ft.shape[-1]), model.ag_encoder.tl_kv_layers()).view(ft.shape[0], n * L, -1)
+                    kv = kv_pieces[i][step - 1 - c0] if i in kv_pieces else None
+                    # (with the tables at hand the engine path does not read the features: no per-step gather of them)
+                    return (f[:, step - 1 - c0].reshape(n * L, -1) if kv is None else f[:, step - 1 - c0]), kv
 
         def policy1(step, hist, valid_, pose_, navi_valid_):
-            pre = None if tl_chunks is None else (tl_of(step), ids)
+            pre = None
+            if tl_chunks is not None:
+                tf_, kv_ = tl_of(step)
+                pre = (tf_, ids, kv_)
             with _DropScope(n, 1, step, restart=_POLICY_SITE0):
                 return policy_step(model, hist, ag_attr6, ag_type, valid_, pose_, z.detach(), z_valid, dest, navi_valid_, tl1, mp1,
                                    model.training, tl_pre=pre, want_logits=not fused)
@@ -1118,7 +1145,9 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
             ht_steps = ht_all.view(n, T, L, W)
             for step in range(1, T + 1):
                 hv, hp, hm, valid_, pose_, navi_valid_ = chain.before(step)
-                mean1, _ = policy1(step, (hv, hp, hm, ht_steps[:, step - 1].contiguous()), valid_, pose_, navi_valid_)
+                # (the light windows are only read when the lights are encoded in the step: not with their tokens made ahead)
+                mean1, _ = policy1(step, (hv, hp, hm, ht_steps[:, step - 1] if tl_chunks is not None else ht_steps[:, step - 1].contiguous()),
+                                   valid_, pose_, navi_valid_)
                 chain.step(step, mean1)
             inputs = chain.windows()
         else:
