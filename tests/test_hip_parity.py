@@ -854,6 +854,84 @@ def test_window_tile_equals_grouped_chain(tb, hip, dev, G, W):
     assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
 
 
+@pytest.mark.parametrize("G,W,add,rider_rows,knn", [(64, 11, False, 64, True), (37, 11, False, 21, True), (128, 11, True, 0, False), (5, 7, False, 0, True)])
+def test_front_equals_its_three_launches(tb, hip, dev, G, W, add, rider_rows, knn):
+    """tbx_front - window PointNet + the first projection of its pooled rows (+ rider) + K-nearest searches and pose-embedding job in
+    ONE launch (csrc/front.hip) - against tbx_window_tile -> tbx_layer_tile (rider) and tbx_knn_embed_multi_pe as launches of their
+    own: the same device functions on the same operands, so pooled rows, q | k | v | W_k^T q rows, rider rows, K-nearest indices /
+    masks / relative poses and the embedded poses are bit-identical; odd window counts (a ragged last workgroup), a rider whose row
+    count differs from the windows', the lights' "add" mode without searches, a launch smaller than one rider tile."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    wm = _default_model(tb, dev)
+    enc = wm.model.tl_encoder if add else wm.model.ag_encoder
+    g = torch.Generator().manual_seed(G * 3 + W)
+    D = 128
+    if add:
+        attr = torch.randn(G * W, 16, generator=g).to(dev)
+        pe = torch.randn(G, D, generator=g).to(dev)
+        imgs = enc._window_tile_images()
+    else:
+        attr = torch.zeros(G * W, 32)
+        attr[:, :20] = torch.randn(G * W, 20, generator=g)
+        attr, pe = attr.to(dev), torch.randn(G * W, 64, generator=g).to(dev)
+        imgs = enc._window_tile_images(32)
+    inv = torch.rand(G, W, generator=g) < 0.3
+    inv[min(3, G - 1)] = True
+    inv8 = inv.reshape(-1).to(torch.uint8).to(dev)
+    blk = M.TransformerBlockRPE(n_layer=1, mode="enc_self_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.0,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 6)
+    l0 = blk.to(dev).eval().layers[0]
+    rider = lambda out: None
+    if rider_rows:
+        Ws = [(torch.randn(D, D, generator=g) / 8).to(dev) for _ in range(4)]
+        bs = [torch.randn(D, generator=g).to(dev) for _ in range(4)]
+        p3 = torch.cat([(torch.rand(rider_rows, 2, generator=g) - 0.5) * 300, (torch.rand(rider_rows, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
+        fxy, fyw = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
+        add_rows = torch.randn(rider_rows, D, generator=g).to(dev)
+        valid = (torch.rand(rider_rows, generator=g) < 0.7).to(torch.uint8).to(dev)
+        rider = lambda out: dict(pose3=p3, freqs=(fxy, fyw), add=add_rows, out=out, valid=valid,
+                                 images=[hip.packed_weight(w, b, mfma32=True) for w, b in zip(Ws, bs)])
+    jobs = lambda: None
+    if knn:
+        S, T = G, 200
+        sp = torch.cat([(torch.rand(1, S, 2, generator=g) - 0.5) * 200, (torch.rand(1, S, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
+        tp = torch.cat([(torch.rand(1, T, 2, generator=g) - 0.5) * 200, (torch.rand(1, T, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
+        si, ti = (torch.rand(1, S, generator=g) < 0.1).to(torch.uint8).to(dev), (torch.rand(1, T, generator=g) < 0.2).to(torch.uint8).to(dev)
+        common = dict(src_pose=sp, src_invalid=si, dist_limit=150.0, want_rel_pose=True, want_emb=False)
+        jobs = lambda: [dict(common, tgt_pose=tp, tgt_invalid=ti, k=16), dict(common, tgt_pose=sp, tgt_invalid=si, k=min(4, S - 1))]
+    pose_job = lambda out: None
+    if knn and rider_rows == 0:  # (the searches' pose-embedding job: not together with a rider that embeds poses itself)
+        q3 = torch.randn(G, 3, generator=g).to(dev)
+        fxy2, fyw2 = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
+        pose_job = lambda out: dict(pose3=q3, freqs_xy=fxy2, freqs_yaw=fyw2, pe_dim=128, out=out)
+    res = {}
+    for fused in (False, True):
+        x = torch.full((G, D), 7.0, device=dev)
+        qkv = torch.zeros(G, eng.QKV_LD, device=dev)
+        r_out = torch.full((max(rider_rows, 1), D), 5.0, device=dev)
+        pj_out = torch.full((G, D), 3.0, device=dev)
+        with eng.use(eng.DEFAULT):
+            win = dict(attr=attr, pe=pe, row_invalid=inv8, in_images=imgs[0], pn_images=imgs[1], window=W, out=x, add_mode=add)
+            proj = eng.tile_proj_part(l0.norm1, l0.attn, qkv, True, None)
+            if fused:
+                outs = hip.front(window=win, proj=proj, rider=rider(r_out), jobs=jobs(), pose_embed_job=pose_job(pj_out))
+            else:
+                hip.window_tile(**win)
+                hip.layer_tile(x, proj=proj, store_x=False, rider=rider(r_out))
+                outs = hip.knn_embed_multi(jobs(), pose_embed_job=pose_job(pj_out)) if knn else []
+        torch.cuda.synchronize()
+        res[fused] = (x, qkv, r_out, pj_out, outs)
+    a, b = res[False], res[True]
+    assert float(a[0].abs().max()) > 1e-2 and float(a[0][min(3, G - 1)].abs().max()) == 0.0  # (a window without a valid row)
+    for i, name in enumerate(("pooled rows", "q | k | v | qt", "rider rows", "embedded poses")):
+        assert torch.equal(a[i], b[i]), name
+    assert len(a[4]) == len(b[4])
+    for (i0, m0, r0, _), (i1, m1, r1, _) in zip(a[4], b[4]):
+        assert torch.equal(i0, i1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+
+
 @pytest.mark.parametrize("G,W", [(300, 11), (128, 11), (33, 5)])
 def test_window_tile_add_mode_equals_grouped_chain(tb, hip, dev, G, W):
     """tbx_window_tile in "add" mode = the traffic lights' temporal encoder (traffic_light.py:219-226: input MLP 16 -> 128 -> 128 ->
