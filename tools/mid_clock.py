@@ -39,7 +39,8 @@ def main():
     lib.tbx_debug_mid_dump.argtypes = [C.c_void_p, C.c_int]
     wm, full = bench.build(tb, args, dev, 0)
     eng, _ = bench.gpu_rollout_setup(tb, wm, full, args, dev)
-    eng.sched = eng.sched.replace(lights_ahead=False)
+    if not os.environ.get("TBX_CLOCK_TWO_STREAM"):  # (default: the one-stream order; TBX_CLOCK_TWO_STREAM=1: the timed schedule with the fused step tail)
+        eng.sched = eng.sched.replace(lights_ahead=False)
     eng.run(args.warmup + 3, use_graph=False)
     torch.cuda.synchronize()
     buf = (C.c_uint64 * (256 * 16))()
@@ -51,6 +52,8 @@ def main():
         c = buf[i * 16:(i + 1) * 16]
         d = [(c[j + 1] - c[j]) / 100.0 if c[j + 1] > c[j] else 0.0 for j in range(15)]  # clock64 = s_memtime = shader clocks here (~2.4 GHz: 100 clocks = 0.042 us)
         print(f"launch {i}: {sum(d):6.2f} x 100 shader clocks in workgroup 0")
+        if c[14] > c[13] and c[15] > c[14] and c[0] > c[15]:  # the agents' last layer with the fused step tail: stamp 0 was rewritten at its end
+            print(f"    [heads: {(c[14] - c[13]) / 100.0:.2f}; tbx_sim_step of the row's agent: {(c[15] - c[14]) / 100.0:.2f}; next tbx_agent_prep: {(c[0] - c[15]) / 100.0:.2f}]")
         for name, v in zip(PH if os.environ.get("TBX_DEC_TAIL_MFMA") == "0" else PH_MF, d):
             print(f"    {name:70s} {v:6.2f}")
 

@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
       if (a.type_mask[(int64_t)g * a.mask_stride + row] == 0) v += head_o[g * 2 + threadIdx.x];
     a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
   }
+  MID_CLK(14);
   if (a.fused_tail) {
     // ============================================================== the step's tail for this row's agent (csrc/step_core.h): its
     // tbx_sim_step (dynamics, rule checks, overrides, log, window append: 32 lanes) on the action just written, then the NEXT
@@ -1161,7 +1162,10 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     if (wave == 0 && lane < tbx_step::LPA) tbx_step::sim_agent(a.sim, a.sim_parts, t_step, row, lane, 0);
     if (a.sim_parts & TBX_SIM_ADVANCE) tbx_step::sim_advance(a.sim, t_step, gridDim.x);
     __syncthreads();  // the appended window is
+    MID_CLK(15);
     if (threadIdx.x < 256) tbx_step::agent_prep(a.prep, row, (int)threadIdx.x);
+    __syncthreads();
+    MID_CLK(0);  // (profiling build: the launch's end overwrites its first stamp - tools/mid_clock.py reads the tail from 13 -> 14 -> 15 -> 0)
   }
 }
 
