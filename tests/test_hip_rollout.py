@@ -267,6 +267,35 @@ def test_lights_tail_in_the_last_layers_launch_equals_the_chain(tb, bf16):
     assert float(lg1.abs().max()) <= 3.0
 
 
+@pytest.mark.parametrize("n_sc,A", [(12, 64), (3, 64), (20, 40)])
+def test_several_scenes_default_schedule_vs_exact_schedule(tb, n_sc, A):
+    """Launch sizes between the one-scene closed loop and the large-launch tile kernels (192 / 768 / 800 agent rows: several scenes
+    per call; tbx_front + one-launch layers below Schedule.live_max, tbx_front + row chains above it): the default schedule's
+    teacher-forced steps against the exact-fp32 schedule's - actions to 5e-3 over the 11 forced steps (measured 1e-4), poses to
+    5e-3 over 12 steps (measured 2e-5)."""
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    E = import_module("trafficbots_amd.engine")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=16), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    wm = wm.to(dev).eval()
+    batch = tb.synthetic.make_scene(n_sc, A, 256, 32, seed=1)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+    outs = {}
+    for name, sched in (("exact", E.DEFAULT.replace(dec_tail_mfma=False, tile_small=False, navi_rider=False)), ("default", E.DEFAULT)):
+        wm.schedule = sched
+        mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+        z = torch.randn(n_sc, A, 16, generator=torch.Generator().manual_seed(1)).to(dev)
+        valid = bd["gt/ag_valid"].any(-1)
+        outs[name] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True, step_end=14)
+    a, b = outs["exact"], outs["default"]
+    assert bool(torch.isfinite(b.pred_pose).all()) and torch.equal(a.pred_valid, b.pred_valid)
+    assert float((a.pred_pose[..., :12, :] - b.pred_pose[..., :12, :]).abs().max()) < 5e-3
+    d_act = float((a.vis_dict["action"][..., :11, :] - b.vis_dict["action"][..., :11, :]).abs().max())
+    assert 0.0 < d_act < 5e-3, d_act
+
+
 def test_hoisted_rollout_constants_are_bit_identical(tb):
     """The engine embeds the latent and the destination feature once per rollout instead of in every step's heads chain
     (TrafficBots.rollout_constants): same kernels on the same inputs, so the rollout must not change by a bit."""
