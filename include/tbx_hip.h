@@ -339,6 +339,13 @@ typedef struct tbx_front {
 } tbx_front_t;
 int tbx_front(const tbx_front_t* args /* host */, void* stream);
 
+/* tbx_tall_linear: y [m, n] = x [m, k] W^T (+ b) (optionally relu) over very many rows - the forward / input-gradient products of
+ * training's time-batched pass - on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output): image = tbx_pack_weight_mfma32 of
+ * W [n x k] (wt = 1 for a [k x n] weight: the input gradient dx = dy W), k and n multiples of 128 (<= 1024), ldx / ldy % 4 == 0,
+ * 16-byte aligned. has_bias: add the image's bias. */
+int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                    void* stream);
+
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
 int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups);

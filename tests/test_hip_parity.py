@@ -1102,3 +1102,24 @@ print("WORST", worst)
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().splitlines()[-1].split()[1])
     assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize("m,k,n,wt,bias", [(1000, 128, 128, False, True), (70001, 128, 640, False, True), (4097, 640, 128, False, False),
+                                           (12345, 256, 128, True, False), (333, 128, 512, True, False), (64, 512, 256, False, True)])
+def test_tall_linear_equals_the_library_product(hip, dev, m, k, n, wt, bias):
+    """tbx_tall_linear (training's forward / input-gradient products over very many rows, split-bf16 matrix path) vs torch's fp32
+    product: < 3e-5 of sum_k |x||w| per output (checked against that bound, computed per output); ragged last workgroups, several K
+    chunks / N blocks, the transposed-weight form of the input gradient, a row stride wider than k."""
+    g = torch.Generator().manual_seed(m + k + n)
+    xw = torch.randn(m, k + 8, generator=g).to(dev)
+    x = xw[:, :k]  # (leading dimension k + 8)
+    w = (torch.randn(k, n, generator=g) if wt else torch.randn(n, k, generator=g)).to(dev)
+    b = torch.randn(n, generator=g).to(dev) if bias else None
+    y = hip.tall_linear(x, w, b, wt=wt)
+    wm = w.t() if wt else w
+    ref = torch.nn.functional.linear(x.double(), wm.double(), None if b is None else b.double())
+    bound = torch.nn.functional.linear(x.abs().double(), wm.abs().double())
+    torch.cuda.synchronize()
+    assert y.shape == (m, n)
+    ratio = float(((y.double() - ref).abs() / bound).max())
+    assert 0.0 < ratio < 3e-5, ratio

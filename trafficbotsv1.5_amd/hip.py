@@ -244,6 +244,7 @@ def load():
     lib.tbx_heads_tile.argtypes = [C.POINTER(HeadsTile), vp]
     lib.tbx_window_tile.argtypes = [C.POINTER(WindowTile), vp]
     lib.tbx_front.argtypes = [C.POINTER(Front), vp]
+    lib.tbx_tall_linear.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp]
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
     lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -261,7 +262,7 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
@@ -406,6 +407,27 @@ def keyed_dropout(x: torch.Tensor, p: float, seed: torch.Tensor, site: int, rows
                                   int(time_batch), int(time0), stream_ptr())
     _check(rc, "tbx_keyed_dropout")
     return y
+
+
+def tall_linear_ok(x: torch.Tensor, k: int, n: int) -> bool:
+    """Shapes tbx_tall_linear takes: row-major fp32 rows of k values (a 2-D view after flattening the leading dimensions), k and n
+    multiples of 128 up to 1024, 16-byte aligned, leading dimension a multiple of 4."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == k and k % 128 == 0 and n % 128 == 0 and k <= 1024 and n <= 1024
+            and x.stride(-1) == 1 and x.data_ptr() % 16 == 0)
+
+
+def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False) -> torch.Tensor:
+    """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear). wt: w is stored [k x n] (the input gradient
+    dx = dy W of a Linear with weight W [n_out, n_in]: x = dy, w = W, wt = True)."""
+    n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    img = packed_weight(w, b, wt=wt, mfma32=True)
+    y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device)
+    _check(load().tbx_tall_linear(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
+                                  _ptr(y), n, stream_ptr()), "tbx_tall_linear")
+    return y.view(*x.shape[:-1], n)
 
 
 def linear_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:

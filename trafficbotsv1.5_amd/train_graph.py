@@ -36,6 +36,7 @@ D, NH, DH = 128, 4, 32
 
 
 # ------------------------------------------------------------------------------------------------ dense contractions
+TALL_LINEAR = os.environ.get("TBX_TALL_LINEAR", "1") != "0"  # forward / input-gradient products of the time-batched pass on tbx_tall_linear
 WGRAD_MIN_ROWS = 16384  # from here on dW = dY^T X is a reduction over so many rows that the library GEMM has 1-2 output tiles
 
 
@@ -49,13 +50,21 @@ class TallLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        if TALL_LINEAR and hip.tall_linear_ok(x, w.shape[1], w.shape[0]):
+            # K, N multiples of 128: tbx_tall_linear (split-bf16 matrix path, byte-bound: ~3x the library's exact-fp32 rate)
+            return hip.tall_linear(x, w, b)
         return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = F.linear(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if TALL_LINEAR and hip.tall_linear_ok(dy, w.shape[0], w.shape[1]):
+                dx = hip.tall_linear(dy, w, None, wt=True)
+            else:
+                dx = F.linear(dy, w.t().contiguous())
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             if not dy2.is_contiguous():
