@@ -286,8 +286,22 @@ typedef struct tbx_heads_tile {
   const uint8_t* type_mask;                    /* [3, mask_stride] */
   const float* images[9];
   float* action_out;
-  int32_t mask_stride, pad_;
+  int32_t mask_stride;
+  /* raw != 0 (training's stepping pass): the two embeddings are made in the launch, with the keyed dropouts of the adders' MLPs -
+   *   navi_emb = navi_valid ? mlp_in(dest_feature + mlp_pe(navi_pe)) : 0,  latent_emb = latent_invalid ? 0 : mlp_in(latent_z)
+   * (navigation.py:65-79, add_navi_latent.py:43-50; navi_emb / latent_emb are not read). raw_images: mlp_pe (n 128 k 128), the
+   * navigation adder's mlp_in (3 x n 128 k 128), the latent adder's mlp_in (n 128 k 32 - the 16-wide weight zero-padded -, n 128 k 128
+   * twice). Dropout (drop_thresh != 0): site ids of the 12 relu outputs in the row chain's order - navi mlp_in 0..2, navi mlp 0..2,
+   * latent mlp_in 0..2, latent mlp 0..2 (-1: none) - masks of tbx_keyed_dropout(seed, site, step, row, column of 128). */
+  int32_t raw;
   int64_t n_rows;
+  const float *navi_pe, *dest_feature; /* [n_rows, 128] */
+  const float* latent_z;               /* [n_rows, ld_z >= 16] */
+  const float* raw_images[7];
+  const uint64_t* drop_seed;
+  uint32_t drop_thresh;
+  float drop_scale;
+  int32_t drop_site[12], drop_step, ld_z;
 } tbx_heads_tile_t;
 int tbx_heads_tile(const tbx_heads_tile_t* args /* host */, void* stream);
 

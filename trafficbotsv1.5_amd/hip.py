@@ -112,7 +112,10 @@ class LayerTile(C.Structure):
 class HeadsTile(C.Structure):
     """tbx_heads_tile_t (include/tbx_hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("x", "navi_emb", "latent_emb", "navi_valid", "latent_invalid", "type_mask")]
-                + [("images", C.c_void_p * 9), ("action_out", C.c_void_p), ("mask_stride", C.c_int32), ("pad_", C.c_int32), ("n_rows", C.c_int64)])
+                + [("images", C.c_void_p * 9), ("action_out", C.c_void_p), ("mask_stride", C.c_int32), ("raw", C.c_int32), ("n_rows", C.c_int64),
+                   ("navi_pe", C.c_void_p), ("dest_feature", C.c_void_p), ("latent_z", C.c_void_p), ("raw_images", C.c_void_p * 7),
+                   ("drop_seed", C.c_void_p), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_site", C.c_int32 * 12),
+                   ("drop_step", C.c_int32), ("ld_z", C.c_int32)])
 
 
 class WindowTile(C.Structure):
@@ -759,7 +762,25 @@ def heads_tile(x, hd: dict):
     type_mask u8 [3, rows], action_out [rows, 2])."""
     a = HeadsTile()
     a.x, a.n_rows = _cptr(x, torch.float32), x.shape[0]
-    a.navi_emb, a.latent_emb = _cptr(hd["navi_emb"], torch.float32), _cptr(hd["latent_emb"], torch.float32)
+    raw = hd.get("raw")
+    if raw is not None:  # dict(navi_pe, dest_feature [rows, 128], latent_z [rows, >= 16], images = 7 mfma32 images, drop = None | dict(p, seed, step, sites[12]))
+        a.raw = 1
+        a.navi_pe, a.dest_feature = _cptr(raw["navi_pe"], torch.float32), _cptr(raw["dest_feature"], torch.float32)
+        z = raw["latent_z"]
+        assert z.dim() == 2 and z.stride(1) == 1 and z.shape[1] >= 16 and z.shape[0] == x.shape[0]
+        a.latent_z, a.ld_z = _ptr(z, torch.float32), z.stride(0)
+        assert len(raw["images"]) == 7
+        for i, im in enumerate(raw["images"]):
+            a.raw_images[i] = _ptr(im, torch.float32)
+        dr = raw.get("drop")
+        if dr is not None:
+            th = dr["p"] * 4294967296.0
+            a.drop_thresh, a.drop_scale = (1 if 0 < th < 1 else int(th)), 1.0 / (1.0 - dr["p"])
+            a.drop_seed, a.drop_step = _ptr(dr["seed"], torch.int64), int(dr["step"])
+            for i, st in enumerate(dr["sites"]):
+                a.drop_site[i] = -1 if st is None else int(st)
+    else:
+        a.navi_emb, a.latent_emb = _cptr(hd["navi_emb"], torch.float32), _cptr(hd["latent_emb"], torch.float32)
     a.navi_valid, a.latent_invalid = _cptr(hd["navi_valid"], torch.uint8), _cptr(hd["latent_invalid"], torch.uint8)
     a.type_mask, a.mask_stride, a.action_out = _cptr(hd["type_mask"], torch.uint8), hd["type_mask"].shape[1], _cptr(hd["action_out"], torch.float32)
     assert len(hd["images"]) == 9 and hd["action_out"].shape == (x.shape[0], 2)

@@ -202,6 +202,11 @@ class TrafficBots(nn.Module):
             if hd is not None:
                 hip.heads_tile(feat, hd)
                 return
+        if engine.DROP_CTX is not None and engine.tile_rows_ok(n * A, keyed_dropout=True) and rc.get("dest_feature") is not None:
+            hd = self._heads_tile_raw(prep, rc, ag_latent, latent_invalid, navi_valid_u8, out, n * A)
+            if hd is not None:  # training's stepping pass: embeddings, adders (with their keyed dropouts) and action head in ONE launch
+                hip.heads_tile(feat, hd)
+                return
         navi_pe = prep["navi_pe"]
         ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
         ch.load(feat, BUF1, 0, n=d)
@@ -220,6 +225,42 @@ class TrafficBots(nn.Module):
         self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"), z_premasked=bool(rc.get("latent_premasked")))
         self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
         ch.run(n * A)
+
+    def _heads_tile_raw(self, prep, rc, ag_latent, latent_invalid, navi_valid_u8, out, rows: int):
+        """tbx_heads_tile_t with raw = 1 (training's stepping pass at >= Schedule.tile_min_rows rows): the heads' two row chains -
+        navigation / latent embeddings, the adders with their 12 keyed dropouts, the action head - as one launch; None where the
+        modules are not of the shape the kernel is built for. The dropout site ids are taken in the chains' order."""
+        ah, an, al, d = self.action_head, self.add_navi, self.add_latent, self.hidden_dim
+        l_pe = self.navi_encoder.mlp_pe.linear_layers()
+        lin = lambda mlp: [t[0] for t in mlp.linear_layers()]
+        ok_mlp = lambda mlp, k0: (len(lin(mlp)) == 3 and all(t[1] is None and t[2] for t in mlp.linear_layers())
+                                  and [tuple(l.weight.shape) for l in lin(mlp)] == [(d, k0), (d, d), (d, d)])
+        if not (len(l_pe) == 1 and l_pe[0][1] is None and not l_pe[0][2] and tuple(l_pe[0][0].weight.shape) == (d, d) and d == 128
+                and ok_mlp(an.mlp_in, d) and ok_mlp(an.mlp, 2 * d) and ok_mlp(al.mlp, 2 * d) and ok_mlp(al.mlp_in, al.in_dim) and al.in_dim <= 16
+                and ah.fused_branches and ah.masked_sum_store and len(ah.mlp_mean) == 3 and ah.out_dim <= 16 and prep.get("navi_pe") is not None):
+            return None
+        ps = [an.mlp_in.dropout_p] * 3 + [an.mlp.dropout_p] * 3 + [al.mlp_in.dropout_p] * 3 + [al.mlp.dropout_p] * 3
+        sites = [engine.drop_site(p_) for p_ in ps]  # (the order add_navi.emit / add_latent.emit take them in)
+        live = [s_ for s_ in sites if s_ is not None]
+        if live and len({s_[0] for s_ in live}) != 1:
+            raise NotImplementedError("tbx_heads_tile: one dropout probability for the adders' MLPs")
+        drop = dict(p=live[0][0], seed=live[0][1], step=live[0][3], sites=[None if s_ is None else s_[2] for s_ in sites]) if live else None
+        pw = lambda w, b, **kw: hip.packed_weight(w, b, mfma32=True, **kw)
+        lins = [lin(mlp) for mlp in ah.mlp_mean]
+        w1, b1 = hip.stacked_linear([l[0] for l in lins])
+        w2, b2 = hip.stacked_linear([l[1] for l in lins])
+        w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
+        imgs = [pw(l.weight, l.bias) for l in lin(an.mlp)] + [pw(l.weight, l.bias) for l in lin(al.mlp)]
+        imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
+        li = lin(al.mlp_in)
+        raw_imgs = ([pw(l_pe[0][0].weight, l_pe[0][0].bias)] + [pw(l.weight, l.bias) for l in lin(an.mlp_in)]
+                    + [pw(hip.padded_weight(li[0].weight, 32), li[0].bias), pw(li[1].weight, li[1].bias), pw(li[2].weight, li[2].bias)])
+        z = ag_latent.reshape(rows, -1)
+        if z.shape[1] < 16 or z.stride(0) % 4 or z.data_ptr() % 16:
+            z = torch.nn.functional.pad(z, (0, 16 - z.shape[1])) if z.shape[1] < 16 else z.contiguous()
+        return dict(images=imgs, navi_valid=navi_valid_u8.reshape(-1), latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"],
+                    action_out=out["action_mean"],
+                    raw=dict(navi_pe=prep["navi_pe"], dest_feature=rc["dest_feature"], latent_z=z, images=raw_imgs, drop=drop))
 
     @torch.no_grad()
     def rollout_constants(self, ag_latent: Tensor, dest: Tensor, mp_tokens: Dict[str, Tensor], mp_batch_div: int = 1,

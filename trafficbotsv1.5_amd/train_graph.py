@@ -36,6 +36,7 @@ D, NH, DH = 128, 4, 32
 
 
 # ------------------------------------------------------------------------------------------------ dense contractions
+HEADS_TILE = os.environ.get("TBX_HEADS_TILE_TRAIN", "1") != "0"  # the stepping pass's heads as one tbx_heads_tile launch (raw inputs + keyed dropouts)
 TALL_LINEAR = os.environ.get("TBX_TALL_LINEAR", "1") != "0"  # forward / input-gradient products of the time-batched pass on tbx_tall_linear
 WGRAD_MIN_ROWS = 16384  # from here on dW = dY^T X is a reduction over so many rows that the library GEMM has 1-2 output tiles
 
@@ -667,9 +668,21 @@ def _agent_policy_engine(model, hv, hp, hm, ag_attr6, ag_type, z, z_valid, dest,
     zz = const("z", z, lambda t: t.reshape(n * A, -1).float().contiguous())
     zi = const("zi", z_valid, lambda t: (~t).reshape(-1).to(u8).contiguous())
     dd = const("dest", dest, lambda t: t.contiguous())
+
+    def dest_feature(_):  # mlp_mp(map feature of the destination): no dropout in it, fixed over the rollout (TrafficBots.rollout_constants)
+        M = mp["mp_token_pose"].shape[1]
+        rows_ = (torch.arange(n, device=dd.device).unsqueeze(1) * M + dd).reshape(-1).to(torch.int32).contiguous()
+        dst = torch.empty(n * A, model.hidden_dim, dtype=torch.float32, device=dd.device)
+        ch = hip.Chain(16, 4 * model.hidden_dim + 4)
+        model.navi_encoder.emit_dest_feature(ch, mp["mp_token_feature"].reshape(-1, model.hidden_dim), rows_, dst)
+        ch.run(n * A)
+        return dst
+
+    rc = dict(dest_feature=const("destf", dd, dest_feature)) if HEADS_TILE else None
     engine.DROP_CTX = ctx
     try:
-        model.agent_policy(hv, hp, hm, ag_attr6, type_idx, zz, zi, dd, navi_valid.to(u8).contiguous(), tl_tokens, mp, tl_kv, out)
+        model.agent_policy(hv, hp, hm, ag_attr6, type_idx, zz, zi, dd, navi_valid.to(u8).contiguous(), tl_tokens, mp, tl_kv, out,
+                           rollout_consts=rc)
     finally:
         engine.DROP_CTX = None
     if ctx is not None:
