@@ -1001,6 +1001,63 @@ def test_heads_tile_equals_heads_chain(tb, hip, dev, rows):
     assert float((out - ref).abs().max()) <= 2e-4 * scale, (float((out - ref).abs().max()), scale)
 
 
+@pytest.mark.parametrize("rows,p", [(1040, 0.1), (77, 0.0)])
+def test_heads_tile_raw_with_keyed_dropout_equals_the_two_chains(tb, hip, dev, rows, p):
+    """tbx_heads_tile with raw = 1 (training's stepping pass): navigation embedding mlp_in(dest_feature + mlp_pe(pe)), latent embedding
+    mlp_in(z), both adders with the keyed dropouts of their 12 relu outputs, action head (navigation.py:65-79, add_navi_latent.py:43-65,
+    action_head.py:74-100) in ONE launch, against the row chains it replaces with the SAME dropout site ids (engine.DROP_CTX): the
+    masks are tbx_keyed_dropout's in both (an element dropped in one is dropped in the other: any mismatch would be an O(1)
+    difference), values within 2e-4 of the largest action; p = 0 (no dropout) and a ragged last tile are covered."""
+    eng = import_module("trafficbots_amd.engine")
+    m = _default_model(tb, dev).model
+    for mod in (m.add_navi.mlp_in, m.add_navi.mlp, m.add_latent.mlp_in, m.add_latent.mlp):
+        mod.dropout_p = p if p > 0 else None
+    g = torch.Generator().manual_seed(rows)
+    d = 128
+    x = torch.randn(rows, d, generator=g).to(dev)
+    navi_pe, dest_f = torch.randn(rows, d, generator=g).to(dev), torch.randn(rows, d, generator=g).to(dev)
+    z = torch.randn(rows, 16, generator=g).to(dev)
+    navi_valid = (torch.rand(rows, generator=g) < 0.8).to(torch.uint8).to(dev)
+    lat_inv = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    ty = torch.randint(0, 4, (rows,), generator=g)
+    type_mask = torch.stack([(ty != i) for i in range(3)]).to(torch.uint8).contiguous().to(dev)
+    seed = torch.tensor([1234567], dtype=torch.int64, device=dev)
+    outs = {}
+    for name in ("chain", "tile"):
+        eng.DROP_CTX = dict(seed=seed, site=40, call=3, step=7) if p > 0 else None
+        try:
+            out = torch.full((rows, 2), 7.0, device=dev)
+            if name == "chain":
+                ch = hip.Chain(16, 4 * d + 4)
+                ch.load(x, hip.BUF1, 0, n=d)
+                m.navi_encoder.emit(ch, None, None, navi_pe, dest_feature=dest_f)
+                m.add_navi.emit(ch, navi_valid, mask_is_valid=True)
+                mid = torch.empty_like(x)
+                ch.store(hip.BUF1, 0, d, mid)
+                ch.run(rows)
+                ch = hip.Chain(16, 4 * d + 4)
+                ch.load(mid, hip.BUF1, 0, n=d)
+                m.add_latent.emit(ch, lat_inv, z)
+                m.action_head.emit(ch, type_mask, out)
+                ch.run(rows)
+            else:
+                prep = dict(navi_pe=navi_pe, type_mask=type_mask)
+                hd = m._heads_tile_raw(prep, dict(dest_feature=dest_f), z, lat_inv, navi_valid, dict(action_mean=out), rows)
+                assert hd is not None
+                hip.heads_tile(x, hd)
+            if p > 0:
+                assert eng.DROP_CTX["site"] == 40 + 12
+        finally:
+            eng.DROP_CTX = None
+        torch.cuda.synchronize()
+        outs[name] = out
+    ref, got = outs["chain"], outs["tile"]
+    none = (ty == 3).to(dev)
+    assert float(got[none].abs().max()) == 0.0 and float(ref[none].abs().max()) == 0.0
+    scale = float(ref.abs().max())
+    assert scale > 1e-3 and float((got - ref).abs().max()) <= 2e-4 * scale, (float((got - ref).abs().max()), scale)
+
+
 @pytest.mark.parametrize("bf16,K0,K1", [(False, 25, 64), (False, 70, 0), (True, 24, 88), (False, 8, 3)])
 def test_attention_lds_ring_equals_small_launches(hip, dev, bf16, K0, K1):
     """The LDS-ring form of the wave-per-row attention kernel (large launches: K / V rows of the next passes in flight as LDS-DMA
