@@ -382,7 +382,8 @@ def train_kernel_pass(hip, step, replay_s):
     an event pair can include an enqueue gap: durations are upper bounds; shares are of `replay_s`, the timed hipGraph replay of the
     same launches, which is GPU-bound). Algorithmic work:
     attention forward = SURVEY 8d bytes; backward = the forward's bytes + d(out) and d(q) rows (1280 floats per row) + 8 coefficient
-    floats per pair; tbx_linear_wgrad = dY and X read once (4 (n + k) bytes per row); LayerNorm 1.0 / 1.5 KB per row; chains: flops."""
+    floats per pair; tbx_linear_wgrad = dY and X read once (4 (n + k) bytes per row); tbx_tall_linear = X read, Y written once (the
+    same 4 (n + k) bytes per row); LayerNorm 1.0 / 1.5 KB per row; chains / tile kernels: flops."""
     rec, saved = {}, {}
 
     def T(cls, bound, work, fn, *a, **kw):
@@ -409,6 +410,15 @@ def train_kernel_pass(hip, step, replay_s):
     def wgrad(dy, x, *a, **kw):
         return T("wgrad_partial_kernel (tbx_linear_wgrad)", "hbm", 4.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]), saved["linear_wgrad"], dy, x, *a, **kw)
 
+    def tall(x, w, b=None, wt=False, relu=False):
+        n_, k_ = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
+        return T("tall_linear_kernel (tbx_tall_linear)", "hbm", 4.0 * (x.numel() // k_) * (k_ + n_), saved["tall_linear"], x, w, b, wt=wt, relu=relu)
+
+    def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None, rider=None):
+        mac = (2 * 128 * 128 if attn is not None else 0) + (2 * 128 * 512 if ffn is not None else 0) + (0 if proj is None else 128 * proj["n"] + 128 * 128)
+        return T("tile_layer / tile_heads / tile_window kernels (stepping pass)", "mfma", 2.0 * x.shape[0] * mac, saved["layer_tile"], x, attn=attn, ffn=ffn,
+                 proj=proj, store_x=store_x, drop=drop, rider=rider)
+
     def ln_f(x, *a, **kw):
         return T("ln_fwd_kernel", "hbm", x.numel() * 8.0, saved["layernorm_fwd"], x, *a, **kw)
 
@@ -420,7 +430,7 @@ def train_kernel_pass(hip, step, replay_s):
         return T("rowchain_kernel (stepping pass)", "mfma", fl, saved["Chain.run"], ch, n_rows, group_rows)
 
     names = {"knarpe_attn": attn, "knarpe_attn_bwd_gather": attn_bwd("knarpe_attn_bwd_gather"), "knarpe_attn_bwd": attn_bwd("knarpe_attn_bwd"),
-             "linear_wgrad": wgrad, "layernorm_fwd": ln_f, "layernorm_bwd": ln_b}
+             "linear_wgrad": wgrad, "layernorm_fwd": ln_f, "layernorm_bwd": ln_b, "tall_linear": tall, "layer_tile": lt}
     for n, f in names.items():
         saved[n] = getattr(hip, n)
         setattr(hip, n, f)
@@ -449,7 +459,7 @@ def train_kernel_pass(hip, step, replay_s):
                         "avg_launch_us": t / len(evs) * 1e6, "share_of_step": t / replay_s, "traffic": None})
     kernels.sort(key=lambda k: -k["share_of_step"])
     rest = 1.0 - sum(k["share_of_step"] for k in kernels)
-    kernels.append({"kernel": "library GEMMs (rocBLAS fp32) + aten elementwise / copy / reduce + this repo's smaller kernels", "bound": None,
+    kernels.append({"kernel": "library GEMMs of the odd-width layers (rocBLAS fp32) + aten elementwise / copy / reduce + this repo's smaller kernels", "bound": None,
                     "share_of_step": rest})
     roof = dict(kernels[0])
     roof["note"] = ("largest of this repo's kernel classes in ONE eager training step (event pairs on the launch stream: upper bounds, the eager "
