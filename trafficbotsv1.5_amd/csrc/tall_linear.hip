@@ -39,28 +39,44 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int KC = a.k >> 7, NB = a.n >> 7, T = a.n >> 4;  // 128-wide K chunks, N blocks; 16-channel tiles of the image
-  const int64_t n_rb = (a.m + ROWS - 1) / ROWS;          // row blocks: this workgroup takes blockIdx.x, + gridDim.x, ...
-  const int64_t my_rb = (n_rb - (int64_t)blockIdx.x + gridDim.x - 1) / gridDim.x;
-  // the thread's share of a 64 x 128 chunk of rows: 4 float4 (row r = q * 16 + (tid >> 5), columns (tid & 31) * 4)
+  const int n_rb = (int)((a.m + ROWS - 1) / ROWS);        // row blocks: this workgroup takes blockIdx.x, + gridDim.x, ...
+  const int my_rb = (n_rb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Index arithmetic is what this loop must NOT spend its issue slots on (a matrix instruction leaves ~4 of them): everything below
+  // is pointers stepped by precomputed strides and 32-bit counters.
+  // the thread's share of a 64 x 128 chunk of rows: 4 float4 (row q * 16 + lr, columns lc ..)
   const int lr = tid >> 5, lc = (tid & 31) * 4;
+  const int64_t x16 = 16 * (int64_t)a.ldx, y16 = 16 * (int64_t)a.ldy;
+  const int64_t x_rb = (int64_t)gridDim.x * ROWS * a.ldx, y_rb = (int64_t)gridDim.x * ROWS * a.ldy;  // to this workgroup's next row block
+  const float* xp = a.x + ((int64_t)blockIdx.x * ROWS + lr) * a.ldx + lc;                // the row block whose rows are requested next
+  float* yp = a.y + ((int64_t)blockIdx.x * ROWS + j) * a.ldy + 16 * wave + 4 * g;        // the row block being multiplied
+  const TBX_GLOBAL float* wq = (const TBX_GLOBAL float*)a.img + (int64_t)wave * UNIT + lane * 4;  // the wave's units; the lane's 16 bytes
+  int rows_req = (int)(a.m - (int64_t)blockIdx.x * ROWS);  // rows left from the requested row block on (may exceed 64)
+  int rows_cur = rows_req;
   f32x4 xin[4];
-  auto request_x = [&](int64_t rb, int kc) {
-    const int64_t r0 = rb * ROWS;
+  auto request_x = [&](int kc) {  // rows of the row block at xp, K chunk kc
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t r = r0 + q * 16 + lr;
       xin[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (r < a.m) xin[q] = gld4(a.x + r * (int64_t)a.ldx + kc * 128 + lc);
+      if (q * 16 + lr < rows_req) xin[q] = *(const TBX_GLOBAL f32x4*)(xp + q * x16 + kc * 128);
     }
   };
   auto park_x = [&](char* P) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) planes_write4<PL>(P, q * 16 + lr, lc, xin[q]);
   };
+  auto load_w = [&](W& w, int unit) {  // unit = kc * T + nb * 8 (+ wave: in wq)
+    const TBX_GLOBAL float* base = wq + (uint32_t)unit * (uint32_t)UNIT;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512);
+      w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256);
+    }
+    w.bias = *(const TBX_GLOBAL f32x4*)(base - lane * 4 + 2048 + g * 4);
+  };
   W wb[2];
   int buf = 0;
-  request_x(blockIdx.x, 0);
-  load_unit(wb[0], a.img, wave, lane);  // (N block 0, K chunk 0): unit = kc * T + tile
+  request_x(0);
+  load_w(wb[0], 0);
   park_x(lds_c);
   __syncthreads();
   Acc acc[4];
@@ -68,25 +84,25 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   // iterations of this workgroup: (its row blocks) x (N blocks) x (K chunks), K innermost; two per loop trip: the register slots stay
   // compile-time. A chunk of rows (row block, K chunk) is parked in LDS when the iteration before its first use ends - with K = 128
   // the planes serve all N blocks of the row block, and the next row block's rows are requested under the last N block.
-  const int per_rb = NB * KC;
-  const int64_t I = my_rb * per_rb;
-  auto body = [&](const int64_t it, const W& cur, W& nxt) {
-    const int64_t ib = it / per_rb;
-    const int in = (int)(it - ib * per_rb);
-    const int nb = in / KC, kc = in - nb * KC;
-    const int64_t rb = (int64_t)blockIdx.x + ib * gridDim.x;
+  const int I = my_rb * NB * KC;
+  int nb = 0, kc = 0;
+  auto body = [&](const int it, const W& cur, W& nxt) {
     if (kc == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q].zero();
       bias = cur.bias;
     }
     const bool more = it + 1 < I;
-    const int64_t ib2 = (it + 1) / per_rb;
-    const int in2 = (int)((it + 1) - ib2 * per_rb);
-    const int nb2 = in2 / KC, kc2 = in2 - nb2 * KC;
-    const bool new_x = more && (KC > 1 || ib2 != ib);  // the next iteration reads another chunk of rows
-    if (new_x) request_x((int64_t)blockIdx.x + ib2 * gridDim.x, kc2);
-    if (more) load_unit(nxt, a.img, kc2 * T + nb2 * 8 + wave, lane);
+    int nb2 = nb, kc2 = kc + 1;
+    bool next_rb = false;
+    if (kc2 == KC) {
+      kc2 = 0;
+      if (++nb2 == NB) nb2 = 0, next_rb = true;
+    }
+    const bool new_x = more && (KC > 1 || next_rb);  // the next iteration reads another chunk of rows
+    if (more && next_rb) xp += x_rb, rows_req -= (int)gridDim.x * ROWS;
+    if (new_x) request_x(kc2);
+    if (more) load_w(nxt, kc2 * T + nb2 * 8);
     const char* P = lds_c + buf * 2 * PLANE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -100,19 +116,19 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
       buf ^= 1;
     }
     if (kc + 1 == KC) {  // the N block's 64 x 128 outputs: lane = (row tile q, row j, channels 16 * wave + 4 g ..)
-      const int c = nb * 128 + 16 * wave + 4 * g;
-      const int64_t r0 = rb * ROWS;
+      float* yo = yp + nb * 128;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int64_t r = r0 + q * 16 + j;
         f32x4 v = acc[q].sum();
         if (a.has_bias) v += bias;
         if (a.relu) v = relu4(v);
-        if (r < a.m) gst4(a.y + r * (int64_t)a.ldy + c, v);
+        if (q * 16 + j < rows_cur) *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
       }
+      if (next_rb) yp += y_rb, rows_cur -= (int)gridDim.x * ROWS;
     }
+    nb = nb2, kc = kc2;
   };
-  for (int64_t it = 0; it < I; it += 2) {
+  for (int it = 0; it < I; it += 2) {
     body(it, wb[0], wb[1]);
     if (it + 1 < I) body(it + 1, wb[1], wb[0]);
   }
