@@ -76,6 +76,8 @@ class Schedule:
     # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
     # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
     tile_small: bool = True
+    front_big: bool = False  # ... at large launches too - measured SLOWER at the WOSAC shape (6.30 -> 4.56 M agent-steps/s: two pooled rows per
+    # workgroup pull the projection's four 64 KiB weight units through every workgroup's L2 port), kept as a switch only
     front_fused: bool = True  # small launches: window PointNet + first projection (+ rider) + the K-nearest searches as ONE launch (tbx_front)
     fused_tail: bool = True  # the agents' tbx_sim_step and the next step's tbx_agent_prep in the tail of the last decoder layer's launch (with the heads)
     navi_rider: bool = True  # small launches: the heads' navigation embedding in extra workgroups of the agents' first-projection launch (no auxiliary stream in the step)
@@ -105,7 +107,7 @@ class Schedule:
                    live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
                    kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
                    split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
-                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), fused_tail=on("TBX_FUSED_TAIL"), front_fused=on("TBX_FRONT_FUSED"), sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), fused_tail=on("TBX_FUSED_TAIL"), front_fused=on("TBX_FRONT_FUSED"), front_big=_env("TBX_FRONT_BIG", "0") == "1", sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
                    graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
 
     def replace(self, **kw) -> "Schedule":
@@ -376,7 +378,11 @@ def tile_rows_ok(rows: int, keyed_dropout: bool = False) -> bool:
 def front_ok(rows: int) -> bool:
     """tbx_front for this launch: the small-launch tile schedule, inference."""
     c = current()
-    return c.front_fused and tile_small_ok() and not tile_rows_ok(rows, keyed_dropout=True) and rows < 4096
+    if not (c.front_fused and tile_small_ok()):
+        return False
+    if tile_rows_ok(rows, keyed_dropout=True):  # large launches: Schedule.front_big
+        return c.front_big and DROP_CTX is None
+    return rows < 4096
 
 
 def front_proj_buffers(rows: int, dev) -> dict:
