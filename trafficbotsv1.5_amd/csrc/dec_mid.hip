@@ -785,6 +785,8 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row: channels c_out .. c_out + 3 of a 128-wide stage
   const int c_out = 16 * wave + 4 * g4;
   const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
+  // (the step counter of the fused tail: read here, a round trip to memory before that tail needs it)
+  const int t_step = a.fused_tail ? __builtin_amdgcn_readfirstlane(*a.sim.step) : 0;
   W wb[3];
   if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
   if (threadIdx.x < D) bk2_s[threadIdx.x] = a.bias_k2[threadIdx.x];
@@ -1157,13 +1159,12 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     // ============================================================== the step's tail for this row's agent (csrc/step_core.h): its
     // tbx_sim_step (dynamics, rule checks, overrides, log, window append: 32 lanes) on the action just written, then the NEXT
     // step's tbx_agent_prep of its new window (4 waves) - neither reads anything of another agent's
-    const int t_step = *a.sim.step;
     __syncthreads();  // the action is in memory (workgroup scope)
     if (wave == 0 && lane < tbx_step::LPA) tbx_step::sim_agent(a.sim, a.sim_parts, t_step, row, lane, 0);
     if (a.sim_parts & TBX_SIM_ADVANCE) tbx_step::sim_advance(a.sim, t_step, gridDim.x);
     __syncthreads();  // the appended window is
     MID_CLK(15);
-    if (threadIdx.x < 256) tbx_step::agent_prep(a.prep, row, (int)threadIdx.x);
+    tbx_step::agent_prep(a.prep, row, (int)threadIdx.x, 512);
     __syncthreads();
     MID_CLK(0);  // (profiling build: the launch's end overwrites its first stamp - tools/mid_clock.py reads the tail from 13 -> 14 -> 15 -> 0)
   }

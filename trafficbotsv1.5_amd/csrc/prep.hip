@@ -16,7 +16,7 @@ using tbx_step::to_local;
 
 // One workgroup (4 wavefronts) per agent: the window's steps are dealt to the wavefronts, the last valid step comes from one
 // ballot over the validity bytes (the kernel opens every agent step: 14 -> ~6 us at 64 agents).
-__global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) { tbx_step::agent_prep(a, (int)blockIdx.x, (int)threadIdx.x); }
+__global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) { tbx_step::agent_prep(a, (int)blockIdx.x, (int)threadIdx.x, 256); }
 
 __global__ void tl_prep_kernel(const uint8_t* __restrict__ hist_tl, const uint8_t* __restrict__ tl_invalid, int n_tok,
                                int window, int ld_attr, float* __restrict__ attr, uint8_t* __restrict__ row_invalid) {

@@ -21,20 +21,74 @@ __device__ __forceinline__ float sim_sl1(float d) {  // F.smooth_l1_loss, beta =
 // One closed-loop step of agent i by 32 lanes (`sub` = 0..31; half_shift = 0 / 32: which half of the wavefront's ballot is theirs),
 // t = *s.step read by the caller: every lane repeats the agent's scalar dynamics (broadcast loads), the lanes split the destination
 // polyline's nodes and the window shift.
+// Shape of the body: EVERY load first (one round trip to memory - two for the type's limits - instead of one per section: with the
+// log's stores between the sections the compiler may not move a later section's loads above them, and in the tail of the last
+// decoder layer's launch each round trip is ~0.8 us of the step's critical path), then the arithmetic, then every store.
 __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int sub, const int half_shift) {
   const int T = s.n_step_out;
   const int W = s.window;
   const int b = i / s.n_ag;
+  // ---------------------------------------------------------------- loads
   const bool valid0 = s.ag_valid[i] != 0;
   const int ty = s.ag_type_idx[i];
-  float px = s.ag_pose[i * 3], py = s.ag_pose[i * 3 + 1], pyaw = s.ag_pose[i * 3 + 2];
-  float spd = s.ag_motion[i * 3];
-  // Dynamics.update_ag + MultiPathPP (dynamics.py:84-120,237-274)
+  const float px = s.ag_pose[i * 3], py = s.ag_pose[i * 3 + 1], pyaw = s.ag_pose[i * 3 + 2];
+  const float spd = s.ag_motion[i * 3];
+  const float am0 = s.action_mean[i * 2], am1 = s.action_mean[i * 2 + 1];
+  const bool player = s.player_valid != nullptr && s.player_valid[i] != 0;
+  const float* bd = s.boundary + b * 4;
+  const float bd0 = bd[0], bd1 = bd[1], bd2 = bd[2], bd3 = bd[3];
+  const bool outside0 = s.outside_map[i] != 0;
+  const float thresh = s.dest_thresh[i];
+  const uint8_t kind = s.dest_kind[i];
+  const bool reached0 = s.dest_reached[i] != 0;
+  const bool disabled0 = s.ag_disabled[i] != 0;
+  // the destination polyline's first 32 nodes (n_node = 20 by default: all of them)
+  bool d_ok = false;
+  float d_px = 0.f, d_py = 0.f, d_dx = 0.f, d_dy = 0.f;
+  if (sub < s.n_node) {
+    const int64_t d = (int64_t)i * s.n_node + sub;
+    d_ok = s.dest_invalid[d] == 0;
+    d_px = s.dest_pos[d * 2], d_py = s.dest_pos[d * 2 + 1];
+    d_dx = s.dest_dir[d * 2], d_dy = s.dest_dir[d * 2 + 1];
+  }
+  const bool has_gt = t < s.n_step_gt;
+  const int64_t g = (int64_t)i * s.n_step_gt + t;
+  bool gt_v = false, tf_gt = false;
+  float g_px = 0.f, g_py = 0.f, g_yaw = 0.f, g_spd = 0.f, g_acc = 0.f, g_yr = 0.f;
+  if (has_gt) {
+    gt_v = s.gt_valid[g] != 0;
+    if (s.ov_valid == nullptr) tf_gt = s.tf_mask[g] != 0;
+    g_px = s.gt_pose[g * 3], g_py = s.gt_pose[g * 3 + 1], g_yaw = s.gt_pose[g * 3 + 2];
+    g_spd = s.gt_motion[g * 3], g_acc = s.gt_motion[g * 3 + 1], g_yr = s.gt_motion[g * 3 + 2];
+  }
+  bool tf_ov = false;
+  float o_px = 0.f, o_py = 0.f, o_yaw = 0.f, o_spd = 0.f, o_acc = 0.f, o_yr = 0.f;
+  if (s.ov_valid != nullptr) {  // the step's ag_override handed over explicitly (WaymoMotion.forward)
+    tf_ov = s.ov_valid[i] != 0;
+    o_px = s.ov_pose[i * 3], o_py = s.ov_pose[i * 3 + 1], o_yaw = s.ov_pose[i * 3 + 2];
+    o_spd = s.ov_motion[i * 3], o_acc = s.ov_motion[i * 3 + 1], o_yr = s.ov_motion[i * 3 + 2];
+  }
+  // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see. Lane w
+  // moves entry w + 1 to w (first chunk of 32 loaded here; W - 1 <= 32 by default: all of it)
+  uint8_t* hv = s.hist_valid + (int64_t)i * W;
+  float* hp = s.hist_pose + (int64_t)i * W * 3;
+  float* hm = s.hist_motion + (int64_t)i * W * 3;
+  const bool append = (parts & TBX_SIM_NO_APPEND) == 0;
+  const bool mv0 = append && sub < W - 1;
+  uint8_t h_v = 0;
+  float h_p0 = 0.f, h_p1 = 0.f, h_p2 = 0.f, h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f;
+  if (mv0) {
+    h_v = hv[sub + 1];
+    h_p0 = hp[(sub + 1) * 3], h_p1 = hp[(sub + 1) * 3 + 1], h_p2 = hp[(sub + 1) * 3 + 2];
+    h_m0 = hm[(sub + 1) * 3], h_m1 = hm[(sub + 1) * 3 + 1], h_m2 = hm[(sub + 1) * 3 + 2];
+  }
+  const float lim_acc = s.max_acc[ty], lim_yr = s.max_yaw_rate[ty];
+  // ---------------------------------------------------------------- Dynamics.update_ag + MultiPathPP (dynamics.py:84-120,237-274)
   float acc = 0.f, yr = 0.f;
   if (valid0) {
-    acc = tanhf(s.action_mean[i * 2]) * s.max_acc[ty];
-    yr = tanhf(s.action_mean[i * 2 + 1]) * s.max_yaw_rate[ty];
-    if (s.player_valid != nullptr && s.player_valid[i] != 0) {  // player-controlled agent (dynamics.py:104-107)
+    acc = tanhf(am0) * lim_acc;
+    yr = tanhf(am1) * lim_yr;
+    if (player) {  // player-controlled agent (dynamics.py:104-107)
       acc = s.player_action[i * 2];
       yr = s.player_action[i * 2 + 1];
     }
@@ -47,30 +101,22 @@ __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int pa
   float nyaw = pyaw + s.dt * yr;
   float nspd = spd + s.dt * acc, nacc = acc, nyr = yr;
   if (!valid0) nx = ny = nyaw = nspd = nacc = nyr = 0.f;
-  const float qx = nx, qy = ny, qyaw = nyaw, qspd = nspd;  // the prediction (before the override), for the reward
-  if (t - 1 < T && sub == 0) {
-    const int64_t o = (int64_t)i * T + (t - 1);
-    s.out_valid[o] = valid0 ? 1 : 0;
-    s.out_pose[o * 3] = nx;
-    s.out_pose[o * 3 + 1] = ny;
-    s.out_pose[o * 3 + 2] = nyaw;
-    s.out_motion[o * 3] = nspd;
-    s.out_motion[o * 3 + 1] = nacc;
-    s.out_motion[o * 3 + 2] = nyr;
-    s.out_action[o * 2] = acc;
-    s.out_action[o * 2 + 1] = yr;
-  }
+  const float qx = nx, qy = ny, qyaw = nyaw, qspd = nspd, qacc = nacc, qyr = nyr;  // the prediction (before the override): the log's, the reward's
   // outside-map / destination-reached on the predicted (pre-override) state (traffic_rule_checker.py:109-120,300-330)
-  const float* bd = s.boundary + b * 4;
-  const bool out_now = valid0 && (nx > bd[1] || nx < bd[0] || ny > bd[3] || ny < bd[2]);
-  const bool outside = (s.outside_map[i] != 0) || out_now;
+  const bool out_now = valid0 && (nx > bd1 || nx < bd0 || ny > bd3 || ny < bd2);
+  const bool outside = outside0 || out_now;
   bool pos_ok = false, rot_ok = false;
   const float hx = cosf(nyaw), hy = sinf(nyaw);
-  for (int k = sub; k < s.n_node; k += LPA) {
+  if (sub < s.n_node) {
+    const float ex = nx - d_px, ey = ny - d_py;
+    pos_ok = d_ok && sqrtf(ex * ex + ey * ey) < thresh;
+    rot_ok = d_ok && hx * d_dx + hy * d_dy > 0.8660254037844387f;
+  }
+  for (int k = sub + LPA; k < s.n_node; k += LPA) {  // (polylines of more than 32 nodes)
     const int64_t d = (int64_t)i * s.n_node + k;
     const bool ok = s.dest_invalid[d] == 0;
     const float ex = nx - s.dest_pos[d * 2], ey = ny - s.dest_pos[d * 2 + 1];
-    pos_ok = pos_ok || (ok && sqrtf(ex * ex + ey * ey) < s.dest_thresh[i]);
+    pos_ok = pos_ok || (ok && sqrtf(ex * ex + ey * ey) < thresh);
     rot_ok = rot_ok || (ok && hx * s.dest_dir[d * 2] + hy * s.dest_dir[d * 2 + 1] > 0.8660254037844387f);
   }
   {  // any() over the agent's 32 lanes (its half of the wavefront's ballot)
@@ -78,58 +124,18 @@ __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int pa
     pos_ok = ((__ballot(pos_ok) >> sh) & 0xffffffffull) != 0ull;
     rot_ok = ((__ballot(rot_ok) >> sh) & 0xffffffffull) != 0ull;
   }
-  const uint8_t kind = s.dest_kind[i];
-  const bool reached0 = s.dest_reached[i] != 0;
   const bool reach_now = !reached0 && valid0 && (((kind & 1) && pos_ok && rot_ok) || ((kind & 2) && pos_ok));
   const bool reached = reached0 || reach_now;
-  if (t - 1 < T && sub == 0) {
-    s.out_outside_map[(int64_t)i * T + (t - 1)] = outside ? 1 : 0;
-    s.out_dest_reached[(int64_t)i * T + (t - 1)] = reached ? 1 : 0;
-  }
   // TeacherForcing.get + Dynamics.override_ag (teacher_forcing.py:128-147, dynamics.py:122-141)
   bool valid = valid0;
-  bool disabled = s.ag_disabled[i] != 0;
-  bool has_gt = t < s.n_step_gt;
-  bool gt_v = false, tf_now = false;
-  const int64_t g = (int64_t)i * s.n_step_gt + t;
-  if (has_gt) gt_v = s.gt_valid[g] != 0;
-  if (s.ov_valid != nullptr) {  // the step's ag_override handed over explicitly (WaymoMotion.forward)
-    tf_now = s.ov_valid[i] != 0;
-    if (tf_now && !disabled) {
-      valid = true;
-      nx = s.ov_pose[i * 3], ny = s.ov_pose[i * 3 + 1], nyaw = s.ov_pose[i * 3 + 2];
-      nspd = s.ov_motion[i * 3], nacc = s.ov_motion[i * 3 + 1], nyr = s.ov_motion[i * 3 + 2];
-    }
-  } else if (has_gt) {
-    tf_now = s.tf_mask[g] != 0;
-    if (tf_now && !disabled) {
-      valid = true;
-      nx = s.gt_pose[g * 3];
-      ny = s.gt_pose[g * 3 + 1];
-      nyaw = s.gt_pose[g * 3 + 2];
-      nspd = s.gt_motion[g * 3];
-      nacc = s.gt_motion[g * 3 + 1];
-      nyr = s.gt_motion[g * 3 + 2];
-    }
-  }
-  if (t - 1 < T && sub == 0) {
-    const int64_t o = (int64_t)i * T + (t - 1);
-    if (s.out_tf != nullptr) s.out_tf[o] = tf_now ? 1 : 0;
-    // DifferentiableReward.get on the prediction (rewards.py:58-74; the same expressions as tbx_train_chain_fwd)
-    if (s.out_reward != nullptr) {
-      float r_pos = 0.f, r_rot = 0.f, r_spd = 0.f;
-      bool r_valid = valid0;
-      if (has_gt) {
-        r_valid = valid0 && gt_v;
-        if (r_valid) {
-          r_pos = -s.w_pos * (sim_sl1(s.gt_pose[g * 3] - qx) + sim_sl1(s.gt_pose[g * 3 + 1] - qy));
-          r_rot = -s.w_rot * (0.5f * (1.f - cosf(s.gt_pose[g * 3 + 2] - qyaw)));
-          r_spd = -s.w_spd * sim_sl1(s.gt_motion[g * 3] - qspd);
-        }
-      }
-      s.out_reward[o * 4] = r_pos, s.out_reward[o * 4 + 1] = r_rot, s.out_reward[o * 4 + 2] = r_spd;
-      s.out_reward[o * 4 + 3] = (r_pos + r_rot) + r_spd;
-      if (s.out_reward_valid != nullptr) s.out_reward_valid[o] = r_valid ? 1 : 0;
+  bool disabled = disabled0;
+  const bool tf_now = s.ov_valid != nullptr ? tf_ov : tf_gt;
+  if (tf_now && !disabled) {
+    valid = true;
+    if (s.ov_valid != nullptr) {
+      nx = o_px, ny = o_py, nyaw = o_yaw, nspd = o_spd, nacc = o_acc, nyr = o_yr;
+    } else {
+      nx = g_px, ny = g_py, nyaw = g_yaw, nspd = g_spd, nacc = g_acc, nyr = g_yr;
     }
   }
   // Dynamics.disable_ag / disable_navi (dynamics.py:165-204); a step-wise caller does both itself from now_*
@@ -137,16 +143,16 @@ __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int pa
   const bool dis = !no_disable && out_now && !(has_gt && gt_v);
   disabled = disabled || dis;
   valid = valid && !dis;
-  if (sub == 0 && s.now_outside != nullptr) s.now_outside[i] = out_now ? 1 : 0;
-  if (sub == 0 && s.now_reached != nullptr) s.now_reached[i] = reach_now ? 1 : 0;
-  // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see. Lane w
-  // moves entry w + 1 to w: the wavefront runs in lockstep, so every lane has loaded before any lane stores (chunks of 32
-  // go upwards, each reads only entries no earlier chunk wrote).
-  uint8_t* hv = s.hist_valid + (int64_t)i * W;
-  float* hp = s.hist_pose + (int64_t)i * W * 3;
-  float* hm = s.hist_motion + (int64_t)i * W * 3;
-  const bool append = (parts & TBX_SIM_NO_APPEND) == 0;
-  for (int w0 = 0; append && w0 < W - 1; w0 += LPA) {
+  // ---------------------------------------------------------------- stores
+  // the window: the wavefront runs in lockstep, so every lane has loaded before any lane stores (chunks of 32 go upwards, each reads
+  // only entries no earlier chunk wrote)
+  if (mv0) {
+    hv[sub] = h_v;
+    hp[sub * 3] = h_p0, hp[sub * 3 + 1] = h_p1, hp[sub * 3 + 2] = h_p2;
+    hm[sub * 3] = h_m0, hm[sub * 3 + 1] = h_m1, hm[sub * 3 + 2] = h_m2;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int w0 = LPA; append && w0 < W - 1; w0 += LPA) {  // (windows of more than 33 steps)
     const int w = w0 + sub;
     const bool mv = w < W - 1;
     uint8_t v1 = 0;
@@ -164,27 +170,59 @@ __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int pa
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (sub == 0) {
-    s.ag_valid[i] = valid ? 1 : 0;
-    s.ag_disabled[i] = disabled ? 1 : 0;
-    s.ag_pose[i * 3] = nx;
-    s.ag_pose[i * 3 + 1] = ny;
-    s.ag_pose[i * 3 + 2] = nyaw;
-    s.ag_motion[i * 3] = nspd;
-    s.ag_motion[i * 3 + 1] = nacc;
-    s.ag_motion[i * 3 + 2] = nyr;
-    s.outside_map[i] = outside ? 1 : 0;
-    s.dest_reached[i] = reached ? 1 : 0;
-    if (reach_now && !no_disable) s.navi_valid[i] = 0;
-    if (append) {
-      hv[W - 1] = valid ? 1 : 0;
-      hp[(W - 1) * 3] = nx;
-      hp[(W - 1) * 3 + 1] = ny;
-      hp[(W - 1) * 3 + 2] = nyaw;
-      hm[(W - 1) * 3] = nspd;
-      hm[(W - 1) * 3 + 1] = nacc;
-      hm[(W - 1) * 3 + 2] = nyr;
+  if (sub != 0) return;
+  if (t - 1 < T) {
+    const int64_t o = (int64_t)i * T + (t - 1);
+    s.out_valid[o] = valid0 ? 1 : 0;
+    s.out_pose[o * 3] = qx;
+    s.out_pose[o * 3 + 1] = qy;
+    s.out_pose[o * 3 + 2] = qyaw;
+    s.out_motion[o * 3] = qspd;
+    s.out_motion[o * 3 + 1] = qacc;
+    s.out_motion[o * 3 + 2] = qyr;
+    s.out_action[o * 2] = acc;
+    s.out_action[o * 2 + 1] = yr;
+    s.out_outside_map[o] = outside ? 1 : 0;
+    s.out_dest_reached[o] = reached ? 1 : 0;
+    if (s.out_tf != nullptr) s.out_tf[o] = tf_now ? 1 : 0;
+    // DifferentiableReward.get on the prediction (rewards.py:58-74; the same expressions as tbx_train_chain_fwd)
+    if (s.out_reward != nullptr) {
+      float r_pos = 0.f, r_rot = 0.f, r_spd = 0.f;
+      bool r_valid = valid0;
+      if (has_gt) {
+        r_valid = valid0 && gt_v;
+        if (r_valid) {
+          r_pos = -s.w_pos * (sim_sl1(g_px - qx) + sim_sl1(g_py - qy));
+          r_rot = -s.w_rot * (0.5f * (1.f - cosf(g_yaw - qyaw)));
+          r_spd = -s.w_spd * sim_sl1(g_spd - qspd);
+        }
+      }
+      s.out_reward[o * 4] = r_pos, s.out_reward[o * 4 + 1] = r_rot, s.out_reward[o * 4 + 2] = r_spd;
+      s.out_reward[o * 4 + 3] = (r_pos + r_rot) + r_spd;
+      if (s.out_reward_valid != nullptr) s.out_reward_valid[o] = r_valid ? 1 : 0;
     }
+  }
+  if (s.now_outside != nullptr) s.now_outside[i] = out_now ? 1 : 0;
+  if (s.now_reached != nullptr) s.now_reached[i] = reach_now ? 1 : 0;
+  s.ag_valid[i] = valid ? 1 : 0;
+  s.ag_disabled[i] = disabled ? 1 : 0;
+  s.ag_pose[i * 3] = nx;
+  s.ag_pose[i * 3 + 1] = ny;
+  s.ag_pose[i * 3 + 2] = nyaw;
+  s.ag_motion[i * 3] = nspd;
+  s.ag_motion[i * 3 + 1] = nacc;
+  s.ag_motion[i * 3 + 2] = nyr;
+  s.outside_map[i] = outside ? 1 : 0;
+  s.dest_reached[i] = reached ? 1 : 0;
+  if (reach_now && !no_disable) s.navi_valid[i] = 0;
+  if (append) {
+    hv[W - 1] = valid ? 1 : 0;
+    hp[(W - 1) * 3] = nx;
+    hp[(W - 1) * 3 + 1] = ny;
+    hp[(W - 1) * 3 + 2] = nyaw;
+    hm[(W - 1) * 3] = nspd;
+    hm[(W - 1) * 3 + 1] = nacc;
+    hm[(W - 1) * 3 + 2] = nyr;
   }
 }
 
@@ -205,29 +243,55 @@ __device__ __forceinline__ void sim_advance(const tbx_sim_state_t& s, const int 
 
 typedef tbx_agent_prep_args_t AgentPrepArgs;  // (field order = tbx_agent_prep's parameter groups)
 
+// (contraction off: HIP's __fmul_rn / __fadd_rn are plain operators, and which of the two products the compiler fuses into the sum
+// is otherwise its choice per call site - the standalone kernel and the decoder layer's tail would round differently)
 __device__ __forceinline__ void to_local(float x0, float y0, float c, float s, float x, float y, float& rx, float& ry) {
+#pragma clang fp contract(off)
   const float dx = __fsub_rn(x, x0), dy = __fsub_rn(y, y0);
   rx = __fadd_rn(__fmul_rn(dx, c), __fmul_rn(dy, s));
   ry = __fadd_rn(__fmul_rn(dx, -s), __fmul_rn(dy, c));
 }
 
-// tbx_agent_prep for agent i by 256 threads (tid = 0..255; 4 wavefronts): the window's steps are dealt to the wavefronts, the last valid
-// step comes from one ballot over the validity bytes.
-__device__ __forceinline__ void agent_prep(const AgentPrepArgs& a, const int i, const int tid) {
+// tbx_agent_prep for agent i by `nthreads` threads (a multiple of 64; tid = 0..nthreads-1). A "slot" = 32 lanes (the pose embedding
+// of one window step is 32 sincosf arguments at the default pe_dim = 64): the window's steps are dealt to the slots - with the 512
+// threads of the decoder layer's workgroup every step of the default window of 11 has its own - and the destination's relative pose
+// goes to the last slot. Every wavefront loads the whole window once (validity bytes, 3 W + 3 W floats: one round trip to memory);
+// the last valid step comes from one ballot, its pose and each slot's own step from lane shuffles of those registers.
+__device__ __forceinline__ void agent_prep(const AgentPrepArgs& a, const int i, const int tid, const int nthreads) {
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int l = tid & 31;
+  const int slot = tid >> 5, n_slot = nthreads >> 5;
   if (i >= a.n_tok) return;
   const int W = a.window;  // <= 23 (attribute row: 9 + W <= 32)
   const uint8_t* hv = a.hist_valid + (int64_t)i * W;
   const float* hp = a.hist_pose + (int64_t)i * W * 3;
   const float* hm = a.hist_motion + (int64_t)i * W * 3;
-  const unsigned long long vmask = __ballot(lane < W && hv[lane < W ? lane : 0] != 0);
+  // ---------------------------------------------------------------- loads
+  const bool hv_l = lane < W && hv[lane < W ? lane : 0] != 0;
+  const float hp0 = lane < 3 * W ? hp[lane] : 0.f, hp1 = lane + 64 < 3 * W ? hp[lane + 64] : 0.f;
+  const float hm0 = lane < 3 * W ? hm[lane] : 0.f, hm1 = lane + 64 < 3 * W ? hm[lane + 64] : 0.f;
+  const float attr6 = l < 6 ? a.ag_attr6[(int64_t)i * 6 + l] : 0.f;
+  const bool dest_slot = slot == n_slot - 1;
+  float dpx = 0.f, dpy = 0.f, dpyaw = 0.f;
+  int64_t mrow = 0;
+  int ty = 0;
+  if (dest_slot) {
+    if (a.type_mask != nullptr) ty = a.ag_type_idx[i];
+    if (a.dest != nullptr) {
+      const int b = i / a.n_ag;
+      mrow = (int64_t)(b / a.mp_batch_div) * a.n_mp + a.dest[i];
+      dpx = a.mp_tok_pose[mrow * 3], dpy = a.mp_tok_pose[mrow * 3 + 1], dpyaw = a.mp_tok_pose[mrow * 3 + 2];
+    }
+  }
+  auto at = [&](const float f0, const float f1, const int idx) { return idx < 64 ? __shfl(f0, idx) : __shfl(f1, idx - 64); };
+  // ----------------------------------------------------------------
+  const unsigned long long vmask = __ballot(hv_l);
   const int last = vmask ? 63 - __builtin_clzll(vmask) : -1;
   float x0 = 0.f, y0 = 0.f, yaw0 = 0.f;
-  if (last >= 0) {
-    x0 = hp[last * 3];
-    y0 = hp[last * 3 + 1];
-    yaw0 = hp[last * 3 + 2];
+  {
+    const int q = last >= 0 ? last * 3 : 0;
+    const float fx = at(hp0, hp1, q), fy = at(hp0, hp1, q + 1), fw = at(hp0, hp1, q + 2);
+    if (last >= 0) x0 = fx, y0 = fy, yaw0 = fw;
   }
   if (tid == 0) {
     a.tok_pose[i * 3] = x0;
@@ -236,39 +300,42 @@ __device__ __forceinline__ void agent_prep(const AgentPrepArgs& a, const int i, 
     a.tok_invalid[i] = last < 0 ? 1 : 0;
   }
   const float c = cosf(yaw0), s = sinf(yaw0);
-  for (int w = wave; w < W; w += 4) {
+  const int n_it = (W + n_slot - 1) / n_slot;  // (the shuffles below want every lane of the wavefront: no slot leaves the loop early)
+  for (int it = 0; it < n_it; ++it) {
+    const int w = it * n_slot + slot;
+    const int wq = w < W ? w : 0;
+    const float qx = at(hp0, hp1, wq * 3), qy = at(hp0, hp1, wq * 3 + 1), qyaw = at(hp0, hp1, wq * 3 + 2);
+    const int mi = wq * 3 + (l >= 6 && l < 9 ? l - 6 : 0);
+    const float mot = at(hm0, hm1, mi);
+    if (w >= W) continue;
     const int64_t r = (int64_t)i * W + w;
     float rx, ry;
-    to_local(x0, y0, c, s, hp[w * 3], hp[w * 3 + 1], rx, ry);
-    const float ryaw = __fsub_rn(hp[w * 3 + 2], yaw0);
-    tbx::pose_emb_write(a.pe + r * a.pe_dim, a.pe_dim, rx, ry, ryaw, a.freqs_xy, a.freqs_yaw, lane, 64);
-    if (lane < 32) {
-      float v = 0.f;
-      if (lane < 6)
-        v = a.ag_attr6[(int64_t)i * 6 + lane];
-      else if (lane < 9)
-        v = hm[w * 3 + lane - 6];
-      else if (lane - 9 == w)
-        v = 1.f;
-      a.attr[r * 32 + lane] = v;
-    }
-    if (lane == 32) a.row_invalid[r] = ((vmask >> w) & 1ull) ? 0 : 1;
+    to_local(x0, y0, c, s, qx, qy, rx, ry);
+    const float ryaw = __fsub_rn(qyaw, yaw0);
+    tbx::pose_emb_write(a.pe + r * a.pe_dim, a.pe_dim, rx, ry, ryaw, a.freqs_xy, a.freqs_yaw, l, 32);
+    float v = 0.f;
+    if (l < 6)
+      v = attr6;
+    else if (l < 9)
+      v = mot;
+    else if (l - 9 == w)
+      v = 1.f;
+    a.attr[r * 32 + l] = v;
+    if (l == 0) a.row_invalid[r] = ((vmask >> w) & 1ull) ? 0 : 1;
   }
-  if (wave != 0) return;
-  if (a.type_mask != nullptr && lane < 3) {
-    const bool now = hv[W - 1] != 0;
-    a.type_mask[(int64_t)lane * a.n_tok + i] = (now && a.ag_type_idx[i] == lane) ? 0 : 1;
+  const float ax = at(hp0, hp1, (W - 1) * 3), ay = at(hp0, hp1, (W - 1) * 3 + 1), ayaw = at(hp0, hp1, (W - 1) * 3 + 2);
+  if (!dest_slot) return;
+  if (a.type_mask != nullptr && l < 3) {
+    const bool now = ((vmask >> (W - 1)) & 1ull) != 0;
+    a.type_mask[(int64_t)l * a.n_tok + i] = (now && ty == l) ? 0 : 1;
   }
-  if (a.dest != nullptr && lane == 0) {
-    const int b = i / a.n_ag;
-    const int64_t mrow = (int64_t)(b / a.mp_batch_div) * a.n_mp + a.dest[i];
-    const float ax = hp[(W - 1) * 3], ay = hp[(W - 1) * 3 + 1], ayaw = hp[(W - 1) * 3 + 2];
+  if (a.dest != nullptr && l == 0) {
     const float cc = cosf(ayaw), ss = sinf(ayaw);
     float rx, ry;
-    to_local(ax, ay, cc, ss, a.mp_tok_pose[mrow * 3], a.mp_tok_pose[mrow * 3 + 1], rx, ry);
+    to_local(ax, ay, cc, ss, dpx, dpy, rx, ry);
     a.navi_pose3[i * 3] = rx;
     a.navi_pose3[i * 3 + 1] = ry;
-    a.navi_pose3[i * 3 + 2] = __fsub_rn(a.mp_tok_pose[mrow * 3 + 2], ayaw);
+    a.navi_pose3[i * 3 + 2] = __fsub_rn(dpyaw, ayaw);
     a.navi_row[i] = (int32_t)mrow;
   }
 }
