@@ -177,7 +177,9 @@ typedef struct tbx_heads_tail {
   const float* images[9];
   const float *navi_emb, *latent_emb;    /* [rows, 128] */
   const uint8_t *navi_valid, *latent_invalid; /* [rows] */
-  const uint8_t* type_mask;              /* [3, mask_stride]: byte set = the agent is not of that type (or not valid) */
+  const uint8_t* type_mask;              /* [3, mask_stride]: byte set = the agent is not of that type (or not valid). The all-mfma32 layer
+                                          * (tail_mfma32) computes only the branches a row's bytes let through - one for a one-hot type,
+                                          * none for an invalid agent - and sums them in branch order, as the others do over all three */
   float* action_out;                     /* [rows, 2] */
   int32_t mask_stride;
   /* Fused step tail (tail_mfma32 launches; sim_state and next_prep both or neither; host pointers): behind a row's action the

@@ -537,8 +537,9 @@ using tbx_tile::W;
 constexpr int NSW = 8;  // all 8 waves sweep: a row's targets 8 per pass per wave, two waves per SIMD hide each other's load latencies
 constexpr int LO128 = 256, LO384 = 768, LO512 = 1024, LO640 = 1280;  // byte offset of the lo plane behind a K-wide hi plane
 
+// (br: the action-head branch units 22 / 23 / 24 are taken from - the agents' heads only)
 template <int N>
-__device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wave, int lane) {
+__device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wave, int lane, int br = 0) {
   using tbx_tile::load_unit;
   if constexpr (N == 0) load_unit(w, a.fold1, wave, lane);
   else if constexpr (N == 1) load_unit(w, a.wo, wave, lane);
@@ -560,9 +561,13 @@ __device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wa
     else if constexpr (N == 15 || N == 19) load_unit(w, a.hw[N == 15 ? 0 : 3], 8 + wave, lane);
     else if constexpr (N == 16 || N == 17) load_unit(w, a.hw[N - 15], wave, lane);
     else if constexpr (N == 20 || N == 21) load_unit(w, a.hw[N - 16], wave, lane);
-    else if constexpr (N >= 22 && N <= 24) load_unit(w, a.hw[6], 8 * (N - 22) + wave, lane);
-    else if constexpr (N >= 25 && N <= 27) load_unit(w, a.hw[7], 8 * (N - 25) + wave, lane);
-    else if constexpr (N == 28) load_unit(w, a.hw[8], wave < 3 ? wave : 2, lane);
+    else if constexpr (N == 22) {  // the action head's three layers of branch br (none: an invalid agent)
+      if (br >= 0) load_unit(w, a.hw[6], 8 * br + wave, lane);
+    } else if constexpr (N == 23) {
+      if (br >= 0) load_unit(w, a.hw[7], 8 * br + wave, lane);
+    } else if constexpr (N == 24) {
+      if (wave == 0) load_unit(w, a.hw[8], br, lane);
+    }
   }
 }
 
@@ -1076,31 +1081,38 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   }
   if (col0) put4(Pv, LO384, c_out, *(const f32x4*)(xs + c_out));  // (this lane's own 4 channels of x, written above)
   const bool ok_navi = a.navi_valid[row] != 0, ok_lat = a.latent_invalid[row] == 0;
+  // the action head's branches this agent's type masks let through (action_head.py:64-100: one per agent type - an agent has one type,
+  // an invalid agent none): only those are computed, each 3 weight units instead of all three branches' 7
+  int act = 0;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) act |= (a.type_mask[(int64_t)g * a.mask_stride + row] == 0 ? 1 : 0) << g;
+  act = __builtin_amdgcn_readfirstlane(act);
+  const int br0 = act ? __builtin_ctz((unsigned)act) : -1;
   __syncthreads();
 #define TBX_MF_ADDER(N, ZSTEP, OK)                                                                    \
   do {                                                                                                \
     {                                                                                                 \
       Acc acc;                                                                                        \
       acc.zero();                                                                                     \
-      issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                                        \
+      issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane, br0);                                        \
       const W& w0 = wb[(N) % 3];                                                                      \
       const f32x4 bias = w0.bias;                                                                     \
       _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w0.hi[st], w0.lo[st], Pv, LO384, st, g4); \
-      issue<(N) + 3>(wb[((N) + 3) % 3], a, heads, wave, lane);                                        \
+      issue<(N) + 3>(wb[((N) + 3) % 3], a, heads, wave, lane, br0);                                        \
       const W& w1 = wb[((N) + 1) % 3];                                                                \
       _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w1.hi[st], w1.lo[st], Pv, LO384, (ZSTEP) + st, g4); \
       if (col0) put4(Ph, LO128, c_out, tbx_tile::relu4(acc.sum() + bias));                            \
     }                                                                                                 \
     __syncthreads();                                                                                  \
     {                                                                                                 \
-      issue<(N) + 4>(wb[((N) + 4) % 3], a, heads, wave, lane);                                        \
+      issue<(N) + 4>(wb[((N) + 4) % 3], a, heads, wave, lane, br0);                                        \
       const W& w = wb[((N) + 2) % 3];                                                                 \
       const f32x4 hdn = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);                         \
       if (col0) put4(Pq, LO128, c_out, hdn);                                                          \
     }                                                                                                 \
     __syncthreads();                                                                                  \
     {                                                                                                 \
-      issue<(N) + 5>(wb[((N) + 5) % 3], a, heads, wave, lane);                                        \
+      issue<(N) + 5>(wb[((N) + 5) % 3], a, heads, wave, lane, br0);                                        \
       const W& w = wb[((N) + 3) % 3];                                                                 \
       const f32x4 upd = tbx_tile::relu4(gemv4(w, Pq, LO128, 0, g4) + w.bias);                         \
       if (col0) {                                                                                     \
@@ -1115,43 +1127,39 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   TBX_MF_ADDER(14, 4, ok_navi);
   TBX_MF_ADDER(18, 8, ok_lat);
 #undef TBX_MF_ADDER
-  // ---- action head layer 1: 128 -> 3 x 128 (units 22..24), relu -> Pu[g * 128 ..]
-#define TBX_MF_A1(N)                                                                 \
-  do {                                                                               \
-    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
-    const W& w = wb[(N) % 3];                                                        \
-    const f32x4 u = tbx_tile::relu4(gemv4(w, Pv, LO384, 0, g4) + w.bias);            \
-    if (col0) put4(Pu, LO512, ((N) - 22) * D + c_out, u);                            \
-  } while (0)
-  TBX_MF_A1(22);
-  TBX_MF_A1(23);
-  TBX_MF_A1(24);
-#undef TBX_MF_A1
-  __syncthreads();
-  // ---- layer 2: block-diagonal 3 x (128 -> 128) (units 25..27), relu: branch g reads Pu[g * 128 ..] -> Pv[g * 128 ..]
-#define TBX_MF_A2(N)                                                                 \
-  do {                                                                               \
-    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
-    const W& w = wb[(N) % 3];                                                        \
-    const f32x4 u = tbx_tile::relu4(gemv4(w, Pu, LO512, 4 * ((N) - 25), g4) + w.bias); \
-    if (col0) put4(Pv, LO384, ((N) - 25) * D + c_out, u);                            \
-  } while (0)
-  TBX_MF_A2(25);
-  TBX_MF_A2(26);
-  TBX_MF_A2(27);
-#undef TBX_MF_A2
-  __syncthreads();
-  // ---- layer 3 (unit 28): wave g < 3 = branch g, 16 zero-padded outputs of which the first 2 are the action
-  if (wave < 3) {
-    const W& w = wb[28 % 3];
-    const f32x4 o = gemv4(w, Pv, LO384, 4 * wave, g4) + w.bias;
-    if (lane == 0) head_o[wave * 2] = o[0], head_o[wave * 2 + 1] = o[1];
+  // ---- action head, branch by branch in branch order (unit slots 22 / 23 / 24 mod 3 for its layers 1 / 2 / 3): 128 -> 128 relu (x
+  // planes in Pv -> Pu[br * 128 ..]), 128 -> 128 relu (-> Ph), 128 -> 2 of 16 zero-padded outputs (wave 0)
+  for (int br = br0; br >= 0;) {
+    int nx = -1;  // the next branch let through (none for a one-hot type)
+    for (int g = 2; g > br; --g)
+      if ((act >> g) & 1) nx = g;
+    {
+      issue<24>(wb[24 % 3], a, heads, wave, lane, br);
+      const W& w = wb[22 % 3];
+      const f32x4 u = tbx_tile::relu4(gemv4(w, Pv, LO384, 0, g4) + w.bias);
+      if (col0) put4(Pu, LO512, br * D + c_out, u);
+    }
+    __syncthreads();
+    {
+      issue<22>(wb[22 % 3], a, heads, wave, lane, nx);
+      const W& w = wb[23 % 3];
+      const f32x4 u = tbx_tile::relu4(gemv4(w, Pu, LO512, 4 * br, g4) + w.bias);
+      if (col0) put4(Ph, LO128, c_out, u);
+    }
+    __syncthreads();
+    issue<23>(wb[23 % 3], a, heads, wave, lane, nx);
+    if (wave == 0) {
+      const W& w = wb[24 % 3];
+      const f32x4 o = gemv4(w, Ph, LO128, 0, g4) + w.bias;
+      if (lane == 0) head_o[br * 2] = o[0], head_o[br * 2 + 1] = o[1];
+    }
+    __syncthreads();
+    br = nx;
   }
-  __syncthreads();
   if (threadIdx.x < 2) {  // the masked sum over the branches, in branch order from 0
     float v = 0.f;
     for (int g = 0; g < 3; ++g)
-      if (a.type_mask[(int64_t)g * a.mask_stride + row] == 0) v += head_o[g * 2 + threadIdx.x];
+      if ((act >> g) & 1) v += head_o[g * 2 + threadIdx.x];
     a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
   }
   MID_CLK(14);
