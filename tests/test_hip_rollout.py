@@ -238,6 +238,53 @@ def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
             assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
 
 
+def test_action_head_branches_follow_the_type_masks(tb):
+    """The heads in the last decoder layer's launch compute only the action-head branches a row's type-mask bytes let through
+    (tbx_heads_tail_t.type_mask; action_head.py:64-100 sums one branch per agent type). One policy evaluation on masks a real scene
+    never has - all three branches, two, none - next to ordinary one-hot rows, default schedule against the exact-fp32 one (which
+    evaluates every branch and masks the sum): the same actions to 2e-3, exactly 0 for the rows without a branch, and the crafted rows
+    really are sums of several branches."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, (64, 1024, 128), 32)
+    E = import_module("trafficbots_amd.engine")
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    z = torch.randn(1, 64, 16, generator=torch.Generator().manual_seed(4)).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    wm.schedule = E.DEFAULT
+    wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True, step_end=3, use_graph=False)
+    eng, m = wm._engine, wm.model
+    S = eng.S
+    n, A, _ = S["hist_valid"].shape
+    div = eng.tl_tokens.get("ag_mp_batch_div", eng.tl_tokens.get("mp_batch_div", 1))
+    outs, masks = {}, {}
+    for name, sched in (("exact", E.DEFAULT.replace(dec_tail_mfma=False, tile_small=False, navi_rider=False)), ("default", E.DEFAULT),
+                        ("one_hot", E.DEFAULT)):
+        with E.use(sched):
+            prep = m.ag_encoder.alloc_prep(n, A, dev, with_heads=True)
+            m.ag_encoder.run_prep(S["hist_valid"], S["hist_pose"], S["hist_motion"], eng.ag_attr6, S["ag_type_idx"], prep, eng.dest, eng.mp_tokens, div)
+            if name != "one_hot":
+                prep["type_mask"][:, 0] = 0  # all three branches
+                prep["type_mask"][:2, 1] = 0  # branches 0 and 1 (+ whatever the agent's own type lets through)
+                prep["type_mask"][1:, 3] = 0  # branches 1 and 2
+                prep["type_mask"][:, 2] = 1  # none
+            out = dict(action_mean=torch.full((n * A, 2), 9.0, device=dev), prep=prep)
+            m.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], eng.ag_attr6, S["ag_type_idx"], eng.ag_latent, eng.latent_invalid,
+                           eng.dest, S["navi_valid"], eng.tl_tokens, eng.mp_tokens, eng.tl_kv[eng.parity], out, rollout_consts=eng.consts,
+                           prep_ready=True)
+            torch.cuda.synchronize()
+            outs[name], masks[name] = out["action_mean"].clone(), prep["type_mask"].clone()
+    ex, df, oh = outs["exact"], outs["default"], outs["one_hot"]
+    assert torch.equal(masks["exact"], masks["default"])
+    none = (masks["default"] != 0).all(0)
+    assert bool(none[2]) and float(df[none].abs().max()) == 0.0 and float(ex[none].abs().max()) == 0.0
+    scale = float(ex.abs().max())
+    assert scale > 1e-2 and float((df - ex).abs().max()) <= 2e-3 * max(1.0, scale), (float((df - ex).abs().max()), scale)
+    assert float((df[0] - oh[0]).abs().max()) > 1e-4 and float((df[3] - oh[3]).abs().max()) > 1e-4  # several branches: not the one-hot row's action
+    rest = torch.ones(n * A, dtype=torch.bool, device=dev)
+    rest[:4] = False
+    assert torch.equal(df[rest], oh[rest])  # the ordinary rows do not see the crafted ones
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_lights_tail_in_the_last_layers_launch_equals_the_chain(tb, bf16):
     """tbx_tl_tail_t: the lights' tail - the K/V rows the agents' four layers read and the next-state logits (traffic_bots.py:188-199,
