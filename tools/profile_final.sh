@@ -26,7 +26,7 @@ db=$(find $out/kt_train -name '*.db' | head -1)
 rm -rf $out/kt_train
 # phase clock inside the one-launch decoder layer (profiling build: make -C trafficbotsv1.5_amd/csrc clk)
 if [ -f trafficbotsv1.5_amd/csrc/libtbx_hip_clk.so ]; then
-  { echo "tools/mid_clock.py: s_memtime stamps of workgroup 0 in every dec_layer_mf_kernel launch of one eager step (launches 0-3: the lights' 128 rows, 4-7: the agents' 64 rows; unit = 100 shader clocks, ~0.042 us)"; python3 tools/mid_clock.py 2>/dev/null | grep -v amdgpu.ids; } > $out/${tag}_dec_layer_phase_clock.txt
+  { echo "tools/mid_clock.py (TBX_CLOCK_TWO_STREAM=1: the timed two-stream schedule, eager): s_memtime stamps of workgroup 0 in every dec_layer_mf_kernel launch of one step (launches 0-3: the lights' 128 rows, the last with their K/V + logits tail; 4-7: the agents' 64 rows, the last with heads + tbx_sim_step + the next tbx_agent_prep; unit = 100 shader clocks, ~0.042 us)"; TBX_CLOCK_TWO_STREAM=1 python3 tools/mid_clock.py 2>/dev/null | grep -v amdgpu.ids; } > $out/${tag}_dec_layer_phase_clock.txt
 fi
 python bench.py > $out/${tag}_bench_default.log 2>&1
 tail -1 $out/${tag}_bench_default.log | cut -c1-200
