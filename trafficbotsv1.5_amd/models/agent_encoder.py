@@ -130,9 +130,12 @@ class AgentEncoder(nn.Module):
             # (large launches: the destination's pose embedding is built inside the rider - nothing of it rides on the searches)
             rider = navi_rider(prep, pose3=not pe_rides)  # (None: the modules are not of the shape the rider is built for)
         use_rider = rider is not None
-        if use_rider:
+        # Schedule.knn_aux_big: at large launches the three searches (35 us at 4096 rows) run on the auxiliary stream beside the window
+        # PointNet + first projection (50 us) - there the two cross-queue edges cost less than the launches they hide
+        knn_aux = aux_stream is not None and engine_current().knn_aux_big and n * A >= 4096
+        if use_rider and not knn_aux:
             aux_stream = None  # nothing of this step runs beside this stream
-        knn_main = aux_stream is not None and engine_current().knn_main
+        knn_main = aux_stream is not None and engine_current().knn_main and not knn_aux
         if aux_stream is not None and not knn_main:
             aux_stream.wait_stream(main)  # fork: the searches depend on agent_prep only
         ie = self.input_encoder
