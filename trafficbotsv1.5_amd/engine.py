@@ -76,6 +76,7 @@ class Schedule:
     # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
     # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
     tile_small: bool = True
+    prime_graph: bool = True  # RolloutEngine.restore() / refill(): the lights' first pass + first tbx_agent_prep replayed as a graph
     knn_aux_big: bool = True  # large launches: the K-nearest searches on the auxiliary stream beside the window PointNet
     front_big: bool = False  # ... at large launches too - measured SLOWER at the WOSAC shape (6.30 -> 4.56 M agent-steps/s: two pooled rows per
     # workgroup pull the projection's four 64 KiB weight units through every workgroup's L2 port), kept as a switch only
@@ -108,7 +109,7 @@ class Schedule:
                    live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
                    kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
                    split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
-                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), fused_tail=on("TBX_FUSED_TAIL"), front_fused=on("TBX_FRONT_FUSED"), front_big=_env("TBX_FRONT_BIG", "0") == "1", knn_aux_big=on("TBX_KNN_AUX_BIG"), sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), fused_tail=on("TBX_FUSED_TAIL"), front_fused=on("TBX_FRONT_FUSED"), front_big=_env("TBX_FRONT_BIG", "0") == "1", knn_aux_big=on("TBX_KNN_AUX_BIG"), prime_graph=on("TBX_PRIME_GRAPH"), sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
                    graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
 
     def replace(self, **kw) -> "Schedule":

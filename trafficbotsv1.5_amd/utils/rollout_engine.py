@@ -199,7 +199,8 @@ class RolloutEngine:
         own.step = S["step_tl"].data_ptr()
         self.sim_state_tl_own = own
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
-        self.graph = self.graph_multi = None
+        self.graph = self.graph_multi = self.graph_prime = None
+        self._prime_prepares = False
         self._tl_prep = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
@@ -255,9 +256,7 @@ class RolloutEngine:
                     assert self.consts[k] == v
         self.parity = 0
         self._n_forward = 0
-        if not self.stepwise:
-            self._tl_ahead(0)
-        self._prime_prep()
+        self._prime()
 
     @staticmethod
     def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor]) -> None:
@@ -280,6 +279,18 @@ class RolloutEngine:
             self.S[k].copy_(v)
         self.parity = 0
         self._n_forward = 0
+        self._prime()
+
+    def _prime(self) -> None:
+        """What a (re)set state needs before its first step: the lights' encoder pass on the initial window (tables for the agents'
+        first step, logits for the lights' first update) and, with a fused tail, the first step's tbx_agent_prep. Eagerly these are ~7
+        launches behind ~1.2 ms of host work per rollout; capture() records them once (graph_prime: every buffer they touch is
+        refilled in place) and every later restore() / refill() replays that."""
+        if self.graph_prime is not None:
+            self.policy_out["tl_kv"] = self.tl_kv[0]
+            self.graph_prime.replay()
+            self._prep_ready = self._prime_prepares
+            return
         if not self.stepwise:
             self._tl_ahead(0)
         self._prime_prep()
@@ -387,6 +398,14 @@ class RolloutEngine:
             self.graph_multi = g
         self.parity = 0
         self.graph = graphs
+        # the priming of a (re)set state as a graph too (_prime): the state is at the restored, primed start - capturing executes nothing
+        if self.sched.prime_graph and not self.stepwise:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._tl_ahead(0)
+                self._prime_prep()
+            self._prime_prepares = self._prep_ready
+            self.graph_prime = g
 
     @_scheduled
     def run(self, n_steps: Optional[int] = None, use_graph: bool = True) -> None:
