@@ -771,7 +771,6 @@ __device__ __forceinline__ void combine(RowAcc& st, const float (&M)[NH], const 
 template <bool KV16>
 __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   using namespace mf;
-  constexpr int NW = 8;
   __shared__ __attribute__((aligned(16))) float red_s[NSW][RED];
   __shared__ __attribute__((aligned(16))) float comb_s[D], xs[D], q2[D], qt2[NH * D], bk2_s[D], head_o[3 * 2];
   __shared__ __attribute__((aligned(16))) char Pc[2 * LO640], Ph[2 * LO128], Pq[2 * LO128], Pu[2 * LO512], Pv[2 * LO384];
