@@ -53,6 +53,9 @@ __device__ __forceinline__ const TBX_GLOBAL float* unit_ptr(const float* img, in
 }
 __device__ __forceinline__ void load_unit(W& w, const float* img, int unit, int lane) {
   const TBX_GLOBAL float* base = unit_ptr(img, unit);
+#ifdef TBX_ABL_NOLOAD  // (ablation builds, tools/scratch/tile_ablation.sh: every unit is the image's first 8 KiB - L1-resident)
+  base = unit_ptr(img, 0);
+#endif
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + lane * 4);
@@ -78,9 +81,15 @@ template <int PLANE>
 __device__ __forceinline__ void mfma_step(Acc& a, const bf16x8 whi, const bf16x8 wlo, const char* act_hi, int step) {
   const bf16x8 xh = *(const bf16x8*)(act_hi + step * 16);
   const bf16x8 xl = *(const bf16x8*)(act_hi + PLANE + step * 16);
+#ifdef TBX_ABL_NOMFMA  // (ablation builds: one product instead of three)
+  a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
+  a.hl[0] += (float)xl[0];
+  a.lh[0] += (float)wlo[0];
+#else
   a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
   a.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, a.hl, 0, 0, 0);
   a.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, a.lh, 0, 0, 0);
+#endif
 }
 
 // 4 fp32 values -> bf16 hi (RNE) and lo = bf16(v - hi), 8 bytes each
