@@ -60,6 +60,18 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
   }
 }
 
+// profiling build (make clk): the LAST workgroup's wave 0 stamps the shader clock at the phase boundaries of every launch
+#ifdef TBX_STAGE_CLOCK
+__device__ unsigned long long g_tl_clk[256 * 16];
+__device__ unsigned int g_tl_launch;
+#define TL_CLK(i)                                                                                      \
+  do {                                                                                                 \
+    if (tl_slot < 256u) g_tl_clk[tl_slot * 16 + (i)] = clock64();                                      \
+  } while (0)
+#else
+#define TL_CLK(i)
+#endif
+
 template <bool ATTN, bool FFN, int PROJ>
 __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,6 +90,14 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
+#ifdef TBX_STAGE_CLOCK
+  unsigned tl_slot = 0xffffffffu;
+  if (blockIdx.x == 0 && tid == 0) {
+    tl_slot = atomicAdd(&g_tl_launch, 1u);
+    if (tl_slot < 256u) g_tl_clk[tl_slot * 16 + 15] = (unsigned long long)((ATTN ? 100 : 0) + (FFN ? 10 : 0) + PROJ);  // which instantiation
+  }
+#endif
+  TL_CLK(0);
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int nv = (t.n_rows - row0) < ROWS ? (int)(t.n_rows - row0) : ROWS;
   const bool row_ok = j < nv;
@@ -123,6 +143,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     }
   }
   __syncthreads();
+  TL_CLK(1);
 
   if constexpr (ATTN) {
     {  // value half of linear_rpe: y_h = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_h; wave w = head w / 2, 16 of its 32 channels
@@ -137,6 +158,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       planes_write4<PL>(Pb, j, c_out, y);
     }
     __syncthreads();
+    TL_CLK(2);
     {  // x += row without a valid target ? 0 : out_proj(y)
       TBX_NEXT(E_OUT);
       const W& w = wb[E_OUT & 1];
@@ -156,12 +178,14 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       if (!FFN && t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
     }
     __syncthreads();
+    TL_CLK(3);
   }
 
   if constexpr (FFN) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.norm2_weight, t.norm2_bias, t.norm2_eps);
     __syncthreads();
+    TL_CLK(4);
     const bool drop_h = t.drop_thresh != 0u && t.drop_site[1] >= 0;
     DropKey4 dkh;
     if (drop_h) dkh.init(t.drop_seed, (uint32_t)t.drop_site[1], (uint32_t)t.drop_step, t.drop_thresh, t.drop_scale);
@@ -183,6 +207,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TBX_L1(3);
 #undef TBX_L1
     __syncthreads();
+    TL_CLK(5);
     {  // x += linear2(h): K = 512 in 4 units into one accumulator triple; x[invalid] = 0
       Acc acc;
       acc.zero();
@@ -211,12 +236,14 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       if (t.store_x && row_ok) gst4(t.x + grow * D + c_out, xv);
     }
     __syncthreads();
+    TL_CLK(6);
   }
 
   if constexpr (PROJ != 0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.proj_norm_weight, t.proj_norm_bias, t.proj_norm_eps);
     __syncthreads();
+    TL_CLK(7);
     {  // q
       TBX_NEXT(E_Q);
       const W& w = wb[E_Q & 1];
@@ -251,6 +278,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #undef TBX_KV
     }
     __syncthreads();
+    TL_CLK(8);
     {  // qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (one step, the head's own)
       TBX_NEXT(E_QF);
       const W& w = wb[E_QF & 1];
@@ -266,6 +294,10 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       }
     }
   }
+#ifdef TBX_STAGE_CLOCK
+  __builtin_amdgcn_s_waitcnt(0);  // the launch's stores have left
+#endif
+  TL_CLK(9);
 #undef TBX_NEXT
 }
 
@@ -414,3 +446,15 @@ extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
 #undef TBX_TL
   return TBX_ERR_UNSUPPORTED;
 }
+
+#ifdef TBX_STAGE_CLOCK
+extern "C" int tbx_debug_tl_dump(unsigned long long* host_out, int max_launches) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_launch), sizeof(n)) != hipSuccess) return -1;
+  const int m = (int)n < max_launches ? (int)n : max_launches;
+  if (m > 0 && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tl_clk), (size_t)m * 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_launch), &z, sizeof(z));
+  return m;
+}
+#endif
