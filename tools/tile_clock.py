@@ -49,6 +49,9 @@ def main():
             if c[j] > last:
                 print(f"    {PH[j - 1]:70s} {(c[j] - last) / 100.0:6.2f}")
                 last = c[j]
+        if c[14] > c[10] > 0:  # linear1's first unit taken apart (profiling build only)
+            print(f"    [linear1 unit 0: wait for its weights {(c[11] - c[10]) / 100.0:.2f}; load latency of the next unit {(c[12] - c[11]) / 100.0:.2f}; "
+                  f"LDS reads + 12 MFMAs + sum {(c[13] - c[12]) / 100.0:.2f}; relu / split / planes write {(c[14] - c[13]) / 100.0:.2f}]")
 
 
 if __name__ == "__main__":

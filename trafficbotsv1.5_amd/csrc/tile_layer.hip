@@ -201,7 +201,28 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     if (drop_h) h = dkh.apply(h, row0 + j, (R) * D + c_out, 4 * D);                             \
     planes_write4<PL>(Pb, j, (R) * D + c_out, h);                                                   \
   } while (0)
+#ifdef TBX_STAGE_CLOCK  // (stamps 10..14: linear1's first unit taken apart - its weights' arrival, the next unit's load latency, MFMAs, epilogue)
+    {
+      TL_CLK(10);
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) (lgkmcnt / expcnt free): this unit's weights are here
+      TL_CLK(11);
+      TBX_NEXT(E_L1);
+      __builtin_amdgcn_s_waitcnt(0x0070);  // ... and the next unit's: one unit's load latency, nothing else in flight
+      TL_CLK(12);
+      const W& w = wb[E_L1 & 1];
+      Acc acc;
+      acc.zero();
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s);
+      f32x4 h = relu4(acc.sum() + w.bias);
+      if (tl_slot < 256u) g_tl_clk[tl_slot * 16 + 13] = clock64() + (unsigned long long)(h[0] != h[0]);  // (after the MFMAs' results)
+      if (drop_h) h = dkh.apply(h, row0 + j, c_out, 4 * D);
+      planes_write4<PL>(Pb, j, c_out, h);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the planes are written
+      TL_CLK(14);
+    }
+#else
     TBX_L1(0);
+#endif
     TBX_L1(1);
     TBX_L1(2);
     TBX_L1(3);
