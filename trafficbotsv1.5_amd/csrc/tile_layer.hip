@@ -60,6 +60,10 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
   }
 }
 
+#ifndef TBX_TILE_RING
+#define TBX_TILE_RING 3
+#endif
+
 // profiling build (make clk): the LAST workgroup's wave 0 stamps the shader clock at the phase boundaries of every launch
 #ifdef TBX_STAGE_CLOCK
 __device__ unsigned long long g_tl_clk[256 * 16];
@@ -107,11 +111,19 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 
   constexpr int E_FOLD = 0, E_OUT = 1, E_L1 = ATTN ? 2 : 0, E_L2 = E_L1 + 4, E_Q = (ATTN ? 2 : 0) + (FFN ? 8 : 0);
   constexpr int E_KV = E_Q + 1, E_QF = E_Q + (PROJ == 2 ? 3 : 1), E_END = E_Q + (PROJ == 2 ? 4 : (PROJ == 1 ? 2 : 0));
-  W wb[2];
-  load_unit(wb[0], a.ent[0], wave, lane);
+  // weight units through a ring of RING register slots, RING - 1 units ahead of the stage that multiplies them. The ring is primed
+  // BEHIND the requests for the tile's own rows (memory answers a wave in order: 64 KiB of weights per unit in front of them delayed
+  // every stage of the launch)
+  constexpr int RING = TBX_TILE_RING;
+  W wb[RING];
 #define TBX_NEXT(E)                                                          \
   do {                                                                       \
-    if constexpr ((E) + 1 < E_END) load_unit(wb[((E) + 1) & 1], a.ent[(E) + 1], wave, lane); \
+    if constexpr ((E) + RING - 1 < E_END) load_unit(wb[((E) + RING - 1) % RING], a.ent[(E) + RING - 1], wave, lane); \
+  } while (0)
+#define TBX_PRIME()                                                          \
+  do {                                                                       \
+    _Pragma("unroll") for (int u = 0; u < RING - 1; ++u)                     \
+      if (u < E_END) load_unit(wb[u], a.ent[u], wave, lane);                 \
   } while (0)
 
   uint8_t f_nov = 0, f_inv = 0;
@@ -119,11 +131,12 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   if (FFN && t.src_invalid != nullptr) f_inv = *(const TBX_GLOBAL uint8_t*)(t.src_invalid + grow);
 
   // ---- the tile's token rows (and the attention output, split into planes; its first 128 columns also as fp32: the fold's addend)
-  {
-    const int r = tid >> 5, c4 = tid & 31;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < nv) v = gld4(t.x + (row0 + r) * D + c4 * 4);
-    *(f32x4*)(X + r * XLD + c4 * 4) = v;
+  const int xr = tid >> 5, xc4 = tid & 31;
+  f32x4 xv0 = {0.f, 0.f, 0.f, 0.f};
+  if (xr < nv) xv0 = gld4(t.x + (row0 + xr) * D + xc4 * 4);
+  if constexpr (!ATTN) {
+    TBX_PRIME();
+    *(f32x4*)(X + xr * XLD + xc4 * 4) = xv0;
   }
   if constexpr (ATTN) {
     f32x4 v[5];
@@ -136,6 +149,8 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (rr[i] < nv) v[i] = gld4(t.attn_out + (row0 + rr[i]) * (int64_t)t.ld_attn + cc[i] * 4);
     }
+    TBX_PRIME();
+    *(f32x4*)(X + xr * XLD + xc4 * 4) = xv0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       planes_write4<PL>(Pa, rr[i], cc[i] * 4, v[i]);
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   if constexpr (ATTN) {
     {  // value half of linear_rpe: y_h = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_h; wave w = head w / 2, 16 of its 32 channels
       TBX_NEXT(E_FOLD);
-      const W& w = wb[E_FOLD & 1];
+      const W& w = wb[E_FOLD % RING];
       Acc acc;
       acc.zero();
       const int step0 = 4 + 4 * (wave >> 1);
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TL_CLK(2);
     {  // x += row without a valid target ? 0 : out_proj(y)
       TBX_NEXT(E_OUT);
-      const W& w = wb[E_OUT & 1];
+      const W& w = wb[E_OUT % RING];
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_L1(R)                                                                               \
   do {                                                                                          \
     TBX_NEXT(E_L1 + (R));                                                                       \
-    const W& w = wb[(E_L1 + (R)) & 1];                                                          \
+    const W& w = wb[(E_L1 + (R)) % RING];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       TBX_NEXT(E_L1);
       __builtin_amdgcn_s_waitcnt(0x0070);  // ... and the next unit's: one unit's load latency, nothing else in flight
       TL_CLK(12);
-      const W& w = wb[E_L1 & 1];
+      const W& w = wb[E_L1 % RING];
       Acc acc;
       acc.zero();
       _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s);
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_L2(R)                                                                                         \
   do {                                                                                                    \
     TBX_NEXT(E_L2 + (R));                                                                                 \
-    const W& w = wb[(E_L2 + (R)) & 1];                                                                    \
+    const W& w = wb[(E_L2 + (R)) % RING];                                                                    \
     if ((R) == 0) bias = w.bias;                                                                          \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
   } while (0)
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TL_CLK(7);
     {  // q
       TBX_NEXT(E_Q);
-      const W& w = wb[E_Q & 1];
+      const W& w = wb[E_Q % RING];
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #define TBX_KV(R)                                                                               \
   do {                                                                                          \
     TBX_NEXT(E_KV + (R));                                                                       \
-    const W& w = wb[(E_KV + (R)) & 1];                                                          \
+    const W& w = wb[(E_KV + (R)) % RING];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TL_CLK(8);
     {  // qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (one step, the head's own)
       TBX_NEXT(E_QF);
-      const W& w = wb[E_QF & 1];
+      const W& w = wb[E_QF % RING];
       const int h = wave >> 1;
       const int qt_off = PROJ == 2 ? 3 * D : D;
 #pragma unroll
@@ -320,6 +335,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 #endif
   TL_CLK(9);
 #undef TBX_NEXT
+#undef TBX_PRIME
 }
 
 // tbx_pack_weight_mfma32 image of W_g [n x k] (g < groups; [k x n] with wt): T = groups * n / 16 tiles of 16 output channels, a
