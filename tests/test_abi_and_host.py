@@ -190,3 +190,31 @@ def test_graphed_train_step_refuses_without_the_ordered_memset_path(tb, monkeypa
             monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", bad)
         with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE=0"):
             DP.GraphedTrainStep(object(), object(), {})
+
+
+def test_schedule_switches_follow_the_environment_and_replace(tb, monkeypatch):
+    """engine.Schedule: every boolean switch is on by default except the opt-ins (measured slower: front_big, attn_fold_big, pool_proj;
+    a different arithmetic: kv_bf16, split_bf16), `TBX_<NAME>=0 / 1` flips it in from_env(), replace() leaves the original alone, and a
+    schedule is a value (two equal ones compare equal: engines are cached by it)."""
+    import dataclasses
+    from importlib import import_module
+
+    E = import_module("trafficbots_amd.engine")
+    for k in list(__import__("os").environ):
+        if k.startswith("TBX_"):
+            monkeypatch.delenv(k)
+    d = E.Schedule.from_env()
+    off = {"front_big", "attn_fold_big", "pool_proj", "kv_bf16", "split_bf16"}
+    bools = [f.name for f in dataclasses.fields(E.Schedule) if isinstance(getattr(d, f.name), bool)]
+    assert {"knn_aux_big", "prime_graph", "fused_tail", "front_fused", "dec_tail_mfma", "front_big"} <= set(bools)
+    for name in bools:
+        assert getattr(d, name) == (name not in off), name
+    assert d == E.Schedule.from_env() and hash(dataclasses.astuple(d)) == hash(dataclasses.astuple(E.Schedule.from_env()))
+    for name, env in (("knn_aux_big", "TBX_KNN_AUX_BIG"), ("prime_graph", "TBX_PRIME_GRAPH"), ("fused_tail", "TBX_FUSED_TAIL")):
+        monkeypatch.setenv(env, "0")
+        assert getattr(E.Schedule.from_env(), name) is False
+        monkeypatch.delenv(env)
+    monkeypatch.setenv("TBX_FRONT_BIG", "1")
+    assert E.Schedule.from_env().front_big is True
+    r = d.replace(knn_aux_big=False)
+    assert r.knn_aux_big is False and d.knn_aux_big is True and r != d
