@@ -1,0 +1,199 @@
+"""The timed closed-loop rollout of one workload on this rank: engine set-up, graph capture, device pre-roll, `--repeats` timed
+regions (W teacher-forced prime steps untimed + K closed-loop steps timed), new scenes through the same engine (end-to-end figure),
+and the per-kernel-class HIP-event pass the `roofline` object comes from. Reference loop: pl_modules/waymo_motion.py:118-204."""
+import os
+import time
+from importlib import import_module
+
+import torch
+
+from . import events
+from .args import shard_scenes
+
+
+def build(tb, args, dev, rank):
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    torch.manual_seed(0)
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    wm = wm.to(dev).eval()  # random init of the reference architecture (no checkpoint on the box)
+    # weak scaling: rank r simulates scenes [r*S, (r+1)*S) of the global list (seed = scene id)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    seeds = shard_scenes(args.scenes * world, rank, world)
+    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=seeds[0])
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    return wm, full
+
+
+def scene_on_device(tb, wm, args, dev, seed):
+    """A synthetic scene batch of this workload's shape (seed = scene id), pre-processed, resident in HBM."""
+    batch = tb.synthetic.make_scene(args.scenes, args.agents, args.polylines, args.lights, seed=seed)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    return wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+
+
+def engine_inputs(wm, bd, args, dev, n_step):
+    """Once-per-scene work (map encoder, traffic-light pre-compute, K/V tables) + the arguments of RolloutEngine.reset / refill."""
+    R = args.rollouts
+    mp, tl = wm.encode_scene(bd, n_rollout=R)
+    r = (lambda t: t.repeat_interleave(R, 0)) if R > 1 else (lambda t: t)
+    n, A = args.scenes * R, args.agents
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(n, A, 16, generator=g).to(dev)  # prior sample (std-normal), injected
+    valid = r(bd["sc/ag_valid"].any(-1))
+    tf = wm.teacher_forcing_joint_future_pred
+    tf.init(ag_valid=r(bd["sc/ag_valid"]), ag_pose=r(bd["sc/ag_pose"]), ag_motion=r(bd["sc/ag_motion"]),
+            tl_state=r(bd["sc/tl_state"]), current_epoch=0)
+    return dict(gt_valid=r(bd["sc/ag_valid"]), gt_pose=r(bd["sc/ag_pose"]), gt_motion=r(bd["sc/ag_motion"]),
+                tl_state_gt=r(bd["sc/tl_state"]), tf_mask=tf.ag_teacher_forcing, ag_type=r(bd["ref/ag_type"]),
+                ag_attr=r(bd["sc/ag_attr"]), ag_latent=z, ag_latent_valid=valid, ag_navi=r(bd["gt/ag_navi"]), ag_navi_valid=valid,
+                mp_tokens=mp, tl_tokens=tl, map_valid=bd["map/valid"], map_type=bd["map/type"], map_pos=bd["map/pos"],
+                map_dir=bd["map/dir"], map_boundary=bd["map/boundary"], n_step=n_step)
+
+
+def gpu_rollout_setup(tb, wm, full, args, dev):
+    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+    t0 = time.perf_counter()
+    kw = engine_inputs(wm, bd, args, dev, args.warmup + args.steps + 2 * args.profile_steps)
+    torch.cuda.synchronize()
+    t_scene = time.perf_counter() - t0
+    Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
+    eng.reset(**kw)
+    return eng, t_scene
+
+
+def measure(a, tb, hip, dev, rank, world, dist):
+    """-> (result dict, wm, full). The result holds `value`, `ms_per_step`, the repeats, `config`, `roofline`, `kernels`, the
+    end-to-end figures; report.py decides what of it goes on the judged line."""
+    E = import_module("trafficbots_amd.engine")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    wm, full = build(tb, a, dev, rank)
+    # (a timed region shorter than --graph-steps: one graph of all of it; after an odd number of warm-up steps the light tables'
+    # double buffer is at parity 1 and the multi-step graph, captured at parity 0, starts one step in)
+    gsteps = max(1, min(a.graph_steps, a.steps - (a.warmup % 2)) // 2 * 2)
+    # this measurement's schedule belongs to its module / engine (engine.Schedule), not to the process
+    wm.schedule = E.DEFAULT.replace(kv_bf16=bool(a.kv_bf16), lights_ahead=not a.no_lights_ahead, graph_steps=gsteps)
+    eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
+    use_graph = not a.no_graph
+    t_cap = time.perf_counter()
+    if use_graph:
+        eng.capture()
+        torch.cuda.synchronize()
+    t_cap = time.perf_counter() - t_cap
+    # device pre-roll (untimed, not part of W): the timed region is ~25 ms of a chain of 20-40 us launches, and a device that
+    # was idle a moment ago runs its first hundreds of milliseconds below its steady clocks (the same binary measured 193 k,
+    # 195 k, 200 k agent-steps/s in three consecutive processes). Whole rollouts are replayed and rewound until
+    # --pre-roll-ms of wall time have passed.
+    t_pre, n_pre = time.perf_counter(), 0
+    while use_graph and (time.perf_counter() - t_pre) * 1e3 < a.pre_roll_ms:
+        eng.run(a.warmup + a.steps, use_graph=True)
+        torch.cuda.synchronize()
+        eng.restore()
+        n_pre += 1
+    dts = []
+    for rep in range(max(1, a.repeats)):  # the region is timed >= 3 times; median and minimum are reported
+        if rep:
+            eng.restore()
+        eng.run(a.warmup, use_graph=use_graph)  # teacher-forced prime steps (untimed)
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(a.steps, use_graph=use_graph)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
+    dt = sorted(dts)[len(dts) // 2]
+    units = world * a.scenes * a.rollouts * a.agents * a.steps
+    timing = {"value": units / dt, "ms_per_step": dt / a.steps * 1e3, "repeats": len(dts), "ms_per_step_min": min(dts) / a.steps * 1e3,
+              "ms_per_step_all": [d / a.steps * 1e3 for d in dts], "value_best": units / min(dts)}
+    # ---- scene-to-scene reuse (the reference's validation_step loops over scenes, waymo_motion.py:526): NEW scenes through the
+    # same engine - once-per-scene encoders + RolloutEngine.refill (in place: the captured graphs stay valid) + the W prime and K
+    # closed-loop steps, everything timed; scene tensors resident in HBM as in the headline. No graph capture in this loop.
+    reuse = None
+    if use_graph and a.new_scenes > 0 and world == 1:
+        first = shard_scenes(a.scenes * world, rank, world)[0]
+        n_all = a.warmup + a.steps + 2 * a.profile_steps
+        bds = [scene_on_device(tb, wm, a, dev, first + 1000 + i) for i in range(a.new_scenes)]
+        with E.use(wm.schedule):
+            # two untimed scenes first (refill + rollout): the first refills of a process pay one-time costs (allocator growth;
+            # measured 90 ms, once, in the first OR the second refill) - the figure is the steady state of a loop over scenes
+            for w_ in range(2):
+                eng.refill(**engine_inputs(wm, scene_on_device(tb, wm, a, dev, first + 998 + w_), a, dev, n_all))
+                eng.run(a.warmup + a.steps, use_graph=True)
+        torch.cuda.synchronize()
+        t_enc, t_all = [], time.perf_counter()
+        with E.use(wm.schedule):
+            for bd in bds:
+                torch.cuda.synchronize()  # (attribution only: the previous scene's rollout is done before this one's clock starts)
+                t0 = time.perf_counter()
+                eng.refill(**engine_inputs(wm, bd, a, dev, n_all))
+                torch.cuda.synchronize()
+                t_enc.append(time.perf_counter() - t0)
+                eng.run(a.warmup + a.steps, use_graph=True)
+            torch.cuda.synchronize()
+        t_all = time.perf_counter() - t_all
+        reuse = {"scenes": a.new_scenes, "new_scene_ms": sorted(t_enc)[len(t_enc) // 2] * 1e3, "new_scene_ms_all": [t * 1e3 for t in t_enc],
+                 "end_to_end_value": a.new_scenes * a.scenes * a.rollouts * a.agents * a.steps / t_all,
+                 "ms_per_scene": t_all / a.new_scenes * 1e3,
+                 "note": "per new scene: map encoder + light pre-compute + K/V tables + RolloutEngine.refill (new_scene_ms), then W prime + K "
+                         "closed-loop steps on the graphs captured once for this shape; end_to_end_value counts the K steps' agent-steps "
+                         "over ALL of that time"}
+        eng.restore()
+    workload = {"workload": f"{a.agents}-agent/{a.polylines}-polyline/{a.lights}-light synthetic scene, "
+                            f"{a.warmup}-step teacher-forced prime + {a.steps}-step closed-loop rollout",
+                "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
+                "steps_per_graph_replay": gsteps if use_graph else 0,
+                "pre_roll_rollouts": n_pre,  # untimed whole-rollout replays before the W warm-up steps (device at steady clocks)
+                "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
+                "weights": "random init of the 10,657,094-parameter default architecture"}
+    if a.profile_steps <= 0:  # tooling only (timeline traces, A/B runs, the scenes-per-GPU curve): no per-kernel timing pass
+        return {**timing, "config": workload, "roofline": None, "kernels": None,
+                "note": "--profile-steps 0: no per-kernel timing pass, not a judged line",
+                "scene_encode_ms": t_scene * 1e3, "graph_capture_ms": t_cap * 1e3,
+                "finite": bool(torch.isfinite(eng.S["out_pose"]).all())}, wm, full
+    # ---- live per-kernel timing: eager steps right after the timed region, same state and the SAME launches as the timed
+    # schedule, events on the launch stream, in the engine's one-stream order so that a kernel's duration is its own (in the
+    # timed region the light and agent halves share the device, which stretches the kernels of both)
+    eng.sched = eng.sched.replace(lights_ahead=False)
+    # the host must be AHEAD of the device while the events are recorded: an event pair around a launch otherwise also
+    # times the wait for the host to enqueue that launch (seen on a loaded box: 27 us "launches" of a 10 us kernel).
+    # A device-side delay in front lets the host queue all launches of the profiled steps first.
+    torch.cuda._sleep(int(2.4e9 * (0.01 + 0.006 * a.profile_steps)))
+    with events.KernelEvents(hip) as ke:
+        eng.run(a.profile_steps, use_graph=False)
+    classes = ke.classes(a.profile_steps)
+    products = int(getattr(eng.sched, "mfma_products", 3))
+    kernels = [events.kernel_entry(a, c, products) for c in classes]
+    # the judged object: the kernel class the largest share of the step's kernel time goes to
+    roof = dict(next(k for k in kernels if k["bound"] != "latency"))
+    cnt = events.attn_counters(a)
+    att = next((k for k in kernels if k["class"] == "attn" and k["source_rows_per_launch"] >= 1024), None)
+    if cnt and att is not None:
+        if cnt.get("l2_read_requests_per_launch"):  # 128-byte L1 -> L2 read requests of a launch over its live duration
+            cnt["l2_request_frac"] = cnt["l2_read_requests_per_launch"] * 128.0 / (att["avg_launch_us"] * 1e-6) / 1e9 / events.L2_PEAK_GBS
+        att["counters"] = cnt
+    res = {
+        **timing,
+        "config": workload,
+        "roofline": roof,
+        "kernels": kernels,  # every kernel class of the step, largest share first (roofline = the first non-elementwise one)
+        "roofline_gemm": events.gemm_summary(kernels),
+        "scene_encode_ms": t_scene * 1e3, "graph_capture_ms": t_cap * 1e3,
+        # SURVEY §8d "end-to-end": the once-per-scene work (map encoder, traffic-light pre-compute, K/V tables, engine refill)
+        # counted into the same units, over new scenes rolled through the SAME engine; the first scene of a process additionally
+        # pays scene_encode_ms (cold: allocations, weight packing) and graph_capture_ms once per shape
+        "end_to_end_value": reuse["end_to_end_value"] if reuse else units / (dt + t_scene),
+        "scene_reuse": reuse,
+        "first_scene_value": units / (dt + t_scene + t_cap),
+        "finite": bool(torch.isfinite(eng.S["out_pose"]).all()),
+    }
+    return res, wm, full
