@@ -88,6 +88,14 @@ int tbx_knn_embed_multi_pe(const tbx_knn_job_t* jobs /* host */, int n_jobs, con
 int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_xy, const float* freqs_yaw, int pe_dim, float* out,
                    int ld_out, int col_off, void* stream);
 
+/* utils/rpe.py:8-37 (get_rel_pose) / :41-58 (get_rel_dist) as DENSE tensors - the reference's stand-alone utility functions; the
+ * hot path never materialises them (tbx_knn_embed ranks and gathers in registers). Same expressions as the search: a dense distance
+ * equals the key tbx_knn_embed ranks by, bit for bit.
+ *   rel_pose [n_batch, n_src, n_tgt, 3] (may be NULL)   rotated offset into the source frame, un-wrapped yaw difference
+ *   rel_dist [n_batch, n_src, n_tgt]    (may be NULL)   |rotated offset|, +inf where source or target is invalid */
+int tbx_rel_pose_dense(const float* src_pose, const uint8_t* src_invalid, const float* tgt_pose, const uint8_t* tgt_invalid,
+                       int n_batch, int n_src, int n_tgt, int tgt_batch_div, float* rel_pose, float* rel_dist, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K6: fused KNARPE attention (gather + relative-pose bias + ragged masked softmax + weighted sum).
  * Replaces modules/attention_rpe.py:137-190 (rpe branch, apply_q_rpe = False) in the exact factorised form
@@ -799,6 +807,14 @@ int tbx_sim_step_parts(const tbx_sim_state_t* st /* host */, int parts, void* st
  * tbx_sim_step_parts. */
 int tbx_sim_step_tl_prep(const tbx_sim_state_t* st /* host */, int parts, const uint8_t* tl_invalid, int ld_attr, float* attr,
                          uint8_t* row_invalid, void* stream);
+
+/* utils/rewards.py:35-85 (DifferentiableReward.get, default configuration: the three imitation terms; w_collision = 0) for ONE step
+ * on caller-supplied tensors - what tbx_sim_step logs into out_reward, as a call of its own. n = n_sc * n_ag rows.
+ *   out4 [n, 4] = r_imitation_pos, r_imitation_rot ("cosine", metrics/loss.py:9-36), r_imitation_spd, diffbar_reward = (pos + rot) + spd
+ *   out_valid [n] = pred_valid & gt_valid  (gt_valid NULL: pred_valid, all terms 0 - rewards.py:49-57) */
+int tbx_diffbar_reward(const uint8_t* pred_valid, const float* pred_pose, const float* pred_motion, const uint8_t* gt_valid,
+                       const float* gt_pose, const float* gt_motion, int64_t n, float w_pos, float w_rot, float w_spd, float* out4,
+                       uint8_t* out_valid, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -218,3 +218,40 @@ def test_schedule_switches_follow_the_environment_and_replace(tb, monkeypatch):
     assert E.Schedule.from_env().front_big is True
     r = d.replace(knn_aux_big=False)
     assert r.knn_aux_big is False and d.knn_aux_big is True and r != d
+
+
+def test_training_metrics_class_equals_the_captured_steps_loss(tb):
+    """models/metrics/training.py::TrainingMetrics (the reference-shaped accumulator: update(buffer, ...) / compute()) and
+    train_graph.training_loss (the fused expression the captured training step uses, itself checked against the reference's golden
+    loss dict in tests/test_hip_training.py) give the same numbers on the same rollout log - both switch settings of
+    loss_for_teacher_forcing, and a batch without a valid light drops its term the way the reference's `if counter > 0` does."""
+    from importlib import import_module
+    from types import SimpleNamespace
+
+    TG = import_module("trafficbots_amd.train_graph")
+    TM = import_module("trafficbots_amd.models.metrics.training")
+    D = import_module("trafficbots_amd.models.modules.distributions")
+    g = torch.Generator().manual_seed(0)
+    n, A, T, L, M = 3, 9, 30, 5, 20
+    r = lambda *s: torch.rand(*s, generator=g)
+    for tf_loss, no_lights in ((True, False), (False, False), (True, True)):
+        cfg = tb.config.default_sim_cfg()["training_metrics"]
+        cfg["loss_for_teacher_forcing"] = tf_loss
+        ro = dict(pred_valid=r(n, A, T) < 0.8, tf=r(n, A, T) < 0.2, reward_valid=r(n, A, T) < 0.9, reward=-r(n, A, T),
+                  tl_nll_invalid=(r(n, L, T) < 0.3) | no_lights, tl_nll=r(n, L, T))
+        post = D.DiagGaussian(torch.randn(n, A, 16, generator=g), torch.randn(n, A, 16, generator=g) * 0.3, valid=r(n, A) < 0.9)
+        prior = D.DiagGaussian(torch.zeros(n, A, 16), torch.zeros(16), valid=r(n, A) < 0.8)
+        navi = D.DestCategorical(logits=torch.randn(n, A, M, generator=g), valid=r(n, A) < 0.9)
+        navi_gt = torch.randint(0, M, (n, A), generator=g)
+        want = TG.training_loss(cfg, ro, navi, navi_gt, post, prior)
+        buf = SimpleNamespace(pred_valid=ro["pred_valid"], mask_teacher_forcing=ro["tf"], tl_state_nll=ro["tl_nll"],
+                              tl_state_nll_invalid=ro["tl_nll_invalid"],
+                              diffbar_reward={"diffbar_reward_valid": ro["reward_valid"], "diffbar_reward": ro["reward"]})
+        m = TM.TrainingMetrics(prefix="training", train_navi=True, train_latent=True, **cfg)
+        got = m(buf, None, navi, navi_gt, post, prior)
+        for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss"):
+            torch.testing.assert_close(got[f"training/{k}"], want[k], rtol=1e-6, atol=1e-6)
+        if no_lights:
+            assert "training/tl_state_loss" not in got and float(want["tl_state_loss"]) == 0.0
+        else:
+            torch.testing.assert_close(got["training/tl_state_loss"], want["tl_state_loss"], rtol=1e-6, atol=1e-6)

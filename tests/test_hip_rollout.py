@@ -238,6 +238,35 @@ def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
             assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
 
 
+@pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
+def test_front_without_rider_fills_the_navigation_embedding(tb, sizes, knn):
+    """tbx_front without the navigation rider and without an auxiliary stream (Schedule(lights_ahead=False, navi_rider=False): the
+    one-stream order, the heads chain reads prep["navi_pe"]): the destination's pose embedding must ride in THAT launch as its
+    pose-embedding job - the rollout equals, bit for bit, the one with the three launches (front_fused=False), whose searches carry
+    the job. (Round 3 left the buffer uninitialised in this combination: ADVICE r03.)"""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    E = import_module("trafficbots_amd.engine")
+    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    z = torch.randn(1, sizes[0], 16, generator=torch.Generator().manual_seed(4)).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    outs = {}
+    for front in (False, True):
+        for rides in (True, False):
+            wm.schedule = E.DEFAULT.replace(lights_ahead=False, navi_rider=False, front_fused=front, pe_rides=rides)
+            # poison the allocator's free blocks: an unfilled torch.empty buffer then shows as NaN instead of a lucky stale copy
+            junk = torch.full((1 << 22,), float("nan"), device=dev)
+            del junk
+            outs[front, rides] = wm.reactive_replay(bd, mp, tl, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred,
+                                                    True, step_end=20, use_graph=False)
+    ref = outs[False, True]
+    assert bool(torch.isfinite(ref.pred_pose).all())
+    for k, o in outs.items():
+        for name in ("pred_pose", "pred_valid", "pred_motion", "action_log_prob"):
+            assert torch.equal(getattr(o, name), getattr(ref, name)), (k, name)
+        assert torch.equal(o.vis_dict["action"], ref.vis_dict["action"]), k
+
+
 def test_action_head_branches_follow_the_type_masks(tb):
     """The heads in the last decoder layer's launch compute only the action-head branches a row's type-mask bytes let through
     (tbx_heads_tail_t.type_mask; action_head.py:64-100 sums one branch per agent type). One policy evaluation on masks a real scene

@@ -158,13 +158,9 @@ extern "C" int tbx_front(const tbx_front_t* args, void* stream) {
   } else if (args->pe != nullptr) {
     return TBX_ERR_ARG;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)front_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)front_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
-      return TBX_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)front_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)front_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const dim3 grid((unsigned)(a.n_win_blocks + a.n_rider_blocks + a.n_knn_blocks));
   if (w.d_mlp == 64)
     hipLaunchKernelGGL((front_kernel<64, false>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);

@@ -159,3 +159,43 @@ extern "C" int tbx_pose_embed(const float* pose3, int64_t n, const float* freqs_
                      freqs_xy, freqs_yaw, pe_dim, out, ld_out, col_off);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
+
+// utils/rpe.py:8-58 as dense tensors (the stand-alone `get_rel_pose` / `get_rel_dist` of the reference): one thread per (source,
+// target) pair, the SAME expressions as the K-nearest search above (tbx_knn::rel_xy, un-fused distance), so a dense distance equals
+// the key the search ranks by, bit for bit.
+namespace {
+__global__ __launch_bounds__(256) void rel_pose_dense_kernel(const float* __restrict__ src_pose, const uint8_t* __restrict__ src_invalid,
+                                                             const float* __restrict__ tgt_pose, const uint8_t* __restrict__ tgt_invalid,
+                                                             int64_t n_pairs, int n_src, int n_tgt, int tgt_batch_div,
+                                                             float* __restrict__ rel_pose, float* __restrict__ rel_dist) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int64_t row = p / n_tgt;
+  const int j = (int)(p - row * n_tgt);
+  const int64_t bt = (row / n_src) / tgt_batch_div;
+  const float x1 = src_pose[row * 3], y1 = src_pose[row * 3 + 1], yaw1 = src_pose[row * 3 + 2];
+  const float* t = tgt_pose + (bt * n_tgt + j) * 3;
+  float rx, ry;
+  tbx_knn::rel_xy(x1, y1, cosf(yaw1), sinf(yaw1), t[0], t[1], rx, ry);
+  if (rel_pose != nullptr) {
+    rel_pose[p * 3] = rx;
+    rel_pose[p * 3 + 1] = ry;
+    rel_pose[p * 3 + 2] = __fsub_rn(t[2], yaw1);  // not wrapped (rpe.py:32, cast=False)
+  }
+  if (rel_dist != nullptr) {
+    const bool inv = src_invalid[row] != 0 || tgt_invalid[bt * n_tgt + j] != 0;
+    rel_dist[p] = inv ? INFINITY : __fsqrt_rn(__fmaf_rn(ry, ry, __fmul_rn(rx, rx)));
+  }
+}
+}  // namespace
+
+extern "C" int tbx_rel_pose_dense(const float* src_pose, const uint8_t* src_invalid, const float* tgt_pose, const uint8_t* tgt_invalid,
+                                  int n_batch, int n_src, int n_tgt, int tgt_batch_div, float* rel_pose, float* rel_dist, void* stream) {
+  if (!src_pose || !src_invalid || !tgt_pose || !tgt_invalid || (!rel_pose && !rel_dist)) return TBX_ERR_ARG;
+  if (n_batch <= 0 || n_src <= 0 || n_tgt <= 0 || tgt_batch_div <= 0 || n_batch % tgt_batch_div != 0) return TBX_ERR_ARG;
+  const int64_t n_pairs = (int64_t)n_batch * n_src * n_tgt;
+  if ((n_pairs + 255) / 256 > 0x7fffffff) return TBX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rel_pose_dense_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_pose,
+                     src_invalid, tgt_pose, tgt_invalid, n_pairs, n_src, n_tgt, tgt_batch_div, rel_pose, rel_dist);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

@@ -183,3 +183,40 @@ extern "C" int tbx_sim_step_tl_prep(const tbx_sim_state_t* st, int parts, const 
   }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
+
+// utils/rewards.py:35-85 (DifferentiableReward.get, default configuration: imitation terms, w_collision = 0) for ONE step as a
+// call of its own: the expressions of tbx_sim_step's log (step_core.h) on caller-supplied prediction / ground truth.
+namespace {
+using tbx_step::sim_sl1;
+__global__ __launch_bounds__(256) void diffbar_reward_kernel(const uint8_t* __restrict__ pred_valid, const float* __restrict__ pred_pose,
+                                                             const float* __restrict__ pred_motion, const uint8_t* __restrict__ gt_valid,
+                                                             const float* __restrict__ gt_pose, const float* __restrict__ gt_motion,
+                                                             int64_t n, float w_pos, float w_rot, float w_spd, float* __restrict__ out4,
+                                                             uint8_t* __restrict__ out_valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool r_valid = pred_valid[i] != 0;
+  float r_pos = 0.f, r_rot = 0.f, r_spd = 0.f;
+  if (gt_valid != nullptr) {
+    r_valid = r_valid && gt_valid[i] != 0;
+    if (r_valid) {
+      r_pos = -w_pos * (sim_sl1(gt_pose[i * 3] - pred_pose[i * 3]) + sim_sl1(gt_pose[i * 3 + 1] - pred_pose[i * 3 + 1]));
+      r_rot = -w_rot * (0.5f * (1.f - cosf(gt_pose[i * 3 + 2] - pred_pose[i * 3 + 2])));
+      r_spd = -w_spd * sim_sl1(gt_motion[i * 3] - pred_motion[i * 3]);
+    }
+  }
+  out4[i * 4] = r_pos, out4[i * 4 + 1] = r_rot, out4[i * 4 + 2] = r_spd;
+  out4[i * 4 + 3] = (r_pos + r_rot) + r_spd;
+  out_valid[i] = r_valid ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int tbx_diffbar_reward(const uint8_t* pred_valid, const float* pred_pose, const float* pred_motion, const uint8_t* gt_valid,
+                                  const float* gt_pose, const float* gt_motion, int64_t n, float w_pos, float w_rot, float w_spd,
+                                  float* out4, uint8_t* out_valid, void* stream) {
+  if (!pred_valid || !pred_pose || !pred_motion || !out4 || !out_valid || n <= 0) return TBX_ERR_ARG;
+  if (gt_valid != nullptr && (!gt_pose || !gt_motion)) return TBX_ERR_ARG;
+  hipLaunchKernelGGL(diffbar_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_valid, pred_pose,
+                     pred_motion, gt_valid, gt_pose, gt_motion, n, w_pos, w_rot, w_spd, out4, out_valid);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}

@@ -143,11 +143,8 @@ extern "C" int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const 
   if (ldx < k || ldy < n || (ldx % 4) || (ldy % 4)) return TBX_ERR_ARG;
   if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)image)) & 15) return TBX_ERR_ALIGN;
   TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu};
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tall_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return TBX_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tall_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const int64_t n_rb = (m + ROWS - 1) / ROWS;
   static const int grid_max = [] { const char* e = getenv("TBX_TALL_GRID"); return e ? atoi(e) : 256; }();  // one workgroup per CU, striding over the row blocks
   hipLaunchKernelGGL(tall_linear_kernel, dim3((unsigned)(n_rb < grid_max ? n_rb : grid_max)), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);

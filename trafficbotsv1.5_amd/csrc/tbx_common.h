@@ -4,7 +4,26 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace tbx {
+
+// Host side: hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel, and launches come from several
+// host threads (a training step is captured on a thread of its own). One of these per launch site: `set` runs once per device
+// (a bit per device ordinal; two threads racing both set the same value - idempotent), failures are reported every time.
+struct PerDeviceOnce {
+  std::atomic<uint64_t> done{0};
+  template <class F>
+  bool operator()(F&& set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set();
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (!set()) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+  }
+};
 
 // Cross-lane exchange without the LDS crossbar: DPP modifiers inside a 16-lane row (they fuse into the consuming
 // v_add / v_max) and the gfx950 v_permlane{16,32}_swap for the two cross-row steps. Each helper returns exactly what the

@@ -310,13 +310,9 @@ extern "C" int tbx_heads_tile(const tbx_heads_tile_t* args, void* stream) {
   for (int r = 0; r < 3; ++r) put(t.images[7], 8 * r);
   put(t.images[8], 0);
   for (; e < 24; ++e) a.ent[e].img = nullptr, a.ent[e].unit0 = 0, a.ent[e].pad = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tile_heads_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)tile_heads_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
-      return TBX_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tile_heads_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tile_heads_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const dim3 grid((unsigned)((t.n_rows + ROWS - 1) / ROWS));
   if (raw)
     hipLaunchKernelGGL(tile_heads_kernel<true>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);

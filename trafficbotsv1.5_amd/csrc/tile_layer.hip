@@ -399,12 +399,8 @@ int64_t mfma32_units(int n, int k, int groups) {
 
 template <bool ATTN, bool FFN, int PROJ>
 int launch(const TileArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tile_layer_kernel<ATTN, FFN, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
-      return TBX_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tile_layer_kernel<ATTN, FFN, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const unsigned grid = (unsigned)((a.t.n_rows + ROWS - 1) / ROWS) + (unsigned)((a.t.rider_rows + ROWS - 1) / ROWS);
   hipLaunchKernelGGL((tile_layer_kernel<ATTN, FFN, PROJ>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

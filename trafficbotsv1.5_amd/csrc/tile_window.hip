@@ -41,13 +41,9 @@ extern "C" int tbx_window_tile(const tbx_window_tile_t* args, void* stream) {
   if (t.drop_thresh != 0u && t.drop_seed == nullptr) return TBX_ERR_ARG;
   WindowArgs a;
   a.t = t;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tile_window_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)tile_window_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess)
-      return TBX_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tile_window_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tile_window_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const dim3 grid((unsigned)((t.n_groups + RT - 1) / RT));
   if (t.d_mlp == 64)
     hipLaunchKernelGGL((tile_window_kernel<64, false>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);

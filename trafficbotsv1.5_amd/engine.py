@@ -101,16 +101,46 @@ class Schedule:
 
     @classmethod
     def from_env(cls) -> "Schedule":
-        on = lambda name, d="1": _env(name, d) != "0"
-        return cls(fused_residual=on("TBX_FUSED_RESIDUAL"), load2=on("TBX_LOAD2"), attn_fold=on("TBX_ATTN_FOLD"),
-                   attn_fold_big=_env("TBX_ATTN_FOLD_BIG", "0") == "1", dec_mid=on("TBX_DEC_MID"), dec_layer=on("TBX_DEC_LAYER"),
-                   heads_tail=on("TBX_HEADS_TAIL"), tail_split=on("TBX_TAIL_SPLIT"), rowzero=on("TBX_ROWZERO"),
-                   masked_groupmax=on("TBX_MASKED_GROUPMAX"), big_rows=int(_env("TBX_BIG_ROWS", "16384")),
-                   live_rows=int(_env("TBX_LIVE_ROWS", "1")), live_max=int(_env("TBX_LIVE_MAX", "512")),
-                   kv_bf16=_env("TBX_KV_BF16", "0") == "1", pool_proj=_env("TBX_POOL_PROJ", "0") == "1",
-                   split_bf16=_env("TBX_SPLIT_BF16", "0") == "1", tile_layer=on("TBX_TILE_LAYER"),
-                   tile_min_rows=int(_env("TBX_TILE_MIN_ROWS", "1024")), tile_small=on("TBX_TILE_SMALL"), dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"), knn_main=on("TBX_KNN_MAIN"), navi_rider=on("TBX_NAVI_RIDER"), fused_tail=on("TBX_FUSED_TAIL"), front_fused=on("TBX_FRONT_FUSED"), front_big=_env("TBX_FRONT_BIG", "0") == "1", knn_aux_big=on("TBX_KNN_AUX_BIG"), prime_graph=on("TBX_PRIME_GRAPH"), sim_before_join=on("TBX_SIM_BEFORE_JOIN"), pe_rides=on("TBX_PE_RIDES"), tl_prep_rides=on("TBX_TL_PREP_RIDES"),
-                   graph_steps=max(1, int(_env("TBX_GRAPH_STEPS", "4")) // 2 * 2), hoist_constants=os.environ.get("TBX_NO_HOIST") is None)
+        """Every switch from its TBX_* environment variable (read once, at import). "1" / "0" for the booleans."""
+        on = lambda name: _env(name, "1") != "0"        # default on
+        off = lambda name: _env(name, "0") == "1"       # default off
+        num = lambda name, d: int(_env(name, str(d)))
+        return cls(
+            fused_residual=on("TBX_FUSED_RESIDUAL"),
+            load2=on("TBX_LOAD2"),
+            attn_fold=on("TBX_ATTN_FOLD"),
+            attn_fold_big=off("TBX_ATTN_FOLD_BIG"),
+            dec_mid=on("TBX_DEC_MID"),
+            dec_layer=on("TBX_DEC_LAYER"),
+            heads_tail=on("TBX_HEADS_TAIL"),
+            tail_split=on("TBX_TAIL_SPLIT"),
+            rowzero=on("TBX_ROWZERO"),
+            masked_groupmax=on("TBX_MASKED_GROUPMAX"),
+            big_rows=num("TBX_BIG_ROWS", 16384),
+            live_rows=num("TBX_LIVE_ROWS", 1),
+            live_max=num("TBX_LIVE_MAX", 512),
+            kv_bf16=off("TBX_KV_BF16"),
+            pool_proj=off("TBX_POOL_PROJ"),
+            split_bf16=off("TBX_SPLIT_BF16"),
+            tile_layer=on("TBX_TILE_LAYER"),
+            tile_min_rows=num("TBX_TILE_MIN_ROWS", 1024),
+            tile_small=on("TBX_TILE_SMALL"),
+            prime_graph=on("TBX_PRIME_GRAPH"),
+            knn_aux_big=on("TBX_KNN_AUX_BIG"),
+            front_big=off("TBX_FRONT_BIG"),
+            front_fused=on("TBX_FRONT_FUSED"),
+            fused_tail=on("TBX_FUSED_TAIL"),
+            navi_rider=on("TBX_NAVI_RIDER"),
+            knn_main=on("TBX_KNN_MAIN"),
+            sim_before_join=on("TBX_SIM_BEFORE_JOIN"),
+            dec_tail_mfma=on("TBX_DEC_TAIL_MFMA"),
+            pe_rides=on("TBX_PE_RIDES"),
+            tl_prep_rides=on("TBX_TL_PREP_RIDES"),
+            lights_ahead=on("TBX_LIGHTS_AHEAD"),
+            graph_steps=max(1, num("TBX_GRAPH_STEPS", 4) // 2 * 2),
+            share_lights=on("TBX_SHARE_LIGHTS"),
+            hoist_constants=os.environ.get("TBX_NO_HOIST") is None,
+        )
 
     def replace(self, **kw) -> "Schedule":
         return dataclasses.replace(self, **kw)

@@ -197,6 +197,8 @@ def load():
     i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
     lib.tbx_knn_embed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.tbx_pose_embed.argtypes = [vp, i64, vp, vp, i32, vp, i32, i32, vp]
+    lib.tbx_rel_pose_dense.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.tbx_diffbar_reward.argtypes = [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
@@ -266,7 +268,8 @@ def load():
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
     for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures"):
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures",
+                 "tbx_rel_pose_dense", "tbx_diffbar_reward"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -362,6 +365,32 @@ def _knn_jobs(jobs, pe_dim: int = 128):
                        q.get("tgt_batch_div", 1), k, float(q["dist_limit"]))
         outs.append((idx, inv, rel, emb))
     return outs, cj
+
+
+def rel_pose_dense(src_pose, src_invalid, tgt_pose, tgt_invalid, tgt_batch_div: int = 1, want_rel_pose: bool = True, want_dist: bool = True):
+    """utils/rpe.py:8-58 as dense tensors -> rel_pose f32 [n,S,T,3] | None, rel_dist f32 [n,S,T] | None (+inf on invalid pairs)."""
+    n, S, _ = src_pose.shape
+    T = tgt_pose.shape[1]
+    dev = src_pose.device
+    rel = torch.empty(n, S, T, 3, dtype=torch.float32, device=dev) if want_rel_pose else None
+    dist = torch.empty(n, S, T, dtype=torch.float32, device=dev) if want_dist else None
+    _check(load().tbx_rel_pose_dense(_cptr(src_pose, torch.float32), _cptr(src_invalid, torch.uint8), _cptr(tgt_pose, torch.float32),
+                                     _cptr(tgt_invalid, torch.uint8), n, S, T, tgt_batch_div, _ptr(rel), _ptr(dist), stream_ptr()),
+           "tbx_rel_pose_dense")
+    return rel, dist
+
+
+def diffbar_reward(pred_valid, pred_pose, pred_motion, gt_valid, gt_pose, gt_motion, w_pos: float, w_rot: float, w_spd: float):
+    """utils/rewards.py:35-85 for one step -> (out4 f32 [..., 4] = pos, rot, spd, sum; valid u8 [...]). gt_valid None: no imitation terms."""
+    n = pred_valid.numel()
+    out4 = torch.empty(*pred_valid.shape, 4, dtype=torch.float32, device=pred_pose.device)
+    ov = torch.empty(pred_valid.shape, dtype=torch.uint8, device=pred_pose.device)
+    has_gt = gt_valid is not None
+    _check(load().tbx_diffbar_reward(_cptr(pred_valid, torch.uint8), _cptr(pred_pose, torch.float32), _cptr(pred_motion, torch.float32),
+                                     _cptr(gt_valid, torch.uint8) if has_gt else None, _cptr(gt_pose, torch.float32) if has_gt else None,
+                                     _cptr(gt_motion, torch.float32) if has_gt else None, n, float(w_pos), float(w_rot), float(w_spd),
+                                     _ptr(out4), _ptr(ov), stream_ptr()), "tbx_diffbar_reward")
+    return out4, ov
 
 
 def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int = 0):

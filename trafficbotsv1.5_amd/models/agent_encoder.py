@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import current as engine_current, drop_site, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
+from ..engine import current as engine_current, drop_site, emit_mlp, D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_dtype, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -42,10 +42,11 @@ class AgentEncoder(nn.Module):
         """K/V tables of the map tokens for this encoder's ag2mp layers; cached in the map-token dict (refresh: recomputed into the
         cached tensor - the token features were overwritten in place, RolloutEngine.refill)."""
         cache = mp.setdefault("_kv_ag", {})
-        if id(self) not in cache or refresh:
+        key = (id(self), kv_dtype())  # (an fp32 engine and a bf16-table engine may share one token dict: a table per element type)
+        if key not in cache or refresh:
             feat = mp["mp_token_feature"].reshape(-1, self.hidden_dim).contiguous()
-            cache[id(self)] = kv_tables(feat, [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers], out=cache.get(id(self)))
-        return cache[id(self)]
+            cache[key] = kv_tables(feat, [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers], out=cache.get(key))
+        return cache[key]
 
     def tl_kv_layers(self):
         return [(l.norm_tgt, l.attn) for l in self.tf_ag2agmptl.layers]
@@ -185,16 +186,18 @@ class AgentEncoder(nn.Module):
                     dict(common, tgt_pose=tok_pose, tgt_invalid=tok_inv, k=self.n_tgt_knn_ag2ag, out=prep.get("_knn_aa")),
                     dict(common, tgt_pose=tl_pose, tgt_invalid=tl_invalid_u8, k=self.n_tgt_knn_ag2tl, tgt_batch_div=tl_batch_div,
                          out=prep.get("_knn_at"))]
+            # the destination's pose embedding as a job of the searches' launch (pe_rides) - unless the rider builds it itself
+            pj = dict(pose3=prep["navi_pose3"], freqs_xy=navi_rpe.pe_xy.freqs, freqs_yaw=navi_rpe.pe_yaw.freqs, pe_dim=navi_rpe.out_dim,
+                      out=prep["navi_pe"]) if pe_rides else None
             if fused_front:
                 l0 = self.tf_ag2agmptl.layers[0]
                 fp = front_proj_buffers(n * A, dev)
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.front(
                     window=dict(attr=prep["attr"], pe=prep["pe"], row_invalid=prep["row_invalid"], in_images=wt_[0], pn_images=wt_[1], window=W, out=x),
-                    proj=tile_proj_part(l0.norm_src, l0.attn_src, fp["qkv"], True, fp["kv16"]), rider=rider if use_rider else None, jobs=jobs)
+                    proj=tile_proj_part(l0.norm_src, l0.attn_src, fp["qkv"], True, fp["kv16"]), rider=rider if use_rider else None, jobs=jobs,
+                    pose_embed_job=None if use_rider else pj)  # (no rider: prep["navi_pe"] is read by the heads chain - it must be filled here)
                 rider = None  # (ran in that launch)
             elif n * A < 4096:  # one launch for the three searches (the 4-waves-per-row form of the kernel)
-                pj = dict(pose3=prep["navi_pose3"], freqs_xy=navi_rpe.pe_xy.freqs, freqs_yaw=navi_rpe.pe_yaw.freqs, pe_dim=navi_rpe.out_dim,
-                          out=prep["navi_pe"]) if pe_rides else None
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = hip.knn_embed_multi(jobs, pose_embed_job=pj)
             else:
                 (i_am, m_am, r_am, _), (i_aa, m_aa, r_aa, _), (i_at, m_at, r_at, _) = (hip.knn_embed(**q) for q in jobs)

@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip
-from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
+from ..engine import D, FIRST_PROJ_LDW, SelfKnn, emit_first_proj, emit_pointnet, first_proj_buffers, front_ok, front_proj_buffers, kv_dtype, kv_tables, run_block, tile_proj_part, tile_rows_ok, tile_small_ok
 from ..hip import BUF0, BUF1, Chain, Seg
 from ..utils.pose_emb import PoseEmb
 from .modules.input_encoder import InputEncoder
@@ -69,10 +69,11 @@ class TrafficLightEncoder(nn.Module):
         """K/V tables of the map tokens for this encoder's tl2mp layers (static per scene, cached in the token dict; refresh:
         recomputed into the cached tensor after the token features were overwritten in place)."""
         cache = t.setdefault("_kv_mp", {})
-        if id(self) not in cache or refresh:
-            cache[id(self)] = kv_tables(t["mp_feat_flat"].contiguous(), [(l.norm_tgt, l.attn) for l in self.tf_tl2tlmp.layers],
-                                        out=cache.get(id(self)))
-        return cache[id(self)]
+        key = (id(self), kv_dtype())  # (a table per element type: fp32 and bf16-table engines may share one token dict)
+        if key not in cache or refresh:
+            cache[key] = kv_tables(t["mp_feat_flat"].contiguous(), [(l.norm_tgt, l.attn) for l in self.tf_tl2tlmp.layers],
+                                   out=cache.get(key))
+        return cache[key]
 
     def _window_tile_images(self):
         """(input MLP images, PointNet images) for tbx_window_tile in "add" mode, or None where the module is not of the default shape

@@ -125,14 +125,20 @@ class WaymoMotion(LightningModule):
         # One engine per (shapes, schedule, weights), refilled in place: a loop over scenes (validation_step, waymo_motion.py:526)
         # captures its hipGraphs once. `engine_cache = 0` turns the cache off (a fresh engine per rollout).
         sched = self.schedule if self.schedule is not None else engine.current()
+        # (weights: every parameter's storage AND version - an optimizer step, load_state_dict, .to() or `p.data = ` all change one)
         key = (RolloutEngine.shape_key(**kw), dataclasses.astuple(sched), str(dev), self.training,
-               sum(p._version for p in self.model.parameters()))
+               hash(tuple((p.data_ptr(), p._version) for p in self.model.parameters())))
         eng = self._engines.get(key) if self.engine_cache > 0 else None
         if eng is not None:
             eng.refill(**kw)
             self._engines.move_to_end(key)
         else:
             eng = RolloutEngine(self.model, self.dynamics, dev, schedule=sched)
+            if self.engine_cache > 0:
+                # a cached engine is refilled in place with later scenes: it owns COPIES of the first scene's token dicts (one copy
+                # per engine, not per rollout), so a caller still holding encode_scene()'s output never sees it change
+                own = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items() if not k.startswith("_")}
+                kw["mp_tokens"], kw["tl_tokens"] = own(mp_tokens), own(tl_tokens)
             eng.reset(**kw)
             if self.engine_cache > 0:
                 eng.reused = True
