@@ -131,6 +131,18 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
                         uint8_t* row_no_valid, const float* freqs_xy /* [32] or NULL */, const float* freqs_yaw /* [64] or NULL */,
                         void* stream);
 
+/* The forward of LARGE launches (a wavefront per source row; >= 1024 rows) on the bf16 matrix cores (csrc/attn_mfma.hip): scores and
+ * weighted sums as v_mfma_f32_16x16x32_bf16 products per source row (heads padded 4 -> 16), the pair's embedding evaluated in the
+ * operand layout, V / embedding rows transposed through LDS (ds_read_b64_tr_b16), online softmax in fp32. Same arguments, `out`
+ * layout and row_no_valid as tbx_knarpe_attn_fwd (every segment in the relative-pose form: emb == NULL; the constant q . b_rpe_k
+ * per head cancels in the softmax and is not formed); fp32 or bfloat16 K/V tables. Operands are rounded to bfloat16 (q, qt, K, V,
+ * e, softmax weights), accumulation and softmax in fp32: the bf16-ARITHMETIC schedule BASELINE configs[1] names (the reference runs
+ * at precision 16, configs/trainer/default.yaml:16); tolerance in tests/test_hip_attn_mfma.py. A persistent launch (<= 2 workgroups
+ * per CU) whose waves prefetch the next chunk's / the next row's gathers under the current chunk's arithmetic. */
+int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
+                             const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                             const float* freqs_xy /* [32] */, const float* freqs_yaw /* [64] */, void* stream);
+
 /* The forward for launches of a few hundred rows (the closed loop at one or a few scenes: 4 wavefronts share a row), with the
  * value half of `linear_rpe` applied in the epilogue (attention_rpe.py:147,181-182: sum a (v + W_v e + b_v), softmax sums to 1):
  *   out [n_batch*n_src, ldo >= 128] = (sum a v)_h + W_rpe_v,h (sum a e)_h + b_rpe_v,h   (zero rows where row_no_valid)

@@ -34,6 +34,9 @@ def parse(argv=None):
     ap.add_argument("--no-train-graph", action="store_true", help="training: eager fwd+bwd instead of one hipGraph replay per step")
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of that appended measurement (after 3 warm-up steps)")
     ap.add_argument("--kv-bf16", action="store_true", help="bfloat16 K/V tables (BASELINE config 2's dtype; 529 B per attention pair)")
+    ap.add_argument("--attn-mfma", type=int, default=None, choices=[0, 1],
+                    help="Schedule.attn_mfma of the measured engines: 0 fp32 VALU attention, 1 bf16 matrix-core attention (default: the "
+                         "engine's own default)")
     ap.add_argument("--no-bf16-shape", action="store_true", help="skip the bf16-table measurements the default run appends")
     ap.add_argument("--scene-curve", type=str, default=None, metavar="S1,S2,..",
                     help="also time the rollout at these scenes-per-GPU counts (same scene shape); one line each goes to the detail file")

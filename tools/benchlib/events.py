@@ -75,7 +75,7 @@ class KernelEvents:
       tile       tbx_layer_tile / tbx_heads_tile / tbx_window_tile / tbx_front (split-bf16 tile kernels)
       other      K-nearest searches, preparation, tbx_sim_step (elementwise / latency)"""
 
-    WRAPPED = ("knarpe_attn", "knarpe_dec_mid", "knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed",
+    WRAPPED = ("knarpe_attn", "knarpe_attn_mfma", "knarpe_dec_mid", "knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed",
                "layer_tile", "heads_tile", "window_tile", "front", "pair_embed")
 
     def __init__(self, hip):
@@ -114,6 +114,12 @@ class KernelEvents:
             b = attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs), eb)
             return T("attn", n_batch * n_src, b, sv["knarpe_attn"], qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw)
 
+        def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw):
+            eb = 2 if segs[0].kv.dtype == torch.bfloat16 else 4
+            b = attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs), eb)
+            self.attn_kernel = "knarpe_attn_mfma_kernel"
+            return T("attn", n_batch * n_src, b, sv["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw)
+
         def run(ch, n_rows, group_rows=0):
             fl = sum(2.0 * n_rows * s.k * s.n * max(1, s.reserved) for s in ch.stages if s.op == hip.OP_LINEAR)
             if ch.live_rows:
@@ -147,6 +153,8 @@ class KernelEvents:
             return lambda *a, **kw: T("other", name, 0.0, sv[name], *a, **kw)
 
         hip.knarpe_attn, hip.Chain.run, hip.knarpe_dec_mid = attn, run, mid
+        if "knarpe_attn_mfma" in sv:
+            hip.knarpe_attn_mfma = attn_m
         hip.layer_tile, hip.heads_tile, hip.window_tile, hip.front = lt, ht, wt, fr
         for n in ("knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed", "pair_embed"):
             if n in sv:

@@ -79,6 +79,8 @@ def measure(a, tb, hip, dev, rank, world, dist):
     gsteps = max(1, min(a.graph_steps, a.steps - (a.warmup % 2)) // 2 * 2)
     # this measurement's schedule belongs to its module / engine (engine.Schedule), not to the process
     wm.schedule = E.DEFAULT.replace(kv_bf16=bool(a.kv_bf16), lights_ahead=not a.no_lights_ahead, graph_steps=gsteps)
+    if getattr(a, "attn_mfma", None) is not None:
+        wm.schedule = wm.schedule.replace(attn_mfma=bool(a.attn_mfma))
     eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
     use_graph = not a.no_graph
     t_cap = time.perf_counter()
@@ -153,7 +155,7 @@ def measure(a, tb, hip, dev, rank, world, dist):
                 "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
                 "steps_per_graph_replay": gsteps if use_graph else 0,
                 "pre_roll_rollouts": n_pre,  # untimed whole-rollout replays before the W warm-up steps (device at steady clocks)
-                "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead,
+                "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead, "attn_mfma": wm.schedule.attn_mfma,
                 "weights": "random init of the 10,657,094-parameter default architecture"}
     if a.profile_steps <= 0:  # tooling only (timeline traces, A/B runs, the scenes-per-GPU curve): no per-kernel timing pass
         return {**timing, "config": workload, "roofline": None, "kernels": None,

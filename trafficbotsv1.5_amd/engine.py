@@ -98,6 +98,10 @@ class Schedule:
     # steps the lights once per scene and the agents of the K rollouts attend to that one copy. Bit-identical rollouts.
     share_lights: bool = True
     hoist_constants: bool = True  # False: the heads chain re-embeds the latent / destination feature every step (same values)
+    # large launches (a wavefront per source row, >= 1024 rows, inference): the attention on the bf16 matrix cores
+    # (tbx_knarpe_attn_fwd_mfma, csrc/attn_mfma.hip): bf16 operands with fp32 accumulation - part of the bf16-ARITHMETIC schedule
+    # (Schedule.reduced(); tests/test_hip_attn_mfma.py). False: the fp32 VALU kernel
+    attn_mfma: bool = False
 
     @classmethod
     def from_env(cls) -> "Schedule":
@@ -140,6 +144,7 @@ class Schedule:
             graph_steps=max(1, num("TBX_GRAPH_STEPS", 4) // 2 * 2),
             share_lights=on("TBX_SHARE_LIGHTS"),
             hoist_constants=os.environ.get("TBX_NO_HOIST") is None,
+            attn_mfma=off("TBX_ATTN_MFMA"),
         )
 
     def replace(self, **kw) -> "Schedule":
@@ -186,6 +191,16 @@ def drop_call(attn):
         return None
     DROP_CTX["call"] += 1
     return (float(attn.dropout_p), DROP_CTX["seed"], DROP_CTX["call"], 1, DROP_CTX["step"])
+
+
+def attention(qbuf, q_off: int, qt_off: int, attn, n: int, S: int, segs, obuf, flag, fxy, fyw, drop=None, fold=None):
+    """One KNARPE attention call (attention_rpe.py:137-190): hip.knarpe_attn, or - large inference launches whose segments are all
+    given as relative poses, Schedule.attn_mfma - the matrix-core form (same output rows, its own rounding)."""
+    if (current().attn_mfma and drop is None and fold is None and n * S >= 1024 and obuf.shape[1] >= D + NH * D and fxy is not None
+            and all(sg.rel is not None and sg.emb is None for sg in segs)):
+        hip.knarpe_attn_mfma(qbuf, q_off, qt_off, n, S, segs, obuf, flag, fxy, fyw)
+        return
+    hip.knarpe_attn(qbuf, q_off, qt_off, attn.linear_rpe.bias, n, S, segs, obuf, flag, fxy, fyw, drop=drop, fold=fold)
 
 
 def emit_qkv(ch: Chain, attn, src_buf: int, src_col: int, dst_buf: int, dst_col: int, with_kv: bool) -> int:
@@ -609,14 +624,13 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
                 tail(ch)
             ch.run(rows)
             continue
-        hip.knarpe_attn(qkv, 0, 3 * D, a1.linear_rpe.bias, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1),
-                        fold=attn_fold_image(a1) if fold else None)
+        attention(qkv, 0, 3 * D, a1, n, S, [self_seg], obuf, flag, fxy, fyw, drop=next_call(a1), fold=attn_fold_image(a1) if fold else None)
         if tile:  # the layer's row-local chains as tbx_layer_tile launches (split-bf16 MFMA stages, no program to interpret)
             a_last = a1
             if dec:
                 hip.layer_tile(x, attn=tile_attn_part(a1, obuf, flag), proj=tile_proj_part(layer.norm1, layer.attn, q2, False),
                                drop=_tile_drop(next_site()))
-                hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
+                attention(q2, 0, D, layer.attn, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn))
                 a_last = layer.attn
             last = l + 1 == len(layers)
             hip.layer_tile(x, attn=tile_attn_part(a_last, obuf, flag), ffn=tile_ffn_part(layer, src_invalid),
@@ -634,8 +648,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             ch.store(BUF1, 0, D, x)
             emit_proj(ch, rows, layer.norm1, layer.attn, q2, with_kv=False)
             ch.run(rows)
-            hip.knarpe_attn(q2, 0, D, layer.attn.linear_rpe.bias, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn),
-                            fold=attn_fold_image(layer.attn) if fold else None)
+            attention(q2, 0, D, layer.attn, n, S, list(cross(l)), obuf, flag, fxy, fyw, drop=next_call(layer.attn),
+                      fold=attn_fold_image(layer.attn) if fold else None)
             ch = layer_chain(rows)
             emit_attn_out(ch, layer.attn, obuf, flag, drop=next_site(), x=x)
         if not emit_ffn(ch, layer, drop_hidden=next_site(), drop_out=next_site(), zero_rows=src_invalid):

@@ -201,6 +201,7 @@ def load():
     lib.tbx_diffbar_reward.argtypes = [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.tbx_knarpe_attn_fwd_mfma.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
     lib.tbx_knarpe_dec_layer.argtypes = [C.POINTER(DecLayer), vp]
     lib.tbx_knn_embed_multi.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, vp]
@@ -269,7 +270,7 @@ def load():
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
     for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures",
-                 "tbx_rel_pose_dense", "tbx_diffbar_reward"):
+                 "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")
@@ -637,6 +638,16 @@ def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: 
                                             _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy), _cptr(freqs_yaw), float(p),
                                             _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd")
+
+
+def knarpe_attn_mfma(qbuf, q_off: int, qt_off: int, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid, freqs_xy, freqs_yaw):
+    """tbx_knarpe_attn_fwd_mfma: the wave-per-row forward on the bf16 matrix cores (bf16 operands, fp32 accumulation / softmax).
+    Same `out` [rows, >= 640] / row_no_valid as knarpe_attn; segments in the relative-pose form."""
+    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
+    rc = load().tbx_knarpe_attn_fwd_mfma(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, n_batch, n_src, arr, len(segs),
+                                         _ptr(out, torch.float32), out.stride(0), _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy),
+                                         _cptr(freqs_yaw), stream_ptr())
+    _check(rc, "tbx_knarpe_attn_fwd_mfma")
 
 
 def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
