@@ -35,7 +35,7 @@ from tools.benchlib import launch  # noqa: E402
 from tools.benchlib.args import parse, shard_scenes  # noqa: E402,F401  (shard_scenes: tests/test_multiprocess_sharding.py)
 
 DTYPE_F32 = "f32 (split-bf16 MFMA products)"  # every LINEAR of the default schedule = three bf16 MFMA products per fp32 product
-DTYPE_BF16 = "bf16 K/V tables, f32 arithmetic (split-bf16 MFMA products)"
+DTYPE_BF16 = "bf16: K/V tables + matrix-core attention operands (launches >= 1024 rows); f32 (split-bf16 MFMA products) elsewhere"
 
 
 def __getattr__(name):
@@ -124,15 +124,16 @@ def main(argv=None):
         r5, _, _ = measure(big)
         full["wosac_shape"] = {"metric": full["metric"], "unit": full["unit"], "n_gpus": world, "steps": big.steps, "warmup": big.warmup, **r5}
     if args.bf16_shape:
-        # BASELINE.json configs[1] says bf16: the same two workloads with bfloat16 K/V tables (Schedule.kv_bf16: 529 B per pair,
-        # fp32 queries / embeddings / softmax / sums; tolerances in tests/test_hip_bf16.py). The fp32 line above stays the parity line.
+        # BASELINE.json configs[1] says bf16: the same two workloads on the bf16-arithmetic schedule (Schedule.reduced(): bfloat16 K/V
+        # tables - 529 B per pair - and, from 1024 source rows, the attention with bf16 operands on the matrix cores; tolerances in
+        # tests/test_hip_bf16.py / test_hip_attn_mfma.py). The fp32 line above stays the parity line.
         b16 = copy.copy(args)
-        b16.kv_bf16 = True
+        b16.kv_bf16, b16.attn_mfma = True, 1
         r16, _, _ = measure(b16)
         full["bf16"] = {"dtype": DTYPE_BF16, "steps": b16.steps, "warmup": b16.warmup, **r16}
         if args.wosac_shape:
             b16 = copy.copy(args)
-            b16.kv_bf16, b16.scenes, b16.rollouts, b16.agents, b16.steps = True, 1, 32, 128, min(args.steps, 40)
+            b16.kv_bf16, b16.attn_mfma, b16.scenes, b16.rollouts, b16.agents, b16.steps = True, 1, 1, 32, 128, min(args.steps, 40)
             r16, _, _ = measure(b16)
             full["bf16"]["wosac_shape"] = {"steps": b16.steps, "warmup": b16.warmup, **r16}
     if args.scene_curve:

@@ -204,7 +204,7 @@ def test_schedule_switches_follow_the_environment_and_replace(tb, monkeypatch):
         if k.startswith("TBX_"):
             monkeypatch.delenv(k)
     d = E.Schedule.from_env()
-    off = {"front_big", "attn_fold_big", "pool_proj", "kv_bf16", "split_bf16"}
+    off = {"front_big", "attn_fold_big", "pool_proj", "kv_bf16", "split_bf16", "attn_mfma"}
     bools = [f.name for f in dataclasses.fields(E.Schedule) if isinstance(getattr(d, f.name), bool)]
     assert {"knn_aux_big", "prime_graph", "fused_tail", "front_fused", "dec_tail_mfma", "front_big"} <= set(bools)
     for name in bools:

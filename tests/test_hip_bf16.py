@@ -138,3 +138,55 @@ def test_bf16_closed_loop_gathers_the_rows_the_fp32_path_gathers(tb, sizes, knn)
                 assert torch.equal(a[k], c[k]), (t, k)
         assert float((a["action"] - c["action"]).abs().max()) <= 2e-2 * max(scale, 1e-3), t
     assert not torch.equal(runs["fp32"][3]["action"], runs["bf16"][3]["action"])  # the tables really were rounded
+
+
+def test_reduced_schedule_joint_futures_vs_fp32(tb):
+    """Schedule.reduced() - bf16 tables + the matrix-core attention with bf16 operands (tbx_knarpe_attn_fwd_mfma; active from 1024
+    source rows: here 16 joint futures x 64 agents) - against the fp32 schedule on the same scene, latents and destinations:
+    over the 10 teacher-forced warm-start steps the K-nearest sets are bit-identical (the searches are fp32 and read no table) and
+    the action means stay within 3e-2 of the fp32 ones (bf16 operands: 2^-9 relative on q, k, v, e and the softmax weights);
+    over 6 further free steps poses stay within 0.1 m / 0.05 rad of the fp32 rollout's; light states are identical."""
+    dev = torch.device(DEV)
+    E = import_module("trafficbots_amd.engine")
+    D = import_module("trafficbots_amd.models.modules.distributions")
+    wm, P, b, bd = _setup(tb, dev, (64, 1024, 128), 32)
+    n, A = bd["sc/ag_valid"].shape[:2]
+    K = 16
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, A, 16, generator=g).to(dev)
+    valid = bd["sc/ag_valid"].any(-1)
+    onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], bd["sc/mp_valid"].shape[1]).float()
+    wm.hp.joint_future_pred_deterministic_k0 = False
+    calls = {"mfma": 0}
+    hip = import_module("trafficbots_amd.hip")
+    orig = hip.knarpe_attn_mfma
+
+    def counted(*a, **kw):
+        calls["mfma"] += 1
+        return orig(*a, **kw)
+
+    outs = {}
+    hip.knarpe_attn_mfma = counted
+    try:
+        for name, sched in (("fp32", E.DEFAULT), ("reduced", E.DEFAULT.reduced())):
+            wm.schedule = sched
+            wm.engine_cache = 0
+            mp, tl = wm.encode_scene(bd, n_rollout=K)
+            lat = D.DiagGaussian(z, torch.full((16,), -1.0, device=dev), valid=valid)  # K different latent samples per agent
+            nav = D.DestCategorical(probs=onehot, valid=valid)
+            torch.manual_seed(11)
+            n_before = calls["mfma"]
+            outs[name] = wm.joint_future_pred(bd, mp, tl, lat, nav, wm.teacher_forcing_joint_future_pred, K, step_end=16, use_graph=False)
+            assert (calls["mfma"] > n_before) == (name == "reduced")  # the matrix-core kernel really ran (and only there)
+    finally:
+        hip.knarpe_attn_mfma = orig
+    a, r = outs["fp32"], outs["reduced"]
+    assert torch.equal(a.pred_valid, r.pred_valid)
+    assert torch.equal(a.vis_dict["tl_state"], r.vis_dict["tl_state"])
+    act_a, act_r = a.vis_dict["action"], r.vis_dict["action"]  # [n, K, A, T, 2]
+    scale = float(act_a[..., :10, :].abs().max())
+    assert float((act_a[..., :10, :] - act_r[..., :10, :]).abs().max()) <= 3e-2 * max(scale, 1.0)
+    assert not torch.equal(act_a[..., :10, :], act_r[..., :10, :])
+    dpose = (a.pred_pose - r.pred_pose).abs()
+    assert float(dpose[..., :10, :].max()) <= 1e-2          # teacher-forced steps: the prediction before the override
+    assert float(dpose[..., :2].max()) <= 0.1 and float(dpose[..., 2].max()) <= 0.05

@@ -189,8 +189,9 @@ def kernel_entry(args, c, products: int = 3):
     e = {"class": cls, "share_of_step_kernel_time": c["share"], "launches_per_step": c["per_step"], "avg_launch_us": avg * 1e6}
     if cls in ("dec_layer", "attn"):
         ach = c["work"] / c["t"] / 1e9
-        name = "dec_layer_mf_kernel" if cls == "dec_layer" else "knarpe_attn_kernel"  # (dec_mid_kernel with Schedule.dec_tail_mfma off)
-        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_kernel<1,"] if key >= 1024 else ["knarpe_attn_kernel<4,"])
+        mf = cls == "attn" and getattr(args, "attn_mfma", None) and key >= 1024  # (Schedule.attn_mfma: the matrix-core kernel from 1024 rows)
+        name = "dec_layer_mf_kernel" if cls == "dec_layer" else ("knarpe_attn_mfma_kernel" if mf else "knarpe_attn_kernel")  # (dec_mid_kernel with Schedule.dec_tail_mfma off)
+        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_mfma_kernel<"] if mf else (["knarpe_attn_kernel<1,"] if key >= 1024 else ["knarpe_attn_kernel<4,"]))
         e.update(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                  algorithmic_bytes_per_launch=c["work"] / c["n"], source_rows_per_launch=key,
                  bytes_per_pair=529 if args.kv_bf16 else 1041)

@@ -150,6 +150,13 @@ class Schedule:
     def replace(self, **kw) -> "Schedule":
         return dataclasses.replace(self, **kw)
 
+    def reduced(self) -> "Schedule":
+        """The bf16-ARITHMETIC schedule (BASELINE configs[1] says bf16; the reference runs at precision 16,
+        configs/trainer/default.yaml:16): bfloat16 K/V tables and, on launches of >= 1024 source rows, the attention with bf16
+        operands on the matrix cores (fp32 accumulation and softmax). K-nearest searches, dynamics and every LINEAR stage keep
+        their fp32-class arithmetic. Tolerances: tests/test_hip_attn_mfma.py (one call), tests/test_hip_bf16.py (closed loop)."""
+        return self.replace(kv_bf16=True, attn_mfma=True)
+
 
 DEFAULT = Schedule.from_env()
 _tls = threading.local()
