@@ -1030,13 +1030,22 @@ static int fold_grid_max() {  // 2 workgroups (78 KiB of LDS each) per CU
   return g;
 }
 
-static int attn_big_rows() {
+// from how many source rows a wave takes a whole row (below: 4 waves split a row's targets). Calls with attention dropout (training's
+// stepping pass): 1024, measured there at 1024 rows x 89 pairs (28 us with 4 waves per row, ~24 us with one). Inference: 193 - on
+// the scenes-per-GPU curve (profiles/r04_scene_curve.json) 256 .. 512 agents' rows run 0.398 -> 0.306 ms per step (4 scenes) and
+// 0.470 -> 0.333 (8 scenes) with the wave-per-row forms (the LDS ring when a SIMD has a lone wave) behind the tile kernels.
+static int attn_big_rows(bool dropout = true) {
   static const int big_rows = [] {
     const char* e = getenv("TBX_ATTN_BIG_ROWS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 1024;  // measured at 1024 rows x 89 pairs (training's stepping pass): 28 us with 4 waves per row, ~24 us with one
+    return v > 0 ? v : 1024;
   }();
-  return big_rows;
+  static const int big_rows_infer = [] {
+    const char* e = getenv("TBX_ATTN_BIG_ROWS_INFER");
+    const int v = e ? atoi(e) : (getenv("TBX_ATTN_BIG_ROWS") ? atoi(getenv("TBX_ATTN_BIG_ROWS")) : 0);
+    return v > 0 ? v : 193;
+  }();
+  return dropout ? big_rows : big_rows_infer;
 }
 
 extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias,
@@ -1053,7 +1062,7 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
   if (rc != TBX_OK) return rc;
   a.out = out;
   a.row_no_valid = row_no_valid;
-  const bool big = a.n_rows >= attn_big_rows();  // a wave per row from here on (below: 4 waves split a row's targets)
+  const bool big = a.n_rows >= attn_big_rows(a.drop_thresh != 0u);  // a wave per row from here on (below: 4 waves split a row's targets)
   const dim3 grid(big ? (a.n_rows + 3) / 4 : a.n_rows), block(256);
   hipStream_t hs = (hipStream_t)stream;
   // the LDS-ring form (opt-in, TBX_ATTN_RING=1 / 2): large launches without dropout whose segments are all given as relative poses

@@ -60,7 +60,12 @@ class Schedule:
     # launches of a few hundred rows in all (one 64-agent scene) are latency-bound: they run as tbx_rowchain_live programs - tiles
     # of live_rows rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA tiles) - up to live_max rows.
     live_rows: int = 1
-    live_max: int = 512
+    # Measured on the scenes-per-GPU curve (profiles/r04_scene_curve.json, 64 agents / 128 lights per scene): the one-row-per-
+    # workgroup layers win up to 256 rows for the lights' block (48 pairs per row) and up to 192 rows for the agents' block (114
+    # pairs per row); from there the tile kernels + the wave-per-row attention do (4 scenes: 0.398 -> 0.309 ms per step, 8 scenes:
+    # 0.470 -> 0.332). live_max_agents applies inside TrafficBots.agent_policy (engine.live_limit).
+    live_max: int = 256
+    live_max_agents: int = 192
     # BASELINE config 2 names bf16: the K/V tables every attention call gathers from stored as bfloat16 (529 B per pair instead of
     # 1041); queries, pose embeddings, scores, softmax and all sums stay fp32. Off: the fp32 parity path.
     kv_bf16: bool = False
@@ -72,7 +77,7 @@ class Schedule:
     # launches past live_max rows (no keyed dropout): a layer's row-local chains as tbx_layer_tile launches - straight-line 16-row
     # tiles, LINEAR on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) - instead of tbx_rowchain programs (exact fp32)
     tile_layer: bool = True
-    tile_min_rows: int = 1024
+    tile_min_rows: int = 193
     # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
     # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
     tile_small: bool = True
@@ -122,12 +127,13 @@ class Schedule:
             masked_groupmax=on("TBX_MASKED_GROUPMAX"),
             big_rows=num("TBX_BIG_ROWS", 16384),
             live_rows=num("TBX_LIVE_ROWS", 1),
-            live_max=num("TBX_LIVE_MAX", 512),
+            live_max=num("TBX_LIVE_MAX", 256),
+            live_max_agents=num("TBX_LIVE_MAX_AGENTS", 192),
             kv_bf16=off("TBX_KV_BF16"),
             pool_proj=off("TBX_POOL_PROJ"),
             split_bf16=off("TBX_SPLIT_BF16"),
             tile_layer=on("TBX_TILE_LAYER"),
-            tile_min_rows=num("TBX_TILE_MIN_ROWS", 1024),
+            tile_min_rows=num("TBX_TILE_MIN_ROWS", 193),
             tile_small=on("TBX_TILE_SMALL"),
             prime_graph=on("TBX_PRIME_GRAPH"),
             knn_aux_big=on("TBX_KNN_AUX_BIG"),
@@ -348,8 +354,21 @@ def kv_dtype():
     return torch.bfloat16 if current().kv_bf16 else torch.float32
 
 
+@contextlib.contextmanager
+def live_limit(max_rows: Optional[int]):
+    """Inside the block the live-row schedule ends at `max_rows` rows instead of Schedule.live_max (None: unchanged)."""
+    prev = getattr(_tls, "live_max", None)
+    _tls.live_max = max_rows if max_rows is not None else prev
+    try:
+        yield
+    finally:
+        _tls.live_max = prev
+
+
 def live_rows_for(rows: int) -> int:
-    return current().live_rows if (current().live_rows and rows <= current().live_max and DROP_CTX is None) else 0
+    lim = getattr(_tls, "live_max", None)
+    lim = current().live_max if lim is None else lim
+    return current().live_rows if (current().live_rows and rows <= lim and DROP_CTX is None) else 0
 
 
 def row_chain(rows: int, ldw: int, ldw1: Optional[int] = None, ld_aux: Optional[int] = None, big: Optional[tuple] = None) -> Chain:

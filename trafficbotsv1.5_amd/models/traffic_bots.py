@@ -123,108 +123,109 @@ class TrafficBots(nn.Module):
         n, A, W = hist_valid.shape
         d = self.hidden_dim
         dev = hist_pose.device
-        # rollouts of one scene share its map tokens (mp_batch_div) and, in the rollout engine, its lights (tl_batch_div: the
-        # light tokens are then per scene and "ag_mp_batch_div" carries the agents' map sharing)
-        div = tl_tokens.get("ag_mp_batch_div", tl_tokens.get("mp_batch_div", 1))
-        tl_inv = tl_tokens["tl_token_invalid_u8"]
-        rc = rollout_consts or {}
-        mp_flat = mp_tokens["mp_token_feature"].reshape(-1, d)
-        # inference with an auxiliary stream: the navigation embedding mlp_in(navi feature) (navigation.py:65-79 +
-        # add_navi_latent.py:43-50) reads nothing the agent layers produce - it runs there, behind the K-nearest searches, instead
-        # of as the first five stages of the heads chain (same stages, same values)
-        tile = engine.tile_rows_ok(n * A)  # large launches: the heads as one tbx_heads_tile launch (needs the embedding made ahead)
-        # (Schedule.navi_rider: on small launches it rides in the agents' first-projection launch instead, with or without that stream)
-        navi_ahead = (aux_stream is not None or tile or engine.current().navi_rider) and engine.DROP_CTX is None and self.NAVI_AHEAD
+        with engine.live_limit(engine.current().live_max_agents):  # (the agents' block leaves the one-row-per-workgroup layers earlier)
+            # rollouts of one scene share its map tokens (mp_batch_div) and, in the rollout engine, its lights (tl_batch_div: the
+            # light tokens are then per scene and "ag_mp_batch_div" carries the agents' map sharing)
+            div = tl_tokens.get("ag_mp_batch_div", tl_tokens.get("mp_batch_div", 1))
+            tl_inv = tl_tokens["tl_token_invalid_u8"]
+            rc = rollout_consts or {}
+            mp_flat = mp_tokens["mp_token_feature"].reshape(-1, d)
+            # inference with an auxiliary stream: the navigation embedding mlp_in(navi feature) (navigation.py:65-79 +
+            # add_navi_latent.py:43-50) reads nothing the agent layers produce - it runs there, behind the K-nearest searches, instead
+            # of as the first five stages of the heads chain (same stages, same values)
+            tile = engine.tile_rows_ok(n * A)  # large launches: the heads as one tbx_heads_tile launch (needs the embedding made ahead)
+            # (Schedule.navi_rider: on small launches it rides in the agents' first-projection launch instead, with or without that stream)
+            navi_ahead = (aux_stream is not None or tile or engine.current().navi_rider) and engine.DROP_CTX is None and self.NAVI_AHEAD
 
-        def aux_tail(prep):
-            if prep.get("navi_emb") is None:
-                prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
-            cn = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
-            self.navi_encoder.emit(cn, mp_flat, prep["navi_row"], prep["navi_pe"], dest_feature=rc.get("dest_feature"))
-            prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
-            cn.run(n * A)
+            def aux_tail(prep):
+                if prep.get("navi_emb") is None:
+                    prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+                cn = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
+                self.navi_encoder.emit(cn, mp_flat, prep["navi_row"], prep["navi_pe"], dest_feature=rc.get("dest_feature"))
+                prep["_navi_premasked"] = self.add_navi.emit_embed_buf(cn, prep["navi_emb"], navi_valid_u8.reshape(-1), mask_is_valid=True)
+                cn.run(n * A)
 
-        def navi_rider(prep, pose3: bool = False):
-            """The same four stages as `aux_tail` as tbx_layer_tile_t's rider (agent_encoder.encode), or None. pose3: stage 0 reads the
-            pose embedding the rider builds itself from prep["navi_pose3"] instead of prep["navi_pe"]."""
-            l_pe = self.navi_encoder.mlp_pe.linear_layers()
-            l_in = self.add_navi.mlp_in.linear_layers()
-            if (rc.get("dest_feature") is None or len(l_pe) != 1 or len(l_in) != 3 or any(ln is not None for _, ln, _ in l_pe + l_in)
-                    or any(tuple(t[0].weight.shape) != (d, d) for t in l_pe + l_in) or not all(act for _, _, act in l_in) or l_pe[0][2]):
-                return None
-            if prep.get("navi_emb") is None:
-                prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
-            prep["_navi_premasked"] = True
-            src = (dict(pose3=prep["navi_pose3"], freqs=(self.pose_rpe.pe_xy.freqs, self.pose_rpe.pe_yaw.freqs)) if pose3
-                   else dict(inp=prep["navi_pe"]))
-            if pose3 and self.pose_rpe.out_dim != d:
-                return None
-            return dict(add=rc["dest_feature"], out=prep["navi_emb"], valid=navi_valid_u8.reshape(-1),
-                        images=[hip.packed_weight(t[0].weight, t[0].bias, mfma32=True) for t in l_pe + l_in], **src)
+            def navi_rider(prep, pose3: bool = False):
+                """The same four stages as `aux_tail` as tbx_layer_tile_t's rider (agent_encoder.encode), or None. pose3: stage 0 reads the
+                pose embedding the rider builds itself from prep["navi_pose3"] instead of prep["navi_pe"]."""
+                l_pe = self.navi_encoder.mlp_pe.linear_layers()
+                l_in = self.add_navi.mlp_in.linear_layers()
+                if (rc.get("dest_feature") is None or len(l_pe) != 1 or len(l_in) != 3 or any(ln is not None for _, ln, _ in l_pe + l_in)
+                        or any(tuple(t[0].weight.shape) != (d, d) for t in l_pe + l_in) or not all(act for _, _, act in l_in) or l_pe[0][2]):
+                    return None
+                if prep.get("navi_emb") is None:
+                    prep["navi_emb"] = torch.empty(n * A, d, dtype=torch.float32, device=dev)
+                prep["_navi_premasked"] = True
+                src = (dict(pose3=prep["navi_pose3"], freqs=(self.pose_rpe.pe_xy.freqs, self.pose_rpe.pe_yaw.freqs)) if pose3
+                       else dict(inp=prep["navi_pe"]))
+                if pose3 and self.pose_rpe.out_dim != d:
+                    return None
+                return dict(add=rc["dest_feature"], out=prep["navi_emb"], valid=navi_valid_u8.reshape(-1),
+                            images=[hip.packed_weight(t[0].weight, t[0].bias, mfma32=True) for t in l_pe + l_in], **src)
 
-        def heads_tail(prep, mfma32: bool = False):
-            """The heads as tbx_heads_tail_t / tbx_heads_tile_t fields when everything they read is at hand in the form the fused
-            launch takes it: navigation embedding from the auxiliary stream (masked by its producer), latent embedding of the
-            rollout (masked once), 3-layer adders without layernorm, the action head's stacked branches. mfma32: the images of
-            tbx_heads_tile (large launches) instead of the gemv images of tbx_knarpe_dec_layer's tail."""
-            ah, an, al = self.action_head, self.add_navi, self.add_latent
-            if not (navi_ahead and prep.get("_navi_premasked") and rc.get("latent_premasked") and rc.get("latent_embedded") is not None
-                    and ah.fused_branches and ah.masked_sum_store and len(ah.mlp_mean) == 3 and ah.out_dim <= 16):
-                return None
-            pw = lambda w, b, **kw: hip.packed_weight(w, b, **(dict(mfma32=True) if mfma32 else dict(gemv=True)), **kw)
-            lins = [[t[0] for t in mlp.linear_layers()] for mlp in ah.mlp_mean]
-            w1, b1 = hip.stacked_linear([l[0] for l in lins])
-            w2, b2 = hip.stacked_linear([l[1] for l in lins])
-            w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
-            imgs = [pw(t[0].weight, t[0].bias) for t in an.mlp.linear_layers()] + [pw(t[0].weight, t[0].bias) for t in al.mlp.linear_layers()]
-            imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
-            hd = dict(images=imgs, navi_emb=prep["navi_emb"], latent_emb=rc["latent_embedded"], navi_valid=navi_valid_u8.reshape(-1),
-                      latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"], action_out=out["action_mean"])
-            if fused_tail is not None and mfma32 and engine.current().fused_tail:
-                fused["args"] = self.ag_encoder.prep_args(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, prep, dest, mp_tokens, div)
-                hd.update(sim_state=fused_tail["sim_state"], sim_parts=fused_tail["parts"], next_prep=fused["args"])
-            return hd
+            def heads_tail(prep, mfma32: bool = False):
+                """The heads as tbx_heads_tail_t / tbx_heads_tile_t fields when everything they read is at hand in the form the fused
+                launch takes it: navigation embedding from the auxiliary stream (masked by its producer), latent embedding of the
+                rollout (masked once), 3-layer adders without layernorm, the action head's stacked branches. mfma32: the images of
+                tbx_heads_tile (large launches) instead of the gemv images of tbx_knarpe_dec_layer's tail."""
+                ah, an, al = self.action_head, self.add_navi, self.add_latent
+                if not (navi_ahead and prep.get("_navi_premasked") and rc.get("latent_premasked") and rc.get("latent_embedded") is not None
+                        and ah.fused_branches and ah.masked_sum_store and len(ah.mlp_mean) == 3 and ah.out_dim <= 16):
+                    return None
+                pw = lambda w, b, **kw: hip.packed_weight(w, b, **(dict(mfma32=True) if mfma32 else dict(gemv=True)), **kw)
+                lins = [[t[0] for t in mlp.linear_layers()] for mlp in ah.mlp_mean]
+                w1, b1 = hip.stacked_linear([l[0] for l in lins])
+                w2, b2 = hip.stacked_linear([l[1] for l in lins])
+                w3, b3 = hip.stacked_linear([l[2] for l in lins], pad_out_to=16)
+                imgs = [pw(t[0].weight, t[0].bias) for t in an.mlp.linear_layers()] + [pw(t[0].weight, t[0].bias) for t in al.mlp.linear_layers()]
+                imgs += [pw(w1, b1), pw(w2, b2, groups=3), pw(w3, b3, groups=3)]
+                hd = dict(images=imgs, navi_emb=prep["navi_emb"], latent_emb=rc["latent_embedded"], navi_valid=navi_valid_u8.reshape(-1),
+                          latent_invalid=latent_invalid.reshape(-1), type_mask=prep["type_mask"], action_out=out["action_mean"])
+                if fused_tail is not None and mfma32 and engine.current().fused_tail:
+                    fused["args"] = self.ag_encoder.prep_args(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, prep, dest, mp_tokens, div)
+                    hd.update(sim_state=fused_tail["sim_state"], sim_parts=fused_tail["parts"], next_prep=fused["args"])
+                return hd
 
-        fused = {}
-        feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
-                                            tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
-                                            dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
-                                            aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None,
-                                            heads_tail=heads_tail if navi_ahead else None,
-                                            navi_rider=navi_rider if navi_ahead else None, prep_ready=prep_ready)
-        out["prep"], out["ag_feat"] = prep, feat
-        prep["_tail_fused"] = bool(prep.get("_heads_done")) and "args" in fused
-        prep["_tail_keep"] = fused.get("args")  # (the ctypes structure outlives the launch call anyway; kept for clarity)
-        if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
-            return
-        if tile:
-            hd = heads_tail(prep, mfma32=True)
-            if hd is not None:
-                hip.heads_tile(feat, hd)
+            fused = {}
+            feat, prep = self.ag_encoder.encode(hist_valid, hist_pose, hist_motion, ag_attr6, mp_tokens, tl_inv,
+                                                tl_tokens["tl_token_pose"], tl_kv, prep=out.get("prep"), ag_type_idx=ag_type_idx,
+                                                dest=dest, mp_batch_div=div, tl_batch_div=tl_tokens.get("tl_batch_div", 1),
+                                                aux_stream=aux_stream, navi_rpe=self.pose_rpe, aux_tail=aux_tail if navi_ahead else None,
+                                                heads_tail=heads_tail if navi_ahead else None,
+                                                navi_rider=navi_rider if navi_ahead else None, prep_ready=prep_ready)
+            out["prep"], out["ag_feat"] = prep, feat
+            prep["_tail_fused"] = bool(prep.get("_heads_done")) and "args" in fused
+            prep["_tail_keep"] = fused.get("args")  # (the ctypes structure outlives the launch call anyway; kept for clarity)
+            if prep.get("_heads_done"):  # the last layer's launch already ran the adders and the action head (engine.run_block)
                 return
-        if engine.DROP_CTX is not None and engine.tile_rows_ok(n * A, keyed_dropout=True) and rc.get("dest_feature") is not None:
-            hd = self._heads_tile_raw(prep, rc, ag_latent, latent_invalid, navi_valid_u8, out, n * A)
-            if hd is not None:  # training's stepping pass: embeddings, adders (with their keyed dropouts) and action head in ONE launch
-                hip.heads_tile(feat, hd)
-                return
-        navi_pe = prep["navi_pe"]
-        ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
-        ch.load(feat, BUF1, 0, n=d)
-        if navi_ahead:  # (its stream was joined before the first attention launch - run_block - with this chain already enqueued on it)
-            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"],
-                               z_premasked=bool(prep.get("_navi_premasked")))
-        else:
-            self.navi_encoder.emit(ch, mp_flat, prep["navi_row"], navi_pe, dest_feature=rc.get("dest_feature"))
-            self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
-        if engine.DROP_CTX is not None:  # training's stepping pass: 12 DROPOUT stages more than a program holds - two launches
-            mid = torch.empty_like(feat)
-            ch.store(BUF1, 0, d, mid)
+            if tile:
+                hd = heads_tail(prep, mfma32=True)
+                if hd is not None:
+                    hip.heads_tile(feat, hd)
+                    return
+            if engine.DROP_CTX is not None and engine.tile_rows_ok(n * A, keyed_dropout=True) and rc.get("dest_feature") is not None:
+                hd = self._heads_tile_raw(prep, rc, ag_latent, latent_invalid, navi_valid_u8, out, n * A)
+                if hd is not None:  # training's stepping pass: embeddings, adders (with their keyed dropouts) and action head in ONE launch
+                    hip.heads_tile(feat, hd)
+                    return
+            navi_pe = prep["navi_pe"]
+            ch = engine.row_chain(n * A, 4 * d + 4, big=(32, 4 * d + 4, d + 4, d + 4))
+            ch.load(feat, BUF1, 0, n=d)
+            if navi_ahead:  # (its stream was joined before the first attention launch - run_block - with this chain already enqueued on it)
+                self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True, z_embedded=prep["navi_emb"],
+                                   z_premasked=bool(prep.get("_navi_premasked")))
+            else:
+                self.navi_encoder.emit(ch, mp_flat, prep["navi_row"], navi_pe, dest_feature=rc.get("dest_feature"))
+                self.add_navi.emit(ch, navi_valid_u8.reshape(-1), mask_is_valid=True)
+            if engine.DROP_CTX is not None:  # training's stepping pass: 12 DROPOUT stages more than a program holds - two launches
+                mid = torch.empty_like(feat)
+                ch.store(BUF1, 0, d, mid)
+                ch.run(n * A)
+                ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
+                ch.load(mid, BUF1, 0, n=d)
+            self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"), z_premasked=bool(rc.get("latent_premasked")))
+            self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
             ch.run(n * A)
-            ch = Chain(32, 4 * d + 4, d + 4, d + 4) if n * A >= 16384 else Chain(16, 4 * d + 4)
-            ch.load(mid, BUF1, 0, n=d)
-        self.add_latent.emit(ch, latent_invalid, ag_latent, z_embedded=rc.get("latent_embedded"), z_premasked=bool(rc.get("latent_premasked")))
-        self.action_head.emit(ch, prep["type_mask"], out["action_mean"])
-        ch.run(n * A)
 
     def _heads_tile_raw(self, prep, rc, ag_latent, latent_invalid, navi_valid_u8, out, rows: int):
         """tbx_heads_tile_t with raw = 1 (training's stepping pass at >= Schedule.tile_min_rows rows): the heads' two row chains -
