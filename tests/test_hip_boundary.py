@@ -308,3 +308,57 @@ def test_c2_free_rollout_80_steps_damped_policy(tb):
     buf.flatten_joint_future(1)
     _compare(buf, ro, T, 5e-3)
     torch.testing.assert_close(buf.tl_state_nll[:, 0].cpu(), ro["tl_state_nll"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("sizes,knn,K", [((8, 64, 8), 4, 1), ((16, 64, 8), 4, 4)])
+def test_scene_loader_graph_equals_eager_refill(tb, sizes, knn, K):
+    """pl_modules/scene_loader.SceneLoader: [encoders + RolloutEngine.refill + prime] captured as ONE hipGraph on static inputs. Three
+    different scenes loaded through the graph give, bit for bit, the rollout logs of an engine refilled eagerly with the same scenes
+    (which test_cached_engine_refilled_in_place_equals_fresh_engines ties to fresh engines) - poses, validity, actions, light states,
+    rewards - and the device-side light-sharing check of a refill passes (K > 1)."""
+    from types import SimpleNamespace
+
+    from tools.benchlib import rollout as R
+
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    SL = import_module("trafficbots_amd.pl_modules.scene_loader")
+    Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    E = import_module("trafficbots_amd.engine")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=knn), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    wm = wm.to(dev).eval()
+    wm.schedule = E.DEFAULT.replace(graph_steps=4)
+    a = SimpleNamespace(rollouts=K, scenes=1, agents=sizes[0])
+    T = 24
+
+    def scene(seed):
+        batch = tb.synthetic.make_scene(1, *sizes, seed=seed)
+        full = {**batch, **tb.synthetic.to_history_batch(batch)}
+        return wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+
+    scenes = [scene(s) for s in (21, 22, 23)]
+    keys = ("out_pose", "out_valid", "out_motion", "out_action", "out_tl_state", "out_reward", "out_reward_valid", "out_tf", "out_tl_nll",
+            "out_outside_map", "out_dest_reached")
+    logs = {}
+    for mode in ("eager", "graph"):
+        with E.use(wm.schedule):
+            eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
+            eng.reset(**R.engine_inputs(wm, scenes[0], a, dev, T))
+            eng.capture()
+            loader = SL.SceneLoader(eng, scenes[0], lambda sb: R.engine_inputs(wm, sb, a, dev, T)) if mode == "graph" else None
+            out = []
+            for bd in scenes[1:] + scenes[:1]:
+                if loader is not None:
+                    loader.load(bd)
+                else:
+                    eng.refill(**R.engine_inputs(wm, bd, a, dev, T))
+                eng.run(T, use_graph=True)
+                torch.cuda.synchronize()
+                out.append({k: eng.S[k].clone() for k in keys})
+                eng.buffer(10)  # (reads the device-side light-sharing flag of the refill: must not raise)
+        logs[mode] = out
+    assert not torch.equal(logs["eager"][0]["out_pose"], logs["eager"][1]["out_pose"])  # the scenes do differ
+    for i, (e, g) in enumerate(zip(logs["eager"], logs["graph"])):
+        for k in keys:
+            assert torch.equal(e[k], g[k]), (i, k)

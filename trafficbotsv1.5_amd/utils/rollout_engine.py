@@ -90,7 +90,7 @@ class RolloutEngine:
               ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
               map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int,
               reward_weights=(0.1, 10.0, 0.1), ag_navi_log_prob: Optional[Tensor] = None, stepwise: bool = False,
-              _lights_ahead_pass: bool = True) -> None:
+              _lights_ahead_pass: bool = True, _tl_div: Optional[int] = None) -> None:
         """All tensors on the device. gt_* [n,A,Tg(,3)], tl_state_gt [n,L,Tt,5] bool, tf_mask [n,A,Tg] bool
         (TeacherForcing.ag_teacher_forcing), ag_navi [n,A] int64 dest; map_* are the raw polylines of the scene(s)
         ([n/div, M, N, ..]) for the destination check. reward_weights = (l_pos, l_rot, l_spd).weight of the
@@ -108,12 +108,22 @@ class RolloutEngine:
         self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
         # lights once per scene when the K = div rollouts of every scene were given identical lights (one host check per reset)
         kl = 1
+        self.tl_share_ok = None
         if self.sched.share_lights and not stepwise and div > 1 and n % div == 0 and tl_tokens.get("tl_batch_div", 1) == 1:
             g = tl_state_gt.reshape(n // div, div, *tl_state_gt.shape[1:])
             tv = tl_tokens["tl_token_valid"].reshape(n // div, div, L)
             tp = tl_tokens["tl_token_pose"].reshape(n // div, div, L, 3)
-            if bool((g == g[:, :1]).all()) and bool((tv == tv[:, :1]).all()) and bool((tp == tp[:, :1]).all()):
-                kl = div
+            same = (g == g[:, :1]).all() & (tv == tv[:, :1]).all() & (tp == tp[:, :1]).all()
+            if _tl_div is None:
+                if bool(same):  # (one host check per reset)
+                    kl = div
+            else:
+                # refill: the engine's graphs were captured for _tl_div; the new scene's lights must be shared the same way. The
+                # check stays on the device (no host round trip between scenes) and is read when the log is handed out (buffer())
+                kl = _tl_div
+                self.tl_share_ok = same if kl > 1 else ~same
+        elif _tl_div is not None:
+            kl = _tl_div
         self.tl_div = kl
         nl = n // kl  # light batch entries
         self.tl_invalid_full = tl_tokens["tl_token_invalid"] if "tl_token_invalid" in tl_tokens else ~tl_tokens["tl_token_valid"]
@@ -145,8 +155,10 @@ class RolloutEngine:
         self.dest = ag_navi.contiguous()
         # ---- initial dynamic state (Dynamics.init, dynamics.py:29-64) and its pristine copy
         init = dict(
-            step=torch.tensor([1, 0], dtype=torch.int32, device=dev),  # [step index, arrival counter of the fused advance]
-            step_tl=torch.tensor([1, 0], dtype=torch.int32, device=dev),  # the lights' own copy (sim_state_tl_own below)
+            # [step index = 1, arrival counter of the fused advance = 0], built on the device: torch.tensor([..], device=) is a
+            # BLOCKING host-to-device copy - it would wait for the previous scene's whole rollout on this stream (refill)
+            step=torch.arange(1, -1, -1, dtype=torch.int32, device=dev),
+            step_tl=torch.arange(1, -1, -1, dtype=torch.int32, device=dev),  # the lights' own copy (sim_state_tl_own below)
             ag_valid=_u8(gt_valid[:, :, 0]), ag_disabled=z(n, A, dt=u8), ag_pose=gt_pose[:, :, 0].float().contiguous(),
             ag_motion=gt_motion[:, :, 0].float().contiguous(), navi_valid=_u8(ag_navi_valid), outside_map=z(n, A, dt=u8),
             dest_reached=z(n, A, dt=u8), tl_state=S["tl_gt"][:, :, 0].contiguous(),
@@ -199,7 +211,7 @@ class RolloutEngine:
         own.step = S["step_tl"].data_ptr()
         self.sim_state_tl_own = own
         self.policy_out = dict(action_mean=S["action_mean"], tl_logits=S["tl_logits"])
-        self.graph = self.graph_multi = self.graph_prime = None
+        self.graph = self.graph_multi = self.graph_prime = self.graph_refill = None
         self._prime_prepares = False
         self._tl_prep = None
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
@@ -226,13 +238,26 @@ class RolloutEngine:
         """ANOTHER scene of the same shapes (reset's arguments) into this engine's buffers, in place: every pointer the captured
         hipGraphs hold stays valid, so a loop over scenes (the reference's validation_step, waymo_motion.py:526) pays the capture
         once per shape instead of once per rollout. The engine owns the token dicts it was first reset with: their tensors are
-        overwritten. Results are those of a fresh engine, bit for bit (tests/test_hip_rollout.py)."""
+        overwritten. Results are those of a fresh engine, bit for bit (tests/test_hip_rollout.py).
+        = refill_prepare (reads nothing of this engine's state: may run beside its rollout) + refill_commit."""
+        self.refill_commit(self.refill_prepare.__wrapped__(self, **kw))
+
+    @_scheduled
+    def refill_prepare(self, **kw) -> "RolloutEngine":
+        """The derived state of the new scene as a scratch engine (reset's arithmetic on reset's arguments). Touches none of THIS
+        engine's buffers: it may be enqueued on another stream while this engine's rollout of the previous scene is still running."""
         key = self.shape_key(**kw)
         if key != self._shape_key:
             raise ValueError("refill: shapes differ from the ones this engine was built for (use a new engine)")
         fresh = RolloutEngine(self.model, self.dyn, self.dev, schedule=self.sched)
-        RolloutEngine.reset.__wrapped__(fresh, _lights_ahead_pass=False, **kw)
-        assert fresh.tl_div == self.tl_div, "refill: the new scene's lights are (not) shared across its rollouts unlike the first scene's"
+        RolloutEngine.reset.__wrapped__(fresh, _lights_ahead_pass=False, _tl_div=self.tl_div, **kw)
+        return fresh
+
+    @_scheduled
+    def refill_commit(self, fresh: "RolloutEngine") -> None:
+        """refill_prepare's result into this engine's buffers (the ones its graphs read) + the map K/V tables + the priming of the
+        first step. Must follow this engine's previous rollout in stream order."""
+        self.tl_share_ok = fresh.tl_share_ok  # (device flag: checked in buffer(), not here - no host round trip between scenes)
         assert fresh.S.keys() == self.S.keys()
         for k, v in fresh.S.items():
             self.S[k].copy_(v)
@@ -240,9 +265,13 @@ class RolloutEngine:
             self.init_state[k].copy_(v)
         for name in ("ag_attr6", "ag_latent", "latent_invalid", "dest"):
             getattr(self, name).copy_(getattr(fresh, name))
+        # (what buffer() reads on the host side: engine-owned copies - `fresh` may be overwritten by the NEXT scene's prepare while
+        # this scene's log is still to be handed out)
         if torch.is_tensor(self.tl_invalid_full):
-            self.tl_invalid_full = fresh.tl_invalid_full  # (host-side use only: buffer())
-        self.ag_type, self.navi_log_prob0, self.navi_valid0 = fresh.ag_type, fresh.navi_log_prob0, fresh.navi_valid0
+            self.tl_invalid_full = self._own("tl_invalid_full", fresh.tl_invalid_full)
+        self.ag_type = self._own("ag_type", fresh.ag_type)
+        self.navi_valid0 = self._own("navi_valid0", fresh.navi_valid0)
+        self.navi_log_prob0 = None if fresh.navi_log_prob0 is None else self._own("navi_log_prob0", fresh.navi_log_prob0)
         self._copy_tokens(self.mp_tokens, fresh.mp_tokens)
         self._copy_tokens(self.tl_tokens, fresh.tl_tokens)
         # per-scene K/V tables of the map tokens (cached in the token dicts): recomputed into the tables the graphs read
@@ -257,6 +286,71 @@ class RolloutEngine:
         self.parity = 0
         self._n_forward = 0
         self._prime()
+
+    def _own(self, name: str, src: Tensor) -> Tensor:
+        """An engine-owned tensor `name` holding a copy of src (allocated once, refilled in place)."""
+        own = self.__dict__.setdefault("_owned", {})
+        if name not in own or own[name].shape != src.shape or own[name].dtype != src.dtype:
+            own[name] = torch.empty_like(src)
+        own[name].copy_(src)
+        return own[name]
+
+    def capture_refill(self, make_kw) -> None:
+        """`refill` of this engine as TWO hipGraphs. make_kw() builds reset's keyword arguments from STATIC input tensors (the caller
+        overwrites those in place, then replays):
+          graph_prepare  make_kw() + refill_prepare: the once-per-scene encoders if make_kw runs them + the derived state. Reads
+                         nothing of the engine: replayed on a SIDE stream beside the previous scene's rollout (prefetch_refill);
+          graph_commit   refill_commit: ~80 copies into the buffers the step graphs read, the map K/V tables, the lights' first pass,
+                         the first tbx_agent_prep. Replayed on the launch stream behind that rollout (commit_refill).
+        ~300 launch-bound launches per scene become two (a loop over scenes paid ~2 ms of device time per scene for them eagerly,
+        tools/scene_loop_profile.py). Nothing in refill waits for the device or draws random numbers, so the capture is exact:
+        replays equal eager refills bit for bit (tests/test_hip_boundary.py)."""
+        assert self.graph is not None, "capture() the step graphs first"
+        main = torch.cuda.current_stream()
+        self._refill_side = torch.cuda.Stream(device=self.dev)
+        side = self._refill_side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # eager warm-up off the launch stream (allocator growth, weight images, caches)
+            self.refill(**make_kw())
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            fresh = self.refill_prepare(**make_kw())
+        with torch.cuda.graph(gb):
+            self.refill_commit(fresh)
+        self.graph_prepare, self.graph_commit, self._fresh_static = ga, gb, fresh
+        self.graph_refill = gb
+        self._tl_share_static = self.tl_share_ok  # (device flag of the light-sharing check, rewritten by every replay)
+        self._ev_prepared = self._ev_committed = None
+
+    def prefetch_refill(self, fill_inputs=None) -> None:
+        """graph_prepare on the side stream: fill_inputs() (the caller's in-place copies into the static inputs) + the replay. Call
+        it right after the previous scene's run() was enqueued - it executes beside that rollout."""
+        main, side = torch.cuda.current_stream(), self._refill_side
+        side.wait_stream(main)  # (the scene tensors were made on the launch stream; the previous commit has read `fresh`)
+        with torch.cuda.stream(side):
+            if fill_inputs is not None:
+                fill_inputs()
+            self.graph_prepare.replay()
+            self._ev_prepared = side.record_event()
+
+    def commit_refill(self) -> None:
+        """graph_commit on the launch stream, behind the prepare and behind this engine's previous rollout (stream order)."""
+        main = torch.cuda.current_stream()
+        if self._ev_prepared is not None:
+            main.wait_event(self._ev_prepared)
+            self._ev_prepared = None
+        self.graph_commit.replay()
+        self.tl_share_ok = self._tl_share_static
+        self.parity = 0
+        self._n_forward = 0
+        self._prep_ready = self._prime_prepares
+
+    def replay_refill(self, fill_inputs=None) -> None:
+        """prefetch_refill + commit_refill back to back (no overlap with a rollout)."""
+        self.prefetch_refill(fill_inputs)
+        self.commit_refill()
 
     @staticmethod
     def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor]) -> None:
@@ -286,7 +380,7 @@ class RolloutEngine:
         first step, logits for the lights' first update) and, with a fused tail, the first step's tbx_agent_prep. Eagerly these are ~7
         launches behind ~1.2 ms of host work per rollout; capture() records them once (graph_prime: every buffer they touch is
         refilled in place) and every later restore() / refill() replays that."""
-        if self.graph_prime is not None:
+        if self.graph_prime is not None and not torch.cuda.is_current_stream_capturing():  # (inside capture_refill: eagerly, into that graph)
             self.policy_out["tl_kv"] = self.tl_kv[0]
             self.graph_prime.replay()
             self._prep_ready = self._prime_prepares
@@ -485,6 +579,11 @@ class RolloutEngine:
         (collided, collided_wosac, run_road_edge, run_red_light, passive: waymo_motion.py:250 in the reference's loop) are
         evaluated here for all steps at once from the device-resident log (tbx_rule_check over n x T frames)."""
         S, buf = self.S, RolloutBuffer(self.T, step_current)
+        if getattr(self, "tl_share_ok", None) is not None:
+            ok, self.tl_share_ok = self.tl_share_ok, None
+            if not bool(ok):  # (the one host read of a refilled engine's rollout; the log is about to be read anyway)
+                raise RuntimeError("refill: the new scene's lights are (not) shared across its rollouts unlike the scene this engine was "
+                                   "captured for (use a new engine: WaymoMotion.engine_cache = 0)")
         if self.reused:  # the log tensors are rewritten by this engine's next rollout: the buffer gets its own copies
             S = {k: (v.clone() if k.startswith("out_") else v) for k, v in S.items()}
         buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
