@@ -561,3 +561,18 @@ def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
         buf.flatten_joint_future(1)
         for n_cmp, tol in checks:
             _compare(buf, ro, n_cmp, tol)
+        # ---- the rollout-level acceptance figures over the WHOLE 90-step horizon (where point-wise comparison has long given way
+        # to the loop's amplification): average displacement error against the oracle's trajectory over every valid agent-step,
+        # final displacement error at step 90, and agreement of the logged validity / map-exit / destination flags. Stated for both
+        # arithmetic classes; the default (split-bf16 LINEAR stages) is the one closed-loop metrics run on.
+        pv = ro["pred_valid"]
+        d = (buf.pred_pose[:, 0, :, :, :2].cpu() - ro["pred_pose"][..., :2]).norm(dim=-1)
+        both = pv & buf.pred_valid[:, 0].cpu()
+        ade, fde = float(d[both].mean()), float(d[..., -1][both[..., -1]].mean())
+        agree = lambda a_, b_: float((a_ == b_).float().mean())
+        flags = min(agree(buf.pred_valid[:, 0].cpu(), pv), agree(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]),
+                    agree(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"]))
+        print(f"[rollout acceptance] tile_small={tile_small}: ADE {ade:.4g} m, FDE {fde:.4g} m over 90 steps, flag agreement {flags:.4f}")
+        # measured (MI355X): exact-fp32 schedule ADE 0.67 mm / FDE 6.0 mm, default schedule ADE 1.5 mm / FDE 11 mm, flags 100 %
+        ade_max, fde_max = (3e-3, 5e-2) if not tile_small else (1e-2, 0.1)
+        assert ade < ade_max and fde < fde_max and flags >= 0.995, (tile_small, ade, fde, flags)
