@@ -381,10 +381,11 @@ def gen_model(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_roll_steps, train_fixture):
     npz(f"model_{tag}.npz", **out)
 
 
-def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn):
+def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_sc=1):
     """§8a rows 19-20 at the size of BASELINE config 3's scenes (one scene of 64 agents / 1024 polylines / 128 lights): the
     reference's training_step with every RNG site neutralised and the damped action head (see gen_model): loss dict, per-module
-    gradient norms, spot gradients. ~3 min of reference CPU time."""
+    gradient norms, spot gradients. ~3 min of reference CPU time. n_sc > 1: a BATCH of scenes (BASELINE config 3 trains on batches:
+    the loss terms are ratios of sums over the whole batch, metrics/training.py:166-186)."""
     torch.manual_seed(0)
     mcfg0 = ref_model_cfg(n_tgt_knn=n_tgt_knn)
     mcfg0["tf_cfg"]["dropout_p"] = 0.0
@@ -399,7 +400,7 @@ def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn):
         for k, p in wm_t.model.named_parameters():
             if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
                 p.mul_(0.02)
-    batch = tb.synthetic.make_scene(1, n_ag, n_mp, n_tl, seed=0)
+    batch = tb.synthetic.make_scene(n_sc, n_ag, n_mp, n_tl, seed=0)
     torch.manual_seed(7)
     loss = wm_t.training_step({k: v.clone() for k, v in batch.items()}, 0)
     loss.backward()
@@ -481,7 +482,7 @@ def gen_filter():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "rules", "filter"]
+    which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "train_c1_b3", "rules", "filter"]
     if "filter" in which:
         gen_filter()
     if "rules" in which:
@@ -494,3 +495,5 @@ if __name__ == "__main__":
         gen_model("c2", 64, 1024, 128, 32, n_roll_steps=14, train_fixture=False)
     if "train_c2" in which:
         gen_train("c2", 64, 1024, 128, 32)
+    if "train_c1_b3" in which:
+        gen_train("c1_b3", 8, 64, 8, 4, n_sc=3)

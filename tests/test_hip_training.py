@@ -47,8 +47,9 @@ def test_attention_backward_vs_oracle_autograd(tb):
         torch.testing.assert_close(p.grad.cpu(), P["a." + k].grad, **tol)
 
 
-@pytest.mark.parametrize("sizes,knn,fixture", [((8, 64, 8), 4, "model_c1.npz"), ((64, 1024, 128), 32, "train_c2.npz")])
-def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture):
+@pytest.mark.parametrize("sizes,knn,fixture,n_sc", [((8, 64, 8), 4, "model_c1.npz", 1), ((64, 1024, 128), 32, "train_c2.npz", 1),
+                                                    ((8, 64, 8), 4, "train_c1_b3.npz", 3)])  # last: a BATCH of 3 scenes (the reference's own numbers)
+def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture, n_sc):
     """One training_step with every RNG site neutralised (dropout 0, posterior latent, no random forcing) at C1 and at the
     scene size of BASELINE config 3 (64 agents / 1024 polylines / 128 lights, default K-nearest sizes: the shape behind the
     training scenes/s figure): loss terms vs the reference's golden values; per-module gradient norms vs the reference's; spot
@@ -71,7 +72,7 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
             if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
                 p.mul_(0.02)
     wm = wm.to(dev).train()
-    batch = tb.synthetic.make_scene(1, *sizes, seed=0)
+    batch = tb.synthetic.make_scene(n_sc, *sizes, seed=0)
     torch.manual_seed(7)
     loss = wm.training_step({k: v.to(dev) for k, v in batch.items()}, 0)
     loss.backward()

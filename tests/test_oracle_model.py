@@ -87,11 +87,12 @@ def test_model_c2_eval(tb, golden_dir):
     check_eval(tb, g, cfg, P, (64, 1024, 128), 14, dict(rtol=2e-4, atol=2e-5))
 
 
-@pytest.mark.parametrize("damped", [False, True])
-def test_model_c1_training_step(tb, golden_dir, damped):
+@pytest.mark.parametrize("damped,n_sc", [(False, 1), (True, 1), (True, 3)])
+def test_model_c1_training_step(tb, golden_dir, damped, n_sc):
     """Row 19/20: loss dict and per-module gradient norms of one training_step with every RNG site neutralised
-    (also with the action head damped by 0.02: the non-chaotic variant the GPU path is compared on)."""
-    g = np.load(golden_dir / "model_c1.npz")
+    (also with the action head damped by 0.02: the non-chaotic variant the GPU path is compared on; n_sc = 3: a BATCH of three
+    scenes - the reference's loss terms are ratios of sums over the batch, metrics/training.py:166-186)."""
+    g = np.load(golden_dir / ("model_c1.npz" if n_sc == 1 else f"train_c1_b{n_sc}.npz"))
     pre = "dtrain_" if damped else "train_"
     gpre = "dgradnorm_" if damped else "gradnorm_"
     cfg, P = build(tb, 4, no_dropout=True)
@@ -106,7 +107,7 @@ def test_model_c1_training_step(tb, golden_dir, damped):
     scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
     m = O.TrafficBotsOracle(P, cfg, training=True)
     sim = O.Sim(m, scfg, training=True)
-    batch = tb.synthetic.make_scene(1, 8, 64, 8, seed=0)
+    batch = tb.synthetic.make_scene(n_sc, 8, 64, 8, seed=0)
     torch.manual_seed(7)
     out = sim.training_step(batch)
     for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss"):

@@ -1,18 +1,19 @@
 # Final-build evidence for a round, on the GPU box (gpurun): GPU test suite, kernel-trace + PMC passes of the 64-agent scene and the
 # 32 x 128 shape with fp32 and bf16 tables (tools/profile_round.sh), SQ / cache counters of the attention kernel (tools/pmc_attn.sh),
-# kernel stats of two eager training steps, and the default bench line. TAG=r03 by default; copy the summaries from gpurun_out/ into
+# kernel stats of two eager training steps, and the default bench line. TAG=r04 by default; copy the summaries from gpurun_out/ into
 # profiles/.
 set -x
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 mkdir -p gpurun_out
-tag=${TAG:-r03}
+tag=${TAG:-r04}
 if [ -z "${SKIP_TESTS:-}" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${tag}_gpu_tests.log; fi
 bash tools/profile_round.sh ${tag}_c2 64 1024 128 1 1
 bash tools/profile_round.sh ${tag}_c5 128 1024 128 1 32 --steps 40
-bash tools/profile_round.sh ${tag}_c5_bf16 128 1024 128 1 32 --steps 40 --kv-bf16
+bash tools/profile_round.sh ${tag}_c5_bf16 128 1024 128 1 32 --steps 40 --kv-bf16 --attn-mfma 1  # (Schedule.reduced(): bf16 tables + matrix-core attention)
 bash tools/profile_round.sh ${tag}_c2_bf16 64 1024 128 1 1 --kv-bf16
-TAG=$tag bash tools/pmc_attn.sh
+TAG=${tag}_valu bash tools/pmc_attn.sh
+TAG=${tag}_mfma KPAT=%knarpe_attn_mfma_kernel% MINGRID=65536 EXTRA="--kv-bf16 --attn-mfma 1" bash tools/pmc_attn.sh
 # one steady-state step of the default two-stream graph replay, kernel by kernel
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/tl_final -o tl -- python3 $root/bench.py --no-cpu-baseline --no-wosac-shape --no-train-shape --no-bf16-shape --profile-steps 0 --new-scenes 0 > /dev/null 2>&1 )
 python3 tools/step_timeline2.py $(ls /tmp/tl_final/*.db | head -1) > gpurun_out/${tag}_c2_two_stream_timeline.txt 2>&1
