@@ -1101,66 +1101,6 @@ def test_attention_lds_ring_equals_small_launches(hip, dev, bf16, K0, K1):
     assert float((big - small).abs().max()) <= 1e-5 * scale, (float((big - small).abs().max()), scale)
 
 
-def test_attention_software_pipelined_form_equals_small_launches(dev):
-    """knarpe_attn_pf_kernel (opt-in, TBX_ATTN_PF: query side in LDS, the next pass's rows prefetched in registers; csrc/attn.hip -
-    a measured-slower experiment kept as a record) against the same rows launched in chunks of 600 rows (4 wavefronts per row):
-    the same per-pair arithmetic merged in a different order - 1e-5 of the largest output; fp32 and bf16 tables, two segments,
-    shared tables, a row without a valid target. Runs in a child process: the switch is read once per process."""
-    import subprocess
-    import sys
-    from pathlib import Path
-
-    root = Path(__file__).resolve().parent.parent
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from importlib import import_module
-from __graft_entry__ import load_package
-load_package()
-hip = import_module("trafficbots_amd.hip")
-from oracle import hptr_ops as H
-dev = torch.device("cuda:0")
-worst = 0.0
-for bf16, K0, K1 in ((False, 25, 64), (True, 24, 88), (False, 70, 0)):
-    g = torch.Generator().manual_seed(K0 * 7 + K1)
-    n, S, T0, T1, D = 8, 300, 300, 500, 128
-    rows = n * S
-    qbuf = torch.randn(rows, 640, generator=g).to(dev)
-    bias = torch.randn(128, generator=g).to(dev)
-    fxy, fyw = H.make_freqs_xy(32, 1e3).to(dev), H.make_freqs_rad(64).to(dev)
-    def seg(T, K, div):
-        kv = torch.randn((n // div) * T, 256, generator=g)
-        kv = (kv.to(torch.bfloat16) if bf16 else kv).to(dev)
-        idx = torch.randint(0, T, (n, S, K), generator=g).to(torch.int32).to(dev)
-        inv = (torch.rand(n, S, K, generator=g) < 0.3).to(torch.uint8)
-        inv[1, 5] = 1
-        rel = torch.cat([(torch.rand(n, S, K, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K, 1, generator=g) - 0.5) * 6], -1).to(dev).contiguous()
-        return kv, idx, inv.to(dev), rel, T, div
-    specs = [seg(T0, K0, 1)] + ([seg(T1, K1, 2)] if K1 else [])
-    def run(r0, r1, out, flag):
-        nb = (r1 - r0) // S
-        segs = [hip.Seg(kv[(r0 // S // div) * T:], 0, D, T, idx[r0 // S:r1 // S].contiguous(), inv[r0 // S:r1 // S].contiguous(), None, div,
-                        rel=rel[r0 // S:r1 // S].contiguous()) for kv, idx, inv, rel, T, div in specs]
-        hip.knarpe_attn(qbuf[r0:r1], 0, D, bias, nb, S, segs, out[r0:r1], flag[r0:r1], fxy, fyw)
-    big, bflag = torch.full((rows, 640), 3.0, device=dev), torch.full((rows,), 9, dtype=torch.uint8, device=dev)
-    run(0, rows, big, bflag)  # 2400 rows >= TBX_ATTN_PF
-    small, sflag = torch.full((rows, 640), 5.0, device=dev), torch.full((rows,), 9, dtype=torch.uint8, device=dev)
-    for r0 in range(0, rows, 2 * S):
-        run(r0, r0 + 2 * S, small, sflag)
-    torch.cuda.synchronize()
-    assert torch.equal(bflag, sflag) and int(bflag[S + 5]) == 1 and float(big[S + 5].abs().max()) == 0.0
-    worst = max(worst, float((big - small).abs().max()) / float(small.abs().max()))
-print("WORST", worst)
-""" % str(root)
-    import os
-
-    env = dict(os.environ, TBX_ATTN_PF="2048", TBX_ATTN_RING_LONE_ROWS="0")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    worst = float(out.stdout.strip().splitlines()[-1].split()[1])
-    assert worst <= 1e-5, worst
-
-
 @pytest.mark.parametrize("m,k,n,wt,bias", [(1000, 128, 128, False, True), (70001, 128, 640, False, True), (4097, 640, 128, False, False),
                                            (12345, 256, 128, True, False), (333, 128, 512, True, False), (64, 512, 256, False, True)])
 def test_tall_linear_equals_the_library_product(hip, dev, m, k, n, wt, bias):

@@ -270,184 +270,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 
   }  // quad loop
 }
 
-// =====================================================================================================================
-// The wave-per-row forward for LARGE launches, software-pipelined: the sweep is one dependent pass after another - target index ->
-// 8 row gathers (~2300 shader clocks under load) -> ~1250 clocks of arithmetic (profiles/r03_attn_phase_clock.txt) - and
-// knarpe_attn_kernel has ONE pass in flight per wave at two waves per SIMD (~250 VGPRs): the VALU idles a third of the time and
-// registers cannot hold a second pass's rows. Here the query side leaves the registers - q (16 floats per lane) and W_k^T q (64
-// per lane) are only READ, once per pass: they sit in a per-wave 2.5 KiB LDS copy (17 ds_read_b128 per pass and lane, broadcast
-// within each 8-lane target slot) - and the 80 registers hold the NEXT pass's operands instead: the target index / mask are
-// requested two passes ahead, the K / V rows and the relative pose one pass ahead, so a pass's arithmetic runs under the next
-// pass's gathers (in-order VMEM returns: the waits the compiler places are for the older requests only). Passes in the same order,
-// the same arithmetic: rows bit-identical to knarpe_attn_kernel's (tested). MEASURED SLOWER (see the launch code below): kept as the
-// record of the experiment, opt-in. (Three waves per SIMD with the query in LDS and one pass in flight was also built: 168 VGPRs do
-// not hold the sweep - 80-96 spilled registers, 2.2 x slower.)
-template <bool KV16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void knarpe_attn_pf_kernel(const AttnArgs a) {
-  // per wave: q [128] | W_k^T q [4 x 128] | q . b_k per head [4] | the 8 channel slices' embedding frequencies [8][8] (6 used)
-  constexpr int QB_OFF = D + NH * DR, FQ_OFF = QB_OFF + 4;
-  __shared__ __attribute__((aligned(16))) float q_s[4][FQ_OFF + 64];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int quad = blockIdx.x;
-  int row = __builtin_amdgcn_readfirstlane(quad * 4 + wave);
-  if (a.batch_major) row = __builtin_amdgcn_readfirstlane((4 * (quad / a.n_src) + wave) * a.n_src + quad % a.n_src);
-  if (row >= a.n_rows) return;
-  const int b = row / a.n_src;
-  const int s8 = lane & 7, tg = lane >> 3;
-  const float* qrow = a.qbuf + (int64_t)row * a.ldq;
-  float* ql = q_s[wave];
-  // the wave's own copy (LDS operations of one wave complete in order: no barrier between these writes and the passes' reads)
-  if (lane < 32) *(float4*)(ql + lane * 4) = *(const float4*)(qrow + a.q_off + lane * 4);
-  *(float4*)(ql + D + lane * 4) = *(const float4*)(qrow + a.qt_off + lane * 4);
-  *(float4*)(ql + D + 256 + lane * 4) = *(const float4*)(qrow + a.qt_off + 256 + lane * 4);
-  {
-    EFreq fq;
-    fq.init(a.fxy, a.fyaw, s8);
-    if (tg == 0) {
-      *(float2*)(ql + FQ_OFF + s8 * 8) = make_float2(fq.fx[0], fq.fx[1]);
-      *(float4*)(ql + FQ_OFF + s8 * 8 + 4) = make_float4(fq.fw[0], fq.fw[1], fq.fw[2], fq.fw[3]);
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float4 q = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
-      const float4 bk = *(const float4*)(a.rpe_k_bias + h * DH + s8 * 4);
-      const float qbh = tbx::group8_sum(dot4(q, bk));
-      if (lane == 0) ql[QB_OFF + h] = qbh;
-    }
-  }
-  RowAcc st;
-  st.zero();
-  float(&m_run)[NH] = st.m_run;
-  float(&l_run)[NH] = st.l_run;
-  float4(&oacc)[NH] = st.oacc;
-  ESlice(&eacc)[NH] = st.eacc;
-  // flat pass index p: segment 0's passes, then segment 1's (8 targets each)
-  const int P0 = (a.seg[0].k + 7) >> 3;
-  const int P = P0 + (a.n_seg > 1 ? (a.seg[1].k + 7) >> 3 : 0);
-  typedef typename std::conditional<KV16, uint2, float4>::type kv4_t;  // bf16 tables: 4 channels stay packed until the pass uses them
-  struct Raw {
-    kv4_t kq[4], v[4];
-    float rx, ry, rw;
-  };
-  auto widen = [](const kv4_t& x) -> float4 {
-    if constexpr (KV16)
-      return make_float4(__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u), __uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u));
-    else
-      return x;
-  };
-  auto load_idx = [&](int p, int& j, bool& ok) {
-    const bool live = p < P;
-    p = live ? p : P - 1;
-    const tbx_attn_seg_t& S = a.seg[p < P0 ? 0 : 1];
-    const int t = (p < P0 ? p : p - P0) * 8 + tg;
-    const bool active = t < S.k;
-    const int64_t pi = (int64_t)row * S.k + (active ? t : S.k - 1);
-    j = S.idx[pi];
-    ok = (S.invalid[pi] == 0) & active & live;
-  };
-  auto load_rows = [&](int p, int j, Raw& r) {
-    p = p < P ? p : P - 1;
-    const tbx_attn_seg_t& S = a.seg[p < P0 ? 0 : 1];
-    constexpr int ES = KV16 ? 2 : 1;
-    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-    const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
-    const int t = (p < P0 ? p : p - P0) * 8 + tg;
-    const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if constexpr (KV16) {
-        r.kq[q] = *(const uint2*)((const uint16_t*)trow + S.k_off + q * 32 + s8 * 4);
-        r.v[q] = *(const uint2*)((const uint16_t*)trow + S.v_off + q * 32 + s8 * 4);
-      } else {
-        r.kq[q] = *(const float4*)(trow + S.k_off + q * 32 + s8 * 4);
-        r.v[q] = *(const float4*)(trow + S.v_off + q * 32 + s8 * 4);
-      }
-    }
-    r.rx = S.rel_pose[pi * 3], r.ry = S.rel_pose[pi * 3 + 1], r.rw = S.rel_pose[pi * 3 + 2];
-  };
-  auto pass = [&](const Raw& r, const bool ok) {  // attn_core.h's sweep body, the query side read from LDS
-    int zero = 0;
-    asm volatile("" : "+v"(zero));  // (an offset the compiler cannot see through: the query-side reads stay inside the pass - hoisted
-    const float* qp = ql + zero;    //  out of the loop as invariant they would be the 90 registers again)
-    ESlice e;
-    {
-      EFreq fq;
-      const float2 fx = *(const float2*)(qp + FQ_OFF + s8 * 8);
-      const float4 fw = *(const float4*)(qp + FQ_OFF + s8 * 8 + 4);
-      fq.fx[0] = fx.x, fq.fx[1] = fx.y, fq.fw[0] = fw.x, fq.fw[1] = fw.y, fq.fw[2] = fw.z, fq.fw[3] = fw.w;
-      const float rel[3] = {r.rx, r.ry, r.rw};
-      fq.embed(rel, e);
-    }
-    float sc[NH];
-    bool jump = false;
-    const float4 qb4 = *(const float4*)(qp + QB_OFF);
-    const float qb[NH] = {qb4.x, qb4.y, qb4.z, qb4.w};
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float4 qvh = *(const float4*)(qp + h * DH + s8 * 4);
-      ESlice qth;
-      qth.load(qp + D + h * DR, s8);
-      sc[h] = (tbx::group8_sum(pair_score(widen(r.kq[h]), qvh, e, qth)) + qb[h]) * a.scale2;
-      jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
-    }
-    if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
-          const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
-          l_run[h] *= alpha;
-          scale4(oacc[h], alpha);
-          eacc[h].scale(alpha);
-          m_run[h] = sc[h];
-        }
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];
-      const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
-      l_run[h] += pr;
-      fma4(oacc[h], pr, widen(r.v[h]));
-      eacc[h].fma(pr, e);
-    }
-  };
-  Raw A, B;
-  int jE, jO;
-  bool okE, okO, okA, okB;
-  load_idx(0, jE, okE);
-  load_idx(1, jO, okO);
-  load_rows(0, jE, A);
-  okA = okE;
-  for (int p = 0; p < P; p += 2) {
-    load_idx(p + 2, jE, okE);
-    load_rows(p + 1, jO, B);
-    okB = okO;
-    pass(A, okA);
-    if (p + 1 >= P) break;
-    load_idx(p + 3, jO, okO);
-    load_rows(p + 2, jE, A);
-    okA = okE;
-    pass(B, okB);
-  }
-  float M[NH], L[NH];
-  merge_slots(st, M, L);
-  float* orow = a.out + (int64_t)row * a.ldo;
-  const bool any_valid = M[0] > -INFINITY;
-  if (tg == 0) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
-      float4 o = oacc[h];
-      scale4(o, inv_l);
-      *(float4*)(orow + h * DH + s8 * 4) = o;
-      ESlice ev = eacc[h];
-      ev.scale(inv_l);
-      ev.store(orow + D + h * DR, s8);
-    }
-  }
-  if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
-}
+// (A software-pipelined wave-per-row form - the query side in a per-wave LDS copy, the next pass's K / V rows and pose requested one
+// pass ahead - was built in round 3 and measured SLOWER at the 32 x 128 shape (fp32 tables 5.97 -> 5.16 M agent-steps/s with 15
+// spilled registers, bf16 tables 5.93 -> 5.57 M): git history (knarpe_attn_pf_kernel) and profiles/MEASUREMENT_LOG.md, not the build.
+// The matrix-core form of large launches is csrc/attn_mfma.hip.)
 
 // =====================================================================================================================
 // LDS-ring form of the wave-per-row forward (large launches, inference). Why: at 4096 rows x 104 pairs the sweep above runs
@@ -1095,19 +921,6 @@ extern "C" int tbx_knarpe_attn_fwd_dropout_tb(const float* qbuf, int ldq, int q_
     else
       TBX_RING_LAUNCH(false, 4, 1, false);
 #undef TBX_RING_LAUNCH
-    return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
-  }
-  // large launches without dropout, every segment given as relative poses: the software-pipelined form - opt-in (TBX_ATTN_PF=1: from
-  // 2048 rows, TBX_ATTN_PF=<rows>: from that many): measured SLOWER than knarpe_attn_kernel at the 32 x 128 shape (fp32 tables 5.97 ->
-  // 5.16 M agent-steps/s with 15 spilled registers, bf16 tables 5.93 -> 5.57 M with 3) - DESIGN.md 0
-  static const int pf_rows = [] { const char* e = getenv("TBX_ATTN_PF"); return !e || atoi(e) == 0 ? INT_MAX : (atoi(e) > 1 ? atoi(e) : 2048); }();
-  bool pf_ok = big && a.drop_thresh == 0u && a.n_rows >= pf_rows;
-  for (int i = 0; i < n_seg; ++i) pf_ok = pf_ok && segs[i].rel_pose != nullptr && segs[i].emb == nullptr && segs[i].k > 0;
-  if (pf_ok) {
-    if (segs[0].kv_bf16 != 0)
-      hipLaunchKernelGGL((knarpe_attn_pf_kernel<true>), grid, block, 0, hs, a);
-    else
-      hipLaunchKernelGGL((knarpe_attn_pf_kernel<false>), grid, block, 0, hs, a);
     return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
   }
   if (segs[0].kv_bf16 != 0) {  // bf16 K/V tables: inference only

@@ -445,6 +445,263 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention at THREE waves per SIMD (knarpe_attn_mfma3_kernel). knarpe_attn_mfma_kernel holds 64 accumulator registers per
+// lane of which a quarter are useful (heads padded 4 -> 16 in stage 2) and 32 targets' K / V rows: 250 VGPRs, two waves per SIMD,
+// a third of the SIMD's cycles busy (profiles/r04_attn_mfma_counters.json). Here
+//   * stage 2 runs on v_mfma_f32_4x4x4_16B_bf16 (16 blocks of [4 heads] x [4 channels] x [4 targets], probed:
+//     tools/probes/mfma4x4_probe.hip): block b = lane >> 2 owns channels 4 b .. 4 b + 3 of a 64-channel group, its B operand (4
+//     targets of one channel per lane) is ONE transposing read of the [V | embedding] image for all 64 lanes, and the A operand -
+//     the 4 heads' weights of those 4 targets - sits, straight out of stage 1, in the four lanes 16 g .. 16 g + 3 = block 4 g: the
+//     instruction's A-broadcast (cbsz = 4, abid = 4 g) hands it to all 16 blocks. Every lane's 4 results are useful: 16 accumulator
+//     registers (4 channel groups) instead of 64;
+//   * a chunk is ONE 16-target tile: 16 + 16 registers of K / V rows, 9 KiB of LDS image per wave;
+// => <= 168 VGPRs and 11 KiB of LDS per wave: three workgroups (12 waves) per CU. Same pipeline across chunks and rows.
+constexpr int CH3 = 16;             // targets per chunk
+constexpr int YS3 = 288;            // halfwords per image row: 128 V | 128 embedding | 32 padding (576 B = 16 banks mod 64: the 4 rows
+                                    // of a transposing read land in 4 disjoint 64-byte windows per 32 lanes)
+struct Geom3 {
+  static constexpr int WAVE_BYTES = CH3 * YS3 * 2 + NH * DR * 4;
+  static constexpr int BYTES = WAVES * WAVE_BYTES + 64 * 4;
+};
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <bool KV16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void knarpe_attn_mfma3_kernel(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int m = lane & 15, kb = lane >> 4;
+  unsigned char* wbase = lds_raw + wave * Geom3::WAVE_BYTES;
+  uint16_t* img = (uint16_t*)wbase;                           // [16][YS3]
+  float* qst = (float*)(wbase + CH3 * YS3 * 2);               // the NEXT row's qt [4][128] floats, by LDS-DMA
+  float* frt = (float*)(lds_raw + WAVES * Geom3::WAVE_BYTES);  // [4 octet owners][16] frequencies / 2 pi (workgroup-wide)
+  if (threadIdx.x < 64) {
+    const int okb = threadIdx.x >> 4, oi = threadIdx.x & 15;
+    const float f = okb < 2 ? a.fxy[2 * oi] : a.fyaw[2 * (16 * (okb - 2) + oi)];
+    frt[threadIdx.x] = f * 0.15915494309189535f;
+  }
+  __syncthreads();
+  const int n_quads = a.batch_major ? a.n_rows / WAVES : (a.n_rows + WAVES - 1) / WAVES;
+  auto row_at = [&](int i) -> int {
+    const int q = (int)blockIdx.x + i * (int)gridDim.x;
+    if (q >= n_quads) return -1;
+    const int r = a.batch_major ? (WAVES * (q / a.n_src) + wave) * a.n_src + q % a.n_src : q * WAVES + wave;
+    return r < a.n_rows ? r : -1;
+  };
+  constexpr int EB = KV16 ? 2 : 4;
+  const int nch0 = (a.seg[0].k + CH3 - 1) / CH3;
+  const int nch = nch0 + (a.n_seg > 1 ? (a.seg[1].k + CH3 - 1) / CH3 : 0);
+  struct Meta {
+    int j;
+    uint8_t inv;
+    float u;
+  };
+  const int ucol = kb < 2 ? kb : 2;
+  auto seg_of = [&](int c) -> const tbx_attn_seg_t& { return a.seg[c >= nch0 ? 1 : 0]; };
+  auto t0_of = [&](int c) { return (c >= nch0 ? c - nch0 : c) * CH3; };
+  auto load_meta = [&](int row, int c, Meta& M) {
+    const tbx_attn_seg_t& S = seg_of(c);
+    const int t = t0_of(c) + m;
+    const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
+    M.j = S.idx[pi];
+    M.inv = S.invalid[pi];
+    M.u = S.rel_pose[pi * 3 + ucol];
+  };
+  auto seg_base = [&](int row, int c) -> const char* {
+    const tbx_attn_seg_t& S = seg_of(c);
+    return (const char*)S.kv + ((int64_t)((row / a.n_src) / S.batch_div) * S.n_tgt * S.ld_kv) * EB;
+  };
+  auto ok_mask = [&](int c, const Meta& M) -> uint64_t { return __ballot(M.inv == 0 && t0_of(c) + m < seg_of(c).k); };
+  bf16x8 akh[4], vvh[4];
+  auto load_k = [&](int row, int c, const Meta& M) {
+    const tbx_attn_seg_t& S = seg_of(c);
+    const char* base = seg_base(row, c);
+    const uint32_t r = (uint32_t)M.j * ((uint32_t)S.ld_kv * EB) + (uint32_t)(S.k_off + kb * 8) * EB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) akh[ks] = row8<KV16>(base, r + ks * 32 * EB);
+  };
+  auto load_v = [&](int row, int c, const Meta& M) {
+    const tbx_attn_seg_t& S = seg_of(c);
+    const char* base = seg_base(row, c);
+    const uint32_t r = (uint32_t)M.j * ((uint32_t)S.ld_kv * EB) + (uint32_t)(S.v_off + kb * 8) * EB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vvh[q] = row8<KV16>(base, r + q * 32 * EB);
+  };
+  const uint32_t qst_lds = lds_addr(qst);
+  f32x8 qk;
+  auto request_q = [&](int row) {
+    const float* qrow = a.qbuf + (int64_t)row * a.ldq;
+    glds_1k(qrow + a.qt_off + lane * 4, qst_lds);
+    glds_1k(qrow + a.qt_off + 256 + lane * 4, qst_lds + 1024u);
+    qk = load8f(qrow + a.q_off + (m & (NH - 1)) * DH + kb * 8);
+  };
+
+  int i_row = 0, row = row_at(0);
+  if (row < 0) return;
+  int c = 0;
+  int c1 = nch > 1 ? 1 : 0, row1 = nch > 1 ? row : row_at(1), i1 = nch > 1 ? 0 : 1;
+  Meta m1, m2;
+  float u_cur;
+  uint64_t okm_cur;
+  {
+    request_q(row);
+    Meta m0;
+    load_meta(row, 0, m0);
+    if (row1 >= 0) load_meta(row1, c1, m1);
+    load_v(row, 0, m0);
+    load_k(row, 0, m0);
+    u_cur = m0.u;
+    okm_cur = ok_mask(0, m0);
+  }
+  bf16x8 bqh[8];
+  f32x4 acc[4];  // lane l, channel group cg: O[head 0..3][channel cg * 64 + l] of [v | e-positions]
+  float m_run = -INFINITY, l_run = 0.f;
+  // LDS image: 16-byte piece p of row r is stored at piece p ^ ((r >> 1) & 3) (the low two bits): the 8 rows a ds_write_b128 group
+  // touches at one column land in 8 distinct 4-bank windows (rows alternate between two 64-byte windows at 576-byte rows); a
+  // transposing read's lanes address the same swizzle per row
+  const int sw_w = (m >> 1) & 3;                    // writes: image row m
+  const int grp = kb, li = m;                       // transposing read: 16-lane group, lane in group
+  const int rr = li >> 2;                           // its row within the 4-row block
+  const int hq = (grp * 16 + 4 * (li & 3)) >> 3;    // logical piece within a 64-channel group (0..7), + 8 per channel group
+  const int ho = 4 * (li & 1);                      // halfword offset inside the piece
+
+  while (true) {
+    int c2 = c1 + 1, row2 = row1, i2 = i1;
+    if (row1 >= 0 && c2 >= nch) c2 = 0, i2 = i1 + 1, row2 = row_at(i2);
+    if (c == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const f32x8 z8 = (f32x8){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bqh[ks] = cvt8(m == ks ? qk : z8);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x8 q8 = load8f(qst + (m & (NH - 1)) * DR + e_channel(kb, ks * 8));
+        bqh[4 + ks] = cvt8(m < NH ? q8 : z8);
+      }
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) acc[cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      m_run = -INFINITY, l_run = 0.f;
+    }
+    // ---- this chunk's V rows -> image row m, logical pieces q * 4 + kb
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(bf16x8*)(img + m * YS3 + (q * 4 + (kb ^ sw_w)) * 8) = vvh[q];
+    if (c == 0) {
+      const int rn = row_at(i_row + 1);
+      if (rn >= 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        request_q(rn);
+      }
+    }
+    if (row2 >= 0) load_meta(row2, c2, m2);
+    if (row1 >= 0) load_v(row1, c1, m1);
+    // ---- stage 1: K half, then the embedding (16 sincos per lane) and its half
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s1 = mma(akh[ks], bqh[ks], s1);
+    {
+      // (8 arguments at a time - cos octet, then sin octet - so that only 16 fp32 temporaries are live beside the K / V registers)
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x4 fa = *(const f32x4*)(frt + kb * 16 + h2 * 8), fb = *(const f32x4*)(frt + kb * 16 + h2 * 8 + 4);
+        f32x8 rev, t8;
+#pragma unroll
+        for (int i0 = 0; i0 < 4; ++i0) rev[i0] = u_cur * fa[i0], rev[4 + i0] = u_cur * fb[i0];
+#pragma unroll
+        for (int i0 = 0; i0 < 8; ++i0) t8[i0] = __builtin_amdgcn_cosf(rev[i0]);
+        const bf16x8 ac = cvt8(t8);
+        *(bf16x8*)(img + m * YS3 + (16 + kb * 4 + (h2 ^ sw_w)) * 8) = ac;          // positions i = h2 * 8 .. + 8 (cos)
+        s = mma(ac, bqh[4 + h2], s);
+#pragma unroll
+        for (int i0 = 0; i0 < 8; ++i0) t8[i0] = __builtin_amdgcn_sinf(rev[i0]);
+        const bf16x8 as = cvt8(t8);
+        *(bf16x8*)(img + m * YS3 + (16 + kb * 4 + ((2 + h2) ^ sw_w)) * 8) = as;    // positions i = 16 + h2 * 8 .. + 8 (sin)
+        s = mma(as, bqh[6 + h2], s);
+      }
+      s1 += s;
+    }
+    if (row1 >= 0) load_k(row1, c1, m1);
+    // ---- softmax weights: lane (head l & 15, g = l >> 4) holds targets g * 4 + r
+    float sc[4];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = ((okm_cur >> (kb * 4 + r)) & 1ull) ? s1[r] * a.scale2 : -INFINITY;
+      cmax = fmaxf(cmax, sc[r]);
+    }
+    cmax = quad_max(cmax);
+    const bool first = m_run == -INFINITY;
+    const bool jump = !first && cmax - m_run > 24.f;
+    if (__builtin_expect(__ballot(jump && m < NH) != 0ull, 0)) {
+      // (the accumulators of head i live in register i of EVERY lane here: the rescale factor of each head comes from its lanes)
+      float alpha = jump ? __builtin_amdgcn_exp2f(m_run - cmax) : 1.f;
+      if (jump) l_run *= alpha, m_run = cmax;
+      float al[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) al[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), h));
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[cg][h] *= al[h];
+    }
+    m_run = first ? cmax : m_run;
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = sc[r] > -INFINITY ? __builtin_amdgcn_exp2f(sc[r] - m_run) : 0.f;
+      l_run += p[r];
+    }
+    const bf16x4 pb = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+    const s16x4 pa = __builtin_bit_cast(s16x4, pb);
+    // ---- stage 2: per 4 targets (k-step g: the weights in lanes 16 g .. 16 g + 3 = block 4 g, broadcast) and 64-channel group
+#define TBX_STAGE2(G)                                                                                                              \
+  _Pragma("unroll") for (int cg = 0; cg < 4; ++cg) {                                                                               \
+    const int r_ = 4 * (G) + rr;                                                                                                   \
+    const uint16_t* src_ = img + r_ * YS3 + (((cg * 8 + hq) ^ ((r_ >> 1) & 3)) * 8) + ho;                                          \
+    const s16x4 y_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)src_);                                                  \
+    acc[cg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(pa, y_, acc[cg], 4, 4 * (G), 0);                                              \
+  }
+    TBX_STAGE2(0)
+    TBX_STAGE2(1)
+    TBX_STAGE2(2)
+    TBX_STAGE2(3)
+#undef TBX_STAGE2
+    if (c + 1 == nch) {
+      // ---- the row's last chunk: normalise and store. l_run / m_run of head h live in lanes (l & 15) == h
+      const float l_tot = quad_sum(l_run);
+      const bool any_valid = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run), 0)) > -INFINITY;
+      const float inv_mine = any_valid ? 1.0f / l_tot : 0.f;
+      float inv_l[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) inv_l[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_mine), h));
+      float* orow = a.out + (int64_t)row * a.ldo;
+      // V channels c = cg * 64 + lane (cg = 0, 1) belong to head c >> 5: each lane keeps its head's register
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const int hc = (cg * 64 + lane) >> 5;
+        const float v = hc == 0 ? acc[cg][0] * inv_l[0] : (hc == 1 ? acc[cg][1] * inv_l[1] : (hc == 2 ? acc[cg][2] * inv_l[2] : acc[cg][3] * inv_l[3]));
+        orow[cg * 64 + lane] = v;
+      }
+      // embedding positions p = (cg - 2) * 64 + lane = (octet owner p >> 5, i = p & 31) -> their channels, all 4 heads
+#pragma unroll
+      for (int cg = 2; cg < 4; ++cg) {
+        const int pp = (cg - 2) * 64 + lane;
+        const int ch = e_channel(pp >> 5, pp & 31);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) orow[D + h * DR + ch] = acc[cg][h] * inv_l[h];
+      }
+      if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
+    }
+    if (row1 < 0) break;
+    u_cur = m1.u;
+    okm_cur = ok_mask(c1, m1);
+    m1 = m2;
+    row = row1, c = c1, i_row = i1;
+    row1 = row2, c1 = c2, i1 = i2;
+  }
+}
+
 }  // namespace
 
 extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
@@ -494,6 +751,29 @@ extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, i
       return TBX_ERR_LAUNCH;                                                                                                     \
     hipLaunchKernelGGL((knarpe_attn_mfma_kernel<KV16F>), grid, block, Geom::BYTES, hs, a);                                       \
   } while (0)
+  static const int v3 = [] { const char* e = getenv("TBX_ATTN_MFMA_V3"); return e ? atoi(e) : 0; }();
+  if (v3) {
+    static const int max_wg3 = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return 3 * (cus > 0 ? cus : 256);
+    }();
+    const dim3 grid3((unsigned)(n_quads < max_wg3 ? n_quads : max_wg3));
+#define TBX_MFMA3_LAUNCH(KV16F)                                                                                                  \
+  do {                                                                                                                           \
+    static tbx::PerDeviceOnce lds_attr3;                                                                                         \
+    if (!lds_attr3([&] {                                                                                                         \
+          return hipFuncSetAttribute((const void*)knarpe_attn_mfma3_kernel<KV16F>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                     Geom3::BYTES) == hipSuccess;                                                                \
+        }))                                                                                                                      \
+      return TBX_ERR_LAUNCH;                                                                                                     \
+    hipLaunchKernelGGL((knarpe_attn_mfma3_kernel<KV16F>), grid3, block, Geom3::BYTES, hs, a);                                    \
+  } while (0)
+    if (kv16) TBX_MFMA3_LAUNCH(true);
+    else TBX_MFMA3_LAUNCH(false);
+#undef TBX_MFMA3_LAUNCH
+    return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+  }
   if (kv16) TBX_MFMA_LAUNCH(true);
   else TBX_MFMA_LAUNCH(false);
 #undef TBX_MFMA_LAUNCH

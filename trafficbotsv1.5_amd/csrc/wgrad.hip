@@ -103,103 +103,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a
   }
 }
 
-// The split-bf16 form (TBX_WGRAD_BF16=1; measured against the exact-fp32 kernel above - see DESIGN.md 0): dY = dY_hi + dY_lo, X = X_hi +
-// X_lo in bf16 (round to nearest), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (< 3e-5 of sum_r |dY||X|
-// per entry). The reduction index of the matrix instruction is the ROW: a lane holds 8 consecutive rows (rows 8 (l >> 4) .. + 7 of a
-// 32-row group) of its columns - float4 of dY (4 tile rows t), float2 of X (2 tile columns u): a wavefront owns a 64 x 32 block
-// (half the accumulators of the kernel above: the 8-row operands and their bf16 halves need the registers).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
-  hi = __builtin_convertvector(v, bf16x8);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
-}
-
-__global__ __launch_bounds__(256, 2) void wgrad_partial_bf16_kernel(const WgradArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // groups_k counts 64-wide K groups here: the 4 waves of a workgroup take (n half, k half) of a 128 x 64 block
-  const int gk = blockIdx.x % a.groups_k, gn = blockIdx.x / a.groups_k;
-  const int n0 = (gn * 2 + (wave & 1)) * 64, k0 = gk * 64 + (wave >> 1) * 32;
-  if (n0 >= a.n || k0 >= a.k) return;  // no barriers below: a wave may leave
-  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_split;
-  const int64_t r1 = r0 + a.rows_per_split < a.rows ? r0 + a.rows_per_split : a.rows;
-  const int rg = lane >> 4, c = (lane & 15) * 4, c2 = (lane & 15) * 2;
-  const bool n_ok = n0 + c < a.n, k_ok = k0 + c2 < a.k;  // (n % 4 == 0, k % 4 == 0: whole vectors inside or outside)
-  const float* py = a.dy + n0 + c;
-  const float* px = a.x + k0 + c2;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x2 zero2 = {0.f, 0.f};
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = zero;
-  f32x4 bsum = zero;
-  const bool want_db = a.with_db && k0 == 0;
-  f32x4 yn[8];
-  f32x2 xn[8];
-  auto load = [&](int64_t r) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int64_t row = r + rg * 8 + e;
-      const bool live = row < r1;
-      yn[e] = (live && n_ok) ? ldg4(py + row * a.ld_dy) : zero;
-      xn[e] = (live && k_ok) ? *(const TBX_GLOBAL f32x2*)(px + row * a.ld_x) : zero2;
-    }
-  };
-  load(r0);
-  for (int64_t r = r0; r < r1; r += 32) {
-    bf16x8 yh[4], yl[4], xh[2], xl[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x8 vy = {yn[0][t], yn[1][t], yn[2][t], yn[3][t], yn[4][t], yn[5][t], yn[6][t], yn[7][t]};
-      split8(vy, yh[t], yl[t]);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const f32x8 vx = {xn[0][u], xn[1][u], xn[2][u], xn[3][u], xn[4][u], xn[5][u], xn[6][u], xn[7][u]};
-      split8(vx, xh[u], xl[u]);
-    }
-    if (want_db) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bsum += yn[e];
-    }
-    load(r + 32);  // (rows past r1 read as zeros)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[t], xh[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[t], xl[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[t], xh[u], acc[t][u], 0, 0, 0);
-      }
-  }
-  // acc[t][u][reg] at lane l = dW[n0 + 4 ((l >> 4) * 4 + reg) + t][k0 + 2 (l & 15) + u]
-  float* part = a.part + (int64_t)blockIdx.y * ((int64_t)a.n * a.k + a.n);
-  if (k_ok) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int n = n0 + 4 * (rg * 4 + reg) + t;
-        if (n < a.n) {
-          const f32x2 v = {acc[t][0][reg], acc[t][1][reg]};
-          *(TBX_GLOBAL f32x2*)(part + (int64_t)n * a.k + k0 + c2) = v;
-        }
-      }
-  }
-  if (want_db) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = bsum[e];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      bsum[e] = v;
-    }
-    if (rg == 0 && n_ok) *(TBX_GLOBAL f32x4*)(part + (int64_t)a.n * a.k + n0 + c) = bsum;
-  }
-}
+// (A split-bf16 form - dY and X as bf16 hi + lo, three products on v_mfma_f32_16x16x32_bf16 with the ROW as the reduction index - was
+// built in round 3 and measured slower than the exact-fp32 kernel above: every lane converts 8 rows of its columns per MFMA group and
+// the VALU splits cost what the MFMAs save. git history (wgrad_partial_bf16_kernel), profiles/MEASUREMENT_LOG.md.)
 
 // out[e] = sum_g part[g][e], e < total (dW then db): a workgroup per 64 outputs, its 4 waves take a quarter of the splits each
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t total, int nk,
@@ -255,17 +161,13 @@ extern "C" int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int 
   if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)scratch)) & 15) return TBX_ERR_ALIGN;
   WgradArgs a;
   a.dy = dy, a.x = x, a.part = scratch, a.rows = rows, a.ld_dy = ld_dy, a.ld_x = ld_x, a.n = n, a.k = k;
-  static const bool bf16_path = [] { const char* e = getenv("TBX_WGRAD_BF16"); return e && atoi(e) != 0; }();
-  const int rstep = bf16_path ? 32 : 4 * P;
+  const int rstep = 4 * P;
   a.rows_per_split = (((rows + splits - 1) / splits + rstep - 1) / rstep) * rstep;
-  a.groups_k = bf16_path ? (k + 63) / 64 : (k + 127) / 128;
+  a.groups_k = (k + 127) / 128;
   a.with_db = db != nullptr;
   const int groups = ((n + 127) / 128) * a.groups_k;
   hipStream_t hs = (hipStream_t)stream;
-  if (bf16_path)
-    hipLaunchKernelGGL(wgrad_partial_bf16_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
-  else
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
   if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
   const int64_t total = (int64_t)n * k + n;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, hs, scratch, splits, total, n * k, dw, db);
