@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Microbenchmark + phase clock of tbx_knarpe_attn_fwd_mfma at the WOSAC shape (32 rollouts x 128 agents): the self attention
+"""Microbenchmark of tbx_knarpe_attn_fwd_mfma at the WOSAC shape (32 rollouts x 128 agents): the self attention
 (25 targets out of the step's own 128 token rows) and the cross attention (64 of 1024 map tokens shared by the 32 rollouts + 25 of
 128 lights), K-nearest sets of neighbouring rollouts nearly equal (as in a real scene). Event-timed against tbx_knarpe_attn_fwd
-(VALU) on the same inputs; with TBX_CLK=1 the profiling build's phase sums (make -C trafficbotsv1.5_amd/csrc clk).
-    python tools/attn_mfma_clock.py            TBX_CLK=1 python tools/attn_mfma_clock.py"""
+(VALU) on the same inputs. (The phase clock of the kernel's first form - s_memtime stamps around its four phases - is in
+profiles/r04_attn_mfma_phase_clock.txt; the stamps went with that form.)
+    python tools/attn_mfma_clock.py"""
 import ctypes as C
 import os
 import sys
@@ -12,9 +13,6 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-CLK = os.environ.get("TBX_CLK") == "1"
-if CLK:
-    os.environ["TBX_HIP_LIB"] = str(ROOT / "trafficbotsv1.5_amd" / "csrc" / "libtbx_hip_clk.so")
 import torch  # noqa: E402
 
 from __graft_entry__ import load_package  # noqa: E402
@@ -77,18 +75,3 @@ for dtype in (torch.bfloat16, torch.float32):
         t = timed(lambda: hip.knarpe_attn_mfma(q, 0, 384, n, S, segs, out, flag, fxy, fyw))
         line += f"   mfma {t:6.1f} us"
         print(line, flush=True)
-        if CLK:
-            lib.tbx_debug_attn_mfma_clock.argtypes = [C.c_void_p]
-            buf = (C.c_uint64 * 8)()
-            lib.tbx_debug_attn_mfma_clock(buf)
-            reps = 20
-            for _ in range(reps):
-                hip.knarpe_attn_mfma(q, 0, 384, n, S, segs, out, flag, fxy, fyw)
-            lib.tbx_debug_attn_mfma_clock(buf)
-            ch, rws = max(1, buf[4]), max(1, buf[7])
-            ph = ["wait for the chunk's V rows + LDS write", "embedding (32 sincos) + LDS write + stage 1", "K request + softmax", "stage 2 (32 transposing reads + 16 MFMA)"]
-            print(f"      phase clock of wave 0 of workgroup 0 (s_memtime ticks): {ch / reps:.0f} chunks, {rws / reps:.0f} rows per launch")
-            for nm, v in zip(ph, buf[:4]):
-                print(f"        {nm:52s} {v / ch:8.0f} ticks per chunk")
-            print(f"        {'sum':52s} {sum(buf[:4]) / ch:8.0f} ticks per chunk")
-            print(f"        of the embedding phase: request issue (index level + next V rows [+ next row's q]) {buf[5] / ch:6.0f}, K-half MFMAs + first tile {buf[6] / ch:6.0f}, second tile {(buf[1] - buf[5] - buf[6]) / ch:6.0f}")
