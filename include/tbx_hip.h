@@ -131,7 +131,7 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
                         uint8_t* row_no_valid, const float* freqs_xy /* [32] or NULL */, const float* freqs_yaw /* [64] or NULL */,
                         void* stream);
 
-/* The forward of LARGE launches (a wavefront per source row; >= 1024 rows) on the bf16 matrix cores (csrc/attn_mfma.hip): scores and
+/* The forward of LARGE launches (a wavefront per source row) on the bf16 matrix cores (csrc/attn_mfma.hip): scores and
  * weighted sums as v_mfma_f32_16x16x32_bf16 products per source row (heads padded 4 -> 16), the pair's embedding evaluated in the
  * operand layout, V / embedding rows transposed through LDS (ds_read_b64_tr_b16), online softmax in fp32. Same arguments, `out`
  * layout and row_no_valid as tbx_knarpe_attn_fwd (every segment in the relative-pose form: emb == NULL; the constant q . b_rpe_k

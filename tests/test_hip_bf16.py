@@ -141,7 +141,7 @@ def test_bf16_closed_loop_gathers_the_rows_the_fp32_path_gathers(tb, sizes, knn)
 
 
 def test_reduced_schedule_joint_futures_vs_fp32(tb):
-    """Schedule.reduced() - bf16 tables + the matrix-core attention with bf16 operands (tbx_knarpe_attn_fwd_mfma; active from 1024
+    """Schedule.reduced() - bf16 tables + the matrix-core attention with bf16 operands (tbx_knarpe_attn_fwd_mfma; active from 193
     source rows: here 16 joint futures x 64 agents) - against the fp32 schedule on the same scene, latents and destinations:
     over the 10 teacher-forced warm-start steps the K-nearest sets are bit-identical (the searches are fp32 and read no table) and
     the action means stay within 3e-2 of the fp32 ones (bf16 operands: 2^-9 relative on q, k, v, e and the softmax weights);

@@ -103,10 +103,12 @@ class Schedule:
     # steps the lights once per scene and the agents of the K rollouts attend to that one copy. Bit-identical rollouts.
     share_lights: bool = True
     hoist_constants: bool = True  # False: the heads chain re-embeds the latent / destination feature every step (same values)
-    # large launches (a wavefront per source row, >= 1024 rows, inference): the attention on the bf16 matrix cores
+    # launches a wavefront takes a whole source row of (inference): the attention on the bf16 matrix cores
     # (tbx_knarpe_attn_fwd_mfma, csrc/attn_mfma.hip): bf16 operands with fp32 accumulation - part of the bf16-ARITHMETIC schedule
     # (Schedule.reduced(); tests/test_hip_attn_mfma.py). False: the fp32 VALU kernel
     attn_mfma: bool = False
+    attn_mfma_min_rows: int = 193   # ... from this many source rows (= where the wave-per-row forms start; 4 scenes of 64 agents: 0.318 ->
+    # 0.264 ms per step, 8 scenes: 0.336 -> 0.286 against a 1024-row threshold, gpurun_out/r04_mfma_rows_*.txt)
 
     @classmethod
     def from_env(cls) -> "Schedule":
@@ -151,6 +153,7 @@ class Schedule:
             share_lights=on("TBX_SHARE_LIGHTS"),
             hoist_constants=os.environ.get("TBX_NO_HOIST") is None,
             attn_mfma=off("TBX_ATTN_MFMA"),
+            attn_mfma_min_rows=num("TBX_ATTN_MFMA_MIN_ROWS", 193),
         )
 
     def replace(self, **kw) -> "Schedule":
@@ -158,7 +161,7 @@ class Schedule:
 
     def reduced(self) -> "Schedule":
         """The bf16-ARITHMETIC schedule (BASELINE configs[1] says bf16; the reference runs at precision 16,
-        configs/trainer/default.yaml:16): bfloat16 K/V tables and, on launches of >= 1024 source rows, the attention with bf16
+        configs/trainer/default.yaml:16): bfloat16 K/V tables and, on launches of >= 193 source rows, the attention with bf16
         operands on the matrix cores (fp32 accumulation and softmax). K-nearest searches, dynamics and every LINEAR stage keep
         their fp32-class arithmetic. Tolerances: tests/test_hip_attn_mfma.py (one call), tests/test_hip_bf16.py (closed loop)."""
         return self.replace(kv_bf16=True, attn_mfma=True)
@@ -209,7 +212,7 @@ def drop_call(attn):
 def attention(qbuf, q_off: int, qt_off: int, attn, n: int, S: int, segs, obuf, flag, fxy, fyw, drop=None, fold=None):
     """One KNARPE attention call (attention_rpe.py:137-190): hip.knarpe_attn, or - large inference launches whose segments are all
     given as relative poses, Schedule.attn_mfma - the matrix-core form (same output rows, its own rounding)."""
-    if (current().attn_mfma and drop is None and fold is None and n * S >= 1024 and obuf.shape[1] >= D + NH * D and fxy is not None
+    if (current().attn_mfma and drop is None and fold is None and n * S >= current().attn_mfma_min_rows and obuf.shape[1] >= D + NH * D and fxy is not None
             and all(sg.rel is not None and sg.emb is None for sg in segs)):
         hip.knarpe_attn_mfma(qbuf, q_off, qt_off, n, S, segs, obuf, flag, fxy, fyw)
         return
