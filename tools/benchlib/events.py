@@ -3,6 +3,7 @@ engine launches on torch's current stream) around every launch of this repo's ke
 bytes or flops of each launch beside them, and the HBM traffic of the same kernel from the committed PMC passes."""
 import glob
 import json
+import os
 import time
 from pathlib import Path
 
@@ -189,15 +190,17 @@ def kernel_entry(args, c, products: int = 3):
     e = {"class": cls, "share_of_step_kernel_time": c["share"], "launches_per_step": c["per_step"], "avg_launch_us": avg * 1e6}
     if cls in ("dec_layer", "attn"):
         ach = c["work"] / c["t"] / 1e9
-        mf = cls == "attn" and getattr(args, "attn_mfma", None) and key >= 1024  # (Schedule.attn_mfma: the matrix-core kernel from 1024 rows)
+        wave_rows = int(os.environ.get("TBX_ATTN_BIG_ROWS_INFER", 193))  # (attn.hip attn_big_rows: a wavefront per source row from here)
+        mf_rows = int(os.environ.get("TBX_ATTN_MFMA_MIN_ROWS", 193))  # (Schedule.attn_mfma_min_rows)
+        mf = cls == "attn" and getattr(args, "attn_mfma", None) and key >= mf_rows
         name = "dec_layer_mf_kernel" if cls == "dec_layer" else ("knarpe_attn_mfma_kernel" if mf else "knarpe_attn_kernel")  # (dec_mid_kernel with Schedule.dec_tail_mfma off)
-        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_mfma_kernel<"] if mf else (["knarpe_attn_kernel<1,"] if key >= 1024 else ["knarpe_attn_kernel<4,"]))
+        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_mfma_kernel<"] if mf else (["knarpe_attn_kernel<1,"] if key >= wave_rows else ["knarpe_attn_kernel<4,"]))
         e.update(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                  algorithmic_bytes_per_launch=c["work"] / c["n"], source_rows_per_launch=key,
                  bytes_per_pair=529 if args.kv_bf16 else 1041)
         if cls == "attn":
             e.update(l2_frac=ach / L2_PEAK_GBS, l2_peak=L2_PEAK_GBS)
-        if cls == "dec_layer" or key < 1024:
+        if cls == "dec_layer" or key < 1024:  # (under 4 workgroups per CU)
             e["note"] = ("latency-bound at this size: a launch has one workgroup per source row (64-128 of them on 256 CUs) and the "
                          "step is a chain of dependent launches; frac is bytes over time, not a bandwidth-limited figure")
     elif cls in ("chain", "chain_live", "tile"):
