@@ -107,7 +107,7 @@ def test_bench_train_mode_agrees_with_the_default_lines_training_entry():
     assert a["metric"] == "training scenes/sec" and a["n_gpus"] == 1 and a["finite"] and a["steps"] == 2
     assert a["config"]["parallelism"] == "dp1" and a["config"]["global_batch"] == 2
     assert a["config"]["allreduce_bytes"] > 30e6
-    assert abs(a["value"] - 2 * 2 / (a["ms_per_step"] * 2e-3)) < 1e-6 * a["value"]
+    assert abs(a["value"] - 2 * 2 / (a["ms_per_step"] * 2e-3)) < 2e-5 * a["value"]  # (the line rounds to 6 significant digits)
 
 
 def test_loss_terms_with_empty_counters_are_left_out(tb):
