@@ -89,13 +89,21 @@ def main(argv=None):
         sys.exit(2)
     if args.dry_run:
         return dry_run(args, rank, world, report)
+    # (TBX_BENCH_SHARE_GPU=1 TBX_BENCH_BACKEND=gloo: the N-rank flow on a box with fewer GPUs than ranks - a functional check of the
+    # multi-rank path, tests/test_hip_data_parallel.py; its numbers mean nothing. RCCL refuses two ranks on one device.)
+    if os.environ.get("TBX_BENCH_SHARE_GPU"):
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TBX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     tb = load_package()
     hip = import_module("trafficbots_amd.hip")
     hip.load()  # raises if libtbx_hip.so is missing: there is no fallback path

@@ -110,6 +110,23 @@ def test_bench_train_mode_agrees_with_the_default_lines_training_entry():
     assert abs(a["value"] - 2 * 2 / (a["ms_per_step"] * 2e-3)) < 2e-5 * a["value"]  # (the line rounds to 6 significant digits)
 
 
+def test_two_ranks_through_bench_on_one_gpu():
+    """The N > 1 flow of bench.py end to end on a one-GPU box: `--gpus 2` starts its own two ranks (tools/benchlib/launch.py), both on
+    cuda:0 over gloo (TBX_BENCH_SHARE_GPU / TBX_BENCH_BACKEND: RCCL refuses two ranks on one device) - rendezvous, scene sharding,
+    barriers, the MAX-over-ranks clock, rank 0's line, the flat gradient all-reduce of the training step. A functional check of the
+    multi-rank path (run.py:50-52, strategy="ddp"); the numbers of two processes sharing a GPU mean nothing."""
+    env = {"TBX_BENCH_SHARE_GPU": "1", "TBX_BENCH_BACKEND": "gloo"}
+    small = ["--agents", "32", "--polylines", "128", "--lights", "32"]
+    a = json.loads(_run([sys.executable, "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--no-wosac-shape", "--no-bf16-shape",
+                         "--no-train-shape", "--profile-steps", "0", "--new-scenes", "0", *small], env).strip().splitlines()[-1])
+    assert a["n_gpus"] == 2 and a["finite"] and a["steps"] == 8 and a["scaling"] == "weak" and "cpu_baseline" not in a
+    assert abs(a["value"] - 2 * 32 * 8 / (a["ms_per_step"] * 8e-3)) < 2e-5 * a["value"]  # both ranks' agent-steps over the slower rank's time
+    b = json.loads(_run([sys.executable, "bench.py", "--mode", "train", "--gpus", "2", "--scenes", "2", "--steps", "2", "--warmup", "1",
+                         *small], env).strip().splitlines()[-1])
+    assert b["metric"] == "training scenes/sec" and b["n_gpus"] == 2 and b["finite"]
+    assert b["config"]["parallelism"] == "dp2" and b["config"]["global_batch"] == 4 and b["config"]["allreduce_bytes"] > 30e6
+
+
 def test_loss_terms_with_empty_counters_are_left_out(tb):
     """A per-GPU batch without a single valid traffic light (plausible on WOMD at batch 3): the reference leaves a term whose
     counter is zero out of the loss (metrics/training.py:166-186); the step must not turn NaN."""
