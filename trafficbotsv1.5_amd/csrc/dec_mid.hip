@@ -630,7 +630,10 @@ __device__ __forceinline__ void pre_index(const Sweep& a, int row, int wir, int 
   j = S.idx[pi];
   ok = (S.invalid[pi] == 0) & active;
 }
-template <bool KV16>
+// REL: every segment of the launch gives its pairs as relative poses (seg.emb == NULL: the default schedule) - known at compile time,
+// because a run-time branch between "load the embedding" and "load the pose" makes the wait-count pass merge the two paths' pending
+// loads: the pose path then waited for EVERYTHING in flight (a register of the other path's loads was re-used for its address).
+template <bool KV16, bool REL>
 __device__ __forceinline__ void pre_rows(const Sweep& a, int row, int b, int wir, int s8, int tg, int j, const EFreq& fq, Pre& p) {
   const tbx_attn_seg_t& S = a.seg[0];
   constexpr int ES = KV16 ? 2 : 1;
@@ -638,17 +641,21 @@ __device__ __forceinline__ void pre_rows(const Sweep& a, int row, int b, int wir
   const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
   const int t = wir * 8 + tg;
   const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
+  if constexpr (REL) {
+    p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
+  } else {
+    if (S.emb != nullptr)
+      p.e.load(S.emb + pi * DR, s8);
+    else
+      p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
+  }
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     p.kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
     p.v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
   }
-  if (S.emb != nullptr)
-    p.e.load(S.emb + pi * DR, s8);
-  else
-    p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
 }
-template <bool KV16>
+template <bool KV16, bool REL>
 __device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir, int s8, int tg, const float4 (&qv)[NH], const ESlice (&qt)[NH],
                                          const float (&qb)[NH], const EFreq& fq, Pre& pre, bool pre_ok, RowAcc& st) {
   float(&m_run)[NH] = st.m_run;
@@ -685,7 +692,7 @@ __device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir
     }
   };
   if (wir * 8 < a.seg[0].k) {
-    if (a.seg[0].emb == nullptr) {
+    if (REL || a.seg[0].emb == nullptr) {
       const float rel[3] = {pre.e.wc.x, pre.e.wc.y, pre.e.wc.z};
       fq.embed(rel, pre.e);
     }
@@ -710,7 +717,8 @@ __device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir
         v[q] = kv_load4<KV16>(trow, S.v_off + q * 32 + s8 * 4);
       }
       ESlice e;
-      load_e(S, pi, s8, fq, e);
+      if constexpr (REL) fq.embed(S.rel_pose + pi * 3, e);
+      else load_e(S, pi, s8, fq, e);
       pass(ok, kq, v, e);
     }
   }
@@ -768,7 +776,7 @@ __device__ __forceinline__ void combine(RowAcc& st, const float (&M)[NH], const 
 }
 }  // namespace mf
 
-template <bool KV16>
+template <bool KV16, bool REL>
 __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   using namespace mf;
   __shared__ __attribute__((aligned(16))) float red_s[NSW][RED];
@@ -785,15 +793,22 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   MID_CLK(0);
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
+  // the target index / mask of BOTH sweeps' first pass (the K-nearest sets are inputs of the launch): the kernel's first requests, so
+  // that the self sweep's row gathers leave before anything waits for the query side (they sat behind two dependent round trips)
+  int j1, j2;
+  bool ok1, ok2;
+  pre_index(a.self, row, wir, tg, j1, ok1);
+  pre_index(a.cross, row, wir, tg, j2, ok2);
   const int g4 = lane >> 4;
   const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row: channels c_out .. c_out + 3 of a 128-wide stage
   const int c_out = 16 * wave + 4 * g4;
   const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
-  // (the step counter of the fused tail: read here, a round trip to memory before that tail needs it)
-  const int t_step = a.fused_tail ? __builtin_amdgcn_readfirstlane(*a.sim.step) : 0;
+  // (the step counter of the fused tail: requested here, a round trip to memory before that tail needs it)
+  const int t_step_v = a.fused_tail ? *a.sim.step : 0;
   W wb[3];
-  if (threadIdx.x < D) xs[threadIdx.x] = a.x[(int64_t)row * D + threadIdx.x];
-  if (threadIdx.x < D) bk2_s[threadIdx.x] = a.bias_k2[threadIdx.x];
+  // (the row and the cross bias go to LDS behind the query-side requests: a load straight into an LDS write is waited for on the spot)
+  float x_r = 0.f, bk2_r = 0.f;
+  if (threadIdx.x < D) x_r = a.x[(int64_t)row * D + threadIdx.x], bk2_r = a.bias_k2[threadIdx.x];
   float lg1[2] = {0.f, 0.f}, lb1[2] = {0.f, 0.f}, lg2[2] = {0.f, 0.f}, lb2[2] = {0.f, 0.f}, lg3[2] = {0.f, 0.f}, lb3[2] = {0.f, 0.f};
   // (LayerNorm parameters: requested with the weight units behind each sweep - nothing is kept in registers across one)
   EFreq fq;
@@ -801,21 +816,21 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   float4 qv[NH];
   ESlice qt[NH];
   float qb[NH];
-  // the target index / mask of the cross sweep's first pass (the K-nearest sets are inputs of the launch)
-  int j2;
-  bool ok2;
-  pre_index(a.cross, row, wir, tg, j2, ok2);
   Pre pre;
   // ---------------------------------------------------------------- self attention
   {
     const float* qrow = a.qkv + (int64_t)row * a.ld_qkv;
+    float4 bk[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
-      const float4 bk = *(const float4*)(a.bias_k1 + h * DH + s8 * 4);
-      qb[h] = tbx::group8_sum(dot4(qv[h], bk));
+      bk[h] = *(const float4*)(a.bias_k1 + h * DH + s8 * 4);
       qt[h].load(qrow + a.qt_off + h * DR, s8);
     }
+    pre_rows<KV16, REL>(a.self, row, b, wir, s8, tg, j1, fq, pre);  // (behind the query-side requests: waiting for those does not wait for these)
+    if (threadIdx.x < D) xs[threadIdx.x] = x_r, bk2_s[threadIdx.x] = bk2_r;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) qb[h] = tbx::group8_sum(dot4(qv[h], bk[h]));
   }
   bool valid1, valid2;
   MID_CLK(1);
@@ -823,14 +838,14 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     RowAcc st;
     st.zero();
     float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
-    sweep<NSW, false, KV16>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, st);
+    sweep_pf<KV16, REL>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok1, st);
     merge_slots(st, M, L);
     MID_CLK(2);
     combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid1, [&]() {
       issue<0>(wb[0], a, heads, wave, lane);
       issue<1>(wb[1], a, heads, wave, lane);
       if (wave == 0) lg1[0] = a.ln_w[lane], lg1[1] = a.ln_w[64 + lane], lb1[0] = a.ln_b[lane], lb1[1] = a.ln_b[64 + lane];
-      pre_rows<KV16>(a.cross, row, b, wir, s8, tg, j2, fq, pre);  // the cross sweep's first pass: in flight under the layer's middle
+      pre_rows<KV16, REL>(a.cross, row, b, wir, s8, tg, j2, fq, pre);  // the cross sweep's first pass: in flight under the layer's middle
     });
   }
   // ---- 0: y = sum a v + W_rpe_v (sum a e) + b (wave w: head w / 2, 16 of its 32 channels)
@@ -889,7 +904,7 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
     RowAcc st;
     st.zero();
     float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
-    sweep_pf<KV16>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok2, st);
+    sweep_pf<KV16, REL>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok2, st);
     merge_slots(st, M, L);
     MID_CLK(9);
     combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid2, [&]() {
@@ -1163,6 +1178,7 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   }
   MID_CLK(14);
   if (a.fused_tail) {
+    const int t_step = __builtin_amdgcn_readfirstlane(t_step_v);
     // ============================================================== the step's tail for this row's agent (csrc/step_core.h): its
     // tbx_sim_step (dynamics, rule checks, overrides, log, window append: 32 lanes) on the action just written, then the NEXT
     // step's tbx_agent_prep of its new window (4 waves) - neither reads anything of another agent's
@@ -1288,10 +1304,15 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
   } while (0)
   a.tail_mfma = t ? t->tail_mfma32 : 0;
-  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0)
-    hipLaunchKernelGGL((dec_layer_mf_kernel<true>), dim3(a.n_rows), dim3(512), 0, hs, a);
-  else if (t && a.tail_mfma)
-    hipLaunchKernelGGL((dec_layer_mf_kernel<false>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  bool rel = p->self_seg.emb == nullptr;
+  for (int i = 0; i < p->n_cross; ++i) rel = rel && p->cross_seg[i].emb == nullptr;
+  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0) {
+    if (rel) hipLaunchKernelGGL((dec_layer_mf_kernel<true, true>), dim3(a.n_rows), dim3(512), 0, hs, a);
+    else hipLaunchKernelGGL((dec_layer_mf_kernel<true, false>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  } else if (t && a.tail_mfma) {
+    if (rel) hipLaunchKernelGGL((dec_layer_mf_kernel<false, true>), dim3(a.n_rows), dim3(512), 0, hs, a);
+    else hipLaunchKernelGGL((dec_layer_mf_kernel<false, false>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  }
   else if (t && p->self_seg.kv_bf16 != 0)
     TBX_MID_LAUNCH(true, 8);
   else if (t)
