@@ -134,27 +134,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 
   RowAcc st;
   st.zero();
   sweep<WPR, DROP, KV16>(a, row, b, wir, s8, tg, qv, qt, qb, fq, st);
-  float M[NH], L[NH];
-  merge_slots(st, M, L);
-  float4(&oacc)[NH] = st.oacc;
-  ESlice(&eacc)[NH] = st.eacc;
+  // (merge_slots_by_head: lane l holds head l >> 4's sums of channel slice s8; lanes l and l ^ 8 the same numbers)
+  float M[NH], Mh, Lh;
+  float4 om;
+  ESlice em;
+  merge_slots_by_head(st, M, Mh, Lh, om, em);
+  const int hq = lane >> 4;
   float* orow = a.out + (int64_t)row * a.ldo;
   if constexpr (WPR == 1 && FOLD) {
     // a wave per row, 4 rows per workgroup: the normalised row goes to LDS, then thread (c = tid & 127, r0 = tid >> 7) runs the
     // value fold of output column c for rows r0 and r0 + 2 (one read of the weight image for both) - the same k-ordered v_fma
     // chain as the 4-waves-per-row form below and as the LINEAR stage it replaces: 128 floats per row leave the kernel
     const bool any_valid = M[0] > -INFINITY;
-    if (tg == 0) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
-        float4 o = oacc[h];
-        scale4(o, inv_l);
-        *(float4*)(&comb_s[rib * OUTW + h * DH + s8 * 4]) = o;
-        ESlice ev = eacc[h];
-        ev.scale(inv_l);
-        ev.store(&comb_s[rib * OUTW + D + h * DR], s8);
-      }
+    if ((lane & 8) == 0) {
+      const float inv_l = any_valid ? 1.0f / Lh : 0.f;
+      scale4(om, inv_l);
+      *(float4*)(&comb_s[rib * OUTW + hq * DH + s8 * 4]) = om;
+      em.scale(inv_l);
+      em.store(&comb_s[rib * OUTW + D + hq * DR], s8);
     }
     if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the fold image have landed
@@ -193,31 +190,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 
     __syncthreads();  // comb_s is rewritten by the next quad
   } else if constexpr (WPR == 1) {
     const bool any_valid = M[0] > -INFINITY;  // masks are per target, so every head sees the same validity
-    if (tg == 0) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
-        float4 o = oacc[h];
-        scale4(o, inv_l);
-        *(float4*)(orow + h * DH + s8 * 4) = o;
-        ESlice ev = eacc[h];
-        ev.scale(inv_l);
-        ev.store(orow + D + h * DR, s8);
-      }
+    if ((lane & 8) == 0) {
+      const float inv_l = any_valid ? 1.0f / Lh : 0.f;
+      scale4(om, inv_l);
+      *(float4*)(orow + hq * DH + s8 * 4) = om;
+      em.scale(inv_l);
+      em.store(orow + D + hq * DR, s8);
     }
     if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
   } else {
     // per-wave (M, L, un-normalised sums) -> LDS, then all threads combine the WPR waves
-    if (tg == 0) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        *(float4*)(&red_s[wir][h * DH + s8 * 4]) = oacc[h];
-        eacc[h].store(&red_s[wir][D + h * DR], s8);
-      }
+    if ((lane & 8) == 0) {
+      *(float4*)(&red_s[wir][hq * DH + s8 * 4]) = om;
+      em.store(&red_s[wir][D + hq * DR], s8);
     }
-    if (lane < NH) {
-      red_s[wir][OUTW + lane] = M[lane];
-      red_s[wir][OUTW + NH + lane] = L[lane];
+    if ((lane & 15) == 0) {
+      red_s[wir][OUTW + hq] = Mh;
+      red_s[wir][OUTW + NH + hq] = Lh;
     }
     if constexpr (FOLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the fold image have landed
     __syncthreads();
@@ -485,21 +474,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     }
   }
 
-  float M[NH], L[NH];
-  merge_slots(st, M, L);
+  float M[NH], Mh, Lh;
+  float4 om;
+  ESlice em;
+  merge_slots_by_head(st, M, Mh, Lh, om, em);  // (lane l: head l >> 4's sums of channel slice s8; lanes l and l ^ 8 the same numbers)
+  const int hq = lane >> 4;
   float* orow = a.out + (int64_t)row * a.ldo;
   const bool any_valid = M[0] > -INFINITY;
-  if (tg == 0) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float inv_l = any_valid ? 1.0f / L[h] : 0.f;
-      float4 o = oacc[h];
-      scale4(o, inv_l);
-      *(float4*)(orow + h * DH + s8 * 4) = o;
-      ESlice ev = eacc[h];
-      ev.scale(inv_l);
-      ev.store(orow + D + h * DR, s8);
-    }
+  if ((lane & 8) == 0) {
+    const float inv_l = any_valid ? 1.0f / Lh : 0.f;
+    scale4(om, inv_l);
+    *(float4*)(orow + hq * DH + s8 * 4) = om;
+    em.scale(inv_l);
+    em.store(orow + D + hq * DR, s8);
   }
   if (lane == 0) a.row_no_valid[row] = any_valid ? 0 : 1;
 }

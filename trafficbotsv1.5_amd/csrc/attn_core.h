@@ -322,6 +322,38 @@ __device__ __forceinline__ void merge_slots(RowAcc& st, float (&M)[NH], float (&
   }
 }
 
+// merge_slots with the result BY HEAD: on return lane l holds, for head l >> 4 and its channel slice s8 = l & 7, the wave's
+// un-normalised sums `o` (4 value channels) / `e` (16 embedding channels) relative to the wave's maximum, that head's maximum `Mh` and
+// normaliser `Lh` (lanes l and l ^ 8 hold the same numbers); M[h] = every head's maximum, wave-uniform. Bit-identical to merge_slots
+// (tbx::slot_sum4 is the same butterfly) at a quarter of its instructions: the merge was ~1,300 of the ~2,700 vector instructions a
+// wave spends on a row at the WOSAC shape, and 2 x ~2 us of the one-launch decoder layer's 27.
+__device__ __forceinline__ void merge_slots_by_head(RowAcc& st, float (&M)[NH], float& Mh, float& Lh, float4& o, ESlice& e) {
+  static_assert(NH == 4, "four heads: one per quarter of the wavefront");
+  float(&m)[NH] = st.m_run;
+  Mh = tbx::slot_max4(m[0], m[1], m[2], m[3]);
+  float f[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    M[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mh), 16 * h));
+    f[h] = (m[h] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m[h] - M[h]);
+    st.l_run[h] *= f[h];
+    scale4(st.oacc[h], f[h]);
+    st.eacc[h].scale(f[h]);
+  }
+  const float4(&a)[NH] = st.oacc;
+  const ESlice(&b)[NH] = st.eacc;
+  Lh = tbx::slot_sum4(st.l_run[0], st.l_run[1], st.l_run[2], st.l_run[3]);
+#define TBX_S4(F) tbx::slot_sum4(a[0].F, a[1].F, a[2].F, a[3].F)
+  o.x = TBX_S4(x), o.y = TBX_S4(y), o.z = TBX_S4(z), o.w = TBX_S4(w);
+#undef TBX_S4
+#define TBX_S4(F) tbx::slot_sum4(b[0].F, b[1].F, b[2].F, b[3].F)
+  e.xc.x = TBX_S4(xc.x), e.xc.y = TBX_S4(xc.y), e.xs.x = TBX_S4(xs.x), e.xs.y = TBX_S4(xs.y);
+  e.yc.x = TBX_S4(yc.x), e.yc.y = TBX_S4(yc.y), e.ys.x = TBX_S4(ys.x), e.ys.y = TBX_S4(ys.y);
+  e.wc.x = TBX_S4(wc.x), e.wc.y = TBX_S4(wc.y), e.wc.z = TBX_S4(wc.z), e.wc.w = TBX_S4(wc.w);
+  e.ws.x = TBX_S4(ws.x), e.ws.y = TBX_S4(ws.y), e.ws.z = TBX_S4(ws.z), e.ws.w = TBX_S4(ws.w);
+#undef TBX_S4
+}
+
 // 1 KiB per wave instruction from global memory straight into LDS (global_load_lds_dwordx4), as inline asm: hipcc orders every
 // later ds_read behind a DMA it knows about; this form is invisible to its counters (which can then only over-wait: VMEM returns
 // in order) and the LDS hazard is the caller's: every consumer sits behind "s_waitcnt vmcnt(0)" + a workgroup barrier

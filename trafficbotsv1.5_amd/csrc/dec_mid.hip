@@ -726,18 +726,17 @@ __device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir
 
 // combine_fold's first half for 8 sweeping waves: their partials -> the row's normalised sums comb_s [640] (fp32) and their planes Pc
 template <class F>
-__device__ __forceinline__ void combine(RowAcc& st, const float (&M)[NH], const float (&L)[NH], float (*red_s)[RED], float* comb_s, char* Pc,
-                                        int wir, int lane, int s8, int tg, bool& any_valid, F&& request) {
-  if (tg == 0) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      *(float4*)(&red_s[wir][h * DH + s8 * 4]) = st.oacc[h];
-      st.eacc[h].store(&red_s[wir][D + h * DR], s8);
-    }
+__device__ __forceinline__ void combine(float Mh, float Lh, const float4& o, const ESlice& e, float (*red_s)[RED], float* comb_s, char* Pc,
+                                        int wir, int lane, int s8, bool& any_valid, F&& request) {
+  // (merge_slots_by_head: lane l holds head l >> 4's sums of channel slice s8; lanes l and l ^ 8 the same)
+  const int hq = lane >> 4;
+  if ((lane & 8) == 0) {
+    *(float4*)(&red_s[wir][hq * DH + s8 * 4]) = o;
+    e.store(&red_s[wir][D + hq * DR], s8);
   }
-  if (lane < NH) {
-    red_s[wir][OUTW + lane] = M[lane];
-    red_s[wir][OUTW + NH + lane] = L[lane];
+  if ((lane & 15) == 0) {
+    red_s[wir][OUTW + hq] = Mh;
+    red_s[wir][OUTW + NH + hq] = Lh;
   }
   request();  // (the sweep's sums have left the registers: the next two weight units fly under the combination)
   __syncthreads();
@@ -837,11 +836,14 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   {
     RowAcc st;
     st.zero();
-    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    float M[NH] = {0.f, 0.f, 0.f, 0.f};
     sweep_pf<KV16, REL>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok1, st);
-    merge_slots(st, M, L);
+    float Mh, Lh;
+    float4 om;
+    ESlice em;
+    merge_slots_by_head(st, M, Mh, Lh, om, em);
     MID_CLK(2);
-    combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid1, [&]() {
+    combine(Mh, Lh, om, em, red_s, comb_s, Pc, wir, lane, s8, valid1, [&]() {
       issue<0>(wb[0], a, heads, wave, lane);
       issue<1>(wb[1], a, heads, wave, lane);
       if (wave == 0) lg1[0] = a.ln_w[lane], lg1[1] = a.ln_w[64 + lane], lb1[0] = a.ln_b[lane], lb1[1] = a.ln_b[64 + lane];
@@ -903,11 +905,14 @@ __global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
   {
     RowAcc st;
     st.zero();
-    float M[NH] = {0.f, 0.f, 0.f, 0.f}, L[NH] = {0.f, 0.f, 0.f, 0.f};
+    float M[NH] = {0.f, 0.f, 0.f, 0.f};
     sweep_pf<KV16, REL>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok2, st);
-    merge_slots(st, M, L);
+    float Mh, Lh;
+    float4 om;
+    ESlice em;
+    merge_slots_by_head(st, M, Mh, Lh, om, em);
     MID_CLK(9);
-    combine(st, M, L, red_s, comb_s, Pc, wir, lane, s8, tg, valid2, [&]() {
+    combine(Mh, Lh, om, em, red_s, comb_s, Pc, wir, lane, s8, valid2, [&]() {
       issue<4>(wb[1], a, heads, wave, lane);
       issue<5>(wb[2], a, heads, wave, lane);
       if (wave == 0) {

@@ -56,6 +56,44 @@ __device__ __forceinline__ void swap32(float v, float* a, float* b) {
   *b = y;
 }
 
+// the same two instructions on two DIFFERENT registers: afterwards x = (x rows 0, y rows 0, x rows 2, y rows 2), y = (x rows 1, y rows 1,
+// x rows 3, y rows 3) / x = (x lower half | y lower half), y = (x upper half | y upper half)
+__device__ __forceinline__ void pswap16(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ void pswap32(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+
+// slot_sum / slot_max of FOUR values at once: the result of value q lands in the lanes of quarter q (lanes 16 q .. 16 q + 15; lanes l
+// and l ^ 8 hold the same number). Same butterfly as four slot_sum calls - (l + l^8), then + (^16), then + (^32), the same operands
+// per add - so the sums are bit-identical; 10 instructions instead of ~50: the two cross-row steps exchange rows of two DIFFERENT
+// values (both halves of a swap are useful) instead of a value with a copy of itself.
+__device__ __forceinline__ float slot_sum4(float a0, float a1, float a2, float a3) {
+  a0 += dpp<DPP_XOR8>(a0);
+  a1 += dpp<DPP_XOR8>(a1);
+  a2 += dpp<DPP_XOR8>(a2);
+  a3 += dpp<DPP_XOR8>(a3);
+  pswap16(a0, a1);
+  float u01 = a0 + a1;  // rows: a0 (r0 + r1) | a1 (r0 + r1) | a0 (r2 + r3) | a1 (r2 + r3)
+  pswap16(a2, a3);
+  float u23 = a2 + a3;
+  pswap32(u01, u23);    // (a0', a1' | a2', a3') and (a0'', a1'' | a2'', a3'')
+  return u01 + u23;
+}
+__device__ __forceinline__ float slot_max4(float a0, float a1, float a2, float a3) {
+  a0 = fmaxf(a0, dpp<DPP_XOR8>(a0));
+  a1 = fmaxf(a1, dpp<DPP_XOR8>(a1));
+  a2 = fmaxf(a2, dpp<DPP_XOR8>(a2));
+  a3 = fmaxf(a3, dpp<DPP_XOR8>(a3));
+  pswap16(a0, a1);
+  float u01 = fmaxf(a0, a1);
+  pswap16(a2, a3);
+  float u23 = fmaxf(a2, a3);
+  pswap32(u01, u23);
+  return fmaxf(u01, u23);
+}
+
 // sum / max over lanes l ^ {8, 16, 32} (the 8 lanes that share l & 7)
 __device__ __forceinline__ float slot_sum(float v) {
   float a, b;
