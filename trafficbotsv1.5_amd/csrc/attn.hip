@@ -699,23 +699,26 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
       }
     }
   }
-  auto red4 = [](float4 v) {
-    v.x = tbx::slot_sum(v.x); v.y = tbx::slot_sum(v.y); v.z = tbx::slot_sum(v.z); v.w = tbx::slot_sum(v.w);
-    return v;
-  };
+  // the 8 target slots' sums by head (tbx::slot_sum4: four values per cross-row exchange, the same butterfly as slot_sum - see
+  // merge_slots_by_head): lane l ends with head l >> 4's dq / d bias_k / dqt of channel slice s8, lanes l and l ^ 8 the same numbers
+  float4 r, rb;
+  ESlice rt;
+#define TBX_S4(A, F) tbx::slot_sum4(A[0].F, A[1].F, A[2].F, A[3].F)
+  r.x = TBX_S4(dq, x), r.y = TBX_S4(dq, y), r.z = TBX_S4(dq, z), r.w = TBX_S4(dq, w);
+  rb.x = TBX_S4(dbk, x), rb.y = TBX_S4(dbk, y), rb.z = TBX_S4(dbk, z), rb.w = TBX_S4(dbk, w);
+  rt.xc.x = TBX_S4(dqt, xc.x), rt.xc.y = TBX_S4(dqt, xc.y), rt.xs.x = TBX_S4(dqt, xs.x), rt.xs.y = TBX_S4(dqt, xs.y);
+  rt.yc.x = TBX_S4(dqt, yc.x), rt.yc.y = TBX_S4(dqt, yc.y), rt.ys.x = TBX_S4(dqt, ys.x), rt.ys.y = TBX_S4(dqt, ys.y);
+  rt.wc.x = TBX_S4(dqt, wc.x), rt.wc.y = TBX_S4(dqt, wc.y), rt.wc.z = TBX_S4(dqt, wc.z), rt.wc.w = TBX_S4(dqt, wc.w);
+  rt.ws.x = TBX_S4(dqt, ws.x), rt.ws.y = TBX_S4(dqt, ws.y), rt.ws.z = TBX_S4(dqt, ws.z), rt.ws.w = TBX_S4(dqt, ws.w);
+#undef TBX_S4
   float* dqrow = b.dqbuf + (int64_t)row * a.ldq;
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const float4 r = red4(dq[h]);
-    const float4 rb = red4(dbk[h]);
-    dqt[h].reduce_slots();
-    if (tg == 0) {
-      *(float4*)(dqrow + a.q_off + h * DH + s8 * 4) = r;
-      // per-row part of d(rpe_k_bias): every row adding into the same 128 floats serialises ~10^3-deep at the L2 atomic
-      // units (measured: ~200 us of a 335 us launch at 1024 rows); the caller sums the rows
-      *(float4*)(b.dbias_k + (int64_t)row * D + h * DH + s8 * 4) = rb;
-      dqt[h].store(dqrow + a.qt_off + h * DR, s8);
-    }
+  if ((lane & 8) == 0) {
+    const int hq = lane >> 4;
+    *(float4*)(dqrow + a.q_off + hq * DH + s8 * 4) = r;
+    // per-row part of d(rpe_k_bias): every row adding into the same 128 floats serialises ~10^3-deep at the L2 atomic
+    // units (measured: ~200 us of a 335 us launch at 1024 rows); the caller sums the rows
+    *(float4*)(b.dbias_k + (int64_t)row * D + hq * DH + s8 * 4) = rb;
+    rt.store(dqrow + a.qt_off + hq * DR, s8);
   }
 }
 
