@@ -14,7 +14,7 @@ reference's >= 19 host synchronisations per step (SURVEY.md Appx D.1) are gone: 
 import ctypes as C
 import math
 import os
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -259,41 +259,66 @@ class RolloutEngine:
         first step. Must follow this engine's previous rollout in stream order."""
         self.tl_share_ok = fresh.tl_share_ok  # (device flag: checked in buffer(), not here - no host round trip between scenes)
         assert fresh.S.keys() == self.S.keys()
+        # every copy of the commit as a few multi-tensor launches (_copy_all) instead of ~80 single ones: 4-8 us each on the stream
+        # the next rollout waits on
+        pairs: List[Tuple[Tensor, Tensor]] = []
         for k, v in fresh.S.items():
-            self.S[k].copy_(v)
+            pairs.append((self.S[k], v))
         for k, v in fresh.init_state.items():
-            self.init_state[k].copy_(v)
+            pairs.append((self.init_state[k], v))
         for name in ("ag_attr6", "ag_latent", "latent_invalid", "dest"):
-            getattr(self, name).copy_(getattr(fresh, name))
+            pairs.append((getattr(self, name), getattr(fresh, name)))
         # (what buffer() reads on the host side: engine-owned copies - `fresh` may be overwritten by the NEXT scene's prepare while
         # this scene's log is still to be handed out)
         if torch.is_tensor(self.tl_invalid_full):
-            self.tl_invalid_full = self._own("tl_invalid_full", fresh.tl_invalid_full)
-        self.ag_type = self._own("ag_type", fresh.ag_type)
-        self.navi_valid0 = self._own("navi_valid0", fresh.navi_valid0)
-        self.navi_log_prob0 = None if fresh.navi_log_prob0 is None else self._own("navi_log_prob0", fresh.navi_log_prob0)
-        self._copy_tokens(self.mp_tokens, fresh.mp_tokens)
-        self._copy_tokens(self.tl_tokens, fresh.tl_tokens)
-        # per-scene K/V tables of the map tokens (cached in the token dicts): recomputed into the tables the graphs read
-        self.model.ag_encoder.kv_mp(self.mp_tokens, refresh=True)
-        self.model.tl_encoder._kv_mp(self.tl_tokens, refresh=True)
+            self.tl_invalid_full = self._own("tl_invalid_full", fresh.tl_invalid_full, pairs)
+        self.ag_type = self._own("ag_type", fresh.ag_type, pairs)
+        self.navi_valid0 = self._own("navi_valid0", fresh.navi_valid0, pairs)
+        self.navi_log_prob0 = None if fresh.navi_log_prob0 is None else self._own("navi_log_prob0", fresh.navi_log_prob0, pairs)
+        late = self._copy_tokens(self.mp_tokens, fresh.mp_tokens, pairs) + self._copy_tokens(self.tl_tokens, fresh.tl_tokens, pairs)
         if self.consts is not None:
             for k, v in fresh.consts.items():
                 if torch.is_tensor(v):
-                    self.consts[k].copy_(v)
+                    pairs.append((self.consts[k], v))
                 else:
                     assert self.consts[k] == v
+        self._copy_all(pairs)
+        for dst, src in late:  # (u8 views of masks refreshed above)
+            dst.copy_(src.to(torch.uint8))
+        # per-scene K/V tables of the map tokens (cached in the token dicts): recomputed into the tables the graphs read
+        self.model.ag_encoder.kv_mp(self.mp_tokens, refresh=True)
+        self.model.tl_encoder._kv_mp(self.tl_tokens, refresh=True)
         self.parity = 0
         self._n_forward = 0
         self._prime()
 
-    def _own(self, name: str, src: Tensor) -> Tensor:
-        """An engine-owned tensor `name` holding a copy of src (allocated once, refilled in place)."""
+    def _own(self, name: str, src: Tensor, pairs: Optional[list] = None) -> Tensor:
+        """An engine-owned tensor `name` holding a copy of src (allocated once, refilled in place; pairs: the copy is queued there)."""
         own = self.__dict__.setdefault("_owned", {})
         if name not in own or own[name].shape != src.shape or own[name].dtype != src.dtype:
             own[name] = torch.empty_like(src)
-        own[name].copy_(src)
+        if pairs is None:
+            own[name].copy_(src)
+        else:
+            pairs.append((own[name], src))
         return own[name]
+
+    @staticmethod
+    def _copy_all(pairs) -> None:
+        """dst.copy_(src) for every pair; same-dtype contiguous pairs of equal shape go through torch._foreach_copy_ (one launch per
+        few dozen tensors), the rest one by one."""
+        groups: Dict[torch.dtype, Tuple[list, list]] = {}
+        for dst, src in pairs:
+            if dst.data_ptr() == src.data_ptr():
+                continue
+            if dst.dtype == src.dtype and dst.shape == src.shape and dst.is_contiguous() and src.is_contiguous() and dst.device == src.device:
+                g = groups.setdefault(dst.dtype, ([], []))
+                g[0].append(dst)
+                g[1].append(src)
+            else:
+                dst.copy_(src)
+        for dsts, srcs in groups.values():
+            torch._foreach_copy_(dsts, srcs)
 
     def capture_refill(self, make_kw) -> None:
         """`refill` of this engine as TWO hipGraphs. make_kw() builds reset's keyword arguments from STATIC input tensors (the caller
@@ -353,24 +378,26 @@ class RolloutEngine:
         self.commit_refill()
 
     @staticmethod
-    def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor]) -> None:
+    def _copy_tokens(dst: Dict[str, Tensor], src: Dict[str, Tensor], pairs: list) -> list:
+        """Queues the token tensors' copies in `pairs`; returns the (u8 copy, its source mask) pairs to refresh AFTER those ran."""
         for k, v in src.items():
             if k.startswith("_"):
                 continue  # caches: rebuilt by their owners
             if torch.is_tensor(v):
                 if dst[k].data_ptr() != v.data_ptr():
-                    dst[k].copy_(v)
+                    pairs.append((dst[k], v))
             elif isinstance(v, (int, float, bool)):
                 assert dst[k] == v, (k, dst[k], v)
+        late = []
         for k in dst:  # u8 copies of a mask that a consumer added lazily (e.g. mp_token_invalid_u8): refreshed from their source
             if k.endswith("_u8") and k not in src and torch.is_tensor(dst.get(k[:-3])):
-                dst[k].copy_(dst[k[:-3]].to(torch.uint8))
+                late.append((dst[k], dst[k[:-3]]))
+        return late
 
     @_scheduled
     def restore(self) -> None:
         """Back to step 1 without re-allocating (pointers captured in the graph stay valid)."""
-        for k, v in self.init_state.items():
-            self.S[k].copy_(v)
+        self._copy_all([(self.S[k], v) for k, v in self.init_state.items()])
         self.parity = 0
         self._n_forward = 0
         self._prime()
