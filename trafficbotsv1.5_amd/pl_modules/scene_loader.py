@@ -34,9 +34,11 @@ class SceneLoader:
             if src.shape != dst.shape or src.dtype != dst.dtype:
                 raise ValueError(f"SceneLoader: {k} is {tuple(src.shape)} {src.dtype}, the captured shape is {tuple(dst.shape)} {dst.dtype}")
 
-        def copies():
+        def copies():  # (device-resident scenes: a few multi-tensor launches; host tensors: one asynchronous copy each)
+            self.eng._copy_all([(dst, batch[k]) for k, dst in self.static.items() if batch[k].device == dst.device])
             for k, dst in self.static.items():
-                dst.copy_(batch[k], non_blocking=True)
+                if batch[k].device != dst.device:
+                    dst.copy_(batch[k], non_blocking=True)
 
         return copies
 
