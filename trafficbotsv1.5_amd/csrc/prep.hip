@@ -4,6 +4,7 @@
 #include <float.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tbx_hip.h"
 #include "tbx_common.h"
@@ -17,6 +18,12 @@ using tbx_step::to_local;
 // One workgroup (4 wavefronts) per agent: the window's steps are dealt to the wavefronts, the last valid step comes from one
 // ballot over the validity bytes (the kernel opens every agent step: 14 -> ~6 us at 64 agents).
 __global__ __launch_bounds__(256) void agent_prep_kernel(const AgentPrepArgs a) { tbx_step::agent_prep(a, (int)blockIdx.x, (int)threadIdx.x, 256); }
+// ... and a WAVEFRONT per agent (its two 32-lane slots walk the window) for launches of many agents: at 4096 agents the form above is
+// 4096 workgroups of a few hundred instructions each - bound by the rate workgroups are dispatched at (14.3 us; this form: see
+// DESIGN.md 5). Same per-(agent, step) arithmetic: bit-identical rows.
+__global__ __launch_bounds__(256) void agent_prep_wave_kernel(const AgentPrepArgs a) {
+  tbx_step::agent_prep(a, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), 64);
+}
 
 __global__ void tl_prep_kernel(const uint8_t* __restrict__ hist_tl, const uint8_t* __restrict__ tl_invalid, int n_tok,
                                int window, int ld_attr, float* __restrict__ attr, uint8_t* __restrict__ row_invalid) {
@@ -102,7 +109,14 @@ extern "C" int tbx_agent_prep(const uint8_t* hist_valid, const float* hist_pose,
   AgentPrepArgs a{hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, tok_pose, tok_invalid,
                   attr, pe, row_invalid, type_mask, dest, mp_tok_pose, navi_pose3, navi_row, n_batch * n_ag, n_ag, window,
                   pe_dim, n_mp, mp_batch_div};
-  hipLaunchKernelGGL(agent_prep_kernel, dim3(a.n_tok), dim3(256), 0, (hipStream_t)stream, a);
+  static const int wave_rows = [] {
+    const char* e = getenv("TBX_PREP_WAVE_ROWS");
+    return e && atoi(e) > 0 ? atoi(e) : 512;
+  }();
+  if (a.n_tok >= wave_rows)
+    hipLaunchKernelGGL(agent_prep_wave_kernel, dim3((a.n_tok + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(agent_prep_kernel, dim3(a.n_tok), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
