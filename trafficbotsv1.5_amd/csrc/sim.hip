@@ -174,9 +174,14 @@ extern "C" int tbx_sim_step_tl_prep(const tbx_sim_state_t* st, int parts, const 
     // TBX_SIM_ADVANCE inside the launch = one arrival per workgroup on ONE counter: same-address atomics serialise in L2 at ~10 ns
     // each (measured at 32 x 128 agents: 1024 arrivals = ~8 us of a 16 us launch). Large grids advance by a one-thread launch
     // behind the step instead (stream order: every workgroup has read *step by then).
-    const unsigned blocks = (unsigned)((n + 127) / 128);
+    // ... unless workgroups of up to 1024 threads bring the grid down to 256 arrivals (4096 agents: 256 workgroups of 512): the extra
+    // launch is ~5 us + its gaps on the critical path of every step at the WOSAC shape.
+    unsigned bs = 128;
+    if (parts & TBX_SIM_ADVANCE)
+      while (bs < 1024 && (n + bs - 1) / bs > 256) bs *= 2;
+    const unsigned blocks = (unsigned)((n + bs - 1) / bs);
     const bool bump_after = (parts & TBX_SIM_ADVANCE) && blocks > 256;
-    hipLaunchKernelGGL(sim_step_kernel, dim3(blocks), dim3(128), 0, hs, s, bump_after ? (parts & ~TBX_SIM_ADVANCE) : parts, tp);
+    hipLaunchKernelGGL(sim_step_kernel, dim3(blocks), dim3(bs), 0, hs, s, bump_after ? (parts & ~TBX_SIM_ADVANCE) : parts, tp);
     if (bump_after) hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
   } else {
     hipLaunchKernelGGL(sim_bump_kernel, dim3(1), dim3(1), 0, hs, s.step);
