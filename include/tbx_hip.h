@@ -801,9 +801,10 @@ int tbx_sim_step(const tbx_sim_state_t* st /* host */, void* stream);
  * tl_state, traffic_bots.py:188-199 + dynamics.py:143-163) never reads an agent, so a rollout may advance the lights on
  * one stream while the agents of the same step run on another; both parts read *step, TBX_SIM_ADVANCE bumps it and
  * must be ordered after both. With TBX_SIM_ADVANCE next to a part, the last workgroup of that part's kernel to arrive
- * bumps the counter (every workgroup has read it by then): no extra launch - for grids of up to 256 workgroups; a larger grid's
- * arrivals on the one counter would serialise in L2 (~10 ns each), so there the call makes a second, one-thread launch on the same
- * stream that bumps it. tbx_sim_step == all three, one kernel (two for such a grid). */
+ * bumps the counter (every workgroup has read it by then): no extra launch - for grids of up to 256 workgroups (the call uses
+ * workgroups of up to 1024 threads to stay there: 8192 agents); a larger grid's arrivals on the one counter would serialise in L2
+ * (~10 ns each), so there the call makes a second, one-thread launch on the same stream that bumps it. tbx_sim_step == all three,
+ * one kernel (two for such a grid). */
 enum { TBX_SIM_AGENTS = 1, TBX_SIM_LIGHTS = 2, TBX_SIM_ADVANCE = 4,
        /* Step-wise drivers split a step where the reference's Python does (waymo_motion.py:118-204 is `forward`, :250-275 the
         * caller's rule check + disable_ag / disable_navi, traffic_bots.py:123-143 appends the windows at the NEXT forward):
