@@ -35,7 +35,8 @@ from tools.benchlib import launch  # noqa: E402
 from tools.benchlib.args import parse, shard_scenes  # noqa: E402,F401  (shard_scenes: tests/test_multiprocess_sharding.py)
 
 DTYPE_F32 = "f32 (split-bf16 MFMA products)"  # every LINEAR of the default schedule = three bf16 MFMA products per fp32 product
-DTYPE_BF16 = "bf16: K/V tables + matrix-core attention operands (launches >= 193 rows); f32 (split-bf16 MFMA products) elsewhere"
+DTYPE_BF16 = ("bf16: K/V tables + matrix-core attention operands (launches >= 193 rows) + one bf16 product per LINEAR of the one-launch decoder "
+              "layer (launches <= 256 rows); f32 (split-bf16 MFMA products) elsewhere")
 
 
 def __getattr__(name):
@@ -133,8 +134,9 @@ def main(argv=None):
         full["wosac_shape"] = {"metric": full["metric"], "unit": full["unit"], "n_gpus": world, "steps": big.steps, "warmup": big.warmup, **r5}
     if args.bf16_shape:
         # BASELINE.json configs[1] says bf16: the same two workloads on the bf16-arithmetic schedule (Schedule.reduced(): bfloat16 K/V
-        # tables - 529 B per pair - and, from 193 source rows, the attention with bf16 operands on the matrix cores; tolerances in
-        # tests/test_hip_bf16.py / test_hip_attn_mfma.py). The fp32 line above stays the parity line.
+        # tables - 529 B per pair -, from 193 source rows the attention with bf16 operands on the matrix cores, and the one-launch
+        # decoder layer's LINEAR stages as one bf16 product; tolerances in tests/test_hip_bf16.py / test_hip_attn_mfma.py /
+        # test_hip_rollout.py). The fp32 line above stays the parity line.
         b16 = copy.copy(args)
         b16.kv_bf16, b16.attn_mfma = True, 1
         r16, _, _ = measure(b16)

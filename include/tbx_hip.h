@@ -239,7 +239,9 @@ typedef struct tbx_dec_layer {
   int32_t ld_qkv_out;
   int32_t tail_mfma32; /* != 0: EVERY image of the call (mid.fold_self / out_proj / q / qfold / fold_cross, out_proj2 / linear1 / linear2 /
                         * next_in_proj / next_qfold, heads->images) is a tbx_pack_weight_mfma32 image and every LINEAR stage runs on
-                        * the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32 fma chains */
+                        * the split-bf16 matrix path (< 3e-5 of sum |x||w| per output) instead of exact-fp32 fma chains.
+                        * 2 (bf16 tables only): the same images, ONE bf16 product per LINEAR - weights and activations rounded to
+                        * bfloat16 (2^-9 relative per operand), fp32 accumulation; the lo halves of the weight units are not read */
   const tbx_tl_tail_t* lights; /* host pointer or NULL; only with qkv_out == NULL, heads == NULL and tail_mfma32 */
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);

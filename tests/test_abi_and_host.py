@@ -194,7 +194,7 @@ def test_graphed_train_step_refuses_without_the_ordered_memset_path(tb, monkeypa
 
 def test_schedule_switches_follow_the_environment_and_replace(tb, monkeypatch):
     """engine.Schedule: every boolean switch is on by default except the opt-ins (measured slower: front_big, attn_fold_big, pool_proj;
-    a different arithmetic: kv_bf16, split_bf16, attn_mfma), `TBX_<NAME>=0 / 1` flips it in from_env(), replace() leaves the original alone, and a
+    a different arithmetic: kv_bf16, split_bf16, attn_mfma, linear_bf16), `TBX_<NAME>=0 / 1` flips it in from_env(), replace() leaves the original alone, and a
     schedule is a value (two equal ones compare equal: engines are cached by it)."""
     import dataclasses
     from importlib import import_module
@@ -204,7 +204,7 @@ def test_schedule_switches_follow_the_environment_and_replace(tb, monkeypatch):
         if k.startswith("TBX_"):
             monkeypatch.delenv(k)
     d = E.Schedule.from_env()
-    off = {"front_big", "attn_fold_big", "pool_proj", "kv_bf16", "split_bf16", "attn_mfma"}
+    off = {"front_big", "attn_fold_big", "pool_proj", "kv_bf16", "split_bf16", "attn_mfma", "linear_bf16"}
     bools = [f.name for f in dataclasses.fields(E.Schedule) if isinstance(getattr(d, f.name), bool)]
     assert {"knn_aux_big", "prime_graph", "fused_tail", "front_fused", "dec_tail_mfma", "front_big"} <= set(bools)
     for name in bools:

@@ -550,8 +550,15 @@ def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
     assert float(ro["action"][:, :, 12:].abs().max()) > 1.0
     # exact-fp32 schedule (window PointNets / first projections as row chains), then the default one (tile kernels: their split-bf16
     # stages start the same amplification from ~1e-5 instead of ~1e-7, so the point-wise horizon is shorter)
-    for tile_small, checks in ((False, ((60, 1e-3), (70, 5e-2))), (True, ((40, 5e-3), (60, 5e-2)))):
-        wm.schedule = E.DEFAULT.replace(tile_small=tile_small, dec_tail_mfma=tile_small)
+    # ... and the bf16-ARITHMETIC schedule (Schedule.reduced(): bfloat16 tables, one bf16 product per LINEAR of the one-launch layer):
+    # no point-wise horizon is claimed for it, only the rollout-level figures
+    for tile_small, checks in ((False, ((60, 1e-3), (70, 5e-2))), (True, ((40, 5e-3), (60, 5e-2))), ("tables", ()), ("reduced", ())):
+        if tile_small == "tables":
+            wm.schedule = E.DEFAULT.replace(kv_bf16=True)
+        elif tile_small == "reduced":
+            wm.schedule = E.DEFAULT.reduced()
+        else:
+            wm.schedule = E.DEFAULT.replace(tile_small=tile_small, dec_tail_mfma=tile_small)
         mp, tl = wm.encode_scene(bd)
         ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
                      "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
@@ -573,6 +580,8 @@ def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
         flags = min(agree(buf.pred_valid[:, 0].cpu(), pv), agree(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]),
                     agree(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"]))
         print(f"[rollout acceptance] tile_small={tile_small}: ADE {ade:.4g} m, FDE {fde:.4g} m over 90 steps, flag agreement {flags:.4f}")
-        # measured (MI355X): exact-fp32 schedule ADE 0.67 mm / FDE 6.0 mm, default schedule ADE 1.5 mm / FDE 11 mm, flags 100 %
-        ade_max, fde_max = (3e-3, 5e-2) if not tile_small else (1e-2, 0.1)
-        assert ade < ade_max and fde < fde_max and flags >= 0.995, (tile_small, ade, fde, flags)
+        # measured (MI355X): exact-fp32 schedule ADE 0.67 mm / FDE 6.0 mm, default schedule ADE 0.76 mm / FDE 6.1 mm, bf16 tables ADE 33 mm /
+        # FDE 0.19 m, the bf16-arithmetic schedule (one bf16 product per LINEAR: 2^-9 per operand into a loop that amplifies ~100x per
+        # 10 steps) ADE 0.44 m / FDE 1.7 m; flags 100 % in all four
+        ade_max, fde_max, flags_min = {False: (3e-3, 5e-2, 0.995), True: (1e-2, 0.1, 0.995), "tables": (0.1, 0.6, 0.995), "reduced": (1.5, 6.0, 0.995)}[tile_small]
+        assert ade < ade_max and fde < fde_max and flags >= flags_min, (tile_small, ade, fde, flags)

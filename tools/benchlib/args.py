@@ -34,6 +34,8 @@ def parse(argv=None):
     ap.add_argument("--no-train-graph", action="store_true", help="training: eager fwd+bwd instead of one hipGraph replay per step")
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of that appended measurement (after 3 warm-up steps)")
     ap.add_argument("--kv-bf16", action="store_true", help="bfloat16 K/V tables (BASELINE config 2's dtype; 529 B per attention pair)")
+    ap.add_argument("--linear-bf16", type=int, choices=(0, 1), default=1,
+                    help="with --kv-bf16 --attn-mfma 1: Schedule.linear_bf16 (one bf16 product per LINEAR of the one-launch decoder layer; default 1 = Schedule.reduced())")
     ap.add_argument("--attn-mfma", type=int, default=None, choices=[0, 1],
                     help="Schedule.attn_mfma of the measured engines: 0 fp32 VALU attention, 1 bf16 matrix-core attention (default: the "
                          "engine's own default)")

@@ -92,6 +92,8 @@ def measure(a, tb, hip, dev, rank, world, dist):
     wm.schedule = E.DEFAULT.replace(kv_bf16=bool(a.kv_bf16), lights_ahead=not a.no_lights_ahead, graph_steps=gsteps)
     if getattr(a, "attn_mfma", None) is not None:
         wm.schedule = wm.schedule.replace(attn_mfma=bool(a.attn_mfma))
+    if a.kv_bf16 and getattr(a, "attn_mfma", None):  # = Schedule.reduced(): the bf16-arithmetic schedule (--linear-bf16 0: its LINEAR stages fp32-class)
+        wm.schedule = wm.schedule.replace(linear_bf16=bool(getattr(a, "linear_bf16", 1)))
     eng, t_scene = gpu_rollout_setup(tb, wm, full, a, dev)
     use_graph = not a.no_graph
     t_cap = time.perf_counter()

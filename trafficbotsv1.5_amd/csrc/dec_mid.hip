@@ -526,677 +526,20 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
 // 14..16 next in_proj (q, k, v), 17 next qfold, or the heads: 14..17 add_navi (k-chunk x, k-chunk embedding, layer 2, layer 3),
 // 18..21 add_latent, 22..24 / 25..27 / 28 the action head's three stacked stages (csrc/tile_heads.hip's entries), or the lights' tail:
 // 14..21 k, v of the agents' 4 layers, 22..24 the next-state predictor, or nothing.
-namespace mf {
-using tbx_tile::Acc;
-using tbx_tile::bf16x4;
-using tbx_tile::bf16x8;
-using tbx_tile::f32x4;
-using tbx_tile::u32x2;
-using tbx_tile::W;
-
-constexpr int NSW = 8;  // all 8 waves sweep: a row's targets 8 per pass per wave, two waves per SIMD hide each other's load latencies
-constexpr int LO128 = 256, LO384 = 768, LO512 = 1024, LO640 = 1280;  // byte offset of the lo plane behind a K-wide hi plane
-
-// (br: the action-head branch units 22 / 23 / 24 are taken from - the agents' heads only)
-template <int N>
-__device__ __forceinline__ void issue(W& w, const MidArgs& a, bool heads, int wave, int lane, int br = 0) {
-  using tbx_tile::load_unit;
-  if constexpr (N == 0) load_unit(w, a.fold1, wave, lane);
-  else if constexpr (N == 1) load_unit(w, a.wo, wave, lane);
-  else if constexpr (N == 2) load_unit(w, a.wq, wave, lane);
-  else if constexpr (N == 3) load_unit(w, a.wkf, wave, lane);
-  else if constexpr (N == 4) load_unit(w, a.fold2, wave, lane);
-  else if constexpr (N == 5) load_unit(w, a.wo2, wave, lane);
-  else if constexpr (N <= 9) load_unit(w, a.w1, 8 * (N - 6) + wave, lane);
-  else if constexpr (N <= 13) load_unit(w, a.w2, 8 * (N - 10) + wave, lane);
-  else if (a.qkv_out != nullptr) {
-    if constexpr (N <= 16) load_unit(w, a.wqkv, 8 * (N - 14) + wave, lane);
-    else if constexpr (N == 17) load_unit(w, a.wqt, wave, lane);
-  } else if (a.tl.kv_out != nullptr) {  // 14..21: k, v of the agents' 4 layers; 22..24: the state predictor
-    if constexpr (N >= 14 && N <= 21) load_unit(w, a.tl.kv_images[(N - 14) >> 1], 8 * ((N - 14) & 1) + wave, lane);
-    else if constexpr (N == 22 || N == 23) load_unit(w, a.tl.mlp_images[N - 22], wave, lane);
-    else if constexpr (N == 24) load_unit(w, a.tl.mlp_images[2], 0, lane);
-  } else if (heads) {
-    if constexpr (N == 14 || N == 18) load_unit(w, a.hw[N == 14 ? 0 : 3], wave, lane);
-    else if constexpr (N == 15 || N == 19) load_unit(w, a.hw[N == 15 ? 0 : 3], 8 + wave, lane);
-    else if constexpr (N == 16 || N == 17) load_unit(w, a.hw[N - 15], wave, lane);
-    else if constexpr (N == 20 || N == 21) load_unit(w, a.hw[N - 16], wave, lane);
-    else if constexpr (N == 22) {  // the action head's three layers of branch br (none: an invalid agent)
-      if (br >= 0) load_unit(w, a.hw[6], 8 * br + wave, lane);
-    } else if constexpr (N == 23) {
-      if (br >= 0) load_unit(w, a.hw[7], 8 * br + wave, lane);
-    } else if constexpr (N == 24) {
-      if (wave == 0) load_unit(w, a.hw[8], br, lane);
-    }
-  }
-}
-
-// 4 values of the row -> planes (hi at P + 2 c, lo `lo` bytes behind)
-__device__ __forceinline__ void put4(char* P, int lo, int c, const f32x4 v) {
-  u32x2 hi, l;
-  tbx_tile::split4(v, hi, l);
-  *(u32x2*)(P + c * 2) = hi;
-  *(u32x2*)(P + lo + c * 2) = l;
-}
-
-// one 32-k step of D += W x^T with the row's planes as the B operand
-__device__ __forceinline__ void step(Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int lo, int st, int g4) {
-  const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
-  const bf16x8 xl = *(const bf16x8*)(P + lo + (st * 32 + g4 * 8) * 2);
-  acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
-  acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
-  acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
-}
-
-__device__ __forceinline__ f32x4 gemv4(const W& w, const char* P, int lo, int st0, int g4) {
-  Acc acc;
-  acc.zero();
-#pragma unroll
-  for (int st = 0; st < 4; ++st) step(acc, w.hi[st], w.lo[st], P, lo, st0 + st, g4);
-  return acc.sum();
-}
-
-// LayerNorm of the 128-float row `src` by one wavefront (ln_row128's order) -> planes
-__device__ __forceinline__ void ln_planes(const float* src, char* P, int lane, float eps, const float (&g)[2], const float (&bt)[2]) {
-  float v[2];
-  v[0] = src[lane], v[1] = src[lane + 64];
-  const float mean = tbx::wave_sum(v[0] + v[1]) / (float)D;
-  const float d0 = v[0] - mean, d1 = v[1] - mean;
-  const float var = tbx::wave_sum(d0 * d0 + d1 * d1) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float y = (v[q] - mean) * rstd * g[q] + bt[q];
-    const __bf16 h = (__bf16)y;
-    *(__bf16*)(P + 2 * (lane + 64 * q)) = h;
-    *(__bf16*)(P + LO128 + 2 * (lane + 64 * q)) = (__bf16)(y - (float)h);
-  }
-}
-
-// attn_core.h's `sweep` for NSW waves per row with the FIRST pass of segment 0 handed in: its target index / mask are fetched at
-// the top of the kernel and its K / V rows and embedding slice while the previous phase finishes (`Pre`), so the sweep starts on
-// operands that are already in registers instead of behind two dependent memory round trips (~2500 shader clocks each at this
-// occupancy, profiles/r03_attn_phase_clock.txt). Same passes in the same order as sweep<NSW>: the same sums.
-struct Pre {
-  float4 kq[4], v[4];
-  ESlice e;  // the materialised embedding slice (seg.emb), or - in e.wc.x / y / z - the relative pose it is rebuilt from when the pass
-             // runs (rebuilding it where it is requested would wait for the pose there)
-};
-__device__ __forceinline__ void pre_index(const Sweep& a, int row, int wir, int tg, int& j, bool& ok) {
-  const tbx_attn_seg_t& S = a.seg[0];
-  const int t = wir * 8 + tg;
-  const bool active = t < S.k;
-  const int64_t pi = (int64_t)row * S.k + (active ? t : S.k - 1);
-  j = S.idx[pi];
-  ok = (S.invalid[pi] == 0) & active;
-}
-// REL: every segment of the launch gives its pairs as relative poses (seg.emb == NULL: the default schedule) - known at compile time,
-// because a run-time branch between "load the embedding" and "load the pose" makes the wait-count pass merge the two paths' pending
-// loads: the pose path then waited for EVERYTHING in flight (a register of the other path's loads was re-used for its address).
-template <bool KV16, bool REL>
-__device__ __forceinline__ void pre_rows(const Sweep& a, int row, int b, int wir, int s8, int tg, int j, const EFreq& fq, Pre& p) {
-  const tbx_attn_seg_t& S = a.seg[0];
-  constexpr int ES = KV16 ? 2 : 1;
-  const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-  const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
-  const int t = wir * 8 + tg;
-  const int64_t pi = (int64_t)row * S.k + (t < S.k ? t : S.k - 1);
-  if constexpr (REL) {
-    p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
-  } else {
-    if (S.emb != nullptr)
-      p.e.load(S.emb + pi * DR, s8);
-    else
-      p.e.wc.x = S.rel_pose[pi * 3], p.e.wc.y = S.rel_pose[pi * 3 + 1], p.e.wc.z = S.rel_pose[pi * 3 + 2];
-  }
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    p.kq[st] = kv_load4<KV16>(trow, S.k_off + st * 32 + s8 * 4);
-    p.v[st] = kv_load4<KV16>(trow, S.v_off + st * 32 + s8 * 4);
-  }
-}
-template <bool KV16, bool REL>
-__device__ __forceinline__ void sweep_pf(const Sweep& a, int row, int b, int wir, int s8, int tg, const float4 (&qv)[NH], const ESlice (&qt)[NH],
-                                         const float (&qb)[NH], const EFreq& fq, Pre& pre, bool pre_ok, RowAcc& st) {
-  float(&m_run)[NH] = st.m_run;
-  float(&l_run)[NH] = st.l_run;
-  float4(&oacc)[NH] = st.oacc;
-  ESlice(&eacc)[NH] = st.eacc;
-  auto pass = [&](const bool ok, const float4(&kq)[4], const float4(&v)[4], const ESlice& e) {
-    float sc[NH];
-    bool jump = false;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      sc[h] = (tbx::group8_sum(pair_score(kq[h], qv[h], e, qt[h])) + qb[h]) * a.scale2;
-      jump = jump || (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f);
-    }
-    if (__builtin_expect(__ballot(jump) != 0ull, 0)) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (ok && m_run[h] > -INFINITY && sc[h] - m_run[h] > 64.f) {
-          const float alpha = __builtin_amdgcn_exp2f(m_run[h] - sc[h]);
-          l_run[h] *= alpha;
-          scale4(oacc[h], alpha);
-          eacc[h].scale(alpha);
-          m_run[h] = sc[h];
-        }
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      m_run[h] = (ok && m_run[h] == -INFINITY) ? sc[h] : m_run[h];
-      const float pr = ok ? __builtin_amdgcn_exp2f(sc[h] - m_run[h]) : 0.f;
-      l_run[h] += pr;
-      fma4(oacc[h], pr, v[h]);
-      eacc[h].fma(pr, e);
-    }
-  };
-  if (wir * 8 < a.seg[0].k) {
-    if (REL || a.seg[0].emb == nullptr) {
-      const float rel[3] = {pre.e.wc.x, pre.e.wc.y, pre.e.wc.z};
-      fq.embed(rel, pre.e);
-    }
-    pass(pre_ok, pre.kq, pre.v, pre.e);
-  }
-  for (int sg = 0; sg < a.n_seg; ++sg) {
-    const tbx_attn_seg_t& S = a.seg[sg];
-    constexpr int ES = KV16 ? 2 : 1;
-    const float* kvb = (const float*)((const char*)S.kv + ((int64_t)(b / S.batch_div) * S.n_tgt * S.ld_kv) * (4 / ES));
-    const int64_t pbase = (int64_t)row * S.k;
-    for (int base = wir * 8 + (sg == 0 ? 8 * NSW : 0); base < S.k; base += 8 * NSW) {
-      const int t = base + tg;
-      const bool active = t < S.k;
-      const int64_t pi = pbase + (active ? t : S.k - 1);
-      const int j = S.idx[pi];
-      const bool ok = (S.invalid[pi] == 0) & active;
-      const float* trow = (const float*)((const char*)kvb + ((int64_t)j * S.ld_kv) * (4 / ES));
-      float4 kq[4], v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        kq[q] = kv_load4<KV16>(trow, S.k_off + q * 32 + s8 * 4);
-        v[q] = kv_load4<KV16>(trow, S.v_off + q * 32 + s8 * 4);
-      }
-      ESlice e;
-      if constexpr (REL) fq.embed(S.rel_pose + pi * 3, e);
-      else load_e(S, pi, s8, fq, e);
-      pass(ok, kq, v, e);
-    }
-  }
-}
-
-// combine_fold's first half for 8 sweeping waves: their partials -> the row's normalised sums comb_s [640] (fp32) and their planes Pc
-template <class F>
-__device__ __forceinline__ void combine(float Mh, float Lh, const float4& o, const ESlice& e, float (*red_s)[RED], float* comb_s, char* Pc,
-                                        int wir, int lane, int s8, bool& any_valid, F&& request) {
-  // (merge_slots_by_head: lane l holds head l >> 4's sums of channel slice s8; lanes l and l ^ 8 the same)
-  const int hq = lane >> 4;
-  if ((lane & 8) == 0) {
-    *(float4*)(&red_s[wir][hq * DH + s8 * 4]) = o;
-    e.store(&red_s[wir][D + hq * DR], s8);
-  }
-  if ((lane & 15) == 0) {
-    red_s[wir][OUTW + hq] = Mh;
-    red_s[wir][OUTW + NH + hq] = Lh;
-  }
-  request();  // (the sweep's sums have left the registers: the next two weight units fly under the combination)
-  __syncthreads();
-  {  // (a valid target gives every head a score: head 0's maxima tell)
-    float mm0 = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NSW; ++w) mm0 = fmaxf(mm0, red_s[w][OUTW]);
-    any_valid = mm0 > -INFINITY;
-  }
-  if (threadIdx.x < OUTW / 4) {  // 160 threads, 4 consecutive columns each (one head's)
-    const int c = (int)threadIdx.x * 4;
-    const int h = c < D ? c / DH : (c - D) / DR;
-    float mm = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NSW; ++w) mm = fmaxf(mm, red_s[w][OUTW + h]);
-    float ll = 0.f, fw[NSW];
-#pragma unroll
-    for (int w = 0; w < NSW; ++w) {
-      const float mw = red_s[w][OUTW + h];
-      fw[w] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
-      ll = __builtin_fmaf(fw[w], red_s[w][OUTW + NH + h], ll);
-    }
-    const float inv_l = (mm > -INFINITY) ? 1.0f / ll : 0.f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NSW; ++w) {
-      const f32x4 r = *(const f32x4*)(&red_s[w][c]);
-      acc[0] = __builtin_fmaf(fw[w], r[0], acc[0]), acc[1] = __builtin_fmaf(fw[w], r[1], acc[1]);
-      acc[2] = __builtin_fmaf(fw[w], r[2], acc[2]), acc[3] = __builtin_fmaf(fw[w], r[3], acc[3]);
-    }
-    acc *= inv_l;
-    if (c < D) *(f32x4*)(comb_s + c) = acc;  // (sum a v: the fold's fp32 addend)
-    put4(Pc, LO640, c, acc);
-  }
-  __syncthreads();
-}
-}  // namespace mf
-
-template <bool KV16, bool REL>
-__global__ __launch_bounds__(512) void dec_layer_mf_kernel(const MidArgs a) {
-  using namespace mf;
-  __shared__ __attribute__((aligned(16))) float red_s[NSW][RED];
-  __shared__ __attribute__((aligned(16))) float comb_s[D], xs[D], q2[D], qt2[NH * D], bk2_s[D], head_o[3 * 2];
-  __shared__ __attribute__((aligned(16))) char Pc[2 * LO640], Ph[2 * LO128], Pq[2 * LO128], Pu[2 * LO512], Pv[2 * LO384];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wir = wave;
-  const int row = blockIdx.x;
-#ifdef TBX_STAGE_CLOCK
-  unsigned mid_slot = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) mid_slot = atomicAdd(&g_mid_launch, 1u);
-#endif
-  MID_CLK(0);
-  const int b = row / a.n_src;
-  const int s8 = lane & 7, tg = lane >> 3;
-  // the target index / mask of BOTH sweeps' first pass (the K-nearest sets are inputs of the launch): the kernel's first requests, so
-  // that the self sweep's row gathers leave before anything waits for the query side (they sat behind two dependent round trips)
-  int j1, j2;
-  bool ok1, ok2;
-  pre_index(a.self, row, wir, tg, j1, ok1);
-  pre_index(a.cross, row, wir, tg, j2, ok2);
-  const int g4 = lane >> 4;
-  const bool col0 = (lane & 15) == 0;  // the lanes that hold column 0 = the row: channels c_out .. c_out + 3 of a 128-wide stage
-  const int c_out = 16 * wave + 4 * g4;
-  const bool heads = a.hw[0] != nullptr && a.qkv_out == nullptr;
-  // (the step counter of the fused tail: requested here, a round trip to memory before that tail needs it)
-  const int t_step_v = a.fused_tail ? *a.sim.step : 0;
-  W wb[3];
-  // (the row and the cross bias go to LDS behind the query-side requests: a load straight into an LDS write is waited for on the spot)
-  float x_r = 0.f, bk2_r = 0.f;
-  if (threadIdx.x < D) x_r = a.x[(int64_t)row * D + threadIdx.x], bk2_r = a.bias_k2[threadIdx.x];
-  float lg1[2] = {0.f, 0.f}, lb1[2] = {0.f, 0.f}, lg2[2] = {0.f, 0.f}, lb2[2] = {0.f, 0.f}, lg3[2] = {0.f, 0.f}, lb3[2] = {0.f, 0.f};
-  // (LayerNorm parameters: requested with the weight units behind each sweep - nothing is kept in registers across one)
-  EFreq fq;
-  fq.init(a.fxy, a.fyaw, s8);
-  float4 qv[NH];
-  ESlice qt[NH];
-  float qb[NH];
-  Pre pre;
-  // ---------------------------------------------------------------- self attention
-  {
-    const float* qrow = a.qkv + (int64_t)row * a.ld_qkv;
-    float4 bk[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      qv[h] = *(const float4*)(qrow + a.q_off + h * DH + s8 * 4);
-      bk[h] = *(const float4*)(a.bias_k1 + h * DH + s8 * 4);
-      qt[h].load(qrow + a.qt_off + h * DR, s8);
-    }
-    pre_rows<KV16, REL>(a.self, row, b, wir, s8, tg, j1, fq, pre);  // (behind the query-side requests: waiting for those does not wait for these)
-    if (threadIdx.x < D) xs[threadIdx.x] = x_r, bk2_s[threadIdx.x] = bk2_r;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) qb[h] = tbx::group8_sum(dot4(qv[h], bk[h]));
-  }
-  bool valid1, valid2;
-  MID_CLK(1);
-  {
-    RowAcc st;
-    st.zero();
-    float M[NH] = {0.f, 0.f, 0.f, 0.f};
-    sweep_pf<KV16, REL>(a.self, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok1, st);
-    float Mh, Lh;
-    float4 om;
-    ESlice em;
-    merge_slots_by_head(st, M, Mh, Lh, om, em);
-    MID_CLK(2);
-    combine(Mh, Lh, om, em, red_s, comb_s, Pc, wir, lane, s8, valid1, [&]() {
-      issue<0>(wb[0], a, heads, wave, lane);
-      issue<1>(wb[1], a, heads, wave, lane);
-      if (wave == 0) lg1[0] = a.ln_w[lane], lg1[1] = a.ln_w[64 + lane], lb1[0] = a.ln_b[lane], lb1[1] = a.ln_b[64 + lane];
-      pre_rows<KV16, REL>(a.cross, row, b, wir, s8, tg, j2, fq, pre);  // the cross sweep's first pass: in flight under the layer's middle
-    });
-  }
-  // ---- 0: y = sum a v + W_rpe_v (sum a e) + b (wave w: head w / 2, 16 of its 32 channels)
-  issue<2>(wb[2], a, heads, wave, lane);
-  {
-    const f32x4 y = gemv4(wb[0], Pc, LO640, 4 + 4 * (wave >> 1), g4) + wb[0].bias + *(const f32x4*)(comb_s + c_out);
-    if (col0) put4(Ph, LO128, c_out, y);
-  }
-  __syncthreads();
-  MID_CLK(3);
-  // ---- 1: x += no valid target ? 0 : out_proj(y)
-  issue<3>(wb[0], a, heads, wave, lane);
-  {
-    const f32x4 u = gemv4(wb[1], Ph, LO128, 0, g4) + wb[1].bias;
-    if (col0 && valid1) *(f32x4*)(xs + c_out) = *(const f32x4*)(xs + c_out) + u;
-  }
-  __syncthreads();
-  MID_CLK(4);
-  if (wave == 0) ln_planes(xs, Ph, lane, a.ln_eps, lg1, lb1);  // LN_1(x)
-  __syncthreads();
-  MID_CLK(5);
-  // ---- 2: q = W_q LN(x) + b_q
-  {
-    const f32x4 q = gemv4(wb[2], Ph, LO128, 0, g4) + wb[2].bias;
-    if (col0) {
-      *(f32x4*)(q2 + c_out) = q;
-      put4(Pq, LO128, c_out, q);
-    }
-  }
-  __syncthreads();
-  MID_CLK(6);
-  // ---- 3: qt_h = W_rpe_k,h^T q_h: wave w = head w / 2, 4 of its 8 tiles of 16 channels, K = 32 (the head's own step)
-  {
-    const int h = wave >> 1;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      Acc acc;
-      acc.zero();
-      step(acc, wb[0].hi[st], wb[0].lo[st], Pq, LO128, h, g4);
-      if (col0) *(f32x4*)(qt2 + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
-    }
-  }
-  __syncthreads();
-  MID_CLK(7);
-  // ---------------------------------------------------------------- cross attention
-  {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      qv[h] = *(const float4*)(q2 + h * DH + s8 * 4);
-      qb[h] = tbx::group8_sum(dot4(qv[h], *(const float4*)(bk2_s + h * DH + s8 * 4)));
-      qt[h].load(qt2 + h * DR, s8);
-    }
-  }
-  MID_CLK(8);
-  {
-    RowAcc st;
-    st.zero();
-    float M[NH] = {0.f, 0.f, 0.f, 0.f};
-    sweep_pf<KV16, REL>(a.cross, row, b, wir, s8, tg, qv, qt, qb, fq, pre, ok2, st);
-    float Mh, Lh;
-    float4 om;
-    ESlice em;
-    merge_slots_by_head(st, M, Mh, Lh, om, em);
-    MID_CLK(9);
-    combine(Mh, Lh, om, em, red_s, comb_s, Pc, wir, lane, s8, valid2, [&]() {
-      issue<4>(wb[1], a, heads, wave, lane);
-      issue<5>(wb[2], a, heads, wave, lane);
-      if (wave == 0) {
-        lg2[0] = a.ln2_w[lane], lg2[1] = a.ln2_w[64 + lane], lb2[0] = a.ln2_b[lane], lb2[1] = a.ln2_b[64 + lane];
-        if (a.qkv_out != nullptr) lg3[0] = a.ln3_w[lane], lg3[1] = a.ln3_w[64 + lane], lb3[0] = a.ln3_b[lane], lb3[1] = a.ln3_b[64 + lane];
-      }
-    });
-  }
-  const bool x_valid = a.src_invalid[row] == 0;
-  // ---- 4: the cross attention's value fold
-  issue<6>(wb[0], a, heads, wave, lane);
-  {
-    const f32x4 y = gemv4(wb[1], Pc, LO640, 4 + 4 * (wave >> 1), g4) + wb[1].bias + *(const f32x4*)(comb_s + c_out);
-    if (col0) put4(Ph, LO128, c_out, y);
-  }
-  __syncthreads();
-  // ---- 5: x += no valid cross target ? 0 : out_proj2(y)
-  issue<7>(wb[1], a, heads, wave, lane);
-  {
-    const f32x4 u = gemv4(wb[2], Ph, LO128, 0, g4) + wb[2].bias;
-    if (col0 && valid2) *(f32x4*)(xs + c_out) = *(const f32x4*)(xs + c_out) + u;
-  }
-  __syncthreads();
-  MID_CLK(10);
-  if (wave == 0) ln_planes(xs, Ph, lane, a.ln2_eps, lg2, lb2);  // h = norm2(x)
-  __syncthreads();
-  MID_CLK(11);
-  // ---- 6..9: u = relu(linear1(h)), 4 rounds of 128 channels (no barrier between them: they read Ph and write disjoint parts of Pu)
-#define TBX_MF_L1(N)                                                                 \
-  do {                                                                               \
-    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
-    const W& w = wb[(N) % 3];                                                        \
-    const f32x4 u = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);            \
-    if (col0) put4(Pu, LO512, ((N) - 6) * D + c_out, u);                             \
-  } while (0)
-  TBX_MF_L1(6);
-  TBX_MF_L1(7);
-  TBX_MF_L1(8);
-  TBX_MF_L1(9);
-#undef TBX_MF_L1
-  __syncthreads();
-  MID_CLK(12);
-  {  // ---- 10..13: x += linear2(u), K = 512 as 4 units into one accumulator triple; invalid source rows come out as 0
-    Acc acc;
-    acc.zero();
-    const f32x4 bias = wb[10 % 3].bias;
-#define TBX_MF_L2(N)                                                                 \
-  do {                                                                               \
-    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                         \
-    const W& w = wb[(N) % 3];                                                        \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w.hi[st], w.lo[st], Pu, LO512, 4 * ((N) - 10) + st, g4); \
-  } while (0)
-    TBX_MF_L2(10);
-    TBX_MF_L2(11);
-    TBX_MF_L2(12);
-    TBX_MF_L2(13);
-#undef TBX_MF_L2
-    if (col0) {
-      f32x4 v = *(const f32x4*)(xs + c_out) + (acc.sum() + bias);
-      if (!x_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      *(f32x4*)(xs + c_out) = v;
-      *(TBX_GLOBAL f32x4*)(a.x + (int64_t)row * D + c_out) = v;
-    }
-  }
-  MID_CLK(13);
-  if (a.qkv_out != nullptr) {
-    // ================================================================ the next layer's projections (attention_rpe.py:92-98,147)
-    __syncthreads();
-    if (wave == 0) ln_planes(xs, Ph, lane, a.ln3_eps, lg3, lb3);
-    __syncthreads();
-    float* qrow_out = a.qkv_out + (int64_t)row * a.ld_qkv_out;
-    {  // 14: q
-      issue<16>(wb[16 % 3], a, heads, wave, lane);
-      const W& w = wb[14 % 3];
-      const f32x4 q = gemv4(w, Ph, LO128, 0, g4) + w.bias;
-      if (col0) {
-        put4(Pq, LO128, c_out, q);
-        *(TBX_GLOBAL f32x4*)(qrow_out + c_out) = q;
-      }
-    }
-#define TBX_MF_KV(N)                                                                                  \
-  do {                                                                                                \
-    const W& w = wb[(N) % 3];                                                                         \
-    const f32x4 kv = gemv4(w, Ph, LO128, 0, g4) + w.bias;                                             \
-    if (col0) {                                                                                       \
-      *(TBX_GLOBAL f32x4*)(qrow_out + ((N) - 14) * D + c_out) = kv;                                   \
-      if (a.kv16_out != nullptr) {                                                                    \
-        const bf16x4 h16 = __builtin_convertvector(kv, bf16x4);                                       \
-        *(TBX_GLOBAL u32x2*)(a.kv16_out + (int64_t)row * (2 * D) + ((N) - 15) * D + c_out) = __builtin_bit_cast(u32x2, h16); \
-      }                                                                                               \
-    }                                                                                                 \
-  } while (0)
-    issue<17>(wb[17 % 3], a, heads, wave, lane);
-    TBX_MF_KV(15);
-    TBX_MF_KV(16);
-#undef TBX_MF_KV
-    __syncthreads();  // q's planes complete
-    MID_CLK(14);
-    {  // 17: W_rpe_k^T q per head
-      const W& w = wb[17 % 3];
-      const int h = wave >> 1;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        Acc acc;
-        acc.zero();
-        step(acc, w.hi[st], w.lo[st], Pq, LO128, h, g4);
-        if (col0) *(TBX_GLOBAL f32x4*)(qrow_out + 3 * D + h * D + ((wave & 1) * 4 + st) * 16 + 4 * g4) = acc.sum();
-      }
-    }
-    MID_CLK(15);
-    return;
-  }
-  if (a.tl.kv_out != nullptr) {
-    // ================================================================ the lights' tail (traffic_bots.py:188-199): the K/V rows the agents'
-    // 4 layers read (emit_kv_tables: LayerNorm_l + in_proj_kv,l) and the next-state logits (traffic_light.py:249-286)
-    __shared__ __attribute__((aligned(16))) char Pl[4][2 * LO128];
-    __syncthreads();  // xs complete
-    if (wave < 4) {   // the four layers' LayerNorms at once, a wave each
-      float g[2], bt[2];
-      g[0] = a.tl.norm_weight[wave][lane], g[1] = a.tl.norm_weight[wave][64 + lane];
-      bt[0] = a.tl.norm_bias[wave][lane], bt[1] = a.tl.norm_bias[wave][64 + lane];
-      ln_planes(xs, Pl[wave], lane, a.tl.norm_eps[wave], g, bt);
-    }
-    if (col0) put4(Ph, LO128, c_out, *(const f32x4*)(xs + c_out));  // (the predictor reads x itself; this lane wrote these 4 channels)
-    __syncthreads();
-    const int64_t kv_row = (int64_t)row * a.tl.ld_kv;
-#define TBX_MF_TLKV(N)                                                                                    \
-  do {                                                                                                    \
-    issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane);                                              \
-    const W& w = wb[(N) % 3];                                                                             \
-    const f32x4 y = gemv4(w, Pl[((N) - 14) >> 1], LO128, 0, g4) + w.bias;                                 \
-    if (col0) {                                                                                           \
-      const int64_t o = kv_row + (((N) - 14) >> 1) * 2 * D + (((N) - 14) & 1) * D + c_out;                \
-      if (a.tl.kv_bf16) {                                                                                 \
-        const bf16x4 h16 = __builtin_convertvector(y, bf16x4);                                            \
-        *(TBX_GLOBAL u32x2*)((uint16_t*)a.tl.kv_out + o) = __builtin_bit_cast(u32x2, h16);                \
-      } else {                                                                                            \
-        *(TBX_GLOBAL f32x4*)((float*)a.tl.kv_out + o) = y;                                                \
-      }                                                                                                   \
-    }                                                                                                     \
-  } while (0)
-    TBX_MF_TLKV(14);
-    TBX_MF_TLKV(15);
-    TBX_MF_TLKV(16);
-    TBX_MF_TLKV(17);
-    TBX_MF_TLKV(18);
-    TBX_MF_TLKV(19);
-    TBX_MF_TLKV(20);
-    TBX_MF_TLKV(21);
-#undef TBX_MF_TLKV
-    {  // 22, 23: the predictor's hidden layers (Ph -> Pq -> Ph)
-      issue<24>(wb[24 % 3], a, heads, wave, lane);
-      const W& w = wb[22 % 3];
-      const f32x4 h1 = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);
-      if (col0) put4(Pq, LO128, c_out, h1);
-    }
-    __syncthreads();
-    {
-      const W& w = wb[23 % 3];
-      const f32x4 h2 = tbx_tile::relu4(gemv4(w, Pq, LO128, 0, g4) + w.bias);
-      if (col0) put4(Ph, LO128, c_out, h2);
-    }
-    __syncthreads();
-    if (wave == 0) {  // 24: n_state <= 16 logits (zero-padded tile 0): masked, clamped
-      const W& w = wb[24 % 3];
-      const f32x4 o = gemv4(w, Ph, LO128, 0, g4) + w.bias;
-      const bool bad = a.tl.tl_invalid[row] != 0;
-      if (col0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 4 * g4 + r;
-          if (c < a.tl.n_state) a.tl.logits_out[(int64_t)row * a.tl.n_state + c] = fminf(fmaxf(bad ? 0.f : o[r], a.tl.clamp_lo), a.tl.clamp_hi);
-        }
-      }
-    }
-    return;
-  }
-  if (!heads) return;
-  // ================================================================ the agents' heads (traffic_bots.py:206-221; csrc/tile_heads.hip's
-  // stages on one row): Pv = [x | navi_emb | latent_emb] planes, the adders' hidden rows in Ph / Pq, the action head's in Pu / Pv
-  if (threadIdx.x < 64) {
-    const int c = ((int)threadIdx.x & 31) * 4;
-    const float* src = threadIdx.x < 32 ? a.navi_emb : a.latent_emb;
-    put4(Pv, LO384, (threadIdx.x < 32 ? D : 2 * D) + c, *(const TBX_GLOBAL f32x4*)(src + (int64_t)row * D + c));
-  }
-  if (col0) put4(Pv, LO384, c_out, *(const f32x4*)(xs + c_out));  // (this lane's own 4 channels of x, written above)
-  const bool ok_navi = a.navi_valid[row] != 0, ok_lat = a.latent_invalid[row] == 0;
-  // the action head's branches this agent's type masks let through (action_head.py:64-100: one per agent type - an agent has one type,
-  // an invalid agent none): only those are computed, each 3 weight units instead of all three branches' 7
-  int act = 0;
-#pragma unroll
-  for (int g = 0; g < 3; ++g) act |= (a.type_mask[(int64_t)g * a.mask_stride + row] == 0 ? 1 : 0) << g;
-  act = __builtin_amdgcn_readfirstlane(act);
-  const int br0 = act ? __builtin_ctz((unsigned)act) : -1;
-  __syncthreads();
-#define TBX_MF_ADDER(N, ZSTEP, OK)                                                                    \
-  do {                                                                                                \
-    {                                                                                                 \
-      Acc acc;                                                                                        \
-      acc.zero();                                                                                     \
-      issue<(N) + 2>(wb[((N) + 2) % 3], a, heads, wave, lane, br0);                                        \
-      const W& w0 = wb[(N) % 3];                                                                      \
-      const f32x4 bias = w0.bias;                                                                     \
-      _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w0.hi[st], w0.lo[st], Pv, LO384, st, g4); \
-      issue<(N) + 3>(wb[((N) + 3) % 3], a, heads, wave, lane, br0);                                        \
-      const W& w1 = wb[((N) + 1) % 3];                                                                \
-      _Pragma("unroll") for (int st = 0; st < 4; ++st) step(acc, w1.hi[st], w1.lo[st], Pv, LO384, (ZSTEP) + st, g4); \
-      if (col0) put4(Ph, LO128, c_out, tbx_tile::relu4(acc.sum() + bias));                            \
-    }                                                                                                 \
-    __syncthreads();                                                                                  \
-    {                                                                                                 \
-      issue<(N) + 4>(wb[((N) + 4) % 3], a, heads, wave, lane, br0);                                        \
-      const W& w = wb[((N) + 2) % 3];                                                                 \
-      const f32x4 hdn = tbx_tile::relu4(gemv4(w, Ph, LO128, 0, g4) + w.bias);                         \
-      if (col0) put4(Pq, LO128, c_out, hdn);                                                          \
-    }                                                                                                 \
-    __syncthreads();                                                                                  \
-    {                                                                                                 \
-      issue<(N) + 5>(wb[((N) + 5) % 3], a, heads, wave, lane, br0);                                        \
-      const W& w = wb[((N) + 3) % 3];                                                                 \
-      const f32x4 upd = tbx_tile::relu4(gemv4(w, Pq, LO128, 0, g4) + w.bias);                         \
-      if (col0) {                                                                                     \
-        f32x4 xv = *(const f32x4*)(xs + c_out);                                                       \
-        if (OK) xv += upd;                                                                            \
-        *(f32x4*)(xs + c_out) = xv;                                                                   \
-        put4(Pv, LO384, c_out, xv);                                                                   \
-      }                                                                                               \
-    }                                                                                                 \
-    __syncthreads();                                                                                  \
-  } while (0)
-  TBX_MF_ADDER(14, 4, ok_navi);
-  TBX_MF_ADDER(18, 8, ok_lat);
-#undef TBX_MF_ADDER
-  // ---- action head, branch by branch in branch order (unit slots 22 / 23 / 24 mod 3 for its layers 1 / 2 / 3): 128 -> 128 relu (x
-  // planes in Pv -> Pu[br * 128 ..]), 128 -> 128 relu (-> Ph), 128 -> 2 of 16 zero-padded outputs (wave 0)
-  for (int br = br0; br >= 0;) {
-    int nx = -1;  // the next branch let through (none for a one-hot type)
-    for (int g = 2; g > br; --g)
-      if ((act >> g) & 1) nx = g;
-    {
-      issue<24>(wb[24 % 3], a, heads, wave, lane, br);
-      const W& w = wb[22 % 3];
-      const f32x4 u = tbx_tile::relu4(gemv4(w, Pv, LO384, 0, g4) + w.bias);
-      if (col0) put4(Pu, LO512, br * D + c_out, u);
-    }
-    __syncthreads();
-    {
-      issue<22>(wb[22 % 3], a, heads, wave, lane, nx);
-      const W& w = wb[23 % 3];
-      const f32x4 u = tbx_tile::relu4(gemv4(w, Pu, LO512, 4 * br, g4) + w.bias);
-      if (col0) put4(Ph, LO128, c_out, u);
-    }
-    __syncthreads();
-    issue<23>(wb[23 % 3], a, heads, wave, lane, nx);
-    if (wave == 0) {
-      const W& w = wb[24 % 3];
-      const f32x4 o = gemv4(w, Ph, LO128, 0, g4) + w.bias;
-      if (lane == 0) head_o[br * 2] = o[0], head_o[br * 2 + 1] = o[1];
-    }
-    __syncthreads();
-    br = nx;
-  }
-  if (threadIdx.x < 2) {  // the masked sum over the branches, in branch order from 0
-    float v = 0.f;
-    for (int g = 0; g < 3; ++g)
-      if ((act >> g) & 1) v += head_o[g * 2 + threadIdx.x];
-    a.action_out[(int64_t)row * 2 + threadIdx.x] = v;
-  }
-  MID_CLK(14);
-  if (a.fused_tail) {
-    const int t_step = __builtin_amdgcn_readfirstlane(t_step_v);
-    // ============================================================== the step's tail for this row's agent (csrc/step_core.h): its
-    // tbx_sim_step (dynamics, rule checks, overrides, log, window append: 32 lanes) on the action just written, then the NEXT
-    // step's tbx_agent_prep of its new window (4 waves) - neither reads anything of another agent's
-    __syncthreads();  // the action is in memory (workgroup scope)
-    if (wave == 0 && lane < tbx_step::LPA) tbx_step::sim_agent(a.sim, a.sim_parts, t_step, row, lane, 0);
-    if (a.sim_parts & TBX_SIM_ADVANCE) tbx_step::sim_advance(a.sim, t_step, gridDim.x);
-    __syncthreads();  // the appended window is
-    MID_CLK(15);
-    tbx_step::agent_prep(a.prep, row, (int)threadIdx.x, 512);
-    __syncthreads();
-    MID_CLK(0);  // (profiling build: the launch's end overwrites its first stamp - tools/mid_clock.py reads the tail from 13 -> 14 -> 15 -> 0)
-  }
-}
+#define TBX_MF_NS mf
+#define TBX_MF_KERNEL dec_layer_mf_kernel
+#define TBX_MF_SINGLE 0
+#include "dec_layer_mf.inc"
+#undef TBX_MF_NS
+#undef TBX_MF_KERNEL
+#undef TBX_MF_SINGLE
+#define TBX_MF_NS mf1
+#define TBX_MF_KERNEL dec_layer_mf1_kernel
+#define TBX_MF_SINGLE 1
+#include "dec_layer_mf.inc"
+#undef TBX_MF_NS
+#undef TBX_MF_KERNEL
+#undef TBX_MF_SINGLE
 
 int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
   if (!s.kv || !s.idx || !s.invalid || (!s.emb && !s.rel_pose) || s.k <= 0 || s.n_tgt <= 0 || s.batch_div <= 0) return TBX_ERR_ARG;
@@ -1311,7 +654,12 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   a.tail_mfma = t ? t->tail_mfma32 : 0;
   bool rel = p->self_seg.emb == nullptr;
   for (int i = 0; i < p->n_cross; ++i) rel = rel && p->cross_seg[i].emb == nullptr;
-  if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0) {
+  if (t && a.tail_mfma == 2 && p->self_seg.kv_bf16 != 0) {  // one bf16 product per LINEAR (bf16 tables only: the bf16-arithmetic schedule)
+    if (rel) hipLaunchKernelGGL((dec_layer_mf1_kernel<true, true>), dim3(a.n_rows), dim3(512), 0, hs, a);
+    else hipLaunchKernelGGL((dec_layer_mf1_kernel<true, false>), dim3(a.n_rows), dim3(512), 0, hs, a);
+  } else if (t && a.tail_mfma == 2) {
+    return TBX_ERR_UNSUPPORTED;
+  } else if (t && a.tail_mfma && p->self_seg.kv_bf16 != 0) {
     if (rel) hipLaunchKernelGGL((dec_layer_mf_kernel<true, true>), dim3(a.n_rows), dim3(512), 0, hs, a);
     else hipLaunchKernelGGL((dec_layer_mf_kernel<true, false>), dim3(a.n_rows), dim3(512), 0, hs, a);
   } else if (t && a.tail_mfma) {

@@ -107,6 +107,8 @@ class Schedule:
     # (tbx_knarpe_attn_fwd_mfma, csrc/attn_mfma.hip): bf16 operands with fp32 accumulation - part of the bf16-ARITHMETIC schedule
     # (Schedule.reduced(); tests/test_hip_attn_mfma.py). False: the fp32 VALU kernel
     attn_mfma: bool = False
+    linear_bf16: bool = False       # the one-launch decoder layer's LINEAR stages as ONE bf16 product (tail_mfma32 = 2; with kv_bf16 only): weights
+                                    # and activations rounded to bfloat16 - half the weight bytes a stage streams through its CU's L2 port
     attn_mfma_min_rows: int = 193   # ... from this many source rows (= where the wave-per-row forms start; 4 scenes of 64 agents: 0.318 ->
     # 0.264 ms per step, 8 scenes: 0.336 -> 0.286 against a 1024-row threshold, gpurun_out/r04_mfma_rows_*.txt)
 
@@ -153,6 +155,7 @@ class Schedule:
             share_lights=on("TBX_SHARE_LIGHTS"),
             hoist_constants=os.environ.get("TBX_NO_HOIST") is None,
             attn_mfma=off("TBX_ATTN_MFMA"),
+            linear_bf16=off("TBX_LINEAR_BF16"),
             attn_mfma_min_rows=num("TBX_ATTN_MFMA_MIN_ROWS", 193),
         )
 
@@ -161,10 +164,14 @@ class Schedule:
 
     def reduced(self) -> "Schedule":
         """The bf16-ARITHMETIC schedule (BASELINE configs[1] says bf16; the reference runs at precision 16,
-        configs/trainer/default.yaml:16): bfloat16 K/V tables and, on launches of >= 193 source rows, the attention with bf16
-        operands on the matrix cores (fp32 accumulation and softmax). K-nearest searches, dynamics and every LINEAR stage keep
-        their fp32-class arithmetic. Tolerances: tests/test_hip_attn_mfma.py (one call), tests/test_hip_bf16.py (closed loop)."""
-        return self.replace(kv_bf16=True, attn_mfma=True)
+        configs/trainer/default.yaml:16): bfloat16 K/V tables; on launches of >= 193 source rows the attention with bf16 operands on
+        the matrix cores (fp32 accumulation and softmax); in the one-launch decoder layer (launches of <= 256 rows: the closed loop at
+        one or a few scenes) every LINEAR as ONE bf16 product (weights and activations rounded to bfloat16, fp32 accumulation) - as
+        torch's autocast(bfloat16) would run them. K-nearest searches, dynamics, LayerNorms and the tile kernels' LINEAR stages
+        (no faster with one product: profiles/MEASUREMENT_LOG.md) keep their fp32-class arithmetic. Tolerances:
+        tests/test_hip_attn_mfma.py (one call), tests/test_hip_bf16.py (closed loop, teacher-forced + 6 free steps),
+        tests/test_hip_rollout.py (90-step free loop: ADE / FDE / flags)."""
+        return self.replace(kv_bf16=True, attn_mfma=True, linear_bf16=True)
 
 
 DEFAULT = Schedule.from_env()
@@ -601,7 +608,8 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             tl_ = dict(out_proj2=hip.packed_weight(a2.out_proj_weight, a2.out_proj_bias, **tkw),
                        linear1=hip.packed_weight(layer.linear1.weight, layer.linear1.bias, **tkw),
                        linear2=hip.packed_weight(layer.linear2.weight, layer.linear2.bias, **tkw),
-                       norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid, mfma32=tmf)
+                       norm2=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), src_invalid=src_invalid,
+                       mfma32=(2 if (tmf and current().linear_bf16 and kv16 is not None) else tmf))
             if last and heads_tail is not None and current().heads_tail:
                 tl_["heads"] = heads_tail  # the agents' heads in this launch too (tbx_heads_tail_t)
                 heads_done = True

@@ -428,7 +428,7 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     n2 = tail["norm2"]
     t.norm2_weight, t.norm2_bias, t.norm2_eps = _ptr(n2[0], torch.float32), _ptr(n2[1], torch.float32), float(n2[2])
     t.src_invalid = _cptr(tail["src_invalid"], torch.uint8)
-    t.tail_mfma32 = int(bool(tail.get("mfma32")))
+    t.tail_mfma32 = int(tail.get("mfma32") or 0)  # (1: three bf16 products per fp32 product; 2: one - Schedule.linear_bf16)
     qo = tail.get("qkv_out")
     if qo is not None:
         n3 = tail["next_norm"]
