@@ -11,7 +11,7 @@ if [ -z "${SKIP_TESTS:-}" ]; then timeout 1500 python -m pytest tests -m gpu -q 
 bash tools/profile_round.sh ${tag}_c2 64 1024 128 1 1
 bash tools/profile_round.sh ${tag}_c5 128 1024 128 1 32 --steps 40
 bash tools/profile_round.sh ${tag}_c5_bf16 128 1024 128 1 32 --steps 40 --kv-bf16 --attn-mfma 1  # (Schedule.reduced(): bf16 tables + matrix-core attention)
-bash tools/profile_round.sh ${tag}_c2_bf16 64 1024 128 1 1 --kv-bf16
+bash tools/profile_round.sh ${tag}_c2_bf16 64 1024 128 1 1 --kv-bf16 --attn-mfma 1  # (Schedule.reduced() at configs[1]: bf16 tables + one bf16 product per LINEAR of the one-launch layer)
 TAG=${tag}_valu bash tools/pmc_attn.sh
 TAG=${tag}_mfma KPAT=%knarpe_attn_mfma_kernel% MINGRID=65536 EXTRA="--kv-bf16 --attn-mfma 1" bash tools/pmc_attn.sh
 # one steady-state step of the default two-stream graph replay, kernel by kernel

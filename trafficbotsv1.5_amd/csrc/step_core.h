@@ -24,74 +24,105 @@ __device__ __forceinline__ float sim_sl1(float d) {  // F.smooth_l1_loss, beta =
 // Shape of the body: EVERY load first (one round trip to memory - two for the type's limits - instead of one per section: with the
 // log's stores between the sections the compiler may not move a later section's loads above them, and in the tail of the last
 // decoder layer's launch each round trip is ~0.8 us of the step's critical path), then the arithmetic, then every store.
-__device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int sub, const int half_shift) {
-  const int T = s.n_step_out;
+// Everything sim_agent reads EXCEPT the step's action, as a value: a caller that produces the action itself (the last decoder layer's
+// launch, csrc/dec_layer_mf.inc) requests these a few stages before its heads finish - the loads (two dependent round trips: the
+// agent's type, then that type's limits) then fly under the heads instead of behind them.
+struct SimLoads {
+  bool valid0, player, outside0, reached0, disabled0, d_ok, gt_v, tf_gt, tf_ov;
+  int ty;
+  uint8_t kind, h_v;
+  float px, py, pyaw, spd, bd0, bd1, bd2, bd3, thresh, d_px, d_py, d_dx, d_dy, g_px, g_py, g_yaw, g_spd, g_acc, g_yr;
+  float o_px, o_py, o_yaw, o_spd, o_acc, o_yr, h_p0, h_p1, h_p2, h_m0, h_m1, h_m2, lim_acc, lim_yr, pl0, pl1;
+};
+
+__device__ __forceinline__ SimLoads sim_loads(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int sub) {
+  SimLoads L;
   const int W = s.window;
   const int b = i / s.n_ag;
-  // ---------------------------------------------------------------- loads
-  const bool valid0 = s.ag_valid[i] != 0;
-  const int ty = s.ag_type_idx[i];
-  const float px = s.ag_pose[i * 3], py = s.ag_pose[i * 3 + 1], pyaw = s.ag_pose[i * 3 + 2];
-  const float spd = s.ag_motion[i * 3];
-  const float am0 = s.action_mean[i * 2], am1 = s.action_mean[i * 2 + 1];
-  const bool player = s.player_valid != nullptr && s.player_valid[i] != 0;
+  L.valid0 = s.ag_valid[i] != 0;
+  L.ty = s.ag_type_idx[i];
+  L.px = s.ag_pose[i * 3], L.py = s.ag_pose[i * 3 + 1], L.pyaw = s.ag_pose[i * 3 + 2];
+  L.spd = s.ag_motion[i * 3];
+  L.player = s.player_valid != nullptr && s.player_valid[i] != 0;
   const float* bd = s.boundary + b * 4;
-  const float bd0 = bd[0], bd1 = bd[1], bd2 = bd[2], bd3 = bd[3];
-  const bool outside0 = s.outside_map[i] != 0;
-  const float thresh = s.dest_thresh[i];
-  const uint8_t kind = s.dest_kind[i];
-  const bool reached0 = s.dest_reached[i] != 0;
-  const bool disabled0 = s.ag_disabled[i] != 0;
+  L.bd0 = bd[0], L.bd1 = bd[1], L.bd2 = bd[2], L.bd3 = bd[3];
+  L.outside0 = s.outside_map[i] != 0;
+  L.thresh = s.dest_thresh[i];
+  L.kind = s.dest_kind[i];
+  L.reached0 = s.dest_reached[i] != 0;
+  L.disabled0 = s.ag_disabled[i] != 0;
   // the destination polyline's first 32 nodes (n_node = 20 by default: all of them)
-  bool d_ok = false;
-  float d_px = 0.f, d_py = 0.f, d_dx = 0.f, d_dy = 0.f;
+  L.d_ok = false;
+  L.d_px = L.d_py = L.d_dx = L.d_dy = 0.f;
   if (sub < s.n_node) {
     const int64_t d = (int64_t)i * s.n_node + sub;
-    d_ok = s.dest_invalid[d] == 0;
-    d_px = s.dest_pos[d * 2], d_py = s.dest_pos[d * 2 + 1];
-    d_dx = s.dest_dir[d * 2], d_dy = s.dest_dir[d * 2 + 1];
+    L.d_ok = s.dest_invalid[d] == 0;
+    L.d_px = s.dest_pos[d * 2], L.d_py = s.dest_pos[d * 2 + 1];
+    L.d_dx = s.dest_dir[d * 2], L.d_dy = s.dest_dir[d * 2 + 1];
   }
   const bool has_gt = t < s.n_step_gt;
   const int64_t g = (int64_t)i * s.n_step_gt + t;
-  bool gt_v = false, tf_gt = false;
-  float g_px = 0.f, g_py = 0.f, g_yaw = 0.f, g_spd = 0.f, g_acc = 0.f, g_yr = 0.f;
+  L.gt_v = L.tf_gt = false;
+  L.g_px = L.g_py = L.g_yaw = L.g_spd = L.g_acc = L.g_yr = 0.f;
   if (has_gt) {
-    gt_v = s.gt_valid[g] != 0;
-    if (s.ov_valid == nullptr) tf_gt = s.tf_mask[g] != 0;
-    g_px = s.gt_pose[g * 3], g_py = s.gt_pose[g * 3 + 1], g_yaw = s.gt_pose[g * 3 + 2];
-    g_spd = s.gt_motion[g * 3], g_acc = s.gt_motion[g * 3 + 1], g_yr = s.gt_motion[g * 3 + 2];
+    L.gt_v = s.gt_valid[g] != 0;
+    if (s.ov_valid == nullptr) L.tf_gt = s.tf_mask[g] != 0;
+    L.g_px = s.gt_pose[g * 3], L.g_py = s.gt_pose[g * 3 + 1], L.g_yaw = s.gt_pose[g * 3 + 2];
+    L.g_spd = s.gt_motion[g * 3], L.g_acc = s.gt_motion[g * 3 + 1], L.g_yr = s.gt_motion[g * 3 + 2];
   }
-  bool tf_ov = false;
-  float o_px = 0.f, o_py = 0.f, o_yaw = 0.f, o_spd = 0.f, o_acc = 0.f, o_yr = 0.f;
+  L.tf_ov = false;
+  L.o_px = L.o_py = L.o_yaw = L.o_spd = L.o_acc = L.o_yr = 0.f;
   if (s.ov_valid != nullptr) {  // the step's ag_override handed over explicitly (WaymoMotion.forward)
-    tf_ov = s.ov_valid[i] != 0;
-    o_px = s.ov_pose[i * 3], o_py = s.ov_pose[i * 3 + 1], o_yaw = s.ov_pose[i * 3 + 2];
-    o_spd = s.ov_motion[i * 3], o_acc = s.ov_motion[i * 3 + 1], o_yr = s.ov_motion[i * 3 + 2];
+    L.tf_ov = s.ov_valid[i] != 0;
+    L.o_px = s.ov_pose[i * 3], L.o_py = s.ov_pose[i * 3 + 1], L.o_yaw = s.ov_pose[i * 3 + 2];
+    L.o_spd = s.ov_motion[i * 3], L.o_acc = s.ov_motion[i * 3 + 1], L.o_yr = s.ov_motion[i * 3 + 2];
   }
   // TrafficBots._append_hist (traffic_bots.py:123-143): slide the window, append the state the next step will see. Lane w
   // moves entry w + 1 to w (first chunk of 32 loaded here; W - 1 <= 32 by default: all of it)
+  const uint8_t* hv = s.hist_valid + (int64_t)i * W;
+  const float* hp = s.hist_pose + (int64_t)i * W * 3;
+  const float* hm = s.hist_motion + (int64_t)i * W * 3;
+  const bool mv0 = (parts & TBX_SIM_NO_APPEND) == 0 && sub < W - 1;
+  L.h_v = 0;
+  L.h_p0 = L.h_p1 = L.h_p2 = L.h_m0 = L.h_m1 = L.h_m2 = 0.f;
+  if (mv0) {
+    L.h_v = hv[sub + 1];
+    L.h_p0 = hp[(sub + 1) * 3], L.h_p1 = hp[(sub + 1) * 3 + 1], L.h_p2 = hp[(sub + 1) * 3 + 2];
+    L.h_m0 = hm[(sub + 1) * 3], L.h_m1 = hm[(sub + 1) * 3 + 1], L.h_m2 = hm[(sub + 1) * 3 + 2];
+  }
+  L.pl0 = L.pl1 = 0.f;
+  if (L.player) L.pl0 = s.player_action[i * 2], L.pl1 = s.player_action[i * 2 + 1];  // player-controlled agent (dynamics.py:104-107)
+  L.lim_acc = s.max_acc[L.ty], L.lim_yr = s.max_yaw_rate[L.ty];
+  return L;
+}
+
+// One closed-loop step of agent i by 32 lanes (`sub` = 0..31; half_shift = 0 / 32: which half of the wavefront's ballot is theirs),
+// t = *s.step read by the caller, on loads `Ld` (sim_loads) and the action (am0, am1).
+__device__ __forceinline__ void sim_agent_on(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int sub, const int half_shift,
+                                             const SimLoads& Ld, const float am0, const float am1) {
+  const int T = s.n_step_out;
+  const int W = s.window;
+  const bool valid0 = Ld.valid0, player = Ld.player, outside0 = Ld.outside0, reached0 = Ld.reached0, disabled0 = Ld.disabled0, d_ok = Ld.d_ok;
+  const bool gt_v = Ld.gt_v, tf_gt = Ld.tf_gt, tf_ov = Ld.tf_ov;
+  const uint8_t kind = Ld.kind, h_v = Ld.h_v;
+  const float px = Ld.px, py = Ld.py, pyaw = Ld.pyaw, spd = Ld.spd, bd0 = Ld.bd0, bd1 = Ld.bd1, bd2 = Ld.bd2, bd3 = Ld.bd3, thresh = Ld.thresh;
+  const float d_px = Ld.d_px, d_py = Ld.d_py, d_dx = Ld.d_dx, d_dy = Ld.d_dy;
+  const float g_px = Ld.g_px, g_py = Ld.g_py, g_yaw = Ld.g_yaw, g_spd = Ld.g_spd, g_acc = Ld.g_acc, g_yr = Ld.g_yr;
+  const float o_px = Ld.o_px, o_py = Ld.o_py, o_yaw = Ld.o_yaw, o_spd = Ld.o_spd, o_acc = Ld.o_acc, o_yr = Ld.o_yr;
+  const float h_p0 = Ld.h_p0, h_p1 = Ld.h_p1, h_p2 = Ld.h_p2, h_m0 = Ld.h_m0, h_m1 = Ld.h_m1, h_m2 = Ld.h_m2;
+  const float lim_acc = Ld.lim_acc, lim_yr = Ld.lim_yr;
+  const bool has_gt = t < s.n_step_gt;
   uint8_t* hv = s.hist_valid + (int64_t)i * W;
   float* hp = s.hist_pose + (int64_t)i * W * 3;
   float* hm = s.hist_motion + (int64_t)i * W * 3;
   const bool append = (parts & TBX_SIM_NO_APPEND) == 0;
   const bool mv0 = append && sub < W - 1;
-  uint8_t h_v = 0;
-  float h_p0 = 0.f, h_p1 = 0.f, h_p2 = 0.f, h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f;
-  if (mv0) {
-    h_v = hv[sub + 1];
-    h_p0 = hp[(sub + 1) * 3], h_p1 = hp[(sub + 1) * 3 + 1], h_p2 = hp[(sub + 1) * 3 + 2];
-    h_m0 = hm[(sub + 1) * 3], h_m1 = hm[(sub + 1) * 3 + 1], h_m2 = hm[(sub + 1) * 3 + 2];
-  }
-  const float lim_acc = s.max_acc[ty], lim_yr = s.max_yaw_rate[ty];
   // ---------------------------------------------------------------- Dynamics.update_ag + MultiPathPP (dynamics.py:84-120,237-274)
   float acc = 0.f, yr = 0.f;
   if (valid0) {
     acc = tanhf(am0) * lim_acc;
     yr = tanhf(am1) * lim_yr;
-    if (player) {  // player-controlled agent (dynamics.py:104-107)
-      acc = s.player_action[i * 2];
-      yr = s.player_action[i * 2 + 1];
-    }
+    if (player) acc = Ld.pl0, yr = Ld.pl1;  // player-controlled agent (dynamics.py:104-107)
   }
   const float half_dt = 0.5f * s.dt;
   const float v_t = spd + half_dt * acc;
@@ -224,6 +255,13 @@ __device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int pa
     hm[(W - 1) * 3 + 1] = nacc;
     hm[(W - 1) * 3 + 2] = nyr;
   }
+}
+
+// ... with its own loads and the action from memory (s.action_mean): the stand-alone kernel's form
+__device__ __forceinline__ void sim_agent(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int sub, const int half_shift) {
+  const float am0 = s.action_mean[i * 2], am1 = s.action_mean[i * 2 + 1];
+  const SimLoads Ld = sim_loads(s, parts, t, i, sub);
+  sim_agent_on(s, parts, t, i, sub, half_shift, Ld, am0, am1);
 }
 
 // TBX_SIM_ADVANCE next to a part: every thread of this workgroup has read *step; the last of the n_wg workgroups to arrive advances it
