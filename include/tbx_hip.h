@@ -297,6 +297,9 @@ typedef struct tbx_layer_tile {
   int64_t rider_rows;
 } tbx_layer_tile_t;
 int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
+/* The same launch with ONE bf16 product per LINEAR stage (the bf16-arithmetic schedule): weights and activations rounded to bfloat16
+ * (2^-9 relative per operand), fp32 accumulation; the same images (their lo halves are not read). Inference only (no dropout sites). */
+int tbx_layer_tile_bf16(const tbx_layer_tile_t* args /* host */, void* stream);
 /* tbx_heads_tile: the agents' heads (traffic_bots.py:206-221) for large launches, same arithmetic class as tbx_layer_tile:
  * x' = x + (navi_valid ? add_navi.mlp([x | navi_emb]) : 0); x'' = x' + (latent_invalid ? 0 : add_latent.mlp([x' | latent_emb]));
  * action_out [n_rows, 2] = sum over the branches g with type_mask[g, row] == 0 of branch_g(x'') (action_head.py:74-100). x is not
@@ -328,6 +331,9 @@ typedef struct tbx_heads_tile {
   int32_t drop_site[12], drop_step, ld_z;
 } tbx_heads_tile_t;
 int tbx_heads_tile(const tbx_heads_tile_t* args /* host */, void* stream);
+/* The same launch with ONE bf16 product per LINEAR stage (the bf16-arithmetic schedule): weights and activations rounded to bfloat16
+ * (2^-9 relative per operand), fp32 accumulation; the same images (their lo halves are not read). Inference only (no dropout sites). */
+int tbx_heads_tile_bf16(const tbx_heads_tile_t* args /* host */, void* stream);
 
 /* tbx_window_tile: the temporal PointNet of the agents' windows for large launches (agent_encoder.py:130-159: input encoder in
  * "cat" mode; polyline_encoder.py:49-61; pooling.py:18-19,38): per row f = [mlp(attr) | pe], three layers of
@@ -356,6 +362,9 @@ typedef struct tbx_window_tile {
   int32_t drop_site[3], drop_step;
 } tbx_window_tile_t;
 int tbx_window_tile(const tbx_window_tile_t* args /* host */, void* stream);
+/* The same launch with ONE bf16 product per LINEAR stage (the bf16-arithmetic schedule): weights and activations rounded to bfloat16
+ * (2^-9 relative per operand), fp32 accumulation; the same images (their lo halves are not read). Inference only (no dropout sites). */
+int tbx_window_tile_bf16(const tbx_window_tile_t* args /* host */, void* stream);
 /* tbx_front: everything between the feature preparation and a block's first decoder layer as ONE launch (small launches: the
  * closed loop at a few scenes), instead of tbx_window_tile -> tbx_knn_embed_multi_pe -> tbx_layer_tile one after the other:
  *   win    the block's window PointNet (tbx_window_tile's arguments; no dropout);

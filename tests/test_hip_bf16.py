@@ -142,10 +142,11 @@ def test_bf16_closed_loop_gathers_the_rows_the_fp32_path_gathers(tb, sizes, knn)
 
 def test_reduced_schedule_joint_futures_vs_fp32(tb):
     """Schedule.reduced() - bf16 tables + the matrix-core attention with bf16 operands (tbx_knarpe_attn_fwd_mfma; active from 193
-    source rows: here 16 joint futures x 64 agents) - against the fp32 schedule on the same scene, latents and destinations:
+    source rows: here 16 joint futures x 64 agents) + one bf16 product per LINEAR (the tile kernels' *_bf16 entry points for the
+    agents' 1024 rows, tail_mfma32 = 2 for the lights' 128) - against the fp32 schedule on the same scene, latents and destinations:
     over the 10 teacher-forced warm-start steps the K-nearest sets are bit-identical (the searches are fp32 and read no table) and
     the action means stay within 3e-2 of the fp32 ones (bf16 operands: 2^-9 relative on q, k, v, e and the softmax weights);
-    over 6 further free steps poses stay within 0.1 m / 0.05 rad of the fp32 rollout's; light states are identical."""
+    over 6 further free steps poses stay within 0.15 m / 0.1 rad of the fp32 rollout's; light states are identical."""
     dev = torch.device(DEV)
     E = import_module("trafficbots_amd.engine")
     D = import_module("trafficbots_amd.models.modules.distributions")
@@ -188,5 +189,5 @@ def test_reduced_schedule_joint_futures_vs_fp32(tb):
     assert float((act_a[..., :10, :] - act_r[..., :10, :]).abs().max()) <= 3e-2 * max(scale, 1.0)
     assert not torch.equal(act_a[..., :10, :], act_r[..., :10, :])
     dpose = (a.pred_pose - r.pred_pose).abs()
-    assert float(dpose[..., :10, :].max()) <= 1e-2          # teacher-forced steps: the prediction before the override
-    assert float(dpose[..., :2].max()) <= 0.1 and float(dpose[..., 2].max()) <= 0.05
+    assert float(dpose[..., :10, :].max()) <= 2e-2          # teacher-forced steps: the prediction before the override (measured 1.1e-2)
+    assert float(dpose[..., :2].max()) <= 0.15 and float(dpose[..., 2].max()) <= 0.1  # (measured 0.078 m / 0.076 rad)

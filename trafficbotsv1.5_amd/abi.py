@@ -247,6 +247,9 @@ def load():
     lib.tbx_layer_tile.argtypes = [C.POINTER(LayerTile), vp]
     lib.tbx_heads_tile.argtypes = [C.POINTER(HeadsTile), vp]
     lib.tbx_window_tile.argtypes = [C.POINTER(WindowTile), vp]
+    lib.tbx_layer_tile_bf16.argtypes = [C.POINTER(LayerTile), vp]
+    lib.tbx_heads_tile_bf16.argtypes = [C.POINTER(HeadsTile), vp]
+    lib.tbx_window_tile_bf16.argtypes = [C.POINTER(WindowTile), vp]
     lib.tbx_front.argtypes = [C.POINTER(Front), vp]
     lib.tbx_tall_linear.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp]
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
@@ -272,5 +275,9 @@ def load():
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")
+    # (an entry point without argtypes would get 64-bit handles - stream pointers under graph capture - as C ints)
+    untyped = [s for s in declared_symbols() if getattr(lib, s).argtypes is None and s not in ("tbx_error_string", "tbx_version")]
+    if untyped:
+        raise ImportError(f"abi.load(): no argtypes for {untyped}")
     _lib = lib
     return lib

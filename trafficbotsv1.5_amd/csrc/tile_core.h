@@ -7,6 +7,19 @@
 #include "../../include/tbx_hip.h"
 #include "tbx_common.h"
 
+// TBX_TILE_SINGLE (tile_layer / tile_heads / tile_window are compiled a second time with it: the *_bf16 entry points,
+// Schedule.linear_bf16): ONE bf16 product per LINEAR - weights and activations rounded to bfloat16, fp32 accumulation; the lo halves of
+// the weight units are not fetched (a unit's 8 KiB per wave go through the CU's 64 B/clk L1 port whether they hit or not) and no lo
+// planes are written or read.
+#ifndef TBX_TILE_SINGLE
+#define TBX_TILE_SINGLE 0
+#endif
+#if TBX_TILE_SINGLE
+#define TBX_TILE_ENTRY(name) name##_bf16
+#else
+#define TBX_TILE_ENTRY(name) name
+#endif
+
 namespace tbx_tile {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -59,7 +72,9 @@ __device__ __forceinline__ void load_unit(W& w, const float* img, int unit, int 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + lane * 4);
+#if !TBX_TILE_SINGLE
     w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256 + lane * 4);
+#endif
   }
   w.bias = *(const TBX_GLOBAL f32x4*)(base + 2048 + (lane >> 4) * 4);
 }
@@ -80,6 +95,10 @@ struct Acc {
 template <int PLANE>
 __device__ __forceinline__ void mfma_step(Acc& a, const bf16x8 whi, const bf16x8 wlo, const char* act_hi, int step) {
   const bf16x8 xh = *(const bf16x8*)(act_hi + step * 16);
+#if TBX_TILE_SINGLE
+  a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
+  return;
+#endif
   const bf16x8 xl = *(const bf16x8*)(act_hi + PLANE + step * 16);
 #ifdef TBX_ABL_NOMFMA  // (ablation builds: one product instead of three)
   a.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, a.hh, 0, 0, 0);
@@ -104,11 +123,15 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 // 4 consecutive channels [c, c + 4) (c % 4 == 0) of plane row `row` into a plane pair (hi at p, lo at p + PLANE)
 template <class PL>
 __device__ __forceinline__ void planes_write4(char* p, int row, int c, const f32x4 v) {
+  const int o = PL::off(row, c);
+#if TBX_TILE_SINGLE
+  *(u32x2*)(p + o) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+#else
   u32x2 hi, lo;
   split4(v, hi, lo);
-  const int o = PL::off(row, c);
   *(u32x2*)(p + o) = hi;
   *(u32x2*)(p + PL::PLANE + o) = lo;
+#endif
 }
 
 // tbx_keyed_dropout's mask (csrc/dropout.hip, rowchain.hip op_dropout) on the lane's 4 consecutive columns [c, c + 4) of global

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NT) void tile_heads_kernel(const HeadsArgs a) {
 
 }  // namespace
 
-extern "C" int tbx_heads_tile(const tbx_heads_tile_t* args, void* stream) {
+extern "C" int TBX_TILE_ENTRY(tbx_heads_tile)(const tbx_heads_tile_t* args, void* stream) {
   if (args == nullptr || args->n_rows <= 0) return TBX_ERR_ARG;
   const tbx_heads_tile_t& t = *args;
   const bool raw = t.raw != 0;

@@ -53,10 +53,11 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
   for (int q = 0; q < 2; ++q) {
     const float y = (v[q] - mean) * rstd * gm[q] + bt[q];
     const __bf16 h = (__bf16)y;
-    const __bf16 l = (__bf16)(y - (float)h);
     const int o = PL::off(r, lane + 64 * q);
     *(__bf16*)(P + o) = h;
-    *(__bf16*)(P + PLANE + o) = l;
+#if !TBX_TILE_SINGLE
+    *(__bf16*)(P + PLANE + o) = (__bf16)(y - (float)h);
+#endif
   }
 }
 
@@ -408,6 +409,7 @@ int launch(const TileArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#if !TBX_TILE_SINGLE
 extern "C" int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups) {
   const int64_t u = mfma32_units(n, k, groups);
   return u < 0 ? u : u * UNIT;
@@ -423,7 +425,9 @@ extern "C" int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, 
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
-extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
+#endif  // !TBX_TILE_SINGLE
+
+extern "C" int TBX_TILE_ENTRY(tbx_layer_tile)(const tbx_layer_tile_t* args, void* stream) {
   if (args == nullptr || args->x == nullptr || args->n_rows <= 0) return TBX_ERR_ARG;
   const tbx_layer_tile_t& t = *args;
   const bool attn = t.attn_out != nullptr, ffn = t.linear1_image != nullptr;
@@ -480,7 +484,7 @@ extern "C" int tbx_layer_tile(const tbx_layer_tile_t* args, void* stream) {
   return TBX_ERR_UNSUPPORTED;
 }
 
-#ifdef TBX_STAGE_CLOCK
+#if defined(TBX_STAGE_CLOCK) && !TBX_TILE_SINGLE
 extern "C" int tbx_debug_tl_dump(unsigned long long* host_out, int max_launches) {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_launch), sizeof(n)) != hipSuccess) return -1;

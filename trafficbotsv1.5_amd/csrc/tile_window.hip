@@ -27,7 +27,7 @@ __global__ __launch_bounds__(NT) void tile_window_kernel(const WindowArgs a) {
 
 }  // namespace
 
-extern "C" int tbx_window_tile(const tbx_window_tile_t* args, void* stream) {
+extern "C" int TBX_TILE_ENTRY(tbx_window_tile)(const tbx_window_tile_t* args, void* stream) {
   if (args == nullptr || args->n_groups <= 0) return TBX_ERR_ARG;
   const tbx_window_tile_t& t = *args;
   if (t.attr == nullptr || t.pe == nullptr || t.row_invalid == nullptr || t.out == nullptr) return TBX_ERR_ARG;

@@ -107,8 +107,9 @@ class Schedule:
     # (tbx_knarpe_attn_fwd_mfma, csrc/attn_mfma.hip): bf16 operands with fp32 accumulation - part of the bf16-ARITHMETIC schedule
     # (Schedule.reduced(); tests/test_hip_attn_mfma.py). False: the fp32 VALU kernel
     attn_mfma: bool = False
-    linear_bf16: bool = False       # the one-launch decoder layer's LINEAR stages as ONE bf16 product (tail_mfma32 = 2; with kv_bf16 only): weights
-                                    # and activations rounded to bfloat16 - half the weight bytes a stage streams through its CU's L2 port
+    linear_bf16: bool = False       # ONE bf16 product per LINEAR - weights and activations rounded to bfloat16, half the weight bytes a stage streams
+                                    # through its CU's L1 port - in the one-launch decoder layer (tail_mfma32 = 2; with kv_bf16 only) and the tile
+                                    # kernels (tbx_layer_tile_bf16 / tbx_heads_tile_bf16 / tbx_window_tile_bf16; inference launches)
     attn_mfma_min_rows: int = 193   # ... from this many source rows (= where the wave-per-row forms start; 4 scenes of 64 agents: 0.318 ->
     # 0.264 ms per step, 8 scenes: 0.336 -> 0.286 against a 1024-row threshold, gpurun_out/r04_mfma_rows_*.txt)
 
@@ -181,6 +182,9 @@ _tls = threading.local()
 def current() -> Schedule:
     """The schedule of whoever is running (innermost `use`), else the process default."""
     return getattr(_tls, "sched", None) or DEFAULT
+
+
+hip.tile_products = lambda: 1 if current().linear_bf16 else 3  # (the tile kernels' *_bf16 entry points under Schedule.linear_bf16)
 
 
 @contextlib.contextmanager

@@ -529,10 +529,16 @@ def _layer_tile_args(x, attn=None, ffn=None, proj=None, store_x: bool = True, dr
     return a
 
 
+# products per LINEAR of the tile kernels: 3 (fp32-class) or 1 (the *_bf16 entry points); engine.py points this at the scoped
+# Schedule (linear_bf16) - this module knows no schedules
+tile_products = lambda: 3
+
+
 def layer_tile(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None):
     """tbx_layer_tile (arguments: _layer_tile_args)."""
     a = _layer_tile_args(x, attn, ffn, proj, store_x, drop, rider)
-    _check(load().tbx_layer_tile(C.byref(a), stream_ptr()), "tbx_layer_tile")
+    fn = "tbx_layer_tile_bf16" if (tile_products() == 1 and drop is None) else "tbx_layer_tile"
+    _check(getattr(load(), fn)(C.byref(a), stream_ptr()), fn)
 
 
 def heads_tile(x, hd: dict):
@@ -564,7 +570,8 @@ def heads_tile(x, hd: dict):
     assert len(hd["images"]) == 9 and hd["action_out"].shape == (x.shape[0], 2)
     for i, im in enumerate(hd["images"]):
         a.images[i] = _ptr(im, torch.float32)
-    _check(load().tbx_heads_tile(C.byref(a), stream_ptr()), "tbx_heads_tile")
+    fn = "tbx_heads_tile_bf16" if (tile_products() == 1 and a.drop_thresh == 0) else "tbx_heads_tile"
+    _check(getattr(load(), fn)(C.byref(a), stream_ptr()), fn)
 
 
 def _window_tile_args(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None) -> "WindowTile":
@@ -591,7 +598,8 @@ def _window_tile_args(attr, pe, row_invalid, in_images, pn_images, window: int, 
 def window_tile(attr, pe, row_invalid, in_images, pn_images, window: int, out, add_mode: bool = False, drop=None):
     """tbx_window_tile (arguments: _window_tile_args)."""
     a = _window_tile_args(attr, pe, row_invalid, in_images, pn_images, window, out, add_mode, drop)
-    _check(load().tbx_window_tile(C.byref(a), stream_ptr()), "tbx_window_tile")
+    fn = "tbx_window_tile_bf16" if (tile_products() == 1 and drop is None) else "tbx_window_tile"
+    _check(getattr(load(), fn)(C.byref(a), stream_ptr()), fn)
 
 
 def front(window: dict, proj: dict, rider=None, jobs=None, pose_embed_job=None):
