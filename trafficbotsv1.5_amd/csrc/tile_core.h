@@ -176,17 +176,23 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // has its own copies next to the kernel they were written for).
 namespace row1 {
 __device__ __forceinline__ void put4(char* P, int lo, int c, const f32x4 v) {
+#if TBX_TILE_SINGLE
+  *(u32x2*)(P + c * 2) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+#else
   u32x2 hi, l;
   split4(v, hi, l);
   *(u32x2*)(P + c * 2) = hi;
   *(u32x2*)(P + lo + c * 2) = l;
+#endif
 }
 __device__ __forceinline__ void step(Acc& acc, const bf16x8 whi, const bf16x8 wlo, const char* P, int lo, int st, int g4) {
   const bf16x8 xh = *(const bf16x8*)(P + (st * 32 + g4 * 8) * 2);
-  const bf16x8 xl = *(const bf16x8*)(P + lo + (st * 32 + g4 * 8) * 2);
   acc.hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xh, acc.hh, 0, 0, 0);
+#if !TBX_TILE_SINGLE
+  const bf16x8 xl = *(const bf16x8*)(P + lo + (st * 32 + g4 * 8) * 2);
   acc.hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xl, acc.hl, 0, 0, 0);
   acc.lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc.lh, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x4 gemv4(const W& w, const char* P, int lo, int st0, int g4) {
   Acc acc;
@@ -213,7 +219,9 @@ __device__ __forceinline__ void ln_planes(const float* src, char* P, int lane, f
     const float y = (v[q] - mean) * rstd * gm[q] + bt[q];
     const __bf16 h = (__bf16)y;
     *(__bf16*)(P + 2 * (lane + 64 * q)) = h;
+#if !TBX_TILE_SINGLE
     *(__bf16*)(P + 256 + 2 * (lane + 64 * q)) = (__bf16)(y - (float)h);
+#endif
   }
 }
 }  // namespace row1
