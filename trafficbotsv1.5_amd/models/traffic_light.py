@@ -1,6 +1,7 @@
 """`TrafficLightEncoder` / `TrafficLightStatePredictor` (models/traffic_light.py:15-287), tl_mode=lane, HPTR.
 Static per scene (pre_compute): tl2tl / tl2mp KNN sets, their pose embeddings, and the K/V tables of the map tokens
 for each tl2mp attention layer. Per step: state window -> PointNet token -> 4 dec_cross_attn layers."""
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -52,10 +53,11 @@ class TrafficLightEncoder(nn.Module):
              "tl_token_attr": mp_token_feature[bsel, tl_attr].contiguous()}
         pose = t["tl_token_pose"]
         mp_pose = mp_token_pose.float().contiguous()
-        # Static per scene. Few rollouts: materialise the 128-d pose embeddings once (every step then just reads them);
-        # many rollouts: keep only the 12-B relative poses and let the attention kernel rebuild the embedding (the step is
-        # HBM-bound there and the materialised form is 512 B per pair per layer).
-        mat = n * L < 2048
+        # Static per scene: the 12-byte relative poses; the attention kernels rebuild the 128-d embedding from them as they do for the
+        # agents' pairs. (Rounds 2-3 materialised the embeddings for few rollouts - 512 B per pair per layer and, in the one-launch
+        # decoder layer, the run-time-mode instantiation with its spilled registers: configs[1] 470 -> 494 k with the poses instead.
+        # TBX_TL_MAT_ROWS > n * L restores it.)
+        mat = n * L < int(os.environ.get("TBX_TL_MAT_ROWS", 0))
         i_tt, m_tt, r_tt, e_tt = hip.knn_embed(pose, tl_inv, pose, tl_inv, self.n_tgt_knn_tl2tl, self.dist_limit, rp.pe_xy.freqs,
                                                rp.pe_yaw.freqs, rp.out_dim, want_rel_pose=not mat, want_emb=mat)
         i_tm, m_tm, r_tm, e_tm = hip.knn_embed(pose, tl_inv, mp_pose, mp_inv, self.n_tgt_knn_tl2mp, self.dist_limit, rp.pe_xy.freqs,
