@@ -85,9 +85,9 @@ def measure(a, tb, hip, dev, rank, world, dist):
         torch.cuda.synchronize()
 
     wm, full = build(tb, a, dev, rank)
-    # (a timed region shorter than --graph-steps: one graph of all of it; after an odd number of warm-up steps the light tables'
-    # double buffer is at parity 1 and the multi-step graph, captured at parity 0, starts one step in)
-    gsteps = max(1, min(a.graph_steps, a.steps - (a.warmup % 2)) // 2 * 2)
+    # (a timed region shorter than --graph-steps: one graph of all of it - the engine captures the multi-step graph for both
+    # parities of the light tables' double buffer, so an odd number of warm-up steps does not split it)
+    gsteps = max(1, min(a.graph_steps, a.steps) // 2 * 2)
     # this measurement's schedule belongs to its module / engine (engine.Schedule), not to the process
     wm.schedule = E.DEFAULT.replace(kv_bf16=bool(a.kv_bf16), lights_ahead=not a.no_lights_ahead, graph_steps=gsteps)
     if getattr(a, "attn_mfma", None) is not None:

@@ -81,7 +81,7 @@ class RolloutEngine:
         self._graph_steps = 1  # steps per replay of graph_multi, fixed when it is captured
         self.reused = False    # True: kept by its owner across rollouts (refill): buffer() hands out copies of the logs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.graph_multi: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_multi: Optional[Dict[int, torch.cuda.CUDAGraph]] = None  # by starting parity
 
     # ------------------------------------------------------------------ setup
     @_scheduled
@@ -511,12 +511,16 @@ class RolloutEngine:
         self.graph_multi = None
         self._graph_steps = max(1, int(self.sched.graph_steps) // 2 * 2) if self.sched.graph_steps > 1 else 1
         if self._graph_steps > 1:
-            self.parity = 0
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for _ in range(self._graph_steps):
-                    self.step()
-            self.graph_multi = g
+            # one per parity it can start at (an odd number of warm-up steps leaves the double buffer at parity 1: without its own
+            # graph the run fell back to single-step replays around a shorter multi-step one - ~9 us of idle device per extra replay)
+            self.graph_multi = {}
+            for p in range(len(graphs)):
+                self.parity = p
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(self._graph_steps):
+                        self.step()
+                self.graph_multi[p] = g
         self.parity = 0
         self.graph = graphs
         # the priming of a (re)set state as a graph too (_prime): the state is at the restored, primed start - capturing executes nothing
@@ -538,8 +542,8 @@ class RolloutEngine:
             if not use_graph:
                 self.step()
                 done += 1
-            elif self.graph_multi is not None and n_steps - done >= self._graph_steps and self.parity % len(self.graph) == 0:
-                self.graph_multi.replay()  # an even number of steps: the parity is back where it was
+            elif self.graph_multi is not None and n_steps - done >= self._graph_steps:
+                self.graph_multi[self.parity % len(self.graph)].replay()  # an even number of steps: the parity is back where it was
                 done += self._graph_steps
             else:
                 self.graph[self.parity % len(self.graph)].replay()
