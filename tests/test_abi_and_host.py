@@ -255,3 +255,26 @@ def test_training_metrics_class_equals_the_captured_steps_loss(tb):
             assert "training/tl_state_loss" not in got and float(want["tl_state_loss"]) == 0.0
         else:
             torch.testing.assert_close(got["training/tl_state_loss"], want["tl_state_loss"], rtol=1e-6, atol=1e-6)
+
+
+def test_multi_tensor_copy_of_the_engine_refill(tb):
+    """RolloutEngine._copy_all (the ~80 copies of a scene commit as a few multi-tensor launches): same-dtype contiguous pairs of equal
+    shape are grouped by dtype, everything else - dtype conversions, strided views, broadcasts - falls back to copy_, aliased pairs
+    are skipped; every destination ends equal to its source."""
+    R = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    g = torch.Generator().manual_seed(0)
+    f = lambda *s: torch.randn(*s, generator=g)
+    same = f(4, 3)
+    base = torch.zeros(6, 8)
+    pairs = [(torch.zeros(4, 3), f(4, 3)), (torch.zeros(5), f(5)),                                  # float32, contiguous: one group
+             (torch.zeros(7, dtype=torch.uint8), (torch.rand(7, generator=g) < 0.5).to(torch.uint8)),  # uint8: another group
+             (torch.zeros(2, 3, dtype=torch.int64), torch.randint(0, 9, (2, 3), generator=g)),          # int64
+             (torch.zeros(4, dtype=torch.float32), torch.randint(0, 9, (4,), generator=g)),            # conversion: copy_
+             (base[:, ::2], f(6, 4)),                                                                 # strided destination: copy_
+             (torch.zeros(3, 4), f(1, 4)),                                                            # broadcast source: copy_
+             (same, same)]                                                                            # aliased: skipped
+    want = [s.clone() for _, s in pairs]
+    R._copy_all(pairs)
+    for (d, _), w in zip(pairs, want):
+        assert torch.equal(d, w.to(d.dtype).expand_as(d))
+    R._copy_all([])  # (nothing to do)
