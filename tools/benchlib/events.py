@@ -239,6 +239,21 @@ def gemm_summary(kernels):
             "note": "frac = sum(flops_i / peak_i) / sum(t_i): each class against the dense peak of the MFMA instruction it issues"}
 
 
+def train_pmc_traffic(cls: str):
+    """-> {traffic, traffic_source, traffic_kernel} of a training kernel class from profiles/*train_pmc*.json (launch-weighted average
+    over the launches of the two eager training steps profiled: separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
+    stem = cls.split(" ")[0]  # "knarpe_attn_bwd_kernel + dkv" -> knarpe_attn_bwd_kernel
+    if not stem.endswith("_kernel"):
+        return None
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*train_pmc*.json")), reverse=True):
+        v = json.load(open(f)).get("kernels", {}).get(stem)
+        if v:
+            return {"traffic": v["traffic_bytes_per_launch"], "traffic_source": Path(f).name, "traffic_kernel": stem,
+                    "traffic_note": "launch-weighted average over every launch of this kernel in the profiled steps (the event pass's "
+                                    "algorithmic bytes are per call of the entry point)"}
+    return None
+
+
 def train_kernel_pass(hip, step, replay_s):
     """Times this repo's kernels inside one eager training step (HIP events on the launch stream, behind a device-side delay that lets
     the host enqueue the step ahead of the device: the pairs then bracket back-to-back launches; shares are of `replay_s`, the timed
@@ -343,6 +358,10 @@ def train_kernel_pass(hip, step, replay_s):
             peak, unit, ach = (SPLIT_BF16_PEAK_TF if bound == "mfma3" else FP32_MFMA_PEAK_TF), "TFLOP/s", w / t / 1e12
         kernels.append({"kernel": cls, "bound": "hbm" if bound == "hbm" else "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                         "launches_per_step": len(evs), "avg_launch_us": t / len(evs) * 1e6, "share_of_step": t / replay_s, "traffic": None})
+    for k in kernels:  # HBM bytes per launch from the committed PMC passes of an eager training step (tools/pmc_train.sh), if any
+        tr = train_pmc_traffic(k["kernel"])
+        if tr:
+            k.update(tr)
     kernels.sort(key=lambda k: -k["share_of_step"])
     rest = 1.0 - sum(k["share_of_step"] for k in kernels)
     kernels.append({"kernel": "library GEMMs of the odd-width layers (rocBLAS fp32) + aten elementwise / copy / reduce + this repo's smaller kernels", "bound": None,

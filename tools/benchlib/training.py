@@ -65,9 +65,6 @@ def train_main(args, tb, dev, rank, world, dist):
         try:
             roof, kernels = events.train_kernel_pass(import_module("trafficbots_amd.hip"),
                                                      lambda: DP.train_step(wm, opt, {k: v.clone() for k, v in batch.items()}, live=live), dt / args.steps)
-            tr = events.train_pmc_traffic(roof["kernel"]) if hasattr(events, "train_pmc_traffic") else None
-            if tr:
-                roof.update(tr)
         except Exception as e:  # noqa: BLE001 - the line must still be printed
             roof = {"error": f"{type(e).__name__}: {e}"}
     return {
