@@ -240,17 +240,25 @@ def gemm_summary(kernels):
 
 
 def train_pmc_traffic(cls: str):
-    """-> {traffic, traffic_source, traffic_kernel} of a training kernel class from profiles/*train_pmc*.json (launch-weighted average
-    over the launches of the two eager training steps profiled: separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
+    """-> {traffic, traffic_source, traffic_kernel} of a training kernel class from profiles/*train_pmc*.json (separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of two eager training steps, tools/pmc_train.sh), per call of the class's entry point, or None. The attention
+    forward class covers two kernels (the wave-per-row kernel of the time-batched pass and the ring form of the stepping pass):
+    launch-weighted; a backward call is one launch of the row kernel + one of the dK / dV kernel: summed."""
     stem = cls.split(" ")[0]  # "knarpe_attn_bwd_kernel + dkv" -> knarpe_attn_bwd_kernel
     if not stem.endswith("_kernel"):
         return None
+    parts = {"knarpe_attn_kernel": (("knarpe_attn_kernel", "knarpe_attn_ring_kernel"), "mean"),
+             "knarpe_attn_bwd_kernel": (("knarpe_attn_bwd_kernel", "knarpe_attn_dkv_kernel"), "sum")}.get(stem, ((stem,), "mean"))
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*train_pmc*.json")), reverse=True):
-        v = json.load(open(f)).get("kernels", {}).get(stem)
-        if v:
-            return {"traffic": v["traffic_bytes_per_launch"], "traffic_source": Path(f).name, "traffic_kernel": stem,
-                    "traffic_note": "launch-weighted average over every launch of this kernel in the profiled steps (the event pass's "
-                                    "algorithmic bytes are per call of the entry point)"}
+        ks = json.load(open(f)).get("kernels", {})
+        vs = [ks[k] for k in parts[0] if k in ks]
+        if not vs:
+            continue
+        if parts[1] == "sum":
+            tr = sum(v["traffic_bytes_per_launch"] for v in vs)
+        else:
+            tr = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in vs) / sum(v["launches"] for v in vs)
+        return {"traffic": int(tr), "traffic_source": Path(f).name, "traffic_kernel": " + ".join(k for k in parts[0] if k in ks)}
     return None
 
 
