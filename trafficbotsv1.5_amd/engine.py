@@ -61,10 +61,11 @@ class Schedule:
     # of live_rows rows, LINEAR stages as v_fma chains per output column (bit-identical to the MFMA tiles) - up to live_max rows.
     live_rows: int = 1
     # Measured on the scenes-per-GPU curve (profiles/r04_scene_curve.json, 64 agents / 128 lights per scene): the one-row-per-
-    # workgroup layers win up to 256 rows for the lights' block (48 pairs per row) and up to 192 rows for the agents' block (114
-    # pairs per row); from there the tile kernels + the wave-per-row attention do (4 scenes: 0.398 -> 0.309 ms per step, 8 scenes:
+    # workgroup layers win up to 384 rows for the lights' block (48 pairs per row; re-measured at the end of round 4 with the faster
+    # layer: 3 scenes = 384 light rows 675 -> 742 k agent-steps/s; 512 rows: the tile kernels) and up to 192 rows for the agents' block
+    # (114 pairs per row); from there the tile kernels + the wave-per-row attention do (4 scenes: 0.398 -> 0.309 ms per step, 8 scenes:
     # 0.470 -> 0.332). live_max_agents applies inside TrafficBots.agent_policy (engine.live_limit).
-    live_max: int = 256
+    live_max: int = 384
     live_max_agents: int = 192
     # BASELINE config 2 names bf16: the K/V tables every attention call gathers from stored as bfloat16 (529 B per pair instead of
     # 1041); queries, pose embeddings, scores, softmax and all sums stay fp32. Off: the fp32 parity path.
@@ -132,7 +133,7 @@ class Schedule:
             masked_groupmax=on("TBX_MASKED_GROUPMAX"),
             big_rows=num("TBX_BIG_ROWS", 16384),
             live_rows=num("TBX_LIVE_ROWS", 1),
-            live_max=num("TBX_LIVE_MAX", 256),
+            live_max=num("TBX_LIVE_MAX", 384),
             live_max_agents=num("TBX_LIVE_MAX_AGENTS", 192),
             kv_bf16=off("TBX_KV_BF16"),
             pool_proj=off("TBX_POOL_PROJ"),
