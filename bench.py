@@ -132,6 +132,26 @@ def main(argv=None):
         big.scenes, big.rollouts, big.agents, big.steps = 1, 32, 128, min(args.steps, 40)
         r5, _, _ = measure(big)
         full["wosac_shape"] = {"metric": full["metric"], "unit": full["unit"], "n_gpus": world, "steps": big.steps, "warmup": big.warmup, **r5}
+    if args.submission_shape:
+        # the reference's WOSAC SUBMISSION shape (configs/resume/submission.yaml:5: 128 joint futures per scenario; 32 is the
+        # training-time validation value): 128 rollouts x 128 agents = 16,384 agent rows on one GPU, the rule checks over the
+        # 128 x 50 frames and the 32-of-128 filter inside `with_rule_checks`
+        sub = copy.copy(args)
+        sub.scenes, sub.rollouts, sub.agents, sub.steps, sub.new_scenes = 1, 128, 128, min(args.steps, 40), 0
+        try:
+            rs, _, _ = measure(sub)
+            full["submission_shape"] = {"metric": full["metric"], "unit": full["unit"], "n_gpus": world, "steps": sub.steps, "warmup": sub.warmup, **rs}
+        except Exception as e:  # noqa: BLE001
+            full["submission_shape"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if args.batched_shape:
+        # the multi-scene serving shape: 16 independent configs[1] scenes batched in one engine (the scenes-per-GPU curve's knee)
+        bt = copy.copy(args)
+        bt.scenes, bt.steps, bt.new_scenes = 16, min(args.steps, 40), 0
+        try:
+            rb, _, _ = measure(bt)
+            full["batched"] = {"metric": full["metric"], "unit": full["unit"], "n_gpus": world, "steps": bt.steps, "warmup": bt.warmup, **rb}
+        except Exception as e:  # noqa: BLE001
+            full["batched"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if args.bf16_shape:
         # BASELINE.json configs[1] says bf16: the same two workloads on the bf16-arithmetic schedule (Schedule.reduced(): bfloat16 K/V
         # tables - 529 B per pair -, from 193 source rows the attention with bf16 operands on the matrix cores, and the one-launch

@@ -207,7 +207,17 @@ def test_navi_predictor_forward_vs_reference_golden(tb, golden_dir, sizes, knn, 
     assert int(clear.sum()) >= int(0.5 * g["navi_valid"].sum())
 
 
-def test_wosac_shape_joint_futures_vs_oracle(tb):
+# Tolerances of the WOSAC-shape check per schedule: (pose / action atol over the 16 compared steps of three rollouts, pose / action atol over
+# the 10 warm-start steps of all 32, light-state NLL atol). "reduced" = Schedule.reduced(), the bf16-ARITHMETIC schedule (bf16 tables,
+# tbx_knarpe_attn_fwd_mfma, tbx_layer_tile_bf16 / tbx_heads_tile_bf16 / tbx_window_tile_bf16 for the agents' 4096 rows, dec_layer_mf1_kernel
+# for the lights' 128): 2 x the largest difference measured against the ORACLE on MI355X (the test prints them;
+# profiles/r05_reduced_tolerances.txt). Validity, light states, map-exit flags and the rule flags stay bit-identical in both.
+WOSAC_TOL = {"default": dict(free=(3e-3, 3e-3), warm=(1e-3, 2e-3), nll=1e-4),
+             "reduced": dict(free=(0.3, 0.2), warm=(3e-2, 3e-2), nll=5e-2)}
+
+
+@pytest.mark.parametrize("sched", ["default", "reduced"])
+def test_wosac_shape_joint_futures_vs_oracle(tb, sched):
     """BASELINE config 5 at its own size: 32 rollouts x 128 agents / 1024 polylines / 128 lights through
     `joint_future_pred` - map tokens and K/V tables shared by the 32 rollouts (batch_div), lights stepped once per scene
     (share_lights) - vs the oracle's Sim.rollout run rollout by rollout with THAT rollout's sampled latent and destination.
@@ -216,6 +226,9 @@ def test_wosac_shape_joint_futures_vs_oracle(tb):
     dev = torch.device(DEV)
     K, A, T, n_cmp = 32, 128, 16, 16
     wm, P, b, bd = _setup(tb, dev, (A, 1024, 128), 32)
+    tol = WOSAC_TOL[sched]
+    if sched == "reduced":
+        wm.schedule = import_module("trafficbots_amd.engine").DEFAULT.reduced()
     D = import_module("trafficbots_amd.models.modules.distributions")
     cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=32), tb.config.default_sim_cfg()
     om = O.TrafficBotsOracle(P, cfg, training=False)
@@ -223,6 +236,8 @@ def test_wosac_shape_joint_futures_vs_oracle(tb):
         mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
         tl_o = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
     mp, tl = wm.encode_scene(bd, n_rollout=K)
+    meas = {"free_pose": 0.0, "free_action": 0.0, "nll": 0.0}
+    dmax = lambda x, y: float((x - y).abs().max())
     valid = bd["sc/ag_valid"].any(-1)
     lat = D.DiagGaussian(torch.zeros(1, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)  # std-normal prior
     onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], 1024).float()
@@ -247,9 +262,12 @@ def test_wosac_shape_joint_futures_vs_oracle(tb):
         assert torch.equal(buf.pred_valid[:, k, :, sl].cpu(), ro["pred_valid"][:, :, sl]), k
         assert torch.equal(buf.vis_dict["tl_state"][:, k, :, sl].cpu(), ro["tl_state"][:, :, sl]), k
         assert torch.equal(buf.violation["outside_map"][:, k, :, sl].cpu(), ro["outside_map"][:, :, sl]), k
-        torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=3e-3)
-        torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=3e-3)
-        torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=1e-4)
+        meas["free_pose"] = max(meas["free_pose"], dmax(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl]))
+        meas["free_action"] = max(meas["free_action"], dmax(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl]))
+        meas["nll"] = max(meas["nll"], dmax(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl]))
+        torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["free"][0])
+        torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=tol["free"][1])
+        torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=tol["nll"])
     # ALL 32 rollouts over the 10 warm-start steps (poses are teacher-forced there, so the oracle runs the 32 rollouts as one
     # batch of 32 scene copies, each with its rollout's latent and destination): every rollout's action means and light states
     rep = lambda t: t.repeat_interleave(K, 0) if torch.is_tensor(t) and t.shape[0] == 1 else t
@@ -262,8 +280,11 @@ def test_wosac_shape_joint_futures_vs_oracle(tb):
     sl = slice(0, 10)
     assert torch.equal(buf.pred_valid[0, :, :, sl].cpu(), roK["pred_valid"][:, :, sl])
     assert torch.equal(buf.vis_dict["tl_state"][0, :, :, sl].cpu(), roK["tl_state"][:, :, sl])
-    torch.testing.assert_close(buf.pred_pose[0, :, :, sl].cpu(), roK["pred_pose"][:, :, sl], rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(buf.vis_dict["action"][0, :, :, sl].cpu(), roK["action"][:, :, sl], rtol=1e-3, atol=2e-3)
+    print(f"[wosac shape vs oracle, {sched}] 16 steps of 3 rollouts: max |d pose| {meas['free_pose']:.3g}, |d action| {meas['free_action']:.3g}, |d nll| {meas['nll']:.3g}; "
+          f"10 warm-start steps of all 32: |d pose| {dmax(buf.pred_pose[0, :, :, sl].cpu(), roK['pred_pose'][:, :, sl]):.3g}, "
+          f"|d action| {dmax(buf.vis_dict['action'][0, :, :, sl].cpu(), roK['action'][:, :, sl]):.3g}")
+    torch.testing.assert_close(buf.pred_pose[0, :, :, sl].cpu(), roK["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["warm"][0])
+    torch.testing.assert_close(buf.vis_dict["action"][0, :, :, sl].cpu(), roK["action"][:, :, sl], rtol=1e-3, atol=tol["warm"][1])
     assert float((roK["action"][0] - roK["action"][1]).abs().max()) > 1e-3  # the rollouts' policies do differ (their latents do)
     # rule flags of three rollouts, bit-exact against the oracle's checks on the logged trajectories
     ks = [0, 13, 31]
@@ -341,24 +362,95 @@ def test_scene_loader_graph_equals_eager_refill(tb, sizes, knn, K):
     keys = ("out_pose", "out_valid", "out_motion", "out_action", "out_tl_state", "out_reward", "out_reward_valid", "out_tf", "out_tl_nll",
             "out_outside_map", "out_dest_reached")
     logs = {}
-    for mode in ("eager", "graph"):
+    # "overlap": the serving loop's order (scene_loader.py's docstring, bench.py's end_to_end_value) - scene k + 1's [encoders + derived
+    # state] replayed on the side stream WHILE scene k's step graphs run, its log read after that prefetch was enqueued
+    for mode in ("eager", "graph", "overlap"):
         with E.use(wm.schedule):
             eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
             eng.reset(**R.engine_inputs(wm, scenes[0], a, dev, T))
             eng.capture()
-            loader = SL.SceneLoader(eng, scenes[0], lambda sb: R.engine_inputs(wm, sb, a, dev, T)) if mode == "graph" else None
+            loader = SL.SceneLoader(eng, scenes[0], lambda sb: R.engine_inputs(wm, sb, a, dev, T)) if mode != "eager" else None
             out = []
-            for bd in scenes[1:] + scenes[:1]:
-                if loader is not None:
+            order = scenes[1:] + scenes[:1]
+            if mode == "overlap":
+                loader.prefetch(order[0])
+            for i, bd in enumerate(order):
+                if mode == "overlap":
+                    loader.commit()
+                    if i + 1 < len(order):
+                        loader.prefetch(order[i + 1])
+                elif loader is not None:
                     loader.load(bd)
                 else:
                     eng.refill(**R.engine_inputs(wm, bd, a, dev, T))
                 eng.run(T, use_graph=True)
-                torch.cuda.synchronize()
-                out.append({k: eng.S[k].clone() for k in keys})
+                if mode != "overlap":
+                    torch.cuda.synchronize()
+                out.append({k: eng.S[k].clone() for k in keys})  # (stream-ordered behind the rollout)
                 eng.buffer(10)  # (reads the device-side light-sharing flag of the refill: must not raise)
+            torch.cuda.synchronize()
         logs[mode] = out
     assert not torch.equal(logs["eager"][0]["out_pose"], logs["eager"][1]["out_pose"])  # the scenes do differ
-    for i, (e, g) in enumerate(zip(logs["eager"], logs["graph"])):
-        for k in keys:
-            assert torch.equal(e[k], g[k]), (i, k)
+    for mode in ("graph", "overlap"):
+        for i, (e, g) in enumerate(zip(logs["eager"], logs[mode])):
+            for k in keys:
+                assert torch.equal(e[k], g[k]), (mode, i, k)
+
+
+def test_light_sharing_flag_belongs_to_the_committed_scene(tb):
+    """in the overlapped order commit(k); prefetch(k + 1); run(); buffer() the light-sharing flag read by buffer()
+    must be scene k's - an engine-owned copy made by graph_commit - not the tensor in graph_prepare's pool that prefetch(k + 1)
+    rewrites. Scenes: A (its K rollouts share their lights), B (rollout 1's light states differ: must be refused), C (shared again).
+    buffer() passes for A although B's prepare has already run, raises for B although C's has, and passes for C."""
+    from types import SimpleNamespace
+
+    from tools.benchlib import rollout as R
+
+    dev = torch.device("cuda:0")
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    SL = import_module("trafficbots_amd.pl_modules.scene_loader")
+    Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
+    E = import_module("trafficbots_amd.engine")
+    sizes, K, T = (16, 64, 8), 4, 14
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    wm = wm.to(dev).eval()
+    wm.schedule = E.DEFAULT.replace(graph_steps=4)
+    a = SimpleNamespace(rollouts=K, scenes=1, agents=sizes[0])
+
+    def scene(seed, mismatch):
+        batch = tb.synthetic.make_scene(1, *sizes, seed=seed)
+        full = {**batch, **tb.synthetic.to_history_batch(batch)}
+        bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+        bd["test/mismatch"] = torch.full((1,), float(mismatch), device=dev)
+        return bd
+
+    def make_kw(sb):
+        kw = R.engine_inputs(wm, sb, a, dev, T)
+        g = kw["tl_state_gt"]  # [K, L, T, 5]: rollout 1's ground-truth light states shifted by one state where the scene says so
+        bad = g.clone()
+        bad[1] = g[1].roll(1, -1)
+        kw["tl_state_gt"] = torch.where(sb["test/mismatch"].view(1, 1, 1, 1) > 0, bad, g)
+        return kw
+
+    A, B, C = scene(31, 0), scene(32, 1), scene(33, 0)
+    with E.use(wm.schedule):
+        eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
+        eng.reset(**make_kw(A))
+        assert eng.tl_div == K
+        eng.capture()
+        loader = SL.SceneLoader(eng, A, make_kw)
+        loader.prefetch(A)
+        loader.commit()
+        loader.prefetch(B)
+        eng.run(T, use_graph=True)
+        eng.buffer(10)  # A: fine, although B's prepare has already been replayed
+        loader.commit()
+        loader.prefetch(C)
+        eng.run(T, use_graph=True)
+        with pytest.raises(RuntimeError, match="lights"):
+            eng.buffer(10)  # B: refused, although C's prepare has already been replayed
+        loader.commit()
+        eng.run(T, use_graph=True)
+        eng.buffer(10)  # C
+        torch.cuda.synchronize()

@@ -95,12 +95,23 @@ def test_reactive_replay_vs_oracle_and_reference(tb, golden_dir, sizes, knn, n_r
         assert np.array_equal(o.violation["outside_map"][:, 0, :, :nc].cpu().numpy(), g["rr_outside_map"][:, :, :nc])
 
 
+# Teacher-forced replay under the bf16-ARITHMETIC schedule (Schedule.reduced()) against the ORACLE: the states are the ground truth's at
+# every step, so nothing amplifies - what is compared is 24 / 90 independent policy evaluations (dec_layer_mf1_kernel, the *_bf16 tile
+# kernels of the window PointNets / first projections, bf16 tables). Flags, validity and light states must be IDENTICAL; the
+# predicted pose before the override / the action mean carry the bf16 operand rounding (2^-9 per operand through 4 + 4 layers).
+# Bounds = 2 x the largest difference measured on MI355X (printed by the test; profiles/r05_reduced_tolerances.txt).
+REDUCED_TF_ATOL = {(8, 64, 8): 2.4e-2, (64, 1024, 128): 3.2e-2}
+
+
+@pytest.mark.parametrize("sched", ["default", "reduced"])
 @pytest.mark.parametrize("sizes,knn,n_roll", [((8, 64, 8), 4, 90), ((64, 1024, 128), 32, 24)])
-def test_teacher_forced_replay(tb, sizes, knn, n_roll):
+def test_teacher_forced_replay(tb, sizes, knn, n_roll, sched):
     """(a) every agent valid and teacher-forced at every step (no free-running agent anywhere in the scene): each step's
     policy + dynamics + override pipeline on realistic states, whole horizon, tight tolerance."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, sizes, knn, ragged=False)
+    if sched == "reduced":
+        wm.schedule = import_module("trafficbots_amd.engine").DEFAULT.reduced()
     cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=knn), tb.config.default_sim_cfg()
     om = O.TrafficBotsOracle(P, cfg, training=False)
     mp_o, tl_o = _oracle_tokens(om, b)
@@ -113,6 +124,16 @@ def test_teacher_forced_replay(tb, sizes, knn, n_roll):
     TF = import_module("trafficbots_amd.utils.teacher_forcing").TeacherForcing
     mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
     buf = wm.reactive_replay(bd, mp, tl, z.to(dev), valid.to(dev), bd["gt/ag_navi"], valid.to(dev), TF(**tf_all), True, step_end=n_roll)
+    if sched == "reduced":
+        E = import_module("trafficbots_amd.engine")
+        with E.use(wm.schedule):
+            assert mp["mp_token_feature"].dtype == torch.float32 and wm.model.ag_encoder.kv_mp(mp).dtype == torch.bfloat16
+        err = {k: float((x.cpu() - y).abs().max()) for k, x, y in (("pose", buf.pred_pose[:, 0], ro["pred_pose"]), ("motion", buf.pred_motion[:, 0], ro["pred_motion"]),
+                                                                     ("action", buf.vis_dict["action"][:, 0], ro["action"]))}
+        print(f"[reduced vs oracle, teacher-forced {sizes} x {n_roll} steps] max |d pose| {err['pose']:.3g}, |d motion| {err['motion']:.3g}, |d action| {err['action']:.3g}")
+        assert max(err.values()) > 1e-5  # the bf16 arithmetic did run
+        _compare(buf, ro, n_roll, REDUCED_TF_ATOL[sizes])
+        return
     _compare(buf, ro, n_roll, 1e-3)
 
 
@@ -583,5 +604,5 @@ def test_free_rollout_80_steps_full_gain_contractive_weights(tb):
         # measured (MI355X): exact-fp32 schedule ADE 0.67 mm / FDE 6.0 mm, default schedule ADE 0.76 mm / FDE 6.1 mm, bf16 tables ADE 33 mm /
         # FDE 0.19 m, the bf16-arithmetic schedule (one bf16 product per LINEAR: 2^-9 per operand into a loop that amplifies ~100x per
         # 10 steps) ADE 0.44 m / FDE 1.7 m; flags 100 % in all four
-        ade_max, fde_max, flags_min = {False: (3e-3, 5e-2, 0.995), True: (1e-2, 0.1, 0.995), "tables": (0.1, 0.6, 0.995), "reduced": (1.5, 6.0, 0.995)}[tile_small]
+        ade_max, fde_max, flags_min = {False: (3e-3, 5e-2, 0.995), True: (1e-2, 0.1, 0.995), "tables": (0.1, 0.6, 0.995), "reduced": (0.9, 3.4, 0.995)}[tile_small]  # (<= 2 x measured; the same figures at configs[1]'s size: tests/test_hip_reduced_oracle.py)
         assert ade < ade_max and fde < fde_max and flags >= flags_min, (tile_small, ade, fde, flags)

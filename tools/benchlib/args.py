@@ -40,6 +40,12 @@ def parse(argv=None):
                     help="Schedule.attn_mfma of the measured engines: 0 fp32 VALU attention, 1 bf16 matrix-core attention (default: the "
                          "engine's own default)")
     ap.add_argument("--no-bf16-shape", action="store_true", help="skip the bf16-table measurements the default run appends")
+    ap.add_argument("--no-rule-checks", action="store_true",
+                    help="skip the `with_rule_checks` figure (the timed region + the per-step rule checks of waymo_motion.py:250 + _filter_futures)")
+    ap.add_argument("--no-submission-shape", action="store_true",
+                    help="skip the 128 rollouts x 128 agents measurement (configs/resume/submission.yaml:5) the default run appends")
+    ap.add_argument("--no-batched-shape", action="store_true",
+                    help="skip the 16-scenes-per-GPU measurement (`batched`) the default run appends")
     ap.add_argument("--scene-curve", type=str, default=None, metavar="S1,S2,..",
                     help="also time the rollout at these scenes-per-GPU counts (same scene shape); one line each goes to the detail file")
     ap.add_argument("--detail-file", type=str, default=None,
@@ -55,6 +61,9 @@ def parse(argv=None):
                      and a.profile_steps > 0)
     a.train_shape = a.wosac_shape and not a.no_train_shape
     a.bf16_shape = a.wosac_shape and not a.no_bf16_shape and not a.kv_bf16
+    a.submission_shape = a.wosac_shape and not a.no_submission_shape
+    a.batched_shape = a.wosac_shape and not a.no_batched_shape
+    a.rule_checks = not tr and not a.no_rule_checks and a.profile_steps > 0
     a.scenes = a.scenes if a.scenes is not None else (16 if tr else 1)
     return a
 

@@ -2,8 +2,10 @@
 engine launches on torch's current stream) around every launch of this repo's kernel classes in a few eager steps, the algorithmic
 bytes or flops of each launch beside them, and the HBM traffic of the same kernel from the committed PMC passes."""
 import glob
+import hashlib
 import json
 import os
+import re
 import time
 from pathlib import Path
 
@@ -28,10 +30,41 @@ def mfma_peak(cls: str, products: int = 3):
     return BF16_MFMA_PEAK_TF / max(1, products), f"v_mfma_f32_16x16x32_bf16 x{max(1, products)} products per fp32 product"
 
 
+def round_tag(name: str):
+    """'r05_c2_pmc.json' -> 5; None for names without a round prefix."""
+    m = re.match(r"r(\d\d)", Path(name).name)
+    return int(m.group(1)) if m else None
+
+
+def newest_round() -> int:
+    """The newest round that has committed evidence under profiles/ (profiles/rNN_*)."""
+    return max([round_tag(f) or 0 for f in glob.glob(str(ROOT / "profiles" / "r??_*"))] or [0])
+
+
+SOURCE_FILES = ("trafficbotsv1.5_amd/csrc/*.hip", "trafficbotsv1.5_amd/csrc/*.h", "trafficbotsv1.5_amd/csrc/*.inc", "include/*.h",
+                "trafficbotsv1.5_amd/engine.py")
+
+
+def source_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources + the launch schedule: what a PMC pass profiled. tools/rocpd_pmc.py writes
+    it into every profile; kernel_entry() compares it with the tree that is being timed (`traffic_matches_build`)."""
+    h = hashlib.sha256()
+    for pat in SOURCE_FILES:
+        for f in sorted(glob.glob(str(ROOT / pat))):
+            h.update(Path(f).name.encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args, prefixes):
-    """HBM traffic per launch from the committed PMC passes (profiles/*pmc*.json; newest round first) of this workload, for the
-    kernel variant whose name starts with one of `prefixes` (the variant with the most launches in that pass)."""
+    """HBM traffic per launch from the committed PMC passes (profiles/*pmc*.json) of this workload, for the kernel variant whose name
+    starts with one of `prefixes` (the variant with the most launches in that pass). Only profiles of the NEWEST round with evidence
+    under profiles/ are accepted: a kernel renamed or rewritten this round must not be described by last round's counters (round 4
+    quoted r03's pass for `dec_layer_mf1_kernel`). -> (bytes, file name, kernel variant, the profile's source hash) or Nones."""
+    newest = newest_round()
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*pmc*.json")), reverse=True):
+        if round_tag(f) != newest:
+            continue
         d = json.load(open(f))
         w = d.get("workload", {})
         if (w.get("agents"), w.get("polylines"), w.get("lights"), w.get("scenes"), w.get("rollouts")) != (
@@ -42,8 +75,8 @@ def pmc_traffic(args, prefixes):
         hits = [(v.get("launches", 0), k, v) for k, v in d.get("kernels", {}).items() if ("<" in k or k in prefixes) and any(k.startswith(p) for p in prefixes)]
         if hits:
             _, k, v = max(hits)
-            return v["traffic_bytes_per_launch"], Path(f).name, k
-    return None, None, None
+            return v["traffic_bytes_per_launch"], Path(f).name, k, d.get("source_sha16")
+    return None, None, None, None
 
 
 def attn_counters(args):
@@ -81,6 +114,8 @@ class KernelEvents:
 
     def __init__(self, hip):
         self.hip, self.rec = hip, {}
+        self.extra = {}  # (class, key) -> per-launch bytes a launch must move beyond its algorithmic bytes
+        self.dec_kernel = "dec_layer_mf_kernel"
         self._saved = {}
 
     def _time(self, cls, key, work, fn, *a, **kw):
@@ -97,8 +132,10 @@ class KernelEvents:
         sv["Chain.run"] = hip.Chain.run
 
         def mid(*args, **kw):
-            # algorithmic bytes of the launch: both attentions' pairs + every weight image once (5 of the attention half;
-            # with a tail the layer's out_proj / FFN / next projections = 13 chunks, with the heads 15 more) + token rows in and out
+            # ALGORITHMIC bytes of the launch = SURVEY 8d only: the launch holds two attention calls (self + cross) - per call
+            # S*2*d*b + P*(2*d*b + 17) + (d_rpe*2d + 2d)*b. What the launch must ALSO move - every weight image once (5 of the attention
+            # half; with a tail the layer's out_proj / FFN / next projections = 13 chunks, with the heads 15 more) + the token rows in
+            # and out - is kept beside it as `compulsory_bytes_per_launch` and never enters `achieved` / `frac`.
             self_seg, cross = args[4], args[5]
             rows = args[9] * args[10]
             eb = 2 if self_seg.kv.dtype == torch.bfloat16 else 4
@@ -107,7 +144,11 @@ class KernelEvents:
             w = (4 * 33 + 36) * 2048
             if tail is not None:
                 w += (8 * 33 + 3 * 32 + (3 * 33 + 36 if tail.get("qkv_out") is not None else 0) + (13 * 33 + 2 * 32 if tail.get("heads") else 0)) * 2048
-            b = 2 * attn_algorithmic_bytes(rows, 0, eb) + pairs * (2 * 128 * eb + 17) + w + rows * (128 * 4 * 2 + (896 * 4 if tail and tail.get("qkv_out") is not None else 0))
+                if tail.get("mfma32") == 2:  # one bf16 product per LINEAR: the hi halves of the weight units only
+                    w //= 2
+            b = 2 * attn_algorithmic_bytes(rows, 0, eb) + pairs * (2 * 128 * eb + 17)
+            self.extra.setdefault(("dec_layer", rows), []).append(w + rows * (128 * 4 * 2 + (896 * 4 if tail and tail.get("qkv_out") is not None else 0)))
+            self.dec_kernel = "dec_layer_mf1_kernel" if (tail is not None and tail.get("mfma32") == 2) else ("dec_layer_mf_kernel" if (tail is not None and tail.get("mfma32")) else "dec_mid_kernel")
             return T("dec_layer", rows, b, sv["knarpe_dec_mid"], *args, **kw)
 
         def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw):
@@ -175,7 +216,8 @@ class KernelEvents:
         out = []
         for (cls, key), evs in self.rec.items():
             t = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) * 1e-3
-            out.append(dict(cls=cls, key=key, t=t, n=len(evs), work=sum(w for *_, w in evs), per_step=len(evs) / n_steps))
+            out.append(dict(cls=cls, key=key, t=t, n=len(evs), work=sum(w for *_, w in evs), per_step=len(evs) / n_steps,
+                            extra=sum(self.extra.get((cls, key), [])), dec_kernel=self.dec_kernel))
         tot = sum(c["t"] for c in out) or 1.0
         for c in out:
             c["share"] = c["t"] / tot
@@ -193,11 +235,14 @@ def kernel_entry(args, c, products: int = 3):
         wave_rows = int(os.environ.get("TBX_ATTN_BIG_ROWS_INFER", 193))  # (attn.hip attn_big_rows: a wavefront per source row from here)
         mf_rows = int(os.environ.get("TBX_ATTN_MFMA_MIN_ROWS", 193))  # (Schedule.attn_mfma_min_rows)
         mf = cls == "attn" and getattr(args, "attn_mfma", None) and key >= mf_rows
-        name = "dec_layer_mf_kernel" if cls == "dec_layer" else ("knarpe_attn_mfma_kernel" if mf else "knarpe_attn_kernel")  # (dec_mid_kernel with Schedule.dec_tail_mfma off)
-        pre = ["dec_layer_mf_kernel<", "dec_mid_kernel<"] if cls == "dec_layer" else (["knarpe_attn_mfma_kernel<"] if mf else (["knarpe_attn_kernel<1,"] if key >= wave_rows else ["knarpe_attn_kernel<4,"]))
+        dec_name = c.get("dec_kernel", "dec_layer_mf_kernel")  # (dec_layer_mf1_kernel under Schedule.linear_bf16, dec_mid_kernel with Schedule.dec_tail_mfma off)
+        name = dec_name if cls == "dec_layer" else ("knarpe_attn_mfma_kernel" if mf else "knarpe_attn_kernel")
+        pre = [dec_name + "<"] if cls == "dec_layer" else (["knarpe_attn_mfma_kernel<"] if mf else (["knarpe_attn_kernel<1,"] if key >= wave_rows else ["knarpe_attn_kernel<4,"]))
         e.update(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                  algorithmic_bytes_per_launch=c["work"] / c["n"], source_rows_per_launch=key,
                  bytes_per_pair=529 if args.kv_bf16 else 1041)
+        if c.get("extra"):
+            e["compulsory_bytes_per_launch"] = c["work"] / c["n"] + c["extra"] / c["n"]  # 8d bytes + weight images + token rows in / out
         if cls == "attn":
             e.update(l2_frac=ach / L2_PEAK_GBS, l2_peak=L2_PEAK_GBS)
         if cls == "dec_layer" or key < 1024:  # (under 4 workgroups per CU)
@@ -217,9 +262,11 @@ def kernel_entry(args, c, products: int = 3):
     else:
         e.update(kernel=f"tbx_{key}", bound="latency", achieved=None, peak=None, unit=None, frac=None)
         return e
-    traffic, src, variant = pmc_traffic(args, pre)
+    traffic, src, variant, sha = pmc_traffic(args, pre)
     e.update(traffic=traffic, traffic_source=src, traffic_kernel=variant,
              traffic_measured=False)  # PMC passes are separate rocprofv3 runs: the committed profile of this workload
+    if src is not None:  # does the profile describe the sources that are being timed? (tools/rocpd_pmc.py stamps every profile)
+        e["traffic_matches_build"] = (sha == source_sha16()) if sha else None
     if traffic is not None:
         e["hbm_measured_frac"] = traffic / avg / 1e9 / HBM_PEAK_GBS
     return e

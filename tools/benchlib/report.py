@@ -13,9 +13,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 MAX_LINE_BYTES = 8192
 
-ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_measured_frac", "avg_launch_us",
-             "launches_per_step", "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch", "flops_per_launch",
-             "bytes_per_pair", "source_rows_per_launch")
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_matches_build", "hbm_measured_frac",
+             "avg_launch_us", "launches_per_step", "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch",
+             "compulsory_bytes_per_launch", "flops_per_launch", "bytes_per_pair", "source_rows_per_launch")
 
 
 def _r(x, sig=6):
@@ -67,7 +67,15 @@ def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps",
     if res.get("roofline_gemm"):
         g = res["roofline_gemm"]
         out["roofline_gemm"] = {k: g[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in g}
+    if res.get("with_rule_checks"):
+        out["with_rule_checks"] = compact_checks(res["with_rule_checks"])
     return out
+
+
+def compact_checks(w):
+    if "error" in w:
+        return {"error": str(w["error"])[:200]}
+    return {k: w[k] for k in ("value", "ms_per_step", "rule_checks_ms", "vs_unchecked", "filter_futures") if k in w}
 
 
 def judged_line(full):
@@ -87,11 +95,16 @@ def judged_line(full):
             line[k] = full[k]
     if full.get("scene_reuse"):
         line["new_scene_ms"] = full["scene_reuse"]["new_scene_ms"]
+    if full.get("with_rule_checks"):
+        line["with_rule_checks"] = compact_checks(full["with_rule_checks"])
     if "cpu_baseline" in full:
         line["cpu_baseline"] = full["cpu_baseline"]
         line["speedup_vs_cpu_baseline"] = full.get("speedup_vs_cpu_baseline")
     if full.get("wosac_shape"):
         line["wosac_shape"] = compact_shape(full["wosac_shape"])
+    for k in ("submission_shape", "batched"):
+        if full.get(k):
+            line[k] = compact_shape(full[k], keys=("value", "ms_per_step", "ms_per_step_min", "steps", "warmup", "finite"))
     if full.get("bf16"):
         b = compact_shape(full["bf16"])
         if full["bf16"].get("wosac_shape"):
@@ -114,7 +127,7 @@ def judged_line(full):
 
 def shrink(line):
     """Last resort if a line still exceeds the limit (long error strings, a long curve): drop optional objects, largest first."""
-    for k in ("scene_curve", "reduced", "bf16", "roofline_gemm", "wosac_shape", "training"):
+    for k in ("scene_curve", "reduced", "submission_shape", "batched", "bf16", "roofline_gemm", "wosac_shape", "training"):
         if len(json.dumps(line)) < MAX_LINE_BYTES:
             break
         if k in line:
@@ -158,6 +171,8 @@ def emit(full, detail_path=None, out=sys.stdout):
     full["detail_file"] = write_detail(full, detail_path)
     kernel_table("headline", full)
     kernel_table("wosac_shape", full.get("wosac_shape"))
+    kernel_table("submission_shape", full.get("submission_shape"))
+    kernel_table("batched", full.get("batched"))
     kernel_table("training", full.get("training"))
     line = shrink(judged_line(full))
     s = json.dumps(line, allow_nan=False)

@@ -70,7 +70,56 @@ def gpu_rollout_setup(tb, wm, full, args, dev):
     Eng = import_module("trafficbots_amd.utils.rollout_engine").RolloutEngine
     eng = Eng(wm.model, wm.dynamics, dev, schedule=wm.schedule)
     eng.reset(**kw)
+    eng._bench_scene = (bd, kw)  # (rule_check_leg: the scene batch the rule checker's map / light tables come from)
     return eng, t_scene
+
+
+def rule_check_leg(a, wm, eng, use_graph, barrier, reduce_max):
+    """The timed region once more WITH what the reference runs on every step of an inference rollout (waymo_motion.py:250:
+    TrafficRuleChecker.check) and what consumes it (`_filter_futures`, data_modules/wosac_post_processing.py:31-64, when more than 32
+    futures were rolled): W prime steps untimed, then K closed-loop steps + RolloutEngine.buffer(rule_checker=...) - the five
+    metric-only checks over the whole device-resident log as ONE tbx_rule_check launch (+ tbx_rule_accumulate), the log handed out as
+    the reference's RolloutBuffer - + the filter, all inside the clock. -> dict(value, ms_per_step, rule_ms, ...)."""
+    from importlib import import_module as im
+
+    bd, kw = eng._bench_scene
+    R = a.rollouts
+    PP = im("trafficbots_amd.data_modules.wosac_post_processing")
+    post = PP.WOSACPostProcessing(step_gt=90, step_current=a.warmup, const_vel_z_sim=True, const_vel_no_sim=True, w_road_edge=0.5, use_wosac_col=True)
+    role = bd.get("ref/ag_role")
+    if role is None:
+        role = torch.ones(a.scenes, a.agents, 3, dtype=torch.bool, device=eng.dev)
+    dts, rule_ms, viol = [], [], None
+    for rep in range(max(1, a.repeats)):
+        eng.restore()
+        checker = wm._rule_checker(bd, kw["ag_navi"], kw["tl_tokens"], n_rollout=R)
+        checker._setup()  # (the compacted road-edge / lane tables: once per scene, like the map encoder - not per rollout)
+        eng.run(a.warmup, use_graph=use_graph)
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(a.steps, use_graph=use_graph)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        buf = eng.buffer(a.warmup, rule_checker=checker)
+        kept = None
+        if R > post.n_joint_future:
+            buf.flatten_joint_future(R)
+            kept = post._filter_futures(buf, role)
+        e1.record()
+        barrier()
+        dts.append(reduce_max(time.perf_counter() - t0))
+        rule_ms.append(e0.elapsed_time(e1))
+        viol = {k: float(v.float().mean()) for k, v in buf.violation.items() if not k.endswith("_this_step")}
+        if kept is not None:
+            viol["kept_futures"] = int(kept.shape[1])
+    eng.restore()
+    dt = sorted(dts)[len(dts) // 2]
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    units = world * a.scenes * R * a.agents * a.steps
+    return {"value": units / dt, "ms_per_step": dt / a.steps * 1e3, "rule_checks_ms": sorted(rule_ms)[len(rule_ms) // 2],
+            "filter_futures": R > post.n_joint_future, "flag_rates": viol,
+            "note": "K closed-loop steps + RolloutEngine.buffer(rule_checker): tbx_rule_check over every (rollout, step) frame of the log + "
+                    "tbx_rule_accumulate (+ tbx_filter_futures for > 32 futures), timed together; rule_checks_ms = device time of that tail"}
 
 
 def measure(a, tb, hip, dev, rank, world, dist):
@@ -130,6 +179,21 @@ def measure(a, tb, hip, dev, rank, world, dist):
     units = world * a.scenes * a.rollouts * a.agents * a.steps
     timing = {"value": units / dt, "ms_per_step": dt / a.steps * 1e3, "repeats": len(dts), "ms_per_step_min": min(dts) / a.steps * 1e3,
               "ms_per_step_all": [d / a.steps * 1e3 for d in dts], "value_best": units / min(dts)}
+    if getattr(a, "rule_checks", False):
+        def reduce_max(x):
+            if world > 1:
+                t = torch.tensor([x], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            return x
+
+        try:
+            with E.use(wm.schedule):
+                wr = rule_check_leg(a, wm, eng, use_graph, barrier, reduce_max)
+            wr["vs_unchecked"] = wr["value"] / timing["value"]
+            timing["with_rule_checks"] = wr
+        except Exception as e:  # noqa: BLE001 - the headline must still be printed
+            timing["with_rule_checks"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # ---- scene-to-scene reuse (the reference's validation_step loops over scenes, waymo_motion.py:526): NEW scenes through the
     # same engine - once-per-scene encoders + RolloutEngine.refill (in place: the captured graphs stay valid) + the W prime and K
     # closed-loop steps, everything timed; scene tensors resident in HBM as in the headline. No graph capture in this loop.

@@ -7,8 +7,14 @@ FETCH_SIZE tallies the 128-byte read requests of wide coalesced loads at 64 B, s
 bench.py's roofline.traffic reads the file whose `workload` matches the run."""
 import argparse
 import json
+import os
 import re
 import sqlite3
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from tools.benchlib.events import source_sha16  # noqa: E402  (hash of the kernel sources + schedule this pass profiled)
 
 
 def per_kernel(path):
@@ -66,6 +72,9 @@ def main():
     for e in kernels.values():
         e["traffic_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KiB_avg"] + e["WRITE_SIZE_KiB_avg"]) * 1024)
     print(json.dumps({
+        # what was profiled: bench.py's roofline compares this hash with the tree it times (`traffic_matches_build`); the commit the
+        # snapshot was taken from, when the caller exported it (the GPU box has no .git: `TBX_GIT_HEAD=$(git rev-parse HEAD)` in front of gpurun)
+        "source_sha16": source_sha16(), "git_head": os.environ.get("TBX_GIT_HEAD"),
         "collected_with": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (separate passes) -- " + a.cmd,
         "workload": {**{k: getattr(a, k) for k in ("agents", "polylines", "lights", "scenes", "rollouts")}, "kv_bf16": bool(a.kv_bf16)},
         "units": "KiB per launch (rocprofv3 counter definition); traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "

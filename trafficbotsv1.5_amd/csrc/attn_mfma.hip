@@ -28,6 +28,7 @@
 // LDS: one workgroup per CU and ~100-200 spilled registers, 66-147 us per launch against the VALU kernel's 46: the fp32-class path
 // stays tbx_knarpe_attn_fwd.)
 // Results: out [n_rows, ldo >= 640] and row_no_valid exactly as tbx_knarpe_attn_fwd (same layout; different rounding).
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -419,12 +420,18 @@ extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, i
   for (int i = 0; i < n_seg; ++i) shared = shared || segs[i].batch_div > 1;
   a.batch_major = (shared && n_batch % WAVES == 0) ? 1 : 0;
   // persistent: at most 3 workgroups per CU (44 KiB of LDS each, 3 waves per SIMD); each wave walks its slot of quads blockIdx.x + i * grid
-  static const int max_wg = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // (cached per device ordinal: a process that drives several devices must not size device 1's grid by device 0's CU count)
+  static std::atomic<int> wg_cap[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int max_wg = wg_cap[dev].load(std::memory_order_relaxed);
+  if (max_wg <= 0) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("TBX_ATTN_MFMA_WG_PER_CU");
-    return (e && atoi(e) > 0 ? atoi(e) : 3) * (cus > 0 ? cus : 256);
-  }();
+    max_wg = (e && atoi(e) > 0 ? atoi(e) : 3) * (cus > 0 ? cus : 256);
+    wg_cap[dev].store(max_wg, std::memory_order_relaxed);
+  }
   const int n_quads = (a.n_rows + WAVES - 1) / WAVES;
   const dim3 grid((unsigned)(n_quads < max_wg ? n_quads : max_wg)), block(WAVES * 64);
   hipStream_t hs = (hipStream_t)stream;

@@ -166,13 +166,17 @@ class Schedule:
 
     def reduced(self) -> "Schedule":
         """The bf16-ARITHMETIC schedule (BASELINE configs[1] says bf16; the reference runs at precision 16,
-        configs/trainer/default.yaml:16): bfloat16 K/V tables; on launches of >= 193 source rows the attention with bf16 operands on
-        the matrix cores (fp32 accumulation and softmax); in the one-launch decoder layer (launches of <= 256 rows: the closed loop at
-        one or a few scenes) every LINEAR as ONE bf16 product (weights and activations rounded to bfloat16, fp32 accumulation) - as
-        torch's autocast(bfloat16) would run them. K-nearest searches, dynamics, LayerNorms and the tile kernels' LINEAR stages
-        (no faster with one product: profiles/MEASUREMENT_LOG.md) keep their fp32-class arithmetic. Tolerances:
-        tests/test_hip_attn_mfma.py (one call), tests/test_hip_bf16.py (closed loop, teacher-forced + 6 free steps),
-        tests/test_hip_rollout.py (90-step free loop: ADE / FDE / flags)."""
+        configs/trainer/default.yaml:16), as torch's autocast(bfloat16) would run the LINEAR / attention contractions:
+          * bfloat16 K/V tables (every attention call; 529 B per pair);
+          * launches of >= attn_mfma_min_rows (193) source rows: the attention with bf16 operands on the matrix cores, fp32 accumulation
+            and softmax (tbx_knarpe_attn_fwd_mfma); calls outside that kernel's preconditions take the VALU kernel (mfma_attention_ok);
+          * EVERY inference LINEAR as ONE bf16 product (weights and activations rounded to bfloat16, fp32 accumulation): the one-launch
+            decoder layer (dec_layer_mf1_kernel: launches of <= live_max = 384 rows, <= live_max_agents = 192 for the agents' block) and,
+            through hip.tile_products, every tbx_layer_tile / tbx_heads_tile / tbx_window_tile launch (their *_bf16 entry points) - the
+            scene encoders (map, lights' pre-compute) included.
+        K-nearest searches, dynamics, LayerNorms, softmax and the row chains keep fp32. Tolerances against the ORACLE, op by op and closed
+        loop, at the sizes the schedule is quoted on: tests/test_hip_reduced_oracle.py (+ tests/test_hip_attn_mfma.py for the kernel,
+        tests/test_hip_rollout.py / test_hip_boundary.py for the teacher-forced and WOSAC-shape loops); table in DESIGN.md 2."""
         return self.replace(kv_bf16=True, attn_mfma=True, linear_bf16=True)
 
 
@@ -221,11 +225,27 @@ def drop_call(attn):
     return (float(attn.dropout_p), DROP_CTX["seed"], DROP_CTX["call"], 1, DROP_CTX["step"])
 
 
+def mfma_attention_ok(qbuf, q_off: int, qt_off: int, segs, obuf) -> bool:
+    """tbx_knarpe_attn_fwd_mfma's preconditions (csrc/attn_mfma.hip: TBX_ERR_UNSUPPORTED / TBX_ERR_ALIGN cases), checked on the host so
+    that a call outside them takes the VALU kernel instead of raising mid-step: one or two segments of <= 128 targets in all, tables of
+    ONE dtype with 8-element-aligned leading dimension and offsets, 16-byte-aligned bases."""
+    if not (1 <= len(segs) <= 2) or sum(sg.k for sg in segs) > 128:
+        return False
+    if qbuf.stride(0) % 4 or q_off % 4 or qt_off % 4 or obuf.stride(0) % 4 or qbuf.data_ptr() % 16 or obuf.data_ptr() % 16:
+        return False
+    for sg in segs:
+        if sg.kv.dtype != segs[0].kv.dtype or sg.kv.stride(0) % 8 or sg.k_off % 8 or sg.v_off % 8 or sg.kv.data_ptr() % 16:
+            return False
+        if sg.n_tgt * sg.kv.stride(0) * 4 >= 1 << 32:
+            return False
+    return True
+
+
 def attention(qbuf, q_off: int, qt_off: int, attn, n: int, S: int, segs, obuf, flag, fxy, fyw, drop=None, fold=None):
     """One KNARPE attention call (attention_rpe.py:137-190): hip.knarpe_attn, or - large inference launches whose segments are all
     given as relative poses, Schedule.attn_mfma - the matrix-core form (same output rows, its own rounding)."""
     if (current().attn_mfma and drop is None and fold is None and n * S >= current().attn_mfma_min_rows and obuf.shape[1] >= D + NH * D and fxy is not None
-            and all(sg.rel is not None and sg.emb is None for sg in segs)):
+            and all(sg.rel is not None and sg.emb is None for sg in segs) and mfma_attention_ok(qbuf, q_off, qt_off, segs, obuf)):
         hip.knarpe_attn_mfma(qbuf, q_off, qt_off, n, S, segs, obuf, flag, fxy, fyw)
         return
     hip.knarpe_attn(qbuf, q_off, qt_off, attn.linear_rpe.bias, n, S, segs, obuf, flag, fxy, fyw, drop=drop, fold=fold)

@@ -120,8 +120,10 @@ class RolloutEngine:
             else:
                 # refill: the engine's graphs were captured for _tl_div; the new scene's lights must be shared the same way. The
                 # check stays on the device (no host round trip between scenes) and is read when the log is handed out (buffer())
+                # (an engine captured with unshared lights runs a scene whose rollouts DO share them correctly, only without the saving:
+                # nothing to check then)
                 kl = _tl_div
-                self.tl_share_ok = same if kl > 1 else ~same
+                self.tl_share_ok = same if kl > 1 else None
         elif _tl_div is not None:
             kl = _tl_div
         self.tl_div = kl
@@ -257,7 +259,6 @@ class RolloutEngine:
     def refill_commit(self, fresh: "RolloutEngine") -> None:
         """refill_prepare's result into this engine's buffers (the ones its graphs read) + the map K/V tables + the priming of the
         first step. Must follow this engine's previous rollout in stream order."""
-        self.tl_share_ok = fresh.tl_share_ok  # (device flag: checked in buffer(), not here - no host round trip between scenes)
         assert fresh.S.keys() == self.S.keys()
         # every copy of the commit as a few multi-tensor launches (_copy_all) instead of ~80 single ones: 4-8 us each on the stream
         # the next rollout waits on
@@ -272,6 +273,10 @@ class RolloutEngine:
         # this scene's log is still to be handed out)
         if torch.is_tensor(self.tl_invalid_full):
             self.tl_invalid_full = self._own("tl_invalid_full", fresh.tl_invalid_full, pairs)
+        # the device flag of the light-sharing check (read in buffer(): no host round trip between scenes) is engine-owned for the same
+        # reason - `fresh` lives in graph_prepare's pool and the NEXT scene's prefetch rewrites it on the side stream before this
+        # scene's buffer() reads it (the flag read would be the next scene's, or race with its write)
+        self.tl_share_ok = None if fresh.tl_share_ok is None else self._own("tl_share_ok", fresh.tl_share_ok, pairs)
         self.ag_type = self._own("ag_type", fresh.ag_type, pairs)
         self.navi_valid0 = self._own("navi_valid0", fresh.navi_valid0, pairs)
         self.navi_log_prob0 = None if fresh.navi_log_prob0 is None else self._own("navi_log_prob0", fresh.navi_log_prob0, pairs)
@@ -346,7 +351,7 @@ class RolloutEngine:
             self.refill_commit(fresh)
         self.graph_prepare, self.graph_commit, self._fresh_static = ga, gb, fresh
         self.graph_refill = gb
-        self._tl_share_static = self.tl_share_ok  # (device flag of the light-sharing check, rewritten by every replay)
+        self._tl_share_static = self.tl_share_ok  # (the engine-owned device flag of the light-sharing check, rewritten by every graph_commit replay)
         self._ev_prepared = self._ev_committed = None
 
     def prefetch_refill(self, fill_inputs=None) -> None:
