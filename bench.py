@@ -48,7 +48,11 @@ def __getattr__(name):
 
 
 def dry_run(args, rank, world, report):
-    """The launch path without a GPU: rendezvous (gloo), the timing barrier + MAX-reduce of bench.py, a stub line from rank 0."""
+    """The launch path without a GPU: rendezvous (gloo), the sharding of scene ids over the ranks (gathered: disjoint and covering), the
+    timing barrier + MAX-reduce of bench.py, a stub line from rank 0. --mode train additionally runs the training leg's exchange
+    pattern on CPU tensors: every rank builds the default model from its OWN seed, rank 0's parameters are broadcast (checksums then
+    agree on all ranks), and a FlatGrads buffer over the parameters - every gradient set to rank + 1 - goes through the one flat
+    all-reduce of the training step (pl_modules/data_parallel.py), whose result must be the mean (world + 1) / 2 everywhere."""
     import time
 
     import torch
@@ -58,16 +62,50 @@ def dry_run(args, rank, world, report):
         dist.init_process_group("gloo")
     t0 = time.perf_counter()
     ids = shard_scenes(args.scenes * world, rank, world)
+    all_ids = [ids]
     if world > 1:
+        all_ids = [None] * world
+        dist.all_gather_object(all_ids, ids)
         dist.barrier()
+    flat_ids = [i for r in all_ids for i in r]
+    cfg = {"workload": "dry run", "scene_ids_rank0": ids, "scene_ids_per_rank": all_ids,
+           "scene_ids_disjoint_and_covering": sorted(flat_ids) == list(range(args.scenes * world)) and len(set(flat_ids)) == len(flat_ids)}
+    if args.mode == "train":
+        from __graft_entry__ import load_package
+
+        tb = load_package()
+        DP = import_module("trafficbots_amd.pl_modules.data_parallel")
+        W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+        torch.manual_seed(1000 + rank)  # a different initialisation on every rank ...
+        wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+        sent = DP.broadcast_parameters(wm.model)  # ... made rank 0's by one flat broadcast
+        chk = DP.parameters_checksum(wm.model)
+        lo, hi = chk.clone(), chk.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params = [p for p in wm.model.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        fg = DP.FlatGrads(params)
+        nbytes = DP.allreduce_gradients(fg, world)
+        want = (world + 1) / 2.0
+        ok = bool(((fg.flat - want).abs() < 1e-6).all()) and all(bool(((p.grad - want).abs() < 1e-6).all()) for p in params[:4])
+        seeds = [DP.rank_seed(1234, r) for r in range(world)]
+        t_ok = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        cfg.update({"global_batch": world * args.scenes, "parallelism": f"dp{world}", "broadcast_bytes": sent,
+                    "checksum_equal_across_ranks": bool(torch.equal(lo, hi)), "allreduce_bytes": nbytes,
+                    "allreduce_is_the_mean_on_every_rank": bool(t_ok.item() == 1.0), "rank_seeds_distinct": len(set(seeds)) == world})
     t = torch.tensor([time.perf_counter() - t0 + rank], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    cfg["max_rank_seen"] = int(t.item())
     if rank == 0:
-        report.emit({"metric": "dry-run (no GPU work)", "value": 0.0, "unit": "sim-agent-steps/s", "n_gpus": world, "steps": args.steps,
-                     "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                     "dtype": DTYPE_F32, "data": "synthetic", "config": {"workload": "dry run", "scene_ids_rank0": ids, "max_rank_seen": int(t.item())},
-                     "roofline": None}, "-")
+        report.emit({"metric": "dry-run (no GPU work)", "value": 0.0, "unit": "scenes/s" if args.mode == "train" else "sim-agent-steps/s", "n_gpus": world,
+                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                     "dtype": DTYPE_F32, "data": "synthetic", "config": cfg, "roofline": None}, "-")
     if world > 1:
         dist.destroy_process_group()
 

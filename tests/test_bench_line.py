@@ -169,3 +169,33 @@ def test_committed_bench_line_rooflines_reproduce_from_their_own_fields():
     head = line["roofline"]
     if head["kernel"].startswith("dec_layer_mf") and head["source_rows_per_launch"] == 64:
         assert head["algorithmic_bytes_per_launch"] == 7990400  # SURVEY 8d at configs[1]'s agents, nothing added
+
+
+def _dry(argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv, "--dry-run"], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_eight_ranks_dry_run_shards_scenes_disjoint_and_covering():
+    """`python bench.py --gpus 8 --dry-run`: the driver's SCALE invocation minus the GPU - bench.py starts 8 ranks itself, they
+    rendezvous on 127.0.0.1 (gloo), every rank's scene ids are gathered: 8 contiguous disjoint blocks covering 0 .. 8 * S - 1
+    (weak scaling: the data path needs no collective), the wall time is MAX-reduced over all 8."""
+    line = _dry(["--gpus", "8", "--scenes", "3"])
+    c = line["config"]
+    assert line["n_gpus"] == 8 and c["max_rank_seen"] == 7
+    assert c["scene_ids_per_rank"] == [[3 * r, 3 * r + 1, 3 * r + 2] for r in range(8)] and c["scene_ids_disjoint_and_covering"] is True
+
+
+def test_eight_ranks_training_dry_run_broadcast_and_flat_allreduce():
+    """`python bench.py --mode train --gpus 8 --dry-run` (configs[3] minus the GPU): 8 ranks with DIFFERENT initial weights end up with
+    rank 0's after the flat broadcast, and the training step's one flat gradient all-reduce (FlatGrads over the default model's
+    parameters, 42.6 MB here: without a backward pass nothing is excluded yet) returns the mean on every rank."""
+    line = _dry(["--mode", "train", "--gpus", "8"])
+    c = line["config"]
+    assert line["n_gpus"] == 8 and line["unit"] == "scenes/s" and c["global_batch"] == 8 * 16 and c["parallelism"] == "dp8"
+    assert c["scene_ids_disjoint_and_covering"] is True and len(c["scene_ids_per_rank"]) == 8
+    assert c["checksum_equal_across_ranks"] is True and c["allreduce_is_the_mean_on_every_rank"] is True and c["rank_seeds_distinct"] is True
+    assert 42_000_000 < c["allreduce_bytes"] <= 10657094 * 4 and c["broadcast_bytes"] >= c["allreduce_bytes"]  # (the trainable ones of 10,657,094)

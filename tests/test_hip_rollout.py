@@ -100,7 +100,9 @@ def test_reactive_replay_vs_oracle_and_reference(tb, golden_dir, sizes, knn, n_r
 # kernels of the window PointNets / first projections, bf16 tables). Flags, validity and light states must be IDENTICAL; the
 # predicted pose before the override / the action mean carry the bf16 operand rounding (2^-9 per operand through 4 + 4 layers).
 # Bounds = 2 x the largest difference measured on MI355X (printed by the test; profiles/r05_reduced_tolerances.txt).
-REDUCED_TF_ATOL = {(8, 64, 8): 2.4e-2, (64, 1024, 128): 3.2e-2}
+# Measured: 8-agent scene x 90 steps: pose 6.7e-3, motion / action 7.4e-2 (actions reach ~6: 1.2 % of the action scale); configs[1]'s scene
+# x 24 steps: pose 6.1e-3, motion / action 6.1e-2.
+REDUCED_TF_ATOL = {(8, 64, 8): dict(pose=1.4e-2, motion=0.15, action=0.15), (64, 1024, 128): dict(pose=1.3e-2, motion=0.125, action=0.125)}
 
 
 @pytest.mark.parametrize("sched", ["default", "reduced"])
@@ -130,9 +132,13 @@ def test_teacher_forced_replay(tb, sizes, knn, n_roll, sched):
             assert mp["mp_token_feature"].dtype == torch.float32 and wm.model.ag_encoder.kv_mp(mp).dtype == torch.bfloat16
         err = {k: float((x.cpu() - y).abs().max()) for k, x, y in (("pose", buf.pred_pose[:, 0], ro["pred_pose"]), ("motion", buf.pred_motion[:, 0], ro["pred_motion"]),
                                                                      ("action", buf.vis_dict["action"][:, 0], ro["action"]))}
-        print(f"[reduced vs oracle, teacher-forced {sizes} x {n_roll} steps] max |d pose| {err['pose']:.3g}, |d motion| {err['motion']:.3g}, |d action| {err['action']:.3g}")
+        print(f"[reduced vs oracle, teacher-forced {sizes} x {n_roll} steps] max |d pose| {err['pose']:.3g}, |d motion| {err['motion']:.3g}, |d action| {err['action']:.3g}"
+              f" (max |action| {float(ro['action'].abs().max()):.3g})")
         assert max(err.values()) > 1e-5  # the bf16 arithmetic did run
-        _compare(buf, ro, n_roll, REDUCED_TF_ATOL[sizes])
+        assert torch.equal(buf.pred_valid[:, 0].cpu(), ro["pred_valid"]) and torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])
+        assert torch.equal(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]) and torch.equal(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"])
+        for k, bound in REDUCED_TF_ATOL[sizes].items():
+            assert err[k] <= bound, (k, err[k], bound)
         return
     _compare(buf, ro, n_roll, 1e-3)
 
