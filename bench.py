@@ -35,8 +35,7 @@ from tools.benchlib import launch  # noqa: E402
 from tools.benchlib.args import parse, shard_scenes  # noqa: E402,F401  (shard_scenes: tests/test_multiprocess_sharding.py)
 
 DTYPE_F32 = "f32 (split-bf16 MFMA products)"  # every LINEAR of the default schedule = three bf16 MFMA products per fp32 product
-DTYPE_BF16 = ("bf16: K/V tables + matrix-core attention operands (launches >= 193 rows) + one bf16 product per LINEAR of the one-launch decoder "
-              "layer (launches <= 256 rows); f32 (split-bf16 MFMA products) elsewhere")
+DTYPE_BF16 = "bf16 (Schedule.reduced(): bf16 K/V tables + matrix-core attention operands + one bf16 product per LINEAR; fp32 accumulation, softmax, LayerNorm)"
 
 
 def __getattr__(name):
@@ -225,6 +224,13 @@ def main(argv=None):
             full["training"] = training.train_main(tr, tb, dev, rank, world, dist)
         except Exception as e:  # noqa: BLE001
             full["training"] = {"error": f"{type(e).__name__}: {e}"}
+        if tr.train_precision != "fp32":  # the fp32-class parity path beside it (no per-kernel pass)
+            t32 = copy.copy(tr)
+            t32.train_precision, t32.profile_steps = "fp32", 0
+            try:
+                full["training_fp32"] = training.train_main(t32, tb, dev, rank, world, dist)
+            except Exception as e:  # noqa: BLE001
+                full["training_fp32"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             full["cpu_baseline"] = cpu.cpu_baseline(tb, wm, full_batch, args)

@@ -142,6 +142,14 @@ int tbx_knarpe_attn_fwd(const float* qbuf, int ldq, int q_off, int qt_off, const
 int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
                              const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
                              const float* freqs_xy /* [32] */, const float* freqs_yaw /* [64] */, void* stream);
+/* ... with dropout on the attention probabilities (training, attention_rpe.py:171-172) and time-batched keys: the arguments and the
+ * mask of tbx_knarpe_attn_fwd_dropout_tb (below) - (seed, call, scene row, step, target slot, head) -, so the fp32 backward entry points
+ * regenerate exactly the mask this forward applied. The forward of training's attention under the bf16-autocast-class arithmetic. */
+int tbx_knarpe_attn_fwd_mfma_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
+                                        const tbx_attn_seg_t* segs /* host */, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                                        const float* freqs_xy /* [32] */, const float* freqs_yaw /* [64] */, float p_drop,
+                                        const uint64_t* drop_seed /* device */, uint32_t drop_call, int time_batch, int time0,
+                                        void* stream);
 
 /* The forward for launches of a few hundred rows (the closed loop at one or a few scenes: 4 wavefronts share a row), with the
  * value half of `linear_rpe` applied in the epilogue (attention_rpe.py:147,181-182: sum a (v + W_v e + b_v), softmax sums to 1):
@@ -392,6 +400,10 @@ int tbx_front(const tbx_front_t* args /* host */, void* stream);
  * 16-byte aligned. has_bias: add the image's bias. */
 int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                     void* stream);
+/* ... with ONE bf16 product per term (x and W rounded to bfloat16, fp32 accumulation; the lo halves of the image are not read):
+ * F.linear under torch.autocast(bfloat16). Same image, same arguments. */
+int tbx_tall_linear_bf16(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                         void* stream);
 
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
@@ -497,6 +509,11 @@ int tbx_relu_drop_bwd(const float* dh, const float* h, int64_t rows, int cols, f
 int tbx_linear_wgrad_splits(int64_t rows, int n, int k);
 int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
                      float* scratch, int splits, void* stream);
+/* The same with ONE bf16 product per term: dy and x rounded to bfloat16 in registers, fp32 accumulation over the rows (db stays an
+ * exact fp32 sum) - the weight gradient of torch.autocast(bfloat16); the reference trains at precision 16
+ * (configs/trainer/default.yaml:16). Same arguments, scratch and determinism. */
+int tbx_linear_wgrad_bf16(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                          float* scratch, int splits, void* stream);
 
 /* Forward and backward of a LayerNorm over rows of 128 (training; autograd of F.layer_norm at modules/transformer_rpe.py:207-245 - norm1 / norm2 /
  * norm_src / norm_tgt - over the time-batched rows): x, dy, dx [rows, 128] contiguous, gamma [128], mean / rstd [rows] as the forward
@@ -572,6 +589,12 @@ int tbx_train_chain_fwd(const tbx_train_chain_t* c /* host */, const float* mean
                         int t1, void* stream);
 int tbx_train_chain_bwd(const tbx_train_chain_t* c /* host */, const float* mean, int64_t mean_stride_n, int64_t mean_stride_t,
                         const float* d_reward, float* d_mean, void* stream);
+/* tbx_train_chain_fwd over steps [t0, t1) (t0 == t1: no step, `mean` may be NULL) and then the policy inputs of step t1 + 1 in the
+ * layout TrafficBots.agent_policy reads (agent_encoder.py:130-159's windows): hv [n,A,W] u8, hp / hm [n,A,W,3] oldest first, valid /
+ * navi_valid [n,A] bytes - by the thread that owns the agent (the stepping pass's six strided copies per step, waymo_motion.py:206-311
+ * with traffic_bots.py:123-143's history append, in the step's own launch). */
+int tbx_train_chain_fwd_windows(const tbx_train_chain_t* c /* host */, const float* mean, int64_t mean_stride_n, int64_t mean_stride_t, int t0,
+                                int t1, uint8_t* hv, float* hp, float* hm, uint8_t* valid, uint8_t* navi_valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K5/K7/K8/K9 + every dense contraction: a row-tile "chain" interpreter. One workgroup owns a tile of rows and runs

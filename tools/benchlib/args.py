@@ -32,6 +32,9 @@ def parse(argv=None):
     ap.add_argument("--no-train-shape", action="store_true",
                     help="skip the training_step measurement (16 scenes per GPU, fwd+bwd+all-reduce+AdamW) the default run appends")
     ap.add_argument("--no-train-graph", action="store_true", help="training: eager fwd+bwd instead of one hipGraph replay per step")
+    ap.add_argument("--train-precision", choices=("bf16", "fp32"), default="bf16",
+                    help="arithmetic class of the training step's contractions (train_graph.py): bf16 = autocast class (the reference trains at precision 16), "
+                         "fp32 = the fp32-class parity path; the default run reports both (`training`, `training_fp32`)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of that appended measurement (after 3 warm-up steps)")
     ap.add_argument("--kv-bf16", action="store_true", help="bfloat16 K/V tables (BASELINE config 2's dtype; 529 B per attention pair)")
     ap.add_argument("--linear-bf16", type=int, choices=(0, 1), default=1,

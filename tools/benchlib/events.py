@@ -340,11 +340,18 @@ def train_kernel_pass(hip, step, replay_s):
         return f
 
     def wgrad(dy, x, *a, **kw):
-        return T("wgrad_partial_kernel (tbx_linear_wgrad)", "hbm", 4.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]), saved["linear_wgrad"], dy, x, *a, **kw)
+        name = "wgrad_partial_bf16_kernel (tbx_linear_wgrad_bf16)" if kw.get("bf16") else "wgrad_partial_kernel (tbx_linear_wgrad)"
+        return T(name, "hbm", 4.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]), saved["linear_wgrad"], dy, x, *a, **kw)
 
-    def tall(x, w, b=None, wt=False, relu=False):
+    def tall(x, w, b=None, wt=False, relu=False, bf16=False):
         n_, k_ = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
-        return T("tall_linear_kernel (tbx_tall_linear)", "hbm", 4.0 * (x.numel() // k_) * (k_ + n_), saved["tall_linear"], x, w, b, wt=wt, relu=relu)
+        return T("tall_linear_kernel (tbx_tall_linear" + ("_bf16)" if bf16 else ")"), "hbm", 4.0 * (x.numel() // k_) * (k_ + n_), saved["tall_linear"], x, w, b,
+                 wt=wt, relu=relu, bf16=bf16)
+
+    def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, *a, **kw):
+        r, p = pairs(n_batch, n_src, segs)  # (fp32 tables: 1041 B per pair as the VALU forward)
+        return T("knarpe_attn_mfma_kernel (forward, bf16 operands)", "hbm", attn_algorithmic_bytes(r, p), saved["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch,
+                 n_src, segs, *a, **kw)
 
     def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None, rider=None):
         mac = (2 * 128 * 128 if attn is not None else 0) + (2 * 128 * 512 if ffn is not None else 0) + (0 if proj is None else 128 * proj["n"] + 128 * 128)
@@ -362,7 +369,7 @@ def train_kernel_pass(hip, step, replay_s):
         return T("rowchain_kernel (stepping pass)", "mfma", fl, saved["Chain.run"], ch, n_rows, group_rows)
 
     names = {"knarpe_attn": attn, "knarpe_attn_bwd_gather": attn_bwd("knarpe_attn_bwd_gather"), "knarpe_attn_bwd": attn_bwd("knarpe_attn_bwd"),
-             "linear_wgrad": wgrad, "layernorm_fwd": ln_f, "layernorm_bwd": ln_b, "tall_linear": tall, "layer_tile": lt}
+             "linear_wgrad": wgrad, "layernorm_fwd": ln_f, "layernorm_bwd": ln_b, "tall_linear": tall, "layer_tile": lt, "knarpe_attn_mfma": attn_m}
     for n, f in names.items():
         saved[n] = getattr(hip, n)
         setattr(hip, n, f)

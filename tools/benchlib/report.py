@@ -57,7 +57,8 @@ def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps",
     if res.get("scene_reuse"):
         out["new_scene_ms"] = res["scene_reuse"]["new_scene_ms"]
     if res.get("config"):
-        out["workload"] = res["config"].get("workload")
+        wl = res["config"].get("workload") or ""
+        out["workload"] = wl.split(" synthetic")[0] if " synthetic" in wl else wl[:120]  # (the long form is the headline's config.workload)
         for k in ("scenes_per_gpu", "rollouts_per_scene", "global_batch", "parallelism", "allreduce_bytes"):
             if k in res["config"]:
                 out[k] = res["config"][k]
@@ -116,8 +117,12 @@ def judged_line(full):
             r["wosac_shape"] = compact_shape(full["reduced"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"))
         line["reduced"] = r
     if full.get("training"):
-        t = compact_shape(full["training"], keys=("metric", "value", "unit", "ms_per_step", "steps", "warmup", "loss", "finite"))
+        t = compact_shape(full["training"], keys=("metric", "value", "unit", "ms_per_step", "steps", "warmup", "loss", "finite", "dtype"))
+        t["train_precision"] = (full["training"].get("config") or {}).get("train_precision")
         line["training"] = t
+    if full.get("training_fp32"):
+        f32 = full["training_fp32"]
+        line["training_fp32"] = {"error": str(f32["error"])[:200]} if "error" in f32 else {k: f32[k] for k in ("value", "ms_per_step", "steps", "warmup", "loss", "finite") if k in f32}
     if full.get("scene_curve"):
         line["scene_curve"] = [{"scenes": c["scenes"], "value": c["value"], "ms_per_step": c["ms_per_step"]} for c in full["scene_curve"]]
     if full.get("detail_file"):
@@ -127,7 +132,7 @@ def judged_line(full):
 
 def shrink(line):
     """Last resort if a line still exceeds the limit (long error strings, a long curve): drop optional objects, largest first."""
-    for k in ("scene_curve", "reduced", "submission_shape", "batched", "bf16", "roofline_gemm", "wosac_shape", "training"):
+    for k in ("scene_curve", "reduced", "training_fp32", "submission_shape", "batched", "bf16", "roofline_gemm", "wosac_shape", "training"):
         if len(json.dumps(line)) < MAX_LINE_BYTES:
             break
         if k in line:

@@ -19,6 +19,7 @@ def train_main(args, tb, dev, rank, world, dist):
     torch.manual_seed(0)  # the same initial weights on every rank ...
     wm = W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
     wm = wm.to(dev).train()
+    wm.train_precision = getattr(args, "train_precision", None) or "bf16"  # (train_graph.py: "bf16" = autocast-class contractions, "fp32" = the fp32-class path)
     DP.broadcast_parameters(wm.model)  # ... and rank 0's by construction (one flat broadcast, as DDP's constructor does)
     (opt,), _ = wm.configure_optimizers()
     seeds = shard_scenes(args.scenes * world, rank, world)
@@ -70,10 +71,14 @@ def train_main(args, tb, dev, rank, world, dist):
     return {
             "metric": "training scenes/sec", "value": world * args.scenes * args.steps / dt, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (split-bf16 MFMA products in the stepping pass)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("bf16 contractions with fp32 accumulation (autocast class: tall LINEARs, weight gradients, attention forward operands); fp32 LayerNorm / softmax / "
+                      "attention backward / losses / AdamW" if wm.train_precision == "bf16" else "f32 (split-bf16 / exact-fp32 MFMA products, VALU attention)"),
+            "data": "synthetic",
             "config": {"workload": f"training_step fwd+bwd+grad all-reduce+AdamW, {args.scenes} scenes/GPU of {args.agents} agents/"
                                    f"{args.polylines} polylines/{args.lights} lights, 90-step rollout, default 10,657,094-param model",
                        "global_batch": world * args.scenes, "parallelism": f"dp{world}", "fwd_bwd_hipgraph": not args.no_train_graph,
+                       "train_precision": wm.train_precision,
                        "allreduce_bytes": n_live * 4, "note": "time-batched rollout (stepping pass + one differentiated policy batch over the 90 steps); dropout as configured (p=0.1) with keyed masks: residual / FFN / MLP through tbx_keyed_dropout, "
                                                              "attention probabilities inside the HIP attention kernels"},
             "roofline": roof, "kernels": kernels,

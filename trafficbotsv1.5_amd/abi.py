@@ -200,6 +200,8 @@ def load():
     lib.tbx_knarpe_attn_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_folded.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp, vp]
     lib.tbx_knarpe_attn_fwd_mfma.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, vp]
+    lib.tbx_knarpe_attn_fwd_mfma_dropout_tb.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp, vp, vp, f32, vp, C.c_uint32,
+                                                        i32, i32, vp]
     lib.tbx_knarpe_dec_mid.argtypes = [C.POINTER(DecMid), vp]
     lib.tbx_knarpe_dec_layer.argtypes = [C.POINTER(DecLayer), vp]
     lib.tbx_knn_embed_multi.argtypes = [C.POINTER(KnnJob), i32, vp, vp, i32, vp]
@@ -220,6 +222,7 @@ def load():
     lib.tbx_keyed_dropout.argtypes = [vp, vp, i64, i32, i32, f32, vp, C.c_uint32, i32, i32, vp]
     lib.tbx_linear_wgrad_splits.argtypes = [i64, i32, i32]
     lib.tbx_linear_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]
+    lib.tbx_linear_wgrad_bf16.argtypes = lib.tbx_linear_wgrad.argtypes
     lib.tbx_residual_drop_fwd.argtypes = [vp, vp, vp, vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
     lib.tbx_residual_drop_bwd.argtypes = [vp, vp, vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp, vp]
     lib.tbx_relu_drop_fwd.argtypes = [vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
@@ -232,6 +235,7 @@ def load():
     lib.tbx_layernorm_bwd_partials.argtypes = [i64]
     lib.tbx_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_fwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp]
+    lib.tbx_train_chain_fwd_windows.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_bwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, vp, vp, vp]
     lib.tbx_knn_inverse.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.tbx_knarpe_attn_bwd_gather.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(AttnSeg), i32, vp, i32, vp,
@@ -252,6 +256,7 @@ def load():
     lib.tbx_window_tile_bf16.argtypes = [C.POINTER(WindowTile), vp]
     lib.tbx_front.argtypes = [C.POINTER(Front), vp]
     lib.tbx_tall_linear.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp]
+    lib.tbx_tall_linear_bf16.argtypes = lib.tbx_tall_linear.argtypes
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
     lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -269,9 +274,9 @@ def load():
     lib.tbx_rule_check.argtypes = [C.POINTER(RuleCtx), vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.tbx_rule_accumulate.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.tbx_filter_futures.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp]
-    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_linear_wgrad_bf16", "tbx_tall_linear_bf16", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_fwd_windows", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures",
-                 "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma"):
+                 "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma", "tbx_knarpe_attn_fwd_mfma_dropout_tb"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:
         raise ImportError("libtbx_hip.so ABI version mismatch")

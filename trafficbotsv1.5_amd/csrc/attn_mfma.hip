@@ -61,6 +61,13 @@ struct MArgs {
   tbx_attn_seg_t seg[2];
   int ldq, q_off, qt_off, ldo, n_rows, n_src, n_seg, batch_major;
   float scale2;  // log2(e) / sqrt(d_head)
+  // dropout on the attention probabilities (training, attention_rpe.py:171-172): the fields and the key of attn.hip's AttnArgs /
+  // attn_core.h's DropKey - (seed, call, scene row, closed-loop step, global target slot, head) - so that the backward kernels
+  // (tbx_knarpe_attn_bwd_*: they recompute the probabilities and regenerate the mask) drop exactly what this forward dropped
+  const uint64_t* drop_seed;
+  uint32_t drop_call, drop_thresh;
+  float drop_scale;
+  int drop_time_batch, drop_time0;
 };
 
 // 8 consecutive floats as two 16-byte loads (16-byte alignment is all the ABI asks for)
@@ -123,7 +130,7 @@ struct Geom {
 };
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
-template <bool KV16>
+template <bool KV16, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void knarpe_attn_mfma_kernel(const MArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -145,12 +152,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // integer divisions), not once per chunk and request: the scalar unit is shared by the CU's 12 waves, and the per-chunk form of
   // this bookkeeping was ~400 scalar instructions per chunk.
   struct RowCtx {
-    int i, row;             // the wave's i-th row (row < 0: past its last)
+    int i, row, b;          // the wave's i-th row (row < 0: past its last), its batch entry
     const char* kvb[2];     // the segments' tables of this row's batch entry
   };
   auto row_ctx = [&](int i) -> RowCtx {
     RowCtx r;
-    r.i = i, r.row = -1, r.kvb[0] = r.kvb[1] = nullptr;
+    r.i = i, r.row = -1, r.b = 0, r.kvb[0] = r.kvb[1] = nullptr;
     const int q = (int)blockIdx.x + i * (int)gridDim.x;
     if (q >= n_quads) return r;
     int b, row;
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       row = q * WAVES + wave, b = row / a.n_src;
     }
     if (row >= a.n_rows) return r;
-    r.row = row;
+    r.row = row, r.b = b;
     r.kvb[0] = (const char*)a.seg[0].kv + ((int64_t)(b / a.seg[0].batch_div) * a.seg[0].n_tgt * a.seg[0].ld_kv) * EB;
     r.kvb[1] = (const char*)a.seg[1].kv + ((int64_t)(b / a.seg[1].batch_div) * a.seg[1].n_tgt * a.seg[1].ld_kv) * EB;
     return r;
@@ -241,6 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   bf16x8 bqh[8];
   f32x4 acc[4];  // lane l, channel group cg: O[head 0..3][channel cg * 64 + l] of [v | e-positions]
   float m_run = -INFINITY, l_run = 0.f;
+  DropKey dk;
+  dk.lo = dk.hi = dk.krow = 0u;
   // LDS image: 16-byte piece p of row r is stored at piece p ^ ((r >> 1) & 3) (the low two bits): the 8 rows a ds_write_b128 group
   // touches at one column land in 8 distinct 4-bank windows (rows alternate between two 64-byte windows at 576-byte rows); a
   // transposing read's lanes address the same swizzle per row
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int cg = 0; cg < 4; ++cg) acc[cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
       m_run = -INFINITY, l_run = 0.f;
+      if constexpr (DROP) dk.init(a, R.row, R.b);
     }
     // ---- this chunk's V pieces -> the image: register q holds logical piece 4 kb + (m & 3) of row 4 (m >> 2) + q
 #pragma unroll
@@ -339,7 +349,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       p[r] = sc[r] > -INFINITY ? __builtin_amdgcn_exp2f(sc[r] - m_run) : 0.f;
-      l_run += p[r];
+      l_run += p[r];  // (the normaliser is that of the un-dropped softmax)
+    }
+    if constexpr (DROP) {
+      // the lane's 4 weights are targets kb * 4 + r of this chunk for head m (lanes m >= 4 hold padding): global slot = targets of
+      // the earlier segment + the chunk's first target + kb * 4 + r, as attn_core.h's sweep counts them
+      const uint32_t tg = (uint32_t)((c >= nch0 ? a.seg[0].k + (c - nch0) * CHUNK : c * CHUNK) + kb * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = dk.keep(tg + (uint32_t)r, (uint32_t)(m & (NH - 1)), a.drop_thresh) ? p[r] * a.drop_scale : 0.f;
     }
     const bf16x4 pb = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
     const s16x4 pa = __builtin_bit_cast(s16x4, pb);
@@ -393,9 +410,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 }  // namespace
 
-extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
-                                        const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
-                                        const float* freqs_xy, const float* freqs_yaw, void* stream) {
+static int mfma_launch(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src, const tbx_attn_seg_t* segs, int n_seg,
+                       float* out, int ldo, uint8_t* row_no_valid, const float* freqs_xy, const float* freqs_yaw, float p_drop,
+                       const uint64_t* drop_seed, uint32_t drop_call, int time_batch, int time0, void* stream) {
   if (!qbuf || !segs || !out || !row_no_valid || !freqs_xy || !freqs_yaw || n_batch <= 0 || n_src <= 0) return TBX_ERR_ARG;
   if (n_seg < 1 || n_seg > 2 || ldo < D + NH * DR) return TBX_ERR_UNSUPPORTED;
   if ((ldq % 4) || (q_off % 4) || (qt_off % 4) || (ldo % 4) || (((uintptr_t)qbuf) & 15) || (((uintptr_t)out) & 15)) return TBX_ERR_ALIGN;
@@ -416,6 +433,15 @@ extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, i
   a.qbuf = qbuf, a.fxy = freqs_xy, a.fyaw = freqs_yaw, a.out = out, a.row_no_valid = row_no_valid;
   a.ldq = ldq, a.q_off = q_off, a.qt_off = qt_off, a.ldo = ldo, a.n_rows = n_batch * n_src, a.n_src = n_src, a.n_seg = n_seg;
   a.scale2 = 1.4426950408889634f / sqrtf((float)DH);
+  a.drop_seed = drop_seed, a.drop_call = drop_call, a.drop_thresh = 0u, a.drop_scale = 1.f, a.drop_time_batch = time_batch, a.drop_time0 = time0;
+  if (p_drop < 0.f || p_drop >= 1.f || time_batch < 1 || time0 < 0) return TBX_ERR_ARG;
+  if (p_drop > 0.f) {  // (threshold and scale exactly as attn.hip's set_dropout: the backward regenerates the mask from them)
+    if (!drop_seed) return TBX_ERR_ARG;
+    const double th = (double)p_drop * 4294967296.0;
+    a.drop_thresh = th < 1.0 ? 1u : (uint32_t)th;
+    a.drop_scale = 1.0f / (1.0f - p_drop);
+  }
+  const bool drop = a.drop_thresh != 0u;
   bool shared = false;
   for (int i = 0; i < n_seg; ++i) shared = shared || segs[i].batch_div > 1;
   a.batch_major = (shared && n_batch % WAVES == 0) ? 1 : 0;
@@ -436,18 +462,35 @@ extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, i
   const dim3 grid((unsigned)(n_quads < max_wg ? n_quads : max_wg)), block(WAVES * 64);
   hipStream_t hs = (hipStream_t)stream;
   const bool kv16 = segs[0].kv_bf16 != 0;
-#define TBX_MFMA_LAUNCH(KV16F)                                                                                                   \
+#define TBX_MFMA_LAUNCH(KV16F, DROPF)                                                                                            \
   do {                                                                                                                           \
     static tbx::PerDeviceOnce lds_attr;                                                                                          \
     if (!lds_attr([&] {                                                                                                          \
-          return hipFuncSetAttribute((const void*)knarpe_attn_mfma_kernel<KV16F>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+          return hipFuncSetAttribute((const void*)knarpe_attn_mfma_kernel<KV16F, DROPF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      Geom::BYTES) == hipSuccess;                                                                \
         }))                                                                                                                      \
       return TBX_ERR_LAUNCH;                                                                                                     \
-    hipLaunchKernelGGL((knarpe_attn_mfma_kernel<KV16F>), grid, block, Geom::BYTES, hs, a);                                      \
+    hipLaunchKernelGGL((knarpe_attn_mfma_kernel<KV16F, DROPF>), grid, block, Geom::BYTES, hs, a);                               \
   } while (0)
-  if (kv16) TBX_MFMA_LAUNCH(true);
-  else TBX_MFMA_LAUNCH(false);
+  if (kv16 && drop) TBX_MFMA_LAUNCH(true, true);
+  else if (kv16) TBX_MFMA_LAUNCH(true, false);
+  else if (drop) TBX_MFMA_LAUNCH(false, true);
+  else TBX_MFMA_LAUNCH(false, false);
 #undef TBX_MFMA_LAUNCH
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_attn_fwd_mfma(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
+                                        const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                                        const float* freqs_xy, const float* freqs_yaw, void* stream) {
+  return mfma_launch(qbuf, ldq, q_off, qt_off, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid, freqs_xy, freqs_yaw, 0.f, nullptr, 0u, 1, 0,
+                     stream);
+}
+
+extern "C" int tbx_knarpe_attn_fwd_mfma_dropout_tb(const float* qbuf, int ldq, int q_off, int qt_off, int n_batch, int n_src,
+                                                   const tbx_attn_seg_t* segs, int n_seg, float* out, int ldo, uint8_t* row_no_valid,
+                                                   const float* freqs_xy, const float* freqs_yaw, float p_drop, const uint64_t* drop_seed,
+                                                   uint32_t drop_call, int time_batch, int time0, void* stream) {
+  return mfma_launch(qbuf, ldq, q_off, qt_off, n_batch, n_src, segs, n_seg, out, ldo, row_no_valid, freqs_xy, freqs_yaw, p_drop, drop_seed,
+                     drop_call, time_batch, time0, stream);
 }

@@ -23,7 +23,9 @@ namespace {
 constexpr int ROWS = 64;
 typedef Planes<ROWS, 4> PL;
 constexpr int PLANE = PL::PLANE;
-constexpr size_t LDS_BYTES = 2 * 2 * PLANE;  // two buffers of (hi, lo)
+// (TBX_TILE_SINGLE build = tbx_tall_linear_bf16: one product, hi planes and the hi halves of the weight units only)
+constexpr int NPL = TBX_TILE_SINGLE ? 1 : 2;        // planes per buffer: hi (, lo)
+constexpr size_t LDS_BYTES = 2 * NPL * PLANE;       // two buffers
 
 struct TallArgs {
   const float* x;
@@ -69,7 +71,9 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       w.hi[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512);
+#if !TBX_TILE_SINGLE
       w.lo[s] = *(const TBX_GLOBAL bf16x8*)(base + s * 512 + 256);
+#endif
     }
     w.bias = *(const TBX_GLOBAL f32x4*)(base - lane * 4 + 2048 + g * 4);
   };
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
     if (more && next_rb) xp += x_rb, rows_req -= (int)gridDim.x * ROWS;
     if (new_x) request_x(kc2);
     if (more) load_w(nxt, kc2 * T + nb2 * 8);
-    const char* P = lds_c + buf * 2 * PLANE;
+    const char* P = lds_c + buf * NPL * PLANE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int aoff = PL::lane_off(lane, q * 16);
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
       for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc[q], cur.hi[s], cur.lo[s], P + aoff, s);
     }
     if (new_x) {
-      park_x(lds_c + (buf ^ 1) * 2 * PLANE);  // (the other buffer: last read before the previous barrier)
+      park_x(lds_c + (buf ^ 1) * NPL * PLANE);  // (the other buffer: last read before the previous barrier)
       __syncthreads();
       buf ^= 1;
     }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
 
 }  // namespace
 
-extern "C" int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+extern "C" int TBX_TILE_ENTRY(tbx_tall_linear)(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                                void* stream) {
   if (x == nullptr || image == nullptr || y == nullptr || m <= 0) return TBX_ERR_ARG;
   if (k <= 0 || n <= 0 || (k % 128) || (n % 128) || k > 1024 || n > 1024) return TBX_ERR_UNSUPPORTED;

@@ -21,8 +21,19 @@ __device__ __forceinline__ float sl1(float d) {  // F.smooth_l1_loss, beta = 1
 }
 __device__ __forceinline__ float sl1_grad(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
 
+// The policy inputs of the NEXT step in the layout the policy reads them in (tbx_train_chain_fwd_windows): the W-step windows [n, A, W
+// (, 3)], oldest first, and the current validity / navigation flags - written by the thread that owns the agent, behind its step (the
+// stepping pass spent six strided-copy launches per closed-loop step on these).
+struct WinOut {
+  uint8_t* hv;   // [n, A, W]
+  float* hp;     // [n, A, W, 3]
+  float* hm;     // [n, A, W, 3]
+  uint8_t* valid;       // [n, A]
+  uint8_t* navi_valid;  // [n, A]
+};
+
 __global__ __launch_bounds__(64) void train_chain_fwd_kernel(const tbx_train_chain_t c, const float* __restrict__ mean, int64_t sn,
-                                                             int64_t st, int t0, int t1) {
+                                                             int64_t st, int t0, int t1, const WinOut win) {
 #pragma clang fp contract(off)
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
@@ -119,6 +130,35 @@ __global__ __launch_bounds__(64) void train_chain_fwd_kernel(const tbx_train_cha
   c.valid[ia] = valid, c.disabled[ia] = disabled, c.navi_valid[ia] = navi_valid, c.outside[ia] = outside, c.reached[ia] = reached;
   c.pose[ia * 3] = px, c.pose[ia * 3 + 1] = py, c.pose[ia * 3 + 2] = pw;
   c.motion[ia * 3] = mv, c.motion[ia * 3 + 1] = ma, c.motion[ia * 3 + 2] = mw;
+  if (win.hv != nullptr) {
+    // the window of step t1 + 1 = record slots t1 .. t1 + W - 1 (slot W - 1 + s holds the state before step s + 1; this thread wrote
+    // all of its agent's slots: the last one just above, the others in earlier launches)
+    // (all of a chunk's loads first, then its stores: a load -> store -> load chain per slot cost 16 us per launch)
+    const int W = c.window;
+    for (int w0 = 0; w0 < W; w0 += 4) {
+      uint8_t v[4];
+      float p[4][3], m[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int w = w0 + q < W ? w0 + q : W - 1;
+        const int64_t ir = ((int64_t)b * rec_T + (t1 + w)) * A + a;
+        v[q] = c.rec_valid[ir];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[q][k] = c.rec_pose[ir * 3 + k], m[q][k] = c.rec_motion[ir * 3 + k];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (w0 + q >= W) break;
+        const int64_t iw = ia * W + w0 + q;
+        win.hv[iw] = v[q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) win.hp[iw * 3 + k] = p[q][k], win.hm[iw * 3 + k] = m[q][k];
+      }
+    }
+    const int64_t ic = ((int64_t)b * rec_T + (t1 + W - 1)) * A + a;
+    win.valid[ia] = c.rec_valid[ic];
+    win.navi_valid[ia] = c.rec_navi_valid[ic];
+  }
 }
 
 // d(mean) from d(reward), all steps, in reverse. Reads what the forward over [0, T) left behind: the records of the state
@@ -192,8 +232,20 @@ extern "C" int tbx_train_chain_fwd(const tbx_train_chain_t* c, const float* mean
   const int rc = check(c);
   if (rc != TBX_OK) return rc;
   if (!mean || t0 < 0 || t1 > c->n_step || t0 >= t1) return TBX_ERR_ARG;
+  const WinOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(train_chain_fwd_kernel, dim3((c->n_ag + 63) / 64, c->n_batch), dim3(64), 0, (hipStream_t)stream, *c, mean,
-                     mean_stride_n, mean_stride_t, t0, t1);
+                     mean_stride_n, mean_stride_t, t0, t1, none);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_train_chain_fwd_windows(const tbx_train_chain_t* c, const float* mean, int64_t mean_stride_n, int64_t mean_stride_t, int t0,
+                                           int t1, uint8_t* hv, float* hp, float* hm, uint8_t* valid, uint8_t* navi_valid, void* stream) {
+  const int rc = check(c);
+  if (rc != TBX_OK) return rc;
+  if (t0 < 0 || t1 > c->n_step || t0 > t1 || (t0 < t1 && !mean) || !hv || !hp || !hm || !valid || !navi_valid) return TBX_ERR_ARG;
+  const WinOut win = {hv, hp, hm, valid, navi_valid};
+  hipLaunchKernelGGL(train_chain_fwd_kernel, dim3((c->n_ag + 63) / 64, c->n_batch), dim3(64), 0, (hipStream_t)stream, *c, mean,
+                     mean_stride_n, mean_stride_t, t0, t1, win);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

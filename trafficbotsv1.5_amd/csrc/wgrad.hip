@@ -107,6 +107,95 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a
 // built in round 3 and measured slower than the exact-fp32 kernel above: every lane converts 8 rows of its columns per MFMA group and
 // the VALU splits cost what the MFMAs save. git history (wgrad_partial_bf16_kernel), profiles/MEASUREMENT_LOG.md.)
 
+// tbx_linear_wgrad_bf16 (round 5): the same blocks, loads and partial / reduce structure with ONE bf16 product per term - dY and X
+// rounded to bfloat16 in registers (v_cvt_pk_bf16_f32), fp32 accumulation over the rows - what torch's autocast(bfloat16) gives a
+// weight gradient (the reference trains at precision 16, configs/trainer/default.yaml:16). The contraction index of an MFMA is the
+// ROW, and a lane already holds what the instruction wants from it: lane (rr = l >> 4, cq = l & 15) has loaded, for the 4 row groups
+// q = 0..3 of a 16-row stage, rows 4 q + rr of its 4 columns - so component t of its 4 dY float4s IS the A operand A[i = cq][kk =
+// 4 rr + q] of v_mfma_f32_16x16x16_bf16 for the strided tile n = n0 + 4 i + t (the order of the 16 rows inside the contraction is
+// free, and the same for both operands), and component u of its 4 X float4s the B operand. 16 MFMAs + 16 packed conversions per 16
+// rows instead of 64 exact-fp32 MFMAs (8 x fewer matrix-core cycles): the kernel is left with its bytes (dY and X read once).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
+  const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(s16x4, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_partial_bf16_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int gk = blockIdx.x % a.groups_k, gn = blockIdx.x / a.groups_k;
+  const int n0 = (gn * 2 + (wave & 1)) * 64, k0 = (gk * 2 + (wave >> 1)) * 64;
+  if (n0 >= a.n || k0 >= a.k) return;  // no barriers below: a wave may leave
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_split;
+  const int64_t r1 = r0 + a.rows_per_split < a.rows ? r0 + a.rows_per_split : a.rows;
+  const int rr = lane >> 4, c = (lane & 15) * 4;
+  const bool n_ok = n0 + c < a.n, k_ok = k0 + c < a.k;
+  const float* py = a.dy + n0 + c;
+  const float* px = a.x + k0 + c;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = zero;
+  f32x4 bsum = zero;
+  const bool want_db = a.with_db && k0 == 0;
+  f32x4 ya[P], xa[P], yb[P], xb[P];
+  auto load = [&](f32x4(&y)[P], f32x4(&x)[P], int64_t r) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int64_t row = r + q * 4 + rr;
+      const bool live = row < r1;
+      y[q] = (live && n_ok) ? ldg4(py + row * a.ld_dy) : zero;
+      x[q] = (live && k_ok) ? ldg4(px + row * a.ld_x) : zero;
+    }
+  };
+  load(ya, xa, r0);
+  for (int64_t r = r0; r < r1; r += 4 * P) {
+    load(yb, xb, r + 4 * P);
+    if (want_db) bsum += (ya[0] + ya[1]) + (ya[2] + ya[3]);  // (the bias gradient stays an exact fp32 sum)
+    s16x4 ay[4], bx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ay[t] = pack4(ya[0][t], ya[1][t], ya[2][t], ya[3][t]);
+      bx[t] = pack4(xa[0][t], xa[1][t], xa[2][t], xa[3][t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ay[t], bx[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < P; ++q) ya[q] = yb[q], xa[q] = xb[q];
+  }
+  // acc[t][u][reg] at lane l = dW[n0 + 4 ((l >> 4) * 4 + reg) + t][k0 + 4 (l & 15) + u]  (as the fp32 kernel)
+  float* part = a.part + (int64_t)blockIdx.y * ((int64_t)a.n * a.k + a.n);
+  if (k_ok) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + 4 * (rr * 4 + reg) + t;
+        if (n < a.n) {
+          f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+          *(TBX_GLOBAL f32x4*)(part + (int64_t)n * a.k + k0 + c) = v;
+        }
+      }
+  }
+  if (want_db) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = bsum[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      bsum[e] = v;
+    }
+    if (rr == 0 && n_ok) *(TBX_GLOBAL f32x4*)(part + (int64_t)a.n * a.k + n0 + c) = bsum;
+  }
+}
+
 // out[e] = sum_g part[g][e], e < total (dW then db): a workgroup per 64 outputs, its 4 waves take a quarter of the splits each
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t total, int nk,
                                                            float* __restrict__ dw, float* __restrict__ db) {
@@ -154,8 +243,8 @@ extern "C" int tbx_linear_wgrad_splits(int64_t rows, int n, int k) {
   return (int)s;
 }
 
-extern "C" int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
-                                float* scratch, int splits, void* stream) {
+static int wgrad_launch(bool bf16, const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                        float* scratch, int splits, void* stream) {
   if (!dy || !x || !dw || !scratch || rows <= 0 || n <= 0 || k <= 0 || splits <= 0) return TBX_ERR_ARG;
   if ((n & 3) || (k & 3) || (ld_dy & 3) || (ld_x & 3) || ld_dy < n || ld_x < k) return TBX_ERR_UNSUPPORTED;
   if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)scratch)) & 15) return TBX_ERR_ALIGN;
@@ -167,9 +256,20 @@ extern "C" int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int 
   a.with_db = db != nullptr;
   const int groups = ((n + 127) / 128) * a.groups_k;
   hipStream_t hs = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
+  if (bf16) hipLaunchKernelGGL(wgrad_partial_bf16_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
+  else hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
   if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
   const int64_t total = (int64_t)n * k + n;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, hs, scratch, splits, total, n * k, dw, db);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                                float* scratch, int splits, void* stream) {
+  return wgrad_launch(false, dy, ld_dy, x, ld_x, rows, n, k, dw, db, scratch, splits, stream);
+}
+
+extern "C" int tbx_linear_wgrad_bf16(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
+                                     float* scratch, int splits, void* stream) {
+  return wgrad_launch(true, dy, ld_dy, x, ld_x, rows, n, k, dw, db, scratch, splits, stream);
 }

@@ -244,9 +244,9 @@ def mfma_attention_ok(qbuf, q_off: int, qt_off: int, segs, obuf) -> bool:
 def attention(qbuf, q_off: int, qt_off: int, attn, n: int, S: int, segs, obuf, flag, fxy, fyw, drop=None, fold=None):
     """One KNARPE attention call (attention_rpe.py:137-190): hip.knarpe_attn, or - large inference launches whose segments are all
     given as relative poses, Schedule.attn_mfma - the matrix-core form (same output rows, its own rounding)."""
-    if (current().attn_mfma and drop is None and fold is None and n * S >= current().attn_mfma_min_rows and obuf.shape[1] >= D + NH * D and fxy is not None
+    if (current().attn_mfma and fold is None and n * S >= current().attn_mfma_min_rows and obuf.shape[1] >= D + NH * D and fxy is not None
             and all(sg.rel is not None and sg.emb is None for sg in segs) and mfma_attention_ok(qbuf, q_off, qt_off, segs, obuf)):
-        hip.knarpe_attn_mfma(qbuf, q_off, qt_off, n, S, segs, obuf, flag, fxy, fyw)
+        hip.knarpe_attn_mfma(qbuf, q_off, qt_off, n, S, segs, obuf, flag, fxy, fyw, drop=drop)  # (drop: training's stepping pass, keyed mask)
         return
     hip.knarpe_attn(qbuf, q_off, qt_off, attn.linear_rpe.bias, n, S, segs, obuf, flag, fxy, fyw, drop=drop, fold=fold)
 

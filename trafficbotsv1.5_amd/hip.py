@@ -187,17 +187,21 @@ def tall_linear_ok(x: torch.Tensor, k: int, n: int) -> bool:
             and x.stride(-1) == 1 and x.data_ptr() % 16 == 0)
 
 
-def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False) -> torch.Tensor:
-    """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear). wt: w is stored [k x n] (the input gradient
-    dx = dy W of a Linear with weight W [n_out, n_in]: x = dy, w = W, wt = True)."""
+def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False,
+                bf16: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear; bf16: ONE bf16 product per term,
+    tbx_tall_linear_bf16). wt: w is stored [k x n] (the input gradient dx = dy W of a Linear with weight W [n_out, n_in]: x = dy,
+    w = W, wt = True)."""
     n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
     x2 = x.reshape(-1, k)
     if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
         x2 = x2.contiguous()
     img = packed_weight(w, b, wt=wt, mfma32=True)
-    y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device)
-    _check(load().tbx_tall_linear(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
-                                  _ptr(y), n, stream_ptr()), "tbx_tall_linear")
+    y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device) if out is None else out
+    assert y.shape == (x2.shape[0], n) and y.is_contiguous() and y.dtype == torch.float32
+    fn = load().tbx_tall_linear_bf16 if bf16 else load().tbx_tall_linear
+    _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
+              _ptr(y), n, stream_ptr()), "tbx_tall_linear")
     return y.view(*x.shape[:-1], n)
 
 
@@ -208,8 +212,9 @@ def linear_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:
             and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
-    """(dw [n,k], db [n] | None) = (dy^T x, sum_rows dy) for dy [rows,n], x [rows,k] (tbx_linear_wgrad)."""
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True, bf16: bool = False):
+    """(dw [n,k], db [n] | None) = (dy^T x, sum_rows dy) for dy [rows,n], x [rows,k] (tbx_linear_wgrad; bf16: one bf16 product per
+    term with fp32 accumulation, tbx_linear_wgrad_bf16)."""
     rows, n = dy.shape
     k = x.shape[1]
     lib = load()
@@ -219,8 +224,8 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True):
     scratch = torch.empty(splits, n * k + n, dtype=torch.float32, device=dy.device)
     dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
     db = torch.empty(n, dtype=torch.float32, device=dy.device) if want_db else None
-    _check(lib.tbx_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits,
-                                stream_ptr()), "tbx_linear_wgrad")
+    fn = lib.tbx_linear_wgrad_bf16 if bf16 else lib.tbx_linear_wgrad
+    _check(fn(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits, stream_ptr()), "tbx_linear_wgrad")
     return dw, db
 
 
@@ -378,10 +383,19 @@ def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: 
     _check(rc, "tbx_knarpe_attn_fwd")
 
 
-def knarpe_attn_mfma(qbuf, q_off: int, qt_off: int, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid, freqs_xy, freqs_yaw):
+def knarpe_attn_mfma(qbuf, q_off: int, qt_off: int, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid, freqs_xy, freqs_yaw,
+                     drop=None):
     """tbx_knarpe_attn_fwd_mfma: the wave-per-row forward on the bf16 matrix cores (bf16 operands, fp32 accumulation / softmax).
-    Same `out` [rows, >= 640] / row_no_valid as knarpe_attn; segments in the relative-pose form."""
+    Same `out` [rows, >= 640] / row_no_valid as knarpe_attn; segments in the relative-pose form. drop: as knarpe_attn's (training:
+    tbx_knarpe_attn_fwd_mfma_dropout_tb, the same mask as the VALU kernels draw for that key)."""
     arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
+    if drop is not None:
+        p, seed, call, tb, t0 = _drop_args(drop)
+        rc = load().tbx_knarpe_attn_fwd_mfma_dropout_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, n_batch, n_src, arr, len(segs),
+                                                        _ptr(out, torch.float32), out.stride(0), _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy),
+                                                        _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
+        _check(rc, "tbx_knarpe_attn_fwd_mfma_dropout_tb")
+        return
     rc = load().tbx_knarpe_attn_fwd_mfma(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, n_batch, n_src, arr, len(segs),
                                          _ptr(out, torch.float32), out.stride(0), _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy),
                                          _cptr(freqs_yaw), stream_ptr())
@@ -743,6 +757,14 @@ SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE, SIM_NO_DISABLE, SIM_NO_APPEND, SIM_APPEND =
 
 def train_chain_fwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, t0: int, t1: int):
     _check(load().tbx_train_chain_fwd(C.byref(args), _ptr(mean, torch.float32), stride_n, stride_t, t0, t1, stream_ptr()), "tbx_train_chain_fwd")
+
+
+def train_chain_fwd_windows(args: TrainChainArgs, mean: Optional[torch.Tensor], stride_n: int, stride_t: int, t0: int, t1: int, hv, hp, hm, valid, navi_valid):
+    """tbx_train_chain_fwd over [t0, t1) (t0 == t1: none) + the policy inputs of step t1 + 1 into hv u8 [n,A,W], hp / hm f32 [n,A,W,3], valid /
+    navi_valid [n,A] (bool or u8 storage)."""
+    _check(load().tbx_train_chain_fwd_windows(C.byref(args), _cptr(mean, torch.float32), stride_n, stride_t, t0, t1, _ptr(hv, torch.uint8),
+                                              _ptr(hp, torch.float32), _ptr(hm, torch.float32), _ptr(valid), _ptr(navi_valid), stream_ptr()),
+           "tbx_train_chain_fwd_windows")
 
 
 def train_chain_bwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, d_reward: torch.Tensor, d_mean: torch.Tensor):

@@ -35,6 +35,33 @@ from .models.modules.distributions import DestCategorical, DiagGaussian
 D, NH, DH = 128, 4, 32
 
 
+# ------------------------------------------------------------------------------------------------ arithmetic class
+# Precision of the training step's CONTRACTIONS - what torch.autocast would switch (the reference trains at `precision: 16`,
+# configs/trainer/default.yaml:16):
+#   "bf16"  ONE bf16 product per term, fp32 accumulation: F.linear forward / input gradient over >= WGRAD_MIN_ROWS rows
+#           (tbx_tall_linear_bf16), their weight gradients (tbx_linear_wgrad_bf16), the attention forward of the differentiated launches
+#           (>= 193 source rows; tbx_knarpe_attn_fwd_mfma_dropout_tb: bf16 q, qt, K, V, e and softmax weights on the matrix cores). LayerNorm,
+#           softmax, the attention backward (it recomputes the probabilities in fp32 and regenerates the forward's dropout mask), the
+#           elementwise glue, the state machine, the losses and the optimizer stay fp32 - as under autocast. The default.
+#   "fp32"  the fp32-class path of rounds 2-4 (split-bf16 products / exact-fp32 MFMA, VALU attention): the tight-tolerance parity path
+#           (tests/test_hip_training.py runs both against the reference's golden loss / gradient norms).
+# `wm.train_precision` overrides the default for one module; training_step makes it current for its forward (autograd Functions keep
+# the flag they ran their forward with for their backward).
+DEFAULT_PRECISION = os.environ.get("TBX_TRAIN_PRECISION", "bf16")
+_PREC: Optional[str] = None
+
+
+def precision() -> str:
+    return _PREC or DEFAULT_PRECISION
+
+
+def bf16_contractions() -> bool:
+    return precision() == "bf16"
+
+
+ATTN_MFMA_MIN_ROWS = 193  # (the differentiated launches of a training step are 10^4..10^5 rows; the stepping pass - 1024 rows - keeps the VALU ring kernel, see _agent_policy_engine)
+
+
 # ------------------------------------------------------------------------------------------------ dense contractions
 HEADS_TILE = os.environ.get("TBX_HEADS_TILE_TRAIN", "1") != "0"  # the stepping pass's heads as one tbx_heads_tile launch (raw inputs + keyed dropouts)
 TALL_LINEAR = os.environ.get("TBX_TALL_LINEAR", "1") != "0"  # forward / input-gradient products of the time-batched pass on tbx_tall_linear
@@ -51,9 +78,11 @@ class TallLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.bf16 = bf16_contractions()  # (the backward runs after training_step has returned: it keeps the forward's class)
         if TALL_LINEAR and hip.tall_linear_ok(x, w.shape[1], w.shape[0]):
-            # K, N multiples of 128: tbx_tall_linear (split-bf16 matrix path, byte-bound: ~3x the library's exact-fp32 rate)
-            return hip.tall_linear(x, w, b)
+            # K, N multiples of 128: tbx_tall_linear (split-bf16 matrix path, byte-bound: ~3x the library's exact-fp32 rate; one
+            # product under the bf16 class)
+            return hip.tall_linear(x, w, b, bf16=ctx.bf16)
         return F.linear(x, w, b)
 
     @staticmethod
@@ -63,7 +92,7 @@ class TallLinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if TALL_LINEAR and hip.tall_linear_ok(dy, w.shape[0], w.shape[1]):
-                dx = hip.tall_linear(dy, w, None, wt=True)
+                dx = hip.tall_linear(dy, w, None, wt=True, bf16=ctx.bf16)
             else:
                 dx = F.linear(dy, w.t().contiguous())
         dw = db = None
@@ -79,7 +108,7 @@ class TallLinearFn(torch.autograd.Function):
                 if x2.data_ptr() % 16:  # a contiguous view at an odd offset: the kernel reads float4 rows
                     x2 = x2.clone()
                 assert hip.linear_wgrad_ok(dy2, x2)
-            dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b)
+            dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b, bf16=ctx.bf16)
             dw, db = dw[:n, :k], (db[:n] if db is not None else None)
         return dx, dw, db
 
@@ -110,7 +139,16 @@ class KnarpeAttnFn(torch.autograd.Function):
         out = torch.empty(n * S, D + NH * D, dtype=torch.float32, device=qbuf.device)
         flag = torch.empty(n * S, dtype=torch.uint8, device=qbuf.device)
         bias_k = bias_k.contiguous()
-        hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, KnarpeAttnFn._segs(kvs, meta), out, flag, *freqs, drop=drop)
+        segs = KnarpeAttnFn._segs(kvs, meta)
+        mfma = False
+        if bf16_contractions() and n * S >= ATTN_MFMA_MIN_ROWS and freqs[0] is not None and all(sg.rel is not None and sg.emb is None for sg in segs):
+            from . import engine
+
+            mfma = engine.mfma_attention_ok(qbuf, 0, D, segs, out)
+        if mfma:  # bf16 operands on the matrix cores, the VALU kernels' dropout mask; the backward below is the fp32 one either way
+            hip.knarpe_attn_mfma(qbuf, 0, D, n, S, segs, out, flag, *freqs, drop=drop)
+        else:
+            hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, segs, out, flag, *freqs, drop=drop)
         ctx.save_for_backward(qbuf, bias_k, *kvs)
         ctx.meta, ctx.n, ctx.S, ctx.freqs, ctx.drop = meta, n, S, freqs, drop
         ctx.mark_non_differentiable(flag)
@@ -681,8 +719,11 @@ def _agent_policy_engine(model, hv, hp, hm, ag_attr6, ag_type, z, z_valid, dest,
     rc = dict(dest_feature=const("destf", dd, dest_feature)) if HEADS_TILE else None
     engine.DROP_CTX = ctx
     try:
-        model.agent_policy(hv, hp, hm, ag_attr6, type_idx, zz, zi, dd, navi_valid.to(u8).contiguous(), tl_tokens, mp, tl_kv, out,
-                           rollout_consts=rc)
+        # (the stepping pass keeps the VALU ring kernel in both classes: at its 1024 source rows - one row per wavefront, one wavefront
+        # per SIMD - the matrix-core form measured 20.0 us per launch against 17.1, profiles/r05b_train_replay_timeline_bf16.txt; the
+        # two passes then differ by the bf16 operand rounding of the batched forward, ~1e-2 of an action, far below the dropout noise)
+        nv8 = navi_valid.view(u8) if navi_valid.dtype == torch.bool else navi_valid.to(u8)
+        model.agent_policy(hv, hp, hm, ag_attr6, type_idx, zz, zi, dd, nv8.contiguous(), tl_tokens, mp, tl_kv, out, rollout_consts=rc)
     finally:
         engine.DROP_CTX = None
     if ctx is not None:
@@ -762,10 +803,15 @@ class NaviPairFirstLayer(torch.autograd.Function):
         w_c = w_e.contiguous()  # [128 out, 128 k], k-contiguous: the GEMM form the library is fast at (a strided slice of the
         # 384-wide weight sent it to a 1.2 TF/s kernel: 28 ms per training step)
         h = torch.empty(n, A, M, d, dtype=torch.float32, device=rel.device)
+        ctx.bf16 = bf16_contractions()
+        tall = TALL_LINEAR and A * M >= WGRAD_MIN_ROWS and d % 128 == 0 and w_c.shape[1] % 128 == 0
         for i in range(n):
             emb = hip.pose_embed(rel[i].reshape(-1, 3), fxy, fyw, w_c.shape[1])
             hi = h[i].view(A * M, d)
-            torch.mm(emb, w_c.t(), out=hi)
+            if tall:  # (65 k rows x 128 x 128: the tall-LINEAR kernel of the step's arithmetic class)
+                hip.tall_linear(emb, w_c, None, bf16=ctx.bf16, out=hi)
+            else:
+                torch.mm(emb, w_c.t(), out=hi)
             h[i] += pa[i].unsqueeze(1) + pm[i].unsqueeze(0)
         ctx.save_for_backward(rel, w_e, fxy, fyw)
         return h
@@ -778,7 +824,7 @@ class NaviPairFirstLayer(torch.autograd.Function):
         dw = torch.zeros(w_e.shape, dtype=torch.float32, device=dh.device)
         for i in range(n):
             emb = hip.pose_embed(rel[i].reshape(-1, 3), fxy, fyw, w_e.shape[1])
-            dw += hip.linear_wgrad(dh[i].view(A * M, -1), emb, want_db=False)[0]  # dY^T X over 65 k rows: tbx_linear_wgrad
+            dw += hip.linear_wgrad(dh[i].view(A * M, -1), emb, want_db=False, bf16=ctx.bf16)[0]  # dY^T X over 65 k rows: tbx_linear_wgrad
         return None, dw, dh.sum(2), dh.sum(1), None, None
 
 
@@ -983,6 +1029,10 @@ class TrainChain:
             setattr(a, name, v.data_ptr())
         self.args = a
         self.init = (gt_valid[:, :, 0].to(u8), gt_pose[:, :, 0].float(), gt_motion[:, :, 0].float(), gt_valid.any(-1).to(u8))
+        # the policy inputs of the NEXT step, written by the step's own launch (tbx_train_chain_fwd_windows): windows + current flags
+        self.win = dict(hv=z(n, A, W, dt=u8), hp=z(n, A, W, 3), hm=z(n, A, W, 3), valid=torch.zeros(n, A, dtype=torch.bool, device=dev),
+                        navi_valid=torch.zeros(n, A, dtype=torch.bool, device=dev))
+        self._win_step = 0  # the step whose inputs self.win holds (0: none)
         self.reset()
 
     def reset(self) -> None:
@@ -994,11 +1044,20 @@ class TrainChain:
             t[name].zero_()
         t["rec_valid"][:, W - 1].copy_(v), t["rec_pose"][:, W - 1].copy_(p), t["rec_motion"][:, W - 1].copy_(m)
         t["rec_navi_valid"][:, W - 1].copy_(nv)
+        self._emit_windows(None, 0, 0)
+
+    def _emit_windows(self, mean, t0: int, t1: int) -> None:
+        w = self.win
+        hip.train_chain_fwd_windows(self.args, mean, self.A * 2, 0, t0, t1, w["hv"], w["hp"], w["hm"], w["valid"], w["navi_valid"])
+        self._win_step = t1 + 1
 
     def before(self, s: int):
         """Policy inputs of step s (1-based): windows (valid u8 [n,A,W], pose, motion [n,A,W,3]; oldest first) and the current
         (valid bool [n,A], pose [n,A,3], navi_valid bool [n,A])."""
         t, W = self.t, self.W
+        if self._win_step == s:  # written by the launch that ran step s - 1 (or by reset): no copies
+            w = self.win
+            return w["hv"], w["hp"], w["hm"], w["valid"], t["rec_pose"][:, s - 1 + W - 1], w["navi_valid"]
         sl = slice(s - 1, s - 1 + W)
         hv = t["rec_valid"][:, sl].permute(0, 2, 1).contiguous()
         hp = t["rec_pose"][:, sl].permute(0, 2, 1, 3).contiguous()
@@ -1008,7 +1067,7 @@ class TrainChain:
 
     def step(self, s: int, mean: Tensor) -> None:
         mean = mean.detach().reshape(self.n, self.A, 2).contiguous()
-        hip.train_chain_fwd(self.args, mean, self.A * 2, 0, s - 1, s)
+        self._emit_windows(mean, s - 1, s)  # the step + the next step's policy inputs in one launch
 
     def windows(self):
         """All steps' policy inputs in [scene][step] order: (hv [n*T,A,W] u8, hp, hm [n*T,A,W,3], valid [n*T,A] bool, pose
@@ -1226,8 +1285,11 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
     the HIP attention kernels (seed on the device, one call id per attention call of the step). `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
     inputs of a step as device tensors: a captured step (pl_modules/data_parallel.GraphedTrainStep) refills them before
     every replay; left None they are drawn here from the CPU generator like the reference's CPU path does."""
-    global _FOLD_CACHE, _DROP
+    global _FOLD_CACHE, _DROP, _PREC
     _FOLD_CACHE = {}
+    _PREC = getattr(wm, "train_precision", None)
+    if _PREC not in (None, "bf16", "fp32"):
+        raise ValueError(f"train_precision {_PREC!r}: 'bf16' (autocast-class contractions) or 'fp32'")
     if wm.model.training:
         seed = getattr(wm, "attn_dropout_seed", None)  # a captured step owns a static seed tensor and refills it per replay
         if seed is None:
@@ -1237,7 +1299,7 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
-        _FOLD_CACHE, _DROP, hip.PACK_SCOPE = None, None, None
+        _FOLD_CACHE, _DROP, hip.PACK_SCOPE, _PREC = None, None, None, None
 
 
 def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
