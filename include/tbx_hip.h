@@ -308,6 +308,12 @@ int tbx_layer_tile(const tbx_layer_tile_t* args /* host */, void* stream);
 /* The same launch with ONE bf16 product per LINEAR stage (the bf16-arithmetic schedule): weights and activations rounded to bfloat16
  * (2^-9 relative per operand), fp32 accumulation; the same images (their lo halves are not read). Inference only (no dropout sites). */
 int tbx_layer_tile_bf16(const tbx_layer_tile_t* args /* host */, void* stream);
+/* tbx_tl_tail_tile: the traffic lights' tail (tbx_tl_tail_t above: the 4 K/V tables of the agents' light cross-attention,
+ * transformer_rpe.py:220-223 + attention_rpe.py:92-98, and the next-state logits, traffic_light.py:249-286; called at
+ * traffic_bots.py:188-199) on the finished light tokens x [n_rows, 128] for LARGE launches, same arithmetic class as tbx_layer_tile
+ * (_bf16: one bf16 product per LINEAR). Small launches run the same tail inside tbx_knarpe_dec_layer. */
+int tbx_tl_tail_tile(const float* x, int64_t n_rows, const tbx_tl_tail_t* tail /* host */, void* stream);
+int tbx_tl_tail_tile_bf16(const float* x, int64_t n_rows, const tbx_tl_tail_t* tail /* host */, void* stream);
 /* tbx_heads_tile: the agents' heads (traffic_bots.py:206-221) for large launches, same arithmetic class as tbx_layer_tile:
  * x' = x + (navi_valid ? add_navi.mlp([x | navi_emb]) : 0); x'' = x' + (latent_invalid ? 0 : add_latent.mlp([x' | latent_emb]));
  * action_out [n_rows, 2] = sum over the branches g with type_mask[g, row] == 0 of branch_g(x'') (action_head.py:74-100). x is not
@@ -404,6 +410,13 @@ int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const float* imag
  * F.linear under torch.autocast(bfloat16). Same image, same arguments. */
 int tbx_tall_linear_bf16(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                          void* stream);
+/* ... with a second output: the same rows rounded to bfloat16, y16 [m, ldy16] (the K/V table of attention_rpe.py:92-98 in the element type
+ * tbx_knarpe_attn_fwd_mfma gathers fastest, written by the producing LINEAR instead of a conversion pass; the fp32 rows stay for the
+ * backward). Both arithmetic classes. */
+int tbx_tall_linear_dual(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                         uint16_t* y16, int ldy16, void* stream);
+int tbx_tall_linear_dual_bf16(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                              uint16_t* y16, int ldy16, void* stream);
 
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */

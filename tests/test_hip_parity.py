@@ -1120,3 +1120,50 @@ def test_tall_linear_equals_the_library_product(hip, dev, m, k, n, wt, bias):
     assert y.shape == (m, n)
     ratio = float(((y.double() - ref).abs() / bound).max())
     assert 0.0 < ratio < 3e-5, ratio
+
+
+@pytest.mark.parametrize("rows,bf16_tables", [(2048, False), (1031, False), (8192, True), (130, True)])
+def test_tl_tail_tile_equals_the_row_chain(tb, hip, dev, rows, bf16_tables):
+    """tbx_tl_tail_tile (large launches: the lights' tail - the K/V tables of the agents' 4 light cross-attention layers,
+    transformer_rpe.py:220-223 + attention_rpe.py:92-98, and the next-state logits, traffic_light.py:249-286 - as one tile launch on the
+    split-bf16 matrix path) vs the exact-fp32 row chain it replaces (TrafficBots.tl_policy's `tl_tail`): K/V rows within 2e-4 of their
+    largest entry (bf16 tables: + one bf16 rounding of a slightly different fp32 value), logits within 2e-4 of the clamp range, rows
+    of invalid lights exactly 0, the ragged last tile covered; the single-product twin (Schedule.linear_bf16) within 1e-2."""
+    eng = import_module("trafficbots_amd.engine")
+    m = _default_model(tb, dev).model
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 128, generator=g).to(dev)
+    inv = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    d = 128
+    layers = m.ag_encoder.tl_kv_layers()
+    lins = [t[0] for t in m.tl_state_predictor.mlp.linear_layers()]
+    pw = lambda w, b: hip.packed_weight(w, b, mfma32=True)
+    w3, b3 = hip.stacked_linear([lins[2]], pad_out_to=16)
+    outs = {}
+    for name in ("chain", "tile", "tile_bf16"):
+        kv = torch.zeros(rows, 2 * d * len(layers), dtype=torch.bfloat16 if bf16_tables else torch.float32, device=dev)
+        logits = torch.full((rows, 5), 7.0, device=dev)
+        if name == "chain":
+            ch = hip.Chain(16, 4 * d + 4)
+            ch.load(x, hip.BUF1, 0, n=d)
+            eng.emit_kv_tables(ch, layers, kv)
+            m.tl_state_predictor.emit(ch, inv, logits)
+            ch.run(rows)
+        else:
+            lights = dict(kv_images=[pw(at.in_proj_weight[d:], at.in_proj_bias[d:]) for _, at in layers],
+                          norms=[(nm.weight, nm.bias, nm.eps) for nm, _ in layers], kv_out=kv,
+                          mlp_images=[pw(lins[0].weight, lins[0].bias), pw(lins[1].weight, lins[1].bias), pw(w3, b3)], tl_invalid=inv,
+                          logits_out=logits, clamp=(-3.0, 3.0))
+            with eng.use(eng.DEFAULT.replace(linear_bf16=(name == "tile_bf16"))):
+                hip.tl_tail_tile(x, lights)
+        torch.cuda.synchronize()
+        outs[name] = (kv.float(), logits)
+    (kv_c, lg_c), (kv_t, lg_t), (kv_1, lg_1) = outs["chain"], outs["tile"], outs["tile_bf16"]
+    scale = float(kv_c.abs().max())
+    assert scale > 0.1 and float(lg_c.abs().max()) <= 3.0 and float(lg_c[inv.bool()].abs().max()) == 0.0
+    assert float(lg_t[inv.bool()].abs().max()) == 0.0 and float(lg_1[inv.bool()].abs().max()) == 0.0
+    tol_kv = (8e-3 if bf16_tables else 2e-4) * scale  # (bf16 tables: one ulp of bf16 = 2^-8 relative where the fp32 values straddle a rounding boundary)
+    assert float((kv_t - kv_c).abs().max()) <= tol_kv, (float((kv_t - kv_c).abs().max()), scale)
+    assert float((lg_t - lg_c).abs().max()) <= 2e-4 * 3.0
+    assert float((kv_1 - kv_c).abs().max()) <= 1.2e-2 * scale and float((lg_1 - lg_c).abs().max()) <= 1.2e-2 * 3.0
+    assert float((kv_1 - kv_t).abs().max()) > 0.0  # the single-product twin really is other arithmetic

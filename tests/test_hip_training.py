@@ -863,6 +863,12 @@ def test_tall_linear_bf16_vs_float64(tb, m, k, n, wt, bias):
     err = (y.double() - ref).abs()
     print(f"[tall linear bf16 vs float64] m={m} k={k} n={n}: max err / sum |x||w| {float((err / worst).max()):.3g}")
     assert float((err / worst).max()) < 2.0 ** -8 and float((err / worst).max()) > 1e-6
+    # the dual-output form (tbx_tall_linear_dual: the K/V tables' bfloat16 copy written by the producing launch): the same fp32 rows, and
+    # their round-to-nearest-even bfloat16 values
+    for cls in (True, False):
+        y16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        yd = hip.tall_linear(x, w, b, wt=wt, bf16=cls, out16=y16)
+        assert torch.equal(yd, hip.tall_linear(x, w, b, wt=wt, bf16=cls)) and torch.equal(y16, yd.to(torch.bfloat16))
     xb, wb = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
     y1, y3 = hip.tall_linear(xb, wb, b, wt=wt, bf16=True), hip.tall_linear(xb, wb, b, wt=wt, bf16=False)
     assert float(((y1 - y3).abs().double() / (xb.double().abs() @ (wb.double() if wt else wb.double().t()).abs() + 1e-30)).max()) < 2e-6

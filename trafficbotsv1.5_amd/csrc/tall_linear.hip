@@ -33,6 +33,8 @@ struct TallArgs {
   float* y;
   int64_t m;
   int ldx, ldy, k, n, has_bias, relu;
+  uint16_t* y16;  // optional second output: the same rows as bfloat16 [m, ldy16] (the K/V tables the matrix-core attention gathers)
+  int ldy16;
 };
 
 __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
@@ -51,6 +53,8 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   const int64_t x_rb = (int64_t)gridDim.x * ROWS * a.ldx, y_rb = (int64_t)gridDim.x * ROWS * a.ldy;  // to this workgroup's next row block
   const float* xp = a.x + ((int64_t)blockIdx.x * ROWS + lr) * a.ldx + lc;                // the row block whose rows are requested next
   float* yp = a.y + ((int64_t)blockIdx.x * ROWS + j) * a.ldy + 16 * wave + 4 * g;        // the row block being multiplied
+  uint16_t* yh = a.y16 == nullptr ? nullptr : a.y16 + ((int64_t)blockIdx.x * ROWS + j) * a.ldy16 + 16 * wave + 4 * g;
+  const int64_t h16 = 16 * (int64_t)a.ldy16, h_rb = (int64_t)gridDim.x * ROWS * a.ldy16;
   const TBX_GLOBAL float* wq = (const TBX_GLOBAL float*)a.img + (int64_t)wave * UNIT + lane * 4;  // the wave's units; the lane's 16 bytes
   int rows_req = (int)(a.m - (int64_t)blockIdx.x * ROWS);  // rows left from the requested row block on (may exceed 64)
   int rows_cur = rows_req;
@@ -126,9 +130,15 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
         f32x4 v = acc[q].sum();
         if (a.has_bias) v += bias;
         if (a.relu) v = relu4(v);
-        if (q * 16 + j < rows_cur) *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
+        if (q * 16 + j < rows_cur) {
+          *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
+          if (yh != nullptr) *(TBX_GLOBAL u32x2*)(yh + nb * 128 + q * h16) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        }
       }
-      if (next_rb) yp += y_rb, rows_cur -= (int)gridDim.x * ROWS;
+      if (next_rb) {
+        yp += y_rb, rows_cur -= (int)gridDim.x * ROWS;
+        if (yh != nullptr) yh += h_rb;
+      }
     }
     nb = nb2, kc = kc2;
   };
@@ -140,17 +150,29 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
 
 }  // namespace
 
-extern "C" int TBX_TILE_ENTRY(tbx_tall_linear)(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
-                               void* stream) {
+static int tall_launch(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                       uint16_t* y16, int ldy16, void* stream) {
   if (x == nullptr || image == nullptr || y == nullptr || m <= 0) return TBX_ERR_ARG;
   if (k <= 0 || n <= 0 || (k % 128) || (n % 128) || k > 1024 || n > 1024) return TBX_ERR_UNSUPPORTED;
   if (ldx < k || ldy < n || (ldx % 4) || (ldy % 4)) return TBX_ERR_ARG;
   if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)image)) & 15) return TBX_ERR_ALIGN;
-  TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu};
+  if (y16 != nullptr && (ldy16 < n || (ldy16 % 4) || (((uintptr_t)y16) & 7))) return TBX_ERR_ALIGN;
+  TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu, y16, ldy16};
   static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
   if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tall_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const int64_t n_rb = (m + ROWS - 1) / ROWS;
   static const int grid_max = [] { const char* e = getenv("TBX_TALL_GRID"); return e ? atoi(e) : 256; }();  // one workgroup per CU, striding over the row blocks
   hipLaunchKernelGGL(tall_linear_kernel, dim3((unsigned)(n_rb < grid_max ? n_rb : grid_max)), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int TBX_TILE_ENTRY(tbx_tall_linear)(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
+                                               void* stream) {
+  return tall_launch(x, m, k, ldx, image, n, has_bias, relu, y, ldy, nullptr, 0, stream);
+}
+
+extern "C" int TBX_TILE_ENTRY(tbx_tall_linear_dual)(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y,
+                                                    int ldy, uint16_t* y16, int ldy16, void* stream) {
+  if (y16 == nullptr) return TBX_ERR_ARG;
+  return tall_launch(x, m, k, ldx, image, n, has_bias, relu, y, ldy, y16, ldy16, stream);
 }

@@ -82,6 +82,9 @@ class Schedule:
     # ... and, at ANY size, the temporal PointNets of the agents' / lights' windows (tbx_window_tile) and a block's first projection
     # (tbx_layer_tile): at a few hundred rows these are 6-9 dependent stages whose latency the tile kernels cut 3-4x (inference only)
     tile_small: bool = True
+    # launches on the tile path: the lights' tail (K/V tables of the agents' 4 layers + next-state logits) as one tbx_tl_tail_tile launch
+    # instead of a 16-row exact-fp32 row chain (48 us per step at 2,048 light rows, 97 us at 8,192: profiles/r05_s16_kernel_stats.md)
+    tl_tail_tile: bool = True
     prime_graph: bool = True  # RolloutEngine.restore() / refill(): the lights' first pass + first tbx_agent_prep replayed as a graph
     knn_aux_big: bool = True  # large launches: the K-nearest searches on the auxiliary stream beside the window PointNet
     front_big: bool = False  # ... at large launches too - measured SLOWER at the WOSAC shape (6.30 -> 4.56 M agent-steps/s: two pooled rows per
@@ -141,6 +144,7 @@ class Schedule:
             tile_layer=on("TBX_TILE_LAYER"),
             tile_min_rows=num("TBX_TILE_MIN_ROWS", 193),
             tile_small=on("TBX_TILE_SMALL"),
+            tl_tail_tile=on("TBX_TL_TAIL_TILE"),
             prime_graph=on("TBX_PRIME_GRAPH"),
             knn_aux_big=on("TBX_KNN_AUX_BIG"),
             front_big=off("TBX_FRONT_BIG"),
@@ -698,11 +702,15 @@ def run_block(block, x: torch.Tensor, src_invalid: torch.Tensor, n: int, S: int,
             hip.layer_tile(x, attn=tile_attn_part(a_last, obuf, flag), ffn=tile_ffn_part(layer, src_invalid),
                            proj=None if last else tile_proj_part(first_norm(l + 1), first_attn(l + 1), qkv, True, kv16),
                            drop=_tile_drop(next_site(), next_site(), next_site()))
-            if last and tail is not None:  # the caller's row-local stages on the finished rows: a short chain of their own
-                ch = layer_chain(rows)
-                ch.load(x, BUF1, 0, n=D)
-                tail(ch)
-                ch.run(rows)
+            if last and tail is not None:  # the caller's row-local stages on the finished rows
+                lights = (tail_mf() if callable(tail_mf) else tail_mf) if (current().tl_tail_tile and DROP_CTX is None) else None
+                if lights is not None:  # the lights' tail (K/V tables of the agents' layers + next-state logits) as ONE tile launch
+                    hip.tl_tail_tile(x, lights)
+                else:  # ... or a short row chain of their own
+                    ch = layer_chain(rows)
+                    ch.load(x, BUF1, 0, n=D)
+                    tail(ch)
+                    ch.run(rows)
             continue
         ch = layer_chain(rows)
         emit_attn_out(ch, a1, obuf, flag, drop=next_site(), x=x)

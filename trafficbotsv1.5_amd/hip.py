@@ -188,7 +188,7 @@ def tall_linear_ok(x: torch.Tensor, k: int, n: int) -> bool:
 
 
 def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False,
-                bf16: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                bf16: bool = False, out: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear; bf16: ONE bf16 product per term,
     tbx_tall_linear_bf16). wt: w is stored [k x n] (the input gradient dx = dy W of a Linear with weight W [n_out, n_in]: x = dy,
     w = W, wt = True)."""
@@ -199,6 +199,12 @@ def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = No
     img = packed_weight(w, b, wt=wt, mfma32=True)
     y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device) if out is None else out
     assert y.shape == (x2.shape[0], n) and y.is_contiguous() and y.dtype == torch.float32
+    if out16 is not None:  # the same rows as bfloat16 as well (tbx_tall_linear_dual)
+        assert out16.shape == y.shape and out16.dtype == torch.bfloat16 and out16.is_contiguous()
+        fn = load().tbx_tall_linear_dual_bf16 if bf16 else load().tbx_tall_linear_dual
+        _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
+                  _ptr(y), n, _ptr(out16, torch.bfloat16), n, stream_ptr()), "tbx_tall_linear_dual")
+        return y.view(*x.shape[:-1], n)
     fn = load().tbx_tall_linear_bf16 if bf16 else load().tbx_tall_linear
     _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
               _ptr(y), n, stream_ptr()), "tbx_tall_linear")
@@ -466,24 +472,38 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
             keep.next_prep = C.addressof(hd["next_prep"])
         t.heads = C.addressof(keep)
     lt_, keep_l = tail.get("lights"), None
-    if lt_ is not None:  # dict(kv_images[4], norms [(w, b, eps)] * 4, kv_out, mlp_images[3], tl_invalid, logits_out, clamp)
-        keep_l = TlTail()
-        for i in range(4):
-            keep_l.kv_images[i] = _ptr(lt_["kv_images"][i], torch.float32)
-            w_, b_, e_ = lt_["norms"][i]
-            keep_l.norm_weight[i], keep_l.norm_bias[i], keep_l.norm_eps[i] = _ptr(w_, torch.float32), _ptr(b_, torch.float32), float(e_)
-        for i in range(3):
-            keep_l.mlp_images[i] = _ptr(lt_["mlp_images"][i], torch.float32)
-        kvo = lt_["kv_out"]
-        assert kvo.dim() == 2 and kvo.stride(1) == 1 and kvo.shape[0] == x.shape[0]
-        keep_l.kv_out, keep_l.ld_kv, keep_l.kv_bf16 = kvo.data_ptr(), kvo.stride(0), int(kvo.dtype == torch.bfloat16)
-        assert kvo.dtype in (torch.bfloat16, torch.float32)
-        lo = lt_["logits_out"]
-        assert lo.is_contiguous() and lo.shape[0] == x.shape[0]
-        keep_l.tl_invalid, keep_l.logits_out, keep_l.n_state = _cptr(lt_["tl_invalid"], torch.uint8), _ptr(lo, torch.float32), lo.shape[1]
-        keep_l.clamp_lo, keep_l.clamp_hi = (float(v) for v in lt_["clamp"])
+    if lt_ is not None:
+        keep_l = tl_tail_struct(lt_, x.shape[0])
         t.lights = C.addressof(keep_l)
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
+
+
+def tl_tail_struct(lt_: dict, rows: int) -> "TlTail":
+    """tbx_tl_tail_t from dict(kv_images[4], norms [(w, b, eps)] * 4, kv_out, mlp_images[3], tl_invalid, logits_out, clamp)."""
+    keep_l = TlTail()
+    for i in range(4):
+        keep_l.kv_images[i] = _ptr(lt_["kv_images"][i], torch.float32)
+        w_, b_, e_ = lt_["norms"][i]
+        keep_l.norm_weight[i], keep_l.norm_bias[i], keep_l.norm_eps[i] = _ptr(w_, torch.float32), _ptr(b_, torch.float32), float(e_)
+    for i in range(3):
+        keep_l.mlp_images[i] = _ptr(lt_["mlp_images"][i], torch.float32)
+    kvo = lt_["kv_out"]
+    assert kvo.dim() == 2 and kvo.stride(1) == 1 and kvo.shape[0] == rows
+    keep_l.kv_out, keep_l.ld_kv, keep_l.kv_bf16 = kvo.data_ptr(), kvo.stride(0), int(kvo.dtype == torch.bfloat16)
+    assert kvo.dtype in (torch.bfloat16, torch.float32)
+    lo = lt_["logits_out"]
+    assert lo.is_contiguous() and lo.shape[0] == rows
+    keep_l.tl_invalid, keep_l.logits_out, keep_l.n_state = _cptr(lt_["tl_invalid"], torch.uint8), _ptr(lo, torch.float32), lo.shape[1]
+    keep_l.clamp_lo, keep_l.clamp_hi = (float(v) for v in lt_["clamp"])
+    return keep_l
+
+
+def tl_tail_tile(x: torch.Tensor, lights: dict) -> None:
+    """tbx_tl_tail_tile (tbx_tl_tail_tile_bf16 under Schedule.linear_bf16) on the finished light tokens x [rows, 128]."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == 128
+    st = tl_tail_struct(lights, x.shape[0])
+    fn = "tbx_tl_tail_tile_bf16" if tile_products() == 1 else "tbx_tl_tail_tile"
+    _check(getattr(load(), fn)(_ptr(x, torch.float32), x.shape[0], C.byref(st), stream_ptr()), fn)
 
 
 def _layer_tile_args(x, attn=None, ffn=None, proj=None, store_x: bool = True, drop=None, rider=None) -> "LayerTile":

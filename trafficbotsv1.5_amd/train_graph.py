@@ -75,18 +75,28 @@ class TallLinearFn(torch.autograd.Function):
     bias gradient - a reduction over 10^5..10^6 rows into a [n, k] block - is tbx_linear_wgrad (csrc/wgrad.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, want16=False):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         ctx.bf16 = bf16_contractions()  # (the backward runs after training_step has returned: it keeps the forward's class)
         if TALL_LINEAR and hip.tall_linear_ok(x, w.shape[1], w.shape[0]):
             # K, N multiples of 128: tbx_tall_linear (split-bf16 matrix path, byte-bound: ~3x the library's exact-fp32 rate; one
             # product under the bf16 class)
+            if want16:  # a K/V table: the rows as bfloat16 as well, written by the same launch (for the matrix-core attention forward)
+                y16 = torch.empty(*x.shape[:-1], w.shape[0], dtype=torch.bfloat16, device=x.device)
+                y = hip.tall_linear(x, w, b, bf16=ctx.bf16, out16=y16.view(-1, w.shape[0]))
+                ctx.mark_non_differentiable(y16)
+                return y, y16
             return hip.tall_linear(x, w, b, bf16=ctx.bf16)
-        return F.linear(x, w, b)
+        y = F.linear(x, w, b)
+        if want16:
+            y16 = y.to(torch.bfloat16)
+            ctx.mark_non_differentiable(y16)
+            return y, y16
+        return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d16=None):
         x, w = ctx.saved_tensors
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = None
@@ -110,7 +120,7 @@ class TallLinearFn(torch.autograd.Function):
                 assert hip.linear_wgrad_ok(dy2, x2)
             dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b, bf16=ctx.bf16)
             dw, db = dw[:n, :k], (db[:n] if db is not None else None)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -118,6 +128,21 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     if torch.is_grad_enabled() and x.is_cuda and x.numel() // max(x.shape[-1], 1) >= WGRAD_MIN_ROWS and (w.requires_grad or x.requires_grad):
         return TallLinearFn.apply(x, w, b)
     return F.linear(x, w, b)
+
+
+# K/V tables of the current training step that also exist as bfloat16 (made by the launch that made the fp32 rows: tbx_tall_linear_dual):
+# fp32 table's data_ptr -> (the fp32 table - kept alive, so the address stays its own -, the bfloat16 copy). None outside a step.
+_KV16: Optional[dict] = None
+
+
+def linear_kv(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """`linear` for a K/V table: under the bf16 class the rows are also kept as bfloat16 for the matrix-core attention forward."""
+    if (_KV16 is not None and bf16_contractions() and torch.is_grad_enabled() and x.is_cuda
+            and x.numel() // max(x.shape[-1], 1) >= WGRAD_MIN_ROWS and (w.requires_grad or x.requires_grad)):
+        y, y16 = TallLinearFn.apply(x, w, b, True)
+        _KV16[y.data_ptr()] = (y, y16)
+        return y
+    return linear(x, w, b)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -146,6 +171,10 @@ class KnarpeAttnFn(torch.autograd.Function):
 
             mfma = engine.mfma_attention_ok(qbuf, 0, D, segs, out)
         if mfma:  # bf16 operands on the matrix cores, the VALU kernels' dropout mask; the backward below is the fp32 one either way
+            if _KV16 is not None:  # tables that exist as bfloat16 (written by their producing LINEAR): half the gathered bytes
+                k16 = [_KV16.get(kv.data_ptr()) for kv in kvs]
+                if all(e is not None and e[0] is kv or (e is not None and e[0].data_ptr() == kv.data_ptr() and e[0].shape == kv.shape) for e, kv in zip(k16, kvs)):
+                    segs = KnarpeAttnFn._segs([e[1] for e in k16], meta)
             hip.knarpe_attn_mfma(qbuf, 0, D, n, S, segs, out, flag, *freqs, drop=drop)
         else:
             hip.knarpe_attn(qbuf, 0, D, bias_k, n, S, segs, out, flag, *freqs, drop=drop)
@@ -377,8 +406,8 @@ def fold_attention_weights(attn):
 def kv_table(attn, norm, t: Targets) -> Tensor:
     """K|V table [tokens, 256] of a target set for one attention layer (LayerNorm + projection, before the gather)."""
     f = fold_attention_weights(attn)
-    make = lambda: linear(layer_norm(t.tokens, norm) if norm is not None else t.tokens,
-                            f["w_kv"], f["b_kv"])
+    make = lambda: linear_kv(layer_norm(t.tokens, norm) if norm is not None else t.tokens,
+                               f["w_kv"], f["b_kv"])
     if t.cache is None or t.key is None:
         return make()
     k = (t.key, id(attn))
@@ -497,6 +526,9 @@ def mlp(m, x: Tensor, training: bool = False) -> Tensor:
         x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
             x = layer_norm(x, lnm)
+        if act and hip.glue_ok(x):
+            x = relu_drop(x, p, training)  # relu + dropout as ONE launch forward and ONE backward (same site id as _drop's)
+            continue
         if act:
             x = F.relu(x)
         x = _drop(x, p, training)
@@ -1285,8 +1317,8 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
     the HIP attention kernels (seed on the device, one call id per attention call of the step). `noise` [n,A,latent] / `use_prior` (0-d bool tensor) are the two host-drawn random
     inputs of a step as device tensors: a captured step (pl_modules/data_parallel.GraphedTrainStep) refills them before
     every replay; left None they are drawn here from the CPU generator like the reference's CPU path does."""
-    global _FOLD_CACHE, _DROP, _PREC
-    _FOLD_CACHE = {}
+    global _FOLD_CACHE, _DROP, _PREC, _KV16
+    _FOLD_CACHE, _KV16 = {}, {}
     _PREC = getattr(wm, "train_precision", None)
     if _PREC not in (None, "bf16", "fp32"):
         raise ValueError(f"train_precision {_PREC!r}: 'bf16' (autocast-class contractions) or 'fp32'")
@@ -1299,7 +1331,7 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
-        _FOLD_CACHE, _DROP, hip.PACK_SCOPE, _PREC = None, None, None, None
+        _FOLD_CACHE, _DROP, hip.PACK_SCOPE, _PREC, _KV16 = None, None, None, None, None
 
 
 def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
