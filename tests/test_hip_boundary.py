@@ -220,93 +220,106 @@ WOSAC_TOL = {"default": dict(n_cmp=16, free=(4e-4, 2.3e-3), warm=(4e-5, 4e-4), n
              "reduced": dict(n_cmp=13, free=(0.035, 0.24), warm=(0.016, 0.16), nll=0.1)}
 
 
-@pytest.mark.parametrize("sched", ["default", "reduced"])
-def test_wosac_shape_joint_futures_vs_oracle(tb, sched):
+def test_wosac_shape_joint_futures_vs_oracle(tb):
     """BASELINE config 5 at its own size: 32 rollouts x 128 agents / 1024 polylines / 128 lights through
     `joint_future_pred` - map tokens and K/V tables shared by the 32 rollouts (batch_div), lights stepped once per scene
     (share_lights) - vs the oracle's Sim.rollout run rollout by rollout with THAT rollout's sampled latent and destination.
     First 16 steps (10 warm start + 6 free; the loop is chaotic after that); rule flags bit-exact vs the oracle's
-    checks on the logged trajectories."""
+    checks on the logged trajectories. Both schedules (default, Schedule.reduced(): WOSAC_TOL) against the same oracle runs: the
+    sampled latents / destinations are those of the default run (same generator seed: asserted equal)."""
     dev = torch.device(DEV)
-    K, A, T, n_cmp = 32, 128, 16, 16
+    K, A, T = 32, 128, 16
+    SUB = list(range(0, K, 4))
     wm, P, b, bd = _setup(tb, dev, (A, 1024, 128), 32)
-    tol = WOSAC_TOL[sched]
-    if sched == "reduced":
-        wm.schedule = import_module("trafficbots_amd.engine").DEFAULT.reduced()
+    E = import_module("trafficbots_amd.engine")
     D = import_module("trafficbots_amd.models.modules.distributions")
     cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=32), tb.config.default_sim_cfg()
     om = O.TrafficBotsOracle(P, cfg, training=False)
     with torch.no_grad():
         mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
         tl_o = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
-    mp, tl = wm.encode_scene(bd, n_rollout=K)
-    meas, checks = {"nll": 0.0}, []
     dmax = lambda x, y: float((x - y).abs().max())
     valid = bd["sc/ag_valid"].any(-1)
-    lat = D.DiagGaussian(torch.zeros(1, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)  # std-normal prior
     onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], 1024).float()
     wm.hp.joint_future_pred_deterministic_k0 = False
-    torch.manual_seed(21)
-    buf = wm.joint_future_pred(bd, mp, tl, lat, D.DestCategorical(probs=onehot, valid=valid), wm.teacher_forcing_joint_future_pred, K,
-                               step_end=T)
-    eng = wm._engine
-    assert eng.tl_div == K and eng.n == K  # the benchmarked sharing is what ran
-    z_all = eng.ag_latent.view(K, A, 16).cpu()
-    dest_all = eng.dest.cpu()
-    assert float((z_all[0] - z_all[1]).abs().max()) > 0.1
     bh = dict(b)
     bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
     sim = O.Sim(om, scfg, False)
     vc = valid.cpu()
-    for k in (0, 13, 31):
-        with torch.no_grad():
-            ro = sim.rollout(bh, mp_o, tl_o, z_all[k:k + 1], vc, dest_all[k:k + 1], vc, scfg.teacher_forcing_joint_future_pred, T,
-                             gt_prefix="hist", tl_gt_key="sc/tl_state")
-        for h in (10, 13, 16):  # what the test measured, per horizon (printed below)
-            hs = slice(0, h)
-            meas[f"pose{h}"] = max(meas.get(f"pose{h}", 0.0), dmax(buf.pred_pose[:, k, :, hs].cpu(), ro["pred_pose"][:, :, hs]))
-            meas[f"action{h}"] = max(meas.get(f"action{h}", 0.0), dmax(buf.vis_dict["action"][:, k, :, hs].cpu(), ro["action"][:, :, hs]))
-        meas["nll"] = max(meas["nll"], dmax(buf.tl_state_nll[:, k, :, :16].cpu(), ro["tl_state_nll"][:, :, :16]))
-        checks.append((k, ro))
-    print(f"[wosac shape vs oracle, {sched}] 3 rollouts, max |d pose| / |d action| over the first 10 / 13 / 16 steps: "
-          + " ; ".join(f"{meas[f'pose{h}']:.3g} / {meas[f'action{h}']:.3g}" for h in (10, 13, 16)) + f"; |d nll| {meas['nll']:.3g}")
-    n_cmp = tol["n_cmp"]
-    for k, ro in checks:
-        sl = slice(0, n_cmp)
-        assert torch.equal(buf.pred_valid[:, k, :, sl].cpu(), ro["pred_valid"][:, :, sl]), k
-        assert torch.equal(buf.vis_dict["tl_state"][:, k, :, sl].cpu(), ro["tl_state"][:, :, sl]), k
-        assert torch.equal(buf.violation["outside_map"][:, k, :, sl].cpu(), ro["outside_map"][:, :, sl]), k
-        torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["free"][0])
-        torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=tol["free"][1])
-        torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=tol["nll"])
-    # ALL 32 rollouts over the 10 warm-start steps (poses are teacher-forced there, so the oracle runs the 32 rollouts as one
-    # batch of 32 scene copies, each with its rollout's latent and destination): every rollout's action means and light states
-    rep = lambda t: t.repeat_interleave(K, 0) if torch.is_tensor(t) and t.shape[0] == 1 else t
-    bK = {k: rep(v) for k, v in bh.items()}
-    mpK = {k: rep(v) for k, v in mp_o.items()}
-    tlK = {k: rep(v) for k, v in tl_o.items()}
-    with torch.no_grad():
-        roK = sim.rollout(bK, mpK, tlK, z_all, vc.expand(K, -1), dest_all, vc.expand(K, -1), scfg.teacher_forcing_joint_future_pred, 10,
-                          gt_prefix="hist", tl_gt_key="sc/tl_state")
-    sl = slice(0, 10)
-    assert torch.equal(buf.pred_valid[0, :, :, sl].cpu(), roK["pred_valid"][:, :, sl])
-    assert torch.equal(buf.vis_dict["tl_state"][0, :, :, sl].cpu(), roK["tl_state"][:, :, sl])
-    print(f"[wosac shape vs oracle, {sched}] 10 warm-start steps of all 32: |d pose| {dmax(buf.pred_pose[0, :, :, sl].cpu(), roK['pred_pose'][:, :, sl]):.3g}, "
-          f"|d action| {dmax(buf.vis_dict['action'][0, :, :, sl].cpu(), roK['action'][:, :, sl]):.3g}")
-    torch.testing.assert_close(buf.pred_pose[0, :, :, sl].cpu(), roK["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["warm"][0])
-    torch.testing.assert_close(buf.vis_dict["action"][0, :, :, sl].cpu(), roK["action"][:, :, sl], rtol=1e-3, atol=tol["warm"][1])
-    assert float((roK["action"][0] - roK["action"][1]).abs().max()) > 1e-3  # the rollouts' policies do differ (their latents do)
-    # rule flags of three rollouts, bit-exact against the oracle's checks on the logged trajectories
-    ks = [0, 13, 31]
-    r = lambda t: t.repeat_interleave(len(ks), 0).cpu()
-    o = R.RuleCheckOracle(r(b["map/valid"]), r(b["map/type"]), r(b["map/pos"]), r(b["map/dir"]), r(b["ref/ag_type"]), r(b["ref/ag_size"]),
-                          tl["tl_token_valid"][ks].cpu(), tl["tl_token_pose"][ks].cpu())
-    pick = lambda t: t[0, ks].cpu()
-    pv, pp, pm, ts = pick(buf.pred_valid), pick(buf.pred_pose), pick(buf.pred_motion), pick(buf.vis_dict["tl_state"])
-    for t in range(T):
-        v = o.check(pv[:, :, t], pp[:, :, t], pm[:, :, t], ts[:, :, t])
-        for key, x in v.items():
-            assert torch.equal(pick(buf.violation[key])[:, :, t], x), (key, t)
+    oracle = {}  # (the oracle's rollouts: made once, from the first schedule's sampled latents / destinations)
+    for sched in ("default", "reduced"):
+        tol = WOSAC_TOL[sched]
+        wm.schedule = E.DEFAULT if sched == "default" else E.DEFAULT.reduced()
+        wm.engine_cache = 0
+        mp, tl = wm.encode_scene(bd, n_rollout=K)
+        lat = D.DiagGaussian(torch.zeros(1, A, 16, device=dev), torch.zeros(16, device=dev), valid=valid)  # std-normal prior
+        torch.manual_seed(21)
+        buf = wm.joint_future_pred(bd, mp, tl, lat, D.DestCategorical(probs=onehot, valid=valid), wm.teacher_forcing_joint_future_pred, K,
+                                   step_end=T)
+        eng = wm._engine
+        assert eng.tl_div == K and eng.n == K  # the benchmarked sharing is what ran
+        z_all = eng.ag_latent.view(K, A, 16).cpu()
+        dest_all = eng.dest.cpu()
+        assert float((z_all[0] - z_all[1]).abs().max()) > 0.1
+        if not oracle:
+            oracle["z"], oracle["dest"] = z_all, dest_all
+            for k in (0, 13, 31):
+                with torch.no_grad():
+                    oracle[k] = sim.rollout(bh, mp_o, tl_o, z_all[k:k + 1], vc, dest_all[k:k + 1], vc, scfg.teacher_forcing_joint_future_pred, T,
+                                            gt_prefix="hist", tl_gt_key="sc/tl_state")
+            # EVERY 4TH of the 32 rollouts over the 10 warm-start steps (poses are teacher-forced there, so the oracle runs them as one batch
+            # of 8 scene copies, each with its rollout's latent and destination - all 32 cost the CPU oracle two minutes): action means and
+            # light states of rollouts 0, 4, .., 28 beside the three full rollouts above
+            rep = lambda t: t.repeat_interleave(len(SUB), 0) if torch.is_tensor(t) and t.shape[0] == 1 else t
+            bK = {k: rep(v) for k, v in bh.items()}
+            mpK = {k: rep(v) for k, v in mp_o.items()}
+            tlK = {k: rep(v) for k, v in tl_o.items()}
+            with torch.no_grad():
+                oracle["K"] = sim.rollout(bK, mpK, tlK, z_all[SUB], vc.expand(len(SUB), -1), dest_all[SUB], vc.expand(len(SUB), -1),
+                                          scfg.teacher_forcing_joint_future_pred, 10, gt_prefix="hist", tl_gt_key="sc/tl_state")
+        else:  # the same samples under both schedules (the generator, not the arithmetic, draws them)
+            assert torch.equal(z_all, oracle["z"]) and torch.equal(dest_all, oracle["dest"])
+        meas = {"nll": 0.0}
+        for k in (0, 13, 31):
+            ro = oracle[k]
+            for h in (10, 13, 16):  # what the test measured, per horizon (printed below)
+                hs = slice(0, h)
+                meas[f"pose{h}"] = max(meas.get(f"pose{h}", 0.0), dmax(buf.pred_pose[:, k, :, hs].cpu(), ro["pred_pose"][:, :, hs]))
+                meas[f"action{h}"] = max(meas.get(f"action{h}", 0.0), dmax(buf.vis_dict["action"][:, k, :, hs].cpu(), ro["action"][:, :, hs]))
+            meas["nll"] = max(meas["nll"], dmax(buf.tl_state_nll[:, k, :, :16].cpu(), ro["tl_state_nll"][:, :, :16]))
+        print(f"[wosac shape vs oracle, {sched}] 3 rollouts, max |d pose| / |d action| over the first 10 / 13 / 16 steps: "
+              + " ; ".join(f"{meas[f'pose{h}']:.3g} / {meas[f'action{h}']:.3g}" for h in (10, 13, 16)) + f"; |d nll| {meas['nll']:.3g}")
+        n_cmp = tol["n_cmp"]
+        for k in (0, 13, 31):
+            ro = oracle[k]
+            sl = slice(0, n_cmp)
+            assert torch.equal(buf.pred_valid[:, k, :, sl].cpu(), ro["pred_valid"][:, :, sl]), k
+            assert torch.equal(buf.vis_dict["tl_state"][:, k, :, sl].cpu(), ro["tl_state"][:, :, sl]), k
+            assert torch.equal(buf.violation["outside_map"][:, k, :, sl].cpu(), ro["outside_map"][:, :, sl]), k
+            torch.testing.assert_close(buf.pred_pose[:, k, :, sl].cpu(), ro["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["free"][0])
+            torch.testing.assert_close(buf.vis_dict["action"][:, k, :, sl].cpu(), ro["action"][:, :, sl], rtol=1e-3, atol=tol["free"][1])
+            torch.testing.assert_close(buf.tl_state_nll[:, k, :, sl].cpu(), ro["tl_state_nll"][:, :, sl], rtol=1e-3, atol=tol["nll"])
+        roK = oracle["K"]
+        sl = slice(0, 10)
+        assert torch.equal(buf.pred_valid[0, SUB, :, sl].cpu(), roK["pred_valid"][:, :, sl])
+        assert torch.equal(buf.vis_dict["tl_state"][0, SUB, :, sl].cpu(), roK["tl_state"][:, :, sl])
+        print(f"[wosac shape vs oracle, {sched}] 10 warm-start steps of 8 of the 32 rollouts: |d pose| {dmax(buf.pred_pose[0, SUB, :, sl].cpu(), roK['pred_pose'][:, :, sl]):.3g}, "
+              f"|d action| {dmax(buf.vis_dict['action'][0, SUB, :, sl].cpu(), roK['action'][:, :, sl]):.3g}")
+        torch.testing.assert_close(buf.pred_pose[0, SUB, :, sl].cpu(), roK["pred_pose"][:, :, sl], rtol=1e-4, atol=tol["warm"][0])
+        torch.testing.assert_close(buf.vis_dict["action"][0, SUB, :, sl].cpu(), roK["action"][:, :, sl], rtol=1e-3, atol=tol["warm"][1])
+        assert torch.isfinite(buf.pred_pose).all() and torch.isfinite(buf.vis_dict["action"]).all()  # (all 32)
+        assert float((roK["action"][0] - roK["action"][1]).abs().max()) > 1e-3  # the rollouts' policies do differ (their latents do)
+        # rule flags of three rollouts, bit-exact against the oracle's checks on the logged trajectories
+        ks = [0, 13, 31]
+        r = lambda t: t.repeat_interleave(len(ks), 0).cpu()
+        o = R.RuleCheckOracle(r(b["map/valid"]), r(b["map/type"]), r(b["map/pos"]), r(b["map/dir"]), r(b["ref/ag_type"]), r(b["ref/ag_size"]),
+                              tl["tl_token_valid"][ks].cpu(), tl["tl_token_pose"][ks].cpu())
+        pick = lambda t: t[0, ks].cpu()
+        pv, pp, pm, ts = pick(buf.pred_valid), pick(buf.pred_pose), pick(buf.pred_motion), pick(buf.vis_dict["tl_state"])
+        for t in range(T):
+            v = o.check(pv[:, :, t], pp[:, :, t], pm[:, :, t], ts[:, :, t])
+            for key, x in v.items():
+                assert torch.equal(pick(buf.violation[key])[:, :, t], x), (key, t)
 
 
 def test_c2_free_rollout_80_steps_damped_policy(tb):
@@ -339,6 +352,22 @@ def test_c2_free_rollout_80_steps_damped_policy(tb):
     buf.flatten_joint_future(1)
     _compare(buf, ro, T, 5e-3)
     torch.testing.assert_close(buf.tl_state_nll[:, 0].cpu(), ro["tl_state_nll"], rtol=1e-3, atol=1e-4)
+    # ---- the same loop under the bf16-arithmetic schedule (Schedule.reduced()) against the SAME oracle run: with the damped head the loop
+    # does not amplify, so it is compared point-wise over all 90 steps - validity, flags and light states identical, poses / motion /
+    # actions within <= 2 x measured (0.184 m-or-rad / 0.0215 / 0.0194 on MI355X; profiles/r05_reduced_tolerances.txt)
+    wm.schedule = import_module("trafficbots_amd.engine").DEFAULT.reduced()
+    wm.engine_cache = 0
+    mp, tl = wm.encode_scene(bd)
+    buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
+                     wm._rule_checker(bd, bd["gt/ag_navi"], tl), T, True)
+    buf.flatten_joint_future(1)
+    dmax = lambda x, y: float((x.cpu() - y).abs().max())
+    print(f"[C2 damped 90-step loop, reduced vs oracle] max |d pose| {dmax(buf.pred_pose[:, 0], ro['pred_pose']):.3g}, |d motion| "
+          f"{dmax(buf.pred_motion[:, 0], ro['pred_motion']):.3g}, |d action| {dmax(buf.vis_dict['action'][:, 0], ro['action']):.3g}")
+    assert torch.equal(buf.pred_valid[:, 0].cpu(), ro["pred_valid"]) and torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])
+    assert torch.equal(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]) and torch.equal(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"])
+    assert dmax(buf.pred_pose[:, 0], ro["pred_pose"]) <= 0.37 and dmax(buf.pred_motion[:, 0], ro["pred_motion"]) <= 0.045
+    assert dmax(buf.vis_dict["action"][:, 0], ro["action"]) <= 0.04
 
 
 @pytest.mark.parametrize("sizes,knn,K", [((8, 64, 8), 4, 1), ((16, 64, 8), 4, 4)])

@@ -363,51 +363,3 @@ def test_c2_free_rollout_90_steps_contractive_weights_acceptance(tb):
         ade_max, fde_max, flags_min = C2_ACCEPT[name]
         assert ade < ade_max and fde < fde_max and flags >= flags_min, (name, ade, fde, flags)
         assert tl_agree >= (1.0 if name != "reduced" else 0.999), (name, tl_agree)
-
-
-REDUCED_DAMPED_ATOL = dict(pose=0.37, motion=0.045, action=0.04)  # measured over the 90 steps: 0.184 m-or-rad / 0.0215 / 0.0194
-
-
-def test_c2_free_rollout_80_steps_damped_policy_reduced_schedule(tb):
-    """test_hip_boundary.py::test_c2_free_rollout_80_steps_damped_policy under Schedule.reduced(): with the action head's output layer
-    x 0.02 the loop does not amplify, so the bf16-arithmetic rollout is compared with the oracle POINT-WISE over all 90 steps:
-    validity, flags and light states identical, poses / motion / actions within the stated bound."""
-    dev = torch.device(DEV)
-    E = import_module("trafficbots_amd.engine")
-    wm, P, b, bd = _setup(tb, dev, (64, 1024, 128), 32)
-    wm.schedule = E.DEFAULT.reduced()
-    with torch.no_grad():
-        for k, p in wm.model.state_dict().items():
-            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
-                p.mul_(0.02)
-                P[k] = P[k] * 0.02
-    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=32), tb.config.default_sim_cfg()
-    om = O.TrafficBotsOracle(P, cfg, training=False)
-    with torch.no_grad():
-        mp_o = om.mp_encoder(b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"])
-        tl_o = om.tl_pre_compute(b["sc/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], **mp_o)
-    g = torch.Generator().manual_seed(0)
-    z = torch.randn(1, 64, 16, generator=g)
-    valid = b["sc/ag_valid"].any(-1)
-    bh = dict(b)
-    bh["hist/ag_valid"], bh["hist/ag_pose"], bh["hist/ag_motion"] = b["sc/ag_valid"], b["sc/ag_pose"], b["sc/ag_motion"]
-    T = 90
-    with torch.no_grad():
-        ro = O.Sim(om, scfg, False).rollout(bh, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, scfg.teacher_forcing_joint_future_pred, T,
-                                            gt_prefix="hist", tl_gt_key="sc/tl_state")
-    mp, tl = wm.encode_scene(bd)
-    ag_tokens = {"ag_type": bd["ref/ag_type"], "ag_size": bd["ref/ag_size"], "ag_attr": bd["sc/ag_attr"], "gt_valid": bd["sc/ag_valid"],
-                 "gt_pose": bd["sc/ag_pose"], "gt_motion": bd["sc/ag_motion"], "ag_latent": z.to(dev), "ag_latent_valid": valid.to(dev),
-                 "ag_navi": bd["gt/ag_navi"], "ag_navi_valid": valid.to(dev)}
-    buf = wm.rollout(ag_tokens, mp, tl, bd["sc/tl_state"], wm.teacher_forcing_joint_future_pred,
-                     wm._rule_checker(bd, bd["gt/ag_navi"], tl), T, True)
-    buf.flatten_joint_future(1)
-    dmax = lambda x, y: float((x.cpu() - y).abs().max())
-    print(f"[C2 damped 90-step loop, reduced vs oracle] max |d pose| {dmax(buf.pred_pose[:, 0], ro['pred_pose']):.3g}, |d motion| "
-          f"{dmax(buf.pred_motion[:, 0], ro['pred_motion']):.3g}, |d action| {dmax(buf.vis_dict['action'][:, 0], ro['action']):.3g}")
-    assert torch.equal(buf.pred_valid[:, 0].cpu(), ro["pred_valid"])
-    assert torch.equal(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]) and torch.equal(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"])
-    assert torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])
-    assert dmax(buf.pred_pose[:, 0], ro["pred_pose"]) <= REDUCED_DAMPED_ATOL["pose"]
-    assert dmax(buf.pred_motion[:, 0], ro["pred_motion"]) <= REDUCED_DAMPED_ATOL["motion"]
-    assert dmax(buf.vis_dict["action"][:, 0], ro["action"]) <= REDUCED_DAMPED_ATOL["action"]

@@ -105,15 +105,13 @@ def test_reactive_replay_vs_oracle_and_reference(tb, golden_dir, sizes, knn, n_r
 REDUCED_TF_ATOL = {(8, 64, 8): dict(pose=1.4e-2, motion=0.15, action=0.15), (64, 1024, 128): dict(pose=1.3e-2, motion=0.125, action=0.125)}
 
 
-@pytest.mark.parametrize("sched", ["default", "reduced"])
 @pytest.mark.parametrize("sizes,knn,n_roll", [((8, 64, 8), 4, 90), ((64, 1024, 128), 32, 24)])
-def test_teacher_forced_replay(tb, sizes, knn, n_roll, sched):
+def test_teacher_forced_replay(tb, sizes, knn, n_roll):
     """(a) every agent valid and teacher-forced at every step (no free-running agent anywhere in the scene): each step's
-    policy + dynamics + override pipeline on realistic states, whole horizon, tight tolerance."""
+    policy + dynamics + override pipeline on realistic states, whole horizon, tight tolerance - for the default schedule and for the
+    bf16-arithmetic schedule (Schedule.reduced(), bounds above) against ONE oracle run."""
     dev = torch.device("cuda:0")
     wm, P, b, bd = _setup(tb, dev, sizes, knn, ragged=False)
-    if sched == "reduced":
-        wm.schedule = import_module("trafficbots_amd.engine").DEFAULT.reduced()
     cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=knn), tb.config.default_sim_cfg()
     om = O.TrafficBotsOracle(P, cfg, training=False)
     mp_o, tl_o = _oracle_tokens(om, b)
@@ -124,10 +122,15 @@ def test_teacher_forced_replay(tb, sizes, knn, n_roll, sched):
     with torch.no_grad():
         ro = O.Sim(om, scfg, False).rollout(b, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, tf_all, n_roll)
     TF = import_module("trafficbots_amd.utils.teacher_forcing").TeacherForcing
-    mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
-    buf = wm.reactive_replay(bd, mp, tl, z.to(dev), valid.to(dev), bd["gt/ag_navi"], valid.to(dev), TF(**tf_all), True, step_end=n_roll)
-    if sched == "reduced":
-        E = import_module("trafficbots_amd.engine")
+    E = import_module("trafficbots_amd.engine")
+    for sched in ("default", "reduced"):
+        wm.schedule = E.DEFAULT if sched == "default" else E.DEFAULT.reduced()
+        wm.engine_cache = 0
+        mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+        buf = wm.reactive_replay(bd, mp, tl, z.to(dev), valid.to(dev), bd["gt/ag_navi"], valid.to(dev), TF(**tf_all), True, step_end=n_roll)
+        if sched == "default":
+            _compare(buf, ro, n_roll, 1e-3)
+            continue
         with E.use(wm.schedule):
             assert mp["mp_token_feature"].dtype == torch.float32 and wm.model.ag_encoder.kv_mp(mp).dtype == torch.bfloat16
         err = {k: float((x.cpu() - y).abs().max()) for k, x, y in (("pose", buf.pred_pose[:, 0], ro["pred_pose"]), ("motion", buf.pred_motion[:, 0], ro["pred_motion"]),
@@ -139,8 +142,6 @@ def test_teacher_forced_replay(tb, sizes, knn, n_roll, sched):
         assert torch.equal(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]) and torch.equal(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"])
         for k, bound in REDUCED_TF_ATOL[sizes].items():
             assert err[k] <= bound, (k, err[k], bound)
-        return
-    _compare(buf, ro, n_roll, 1e-3)
 
 
 def test_free_rollout_90_steps_damped_policy(tb):

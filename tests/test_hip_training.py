@@ -18,10 +18,10 @@ def _fp32_class_by_default(tb):
     exact-fp32 products, VALU attention) at its tight tolerances; the bf16-class default (autocast-class contractions, the schedule the
     `training` bench figure runs on) is checked by the tests with `bf16` in their name / parameters, at stated tolerances."""
     TG = import_module("trafficbots_amd.train_graph")
-    prev = TG.DEFAULT_PRECISION
-    TG.DEFAULT_PRECISION = "fp32"
+    prev = TG.state.DEFAULT_PRECISION
+    TG.state.DEFAULT_PRECISION = "fp32"
     yield
-    TG.DEFAULT_PRECISION = prev
+    TG.state.DEFAULT_PRECISION = prev
 
 
 def test_attention_backward_vs_oracle_autograd(tb):
@@ -515,9 +515,9 @@ def test_nograd_policy_step_on_chain_kernels_equals_torch_ops_with_dropout(tb, s
     with torch.no_grad():
         b = wm.pre_processing(batch)
         for chains in (False, True):
-            TG.NOGRAD_CHAINS = chains
-            TG._DROP = {"seed": torch.tensor([99], dtype=torch.int64, device=dev), "call": 0, "site": 0, "n_batch": n, "tb": 1, "t0": 0}
-            TG._FOLD_CACHE = {}
+            TG.state.NOGRAD_CHAINS = chains
+            TG.state._DROP = {"seed": torch.tensor([99], dtype=torch.int64, device=dev), "call": 0, "site": 0, "n_batch": n, "tb": 1, "t0": 0}
+            TG.state._FOLD_CACHE = {}
             try:
                 mp = TG.map_encoder(model.mp_encoder, b["sc/mp_valid"], b["sc/mp_attr"], b["sc/mp_pose"], b["ref/mp_type"], True)
                 tl = TG.tl_pre_compute(model.tl_encoder, b["gt/tl_valid"], b["sc/tl_attr"], b["sc/tl_pose"], mp)
@@ -538,14 +538,14 @@ def test_nograd_policy_step_on_chain_kernels_equals_torch_ops_with_dropout(tb, s
                 for step in (1, 2):
                     with TG._DropScope(n, 1, step, restart=TG._POLICY_SITE0):
                         tl_feat = TG.tl_encoder(model.tl_encoder, ht, tl, True)
-                        ids = (TG._DROP["site"], TG._DROP["call"])
+                        ids = (TG.state._DROP["site"], TG.state._DROP["call"])
                     with TG._DropScope(n, 1, step, restart=TG._POLICY_SITE0):
                         eng.append(TG.policy_step(model, (hv, hp, hm, ht), b["sc/ag_attr"].float().contiguous(), b["ref/ag_type"], valid,
                                                   b["sc/ag_pose"][:, :, -1], z, valid, b["gt/ag_navi"], valid, tl, mp, True,
                                                   tl_pre=(tl_feat, ids), want_logits=False)[0])
                 outs[("engine", chains)] = eng
             finally:
-                TG._DROP, TG._FOLD_CACHE, TG.NOGRAD_CHAINS = None, None, True
+                TG.state._DROP, TG.state._FOLD_CACHE, TG.state.NOGRAD_CHAINS = None, None, True
     for (m0, l0), (m1, l1) in zip(outs[False], outs[True]):
         torch.testing.assert_close(m1, m0, rtol=2e-4, atol=2e-5 + 2e-4 * float(m0.abs().max()))
         torch.testing.assert_close(l1, l0, rtol=2e-4, atol=2e-5 + 2e-4 * float(l0.abs().max()))
@@ -653,19 +653,19 @@ def test_fused_pointnet_glue_equals_the_aten_ops(tb, G, W, dropout):
     go = torch.randn(G, 128, generator=g).to(dev)
     x, invalid = x.to(dev), invalid.to(dev)
     res = {}
-    saved = (TG.POINTNET_FUSED, TG._DROP)
+    saved = (TG.state.POINTNET_FUSED, TG.state._DROP)
     try:
         for fused in (True, False):
-            TG.POINTNET_FUSED = fused
-            TG._DROP = {"seed": torch.tensor([1234], dtype=torch.int64, device=dev), "call": 0, "site": 7, "n_batch": 1, "tb": 1, "t0": 3}
+            TG.state.POINTNET_FUSED = fused
+            TG.state._DROP = {"seed": torch.tensor([1234], dtype=torch.int64, device=dev), "call": 0, "site": 7, "n_batch": 1, "tb": 1, "t0": 3}
             xx = x.clone().requires_grad_(True)
             enc.zero_grad()
             y = TG.pointnet(enc, xx, invalid, training=dropout)
             assert isinstance(y.grad_fn, TG.MaskedMaxPoolFn._backward_cls) == fused
             (y * go).sum().backward()
-            res[fused] = (y.detach(), xx.grad.clone(), [p.grad.clone() for p in enc.parameters()], TG._DROP["site"])
+            res[fused] = (y.detach(), xx.grad.clone(), [p.grad.clone() for p in enc.parameters()], TG.state._DROP["site"])
     finally:
-        TG.POINTNET_FUSED, TG._DROP = saved
+        TG.state.POINTNET_FUSED, TG.state._DROP = saved
     (ya, dxa, dpa, sa), (yb, dxb, dpb, sb) = res[True], res[False]
     assert sa == sb  # the dropout site ids advance alike
     assert torch.equal(ya, yb) and float(ya[0].abs().max()) == 0.0
@@ -690,19 +690,19 @@ def test_fused_transformer_glue_equals_the_aten_ops(tb, rows, cols, dropout):
     go = torch.randn(rows, cols, generator=g).to(dev)
     p = 0.1
     res = {}
-    saved = (TG.GLUE_FUSED, TG._DROP)
+    saved = (TG.state.GLUE_FUSED, TG.state._DROP)
     try:
         for fused in (True, False):
-            TG.GLUE_FUSED = fused
-            TG._DROP = {"seed": torch.tensor([77], dtype=torch.int64, device=dev), "call": 0, "site": 3, "n_batch": 1, "tb": 1, "t0": 5}
+            TG.state.GLUE_FUSED = fused
+            TG.state._DROP = {"seed": torch.tensor([77], dtype=torch.int64, device=dev), "call": 0, "site": 3, "n_batch": 1, "tb": 1, "t0": 5}
             xx, yy = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
             a = TG.residual(xx, yy, p, dropout, zero_y=zy)                  # attention residual
             b = TG.residual(a, TG.relu_drop(yy, p, dropout), p, dropout, zero_out=zo)   # FFN tail with the closing row mask
             assert isinstance(b.grad_fn, TG.ResidualDropFn._backward_cls) == fused
             (b * go).sum().backward()
-            res[fused] = (a.detach(), b.detach(), xx.grad.clone(), yy.grad.clone(), TG._DROP["site"])
+            res[fused] = (a.detach(), b.detach(), xx.grad.clone(), yy.grad.clone(), TG.state._DROP["site"])
     finally:
-        TG.GLUE_FUSED, TG._DROP = saved
+        TG.state.GLUE_FUSED, TG.state._DROP = saved
     assert res[True][4] == res[False][4] == (6 if dropout else 3)
     for u, v in zip(res[True][:4], res[False][:4]):
         assert torch.equal(u, v)

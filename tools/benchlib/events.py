@@ -156,11 +156,11 @@ class KernelEvents:
             b = attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs), eb)
             return T("attn", n_batch * n_src, b, sv["knarpe_attn"], qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw)
 
-        def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw):
+        def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw, **kw):
             eb = 2 if segs[0].kv.dtype == torch.bfloat16 else 4
             b = attn_algorithmic_bytes(n_batch * n_src, n_batch * n_src * sum(s.k for s in segs), eb)
             self.attn_kernel = "knarpe_attn_mfma_kernel"
-            return T("attn", n_batch * n_src, b, sv["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw)
+            return T("attn", n_batch * n_src, b, sv["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch, n_src, segs, out, flag, fxy, fyw, **kw)
 
         def run(ch, n_rows, group_rows=0):
             fl = sum(2.0 * n_rows * s.k * s.n * max(1, s.reserved) for s in ch.stages if s.op == hip.OP_LINEAR)
@@ -296,7 +296,10 @@ def train_pmc_traffic(cls: str):
         return None
     parts = {"knarpe_attn_kernel": (("knarpe_attn_kernel", "knarpe_attn_ring_kernel"), "mean"),
              "knarpe_attn_bwd_kernel": (("knarpe_attn_bwd_kernel", "knarpe_attn_dkv_kernel"), "sum")}.get(stem, ((stem,), "mean"))
+    newest = newest_round()
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*train_pmc*.json")), reverse=True):
+        if round_tag(f) != newest:  # (as pmc_traffic: this round's kernels are described by this round's counters only)
+            continue
         ks = json.load(open(f)).get("kernels", {})
         vs = [ks[k] for k in parts[0] if k in ks]
         if not vs:
@@ -343,10 +346,10 @@ def train_kernel_pass(hip, step, replay_s):
         name = "wgrad_partial_bf16_kernel (tbx_linear_wgrad_bf16)" if kw.get("bf16") else "wgrad_partial_kernel (tbx_linear_wgrad)"
         return T(name, "hbm", 4.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]), saved["linear_wgrad"], dy, x, *a, **kw)
 
-    def tall(x, w, b=None, wt=False, relu=False, bf16=False):
+    def tall(x, w, b=None, wt=False, relu=False, bf16=False, **kw):  # (kw: out / out16 - the bfloat16 copy adds 2 n bytes per row)
         n_, k_ = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
-        return T("tall_linear_kernel (tbx_tall_linear" + ("_bf16)" if bf16 else ")"), "hbm", 4.0 * (x.numel() // k_) * (k_ + n_), saved["tall_linear"], x, w, b,
-                 wt=wt, relu=relu, bf16=bf16)
+        by = (4.0 * (k_ + n_) + (2.0 * n_ if kw.get("out16") is not None else 0.0)) * (x.numel() // k_)
+        return T("tall_linear_kernel (tbx_tall_linear" + ("_bf16)" if bf16 else ")"), "hbm", by, saved["tall_linear"], x, w, b, wt=wt, relu=relu, bf16=bf16, **kw)
 
     def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, *a, **kw):
         r, p = pairs(n_batch, n_src, segs)  # (fp32 tables: 1041 B per pair as the VALU forward)

@@ -48,12 +48,21 @@ def compact_roofline(r):
     return out
 
 
-def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps", "warmup", "end_to_end_value", "finite")):
+def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps", "warmup", "end_to_end_value", "finite"), lean=False):
+    """lean: a nested shape (the WOSAC shape inside the bf16 object): value, ms/step and the checked value only."""
     if not res:
         return None
     if "error" in res and "value" not in res:
         return {"error": str(res["error"])[:200]}
     out = {k: res[k] for k in keys if k in res}
+    if lean:
+        w = res.get("with_rule_checks") or {}
+        if "value" in w:
+            out["with_rule_checks"] = {"value": w["value"], "vs_unchecked": w.get("vs_unchecked")}
+        r = res.get("roofline") or {}
+        if "frac" in r:
+            out["roofline"] = {k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "peak", "unit", "achieved", "traffic", "traffic_source") if k in r}
+        return out
     if res.get("scene_reuse"):
         out["new_scene_ms"] = res["scene_reuse"]["new_scene_ms"]
     if res.get("config"):
@@ -109,12 +118,12 @@ def judged_line(full):
     if full.get("bf16"):
         b = compact_shape(full["bf16"])
         if full["bf16"].get("wosac_shape"):
-            b["wosac_shape"] = compact_shape(full["bf16"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"))
+            b["wosac_shape"] = compact_shape(full["bf16"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"), lean=True)
         line["bf16"] = b
     if full.get("reduced"):
         r = compact_shape(full["reduced"])
         if full["reduced"].get("wosac_shape"):
-            r["wosac_shape"] = compact_shape(full["reduced"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"))
+            r["wosac_shape"] = compact_shape(full["reduced"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"), lean=True)
         line["reduced"] = r
     if full.get("training"):
         t = compact_shape(full["training"], keys=("metric", "value", "unit", "ms_per_step", "steps", "warmup", "loss", "finite", "dtype"))

@@ -72,8 +72,8 @@ def train_main(args, tb, dev, rank, world, dist):
             "metric": "training scenes/sec", "value": world * args.scenes * args.steps / dt, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16 contractions with fp32 accumulation (autocast class: tall LINEARs, weight gradients, attention forward operands); fp32 LayerNorm / softmax / "
-                      "attention backward / losses / AdamW" if wm.train_precision == "bf16" else "f32 (split-bf16 / exact-fp32 MFMA products, VALU attention)"),
+            "dtype": ("bf16 contractions, fp32 accumulation (autocast class); fp32 LayerNorm / softmax / attention backward / loss / AdamW"
+                      if wm.train_precision == "bf16" else "f32 (split-bf16 / exact-fp32 MFMA products, VALU attention)"),
             "data": "synthetic",
             "config": {"workload": f"training_step fwd+bwd+grad all-reduce+AdamW, {args.scenes} scenes/GPU of {args.agents} agents/"
                                    f"{args.polylines} polylines/{args.lights} lights, 90-step rollout, default 10,657,094-param model",

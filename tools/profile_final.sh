@@ -6,7 +6,7 @@ set -x
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 mkdir -p gpurun_out
-tag=${TAG:-r04}
+tag=${TAG:-r05}
 if [ -z "${SKIP_TESTS:-}" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${tag}_gpu_tests.log; fi
 bash tools/profile_round.sh ${tag}_c2 64 1024 128 1 1
 bash tools/profile_round.sh ${tag}_c5 128 1024 128 1 32 --steps 40
@@ -29,6 +29,15 @@ rm -rf $out/kt_train
 if [ -f trafficbotsv1.5_amd/csrc/libtbx_hip_clk.so ]; then
   { echo "tools/mid_clock.py (TBX_CLOCK_TWO_STREAM=1: the timed two-stream schedule, eager): s_memtime stamps of workgroup 0 in every dec_layer_mf_kernel launch of one step (launches 0-3: the lights' 128 rows, the last with their K/V + logits tail; 4-7: the agents' 64 rows, the last with heads + tbx_sim_step + the next tbx_agent_prep; unit = 100 shader clocks, ~0.042 us)"; TBX_CLOCK_TWO_STREAM=1 python3 tools/mid_clock.py 2>/dev/null | grep -v amdgpu.ids; } > $out/${tag}_dec_layer_phase_clock.txt
 fi
+# round 5: the submission shape, the multi-scene shapes, the attention sweep's phase clock, the training step's HBM traffic
+bash tools/profile_round.sh ${tag}_sub 128 1024 128 1 128 --steps 40 --new-scenes 0
+bash tools/profile_round.sh ${tag}_s16 64 1024 128 16 1 --steps 40 --new-scenes 0
+bash tools/profile_round.sh ${tag}_s64 64 1024 128 64 1 --steps 40 --new-scenes 0
+bash tools/profile_round.sh ${tag}_s64_bf16 64 1024 128 64 1 --steps 40 --new-scenes 0 --kv-bf16 --attn-mfma 1
+if [ -f trafficbotsv1.5_amd/csrc/libtbx_hip_clk.so ]; then
+  python3 tools/attn_clock.py 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_attn_phase_clock.txt
+fi
+TAG=${tag} bash tools/pmc_train.sh > $out/${tag}_train_pmc_top.txt 2>&1
 python bench.py > $out/${tag}_bench_default.log 2>&1
 tail -1 $out/${tag}_bench_default.log | cut -c1-200
 cat $out/${tag}_gpu_tests.log

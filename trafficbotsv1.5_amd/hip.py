@@ -11,34 +11,15 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import abi
+from . import abi, hip_base
 from .abi import *  # noqa: F401,F403  (constants, structures, load, declared_symbols: the C-ABI mirror)
 from .abi import HEADER_PATH, LIB_PATH, load  # noqa: F401
-
-
-def _check(rc: int, what: str):
-    if rc != 0:
-        raise RuntimeError(f"{what}: tbx error {rc}: {load().tbx_error_string(rc).decode()}")
-
-
-def _ptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
-    if t is None:
-        return None
-    if not t.is_cuda:
-        raise RuntimeError("tbx kernels need device tensors (HIP); there is no CPU path")
-    if dtype is not None and t.dtype != dtype:
-        raise TypeError(f"expected {dtype}, got {t.dtype}")
-    return t.data_ptr()
-
-
-def _cptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
-    if t is not None and not t.is_contiguous():
-        raise RuntimeError("tbx kernels need contiguous tensors")
-    return _ptr(t, dtype)
-
-
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+from .hip_base import *  # noqa: F401,F403  (Seg, stream_ptr, packed_weight / stacked_linear / padded_weight)
+from .hip_base import _check, _cptr, _drop_args, _ptr  # noqa: F401
+from .hip_chain import *  # noqa: F401,F403  (Chain, group_tile_rows)
+from .hip_rules import *  # noqa: F401,F403  (rule_tables, rule_check, rule_accumulate, filter_futures)
+from .hip_train import *  # noqa: F401,F403  (the training entry points)
+from .hip_train import _drop6  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------ wrappers
@@ -142,231 +123,6 @@ def pose_embed(pose3, freqs_xy, freqs_yaw, pe_dim: int, out=None, col_off: int =
     return out
 
 
-class Seg:
-    """One target segment of a KNARPE attention call: a K/V table + the KNN set that indexes it."""
-
-    def __init__(self, kv, k_off, v_off, n_tgt, idx, invalid, emb=None, batch_div=1, rel=None):
-        """emb [n,S,k,128] (materialised embedding) or rel [n,S,k,3] (relative pose; embedding rebuilt in-kernel)."""
-        assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32, torch.bfloat16)
-        assert (emb is None) != (rel is None), "exactly one of emb / rel"
-        self.kv, self.k_off, self.v_off, self.n_tgt, self.batch_div = kv, k_off, v_off, n_tgt, batch_div
-        self.idx, self.invalid, self.emb, self.rel = idx, invalid, emb, rel
-        self.k = idx.shape[-1]
-
-    def c(self) -> AttnSeg:
-        return AttnSeg(_ptr(self.kv), _cptr(self.idx, torch.int32), _cptr(self.invalid, torch.uint8),
-                       _cptr(self.emb, torch.float32), _cptr(self.rel, torch.float32), self.kv.stride(0), self.k_off, self.v_off,
-                       self.n_tgt, self.batch_div, self.k, int(self.kv.dtype == torch.bfloat16))
-
-
-def _drop_args(drop):
-    if drop is None:
-        return 0.0, None, 0, 1, 0
-    p, seed, call = drop[:3]
-    tb, t0 = (drop[3], drop[4]) if len(drop) > 3 else (1, 0)
-    return p, seed, call, int(tb), int(t0)
-
-
-def keyed_dropout(x: torch.Tensor, p: float, seed: torch.Tensor, site: int, rows_per_scene: int, time_batch: int = 1,
-                  time0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """tbx_keyed_dropout on x viewed as [rows, cols = x.shape[-1]] (contiguous); rows_per_scene = rows per batch entry."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-    cols = x.shape[-1]
-    rows = x.numel() // cols if cols else 0
-    y = torch.empty_like(x) if out is None else out
-    rc = load().tbx_keyed_dropout(_ptr(x), _ptr(y), rows, cols, rows_per_scene, float(p), _ptr(seed, torch.int64), int(site),
-                                  int(time_batch), int(time0), stream_ptr())
-    _check(rc, "tbx_keyed_dropout")
-    return y
-
-
-def tall_linear_ok(x: torch.Tensor, k: int, n: int) -> bool:
-    """Shapes tbx_tall_linear takes: row-major fp32 rows of k values (a 2-D view after flattening the leading dimensions), k and n
-    multiples of 128 up to 1024, 16-byte aligned, leading dimension a multiple of 4."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == k and k % 128 == 0 and n % 128 == 0 and k <= 1024 and n <= 1024
-            and x.stride(-1) == 1 and x.data_ptr() % 16 == 0)
-
-
-def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False,
-                bf16: bool = False, out: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear; bf16: ONE bf16 product per term,
-    tbx_tall_linear_bf16). wt: w is stored [k x n] (the input gradient dx = dy W of a Linear with weight W [n_out, n_in]: x = dy,
-    w = W, wt = True)."""
-    n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
-    x2 = x.reshape(-1, k)
-    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
-        x2 = x2.contiguous()
-    img = packed_weight(w, b, wt=wt, mfma32=True)
-    y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device) if out is None else out
-    assert y.shape == (x2.shape[0], n) and y.is_contiguous() and y.dtype == torch.float32
-    if out16 is not None:  # the same rows as bfloat16 as well (tbx_tall_linear_dual)
-        assert out16.shape == y.shape and out16.dtype == torch.bfloat16 and out16.is_contiguous()
-        fn = load().tbx_tall_linear_dual_bf16 if bf16 else load().tbx_tall_linear_dual
-        _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
-                  _ptr(y), n, _ptr(out16, torch.bfloat16), n, stream_ptr()), "tbx_tall_linear_dual")
-        return y.view(*x.shape[:-1], n)
-    fn = load().tbx_tall_linear_bf16 if bf16 else load().tbx_tall_linear
-    _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
-              _ptr(y), n, stream_ptr()), "tbx_tall_linear")
-    return y.view(*x.shape[:-1], n)
-
-
-def linear_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:
-    """Shapes tbx_linear_wgrad takes: 2-D row-major fp32 views, n, k and both leading dimensions multiples of 4, 16-B aligned."""
-    return (dy.dim() == 2 and x.dim() == 2 and dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32
-            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0
-            and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
-
-
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True, bf16: bool = False):
-    """(dw [n,k], db [n] | None) = (dy^T x, sum_rows dy) for dy [rows,n], x [rows,k] (tbx_linear_wgrad; bf16: one bf16 product per
-    term with fp32 accumulation, tbx_linear_wgrad_bf16)."""
-    rows, n = dy.shape
-    k = x.shape[1]
-    lib = load()
-    splits = lib.tbx_linear_wgrad_splits(rows, n, k)
-    if splits <= 0:
-        _check(int(splits), "tbx_linear_wgrad_splits")
-    scratch = torch.empty(splits, n * k + n, dtype=torch.float32, device=dy.device)
-    dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
-    db = torch.empty(n, dtype=torch.float32, device=dy.device) if want_db else None
-    fn = lib.tbx_linear_wgrad_bf16 if bf16 else lib.tbx_linear_wgrad
-    _check(fn(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), rows, n, k, _ptr(dw), _ptr(db), _ptr(scratch), splits, stream_ptr()), "tbx_linear_wgrad")
-    return dw, db
-
-
-NO_DROP = (0.0, None, 0, 1, 1, 0)  # (p, seed, site, rows_per_scene, time_batch, time0) of the glue ops without dropout
-
-
-def glue_ok(x: torch.Tensor) -> bool:
-    """Tensors the one-pass glue kernels (tbx_residual_drop_*, tbx_relu_drop_*) take: fp32 on the device, last dimension % 4 == 0."""
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[-1] % 4 == 0 and x.numel() > 0
-
-
-def _drop6(drop):
-    p, seed, site, rps, tb, t0 = drop
-    return float(p), (_ptr(seed, torch.int64) if seed is not None else None), int(site), int(rps), int(tb), int(t0)
-
-
-def residual_drop_fwd(x, y, zero_y, zero_out, drop=NO_DROP):
-    """zero_out[row] ? 0 : x + dropout(zero_y[row] ? 0 : y); zero_* u8 per row or None."""
-    assert glue_ok(x) and x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.dtype == torch.float32
-    cols = x.shape[-1]
-    rows = x.numel() // cols
-    for z in (zero_y, zero_out):
-        assert z is None or (z.dtype == torch.uint8 and z.is_contiguous() and z.numel() == rows)
-    out = torch.empty_like(x)
-    p, seed, site, rps, tb, t0 = _drop6(drop)
-    _check(load().tbx_residual_drop_fwd(_ptr(x), _ptr(y), _ptr(zero_y), _ptr(zero_out), rows, cols, p, seed, site, rps, tb, t0, _ptr(out),
-                                        stream_ptr()), "tbx_residual_drop_fwd")
-    return out
-
-
-def residual_drop_bwd(dout, zero_y, zero_out, drop=NO_DROP):
-    """-> (dy, dx); dx is dout itself when there is no zero_out mask."""
-    assert glue_ok(dout) and dout.is_contiguous()
-    cols = dout.shape[-1]
-    rows = dout.numel() // cols
-    dy = torch.empty_like(dout)
-    dx = torch.empty_like(dout) if zero_out is not None else None
-    p, seed, site, rps, tb, t0 = _drop6(drop)
-    _check(load().tbx_residual_drop_bwd(_ptr(dout), _ptr(zero_y), _ptr(zero_out), rows, cols, p, seed, site, rps, tb, t0, _ptr(dy), _ptr(dx),
-                                        stream_ptr()), "tbx_residual_drop_bwd")
-    return dy, (dx if dx is not None else dout)
-
-
-def relu_drop_fwd(z, drop=NO_DROP):
-    assert glue_ok(z) and z.is_contiguous()
-    cols = z.shape[-1]
-    h = torch.empty_like(z)
-    p, seed, site, rps, tb, t0 = _drop6(drop)
-    _check(load().tbx_relu_drop_fwd(_ptr(z), z.numel() // cols, cols, p, seed, site, rps, tb, t0, _ptr(h), stream_ptr()), "tbx_relu_drop_fwd")
-    return h
-
-
-def relu_drop_bwd(dh, h, p: float):
-    assert glue_ok(dh) and dh.is_contiguous() and h.is_contiguous() and h.shape == dh.shape
-    cols = dh.shape[-1]
-    dz = torch.empty_like(dh)
-    _check(load().tbx_relu_drop_bwd(_ptr(dh), _ptr(h), dh.numel() // cols, cols, float(p), _ptr(dz), stream_ptr()), "tbx_relu_drop_bwd")
-    return dz
-
-
-def pointnet_tail_ok(z: torch.Tensor) -> bool:
-    """z [G, W, 64] fp32 on the device, W <= 16: the shapes tbx_pointnet_tail_* / tbx_masked_maxpool_* take."""
-    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[2] == 64 and 0 < z.shape[1] <= 16 and z.shape[0] > 0
-
-
-def pointnet_tail_fwd(z: torch.Tensor, invalid_u8: torch.Tensor, drop=None) -> torch.Tensor:
-    """[relu(z) (* keyed dropout) | its max over the group's valid rows], invalid rows zeroed. drop = None or (p, seed int64[1] device
-    tensor, site, rows_per_scene, time_batch, time0) - tbx_keyed_dropout's arguments for the [G * W, 64] view."""
-    assert pointnet_tail_ok(z) and z.is_contiguous() and invalid_u8.dtype == torch.uint8 and invalid_u8.is_contiguous()
-    G, W, Cc = z.shape
-    assert invalid_u8.numel() == G * W
-    out = torch.empty(G, W, 2 * Cc, dtype=torch.float32, device=z.device)
-    p, seed, site, rps, tb, t0 = drop if drop is not None else (0.0, None, 0, 1, 1, 0)
-    _check(load().tbx_pointnet_tail_fwd(_ptr(z), _ptr(invalid_u8), G, W, Cc, float(p), _ptr(seed, torch.int64) if seed is not None else None,
-                                        int(site), int(rps), int(tb), int(t0), _ptr(out), stream_ptr()), "tbx_pointnet_tail_fwd")
-    return out
-
-
-def pointnet_tail_bwd(dout: torch.Tensor, out: torch.Tensor, invalid_u8: torch.Tensor, p: float) -> torch.Tensor:
-    G, W, C2 = out.shape
-    assert dout.shape == out.shape and dout.is_contiguous() and dout.dtype == torch.float32
-    dz = torch.empty(G, W, C2 // 2, dtype=torch.float32, device=out.device)
-    _check(load().tbx_pointnet_tail_bwd(_ptr(dout), _ptr(out), _ptr(invalid_u8), G, W, C2 // 2, float(p), _ptr(dz), stream_ptr()),
-           "tbx_pointnet_tail_bwd")
-    return dz
-
-
-def masked_maxpool_fwd(x: torch.Tensor, invalid_u8: torch.Tensor) -> torch.Tensor:
-    G, W, C2 = x.shape
-    assert x.is_contiguous() and x.dtype == torch.float32 and invalid_u8.numel() == G * W
-    y = torch.empty(G, C2, dtype=torch.float32, device=x.device)
-    _check(load().tbx_masked_maxpool_fwd(_ptr(x), _ptr(invalid_u8), G, W, C2, _ptr(y), stream_ptr()), "tbx_masked_maxpool_fwd")
-    return y
-
-
-def masked_maxpool_bwd(dy: torch.Tensor, x: torch.Tensor, invalid_u8: torch.Tensor) -> torch.Tensor:
-    G, W, C2 = x.shape
-    assert dy.is_contiguous() and dy.shape == (G, C2) and dy.dtype == torch.float32
-    dx = torch.empty_like(x)
-    _check(load().tbx_masked_maxpool_bwd(_ptr(dy), _ptr(x), _ptr(invalid_u8), G, W, C2, _ptr(dx), stream_ptr()), "tbx_masked_maxpool_bwd")
-    return dx
-
-
-def layernorm_bwd_ok(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 128 and x.numel() > 0
-
-
-def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
-    """(y, mean [rows], rstd [rows]) of LayerNorm_128 (tbx_layernorm_fwd)."""
-    assert layernorm_bwd_ok(x) and x.is_contiguous()
-    rows = x.numel() // 128
-    y = torch.empty_like(x)
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _check(load().tbx_layernorm_fwd(_ptr(x), _ptr(gamma.contiguous(), torch.float32), _ptr(beta.contiguous(), torch.float32), float(eps), rows, 128,
-                                    _ptr(y), _ptr(mean), _ptr(rstd), stream_ptr()), "tbx_layernorm_fwd")
-    return y, mean, rstd
-
-
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
-    """(dx, dgamma, dbeta) of y = LayerNorm_128(x) * gamma + beta given dy, with the forward's per-row mean / rstd (tbx_layernorm_bwd)."""
-    assert layernorm_bwd_ok(x) and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and dy.dtype == torch.float32
-    rows = x.numel() // 128
-    assert mean.numel() == rows and rstd.numel() == rows and mean.is_contiguous() and rstd.is_contiguous()
-    lib = load()
-    n = lib.tbx_layernorm_bwd_partials(rows)
-    scratch = torch.empty(n, 256, dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x)
-    dg = torch.empty(128, dtype=torch.float32, device=x.device)
-    db = torch.empty(128, dtype=torch.float32, device=x.device)
-    _check(lib.tbx_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma.contiguous(), torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
-                                 rows, 128, _ptr(dx), _ptr(dg), _ptr(db), _ptr(scratch), stream_ptr()), "tbx_layernorm_bwd")
-    return dx, dg, db
-
-
 def knarpe_attn(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], out, row_no_valid,
                 freqs_xy=None, freqs_yaw=None, drop=None, fold=None):
     """drop = None, or (p, seed int64[1] device tensor, call id[, time_batch, time0]): attention-probability dropout
@@ -406,18 +162,6 @@ def knarpe_attn_mfma(qbuf, q_off: int, qt_off: int, n_batch: int, n_src: int, se
                                          _ptr(out, torch.float32), out.stride(0), _ptr(row_no_valid, torch.uint8), _cptr(freqs_xy),
                                          _cptr(freqs_yaw), stream_ptr())
     _check(rc, "tbx_knarpe_attn_fwd_mfma")
-
-
-def knarpe_attn_bwd(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
-                    dkv: Sequence[torch.Tensor], dbias_k, freqs_xy=None, freqs_yaw=None, drop=None):
-    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
-    dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
-    p, seed, call, tb, t0 = _drop_args(drop)
-    rc = load().tbx_knarpe_attn_bwd_dropout_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
-                                            n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
-                                            _ptr(dqbuf, torch.float32), dk, _ptr(dbias_k, torch.float32), _cptr(freqs_xy),
-                                            _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, stream_ptr())
-    _check(rc, "tbx_knarpe_attn_bwd")
 
 
 def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: Sequence[Seg], bias_self, bias_cross, ln, n_batch: int,
@@ -657,80 +401,6 @@ def front(window: dict, proj: dict, rider=None, jobs=None, pose_embed_job=None):
     return outs
 
 
-def padded_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:
-    """w [n, k] zero-padded to k_pad columns; cached like packed_weight (per parameter version, or per training step in PACK_SCOPE)."""
-    if w.shape[1] == k_pad:
-        return w
-    key = ("padded", id(w), k_pad)
-    stamp = (w._version, w.data_ptr())
-    cache = PACK_SCOPE if PACK_SCOPE is not None else w.__dict__.setdefault("_tbx_padded", {})
-    hit = cache.get(key)
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
-    with torch.no_grad():
-        out = torch.zeros(w.shape[0], k_pad, dtype=torch.float32, device=w.device)
-        out[:, :w.shape[1]].copy_(w)
-    cache[key] = (stamp, out)
-    if PACK_SCOPE is not None:
-        PACK_SCOPE.setdefault("_keep", {})[id(w)] = w
-    return out
-
-
-def knn_inverse(idx, invalid, n_tgt: int, tgt_batch_div: int = 1):
-    """Inverse lists of a K-nearest set idx / invalid [n_batch, n_src, k] -> (inv_ptr [n_tables, n_tgt+1], inv_list [n_tables, cap])."""
-    n, S, k = idx.shape
-    nt = n // tgt_batch_div
-    ptr = torch.empty(nt, n_tgt + 1, dtype=torch.int32, device=idx.device)
-    lst = torch.empty(nt, S * tgt_batch_div * k, dtype=torch.int32, device=idx.device)
-    rc = load().tbx_knn_inverse(_cptr(idx, torch.int32), _cptr(invalid, torch.uint8), n, S, k, n_tgt, tgt_batch_div, _ptr(ptr), _ptr(lst),
-                                stream_ptr())
-    _check(rc, "tbx_knn_inverse")
-    return ptr, lst
-
-
-def knarpe_attn_bwd_gather(qbuf, q_off: int, qt_off: int, rpe_k_bias, n_batch: int, n_src: int, segs: Sequence[Seg], dout, dqbuf,
-                           dkv: Sequence[torch.Tensor], dbias_rows, inv: Sequence, freqs_xy=None, freqs_yaw=None, drop=None):
-    """Backward through inverse K-nearest lists (inv[i] = knn_inverse(...) of segment i): no dK / dV atomics."""
-    arr = (AttnSeg * len(segs))(*[s.c() for s in segs])
-    dk = (C.c_void_p * len(segs))(*[_ptr(t, torch.float32) for t in dkv])
-    ip = (C.c_void_p * len(segs))(*[_cptr(p, torch.int32) for p, _ in inv])
-    il = (C.c_void_p * len(segs))(*[_cptr(l, torch.int32) for _, l in inv])
-    coef = torch.empty(n_batch * n_src, sum(s.k for s in segs), 8, dtype=torch.float32, device=qbuf.device)
-    p, seed, call, tb, t0 = _drop_args(drop)
-    rc = load().tbx_knarpe_attn_bwd_gather_tb(_ptr(qbuf, torch.float32), qbuf.stride(0), q_off, qt_off, _ptr(rpe_k_bias, torch.float32),
-                                           n_batch, n_src, arr, len(segs), _ptr(dout, torch.float32), dout.stride(0),
-                                           _ptr(dqbuf, torch.float32), dk, _ptr(dbias_rows, torch.float32), _cptr(freqs_xy),
-                                           _cptr(freqs_yaw), float(p), _ptr(seed, torch.int64), int(call), tb, t0, ip, il, _ptr(coef),
-                                           stream_ptr())
-    _check(rc, "tbx_knarpe_attn_bwd_gather")
-
-
-def dropout_keep_mask(seed: int, call: int, n_rows: int, k_tot: int, p: float, n_head: int = 4, step: int = 0) -> torch.Tensor:
-    """Host restatement of the kernels' counter-based mask (csrc/attn.hip DropKey): bool [n_rows, n_head, k_tot] - for tests
-    and for anyone who needs the mask a (seed, call) pair produces."""
-    import numpy as np
-
-    sd = np.uint64(seed % (1 << 64))
-    m32 = np.uint64(0xFFFFFFFF)
-    lo = np.uint32(sd & m32) ^ np.uint32((call * 0x85EBCA6B) & 0xFFFFFFFF) ^ np.uint32((step * 0x27D4EB2F) & 0xFFFFFFFF)
-    hi = np.uint32((int((sd >> np.uint64(32)) & m32) + call * 0xC2B2AE35 + step * 0x165667B1) & 0xFFFFFFFF)
-    row = np.arange(n_rows, dtype=np.uint32)[:, None, None]
-    h = np.arange(n_head, dtype=np.uint32)[None, :, None]
-    t = np.arange(k_tot, dtype=np.uint32)[None, None, :]
-    with np.errstate(over="ignore"):
-        x = ((row * np.uint32(128) + t) * np.uint32(4) + h) ^ lo
-        x = x * np.uint32(0x9E3779B1)
-        x = x ^ hi
-        x = x ^ (x >> np.uint32(16))
-        x = x * np.uint32(0x7FEB352D)
-        x = x ^ (x >> np.uint32(15))
-        x = x * np.uint32(0x846CA68B)
-        x = x ^ (x >> np.uint32(16))
-    th = p * 4294967296.0
-    th = np.uint32(1 if 0 < th < 1 else int(th))
-    return torch.from_numpy(x >= th)
-
-
 def agent_prep_args(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, freqs_xy, freqs_yaw, pe_dim, out, dest=None,
                     mp_tok_pose=None, n_mp=0, mp_batch_div=1) -> AgentPrepArgs:
     """agent_prep's arguments as tbx_agent_prep_args_t (the fused step tail of tbx_knarpe_dec_layer)."""
@@ -775,23 +445,6 @@ def map_prep(mp_valid_u8, mp_type11, mp_pose, attr, pe, row_invalid, tok_pose, t
 SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE, SIM_NO_DISABLE, SIM_NO_APPEND, SIM_APPEND = 1, 2, 4, 8, 16, 32
 
 
-def train_chain_fwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, t0: int, t1: int):
-    _check(load().tbx_train_chain_fwd(C.byref(args), _ptr(mean, torch.float32), stride_n, stride_t, t0, t1, stream_ptr()), "tbx_train_chain_fwd")
-
-
-def train_chain_fwd_windows(args: TrainChainArgs, mean: Optional[torch.Tensor], stride_n: int, stride_t: int, t0: int, t1: int, hv, hp, hm, valid, navi_valid):
-    """tbx_train_chain_fwd over [t0, t1) (t0 == t1: none) + the policy inputs of step t1 + 1 into hv u8 [n,A,W], hp / hm f32 [n,A,W,3], valid /
-    navi_valid [n,A] (bool or u8 storage)."""
-    _check(load().tbx_train_chain_fwd_windows(C.byref(args), _cptr(mean, torch.float32), stride_n, stride_t, t0, t1, _ptr(hv, torch.uint8),
-                                              _ptr(hp, torch.float32), _ptr(hm, torch.float32), _ptr(valid), _ptr(navi_valid), stream_ptr()),
-           "tbx_train_chain_fwd_windows")
-
-
-def train_chain_bwd(args: TrainChainArgs, mean: torch.Tensor, stride_n: int, stride_t: int, d_reward: torch.Tensor, d_mean: torch.Tensor):
-    _check(load().tbx_train_chain_bwd(C.byref(args), _ptr(mean, torch.float32), stride_n, stride_t, _ptr(d_reward, torch.float32),
-                                      _ptr(d_mean, torch.float32), stream_ptr()), "tbx_train_chain_bwd")
-
-
 def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE, tl_prep=None):
     """tl_prep = (tl_invalid u8 [n*L], attr f32 [n*L*W, ld], row_invalid u8 [n*L*W]): the lights' update also writes the tbx_tl_prep
     rows of their new windows (tbx_sim_step_tl_prep)."""
@@ -803,297 +456,3 @@ def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE
     _check(load().tbx_sim_step_parts(C.byref(state), parts, stream_ptr()), "tbx_sim_step_parts")
 
 
-# ------------------------------------------------------------------------------------------------ rowchain builder
-def rule_tables(mp_valid_u8, mp_type_idx_u8, mp_pos, mp_dir):
-    """-> (seg [n,M*N,4], n_seg [n] i32, lane [n,M*N,2], n_lane [n] i32): compacted road-edge segments / lane-centre nodes."""
-    n, M, N = mp_valid_u8.shape
-    dev = mp_pos.device
-    seg = torch.empty(n, M * N, 4, dtype=torch.float32, device=dev)
-    lane = torch.empty(n, M * N, 2, dtype=torch.float32, device=dev)
-    n_seg = torch.empty(n, dtype=torch.int32, device=dev)
-    n_lane = torch.empty(n, dtype=torch.int32, device=dev)
-    rc = load().tbx_rule_tables(_cptr(mp_valid_u8, torch.uint8), _cptr(mp_type_idx_u8, torch.uint8), _cptr(mp_pos, torch.float32),
-                                _cptr(mp_dir, torch.float32), mp_pos.shape[-1], n, M, N, _ptr(seg), _ptr(n_seg), _ptr(lane),
-                                _ptr(n_lane), stream_ptr())
-    _check(rc, "tbx_rule_tables")
-    return seg, n_seg, lane, n_lane
-
-
-def rule_check(ctx: RuleCtx, valid_u8, pose, motion, tl_state_u8, ld_t: int, t0: int, n_t: int, flags):
-    rc = load().tbx_rule_check(C.byref(ctx), _cptr(valid_u8, torch.uint8), _cptr(pose, torch.float32), _cptr(motion, torch.float32),
-                               _cptr(tl_state_u8, torch.uint8), ld_t, t0, n_t, _cptr(flags, torch.uint8), stream_ptr())
-    _check(rc, "tbx_rule_check")
-
-
-def rule_accumulate(raw, n_rows: int, ld_t: int, t0: int, n_t: int, acc_state, passive_counter, out_now, out_acc):
-    rc = load().tbx_rule_accumulate(_cptr(raw, torch.uint8), n_rows, ld_t, t0, n_t, _cptr(acc_state, torch.uint8),
-                                    _cptr(passive_counter, torch.float32), _cptr(out_now, torch.uint8), _cptr(out_acc, torch.uint8),
-                                    stream_ptr())
-    _check(rc, "tbx_rule_accumulate")
-
-
-def filter_futures(flags, col_bit: int, ag_role_any, n_scene: int, n_k: int, t_start: int, w_road_edge: float, n_keep: int,
-                   pred_pose=None):
-    """flags [n_scene*n_k, A, T] u8 bits, ag_role_any [n_scene, A] u8 -> (score [n_scene,n_k], idx [n_scene,n_keep] i32,
-    trajs [n_scene, n_keep, A, T - t_start, 3] or None)."""
-    A, T = flags.shape[-2:]
-    dev = flags.device
-    score = torch.empty(n_scene, n_k, dtype=torch.float32, device=dev)
-    idx = torch.empty(n_scene, n_keep, dtype=torch.int32, device=dev)
-    trajs = None if pred_pose is None else torch.empty(n_scene, n_keep, A, T - t_start, 3, dtype=torch.float32, device=dev)
-    rc = load().tbx_filter_futures(_cptr(flags, torch.uint8), col_bit, _cptr(ag_role_any, torch.uint8), n_scene, n_k, A, T, t_start,
-                                   w_road_edge, n_keep, _ptr(score), _ptr(idx), _cptr(pred_pose, torch.float32), _ptr(trajs),
-                                   stream_ptr())
-    _check(rc, "tbx_filter_futures")
-    return score, idx, trajs
-
-
-# Set to a dict for the duration of a training step (train_graph.training_step): chain kernels of the step's no-grad stepping
-# pass then pack each weight ONCE PER STEP into this scope instead of the per-parameter cache. A captured training step
-# (GraphedTrainStep) replays after the optimizer has moved the weights: a cached image from before the capture would be read by
-# the replay without ever being re-packed (its tbx_pack_weight launch is not in the graph) - with the scope the packing is.
-PACK_SCOPE: Optional[dict] = None
-
-
-def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
-                  split: bool = False, gemv: bool = False, mfma32: bool = False) -> torch.Tensor:
-    """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
-    per view and version of both tensors: re-packed after an in-place update (optimizer step, load_state_dict), reused
-    otherwise - chains are rebuilt every eager step - and dropped with the parameter.
-    split=True: the tbx_pack_weight_split image (bf16 hi + lo halves) for stages flagged F_WSPLIT.
-    gemv=True: the tbx_pack_weight_gemv image (column streams) for the F_WGEMV stages of live-row chains.
-    mfma32=True: the tbx_pack_weight_mfma32 image (per-wave units of bf16 hi + lo fragments) for tbx_layer_tile."""
-    assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
-    base = w._base if w._base is not None else w
-    bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv, mfma32)
-    if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
-        cache, key = PACK_SCOPE, (id(base),) + key
-        PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
-    else:
-        cache = base.__dict__.setdefault("_tbx_packed", {})
-    stamp = (w._version, w.data_ptr(), None if bias is None else bias._version)
-    hit = cache.get(key)
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
-    n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
-    if bias is not None:
-        assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n
-    lib = load()
-    size = (lib.tbx_pack_weight_mfma32_size if mfma32 else (lib.tbx_pack_weight_gemv_size if gemv else lib.tbx_pack_weight_size))(n, k, groups)
-    if size <= 0:
-        _check(int(size), "tbx_pack_weight_size")
-    out = torch.empty(size, dtype=torch.float32, device=w.device)
-    fn = lib.tbx_pack_weight_mfma32 if mfma32 else (lib.tbx_pack_weight_gemv if gemv else (lib.tbx_pack_weight_split if split else lib.tbx_pack_weight))
-    _check(fn(_ptr(w), _ptr(bias), n, k, w.stride(0), groups, int(wt), _ptr(out), stream_ptr()), "tbx_pack_weight")
-    cache[key] = (stamp, out)
-    return out
-
-
-def stacked_linear(linears, pad_out_to: int = 0):
-    """(W [G * n, k], b [G * n]) = the weights / biases of G equally shaped nn.Linear layers stacked along the output dimension
-    (each block zero-padded to pad_out_to output rows if given): branches that read the same input become ONE LINEAR stage
-    (G * n outputs), parallel branches one block-diagonal stage (groups = G). Cached like packed_weight: per parameter version,
-    or per training step inside PACK_SCOPE."""
-    ws, bs = [l.weight for l in linears], [l.bias for l in linears]
-    key = ("stacked", tuple(id(w) for w in ws), pad_out_to)
-    stamp = tuple((w._version, w.data_ptr(), b._version) for w, b in zip(ws, bs))
-    cache = PACK_SCOPE if PACK_SCOPE is not None else ws[0].__dict__.setdefault("_tbx_stacked", {})
-    hit = cache.get(key)
-    if hit is not None and hit[0] == stamp:
-        return hit[1], hit[2]
-    n, k = ws[0].shape
-    npad = max(n, pad_out_to)
-    with torch.no_grad():
-        W = torch.zeros(len(ws) * npad, k, dtype=torch.float32, device=ws[0].device)
-        B = torch.zeros(len(ws) * npad, dtype=torch.float32, device=ws[0].device)
-        for g, (w, b) in enumerate(zip(ws, bs)):
-            W[g * npad:g * npad + n].copy_(w)
-            B[g * npad:g * npad + n].copy_(b)
-    cache[key] = (stamp, W, B)
-    if PACK_SCOPE is not None:
-        PACK_SCOPE.setdefault("_keep", {})[id(ws[0])] = ws[0]
-    return W, B
-
-
-def group_tile_rows(group_rows: int, n_groups: int) -> int:
-    """Tile height of a grouped chain. Small grids keep one group per 16-row tile (more workgroups, shortest critical path). Once
-    the groups outnumber the CUs several times the per-stage fixed costs of a workgroup are worth sharing: the tile (32 or 48 rows)
-    that wastes the fewest rows holds floor(tile / W) whole groups - 11-step windows: 4 in 48 rows (92 % of the MFMA rows used; 2 in
-    32 rows: 69 %). Measured at 4096 windows of 11 rows: 415 us (16) -> ~230 us (32) -> see DESIGN.md (48). TBX_TILE48=0: never 48."""
-    if n_groups < 1024 or group_rows > 24:
-        return 32 if group_rows > 16 else 16
-    use = lambda t: (t // group_rows) * group_rows / t
-    cands = [t for t in ((32, 48) if os.environ.get("TBX_TILE48", "1") != "0" else (32,)) if t // group_rows >= 1]
-    best = max(cands, key=lambda t: (use(t), -t))
-    return best if best // group_rows >= 2 or group_rows > 16 else 16
-
-
-class Chain:
-    """Builds one tbx_rowchain program. Tensors handed to stages are kept alive by the chain; the encoded program
-    holds raw device pointers, so a chain is valid as long as those tensors are not re-allocated."""
-
-    def __init__(self, tile_rows: int = 16, ldw: int = 132, ldw1: Optional[int] = None, ld_aux: Optional[int] = None,
-                 live_rows: int = 0):
-        """ldw = LDS row width of BUF0 (floats); ldw1 / ld_aux default to ldw / 260 (tbx_rowchain), else tbx_rowchain_ex.
-        live_rows in (1, 2, 4): a tbx_rowchain_live program - tiles of that many rows, LINEAR stages on the thread-per-column path
-        (same results bit for bit; for launches of a few hundred rows at most)."""
-        self.tile_rows, self.ldw, self.live_rows = tile_rows, ldw, live_rows
-        assert live_rows in (0, 1, 2, 4) and (live_rows == 0 or tile_rows == 16)
-        self.ldw1 = ldw if ldw1 is None else ldw1
-        self.ld_aux = AUX_LD if ld_aux is None else ld_aux
-        self.stages: List[Stage] = []
-        self._keep = []
-        self._arr = None
-        self.pack_weights = Chain.pack_default
-        self.split_bf16 = Chain.split_default
-
-    pack_default = True  # LINEAR weights are handed to the kernel as tbx_pack_weight images (row-major kept for tests)
-    # packed LINEAR stages on the three-product split-bf16 MFMA path (~1e-5 relative instead of exact fp32; include/tbx_hip.h
-    # TBX_F_WSPLIT). Off by default: the exact-fp32 MFMA is the parity path; TBX_SPLIT_BF16=1 turns it on for a process.
-    split_default = os.environ.get("TBX_SPLIT_BF16", "0") == "1"
-
-    def _add(self, **kw):
-        p0, p1, p2 = kw.pop("p0", None), kw.pop("p1", None), kw.pop("p2", None)
-        for t in (p0, p1, p2):
-            if t is not None:
-                self._keep.append(t)
-        st = Stage(**kw)
-        st.p0, st.p1, st.p2 = _ptr(p0), _ptr(p1), _ptr(p2)
-        self.stages.append(st)
-        self._arr = None
-        return self
-
-    @staticmethod
-    def _rows2d(t):
-        assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
-        return t
-
-    def load(self, src, dst, dst_col=0, n=None, pad_to=0, accum=False, row_div=0, row_mod=0, row_idx=None, batch_mod=None):
-        """dst[:, dst_col:+n] (=|+=) src[row_of(g), :n]. batch_mod=(rows_per_batch_here, rows_per_batch_src)."""
-        n = src.shape[1] if n is None else n
-        flags, div, k, p1 = (F_ACCUM if accum else 0), 0, pad_to, None
-        if row_div:
-            flags, div = flags | F_ROW_DIV, row_div
-        elif row_mod:
-            flags, div = flags | F_ROW_MOD, row_mod
-        elif row_idx is not None:
-            flags, p1 = flags | F_ROW_IDX, row_idx
-        elif batch_mod is not None:
-            flags, k, div = flags | F_ROW_BATCH_MOD, batch_mod[0], batch_mod[1]
-        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=k, flags=flags, div=div, ld=self._rows2d(src).stride(0),
-                         p0=src, p1=p1)
-
-    def load2(self, src, dst, dst_col, src_b, dst_b, dst_b_col):
-        """Two row loads in ONE stage (one memory round trip): dst[:, dst_col:+src.shape[1]] = src and dst_b[:, dst_b_col:+..] =
-        src_b (whole float4 rows on both sides, src_b at most 256 floats wide)."""
-        a, b = self._rows2d(src), self._rows2d(src_b)
-        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=a.shape[1], k=0, flags=F_LOAD2, ld=a.stride(0), p0=a,
-                         src=dst_b, src_col=dst_b_col, reserved=b.shape[1], ld2=b.stride(0), p2=b)
-
-    def zero(self, dst, dst_col, n):
-        return self._add(op=OP_LOAD, dst=dst, dst_col=dst_col, n=n, k=0, ld=1)
-
-    def linear(self, src, src_col, dst, dst_col, weight, bias=None, relu=False, accum=False, wt=False, groups=1,
-               src_stride=0, dst_stride=0, out=None, skip_rows=None, skip_is_valid=False, zero_skipped=False):
-        """dst[:, dst_col:+n] (=|+=) act(src[:, src_col:+k] @ W^T + b), W = weight [n,k] (or [k,n] if wt).
-        groups > 1: block-diagonal; weight holds the groups' blocks stacked along dim 0, group g reads
-        src_col + g*src_stride and writes dst_col + g*dst_stride.
-        dst = GLOBAL with out = [rows, ld] tensor: the result goes straight to out[g, dst_col:+n] (no LDS staging).
-        skip_rows (packed weights only): u8 per global row; flagged rows (un-flagged with skip_is_valid) keep dst's old content
-        (zero_skipped: are written as 0 instead: LINEAR + ROWMASK in one stage) -
-        with accum into the residual buffer: x += flagged ? 0 : linear(...) in one stage."""
-        w = self._rows2d(weight)
-        n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
-        flags = (F_ACCUM if accum else 0) | (F_WT if wt else 0)
-        assert (dst == GLOBAL) == (out is not None)
-        if out is not None and out.dtype == torch.bfloat16:  # a bf16 K/V table: rounded on the way out (TBX_F_OUT_BF16)
-            assert self.live_rows or self.pack_weights
-            flags |= F_OUT_BF16
-        if self.live_rows:
-            flags = (flags & ~F_WT) | F_WGEMV
-            if skip_rows is not None:
-                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0) | (F_ROWZERO if zero_skipped else 0)
-            return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=packed_weight(w, bias, wt, groups, gemv=True),
-                             p1=skip_rows, p2=out, ld2=0 if out is None else self._rows2d(out).stride(0),
-                             reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
-        if self.pack_weights:
-            w, flags = packed_weight(w, bias, wt, groups, self.split_bf16), (flags & ~F_WT) | F_WPACK
-            if self.split_bf16:
-                flags |= F_WSPLIT
-            if skip_rows is not None:
-                flags |= F_ROWSKIP | (F_MASK_INV if skip_is_valid else 0) | (F_ROWZERO if zero_skipped else 0)
-            return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                             act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=k, p0=w, p1=skip_rows, p2=out,
-                             ld2=0 if out is None else self._rows2d(out).stride(0),
-                             reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
-        assert skip_rows is None, "skip_rows needs packed weights"
-        return self._add(op=OP_LINEAR, src=src, dst=dst, src_col=src_col, dst_col=dst_col, k=k, n=n,
-                         act=ACT_RELU if relu else ACT_NONE, flags=flags, ld=w.stride(0), p0=w, p1=bias, p2=out,
-                         ld2=0 if out is None else self._rows2d(out).stride(0),
-                         reserved=groups if groups > 1 else 0, div=(src_stride << 16) | dst_stride)
-
-    def layernorm(self, src, src_col, dst, dst_col, weight, bias, eps=1e-5):
-        return self._add(op=OP_LAYERNORM, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=weight.shape[0], f0=eps,
-                         p0=weight, p1=bias)
-
-    def add(self, src, src_col, dst, dst_col, n):
-        return self._add(op=OP_ADD, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
-
-    def copy(self, src, src_col, dst, dst_col, n):
-        return self._add(op=OP_COPY, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n)
-
-    def clamp(self, dst, dst_col, n, lo, hi):
-        return self._add(op=OP_CLAMP, dst=dst, dst_col=dst_col, n=n, f0=lo, f1=hi)
-
-    def dropout(self, dst, dst_col, n, p: float, seed, site: int, step: int):
-        """dst[:, dst_col:+n] in place with tbx_keyed_dropout's mask of (seed, site, step, global row, column of n)."""
-        th = p * 4294967296.0
-        th = 1 if 0 < th < 1 else int(th)
-        return self._add(op=OP_DROPOUT, dst=dst, dst_col=dst_col, n=n, k=int(step), div=int(site), f0=1.0 / (1.0 - p),
-                         reserved=th - (1 << 32) if th >= (1 << 31) else th, p0=seed)
-
-    def rowmask(self, dst, dst_col, n, mask=None, fill=0.0, row_div=0, valid_mask=False):
-        """Fill rows whose mask byte is set (valid_mask: whose byte is clear, i.e. `mask` is a validity array)."""
-        flags, div = (F_ROW_DIV, row_div) if row_div else (0, 0)
-        flags |= F_MASK_INV if valid_mask else 0
-        return self._add(op=OP_ROWMASK, dst=dst, dst_col=dst_col, n=n, f0=fill, flags=flags, div=div, p0=mask)
-
-    def groupmax(self, src, src_col, dst, dst_col, n, mask=None):
-        """mask u8 [rows]: masked rows stay out of the maximum and are zeroed in the src and dst columns (see include/tbx_hip.h)."""
-        return self._add(op=OP_GROUPMAX, src=src, dst=dst, src_col=src_col, dst_col=dst_col, n=n, p1=mask)
-
-    def poolmax(self, src, src_col, n, out, out_col=0, mask=None, keep=None):
-        """out[group] = max over the group's unmasked rows. keep=(buf, col): the pooled rows also stay in LDS (row j of `buf` != src =
-        group j of the tile) and the stages after this one run on them - the tile's global rows are then its group indices."""
-        if keep is None:
-            return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
-                             p1=mask)
-        assert keep[0] != src and not self.live_rows
-        return self._add(op=OP_POOLMAX, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
-                         p1=mask, dst=keep[0], k=keep[1], flags=F_POOL_KEEP)
-
-    def store(self, src, src_col, n, out, out_col=0):
-        """out[g, out_col:+n] = src[:, src_col:+n]; a bfloat16 `out` receives the values rounded to nearest even."""
-        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out,
-                         flags=F_OUT_BF16 if out.dtype == torch.bfloat16 else 0)
-
-    def store_masked_sum(self, src, src_col, n, group_stride, masks, out, out_col=0):
-        """out[g, out_col:+n] = sum over the G groups i with masks[i, g] == 0 of src[:, src_col + i*group_stride : +n] (masks u8 [G, rows])."""
-        assert masks.dtype == torch.uint8 and masks.dim() == 2 and masks.is_contiguous() and out.dtype == torch.float32
-        return self._add(op=OP_STORE, src=src, src_col=src_col, n=n, dst_col=out_col, ld=self._rows2d(out).stride(0), p0=out, p1=masks,
-                         reserved=masks.shape[0], div=group_stride, k=masks.shape[1], flags=F_MASKED_SUM)
-
-    def run(self, n_rows: int, group_rows: int = 0):
-        if self._arr is None:
-            assert len(self.stages) <= MAX_STAGES, f"{len(self.stages)} stages > {MAX_STAGES}"
-            self._arr = (Stage * len(self.stages))(*self.stages)
-        if self.live_rows:
-            assert group_rows == 0, "live-row chains are flat"
-            rc = load().tbx_rowchain_live(self._arr, len(self.stages), n_rows, self.live_rows, self.ldw, self.ldw1, self.ld_aux,
-                                          stream_ptr())
-        else:
-            rc = load().tbx_rowchain_ex(self._arr, len(self.stages), n_rows, group_rows, self.tile_rows, self.ldw, self.ldw1,
-                                        self.ld_aux, stream_ptr())
-        _check(rc, "tbx_rowchain")
