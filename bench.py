@@ -203,6 +203,14 @@ def main(argv=None):
             b16.kv_bf16, b16.attn_mfma, b16.scenes, b16.rollouts, b16.agents, b16.steps = True, 1, 1, 32, 128, min(args.steps, 40)
             r16, _, _ = measure(b16)
             full["bf16"]["wosac_shape"] = {"steps": b16.steps, "warmup": b16.warmup, **r16}
+        if args.submission_shape:
+            b16 = copy.copy(args)
+            b16.kv_bf16, b16.attn_mfma, b16.scenes, b16.rollouts, b16.agents, b16.steps, b16.new_scenes = True, 1, 1, 128, 128, min(args.steps, 40), 0
+            try:
+                r16, _, _ = measure(b16)
+                full["bf16"]["submission_shape"] = {"steps": b16.steps, "warmup": b16.warmup, **r16}
+            except Exception as e:  # noqa: BLE001
+                full["bf16"]["submission_shape"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if args.scene_curve:
         # the scenes-per-GPU curve (same scene shape, S scenes batched in one engine): where the one-row-per-workgroup layer
         # stops and the tile path starts. No per-kernel pass; one entry each, headline stays scenes = 1.

@@ -119,6 +119,8 @@ def judged_line(full):
         b = compact_shape(full["bf16"])
         if full["bf16"].get("wosac_shape"):
             b["wosac_shape"] = compact_shape(full["bf16"]["wosac_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"), lean=True)
+        if full["bf16"].get("submission_shape"):
+            b["submission_shape"] = compact_shape(full["bf16"]["submission_shape"], keys=("value", "ms_per_step", "steps", "warmup", "finite"), lean=True)
         line["bf16"] = b
     if full.get("reduced"):
         r = compact_shape(full["reduced"])

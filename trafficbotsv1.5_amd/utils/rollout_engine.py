@@ -622,8 +622,10 @@ class RolloutEngine:
                                    "captured for (use a new engine: WaymoMotion.engine_cache = 0)")
         if self.reused:  # the log tensors are rewritten by this engine's next rollout: the buffer gets its own copies
             S = {k: (v.clone() if k.startswith("out_") else v) for k, v in S.items()}
-        buf.pred_valid, buf.pred_pose, buf.pred_motion = S["out_valid"].bool(), S["out_pose"], S["out_motion"]
-        buf.violation = {"outside_map": S["out_outside_map"].bool(), "dest_reached": S["out_dest_reached"].bool()}
+        # (the u8 logs hold 0 / 1 - tbx_sim_step stores C++ bools -: their bool form is a reinterpreting view, not a conversion launch)
+        b8 = lambda t: t.view(torch.bool) if t.dtype == torch.uint8 else t.bool()
+        buf.pred_valid, buf.pred_pose, buf.pred_motion = b8(S["out_valid"]), S["out_pose"], S["out_motion"]
+        buf.violation = {"outside_map": b8(S["out_outside_map"]), "dest_reached": b8(S["out_dest_reached"])}
         rep = (lambda t: t) if self.tl_div == 1 else (lambda t: t.repeat_interleave(self.tl_div, 0))  # per rollout again
         out_tl = rep(S["out_tl_state"])
         if rule_checker is not None:
@@ -632,14 +634,14 @@ class RolloutEngine:
         buf.vis_dict = {"action": S["out_action"], "tl_state": bits.bool()}
         # what the reference's loop adds per step besides the prediction (waymo_motion.py:250-300)
         r = S["out_reward"]
-        buf.diffbar_reward = {"diffbar_reward_valid": S["out_reward_valid"].bool(), "diffbar_reward": r[..., 3],
+        buf.diffbar_reward = {"diffbar_reward_valid": b8(S["out_reward_valid"]), "diffbar_reward": r[..., 3],
                               "r_imitation_pos": r[..., 0], "r_imitation_rot": r[..., 1], "r_imitation_spd": r[..., 2],
                               "r_traffic_rule_approx": torch.zeros_like(r[..., 0])}
         buf.tl_state_nll = rep(S["out_tl_nll"])
         inv = self.tl_invalid_full.bool().unsqueeze(-1).expand(-1, -1, self.T).clone()
         inv[:, :, max(self.n_step_tl_gt - 1, 0):] = True  # steps past the light ground truth carry no NLL (waymo_motion.py:277-279)
         buf.tl_state_nll_invalid = inv
-        buf.mask_teacher_forcing = S["out_tf"].bool()
+        buf.mask_teacher_forcing = b8(S["out_tf"])
         buf.action_log_prob = self.action_log_prob(S["out_valid"])
         lp0 = self.navi_log_prob0 if self.navi_log_prob0 is not None else torch.zeros(self.n, self.A, device=self.dev)
         buf.navi_log_prob, buf.navi_log_prob_valid = lp0.unsqueeze(-1), self.navi_valid0.bool().unsqueeze(-1)

@@ -34,6 +34,7 @@ class TrafficRuleChecker:
         # the scene tables sorted into a uniform raster (tbx_rule_grid): a vehicle's road-edge / lane tests visit the few cells around it
         # instead of the scene's ~6,400 rows - bit-identical flags (tests/test_hip_rules.py runs both); False: the full scans
         self.use_grid = True
+        self._bits: Optional[Tensor] = None
         self._ctx: Optional[hip.RuleCtx] = None
         self._keep = None
         self._acc: Optional[Tensor] = None          # running OR of the five flags [n, A] u8 bits
@@ -64,6 +65,9 @@ class TrafficRuleChecker:
         for k, v in keep.items():
             setattr(ctx, k, v.data_ptr())
         ctx.collision_size_scale = self.collision_size_scale
+        # the five flag bits as a device tensor made ON the device (a host list -> device copy would wait for the stream to drain)
+        assert [b for _, b in _KEYS] == [1 << i for i in range(len(_KEYS))]
+        self._bits = (1 << torch.arange(len(_KEYS), device=size.device, dtype=torch.int32)).to(u8).view(-1, 1, 1, 1, 1)
         self._keep, self._ctx = keep, ctx
         self._acc = torch.zeros(n, A, dtype=u8, device=size.device)
         self.passive_counter = torch.zeros(n, A, dtype=torch.float32, device=size.device)
@@ -83,14 +87,18 @@ class TrafficRuleChecker:
             z = torch.zeros(n, A, T, dtype=torch.bool, device=pose.device)
             return {k + s: z for k, _ in _KEYS for s in ("", "_this_step")}
         v8 = valid.to(torch.uint8).contiguous()
-        now = torch.zeros(n, A, T, dtype=torch.uint8, device=pose.device)
-        acc = torch.zeros(n, A, T, dtype=torch.uint8, device=pose.device)
+        # (the kernels write every frame of [t0, t0 + n_t): a whole-log call needs no zero fill)
+        alloc = torch.empty if (t0 == 0 and n_t == T) else torch.zeros
+        both = alloc(2, n, A, T, dtype=torch.uint8, device=pose.device)
+        now, acc = both[0], both[1]
         hip.rule_check(ctx, v8, pose.float().contiguous(), motion.float().contiguous(), tl_state_bits.contiguous(), T, t0, n_t, now)
         hip.rule_accumulate(now, n * A, T, t0, n_t, self._acc, self.passive_counter, now, acc)
+        # the ten boolean fields as views of ONE [5 flags, 2 (this step | accumulated), n, A, T] tensor: two launches instead of twenty
+        flags = (both.unsqueeze(0) & self._bits) != 0
         out = {}
-        for k, bit in _KEYS:
-            out[k] = (acc & bit).bool()
-            out[k + "_this_step"] = (now & bit).bool()
+        for i, (k, _) in enumerate(_KEYS):
+            out[k] = flags[i, 1]
+            out[k + "_this_step"] = flags[i, 0]
         return out
 
     # ------------------------------------------------------------------ the reference's per-step entry point
