@@ -352,8 +352,9 @@ def train_kernel_pass(hip, step, replay_s):
         return T("tall_linear_kernel (tbx_tall_linear" + ("_bf16)" if bf16 else ")"), "hbm", by, saved["tall_linear"], x, w, b, wt=wt, relu=relu, bf16=bf16, **kw)
 
     def attn_m(qbuf, q_off, qt_off, n_batch, n_src, segs, *a, **kw):
-        r, p = pairs(n_batch, n_src, segs)  # (fp32 tables: 1041 B per pair as the VALU forward)
-        return T("knarpe_attn_mfma_kernel (forward, bf16 operands)", "hbm", attn_algorithmic_bytes(r, p), saved["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch,
+        r, p = pairs(n_batch, n_src, segs)  # (529 B per pair on the bfloat16 copies of the tables, 1041 on fp32 tables)
+        eb = 2 if segs[0].kv.dtype == torch.bfloat16 else 4
+        return T("knarpe_attn_mfma_kernel (forward, bf16 operands)", "hbm", attn_algorithmic_bytes(r, p, eb), saved["knarpe_attn_mfma"], qbuf, q_off, qt_off, n_batch,
                  n_src, segs, *a, **kw)
 
     def lt(x, attn=None, ffn=None, proj=None, store_x=True, drop=None, rider=None):

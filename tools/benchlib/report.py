@@ -35,12 +35,17 @@ def _r(x, sig=6):
     return x
 
 
-def compact_roofline(r):
+SUB_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "launches_per_step",
+                 "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch", "flops_per_launch")
+
+
+def compact_roofline(r, sub=False):
+    """sub: the roofline of an appended shape (the judged object keeps every key; the detail file keeps everything of all of them)."""
     if not r:
         return None
     if "error" in r:
         return {"error": str(r["error"])[:200]}
-    out = {k: r[k] for k in ROOF_KEYS if k in r}
+    out = {k: r[k] for k in (SUB_ROOF_KEYS if sub else ROOF_KEYS) if k in r}
     out.setdefault("traffic", None)
     c = r.get("counters")
     if c:
@@ -60,8 +65,8 @@ def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps",
         if "value" in w:
             out["with_rule_checks"] = {"value": w["value"], "vs_unchecked": w.get("vs_unchecked")}
         r = res.get("roofline") or {}
-        if "frac" in r:
-            out["roofline"] = {k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "peak", "unit", "achieved", "traffic", "traffic_source") if k in r}
+        if "frac" in r:  # (frac = algorithmic bytes or flops per launch / avg_launch_us / peak, as everywhere; the full object is in the detail file)
+            out["roofline"] = {k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "flops_per_launch", "peak", "traffic", "traffic_source") if r.get(k) is not None}
         return out
     if res.get("scene_reuse"):
         out["new_scene_ms"] = res["scene_reuse"]["new_scene_ms"]
@@ -73,10 +78,7 @@ def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps",
                 out[k] = res["config"][k]
     if "dtype" in res:
         out["dtype"] = res["dtype"]
-    out["roofline"] = compact_roofline(res.get("roofline"))
-    if res.get("roofline_gemm"):
-        g = res["roofline_gemm"]
-        out["roofline_gemm"] = {k: g[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in g}
+    out["roofline"] = compact_roofline(res.get("roofline"), sub=True)
     if res.get("with_rule_checks"):
         out["with_rule_checks"] = compact_checks(res["with_rule_checks"])
     return out
@@ -129,6 +131,7 @@ def judged_line(full):
         line["reduced"] = r
     if full.get("training"):
         t = compact_shape(full["training"], keys=("metric", "value", "unit", "ms_per_step", "steps", "warmup", "loss", "finite", "dtype"))
+        t["workload"] = "training_step fwd+bwd+grad all-reduce+AdamW, 16 scenes/GPU (64/1024/128), 90-step rollout" if t.get("workload") else None
         t["train_precision"] = (full["training"].get("config") or {}).get("train_precision")
         line["training"] = t
     if full.get("training_fp32"):

@@ -70,4 +70,4 @@ with E.use(wm.schedule):
         return e0.elapsed_time(e1) / reps
 
     print(f"graph_prepare (input copies excluded) {timed(eng.graph_prepare.replay):.3f} ms   graph_commit {timed(eng.graph_commit.replay):.3f} ms   "
-          f"prime graph {timed(eng.graph_prime.replay):.3f} ms   one 40-step graph {timed(eng.graph_multi.replay, 5):.3f} ms")
+          f"prime graph {timed(eng.graph_prime.replay):.3f} ms   one 40-step graph {timed((list(eng.graph_multi.values())[0] if isinstance(eng.graph_multi, dict) else eng.graph_multi).replay, 5):.3f} ms")
