@@ -18,6 +18,8 @@
 //   * weights come as a per-wave stream of 8 KiB units (tbx_pack_weight_mfma32: the fragments of [16 channels x 128 k] in register
 //     order), double-buffered in registers one unit ahead across stage boundaries;
 //   * no program to decode: the stage list is the template instantiation.
+#include <atomic>
+
 #include "tile_core.h"
 
 using namespace tbx_tile;
@@ -25,10 +27,16 @@ using namespace tbx_tile;
 namespace {
 
 constexpr int ROWS = 16;
-typedef Planes<ROWS, 20> PL;  // K <= 640 (the attention output: sum a v | sum a e of 4 heads)
-constexpr int PLANE = PL::PLANE;
+// Two plane pairs of different widths: the wide one takes whatever is wider than a token row - the attention output (K = 640: sum a v
+// | sum a e of 4 heads), the FFN's hidden row (K = 512) and q as the A side of the qt fold; the narrow one the 128-wide rows (the
+// folded value rows, the LayerNorm outputs). 69 KiB of LDS per workgroup (43 in the one-product build) instead of the 97 of two wide
+// pairs: TWO workgroups per CU, so a CU whose workgroup waits (weights, a barrier, its rows) has another one to run.
+typedef Planes<ROWS, 20> PA;
+typedef Planes<ROWS, 4> PB;
+constexpr int PLANE_A = PA::PLANE, PLANE_B = PB::PLANE;
+constexpr int NPL = TBX_TILE_SINGLE ? 1 : 2;  // planes per pair: hi | lo, or the one bf16 plane
 constexpr int XLD = 132;      // floats per row of the fp32 buffers X (token rows) and Y (sum a v)
-constexpr size_t LDS_BYTES = 2 * ROWS * XLD * sizeof(float) + 4 * PLANE;
+constexpr size_t LDS_BYTES = 2 * ROWS * XLD * sizeof(float) + NPL * (PLANE_A + PLANE_B);
 
 struct TileArgs {
   tbx_layer_tile_t t;
@@ -37,6 +45,7 @@ struct TileArgs {
 
 // LayerNorm_128 of row X[r] -> planes (k = 0..127), a wavefront per row, in rowchain.hip's ln_row order (bit-identical values
 // before the split)
+template <class PL>
 __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int lane, const float* gamma, const float* beta, float eps) {
   float v[2], gm[2], bt[2];
 #pragma unroll
@@ -56,14 +65,18 @@ __device__ __forceinline__ void ln_to_planes(const float* X, char* P, int r, int
     const int o = PL::off(r, lane + 64 * q);
     *(__bf16*)(P + o) = h;
 #if !TBX_TILE_SINGLE
-    *(__bf16*)(P + PLANE + o) = (__bf16)(y - (float)h);
+    *(__bf16*)(P + PL::PLANE + o) = (__bf16)(y - (float)h);
 #endif
   }
 }
 
-#ifndef TBX_TILE_RING
-#define TBX_TILE_RING 3
-#endif
+// Depth of the per-wave weight ring (register slots of one 8 KiB unit; RING - 1 units are in flight ahead of the stage that
+// multiplies them). Three slots are what a lone workgroup per CU wants (launches of up to one tile per CU: the prefetch is the only
+// thing that hides a unit's latency). With two slots every instantiation of the three-product build fits 128 VGPRs = 4 waves per SIMD
+// = TWO workgroups per CU, which is what launches of more tiles than CUs want (the other workgroup hides the latency; measured in
+// round 5, profiles/MEASUREMENT_LOG.md: +8.6 % at 64 scenes, +4.5 % at the submission shape, -6 % at 16 scenes if used everywhere).
+// The one-product build fits 128 VGPRs with three slots and always uses them.
+constexpr int RING_DEEP = 3, RING_PAIR = TBX_TILE_SINGLE ? 3 : 2;
 
 // profiling build (make clk): the LAST workgroup's wave 0 stamps the shader clock at the phase boundaries of every launch
 #ifdef TBX_STAGE_CLOCK
@@ -77,18 +90,18 @@ __device__ unsigned int g_tl_launch;
 #define TL_CLK(i)
 #endif
 
-template <bool ATTN, bool FFN, int PROJ>
+template <bool ATTN, bool FFN, int PROJ, int RING>
 __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* X = lds;
   float* Y = X + ROWS * XLD;
   char* Pa = (char*)(Y + ROWS * XLD);
-  char* Pb = Pa + 2 * PLANE;
+  char* Pb = Pa + NPL * PLANE_A;  // (Pa: the wide pair, Pb: the narrow one)
   const tbx_layer_tile_t& t = a.t;
   if constexpr (!ATTN && !FFN && PROJ == 2) {
     const int main_tiles = (int)((t.n_rows + ROWS - 1) / ROWS);
     if ((int)blockIdx.x >= main_tiles) {  // (only launched with rider_rows > 0)
-      rider_tile<PL, XLD>(t, (int)blockIdx.x - main_tiles, X, Pa, Pb);
+      rider_tile<PB, XLD>(t, (int)blockIdx.x - main_tiles, X, Pb, Pa);  // (its 128-wide stages: two narrow pairs)
       return;
     }
   }
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   const int nv = (t.n_rows - row0) < ROWS ? (int)(t.n_rows - row0) : ROWS;
   const bool row_ok = j < nv;
   const int64_t grow = row0 + (row_ok ? j : 0);
-  const int aoff = PL::lane_off(lane, 0);  // the lane's (octet, row) offset inside a plane
+  const int aoffA = PA::lane_off(lane, 0), aoffB = PB::lane_off(lane, 0);  // the lane's (octet, row) offset inside a plane
   const int c_out = 16 * wave + 4 * g;  // the lane's 4 output channels of a 128-wide stage
 
   constexpr int E_FOLD = 0, E_OUT = 1, E_L1 = ATTN ? 2 : 0, E_L2 = E_L1 + 4, E_Q = (ATTN ? 2 : 0) + (FFN ? 8 : 0);
@@ -115,7 +128,6 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
   // weight units through a ring of RING register slots, RING - 1 units ahead of the stage that multiplies them. The ring is primed
   // BEHIND the requests for the tile's own rows (memory answers a wave in order: 64 KiB of weights per unit in front of them delayed
   // every stage of the launch)
-  constexpr int RING = TBX_TILE_RING;
   W wb[RING];
 #define TBX_NEXT(E)                                                          \
   do {                                                                       \
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     *(f32x4*)(X + xr * XLD + xc4 * 4) = xv0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      planes_write4<PL>(Pa, rr[i], cc[i] * 4, v[i]);
+      planes_write4<PA>(Pa, rr[i], cc[i] * 4, v[i]);
       if (cc[i] < 32) *(f32x4*)(Y + rr[i] * XLD + cc[i] * 4) = v[i];
     }
   }
@@ -169,9 +181,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       acc.zero();
       const int step0 = 4 + 4 * (wave >> 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, step0 + s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE_A>(acc, w.hi[s], w.lo[s], Pa + aoffA, step0 + s);
       const f32x4 y = acc.sum() + w.bias + *(const f32x4*)(Y + j * XLD + c_out);
-      planes_write4<PL>(Pb, j, c_out, y);
+      planes_write4<PB>(Pb, j, c_out, y);
     }
     __syncthreads();
     TL_CLK(2);
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       Acc acc;
       acc.zero();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE_B>(acc, w.hi[s], w.lo[s], Pb + aoffB, s);
       f32x4 xv = *(const f32x4*)(X + j * XLD + c_out);
       f32x4 upd = acc.sum() + w.bias;
       if (t.drop_thresh != 0u && t.drop_site[0] >= 0) {
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 
   if constexpr (FFN) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.norm2_weight, t.norm2_bias, t.norm2_eps);
+    for (int q = 0; q < 2; ++q) ln_to_planes<PB>(X, Pb, wave * 2 + q, lane, t.norm2_weight, t.norm2_bias, t.norm2_eps);
     __syncthreads();
     TL_CLK(4);
     const bool drop_h = t.drop_thresh != 0u && t.drop_site[1] >= 0;
@@ -212,10 +224,10 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     const W& w = wb[(E_L1 + (R)) % RING];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE_B>(acc, w.hi[s], w.lo[s], Pb + aoffB, s); \
     f32x4 h = relu4(acc.sum() + w.bias);                                                        \
     if (drop_h) h = dkh.apply(h, row0 + j, (R) * D + c_out, 4 * D);                             \
-    planes_write4<PL>(Pb, j, (R) * D + c_out, h);                                                   \
+    planes_write4<PA>(Pa, j, (R) * D + c_out, h);                                                   \
   } while (0)
 #ifdef TBX_STAGE_CLOCK  // (stamps 10..14: linear1's first unit taken apart - its weights' arrival, the next unit's load latency, MFMAs, epilogue)
     {
@@ -228,11 +240,11 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       const W& w = wb[E_L1 % RING];
       Acc acc;
       acc.zero();
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s);
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE_B>(acc, w.hi[s], w.lo[s], Pb + aoffB, s);
       f32x4 h = relu4(acc.sum() + w.bias);
       if (tl_slot < 256u) g_tl_clk[tl_slot * 16 + 13] = clock64() + (unsigned long long)(h[0] != h[0]);  // (after the MFMAs' results)
       if (drop_h) h = dkh.apply(h, row0 + j, c_out, 4 * D);
-      planes_write4<PL>(Pb, j, c_out, h);
+      planes_write4<PA>(Pa, j, c_out, h);
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the planes are written
       TL_CLK(14);
     }
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     TBX_NEXT(E_L2 + (R));                                                                                 \
     const W& w = wb[(E_L2 + (R)) % RING];                                                                    \
     if ((R) == 0) bias = w.bias;                                                                          \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, 4 * (R) + s); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE_A>(acc, w.hi[s], w.lo[s], Pa + aoffA, 4 * (R) + s); \
   } while (0)
       TBX_L2(0);
       TBX_L2(1);
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
 
   if constexpr (PROJ != 0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) ln_to_planes(X, Pa, wave * 2 + q, lane, t.proj_norm_weight, t.proj_norm_bias, t.proj_norm_eps);
+    for (int q = 0; q < 2; ++q) ln_to_planes<PB>(X, Pb, wave * 2 + q, lane, t.proj_norm_weight, t.proj_norm_bias, t.proj_norm_eps);
     __syncthreads();
     TL_CLK(7);
     {  // q
@@ -287,9 +299,9 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       Acc acc;
       acc.zero();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s);
+      for (int s = 0; s < 4; ++s) mfma_step<PLANE_B>(acc, w.hi[s], w.lo[s], Pb + aoffB, s);
       const f32x4 q = acc.sum() + w.bias;
-      planes_write4<PL>(Pb, j, c_out, q);
+      planes_write4<PA>(Pa, j, c_out, q);
       if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + c_out, q);
     }
     if constexpr (PROJ == 2) {  // k | v: straight to the table (fp32 columns [128, 384) of proj_out, or the bfloat16 table)
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
     const W& w = wb[(E_KV + (R)) % RING];                                                          \
     Acc acc;                                                                                    \
     acc.zero();                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pa + aoff, s); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) mfma_step<PLANE_B>(acc, w.hi[s], w.lo[s], Pb + aoffB, s); \
     const f32x4 kv = acc.sum() + w.bias;                                                        \
     if (row_ok) {                                                                               \
       if (t.kv16_out != nullptr) {                                                              \
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(NT) void tile_layer_kernel(const TileArgs a) {
       for (int s = 0; s < 4; ++s) {
         Acc acc;
         acc.zero();
-        mfma_step<PLANE>(acc, w.hi[s], w.lo[s], Pb + aoff, h);
+        mfma_step<PLANE_A>(acc, w.hi[s], w.lo[s], Pa + aoffA, h);
         const f32x4 v = acc.sum();
         if (row_ok) gst4(t.proj_out + grow * (int64_t)t.ld_proj + qt_off + h * D + ((wave & 1) * 4 + s) * 16 + 4 * g, v);
       }
@@ -398,13 +410,36 @@ int64_t mfma32_units(int n, int k, int groups) {
   return T * (k / 128);
 }
 
+template <bool ATTN, bool FFN, int PROJ, int RING>
+int launch_ring(const TileArgs& a, unsigned grid, hipStream_t s) {
+  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
+  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tile_layer_kernel<ATTN, FFN, PROJ, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
+  hipLaunchKernelGGL((tile_layer_kernel<ATTN, FFN, PROJ, RING>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+// the device's CU count (cached per device ordinal): a launch of at least that many tiles takes the two-workgroups-per-CU form
+int cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 template <bool ATTN, bool FFN, int PROJ>
 int launch(const TileArgs& a, hipStream_t s) {
-  static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
-  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tile_layer_kernel<ATTN, FFN, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const unsigned grid = (unsigned)((a.t.n_rows + ROWS - 1) / ROWS) + (unsigned)((a.t.rider_rows + ROWS - 1) / ROWS);
-  hipLaunchKernelGGL((tile_layer_kernel<ATTN, FFN, PROJ>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
-  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+  if constexpr (RING_PAIR != RING_DEEP) {
+    if ((int)grid >= cu_count()) return launch_ring<ATTN, FFN, PROJ, RING_PAIR>(a, grid, s);
+  }
+  return launch_ring<ATTN, FFN, PROJ, RING_DEEP>(a, grid, s);
 }
 
 }  // namespace
