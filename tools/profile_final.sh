@@ -37,7 +37,17 @@ bash tools/profile_round.sh ${tag}_s64_bf16 64 1024 128 64 1 --steps 40 --new-sc
 if [ -f trafficbotsv1.5_amd/csrc/libtbx_hip_clk.so ]; then
   python3 tools/attn_clock.py 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_attn_phase_clock.txt
 fi
-TAG=${tag} bash tools/pmc_train.sh > $out/${tag}_train_pmc_top.txt 2>&1
-python bench.py > $out/${tag}_bench_default.log 2>&1
+# (opt-in: in round 5 the counter service aborted inside an eager training step with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and rocprofv3
+#  then sat until the job's limit - profiles/MEASUREMENT_LOG.md)
+if [ -n "${TRAIN_PMC:-}" ]; then TAG=${tag} timeout 600 bash tools/pmc_train.sh > $out/${tag}_train_pmc_top.txt 2>&1; fi
+# a steady-state step of the 64-scene shape, queue by queue; the overlapped scene loop, call by call
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/tl_s64 -o tl -- python3 $root/bench.py --no-cpu-baseline --no-wosac-shape --scenes 64 --steps 40 --profile-steps 0 --new-scenes 0 > /dev/null 2>&1 )
+python3 tools/step_timeline2.py $(ls /tmp/tl_s64/*.db | head -1) > $out/${tag}_s64_two_stream_timeline.txt 2>&1
+rm -rf /tmp/tl_s64
+timeout 300 python3 tools/scene_loop_profile.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_scene_loop_profile.txt
+# the judged command, last: its line and its detail file
+timeout 900 python bench.py > $out/${tag}_bench_default.log 2>&1
+grep -a '"metric"' $out/${tag}_bench_default.log | tail -1 > $out/${tag}_bench_line.json
+cp $out/bench_detail.json $out/${tag}_bench_detail.json
 tail -1 $out/${tag}_bench_default.log | cut -c1-200
 cat $out/${tag}_gpu_tests.log
