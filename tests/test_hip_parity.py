@@ -718,6 +718,55 @@ def test_layer_tile_equals_row_chains(tb, hip, dev, mode, S, Ks, T, K, n_layer, 
     assert err > 0.0  # the two paths really are different arithmetic
 
 
+@pytest.mark.parametrize("bf16_products", [False, True])
+def test_layer_tile_two_workgroups_per_cu_form_is_bit_identical(tb, hip, dev, bf16_products):
+    """tile_layer.hip picks the depth of its weight ring by the launch's size: at least one tile per CU -> two register slots (<= 128
+    VGPRs: two workgroups per CU), fewer -> three. Same stages, same operands, same order: a block run on 2 x 2,100 rows in one call
+    (263 tiles) must give the bits of the two batch entries run one at a time (132 tiles each), for every instantiation a decoder block
+    launches (<0,0,2> first projection, <1,0,1>, <1,1,2>, <1,1,0>). transformer_rpe.py:207-245."""
+    eng = import_module("trafficbots_amd.engine")
+    M = import_module("trafficbots_amd.models.modules.transformer_rpe")
+    P = import_module("trafficbots_amd.utils.pose_emb")
+    g = torch.Generator().manual_seed(77)
+    blk = M.TransformerBlockRPE(n_layer=2, mode="dec_cross_attn", d_rpe=128, d_model=128, n_head=4, k_feedforward=4, dropout_p=0.1,
+                                bias=True, activation="relu", out_layernorm=False, apply_q_rpe=False)
+    tb.utils.det_fill(blk, 13)
+    blk = blk.to(dev).eval()
+    n, S, Ks, T, K, D = 2, 2100, 8, 96, 12, 128
+    x0 = torch.randn(n * S, D, generator=g).to(dev)
+    src_invalid = (torch.rand(n * S, generator=g) < 0.1).to(torch.uint8).to(dev)
+    x0[src_invalid.bool()] = 0.0
+
+    def knn(T_, K_):
+        rel = torch.cat([(torch.rand(n, S, K_, 2, generator=g) - 0.5) * 100, (torch.rand(n, S, K_, 1, generator=g) - 0.5) * 6], -1)
+        m = (torch.rand(n, S, K_, generator=g) < 0.3).to(torch.uint8).to(dev)
+        m[src_invalid.view(n, S).bool()] = 1
+        return torch.randint(0, T_, (n, S, K_), generator=g).to(torch.int32).to(dev), m, rel.to(dev).contiguous()
+
+    i0, m0, r0 = knn(S, Ks)
+    ic, mc, rc = knn(T, K)
+    kv = torch.randn(n * T, 2 * 256, generator=g).to(dev)
+    pe = P.PoseEmb("pe_xy_yaw", pe_dim=128, theta_xy=1e3).to(dev)
+    sched = eng.DEFAULT.replace(tile_layer=True, tile_min_rows=1024, attn_fold_big=False, linear_bf16=bf16_products)
+
+    def run(b0, b1):
+        nb = b1 - b0
+        x = x0[b0 * S:b1 * S].clone()
+        cross = lambda l: [hip.Seg(kv[b0 * T:b1 * T].contiguous(), l * 256, l * 256 + D, T, ic[b0:b1].contiguous(), mc[b0:b1].contiguous(), None, 1,
+                                   rel=rc[b0:b1].contiguous())]
+        with eng.use(sched):
+            assert eng.tile_rows_ok(nb * S)
+            eng.run_block(blk, x, src_invalid[b0 * S:b1 * S].contiguous(), nb, S,
+                          eng.SelfKnn(i0[b0:b1].contiguous(), m0[b0:b1].contiguous(), rel=r0[b0:b1].contiguous()), cross=cross, pose_rpe=pe)
+        torch.cuda.synchronize()
+        return x
+
+    whole = run(0, 2)
+    halves = torch.cat([run(0, 1), run(1, 2)], 0)
+    assert torch.isfinite(whole).all() and float((whole - x0).abs().max()) > 1e-3
+    assert torch.equal(whole, halves)
+
+
 @pytest.mark.parametrize("rows,r_rows,pose3", [(64, 64, False), (40, 21, False), (16, 130, True), (48, 33, True)])
 def test_layer_tile_rider_equals_the_navigation_chain(tb, hip, dev, rows, r_rows, pose3):
     """tbx_layer_tile_t's rider (extra workgroups of the first-projection launch): y = add + W0 in + b0, three relu LINEARs, invalid
