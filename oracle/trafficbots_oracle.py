@@ -471,14 +471,17 @@ class Sim:
         d_prior = Independent(Normal(prior.base_dist.loc.detach(), prior.base_dist.scale.detach()), 1)
         e0 = torch.clamp(kl_divergence(d_post, prior), min=c.kl_free_nats)
         e1 = torch.clamp(kl_divergence(post, d_prior), min=c.kl_free_nats)
+        # (metrics/training.py:166-186: a term whose counter is zero - a batch without a valid light, say - is LEFT OUT of the loss;
+        #  here: its masked sum is 0, divided by a count of at least 1)
+        ratio = lambda total, count: total / count.clamp(min=1)
         kl_valid = (latent_post.valid if c.kl_for_unseen_agent else latent_prior.valid) & any_valid
-        vae_kl = c.w_vae_kl * (e0 + c.kl_balance_scale * e1).masked_fill(~kl_valid, 0).sum() / kl_valid.sum()
+        vae_kl = c.w_vae_kl * ratio((e0 + c.kl_balance_scale * e1).masked_fill(~kl_valid, 0).sum(), kl_valid.sum())
         r_valid = loss_valid & ro["diffbar_reward_valid"]
-        reward = c.w_diffbar_reward * ro["diffbar_reward"].masked_fill(~r_valid, 0).sum() / r_valid.sum()
+        reward = c.w_diffbar_reward * ratio(ro["diffbar_reward"].masked_fill(~r_valid, 0).sum(), r_valid.sum())
         n_valid = navi_pred.valid & any_valid
-        navi = c.w_navi * (-navi_pred.log_prob(navi_gt)).masked_fill(~n_valid, 0).sum() / n_valid.sum()
+        navi = c.w_navi * ratio((-navi_pred.log_prob(navi_gt)).masked_fill(~n_valid, 0).sum(), n_valid.sum())
         tl_valid = ~ro["tl_state_nll_invalid"]
-        tl = c.w_tl_state * ro["tl_state_nll"].masked_fill(~tl_valid, 0).sum() / tl_valid.sum()
+        tl = c.w_tl_state * ratio(ro["tl_state_nll"].masked_fill(~tl_valid, 0).sum(), tl_valid.sum())
         return {"loss": vae_kl - reward + navi + tl, "vae_kl": vae_kl, "diffbar_reward": reward, "navi_loss": navi,
                 "tl_state_loss": tl}
 

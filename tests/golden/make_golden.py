@@ -381,7 +381,7 @@ def gen_model(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_roll_steps, train_fixture):
     npz(f"model_{tag}.npz", **out)
 
 
-def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_sc=1):
+def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_sc=1, edge=False):
     """§8a rows 19-20 at the size of BASELINE config 3's scenes (one scene of 64 agents / 1024 polylines / 128 lights): the
     reference's training_step with every RNG site neutralised and the damped action head (see gen_model): loss dict, per-module
     gradient norms, spot gradients. ~3 min of reference CPU time. n_sc > 1: a BATCH of scenes (BASELINE config 3 trains on batches:
@@ -400,7 +400,10 @@ def gen_train(tag, n_ag, n_mp, n_tl, n_tgt_knn, n_sc=1):
         for k, p in wm_t.model.named_parameters():
             if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
                 p.mul_(0.02)
-    batch = tb.synthetic.make_scene(n_sc, n_ag, n_mp, n_tl, seed=0)
+    # edge: three scenes with the domain's empty inputs - no valid light / two agents / no valid polyline (synthetic.make_edge_batch)
+    # edge = "no_lights": one scene without a valid light (the light-state term's counter is zero: metrics/training.py:184 leaves it out)
+    batch = (tb.synthetic.make_edge_batch(n_ag, n_mp, n_tl, seed=0, kind=edge if isinstance(edge, str) else "mixed") if edge
+             else tb.synthetic.make_scene(n_sc, n_ag, n_mp, n_tl, seed=0))
     torch.manual_seed(7)
     loss = wm_t.training_step({k: v.clone() for k, v in batch.items()}, 0)
     loss.backward()
@@ -482,7 +485,7 @@ def gen_filter():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "train_c1_b3", "rules", "filter"]
+    which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "train_c1_b3", "train_c1_edge", "train_c1_nolights", "rules", "filter"]
     if "filter" in which:
         gen_filter()
     if "rules" in which:
@@ -497,3 +500,7 @@ if __name__ == "__main__":
         gen_train("c2", 64, 1024, 128, 32)
     if "train_c1_b3" in which:
         gen_train("c1_b3", 8, 64, 8, 4, n_sc=3)
+    if "train_c1_edge" in which:
+        gen_train("c1_edge", 8, 64, 8, 4, n_sc=3, edge=True)
+    if "train_c1_nolights" in which:
+        gen_train("c1_nolights", 8, 64, 8, 4, n_sc=1, edge="no_lights")

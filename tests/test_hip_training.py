@@ -65,11 +65,25 @@ def test_attention_backward_vs_oracle_autograd(tb):
 # difference measured on MI355X (printed by the test; profiles/r05_train_bf16_tolerances.txt).
 TRAIN_TOL = {"fp32": dict(loss=1e-3, gnorm=1e-2, spot_rtol=2e-2, spot_atol_rel=0.0),
              "bf16": dict(loss=5e-4, gnorm=2e-2, spot_rtol=0.0, spot_atol_rel=6e-2)}  # measured: 2.1e-4 / 1.0e-2 / 3.0e-2
+# The batch with the domain's empty inputs (train_c1_edge.npz) is ILL-CONDITIONED for a few parameter blocks: its lights' window rows are
+# replicated (55 distinct attribute rows over 23,760 window rows) in front of LayerNorms and a max-pool, and in the scene without a map the
+# gradient that reaches them is 20 x larger than in a plain batch. Measured (profiles/MEASUREMENT_LOG.md, round 5): replacing
+# tbx_tall_linear's products (within their stated 5e-6 of sum |x||w|: no ReLU sign changes) by the EXACT fp32 products brings every
+# gradient back to the plain batches' agreement with the oracle; exact products + Gaussian noise of 1e-6 / 5e-6 move the lights' input
+# encoder's gradients by 3e-3 / 8e-3 of their largest entry. The fp32 class's spot bound for this fixture is therefore relative to the
+# block's largest entry: measured 3.6e-3, bound 2 x; loss and gradient-norm bounds as everywhere.
+TRAIN_TOL_EDGE_FP32_SPOT = 7.5e-3
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("sizes,knn,fixture,n_sc", [((8, 64, 8), 4, "model_c1.npz", 1), ((64, 1024, 128), 32, "train_c2.npz", 1),
-                                                    ((8, 64, 8), 4, "train_c1_b3.npz", 3)])  # last: a BATCH of 3 scenes (the reference's own numbers)
+                                                    ((8, 64, 8), 4, "train_c1_b3.npz", 3),  # a BATCH of 3 scenes (the reference's own numbers)
+                                                    # ... and a batch with the domain's empty inputs: a scene without a valid light, one with two
+                                                    # agents, one without a valid polyline (synthetic.make_edge_batch)
+                                                    ((8, 64, 8), 4, "train_c1_edge.npz", 3),
+                                                    # ... and ONE scene without a valid light: the light-state term's counter is zero, the
+                                                    # reference leaves the term out (metrics/training.py:184) and no gradient reaches the lights
+                                                    ((8, 64, 8), 4, "train_c1_nolights.npz", 1)])
 def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture, n_sc, prec):
     """One training_step with every RNG site neutralised (dropout 0, posterior latent, no random forcing) at C1 and at the
     scene size of BASELINE config 3 (64 agents / 1024 polylines / 128 lights, default K-nearest sizes: the shape behind the
@@ -95,7 +109,8 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
     wm = wm.to(dev).train()
     wm.train_precision = prec
     tol = TRAIN_TOL[prec]
-    batch = tb.synthetic.make_scene(n_sc, *sizes, seed=0)
+    batch = (tb.synthetic.make_edge_batch(*sizes, seed=0, kind="mixed" if "edge" in fixture else "no_lights") if ("edge" in fixture or "nolights" in fixture)
+             else tb.synthetic.make_scene(n_sc, *sizes, seed=0))
     torch.manual_seed(7)
     calls = {"mfma": 0, "wgrad_bf16": 0, "wgrad": 0}
     hip = import_module("trafficbots_amd.hip")
@@ -119,31 +134,34 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
     # the class that was asked for is what ran (tbx_linear_wgrad only serves the LINEARs of >= 16384 rows: none at the 8-agent size)
     assert (calls["mfma"] > 0) == (prec == "bf16") and calls["wgrad_bf16"] == (calls["wgrad"] if prec == "bf16" else 0)
     g = np.load(golden_dir / fixture)
+    gv = lambda key: g[key] if key in g.files else np.zeros((), np.float32)  # (a term / module the reference left out: counter 0, no gradient)
+    tol = dict(tol, spot_atol_rel=max(tol["spot_atol_rel"], TRAIN_TOL_EDGE_FP32_SPOT)) if "edge" in fixture else tol
     meas = {"loss": 0.0, "gnorm": 0.0, "spot": 0.0}
     for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss"):
-        got, ref = float(wm.last_metrics[k].detach().cpu()), float(g["dtrain_" + k])
+        got, ref = float(wm.last_metrics[k].detach().cpu()), float(gv("dtrain_" + k))
         meas["loss"] = max(meas["loss"], abs(got - ref) / max(abs(ref), 1e-1))
     gn = {}
     for k, p in wm.model.named_parameters():
         if p.grad is not None:
             gn[k.split(".")[0]] = gn.get(k.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
     for top, v in gn.items():
-        ref = float(g["dgradnorm_" + top])
+        ref = float(gv("dgradnorm_" + top))
         meas["gnorm"] = max(meas["gnorm"], abs(v**0.5 - ref) / max(ref, 1e-6))
     named = dict(wm.model.named_parameters())
+    spot = lambda key: (torch.zeros(8, 16) if named[key].grad is None else named[key].grad[:8, :16].cpu())  # (None: no gradient reached the module)
     for k in [x for x in g.files if x.startswith("dgrad_")]:
-        got, ref = named[k[6:]].grad[:8, :16].cpu(), torch.from_numpy(g[k])
+        got, ref = spot(k[6:]), torch.from_numpy(g[k])
         meas["spot"] = max(meas["spot"], float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12))
     print(f"[training step vs reference golden, {fixture}, {prec}] loss terms: max rel diff {meas['loss']:.3g}; per-module gradient norms: max rel diff "
           f"{meas['gnorm']:.3g}; spot gradient blocks: max |d| / max |ref| {meas['spot']:.3g}")
     for k in ("loss", "vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss"):
-        torch.testing.assert_close(wm.last_metrics[k].detach().cpu(), torch.from_numpy(g["dtrain_" + k]), rtol=tol["loss"], atol=1e-1 * tol["loss"])
+        torch.testing.assert_close(wm.last_metrics[k].detach().cpu(), torch.from_numpy(np.asarray(gv("dtrain_" + k))), rtol=tol["loss"], atol=1e-1 * tol["loss"])
     for top, v in gn.items():
-        ref = float(g["dgradnorm_" + top])
+        ref = float(gv("dgradnorm_" + top))
         assert abs(v**0.5 - ref) <= tol["gnorm"] * max(ref, 1e-6), (top, v**0.5, ref)
     for k in [x for x in g.files if x.startswith("dgrad_")]:
         ref = torch.from_numpy(g[k])
-        torch.testing.assert_close(named[k[6:]].grad[:8, :16].cpu(), ref, rtol=tol["spot_rtol"], atol=1e-5 + tol["spot_atol_rel"] * float(ref.abs().max()))
+        torch.testing.assert_close(spot(k[6:]), ref, rtol=tol["spot_rtol"], atol=1e-5 + tol["spot_atol_rel"] * float(ref.abs().max()))
     dead = set((golden_dir / "params_without_grad.txt").read_text().split())
     for k, p in wm.model.named_parameters():
         if k in dead:

@@ -111,6 +111,24 @@ def _one_scene(n_ag, n_mp, n_tl, n_step, seed, n_node, ragged) -> Dict[str, torc
     return out
 
 
+def make_edge_batch(n_ag: int = 8, n_mp: int = 64, n_tl: int = 8, seed: int = 0, kind: str = "mixed") -> Dict[str, torch.Tensor]:
+    """A batch of three scenes with the domain's empty inputs (the training-step fixture `train_c1_edge.npz` and its test are made from
+    it): scene 0 without a valid traffic light, scene 1 with TWO agents, scene 2 without a valid polyline. Everything else as
+    make_scene. kind = "no_lights": ONE scene without a valid light - the light-state term's counter is zero and the reference leaves
+    the term out of the loss (`train_c1_nolights.npz`)."""
+    if kind == "no_lights":
+        b = make_scene(1, n_ag, n_mp, n_tl, seed=seed)
+        b["tl_lane/valid"][:] = False
+        b["tl_stop/valid"][:] = False
+        return b
+    b = make_scene(3, n_ag, n_mp, n_tl, seed=seed)
+    b["tl_lane/valid"][0] = False
+    b["tl_stop/valid"][0] = False
+    b["agent/valid"][1, 2:] = False
+    b["map/valid"][2] = False
+    return b
+
+
 def to_history_batch(batch: Dict[str, torch.Tensor], n_step_hist: int = 11) -> Dict[str, torch.Tensor]:
     """Test-time view of an episode: `history/*` keys hold the first `n_step_hist` steps
     (reference data_h5_womd.py tensor_size_test); map keys are shared."""
