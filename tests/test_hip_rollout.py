@@ -437,6 +437,53 @@ def test_lights_tail_in_the_last_layers_launch_equals_the_chain(tb, bf16):
     assert float(lg1.abs().max()) <= 3.0
 
 
+@pytest.mark.parametrize("n_sc,A,L", [(4, 64, 32), (13, 40, 32)])
+def test_several_scenes_teacher_forced_vs_oracle(tb, n_sc, A, L):
+    """Several scenes in ONE engine (the bench line's `batched` object; BASELINE configs[4] gives a GPU many scenes) against the ORACLE,
+    teacher-forced over 20 steps like test_teacher_forced_replay: 4 x 64 agents = 256 agent rows on the tile kernels + wave-per-row
+    attention with the lights' 128 rows on the one-launch layers; 13 x 40 = 520 agent rows with the lights' 416 rows on the tile path
+    too (tbx_tl_tail_tile). Default schedule: the single-scene tolerance (poses / actions 1e-3); bf16-arithmetic schedule: validity,
+    flags and light states identical, poses / actions inside the single-scene bounds REDUCED_TF_ATOL[(64, 1024, 128)]."""
+    dev = torch.device("cuda:0")
+    knn, n_roll, sizes = 16, 20, (A, 256, L)
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    E = import_module("trafficbots_amd.engine")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=knn), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    tb.utils.det_fill(wm.model, 0)
+    P = {k: v.detach().clone() for k, v in wm.model.state_dict().items()}
+    wm = wm.to(dev).eval()
+    batch = tb.synthetic.make_scene(n_sc, *sizes, seed=1, ragged=False)
+    full = {**batch, **tb.synthetic.to_history_batch(batch)}
+    b = O.scene_centric(full, training=False)
+    bd = wm.pre_processing({k: v.to(dev) for k, v in full.items()})
+    cfg, scfg = tb.config.default_model_cfg(n_tgt_knn=knn), tb.config.default_sim_cfg()
+    om = O.TrafficBotsOracle(P, cfg, training=False)
+    mp_o, tl_o = _oracle_tokens(om, b)
+    z = torch.randn(n_sc, A, 16, generator=torch.Generator().manual_seed(1))
+    valid = b["gt/ag_valid"].any(-1)
+    tf_all = dict(step_spawn_agent=n_roll, step_warm_start=n_roll)
+    with torch.no_grad():
+        ro = O.Sim(om, scfg, False).rollout(b, mp_o, tl_o, z, valid, b["gt/ag_navi"], valid, tf_all, n_roll)
+    TF = import_module("trafficbots_amd.utils.teacher_forcing").TeacherForcing
+    for sched in ("default", "reduced"):
+        wm.schedule = E.DEFAULT if sched == "default" else E.DEFAULT.reduced()
+        wm.engine_cache = 0
+        assert n_sc * A > wm.schedule.live_max_agents and (n_sc * L > wm.schedule.live_max) == (n_sc == 13)  # (which kernels the rows take)
+        mp, tl = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+        buf = wm.reactive_replay(bd, mp, tl, z.to(dev), valid.to(dev), bd["gt/ag_navi"], valid.to(dev), TF(**tf_all), True, step_end=n_roll)
+        if sched == "default":
+            _compare(buf, ro, n_roll, 1e-3)
+            continue
+        err = {k: float((x.cpu() - y).abs().max()) for k, x, y in (("pose", buf.pred_pose[:, 0], ro["pred_pose"]), ("motion", buf.pred_motion[:, 0], ro["pred_motion"]),
+                                                                     ("action", buf.vis_dict["action"][:, 0], ro["action"]))}
+        print(f"[reduced vs oracle, {n_sc} scenes x {A} agents, teacher-forced {n_roll} steps] max |d pose| {err['pose']:.3g}, |d motion| {err['motion']:.3g}, "
+              f"|d action| {err['action']:.3g}")
+        assert torch.equal(buf.pred_valid[:, 0].cpu(), ro["pred_valid"]) and torch.equal(buf.vis_dict["tl_state"][:, 0].cpu(), ro["tl_state"])
+        assert torch.equal(buf.violation["outside_map"][:, 0].cpu(), ro["outside_map"]) and torch.equal(buf.violation["dest_reached"][:, 0].cpu(), ro["dest_reached"])
+        for k, bound in REDUCED_TF_ATOL[(64, 1024, 128)].items():
+            assert err[k] <= bound, (k, err[k], bound)
+
+
 @pytest.mark.parametrize("n_sc,A", [(12, 64), (3, 64), (20, 40)])
 def test_several_scenes_default_schedule_vs_exact_schedule(tb, n_sc, A):
     """Launch sizes between the one-scene closed loop and the large-launch tile kernels (192 / 768 / 800 agent rows: several scenes
