@@ -2,7 +2,7 @@
 # A/B of tile_layer's plane geometry (old lib | ring 3 | ring 2) over the bench shapes; parity test of the tile path first
 out=gpurun_out; mkdir -p $out
 C=trafficbotsv1.5_amd/csrc
-timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_bf16.py -m gpu -q -x 2>&1 | tail -4 > $out/r05_job13_tests.log
+timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_bf16.py -m gpu -q -x 2>&1 | tail -4 > $out/ab_tile_tests.log
 run() {  # name, lib, args...
   local name=$1 lib=$2; shift 2
   TBX_HIP_LIB=$lib timeout 600 python bench.py --no-cpu-baseline --no-wosac-shape --no-train-shape --no-bf16-shape --no-rule-checks --no-submission-shape --no-batched-shape --profile-steps 0 --new-scenes 0 "$@" 2>/dev/null | tail -1 | python -c "
@@ -18,5 +18,5 @@ for lib in main; do
   run "s64 $lib" $L --scenes 64 --steps 40
   run "c5_bf16 $lib" $L --agents 128 --rollouts 32 --kv-bf16 --attn-mfma 1
   run "s64_bf16 $lib" $L --scenes 64 --steps 40 --kv-bf16 --attn-mfma 1
-done > $out/r05_job13_ab.txt 2>&1
-cat $out/r05_job13_tests.log $out/r05_job13_ab.txt
+done > $out/ab_tile_layer_libs.txt 2>&1
+cat $out/ab_tile_tests.log $out/ab_tile_layer_libs.txt
