@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B of tile_layer's plane geometry (old lib | ring 3 | ring 2) over the bench shapes; parity test of the tile path first
+# The bench shapes (configs[1], WOSAC, submission, 16 / 64 scenes, bf16 schedule) on one box with one or more builds of libtbx_hip:
+# `for lib in <names>` runs csrc/libtbx_hip_<name>.so through TBX_HIP_LIB ("main" = the tree's libtbx_hip.so). Round 5 used it for
+# tile_layer's plane geometry: old = the previous commit's build, ring3 / main = the new planes with TBX_TILE_RING 3 / 2
+# (profiles/MEASUREMENT_LOG.md). The tile path's parity tests run first.
 out=gpurun_out; mkdir -p $out
 C=trafficbotsv1.5_amd/csrc
 timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_bf16.py -m gpu -q -x 2>&1 | tail -4 > $out/ab_tile_tests.log
