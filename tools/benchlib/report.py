@@ -39,6 +39,13 @@ SUB_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic
                  "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch", "flops_per_launch")
 
 
+def _gathered_note(roof):
+    """SURVEY 8d prices an attention launch by the bytes its pairs GATHER; rows shared by many source rows come from L2, so that figure
+    over the HBM peak is not bounded by 1: say so where it happens."""
+    if roof.get("bound") == "hbm" and (roof.get("frac") or 0) > 1.0:
+        roof["frac_note"] = "8d gathered bytes (L2-served rows included) / s over HBM peak: not bounded by 1"
+
+
 def compact_roofline(r, sub=False):
     """sub: the roofline of an appended shape (the judged object keeps every key; the detail file keeps everything of all of them)."""
     if not r:
@@ -47,6 +54,7 @@ def compact_roofline(r, sub=False):
         return {"error": str(r["error"])[:200]}
     out = {k: r[k] for k in (SUB_ROOF_KEYS if sub else ROOF_KEYS) if k in r}
     out.setdefault("traffic", None)
+    _gathered_note(out)
     c = r.get("counters")
     if c:
         out["counters"] = {k: c[k] for k in ("valu_busy", "l2_hit_rate", "valu_insts_per_pair", "counters_source") if k in c}
@@ -67,6 +75,7 @@ def compact_shape(res, keys=("value", "ms_per_step", "ms_per_step_min", "steps",
         r = res.get("roofline") or {}
         if "frac" in r:  # (frac = algorithmic bytes or flops per launch / avg_launch_us / peak, as everywhere; the full object is in the detail file)
             out["roofline"] = {k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "flops_per_launch", "peak", "traffic", "traffic_source") if r.get(k) is not None}
+            _gathered_note(out["roofline"])
         return out
     if res.get("scene_reuse"):
         out["new_scene_ms"] = res["scene_reuse"]["new_scene_ms"]
