@@ -940,6 +940,21 @@ int tbx_rule_check(const tbx_rule_ctx_t* ctx /* host */, const uint8_t* valid, c
 int tbx_rule_accumulate(const uint8_t* raw, int n_rows, int ld_t, int t0, int n_t, uint8_t* acc_state, float* passive_counter,
                         uint8_t* out_now, uint8_t* out_acc, void* stream);
 
+/* The checks of TrafficRuleChecker.check that feed back into the simulation, for ONE step (utils/traffic_rule_checker.py:109-120
+ * _check_outside_map, :277-288 _check_goal_reached, :290-330 _check_dest_reached; called at pl_modules/waymo_motion.py:250 between
+ * two `forward`s). The rollout engine's own loop evaluates outside-map / destination-reached inside tbx_sim_step; this entry point
+ * serves a step-wise driver written against the reference.
+ *   valid [n, A] u8, pose [n, A, 3], boundary [n / map_batch_div, 4] (xmin, xmax, ymin, ymax)
+ *   dest_invalid [n, A, n_node] u8, dest_pos / dest_dir [n, A, n_node, 2] (dir = unit vectors), dest_kind [n, A] u8 (bit 0: lane
+ *   destination - position within dest_thresh AND heading within 30 deg of a valid node -, bit 1: road-edge destination - position
+ *   only), dest_thresh [n, A] f32: TrafficRuleChecker._get_dest (:87-107); all five NULL = no destinations (dest_reached stays 0)
+ *   goal [n, A, 4] (x, y, yaw, v), goal_thresh [n, A] (8 agent lengths, :66); both NULL = no goals
+ *   acc [3, n, A] u8: the running ORs outside_map, dest_reached, goal_reached - read and updated (zero them before the first step)
+ *   out_now [3, n, A] u8: outside_map_this_step, dest_reached_this_step, goal_reached_this_step */
+int tbx_rule_navi_check(const uint8_t* valid, const float* pose, const float* boundary, int map_batch_div, const uint8_t* dest_invalid,
+                        const float* dest_pos, const float* dest_dir, const uint8_t* dest_kind, const float* dest_thresh, const float* goal,
+                        const float* goal_thresh, int n_batch, int n_ag, int n_node, uint8_t* acc, uint8_t* out_now, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * WOSAC rollout filter. Replaces WOSACPostProcessing._filter_futures
  * (data_modules/wosac_post_processing.py:31-64): score_k = sum_a role_a * any_{t >= t_start} col[k,a,t]

@@ -360,6 +360,21 @@ class Sim:
         thresh = torch.ones_like(ag_dest, dtype=torch.float32) * 50 * (1 - ty[:, :, 4] * 0.8)
         return dict(invalid=~mp_valid[bi, ag_dest], type=ty, pos=mp_pos[bi, ag_dest][..., :2], dir=d, thresh=thresh)
 
+    @staticmethod
+    @torch.no_grad()
+    def feedback_checks(pred_valid, pred_pose, bnd, dest, dest_reached):
+        """The two rule checks that feed back into the simulation, for one step (traffic_rule_checker.py:109-120 _check_outside_map,
+        :300-330 _check_dest_reached): -> (outside_map_this_step, dest_reached_this_step) [n_sc, n_ag] bool."""
+        x, y = pred_pose[..., 0], pred_pose[..., 1]
+        out_now = ((x > bnd[:, [1]]) | (x < bnd[:, [0]]) | (y > bnd[:, [3]]) | (y < bnd[:, [2]])) & pred_valid
+        dd = torch.norm(pred_pose[:, :, None, :2] - dest["pos"], dim=-1).masked_fill(dest["invalid"], float("inf"))
+        pos_ok = (dd < dest["thresh"].unsqueeze(-1)).any(-1)
+        hf = torch.stack([torch.cos(pred_pose[..., 2]), torch.sin(pred_pose[..., 2])], -1)
+        rot = (hf.unsqueeze(2) * dest["dir"]).sum(-1).masked_fill(dest["invalid"], 0)
+        rot_ok = (rot > math.cos(math.radians(30))).any(-1)
+        reach_now = (~dest_reached) & pred_valid & ((dest["type"][:, :, :4].any(-1) & pos_ok & rot_ok) | (dest["type"][:, :, 4] & pos_ok))
+        return out_now, reach_now
+
     def rollout(self, batch, mp_tokens, tl_tokens, ag_latent, ag_latent_valid, ag_navi, ag_navi_valid, tf_cfg, step_end,
                 gt_prefix: str = "gt", tl_gt_key: str = "gt/tl_state"):
         """reactive_replay + rollout (waymo_motion.py:206-311,387-437) with deterministic actions.
@@ -415,18 +430,9 @@ class Sim:
                 if step < n_tl_gt:
                     tl_state = tl_gt[:, :, step]  # tl_teacher_forcing is all-True (teacher_forcing.py:66)
             # rule checks that feed back (traffic_rule_checker.py:109-120,300-330)
-            with torch.no_grad():
-                x, y = pred_pose[..., 0], pred_pose[..., 1]
-                out_now = ((x > bnd[:, [1]]) | (x < bnd[:, [0]]) | (y > bnd[:, [3]]) | (y < bnd[:, [2]])) & pred_valid
-                outside_map = outside_map | out_now
-                dd = torch.norm(pred_pose[:, :, None, :2] - dest["pos"], dim=-1).masked_fill(dest["invalid"], float("inf"))
-                pos_ok = (dd < dest["thresh"].unsqueeze(-1)).any(-1)
-                hf = torch.stack([torch.cos(pred_pose[..., 2]), torch.sin(pred_pose[..., 2])], -1)
-                rot = (hf.unsqueeze(2) * dest["dir"]).sum(-1).masked_fill(dest["invalid"], 0)
-                rot_ok = (rot > math.cos(math.radians(30))).any(-1)
-                reach_now = (~dest_reached) & pred_valid & ((dest["type"][:, :, :4].any(-1) & pos_ok & rot_ok)
-                                                           | (dest["type"][:, :, 4] & pos_ok))
-                dest_reached = dest_reached | reach_now
+            out_now, reach_now = self.feedback_checks(pred_valid, pred_pose, bnd, dest, dest_reached)
+            outside_map = outside_map | out_now
+            dest_reached = dest_reached | reach_now
             # reward + tl nll (rewards.py:58-74, waymo_motion.py:262-277)
             if step < n_gt:
                 g_valid, g_pose, g_motion = gt_valid[:, :, step], gt_pose[:, :, step], gt_motion[:, :, step]

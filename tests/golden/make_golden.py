@@ -485,6 +485,7 @@ def gen_filter():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
+    # (train_c2_b4 - a batch of 4 full-size scenes, ~12 min of reference CPU and ~40 GB of autograd graph - only on request)
     which = sys.argv[1:] or ["ops", "c1", "c2", "train_c2", "train_c1_b3", "train_c1_edge", "train_c1_nolights", "rules", "filter"]
     if "filter" in which:
         gen_filter()
@@ -498,6 +499,8 @@ if __name__ == "__main__":
         gen_model("c2", 64, 1024, 128, 32, n_roll_steps=14, train_fixture=False)
     if "train_c2" in which:
         gen_train("c2", 64, 1024, 128, 32)
+    if "train_c2_b4" in which:
+        gen_train("c2_b4", 64, 1024, 128, 32, n_sc=4)
     if "train_c1_b3" in which:
         gen_train("c1_b3", 8, 64, 8, 4, n_sc=3)
     if "train_c1_edge" in which:

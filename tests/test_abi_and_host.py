@@ -278,3 +278,79 @@ def test_multi_tensor_copy_of_the_engine_refill(tb):
     for (d, _), w in zip(pairs, want):
         assert torch.equal(d, w.to(d.dtype).expand_as(d))
     R._copy_all([])  # (nothing to do)
+
+
+def test_training_flags_the_time_batched_step_cannot_honour_raise(tb):
+    """training_detach_model_input / training_deterministic_action (waymo_motion.py:158-161, :370): the training step batches the
+    decoder over time, exact only with detached inputs and deterministic actions (the defaults). False used to be accepted and
+    ignored - plausible, wrong gradients; now the constructor refuses, like every other non-default branch."""
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    for flag in ("training_detach_model_input", "training_deterministic_action"):
+        scfg = tb.config.default_sim_cfg()
+        assert scfg[flag] is True
+        scfg[flag] = False
+        with pytest.raises(NotImplementedError, match=flag):
+            W.WaymoMotion(model=tb.config.default_model_cfg(), data_size=tb.synthetic.DATA_SIZE, **scfg)
+
+
+def test_dynamics_init_holds_step_zero_until_the_first_forward(tb):
+    """The reference's prologue `self.dynamics.init(tl_state=tl_state_gt, **ag_tokens)` (waymo_motion.py:228): between it and the
+    first `forward` the state attributes read step 0 of the ground truth (teacher_forcing.get is handed them, :233-235)."""
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    wm = W.WaymoMotion(model=tb.config.default_model_cfg(n_tgt_knn=4), data_size=tb.synthetic.DATA_SIZE, **tb.config.default_sim_cfg())
+    g = torch.Generator().manual_seed(0)
+    n, A, T, L = 2, 5, 11, 3
+    tok = dict(gt_valid=torch.rand(n, A, T, generator=g) > 0.2, gt_pose=torch.randn(n, A, T, 3, generator=g), gt_motion=torch.randn(n, A, T, 3, generator=g),
+               ag_type=torch.eye(3)[torch.randint(0, 3, (n, A), generator=g)].bool(), ag_attr=torch.randn(n, A, 6, generator=g),
+               ag_size=torch.rand(n, A, 3, generator=g), ag_latent=torch.randn(n, A, 16, generator=g), ag_latent_valid=torch.ones(n, A, dtype=torch.bool),
+               ag_navi=torch.randint(0, 7, (n, A), generator=g), ag_navi_valid=torch.rand(n, A, generator=g) > 0.5,
+               ag_navi_log_prob=torch.zeros(n, A))
+    tl = torch.eye(5)[torch.randint(0, 5, (n, L, T), generator=g)].bool()
+    dyn = wm.dynamics
+    with pytest.raises(RuntimeError):
+        dyn.ag_pose
+    dyn.init(tl_state=tl, **tok)
+    wm.model.init()
+    assert torch.equal(dyn.ag_valid, tok["gt_valid"][:, :, 0]) and torch.equal(dyn.ag_pose, tok["gt_pose"][:, :, 0])
+    assert torch.equal(dyn.ag_motion, tok["gt_motion"][:, :, 0]) and torch.equal(dyn.tl_state, tl[:, :, 0])
+    assert torch.equal(dyn.ag_navi_valid, tok["ag_navi_valid"]) and not dyn.mask_navi_reached.any() and not dyn.ag_disabled.any()
+    assert dyn.ag_navi is tok["ag_navi"] and dyn.ag_type is tok["ag_type"]
+    with pytest.raises(RuntimeError):  # no engine yet: the reference's order is init -> forward -> disable_*
+        dyn.disable_navi({"dest_reached_this_step": torch.zeros(n, A, dtype=torch.bool)})
+    tf = wm.teacher_forcing_reactive_replay
+    tf.init(ag_valid=tok["gt_valid"], ag_pose=tok["gt_pose"], ag_motion=tok["gt_motion"], tl_state=tl, current_epoch=0)
+    ag_override, tl_override = tf.get(1, dyn.ag_valid, dyn.ag_pose, dyn.ag_motion)
+    assert ag_override["pose"].shape == (n, A, 3) and tl_override["state"].shape == (n, L, 5)
+
+
+def test_light_tokens_per_rollout_is_a_copy_with_encode_scenes_layout(tb):
+    """joint_future_pred's own expansion of pre_compute's light tokens (the reference's :458-462): every per-light tensor repeated K
+    times along the batch, map targets still indexed per scene (mp_batch_div = K), caches dropped, the caller's dict untouched; the
+    rollout engine's per-scene view (lights_per_scene) of the result is the original."""
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    E = import_module("trafficbots_amd.utils.rollout_engine")
+    n_scene, K, L, M = 2, 4, 5, 7
+    g = torch.Generator().manual_seed(1)
+    tl = {"tl_token_pose": torch.randn(n_scene, L, 3, generator=g), "tl_token_valid": torch.rand(n_scene, L, generator=g) > 0.3,
+          "knn_idx_tl2mp": torch.randint(0, M, (n_scene, L, 2), generator=g), "rel_tl2tl": torch.randn(n_scene, L, 2, 3, generator=g),
+          "rpe_tl2tl": None, "mp_batch_div": 1, "n_mp": M, "mp_feat_flat": torch.randn(n_scene * M, 8, generator=g), "_kv_mp": {"cached": 1}}
+    before = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tl.items()}
+    ex = W.WaymoMotion._tl_tokens_per_rollout(tl, K)
+    assert ex is not tl and "_kv_mp" not in ex and ex["mp_batch_div"] == K and ex["n_mp"] == M and ex["rpe_tl2tl"] is None
+    assert ex["mp_feat_flat"] is tl["mp_feat_flat"]
+    for k in ("tl_token_pose", "tl_token_valid", "knn_idx_tl2mp", "rel_tl2tl"):
+        assert torch.equal(ex[k], tl[k].repeat_interleave(K, 0)), k
+    for k, v in before.items():  # the caller's dict: same keys, same values
+        assert (torch.equal(tl[k], v) if torch.is_tensor(v) else tl[k] == v), k
+    view = E.lights_per_scene(ex, K)
+    for k in ("tl_token_pose", "tl_token_valid", "knn_idx_tl2mp", "rel_tl2tl"):
+        assert torch.equal(view[k], tl[k]), k
+
+
+def test_rule_navi_check_validates_arguments_without_a_gpu(hip):
+    lib = hip.load()
+    assert lib.tbx_rule_navi_check(None, None, None, 1, None, None, None, None, None, None, None, 1, 1, 0, None, None, None) == -1
+    one = C.c_void_p(16)  # (never dereferenced: validation happens before the launch)
+    assert lib.tbx_rule_navi_check(one, one, one, 2, None, None, None, None, None, None, None, 3, 4, 0, one, one, None) == -1  # n % div
+    assert lib.tbx_rule_navi_check(one, one, one, 1, one, None, None, None, None, None, None, 1, 4, 20, one, one, None) == -1  # partial dest tables
+    assert lib.tbx_rule_navi_check(one, one, one, 1, None, None, None, None, None, one, None, 1, 4, 0, one, one, None) == -1   # goal without its threshold

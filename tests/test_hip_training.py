@@ -73,10 +73,21 @@ TRAIN_TOL = {"fp32": dict(loss=1e-3, gnorm=1e-2, spot_rtol=2e-2, spot_atol_rel=0
 # encoder's gradients by 3e-3 / 8e-3 of their largest entry. The fp32 class's spot bound for this fixture is therefore relative to the
 # block's largest entry: measured 3.6e-3, bound 2 x; loss and gradient-norm bounds as everywhere.
 TRAIN_TOL_EDGE_FP32_SPOT = 7.5e-3
+# A 16-scene step against the count-weighted recombination of its 16 one-scene steps: the same arithmetic on the same rows in a
+# different summation order (weight gradients summed over 16 x the rows in one reduction vs 16 partial reductions added up; atomics
+# in the attention backward). Bounds <= 2 x measured on MI355X (printed by the test).
+RECOMBINE_TOL = {"fp32": dict(loss=2e-5, gnorm=1e-3, grad=5e-3), "bf16": dict(loss=1e-4, gnorm=5e-3, grad=2e-2)}
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("sizes,knn,fixture,n_sc", [((8, 64, 8), 4, "model_c1.npz", 1), ((64, 1024, 128), 32, "train_c2.npz", 1),
+                                                    # a BATCH of 4 full-size scenes (~8 min of reference CPU in
+                                                    # make_golden.py): 4 x 90 x 64 = 23,040 agent rows per LINEAR - the >= 16,384-row
+                                                    # branch (tbx_tall_linear / tbx_linear_wgrad and their bf16 forms, the dual-output
+                                                    # K/V tables) and the loss normalisers over several full-size scenes
+                                                    ((64, 1024, 128), 32, "train_c2_b4.npz", 4),
+                                                    # ... the same branch at the 8-agent size: the row threshold lowered to 256
+                                                    ((8, 64, 8), 4, "train_c1_b3.npz|min_rows=256", 3),
                                                     ((8, 64, 8), 4, "train_c1_b3.npz", 3),  # a BATCH of 3 scenes (the reference's own numbers)
                                                     # ... and a batch with the domain's empty inputs: a scene without a valid light, one with two
                                                     # agents, one without a valid polyline (synthetic.make_edge_batch)
@@ -84,12 +95,16 @@ TRAIN_TOL_EDGE_FP32_SPOT = 7.5e-3
                                                     # ... and ONE scene without a valid light: the light-state term's counter is zero, the
                                                     # reference leaves the term out (metrics/training.py:184) and no gradient reaches the lights
                                                     ((8, 64, 8), 4, "train_c1_nolights.npz", 1)])
-def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture, n_sc, prec):
+def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixture, n_sc, prec, monkeypatch):
     """One training_step with every RNG site neutralised (dropout 0, posterior latent, no random forcing) at C1 and at the
     scene size of BASELINE config 3 (64 agents / 1024 polylines / 128 lights, default K-nearest sizes: the shape behind the
     training scenes/s figure): loss terms vs the reference's golden values; per-module gradient norms vs the reference's; spot
     gradients vs the reference's."""
     dev = torch.device("cuda:0")
+    fixture, _, opt = fixture.partition("|")
+    min_rows = int(opt.split("=")[1]) if opt else None
+    if min_rows is not None:  # (train_ops.linear / linear_kv read the module global at call time)
+        monkeypatch.setattr(import_module("trafficbots_amd.train_ops"), "WGRAD_MIN_ROWS", min_rows)
     cfg = tb.config.default_model_cfg(n_tgt_knn=knn)
     cfg["tf_cfg"]["dropout_p"] = 0.0
     cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
@@ -112,9 +127,9 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
     batch = (tb.synthetic.make_edge_batch(*sizes, seed=0, kind="mixed" if "edge" in fixture else "no_lights") if ("edge" in fixture or "nolights" in fixture)
              else tb.synthetic.make_scene(n_sc, *sizes, seed=0))
     torch.manual_seed(7)
-    calls = {"mfma": 0, "wgrad_bf16": 0, "wgrad": 0}
+    calls = {"mfma": 0, "wgrad_bf16": 0, "wgrad": 0, "tall": 0, "tall_bf16": 0, "tall_dual16": 0}
     hip = import_module("trafficbots_amd.hip")
-    orig = (hip.knarpe_attn_mfma, hip.linear_wgrad)
+    orig = (hip.knarpe_attn_mfma, hip.linear_wgrad, hip.tall_linear)
 
     def mf(*a, **kw):
         calls["mfma"] += 1
@@ -125,14 +140,27 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
         calls["wgrad"] += 1
         return orig[1](*a, **kw)
 
-    hip.knarpe_attn_mfma, hip.linear_wgrad = mf, wg
+    def tall(*a, **kw):
+        calls["tall"] += 1
+        calls["tall_bf16"] += int(bool(kw.get("bf16")))
+        calls["tall_dual16"] += int(kw.get("out16") is not None)
+        return orig[2](*a, **kw)
+
+    hip.knarpe_attn_mfma, hip.linear_wgrad, hip.tall_linear = mf, wg, tall
     try:
         loss = wm.training_step({k: v.to(dev) for k, v in batch.items()}, 0)
         loss.backward()
     finally:
-        hip.knarpe_attn_mfma, hip.linear_wgrad = orig
+        hip.knarpe_attn_mfma, hip.linear_wgrad, hip.tall_linear = orig
     # the class that was asked for is what ran (tbx_linear_wgrad only serves the LINEARs of >= 16384 rows: none at the 8-agent size)
     assert (calls["mfma"] > 0) == (prec == "bf16") and calls["wgrad_bf16"] == (calls["wgrad"] if prec == "bf16" else 0)
+    assert calls["tall_bf16"] == (calls["tall"] if prec == "bf16" else 0)
+    if min_rows is not None or n_sc * sizes[0] * 90 >= 16384:
+        # the tall branch end to end inside a reference-checked step (the 8-agent fixtures alone never reached it): the tall
+        # LINEARs forward + input gradient, the weight gradients, and under the bf16 class the K/V tables written as bfloat16 beside fp32
+        assert calls["wgrad"] > 10 and calls["tall"] > 10, calls
+        assert (calls["tall_dual16"] > 0) == (prec == "bf16"), calls
+    print(f"[training step, {fixture}{' ' + opt if opt else ''}, {prec}] kernel calls: {calls}")
     g = np.load(golden_dir / fixture)
     gv = lambda key: g[key] if key in g.files else np.zeros((), np.float32)  # (a term / module the reference left out: counter 0, no gradient)
     tol = dict(tol, spot_atol_rel=max(tol["spot_atol_rel"], TRAIN_TOL_EDGE_FP32_SPOT)) if "edge" in fixture else tol
@@ -168,11 +196,18 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
 
 
-def test_graphed_train_step_equals_eager_across_optimizer_steps(tb):
+@pytest.mark.parametrize("tall_rows", [None, 256])
+def test_graphed_train_step_equals_eager_across_optimizer_steps(tb, monkeypatch, tall_rows):
     """GraphedTrainStep (fwd + bwd replayed as one hipGraph) vs the eager step: after real AdamW updates between replays the
     replayed loss / gradients must be those of the CURRENT weights and inputs (a stale replay - see the ROCm caveat in
-    data_parallel.py - passes a same-weights comparison), and two replays of the same inputs must agree."""
+    data_parallel.py - passes a same-weights comparison), and two replays of the same inputs must agree.
+    tall_rows = 256: the row threshold of the tall LINEAR path lowered so that TallLinearFn runs at this size - its BACKWARD packs the
+    W^T image of every such weight, and a captured backward that found the warm-up passes' image in the per-parameter cache replayed
+    the capture-time W^T forever: the input gradients of every replay after the first optimizer step were wrong.
+    ... and a new epoch re-captures (TeacherForcing's schedules read current_epoch on the host) instead of asserting."""
     dev = torch.device("cuda:0")
+    if tall_rows is not None:
+        monkeypatch.setattr(import_module("trafficbots_amd.train_ops"), "WGRAD_MIN_ROWS", tall_rows)
     DP = import_module("trafficbots_amd.pl_modules.data_parallel")
     W = import_module("trafficbots_amd.pl_modules.waymo_motion")
     cfg = tb.config.default_model_cfg(n_tgt_knn=4)
@@ -187,9 +222,14 @@ def test_graphed_train_step_equals_eager_across_optimizer_steps(tb):
     wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg).to(dev).train()
     (opt,), _ = wm.configure_optimizers()
     batches = [{k: v.to(dev) for k, v in tb.synthetic.make_scene(2, 8, 64, 8, seed=s).items()} for s in (0, 2)]
-    gs = DP.GraphedTrainStep(wm, opt, batches[0], warmup=1)
+    gs = DP.GraphedTrainStep(wm, opt, batches[0], warmup=2 if tall_rows else 1)  # (2 warm-up passes: the default, and what left the stale cache)
     for i in range(3):  # replay + clip + AdamW: the weights move
         gs(batches[i % 2])
+    if tall_rows is None:  # an epoch change: the step is re-captured (the forcing schedule of the new epoch), the optimizer state kept
+        g0, state0 = gs.graph, len(opt.state)
+        wm.current_epoch += 1
+        gs(batches[0])
+        assert gs.graph is not g0 and gs.epoch == wm.current_epoch and len(opt.state) == state0 > 0
     gs.opt, gs.clip = torch.optim.SGD(gs.live, lr=0.0), 0
     m = gs(batches[1])
     loss_g = float(m["loss"].detach())
@@ -939,3 +979,81 @@ def test_mfma_attention_forward_draws_the_valu_kernels_dropout_mask(tb):
     assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) and float((a - b).abs().max()) > 0.0
     kept = float((a != 0).float().mean())
     assert 0.3 < kept < 0.9
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_sixteen_scene_step_is_the_count_weighted_recombination_of_its_scenes(tb, prec, monkeypatch):
+    """BASELINE config 3 at its own batch size (batch 16 was benchmarked, never checked): one training step on 16
+    scenes of 64 agents / 1024 polylines / 128 lights against the EXACT recombination of 16 one-scene steps. Every loss term of the
+    reference is a ratio of sums over the whole batch (metrics/training.py:166-186), so with c_i the term's counter in scene i:
+        term(batch) = sum_i c_i term_i / sum_i c_i,      d term(batch) / d theta = sum_i (c_i / sum_j c_j) d term_i / d theta.
+    Scenes do not interact anywhere else (every kernel works row by row / scene by scene), so the 16-scene launches - 92,160 agent
+    rows per LINEAR: tbx_tall_linear / tbx_linear_wgrad and their bf16 forms at the benchmarked size, the time-batched attention and
+    chain kernels over 16 x 90 batch entries - must reproduce the per-scene results (themselves pinned to the reference at this scene
+    size: train_c2.npz, train_c2_b4.npz) up to summation order. RNG sites neutralised as in those fixtures.
+    The row threshold of the tall LINEAR path is lowered to 4,096 for BOTH sides: a single scene has 5,760 agent / 11,520 light rows
+    per LINEAR and would otherwise take the library's fp32 GEMM where the batch takes tbx_tall_linear(_bf16) - a different arithmetic
+    class, not a different summation order. (The batch's own population of tall LINEARs is unchanged: all of them have >= 16,384 rows.)"""
+    dev = torch.device("cuda:0")
+    monkeypatch.setattr(import_module("trafficbots_amd.train_ops"), "WGRAD_MIN_ROWS", 4096)
+    n_sc, sizes = 16, (64, 1024, 128)
+    cfg = tb.config.default_model_cfg(n_tgt_knn=32)
+    cfg["tf_cfg"]["dropout_p"] = 0.0
+    cfg["mp_encoder"]["pl_encoder"]["mlp_dropout_p"] = 0.0
+    cfg["add_navi_latent"]["mlp_dropout_p"] = 0.0
+    scfg = tb.config.default_sim_cfg(p_training_rollout_prior=0.0)
+    scfg["teacher_forcing_training"]["prob_forcing_agent"] = 0.0
+    scfg["pre_processing"]["scene_centric"]["dropout_p_history"] = -1.0
+    W = import_module("trafficbots_amd.pl_modules.waymo_motion")
+    wm = W.WaymoMotion(model=cfg, data_size=tb.synthetic.DATA_SIZE, **scfg)
+    tb.utils.det_fill(wm.model, 0)
+    with torch.no_grad():
+        for k, p in wm.model.named_parameters():
+            if k.startswith("action_head.mlp_mean") and ".fc_layers.4." in k:
+                p.mul_(0.02)
+    wm = wm.to(dev).train()
+    wm.train_precision = prec
+    batch = {k: v.to(dev) for k, v in tb.synthetic.make_scene(n_sc, *sizes, seed=0).items()}
+    noise = torch.randn(n_sc, sizes[0], 16, generator=torch.Generator().manual_seed(3)).to(dev)
+    use_prior = torch.zeros((), dtype=torch.bool, device=dev)
+    terms = ("vae_kl", "diffbar_reward", "navi_loss", "tl_state_loss")
+    sign = {"vae_kl": 1.0, "diffbar_reward": -1.0, "navi_loss": 1.0, "tl_state_loss": 1.0}
+    # ---- the 16-scene step
+    loss = wm.training_step({k: v.clone() for k, v in batch.items()}, 0, noise=noise, use_prior=use_prior)
+    loss.backward()
+    big = {k: float(v.detach()) for k, v in wm.last_metrics.items()}
+    C = {k: float(wm.last_counts[k]) for k in terms}
+    assert all(c > 0 for c in C.values())
+    named = [(k, p) for k, p in wm.model.named_parameters() if p.grad is not None]
+    g_big = {k: p.grad.detach().double().clone() for k, p in named}
+    for _, p in named:
+        p.grad = None
+    # ---- 16 one-scene steps, each term weighted by its share of the batch's counter
+    rec = {k: 0.0 for k in terms}
+    for i in range(n_sc):
+        one = {k: v[i:i + 1].clone() for k, v in batch.items()}
+        wm.training_step(one, 0, noise=noise[i:i + 1], use_prior=use_prior)
+        m, c = wm.last_metrics, wm.last_counts
+        comb = 0.0
+        for k in terms:
+            w = float(c[k]) / C[k]
+            rec[k] += w * float(m[k].detach())
+            comb = comb + sign[k] * w * m[k]
+        comb.backward()  # (gradients accumulate over the scenes)
+    rec["loss"] = sum(sign[k] * rec[k] for k in terms)
+    meas = {"loss": 0.0, "gnorm": 0.0, "grad": 0.0}
+    for k in ("loss",) + terms:
+        meas["loss"] = max(meas["loss"], abs(big[k] - rec[k]) / max(abs(rec[k]), 1e-1))
+    gn_b, gn_r = {}, {}
+    for k, p in named:
+        top = k.split(".")[0]
+        g = p.grad.detach().double()
+        gn_b[top] = gn_b.get(top, 0.0) + float(g_big[k].pow(2).sum())
+        gn_r[top] = gn_r.get(top, 0.0) + float(g.pow(2).sum())
+        meas["grad"] = max(meas["grad"], float((g_big[k] - g).abs().max()) / max(float(g.abs().max()), 1e-12))
+    for top in gn_b:
+        meas["gnorm"] = max(meas["gnorm"], abs(gn_b[top] ** 0.5 - gn_r[top] ** 0.5) / max(gn_r[top] ** 0.5, 1e-12))
+    print(f"[16-scene step vs recombined one-scene steps, {prec}] loss terms: max rel diff {meas['loss']:.3g}; per-module gradient norms: max rel diff "
+          f"{meas['gnorm']:.3g}; per-parameter gradients: max |d| / max |g| {meas['grad']:.3g}; counters {C}")
+    tol = RECOMBINE_TOL[prec]
+    assert meas["loss"] <= tol["loss"] and meas["gnorm"] <= tol["gnorm"] and meas["grad"] <= tol["grad"], meas

@@ -501,7 +501,73 @@ __global__ void filter_gather_kernel(const float* __restrict__ pose, const int32
   out[i] = pose[((((int64_t)b * K + k) * A + a) * ld_t + t_start) * 3 + c];
 }
 
+// ---------------------------------------------------------------------------------------------- outside-map / destination-reached
+// TrafficRuleChecker._check_outside_map / _check_dest_reached (traffic_rule_checker.py:109-120,300-330) for ONE step: the two checks
+// that feed back into the simulation. The rollout engine evaluates them inside tbx_sim_step; this stand-alone form serves
+// `TrafficRuleChecker.check` as the reference's `rollout` calls it between two `WaymoMotion.forward`s. One thread per agent.
+__global__ void rule_navi_kernel(const uint8_t* __restrict__ valid, const float* __restrict__ pose, const float* __restrict__ boundary,
+                                 int map_batch_div, const uint8_t* __restrict__ dest_invalid, const float* __restrict__ dest_pos,
+                                 const float* __restrict__ dest_dir, const uint8_t* __restrict__ dest_kind,
+                                 const float* __restrict__ dest_thresh, const float* __restrict__ goal, const float* __restrict__ goal_thresh,
+                                 int n_rows, int n_ag, int n_node, uint8_t* __restrict__ acc, uint8_t* __restrict__ out_now) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const bool v = valid[i] != 0;
+  const float x = pose[i * 3], y = pose[i * 3 + 1], yaw = pose[i * 3 + 2];
+  const float* bd = boundary + (int64_t)(i / n_ag / map_batch_div) * 4;  // xmin, xmax, ymin, ymax
+  const bool out_now_ = v && (x > bd[1] || x < bd[0] || y > bd[3] || y < bd[2]);
+  bool reach_now = false;
+  if (dest_invalid != nullptr) {
+    const float hx = cosf(yaw), hy = sinf(yaw);
+    const float thresh = dest_thresh[i];
+    bool pos_ok = false, rot_ok = false;
+    for (int k = 0; k < n_node; ++k) {
+      const int64_t d = (int64_t)i * n_node + k;
+      if (dest_invalid[d]) continue;
+      pos_ok = pos_ok || norm2(__fsub_rn(x, dest_pos[d * 2]), __fsub_rn(y, dest_pos[d * 2 + 1])) < thresh;
+      rot_ok = rot_ok || __fadd_rn(__fmul_rn(hx, dest_dir[d * 2]), __fmul_rn(hy, dest_dir[d * 2 + 1])) > 0.8660254037844387f;
+    }
+    const uint8_t kind = dest_kind[i];  // bit 0: lane destination (position and heading), bit 1: road-edge destination (position)
+    reach_now = acc[n_rows + i] == 0 && v && (((kind & 1) && pos_ok && rot_ok) || ((kind & 2) && pos_ok));
+  }
+  bool goal_now = false;
+  if (goal != nullptr) {  // _check_goal_reached (:277-288): within 8 agent lengths and 15 degrees of (x, y, yaw) of the goal
+    const float* g = goal + (int64_t)i * 4;
+    const bool pos_ok = norm2(__fsub_rn(x, g[0]), __fsub_rn(y, g[1])) < goal_thresh[i];
+    // cast_rad (transform_utils.py:9-11): torch's remainder = fmod, moved into the divisor's sign
+    const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+    float m = fmodf(__fadd_rn(__fsub_rn(yaw, g[2]), pi), two_pi);
+    if (m != 0.f && m < 0.f) m = __fadd_rn(m, two_pi);
+    const bool rot_ok = fabsf(__fsub_rn(m, pi)) < 0.2617993877991494f;
+    goal_now = pos_ok && rot_ok && v && acc[2 * n_rows + i] == 0;
+  }
+  out_now[i] = out_now_ ? 1 : 0;
+  out_now[n_rows + i] = reach_now ? 1 : 0;
+  out_now[2 * n_rows + i] = goal_now ? 1 : 0;
+  if (out_now_) acc[i] = 1;
+  if (reach_now) acc[n_rows + i] = 1;
+  if (goal_now) acc[2 * n_rows + i] = 1;
+}
+
 }  // namespace
+
+extern "C" int tbx_rule_navi_check(const uint8_t* valid, const float* pose, const float* boundary, int map_batch_div,
+                                   const uint8_t* dest_invalid, const float* dest_pos, const float* dest_dir, const uint8_t* dest_kind,
+                                   const float* dest_thresh, const float* goal, const float* goal_thresh, int n_batch, int n_ag, int n_node,
+                                   uint8_t* acc, uint8_t* out_now, void* stream) {
+  if (!valid || !pose || !boundary || !acc || !out_now) return TBX_ERR_ARG;
+  if ((goal != nullptr) != (goal_thresh != nullptr)) return TBX_ERR_ARG;
+  if (n_batch <= 0 || n_ag <= 0 || map_batch_div <= 0 || n_batch % map_batch_div) return TBX_ERR_ARG;
+  const bool dest = dest_invalid != nullptr;
+  if (dest != (dest_pos != nullptr) || dest != (dest_dir != nullptr) || dest != (dest_kind != nullptr) || dest != (dest_thresh != nullptr))
+    return TBX_ERR_ARG;
+  if (dest && n_node <= 0) return TBX_ERR_ARG;
+  const int64_t rows = (int64_t)n_batch * n_ag;
+  if (rows > 0x7fffffff) return TBX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rule_navi_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, (hipStream_t)stream, valid, pose, boundary,
+                     map_batch_div, dest_invalid, dest_pos, dest_dir, dest_kind, dest_thresh, goal, goal_thresh, (int)rows, n_ag, n_node, acc, out_now);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
 
 extern "C" int tbx_rule_tables(const uint8_t* mp_valid, const uint8_t* mp_type_idx, const float* mp_pos, const float* mp_dir,
                                int ld_xy, int n_scene, int n_mp, int n_node, float* seg, int32_t* n_seg, float* lane,

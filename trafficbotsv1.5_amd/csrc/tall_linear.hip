@@ -150,6 +150,21 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
 
 }  // namespace
 
+// the device's CU count, cached per device ordinal (as tile_layer.hip's cu_count)
+static int tall_cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 static int tall_launch(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                        uint16_t* y16, int ldy16, void* stream) {
   if (x == nullptr || image == nullptr || y == nullptr || m <= 0) return TBX_ERR_ARG;
@@ -161,7 +176,9 @@ static int tall_launch(const float* x, int64_t m, int k, int ldx, const float* i
   static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
   if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tall_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const int64_t n_rb = (m + ROWS - 1) / ROWS;
-  static const int grid_max = [] { const char* e = getenv("TBX_TALL_GRID"); return e ? atoi(e) : 256; }();  // one workgroup per CU, striding over the row blocks
+  // one workgroup per CU, striding over the row blocks (TBX_TALL_GRID: an explicit grid size for A/B runs, clamped to >= 1)
+  static const int grid_env = [] { const char* e = getenv("TBX_TALL_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int grid_max = grid_env > 0 ? grid_env : tall_cu_count();
   hipLaunchKernelGGL(tall_linear_kernel, dim3((unsigned)(n_rb < grid_max ? n_rb : grid_max)), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

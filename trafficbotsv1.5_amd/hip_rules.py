@@ -54,6 +54,20 @@ def rule_accumulate(raw, n_rows: int, ld_t: int, t0: int, n_t: int, acc_state, p
     _check(rc, "tbx_rule_accumulate")
 
 
+def rule_navi_check(valid_u8, pose, boundary, map_batch_div: int, dest: Optional[dict], goal, goal_thresh, acc, out_now):
+    """tbx_rule_navi_check: outside-map / destination-reached / goal-reached of ONE step. dest = dict(invalid [n,A,N] u8, pos / dir
+    [n,A,N,2] f32, kind [n,A] u8, thresh [n,A] f32) or None (no destinations); goal [n,A,4] + goal_thresh [n,A] or None; acc [3,n,A] u8
+    (outside_map, dest_reached, goal_reached) updated in place; out_now [3,n,A] u8."""
+    n, A = valid_u8.shape
+    d = dest or {}
+    rc = load().tbx_rule_navi_check(_cptr(valid_u8, torch.uint8), _cptr(pose, torch.float32), _cptr(boundary, torch.float32), map_batch_div,
+                                    _cptr(d.get("invalid"), torch.uint8), _cptr(d.get("pos"), torch.float32), _cptr(d.get("dir"), torch.float32),
+                                    _cptr(d.get("kind"), torch.uint8), _cptr(d.get("thresh"), torch.float32), _cptr(goal, torch.float32),
+                                    _cptr(goal_thresh, torch.float32), n, A, d["invalid"].shape[2] if dest else 0, _cptr(acc, torch.uint8),
+                                    _cptr(out_now, torch.uint8), stream_ptr())
+    _check(rc, "tbx_rule_navi_check")
+
+
 def filter_futures(flags, col_bit: int, ag_role_any, n_scene: int, n_k: int, t_start: int, w_road_edge: float, n_keep: int,
                    pred_pose=None):
     """flags [n_scene*n_k, A, T] u8 bits, ag_role_any [n_scene, A] u8 -> (score [n_scene,n_k], idx [n_scene,n_keep] i32,

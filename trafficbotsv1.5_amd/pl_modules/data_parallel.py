@@ -196,9 +196,25 @@ class GraphedTrainStep:
         self.noise = torch.zeros(n, A, wm.model.latent_encoder.out_dim, device=dev)
         self.use_prior = torch.zeros((), dtype=torch.bool, device=dev)
         wm.attn_dropout_seed = self.drop_seed = torch.zeros(1, dtype=torch.int64, device=dev)  # static: the graph reads it
-        self.epoch = wm.current_epoch
         self.live: Optional[List[torch.nn.Parameter]] = None
         self._say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
+        self._dev, self._warmup = dev, warmup
+        self.graph = self.flat = None
+        self._recapture()
+
+    def _recapture(self) -> None:
+        """Warm-up + capture for the module's CURRENT epoch (constructor; again from __call__ when the epoch has changed). The old
+        graph and its private pool are released first; the live-parameter list and the optimizer are kept."""
+        wm, dev = self.wm, self._dev
+        if self.graph is not None:
+            torch.cuda.synchronize(dev)
+            if self.flat is not None:
+                self.flat.detach()  # (the parameters' .grad views of the old static buffer)
+            self.graph = self.flat = None
+            import gc
+
+            gc.collect()
+        self.epoch = wm.current_epoch
         # hipStreamEndCapture walks the captured graph recursively (~10^5 nodes in a chain: the default 8 MiB stack overflows,
         # measured); warm-up + capture therefore run on a thread with a 1 GiB (virtual, lazily committed) stack
         err: List[BaseException] = []
@@ -206,7 +222,7 @@ class GraphedTrainStep:
         def work():
             try:
                 torch.cuda.set_device(dev)
-                self._capture(optimizer, dev, warmup)
+                self._capture(self.opt, dev, self._warmup)
             except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
                 err.append(e)
 
@@ -262,8 +278,19 @@ class GraphedTrainStep:
         return {k: v for k, v in self.wm.pre_processing({k: v.clone() for k, v in batch.items()}).items() if torch.is_tensor(v)}
 
     def _fwd_bwd(self) -> None:
+        from .. import hip_base
+
         loss = self.wm.training_step(dict(self.static), 0, noise=self.noise, use_prior=self.use_prior)
-        loss.backward()
+        # The backward packs weight images too (TallLinearFn.backward: the W^T image of every tall LINEAR's input gradient). Outside a
+        # scope those come from the per-Parameter cache, stamped by the weights' version - and the warm-up passes (no optimizer step
+        # between them and the capture) leave that cache at the CAPTURE-time version: the captured backward would hit it, its
+        # tbx_pack_weight launch would not be in the graph, and every replay after the first AdamW step would multiply by the W^T of
+        # the warm-up weights. With a scope of its own the packing is part of the backward - eager or captured.
+        hip_base.PACK_SCOPE = {}
+        try:
+            loss.backward()
+        finally:
+            hip_base.PACK_SCOPE = None
 
     def _refill(self) -> None:
         self.noise.copy_(torch.randn(self.noise.shape), non_blocking=False)  # CPU generator, as the reference's CPU path
@@ -271,7 +298,12 @@ class GraphedTrainStep:
         self.drop_seed.random_()  # new attention-dropout masks for this replay
 
     def __call__(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
-        assert self.wm.current_epoch == self.epoch, "re-capture the step after an epoch change"
+        if self.wm.current_epoch != self.epoch:
+            # TeacherForcing's schedules read `current_epoch` on the host while the step is captured (teacher_forcing.py:86-106: the
+            # forcing horizon / probabilities decrease per epoch): a new epoch is a new graph. The weights, the optimizer (its
+            # state included) and the flat gradient buffer's role stay; warm-up + capture run again (a few seconds, once per epoch).
+            self._say("epoch", self.epoch, "->", self.wm.current_epoch, ": re-capturing")
+            self._recapture()
         b = self._pre(batch)  # eager (tiny); its advanced-indexing index tensors are host data, not capturable
         for k, v in self.static.items():
             v.copy_(b[k])

@@ -19,6 +19,7 @@ from ..models.modules.distributions import MyDist
 from ..models.traffic_bots import TrafficBots
 from ..utils.buffer import RolloutBuffer
 from ..utils.dynamics import Dynamics
+from ..utils.rewards import DifferentiableReward
 from ..utils.rollout_engine import RolloutEngine
 from ..utils.teacher_forcing import TeacherForcing
 from ..utils.traffic_rule_checker import TrafficRuleChecker
@@ -59,6 +60,15 @@ class WaymoMotion(LightningModule):
         super().__init__()
         if pred_navi_after_reached:
             raise NotImplementedError("pred_navi_after_reached=False is the default (no per-step host branch)")
+        # The training step batches the decoder over TIME (train_graph.py): that is exact only because every step's model input is
+        # detached (waymo_motion.py:158-161) and the action is the distribution's mean (:370, dynamics.py:87-91). With either flag off
+        # the reference back-propagates through the closed loop / samples actions - gradients this implementation does not compute.
+        if not training_detach_model_input:
+            raise NotImplementedError("training_detach_model_input=False: back-propagation through the closed loop is not implemented "
+                                      "(the time-batched training step needs detached model inputs, the default)")
+        if not training_deterministic_action:
+            raise NotImplementedError("training_deterministic_action=False: sampled actions in the training rollout are not implemented "
+                                      "(the default is the deterministic action)")
         self.save_hyperparameters()  # self.hparams.<constructor argument>, as in the reference (waymo_motion.py:66)
         # tbx_sim_step / tbx_train_chain log the DEFAULT DifferentiableReward (rewards.py:35-85: SmoothL1 position / speed terms, a
         # cosine SmoothL1 rotation term, no collision approximation); anything else would yield a plausible but wrong RolloutBuffer
@@ -76,6 +86,7 @@ class WaymoMotion(LightningModule):
         for _, m in pp:
             kwargs.update(m.model_kwargs)
         self.pre_processing = nn.Sequential(OrderedDict(pp))
+        self.diffbar_reward = DifferentiableReward(**_strip_target(differentiable_reward))  # waymo_motion.py:71
         self.dynamics = Dynamics(navi_mode=kwargs["navi_mode"], **dynamics)
         mcfg = to_attr({**_strip_target(model), **kwargs, "action_dim": self.dynamics.action_dim})
         self.model = TrafficBots(**mcfg)
@@ -122,8 +133,14 @@ class WaymoMotion(LightningModule):
                   map_pos=rule_checker.mp_pos, map_dir=rule_checker.mp_dir, map_boundary=rule_checker.mp_boundary,
                   n_step=step_end, reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight),
                   ag_navi_log_prob=ag_tokens.get("ag_navi_log_prob"), stepwise=stepwise)
-        # One engine per (shapes, schedule, weights), refilled in place: a loop over scenes (validation_step, waymo_motion.py:526)
-        # captures its hipGraphs once. `engine_cache = 0` turns the cache off (a fresh engine per rollout).
+        eng = self._engine_for(kw, dev)
+        self.dynamics.bind(eng)
+        return eng
+
+    def _engine_for(self, kw: dict, dev) -> RolloutEngine:
+        """One engine per (shapes, schedule, weights), refilled in place: a loop over scenes (validation_step, waymo_motion.py:526)
+        captures its hipGraphs once. `engine_cache = 0` turns the cache off (a fresh engine per rollout). kw: RolloutEngine.reset's."""
+        mp_tokens, tl_tokens = kw["mp_tokens"], kw["tl_tokens"]
         sched = self.schedule if self.schedule is not None else engine.current()
         # (weights: every parameter's storage AND version - an optimizer step, load_state_dict, .to() or `p.data = ` all change one)
         key = (RolloutEngine.shape_key(**kw), dataclasses.astuple(sched), str(dev), self.training,
@@ -146,7 +163,6 @@ class WaymoMotion(LightningModule):
                 while len(self._engines) > self.engine_cache:
                     self._engines.popitem(last=False)
         self._engine = eng
-        self.dynamics.bind(eng)
         return eng
 
     @torch.no_grad()
@@ -161,11 +177,17 @@ class WaymoMotion(LightningModule):
         if not deterministic_action:
             raise NotImplementedError("stochastic actions are not used by any default entry point")
         stepwise = stepwise or player_policy is not None
-        eng = self.begin_rollout(ag_tokens, mp_tokens, tl_tokens, tl_state_gt, teacher_forcing, rule_checker, step_end, stepwise)
         if not stepwise:
+            eng = self.begin_rollout(ag_tokens, mp_tokens, tl_tokens, tl_state_gt, teacher_forcing, rule_checker, step_end)
             eng.run(step_end, use_graph=use_graph)
             return eng.buffer(self.hp.time_step_current, rule_checker=rule_checker)
-        dyn, S = self.dynamics, eng.S
+        # ---- the reference's loop, statement by statement (waymo_motion.py:218-311)
+        teacher_forcing.init(ag_valid=ag_tokens["gt_valid"], ag_pose=ag_tokens["gt_pose"], ag_motion=ag_tokens["gt_motion"],
+                             tl_state=tl_state_gt, current_epoch=self.current_epoch)
+        self.dynamics.init(tl_state=tl_state_gt, **ag_tokens)
+        self.model.init()
+        self._forward_steps = step_end  # (the log a forward-driven engine keeps; default hparams.time_step_end)
+        dyn = self.dynamics
         buf = RolloutBuffer(step_end, self.hparams.time_step_current)
         lp0 = ag_tokens.get("ag_navi_log_prob")
         buf.add_navi_log_prob(torch.zeros_like(ag_tokens["gt_pose"][:, :, 0, 0]) if lp0 is None else lp0, ag_tokens["ag_navi_valid"])
@@ -175,11 +197,10 @@ class WaymoMotion(LightningModule):
             player_override = player_policy(dyn.ag_pose) if player_policy is not None else None
             pred_dict, vis_dict = self.forward(mp_tokens, tl_tokens, ag_override, tl_override, player_override, deterministic_action)
             violation = rule_checker.check(pred_dict["pred_valid"], pred_dict["pred_pose"], pred_dict["pred_motion"], dyn.tl_state)
-            violation.update(outside_map=S["outside_map"].bool(), outside_map_this_step=S["now_outside"].bool(),
-                             dest_reached=S["dest_reached"].bool(), dest_reached_this_step=S["now_reached"].bool())
-            violation = {k: v.clone() for k, v in violation.items()}
             _gt_valid = ag_tokens["gt_valid"][:, :, _step] if _step < Tg else None
-            slot = _step - 1
+            # reward and light NLL as tbx_sim_step logged them for this step (the expressions of self.diffbar_reward.get and of
+            # -pred_tl_state_dist.log_prob: the engine's own loop hands out the same log)
+            S, slot = self._engine.S, _step - 1
             r = S["out_reward"][:, :, slot]
             reward = {"diffbar_reward_valid": S["out_reward_valid"][:, :, slot].bool(), "diffbar_reward": r[..., 3],
                       "r_imitation_pos": r[..., 0], "r_imitation_rot": r[..., 1], "r_imitation_spd": r[..., 2],
@@ -196,18 +217,28 @@ class WaymoMotion(LightningModule):
     def forward(self, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], ag_override: Dict[str, Tensor],
                 tl_override: Dict[str, Tensor], player_override: Optional[Dict[str, Tensor]] = None,
                 deterministic_action: bool = True):
-        """Reference signature and semantics (waymo_motion.py:118-204): ONE closed-loop step on the simulation state that
-        `begin_rollout(..., stepwise=True)` / `rollout(..., stepwise=True)` set up - TrafficBots policy on the sliding windows,
+        """Reference signature and semantics (waymo_motion.py:118-204): ONE closed-loop step on the simulation state that the
+        reference's prologue - `self.dynamics.init(tl_state=tl_state_gt, **ag_tokens)`, `self.model.init()` (:228-229) - or
+        `begin_rollout(..., stepwise=True)` set up: TrafficBots policy on the sliding windows,
         Dynamics.update_ag (player_override: {"valid", "action"} replaces the policy's physical action), then
         Dynamics.override_ag(ag_override {"valid", "pose", "motion"}) and override_tl(tl_override {"valid", "state"}).
         Returns (pred_dict, vis_dict) with the reference's keys. Rule checks and disable_ag / disable_navi stay with the caller
         (`self.dynamics.disable_ag(violation, gt_valid)`), as in the reference's `rollout`."""
-        eng = self._engine
-        if eng is None or not eng.stepwise:
-            raise RuntimeError("forward() steps the state set up by begin_rollout(..., stepwise=True)")
+        if self.dynamics._pending is not None:
+            eng = self._engine_from_init(mp_tokens, tl_tokens)
+        else:
+            eng = self._engine
+        if eng is None or not eng.stepwise or self.dynamics._eng is not eng:
+            raise RuntimeError("forward() steps the simulation state that the reference's rollout prologue sets up - teacher_forcing.init, "
+                               "self.dynamics.init(tl_state=..., **ag_tokens), self.model.init() (waymo_motion.py:218-229) - or "
+                               "begin_rollout(..., stepwise=True)")
         if not deterministic_action:
             raise NotImplementedError("stochastic actions are not used by any default entry point")
-        eng.mp_tokens, eng.tl_tokens = mp_tokens, tl_tokens
+        if eng._n_forward >= eng.T:
+            raise RuntimeError(f"forward(): the engine logs {eng.T} steps per rollout (hparams.time_step_end, or rollout's step_end); "
+                               "call self.dynamics.init(...) again to start another rollout")
+        if not eng.reused:  # (a cached engine owns copies of the token dicts it was built from - the same values)
+            eng.mp_tokens, eng.tl_tokens = mp_tokens, tl_tokens
         with torch.no_grad():
             slot = eng.forward_step(ag_override, tl_override, player_override)
         S, n, L = eng.S, eng.n, eng.L
@@ -222,6 +253,21 @@ class WaymoMotion(LightningModule):
                         "action": S["out_action"][:, :, slot], "ag_navi": dyn.ag_navi, "ag_navi_valid": dyn.ag_navi_valid,
                         "navi_reached": dyn.mask_navi_reached, "tl_state": dyn.tl_state}
         return pred_dict, vis_dict
+
+    def _engine_from_init(self, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor]) -> RolloutEngine:
+        """The step-wise engine of a rollout that was started the reference's way (Dynamics.init + TrafficBots.init), built by the
+        first `forward` - the call that brings the tokens. Its tbx_sim_step copies of the outside-map / destination checks get
+        tables that never fire: the caller's `rule_checker.check` evaluates them and `dynamics.disable_ag / disable_navi` apply them."""
+        p = self.dynamics._pending
+        dev = p["gt_pose"].device
+        rc = self.hparams.differentiable_reward
+        kw = dict(tf_mask=torch.zeros_like(p["gt_valid"]), mp_tokens=mp_tokens, tl_tokens=tl_tokens, map_valid=None, map_type=None, map_pos=None,
+                  map_dir=None, map_boundary=None, n_step=int(getattr(self, "_forward_steps", None) or self.hparams.time_step_end),
+                  reward_weights=(rc.l_pos.weight, rc.l_rot.weight, rc.l_spd.weight), stepwise=True, **p)
+        eng = self._engine_for(kw, dev)
+        self.dynamics.bind(eng)
+        self._forward_steps = None
+        return eng
 
     def _rule_checker(self, batch, ag_dest, tl_tokens, n_rollout: int = 1):
         """waymo_motion.py:399-412,497-510. Agent tensors per rollout, map tensors per scene (shared by its rollouts)."""
@@ -250,10 +296,16 @@ class WaymoMotion(LightningModule):
     def joint_future_pred(self, batch, mp_tokens, tl_tokens, ag_latent_dist: Optional[MyDist], ag_navi_dist: Optional[MyDist],
                           teacher_forcing: TeacherForcing, n_joint_future: int, step_end: Optional[int] = None,
                           use_graph: bool = True) -> RolloutBuffer:
-        """waymo_motion.py:439-524: K parallel rollouts per scene from the history only. The K rollouts of a scene
-        share one copy of the map tokens / K-V tables (tl_tokens must come from encode_scene(n_rollout=K))."""
+        """waymo_motion.py:439-524: K parallel rollouts per scene from the history only. mp_tokens / tl_tokens exactly as
+        `model.mp_encoder(...)` and `model.tl_encoder.pre_compute(tl_valid=..., **mp_tokens)` return them (validation_step,
+        :528-535): the per-rollout repeat of the reference (:458-462) happens here, on a COPY of the light tokens (the caller's dicts
+        stay as they are - `reactive_replay` has read the same ones), and only for the lights: the K rollouts of a scene share one copy
+        of the map tokens and K/V tables (mp_batch_div). tl_tokens already expanded by `encode_scene(n_rollout=K)` are taken as is."""
         K = n_joint_future
-        assert tl_tokens.get("mp_batch_div", 1) == K, "build tl_tokens with encode_scene(..., n_rollout=n_joint_future)"
+        if K > 1 and tl_tokens.get("mp_batch_div", 1) == 1:
+            tl_tokens = self._tl_tokens_per_rollout(tl_tokens, K)
+        elif tl_tokens.get("mp_batch_div", 1) != K:
+            raise ValueError(f"tl_tokens were expanded for {tl_tokens.get('mp_batch_div', 1)} rollouts per scene, n_joint_future = {K}")
         r = lambda t: t.repeat_interleave(K, 0)
         ag_tokens = {"ag_type": r(batch["ref/ag_type"]), "ag_size": r(batch["ref/ag_size"]), "ag_attr": r(batch["sc/ag_attr"]),
                      "gt_valid": r(batch["sc/ag_valid"]), "gt_pose": r(batch["sc/ag_pose"]), "gt_motion": r(batch["sc/ag_motion"])}
@@ -262,17 +314,40 @@ class WaymoMotion(LightningModule):
             det[::K] = True
         else:
             det = False
-        ag_latent_dist.repeat_interleave_(K, 0)
+        if ag_latent_dist is None or ag_navi_dist is None:
+            raise NotImplementedError("joint_future_pred: the default configuration predicts a latent and a destination per agent")
+        ag_latent_dist.repeat_interleave_(K, 0)  # (in place, as the reference: :474,488)
         ag_tokens["ag_latent"] = ag_latent_dist.sample(deterministic=det)
         ag_tokens["ag_latent_valid"] = ag_latent_dist.valid
+        ag_latent_log_prob = ag_latent_dist.log_prob(ag_tokens["ag_latent"]).masked_fill(~ag_tokens["ag_latent_valid"], 0)
         ag_navi_dist.repeat_interleave_(K, 0)
         ag_tokens["ag_navi"] = ag_navi_dist.sample(det)
         ag_tokens["ag_navi_valid"] = ag_navi_dist.valid
+        ag_tokens["ag_navi_log_prob"] = ag_navi_dist.log_prob(ag_tokens["ag_navi"]).masked_fill(~ag_tokens["ag_navi_valid"], 0)
         checker = self._rule_checker(batch, ag_tokens["ag_navi"], tl_tokens, n_rollout=K)
         buf = self.rollout(ag_tokens, mp_tokens, tl_tokens, r(batch["sc/tl_state"]), teacher_forcing, checker,
                            step_end or self.hp.time_step_end, True, use_graph=use_graph)
         buf.flatten_joint_future(K)
+        buf.compute_log_prob(ag_latent_log_prob)
         return buf
+
+    @staticmethod
+    def _tl_tokens_per_rollout(tl_tokens: Dict[str, Tensor], K: int) -> Dict[str, Tensor]:
+        """The light tokens of `pre_compute` (one entry per scene) as `encode_scene(n_rollout=K)` makes them: every per-light tensor
+        repeated K times along the batch (waymo_motion.py:460-462), the map targets still indexed per scene (mp_batch_div = K: the
+        K-nearest map indices are local to a scene's M polylines). A new dict - the caller's is not touched -, bit-identical to
+        running pre_compute on the repeated inputs (every row's K-nearest search and relative poses depend on that row alone)."""
+        n = tl_tokens["tl_token_pose"].shape[0]
+        out = {}
+        for key, v in tl_tokens.items():
+            if key.startswith("_"):
+                continue  # per-module caches (K/V tables of the map tokens): rebuilt for the new dict
+            if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n and key != "mp_feat_flat":
+                out[key] = v.repeat_interleave(K, 0)
+            else:
+                out[key] = v
+        out["mp_batch_div"] = K
+        return out
 
     # ------------------------------------------------------------------ training
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int, noise: Optional[Tensor] = None,

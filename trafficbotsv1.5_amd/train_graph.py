@@ -628,8 +628,10 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
                             policy=lambda step, hist, v, p, nv: (mean[:, step - 1], logits[:, step - 1]))
 
 
-def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussian, prior: DiagGaussian) -> Dict[str, Tensor]:
-    """metrics/training.py:74-189 + metrics/loss.py:39-77 (default weights / switches)."""
+def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussian, prior: DiagGaussian,
+                  counts: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    """metrics/training.py:74-189 + metrics/loss.py:39-77 (default weights / switches). counts: receives every term's normaliser
+    (the number of entries its sum runs over, un-clamped) - a term of a batch is the count-weighted mean of its per-scene terms."""
     # A term whose counter is zero (a batch without a valid light / agent) is left out by the reference (training.py:166-186:
     # `if counter > 0`): sum = 0 over a count clamped to 1 gives that 0 without a host branch (the step stays capturable).
     cnt = lambda m: m.sum().clamp(min=1)
@@ -651,6 +653,8 @@ def training_loss(cfg, ro, navi_pred: DestCategorical, navi_gt, post: DiagGaussi
     navi = cfg.w_navi * (-navi_pred.log_prob(navi_gt)).masked_fill(~nv, 0).sum() / cnt(nv)
     tv = ~ro["tl_nll_invalid"]
     tl = cfg.w_tl_state * ro["tl_nll"].masked_fill(~tv, 0).sum() / cnt(tv)
+    if counts is not None:
+        counts.update(vae_kl=kv.sum(), diffbar_reward=rv.sum(), navi_loss=nv.sum(), tl_state_loss=tv.sum())
     return {"loss": vae_kl - reward + navi + tl, "vae_kl": vae_kl, "diffbar_reward": reward, "navi_loss": navi, "tl_state_loss": tl}
 
 
@@ -710,4 +714,5 @@ def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:
             current_epoch=wm.current_epoch)
     rollout = training_rollout_batched if getattr(wm, "time_batched_training", True) else training_rollout
     ro = rollout(wm, b, mp, tl_tokens, z, l_valid, tf.ag_teacher_forcing, hp.time_step_end)
-    return training_loss(hp.training_metrics, ro, navi_pred, b["gt/ag_navi"], post, prior)
+    wm.last_counts = {}
+    return training_loss(hp.training_metrics, ro, navi_pred, b["gt/ag_navi"], post, prior, counts=wm.last_counts)

@@ -21,6 +21,7 @@ from torch import Tensor
 
 from .. import engine, hip
 from .buffer import RolloutBuffer
+from .traffic_rule_checker import dest_tables
 
 
 def _u8(t: Tensor) -> Tensor:
@@ -87,8 +88,8 @@ class RolloutEngine:
     @_scheduled
     def reset(self, *, gt_valid: Tensor, gt_pose: Tensor, gt_motion: Tensor, tl_state_gt: Tensor, tf_mask: Tensor,
               ag_type: Tensor, ag_attr: Tensor, ag_latent: Tensor, ag_latent_valid: Tensor, ag_navi: Tensor,
-              ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Tensor,
-              map_type: Tensor, map_pos: Tensor, map_dir: Tensor, map_boundary: Tensor, n_step: int,
+              ag_navi_valid: Tensor, mp_tokens: Dict[str, Tensor], tl_tokens: Dict[str, Tensor], map_valid: Optional[Tensor],
+              map_type: Optional[Tensor], map_pos: Optional[Tensor], map_dir: Optional[Tensor], map_boundary: Optional[Tensor], n_step: int,
               reward_weights=(0.1, 10.0, 0.1), ag_navi_log_prob: Optional[Tensor] = None, stepwise: bool = False,
               _lights_ahead_pass: bool = True, _tl_div: Optional[int] = None) -> None:
         """All tensors on the device. gt_* [n,A,Tg(,3)], tl_state_gt [n,L,Tt,5] bool, tf_mask [n,A,Tg] bool
@@ -102,9 +103,10 @@ class RolloutEngine:
         n, A, Tg = gt_valid.shape
         L, Tt = tl_state_gt.shape[1], tl_state_gt.shape[2]
         W = self.model.temp_window_size
-        N = map_valid.shape[2]
+        N = map_valid.shape[2] if map_valid is not None else 1
         div = tl_tokens.get("mp_batch_div", 1)
         f32, u8 = torch.float32, torch.uint8
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)
         self.n, self.A, self.L, self.T, self.W = n, A, L, n_step, W
         # lights once per scene when the K = div rollouts of every scene were given identical lights (one host check per reset)
         kl = 1
@@ -132,23 +134,27 @@ class RolloutEngine:
         if kl > 1:
             tl_tokens = lights_per_scene(tl_tokens, kl)
             tl_state_gt = tl_state_gt[::kl]
-        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)
         S = {}
         # ---- static
         S["ag_type_idx"] = _u8(ag_type.to(u8).argmax(-1))
         S["tf_mask"], S["gt_valid"] = _u8(tf_mask), _u8(gt_valid)
         S["gt_pose"], S["gt_motion"] = gt_pose.float().contiguous(), gt_motion.float().contiguous()
         S["tl_gt"] = _state_bits(tl_state_gt)
-        S["boundary"] = map_boundary.float().repeat_interleave(n // map_boundary.shape[0], 0).contiguous()
-        bsel = (torch.arange(n, device=dev) // div).unsqueeze(1)
-        d_type = map_type[bsel, ag_navi]                      # [n,A,11]
-        d_dir = map_dir[bsel, ag_navi][..., :2].float()       # traffic_rule_checker.py:87-107
-        d_dir = d_dir / torch.norm(d_dir, dim=-1, keepdim=True)
-        S["dest_pos"] = map_pos[bsel, ag_navi][..., :2].float().contiguous()
-        S["dest_dir"] = d_dir.contiguous()
-        S["dest_invalid"] = _u8(~map_valid[bsel, ag_navi])
-        S["dest_kind"] = (d_type[:, :, :4].any(-1).to(u8) + 2 * d_type[:, :, 4].to(u8)).contiguous()
-        S["dest_thresh"] = (50.0 * (1 - d_type[:, :, 4].float() * 0.8)).contiguous()
+        if map_valid is None:
+            # a step-wise engine built by WaymoMotion.forward after the reference's prologue (Dynamics.init): the caller's
+            # TrafficRuleChecker.check evaluates outside-map / destination-reached itself (tbx_rule_navi_check) and hands the flags to
+            # Dynamics.disable_ag / disable_navi - the copies inside tbx_sim_step get tables that never fire
+            assert stepwise, "only a step-wise engine runs without the scene's polylines"
+            N = 1
+            S["boundary"] = torch.full((n, 4), math.inf, dtype=f32, device=dev)
+            S["boundary"][:, 0::2] = -math.inf
+            S["dest_pos"], S["dest_dir"], S["dest_invalid"] = z(n, A, 1, 2), z(n, A, 1, 2), torch.ones(n, A, 1, dtype=u8, device=dev)
+            S["dest_kind"], S["dest_thresh"] = z(n, A, dt=u8), z(n, A)
+        else:
+            S["boundary"] = map_boundary.float().repeat_interleave(n // map_boundary.shape[0], 0).contiguous()
+            dt_ = dest_tables(ag_navi, map_valid, map_type, map_pos, map_dir)  # traffic_rule_checker.py:87-107
+            S["dest_pos"], S["dest_dir"], S["dest_invalid"] = dt_["pos"], dt_["dir"], dt_["invalid"]
+            S["dest_kind"], S["dest_thresh"] = dt_["kind"], dt_["thresh"]
         self.ag_attr6 = ag_attr.float().contiguous()
         self.ag_type, self.navi_log_prob0, self.navi_valid0 = ag_type, ag_navi_log_prob, ag_navi_valid
         self.n_step_tl_gt, self.stepwise = Tt, stepwise
@@ -232,7 +238,7 @@ class RolloutEngine:
         """What must agree for `refill` (same buffers, same captured graphs): every shape the engine's buffers depend on."""
         tok = lambda d: tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items() if torch.is_tensor(v))) + tuple(
             sorted((k, v) for k, v in d.items() if isinstance(v, int)))
-        return (tuple(gt_valid.shape), tuple(tl_state_gt.shape), tuple(map_valid.shape), int(n_step), bool(stepwise), tuple(ag_latent.shape),
+        return (tuple(gt_valid.shape), tuple(tl_state_gt.shape), None if map_valid is None else tuple(map_valid.shape), int(n_step), bool(stepwise), tuple(ag_latent.shape),
                 tok(mp_tokens), tok(tl_tokens))
 
     @_scheduled
@@ -622,8 +628,14 @@ class RolloutEngine:
                                    "captured for (use a new engine: WaymoMotion.engine_cache = 0)")
         if self.reused:  # the log tensors are rewritten by this engine's next rollout: the buffer gets its own copies
             S = {k: (v.clone() if k.startswith("out_") else v) for k, v in S.items()}
-        # (the u8 logs hold 0 / 1 - tbx_sim_step stores C++ bools -: their bool form is a reinterpreting view, not a conversion launch)
-        b8 = lambda t: t.view(torch.bool) if t.dtype == torch.uint8 else t.bool()
+        # (THESE u8 logs hold 0 / 1 - tbx_sim_step stores C++ bools into out_valid / out_outside_map / out_dest_reached /
+        # out_reward_valid / out_tf -: their bool form is a reinterpreting view, not a conversion launch. Bit-mask logs (out_tl_state's
+        # 5-bit states, the rule flags) never go through b8.)
+        def b8(t):
+            assert t.dtype == torch.uint8
+            if os.environ.get("TBX_DEBUG_BOOL_LOGS"):
+                assert int(t.max()) <= 1, "a 0/1 log holds a bit mask"
+            return t.view(torch.bool)
         buf.pred_valid, buf.pred_pose, buf.pred_motion = b8(S["out_valid"]), S["out_pose"], S["out_motion"]
         buf.violation = {"outside_map": b8(S["out_outside_map"]), "dest_reached": b8(S["out_dest_reached"])}
         rep = (lambda t: t) if self.tl_div == 1 else (lambda t: t.repeat_interleave(self.tl_div, 0))  # per rollout again

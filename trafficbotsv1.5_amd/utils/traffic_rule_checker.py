@@ -6,8 +6,10 @@ back into the simulation (outside-map -> disable agent, destination reached -> d
 the WOSAC rollout filter, so here they are evaluated for ALL steps of a finished rollout at once from the device-resident
 rollout log (`check_log`, one `tbx_rule_check` launch over n_rollout x n_step frames + one `tbx_rule_accumulate`), which
 fills a 256-CU device where 80 per-step calls on 64-128 agents would not. `check` keeps the reference's per-step
-signature (a one-frame log). Constructor arguments are the reference's; map tensors may be given per scene while the
-agent tensors are per rollout (n_rollout = K * n_scene): the K rollouts of a scene share one copy of the tables.
+signature and its complete result (a one-frame log for the five + `tbx_rule_navi_check` for outside_map / dest_reached, which a
+step-wise caller hands to `Dynamics.disable_ag / disable_navi` as the reference's `rollout` does, waymo_motion.py:250,304-305).
+Constructor arguments are the reference's; map tensors may be given per scene while the agent tensors are per rollout
+(n_rollout = K * n_scene) - or per rollout too, as the reference's `joint_future_pred` repeats them (:497-503).
 
 There is no CPU path: every method needs device tensors and the HIP library.
 """
@@ -17,6 +19,22 @@ import torch
 from torch import Tensor
 
 from .. import hip
+
+def dest_tables(ag_dest: Tensor, mp_valid: Tensor, mp_type: Tensor, mp_pos: Tensor, mp_dir: Tensor) -> Dict[str, Tensor]:
+    """TrafficRuleChecker._get_dest (traffic_rule_checker.py:87-107) in the form tbx_sim_step / tbx_rule_navi_check read:
+    ag_dest [n, A] int64 polyline index; map tensors [n / div, M, N, ..] (div rollouts share a scene's polylines) ->
+    invalid [n,A,N] u8, pos / dir [n,A,N,2] f32 (dir normalised), kind [n,A] u8 (1 lane, 2 road edge), thresh [n,A] f32 (50 m / 10 m)."""
+    n = ag_dest.shape[0]
+    u8 = torch.uint8
+    bsel = (torch.arange(n, device=ag_dest.device) // (n // mp_valid.shape[0])).unsqueeze(1)
+    d_type = mp_type[bsel, ag_dest]                      # [n, A, 11]
+    d_dir = mp_dir[bsel, ag_dest][..., :2].float()
+    d_dir = d_dir / torch.norm(d_dir, dim=-1, keepdim=True)
+    return {"pos": mp_pos[bsel, ag_dest][..., :2].float().contiguous(), "dir": d_dir.contiguous(),
+            "invalid": (~mp_valid[bsel, ag_dest]).to(u8).contiguous(),
+            "kind": (d_type[:, :, :4].any(-1).to(u8) + 2 * d_type[:, :, 4].to(u8)).contiguous(),
+            "thresh": (50.0 * (1 - d_type[:, :, 4].float() * 0.8)).contiguous()}
+
 
 _KEYS = (("collided", hip.RULE_COLLIDED), ("collided_wosac", hip.RULE_COLLIDED_WOSAC), ("run_road_edge", hip.RULE_RUN_ROAD_EDGE),
          ("run_red_light", hip.RULE_RUN_RED_LIGHT), ("passive", hip.RULE_PASSIVE))
@@ -38,6 +56,7 @@ class TrafficRuleChecker:
         self._ctx: Optional[hip.RuleCtx] = None
         self._keep = None
         self._acc: Optional[Tensor] = None          # running OR of the five flags [n, A] u8 bits
+        self._navi: Optional[dict] = None           # check(): the destination tables + the outside_map / dest_reached accumulators
         self.passive_counter: Optional[Tensor] = None  # [n, A] f32 (traffic_rule_checker.py:42)
 
     # ------------------------------------------------------------------ static tables (once per scene batch)
@@ -102,12 +121,32 @@ class TrafficRuleChecker:
         return out
 
     # ------------------------------------------------------------------ the reference's per-step entry point
+    def _navi_setup(self) -> dict:
+        if self._navi is None:
+            n, A = self.ag_type.shape[:2]
+            dev = self.ag_type.device
+            dest = None if self.ag_dest is None else dest_tables(self.ag_dest, self.mp_valid, self.mp_type, self.mp_pos, self.mp_dir)
+            goal = None if self.ag_goal is None else self.ag_goal.float().contiguous()
+            self._navi = dict(dest=dest, boundary=self.mp_boundary.float().contiguous(), div=n // self.mp_boundary.shape[0], goal=goal,
+                              goal_thresh=None if goal is None else (self.ag_size[:, :, 0].float() * 8).contiguous(),  # (:66, un-scaled length)
+                              acc=torch.zeros(3, n, A, dtype=torch.uint8, device=dev))
+        return self._navi
+
     @torch.no_grad()
     def check(self, valid: Tensor, pose: Tensor, motion: Tensor, tl_state: Tensor) -> Dict[str, Tensor]:
         """traffic_rule_checker.py:342-451 for one step: valid [n,A] bool, pose / motion [n,A,3], tl_state [n,L,5] one-hot
-        bool -> {collided, collided_this_step, ...} [n,A] bool, accumulating across calls like the reference's object.
-        (outside_map / dest_reached are produced by the simulation step itself: RolloutBuffer.violation.)"""
+        bool -> the reference's sixteen entries {outside_map, outside_map_this_step, collided, ..., goal_reached, dest_reached,
+        dest_reached_this_step}, [n,A] bool, accumulating across calls like the reference's object."""
         w = 1 << torch.arange(tl_state.shape[-1], device=tl_state.device, dtype=torch.int32)
         bits = (tl_state.to(torch.int32) * w).sum(-1).to(torch.uint8)
         out = self.check_log(valid.unsqueeze(-1), pose.unsqueeze(2), motion.unsqueeze(2), bits.unsqueeze(-1))
-        return {k: v[..., 0] for k, v in out.items()}
+        out = {k: v[..., 0] for k, v in out.items()}
+        nv = self._navi_setup()
+        now = torch.empty_like(nv["acc"])
+        hip.rule_navi_check(valid.to(torch.uint8).contiguous(), pose.float().contiguous(), nv["boundary"], nv["div"], nv["dest"], nv["goal"],
+                            nv["goal_thresh"], nv["acc"], now)
+        acc = nv["acc"].clone().view(torch.bool)  # (the reference hands out its accumulators as of THIS step: `self.x = self.x | now` rebinds)
+        now = now.view(torch.bool)
+        out.update(outside_map=acc[0], outside_map_this_step=now[0], dest_reached=acc[1], dest_reached_this_step=now[1],
+                   goal_reached=acc[2], goal_reached_this_step=now[2])
+        return out
