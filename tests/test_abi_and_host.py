@@ -354,3 +354,47 @@ def test_rule_navi_check_validates_arguments_without_a_gpu(hip):
     assert lib.tbx_rule_navi_check(one, one, one, 2, None, None, None, None, None, None, None, 3, 4, 0, one, one, None) == -1  # n % div
     assert lib.tbx_rule_navi_check(one, one, one, 1, one, None, None, None, None, None, None, 1, 4, 20, one, one, None) == -1  # partial dest tables
     assert lib.tbx_rule_navi_check(one, one, one, 1, None, None, None, None, None, one, None, 1, 4, 0, one, one, None) == -1   # goal without its threshold
+
+
+def test_host_descriptor_paths_read_their_host_arrays_in_bounds(hip):
+    """The entry points that take HOST arrays / structures (job lists, stage programs, nested descriptors) walk them on the host before
+    any launch: driven here with well-formed host data and placeholder device addresses on a machine WITHOUT a GPU, each returns an
+    error code (bad argument, or the launch error once validation has passed) - never a crash. Under tools/sanitize_host.sh
+    (AddressSanitizer + UBSan on the host halves) these are the reads that get checked."""
+    if torch.cuda.is_available():
+        pytest.skip("placeholder device addresses: the no-GPU form of this test (a launch would dereference them)")
+    lib = hip.load()
+    dp = lambda i: 0x10000 * (i + 1)  # 16-byte aligned, distinct, never dereferenced on the host
+    jobs = (hip.KnnJob * 3)()
+    for j, (n_src, n_tgt, k) in enumerate(((64, 64, 25), (64, 1024, 64), (64, 128, 24))):
+        jb = jobs[j]
+        jb.src_pose, jb.src_invalid, jb.tgt_pose, jb.tgt_invalid = dp(8 * j), dp(8 * j + 1), dp(8 * j + 2), dp(8 * j + 3)
+        jb.idx, jb.invalid, jb.rel_pose, jb.emb = dp(8 * j + 4), dp(8 * j + 5), dp(8 * j + 6), None
+        jb.n_batch, jb.n_src, jb.n_tgt, jb.tgt_batch_div, jb.k, jb.dist_limit = 1, n_src, n_tgt, 1, k, 1500.0
+    for n in (1, 2, 3):
+        assert lib.tbx_knn_embed_multi(jobs, n, dp(40), dp(41), 128, None) < 0
+    assert lib.tbx_knn_embed_multi(jobs, 0, dp(40), dp(41), 128, None) == -1
+    jobs[1].k = 4096  # more neighbours than targets
+    assert lib.tbx_knn_embed_multi(jobs, 3, dp(40), dp(41), 128, None) < 0
+    pe = hip.PoseEmbedJob()
+    pe.pose3, pe.freqs_xy, pe.freqs_yaw, pe.out, pe.n, pe.pe_dim, pe.ld_out, pe.col_off = dp(50), dp(51), dp(52), dp(53), 64, 128, 128, 0
+    jobs[1].k = 64
+    assert lib.tbx_knn_embed_multi_pe(jobs, 3, dp(40), dp(41), 128, C.byref(pe), None) < 0
+    # a full stage program (MAX_STAGES entries) and one past it
+    st = (hip.Stage * (hip.MAX_STAGES + 1))()
+    for s in st:
+        s.op, s.src, s.dst, s.k, s.n, s.ld, s.p0 = hip.OP_LINEAR, 0, 1, 128, 128, 128, dp(60)
+    assert lib.tbx_rowchain(st, hip.MAX_STAGES, 16, 0, 16, 132, None) < 0
+    assert lib.tbx_rowchain(st, hip.MAX_STAGES + 1, 16, 0, 16, 132, None) < 0
+    # nested descriptors: zero-initialised (every pointer NULL) and partially filled
+    for cls, fn in ((hip.DecLayer, lib.tbx_knarpe_dec_layer), (hip.LayerTile, lib.tbx_layer_tile), (hip.HeadsTile, lib.tbx_heads_tile),
+                    (hip.WindowTile, lib.tbx_window_tile), (hip.Front, lib.tbx_front)):
+        d = cls()
+        assert fn(C.byref(d), None) < 0, cls.__name__
+    fr = hip.Front()
+    fr.jobs, fr.n_jobs = C.cast(jobs, C.c_void_p), 3
+    assert lib.tbx_front(C.byref(fr), None) < 0
+    ss = hip.SimState()
+    assert lib.tbx_sim_step(C.byref(ss), None) == -1 and lib.tbx_sim_step_parts(C.byref(ss), 3, None) == -1
+    rc = hip.RuleCtx()
+    assert lib.tbx_rule_check(C.byref(rc), dp(1), dp(2), dp(3), dp(4), 1, 0, 1, dp(5), None) == -1
