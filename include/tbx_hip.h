@@ -528,6 +528,19 @@ int tbx_linear_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, int64
 int tbx_linear_wgrad_bf16(const float* dy, int ld_dy, const float* x, int ld_x, int64_t rows, int n, int k, float* dw, float* db,
                           float* scratch, int splits, void* stream);
 
+/* The folded GEMM weights of ONE AttentionRPE module and their backward (training; DESIGN.md 3: the exact algebra that takes
+ * linear_rpe's per-pair projection, attention_rpe.py:137-164, out of the pair loop; autograd of the slices / batched products /
+ * concatenations that built them - ~35 launches per module and training step - as one launch each):
+ *   w [384,128] / b [384] in_proj, wr [256,128] / br [256] linear_rpe (key half rows 0..127, value half 128..255), wo [128,128] / bo [128]
+ *   out_proj  ->  w_in [640,128] = [W_q ; B_k^T W_q], b_in [640], w_kv [256,128] = in_proj rows 128.., b_kv [256], bias_k [128] = br[:128],
+ *   w_out [128,640] = [W_o | W_o B_v^T], b_out [128] = W_o br[128:] + b_o    (B_k / B_v: per-head 32 x 128 blocks of wr's halves)
+ * Backward: g_* = the gradients that arrived for the seven outputs (any may be NULL = zero); d_* overwritten. fp32, fixed order. */
+int tbx_attn_fold_fwd(const float* w, const float* b, const float* wr, const float* br, const float* wo, const float* bo, float* w_in,
+                      float* b_in, float* w_kv, float* b_kv, float* bias_k, float* w_out, float* b_out, void* stream);
+int tbx_attn_fold_bwd(const float* w, const float* b, const float* wr, const float* br, const float* wo, const float* g_w_in,
+                      const float* g_b_in, const float* g_w_kv, const float* g_b_kv, const float* g_bias_k, const float* g_w_out,
+                      const float* g_b_out, float* d_w, float* d_b, float* d_wr, float* d_br, float* d_wo, float* d_bo, void* stream);
+
 /* Forward and backward of a LayerNorm over rows of 128 (training; autograd of F.layer_norm at modules/transformer_rpe.py:207-245 - norm1 / norm2 /
  * norm_src / norm_tgt - over the time-batched rows): x, dy, dx [rows, 128] contiguous, gamma [128], mean / rstd [rows] as the forward
  * (torch.native_layer_norm) produced them; dgamma / dbeta [128]. x and dy are read once, dx written once; `scratch` holds

@@ -1077,3 +1077,34 @@ def test_sixteen_scene_step_is_the_count_weighted_recombination_of_its_quarters(
           f"{meas['gnorm']:.3g}; gradients entry-wise: max |d| / max |g| of the module {meas['grad']:.3g}; counters {C}")
     tol = RECOMBINE_TOL[prec]
     assert meas["loss"] <= tol["loss"] and meas["gnorm"] <= tol["gnorm"] and meas["grad"] <= tol["grad"], meas
+
+
+def test_attention_fold_kernels_equal_the_torch_algebra(tb):
+    """tbx_attn_fold_fwd / _bwd (one launch each per AttentionRPE module) against the slice / bmm / cat algebra they replace
+    (train_ops.fold_attention_weights_torch) and its autograd: the seven folded tensors and the gradients of all six
+    parameters, with every output used and with outputs left unused (their gradient arrives as None)."""
+    dev = torch.device("cuda:0")
+    TO = import_module("trafficbots_amd.train_ops")
+    A = import_module("trafficbots_amd.models.modules.attention_rpe")
+    torch.manual_seed(0)
+    att = A.AttentionRPE(d_model=128, n_head=4, dropout_p=0.0, bias=True, d_rpe=128, apply_q_rpe=False).to(dev)
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    names = ("w_in", "b_in", "w_kv", "b_kv", "bias_k", "w_out", "b_out")
+    params = (att.in_proj_weight, att.in_proj_bias, att.linear_rpe.weight, att.linear_rpe.bias, att.out_proj_weight, att.out_proj_bias)
+    g = torch.Generator().manual_seed(1)
+    ref = TO.fold_attention_weights_torch(att)
+    cot = {k: torch.randn(ref[k].shape, generator=g).to(dev) for k in names}
+    for used in (names, ("w_in", "b_in"), ("w_kv", "b_out"), ("bias_k", "w_out")):
+        ref = TO.fold_attention_weights_torch(att)
+        got = dict(zip(names, TO.AttnFoldFn.apply(*params)))
+        for k in names:
+            torch.testing.assert_close(got[k], ref[k], rtol=1e-5, atol=1e-5)
+        g_ref = torch.autograd.grad(sum((ref[k] * cot[k]).sum() for k in used), params, allow_unused=True)
+        g_got = torch.autograd.grad(sum((got[k] * cot[k]).sum() for k in used), params, allow_unused=True)
+        for p_ref, p_got, p in zip(g_ref, g_got, params):
+            want = torch.zeros_like(p) if p_ref is None else p_ref
+            torch.testing.assert_close(p_got, want, rtol=1e-4, atol=1e-4)
+    # and inside a training step the Function is what runs (the fold's launches are the ones it replaced)
+    assert TO.ATTN_FOLD_KERNEL

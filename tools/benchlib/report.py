@@ -13,8 +13,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 MAX_LINE_BYTES = 8192
 
-ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_matches_build", "hbm_measured_frac",
-             "avg_launch_us", "launches_per_step", "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch",
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_measured", "traffic_matches_build",
+             "hbm_measured_frac", "avg_launch_us", "avg_launch_us_trace", "trace_source", "frac_at_trace_avg", "valu_issue_frac", "valu_issue_floor_us",
+             "bound_8d", "launches_per_step", "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch",
              "compulsory_bytes_per_launch", "flops_per_launch", "bytes_per_pair", "source_rows_per_launch")
 
 
@@ -35,7 +36,8 @@ def _r(x, sig=6):
     return x
 
 
-SUB_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "launches_per_step",
+SUB_ROOF_KEYS = ("kernel", "bound", "bound_8d", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_measured", "hbm_measured_frac",
+                 "valu_issue_frac", "valu_issue_floor_us", "avg_launch_us", "avg_launch_us_trace", "launches_per_step",
                  "share_of_step_kernel_time", "share_of_step", "algorithmic_bytes_per_launch", "flops_per_launch")
 
 

@@ -293,9 +293,9 @@ def measure(a, tb, hip, dev, rank, world, dist):
     cnt = events.attn_counters(a)
     att = next((k for k in kernels if k["class"] == "attn" and k["source_rows_per_launch"] >= 1024), None)
     if cnt and att is not None:
-        if cnt.get("l2_read_requests_per_launch"):  # 128-byte L1 -> L2 read requests of a launch over its live duration
-            cnt["l2_request_frac"] = cnt["l2_read_requests_per_launch"] * 128.0 / (att["avg_launch_us"] * 1e-6) / 1e9 / events.L2_PEAK_GBS
-        att["counters"] = cnt
+        events.attach_attn_counters(att, cnt)
+        if roof.get("class") == "attn" and roof.get("source_rows_per_launch") == att.get("source_rows_per_launch"):
+            roof = dict(att)  # (the judged object was copied before the counters were attached)
     res = {
         **timing,
         "config": workload,

@@ -3,12 +3,12 @@
 // N, K <= a few hundred. The library GEMM for this shape (one or two output tiles, reduction depth R) ran at 2.5-6.7 ms per call;
 // the shape is HBM-bound (both operands are read once: 2 GB at R = 2 M, N = K = 128) with the exact-fp32 MFMA as second bound.
 //
-// A wavefront owns a 64 x 64 block of dW over a range of rows. Per 4 rows every lane loads ONE float4 of dY and ONE of X
+// A wavefront accumulates a 64 x 64 block of dW over a range of rows. Per 4 rows every lane loads ONE float4 of dY and ONE of X
 // (lane l: row l >> 4, columns 4 (l & 15) .. +3 of the block: 256 B contiguous per row) and issues 16 v_mfma_f32_16x16x4_f32:
 // MFMA (t, u) takes component t of the dY float4 as A[i = l & 15][kk = l >> 4] and component u of the X float4 as B, i.e. it
 // accumulates the strided 16 x 16 tile dW[n0 + 4 i + t][k0 + 4 j + u] - 16 independent accumulators (64 VGPRs), 2 loads per
-// 16 MFMAs, no LDS. Row ranges (splits) go to blockIdx.y; partial blocks land in a scratch buffer and a second kernel sums
-// them (deterministic: no float atomics). The 4 waves of a workgroup take a 2 x 2 group of blocks and share the rows (L1 / L2).
+// 16 MFMAs, no LDS in the loop. A workgroup = one block over one row range (its 4 waves a quarter of the rows each, summed through
+// LDS at the end); partial blocks land in a scratch buffer and a second kernel sums them (deterministic: no float atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -26,21 +26,53 @@ struct WgradArgs {
   const float* x;
   float* part;  // [splits][n*k + n]
   int64_t rows, rows_per_split;
-  int ld_dy, ld_x, n, k, groups_k, with_db;
+  int ld_dy, ld_x, n, k, tiles_k, tiles, with_db;
 };
 
 constexpr int P = 4;  // 4-row groups loaded ahead per pipeline stage (16 rows)
+constexpr int N_XCD = 8;
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
+  const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(s16x4, v);
+}
+
+// Round 6: ONE 64 x 64 block of dW per WORKGROUP - its 4 waves take a quarter of the workgroup's rows each and are summed through LDS -
+// instead of a 2 x 2 group of blocks (one per wave) over the same rows:
+//   * partial sums: a workgroup hands 16 KiB to the scratch buffer instead of 64 - at 768 workgroups 12.6 MB instead of 50 MB written
+//     and read back (a [92,160 x 128]^T [92,160 x 128] call reads 94 MB of operands: the partials were half its traffic);
+//   * operand re-reads: the tiles of ONE row range - (n / 64) (k / 64) workgroups, 20 for a 640 x 128 gradient - read the same dY / X
+//     rows. The workgroup index is re-mapped so that they sit on ONE XCD, dispatched back to back (hardware deals consecutive
+//     workgroup ids round-robin over the 8 XCDs, each with its own L2): the re-reads are L2 hits instead of HBM reads on 5 different
+//     XCDs (measured before: 2.4-3.3 TB/s of algorithmic bytes on the 640-wide shapes = ~1.7 x that in HBM traffic).
+// BF16 = tbx_linear_wgrad_bf16: ONE bf16 product per term - dY and X rounded to bfloat16 in registers (v_cvt_pk_bf16_f32), fp32
+// accumulation over the rows - what torch's autocast(bfloat16) gives a weight gradient (the reference trains at precision 16,
+// configs/trainer/default.yaml:16). The contraction index of an MFMA is the ROW, and a lane already holds what the instruction wants
+// from it: lane (rr = l >> 4, cq = l & 15) has loaded, for the 4 row groups q = 0..3 of a 16-row stage, rows 4 q + rr of its 4 columns -
+// component t of its 4 dY float4s IS the A operand A[i = cq][kk = 4 rr + q] of v_mfma_f32_16x16x16_bf16 for the strided tile
+// n = n0 + 4 i + t (the order of the 16 rows inside the contraction is free, and the same for both operands), component u of its 4 X
+// float4s the B operand: 16 MFMAs + 16 packed conversions per 16 rows instead of 64 exact-fp32 MFMAs.
+// (A split-bf16 form - three products with the ROW as the reduction index - was built in round 3 and measured slower than the
+// exact-fp32 kernel: git history, profiles/MEASUREMENT_LOG.md.)
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[3][68][64];  // waves 1..3: 64 accumulator registers + 4 of the bias sum, per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int gk = blockIdx.x % a.groups_k, gn = blockIdx.x / a.groups_k;
-  const int n0 = (gn * 2 + (wave & 1)) * 64, k0 = (gk * 2 + (wave >> 1)) * 64;
-  if (n0 >= a.n || k0 >= a.k) return;  // no barriers below: a wave may leave
-  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_split;
-  const int64_t r1 = r0 + a.rows_per_split < a.rows ? r0 + a.rows_per_split : a.rows;
+  // workgroup id -> (row range, tile): ids congruent mod 8 share an XCD; virtual index v runs through one XCD's ids first
+  const unsigned G = gridDim.x, L = blockIdx.x;
+  const unsigned xcd = L % N_XCD, slot = L / N_XCD, per = G / N_XCD, rem = G % N_XCD;
+  const unsigned v = slot + xcd * per + (xcd < rem ? xcd : rem);
+  const int split = (int)(v / (unsigned)a.tiles), tile = (int)(v % (unsigned)a.tiles);
+  const int n0 = (tile / a.tiles_k) * 64, k0 = (tile % a.tiles_k) * 64;
+  const int64_t rq = a.rows_per_split >> 2;  // rows per wave (a multiple of 16)
+  const int64_t r0 = (int64_t)split * a.rows_per_split + wave * rq;
+  const int64_t r1 = r0 + rq < a.rows ? r0 + rq : a.rows;
   const int rr = lane >> 4, c = (lane & 15) * 4;
   const bool n_ok = n0 + c < a.n, k_ok = k0 + c < a.k;  // n, k are multiples of 4: a float4 is wholly inside or outside
   const float* py = a.dy + n0 + c;
@@ -66,19 +98,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a
   load(ya, xa, r0);
   for (int64_t r = r0; r < r1; r += 4 * P) {
     load(yb, xb, r + 4 * P);
+    if constexpr (BF16) {
+      if (want_db) bsum += (ya[0] + ya[1]) + (ya[2] + ya[3]);  // (the bias gradient stays an exact fp32 sum)
+      s16x4 ay[4], bx[4];
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
-      if (want_db) bsum += ya[q];
+      for (int t = 0; t < 4; ++t) {
+        ay[t] = pack4(ya[0][t], ya[1][t], ya[2][t], ya[3][t]);
+        bx[t] = pack4(xa[0][t], xa[1][t], xa[2][t], xa[3][t]);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[q][t], xa[q][u], acc[t][u], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ay[t], bx[u], acc[t][u], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        if (want_db) bsum += ya[q];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[q][t], xa[q][u], acc[t][u], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < P; ++q) ya[q] = yb[q], xa[q] = xb[q];
+  }
+  // ---- the four waves' blocks summed in a fixed order (wave 0 + 1 + 2 + 3: deterministic); register i of lane l at red[w][i][l]
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wave - 1][(t * 4 + u) * 4 + reg][lane] = acc[t][u][reg];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave - 1][64 + e][lane] = bsum[e];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll 1
+  for (int w = 0; w < 3; ++w) {  // (not unrolled: the three blocks' 204 LDS reads per lane would all be hoisted into registers)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[t][u][reg] += red[w][(t * 4 + u) * 4 + reg][lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[e] += red[w][64 + e][lane];
   }
   // acc[t][u][reg] at lane l = dW[n0 + 4 ((l >> 4) * 4 + reg) + t][k0 + 4 (l & 15) + u]
-  float* part = a.part + (int64_t)blockIdx.y * ((int64_t)a.n * a.k + a.n);
+  float* part = a.part + (int64_t)split * ((int64_t)a.n * a.k + a.n);
   if (k_ok) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -86,111 +156,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_kernel(const WgradArgs a
       for (int reg = 0; reg < 4; ++reg) {
         const int n = n0 + 4 * (rr * 4 + reg) + t;
         if (n < a.n) {
-          f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
-          *(TBX_GLOBAL f32x4*)(part + (int64_t)n * a.k + k0 + c) = v;
+          f32x4 vv = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+          *(TBX_GLOBAL f32x4*)(part + (int64_t)n * a.k + k0 + c) = vv;
         }
       }
   }
   if (want_db) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v = bsum[e];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      bsum[e] = v;
-    }
-    if (rr == 0 && n_ok) *(TBX_GLOBAL f32x4*)(part + (int64_t)a.n * a.k + n0 + c) = bsum;
-  }
-}
-
-// (A split-bf16 form - dY and X as bf16 hi + lo, three products on v_mfma_f32_16x16x32_bf16 with the ROW as the reduction index - was
-// built in round 3 and measured slower than the exact-fp32 kernel above: every lane converts 8 rows of its columns per MFMA group and
-// the VALU splits cost what the MFMAs save. git history (wgrad_partial_bf16_kernel), profiles/MEASUREMENT_LOG.md.)
-
-// tbx_linear_wgrad_bf16 (round 5): the same blocks, loads and partial / reduce structure with ONE bf16 product per term - dY and X
-// rounded to bfloat16 in registers (v_cvt_pk_bf16_f32), fp32 accumulation over the rows - what torch's autocast(bfloat16) gives a
-// weight gradient (the reference trains at precision 16, configs/trainer/default.yaml:16). The contraction index of an MFMA is the
-// ROW, and a lane already holds what the instruction wants from it: lane (rr = l >> 4, cq = l & 15) has loaded, for the 4 row groups
-// q = 0..3 of a 16-row stage, rows 4 q + rr of its 4 columns - so component t of its 4 dY float4s IS the A operand A[i = cq][kk =
-// 4 rr + q] of v_mfma_f32_16x16x16_bf16 for the strided tile n = n0 + 4 i + t (the order of the 16 rows inside the contraction is
-// free, and the same for both operands), and component u of its 4 X float4s the B operand. 16 MFMAs + 16 packed conversions per 16
-// rows instead of 64 exact-fp32 MFMAs (8 x fewer matrix-core cycles): the kernel is left with its bytes (dY and X read once).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
-  const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-  return __builtin_bit_cast(s16x4, v);
-}
-
-__global__ __launch_bounds__(256, 2) void wgrad_partial_bf16_kernel(const WgradArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int gk = blockIdx.x % a.groups_k, gn = blockIdx.x / a.groups_k;
-  const int n0 = (gn * 2 + (wave & 1)) * 64, k0 = (gk * 2 + (wave >> 1)) * 64;
-  if (n0 >= a.n || k0 >= a.k) return;  // no barriers below: a wave may leave
-  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_split;
-  const int64_t r1 = r0 + a.rows_per_split < a.rows ? r0 + a.rows_per_split : a.rows;
-  const int rr = lane >> 4, c = (lane & 15) * 4;
-  const bool n_ok = n0 + c < a.n, k_ok = k0 + c < a.k;
-  const float* py = a.dy + n0 + c;
-  const float* px = a.x + k0 + c;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[t][u] = zero;
-  f32x4 bsum = zero;
-  const bool want_db = a.with_db && k0 == 0;
-  f32x4 ya[P], xa[P], yb[P], xb[P];
-  auto load = [&](f32x4(&y)[P], f32x4(&x)[P], int64_t r) {
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-      const int64_t row = r + q * 4 + rr;
-      const bool live = row < r1;
-      y[q] = (live && n_ok) ? ldg4(py + row * a.ld_dy) : zero;
-      x[q] = (live && k_ok) ? ldg4(px + row * a.ld_x) : zero;
-    }
-  };
-  load(ya, xa, r0);
-  for (int64_t r = r0; r < r1; r += 4 * P) {
-    load(yb, xb, r + 4 * P);
-    if (want_db) bsum += (ya[0] + ya[1]) + (ya[2] + ya[3]);  // (the bias gradient stays an exact fp32 sum)
-    s16x4 ay[4], bx[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ay[t] = pack4(ya[0][t], ya[1][t], ya[2][t], ya[3][t]);
-      bx[t] = pack4(xa[0][t], xa[1][t], xa[2][t], xa[3][t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ay[t], bx[u], acc[t][u], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < P; ++q) ya[q] = yb[q], xa[q] = xb[q];
-  }
-  // acc[t][u][reg] at lane l = dW[n0 + 4 ((l >> 4) * 4 + reg) + t][k0 + 4 (l & 15) + u]  (as the fp32 kernel)
-  float* part = a.part + (int64_t)blockIdx.y * ((int64_t)a.n * a.k + a.n);
-  if (k_ok) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int n = n0 + 4 * (rr * 4 + reg) + t;
-        if (n < a.n) {
-          f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
-          *(TBX_GLOBAL f32x4*)(part + (int64_t)n * a.k + k0 + c) = v;
-        }
-      }
-  }
-  if (want_db) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = bsum[e];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      bsum[e] = v;
+      float vv = bsum[e];
+      vv += __shfl_xor(vv, 16);
+      vv += __shfl_xor(vv, 32);
+      bsum[e] = vv;
     }
     if (rr == 0 && n_ok) *(TBX_GLOBAL f32x4*)(part + (int64_t)a.n * a.k + n0 + c) = bsum;
   }
@@ -230,15 +207,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 extern "C" int tbx_linear_wgrad_splits(int64_t rows, int n, int k) {
   if (rows <= 0 || n <= 0 || k <= 0) return TBX_ERR_ARG;
-  const int groups = ((n + 127) / 128) * ((k + 127) / 128);
+  const int tiles = ((n + 63) / 64) * ((k + 63) / 64);
   static const int target = [] {
     const char* e = getenv("TBX_WGRAD_WGS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 768;
   }();
-  int64_t s = target / groups;  // 768 workgroups = 3 per CU = the 3 wavefronts per SIMD the kernel's 154 VGPRs allow: one full wave of workgroups, no tail
+  int64_t s = target / tiles;  // 768 workgroups = 3 per CU = the 3 wavefronts per SIMD the kernel's registers allow: one full wave of workgroups, no tail
   if (s < 1) s = 1;
-  const int64_t cap = (rows + 63) / 64;  // at least 64 rows per split
+  const int64_t cap = (rows + 63) / 64;  // at least 64 rows per split (16 per wave)
   if (s > cap) s = cap;
   return (int)s;
 }
@@ -250,14 +227,16 @@ static int wgrad_launch(bool bf16, const float* dy, int ld_dy, const float* x, i
   if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)scratch)) & 15) return TBX_ERR_ALIGN;
   WgradArgs a;
   a.dy = dy, a.x = x, a.part = scratch, a.rows = rows, a.ld_dy = ld_dy, a.ld_x = ld_x, a.n = n, a.k = k;
-  const int rstep = 4 * P;
+  const int rstep = 4 * 4 * P;  // 4 waves x 16 rows
   a.rows_per_split = (((rows + splits - 1) / splits + rstep - 1) / rstep) * rstep;
-  a.groups_k = (k + 127) / 128;
+  a.tiles_k = (k + 63) / 64;
+  a.tiles = ((n + 63) / 64) * a.tiles_k;
   a.with_db = db != nullptr;
-  const int groups = ((n + 127) / 128) * a.groups_k;
+  const int64_t grid = (int64_t)a.tiles * splits;
+  if (grid > 0x7fffffff) return TBX_ERR_UNSUPPORTED;
   hipStream_t hs = (hipStream_t)stream;
-  if (bf16) hipLaunchKernelGGL(wgrad_partial_bf16_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
-  else hipLaunchKernelGGL(wgrad_partial_kernel, dim3(groups, splits), dim3(256), 0, hs, a);
+  if (bf16) hipLaunchKernelGGL(wgrad_partial_kernel<true>, dim3((unsigned)grid), dim3(256), 0, hs, a);
+  else hipLaunchKernelGGL(wgrad_partial_kernel<false>, dim3((unsigned)grid), dim3(256), 0, hs, a);
   if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
   const int64_t total = (int64_t)n * k + n;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, hs, scratch, splits, total, n * k, dw, db);

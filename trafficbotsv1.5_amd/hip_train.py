@@ -80,6 +80,27 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = True, bf16: 
     return dw, db
 
 
+def attn_fold_fwd(w, b, wr, br, wo, bo):
+    """tbx_attn_fold_fwd: (w_in [640,128], b_in [640], w_kv [256,128], b_kv [256], bias_k [128], w_out [128,640], b_out [128]) of one
+    AttentionRPE module from in_proj (w [384,128], b [384]), linear_rpe (wr [256,128], br [256]) and out_proj (wo [128,128], bo [128])."""
+    for t, shp in ((w, (384, 128)), (b, (384,)), (wr, (256, 128)), (br, (256,)), (wo, (128, 128)), (bo, (128,))):
+        assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == shp and t.is_contiguous(), shp
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=w.device)
+    out = (e(640, 128), e(640), e(256, 128), e(256), e(128), e(128, 640), e(128))
+    _check(load().tbx_attn_fold_fwd(_ptr(w), _ptr(b), _ptr(wr), _ptr(br), _ptr(wo), _ptr(bo), *[_ptr(t) for t in out], stream_ptr()), "tbx_attn_fold_fwd")
+    return out
+
+
+def attn_fold_bwd(w, b, wr, br, wo, grads):
+    """tbx_attn_fold_bwd: grads = the seven output gradients (None = zero) -> (d_w, d_b, d_wr, d_br, d_wo, d_bo)."""
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=w.device)
+    out = (e(384, 128), e(384), e(256, 128), e(256), e(128, 128), e(128))
+    g = [None if t is None else t.contiguous() for t in grads]
+    _check(load().tbx_attn_fold_bwd(_ptr(w), _ptr(b), _ptr(wr), _ptr(br), _ptr(wo), *[_cptr(t, torch.float32) for t in g], *[_ptr(t) for t in out],
+                                    stream_ptr()), "tbx_attn_fold_bwd")
+    return out
+
+
 NO_DROP = (0.0, None, 0, 1, 1, 0)  # (p, seed, site, rows_per_scene, time_batch, time0) of the glue ops without dropout
 
 

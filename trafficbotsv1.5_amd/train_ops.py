@@ -17,6 +17,7 @@ from .train_state import (ATTN_MFMA_MIN_ROWS, HEADS_TILE, LN_BWD, LN_FWD, TALL_L
                           module_scope, precision)
 
 D, NH, DH = 128, 4, 32
+ATTN_FOLD_KERNEL = os.environ.get("TBX_ATTN_FOLD_KERNEL", "1") != "0"  # (0: the torch algebra, for A/B runs)
 
 
 class TallLinearFn(torch.autograd.Function):
@@ -264,6 +265,38 @@ def relu_drop(z: Tensor, p: float, training: bool) -> Tensor:
     return _drop(F.relu(z), p, training)
 
 
+class AttnFoldFn(torch.autograd.Function):
+    """The folded weights of one AttentionRPE module as ONE launch forward and ONE backward (tbx_attn_fold_fwd / _bwd) instead of the
+    ~10 + ~25 slice / bmm / cat kernels torch ran per module: x 40 attention modules x 2 passes (no-grad stepping pass, differentiated
+    pass) these were ~2,000 of a training step's ~7,000 launches, every one on 64 K floats at most."""
+
+    @staticmethod
+    def forward(ctx, w, b, wr, br, wo, bo):
+        ctx.save_for_backward(w, b, wr, br, wo)
+        return hip.attn_fold_fwd(w.contiguous(), b.contiguous(), wr.contiguous(), br.contiguous(), wo.contiguous(), bo.contiguous())
+
+    @staticmethod
+    def backward(ctx, *grads):
+        w, b, wr, br, wo = ctx.saved_tensors
+        return hip.attn_fold_bwd(w.contiguous(), b.contiguous(), wr.contiguous(), br.contiguous(), wo.contiguous(), grads)
+
+
+def fold_attention_weights_torch(attn):
+    """`fold_attention_weights` as torch algebra: what AttnFoldFn is tested against (tests/test_hip_training.py), and the form taken by
+    modules that are not on the device."""
+    W, b = attn.in_proj_weight, attn.in_proj_bias
+    wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
+    # the block-diagonal products head by head as batched GEMMs (B_k / B_v are never materialised)
+    wq, wo = W[:D], attn.out_proj_weight
+    wk_h = wr[:D].view(NH, DH, D)                                                       # B_k's blocks  [h][32, 128]
+    wv_h = wr[D:].view(NH, DH, D)                                                       # B_v^T's blocks
+    bk_wq = torch.bmm(wk_h.transpose(1, 2), wq.view(NH, DH, D)).reshape(NH * D, D)      # B_k^T W_q   [512, 128]
+    bk_bq = torch.bmm(wk_h.transpose(1, 2), b[:D].view(NH, DH, 1)).reshape(NH * D)      # B_k^T b_q   [512]
+    wo_bv = torch.bmm(wo.view(D, NH, DH).transpose(0, 1), wv_h).transpose(0, 1).reshape(D, NH * D)  # W_o B_v^T  [128, 512]
+    return dict(w_in=torch.cat([wq, bk_wq], 0), b_in=torch.cat([b[:D], bk_bq], 0), w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
+                w_out=torch.cat([wo, wo_bv], 1), b_out=wo @ br[D:] + attn.out_proj_bias)
+
+
 def fold_attention_weights(attn):
     """The exact algebra of DESIGN.md §3 as GEMM weights:
       [q | qt] = x W_in^T + b_in        with  W_in  = [I | B_k]^T W_q           (640 x 128),  b_in  = [I | B_k]^T b_q
@@ -272,18 +305,12 @@ def fold_attention_weights(attn):
     ck = (id(attn), torch.is_grad_enabled())  # a no-grad pass must not hand its graph-less tensors to a differentiated one
     if ST._FOLD_CACHE is not None and ck in ST._FOLD_CACHE:
         return ST._FOLD_CACHE[ck]
-    W, b = attn.in_proj_weight, attn.in_proj_bias
-    wr, br = attn.linear_rpe.weight, attn.linear_rpe.bias
-    # the block-diagonal products head by head as batched GEMMs (B_k / B_v are never materialised: building them with
-    # torch.block_diag cost 8 slice copies per module forward and ~24 tiny kernels backward, x 40 attention modules per step)
-    wq, wo = W[:D], attn.out_proj_weight
-    wk_h = wr[:D].view(NH, DH, D)                                                       # B_k's blocks  [h][32, 128]
-    wv_h = wr[D:].view(NH, DH, D)                                                       # B_v^T's blocks
-    bk_wq = torch.bmm(wk_h.transpose(1, 2), wq.view(NH, DH, D)).reshape(NH * D, D)      # B_k^T W_q   [512, 128]
-    bk_bq = torch.bmm(wk_h.transpose(1, 2), b[:D].view(NH, DH, 1)).reshape(NH * D)      # B_k^T b_q   [512]
-    wo_bv = torch.bmm(wo.view(D, NH, DH).transpose(0, 1), wv_h).transpose(0, 1).reshape(D, NH * D)  # W_o B_v^T  [128, 512]
-    f = dict(w_in=torch.cat([wq, bk_wq], 0), b_in=torch.cat([b[:D], bk_bq], 0), w_kv=W[D:], b_kv=b[D:], bias_k=br[:D],
-             w_out=torch.cat([wo, wo_bv], 1), b_out=wo @ br[D:] + attn.out_proj_bias)
+    W = attn.in_proj_weight
+    if W.is_cuda and tuple(W.shape) == (3 * D, D) and tuple(attn.linear_rpe.weight.shape) == (2 * D, D) and ATTN_FOLD_KERNEL:
+        o = AttnFoldFn.apply(W, attn.in_proj_bias, attn.linear_rpe.weight, attn.linear_rpe.bias, attn.out_proj_weight, attn.out_proj_bias)
+        f = dict(zip(("w_in", "b_in", "w_kv", "b_kv", "bias_k", "w_out", "b_out"), o))
+    else:
+        f = fold_attention_weights_torch(attn)
     if ST._FOLD_CACHE is not None:
         ST._FOLD_CACHE[ck] = f
     return f
