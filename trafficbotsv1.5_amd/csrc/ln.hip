@@ -36,8 +36,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
     for (int u = 0; u < LN_UNROLL; ++u) {
       const int64_t rr = r + u * tw;
       const int64_t rc = rr < a.rows ? rr : r;  // (clamped: the loads of a row past the end are discarded below)
-      xv[u] = *(const float2*)(a.x + rc * LN_D + 2 * lane);
-      dv[u] = *(const float2*)(a.dy + rc * LN_D + 2 * lane);
+      xv[u] = __builtin_nontemporal_load((const float2*)(a.x + rc * LN_D + 2 * lane));  // (read once: profiles/r06_stream_probe.txt)
+      dv[u] = __builtin_nontemporal_load((const float2*)(a.dy + rc * LN_D + 2 * lane));
       mu[u] = a.mean[rc];
       rs[u] = a.rstd[rc];
     }
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const LnFwdArgs a
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {
       const int64_t rr = r + u * tw;
-      xv[u] = *(const float2*)(a.x + (rr < a.rows ? rr : r) * LN_D + 2 * lane);
+      xv[u] = __builtin_nontemporal_load((const float2*)(a.x + (rr < a.rows ? rr : r) * LN_D + 2 * lane));
     }
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {
@@ -113,20 +113,29 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const LnFwdArgs a
   }
 }
 
+// dgamma / dbeta = the column sums of the workgroups' partials [n, 256]. 16 workgroups of 16 columns (one workgroup read the 512 KiB of
+// partials through ONE CU's port, a chain of 128 dependent-latency loads per thread: 19 us per call x 90 LayerNorms per training
+// step): thread = (slice s of 64, column c of 16) sums partials s, s + 64, .. in order, then the 64 slices are summed in a fixed
+// tree - deterministic, 64-byte segments per 16 lanes.
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
-  __shared__ float red[4][2 * LN_D];
-  const int c = threadIdx.x & (2 * LN_D - 1), s = threadIdx.x >> 8;
+  __shared__ float red[64][17];
+  const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
   float acc = 0.f;
-  for (int j = s; j < n; j += 4) acc += part[(int64_t)j * (2 * LN_D) + c];
+  for (int j = s; j < n; j += 64) acc += part[(int64_t)j * (2 * LN_D) + col];
   red[s][c] = acc;
   __syncthreads();
+  for (int h = 32; h >= 1; h >>= 1) {
+    if (s < h) red[s][c] += red[s + h][c];
+    __syncthreads();
+  }
   if (s == 0) {
-    const float v = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-    if (c < LN_D)
-      dgamma[c] = v;
+    const float v = red[0][c];
+    if (col < LN_D)
+      dgamma[col] = v;
     else
-      dbeta[c - LN_D] = v;
+      dbeta[col - LN_D] = v;
   }
 }
 
@@ -158,6 +167,6 @@ extern "C" int tbx_layernorm_bwd(const float* x, const float* dy, const float* g
   const int n = ln_workgroups(rows);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(n), dim3(LN_WAVES * 64), 0, s, a);
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)scratch, n, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * LN_D / 16), dim3(1024), 0, s, (const float*)scratch, n, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

@@ -32,7 +32,18 @@ struct WgradArgs {
 constexpr int P = 4;  // 4-row groups loaded ahead per pipeline stage (16 rows)
 constexpr int N_XCD = 8;
 
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
+// (TBX_STREAM_NT: the operands are read once per workgroup - non-temporal loads; profiles/r06_stream_probe.txt: a read-only pass over
+// 1 GB runs at 0.80 of the HBM peak with the default policy and 0.90 with nt)
+#ifndef TBX_STREAM_NT
+#define TBX_STREAM_NT 1
+#endif
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+#if TBX_STREAM_NT
+  return __builtin_nontemporal_load((const TBX_GLOBAL f32x4*)p);
+#else
+  return *(const TBX_GLOBAL f32x4*)p;
+#endif
+}
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
