@@ -16,12 +16,6 @@ constexpr int LN_WAVES = 16;     // wavefronts per workgroup
 constexpr int LN_MAX_WG = 512;   // 2 workgroups per CU: 8 wavefronts per SIMD
 constexpr int LN_UNROLL = 4;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 ldnt2(const float* p) {  // non-temporal 8-byte load
-  const f32x2 v = __builtin_nontemporal_load((const f32x2*)p);
-  return make_float2(v.x, v.y);
-}
-
 struct LnBwdArgs {
   const float *x, *dy, *gamma, *mean, *rstd;
   float *dx, *part;
@@ -42,8 +36,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
     for (int u = 0; u < LN_UNROLL; ++u) {
       const int64_t rr = r + u * tw;
       const int64_t rc = rr < a.rows ? rr : r;  // (clamped: the loads of a row past the end are discarded below)
-      xv[u] = ldnt2(a.x + rc * LN_D + 2 * lane);  // (read once: profiles/r06_stream_probe.txt)
-      dv[u] = ldnt2(a.dy + rc * LN_D + 2 * lane);
+      xv[u] = *(const float2*)(a.x + rc * LN_D + 2 * lane);
+      dv[u] = *(const float2*)(a.dy + rc * LN_D + 2 * lane);
       mu[u] = a.mean[rc];
       rs[u] = a.rstd[rc];
     }
@@ -97,7 +91,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const LnFwdArgs a
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {
       const int64_t rr = r + u * tw;
-      xv[u] = ldnt2(a.x + (rr < a.rows ? rr : r) * LN_D + 2 * lane);
+      xv[u] = *(const float2*)(a.x + (rr < a.rows ? rr : r) * LN_D + 2 * lane);
     }
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       xin[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q * 16 + lr < rows_req) xin[q] = __builtin_nontemporal_load((const TBX_GLOBAL f32x4*)(xp + q * x16 + kc * 128));  // (rows are read once: profiles/r06_stream_probe.txt)
+      if (q * 16 + lr < rows_req) xin[q] = *(const TBX_GLOBAL f32x4*)(xp + q * x16 + kc * 128);  // (default cache policy: nt measured slower, see wgrad.hip)
     }
   };
   auto park_x = [&](char* P) {

@@ -32,18 +32,11 @@ struct WgradArgs {
 constexpr int P = 4;  // 4-row groups loaded ahead per pipeline stage (16 rows)
 constexpr int N_XCD = 8;
 
-// (TBX_STREAM_NT: the operands are read once per workgroup - non-temporal loads; profiles/r06_stream_probe.txt: a read-only pass over
-// 1 GB runs at 0.80 of the HBM peak with the default policy and 0.90 with nt)
-#ifndef TBX_STREAM_NT
-#define TBX_STREAM_NT 1
-#endif
-__device__ __forceinline__ f32x4 ldg4(const float* p) {
-#if TBX_STREAM_NT
-  return __builtin_nontemporal_load((const TBX_GLOBAL f32x4*)p);
-#else
-  return *(const TBX_GLOBAL f32x4*)p;
-#endif
-}
+// (Non-temporal operand loads were measured and dropped in round 6: a read-only pass over 1 GB streams at 0.90 of the HBM peak with nt
+// against 0.80 without (profiles/r06_stream_probe.txt), but inside the training step these operands were just WRITTEN by their
+// producers - they come out of the 256 MiB Infinity Cache / the XCD's L2, which the tiles of one row range share - and nt gives that
+// up: tbx_linear_wgrad_bf16 13.7 -> 16.4 ms per step, tbx_tall_linear_bf16 17.5 -> 18.2, ln_fwd 1.8 -> 2.1, the step 145.8 -> 148.2 ms.)
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const TBX_GLOBAL f32x4*)p; }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
