@@ -428,7 +428,9 @@ int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, int k, int 
  *   dqbuf  [n_batch*n_src, ldq]  : dq written at q_off, dqt at qt_off (other columns untouched)
  *   dkv[i] : gradient of seg[i].kv, same shape / leading dimension; dK, dV are ACCUMULATED with atomicAdd (zero it first)
  *   dbias_k [n_batch*n_src, 128]: per-row gradient of rpe_k_bias, overwritten (the parameter's gradient is the sum over
- *   rows: one shared 128-float accumulator serialises ~10^3-deep at the L2 atomic units).
+ *   rows: one shared 128-float accumulator serialises ~10^3-deep at the L2 atomic units). May be NULL (every backward entry point):
+ *   the gradient is identically zero in exact arithmetic - q_h . bk_h shifts all scores of a row, which its softmax ignores - and what
+ *   the accumulation returns is round-off; the training step passes NULL and hands the parameter a zero gradient.
  * Probabilities are recomputed from the forward inputs; the pose embeddings carry no gradient (utils/rpe.py:7). */
 int tbx_knarpe_attn_bwd(const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
                         const tbx_attn_seg_t* segs /* host */, int n_seg, const float* dout, int ldo, float* dqbuf,

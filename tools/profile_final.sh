@@ -6,7 +6,7 @@ set -x
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 mkdir -p gpurun_out
-tag=${TAG:-r05}
+tag=${TAG:-r06}
 if [ -z "${SKIP_TESTS:-}" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${tag}_gpu_tests.log; fi
 bash tools/profile_round.sh ${tag}_c2 64 1024 128 1 1
 bash tools/profile_round.sh ${tag}_c5 128 1024 128 1 32 --steps 40
@@ -40,6 +40,15 @@ fi
 # (opt-in: in round 5 the counter service aborted inside an eager training step with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and rocprofv3
 #  then sat until the job's limit - profiles/MEASUREMENT_LOG.md)
 if [ -n "${TRAIN_PMC:-}" ]; then TAG=${tag} timeout 600 bash tools/pmc_train.sh > $out/${tag}_train_pmc_top.txt 2>&1; fi
+# round 6: counters for the training step's streaming kernels alone (--kernel-include-regex; each pass under its own timeout), then the
+# attention kernels in a pass of their own
+TAG=${tag} timeout 1000 bash tools/pmc_train_filtered.sh > $out/${tag}_train_pmc_streaming_top.txt 2>&1
+TAG=${tag} NAME=attention REGEX='knarpe_attn_bwd_kernel|knarpe_attn_dkv_kernel|knarpe_attn_mfma_kernel|knarpe_attn_ring_kernel' timeout 1000 bash tools/pmc_train_filtered.sh > $out/${tag}_train_pmc_attention_top.txt 2>&1
+# launches of ONE graph replay of the training step (kernel trace of the timed mode: warm-up + capture + 3 replays; the last replay's window)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/kt_train_graph -o kt -- python3 $root/bench.py --mode train --no-cpu-baseline --steps 3 --warmup 1 --profile-steps 0 > $out/${tag}_train_graph.log 2>&1 )
+python3 tools/train_replay_timeline.py $(ls /tmp/kt_train_graph/*.db | head -1) > $out/${tag}_train_replay_timeline.txt 2>&1
+rm -rf /tmp/kt_train_graph
+python3 tools/train_shape_table.py bf16 2>&1 | grep -v amdgpu.ids > $out/${tag}_train_shape_table_bf16.txt
 # a steady-state step of the 64-scene shape, queue by queue; the overlapped scene loop, call by call
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/tl_s64 -o tl -- python3 $root/bench.py --no-cpu-baseline --no-wosac-shape --scenes 64 --steps 40 --profile-steps 0 --new-scenes 0 > /dev/null 2>&1 )
 python3 tools/step_timeline2.py $(ls /tmp/tl_s64/*.db | head -1) > $out/${tag}_s64_two_stream_timeline.txt 2>&1

@@ -510,6 +510,10 @@ struct AttnBwdArgs {
   float* coef;        // [rows, ktot, 8]
 };
 
+// WANT_DB: the per-row d(rpe_k_bias) is computed and stored (b.dbias_k != NULL). It is identically zero in exact arithmetic - adding
+// q_h . bk_h to every score of a row leaves its softmax unchanged, so sum_t dS[h,t] = 0 - and what the accumulation yields is round-off
+// of the size of the last bits of dq; the training step passes NULL (16 fmas per pair, 128 floats per row and a column sum less).
+template <bool WANT_DB>
 __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs b) {
   const AttnArgs& a = b.f;
   __shared__ float p_s[4][NH][KMAX];  // raw scores, then probabilities a[h,t]
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
           const float g = ds[h];
           dq[h].x += g * (kq.x + bkv[h].x); dq[h].y += g * (kq.y + bkv[h].y);
           dq[h].z += g * (kq.z + bkv[h].z); dq[h].w += g * (kq.w + bkv[h].w);
-          fma4(dbk[h], g, qv[h]);
+          if constexpr (WANT_DB) fma4(dbk[h], g, qv[h]);
           dqt[h].fma(g, e);
           if (b.coef != nullptr) continue;
           const int c0 = h * 32 + s8 * 4;
@@ -701,11 +705,11 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   }
   // the 8 target slots' sums by head (tbx::slot_sum4: four values per cross-row exchange, the same butterfly as slot_sum - see
   // merge_slots_by_head): lane l ends with head l >> 4's dq / d bias_k / dqt of channel slice s8, lanes l and l ^ 8 the same numbers
-  float4 r, rb;
+  float4 r, rb = make_float4(0.f, 0.f, 0.f, 0.f);
   ESlice rt;
 #define TBX_S4(A, F) tbx::slot_sum4(A[0].F, A[1].F, A[2].F, A[3].F)
   r.x = TBX_S4(dq, x), r.y = TBX_S4(dq, y), r.z = TBX_S4(dq, z), r.w = TBX_S4(dq, w);
-  rb.x = TBX_S4(dbk, x), rb.y = TBX_S4(dbk, y), rb.z = TBX_S4(dbk, z), rb.w = TBX_S4(dbk, w);
+  if constexpr (WANT_DB) rb.x = TBX_S4(dbk, x), rb.y = TBX_S4(dbk, y), rb.z = TBX_S4(dbk, z), rb.w = TBX_S4(dbk, w);
   rt.xc.x = TBX_S4(dqt, xc.x), rt.xc.y = TBX_S4(dqt, xc.y), rt.xs.x = TBX_S4(dqt, xs.x), rt.xs.y = TBX_S4(dqt, xs.y);
   rt.yc.x = TBX_S4(dqt, yc.x), rt.yc.y = TBX_S4(dqt, yc.y), rt.ys.x = TBX_S4(dqt, ys.x), rt.ys.y = TBX_S4(dqt, ys.y);
   rt.wc.x = TBX_S4(dqt, wc.x), rt.wc.y = TBX_S4(dqt, wc.y), rt.wc.z = TBX_S4(dqt, wc.z), rt.wc.w = TBX_S4(dqt, wc.w);
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
     *(float4*)(dqrow + a.q_off + hq * DH + s8 * 4) = r;
     // per-row part of d(rpe_k_bias): every row adding into the same 128 floats serialises ~10^3-deep at the L2 atomic
     // units (measured: ~200 us of a 335 us launch at 1024 rows); the caller sums the rows
-    *(float4*)(b.dbias_k + (int64_t)row * D + hq * DH + s8 * 4) = rb;
+    if constexpr (WANT_DB) *(float4*)(b.dbias_k + (int64_t)row * D + hq * DH + s8 * 4) = rb;
     rt.store(dqrow + a.qt_off + hq * DR, s8);
   }
 }
@@ -977,7 +981,7 @@ extern "C" int tbx_knarpe_attn_bwd_dropout_tb(const float* qbuf, int ldq, int q_
                                               int ldo, float* dqbuf, float* const* dkv, float* dbias_k, const float* freqs_xy,
                                               const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
                                               int time_batch, int time0, void* stream) {
-  if (!dout || !dqbuf || !dkv || !dbias_k) return TBX_ERR_ARG;
+  if (!dout || !dqbuf || !dkv) return TBX_ERR_ARG;  // (dbias_k may be NULL: not computed)
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
@@ -994,7 +998,8 @@ extern "C" int tbx_knarpe_attn_bwd_dropout_tb(const float* qbuf, int ldq, int q_
   b.dqbuf = dqbuf;
   b.dbias_k = dbias_k;
   b.coef = nullptr;
-  hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
+  if (dbias_k != nullptr) hipLaunchKernelGGL(knarpe_attn_bwd_kernel<true>, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
+  else hipLaunchKernelGGL(knarpe_attn_bwd_kernel<false>, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, b);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -1004,7 +1009,7 @@ extern "C" int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_o
                                              const float* freqs_yaw, float p_drop, const uint64_t* drop_seed, uint32_t drop_call,
                                              int time_batch, int time0, const int32_t* const* inv_ptr,
                                              const int32_t* const* inv_list, float* coef, void* stream) {
-  if (!dout || !dqbuf || !dkv || !dbias_k || !inv_ptr || !inv_list || !coef) return TBX_ERR_ARG;
+  if (!dout || !dqbuf || !dkv || !inv_ptr || !inv_list || !coef) return TBX_ERR_ARG;  // (dbias_k may be NULL: not computed)
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)dqbuf) & 15)) return TBX_ERR_ALIGN;
   AttnBwdArgs b;
   int rc = fill_args(b.f, qbuf, ldq, q_off, qt_off, rpe_k_bias, n_batch, n_src, segs, n_seg, ldo, freqs_xy, freqs_yaw);
@@ -1038,7 +1043,8 @@ extern "C" int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_o
   b.dbias_k = dbias_k;
   b.coef = coef;
   hipStream_t hs = (hipStream_t)stream;
-  hipLaunchKernelGGL(knarpe_attn_bwd_kernel, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, hs, b);
+  if (dbias_k != nullptr) hipLaunchKernelGGL(knarpe_attn_bwd_kernel<true>, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, hs, b);
+  else hipLaunchKernelGGL(knarpe_attn_bwd_kernel<false>, dim3((b.f.n_rows + 3) / 4), dim3(256), 0, hs, b);
   if (hipGetLastError() != hipSuccess) return TBX_ERR_LAUNCH;
   hipLaunchKernelGGL(knarpe_attn_dkv_kernel, dim3((d.n_tok + 3) / 4), dim3(256), 0, hs, d);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;

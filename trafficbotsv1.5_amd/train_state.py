@@ -44,7 +44,7 @@ HEADS_TILE = os.environ.get("TBX_HEADS_TILE_TRAIN", "1") != "0"  # the stepping 
 TALL_LINEAR = os.environ.get("TBX_TALL_LINEAR", "1") != "0"  # forward / input-gradient products of the time-batched pass on tbx_tall_linear
 
 
-WGRAD_MIN_ROWS = 16384  # from here on dW = dY^T X is a reduction over so many rows that the library GEMM has 1-2 output tiles
+WGRAD_MIN_ROWS = int(os.environ.get("TBX_WGRAD_MIN_ROWS", "16384"))  # from here on dW = dY^T X is a reduction over so many rows that the library GEMM has 1-2 output tiles
 
 
 # K/V tables of the current training step that also exist as bfloat16 (made by the launch that made the fp32 rows: tbx_tall_linear_dual):
