@@ -403,7 +403,8 @@ int tbx_front(const tbx_front_t* args /* host */, void* stream);
 /* tbx_tall_linear: y [m, n] = x [m, k] W^T (+ b) (optionally relu) over very many rows - the forward / input-gradient products of
  * training's time-batched pass - on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output): image = tbx_pack_weight_mfma32 of
  * W [n x k] (wt = 1 for a [k x n] weight: the input gradient dx = dy W), k and n multiples of 128 (<= 1024), ldx / ldy % 4 == 0,
- * 16-byte aligned. has_bias: add the image's bias. */
+ * 16-byte aligned. has_bias: add the image's bias. k or n = 64 mod 128 (the 64-wide PointNet layers, polyline_encoder.py:49-61): the
+ * image is that of W zero-padded to the next multiples of 128; x rows hold k, y rows n valid columns (loads / stores masked). */
 int tbx_tall_linear(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                     void* stream);
 /* ... with ONE bf16 product per term (x and W rounded to bfloat16, fp32 accumulation; the lo halves of the image are not read):
@@ -417,6 +418,16 @@ int tbx_tall_linear_dual(const float* x, int64_t m, int k, int ldx, const float*
                          uint16_t* y16, int ldy16, void* stream);
 int tbx_tall_linear_dual_bf16(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
                               uint16_t* y16, int ldy16, void* stream);
+/* y = dropout(relu(x W^T + b)) in the same launch: the hidden activation of a transformer layer's FFN (transformer_rpe.py:119-131:
+ * linear1 -> relu -> dropout) / an MLP layer (mlp.py:56-61) over the time-batched rows; the mask is tbx_keyed_dropout's for the [m, n]
+ * output (p_drop = 0: relu only), so tbx_relu_drop_bwd reads relu' and the mask off y exactly as behind tbx_relu_drop_fwd.
+ * Bit-identical to tbx_tall_linear(relu = 1) followed by tbx_keyed_dropout. _bf16: one bf16 product per term. */
+int tbx_tall_linear_relu_drop(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, float* y, int ldy,
+                              float p_drop, const uint64_t* drop_seed, uint32_t site, int rows_per_scene, int time_batch, int time0,
+                              void* stream);
+int tbx_tall_linear_relu_drop_bf16(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, float* y, int ldy,
+                                   float p_drop, const uint64_t* drop_seed, uint32_t site, int rows_per_scene, int time_batch, int time0,
+                                   void* stream);
 
 /* Image for the tbx_*_tile kernels of W_g [n x k] (g < groups; stored [k x n] per group if wt), bias [groups * n] or NULL. k = 32, 64 or a multiple
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */

@@ -491,7 +491,7 @@ def test_tall_linear_fn_gradients(tb):
     w, b = (torch.randn(256, 128, generator=g) * 0.1).to(dev), torch.randn(256, generator=g).to(dev)
     go = torch.randn(40, 500, 256, generator=g).to(dev)
     outs = []
-    for kk, nn in ((128, 256), (121, 5), (31, 121), (128, 1)):  # the odd widths go through zero-padded copies
+    for kk, nn in ((128, 256), (128, 64), (121, 5), (31, 121), (128, 1)):  # the odd widths go through zero-padded copies; 64-wide: tbx_tall_linear on the padded image
         xk, wk, bk, gk = x[..., :kk].contiguous(), w[:nn, :kk].contiguous(), b[:nn].contiguous(), go[..., :nn].contiguous()
         outs = []
         for fn in (TG.linear, torch.nn.functional.linear):
@@ -913,7 +913,10 @@ def test_linear_wgrad_bf16_vs_float64(tb, rows, n, k, ld_pad):
     assert float(((a.double() - b.double()).abs() / magb).max()) < 2e-6
 
 
-@pytest.mark.parametrize("m,k,n,wt,bias", [(1000, 128, 128, False, True), (70001, 128, 640, False, True), (4097, 640, 128, False, False), (20000, 128, 256, True, False)])
+@pytest.mark.parametrize("m,k,n,wt,bias", [(1000, 128, 128, False, True), (70001, 128, 640, False, True), (4097, 640, 128, False, False), (20000, 128, 256, True, False),
+                                           # the 64-wide PointNet layers (round 6): forward 128 -> 64 and its input gradient 64 -> 128 (wt) on the
+                                           # zero-padded image, loads / stores masked by column
+                                           (30011, 128, 64, False, True), (30011, 64, 128, True, False), (5000, 192, 64, False, True)])
 def test_tall_linear_bf16_vs_float64(tb, m, k, n, wt, bias):
     """tbx_tall_linear_bf16 (y = x W^T + b with x and W rounded to bfloat16, fp32 accumulation) vs float64: within 2^-8 sum |x||w| (worst
     case of two 2^-9 roundings per term); exactly the fp32-class kernel's result up to accumulation when x and W are bfloat16 values."""
@@ -1108,3 +1111,39 @@ def test_attention_fold_kernels_equal_the_torch_algebra(tb):
             torch.testing.assert_close(p_got, want, rtol=1e-4, atol=1e-4)
     # and inside a training step the Function is what runs (the fold's launches are the ones it replaced)
     assert TO.ATTN_FOLD_KERNEL
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("rows,k,n,nb,dropout", [(20480, 128, 512, 4, True), (16450, 128, 128, 1, True), (18000, 256, 128, 2, False)])
+def test_linear_relu_drop_one_launch_equals_two(tb, rows, k, n, nb, dropout, prec):
+    """train_ops.linear_relu_drop (tbx_tall_linear_relu_drop: LINEAR + relu + keyed dropout in the launch's epilogue; the FFN's hidden
+    activation / an MLP layer over the time-batched rows) against the two launches it replaces (TallLinearFn, then ReluDropFn): values and
+    all three gradients bit-identical - the same products, the same keyed mask (site ids advance alike; row count not a multiple of 64,
+    several scenes per batch, a time batch with an offset)."""
+    dev = torch.device("cuda:0")
+    TO = import_module("trafficbots_amd.train_ops")
+    ST = import_module("trafficbots_amd.train_state")
+    g = torch.Generator().manual_seed(rows + n)
+    x0 = torch.randn(rows, k, generator=g).to(dev)
+    w0, b0 = (torch.randn(n, k, generator=g) * 0.1).to(dev), torch.randn(n, generator=g).to(dev)
+    go = torch.randn(rows, n, generator=g).to(dev)
+    p = 0.1
+    res = {}
+    saved = (TO.LINEAR_RELU_DROP, ST._DROP, ST._PREC)
+    try:
+        ST._PREC = prec
+        for fused in (True, False):
+            TO.LINEAR_RELU_DROP = fused
+            ST._DROP = {"seed": torch.tensor([91], dtype=torch.int64, device=dev), "call": 0, "site": 7, "n_batch": nb, "tb": 2 if nb % 2 == 0 else 1, "t0": 3}
+            x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            h = TO.linear_relu_drop(x, w, b, p, dropout)
+            assert isinstance(h.grad_fn, TO.TallLinearReluDropFn._backward_cls) == fused
+            (h * go).sum().backward()
+            res[fused] = (h.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone(), ST._DROP["site"])
+    finally:
+        TO.LINEAR_RELU_DROP, ST._DROP, ST._PREC = saved
+    assert res[True][4] == res[False][4] == (8 if dropout else 7)
+    for u, v in zip(res[True][:4], res[False][:4]):
+        assert torch.equal(u, v)
+    frac0 = float((res[True][0] == 0).float().mean())
+    assert (0.5 < frac0 < 0.65) if dropout else (0.4 < frac0 < 0.6)  # relu zeroes ~half, the dropout a tenth of the rest

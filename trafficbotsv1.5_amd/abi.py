@@ -260,6 +260,8 @@ def load():
     lib.tbx_tall_linear_bf16.argtypes = lib.tbx_tall_linear.argtypes
     lib.tbx_tall_linear_dual.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, vp]
     lib.tbx_tall_linear_dual_bf16.argtypes = lib.tbx_tall_linear_dual.argtypes
+    lib.tbx_tall_linear_relu_drop.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, vp, i32, f32, vp, C.c_uint32, i32, i32, i32, vp]
+    lib.tbx_tall_linear_relu_drop_bf16.argtypes = lib.tbx_tall_linear_relu_drop.argtypes
     lib.tbx_tl_tail_tile.argtypes = [vp, i64, C.POINTER(TlTail), vp]
     lib.tbx_tl_tail_tile_bf16.argtypes = lib.tbx_tl_tail_tile.argtypes
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
@@ -285,7 +287,7 @@ def load():
     lib.tbx_attn_fold_bwd.argtypes = [vp] * 19
     lib.tbx_rule_navi_check.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_linear_wgrad_bf16", "tbx_tall_linear_bf16", "tbx_tl_tail_tile", "tbx_tl_tail_tile_bf16", "tbx_tall_linear_dual", "tbx_tall_linear_dual_bf16", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_fwd_windows", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd",
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd", "tbx_tall_linear_relu_drop", "tbx_tall_linear_relu_drop_bf16",
                  "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma", "tbx_knarpe_attn_fwd_mfma_dropout_tb"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:

@@ -1,5 +1,5 @@
 // tbx_tall_linear: y = x W^T (+ b) over VERY many rows (training's time-batched pass: 10^5 .. 2 x 10^6 rows, K and N multiples of
-// 128 up to 640) - the forward and input-gradient products of every nn.Linear of the differentiated pass, which the library ran at
+// 128 up to 640 - or of 64: the image is then that of the weight zero-padded to the next multiple of 128) - the forward and input-gradient products of every nn.Linear of the differentiated pass, which the library ran at
 // 50-105 TF/s of exact-fp32 MFMA (tools/train_gemm_shapes.py: 33 ms of a 200 ms step). These products are BYTE-bound if the
 // arithmetic is cheap enough - (K + N) x 4 B per row against 2 K N flops - so this kernel does the arithmetic on the split-bf16
 // matrix path of the tile kernels (tile_core.h: x = x_hi + x_lo, w = w_hi + w_lo in bf16, hi*hi + hi*lo + lo*hi on
@@ -9,7 +9,8 @@
 //     chunk's loads are in flight while this chunk multiplies;
 //   * wave w owns output tile w (16 channels) of the current 128-wide N block and holds its weights as a register unit
 //     (tbx_pack_weight_mfma32: 8 KiB per [16 channels x 128 k]), the next unit in flight; a unit serves the 4 row tiles (48 MFMAs);
-//   * products are formed transposed (D = W x^T): a lane ends with 4 consecutive channels of one row: one 16-byte store.
+//   * products are formed transposed (D = W x^T): a lane ends with 4 consecutive channels of one row; the N block's 64 x 128 outputs go
+//     through an LDS tile and leave as whole 512-byte rows (round 6).
 // Loop nest: N blocks outside, K chunks inside (every shape of the pass has min(K, N) = 128 or 256: the rows are read once when
 // K = 128 - their planes stay resident across the N blocks - and once per N block otherwise).
 #include <stdlib.h>
@@ -25,7 +26,9 @@ typedef Planes<ROWS, 4> PL;
 constexpr int PLANE = PL::PLANE;
 // (TBX_TILE_SINGLE build = tbx_tall_linear_bf16: one product, hi planes and the hi halves of the weight units only)
 constexpr int NPL = TBX_TILE_SINGLE ? 1 : 2;        // planes per buffer: hi (, lo)
-constexpr size_t LDS_BYTES = 2 * NPL * PLANE;       // two buffers
+constexpr int YLD = 132;                            // floats per row of the output staging tile (528 B: the 16 rows of a store land in 16 distinct 16-byte bank groups)
+constexpr size_t YS_OFF = 2 * NPL * PLANE;          // two buffers of planes, then the staging tile [64][YLD] fp32
+constexpr size_t LDS_BYTES = YS_OFF + (size_t)ROWS * YLD * sizeof(float);
 
 struct TallArgs {
   const float* x;
@@ -35,14 +38,46 @@ struct TallArgs {
   int ldx, ldy, k, n, has_bias, relu;
   uint16_t* y16;  // optional second output: the same rows as bfloat16 [m, ldy16] (the K/V tables the matrix-core attention gathers)
   int ldy16;
+  // optional keyed dropout behind the relu (tbx_tall_linear_relu_drop: the FFN's hidden activation / an MLP layer's output as ONE
+  // launch instead of LINEAR + tbx_relu_drop_fwd): tbx_keyed_dropout's mask for the [m, n] tensor; drop_thresh == 0: none
+  const uint64_t* drop_seed;
+  uint32_t drop_site, drop_thresh;
+  float drop_scale;
+  int rows_per_scene, time_batch, time0;
 };
+
+// tbx_keyed_dropout's keep decision (csrc/dropout.hip `mix`) for 4 consecutive columns [c, c + 4) of global row `row` of the [m, n] output
+__device__ __forceinline__ f32x4 tall_drop4(const TallArgs& a, const uint64_t sd, const int64_t row, const int c, f32x4 v) {
+  const int64_t b = row / a.rows_per_scene;
+  const int64_t sc = b / a.time_batch;
+  const uint32_t ts = (uint32_t)(a.time0 + (int)(b - sc * a.time_batch));
+  const uint32_t krow = (uint32_t)(sc * a.rows_per_scene + (row - b * a.rows_per_scene));
+  const uint32_t lo = (uint32_t)sd ^ (a.drop_site * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
+  const uint32_t hi = (uint32_t)(sd >> 32) + a.drop_site * 0xC2B2AE35u + ts * 0x165667B1u;
+  const uint32_t base = krow * (uint32_t)a.n + (uint32_t)c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint32_t x = (base + (uint32_t)r) ^ lo;
+    x *= 0x9E3779B1u;
+    x ^= hi;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    v[r] = x >= a.drop_thresh ? v[r] * a.drop_scale : 0.f;
+  }
+  return v;
+}
 
 __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_c[];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int KC = a.k >> 7, NB = a.n >> 7, T = a.n >> 4;  // 128-wide K chunks, N blocks; 16-channel tiles of the image
+  // 128-wide K chunks, N blocks; 16-channel tiles of the image. k, n are multiples of 64: a trailing half chunk / half block (the 64-wide
+  // PointNet layers) runs on the image of the weight zero-padded to the next multiple of 128, its loads / stores masked by column
+  const int KC = (a.k + 127) >> 7, NB = (a.n + 127) >> 7, T = NB << 3;
   const int n_rb = (int)((a.m + ROWS - 1) / ROWS);        // row blocks: this workgroup takes blockIdx.x, + gridDim.x, ...
   const int my_rb = (n_rb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   // Index arithmetic is what this loop must NOT spend its issue slots on (a matrix instruction leaves ~4 of them): everything below
@@ -52,18 +87,20 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   const int64_t x16 = 16 * (int64_t)a.ldx, y16 = 16 * (int64_t)a.ldy;
   const int64_t x_rb = (int64_t)gridDim.x * ROWS * a.ldx, y_rb = (int64_t)gridDim.x * ROWS * a.ldy;  // to this workgroup's next row block
   const float* xp = a.x + ((int64_t)blockIdx.x * ROWS + lr) * a.ldx + lc;                // the row block whose rows are requested next
-  float* yp = a.y + ((int64_t)blockIdx.x * ROWS + j) * a.ldy + 16 * wave + 4 * g;        // the row block being multiplied
-  uint16_t* yh = a.y16 == nullptr ? nullptr : a.y16 + ((int64_t)blockIdx.x * ROWS + j) * a.ldy16 + 16 * wave + 4 * g;
+  float* yp = a.y + ((int64_t)blockIdx.x * ROWS + lr) * a.ldy + lc;                      // the row block being multiplied: the thread's row / 4 columns of the coalesced store
+  uint16_t* yh = a.y16 == nullptr ? nullptr : a.y16 + ((int64_t)blockIdx.x * ROWS + lr) * a.ldy16 + lc;
   const int64_t h16 = 16 * (int64_t)a.ldy16, h_rb = (int64_t)gridDim.x * ROWS * a.ldy16;
   const TBX_GLOBAL float* wq = (const TBX_GLOBAL float*)a.img + (int64_t)wave * UNIT + lane * 4;  // the wave's units; the lane's 16 bytes
   int rows_req = (int)(a.m - (int64_t)blockIdx.x * ROWS);  // rows left from the requested row block on (may exceed 64)
   int rows_cur = rows_req;
+  int64_t row_cur = (int64_t)blockIdx.x * ROWS;  // first global row of the row block being multiplied
+  const uint64_t drop_sd = a.drop_thresh != 0u ? *(const TBX_GLOBAL uint64_t*)a.drop_seed : 0ull;
   f32x4 xin[4];
   auto request_x = [&](int kc) {  // rows of the row block at xp, K chunk kc
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       xin[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q * 16 + lr < rows_req) xin[q] = *(const TBX_GLOBAL f32x4*)(xp + q * x16 + kc * 128);  // (default cache policy: nt measured slower, see wgrad.hip)
+      if (q * 16 + lr < rows_req && kc * 128 + lc < a.k) xin[q] = *(const TBX_GLOBAL f32x4*)(xp + q * x16 + kc * 128);  // (default cache policy: nt measured slower, see wgrad.hip)
     }
   };
   auto park_x = [&](char* P) {
@@ -124,19 +161,30 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
       buf ^= 1;
     }
     if (kc + 1 == KC) {  // the N block's 64 x 128 outputs: lane = (row tile q, row j, channels 16 * wave + 4 g ..)
-      float* yo = yp + nb * 128;
+      // Round 6: through an LDS tile, then whole 512-byte rows per half-wave. Stored straight from the accumulators a wave instruction
+      // wrote 16 rows x 64 bytes (its 16 channels): every 128-byte line of Y was written in two halves by two waves at two times.
+      float* ys = (float*)(lds_c + YS_OFF);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = acc[q].sum();
         if (a.has_bias) v += bias;
         if (a.relu) v = relu4(v);
-        if (q * 16 + j < rows_cur) {
+        *(f32x4*)(ys + (q * 16 + j) * YLD + 16 * wave + 4 * g) = v;
+      }
+      __syncthreads();
+      float* yo = yp + nb * 128;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q * 16 + lr < rows_cur && nb * 128 + lc < a.n) {
+          f32x4 v = *(const f32x4*)(ys + (q * 16 + lr) * YLD + lc);
+          if (a.drop_thresh != 0u) v = tall_drop4(a, drop_sd, row_cur + q * 16 + lr, nb * 128 + lc, v);
           *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
           if (yh != nullptr) *(TBX_GLOBAL u32x2*)(yh + nb * 128 + q * h16) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
         }
       }
+      __syncthreads();  // (the tile is rewritten by the next N block's epilogue)
       if (next_rb) {
-        yp += y_rb, rows_cur -= (int)gridDim.x * ROWS;
+        yp += y_rb, rows_cur -= (int)gridDim.x * ROWS, row_cur += (int64_t)gridDim.x * ROWS;
         if (yh != nullptr) yh += h_rb;
       }
     }
@@ -165,14 +213,27 @@ static int tall_cu_count() {
   return n;
 }
 
+struct TallDrop {
+  float p;
+  const uint64_t* seed;
+  uint32_t site;
+  int rows_per_scene, time_batch, time0;
+};
+
 static int tall_launch(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, int relu, float* y, int ldy,
-                       uint16_t* y16, int ldy16, void* stream) {
+                       uint16_t* y16, int ldy16, void* stream, const TallDrop* drop = nullptr) {
   if (x == nullptr || image == nullptr || y == nullptr || m <= 0) return TBX_ERR_ARG;
-  if (k <= 0 || n <= 0 || (k % 128) || (n % 128) || k > 1024 || n > 1024) return TBX_ERR_UNSUPPORTED;
+  if (k <= 0 || n <= 0 || (k % 64) || (n % 64) || k > 1024 || n > 1024) return TBX_ERR_UNSUPPORTED;
   if (ldx < k || ldy < n || (ldx % 4) || (ldy % 4)) return TBX_ERR_ARG;
   if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)image)) & 15) return TBX_ERR_ALIGN;
   if (y16 != nullptr && (ldy16 < n || (ldy16 % 4) || (((uintptr_t)y16) & 7))) return TBX_ERR_ALIGN;
-  TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu, y16, ldy16};
+  TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu, y16, ldy16, nullptr, 0u, 0u, 1.0f, 1, 1, 0};
+  if (drop != nullptr && drop->p > 0.f) {
+    if (drop->p >= 1.f || !drop->seed || drop->rows_per_scene <= 0 || drop->time_batch < 1 || drop->time0 < 0 || m % drop->rows_per_scene) return TBX_ERR_ARG;
+    const double th = (double)drop->p * 4294967296.0;  // (tbx_keyed_dropout's threshold and scale)
+    a.drop_seed = drop->seed, a.drop_site = drop->site, a.drop_thresh = th < 1.0 ? 1u : (uint32_t)th, a.drop_scale = 1.0f / (1.0f - drop->p);
+    a.rows_per_scene = drop->rows_per_scene, a.time_batch = drop->time_batch, a.time0 = drop->time0;
+  }
   static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
   if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)tall_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
   const int64_t n_rb = (m + ROWS - 1) / ROWS;
@@ -192,4 +253,12 @@ extern "C" int TBX_TILE_ENTRY(tbx_tall_linear_dual)(const float* x, int64_t m, i
                                                     int ldy, uint16_t* y16, int ldy16, void* stream) {
   if (y16 == nullptr) return TBX_ERR_ARG;
   return tall_launch(x, m, k, ldx, image, n, has_bias, relu, y, ldy, y16, ldy16, stream);
+}
+
+extern "C" int TBX_TILE_ENTRY(tbx_tall_linear_relu_drop)(const float* x, int64_t m, int k, int ldx, const float* image, int n, int has_bias, float* y,
+                                                         int ldy, float p_drop, const uint64_t* drop_seed, uint32_t site, int rows_per_scene,
+                                                         int time_batch, int time0, void* stream) {
+  if (p_drop < 0.f) return TBX_ERR_ARG;
+  const TallDrop d{p_drop, drop_seed, site, rows_per_scene, time_batch, time0};
+  return tall_launch(x, m, k, ldx, image, n, has_bias, 1, y, ldy, nullptr, 0, stream, &d);
 }

@@ -27,21 +27,50 @@ def keyed_dropout(x: torch.Tensor, p: float, seed: torch.Tensor, site: int, rows
 
 def tall_linear_ok(x: torch.Tensor, k: int, n: int) -> bool:
     """Shapes tbx_tall_linear takes: row-major fp32 rows of k values (a 2-D view after flattening the leading dimensions), k and n
-    multiples of 128 up to 1024, 16-byte aligned, leading dimension a multiple of 4."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == k and k % 128 == 0 and n % 128 == 0 and k <= 1024 and n <= 1024
+    multiples of 64 up to 1024, 16-byte aligned, leading dimension a multiple of 4."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == k and k % 64 == 0 and n % 64 == 0 and k <= 1024 and n <= 1024
             and x.stride(-1) == 1 and x.data_ptr() % 16 == 0)
 
 
+def _pad128(w: torch.Tensor, b: Optional[torch.Tensor]):
+    """(w, b) zero-padded to multiples of 128 in both dimensions (tbx_tall_linear's image for a 64-wide layer); cached like packed_weight:
+    per parameter version, or per training step inside PACK_SCOPE."""
+    from . import hip_base
+
+    n, k = w.shape
+    npad, kpad = -(-n // 128) * 128, -(-k // 128) * 128
+    if (npad, kpad) == (n, k):
+        return w, b
+    key = ("pad128", id(w), None if b is None else id(b))
+    stamp = (w._version, w.data_ptr(), None if b is None else b._version)
+    cache = hip_base.PACK_SCOPE if hip_base.PACK_SCOPE is not None else w.__dict__.setdefault("_tbx_pad128", {})
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        wp = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)
+        wp[:n, :k].copy_(w)
+        bp = None
+        if b is not None:
+            bp = torch.zeros(npad, dtype=torch.float32, device=w.device)
+            bp[:n].copy_(b)
+    cache[key] = (stamp, wp, bp)
+    if hip_base.PACK_SCOPE is not None:
+        hip_base.PACK_SCOPE.setdefault("_keep", {})[id(w)] = w
+    return wp, bp
+
+
 def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, wt: bool = False, relu: bool = False,
-                bf16: bool = False, out: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+                bf16: bool = False, out: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, drop=None) -> torch.Tensor:
     """y = x W^T (+ b) over many rows on the split-bf16 matrix path (tbx_tall_linear; bf16: ONE bf16 product per term,
     tbx_tall_linear_bf16). wt: w is stored [k x n] (the input gradient dx = dy W of a Linear with weight W [n_out, n_in]: x = dy,
-    w = W, wt = True)."""
+    w = W, wt = True). drop (with relu): tbx_keyed_dropout's arguments - dropout(relu(.)) in the same launch."""
     n, k = (w.shape[1], w.shape[0]) if wt else (w.shape[0], w.shape[1])
     x2 = x.reshape(-1, k)
     if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
         x2 = x2.contiguous()
-    img = packed_weight(w, b, wt=wt, mfma32=True)
+    wp, bp = _pad128(w, b)  # (a 64-wide layer: the image of the zero-padded weight; k / n below stay the valid widths)
+    img = packed_weight(wp, bp, wt=wt, mfma32=True)
     y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device) if out is None else out
     assert y.shape == (x2.shape[0], n) and y.is_contiguous() and y.dtype == torch.float32
     if out16 is not None:  # the same rows as bfloat16 as well (tbx_tall_linear_dual)
@@ -49,6 +78,13 @@ def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = No
         fn = load().tbx_tall_linear_dual_bf16 if bf16 else load().tbx_tall_linear_dual
         _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
                   _ptr(y), n, _ptr(out16, torch.bfloat16), n, stream_ptr()), "tbx_tall_linear_dual")
+        return y.view(*x.shape[:-1], n)
+    if drop is not None:  # dropout(relu(.)) in the launch (tbx_tall_linear_relu_drop): drop = (p, seed, site, rows_per_scene, time_batch, time0)
+        assert relu
+        p, seed, site, rps, tb, t0 = _drop6(drop)
+        fn = load().tbx_tall_linear_relu_drop_bf16 if bf16 else load().tbx_tall_linear_relu_drop
+        _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), _ptr(y), n,
+                  p, seed, site, rps, tb, t0, stream_ptr()), "tbx_tall_linear_relu_drop")
         return y.view(*x.shape[:-1], n)
     fn = load().tbx_tall_linear_bf16 if bf16 else load().tbx_tall_linear
     _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),

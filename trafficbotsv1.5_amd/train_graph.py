@@ -98,7 +98,7 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
             s2 = ln(layer.norm1, x)
             ts = Targets(s2, n_tgt=S, **self_knn)
             x = _attn_residual(x, attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S, raw=True), p, training)
-        h = relu_drop(linear(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias), p, training)
+        h = linear_relu_drop(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias, p, training)
         x = residual(x, linear(h, layer.linear2.weight, layer.linear2.bias), p, training, zero_out=inv)
     return x
 

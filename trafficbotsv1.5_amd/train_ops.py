@@ -51,29 +51,56 @@ class TallLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _d16=None):
         x, w = ctx.saved_tensors
-        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if TALL_LINEAR and hip.tall_linear_ok(dy, w.shape[0], w.shape[1]):
-                dx = hip.tall_linear(dy, w, None, wt=True, bf16=ctx.bf16)
-            else:
-                dx = F.linear(dy, w.t().contiguous())
-        dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            if not dy2.is_contiguous():
-                dy2 = dy2.contiguous()
-            n, k = dy2.shape[1], x2.shape[1]
-            if not hip.linear_wgrad_ok(dy2, x2):
-                # odd widths (heads with 1 / 2 / 5 outputs, the 31- / 121-wide map MLP): zero-padded copies with 4-float rows
-                # (the library's GEMM for [n, rows] x [rows, k] with n = 1 took 56 ms at 10^6 rows)
-                dy2 = F.pad(dy2, (0, -n % 4))
-                x2 = F.pad(x2, (0, -k % 4)) if (k % 4 or not x2.is_contiguous()) else x2
-                if x2.data_ptr() % 16:  # a contiguous view at an odd offset: the kernel reads float4 rows
-                    x2 = x2.clone()
-                assert hip.linear_wgrad_ok(dy2, x2)
-            dw, db = hip.linear_wgrad(dy2, x2, ctx.has_b, bf16=ctx.bf16)
-            dw, db = dw[:n, :k], (db[:n] if db is not None else None)
+        dx, dw, db = _tall_linear_backward(x, w, dy, ctx.has_b, ctx.bf16, ctx.needs_input_grad)
         return dx, dw, db, None
+
+
+def _tall_linear_backward(x, w, dy, has_b: bool, bf16: bool, needs):
+    """(dx, dw, db) of y = x W^T + b over very many rows: dx on tbx_tall_linear with the W^T image, dW / db on tbx_linear_wgrad."""
+    dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+    dx = None
+    if needs[0]:
+        if TALL_LINEAR and hip.tall_linear_ok(dy, w.shape[0], w.shape[1]):
+            dx = hip.tall_linear(dy, w, None, wt=True, bf16=bf16)
+        else:
+            dx = F.linear(dy, w.t().contiguous())
+    dw = db = None
+    if needs[1] or (has_b and needs[2]):
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        n, k = dy2.shape[1], x2.shape[1]
+        if not hip.linear_wgrad_ok(dy2, x2):
+            # odd widths (heads with 1 / 2 / 5 outputs, the 31- / 121-wide map MLP): zero-padded copies with 4-float rows
+            # (the library's GEMM for [n, rows] x [rows, k] with n = 1 took 56 ms at 10^6 rows)
+            dy2 = F.pad(dy2, (0, -n % 4))
+            x2 = F.pad(x2, (0, -k % 4)) if (k % 4 or not x2.is_contiguous()) else x2
+            if x2.data_ptr() % 16:  # a contiguous view at an odd offset: the kernel reads float4 rows
+                x2 = x2.clone()
+            assert hip.linear_wgrad_ok(dy2, x2)
+        dw, db = hip.linear_wgrad(dy2, x2, has_b, bf16=bf16)
+        dw, db = dw[:n, :k], (db[:n] if db is not None else None)
+    return dx, dw, db
+
+
+class TallLinearReluDropFn(torch.autograd.Function):
+    """h = dropout(relu(x W^T + b)) as ONE launch (tbx_tall_linear_relu_drop: the FFN's linear1 / an MLP layer over the time-batched
+    rows) instead of TallLinearFn + ReluDropFn - the pre-activation is never written or read back. Backward: relu' and the mask are read
+    off h (tbx_relu_drop_bwd), then TallLinearFn's products. Bit-identical to the two-launch form (tests/test_hip_training.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, p, seed, site, rows_per_scene, tb, t0):
+        ctx.bf16 = bf16_contractions()
+        h = hip.tall_linear(x, w, b, relu=True, bf16=ctx.bf16, drop=(p, seed, site, rows_per_scene, tb, t0))
+        ctx.save_for_backward(x, w, h)
+        ctx.has_b, ctx.p = b is not None, p
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w, h = ctx.saved_tensors
+        dz = hip.relu_drop_bwd(dh.contiguous(), h, ctx.p)
+        dx, dw, db = _tall_linear_backward(x, w, dz, ctx.has_b, ctx.bf16, ctx.needs_input_grad)
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -269,6 +296,20 @@ def relu_drop(z: Tensor, p: float, training: bool) -> Tensor:
     return _drop(F.relu(z), p, training)
 
 
+LINEAR_RELU_DROP = os.environ.get("TBX_LINEAR_RELU_DROP", "1") != "0"  # (0: LINEAR and relu + dropout as two launches, for A/B runs)
+
+
+def linear_relu_drop(x: Tensor, w: Tensor, b: Optional[Tensor], p: float, training: bool) -> Tensor:
+    """dropout(relu(F.linear(x, w, b))): over >= WGRAD_MIN_ROWS rows of the time-batched pass one launch (TallLinearReluDropFn), else
+    `relu_drop(linear(.))`. The dropout site id is taken exactly where relu_drop would take it."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    if (LINEAR_RELU_DROP and TALL_LINEAR and torch.is_grad_enabled() and x.is_cuda and rows >= WGRAD_MIN_ROWS and (w.requires_grad or x.requires_grad)
+            and x.dtype == torch.float32 and hip.tall_linear_ok(x, w.shape[1], w.shape[0]) and ST.GLUE_FUSED
+            and not (training and p > 0 and ST._DROP is None)):
+        return TallLinearReluDropFn.apply(x, w, b, *_drop_args(x, p, training))
+    return relu_drop(linear(x, w, b), p, training)
+
+
 class AttnFoldFn(torch.autograd.Function):
     """The folded weights of one AttentionRPE module as ONE launch forward and ONE backward (tbx_attn_fold_fwd / _bwd) instead of the
     ~10 + ~25 slice / bmm / cat kernels torch ran per module: x 40 attention modules x 2 passes (no-grad stepping pass, differentiated
@@ -375,6 +416,9 @@ def mlp(m, x: Tensor, training: bool = False) -> Tensor:
     """modules/mlp.py:69-72 (Linear [+LN] [+ReLU] [+Dropout] per layer)."""
     p = m.dropout_p
     for lin, lnm, act in m.linear_layers():
+        if act and lnm is None and hip.glue_ok(x) and lin.weight.shape[0] % 4 == 0:
+            x = linear_relu_drop(x, lin.weight, lin.bias, p, training)  # LINEAR + relu + dropout as ONE launch over the time-batched rows
+            continue
         x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
             x = layer_norm(x, lnm)
