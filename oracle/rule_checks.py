@@ -177,6 +177,17 @@ def check_passive_raw(valid, pose, motion, tl_valid, tl_pose, tl_state, lane, la
 
 
 # ---------------------------------------------------------------------------------------------- the per-step checker
+def check_goal_reached(valid: Tensor, pose: Tensor, goal: Tensor, goal_reached: Tensor, ag_length: Tensor) -> Tensor:
+    """traffic_rule_checker.py:277-288 (_check_goal_reached; goal_thresh_pos = 8 agent lengths :66, goal_thresh_rot = 15 deg :67;
+    cast_rad = transform_utils.py:9-11) -> goal_reached_this_step [n_sc, n_ag] bool."""
+    import math
+
+    pos_reached = torch.norm(pose[..., :2] - goal[..., :2], dim=-1) < ag_length * 8
+    d = pose[..., 2] - goal[..., 2]
+    rot_reached = torch.abs((d + math.pi) % (2 * math.pi) - math.pi) < math.radians(15)
+    return pos_reached & rot_reached & valid & (~goal_reached)
+
+
 class RuleCheckOracle:
     """The metric-only half of TrafficRuleChecker.check (traffic_rule_checker.py:342-451): collided, collided_wosac,
     run_road_edge, run_red_light, passive - per step and accumulated. (outside_map / dest_reached feed back into the

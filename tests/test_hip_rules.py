@@ -60,8 +60,14 @@ def test_per_step_check_equals_log_check_and_resumes(tb):
     tl = e["tl/state"].to(DEV)
     for t in range(T):
         v = rc.check(valid[:, :, t], pose[:, :, t].contiguous(), motion[:, :, t].contiguous(), tl[:, :, t])
-        for k, x in v.items():
-            assert torch.equal(x, whole[k][:, :, t]), (k, t)
+        for k in whole:
+            assert torch.equal(v[k], whole[k][:, :, t]), (k, t)
+        # (round 6) ... and the per-step call carries the reference's other six entries (tbx_rule_navi_check): the checks that feed back
+        # into the simulation, which a finished rollout's log gets from tbx_sim_step instead (RolloutBuffer.violation)
+        extra = set(v) - set(whole)
+        assert extra == {a + s for a in ("outside_map", "dest_reached", "goal_reached") for s in ("", "_this_step")}, extra
+        for k in extra:
+            assert v[k].dtype == torch.bool and v[k].shape == valid[:, :, t].shape
     rc2 = _checker(tb, e)
     first = rc2.check_log(valid, pose, motion, bits, t0=0, n_t=17)
     second = rc2.check_log(valid, pose, motion, bits, t0=17)
@@ -261,3 +267,53 @@ def test_grid_tables_give_the_full_scans_flags(tb, tag):
             assert key(sa) == key(sb), (tag, name, sc)
             st = a[2][name + "_start"][sc].cpu()
             assert int(st[0]) == 0 and int(st[-1]) == n and bool((st[1:] >= st[:-1]).all())
+
+
+def test_per_step_feedback_checks_vs_oracle(tb):
+    """tbx_rule_navi_check - `TrafficRuleChecker.check`'s outside_map / dest_reached / goal_reached entries, the ones the reference's
+    `rollout` hands to `dynamics.disable_ag / disable_navi` (waymo_motion.py:250,304-305) - against the oracle's restatement of
+    traffic_rule_checker.py:109-120 (outside map), :290-330 (destination: lane = position + heading, road edge = position) and :277-288
+    (goal) over a 40-step walk that crosses the map boundary and runs into destinations and goals: every flag of every step bit-exact,
+    accumulators included; rollouts sharing one scene's map (map tensors per scene, agents per rollout)."""
+    from oracle import trafficbots_oracle as O
+
+    T_ = import_module("trafficbots_amd.utils.traffic_rule_checker")
+    K = 3
+    b = tb.synthetic.make_scene(2, 16, 64, 8, seed=4)
+    g = torch.Generator().manual_seed(9)
+    n, A = 2 * K, 16
+    rep = lambda t: t.repeat_interleave(K, 0)
+    dest = torch.randint(0, 64, (n, A), generator=g)
+    # goals / starts near a node of the agent's destination polyline, so that positions within the thresholds do occur
+    bi = (torch.arange(n) // K).unsqueeze(1)
+    node = b["map/pos"][bi, dest][:, :, 5, :2]
+    ndir = b["map/dir"][bi, dest][:, :, 5, :2]
+    yaw0 = torch.atan2(ndir[..., 1], ndir[..., 0])
+    goal = torch.cat([node + 3.0 * torch.randn(n, A, 2, generator=g), yaw0.unsqueeze(-1) + 0.2 * torch.randn(n, A, 1, generator=g),
+                      torch.zeros(n, A, 1)], -1)
+    size = rep(b["agent/size"])
+    rc = T_.TrafficRuleChecker(mp_boundary=b["map/boundary"].to(DEV) * 0.4, mp_valid=b["map/valid"].to(DEV), mp_type=b["map/type"].to(DEV),
+                               mp_pos=b["map/pos"].to(DEV), mp_dir=b["map/dir"].to(DEV), ag_type=rep(b["agent/type"]).to(DEV), ag_size=size.to(DEV),
+                               ag_goal=goal.to(DEV), ag_dest=dest.to(DEV), tl_valid=rep(b["tl_lane/valid"][:, :, 0]).to(DEV),
+                               tl_pose=torch.zeros(n, 8, 3, device=DEV), disable_check=True)
+    bnd = rep(b["map/boundary"] * 0.4)
+    dinfo = O.Sim.dest_info(dest, rep(b["map/valid"]), rep(b["map/type"]), rep(b["map/pos"]), rep(b["map/dir"]))
+    outside = torch.zeros(n, A, dtype=torch.bool)
+    reached, goal_r = outside.clone(), outside.clone()
+    tl_state = torch.zeros(n, 8, 5, dtype=torch.bool, device=DEV)
+    fired = {"outside": 0, "dest": 0, "goal": 0}
+    for t in range(40):
+        # a walk from 30 m out towards (and through) the node, heading swinging around the polyline's direction
+        s = 1.0 - t / 20.0
+        xy = node + s * 30.0 * torch.stack([torch.cos(yaw0 + 1.0), torch.sin(yaw0 + 1.0)], -1) + 0.5 * torch.randn(n, A, 2, generator=g)
+        pose = torch.cat([xy, yaw0.unsqueeze(-1) + (0.8 * s) + 0.05 * torch.randn(n, A, 1, generator=g)], -1)
+        valid = torch.rand(n, A, generator=g) > 0.1
+        v = rc.check(valid.to(DEV), pose.to(DEV), torch.zeros(n, A, 3, device=DEV), tl_state)
+        out_now, reach_now = O.Sim.feedback_checks(valid, pose, bnd, dinfo, reached)
+        goal_now = R.check_goal_reached(valid, pose, goal, goal_r, size[:, :, 0])
+        outside, reached, goal_r = outside | out_now, reached | reach_now, goal_r | goal_now
+        for k, want in (("outside_map_this_step", out_now), ("outside_map", outside), ("dest_reached_this_step", reach_now),
+                        ("dest_reached", reached), ("goal_reached_this_step", goal_now), ("goal_reached", goal_r)):
+            assert torch.equal(v[k].cpu(), want), (k, t)
+        fired["outside"] += int(out_now.sum()); fired["dest"] += int(reach_now.sum()); fired["goal"] += int(goal_now.sum())
+    assert all(c > 0 for c in fired.values()), fired  # (the comparison is not of all-false flags)
