@@ -9,8 +9,7 @@
 //     chunk's loads are in flight while this chunk multiplies;
 //   * wave w owns output tile w (16 channels) of the current 128-wide N block and holds its weights as a register unit
 //     (tbx_pack_weight_mfma32: 8 KiB per [16 channels x 128 k]), the next unit in flight; a unit serves the 4 row tiles (48 MFMAs);
-//   * products are formed transposed (D = W x^T): a lane ends with 4 consecutive channels of one row; the N block's 64 x 128 outputs go
-//     through an LDS tile and leave as whole 512-byte rows (round 6).
+//   * products are formed transposed (D = W x^T): a lane ends with 4 consecutive channels of one row: one 16-byte store.
 // Loop nest: N blocks outside, K chunks inside (every shape of the pass has min(K, N) = 128 or 256: the rows are read once when
 // K = 128 - their planes stay resident across the N blocks - and once per N block otherwise).
 #include <stdlib.h>
@@ -26,9 +25,7 @@ typedef Planes<ROWS, 4> PL;
 constexpr int PLANE = PL::PLANE;
 // (TBX_TILE_SINGLE build = tbx_tall_linear_bf16: one product, hi planes and the hi halves of the weight units only)
 constexpr int NPL = TBX_TILE_SINGLE ? 1 : 2;        // planes per buffer: hi (, lo)
-constexpr int YLD = 132;                            // floats per row of the output staging tile (528 B: the 16 rows of a store land in 16 distinct 16-byte bank groups)
-constexpr size_t YS_OFF = 2 * NPL * PLANE;          // two buffers of planes, then the staging tile [64][YLD] fp32
-constexpr size_t LDS_BYTES = YS_OFF + (size_t)ROWS * YLD * sizeof(float);
+constexpr size_t LDS_BYTES = 2 * NPL * PLANE;       // two buffers
 
 struct TallArgs {
   const float* x;
@@ -46,20 +43,28 @@ struct TallArgs {
   int rows_per_scene, time_batch, time0;
 };
 
-// tbx_keyed_dropout's keep decision (csrc/dropout.hip `mix`) for 4 consecutive columns [c, c + 4) of global row `row` of the [m, n] output
-__device__ __forceinline__ f32x4 tall_drop4(const TallArgs& a, const uint64_t sd, const int64_t row, const int c, f32x4 v) {
-  const int64_t b = row / a.rows_per_scene;
-  const int64_t sc = b / a.time_batch;
-  const uint32_t ts = (uint32_t)(a.time0 + (int)(b - sc * a.time_batch));
-  const uint32_t krow = (uint32_t)(sc * a.rows_per_scene + (row - b * a.rows_per_scene));
-  const uint32_t lo = (uint32_t)sd ^ (a.drop_site * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
-  const uint32_t hi = (uint32_t)(sd >> 32) + a.drop_site * 0xC2B2AE35u + ts * 0x165667B1u;
-  const uint32_t base = krow * (uint32_t)a.n + (uint32_t)c;
+// tbx_keyed_dropout's mask (csrc/dropout.hip `mix`): the per-row part of the key (step of the row's batch entry, its row inside the scene)
+// once per row block, the per-element hash in the epilogue
+struct TallRowKey {
+  uint32_t lo, hi, base;  // base = key row * n
+};
+__device__ __forceinline__ TallRowKey tall_row_key(const TallArgs& a, const uint64_t sd, const uint32_t row) {
+  const uint32_t b = row / (uint32_t)a.rows_per_scene;  // (m < 2^31: 32-bit divisions)
+  const uint32_t sc = b / (uint32_t)a.time_batch;
+  const uint32_t ts = (uint32_t)a.time0 + (b - sc * (uint32_t)a.time_batch);
+  const uint32_t krow = sc * (uint32_t)a.rows_per_scene + (row - b * (uint32_t)a.rows_per_scene);
+  TallRowKey k;
+  k.lo = (uint32_t)sd ^ (a.drop_site * 0x85EBCA6Bu) ^ (ts * 0x27D4EB2Fu);
+  k.hi = (uint32_t)(sd >> 32) + a.drop_site * 0xC2B2AE35u + ts * 0x165667B1u;
+  k.base = krow * (uint32_t)a.n;
+  return k;
+}
+__device__ __forceinline__ f32x4 tall_drop4(const TallArgs& a, const TallRowKey& k, const int c, f32x4 v) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    uint32_t x = (base + (uint32_t)r) ^ lo;
+    uint32_t x = (k.base + (uint32_t)(c + r)) ^ k.lo;
     x *= 0x9E3779B1u;
-    x ^= hi;
+    x ^= k.hi;
     x ^= x >> 16;
     x *= 0x7feb352du;
     x ^= x >> 15;
@@ -87,14 +92,17 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
   const int64_t x16 = 16 * (int64_t)a.ldx, y16 = 16 * (int64_t)a.ldy;
   const int64_t x_rb = (int64_t)gridDim.x * ROWS * a.ldx, y_rb = (int64_t)gridDim.x * ROWS * a.ldy;  // to this workgroup's next row block
   const float* xp = a.x + ((int64_t)blockIdx.x * ROWS + lr) * a.ldx + lc;                // the row block whose rows are requested next
-  float* yp = a.y + ((int64_t)blockIdx.x * ROWS + lr) * a.ldy + lc;                      // the row block being multiplied: the thread's row / 4 columns of the coalesced store
-  uint16_t* yh = a.y16 == nullptr ? nullptr : a.y16 + ((int64_t)blockIdx.x * ROWS + lr) * a.ldy16 + lc;
+  float* yp = a.y + ((int64_t)blockIdx.x * ROWS + j) * a.ldy + 16 * wave + 4 * g;        // the row block being multiplied
+  uint16_t* yh = a.y16 == nullptr ? nullptr : a.y16 + ((int64_t)blockIdx.x * ROWS + j) * a.ldy16 + 16 * wave + 4 * g;
   const int64_t h16 = 16 * (int64_t)a.ldy16, h_rb = (int64_t)gridDim.x * ROWS * a.ldy16;
   const TBX_GLOBAL float* wq = (const TBX_GLOBAL float*)a.img + (int64_t)wave * UNIT + lane * 4;  // the wave's units; the lane's 16 bytes
   int rows_req = (int)(a.m - (int64_t)blockIdx.x * ROWS);  // rows left from the requested row block on (may exceed 64)
   int rows_cur = rows_req;
   int64_t row_cur = (int64_t)blockIdx.x * ROWS;  // first global row of the row block being multiplied
   const uint64_t drop_sd = a.drop_thresh != 0u ? *(const TBX_GLOBAL uint64_t*)a.drop_seed : 0ull;
+  TallRowKey rkey[4];  // the lane's 4 output rows (q * 16 + j) of the current row block
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rkey[q] = a.drop_thresh != 0u ? tall_row_key(a, drop_sd, (uint32_t)(row_cur + q * 16 + j)) : TallRowKey{0u, 0u, 0u};
   f32x4 xin[4];
   auto request_x = [&](int kc) {  // rows of the row block at xp, K chunk kc
 #pragma unroll
@@ -161,31 +169,31 @@ __global__ __launch_bounds__(NT) void tall_linear_kernel(const TallArgs a) {
       buf ^= 1;
     }
     if (kc + 1 == KC) {  // the N block's 64 x 128 outputs: lane = (row tile q, row j, channels 16 * wave + 4 g ..)
-      // Round 6: through an LDS tile, then whole 512-byte rows per half-wave. Stored straight from the accumulators a wave instruction
-      // wrote 16 rows x 64 bytes (its 16 channels): every 128-byte line of Y was written in two halves by two waves at two times.
-      float* ys = (float*)(lds_c + YS_OFF);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v = acc[q].sum();
-        if (a.has_bias) v += bias;
-        if (a.relu) v = relu4(v);
-        *(f32x4*)(ys + (q * 16 + j) * YLD + 16 * wave + 4 * g) = v;
-      }
-      __syncthreads();
+      // (Through an LDS tile as whole 512-byte rows - instead of 16 rows x 64 bytes per wave instruction - was measured in round 6:
+      // 184,320 x 128 -> 640 152 -> 147 us, but 92,160 x 128 x 128 25.7 -> 31.1 and the 16,384-row calls + 30 %: two more barriers per N
+      // block; the class + 1 ms per step. Dropped.)
       float* yo = yp + nb * 128;
+      const int c0 = nb * 128 + 16 * wave + 4 * g;
+      if (c0 < a.n) {  // (a trailing half block: the 64-wide layers)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q * 16 + lr < rows_cur && nb * 128 + lc < a.n) {
-          f32x4 v = *(const f32x4*)(ys + (q * 16 + lr) * YLD + lc);
-          if (a.drop_thresh != 0u) v = tall_drop4(a, drop_sd, row_cur + q * 16 + lr, nb * 128 + lc, v);
-          *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
-          if (yh != nullptr) *(TBX_GLOBAL u32x2*)(yh + nb * 128 + q * h16) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = acc[q].sum();
+          if (a.has_bias) v += bias;
+          if (a.relu) v = relu4(v);
+          if (a.drop_thresh != 0u) v = tall_drop4(a, rkey[q], c0, v);
+          if (q * 16 + j < rows_cur) {
+            *(TBX_GLOBAL f32x4*)(yo + q * y16) = v;
+            if (yh != nullptr) *(TBX_GLOBAL u32x2*)(yh + nb * 128 + q * h16) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+          }
         }
       }
-      __syncthreads();  // (the tile is rewritten by the next N block's epilogue)
       if (next_rb) {
         yp += y_rb, rows_cur -= (int)gridDim.x * ROWS, row_cur += (int64_t)gridDim.x * ROWS;
         if (yh != nullptr) yh += h_rb;
+        if (a.drop_thresh != 0u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rkey[q] = tall_row_key(a, drop_sd, (uint32_t)(row_cur + q * 16 + j));
+        }
       }
     }
     nb = nb2, kc = kc2;
@@ -230,6 +238,7 @@ static int tall_launch(const float* x, int64_t m, int k, int ldx, const float* i
   TallArgs a{x, image, y, m, ldx, ldy, k, n, has_bias, relu, y16, ldy16, nullptr, 0u, 0u, 1.0f, 1, 1, 0};
   if (drop != nullptr && drop->p > 0.f) {
     if (drop->p >= 1.f || !drop->seed || drop->rows_per_scene <= 0 || drop->time_batch < 1 || drop->time0 < 0 || m % drop->rows_per_scene) return TBX_ERR_ARG;
+    if (m > 0x7fffffff) return TBX_ERR_UNSUPPORTED;  // (the mask's row arithmetic is 32-bit)
     const double th = (double)drop->p * 4294967296.0;  // (tbx_keyed_dropout's threshold and scale)
     a.drop_seed = drop->seed, a.drop_site = drop->site, a.drop_thresh = th < 1.0 ? 1u : (uint32_t)th, a.drop_scale = 1.0f / (1.0f - drop->p);
     a.rows_per_scene = drop->rows_per_scene, a.time_batch = drop->time_batch, a.time0 = drop->time0;

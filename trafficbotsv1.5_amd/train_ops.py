@@ -21,6 +21,18 @@ ATTN_DBIAS_K = os.environ.get("TBX_ATTN_DBIAS_K", "0") == "1"  # (1: accumulate 
 ATTN_FOLD_KERNEL = os.environ.get("TBX_ATTN_FOLD_KERNEL", "1") != "0"  # (0: the torch algebra, for A/B runs)
 
 
+# tbx_tall_linear takes 64-wide layers too (the PointNet LINEARs 128 -> 64 and their input gradients, on the zero-padded image); inside the
+# training step they stay on the library's fp32 GEMM by default: measured 110.2 -> 110.5 scenes/s with them on the kernel, but under the bf16
+# class the PointNets' max-pools then sit behind bf16 products and the step's agreement with the reference loosens 3-5 x (train_c2.npz: loss
+# 2.0e-4 -> 1.4e-3, spot gradients 2.5e-2 -> 0.11 of the block's largest entry; the 16-scene recombination 3.4e-4 -> 9.6e-3 on the gradient
+# norms), and the fp32 class picks up the split products' 3e-5 on small gradient entries. TBX_TALL_64=1 turns it on.
+TALL_64 = os.environ.get("TBX_TALL_64", "0") == "1"
+
+
+def _tall_ok(x: Tensor, k: int, n: int) -> bool:
+    return TALL_LINEAR and hip.tall_linear_ok(x, k, n) and (TALL_64 or (k % 128 == 0 and n % 128 == 0))
+
+
 class TallLinearFn(torch.autograd.Function):
     """F.linear over very many rows (the time-batched pass: [n_scene * T * tokens (* window), k]). Forward and input gradient
     are library GEMMs in the form the library is fast at (row-major activations x K-contiguous weights: 60-100 TF/s fp32
@@ -32,7 +44,7 @@ class TallLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         ctx.bf16 = bf16_contractions()  # (the backward runs after training_step has returned: it keeps the forward's class)
-        if TALL_LINEAR and hip.tall_linear_ok(x, w.shape[1], w.shape[0]):
+        if _tall_ok(x, w.shape[1], w.shape[0]):
             # K, N multiples of 128: tbx_tall_linear (split-bf16 matrix path, byte-bound: ~3x the library's exact-fp32 rate; one
             # product under the bf16 class)
             if want16:  # a K/V table: the rows as bfloat16 as well, written by the same launch (for the matrix-core attention forward)
@@ -60,7 +72,7 @@ def _tall_linear_backward(x, w, dy, has_b: bool, bf16: bool, needs):
     dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
     dx = None
     if needs[0]:
-        if TALL_LINEAR and hip.tall_linear_ok(dy, w.shape[0], w.shape[1]):
+        if _tall_ok(dy, w.shape[0], w.shape[1]):
             dx = hip.tall_linear(dy, w, None, wt=True, bf16=bf16)
         else:
             dx = F.linear(dy, w.t().contiguous())
@@ -304,7 +316,7 @@ def linear_relu_drop(x: Tensor, w: Tensor, b: Optional[Tensor], p: float, traini
     `relu_drop(linear(.))`. The dropout site id is taken exactly where relu_drop would take it."""
     rows = x.numel() // max(x.shape[-1], 1)
     if (LINEAR_RELU_DROP and TALL_LINEAR and torch.is_grad_enabled() and x.is_cuda and rows >= WGRAD_MIN_ROWS and (w.requires_grad or x.requires_grad)
-            and x.dtype == torch.float32 and hip.tall_linear_ok(x, w.shape[1], w.shape[0]) and ST.GLUE_FUSED
+            and x.dtype == torch.float32 and _tall_ok(x, w.shape[1], w.shape[0]) and ST.GLUE_FUSED
             and not (training and p > 0 and ST._DROP is None)):
         return TallLinearReluDropFn.apply(x, w, b, *_drop_args(x, p, training))
     return relu_drop(linear(x, w, b), p, training)
