@@ -84,7 +84,10 @@ def attn_counters(args):
     tools/pmc_attn.sh at the WOSAC shape) - attached only to that workload's attention entry."""
     if (args.agents, args.rollouts, args.scenes) != (128, 32, 1):
         return None
+    newest = newest_round()
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*attn_counters*.json")), reverse=True):
+        if round_tag(f) != newest:  # (as pmc_traffic: this round's kernels are described by this round's counters only)
+            continue
         d = json.load(open(f))
         if "valu_busy" in d and bool(d.get("kv_bf16", False)) == bool(args.kv_bf16):
             return {"valu_busy": d["valu_busy"], "l2_hit_rate": d.get("l2_hit_rate"), "l2_read_requests_per_launch": d.get("l2_read_requests"),
