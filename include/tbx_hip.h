@@ -233,6 +233,15 @@ typedef struct tbx_tl_tail {
   float* logits_out;                     /* [rows, n_state] */
   int32_t ld_kv, kv_bf16, n_state, pad_;
   float clamp_lo, clamp_hi;
+  /* sim_state != NULL (round 6; with it `prep_*`): behind its logits the row's workgroup also runs the NEXT step of its light -
+   * tbx_sim_step_tl_prep(sim_state, sim_parts = TBX_SIM_LIGHTS [| TBX_SIM_ADVANCE], ...) for that light alone (dynamics.py:143-163,
+   * traffic_bots.py:123-143, traffic_light.py:219-226; rows = sim_state's n_batch * n_tl lights, logits_out = its tl_logits): a light's
+   * step reads nothing of another light's, so the launch that opened every step of the lights' recurrence is the tail of the launch
+   * that produced its logits (the agents' counterpart: tbx_heads_tail_t.sim_state). */
+  int32_t sim_parts, prep_ld_attr;
+  const struct tbx_sim_state* sim_state;
+  float* prep_attr;                      /* [rows * window, prep_ld_attr] */
+  uint8_t* prep_row_invalid;             /* [rows * window] */
 } tbx_tl_tail_t;
 
 typedef struct tbx_dec_layer {
@@ -253,6 +262,11 @@ typedef struct tbx_dec_layer {
   const tbx_tl_tail_t* lights; /* host pointer or NULL; only with qkv_out == NULL, heads == NULL and tail_mfma32 */
 } tbx_dec_layer_t;
 int tbx_knarpe_dec_layer(const tbx_dec_layer_t* args /* host */, void* stream);
+/* TWO independent row sets as ONE launch (round 6): layer l of the agents' block and layer l of the lights' block of a closed-loop step
+ * (the lights run one step ahead of the agents and read nothing of theirs) - n_a + n_b one-row workgroups on one queue instead of two
+ * launches on two queues joined at every step. Both must be tail_mfma32 calls of the same kind (tail_mfma32 value, table element type,
+ * relative-pose segments); either may carry its tail (heads / lights). Same results as the two single launches, bit for bit. */
+int tbx_knarpe_dec_layer_pair(const tbx_dec_layer_t* a /* host */, const tbx_dec_layer_t* b /* host */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * tbx_layer_tile: the row-local part of a transformer layer for LARGE launches (>= ~1000 rows; 16-row tiles, one launch) -
@@ -399,6 +413,9 @@ typedef struct tbx_front {
   int32_t n_jobs, pe_dim;
 } tbx_front_t;
 int tbx_front(const tbx_front_t* args /* host */, void* stream);
+/* The agents' tbx_front (d_mlp 64, "cat") and the lights' (d_mlp 128, "add") of one closed-loop step as ONE launch (round 6; with
+ * tbx_knarpe_dec_layer_pair the step runs on one queue). Same results as the two launches, bit for bit. */
+int tbx_front_pair(const tbx_front_t* agents /* host */, const tbx_front_t* lights /* host */, void* stream);
 
 /* tbx_tall_linear: y [m, n] = x [m, k] W^T (+ b) (optionally relu) over very many rows - the forward / input-gradient products of
  * training's time-batched pass - on the split-bf16 matrix path (< 3e-5 of sum |x||w| per output): image = tbx_pack_weight_mfma32 of

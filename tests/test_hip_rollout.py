@@ -332,6 +332,62 @@ def test_fused_step_tail_is_bit_identical(tb, sizes, knn):
             assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
 
 
+@pytest.mark.parametrize("sizes,knn,K,reduced", [((8, 64, 8), 4, 1, False), ((64, 1024, 128), 32, 1, False), ((16, 64, 8), 4, 4, False),
+                                                 ((64, 1024, 128), 32, 1, True)])
+def test_one_queue_step_is_bit_identical(tb, sizes, knn, K, reduced):
+    """Schedule.one_queue: the closed-loop step as five PAIRED launches on one queue (tbx_front_pair, tbx_knarpe_dec_layer_pair: the
+    lights' and the agents' workgroups of a stage in one grid; the lights' tbx_sim_step in the tail of their last layer,
+    tbx_tl_tail_t.sim_state) instead of two queues joined at every step. The same device functions on the same operands: the whole
+    rollout log - light states and their NLL included - must not differ by a bit from the two-stream step's, eager and as graphs,
+    teacher-forced and free steps, with K rollouts sharing a scene's lights, and again on the cached engine (restore / refill re-prime
+    the lights' first pass AND their first update). reduced: under the bf16-arithmetic schedule (Schedule.reduced(): bfloat16 tables, one
+    bf16 product per LINEAR - dec_layer_mf1_pair_kernel)."""
+    dev = torch.device("cuda:0")
+    wm, P, b, bd = _setup(tb, dev, sizes, knn)
+    E = import_module("trafficbots_amd.engine")
+    D = import_module("trafficbots_amd.models.modules.distributions")
+    base = E.DEFAULT.reduced() if reduced else E.DEFAULT
+    n, A = bd["sc/ag_valid"].shape[:2]
+    mp, tl1 = wm.encode_scene(bd, tl_valid_key="gt/tl_valid")
+    z = torch.randn(1, sizes[0], 16, generator=torch.Generator().manual_seed(6)).to(dev)
+    valid = bd["gt/ag_valid"].any(-1)
+    onehot = torch.nn.functional.one_hot(bd["gt/ag_navi"], bd["sc/mp_valid"].shape[1]).float()
+    wm.hp.joint_future_pred_deterministic_k0 = False
+
+    def run(use_graph):
+        if K == 1:
+            return wm.reactive_replay(bd, mp, tl1, z, valid, bd["gt/ag_navi"], valid, wm.teacher_forcing_joint_future_pred, True, step_end=30,
+                                      use_graph=use_graph)
+        torch.manual_seed(5)  # (the K latent samples of a scene differ from each other, and are the same in every variant)
+        lat = D.DiagGaussian(torch.zeros(n, A, 16, device=dev), torch.zeros(16, device=dev), valid=bd["sc/ag_valid"].any(-1))
+        nav = D.DestCategorical(probs=onehot, valid=bd["sc/ag_valid"].any(-1))
+        _, tl = wm.encode_scene(bd, n_rollout=K)
+        return wm.joint_future_pred(bd, mp, tl, lat, nav, wm.teacher_forcing_joint_future_pred, K, step_end=30, use_graph=use_graph)
+
+    outs, used = {}, {}
+    for one in (False, True):
+        for use_graph in (False, True):
+            wm.schedule = base.replace(one_queue=one)
+            outs[one, use_graph] = run(use_graph)
+            used[one, use_graph] = wm._engine.one_queue
+            if one and use_graph:  # the same (cached) engine again
+                again = run(use_graph)
+                assert torch.equal(again.pred_pose, outs[one, use_graph].pred_pose)
+                assert torch.equal(again.vis_dict["tl_state"], outs[one, use_graph].vis_dict["tl_state"])
+    assert used == {(False, False): False, (False, True): False, (True, False): True, (True, True): True}, used
+    ref = outs[False, False]
+    for k, o in outs.items():
+        for name in ("pred_pose", "pred_valid", "pred_motion", "action_log_prob", "mask_teacher_forcing", "tl_state_nll"):
+            if getattr(ref, name, None) is not None:
+                assert torch.equal(getattr(o, name), getattr(ref, name)), (k, name)
+        for name in ("action", "tl_state"):
+            assert torch.equal(o.vis_dict[name], ref.vis_dict[name]), (k, name)
+        for name in ref.violation:
+            assert torch.equal(o.violation[name], ref.violation[name]), (k, name)
+        for name in ref.diffbar_reward:
+            assert torch.equal(o.diffbar_reward[name], ref.diffbar_reward[name]), (k, name)
+
+
 @pytest.mark.parametrize("sizes,knn", [((8, 64, 8), 4), ((64, 1024, 128), 32)])
 def test_front_without_rider_fills_the_navigation_embedding(tb, sizes, knn):
     """tbx_front without the navigation rider and without an auxiliary stream (Schedule(lights_ahead=False, navi_rider=False): the

@@ -155,7 +155,8 @@ def attn_algorithmic_bytes(n_src_rows: int, n_pairs: int, b: int = 4) -> float:
 class KernelEvents:
     """Brackets every launch of the hot path's kernel classes with HIP events on the launch stream and keeps, per class, the
     algorithmic bytes (HBM-bound classes) or flops (MFMA-bound classes) of each launch:
-      dec_layer  tbx_knarpe_dec_mid / tbx_knarpe_dec_layer (dec_layer_mf_kernel / dec_mid_kernel: a whole decoder layer, or its attention half)
+      dec_layer  tbx_knarpe_dec_mid / tbx_knarpe_dec_layer (dec_layer_mf_kernel / dec_mid_kernel: a whole decoder layer, or its attention half);
+                 tbx_knarpe_dec_layer_pair (dec_layer_mf_pair_kernel: the agents' and the lights' rows of a layer in one launch, Schedule.one_queue)
       attn       tbx_knarpe_attn_* (knarpe_attn_kernel), grouped by source rows
       chain      tbx_rowchain / tbx_rowchain_ex (rowchain_kernel<MT,..>: MFMA row chains), grouped by tile rows
       chain_live tbx_rowchain_live (rowchain_kernel<0,1,0,1>: thread-per-column chains of small launches)
@@ -163,13 +164,14 @@ class KernelEvents:
       other      K-nearest searches, preparation, tbx_sim_step (elementwise / latency)"""
 
     WRAPPED = ("knarpe_attn", "knarpe_attn_mfma", "knarpe_dec_mid", "knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed",
-               "layer_tile", "heads_tile", "window_tile", "front", "pair_embed")
+               "layer_tile", "heads_tile", "window_tile", "front", "pair_embed", "launch_dec_layer_pair", "launch_front_pair")
 
     def __init__(self, hip):
         self.hip, self.rec = hip, {}
         self.extra = {}  # (class, key) -> per-launch bytes a launch must move beyond its algorithmic (SURVEY 8d) bytes
         self.dec_kernel = "dec_layer_mf_kernel"
         self._saved = {}
+        self.half = {}  # id(deferred launch descriptor) -> the work of that half of a paired launch (Schedule.one_queue)
 
     def _time(self, cls, key, work, fn, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -202,7 +204,18 @@ class KernelEvents:
             b = 2 * attn_algorithmic_bytes(rows, 0, eb) + pairs * (2 * 128 * eb + 17)
             self.extra.setdefault(("dec_layer", rows), []).append(w + rows * (128 * 4 * 2 + (896 * 4 if tail and tail.get("qkv_out") is not None else 0)))
             self.dec_kernel = "dec_layer_mf1_kernel" if (tail is not None and tail.get("mfma32") == 2) else ("dec_layer_mf_kernel" if (tail is not None and tail.get("mfma32")) else "dec_mid_kernel")
+            if hip.hip_base.DEFERRED is not None:  # Schedule.one_queue: the call only describes its half of a PAIRED launch (pair_mid below times it)
+                sv["knarpe_dec_mid"](*args, **kw)
+                self.half[id(hip.hip_base.DEFERRED[-1])] = (rows, b, self.extra[("dec_layer", rows)].pop())
+                return None
             return T("dec_layer", rows, b, sv["knarpe_dec_mid"], *args, **kw)
+
+        def pair_mid(a_, b_):
+            # tbx_knarpe_dec_layer_pair: ONE launch = the agents' rows + the lights' rows of a layer - the 8d bytes of both halves
+            (ra, wa, xa), (rb, wb_, xb) = self.half.pop(id(a_)), self.half.pop(id(b_))
+            self.extra.setdefault(("dec_layer", ra + rb), []).append(xa + xb)
+            self.dec_kernel = self.dec_kernel.replace("_kernel", "_pair_kernel") if "_pair_" not in self.dec_kernel else self.dec_kernel
+            return T("dec_layer", ra + rb, wa + wb_, sv["launch_dec_layer_pair"], a_, b_)
 
         def attn(qbuf, q_off, qt_off, bias, n_batch, n_src, segs, out, flag, *freqs, **kw):
             eb = 2 if segs[0].kv.dtype == torch.bfloat16 else 4
@@ -242,7 +255,14 @@ class KernelEvents:
             add = bool(window.get("add_mode"))
             mac_w = (32 * 128 + 2 * 128 * 128 if add else 32 * 64 + 2 * 64 * 64) + 3 * 128 * 64
             fl = 2.0 * window["attr"].shape[0] * mac_w + 2.0 * rows * (128 * 384 + 128 * 128) + (0.0 if rider is None else 2.0 * rider["out"].shape[0] * 4 * 128 * 128)
+            if hip.hip_base.DEFERRED is not None:  # (Schedule.one_queue: one half of tbx_front_pair)
+                r = sv["front"](window, proj, rider=rider, jobs=jobs, pose_embed_job=pose_embed_job)
+                self.half[id(hip.hip_base.DEFERRED[-1])] = fl
+                return r
             return T("tile", "front", fl, sv["front"], window, proj, rider=rider, jobs=jobs, pose_embed_job=pose_embed_job)
+
+        def pair_fr(a_, b_):
+            return T("tile", "front_pair", self.half.pop(id(a_)) + self.half.pop(id(b_)), sv["launch_front_pair"], a_, b_)
 
         def other(name):
             return lambda *a, **kw: T("other", name, 0.0, sv[name], *a, **kw)
@@ -251,6 +271,8 @@ class KernelEvents:
         if "knarpe_attn_mfma" in sv:
             hip.knarpe_attn_mfma = attn_m
         hip.layer_tile, hip.heads_tile, hip.window_tile, hip.front = lt, ht, wt, fr
+        if "launch_dec_layer_pair" in sv:
+            hip.launch_dec_layer_pair, hip.launch_front_pair = pair_mid, pair_fr
         for n in ("knn_embed", "knn_embed_multi", "agent_prep", "tl_prep", "sim_step", "pose_embed", "pair_embed"):
             if n in sv:
                 setattr(hip, n, other(n))
@@ -304,7 +326,7 @@ def kernel_entry(args, c, products: int = 3):
     elif cls in ("chain", "chain_live", "tile"):
         ach = c["work"] / c["t"] / 1e12
         if cls == "tile":
-            name = "front_kernel" if key == "front" else f"tile_{key}_kernel"  # (tbx_front: window tile + first projection + searches)
+            name = {"front": "front_kernel", "front_pair": "front_pair_kernel"}.get(key, f"tile_{key}_kernel")  # (tbx_front: window tile + first projection + searches)
             pre = [name]
         else:
             name = "rowchain_kernel" + ("<live>" if cls == "chain_live" else f"<{key}-row tiles>")

@@ -268,7 +268,9 @@ def measure(a, tb, hip, dev, rank, world, dist):
                 "scenes_per_gpu": a.scenes, "rollouts_per_scene": a.rollouts, "graph": use_graph,
                 "steps_per_graph_replay": gsteps if use_graph else 0,
                 "pre_roll_rollouts": n_pre,  # untimed whole-rollout replays before the W warm-up steps (device at steady clocks)
-                "lights_one_step_ahead_on_second_stream": not a.no_lights_ahead, "attn_mfma": wm.schedule.attn_mfma,
+                "lights_one_step_ahead_on_second_stream": (not a.no_lights_ahead) and not eng.one_queue,
+                "one_queue_paired_launches": bool(eng.one_queue),  # Schedule.one_queue: 5 paired launches per step, the lights one step ahead in the same grids
+                "attn_mfma": wm.schedule.attn_mfma,
                 "weights": "random init of the 10,657,094-parameter default architecture"}
     if a.profile_steps <= 0:  # tooling only (timeline traces, A/B runs, the scenes-per-GPU curve): no per-kernel timing pass
         return {**timing, "config": workload, "roofline": None, "kernels": None,
@@ -278,7 +280,9 @@ def measure(a, tb, hip, dev, rank, world, dist):
     # ---- live per-kernel timing: eager steps right after the timed region, same state and the SAME launches as the timed
     # schedule, events on the launch stream, in the engine's one-stream order so that a kernel's duration is its own (in the
     # timed region the light and agent halves share the device, which stretches the kernels of both)
-    eng.sched = eng.sched.replace(lights_ahead=False)
+    # (a one-queue engine already IS one stream: its paired launches are timed as they run in the timed region)
+    if not eng.one_queue:
+        eng.sched = eng.sched.replace(lights_ahead=False)
     # the host must be AHEAD of the device while the events are recorded: an event pair around a launch otherwise also
     # times the wait for the host to enqueue that launch (seen on a loaded box: 27 us "launches" of a 10 us kernel).
     # A device-side delay in front lets the host queue all launches of the profiled steps first.

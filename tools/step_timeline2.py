@@ -20,6 +20,8 @@ if len(idx) >= 4:
     step = rows[a + 1:b + 1]
 else:  # Schedule.fused_tail: the agents' step runs inside the last decoder layer's launch - a step = one searches' launch to the next
     idx = [i for i, r in enumerate(rows) if "knn_multi_kernel" in r[0]]
+    if len(idx) < 4:  # Schedule.one_queue: no lights' tbx_sim_step either - a step = one tbx_front_pair launch to the next
+        idx = [i for i, r in enumerate(rows) if "front_pair_kernel" in r[0]]
     a, b = idx[-4], idx[-3]
     step = rows[a:b]
 t0 = step[0][1]

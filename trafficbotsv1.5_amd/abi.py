@@ -90,7 +90,8 @@ class TlTail(C.Structure):
     _fields_ = [("kv_images", C.c_void_p * 4), ("norm_weight", C.c_void_p * 4), ("norm_bias", C.c_void_p * 4), ("norm_eps", C.c_float * 4),
                 ("kv_out", C.c_void_p), ("mlp_images", C.c_void_p * 3), ("tl_invalid", C.c_void_p), ("logits_out", C.c_void_p),
                 ("ld_kv", C.c_int32), ("kv_bf16", C.c_int32), ("n_state", C.c_int32), ("pad_", C.c_int32),
-                ("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
+                ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("sim_parts", C.c_int32), ("prep_ld_attr", C.c_int32),
+                ("sim_state", C.c_void_p), ("prep_attr", C.c_void_p), ("prep_row_invalid", C.c_void_p)]
 
 
 class LayerTile(C.Structure):
@@ -256,6 +257,8 @@ def load():
     lib.tbx_heads_tile_bf16.argtypes = [C.POINTER(HeadsTile), vp]
     lib.tbx_window_tile_bf16.argtypes = [C.POINTER(WindowTile), vp]
     lib.tbx_front.argtypes = [C.POINTER(Front), vp]
+    lib.tbx_front_pair.argtypes = [C.POINTER(Front), C.POINTER(Front), vp]
+    lib.tbx_knarpe_dec_layer_pair.argtypes = [C.POINTER(DecLayer), C.POINTER(DecLayer), vp]
     lib.tbx_tall_linear.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp]
     lib.tbx_tall_linear_bf16.argtypes = lib.tbx_tall_linear.argtypes
     lib.tbx_tall_linear_dual.argtypes = [vp, C.c_int64, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, vp]
@@ -287,7 +290,7 @@ def load():
     lib.tbx_attn_fold_bwd.argtypes = [vp] * 19
     lib.tbx_rule_navi_check.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_linear_wgrad_bf16", "tbx_tall_linear_bf16", "tbx_tl_tail_tile", "tbx_tl_tail_tile_bf16", "tbx_tall_linear_dual", "tbx_tall_linear_dual_bf16", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_fwd_windows", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
-                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd", "tbx_tall_linear_relu_drop", "tbx_tall_linear_relu_drop_bf16",
+                 "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd", "tbx_tall_linear_relu_drop", "tbx_tall_linear_relu_drop_bf16", "tbx_front_pair", "tbx_knarpe_dec_layer_pair",
                  "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma", "tbx_knarpe_attn_fwd_mfma_dropout_tb"):
         getattr(lib, name).restype = C.c_int
     if lib.tbx_version() != 3:

@@ -71,6 +71,10 @@ struct MidArgs {
   tbx_agent_prep_args_t prep;
   // the lights' tail (tbx_tl_tail_t): tl.kv_out != NULL
   tbx_tl_tail_t tl;
+  // ... with the row's light stepped behind its logits (tbx_tl_tail_t.sim_state, round 6: the paired launches of a closed-loop step):
+  // `sim` / `sim_parts` above hold the LIGHTS' state then (a launch's rows are agents or lights), tl_prep the tbx_tl_prep rows of its new window
+  int tl_sim;
+  tbx_step::TlPrepArgs tl_prep;
 };
 
 #ifdef TBX_STAGE_CLOCK
@@ -528,17 +532,29 @@ __global__ __launch_bounds__(NW * 64) void dec_mid_kernel(const MidArgs a) {
 // 14..21 k, v of the agents' 4 layers, 22..24 the next-state predictor, or nothing.
 #define TBX_MF_NS mf
 #define TBX_MF_KERNEL dec_layer_mf_kernel
+#define TBX_MF_BODY dec_layer_mf_body
+#define TBX_MF_PAIR_KERNEL dec_layer_mf_pair_kernel
+#define TBX_MF_PAIR_ARGS MidPair
 #define TBX_MF_SINGLE 0
 #include "dec_layer_mf.inc"
 #undef TBX_MF_NS
 #undef TBX_MF_KERNEL
+#undef TBX_MF_BODY
+#undef TBX_MF_PAIR_KERNEL
+#undef TBX_MF_PAIR_ARGS
 #undef TBX_MF_SINGLE
 #define TBX_MF_NS mf1
 #define TBX_MF_KERNEL dec_layer_mf1_kernel
+#define TBX_MF_BODY dec_layer_mf1_body
+#define TBX_MF_PAIR_KERNEL dec_layer_mf1_pair_kernel
+#define TBX_MF_PAIR_ARGS MidPair1
 #define TBX_MF_SINGLE 1
 #include "dec_layer_mf.inc"
 #undef TBX_MF_NS
 #undef TBX_MF_KERNEL
+#undef TBX_MF_BODY
+#undef TBX_MF_PAIR_KERNEL
+#undef TBX_MF_PAIR_ARGS
 #undef TBX_MF_SINGLE
 
 int check_seg(const tbx_attn_seg_t& s, const float* fxy, const float* fyaw) {
@@ -564,7 +580,8 @@ extern "C" int tbx_knarpe_dec_layer(const tbx_dec_layer_t* t, void* stream) {
     if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
   return dec_launch(&t->mid, t, stream);
 }
-static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* stream) {
+// the launch descriptor of a tbx_knarpe_dec_mid / tbx_knarpe_dec_layer call (validated); rel = every segment as relative poses
+static int dec_fill(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, MidArgs& a, bool& rel) {
   if (!p || !p->qkv || !p->x || (!t && (!p->out2 || !p->flag2)) || !p->rpe_k_bias_self || !p->rpe_k_bias_cross || !p->ln_weight || !p->ln_bias ||
       !p->fold_self_image || !p->out_proj_image || !p->q_image || !p->qfold_image || !p->fold_cross_image)
     return TBX_ERR_ARG;
@@ -574,7 +591,6 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
                       p->rpe_k_bias_self, p->rpe_k_bias_cross};
   for (const void* q : al)
     if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
-  MidArgs a;
   int rc = check_seg(p->self_seg, p->freqs_xy, p->freqs_yaw);
   if (rc != TBX_OK) return rc;
   int ktot = 0;
@@ -606,6 +622,8 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   memset(&a.sim, 0, sizeof(a.sim));
   memset(&a.prep, 0, sizeof(a.prep));
   memset(&a.tl, 0, sizeof(a.tl));
+  a.tl_sim = 0;
+  memset(&a.tl_prep, 0, sizeof(a.tl_prep));
   if (t) {
     a.wo2 = t->out_proj2_image, a.w1 = t->linear1_image, a.w2 = t->linear2_image, a.wqkv = t->next_in_proj_image, a.wqt = t->next_qfold_image;
     a.ln2_w = t->norm2_weight, a.ln2_b = t->norm2_bias, a.ln3_w = t->next_norm_weight, a.ln3_b = t->next_norm_bias;
@@ -641,8 +659,27 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
       if (!L.kv_out || !L.tl_invalid || !L.logits_out || L.ld_kv < 8 * D || (L.ld_kv % 4) || L.n_state <= 0 || L.n_state > 16) return TBX_ERR_ARG;
       if (((uintptr_t)L.kv_out) & 15) return TBX_ERR_ALIGN;
       a.tl = L;
+      if (L.sim_state != nullptr) {  // the light's own step behind its logits
+        a.sim = *L.sim_state, a.sim_parts = L.sim_parts, a.tl_sim = 1;
+        if ((a.sim_parts & ~(TBX_SIM_ADVANCE | TBX_SIM_NO_APPEND)) != TBX_SIM_LIGHTS) return TBX_ERR_ARG;
+        if (a.sim.n_batch * a.sim.n_tl != a.n_rows || a.sim.tl_logits != L.logits_out || L.n_state != 5) return TBX_ERR_ARG;
+        if (!a.sim.step || !a.sim.tl_state || !a.sim.hist_tl || !a.sim.tl_gt || !a.sim.out_tl_state) return TBX_ERR_ARG;
+        if (!L.prep_attr || !L.prep_row_invalid || L.prep_ld_attr < 16 || (L.prep_ld_attr % 4) || (((uintptr_t)L.prep_attr) & 15)) return TBX_ERR_ARG;
+        a.tl_prep = tbx_step::TlPrepArgs{L.tl_invalid, L.prep_attr, L.prep_row_invalid, L.prep_ld_attr};
+      }
     }
   }
+  a.tail_mfma = t ? t->tail_mfma32 : 0;
+  rel = p->self_seg.emb == nullptr;
+  for (int i = 0; i < p->n_cross; ++i) rel = rel && p->cross_seg[i].emb == nullptr;
+  return TBX_OK;
+}
+
+static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* stream) {
+  MidArgs a;
+  bool rel = false;
+  const int rc_fill = dec_fill(p, t, a, rel);
+  if (rc_fill != TBX_OK) return rc_fill;
   const size_t lds_bytes = (size_t)(IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float);
   static_assert((IMG128 + IMGKF + 4 * RED + OUTW + 8 * D) * sizeof(float) <= 160 * 1024, "LDS budget");
   hipStream_t hs = (hipStream_t)stream;
@@ -651,9 +688,6 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
     (void)hipFuncSetAttribute((const void*)dec_mid_kernel<KV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     hipLaunchKernelGGL((dec_mid_kernel<KV, NWV>), dim3(a.n_rows), dim3(NWV * 64), lds_bytes, hs, a);                              \
   } while (0)
-  a.tail_mfma = t ? t->tail_mfma32 : 0;
-  bool rel = p->self_seg.emb == nullptr;
-  for (int i = 0; i < p->n_cross; ++i) rel = rel && p->cross_seg[i].emb == nullptr;
   if (t && a.tail_mfma == 2 && p->self_seg.kv_bf16 != 0) {  // one bf16 product per LINEAR (bf16 tables only: the bf16-arithmetic schedule)
     if (rel) hipLaunchKernelGGL((dec_layer_mf1_kernel<true, true>), dim3(a.n_rows), dim3(512), 0, hs, a);
     else hipLaunchKernelGGL((dec_layer_mf1_kernel<true, false>), dim3(a.n_rows), dim3(512), 0, hs, a);
@@ -675,6 +709,46 @@ static int dec_launch(const tbx_dec_mid_t* p, const tbx_dec_layer_t* t, void* st
   else
     TBX_MID_LAUNCH(false, 4);
 #undef TBX_MID_LAUNCH
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_knarpe_dec_layer_pair(const tbx_dec_layer_t* ta, const tbx_dec_layer_t* tb, void* stream) {
+  if (!ta || !tb) return TBX_ERR_ARG;
+  for (const tbx_dec_layer_t* t : {ta, tb}) {  // (tbx_knarpe_dec_layer's own checks)
+    if (!t->out_proj2_image || !t->linear1_image || !t->linear2_image || !t->norm2_weight || !t->norm2_bias || !t->src_invalid) return TBX_ERR_ARG;
+    if (t->qkv_out && (!t->next_in_proj_image || !t->next_qfold_image || !t->next_norm_weight || !t->next_norm_bias || t->ld_qkv_out < 7 * D ||
+                       (t->ld_qkv_out % 4)))
+      return TBX_ERR_ARG;
+    if ((t->mid.self_seg.kv_bf16 != 0) != (t->kv16_out != nullptr) && t->qkv_out) return TBX_ERR_ARG;
+    const void* al[] = {t->out_proj2_image, t->linear1_image, t->linear2_image, t->next_in_proj_image, t->next_qfold_image, t->qkv_out};
+    for (const void* q : al)
+      if (((uintptr_t)q) & 15) return TBX_ERR_ALIGN;
+    if (!t->tail_mfma32) return TBX_ERR_UNSUPPORTED;  // the paired form exists for the matrix-path layer only
+  }
+  MidPair p;
+  static_assert(sizeof(MidPair) == sizeof(MidPair1), "one argument block for both product counts");
+  bool rel_a = false, rel_b = false;
+  int rc = dec_fill(&ta->mid, ta, p.m[0], rel_a);
+  if (rc != TBX_OK) return rc;
+  rc = dec_fill(&tb->mid, tb, p.m[1], rel_b);
+  if (rc != TBX_OK) return rc;
+  const bool kv16 = ta->mid.self_seg.kv_bf16 != 0;
+  if (rel_a != rel_b || kv16 != (tb->mid.self_seg.kv_bf16 != 0) || ta->tail_mfma32 != tb->tail_mfma32) return TBX_ERR_UNSUPPORTED;
+  if (ta->tail_mfma32 == 2 && !kv16) return TBX_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(p.m[0].n_rows + p.m[1].n_rows));
+  hipStream_t hs = (hipStream_t)stream;
+  if (ta->tail_mfma32 == 2) {
+    MidPair1 q;
+    memcpy(&q, &p, sizeof(q));
+    if (rel_a) hipLaunchKernelGGL((dec_layer_mf1_pair_kernel<true, true>), grid, dim3(512), 0, hs, q);
+    else hipLaunchKernelGGL((dec_layer_mf1_pair_kernel<true, false>), grid, dim3(512), 0, hs, q);
+  } else if (kv16) {
+    if (rel_a) hipLaunchKernelGGL((dec_layer_mf_pair_kernel<true, true>), grid, dim3(512), 0, hs, p);
+    else hipLaunchKernelGGL((dec_layer_mf_pair_kernel<true, false>), grid, dim3(512), 0, hs, p);
+  } else {
+    if (rel_a) hipLaunchKernelGGL((dec_layer_mf_pair_kernel<false, true>), grid, dim3(512), 0, hs, p);
+    else hipLaunchKernelGGL((dec_layer_mf_pair_kernel<false, false>), grid, dim3(512), 0, hs, p);
+  }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

@@ -93,9 +93,7 @@ __device__ __forceinline__ void proj_rows(const tbx_layer_tile_t& t, const int b
 }
 
 template <int DM, bool ADD>
-__global__ __launch_bounds__(NT) void front_kernel(const FrontArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char lds_c[];
-  int b = (int)blockIdx.x;
+__device__ __forceinline__ void front_body(const FrontArgs& a, int b, char* lds_c) {
   if (b < a.n_win_blocks) {
     float* pooled = (float*)(lds_c + POOL_OFF);
     tbx_window::window_body<DM, ADD>(a.win, b, lds_c, pooled);
@@ -114,9 +112,30 @@ __global__ __launch_bounds__(NT) void front_kernel(const FrontArgs a) {
   if (threadIdx.x < 256) tbx_knn::knn_multi_body(a.knn, b);
 }
 
-}  // namespace
+template <int DM, bool ADD>
+__global__ __launch_bounds__(NT) void front_kernel(const FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_c[];
+  front_body<DM, ADD>(a, (int)blockIdx.x, lds_c);
+}
 
-extern "C" int tbx_front(const tbx_front_t* args, void* stream) {
+// The agents' front ("cat" input encoder, d_mlp 64) and the lights' ("add", d_mlp 128) of one closed-loop step as ONE launch (round 6,
+// with tbx_knarpe_dec_layer_pair: the step on one queue): blocks [0, n_a) run the first, the rest the second - the two read nothing of
+// each other's (the lights run one step ahead).
+// Block order: the lights' blocks (all window blocks, the launch's longest) first, then the agents' (windows, rider, and last their
+// K-nearest searches - the short ones): at configs[1] the grid is 64 + 228 = 292 workgroups on 256 CUs with one workgroup per CU (LDS),
+// so the last 36 to start must be short ones (agents first, the lights' last 36 window blocks waited for a CU: the launch 13 -> 20 us).
+struct FrontPair {
+  FrontArgs a, b;
+  int n_b;
+};
+__global__ __launch_bounds__(NT) void front_pair_kernel(const FrontPair p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_c[];
+  if ((int)blockIdx.x < p.n_b) front_body<128, true>(p.b, (int)blockIdx.x, lds_c);
+  else front_body<64, false>(p.a, (int)blockIdx.x - p.n_b, lds_c);
+}
+
+// tbx_front's checks + the launch descriptor; blocks = its workgroups
+static int front_fill(const tbx_front_t* args, FrontArgs& a, int& blocks) {
   if (args == nullptr) return TBX_ERR_ARG;
   const tbx_window_tile_t& w = args->win;
   const tbx_layer_tile_t& t = args->layer;
@@ -144,7 +163,6 @@ extern "C" int tbx_front(const tbx_front_t* args, void* stream) {
       if (t.rider_images[i] == nullptr) return TBX_ERR_ARG;
     if ((((uintptr_t)t.rider_in) | ((uintptr_t)t.rider_add) | ((uintptr_t)t.rider_out)) & 15) return TBX_ERR_ALIGN;
   }
-  FrontArgs a;
   a.win = w, a.lt = t;
   a.n_win_blocks = (int)((w.n_groups + tbx_window::RT - 1) / tbx_window::RT);
   a.n_rider_blocks = (int)((t.rider_rows + 15) / 16);
@@ -158,13 +176,43 @@ extern "C" int tbx_front(const tbx_front_t* args, void* stream) {
   } else if (args->pe != nullptr) {
     return TBX_ERR_ARG;
   }
+  blocks = a.n_win_blocks + a.n_rider_blocks + a.n_knn_blocks;
+  return TBX_OK;
+}
+
+static bool front_lds_attr() {
   static tbx::PerDeviceOnce lds_attr;  // (per device, thread-safe: tbx_common.h)
-  if (!lds_attr([&] { return !(hipFuncSetAttribute((const void*)front_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)front_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); })) return TBX_ERR_LAUNCH;
-  const dim3 grid((unsigned)(a.n_win_blocks + a.n_rider_blocks + a.n_knn_blocks));
-  if (w.d_mlp == 64)
+  return lds_attr([&] { return !(hipFuncSetAttribute((const void*)front_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)front_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)front_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess); });
+}
+
+}  // namespace
+
+extern "C" int tbx_front(const tbx_front_t* args, void* stream) {
+  FrontArgs a;
+  int blocks = 0;
+  const int rc = front_fill(args, a, blocks);
+  if (rc != TBX_OK) return rc;
+  if (!front_lds_attr()) return TBX_ERR_LAUNCH;
+  const dim3 grid((unsigned)blocks);
+  if (args->win.d_mlp == 64)
     hipLaunchKernelGGL((front_kernel<64, false>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((front_kernel<128, true>), grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_front_pair(const tbx_front_t* agents, const tbx_front_t* lights, void* stream) {
+  FrontPair p;
+  int na = 0, nb = 0;
+  int rc = front_fill(agents, p.a, na);
+  if (rc != TBX_OK) return rc;
+  rc = front_fill(lights, p.b, nb);
+  if (rc != TBX_OK) return rc;
+  if (agents->win.d_mlp != 64 || lights->win.d_mlp != 128) return TBX_ERR_UNSUPPORTED;  // ("cat" agents first, "add" lights second)
+  if (!front_lds_attr()) return TBX_ERR_LAUNCH;
+  p.n_b = nb;
+  hipLaunchKernelGGL(front_pair_kernel, dim3((unsigned)(na + nb)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

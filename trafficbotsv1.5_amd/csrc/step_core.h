@@ -279,6 +279,84 @@ __device__ __forceinline__ void sim_advance(const tbx_sim_state_t& s, const int 
   }
 }
 
+// tbx_tl_prep of the lights' new windows riding on their update (tbx_sim_step_tl_prep): a light's lanes write its own W rows
+struct TlPrepArgs {
+  const uint8_t* tl_invalid;  // NULL: off
+  float* attr;
+  uint8_t* row_invalid;
+  int ld_attr;
+};
+
+constexpr int LPT = 8;  // lanes per traffic light
+
+// One closed-loop step of light i by LPT lanes (lsub = 0..7 of one wavefront): Dynamics.override_tl (dynamics.py:143-163: argmax of the
+// predictor's logits -> one-hot, ground truth while it lasts), the log (state, NLL: waymo_motion.py:276-283), the window shift
+// (traffic_bots.py:123-143) and, with tp.tl_invalid, the tbx_tl_prep rows of the new window. Every lane repeats the light's few scalar
+// operations (broadcast loads), the lanes split the window's W entries. Shared by sim_step_kernel (csrc/sim.hip) and the lights' tail
+// of the one-launch decoder layer (csrc/dec_layer_mf.inc: the row's own light, right behind its logits).
+__device__ __forceinline__ void sim_light(const tbx_sim_state_t& s, const int parts, const int t, const int i, const int lsub, const TlPrepArgs& tp) {
+  const int T = s.n_step_out;
+  const int W = s.window;
+  const float* lg = s.tl_logits + (int64_t)i * 5;
+  int am = 0;
+  float best = lg[0];
+  for (int c = 1; c < 5; ++c)
+    if (lg[c] > best) {
+      best = lg[c];
+      am = c;
+    }
+  uint8_t st = (uint8_t)(1u << am);
+  if (s.ov_valid != nullptr) {
+    if (s.ov_tl_valid[i] != 0) st = s.ov_tl_state[i];
+  } else if (t < s.n_step_tl_gt) {
+    st = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+  }
+  if (lsub == 0) {
+    s.tl_state[i] = st;
+    if (t - 1 < T) s.out_tl_state[(int64_t)i * T + (t - 1)] = st;
+    if (s.out_tl_nll != nullptr && t - 1 < T) {
+      // -Categorical(logits).log_prob(gt) = logsumexp(logits) - logits[gt] (waymo_motion.py:276-283); 0 past the ground truth
+      float nll = 0.f;
+      if (t < s.n_step_tl_gt) {
+        const uint8_t gm = s.tl_gt[(int64_t)i * s.n_step_tl_gt + t];
+        const int gi = gm ? (__ffs((int)gm) - 1) : 0;
+        float se = 0.f;
+        for (int c = 0; c < 5; ++c) se += expf(lg[c] - best);
+        nll = (best + logf(se)) - lg[gi < 5 ? gi : 0];
+      }
+      s.out_tl_nll[(int64_t)i * T + (t - 1)] = nll;
+    }
+  }
+  // the window: entry w of the new window = old entry w + 1, the last one = the new state. Every lane loads its entries before
+  // any lane stores (the wavefront runs in lockstep; chunks of LPT go upwards, each reads only entries no earlier chunk wrote)
+  uint8_t* ht = s.hist_tl + (int64_t)i * W;
+  const bool append = (parts & TBX_SIM_NO_APPEND) == 0;
+  const bool tok_bad = tp.tl_invalid != nullptr && tp.tl_invalid[i] != 0;
+  for (int w0 = 0; w0 < W; w0 += LPT) {
+    const int w = w0 + lsub;
+    uint8_t hs = 0;
+    if (w < W) hs = append ? (w < W - 1 ? ht[w + 1] : st) : ht[w];
+    __builtin_amdgcn_wave_barrier();
+    if (w < W && append) ht[w] = hs;
+    __builtin_amdgcn_wave_barrier();
+    if (w < W && tp.tl_invalid != nullptr) {  // csrc/prep.hip tl_prep_kernel for row (i, w) of the window just written
+      const bool missing = hs == 0xFF;
+      const int64_t r = (int64_t)i * W + w;
+      for (int c0 = 0; c0 < tp.ld_attr; c0 += 4) {
+        float4 v;
+        float* vv = &v.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + q;
+          vv[q] = c < 5 ? ((!missing && ((hs >> c) & 1)) ? 1.f : 0.f) : (c - 5 == w ? 1.f : 0.f);
+        }
+        *(float4*)(tp.attr + r * tp.ld_attr + c0) = v;
+      }
+      tp.row_invalid[r] = (missing || tok_bad) ? 1 : 0;
+    }
+  }
+}
+
 typedef tbx_agent_prep_args_t AgentPrepArgs;  // (field order = tbx_agent_prep's parameter groups)
 
 // (contraction off: HIP's __fmul_rn / __fadd_rn are plain operators, and which of the two products the compiler fuses into the sum

@@ -99,6 +99,12 @@ class Schedule:
     # ---- RolloutEngine
     tl_prep_rides: bool = True  # tbx_tl_prep inside the lights' tbx_sim_step launch
     lights_ahead: bool = True   # False: the sequential order on one stream (tl encoder -> agents -> tbx_sim_step)
+    # Small launches (both blocks on the one-launch decoder layer: <= live_max light rows, <= live_max_agents agent rows): the step on ONE
+    # queue - the lights' and the agents' tbx_front as one launch (tbx_front_pair), their layer l as one launch (tbx_knarpe_dec_layer_pair),
+    # the lights' tbx_sim_step in the tail of their last layer (tbx_tl_tail_t.sim_state) as the agents' is (fused_tail): 5 launches per
+    # step and no cross-queue edge (the join of the two-stream form costs ~8 us per step: DESIGN.md 8.1). Same launches' arithmetic:
+    # bit-identical rollouts (tests/test_hip_rollout.py).
+    one_queue: bool = True
     # steps per multi-step graph (even; 1: off). A replay boundary costs a few us of idle device: 4 -> 197.9 k, 16 -> 199.4 k, 40 ->
     # 200.4 k agent-steps/s at the 64-agent scene. Capturing g steps costs g eager steps of host time, so the default suits an engine
     # that runs ONE 80-step rollout; a caller that replays an engine many times raises it (bench.py: 40).
@@ -157,6 +163,7 @@ class Schedule:
             pe_rides=on("TBX_PE_RIDES"),
             tl_prep_rides=on("TBX_TL_PREP_RIDES"),
             lights_ahead=on("TBX_LIGHTS_AHEAD"),
+            one_queue=on("TBX_ONE_QUEUE"),
             graph_steps=max(1, num("TBX_GRAPH_STEPS", 4) // 2 * 2),
             share_lights=on("TBX_SHARE_LIGHTS"),
             hoist_constants=os.environ.get("TBX_NO_HOIST") is None,

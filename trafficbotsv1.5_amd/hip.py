@@ -164,6 +164,41 @@ def knarpe_attn_mfma(qbuf, q_off: int, qt_off: int, n_batch: int, n_src: int, se
     _check(rc, "tbx_knarpe_attn_fwd_mfma")
 
 
+# ---- deferred launches (round 6: RolloutEngine's one-queue step). While a list is installed, tbx_front / tbx_knarpe_dec_layer calls
+# are not launched but appended to it as (entry point name, descriptor, objects the descriptor points into); the engine then pairs the
+# lights' list with the agents' and issues tbx_front_pair / tbx_knarpe_dec_layer_pair. Anything else launched meanwhile is an error of the
+# schedule (the pairing assumes the two lists ARE the step), so the other wrappers refuse to run while a list is installed.
+class defer:
+    """with hip.defer() as calls: tbx_front / tbx_knarpe_dec_layer wrappers append (entry point, argument struct, keep-alive) to `calls`
+    instead of launching (hip_base.DEFERRED); any other launch inside raises (hip_base.stream_ptr). The rollout engine's one-queue
+    step collects the lights' and the agents' halves this way and launches them pairwise (launch_front_pair, launch_dec_layer_pair)."""
+
+    def __enter__(self):
+        assert hip_base.DEFERRED is None, "deferred launch lists do not nest"
+        self.calls = []
+        hip_base.DEFERRED = self.calls
+        return self.calls
+
+    def __exit__(self, *exc):
+        hip_base.DEFERRED = None
+
+
+def launch_front_pair(agents, lights) -> None:
+    """agents / lights: ("tbx_front", Front, keep) entries of two deferred lists."""
+    assert agents[0] == lights[0] == "tbx_front"
+    _check(load().tbx_front_pair(C.byref(agents[1]), C.byref(lights[1]), stream_ptr()), "tbx_front_pair")
+
+
+def launch_dec_layer_pair(a, b) -> None:
+    assert a[0] == b[0] == "tbx_knarpe_dec_layer"
+    _check(load().tbx_knarpe_dec_layer_pair(C.byref(a[1]), C.byref(b[1]), stream_ptr()), "tbx_knarpe_dec_layer_pair")
+
+
+def launch_deferred(call) -> None:
+    """One deferred entry as its own launch (the unpaired remainder of a list)."""
+    _check(getattr(load(), call[0])(C.byref(call[1]), stream_ptr()), call[0])
+
+
 def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: Sequence[Seg], bias_self, bias_cross, ln, n_batch: int,
                    n_src: int, fold_self, out_proj, q_img, qfold, fold_cross, out2, flag2, freqs_xy=None, freqs_yaw=None, tail=None):
     """tbx_knarpe_dec_mid: folded self attention -> out-proj into x -> LN -> q -> W_k^T q -> folded cross attention, one launch.
@@ -186,6 +221,7 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     a.ld_qkv, a.q_off, a.qt_off, a.ld_out2 = qkv.stride(0), q_off, qt_off, (out2.stride(0) if out2 is not None else 0)
     a.n_cross, a.n_batch, a.n_src = len(cross_segs), n_batch, n_src
     if t is None:
+        assert hip_base.DEFERRED is None, "tbx_knarpe_dec_mid inside a deferred step"
         _check(load().tbx_knarpe_dec_mid(C.byref(a), stream_ptr()), "tbx_knarpe_dec_mid")
         return
     t.out_proj2_image, t.linear1_image, t.linear2_image = _ptr(tail["out_proj2"]), _ptr(tail["linear1"]), _ptr(tail["linear2"])
@@ -219,6 +255,9 @@ def knarpe_dec_mid(qkv, q_off: int, qt_off: int, x, self_seg: Seg, cross_segs: S
     if lt_ is not None:
         keep_l = tl_tail_struct(lt_, x.shape[0])
         t.lights = C.addressof(keep_l)
+    if hip_base.DEFERRED is not None:
+        hip_base.DEFERRED.append(("tbx_knarpe_dec_layer", t, (keep, keep_l, tail, cs)))
+        return
     _check(load().tbx_knarpe_dec_layer(C.byref(t), stream_ptr()), "tbx_knarpe_dec_layer")
 
 
@@ -239,6 +278,11 @@ def tl_tail_struct(lt_: dict, rows: int) -> "TlTail":
     assert lo.is_contiguous() and lo.shape[0] == rows
     keep_l.tl_invalid, keep_l.logits_out, keep_l.n_state = _cptr(lt_["tl_invalid"], torch.uint8), _ptr(lo, torch.float32), lo.shape[1]
     keep_l.clamp_lo, keep_l.clamp_hi = (float(v) for v in lt_["clamp"])
+    sim = lt_.get("sim")  # dict(state = SimState of the lights, parts, attr, row_invalid): the light's own step behind its logits
+    if sim is not None:
+        keep_l.sim_state, keep_l.sim_parts = C.addressof(sim["state"]), int(sim["parts"])
+        keep_l.prep_attr, keep_l.prep_ld_attr = _ptr(sim["attr"], torch.float32), sim["attr"].stride(0)
+        keep_l.prep_row_invalid = _ptr(sim["row_invalid"], torch.uint8)
     return keep_l
 
 
@@ -397,6 +441,9 @@ def front(window: dict, proj: dict, rider=None, jobs=None, pose_embed_job=None):
             pj = _pose_job(pose_embed_job)
             keep.append(pj)
             f.pe = C.addressof(pj)
+    if hip_base.DEFERRED is not None:
+        hip_base.DEFERRED.append(("tbx_front", f, (keep, window, proj, rider, jobs, outs)))
+        return outs
     _check(load().tbx_front(C.byref(f), stream_ptr()), "tbx_front")
     return outs
 
@@ -448,6 +495,7 @@ SIM_AGENTS, SIM_LIGHTS, SIM_ADVANCE, SIM_NO_DISABLE, SIM_NO_APPEND, SIM_APPEND =
 def sim_step(state: SimState, parts: int = SIM_AGENTS | SIM_LIGHTS | SIM_ADVANCE, tl_prep=None):
     """tl_prep = (tl_invalid u8 [n*L], attr f32 [n*L*W, ld], row_invalid u8 [n*L*W]): the lights' update also writes the tbx_tl_prep
     rows of their new windows (tbx_sim_step_tl_prep)."""
+    assert hip_base.DEFERRED is None, "tbx_sim_step inside a deferred step (the one-queue step runs the lights' update in their last layer's tail)"
     if tl_prep is not None:
         inv, attr, row_inv = tl_prep
         _check(load().tbx_sim_step_tl_prep(C.byref(state), parts, _cptr(inv, torch.uint8), attr.stride(0), _ptr(attr, torch.float32),

@@ -32,7 +32,12 @@ def _cptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
     return _ptr(t, dtype)
 
 
+DEFERRED = None  # hip.defer(): the list that collects launch descriptors instead of launching them
+
+
 def stream_ptr() -> int:
+    if DEFERRED is not None:  # a launch that has no deferred form inside a one-queue step would run out of order
+        raise RuntimeError("a kernel launch inside hip.defer() that is neither tbx_front nor tbx_knarpe_dec_layer")
     return torch.cuda.current_stream().cuda_stream
 
 

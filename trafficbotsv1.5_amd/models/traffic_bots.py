@@ -73,10 +73,12 @@ class TrafficBots(nn.Module):
         self.agent_policy(hist_valid, hist_pose, hist_motion, ag_attr6, ag_type_idx, ag_latent, latent_invalid, dest,
                           navi_valid_u8, tl_tokens, mp_tokens, tl_kv, out, rollout_consts=rollout_consts)
 
-    def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor], prepared=None) -> Tensor:
+    def tl_policy(self, hist_tl: Tensor, tl_tokens: Dict[str, Tensor], out: Dict[str, Tensor], prepared=None, tail_sim=None) -> Tensor:
         """The traffic-light half (traffic_bots.py:188-199): tl tokens of the window -> next-state logits in
         out['tl_logits'] and the per-layer K/V tables the agents' tl cross-attention reads (returned, out['tl_kv']).
-        Reads no agent state, so the rollout engine runs it one step ahead on its own stream."""
+        Reads no agent state, so the rollout engine runs it one step ahead on its own stream.
+        tail_sim = dict(state, parts, attr, row_invalid): the lights' NEXT tbx_sim_step (+ tbx_tl_prep of their new windows) in the tail of
+        the last layer's launch, behind the logits (tbx_tl_tail_t.sim_state: the rollout engine's one-queue step)."""
         n, L, _ = hist_tl.shape
         d = self.hidden_dim
         tl_inv = tl_tokens["tl_token_invalid_u8"]
@@ -103,7 +105,7 @@ class TrafficBots(nn.Module):
             return dict(kv_images=[pw(at.in_proj_weight[d:], at.in_proj_bias[d:]) for _, at in layers],
                         norms=[(nm.weight, nm.bias, nm.eps) for nm, _ in layers], kv_out=tl_kv,
                         mlp_images=[pw(lins[0].weight, lins[0].bias), pw(lins[1].weight, lins[1].bias), pw(w3, b3)], tl_invalid=tl_inv,
-                        logits_out=out["tl_logits"], clamp=(-3.0, 3.0))
+                        logits_out=out["tl_logits"], clamp=(-3.0, 3.0), sim=tail_sim)
 
         out["tl_feat"] = self.tl_encoder.encode(hist_tl, tl_tokens, tail=tl_tail, prepared=prepared, tail_mf=tl_tail_mf)  # prepared: TlEncoder.encode
         return tl_kv

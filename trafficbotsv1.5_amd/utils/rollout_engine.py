@@ -222,6 +222,7 @@ class RolloutEngine:
         self.graph = self.graph_multi = self.graph_prime = self.graph_refill = None
         self._prime_prepares = False
         self._tl_prep = None
+        self.one_queue = self._one_queue_ok(n, A, nl, L, stepwise)
         self.tl_kv = None  # two K/V table buffers of the light tokens: agents of step t read [t & 1], the lights' pass writes the other
         self.parity = 0
         self._prep_ready = False  # this step's tbx_agent_prep already ran in the previous step's fused tail (step())
@@ -442,14 +443,30 @@ class RolloutEngine:
 
     def _tl_ahead(self, slot: int, prepared=None) -> None:
         """tl encoder on the current light window: logits for the next lights update, K/V tables (into buffer `slot`)
-        for the next agent step. prepared: the window's tbx_tl_prep rows were written by the lights' update (step())."""
+        for the next agent step. prepared: the window's tbx_tl_prep rows were written by the lights' update (step()).
+        One-queue engines (self.one_queue): the pass ENDS with the lights' update (tbx_tl_tail_t.sim_state) - the window it leaves is the
+        next pass's, its tbx_tl_prep rows included."""
+        sim = self._tl_tail_sim() if self.one_queue else None
         if self.tl_kv is None:
             self.policy_out.pop("tl_kv", None)
-            kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out)
+            kv = self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out, tail_sim=sim)
             self.tl_kv = [kv, torch.empty_like(kv)] if slot == 0 else [torch.empty_like(kv), kv]
             return
         self.policy_out["tl_kv"] = self.tl_kv[slot]
-        self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out, prepared=prepared)
+        self.model.tl_policy(self.S["hist_tl"], self.tl_tokens, self.policy_out, prepared=prepared, tail_sim=sim)
+
+    def _tl_tail_sim(self) -> dict:
+        if self._tl_prep is None:
+            hist = self.S["hist_tl"]
+            self._tl_prep = self.model.tl_encoder.prep_buffers(hist.shape[0], hist.shape[1], hist.device)
+        return dict(state=self.sim_state_tl_own, parts=hip.SIM_LIGHTS | hip.SIM_ADVANCE, attr=self._tl_prep[0], row_invalid=self._tl_prep[1])
+
+    def _one_queue_ok(self, n: int, A: int, nl: int, L: int, stepwise: bool) -> bool:
+        """The one-queue step applies: both blocks on the one-launch decoder layer with their tails in the launch (Schedule docstring)."""
+        c = self.sched
+        return bool(c.one_queue and c.lights_ahead and c.sim_before_join and c.fused_tail and c.tl_prep_rides and c.dec_layer and c.dec_mid
+                    and c.dec_tail_mfma and c.front_fused and c.tile_small and c.heads_tail and c.navi_rider and c.knn_main and not stepwise
+                    and n * A <= min(c.live_max_agents, c.live_max) and nl * L <= c.live_max and self.model.tl_encoder.temp_window_size <= 16)
 
     # ------------------------------------------------------------------ stepping
     @_scheduled
@@ -465,6 +482,8 @@ class RolloutEngine:
             else:
                 hip.sim_step(self.sim_state)
             return
+        if self.one_queue:
+            return self._step_one_queue()
         p = self.parity
         early = self.sched.sim_before_join
         st_tl, parts_tl = (self.sim_state_tl_own, hip.SIM_LIGHTS | hip.SIM_ADVANCE) if early else (self.sim_state_tl, hip.SIM_LIGHTS)
@@ -501,6 +520,41 @@ class RolloutEngine:
         else:
             main.wait_stream(self.side)
             hip.sim_step(self.sim_state, hip.SIM_AGENTS | hip.SIM_ADVANCE)
+        self.parity = 1 - p
+
+    def _step_one_queue(self) -> None:
+        """One closed-loop step as FIVE launches on the stepping stream (Schedule.one_queue): the lights' pass for the NEXT agent step
+        (window -> tables into the other buffer, logits, then - in its last layer's tail - the lights' own update) paired launch by
+        launch with the agents' step on this step's tables. The wrappers collect both halves' launch descriptors (hip.defer) instead
+        of launching; the halves are independent, so pairing them changes no result."""
+        S, p = self.S, self.parity
+        tail = dict(sim_state=self.sim_state, parts=hip.SIM_AGENTS | hip.SIM_ADVANCE)
+        if not self._prep_ready:
+            # the very first step of a fresh engine (no tbx_agent_prep buffers yet: _prime_prep): the same launches one after the other
+            self._tl_ahead(1 - p, prepared=self._tl_prep)
+            self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"], self.ag_latent,
+                                    self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens, self.tl_kv[p], self.policy_out,
+                                    aux_stream=self.aux, rollout_consts=self.consts, fused_tail=tail, prep_ready=False)
+            if not self.policy_out["prep"].get("_tail_fused"):
+                raise RuntimeError("one-queue step: the agents' last layer did not take the fused tail; use Schedule(one_queue=False)")
+            self._prep_ready = True
+            self.parity = 1 - p
+            return
+        with hip.defer() as lights:
+            self._tl_ahead(1 - p, prepared=self._tl_prep)  # (the previous pass's tail - the prime's for the first step - wrote these rows)
+        with hip.defer() as agents:
+            self.model.agent_policy(S["hist_valid"], S["hist_pose"], S["hist_motion"], self.ag_attr6, S["ag_type_idx"], self.ag_latent,
+                                    self.latent_invalid, self.dest, S["navi_valid"], self.tl_tokens, self.mp_tokens, self.tl_kv[p], self.policy_out,
+                                    aux_stream=self.aux, rollout_consts=self.consts, fused_tail=tail, prep_ready=True)
+        want = ["tbx_front"] + ["tbx_knarpe_dec_layer"] * (len(lights) - 1)
+        if not (len(lights) == len(agents) >= 2 and [c[0] for c in lights] == want == [c[0] for c in agents]
+                and self.policy_out["prep"].get("_tail_fused")):
+            raise RuntimeError("one-queue step: the two halves did not reduce to [tbx_front, tbx_knarpe_dec_layer x layers] with fused tails "
+                               f"(lights {[c[0] for c in lights]}, agents {[c[0] for c in agents]}); use Schedule(one_queue=False)")
+        hip.launch_front_pair(agents[0], lights[0])
+        for a_, l_ in zip(agents[1:], lights[1:]):
+            hip.launch_dec_layer_pair(a_, l_)
+        self._prep_ready = True
         self.parity = 1 - p
 
     @_scheduled
