@@ -585,7 +585,8 @@ int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const
 
 /* The glue of a PointNet layer over the time-batched windows, forward and backward (training; autograd of polyline_encoder.py:49-61 and
  * pooling.py:18-19,38: relu / dropout / masked_fill / amax / expand / cat and their backward kernels). A wavefront per group of
- * group_rows <= 16 rows; every tensor is read or written once.
+ * group_rows <= 32 rows (two register footprints: <= 16 - the windows of 11 - and <= 32 - the map's polylines of 20 nodes); every tensor is read or
+ * written once.
  *   tbx_pointnet_tail_fwd: z [n_groups, group_rows, 64] = the layer's Linear output, invalid [n_groups, group_rows] u8 ->
  *     out [n_groups, group_rows, 128] = [h | max over the group's valid rows of h], invalid rows zeroed, h = dropout(relu(z)) with
  *     tbx_keyed_dropout's mask for the [n_groups * group_rows, 64] view (p_drop = 0: none; site / rows_per_scene / time_batch / time0

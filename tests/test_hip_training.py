@@ -699,7 +699,7 @@ def test_layernorm_backward_vs_float64_autograd(tb, shape):
     assert float(((db.double() - bd.grad).abs() / mag_b.clamp_min(1e-30)).max()) < 2e-6
 
 
-@pytest.mark.parametrize("G,W,dropout", [(5, 11, False), (3000, 11, True), (777, 16, True), (64, 1, False)])
+@pytest.mark.parametrize("G,W,dropout", [(5, 11, False), (3000, 11, True), (777, 16, True), (64, 1, False), (1500, 20, True), (300, 19, False), (9, 32, True)])
 def test_fused_pointnet_glue_equals_the_aten_ops(tb, G, W, dropout):
     """train_graph.pointnet with tbx_pointnet_tail_* / tbx_masked_maxpool_* (one launch per layer for relu / keyed dropout / masked max /
     concat / zeroing, one for their backward) vs the same function on aten ops: forward bit-identical (same masks: the dropout ids

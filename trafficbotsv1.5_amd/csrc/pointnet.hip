@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int PN_C = 64;      // channels of a layer's Linear (one per lane); the layer's output is 2 * PN_C wide
-constexpr int PN_MAXW = 16;   // rows per group kept in registers
+constexpr int PN_MAXW = 32;   // rows per group kept in registers: the kernels come in two sizes, <MAXW = 16> (the windows of 11) and <32> (the map's polylines of 20 nodes, the posterior's windows of 19)
 constexpr int PN_WAVES = 4;
 
 // tbx_keyed_dropout's hash (csrc/dropout.hip)
@@ -48,6 +48,7 @@ __device__ __forceinline__ uint32_t invalid_bits(const uint8_t* invalid, int64_t
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(inv));
 }
 
+template <int MAXW>
 __global__ __launch_bounds__(PN_WAVES * 64) void pointnet_tail_fwd_kernel(const TailArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (int64_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
@@ -55,10 +56,10 @@ __global__ __launch_bounds__(PN_WAVES * 64) void pointnet_tail_fwd_kernel(const 
   const int W = a.W;
   const uint32_t inv = invalid_bits(a.invalid, g, W, lane);
   const uint64_t sd = a.seed != nullptr ? *a.seed : 0;
-  float h[PN_MAXW];
+  float h[MAXW];
   float m = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       const int64_t row = g * W + w;
       float v = fmaxf(a.z[row * PN_C + lane], 0.f);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(PN_WAVES * 64) void pointnet_tail_fwd_kernel(const 
     }
   }
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       const bool bad = (inv >> w) & 1;
       float* o = a.out + (g * W + w) * (2 * PN_C);
@@ -96,16 +97,17 @@ struct TailBwdArgs {
   float scale;           // 1 / (1 - p), or 1 without dropout
 };
 
+template <int MAXW>
 __global__ __launch_bounds__(PN_WAVES * 64) void pointnet_tail_bwd_kernel(const TailBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (int64_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
   if (g >= a.G) return;
   const int W = a.W;
   const uint32_t inv = invalid_bits(a.invalid, g, W, lane);
-  float h[PN_MAXW], d[PN_MAXW];
+  float h[MAXW], d[MAXW];
   float m = -INFINITY, gm = 0.f;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       const int64_t row = g * W + w;
       h[w] = a.out[row * (2 * PN_C) + lane];
@@ -119,11 +121,11 @@ __global__ __launch_bounds__(PN_WAVES * 64) void pointnet_tail_bwd_kernel(const 
   }
   int ties = 0;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w)
+  for (int w = 0; w < MAXW; ++w)
     if (w < W && !((inv >> w) & 1) && h[w] == m) ++ties;
   const float share = ties > 0 ? gm / (float)ties : 0.f;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       float v = 0.f;
       if (!((inv >> w) & 1) && h[w] > 0.f) v = (d[w] + (h[w] == m ? share : 0.f)) * a.scale;
@@ -141,6 +143,7 @@ struct PoolArgs {
   int W;
 };
 
+template <int MAXW>
 __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_fwd_kernel(const PoolArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (int64_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_fwd_kernel(const
   float2 m = make_float2(-INFINITY, -INFINITY);
   bool any = false;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W && !((inv >> w) & 1)) {
       const float2 v = *(const float2*)(a.x + (g * W + w) * (2 * PN_C) + 2 * lane);
       m.x = fmaxf(m.x, v.x);
@@ -162,16 +165,17 @@ __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_fwd_kernel(const
   *(float2*)(a.y + g * (2 * PN_C) + 2 * lane) = m;
 }
 
+template <int MAXW>
 __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_bwd_kernel(const PoolArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (int64_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
   if (g >= a.G) return;
   const int W = a.W;
   const uint32_t inv = invalid_bits(a.invalid, g, W, lane);
-  float2 v[PN_MAXW];
+  float2 v[MAXW];
   float2 m = make_float2(-INFINITY, -INFINITY);
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       v[w] = *(const float2*)(a.x + (g * W + w) * (2 * PN_C) + 2 * lane);
       if (!((inv >> w) & 1)) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_bwd_kernel(const
   }
   int tx = 0, ty = 0;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w)
+  for (int w = 0; w < MAXW; ++w)
     if (w < W && !((inv >> w) & 1)) {
       tx += v[w].x == m.x;
       ty += v[w].y == m.y;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(PN_WAVES * 64) void masked_maxpool_bwd_kernel(const
   const float2 dy = *(const float2*)(a.y + g * (2 * PN_C) + 2 * lane);
   const float sx = tx > 0 ? dy.x / (float)tx : 0.f, sy = ty > 0 ? dy.y / (float)ty : 0.f;
 #pragma unroll
-  for (int w = 0; w < PN_MAXW; ++w) {
+  for (int w = 0; w < MAXW; ++w) {
     if (w < W) {
       float2 o = make_float2(0.f, 0.f);
       if (!((inv >> w) & 1)) {
@@ -220,7 +224,8 @@ extern "C" int tbx_pointnet_tail_fwd(const float* z, const uint8_t* invalid, int
     a.seed = drop_seed, a.thresh = th < 1.0 ? 1u : (uint32_t)th, a.scale = 1.0f / (1.0f - p_drop);
     a.rows_per_scene = rows_per_scene, a.time_batch = time_batch, a.time0 = time0;
   }
-  hipLaunchKernelGGL(pointnet_tail_fwd_kernel, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (group_rows <= 16) hipLaunchKernelGGL(pointnet_tail_fwd_kernel<16>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(pointnet_tail_fwd_kernel<32>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -229,7 +234,8 @@ extern "C" int tbx_pointnet_tail_bwd(const float* dout, const float* out, const 
   if (!dout || !out || !invalid || !dz || p_drop < 0.f || p_drop >= 1.f) return TBX_ERR_ARG;
   if (!shape_ok(n_groups, group_rows, cols)) return TBX_ERR_UNSUPPORTED;
   TailBwdArgs a{dout, out, invalid, dz, n_groups, group_rows, p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f};
-  hipLaunchKernelGGL(pointnet_tail_bwd_kernel, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (group_rows <= 16) hipLaunchKernelGGL(pointnet_tail_bwd_kernel<16>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(pointnet_tail_bwd_kernel<32>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -238,7 +244,8 @@ extern "C" int tbx_masked_maxpool_fwd(const float* x, const uint8_t* invalid, in
   if (!x || !invalid || !y) return TBX_ERR_ARG;
   if (!shape_ok(n_groups, group_rows, cols / 2) || (cols & 1)) return TBX_ERR_UNSUPPORTED;
   PoolArgs a{x, invalid, y, nullptr, n_groups, group_rows};
-  hipLaunchKernelGGL(masked_maxpool_fwd_kernel, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (group_rows <= 16) hipLaunchKernelGGL(masked_maxpool_fwd_kernel<16>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(masked_maxpool_fwd_kernel<32>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
@@ -247,6 +254,7 @@ extern "C" int tbx_masked_maxpool_bwd(const float* dy, const float* x, const uin
   if (!dy || !x || !invalid || !dx) return TBX_ERR_ARG;
   if (!shape_ok(n_groups, group_rows, cols / 2) || (cols & 1)) return TBX_ERR_UNSUPPORTED;
   PoolArgs a{x, invalid, (float*)dy, dx, n_groups, group_rows};
-  hipLaunchKernelGGL(masked_maxpool_bwd_kernel, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (group_rows <= 16) hipLaunchKernelGGL(masked_maxpool_bwd_kernel<16>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(masked_maxpool_bwd_kernel<32>, grid_of(n_groups), dim3(PN_WAVES * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }

@@ -195,8 +195,8 @@ def relu_drop_bwd(dh, h, p: float):
 
 
 def pointnet_tail_ok(z: torch.Tensor) -> bool:
-    """z [G, W, 64] fp32 on the device, W <= 16: the shapes tbx_pointnet_tail_* / tbx_masked_maxpool_* take."""
-    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[2] == 64 and 0 < z.shape[1] <= 16 and z.shape[0] > 0
+    """z [G, W, 64] fp32 on the device, W <= 32: the shapes tbx_pointnet_tail_* / tbx_masked_maxpool_* take."""
+    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[2] == 64 and 0 < z.shape[1] <= 32 and z.shape[0] > 0
 
 
 def pointnet_tail_fwd(z: torch.Tensor, invalid_u8: torch.Tensor, drop=None) -> torch.Tensor:

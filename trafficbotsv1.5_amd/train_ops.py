@@ -42,6 +42,9 @@ class TallLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, want16=False):
         ctx.save_for_backward(x, w)
+        # (the bfloat16 copy takes no gradient: without this the engine fills a [rows, n] bfloat16 tensor of zeros for it at every backward -
+        # 36 fills / 1.1 GB per step, tools/train_aten_sources.py)
+        ctx.set_materialize_grads(False)
         ctx.has_b = b is not None
         ctx.bf16 = bf16_contractions()  # (the backward runs after training_step has returned: it keeps the forward's class)
         if _tall_ok(x, w.shape[1], w.shape[0]):
@@ -62,6 +65,8 @@ class TallLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _d16=None):
+        if dy is None:
+            return None, None, None, None
         x, w = ctx.saved_tensors
         dx, dw, db = _tall_linear_backward(x, w, dy, ctx.has_b, ctx.bf16, ctx.needs_input_grad)
         return dx, dw, db, None
@@ -168,10 +173,13 @@ class KnarpeAttnFn(torch.autograd.Function):
         ctx.save_for_backward(qbuf, bias_k, *kvs)
         ctx.meta, ctx.n, ctx.S, ctx.freqs, ctx.drop = meta, n, S, freqs, drop
         ctx.mark_non_differentiable(flag)
+        ctx.set_materialize_grads(False)  # (no zero fill for the flag's gradient at every backward)
         return out, flag
 
     @staticmethod
     def backward(ctx, dout, _dflag):
+        if dout is None:
+            return (None,) * (7 + len(ctx.saved_tensors) - 2)
         qbuf, bias_k, *kvs = ctx.saved_tensors
         meta, n, S = ctx.meta, ctx.n, ctx.S
         dq = torch.empty_like(qbuf)
@@ -473,7 +481,7 @@ class MaskedMaxPoolFn(torch.autograd.Function):
 
 
 def _pointnet_fused_ok(enc, x: Tensor, training: bool) -> bool:
-    if not (ST.POINTNET_FUSED and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and 0 < x.shape[1] <= 16 and x.shape[0] > 0):
+    if not (ST.POINTNET_FUSED and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and 0 < x.shape[1] <= 32 and x.shape[0] > 0):
         return False
     for m in enc.mlp_layers:
         ll = m.linear_layers()
