@@ -450,6 +450,15 @@ int tbx_tall_linear_relu_drop_bf16(const float* x, int64_t m, int k, int ldx, co
  * of 128, n % 16 == 0. Size in floats (negative: error code). Layout: csrc/tile_layer.hip. */
 int64_t tbx_pack_weight_mfma32_size(int n, int k, int groups);
 int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, int k, int ld, int groups, int wt, float* out, void* stream);
+/* n_jobs images in ONE launch (a training step re-packs ~300 images of <= 640 x 128 weights after every optimizer step: the launches,
+ * not the bytes, were the cost). jobs is a HOST array; every job as tbx_pack_weight_mfma32's arguments. */
+typedef struct tbx_pack_job {
+  const float* w;
+  const float* bias; /* or NULL */
+  float* out;
+  int32_t n, k, ld, groups, wt, pad_;
+} tbx_pack_job_t;
+int tbx_pack_weight_mfma32_multi(const tbx_pack_job_t* jobs /* host */, int n_jobs, void* stream);
 
 /* Backward of tbx_knarpe_attn_fwd (training; autograd of modules/attention_rpe.py:137-190 in the factorised form).
  *   dout   [n_batch*n_src, ldo >= 640] = d(sum a v) | d(sum a e per head)
@@ -543,6 +552,11 @@ int tbx_residual_drop_bwd(const float* dout, const uint8_t* zero_y, const uint8_
 int tbx_relu_drop_fwd(const float* z, int64_t rows, int cols, float p_drop, const uint64_t* drop_seed /* device */, uint32_t site,
                       int rows_per_scene, int time_batch, int time0, float* h, void* stream);
 int tbx_relu_drop_bwd(const float* dh, const float* h, int64_t rows, int cols, float p_drop, float* dz, void* stream);
+/* h [n_batch, n_a, n_m, cols] += pa [n_batch, n_a, cols] (per agent) + pm [n_batch, n_m, cols] (per polyline), then relu if `relu`, in
+ * place and in one pass: the broadcast terms of NaviPredictor's first Linear over agent x polyline pairs (navigation.py:245-262 - the
+ * reference concatenates [f_a | f_m | e] per pair and multiplies by W [128, 384]; here W_a f_a and W_m f_m + b are computed per agent /
+ * per polyline and added onto W_e e). cols % 4 == 0, 16-byte aligned. */
+int tbx_pair_bias_relu(float* h, const float* pa, const float* pm, int64_t n_batch, int n_a, int n_m, int cols, int relu, void* stream);
 
 /* Weight gradient of a LINEAR over very many rows (training; autograd of F.linear at modules/mlp.py:69-72,
  * attention_rpe.py:95-120,190, transformer_rpe.py:119-131 in the time-batched pass): dw[n,k] = dy[rows,n]^T x[rows,k],
@@ -582,6 +596,11 @@ int tbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 int tbx_layernorm_bwd_partials(int64_t rows);
 int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, int64_t rows, int cols,
                       float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* ... with the gradient of the residual branch that forks off x added in the same pass: dx = add + (the LayerNorm's input gradient); add
+ * [rows, 128] or NULL (= tbx_layernorm_bwd). In x_{i+1} = x_i + f(LayerNorm(x_i)) (transformer_rpe.py:207-245) autograd sums the two
+ * gradients of x_i with a kernel of its own: three more passes over [rows, 128] per LayerNorm. */
+int tbx_layernorm_bwd_add(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, int64_t rows, int cols,
+                          const float* add, float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
 
 /* The glue of a PointNet layer over the time-batched windows, forward and backward (training; autograd of polyline_encoder.py:49-61 and
  * pooling.py:18-19,38: relu / dropout / masked_fill / amax / expand / cat and their backward kernels). A wavefront per group of

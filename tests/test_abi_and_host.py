@@ -101,7 +101,7 @@ def test_ctypes_mirrors_have_the_layout_gcc_gives_the_header(hip, tmp_path):
     root = Path(__file__).resolve().parent.parent
     pairs = [("tbx_stage_t", hip.Stage), ("tbx_attn_seg_t", hip.AttnSeg), ("tbx_dec_mid_t", hip.DecMid), ("tbx_dec_layer_t", hip.DecLayer), ("tbx_heads_tail_t", hip.HeadsTail), ("tbx_knn_job_t", hip.KnnJob), ("tbx_pose_embed_job_t", hip.PoseEmbedJob), ("tbx_sim_state_t", hip.SimState),
              ("tbx_train_chain_t", hip.TrainChainArgs), ("tbx_rule_ctx_t", hip.RuleCtx), ("tbx_layer_tile_t", hip.LayerTile),
-             ("tbx_heads_tile_t", hip.HeadsTile), ("tbx_window_tile_t", hip.WindowTile), ("tbx_agent_prep_args_t", hip.AgentPrepArgs), ("tbx_front_t", hip.Front), ("tbx_tl_tail_t", hip.TlTail)]
+             ("tbx_heads_tile_t", hip.HeadsTile), ("tbx_window_tile_t", hip.WindowTile), ("tbx_agent_prep_args_t", hip.AgentPrepArgs), ("tbx_front_t", hip.Front), ("tbx_tl_tail_t", hip.TlTail), ("tbx_pack_job_t", hip.PackJob)]
     src = tmp_path / "sz.c"
     # ... and offsetof of every field (same names on both sides): runs of same-sized pointers keep sizeof when two fields swap
     fields = [(c, t, f[0]) for c, t in pairs for f in t._fields_]

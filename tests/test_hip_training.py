@@ -699,6 +699,56 @@ def test_layernorm_backward_vs_float64_autograd(tb, shape):
     assert float(((db.double() - bd.grad).abs() / mag_b.clamp_min(1e-30)).max()) < 2e-6
 
 
+@pytest.mark.parametrize("rows", [37, 20000])
+def test_layer_norm_join_backward_is_the_sum_autograd_forms(tb, rows):
+    """train_ops.layer_norm_join (LayerNormJoinFn: x handed back beside LayerNorm(x), ONE backward pass dx = d_residual + LayerNorm'(dy),
+    tbx_layernorm_bwd_add) in the pre-norm residual form x' = x + f(LayerNorm(x)) vs layer_norm + autograd's own sum of the two gradients
+    of x: outputs and every gradient bit-identical; a LayerNorm whose output is not used, and one whose x is not, included."""
+    dev = torch.device("cuda:0")
+    TG = import_module("trafficbots_amd.train_graph")
+    g = torch.Generator().manual_seed(rows)
+    m = torch.nn.LayerNorm(128).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(128, generator=g)), m.bias.copy_(torch.randn(128, generator=g))
+    x0 = torch.randn(rows, 128, generator=g).to(dev)
+    wf = torch.randn(128, 128, generator=g).to(dev)
+    go = torch.randn(rows, 128, generator=g).to(dev)
+    res = {}
+    for join in (True, False):
+        x = x0.clone().requires_grad_(True)
+        m.zero_grad()
+        xa, xb = x * 1.0, x * 1.0  # (non-leaves, as in the block; every junction sums TWO gradients, as there - three would associate differently)
+        if join:
+            xr, s = TG.layer_norm_join(xa, m)
+            assert isinstance(s.grad_fn, TG.LayerNormJoinFn._backward_cls) and xr.grad_fn is s.grad_fn
+            _, unused = TG.layer_norm_join(xr, m)  # its LayerNorm output takes no gradient: the residual's passes through
+            only_ln = TG.layer_norm_join(xb, m)[1]  # its x takes none
+        else:
+            xr, s = xa, TG.layer_norm(xa, m)
+            only_ln = TG.layer_norm(xb, m)
+        y = xr + torch.tanh(s @ wf) + 0.5 * only_ln
+        (y * go).sum().backward()
+        res[join] = (y.detach(), x.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone())
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_pair_bias_relu_equals_the_broadcast_adds(tb, relu):
+    """tbx_pair_bias_relu (NaviPredictor's first Linear, train_ops.NaviPairFirstLayer): h[n, a, m] += pa[n, a] + pm[n, m] (+ relu) in one
+    in-place pass vs the torch broadcast ops it replaces - bit-identical (h + (pa + pm), the same association)."""
+    dev = torch.device("cuda:0")
+    hip = import_module("trafficbots_amd.hip")
+    g = torch.Generator().manual_seed(11)
+    n, A, M, d = 3, 7, 33, 128
+    h = torch.randn(n, A, M, d, generator=g).to(dev)
+    pa, pm = torch.randn(n, A, d, generator=g).to(dev), torch.randn(n, M, d, generator=g).to(dev)
+    ref = h + (pa.unsqueeze(2) + pm.unsqueeze(1))
+    ref = torch.relu(ref) if relu else ref
+    out = hip.pair_bias_relu(h.clone(), pa, pm, relu)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("G,W,dropout", [(5, 11, False), (3000, 11, True), (777, 16, True), (64, 1, False), (1500, 20, True), (300, 19, False), (9, 32, True)])
 def test_fused_pointnet_glue_equals_the_aten_ops(tb, G, W, dropout):
     """train_graph.pointnet with tbx_pointnet_tail_* / tbx_masked_maxpool_* (one launch per layer for relu / keyed dropout / masked max /

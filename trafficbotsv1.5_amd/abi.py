@@ -94,6 +94,12 @@ class TlTail(C.Structure):
                 ("sim_state", C.c_void_p), ("prep_attr", C.c_void_p), ("prep_row_invalid", C.c_void_p)]
 
 
+class PackJob(C.Structure):
+    """tbx_pack_job_t (include/tbx_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32), ("ld", C.c_int32),
+                ("groups", C.c_int32), ("wt", C.c_int32), ("pad_", C.c_int32)]
+
+
 class LayerTile(C.Structure):
     """tbx_layer_tile_t (include/tbx_hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("x", "attn_out", "row_no_valid", "fold_image", "out_proj_image", "norm2_weight", "norm2_bias",
@@ -229,6 +235,7 @@ def load():
     lib.tbx_residual_drop_bwd.argtypes = [vp, vp, vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp, vp]
     lib.tbx_relu_drop_fwd.argtypes = [vp, i64, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
     lib.tbx_relu_drop_bwd.argtypes = [vp, vp, i64, i32, C.c_float, vp, vp]
+    lib.tbx_pair_bias_relu.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.tbx_pointnet_tail_fwd.argtypes = [vp, vp, i64, i32, i32, C.c_float, vp, C.c_uint32, i32, i32, i32, vp, vp]
     lib.tbx_pointnet_tail_bwd.argtypes = [vp, vp, vp, i64, i32, i32, C.c_float, vp, vp]
     lib.tbx_masked_maxpool_fwd.argtypes = [vp, vp, i64, i32, i32, vp, vp]
@@ -236,6 +243,7 @@ def load():
     lib.tbx_layernorm_fwd.argtypes = [vp, vp, vp, C.c_float, i64, i32, vp, vp, vp, vp]
     lib.tbx_layernorm_bwd_partials.argtypes = [i64]
     lib.tbx_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
+    lib.tbx_layernorm_bwd_add.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_fwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp]
     lib.tbx_train_chain_fwd_windows.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.tbx_train_chain_bwd.argtypes = [C.POINTER(TrainChainArgs), vp, i64, i64, vp, vp, vp]
@@ -270,6 +278,7 @@ def load():
     lib.tbx_pack_weight_mfma32_size.argtypes = [i32, i32, i32]
     lib.tbx_pack_weight_mfma32_size.restype = C.c_int64
     lib.tbx_pack_weight_mfma32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.tbx_pack_weight_mfma32_multi.argtypes = [C.POINTER(PackJob), i32, vp]
     lib.tbx_rowchain_live.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, vp]
     lib.tbx_rowchain.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, vp]
     lib.tbx_rowchain_ex.argtypes = [C.POINTER(Stage), i32, i64, i32, i32, i32, i32, i32, vp]
@@ -289,7 +298,7 @@ def load():
     lib.tbx_attn_fold_fwd.argtypes = [vp] * 14
     lib.tbx_attn_fold_bwd.argtypes = [vp] * 19
     lib.tbx_rule_navi_check.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
-    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_linear_wgrad_bf16", "tbx_tall_linear_bf16", "tbx_tl_tail_tile", "tbx_tl_tail_tile_bf16", "tbx_tall_linear_dual", "tbx_tall_linear_dual_bf16", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_fwd_windows", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
+    for name in ("tbx_layer_tile", "tbx_heads_tile", "tbx_window_tile", "tbx_front", "tbx_tall_linear", "tbx_pack_weight_mfma32", "tbx_pack_weight_mfma32_multi", "tbx_pack_weight", "tbx_pack_weight_split", "tbx_pack_weight_gemv", "tbx_rowchain_live", "tbx_knarpe_attn_fwd_folded", "tbx_knarpe_dec_mid", "tbx_knarpe_dec_layer", "tbx_knn_embed_multi", "tbx_knn_embed_multi_pe", "tbx_knn_embed", "tbx_pose_embed", "tbx_knarpe_attn_fwd", "tbx_knarpe_attn_bwd", "tbx_knarpe_attn_fwd_dropout", "tbx_knarpe_attn_bwd_dropout", "tbx_knarpe_attn_bwd_gather", "tbx_knarpe_attn_fwd_dropout_tb", "tbx_knarpe_attn_bwd_dropout_tb", "tbx_knarpe_attn_bwd_gather_tb", "tbx_keyed_dropout", "tbx_linear_wgrad_splits", "tbx_linear_wgrad", "tbx_linear_wgrad_bf16", "tbx_tall_linear_bf16", "tbx_tl_tail_tile", "tbx_tl_tail_tile_bf16", "tbx_tall_linear_dual", "tbx_tall_linear_dual_bf16", "tbx_layernorm_fwd", "tbx_layernorm_bwd_partials", "tbx_layernorm_bwd", "tbx_layernorm_bwd_add", "tbx_residual_drop_fwd", "tbx_residual_drop_bwd", "tbx_relu_drop_fwd", "tbx_relu_drop_bwd", "tbx_pair_bias_relu", "tbx_pointnet_tail_fwd", "tbx_pointnet_tail_bwd", "tbx_masked_maxpool_fwd", "tbx_masked_maxpool_bwd", "tbx_train_chain_fwd", "tbx_train_chain_fwd_windows", "tbx_train_chain_bwd", "tbx_knn_inverse", "tbx_rowchain", "tbx_rowchain_ex", "tbx_agent_prep", "tbx_tl_prep",
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd", "tbx_tall_linear_relu_drop", "tbx_tall_linear_relu_drop_bf16", "tbx_front_pair", "tbx_knarpe_dec_layer_pair",
                  "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma", "tbx_knarpe_attn_fwd_mfma_dropout_tb"):
         getattr(lib, name).restype = C.c_int

@@ -219,6 +219,43 @@ extern "C" int tbx_relu_drop_bwd(const float* dh, const float* h, int64_t rows, 
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 
+// h[n, a, m, :] = [relu](h[n, a, m, :] + (pa[n, a, :] + pm[n, m, :])) in place: the per-agent and per-polyline terms of NaviPredictor's first
+// Linear broadcast onto the per-pair term (train_ops.NaviPairFirstLayer) - one pass over the [n, A, M, cols] tensor instead of three
+// torch launches per scene (add, add_, copy_) and a relu over the whole of it.
+struct PairBiasArgs {
+  float* h;
+  const float* pa;
+  const float* pm;
+  int64_t total;  // n * A * M * cols / 4
+  int A, M, c4, relu;
+};
+__global__ __launch_bounds__(256) void pair_bias_kernel(const PairBiasArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += stride) {
+    const int64_t row = i / a.c4;
+    const int c = (int)(i - row * a.c4);
+    const int64_t na = row / a.M;
+    const int m = (int)(row - na * a.M);
+    const int64_t nn = na / a.A;
+    const float4 u = *(const float4*)(a.pa + (na * a.c4 + c) * 4);
+    const float4 w = *(const float4*)(a.pm + ((nn * a.M + m) * a.c4 + c) * 4);
+    float4 v = *(const float4*)(a.h + i * 4);
+    v.x += u.x + w.x, v.y += u.y + w.y, v.z += u.z + w.z, v.w += u.w + w.w;
+    if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    *(float4*)(a.h + i * 4) = v;
+  }
+}
+
+extern "C" int tbx_pair_bias_relu(float* h, const float* pa, const float* pm, int64_t n_batch, int n_a, int n_m, int cols, int relu, void* stream) {
+  if (!h || !pa || !pm || n_batch < 0 || n_a <= 0 || n_m <= 0 || cols <= 0 || (cols & 3)) return TBX_ERR_ARG;
+  if (!aligned16(h) || !aligned16(pa) || !aligned16(pm)) return TBX_ERR_ALIGN;
+  if (n_batch == 0) return TBX_OK;
+  PairBiasArgs a{h, pa, pm, n_batch * n_a * n_m * (cols / 4), n_a, n_m, cols / 4, relu};
+  const int64_t want = (a.total + 255) / 256;
+  hipLaunchKernelGGL(pair_bias_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
 extern "C" int tbx_keyed_dropout(const float* x, float* y, int64_t rows, int cols, int rows_per_scene, float p_drop,
                                  const uint64_t* drop_seed, uint32_t site, int time_batch, int time0, void* stream) {
   if (!x || !y || !drop_seed || rows < 0 || cols <= 0 || rows_per_scene <= 0 || time_batch < 1 || time0 < 0) return TBX_ERR_ARG;

@@ -20,8 +20,10 @@ struct LnBwdArgs {
   const float *x, *dy, *gamma, *mean, *rstd;
   float *dx, *part;
   int64_t rows;
+  const float* add;  // ADD: dx = add + (the LayerNorm's input gradient) - the gradient of the residual branch that forks off x
 };
 
+template <bool ADD>
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a) {
   __shared__ float red[LN_WAVES][2 * LN_D];
   const int lane = threadIdx.x & 63;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
   const float2 gm = *(const float2*)(a.gamma + 2 * lane);
   float2 dg = make_float2(0.f, 0.f), db = make_float2(0.f, 0.f);
   for (int64_t r = w0; r < a.rows; r += tw * LN_UNROLL) {
-    float2 xv[LN_UNROLL], dv[LN_UNROLL];
+    float2 xv[LN_UNROLL], dv[LN_UNROLL], av[LN_UNROLL];
     float mu[LN_UNROLL], rs[LN_UNROLL];
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
       const int64_t rc = rr < a.rows ? rr : r;  // (clamped: the loads of a row past the end are discarded below)
       xv[u] = *(const float2*)(a.x + rc * LN_D + 2 * lane);
       dv[u] = *(const float2*)(a.dy + rc * LN_D + 2 * lane);
+      if (ADD) av[u] = *(const float2*)(a.add + rc * LN_D + 2 * lane);
       mu[u] = a.mean[rc];
       rs[u] = a.rstd[rc];
     }
@@ -52,6 +55,11 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a
       float2 o;
       o.x = rs[u] * (gx - s1 - hx * s2);
       o.y = rs[u] * (gy - s1 - hy * s2);
+      if (ADD) {  // (contraction off: o + add as autograd's own sum rounds it, not fused into the product above)
+#pragma clang fp contract(off)
+        o.x = o.x + av[u].x;
+        o.y = o.y + av[u].y;
+      }
       *(float2*)(a.dx + rr * LN_D + 2 * lane) = o;
       dg.x += dv[u].x * hx;
       dg.y += dv[u].y * hy;
@@ -158,15 +166,22 @@ extern "C" int tbx_layernorm_fwd(const float* x, const float* gamma, const float
 
 extern "C" int tbx_layernorm_bwd_partials(int64_t rows) { return ln_workgroups(rows); }
 
-extern "C" int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
-                                 int64_t rows, int cols, float* dx, float* dgamma, float* dbeta, float* scratch, void* stream) {
+extern "C" int tbx_layernorm_bwd_add(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                                     int64_t rows, int cols, const float* add, float* dx, float* dgamma, float* dbeta, float* scratch,
+                                     void* stream) {
   if (!x || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch || rows <= 0) return TBX_ERR_ARG;
   if (cols != LN_D) return TBX_ERR_UNSUPPORTED;
-  if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 7) return TBX_ERR_ALIGN;
-  LnBwdArgs a{x, dy, gamma, mean, rstd, dx, scratch, rows};
+  if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma) | ((uintptr_t)add)) & 7) return TBX_ERR_ALIGN;
+  LnBwdArgs a{x, dy, gamma, mean, rstd, dx, scratch, rows, add};
   const int n = ln_workgroups(rows);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n), dim3(LN_WAVES * 64), 0, s, a);
+  if (add != nullptr) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(n), dim3(LN_WAVES * 64), 0, s, a);
+  else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(n), dim3(LN_WAVES * 64), 0, s, a);
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * LN_D / 16), dim3(1024), 0, s, (const float*)scratch, n, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                                 int64_t rows, int cols, float* dx, float* dgamma, float* dbeta, float* scratch, void* stream) {
+  return tbx_layernorm_bwd_add(x, dy, gamma, mean, rstd, rows, cols, nullptr, dx, dgamma, dbeta, scratch, stream);
 }

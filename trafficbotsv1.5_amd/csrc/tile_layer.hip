@@ -368,8 +368,8 @@ __device__ __forceinline__ void unit_group(int k, int T, int64_t u, int s, int& 
   }
 }
 
-__global__ void pack_mfma32_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld, int groups, int wt,
-                                   float* __restrict__ out, int64_t total) {
+__device__ __forceinline__ void pack_mfma32_body(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld, int groups, int wt,
+                                                 float* __restrict__ out, int64_t total) {
   const int T = groups * n / 16;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t u = e / UNIT;
@@ -399,6 +399,23 @@ __global__ void pack_mfma32_kernel(const float* __restrict__ w, const float* __r
     }
     out[e] = __uint_as_float(bits);
   }
+}
+
+__global__ void pack_mfma32_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int ld, int groups, int wt,
+                                   float* __restrict__ out, int64_t total) {
+  pack_mfma32_body(w, bias, n, k, ld, groups, wt, out, total);
+}
+
+// tbx_pack_weight_mfma32_multi: blockIdx.y = the job (a training step packs ~300 images of at most 640 x 128 each: one launch per
+// group of them instead of one each)
+constexpr int PACK_MULTI_MAX = 48;
+struct PackMultiArgs {
+  tbx_pack_job_t job[PACK_MULTI_MAX];
+  int64_t total[PACK_MULTI_MAX];
+};
+__global__ void pack_mfma32_multi_kernel(const PackMultiArgs a) {
+  const tbx_pack_job_t& j = a.job[blockIdx.y];
+  pack_mfma32_body(j.w, j.bias, j.n, j.k, j.ld, j.groups, j.wt, j.out, a.total[blockIdx.y]);
 }
 
 int64_t mfma32_units(int n, int k, int groups) {
@@ -457,6 +474,26 @@ extern "C" int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, 
   if (total < 0) return (int)total;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_mfma32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, bias, n, k, ld, groups, wt, out, total);
+  return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
+}
+
+extern "C" int tbx_pack_weight_mfma32_multi(const tbx_pack_job_t* jobs, int n_jobs, void* stream) {
+  if (n_jobs < 0 || (n_jobs > 0 && jobs == nullptr)) return TBX_ERR_ARG;
+  for (int j0 = 0; j0 < n_jobs; j0 += PACK_MULTI_MAX) {
+    PackMultiArgs a;
+    const int m = n_jobs - j0 < PACK_MULTI_MAX ? n_jobs - j0 : PACK_MULTI_MAX;
+    int64_t most = 0;
+    for (int j = 0; j < m; ++j) {
+      const tbx_pack_job_t& q = jobs[j0 + j];
+      if (q.w == nullptr || q.out == nullptr || q.ld <= 0) return TBX_ERR_ARG;
+      const int64_t total = tbx_pack_weight_mfma32_size(q.n, q.k, q.groups);
+      if (total < 0) return (int)total;
+      a.job[j] = q, a.total[j] = total;
+      most = total > most ? total : most;
+    }
+    const int blocks = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
+    hipLaunchKernelGGL(pack_mfma32_multi_kernel, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return hipGetLastError() == hipSuccess ? TBX_OK : TBX_ERR_LAUNCH;
 }
 

@@ -92,6 +92,89 @@ def padded_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:
 PACK_SCOPE: Optional[dict] = None
 
 
+def _pack_key(w, bias, wt, groups, split, gemv, mfma32):
+    """-> (cache dict, key, stamp) of a packed_weight request (see there)."""
+    base = w._base if w._base is not None else w
+    bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
+    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv, mfma32)
+    if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
+        cache, key = PACK_SCOPE, (id(base),) + key
+        PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
+    else:
+        cache = base.__dict__.setdefault("_tbx_packed", {})
+    return cache, key, (w._version, w.data_ptr(), None if bias is None else bias._version)
+
+
+def packed_weights_mfma32_multi(reqs) -> None:
+    """reqs = [(w, bias | None, wt, groups)]: the tbx_pack_weight_mfma32 images of all of them in ONE launch
+    (tbx_pack_weight_mfma32_multi), left in the cache packed_weight(.., mfma32=True) looks them up in. Requests whose image is current
+    are skipped."""
+    from .abi import PackJob
+
+    lib, jobs, keep = load(), [], []
+    for w, bias, wt, groups in reqs:
+        assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
+        cache, key, stamp = _pack_key(w, bias, wt, groups, False, False, True)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            continue
+        n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
+        size = lib.tbx_pack_weight_mfma32_size(n, k, groups)
+        if size <= 0:
+            _check(int(size), "tbx_pack_weight_mfma32_size")
+        if bias is not None:
+            assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n
+        out = torch.empty(size, dtype=torch.float32, device=w.device)
+        j = PackJob()
+        j.w, j.bias, j.out, j.n, j.k, j.ld, j.groups, j.wt = _ptr(w), _ptr(bias), _ptr(out), n, k, w.stride(0), groups, int(wt)
+        jobs.append(j)
+        keep.append((cache, key, stamp, out))
+    if not jobs:
+        return
+    arr = (PackJob * len(jobs))(*jobs)
+    _check(lib.tbx_pack_weight_mfma32_multi(arr, len(jobs), stream_ptr()), "tbx_pack_weight_mfma32_multi")
+    for cache, key, stamp, out in keep:
+        cache[key] = (stamp, out)
+
+
+def pack_group(tensors, reqs) -> None:
+    """Inside a PACK_SCOPE: the first packed_weight(.., mfma32=True) request for any of `tensors` packs ALL of `reqs` in one launch (the
+    folded weights of an attention module: its three LINEARs' images and the W^T images of their input gradients)."""
+    if PACK_SCOPE is None:
+        return
+    g = PACK_SCOPE.setdefault("_groups", {})
+    keep = PACK_SCOPE.setdefault("_keep", {})
+    reqs = list(reqs)
+    for t in tensors:
+        g[id(t)] = reqs
+        keep[("group", id(t))] = t
+
+
+# The image requests of a training step whose sources are nn.Parameters (ready when the step starts) are kept, per owner (the model:
+# the list dies with it) and key, as recorded during the previous step: open_pack_scope packs all of them in ONE launch (a 16-scene step
+# asked for ~80 of them one by one, forward and backward).
+def open_pack_scope(owner=None, plan_key=None) -> dict:
+    """PACK_SCOPE = a new scope; with a list recorded for (owner, plan_key), its images first (one launch). -> the scope."""
+    global PACK_SCOPE
+    plans = None if owner is None else owner.__dict__.setdefault("_tbx_pack_plans", {})
+    PACK_SCOPE = {"_plans": plans, "_plan_key": plan_key, "_record": {}}
+    plan = plans.get(plan_key) if plans is not None else None
+    if plan:
+        packed_weights_mfma32_multi(plan)
+        for r in plan:
+            PACK_SCOPE["_record"][_pack_key(r[0], r[1], r[2], r[3], False, False, True)[1]] = r
+    return PACK_SCOPE
+
+
+def close_pack_scope(scope: Optional[dict] = None) -> None:
+    """PACK_SCOPE = None; the scope's Parameter-sourced requests become the list the next scope of its owner and key starts from."""
+    global PACK_SCOPE
+    scope = PACK_SCOPE if scope is None else scope
+    if scope is not None and scope.get("_plans") is not None:
+        scope["_plans"][scope["_plan_key"]] = list(scope["_record"].values())
+    PACK_SCOPE = None
+
+
 def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool = False, groups: int = 1,
                   split: bool = False, gemv: bool = False, mfma32: bool = False) -> torch.Tensor:
     """tbx_pack_weight image of a LINEAR weight (+ bias). Cached on the weight's base tensor object (the nn.Parameter)
@@ -101,18 +184,19 @@ def packed_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, wt: bool
     gemv=True: the tbx_pack_weight_gemv image (column streams) for the F_WGEMV stages of live-row chains.
     mfma32=True: the tbx_pack_weight_mfma32 image (per-wave units of bf16 hi + lo fragments) for tbx_layer_tile."""
     assert w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
-    base = w._base if w._base is not None else w
-    bkey = None if bias is None else (bias.data_ptr(), bias.shape[0])
-    key = (w.storage_offset(), tuple(w.shape), w.stride(0), wt, groups, bkey, split, gemv, mfma32)
-    if PACK_SCOPE is not None:  # a training step: images live (and are re-packed) per step, see PACK_SCOPE
-        cache, key = PACK_SCOPE, (id(base),) + key
-        PACK_SCOPE.setdefault("_keep", {})[id(base)] = base  # ids stay unique while the scope lives
-    else:
-        cache = base.__dict__.setdefault("_tbx_packed", {})
-    stamp = (w._version, w.data_ptr(), None if bias is None else bias._version)
+    cache, key, stamp = _pack_key(w, bias, wt, groups, split, gemv, mfma32)
+    if mfma32 and PACK_SCOPE is not None and "_record" in PACK_SCOPE:
+        base = w._base if w._base is not None else w
+        if isinstance(base, torch.nn.Parameter) and (bias is None or isinstance(bias if bias._base is None else bias._base, torch.nn.Parameter)):
+            PACK_SCOPE["_record"].setdefault(key, (w, bias, wt, groups))  # (open_pack_scope: next step's plan)
     hit = cache.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
+    if mfma32 and PACK_SCOPE is not None:
+        grp = PACK_SCOPE.get("_groups", {}).get(id(w))
+        if grp is not None and any(r[0] is w and r[1] is bias and bool(r[2]) == bool(wt) and r[3] == groups for r in grp):
+            packed_weights_mfma32_multi(grp)  # pack_group: this request's image and its siblings' in one launch
+            return cache[key][1]
     n, k = (w.shape[1], w.shape[0] // groups) if wt else (w.shape[0] // groups, w.shape[1])
     if bias is not None:
         assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == groups * n

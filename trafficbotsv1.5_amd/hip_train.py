@@ -194,6 +194,16 @@ def relu_drop_bwd(dh, h, p: float):
     return dz
 
 
+def pair_bias_relu(h, pa, pm, relu: bool):
+    """h [n, A, M, d] += pa [n, A, d] + pm [n, M, d] (broadcast), relu'd if `relu`, in place (tbx_pair_bias_relu)."""
+    n, A, M, d = h.shape
+    assert glue_ok(h) and h.is_contiguous() and pa.shape == (n, A, d) and pm.shape == (n, M, d)
+    pa, pm = pa.contiguous(), pm.contiguous()
+    _check(load().tbx_pair_bias_relu(_ptr(h, torch.float32), _ptr(pa, torch.float32), _ptr(pm, torch.float32), n, A, M, d, int(bool(relu)), stream_ptr()),
+           "tbx_pair_bias_relu")
+    return h
+
+
 def pointnet_tail_ok(z: torch.Tensor) -> bool:
     """z [G, W, 64] fp32 on the device, W <= 32: the shapes tbx_pointnet_tail_* / tbx_masked_maxpool_* take."""
     return z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[2] == 64 and 0 < z.shape[1] <= 32 and z.shape[0] > 0
@@ -253,9 +263,11 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, mean, rstd
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
-    """(dx, dgamma, dbeta) of y = LayerNorm_128(x) * gamma + beta given dy, with the forward's per-row mean / rstd (tbx_layernorm_bwd)."""
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, add: Optional[torch.Tensor] = None):
+    """(dx, dgamma, dbeta) of y = LayerNorm_128(x) * gamma + beta given dy, with the forward's per-row mean / rstd (tbx_layernorm_bwd).
+    add [rows, 128]: dx = add + that gradient in the same pass (tbx_layernorm_bwd_add: the residual branch's gradient of x)."""
     assert layernorm_bwd_ok(x) and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and dy.dtype == torch.float32
+    assert add is None or (add.is_contiguous() and add.shape == x.shape and add.dtype == torch.float32)
     rows = x.numel() // 128
     assert mean.numel() == rows and rstd.numel() == rows and mean.is_contiguous() and rstd.is_contiguous()
     lib = load()
@@ -264,8 +276,8 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: 
     dx = torch.empty_like(x)
     dg = torch.empty(128, dtype=torch.float32, device=x.device)
     db = torch.empty(128, dtype=torch.float32, device=x.device)
-    _check(lib.tbx_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma.contiguous(), torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
-                                 rows, 128, _ptr(dx), _ptr(dg), _ptr(db), _ptr(scratch), stream_ptr()), "tbx_layernorm_bwd")
+    _check(lib.tbx_layernorm_bwd_add(_ptr(x), _ptr(dy), _ptr(gamma.contiguous(), torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
+                                     rows, 128, _ptr(add), _ptr(dx), _ptr(dg), _ptr(db), _ptr(scratch), stream_ptr()), "tbx_layernorm_bwd_add")
     return dx, dg, db
 
 

@@ -152,7 +152,10 @@ def train_step(wm, optimizer: torch.optim.Optimizer, batch: Dict[str, Tensor], c
     (gradients accumulate into its buffer, which is what travels)."""
     optimizer.zero_grad(set_to_none=True)  # (the parameters without a gradient path stay None; the live ones are handed theirs)
     loss = wm.training_step(batch, 0)
-    loss.backward()
+    from ..train_graph import backward_pack_scope
+
+    with backward_pack_scope(wm):
+        loss.backward()
     if isinstance(live, FlatGrads):
         live.gather()
     params = live if live is not None else live_parameters(wm.model)
@@ -286,11 +289,11 @@ class GraphedTrainStep:
         # between them and the capture) leave that cache at the CAPTURE-time version: the captured backward would hit it, its
         # tbx_pack_weight launch would not be in the graph, and every replay after the first AdamW step would multiply by the W^T of
         # the warm-up weights. With a scope of its own the packing is part of the backward - eager or captured.
-        hip_base.PACK_SCOPE = {}
-        try:
+        # ... in the scope of the forward that produced `loss`: the W^T images of last step's list were packed with the forward's.
+        from ..train_graph import backward_pack_scope
+
+        with backward_pack_scope(self.wm):
             loss.backward()
-        finally:
-            hip_base.PACK_SCOPE = None
 
     def _refill(self) -> None:
         self.noise.copy_(torch.randn(self.noise.shape), non_blocking=False)  # CPU generator, as the reference's CPU path

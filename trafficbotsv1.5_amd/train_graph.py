@@ -82,23 +82,24 @@ def transformer_block(block, x: Tensor, src_invalid: Tensor, n: int, S: int, sel
     cross(layer) -> list[Targets] with UN-normalised tokens (norm_tgt is applied here)."""
     if _chains_ok(x):
         return _transformer_block_chains(block, x, src_invalid, n, S, self_knn, cross, p, training)
-    ln = lambda m, t: layer_norm(t, m)
+    ln = lambda m, t: layer_norm_join(t, m)  # -> (x to continue the residual branch from, LayerNorm(x)): train_ops.LayerNormJoinFn
     inv = src_invalid.reshape(-1).to(torch.uint8)
     # the glue between the GEMMs / attention calls (zeroing of rows without a valid target, dropout, residual add, relu, the closing
     # row mask) as one pass per tensor: residual() / relu_drop() - the dropout sites keep the order of the reference's modules
     for layer in block.layers:
         if block.mode == "dec_cross_attn":
-            s = ln(layer.norm_src, x)
+            x, s = ln(layer.norm_src, x)
             ts = Targets(s, n_tgt=S, **self_knn)
             x = _attn_residual(x, attention(layer.attn_src, s, [ts], [kv_table(layer.attn_src, None, ts)], n, S, raw=True), p, training)
-            s2 = ln(layer.norm1, x)
+            x, s2 = ln(layer.norm1, x)
             tg = list(cross(layer))
             x = _attn_residual(x, attention(layer.attn, s2, tg, [kv_table(layer.attn, layer.norm_tgt, t) for t in tg], n, S, raw=True), p, training)
         else:  # enc_self_attn: gathered targets share norm1 with the source
-            s2 = ln(layer.norm1, x)
+            x, s2 = ln(layer.norm1, x)
             ts = Targets(s2, n_tgt=S, **self_knn)
             x = _attn_residual(x, attention(layer.attn, s2, [ts], [kv_table(layer.attn, None, ts)], n, S, raw=True), p, training)
-        h = linear_relu_drop(ln(layer.norm2, x), layer.linear1.weight, layer.linear1.bias, p, training)
+        x, s3 = ln(layer.norm2, x)
+        h = linear_relu_drop(s3, layer.linear1.weight, layer.linear1.bias, p, training)
         x = residual(x, linear(h, layer.linear2.weight, layer.linear2.bias), p, training, zero_out=inv)
     return x
 
@@ -350,13 +351,17 @@ def navi_predictor(npd, b, mp, training: bool) -> DestCategorical:
     w1 = lin1.weight
     pa = linear(feat.view(n, A, d), w1[:, :d], None)
     pm = linear(mpf, w1[:, d:2 * d], lin1.bias)
-    x = NaviPairFirstLayer.apply(rel, w1[:, 2 * d:], pa, pm, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs)
+    relu_in = bool(act1) and ln1 is None  # the first layer's relu in the launch that adds the broadcast terms
+    x = NaviPairFirstLayer.apply(rel, w1[:, 2 * d:], pa, pm, npd.pose_rpe.pe_xy.freqs, npd.pose_rpe.pe_yaw.freqs, relu_in)
     if ln1 is not None:
         x = layer_norm(x, ln1)
-    if act1:
+    if act1 and not relu_in:
         x = F.relu(x)
     x = _drop(x, npd.mlp.dropout_p, training)
     for lin, lnm, act in rest:
+        if act and lnm is None and hip.glue_ok(x) and lin.weight.shape[0] % 4 == 0:  # (as train_ops.mlp: LINEAR + relu + dropout as one launch)
+            x = linear_relu_drop(x, lin.weight, lin.bias, npd.mlp.dropout_p, training)
+            continue
         x = linear(x, lin.weight, lin.bias)
         if lnm is not None:
             x = layer_norm(x, lnm)
@@ -672,11 +677,34 @@ def training_step(wm, raw_batch: Dict[str, Tensor], noise: Optional[Tensor] = No
         if seed is None:
             seed = torch.empty(1, dtype=torch.int64, device=next(wm.model.parameters()).device).random_()
         ST._DROP = {"seed": seed, "call": 0, "site": 0, "n_batch": 0, "tb": 1, "t0": 0}
-    hip_base.PACK_SCOPE = {}  # chain kernels of the stepping pass: weight images packed once per step (inside a captured step too)
+    # weight images packed once per step (inside a captured step too): the Parameter-sourced ones of the previous step's list in ONE launch
+    # now (hip_base.open_pack_scope), the folded attention weights' per module (train_ops.fold_attention_weights: hip_base.pack_group)
+    scope = hip_base.open_pack_scope(wm.model, ("training_step", ST._PREC, bool(wm.model.training)))
     try:
         return _training_step(wm, raw_batch, noise, use_prior)
     finally:
-        ST._FOLD_CACHE, ST._DROP, hip_base.PACK_SCOPE, ST._PREC, ST._KV16 = None, None, None, None, None
+        hip_base.close_pack_scope(scope)
+        # the backward of this step (before any optimizer step) may go on with the same images: backward_pack_scope()
+        wm._pack_scope = scope
+        ST._FOLD_CACHE, ST._DROP, ST._PREC, ST._KV16 = None, None, None, None
+
+
+class backward_pack_scope:
+    """with backward_pack_scope(wm): loss.backward() - the backward's weight images (the W^T image of every tall LINEAR's input gradient)
+    in the scope of the training_step that produced `loss`: packed with the forward's (their requests join its list), never taken from
+    the per-Parameter cache - a captured backward must contain its packing (pl_modules/data_parallel.GraphedTrainStep._fwd_bwd)."""
+
+    def __init__(self, wm):
+        self.wm = wm
+
+    def __enter__(self):
+        scope = getattr(self.wm, "_pack_scope", None)
+        self.wm._pack_scope = None  # (one backward per scope: the optimizer step that follows ends the images' validity)
+        hip_base.PACK_SCOPE = scope if scope is not None else {}
+        return hip_base.PACK_SCOPE
+
+    def __exit__(self, *exc):
+        hip_base.close_pack_scope()
 
 
 def _training_step(wm, raw_batch, noise, use_prior) -> Dict[str, Tensor]:

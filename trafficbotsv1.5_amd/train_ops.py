@@ -233,6 +233,43 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class LayerNormJoinFn(torch.autograd.Function):
+    """(x, LayerNorm(x)) for the pre-norm residual form x' = x + f(LayerNorm(x)) (transformer_rpe.py:207-245): x is handed back so that
+    BOTH of its gradients - the residual branch's and the LayerNorm's - arrive at this node, and the backward is ONE pass
+    dx = d_residual + LayerNorm'(dy) (tbx_layernorm_bwd_add) where autograd ran tbx_layernorm_bwd and then summed the two with a kernel
+    of its own: 92 such sums / 6.6 GB of traffic per 16-scene step (tools/train_aten_sources.py). Same values (a + b = b + a)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        assert x.is_contiguous()
+        if LN_FWD:
+            y, mean, rstd = hip.layernorm_fwd(x, w, b, eps)
+        else:
+            y, mean, rstd = torch.native_layer_norm(x, (x.shape[-1],), w, b, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return x, y  # (an input returned as an output: autograd hands out a view of it whose grad_fn is this node)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        if dy is None:
+            return dres, None, None, None
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = hip.layernorm_bwd(x, dy.contiguous(), w, mean, rstd, add=None if dres is None else dres.contiguous())
+        return dx, dw, db, None
+
+
+LN_JOIN = os.environ.get("TBX_LN_JOIN", "1") != "0"  # (0: layer_norm + autograd's own sum, for A/B runs)
+
+
+def layer_norm_join(x: Tensor, m):
+    """-> (x', LayerNorm(x)): continue the residual branch from x' (LayerNormJoinFn); plain (x, layer_norm(x, m)) where that does not apply."""
+    if (LN_JOIN and LN_BWD and m.weight.shape == (D,) and hip.layernorm_bwd_ok(x) and torch.is_grad_enabled() and x.requires_grad
+            and x.is_contiguous()):
+        return LayerNormJoinFn.apply(x, m.weight, m.bias, m.eps)
+    return x, layer_norm(x, m)
+
+
 def layer_norm(x: Tensor, m) -> Tensor:
     """m = an nn.LayerNorm over the last dimension."""
     if LN_BWD and m.weight.shape == (D,) and hip.layernorm_bwd_ok(x) and torch.is_grad_enabled():
@@ -376,6 +413,14 @@ def fold_attention_weights(attn):
         f = dict(zip(("w_in", "b_in", "w_kv", "b_kv", "bias_k", "w_out", "b_out"), o))
     else:
         f = fold_attention_weights_torch(attn)
+    if torch.is_grad_enabled() and W.is_cuda:
+        # the module's three tall LINEARs (TallLinearFn: q | qt, K | V, out-projection) and their input gradients: six images, ONE launch at
+        # the first request for any of them (none if the module's rows stay on the library's GEMM)
+        from . import hip_base
+
+        hip_base.pack_group([f["w_in"], f["w_kv"], f["w_out"]],
+                            [(f[w], f[b], False, 1) for w, b in (("w_in", "b_in"), ("w_kv", "b_kv"), ("w_out", "b_out"))]
+                            + [(f[w], None, True, 1) for w in ("w_in", "w_kv", "w_out")])
     if ST._FOLD_CACHE is not None:
         ST._FOLD_CACHE[ck] = f
     return f
@@ -524,7 +569,7 @@ class NaviPairFirstLayer(torch.autograd.Function):
     neither the concatenation (1,536 B per pair) nor the embedding (512 B per pair) is kept for autograd: 12 B per pair are."""
 
     @staticmethod
-    def forward(ctx, rel, w_e, pa, pm, fxy, fyw):
+    def forward(ctx, rel, w_e, pa, pm, fxy, fyw, relu=False):
         n, A, M, _ = rel.shape
         d = w_e.shape[0]
         w_c = w_e.contiguous()  # [128 out, 128 k], k-contiguous: the GEMM form the library is fast at (a strided slice of the
@@ -539,20 +584,28 @@ class NaviPairFirstLayer(torch.autograd.Function):
                 hip.tall_linear(emb, w_c, None, bf16=ctx.bf16, out=hi)
             else:
                 torch.mm(emb, w_c.t(), out=hi)
-            h[i] += pa[i].unsqueeze(1) + pm[i].unsqueeze(0)
-        ctx.save_for_backward(rel, w_e, fxy, fyw)
+        # + the per-agent and per-polyline terms (and the layer's relu, when it follows directly) in ONE pass over all scenes
+        # (was: h[i] += pa[i][:, None] + pm[i][None] per scene - add, add_, copy_: 48 launches, 3 GB of traffic - and F.relu over the whole)
+        ctx.relu = bool(relu) and hip.glue_ok(h)
+        if hip.glue_ok(h):
+            hip.pair_bias_relu(h, pa, pm, ctx.relu)
+        else:
+            h += pa.unsqueeze(2) + pm.unsqueeze(1)
+        ctx.save_for_backward(rel, w_e, fxy, fyw, *((h,) if ctx.relu else ()))
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        rel, w_e, fxy, fyw = ctx.saved_tensors
+        rel, w_e, fxy, fyw, *hs = ctx.saved_tensors
         n, A, M, _ = rel.shape
         dh = dh.contiguous()
+        if ctx.relu:
+            dh = hip.relu_drop_bwd(dh, hs[0], 0.0)  # relu' read off the output
         dw = torch.zeros(w_e.shape, dtype=torch.float32, device=dh.device)
         for i in range(n):
             emb = hip.pose_embed(rel[i].reshape(-1, 3), fxy, fyw, w_e.shape[1])
             dw += hip.linear_wgrad(dh[i].view(A * M, -1), emb, want_db=False, bf16=ctx.bf16)[0]  # dY^T X over 65 k rows: tbx_linear_wgrad
-        return None, dw, dh.sum(2), dh.sum(1), None, None
+        return None, dw, dh.sum(2), dh.sum(1), None, None, None
 
 
 class TrainChain:
