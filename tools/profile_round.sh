@@ -10,8 +10,11 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
 wl="--agents $ag --polylines $pl --lights $tl --scenes $sc --rollouts $ro"
-kt="bench.py --no-cpu-baseline --no-wosac-shape --no-lights-ahead $wl $*"
-pmc="bench.py --no-cpu-baseline --no-wosac-shape --no-lights-ahead --no-graph --profile-steps 0 --steps 8 --warmup 2 $wl $*"
+# one stream, so that a kernel's duration and counters are its own: the sequential order (--no-lights-ahead) where the timed schedule
+# runs the lights on a second queue; ORDER="" for the shapes whose timed schedule already is one queue (Schedule.one_queue: configs[1])
+order=${ORDER---no-lights-ahead}
+kt="bench.py --no-cpu-baseline --no-wosac-shape $order $wl $*"
+pmc="bench.py --no-cpu-baseline --no-wosac-shape $order --no-graph --profile-steps 0 --steps 8 --warmup 2 $wl $*"
 
 rocprofv3 --kernel-trace --stats -d "$out/kt_$tag" -o kt -- python3 $kt > "$out/${tag}_bench.log" 2>&1
 db=$(find "$out/kt_$tag" -name '*.db' | head -1)
