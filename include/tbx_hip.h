@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define TBX_ABI_VERSION 3
+#define TBX_ABI_VERSION 4
 
 enum {
   TBX_OK = 0,

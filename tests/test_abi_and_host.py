@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip):
                          "tbx_rowchain", "tbx_rowchain_ex", "tbx_knarpe_attn_bwd", "tbx_agent_prep", "tbx_tl_prep", "tbx_map_prep", "tbx_sim_step"}
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.tbx_version() == 3
+    assert lib.tbx_version() == 4
     assert lib.tbx_error_string(-2).decode().startswith("shape")
 
 

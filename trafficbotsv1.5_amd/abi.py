@@ -302,7 +302,7 @@ def load():
                  "tbx_map_prep", "tbx_sim_step", "tbx_sim_step_parts", "tbx_sim_step_tl_prep", "tbx_rule_tables", "tbx_rule_grid", "tbx_rule_grid_cells", "tbx_rule_check", "tbx_rule_accumulate", "tbx_filter_futures", "tbx_rule_navi_check", "tbx_attn_fold_fwd", "tbx_attn_fold_bwd", "tbx_tall_linear_relu_drop", "tbx_tall_linear_relu_drop_bf16", "tbx_front_pair", "tbx_knarpe_dec_layer_pair",
                  "tbx_rel_pose_dense", "tbx_diffbar_reward", "tbx_knarpe_attn_fwd_mfma", "tbx_knarpe_attn_fwd_mfma_dropout_tb"):
         getattr(lib, name).restype = C.c_int
-    if lib.tbx_version() != 3:
+    if lib.tbx_version() != 4:
         raise ImportError("libtbx_hip.so ABI version mismatch")
     # (an entry point without argtypes would get 64-bit handles - stream pointers under graph capture - as C ints)
     untyped = [s for s in declared_symbols() if getattr(lib, s).argtypes is None and s not in ("tbx_error_string", "tbx_version")]
