@@ -148,6 +148,11 @@ def test_training_step_vs_oracle_and_reference(tb, golden_dir, sizes, knn, fixtu
         return orig[1](*a, **kw)
 
     def tall(*a, **kw):
+        if kw.get("out") is not None and kw["out"].stride(0) != kw["out"].shape[1]:
+            # the no-grad stepping pass's K/V tables (train_graph._kv_tables_tall: column blocks of one table): the inference schedule's
+            # fp32-equivalent products in BOTH classes - the closed loop's states do not depend on the training class
+            assert not kw.get("bf16") and not torch.is_grad_enabled()
+            return orig[2](*a, **kw)
         calls["tall"] += 1
         calls["tall_bf16"] += int(bool(kw.get("bf16")))
         calls["tall_dual16"] += int(kw.get("out16") is not None)

@@ -72,24 +72,26 @@ def tall_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = No
     wp, bp = _pad128(w, b)  # (a 64-wide layer: the image of the zero-padded weight; k / n below stay the valid widths)
     img = packed_weight(wp, bp, wt=wt, mfma32=True)
     y = torch.empty(x2.shape[0], n, dtype=torch.float32, device=x.device) if out is None else out
-    assert y.shape == (x2.shape[0], n) and y.is_contiguous() and y.dtype == torch.float32
+    # (out: rows may be a column block of a wider table - leading dimension a multiple of 4 floats, 16-byte aligned)
+    assert y.shape == (x2.shape[0], n) and y.stride(1) == 1 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0 and y.dtype == torch.float32
+    ldy = y.stride(0)
     if out16 is not None:  # the same rows as bfloat16 as well (tbx_tall_linear_dual)
         assert out16.shape == y.shape and out16.dtype == torch.bfloat16 and out16.is_contiguous()
         fn = load().tbx_tall_linear_dual_bf16 if bf16 else load().tbx_tall_linear_dual
         _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
-                  _ptr(y), n, _ptr(out16, torch.bfloat16), n, stream_ptr()), "tbx_tall_linear_dual")
-        return y.view(*x.shape[:-1], n)
+                  _ptr(y), ldy, _ptr(out16, torch.bfloat16), n, stream_ptr()), "tbx_tall_linear_dual")
+        return y if out is not None else y.view(*x.shape[:-1], n)
     if drop is not None:  # dropout(relu(.)) in the launch (tbx_tall_linear_relu_drop): drop = (p, seed, site, rows_per_scene, time_batch, time0)
         assert relu
         p, seed, site, rps, tb, t0 = _drop6(drop)
         fn = load().tbx_tall_linear_relu_drop_bf16 if bf16 else load().tbx_tall_linear_relu_drop
-        _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), _ptr(y), n,
+        _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), _ptr(y), ldy,
                   p, seed, site, rps, tb, t0, stream_ptr()), "tbx_tall_linear_relu_drop")
-        return y.view(*x.shape[:-1], n)
+        return y if out is not None else y.view(*x.shape[:-1], n)
     fn = load().tbx_tall_linear_bf16 if bf16 else load().tbx_tall_linear
     _check(fn(_ptr(x2, torch.float32), x2.shape[0], k, x2.stride(0), _ptr(img, torch.float32), n, int(b is not None), int(relu),
-              _ptr(y), n, stream_ptr()), "tbx_tall_linear")
-    return y.view(*x.shape[:-1], n)
+              _ptr(y), ldy, stream_ptr()), "tbx_tall_linear")
+    return y if out is not None else y.view(*x.shape[:-1], n)
 
 
 def linear_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:

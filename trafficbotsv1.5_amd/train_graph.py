@@ -518,6 +518,27 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+KV_TABLES_TALL = os.environ.get("TBX_KV_TABLES_TALL", "1") != "0"  # (0: the exact-fp32 row chain, for A/B runs)
+
+
+def _kv_tables_tall(x: Tensor, norms_and_attns) -> Tensor:
+    """engine.kv_tables (out[:, l * 256 ..] = LN_l(x) W_kv,l^T + b_kv,l: transformer_rpe.py:220-223 + attention_rpe.py:92-98) for the
+    10^5 light-token rows of a whole piece of the stepping pass: per layer tbx_layernorm_fwd + tbx_tall_linear (the three-product
+    split-bf16 matrix path: the arithmetic of the inference schedule's tbx_tl_tail_tile, < 3e-5 of sum |x||w|) straight into the layer's
+    column block - byte-bound launches instead of ONE exact-fp32 row chain at the fp32 MFMA rate (184,320 rows: 1.2 ms -> ~0.6)."""
+    from . import engine
+
+    rows, L = x.shape[0], len(norms_and_attns)
+    if not (KV_TABLES_TALL and TALL_LINEAR and rows >= WGRAD_MIN_ROWS and engine.kv_dtype() == torch.float32 and hip.tall_linear_ok(x, D, 2 * D)
+            and hip.layernorm_bwd_ok(x)):
+        return engine.kv_tables(x, norms_and_attns)
+    out = torch.empty(rows, 2 * D * L, dtype=torch.float32, device=x.device)
+    for l, (nm, attn) in enumerate(norms_and_attns):
+        y = hip.layernorm_fwd(x, nm.weight, nm.bias, nm.eps)[0]
+        hip.tall_linear(y, attn.in_proj_weight[D:], attn.in_proj_bias[D:], out=out[:, l * 2 * D:(l + 1) * 2 * D])
+    return out
+
+
 def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, step_end: int) -> Dict[str, Tensor]:
     """The same rollout, time-batched (module docstring): a step-by-step pass without autograd that records every step's
     policy inputs, then the T policy evaluations of every scene as one differentiated batch of n x T entries in [scene][step]
@@ -587,7 +608,7 @@ def training_rollout_batched(wm, b, mp, tl_tokens, z, z_valid, tf_mask: Tensor, 
                         from . import engine
 
                         ft = f.permute(1, 0, 2, 3).contiguous()  # [Tc, n, L, d]
-                        kv_pieces[i] = engine.kv_tables(ft.view(-1, ft.shape[-1]), model.ag_encoder.tl_kv_layers()).view(ft.shape[0], n * L, -1)
+                        kv_pieces[i] = _kv_tables_tall(ft.view(-1, ft.shape[-1]), model.ag_encoder.tl_kv_layers()).view(ft.shape[0], n * L, -1)
                     kv = kv_pieces[i][step - 1 - c0] if i in kv_pieces else None
                     # (with the tables at hand the engine path does not read the features: no per-step gather of them)
                     return (f[:, step - 1 - c0].reshape(n * L, -1) if kv is None else f[:, step - 1 - c0]), kv
