@@ -735,7 +735,25 @@ extern "C" int tbx_knarpe_dec_layer_pair(const tbx_dec_layer_t* ta, const tbx_de
   const bool kv16 = ta->mid.self_seg.kv_bf16 != 0;
   if (rel_a != rel_b || kv16 != (tb->mid.self_seg.kv_bf16 != 0) || ta->tail_mfma32 != tb->tail_mfma32) return TBX_ERR_UNSUPPORTED;
   if (ta->tail_mfma32 == 2 && !kv16) return TBX_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)(p.m[0].n_rows + p.m[1].n_rows));
+  // The halves on disjoint XCDs (workgroup b runs on XCD b % 8): an XCD's L2 then holds ONE half's weight units and K/V rows instead of
+  // both - configs[1] (64 + 128 rows): 491.5 -> 499.4 k agent-steps/s with the agents on 3 XCDs (2: 492, 4: 497). Default: the share of
+  // XCDs nearest to the halves' share of rows, if both halves then still have a CU per row (32 CUs per XCD); TBX_PAIR_XCD=0: off, n: forced.
+  static const int pair_xcd = [] { const char* e = getenv("TBX_PAIR_XCD"); return (e && *e) ? atoi(e) : -1; }();
+  const int na = p.m[0].n_rows, nb = p.m[1].n_rows;
+  int xa = pair_xcd;
+  if (xa < 0) {
+    xa = (16 * na + (na + nb)) / (2 * (na + nb));  // round(8 na / (na + nb))
+    xa = xa < 1 ? 1 : (xa > 7 ? 7 : xa);
+    if ((na + xa - 1) / xa > 32 || (nb + 7 - xa) / (8 - xa) > 32) xa = 0;
+  }
+  p.xcd_a = 0;
+  unsigned blocks = (unsigned)(na + nb);
+  if (xa > 0 && xa < 8) {
+    const int sa = (na + xa - 1) / xa, sb = (nb + 7 - xa) / (8 - xa);
+    p.xcd_a = xa;
+    blocks = 8u * (unsigned)(sa > sb ? sa : sb);
+  }
+  const dim3 grid(blocks);
   hipStream_t hs = (hipStream_t)stream;
   if (ta->tail_mfma32 == 2) {
     MidPair1 q;
