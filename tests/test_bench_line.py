@@ -169,6 +169,9 @@ def test_committed_bench_line_rooflines_reproduce_from_their_own_fields():
     head = line["roofline"]
     if head["kernel"].startswith("dec_layer_mf") and head["source_rows_per_launch"] == 64:
         assert head["algorithmic_bytes_per_launch"] == 7990400  # SURVEY 8d at configs[1]'s agents, nothing added
+    if head["kernel"].startswith("dec_layer_mf") and "_pair_" in head["kernel"]:
+        # the paired launch (Schedule.one_queue): the agents' 64 rows x 114 pairs + the lights' 128 rows x 48 pairs, two attention calls each
+        assert head["source_rows_per_launch"] == 192 and abs(head["algorithmic_bytes_per_launch"] - (7990400 + 6922240)) <= 100
 
 
 def _dry(argv, timeout=900):
