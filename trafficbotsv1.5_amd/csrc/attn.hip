@@ -68,6 +68,8 @@ struct AttnArgs {
   // K/V tables and an agent's K-nearest sets barely differ between rollouts, so the workgroup's waves gather the same table rows
   // at about the same time (one L2 fetch, three L1 hits). Set when n_batch % 4 == 0 and a segment is shared (batch_div > 1).
   int batch_major;
+  // consecutive workgroups' rows on ONE XCD (tbx::xcd_block): the rows of a rollout / scene read that rollout's / scene's tables
+  int xcd;
 };
 
 
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPR == 1 ? 
   // CU): the 66 KiB fold image is fetched once per workgroup, not once per 4 rows. Every other form: one pass, quad = blockIdx.x.
   constexpr bool LOOP = FOLD && WPR == 1;
   const int n_quads = LOOP ? (a.n_rows + 3) / 4 : 0;
-  for (int quad = blockIdx.x; quad == (int)blockIdx.x || (LOOP && quad < n_quads); quad += gridDim.x) {
+  const int quad0 = (!LOOP && a.xcd) ? tbx::xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  for (int quad = quad0; quad == quad0 || (LOOP && quad < n_quads); quad += gridDim.x) {
   int row = __builtin_amdgcn_readfirstlane(quad * RPB + rib);  // a wave works on one row: keep it in an SGPR
   if (WPR == 1 && a.batch_major) row = __builtin_amdgcn_readfirstlane((4 * (quad / a.n_src) + rib) * a.n_src + quad % a.n_src);
   if constexpr (LOOP) {
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
   using G = RingGeom<KV16>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  const int row = __builtin_amdgcn_readfirstlane((a.xcd ? tbx::xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 4 + wave);
   if (row >= a.n_rows) return;
   const int b = row / a.n_src;
   const int s8 = lane & 7, tg = lane >> 3;
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_bwd_kernel(const AttnBwdArgs 
   __shared__ uint8_t ok_s[4][KMAX];   // 1 = valid target
   const int lane = threadIdx.x & 63;
   const int rib = threadIdx.x >> 6;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + rib);  // a wave works on one row: scalar addressing below
+  const int row = __builtin_amdgcn_readfirstlane((a.xcd ? tbx::xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 4 + rib);  // a wave works on one row: scalar addressing below
   if (row >= a.n_rows) return;
   const int bidx = row / a.n_src;
   const bool drop = a.drop_thresh != 0u;
@@ -737,12 +740,12 @@ struct DkvArgs {
   const int32_t* inv_list[2];
   float* dkv[2];
   int32_t k[2], t_off[2], n_tgt[2], ld_kv[2], k_off[2], v_off[2], list_cap[2], tok0[2];  // tok0: first wave of the segment
-  int ldq, q_off, ldo, ktot, n_tok;
+  int ldq, q_off, ldo, ktot, n_tok, xcd;
 };
 
 __global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int w = __builtin_amdgcn_readfirstlane((a.xcd ? tbx::xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 4 + (threadIdx.x >> 6));
   if (w >= a.n_tok) return;
   const int sg = (w >= a.tok0[1]) ? 1 : 0;
   const int tok = w - a.tok0[sg];            // table * n_tgt + j
@@ -775,6 +778,18 @@ __global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
   float* out = a.dkv[sg] + ((int64_t)table * a.n_tgt[sg] + j) * a.ld_kv[sg] + (half ? a.v_off[sg] : a.k_off[sg]) + c4 * 4;
   *(float4*)out = acc;  // every token's K and V gradient columns are written (zero when nobody selected it): no pre-zeroing
 }
+
+// XCD-contiguous rows (tbx::xcd_block). TBX_ATTN_XCD: bit 0 the forward kernels (knarpe_attn_kernel, the ring form), bit 1 the backward
+// (knarpe_attn_bwd_kernel, knarpe_attn_dkv_kernel), bit 2 the matrix-core forward (attn_mfma.hip). Default 1 = the forward kernels of
+// inference launches (no dropout). Measured (profiles/r06_attn_xcd_ab.txt): 32 x 128 agents 7.14 -> 7.28 M agent-steps/s, 128 x 128
+// 9.00 -> 9.16 M, 16 / 64 scenes +1.1 / +2.7 % - a rollout's / scene's K/V tables then live in one XCD's L2; the matrix-core forward
+// -0.8 % (its persistent grid already walks the rows in order); the backward kernels 139 -> 149 ms per training step (they stream
+// [rows, pairs, 8] coefficient arrays: eight XCDs on eight distant regions instead of one); training's stepping pass +0.3 ms.
+static int attn_xcd_mask() {
+  static const int v = [] { const char* e = getenv("TBX_ATTN_XCD"); return (e && *e) ? atoi(e) : 1; }();
+  return v;
+}
+static int attn_xcd() { return attn_xcd_mask() & 1; }
 
 int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, const float* rpe_k_bias, int n_batch, int n_src,
               const tbx_attn_seg_t* segs, int n_seg, int ldo, const float* fxy, const float* fyaw) {
@@ -815,6 +830,7 @@ int fill_args(AttnArgs& a, const float* qbuf, int ldq, int q_off, int qt_off, co
   bool shared = false;
   for (int i = 0; i < n_seg; ++i) shared = shared || segs[i].batch_div > 1;
   a.batch_major = (bm_env && shared && n_batch % 4 == 0) ? 1 : 0;
+  a.xcd = attn_xcd();  // (set_dropout clears it for training's launches)
   return TBX_OK;
 }
 
@@ -834,6 +850,7 @@ int set_dropout(AttnArgs& a, float p_drop, const uint64_t* drop_seed, uint32_t d
     const double th = (double)p_drop * 4294967296.0;
     a.drop_thresh = th < 1.0 ? 1u : (uint32_t)th;
     a.drop_scale = 1.0f / (1.0f - p_drop);
+    if (!(attn_xcd_mask() & 8)) a.xcd = 0;  // (training's launches: the plain order - see attn_xcd_mask; bit 3 forces it on)
   }
   return TBX_OK;
 }
@@ -1038,6 +1055,8 @@ extern "C" int tbx_knarpe_attn_bwd_gather_tb(const float* qbuf, int ldq, int q_o
   }
   d.ktot = t_off;
   d.n_tok = tok;
+  d.xcd = (attn_xcd_mask() >> 1) & 1;
+  b.f.xcd = d.xcd;
   b.dout = dout;
   b.dqbuf = dqbuf;
   b.dbias_k = dbias_k;

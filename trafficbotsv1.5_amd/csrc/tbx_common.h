@@ -120,6 +120,16 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+// Workgroup b of a 1-D grid runs on XCD b % 8 (MI300 / MI355X dispatch order). xcd_block(b, grid) = a virtual block index under
+// which XCD x owns the CONTIGUOUS range [x * per + min(x, rem), ...) of the grid's blocks (per = grid / 8, rem = grid % 8): kernels
+// whose consecutive blocks read the same tables (the rows of one rollout / scene / time-batched scene) then keep a table in ONE
+// XCD's L2 instead of all eight.
+__device__ __forceinline__ int xcd_block(const int b, const int grid) {
+  const int xcd = b & 7, slot = b >> 3;
+  const int per = grid >> 3, rem = grid & 7;
+  return xcd * per + (xcd < rem ? xcd : rem) + slot;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = group8_sum(v);
   v += dpp<DPP_MIRROR>(v);
