@@ -15,16 +15,17 @@ mkdir -p "$out"
 flags="-O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-gpu-sanitize -fno-omit-frame-pointer -Wall -Wno-unused-function"
 srcs=$(sed -n 's/^SRCS = //p' "$src/Makefile")
 objs=""
+newest_dep() { ls -t "$src"/*.h "$src"/*.inc "$root"/include/*.h "$1" | head -1; }  # (a header changed: every object is stale)
 throttle() { while [ "$(jobs -r | wc -l)" -ge 4 ]; do sleep 0.2; done; }  # at most 4 compiles at a time (8 CPUs, ~1 GB each)
 for f in $srcs; do
   o=$out/${f%.hip}.o
-  [ "$o" -nt "$src/$f" ] || $hipcc $flags -c "$src/$f" -o "$o" &
+  [ "$o" -nt "$(newest_dep "$src/$f")" ] || $hipcc $flags -c "$src/$f" -o "$o" &
   objs="$objs $o"
   throttle
 done
 for f in tile_layer tile_heads tile_window tall_linear tile_tail; do
   o=$out/${f}_p1.o
-  [ "$o" -nt "$src/$f.hip" ] || $hipcc $flags -DTBX_TILE_SINGLE=1 -c "$src/$f.hip" -o "$o" &
+  [ "$o" -nt "$(newest_dep "$src/$f.hip")" ] || $hipcc $flags -DTBX_TILE_SINGLE=1 -c "$src/$f.hip" -o "$o" &
   objs="$objs $o"
   throttle
 done
