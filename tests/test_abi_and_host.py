@@ -394,6 +394,24 @@ def test_host_descriptor_paths_read_their_host_arrays_in_bounds(hip):
     fr = hip.Front()
     fr.jobs, fr.n_jobs = C.cast(jobs, C.c_void_p), 3
     assert lib.tbx_front(C.byref(fr), None) < 0
+    # round 6: the paired launches (two nested descriptors each), the job array of the multi-image pack, the new glue entry points
+    da, db = hip.DecLayer(), hip.DecLayer()
+    assert lib.tbx_knarpe_dec_layer_pair(C.byref(da), C.byref(db), None) < 0 and lib.tbx_knarpe_dec_layer_pair(None, C.byref(db), None) == -1
+    fa, fb = hip.Front(), hip.Front()
+    assert lib.tbx_front_pair(C.byref(fa), C.byref(fb), None) < 0 and lib.tbx_front_pair(C.byref(fa), None, None) == -1
+    pj = (hip.PackJob * 50)()  # (more than one launch's worth: 48 jobs per launch)
+    for i, j in enumerate(pj):
+        j.w, j.bias, j.out, j.n, j.k, j.ld, j.groups, j.wt = dp(70 + 2 * i), None, dp(71 + 2 * i), 128, 128, 128, 1, i & 1
+    assert lib.tbx_pack_weight_mfma32_multi(pj, 0, None) == 0  # nothing to do
+    assert lib.tbx_pack_weight_mfma32_multi(None, 3, None) == -1
+    pj[49].k = 100  # an unsupported width in the LAST job: found by the host-side walk of its group
+    assert lib.tbx_pack_weight_mfma32_multi(pj, 50, None) < 0
+    pj[49].k, pj[7].out = 128, None
+    assert lib.tbx_pack_weight_mfma32_multi(pj, 50, None) == -1
+    assert lib.tbx_pair_bias_relu(None, dp(1), dp(2), 1, 4, 8, 128, 1, None) == -1 and lib.tbx_pair_bias_relu(dp(0), dp(1), dp(2), 1, 4, 8, 126, 1, None) == -1
+    assert lib.tbx_pair_bias_relu(dp(0), dp(1), dp(2), 0, 4, 8, 128, 1, None) == 0  # an empty batch
+    assert lib.tbx_layernorm_bwd_add(dp(0), dp(1), dp(2), dp(3), dp(4), 16, 64, dp(5), dp(6), dp(7), dp(8), dp(9), None) < 0  # cols != 128
+    assert lib.tbx_layernorm_bwd_add(dp(0), dp(1), dp(2), dp(3), dp(4), 16, 128, 0x10004, dp(6), dp(7), dp(8), dp(9), None) < 0  # misaligned `add`
     ss = hip.SimState()
     assert lib.tbx_sim_step(C.byref(ss), None) == -1 and lib.tbx_sim_step_parts(C.byref(ss), 3, None) == -1
     rc = hip.RuleCtx()

@@ -479,6 +479,12 @@ extern "C" int tbx_pack_weight_mfma32(const float* w, const float* bias, int n, 
 
 extern "C" int tbx_pack_weight_mfma32_multi(const tbx_pack_job_t* jobs, int n_jobs, void* stream) {
   if (n_jobs < 0 || (n_jobs > 0 && jobs == nullptr)) return TBX_ERR_ARG;
+  if (n_jobs == 0) return TBX_OK;
+  for (int j = 0; j < n_jobs; ++j) {  // every job is checked before the first launch
+    if (jobs[j].w == nullptr || jobs[j].out == nullptr || jobs[j].ld <= 0) return TBX_ERR_ARG;
+    const int64_t total = tbx_pack_weight_mfma32_size(jobs[j].n, jobs[j].k, jobs[j].groups);
+    if (total < 0) return (int)total;
+  }
   for (int j0 = 0; j0 < n_jobs; j0 += PACK_MULTI_MAX) {
     PackMultiArgs a;
     const int m = n_jobs - j0 < PACK_MULTI_MAX ? n_jobs - j0 : PACK_MULTI_MAX;
