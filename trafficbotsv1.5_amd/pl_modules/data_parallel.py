@@ -83,6 +83,18 @@ class FlatGrads:
         return self.nbytes
 
 
+def clip_gradients(params, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ (trainer/default.yaml:13 gradient_clip_val). With a FlatGrads the gradients ARE one buffer: its
+    2-norm is the norm of the per-tensor norms, and one in-place scale replaces the foreach passes over ~700 tensors (4 launches)."""
+    if not (max_norm and max_norm > 0):
+        return None
+    if isinstance(params, FlatGrads):
+        total = torch.linalg.vector_norm(params.flat)
+        params.flat.mul_((max_norm / (total + 1e-6)).clamp(max=1.0))  # (clip_grad_norm_'s coefficient)
+        return total
+    return torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+
 def allreduce_gradients(params, world_size: Optional[int] = None, group=None) -> int:
     """Average the gradients of `params` across ranks in place with one flat all-reduce. Returns the bytes exchanged.
     `params`: a FlatGrads (the gradients already live in one buffer: nothing is copied) or an iterable of parameters (their
@@ -160,9 +172,7 @@ def train_step(wm, optimizer: torch.optim.Optimizer, batch: Dict[str, Tensor], c
         live.gather()
     params = live if live is not None else live_parameters(wm.model)
     allreduce_gradients(params)
-    plist = params.params if isinstance(params, FlatGrads) else params
-    if clip_grad_norm and clip_grad_norm > 0:
-        torch.nn.utils.clip_grad_norm_(plist, clip_grad_norm)
+    clip_gradients(params, clip_grad_norm)
     optimizer.step()
     return wm.last_metrics
 
@@ -198,6 +208,7 @@ class GraphedTrainStep:
         n, A = example_batch["agent/valid"].shape[:2]
         self.noise = torch.zeros(n, A, wm.model.latent_encoder.out_dim, device=dev)
         self.use_prior = torch.zeros((), dtype=torch.bool, device=dev)
+        self._noise_pin, self._noise_turn = None, 0  # pinned staging of the host-drawn noise (_refill)
         wm.attn_dropout_seed = self.drop_seed = torch.zeros(1, dtype=torch.int64, device=dev)  # static: the graph reads it
         self.live: Optional[List[torch.nn.Parameter]] = None
         self._say = (lambda *a: print("[GraphedTrainStep]", *a, flush=True)) if verbose else (lambda *a: None)
@@ -296,7 +307,19 @@ class GraphedTrainStep:
             loss.backward()
 
     def _refill(self) -> None:
-        self.noise.copy_(torch.randn(self.noise.shape), non_blocking=False)  # CPU generator, as the reference's CPU path
+        # The latent noise comes from the CPU generator, as on the reference's CPU path. A copy from pageable memory blocks the host until
+        # the stream has drained - i.e. until the PREVIOUS step's replay, gather, clip and AdamW are done - and the next replay is only
+        # enqueued after it: the device idled between steps. Two pinned staging buffers + an event each: the copy is asynchronous, the host
+        # runs one step ahead and only waits if it gets two ahead.
+        if self._noise_pin is None:
+            self._noise_pin = [(torch.empty(self.noise.shape, dtype=self.noise.dtype).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._noise_turn = 0
+        buf, ev = self._noise_pin[self._noise_turn]
+        self._noise_turn ^= 1
+        ev.synchronize()  # (the copy that last read this buffer has run; a fresh event is complete)
+        torch.randn(self.noise.shape, out=buf)
+        self.noise.copy_(buf, non_blocking=True)
+        ev.record()
         self.use_prior.fill_(bool(torch.rand(1) < self.wm.hp.p_training_rollout_prior))
         self.drop_seed.random_()  # new attention-dropout masks for this replay
 
@@ -314,7 +337,6 @@ class GraphedTrainStep:
         self.graph.replay()
         self.flat.attach()  # a zero_grad(set_to_none=True) elsewhere must not detach the static buffer's views
         allreduce_gradients(self.flat)
-        if self.clip and self.clip > 0:
-            torch.nn.utils.clip_grad_norm_(self.live, self.clip)
+        clip_gradients(self.flat, self.clip)
         self.opt.step()
         return self.metrics
