@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void knarpe_attn_dkv_kernel(const DkvArgs a) {
 }
 
 // XCD-contiguous rows (tbx::xcd_block). TBX_ATTN_XCD: bit 0 the forward kernels (knarpe_attn_kernel, the ring form), bit 1 the backward
-// (knarpe_attn_bwd_kernel, knarpe_attn_dkv_kernel), bit 2 the matrix-core forward (attn_mfma.hip). Default 1 = the forward kernels of
+// (knarpe_attn_bwd_kernel, knarpe_attn_dkv_kernel), bit 3 training's forward launches too. Default 1 = the forward kernels of
 // inference launches (no dropout). Measured (profiles/r06_attn_xcd_ab.txt): 32 x 128 agents 7.14 -> 7.28 M agent-steps/s, 128 x 128
 // 9.00 -> 9.16 M, 16 / 64 scenes +1.1 / +2.7 % - a rollout's / scene's K/V tables then live in one XCD's L2; the matrix-core forward
 // -0.8 % (its persistent grid already walks the rows in order); the backward kernels 139 -> 149 ms per training step (they stream

@@ -60,7 +60,6 @@ struct MArgs {
   uint8_t* row_no_valid;
   tbx_attn_seg_t seg[2];
   int ldq, q_off, qt_off, ldo, n_rows, n_src, n_seg, batch_major;
-  int xcd;  // the quads of XCD x's workgroups = a contiguous eighth of the rows (tbx::xcd_block's idea for a persistent grid)
   float scale2;  // log2(e) / sqrt(d_head)
   // dropout on the attention probabilities (training, attention_rpe.py:171-172): the fields and the key of attn.hip's AttnArgs /
   // attn_core.h's DropKey - (seed, call, scene row, closed-loop step, global target slot, head) - so that the backward kernels
@@ -159,15 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   auto row_ctx = [&](int i) -> RowCtx {
     RowCtx r;
     r.i = i, r.row = -1, r.b = 0, r.kvb[0] = r.kvb[1] = nullptr;
-    int q = (int)blockIdx.x + i * (int)gridDim.x;
-    if (a.xcd) {  // workgroup b runs on XCD b % 8: XCD x walks quads [x * per + min(x, rem), + per + (x < rem)) with its own workgroups
-      const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-      const int g8 = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
-      const int per = n_quads >> 3, rem = n_quads & 7;
-      const int local = slot + i * g8;
-      if (local >= per + (xcd < rem ? 1 : 0)) return r;
-      q = xcd * per + (xcd < rem ? xcd : rem) + local;
-    }
+    // (an XCD-contiguous walk - XCD x's workgroups on a contiguous eighth of the quads, as attn.hip's forward kernels do - was measured in
+    //  round 6: 32 x 128 agents 10.50 -> 10.43 M agent-steps/s, the training step + 0.4 ms, and its index arithmetic cost 2 registers
+    //  of a kernel that lives at the 168-register limit of three waves per SIMD; removed)
+    const int q = (int)blockIdx.x + i * (int)gridDim.x;
     if (q >= n_quads) return r;
     int b, row;
     if (a.batch_major) {
@@ -454,8 +448,6 @@ static int mfma_launch(const float* qbuf, int ldq, int q_off, int qt_off, int n_
   bool shared = false;
   for (int i = 0; i < n_seg; ++i) shared = shared || segs[i].batch_div > 1;
   a.batch_major = (shared && n_batch % WAVES == 0) ? 1 : 0;
-  static const int xcd_env = [] { const char* e = getenv("TBX_ATTN_XCD"); return ((e && *e) ? atoi(e) : 1) >> 2 & 1; }();  // (bit 2; attn.hip)
-  a.xcd = xcd_env;
   // persistent: at most 3 workgroups per CU (44 KiB of LDS each, 3 waves per SIMD); each wave walks its slot of quads blockIdx.x + i * grid
   // (cached per device ordinal: a process that drives several devices must not size device 1's grid by device 0's CU count)
   static std::atomic<int> wg_cap[64];
