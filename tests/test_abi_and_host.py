@@ -416,3 +416,26 @@ def test_host_descriptor_paths_read_their_host_arrays_in_bounds(hip):
     assert lib.tbx_sim_step(C.byref(ss), None) == -1 and lib.tbx_sim_step_parts(C.byref(ss), 3, None) == -1
     rc = hip.RuleCtx()
     assert lib.tbx_rule_check(C.byref(rc), dp(1), dp(2), dp(3), dp(4), 1, 0, 1, dp(5), None) == -1
+
+
+def test_clip_on_the_flat_gradient_buffer_equals_clip_grad_norm(tb):
+    """pl_modules/data_parallel.clip_gradients on a FlatGrads (one 2-norm + one scale of the flat buffer) against
+    torch.nn.utils.clip_grad_norm_ on the same gradients as a parameter list: same total norm, same clipped gradients (fp32 summation
+    order apart), both when the norm exceeds the bound and when it does not."""
+    DP = import_module("trafficbots_amd.pl_modules.data_parallel")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 128), (128,), (640, 128), (5,), (1, 128)]
+    for scale, max_norm in ((10.0, 5.0), (1e-3, 5.0)):
+        pa = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        pb = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        grads = [torch.randn(s, generator=g) * scale for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        flat = DP.FlatGrads(pa)
+        total = DP.clip_gradients(flat, max_norm)
+        ref = torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        torch.testing.assert_close(total, ref, rtol=1e-6, atol=0)
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert p.grad.data_ptr() == flat.views[i].data_ptr()  # still the flat buffer's slice
+            torch.testing.assert_close(p.grad, q.grad, rtol=2e-6, atol=0)
+        assert DP.clip_gradients(flat, 0) is None
