@@ -36,7 +36,9 @@ class SceneCentricPreProcessing(nn.Module):
         b["sc/mp_attr"] = b["map/type"].type_as(b["map/pos"])
         # (slices, not `[..., [1]]`: a Python list index becomes a host tensor whose copy to the device blocks the host until the stream has
         #  drained - once per training step, in front of the next step's replay: tools/train_host_timeline.py)
-        b["sc/mp_pose"] = torch.cat([b["map/pos"][..., :2], torch.atan2(b["map/dir"][..., 1:2], b["map/dir"][..., 0:1])], -1)
+        #  (contiguous copies of the slices, as the list index made them: on the CPU atan2 takes another - vectorised - path on contiguous
+        #  operands and the oracle comparison of tests/test_abi_and_host.py is bit-exact)
+        b["sc/mp_pose"] = torch.cat([b["map/pos"][..., :2], torch.atan2(b["map/dir"][..., 1:2].contiguous(), b["map/dir"][..., 0:1].contiguous())], -1)
         b["sc/tl_valid"], b["sc/tl_state"] = self._merge_invalid_tl_into_state(b[p + "tl_lane/valid"][:, :, :H],
                                                                                b[p + "tl_lane/state"][:, :, :H])
         b["sc/tl_attr"] = b[p + "tl_lane/idx"]
