@@ -160,6 +160,7 @@ def open_pack_scope(owner=None, plan_key=None) -> dict:
     PACK_SCOPE = {"_plans": plans, "_plan_key": plan_key, "_record": {}}
     plan = plans.get(plan_key) if plans is not None else None
     if plan:
+        plan = [r for r in plan if r[0].is_cuda and (r[1] is None or r[1].is_cuda)]  # (a model moved off the device since: nothing to pre-pack)
         packed_weights_mfma32_multi(plan)
         for r in plan:
             PACK_SCOPE["_record"][_pack_key(r[0], r[1], r[2], r[3], False, False, True)[1]] = r
