@@ -71,6 +71,7 @@ out["graph_loss_finite"] = bool(torch.isfinite(m["loss"]))
 out["graph_allreduce_calls"] = calls["n"]
 out["graph_allreduce_bytes"] = calls["bytes"]
 out["graph_live_bytes"] = sum(p.numel() for p in gs.live) * 4
+out["graph_flat_bytes"], out["graph_n_live"] = gs.flat.nbytes, len(gs.live)
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out), flush=True)
 '''
@@ -95,7 +96,10 @@ def test_one_rank_rccl_training_step_takes_the_real_exchange_path(tmp_path):
     assert len(set(res["rank_seeds"])) == 8 and res["rank_seeds"][0] == 1234
     assert res["eager_loss_finite"] and res["graph_loss_finite"]
     assert res["eager_allreduce_bytes"] == res["live_bytes"] > 30e6  # every live gradient travelled, as ONE flat buffer
-    assert res["graph_allreduce_calls"] == 2 and res["graph_allreduce_bytes"] == 2 * res["graph_live_bytes"]
+    # (the captured step's buffer starts every parameter's slice at a multiple of 64 elements - FlatAdamW lays the parameters' data out
+    #  the same way: the exchange carries the gaps, < 256 bytes per parameter)
+    assert res["graph_allreduce_calls"] == 2 and res["graph_allreduce_bytes"] == 2 * res["graph_flat_bytes"]
+    assert 0 <= res["graph_flat_bytes"] - res["graph_live_bytes"] < 256 * res["graph_n_live"]
     assert res["graph_live_bytes"] == res["live_bytes"]
 
 
@@ -145,3 +149,51 @@ def test_loss_terms_with_empty_counters_are_left_out(tb):
     m = wm.last_metrics
     assert bool(torch.isfinite(loss)) and float(m["tl_state_loss"]) == 0.0
     assert abs(float(m["loss"]) - float(m["vae_kl"] - m["diffbar_reward"] + m["navi_loss"])) < 1e-5 * max(1.0, abs(float(m["loss"])))
+
+
+@pytest.mark.gpu
+def test_flat_adamw_equals_the_fused_optimizer_and_keeps_its_state_layout(tb):
+    """pl_modules/data_parallel.FlatAdamW (parameters, moments and step counters as slices of flat buffers, ONE fused launch per run of a
+    parameter group) against torch.optim.AdamW(fused=True) stepping the same parameters with the same gradients: bit-identical
+    parameters and moments after several steps with two parameter groups (different lr) and an lr change in between; the optimizer's own
+    state entries stay per-parameter tensors (state_dict round trip), and a direct optimizer.step() afterwards continues from the same state."""
+    dev = torch.device("cuda:0")
+    DP = import_module("trafficbots_amd.pl_modules.data_parallel")
+    g = torch.Generator().manual_seed(0)
+    shapes = [(128, 128), (128,), (640, 128), (5,), (256, 128), (1, 128), (121, 31)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(dev)) for i, s in enumerate(shapes)]
+        opt = torch.optim.AdamW(ps[:4], lr=1e-3, weight_decay=0.01, fused=True)
+        opt.add_param_group({"params": ps[4:], "lr": 3e-4})
+        return ps, opt
+
+    (pa, oa), (pb, ob) = make(), make()
+    grads = [[(torch.randn(s, generator=g) * 0.1).to(dev) for s in shapes] for _ in range(6)]
+    flat = DP.FlatGrads(pa)
+    assert DP.FlatAdamW.usable(oa, flat)
+    fa = DP.FlatAdamW(oa, flat)
+    assert len(fa.runs) == 2 and all(p.data_ptr() != 0 for p in pa)
+    for t, gs in enumerate(grads[:4]):
+        if t == 2:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-4  # (what an lr scheduler does)
+        for p, q, gr in zip(pa, pb, gs):
+            q.grad = gr.clone()
+        torch._foreach_copy_(flat.views, gs)
+        fa.step()
+        ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)
+        assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"])
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 4.0
+    sd = oa.state_dict()
+    assert len(sd["state"]) == len(shapes) and tuple(sd["state"][6]["exp_avg"].shape) == shapes[6]
+    # ... and the optimizer's own step() goes on from there (the state entries are ordinary per-parameter tensors: views of the flat buffers)
+    for gs in grads[4:]:
+        for p, q, gr in zip(pa, pb, gs):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q) and float(oa.state[p]["step"]) == 6.0
