@@ -1,3 +1,5 @@
+"""Device time of one AdamW step over the default model's 874 parameter tensors: torch's fused multi-tensor form, the foreach form, and the fused
+form over ONE flat tensor of the same 10,657,094 elements (what pl_modules/data_parallel.FlatAdamW runs).   python tools/opt_time.py"""
 import os, sys
 sys.path.insert(0, '.')
 import torch
